@@ -1,0 +1,156 @@
+/*
+ * mpcombi.h -- C ABI of the MI355X-native combinatorial mpLP/mpQP engine (libmpcombi_hip.so).
+ *
+ * The reference (PPOPT, pure Python) has no FFI; its plug points for this path are Python callables.
+ * Each entry point below names the reference interface it replaces (paths relative to
+ * /root/reference/src/ppopt):
+ *
+ *   mpc_create / mpc_destroy     the read-only `program` object every worker receives
+ *                                (mpqp_program.py:29-42, mplp_program.py:60-134; matrices AFTER presolve)
+ *   mpc_check_level              the batched operator  pool.map(lambda a: full_process(program, a, murder_list,
+ *                                gen_children), to_check)   mp_solvers/mpqp_parrallel_combinatorial.py:110-116, :17-64
+ *   mpc_frontier_* / mpc_level_* the same operator with the frontier (to_check), the pruned list (murder_list,
+ *                                mp_solvers/solver_utils.py:15-55) and the children (future_list, driver :127-135) kept
+ *                                resident in HBM between levels
+ *   mpc_lp_solve_batch           the deterministic-solver plug  Solver.solve_lp(c, A, b, equality_constraints)
+ *                                solver.py:211-246 -> solver_interface/cvxopt_interface.py:153-208, batched
+ *
+ * Conventions: plain pointers and sizes, row-major float64, int32 indices, caller-owned buffers that are
+ * copied at creation; integer return codes (0 = MPC_OK), never C++ exceptions; per-candidate numerical
+ * trouble is a status value, not an error.  A handle is bound to one device and one stream and is not
+ * re-entrant; use one handle per GPU.
+ */
+#ifndef MPCOMBI_H
+#define MPCOMBI_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MPC_OK 0
+#define MPC_ERR_INVALID 1      /* bad argument / unsupported dimensions                      */
+#define MPC_ERR_HIP 2          /* a HIP runtime call failed (mpc_last_error has the text)     */
+#define MPC_ERR_CAPACITY 3     /* caller buffer too small; required size returned in-place    */
+#define MPC_ERR_STATE 4        /* call sequence error (e.g. level results requested before run) */
+
+/* per-candidate status == verdict of full_process (driver lines 17-64) */
+#define MPC_INFEASIBLE 0        /* rank deficient or (x,theta) LP infeasible -> pruned                     */
+#define MPC_FEASIBLE 1          /* feasible, not optimal -> children                                       */
+#define MPC_OPTIMAL_NO_REGION 2 /* optimal, region lower dimensional (gen_cr returned None) -> pruned      */
+#define MPC_REGION 3            /* critical region -> children                                             */
+#define MPC_SINGULAR_KKT 4      /* feasible, KKT matrix numerically singular: no region, children expanded */
+#define MPC_LP_LIMIT 5          /* an LP hit its iteration limit: treated as MPC_FEASIBLE by the driver    */
+
+/* LP status of mpc_lp_solve_batch (anything but OPTIMAL is `None` in the reference) */
+#define MPC_LP_OPTIMAL 0
+#define MPC_LP_INFEASIBLE 1
+#define MPC_LP_UNBOUNDED 2
+#define MPC_LP_ITERLIMIT 3
+
+#define MPC_MASK_WORDS 2        /* active sets as bit masks: n_c <= 128 */
+#define MPC_MAX_NC 128
+#define MPC_MAX_ROWS 192        /* n_c + n_tc + 1 */
+
+typedef struct mpc_handle mpc_handle;
+
+/* A presolved multiparametric program:  min 1/2 x'Qx + theta'H'x + c'x  s.t.  A x <= b + F theta
+ * (first n_eq rows are equalities),  A_t theta <= b_t.   Q == NULL => mpLP. */
+typedef struct {
+    int32_t n_x, n_t, n_c, n_eq, n_tc;
+    const double *A;   /* n_c  x n_x */
+    const double *b;   /* n_c        */
+    const double *F;   /* n_c  x n_t */
+    const double *c;   /* n_x        */
+    const double *H;   /* n_x  x n_t */
+    const double *Q;   /* n_x  x n_x, or NULL */
+    const double *A_t; /* n_tc x n_t */
+    const double *b_t; /* n_tc       */
+} mpc_problem;
+
+typedef struct {
+    int64_t n;             /* candidates in the level                                 */
+    int32_t k;             /* their cardinality (incl. equalities)                    */
+    int32_t kkt_mode;      /* 0 Schur/Cholesky (Q > 0), 1 dense KKT LU (mpLP, PSD Q)    */
+    int64_t n_status[6];   /* histogram of the status byte                            */
+    int64_t n_regions;     /* == n_status[MPC_REGION]                                 */
+    int64_t n_children;    /* size of the next frontier (0 when gen_children == 0)    */
+    int64_t n_pruned_new;  /* masks appended to the pruned list by this level         */
+    int64_t lp_pivots;     /* simplex pivots executed by this level (all LPs)         */
+    float ms_verdict, ms_region, ms_children, ms_total; /* HIP-event times on the handle's stream */
+} mpc_level_stats;
+
+/* ---- library / device ------------------------------------------------------------------------------ */
+int mpc_device_count(void);
+const char *mpc_version(void);
+/* text of the last error of a call that had no handle (mpc_create, mpc_lp_solve_batch) */
+const char *mpc_last_global_error(void);
+
+/* ---- program handle ---------------------------------------------------------------------------------- */
+/* stream: a hipStream_t (as void*) the handle should launch on, or NULL to create its own. */
+int mpc_create(const mpc_problem *problem, int32_t device, void *stream, mpc_handle **out);
+int mpc_destroy(mpc_handle *h);
+const char *mpc_last_error(const mpc_handle *h);
+/* fixed strides of one region record for this program (see mpc_level_regions) */
+int64_t mpc_region_doubles(const mpc_handle *h);
+int64_t mpc_region_ints(const mpc_handle *h);
+/* dynamic LDS bytes per wavefront of the verdict / region kernels (for reports) */
+int32_t mpc_lds_bytes(const mpc_handle *h, int32_t which);
+/* the HIP stream the handle launches on (hipStream_t as void*) */
+void *mpc_stream(const mpc_handle *h);
+
+/* ---- frontier (to_check) and pruned list (murder_list), resident on the device ------------------------ */
+/* generate_children_sets(equality_indices, n_c)  (driver line 98) */
+int mpc_frontier_root(mpc_handle *h);
+int mpc_frontier_set(mpc_handle *h, const int32_t *cand_host, int64_t n, int32_t k);
+int mpc_frontier_set_device(mpc_handle *h, const int32_t *cand_dev, int64_t n, int32_t k);
+int mpc_frontier_info(const mpc_handle *h, int64_t *n, int32_t *k);
+int mpc_frontier_get(mpc_handle *h, int32_t *cand_host, int64_t cap);
+int mpc_pruned_clear(mpc_handle *h);
+int mpc_pruned_add(mpc_handle *h, const uint64_t *masks_host, int64_t m);        /* m x MPC_MASK_WORDS */
+int mpc_pruned_add_device(mpc_handle *h, const uint64_t *masks_dev, int64_t m);
+int64_t mpc_pruned_count(const mpc_handle *h);
+int mpc_pruned_get(mpc_handle *h, uint64_t *masks_host, int64_t cap);
+
+/* ---- one BFS level over the resident frontier --------------------------------------------------------- */
+/* Runs verdict -> region -> (gen_children ? child generation against the CURRENT pruned list : nothing).
+ * Sets pruned by this level become visible to child generation only after mpc_frontier_advance, which is the
+ * reference's worker semantics (workers hold the murder_list of the previous levels, driver :110-131). */
+int mpc_level_run(mpc_handle *h, int32_t gen_children, mpc_level_stats *stats);
+int mpc_level_status(mpc_handle *h, uint8_t *status_host);                       /* n bytes, frontier order */
+/* Region records of this level in frontier order.  cand_index[i] = position of region i's candidate.
+ *   rec_d (mpc_region_doubles each): A_x[n_x*n_t] b_x[n_x] A_l[n_c*n_t] b_l[n_c] E[(n_c+n_tc)*n_t] f[n_c+n_tc]
+ *   rec_i (mpc_region_ints each):    k n_E n_omega n_lambda n_regular | active[n_c] | omega[n_tc] | lambda[n_c]
+ *                                     | regular_idx[n_c] | regular_con[n_c]                      (unused = -1)
+ * i.e. every field of CriticalRegion (critical_region.py:34-48); E/f are the non-redundant unit-norm rows
+ * before exact-duplicate removal. */
+int mpc_level_regions(mpc_handle *h, double *rec_d_host, int32_t *rec_i_host, int64_t *cand_index_host, int64_t cap);
+int mpc_level_children(mpc_handle *h, int32_t *children_host, int64_t cap);     /* n_children x (k+1) */
+int mpc_level_children_device(mpc_handle *h, int32_t *children_dev, int64_t cap);
+int mpc_level_pruned_new(mpc_handle *h, uint64_t *masks_host, int64_t cap);
+int mpc_level_pruned_new_device(mpc_handle *h, uint64_t *masks_dev, int64_t cap);
+/* frontier := children of this level; pruned list += sets pruned by this level  (driver :127-135) */
+int mpc_frontier_advance(mpc_handle *h);
+
+/* ---- the batched operator with host buffers (drop-in for pool.map(full_process)) ---------------------- */
+/* Uploads cand (n x k) and the pruned masks (m x MPC_MASK_WORDS; replaces the handle's list), runs the level
+ * and downloads status, regions and children.  On MPC_ERR_CAPACITY *n_regions / *n_children hold the
+ * required capacities. */
+int mpc_check_level(mpc_handle *h, const int32_t *cand, int64_t n, int32_t k, const uint64_t *pruned_masks, int64_t m,
+                    int32_t gen_children, uint8_t *status, int64_t *n_regions, double *rec_d, int32_t *rec_i,
+                    int64_t *region_cand, int64_t region_cap, int64_t *n_children, int32_t *children,
+                    int64_t children_cap);
+
+/* ---- deterministic-solver plug: a batch of small dense LPs, one wavefront each ------------------------- */
+/* min c'x s.t. A x <= b (rows flagged in eq as equalities), x free.  A: n_lp x m x n unless shared_A != 0
+ * (then m x n, likewise b with shared_b, c with shared_c; c may be NULL = feasibility); eq: n_lp x m bytes.
+ * Outputs (host): status[n_lp]; x[n_lp x n] and obj[n_lp] may be NULL. */
+int mpc_lp_solve_batch(int32_t device, int64_t n_lp, int32_t m, int32_t n, const double *A, int32_t shared_A,
+                       const double *b, int32_t shared_b, const double *c, int32_t shared_c, const uint8_t *eq,
+                       int32_t *status, double *x, double *obj, int32_t *iters);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MPCOMBI_H */

@@ -1,0 +1,335 @@
+"""ctypes binding of libmpcombi_hip.so (the C ABI declared in include/mpcombi.h).
+
+This is the only doorway from the Python host code to the device kernels.  There is no CPU fallback: if the
+shared library is missing, or no HIP device is usable, every call raises ``MpcError``.
+"""
+import ctypes
+import os
+from typing import Optional
+
+import numpy
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'csrc', 'libmpcombi_hip.so')
+
+MPC_OK, MPC_ERR_INVALID, MPC_ERR_HIP, MPC_ERR_CAPACITY, MPC_ERR_STATE = range(5)
+INFEASIBLE, FEASIBLE, OPTIMAL_NO_REGION, REGION, SINGULAR_KKT, LP_LIMIT = range(6)
+LP_OPTIMAL, LP_INFEASIBLE, LP_UNBOUNDED, LP_ITERLIMIT = range(4)
+MASK_WORDS = 2
+
+_dp = ctypes.POINTER(ctypes.c_double)
+_ip = ctypes.POINTER(ctypes.c_int32)
+_lp = ctypes.POINTER(ctypes.c_int64)
+_u8p = ctypes.POINTER(ctypes.c_uint8)
+_u64p = ctypes.POINTER(ctypes.c_uint64)
+
+
+class MpcError(RuntimeError):
+    pass
+
+
+class MpcProblem(ctypes.Structure):
+    _fields_ = [('n_x', ctypes.c_int32), ('n_t', ctypes.c_int32), ('n_c', ctypes.c_int32), ('n_eq', ctypes.c_int32),
+                ('n_tc', ctypes.c_int32), ('A', _dp), ('b', _dp), ('F', _dp), ('c', _dp), ('H', _dp), ('Q', _dp),
+                ('A_t', _dp), ('b_t', _dp)]
+
+
+class LevelStats(ctypes.Structure):
+    _fields_ = [('n', ctypes.c_int64), ('k', ctypes.c_int32), ('kkt_mode', ctypes.c_int32),
+                ('n_status', ctypes.c_int64 * 6), ('n_regions', ctypes.c_int64), ('n_children', ctypes.c_int64),
+                ('n_pruned_new', ctypes.c_int64), ('lp_pivots', ctypes.c_int64), ('ms_verdict', ctypes.c_float),
+                ('ms_region', ctypes.c_float), ('ms_children', ctypes.c_float), ('ms_total', ctypes.c_float)]
+
+
+_lib = None
+
+
+def load():
+    """Loads the HIP library; raises MpcError (never falls back) when it is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise MpcError(f'{LIB_PATH} is missing: build it with `python -c "import __graft_entry__ as g; g.build()"` '
+                       f'(hipcc --offload-arch=gfx950). ppopt_amd has no CPU fallback.')
+    L = ctypes.CDLL(LIB_PATH)
+    H = ctypes.c_void_p
+    sig = {
+        'mpc_device_count': (ctypes.c_int, []),
+        'mpc_version': (ctypes.c_char_p, []),
+        'mpc_last_global_error': (ctypes.c_char_p, []),
+        'mpc_create': (ctypes.c_int, [ctypes.POINTER(MpcProblem), ctypes.c_int32, ctypes.c_void_p, ctypes.POINTER(H)]),
+        'mpc_destroy': (ctypes.c_int, [H]),
+        'mpc_last_error': (ctypes.c_char_p, [H]),
+        'mpc_region_doubles': (ctypes.c_int64, [H]),
+        'mpc_region_ints': (ctypes.c_int64, [H]),
+        'mpc_lds_bytes': (ctypes.c_int32, [H, ctypes.c_int32]),
+        'mpc_stream': (ctypes.c_void_p, [H]),
+        'mpc_frontier_root': (ctypes.c_int, [H]),
+        'mpc_frontier_set': (ctypes.c_int, [H, _ip, ctypes.c_int64, ctypes.c_int32]),
+        'mpc_frontier_set_device': (ctypes.c_int, [H, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32]),
+        'mpc_frontier_info': (ctypes.c_int, [H, _lp, _ip]),
+        'mpc_frontier_get': (ctypes.c_int, [H, _ip, ctypes.c_int64]),
+        'mpc_pruned_clear': (ctypes.c_int, [H]),
+        'mpc_pruned_add': (ctypes.c_int, [H, _u64p, ctypes.c_int64]),
+        'mpc_pruned_add_device': (ctypes.c_int, [H, ctypes.c_void_p, ctypes.c_int64]),
+        'mpc_pruned_count': (ctypes.c_int64, [H]),
+        'mpc_pruned_get': (ctypes.c_int, [H, _u64p, ctypes.c_int64]),
+        'mpc_level_run': (ctypes.c_int, [H, ctypes.c_int32, ctypes.POINTER(LevelStats)]),
+        'mpc_level_status': (ctypes.c_int, [H, _u8p]),
+        'mpc_level_regions': (ctypes.c_int, [H, _dp, _ip, _lp, ctypes.c_int64]),
+        'mpc_level_children': (ctypes.c_int, [H, _ip, ctypes.c_int64]),
+        'mpc_level_children_device': (ctypes.c_int, [H, ctypes.c_void_p, ctypes.c_int64]),
+        'mpc_level_pruned_new': (ctypes.c_int, [H, _u64p, ctypes.c_int64]),
+        'mpc_level_pruned_new_device': (ctypes.c_int, [H, ctypes.c_void_p, ctypes.c_int64]),
+        'mpc_frontier_advance': (ctypes.c_int, [H]),
+        'mpc_check_level': (ctypes.c_int, [H, _ip, ctypes.c_int64, ctypes.c_int32, _u64p, ctypes.c_int64, ctypes.c_int32,
+                                           _u8p, _lp, _dp, _ip, _lp, ctypes.c_int64, _lp, _ip, ctypes.c_int64]),
+        'mpc_lp_solve_batch': (ctypes.c_int, [ctypes.c_int32, ctypes.c_int64, ctypes.c_int32, ctypes.c_int32, _dp,
+                                              ctypes.c_int32, _dp, ctypes.c_int32, _dp, ctypes.c_int32, _u8p, _ip, _dp,
+                                              _dp, _ip]),
+    }
+    for name, (res, args) in sig.items():
+        fn = getattr(L, name)  # AttributeError if the library does not export a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    _lib = L
+    return L
+
+
+EXPORTED_SYMBOLS = ['mpc_device_count', 'mpc_version', 'mpc_last_global_error', 'mpc_create', 'mpc_destroy',
+                    'mpc_last_error', 'mpc_region_doubles', 'mpc_region_ints', 'mpc_lds_bytes', 'mpc_stream',
+                    'mpc_frontier_root', 'mpc_frontier_set', 'mpc_frontier_set_device', 'mpc_frontier_info',
+                    'mpc_frontier_get', 'mpc_pruned_clear', 'mpc_pruned_add', 'mpc_pruned_add_device',
+                    'mpc_pruned_count', 'mpc_pruned_get', 'mpc_level_run', 'mpc_level_status', 'mpc_level_regions',
+                    'mpc_level_children', 'mpc_level_children_device', 'mpc_level_pruned_new',
+                    'mpc_level_pruned_new_device', 'mpc_frontier_advance', 'mpc_check_level', 'mpc_lp_solve_batch']
+
+
+def _f64(a):
+    return numpy.ascontiguousarray(a, dtype=numpy.float64)
+
+
+def sets_to_masks(sets) -> numpy.ndarray:
+    """Active sets (iterables of row indices < 128) -> (m, 2) uint64 bit masks."""
+    out = numpy.zeros((len(sets), MASK_WORDS), dtype=numpy.uint64)
+    for i, s in enumerate(sets):
+        for v in s:
+            out[i, int(v) >> 6] |= numpy.uint64(1) << numpy.uint64(int(v) & 63)
+    return out
+
+
+def masks_to_sets(masks: numpy.ndarray):
+    out = []
+    for row in numpy.asarray(masks, dtype=numpy.uint64).reshape(-1, MASK_WORDS):
+        s = []
+        for w in range(MASK_WORDS):
+            v = int(row[w])
+            while v:
+                low = v & -v
+                s.append(w * 64 + low.bit_length() - 1)
+                v ^= low
+        out.append(tuple(s))
+    return out
+
+
+class Engine:
+    """One device-resident program (mpc_handle).  Mirrors what every reference worker holds: the presolved
+    matrices of the program plus the pruned list; see include/mpcombi.h for the call-by-call mapping."""
+
+    def __init__(self, A, b, F, c, H, Q, A_t, b_t, n_eq: int, device: int = 0, stream: Optional[int] = None):
+        L = load()
+        self._L = L
+        self._h = ctypes.c_void_p()
+        self.A, self.b, self.F = _f64(A), _f64(b).reshape(-1), _f64(F)
+        self.c, self.H = _f64(c).reshape(-1), _f64(H)
+        self.Q = None if Q is None else _f64(Q)
+        self.A_t, self.b_t = _f64(A_t), _f64(b_t).reshape(-1)
+        self.n_c, self.n_x = self.A.shape
+        self.n_t = self.F.shape[1]
+        self.n_tc = self.A_t.shape[0]
+        self.n_eq = int(n_eq)
+        if self.A_t.ndim != 2:
+            self.A_t = self.A_t.reshape(self.n_tc, self.n_t)
+        p = MpcProblem(self.n_x, self.n_t, self.n_c, self.n_eq, self.n_tc, self.A.ctypes.data_as(_dp),
+                       self.b.ctypes.data_as(_dp), self.F.ctypes.data_as(_dp), self.c.ctypes.data_as(_dp),
+                       self.H.ctypes.data_as(_dp), None if self.Q is None else self.Q.ctypes.data_as(_dp),
+                       self.A_t.ctypes.data_as(_dp) if self.n_tc else None,
+                       self.b_t.ctypes.data_as(_dp) if self.n_tc else None)
+        rc = L.mpc_create(ctypes.byref(p), int(device), ctypes.c_void_p(stream) if stream else None,
+                          ctypes.byref(self._h))
+        if rc != MPC_OK:
+            raise MpcError(f'mpc_create failed ({rc}): {L.mpc_last_global_error().decode()}')
+        self.rec_d = int(L.mpc_region_doubles(self._h))
+        self.rec_i = int(L.mpc_region_ints(self._h))
+        self.device = int(device)
+
+    # -- plumbing ----------------------------------------------------------------------------------------------
+    def _check(self, rc, what):
+        if rc != MPC_OK:
+            raise MpcError(f'{what} failed ({rc}): {self._L.mpc_last_error(self._h).decode()}')
+
+    def close(self):
+        if self._h:
+            self._L.mpc_destroy(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def stream(self) -> int:
+        return int(self._L.mpc_stream(self._h) or 0)
+
+    def lds_bytes(self, which: int = 0) -> int:
+        return int(self._L.mpc_lds_bytes(self._h, which))
+
+    # -- frontier / pruned list ----------------------------------------------------------------------------------
+    def frontier_root(self):
+        self._check(self._L.mpc_frontier_root(self._h), 'mpc_frontier_root')
+
+    def frontier_set(self, cands: numpy.ndarray):
+        cands = numpy.ascontiguousarray(cands, dtype=numpy.int32)
+        n, k = cands.shape
+        self._check(self._L.mpc_frontier_set(self._h, cands.ctypes.data_as(_ip), n, k), 'mpc_frontier_set')
+
+    def frontier_set_device(self, ptr: int, n: int, k: int):
+        self._check(self._L.mpc_frontier_set_device(self._h, ctypes.c_void_p(ptr), n, k), 'mpc_frontier_set_device')
+
+    def frontier_info(self):
+        n, k = ctypes.c_int64(0), ctypes.c_int32(0)
+        self._check(self._L.mpc_frontier_info(self._h, ctypes.byref(n), ctypes.byref(k)), 'mpc_frontier_info')
+        return n.value, k.value
+
+    def frontier_get(self) -> numpy.ndarray:
+        n, k = self.frontier_info()
+        out = numpy.zeros((n, k), dtype=numpy.int32)
+        if n:
+            self._check(self._L.mpc_frontier_get(self._h, out.ctypes.data_as(_ip), n), 'mpc_frontier_get')
+        return out
+
+    def pruned_clear(self):
+        self._check(self._L.mpc_pruned_clear(self._h), 'mpc_pruned_clear')
+
+    def pruned_add(self, masks: numpy.ndarray):
+        masks = numpy.ascontiguousarray(masks, dtype=numpy.uint64).reshape(-1, MASK_WORDS)
+        if len(masks):
+            self._check(self._L.mpc_pruned_add(self._h, masks.ctypes.data_as(_u64p), len(masks)), 'mpc_pruned_add')
+
+    def pruned_add_device(self, ptr: int, m: int):
+        self._check(self._L.mpc_pruned_add_device(self._h, ctypes.c_void_p(ptr), m), 'mpc_pruned_add_device')
+
+    def pruned_count(self) -> int:
+        return int(self._L.mpc_pruned_count(self._h))
+
+    def pruned_get(self) -> numpy.ndarray:
+        m = self.pruned_count()
+        out = numpy.zeros((m, MASK_WORDS), dtype=numpy.uint64)
+        if m:
+            self._check(self._L.mpc_pruned_get(self._h, out.ctypes.data_as(_u64p), m), 'mpc_pruned_get')
+        return out
+
+    # -- one level --------------------------------------------------------------------------------------------------
+    def level_run(self, gen_children: bool) -> LevelStats:
+        st = LevelStats()
+        self._check(self._L.mpc_level_run(self._h, int(bool(gen_children)), ctypes.byref(st)), 'mpc_level_run')
+        self._last = st
+        return st
+
+    def level_status(self) -> numpy.ndarray:
+        n, _ = self.frontier_info()
+        out = numpy.zeros(n, dtype=numpy.uint8)
+        if n:
+            self._check(self._L.mpc_level_status(self._h, out.ctypes.data_as(_u8p)), 'mpc_level_status')
+        return out
+
+    def level_regions(self):
+        nr = int(self._last.n_regions)
+        d = numpy.zeros((nr, self.rec_d))
+        i = numpy.zeros((nr, self.rec_i), dtype=numpy.int32)
+        idx = numpy.zeros(nr, dtype=numpy.int64)
+        if nr:
+            self._check(self._L.mpc_level_regions(self._h, d.ctypes.data_as(_dp), i.ctypes.data_as(_ip),
+                                                  idx.ctypes.data_as(_lp), nr), 'mpc_level_regions')
+        return d, i, idx
+
+    def level_children(self) -> numpy.ndarray:
+        n = int(self._last.n_children)
+        out = numpy.zeros((n, int(self._last.k) + 1), dtype=numpy.int32)
+        if n:
+            self._check(self._L.mpc_level_children(self._h, out.ctypes.data_as(_ip), n), 'mpc_level_children')
+        return out
+
+    def level_children_device(self, ptr: int, cap: int):
+        self._check(self._L.mpc_level_children_device(self._h, ctypes.c_void_p(ptr), cap), 'mpc_level_children_device')
+
+    def level_pruned_new(self) -> numpy.ndarray:
+        m = int(self._last.n_pruned_new)
+        out = numpy.zeros((m, MASK_WORDS), dtype=numpy.uint64)
+        if m:
+            self._check(self._L.mpc_level_pruned_new(self._h, out.ctypes.data_as(_u64p), m), 'mpc_level_pruned_new')
+        return out
+
+    def level_pruned_new_device(self, ptr: int, cap: int):
+        self._check(self._L.mpc_level_pruned_new_device(self._h, ctypes.c_void_p(ptr), cap),
+                    'mpc_level_pruned_new_device')
+
+    def frontier_advance(self):
+        self._check(self._L.mpc_frontier_advance(self._h), 'mpc_frontier_advance')
+
+    # -- the host-buffer operator (pool.map(full_process) replacement) --------------------------------------------
+    def check_level(self, cands: numpy.ndarray, pruned_masks: numpy.ndarray, gen_children: bool):
+        cands = numpy.ascontiguousarray(cands, dtype=numpy.int32)
+        n, k = cands.shape
+        pm = numpy.ascontiguousarray(pruned_masks, dtype=numpy.uint64).reshape(-1, MASK_WORDS)
+        status = numpy.zeros(n, dtype=numpy.uint8)
+        nreg, nch = ctypes.c_int64(0), ctypes.c_int64(0)
+        rcap, ccap = 0, 0
+        for _ in range(2):
+            d = numpy.zeros((max(rcap, 1), self.rec_d))
+            i = numpy.zeros((max(rcap, 1), self.rec_i), dtype=numpy.int32)
+            idx = numpy.zeros(max(rcap, 1), dtype=numpy.int64)
+            ch = numpy.zeros((max(ccap, 1), k + 1), dtype=numpy.int32)
+            rc = self._L.mpc_check_level(self._h, cands.ctypes.data_as(_ip), n, k, pm.ctypes.data_as(_u64p), len(pm),
+                                         int(bool(gen_children)), status.ctypes.data_as(_u8p), ctypes.byref(nreg),
+                                         d.ctypes.data_as(_dp), i.ctypes.data_as(_ip), idx.ctypes.data_as(_lp), rcap,
+                                         ctypes.byref(nch), ch.ctypes.data_as(_ip), ccap)
+            if rc == MPC_ERR_CAPACITY:
+                rcap, ccap = nreg.value, nch.value
+                continue
+            self._check(rc, 'mpc_check_level')
+            break
+        return status, d[:nreg.value], i[:nreg.value], idx[:nreg.value], ch[:nch.value]
+
+
+def lp_solve_batch(A, b, c, eq_flags, device: int = 0):
+    """Batched LPs on the device.  A: (n_lp, m, n) or (m, n) shared; b likewise; c (n_lp, n) / (n,) / None;
+    eq_flags: (n_lp, m) bool.  Returns (status, x, obj, iterations)."""
+    L = load()
+    A = _f64(A)
+    eq_flags = numpy.ascontiguousarray(eq_flags, dtype=numpy.uint8)
+    n_lp, m = eq_flags.shape
+    shared_A = A.ndim == 2
+    n = A.shape[-1]
+    b = _f64(b)
+    shared_b = b.size == m and n_lp != 1 or b.size == m
+    if b.size != m:
+        shared_b = False
+    cp, shared_c = None, 1
+    if c is not None:
+        c = _f64(c)
+        shared_c = int(c.size == n)
+        cp = c.ctypes.data_as(_dp)
+    status = numpy.zeros(n_lp, dtype=numpy.int32)
+    x = numpy.zeros((n_lp, n))
+    obj = numpy.zeros(n_lp)
+    it = numpy.zeros(n_lp, dtype=numpy.int32)
+    rc = L.mpc_lp_solve_batch(int(device), n_lp, m, n, A.ctypes.data_as(_dp), int(shared_A), b.ctypes.data_as(_dp),
+                              int(shared_b), cp, shared_c, eq_flags.ctypes.data_as(_u8p), status.ctypes.data_as(_ip),
+                              x.ctypes.data_as(_dp), obj.ctypes.data_as(_dp), it.ctypes.data_as(_ip))
+    if rc != MPC_OK:
+        raise MpcError(f'mpc_lp_solve_batch failed ({rc}): {L.mpc_last_global_error().decode()}')
+    return status, x, obj, it

@@ -1,0 +1,616 @@
+// kernels.hpp -- the batched per-candidate kernels of the combinatorial mpLP/mpQP path (gfx950).
+//
+// One 64-lane wavefront (= one 64-thread workgroup) owns one candidate active set from start to finish;
+// work is pulled from an atomic queue so that wavefronts whose LPs terminate early pick up the next candidate.
+// Everything a candidate touches after the initial gathers lives in that wavefront's LDS slice:
+//   ints   active set, inactive list, simplex bookkeeping
+//   KKT    gathered Schur block S = W[as,as] (+ right-hand sides) or the dense KKT matrix
+//   T      one simplex tableau, reused by every LP of the candidate
+// Shared, read-only problem blocks (A|b|F, W, UV, G', the base tableau) are read from HBM/L2 with coalesced
+// or broadcast loads.
+//
+// Reference functions replaced (relative to /root/reference/src/ppopt):
+//   k_verdict   full_process up to the optimal/feasible decision: is_full_rank + check_feasibility
+//               (mplp_program.py:411-444) and check_optimality (mpqp_program.py:203-322,
+//               mplp_program.py:446-569) -- the latter in its reduced theta-space form (KKT solve, then an LP over
+//               theta only; same rows as mpqp_utils.py:111-121, same test as mpqp_combi_graph.py:48-66)
+//   k_region    gen_cr_from_active_set (utils/mpqp_utils.py:89-320): optimal_control_law, region rows, zero-row
+//               filter, scaling, Chebyshev-ball full-dimension test (chebyshev_ball.py:10-63), one LP per facet
+//   k_children* generate_children_sets + CombinationTester.check (mp_solvers/solver_utils.py:15-55,154-166)
+#pragma once
+#include <stdint.h>
+
+#include "kkt.hpp"
+
+namespace mpc {
+
+constexpr int ST_INFEASIBLE = 0, ST_FEASIBLE = 1, ST_OPT_NO_REGION = 2, ST_REGION = 3, ST_SINGULAR = 4, ST_LP_LIMIT = 5;
+constexpr int ST_OPT_PENDING = 6;  // internal: optimal, waiting for k_region
+constexpr double ZERO_ROW_ATOL = 1e-8;  // numerically_nonzero_rows, constraint_utilities.py:469-470
+constexpr double FULL_DIM_RADIUS = 1e-8;  // is_full_dimensional, mpqp_utils.py:342-344
+
+struct DevProblem {
+    int n_x, n_t, n_c, n_eq, n_tc, is_qp, kkt_mode;
+    const double *A, *b, *F, *c, *H, *Q, *A_t, *b_t;
+    const double *W;    // n_c x n_c            A Q^-1 A'
+    const double *UV;   // n_c x (n_t+1)        [A Q^-1 c + b | A Q^-1 H + F]
+    const double *Gt;   // n_c x n_x            row i = (Q^-1 A_i')'
+    const double *X0H;  // n_x x (n_t+1)        [-Q^-1 c | -Q^-1 H]
+    const double *base; // (n_c+n_tc) x (1+n_x+n_t)   [b | A | -F ; b_t | 0 | A_t]
+    // LDS layout (offsets in doubles from the start of dynamic LDS; ints follow the doubles)
+    int kmax;           // largest cardinality with a solvable KKT (= min(n_c, n_x))
+    int ld_x, ld_t;     // odd tableau strides of the (x,theta) LP and of the theta-space LPs
+    int off_T, off_K, off_L, off_E, off_X, n_doubles;  // T tableau, K kkt matrix, L multipliers, E region rows, X x-law
+    int off_as, off_inact, off_colvar, off_rowvar, off_rowkind, off_kept, n_ints;
+};
+
+struct LevelCounters {
+    unsigned long long status[8];
+    unsigned long long pivots;
+    unsigned int work_verdict, work_region, n_opt, n_pruned_new;
+};
+
+struct Smem {
+    double *T, *K, *L, *E, *X;
+    int *as, *inact, *colvar, *rowvar, *rowkind, *kept;
+};
+
+__device__ __forceinline__ Smem carve(const DevProblem &P, double *base) {
+    Smem s;
+    s.T = base + P.off_T;
+    s.K = base + P.off_K;
+    s.L = base + P.off_L;
+    s.E = base + P.off_E;
+    s.X = base + P.off_X;
+    int *ib = reinterpret_cast<int *>(base + P.n_doubles);
+    s.as = ib + P.off_as;
+    s.inact = ib + P.off_inact;
+    s.colvar = ib + P.off_colvar;
+    s.rowvar = ib + P.off_rowvar;
+    s.rowkind = ib + P.off_rowkind;
+    s.kept = ib + P.off_kept;
+    return s;
+}
+
+// active set -> LDS, complement -> inact[] (ascending).  Returns the number of inactive rows.
+__device__ inline int load_active_set(const DevProblem &P, const int32_t *cand, int k, Smem &s) {
+    const int lane = lane_id();
+    wave_sync();
+    for (int i = lane; i < k; i += 64) s.as[i] = cand[i];
+    wave_sync();
+    int base = 0;
+    for (int j0 = 0; j0 < P.n_c; j0 += 64) {
+        const int j = j0 + lane;
+        bool inactive = j < P.n_c;
+        if (inactive)
+            for (int i = 0; i < k; ++i) inactive = inactive && (s.as[i] != j);
+        const unsigned long long bal = __ballot(inactive);
+        if (inactive) s.inact[base + __popcll(bal & ((1ull << lane) - 1ull))] = j;
+        base += __popcll(bal);
+    }
+    wave_sync();
+    return base;
+}
+
+// KKT solve.  On success L (k x (n_t+1)) holds [b_l | A_l]; in mode 1 X (n_x x (n_t+1)) also holds [b_x | A_x].
+// returns 0 ok, 1 rank deficient active set, 2 singular KKT, 3 mpLP active set that is not a vertex
+__device__ inline int kkt_solve(const DevProblem &P, int k, Smem &s) {
+    const int lane = lane_id(), nr = P.n_t + 1, nx = P.n_x, nc = P.n_c;
+    if (k > nx) return 1;
+    if (k == 0) {
+        if (P.kkt_mode == 1) {
+            if (!P.is_qp) return 3;
+            // x = -Q^-1 (c + H theta): solve Q X = -[c | H]
+            for (int idx = lane; idx < nx * nx; idx += 64) s.K[idx] = P.Q[idx];
+            for (int idx = lane; idx < nx * nr; idx += 64) {
+                const int i = idx / nr, t = idx % nr;
+                s.X[idx] = t == 0 ? -P.c[i] : -P.H[i * P.n_t + t - 1];
+            }
+            wave_sync();
+            if (!lu_solve(s.K, nx, s.X, nr, KKT_SING_TOL)) return 2;
+        }
+        return 0;
+    }
+    if (P.kkt_mode == 0) {
+        double *S = s.K, *diag = s.K + k * k;
+        for (int idx = lane; idx < k * k; idx += 64) {
+            const int i = idx / k, j = idx % k;
+            S[idx] = P.W[s.as[i] * nc + s.as[j]];
+        }
+        for (int i = lane; i < k; i += 64) diag[i] = P.W[s.as[i] * nc + s.as[i]];
+        for (int idx = lane; idx < k * nr; idx += 64) {
+            const int i = idx / nr, t = idx % nr;
+            s.L[idx] = -P.UV[s.as[i] * nr + t];
+        }
+        wave_sync();
+        return chol_solve(S, k, s.L, nr, diag) ? 0 : 1;
+    }
+    // mode 1: rank test on A_as, then the dense KKT system
+    {
+        double *M = s.K;
+        for (int idx = lane; idx < k * nx; idx += 64) M[idx] = P.A[s.as[idx / nx] * nx + idx % nx];
+        wave_sync();
+        if (!full_row_rank(M, k, nx)) return 1;
+    }
+    if (!P.is_qp && k != nx) return 3;  // mpLP: only a vertex (n_x active rows) can be optimal (mplp_program.py:472-473)
+    const int n = nx + k;
+    double *M = s.K, *B = s.K + n * n;
+    for (int idx = lane; idx < n * n; idx += 64) {
+        const int i = idx / n, j = idx % n;
+        double v = 0.0;
+        if (i < k) { if (j < nx) v = P.A[s.as[i] * nx + j]; }
+        else if (j < nx) { if (P.is_qp) v = P.Q[(i - k) * nx + j]; }
+        else v = P.A[s.as[j - nx] * nx + (i - k)];
+        M[idx] = v;
+    }
+    for (int idx = lane; idx < n * nr; idx += 64) {
+        const int i = idx / nr, t = idx % nr;
+        double v;
+        if (i < k) v = t == 0 ? P.b[s.as[i]] : P.F[s.as[i] * P.n_t + t - 1];
+        else v = t == 0 ? -P.c[i - k] : -P.H[(i - k) * P.n_t + t - 1];
+        B[idx] = v;
+    }
+    wave_sync();
+    if (!lu_solve(M, n, B, nr, KKT_SING_TOL)) return 2;
+    for (int idx = lane; idx < nx * nr; idx += 64) s.X[idx] = B[idx];
+    for (int idx = lane; idx < k * nr; idx += 64) s.L[idx] = B[nx * nr + idx];
+    wave_sync();
+    return 0;
+}
+
+// x*(theta) = X[:,0] + X[:,1:] theta for mode 0:  [b_x | A_x] = X0H - sum_a G'[as[a]] (x) L[a]
+__device__ inline void x_law_schur(const DevProblem &P, int k, Smem &s) {
+    const int lane = lane_id(), nr = P.n_t + 1, nx = P.n_x;
+    for (int idx = lane; idx < nx * nr; idx += 64) {
+        const int i = idx / nr, t = idx % nr;
+        double acc = P.X0H[idx];
+        for (int a = 0; a < k; ++a) acc = fma(-P.Gt[s.as[a] * nx + i], s.L[a * nr + t], acc);
+        s.X[idx] = acc;
+    }
+    wave_sync();
+}
+
+// Rows of the critical-region polytope in the order of mpqp_utils.py:111-121:
+//   lambda rows  -A_l[e:] theta <= b_l[e:]  |  inactive rows (A_J A_x - F_J) theta <= b_J - A_J b_x  |  A_t theta <= b_t
+// written to dst (row stride ld, column 0 = rhs, columns 1..n_t = coefficients).  use_x: form the inactive rows
+// from the x-law (reference arithmetic); otherwise from the Schur blocks (no x-law needed: verdict kernel).
+__device__ inline int build_theta_rows(const DevProblem &P, int k, int nin, Smem &s, double *dst, int ld, bool use_x) {
+    const int lane = lane_id(), nt = P.n_t, nr = nt + 1, nx = P.n_x, e = P.n_eq, nlam = k - e;
+    for (int idx = lane; idx < nlam * nr; idx += 64) {
+        const int i = idx / nr, t = idx % nr;
+        const double v = s.L[(e + i) * nr + t];
+        dst[i * ld + t] = t == 0 ? v : -v;
+    }
+    for (int idx = lane; idx < nin * nr; idx += 64) {
+        const int i = idx / nr, t = idx % nr, ci = s.inact[i];
+        double v;
+        if (use_x) {
+            // t == 0: b_J - A_J b_x ;  t > 0: A_J A_x - F_J
+            double acc = 0.0;
+            for (int l = 0; l < nx; ++l) acc = fma(P.A[ci * nx + l], s.X[l * nr + t], acc);
+            v = t == 0 ? P.b[ci] - acc : acc - P.F[ci * nt + t - 1];
+        } else {
+            // slack_j(theta) = UV[j] + W[j,as] L  >= 0   <=>   -(coef) theta <= const
+            double acc = P.UV[ci * nr + t];
+            for (int a = 0; a < k; ++a) acc = fma(P.W[ci * P.n_c + s.as[a]], s.L[a * nr + t], acc);
+            v = t == 0 ? acc : -acc;
+        }
+        dst[(nlam + i) * ld + t] = v;
+    }
+    for (int idx = lane; idx < P.n_tc * nr; idx += 64) {
+        const int i = idx / nr, t = idx % nr;
+        dst[(nlam + nin + i) * ld + t] = t == 0 ? P.b_t[i] : P.A_t[i * nt + t - 1];
+    }
+    wave_sync();
+    return nlam + nin + P.n_tc;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// k_verdict: status per candidate: INFEASIBLE / FEASIBLE / SINGULAR / LP_LIMIT / OPT_PENDING
+// ------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(64) k_verdict(DevProblem P, const int32_t *__restrict__ cands, long long n, int k,
+                                                uint8_t *__restrict__ status, LevelCounters *__restrict__ ctr) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    Smem s = carve(P, smem);
+    const int lane = lane_id(), nt = P.n_t, nx = P.n_x;
+    unsigned long long pivots = 0;
+    for (;;) {
+        unsigned int c = 0;
+        if (lane == 0) c = atomicAdd(&ctr->work_verdict, 1u);
+        c = __shfl(c, 0);
+        if (c >= n) break;
+        const int nin = load_active_set(P, cands + (size_t)c * k, k, s);
+        int st = -1;
+        const int kk = kkt_solve(P, k, s);
+        bool singular = false;
+        if (kk == 1) st = ST_INFEASIBLE;
+        else if (kk == 2) singular = true;
+        else if (kk == 0) {
+            // optimality: feasibility of the theta-space polytope {lambda(theta) >= 0, slack(theta) >= 0, A_t theta <= b_t}
+            Lp lp;
+            lp.T = s.T; lp.ld = P.ld_t; lp.colvar = s.colvar; lp.rowvar = s.rowvar; lp.rowkind = s.rowkind;
+            lp.n = nt;
+            const int m = build_theta_rows(P, k, nin, s, s.T, P.ld_t, P.kkt_mode == 1);
+            lp.m = m;
+            for (int i = lane; i <= m; i += 64) {
+                double *Ti = s.T + i * P.ld_t;
+                if (i == m) { for (int j = 0; j <= nt + 1; ++j) Ti[j] = 0.0; continue; }
+                double mx = 0.0;
+                for (int j = 1; j <= nt; ++j) mx = fmax(mx, fabs(Ti[j]));
+                if (!(mx > ZERO_ROW_ATOL)) for (int j = 1; j <= nt; ++j) Ti[j] = 0.0;
+                s.rowkind[i] = RK_INEQ;
+            }
+            int r = LP_INFEASIBLE;
+            if (lp_prepare(lp)) r = lp_solve(lp, false);
+            pivots += lp.iters;
+            if (r == LP_OPTIMAL) st = ST_OPT_PENDING;
+            else if (r == LP_ITERLIMIT) st = ST_LP_LIMIT;
+        }
+        if (st < 0) {
+            // feasibility of {A x - F theta <= b, A_t theta <= b_t, rows `as` active}   (mplp_program.py:439-444)
+            Lp lp;
+            lp.T = s.T; lp.ld = P.ld_x; lp.colvar = s.colvar; lp.rowvar = s.rowvar; lp.rowkind = s.rowkind;
+            lp.n = nx + nt;
+            lp.m = P.n_c + P.n_tc;
+            const int cols = 1 + nx + nt;
+            wave_sync();
+            for (int i = 0; i < lp.m; ++i)
+                for (int j = lane; j < cols; j += 64) s.T[i * P.ld_x + j] = P.base[i * cols + j];
+            for (int j = lane; j <= cols; j += 64) s.T[lp.m * P.ld_x + j] = 0.0;
+            for (int i = lane; i < lp.m; i += 64) s.rowkind[i] = RK_INEQ;
+            wave_sync();
+            for (int i = lane; i < k; i += 64) s.rowkind[s.as[i]] = RK_EQ;
+            int r = LP_INFEASIBLE;
+            if (lp_prepare(lp)) r = lp_solve(lp, false);
+            pivots += lp.iters;
+            if (r == LP_OPTIMAL) st = singular ? ST_SINGULAR : ST_FEASIBLE;
+            else if (r == LP_ITERLIMIT) st = ST_LP_LIMIT;
+            else st = ST_INFEASIBLE;
+        }
+        if (lane == 0) status[c] = (uint8_t)st;
+    }
+    if (lane == 0) atomicAdd(&ctr->pivots, pivots);
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// k_region: one optimal candidate per wavefront -> region record or OPT_NO_REGION
+// ------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(64) k_region(DevProblem P, const int32_t *__restrict__ cands, int k,
+                                               const int32_t *__restrict__ opt_list, int n_opt,
+                                               uint8_t *__restrict__ status, double *__restrict__ rec_d,
+                                               int32_t *__restrict__ rec_i, long long sd, long long si,
+                                               LevelCounters *__restrict__ ctr) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    Smem s = carve(P, smem);
+    const int lane = lane_id(), nt = P.n_t, nr = nt + 1, nx = P.n_x, nc = P.n_c, ntc = P.n_tc, e = P.n_eq;
+    unsigned long long pivots = 0;
+    for (;;) {
+        unsigned int w = 0;
+        if (lane == 0) w = atomicAdd(&ctr->work_region, 1u);
+        w = __shfl(w, 0);
+        if (w >= (unsigned)n_opt) break;
+        const int c = opt_list[w];
+        const int nin = load_active_set(P, cands + (size_t)c * k, k, s);
+        double *rd = rec_d + (size_t)w * sd;
+        int32_t *ri = rec_i + (size_t)w * si;
+        for (long long i = lane; i < sd; i += 64) rd[i] = 0.0;
+        for (long long i = lane; i < si; i += 64) ri[i] = -1;
+        int st = ST_REGION;
+        const int kk = kkt_solve(P, k, s);
+        if (kk != 0) st = kk == 1 ? ST_INFEASIBLE : ST_SINGULAR;  // cannot happen after k_verdict said optimal
+        int nE = 0, n_om = 0, n_la = 0, n_re = 0;
+        if (st == ST_REGION) {
+            if (P.kkt_mode == 0) x_law_schur(P, k, s);
+            // raw region rows -> T (scratch, row stride nr: column 0 = rhs), then the zero-row filter and unit L2
+            // scaling (remove_numerically_zero_rows + scale_constraint, mpqp_utils.py:123-126) compact them into the
+            // master copy E | f (row stride nr, column 0 = f); kept[] = index of the original row
+            const int ldE = nr;
+            const int nrows = build_theta_rows(P, k, nin, s, s.T, ldE, true);
+            const int nlam = k - e;
+            int nk = 0;
+            for (int r0 = 0; r0 < nrows; r0 += 64) {
+                const int r = r0 + lane;
+                bool keep = false;
+                double ss = 0.0;
+                if (r < nrows)
+                    for (int j = 0; j < nt; ++j) {
+                        const double v = s.T[r * ldE + 1 + j];
+                        if (!(fabs(v) <= ZERO_ROW_ATOL)) keep = true;
+                        ss = fma(v, v, ss);
+                    }
+                const unsigned long long bal = __ballot(keep);
+                if (keep) {
+                    const int dstrow = nk + __popcll(bal & ((1ull << lane) - 1ull));
+                    const double inv = 1.0 / sqrt(ss);
+                    s.kept[dstrow] = r;
+                    for (int j = 0; j <= nt; ++j) s.E[dstrow * ldE + j] = s.T[r * ldE + j] * inv;
+                }
+                nk += __popcll(bal);
+            }
+            wave_sync();
+            if (nt == 1) {
+                // one parameter: interval arithmetic, no LPs (mpqp_utils.py:198-320)
+                double mn = -INFINITY, mx = INFINITY;
+                for (int r = lane; r < nk; r += 64) {
+                    const double a = s.E[r * ldE + 1], v = s.E[r * ldE] / a;
+                    if (a > 0) mx = fmin(mx, v); else mn = fmax(mn, v);
+                }
+                for (int off = 32; off > 0; off >>= 1) { mx = fmin(mx, __shfl_xor(mx, off)); mn = fmax(mn, __shfl_xor(mn, off)); }
+                if (!(mn + 1e-8 <= mx)) st = ST_OPT_NO_REGION;
+                else {
+                    for (int r0 = 0; r0 < nk; r0 += 64) {
+                        const int r = r0 + lane;
+                        bool keep = false;
+                        int cls = 0, val = 0, val2 = 0;
+                        if (r < nk) {
+                            const double v = s.E[r * ldE] / s.E[r * ldE + 1];
+                            keep = (mn <= v && v <= mx);
+                            const int o = s.kept[r];
+                            if (o < nlam) { cls = 0; val = s.as[e + o]; }
+                            else if (o < nlam + nin) { cls = 1; val = o - nlam; val2 = s.inact[o - nlam]; }
+                            else { cls = 2; val = o - nlam - nin; }
+                        }
+                        const unsigned long long b0 = __ballot(keep && cls == 0), b1 = __ballot(keep && cls == 1), b2 = __ballot(keep && cls == 2);
+                        const unsigned long long below = (1ull << lane) - 1ull;
+                        if (keep && cls == 0) ri[5 + nc + ntc + n_la + __popcll(b0 & below)] = val;
+                        if (keep && cls == 1) { const int p = n_re + __popcll(b1 & below); ri[5 + nc + ntc + nc + p] = val; ri[5 + nc + ntc + nc + nc + p] = val2; }
+                        if (keep && cls == 2) ri[5 + nc + n_om + __popcll(b2 & below)] = val;
+                        n_la += __popcll(b0); n_re += __popcll(b1); n_om += __popcll(b2);
+                    }
+                    double *Eo = rd + nx * nt + nx + nc * nt + nc, *fo = Eo + (nc + ntc) * nt;
+                    if (lane == 0) { Eo[0] = 1.0; fo[0] = mx; Eo[1] = -1.0; fo[1] = -mn; }
+                    nE = 2;
+                }
+            } else {
+                // Chebyshev ball: min -r s.t. E theta + ||E_i|| r <= f, -r <= 0   (chebyshev_ball.py:41-60)
+                Lp lp;
+                lp.T = s.T; lp.ld = P.ld_t; lp.colvar = s.colvar; lp.rowvar = s.rowvar; lp.rowkind = s.rowkind;
+                lp.n = nt + 1; lp.m = nk + 1;
+                wave_sync();
+                for (int i = lane; i <= nk + 1; i += 64) {
+                    double *Ti = s.T + i * P.ld_t;
+                    if (i < nk) {
+                        double ss = 0.0;
+                        Ti[0] = s.E[i * ldE];
+                        for (int j = 0; j < nt; ++j) { const double v = s.E[i * ldE + 1 + j]; Ti[1 + j] = v; ss = fma(v, v, ss); }
+                        Ti[1 + nt] = sqrt(ss);
+                        Ti[2 + nt] = 0.0;
+                    } else {
+                        for (int j = 0; j <= nt + 2; ++j) Ti[j] = 0.0;
+                        Ti[1 + nt] = -1.0;  // row nk: -r <= 0 ; row nk+1 (cost): min -r
+                    }
+                    s.rowkind[i] = RK_INEQ;
+                }
+                int r = LP_INFEASIBLE;
+                if (lp_prepare(lp)) r = lp_solve(lp, true);
+                pivots += lp.iters;
+                double radius = 0.0;
+                if (r == LP_OPTIMAL) {
+                    int found = -1;
+                    for (int i = lane; i < lp.m; i += 64)
+                        if (s.rowkind[i] == RK_FREE && s.rowvar[i] == nt) found = i;
+                    double dummy = found >= 0 ? 1.0 : 0.0;
+                    reduce_max_first(dummy, found);
+                    radius = found >= 0 ? s.T[found * P.ld_t] : 0.0;
+                }
+                if (r == LP_ITERLIMIT) st = ST_LP_LIMIT;
+                else if (r != LP_OPTIMAL || !(radius > FULL_DIM_RADIUS)) st = ST_OPT_NO_REGION;
+                // one feasibility LP per kept row with that row as an equality (mpqp_utils.py:143-178)
+                double *Eo = rd + nx * nt + nx + nc * nt + nc, *fo = Eo + (nc + ntc) * nt;
+                for (int row = 0; row < nk && st == ST_REGION; ++row) {
+                    lp.n = nt; lp.m = nk;
+                    wave_sync();
+                    for (int i = lane; i <= nk; i += 64) {
+                        double *Ti = s.T + i * P.ld_t;
+                        if (i < nk) { for (int j = 0; j <= nt; ++j) Ti[j] = s.E[i * ldE + j]; Ti[nt + 1] = 0.0; }
+                        else for (int j = 0; j <= nt + 1; ++j) Ti[j] = 0.0;
+                        s.rowkind[i] = (i == row) ? RK_EQ : RK_INEQ;
+                    }
+                    int rr = LP_INFEASIBLE;
+                    if (lp_prepare(lp)) rr = lp_solve(lp, false);
+                    pivots += lp.iters;
+                    if (rr == LP_ITERLIMIT) { st = ST_LP_LIMIT; break; }
+                    if (rr != LP_OPTIMAL) continue;
+                    const int o = s.kept[row];
+                    if (lane == 0) {
+                        if (o < nlam) ri[5 + nc + ntc + n_la] = s.as[e + o];
+                        else if (o < nlam + nin) { ri[5 + nc + ntc + nc + n_re] = o - nlam; ri[5 + nc + ntc + nc + nc + n_re] = s.inact[o - nlam]; }
+                        else ri[5 + nc + n_om] = o - nlam - nin;
+                        fo[nE] = s.E[row * ldE];
+                    }
+                    for (int j = lane; j < nt; j += 64) Eo[nE * nt + j] = s.E[row * ldE + 1 + j];
+                    if (o < nlam) n_la++; else if (o < nlam + nin) n_re++; else n_om++;
+                    nE++;
+                }
+            }
+        }
+        if (st == ST_REGION) {
+            // x-law, multipliers, header
+            for (int idx = lane; idx < nx * nt; idx += 64) rd[idx] = s.X[(idx / nt) * nr + 1 + idx % nt];
+            for (int i = lane; i < nx; i += 64) rd[nx * nt + i] = s.X[i * nr];
+            double *Al = rd + nx * nt + nx, *bl = Al + nc * nt;
+            for (int idx = lane; idx < k * nt; idx += 64) Al[idx] = s.L[(idx / nt) * nr + 1 + idx % nt];
+            for (int i = lane; i < k; i += 64) bl[i] = s.L[i * nr];
+            for (int i = lane; i < k; i += 64) ri[5 + i] = s.as[i];
+            if (lane == 0) { ri[0] = k; ri[1] = nE; ri[2] = n_om; ri[3] = n_la; ri[4] = n_re; }
+        }
+        if (lane == 0) status[c] = (uint8_t)st;
+    }
+    if (lane == 0) atomicAdd(&ctr->pivots, pivots);
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// small utility kernels: flags, scan, compaction, children, pruned masks
+// ------------------------------------------------------------------------------------------------------------
+__global__ void k_histogram(const uint8_t *__restrict__ status, long long n, LevelCounters *ctr) {
+    __shared__ unsigned int h[8];
+    if (threadIdx.x < 8) h[threadIdx.x] = 0;
+    __syncthreads();
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+        atomicAdd(&h[status[i] & 7], 1u);
+    __syncthreads();
+    if (threadIdx.x < 8 && h[threadIdx.x]) atomicAdd(&ctr->status[threadIdx.x], (unsigned long long)h[threadIdx.x]);
+}
+
+// exclusive scan of int32 values by ONE workgroup of 1024 threads; total written to *total
+__global__ void __launch_bounds__(1024) k_scan_exclusive(const int32_t *__restrict__ in, int32_t *__restrict__ out, long long n,
+                                                        int32_t *__restrict__ total) {
+    __shared__ long long part[1024];
+    const int t = threadIdx.x;
+    const long long chunk = (n + 1023) / 1024, lo = t * chunk, hi = lo + chunk < n ? lo + chunk : n;
+    long long sum = 0;
+    for (long long i = lo; i < hi; ++i) sum += in[i];
+    part[t] = sum;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {
+        const long long v = t >= off ? part[t - off] : 0;
+        __syncthreads();
+        part[t] += v;
+        __syncthreads();
+    }
+    long long run = part[t] - sum;
+    for (long long i = lo; i < hi; ++i) { const int32_t v = in[i]; out[i] = (int32_t)run; run += v; }
+    if (t == 1023) *total = (int32_t)part[1023];
+}
+
+__global__ void k_flag_status(const uint8_t *__restrict__ status, long long n, int which, int32_t *__restrict__ flag) {
+    const long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+    if (i < n) flag[i] = status[i] == which;
+}
+__global__ void k_scatter_index(const int32_t *__restrict__ flag, const int32_t *__restrict__ pos, long long n,
+                                int32_t *__restrict__ list) {
+    const long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+    if (i < n && flag[i]) list[pos[i]] = (int32_t)i;
+}
+
+__device__ __forceinline__ bool expands(int st) { return st == ST_FEASIBLE || st == ST_REGION || st == ST_SINGULAR || st == ST_LP_LIMIT; }
+
+// children of one parent per wavefront: bit i of childmask = [as + {i}] survives CombinationTester.check and the
+// mpLP filter (driver lines 49-51); count[c] = popcount
+__global__ void __launch_bounds__(64) k_children_count(DevProblem P, const int32_t *__restrict__ cands, long long n, int k,
+                                                       const uint8_t *__restrict__ status,
+                                                       const unsigned long long *__restrict__ pruned, long long n_pruned,
+                                                       unsigned long long *__restrict__ childmask, int32_t *__restrict__ count) {
+    const long long c = blockIdx.x;
+    const int lane = lane_id();
+    if (c >= n) return;
+    const int st = status[c];
+    unsigned long long m0 = 0, m1 = 0;
+    int total = 0;
+    if (expands(st)) {
+        const int32_t *as = cands + (size_t)c * k;
+        unsigned long long p0 = 0, p1 = 0;
+        for (int i = 0; i < k; ++i) { const int v = as[i]; if (v < 64) p0 |= 1ull << v; else p1 |= 1ull << (v - 64); }
+        const int start = k > 0 ? as[k - 1] + 1 : 0;
+        for (int half = 0; half < 2; ++half) {
+            const int i = half * 64 + lane;
+            bool ok = i >= start && i < P.n_c;
+            if (ok && !P.is_qp && st == ST_FEASIBLE && i >= (k + 1) + P.n_c - P.n_x) ok = false;
+            const unsigned long long c0 = p0 | (half == 0 ? 1ull << lane : 0ull), c1 = p1 | (half == 1 ? 1ull << lane : 0ull);
+            if (__any(ok)) {
+                for (long long j = 0; j < n_pruned; ++j) {
+                    const unsigned long long q0 = pruned[2 * j], q1 = pruned[2 * j + 1];
+                    if ((c0 & q0) == q0 && (c1 & q1) == q1) ok = false;
+                }
+            }
+            const unsigned long long bal = __ballot(ok);
+            if (half == 0) m0 = bal; else m1 = bal;
+            total += __popcll(bal);
+        }
+    }
+    if (lane == 0) { childmask[2 * c] = m0; childmask[2 * c + 1] = m1; count[c] = total; }
+}
+
+__global__ void __launch_bounds__(64) k_children_write(const int32_t *__restrict__ cands, long long n, int k,
+                                                       const unsigned long long *__restrict__ childmask,
+                                                       const int32_t *__restrict__ offset, int32_t *__restrict__ out) {
+    const long long c = blockIdx.x;
+    const int lane = lane_id();
+    if (c >= n) return;
+    const int32_t *as = cands + (size_t)c * k;
+    int base = offset[c];
+    for (int half = 0; half < 2; ++half) {
+        const unsigned long long mk = childmask[2 * c + half];
+        if (!mk) continue;
+        const bool mine = (mk >> lane) & 1ull;
+        const int pos = base + __popcll(mk & ((1ull << lane) - 1ull));
+        if (mine) {
+            int32_t *o = out + (size_t)pos * (k + 1);
+            for (int i = 0; i < k; ++i) o[i] = as[i];
+            o[k] = half * 64 + lane;
+        }
+        base += __popcll(mk);
+    }
+}
+
+// masks of the candidates pruned by this level (INFEASIBLE, OPT_NO_REGION), appended at pruned[n_pruned_old + ...]
+__global__ void k_pruned_append(const int32_t *__restrict__ cands, long long n, int k, const uint8_t *__restrict__ status,
+                                unsigned long long *__restrict__ out, LevelCounters *ctr) {
+    const long long c = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+    if (c >= n) return;
+    const int st = status[c];
+    if (st != ST_INFEASIBLE && st != ST_OPT_NO_REGION) return;
+    unsigned long long p0 = 0, p1 = 0;
+    const int32_t *as = cands + (size_t)c * k;
+    for (int i = 0; i < k; ++i) { const int v = as[i]; if (v < 64) p0 |= 1ull << v; else p1 |= 1ull << (v - 64); }
+    const unsigned int pos = atomicAdd(&ctr->n_pruned_new, 1u);
+    out[2 * (size_t)pos] = p0;
+    out[2 * (size_t)pos + 1] = p1;
+}
+
+__global__ void k_root_frontier(int n_eq, int n_c, int32_t *out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int cnt = n_c - n_eq;
+    if (i >= cnt) return;
+    int32_t *o = out + (size_t)i * (n_eq + 1);
+    for (int j = 0; j < n_eq; ++j) o[j] = j;
+    o[n_eq] = n_eq + i;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// k_lp_batch: generic LPs, one wavefront each (deterministic-solver plug)
+// ------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(64) k_lp_batch(long long n_lp, int m, int n, int ld, const double *__restrict__ A, int shared_A,
+                                                 const double *__restrict__ b, int shared_b, const double *__restrict__ c,
+                                                 int shared_c, const uint8_t *__restrict__ eq, int32_t *__restrict__ status,
+                                                 double *__restrict__ x, double *__restrict__ obj, int32_t *__restrict__ iters,
+                                                 unsigned int *work) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    const int lane = lane_id();
+    double *T = smem;
+    int *ib = reinterpret_cast<int *>(smem + (size_t)(m + 1) * ld);
+    Lp lp;
+    lp.T = T; lp.ld = ld; lp.colvar = ib; lp.rowvar = ib + ld + 1; lp.rowkind = ib + ld + 1 + m + 1;
+    for (;;) {
+        unsigned int w = 0;
+        if (lane == 0) w = atomicAdd(work, 1u);
+        w = __shfl(w, 0);
+        if (w >= n_lp) break;
+        const double *Aw = A + (shared_A ? 0 : (size_t)w * m * n);
+        const double *bw = b + (shared_b ? 0 : (size_t)w * m);
+        const double *cw = c ? c + (shared_c ? 0 : (size_t)w * n) : nullptr;
+        lp.m = m; lp.n = n;
+        wave_sync();
+        for (int i = 0; i < m; ++i)
+            for (int j = lane; j < n; j += 64) T[i * ld + 1 + j] = Aw[(size_t)i * n + j];
+        for (int i = lane; i < m; i += 64) { T[i * ld] = bw[i]; T[i * ld + n + 1] = 0.0; lp.rowkind[i] = eq[(size_t)w * m + i] ? RK_EQ : RK_INEQ; }
+        for (int j = lane; j <= n + 1; j += 64) T[m * ld + j] = (cw && j >= 1 && j <= n) ? cw[j - 1] : 0.0;
+        int r = LP_INFEASIBLE;
+        if (lp_prepare(lp)) r = lp_solve(lp, cw != nullptr);
+        if (x) {
+            for (int j = lane; j < n; j += 64) x[(size_t)w * n + j] = 0.0;
+            wave_sync();
+            if (r == LP_OPTIMAL)
+                for (int i = lane; i < m; i += 64)
+                    if (lp.rowkind[i] == RK_FREE) x[(size_t)w * n + lp.rowvar[i]] = T[i * ld];
+        }
+        if (lane == 0) {
+            status[w] = r;
+            if (obj) obj[w] = r == LP_OPTIMAL ? -T[m * ld] : 0.0;
+            if (iters) iters[w] = lp.iters;
+        }
+        wave_sync();
+    }
+}
+
+}  // namespace mpc

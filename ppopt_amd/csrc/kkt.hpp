@@ -1,0 +1,160 @@
+// kkt.hpp -- per-candidate KKT solves on LDS-resident blocks, one wavefront per active set (gfx950).
+//
+// Reference: MPQP_Program.optimal_control_law (mpqp_program.py:146-198) solves
+//     [A_as  0    ] [x]   [b_as + F_as theta]
+//     [Q     A_as'] [l] = [-c   - H theta   ]
+// with numpy.linalg.solve.  Two device paths:
+//   mode 0 (Q > 0)  Schur complement on blocks precomputed once per program:
+//          W = A Q^-1 A', UV = [A Q^-1 c + b | A Q^-1 H + F]:   S = W[as,as] (gathered),  S L = -UV[as]
+//          by Cholesky; a non-positive pivot <=> A_as rank deficient (is_full_rank, constraint_utilities.py:222).
+//   mode 1 (mpLP / PSD Q)  the dense (n_x+k) KKT matrix itself, LU with partial pivoting (== LAPACK gesv).
+#pragma once
+#include "lp_engine.hpp"
+
+namespace mpc {
+
+constexpr double RANK_TOL_CHOL = 1e-13;  // pivot / original diagonal (= sin^2 of the angle to the span)
+constexpr double RANK_TOL_GE = 1e-11;    // complete-pivoting elimination, relative to the largest entry
+constexpr double KKT_SING_TOL = 1e-12;   // LU pivot relative to the largest entry of the KKT matrix
+
+// In-place lower Cholesky of the k x k LDS matrix S (row stride k) and solution of S X = R for the k x nr LDS
+// block R.  diag0[i] holds the original diagonal.  Returns false when a pivot falls below RANK_TOL_CHOL.
+__device__ inline bool chol_solve(double *S, int k, double *R, int nr, const double *diag0) {
+    const int lane = lane_id();
+    for (int j = 0; j < k; ++j) {
+        const double d = S[j * k + j];
+        if (!(d > RANK_TOL_CHOL * diag0[j])) return false;
+        const double l = sqrt(d), inv = 1.0 / l;
+        wave_sync();
+        for (int i = j + 1 + lane; i < k; i += 64) S[i * k + j] = S[i * k + j] * inv;
+        if (lane == 0) S[j * k + j] = l;
+        wave_sync();
+        const int cnt = k - j - 1;
+        for (int idx = lane; idx < cnt * cnt; idx += 64) {
+            const int i = j + 1 + idx / cnt, c = j + 1 + idx % cnt;
+            if (c <= i) S[i * k + c] = fma(-S[i * k + j], S[c * k + j], S[i * k + c]);
+        }
+        wave_sync();
+    }
+    // forward substitution L Y = R (column oriented)
+    for (int j = 0; j < k; ++j) {
+        const double inv = 1.0 / S[j * k + j];
+        wave_sync();
+        for (int t = lane; t < nr; t += 64) R[j * nr + t] = R[j * nr + t] * inv;
+        wave_sync();
+        const int cnt = k - j - 1;
+        for (int idx = lane; idx < cnt * nr; idx += 64) {
+            const int i = j + 1 + idx / nr, t = idx % nr;
+            R[i * nr + t] = fma(-S[i * k + j], R[j * nr + t], R[i * nr + t]);
+        }
+        wave_sync();
+    }
+    // back substitution L' X = Y
+    for (int j = k - 1; j >= 0; --j) {
+        const double inv = 1.0 / S[j * k + j];
+        wave_sync();
+        for (int t = lane; t < nr; t += 64) R[j * nr + t] = R[j * nr + t] * inv;
+        wave_sync();
+        for (int idx = lane; idx < j * nr; idx += 64) {
+            const int i = idx / nr, t = idx % nr;
+            R[i * nr + t] = fma(-S[j * k + i], R[j * nr + t], R[i * nr + t]);
+        }
+        wave_sync();
+    }
+    return true;
+}
+
+// LU with partial pivoting of the n x n LDS matrix M (row stride n), applied to the n x nr block B.
+// Returns false if a pivot is <= sing_tol * scale (scale = largest |entry| of M).
+__device__ inline bool lu_solve(double *M, int n, double *B, int nr, double sing_tol) {
+    const int lane = lane_id();
+    double scale = 0.0;
+    for (int idx = lane; idx < n * n; idx += 64) scale = fmax(scale, fabs(M[idx]));
+    for (int off = 32; off > 0; off >>= 1) scale = fmax(scale, __shfl_xor(scale, off));
+    for (int col = 0; col < n; ++col) {
+        double best = -1.0;
+        int piv = -1;
+        for (int i = col + lane; i < n; i += 64) {
+            const double a = fabs(M[i * n + col]);
+            if (a > best) { best = a; piv = i; }
+        }
+        reduce_max_first(best, piv);
+        if (!(best > sing_tol * scale)) return false;
+        wave_sync();
+        if (piv != col) {
+            for (int j = lane; j < n; j += 64) { const double t = M[col * n + j]; M[col * n + j] = M[piv * n + j]; M[piv * n + j] = t; }
+            for (int j = lane; j < nr; j += 64) { const double t = B[col * nr + j]; B[col * nr + j] = B[piv * nr + j]; B[piv * nr + j] = t; }
+            wave_sync();
+        }
+        const double inv = 1.0 / M[col * n + col];
+        wave_sync();
+        for (int i = col + 1 + lane; i < n; i += 64) M[i * n + col] = M[i * n + col] * inv;
+        wave_sync();
+        const int rows = n - col - 1, cols = n - col - 1 + nr;
+        for (int idx = lane; idx < rows * cols; idx += 64) {
+            const int i = col + 1 + idx / cols, c = idx % cols;
+            const double f = M[i * n + col];
+            if (c < n - col - 1) {
+                const int j = col + 1 + c;
+                M[i * n + j] = fma(-f, M[col * n + j], M[i * n + j]);
+            } else {
+                const int t = c - (n - col - 1);
+                B[i * nr + t] = fma(-f, B[col * nr + t], B[i * nr + t]);
+            }
+        }
+        wave_sync();
+    }
+    for (int j = n - 1; j >= 0; --j) {
+        const double inv = 1.0 / M[j * n + j];
+        wave_sync();
+        for (int t = lane; t < nr; t += 64) B[j * nr + t] = B[j * nr + t] * inv;
+        wave_sync();
+        for (int idx = lane; idx < j * nr; idx += 64) {
+            const int i = idx / nr, t = idx % nr;
+            B[i * nr + t] = fma(-M[i * n + j], B[j * nr + t], B[i * nr + t]);
+        }
+        wave_sync();
+    }
+    return true;
+}
+
+// rank(M) == k for the k x n LDS matrix M (row stride n, destroyed): Gaussian elimination with complete pivoting.
+__device__ inline bool full_row_rank(double *M, int k, int n) {
+    const int lane = lane_id();
+    if (k > n) return false;
+    double scale = 0.0;
+    for (int idx = lane; idx < k * n; idx += 64) scale = fmax(scale, fabs(M[idx]));
+    for (int off = 32; off > 0; off >>= 1) scale = fmax(scale, __shfl_xor(scale, off));
+    if (!(scale > 0.0)) return k == 0;
+    for (int s = 0; s < k; ++s) {
+        double best = -1.0;
+        int pos = -1;
+        const int rows = k - s, cols = n - s;
+        for (int idx = lane; idx < rows * cols; idx += 64) {
+            const int i = s + idx / cols, j = s + idx % cols;
+            const double a = fabs(M[i * n + j]);
+            if (a > best) { best = a; pos = i * n + j; }
+        }
+        reduce_max_first(best, pos);
+        if (!(best > RANK_TOL_GE * scale)) return false;
+        const int pi = pos / n, pj = pos % n;
+        wave_sync();
+        if (pi != s) {
+            for (int j = lane; j < n; j += 64) { const double t = M[s * n + j]; M[s * n + j] = M[pi * n + j]; M[pi * n + j] = t; }
+            wave_sync();
+        }
+        if (pj != s) {
+            for (int i = lane; i < k; i += 64) { const double t = M[i * n + s]; M[i * n + s] = M[i * n + pj]; M[i * n + pj] = t; }
+            wave_sync();
+        }
+        const double inv = 1.0 / M[s * n + s];
+        for (int idx = lane; idx < (rows - 1) * (cols - 1); idx += 64) {
+            const int i = s + 1 + idx / (cols - 1), j = s + 1 + idx % (cols - 1);
+            M[i * n + j] = fma(-(M[i * n + s] * inv), M[s * n + j], M[i * n + j]);
+        }
+        wave_sync();
+    }
+    return true;
+}
+
+}  // namespace mpc

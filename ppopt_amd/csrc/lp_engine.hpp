@@ -1,0 +1,340 @@
+// lp_engine.hpp -- one-wavefront dense simplex on an LDS-resident tableau (gfx950).
+//
+// One 64-lane wavefront owns one LP.  The dictionary lives in LDS with an ODD row stride (in doubles) so
+// that "lane i reads row i, column j" is bank-conflict free for ds_read_b64; lanes are mapped to ROWS
+// (row = lane + 64*s), the pivot row is read as an LDS broadcast.  All control flow is wave-uniform:
+// every selection (pivot row, entering column, ratio test) is a butterfly reduction whose result is
+// identical in all lanes.
+//
+// Dictionary:  basic_i = T[i][0] - sum_{j=1..na} T[i][j] * nonbasic_j ;  cost row at index m holds the
+// reduced costs (T[m][0] = -objective).  Method (same rules, tolerances and tie-breaks as the CPU oracle,
+// so both produce the same pivot sequence):
+//   stage A  free structural variables enter the basis (equality rows first, largest |coefficient|);
+//            a fixed (equality) slack that becomes nonbasic has its column deleted
+//   stage B  equality rows still basic leave the basis (or are redundant / inconsistent)
+//   phase 1  x0 method, Dantzig pricing, Bland's rule while stalled at a degenerate vertex
+//   phase 2  primal simplex on the cost row
+// Reference boundary this replaces: Solver.solve_lp -> GLPK (solver.py:211, cvxopt_interface.py:153-208).
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace mpc {
+
+constexpr double TOL_FEAS = 1e-7;
+constexpr double TOL_PIV = 1e-9;
+constexpr double TOL_COST = 1e-9;
+constexpr int DEG_SWITCH = 12;
+
+enum : int { RK_INEQ = 0, RK_EQ = 1, RK_FREE = 2, RK_DEAD = 3, RK_X0 = 4 };
+enum : int { LP_OPTIMAL = 0, LP_INFEASIBLE = 1, LP_UNBOUNDED = 2, LP_ITERLIMIT = 3 };
+
+struct Lp {
+    double *T;     // LDS: (m + 1) rows x ld
+    int *colvar;   // LDS: variable id held by column j (1..na)
+    int *rowvar;   // LDS: variable id basic in row i
+    int *rowkind;  // LDS: RK_*
+    int ld;        // odd row stride in doubles
+    int m;         // constraint rows; the cost row is row m
+    int n;         // structural variables (ids 0..n-1); slack of row i is n+i; x0 is n+m
+    int na;        // alive nonbasic columns 1..na
+    int iters;
+    int max_iter;
+};
+
+__device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
+
+__device__ __forceinline__ void wave_sync() { __syncthreads(); }
+
+// ---- butterfly reductions (results uniform across the wave) ----------------------------------------------
+// largest value, ties -> lowest index; idx < 0 means "no candidate"
+__device__ __forceinline__ void reduce_max_first(double &v, int &idx) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const double ov = __shfl_xor(v, off);
+        const int oi = __shfl_xor(idx, off);
+        const bool take = (oi >= 0) && (idx < 0 || ov > v || (ov == v && oi < idx));
+        if (take) { v = ov; idx = oi; }
+    }
+}
+// smallest value, ties -> lowest key2, then lowest index
+__device__ __forceinline__ void reduce_min_first(double &v, int &key2, int &idx) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const double ov = __shfl_xor(v, off);
+        const int ok = __shfl_xor(key2, off);
+        const int oi = __shfl_xor(idx, off);
+        const bool take = (oi >= 0) && (idx < 0 || ov < v || (ov == v && (ok < key2 || (ok == key2 && oi < idx))));
+        if (take) { v = ov; key2 = ok; idx = oi; }
+    }
+}
+// ratio test: smallest ratio; ties -> x0 row first, then (bland ? lowest basic var : largest pivot), then lowest row
+__device__ __forceinline__ void reduce_ratio(double &ratio, double &piv, int &isx0, int &var, int &idx, bool bland) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const double orat = __shfl_xor(ratio, off);
+        const double opiv = __shfl_xor(piv, off);
+        const int ox0 = __shfl_xor(isx0, off);
+        const int ovar = __shfl_xor(var, off);
+        const int oi = __shfl_xor(idx, off);
+        bool take = false;
+        if (oi >= 0) {
+            if (idx < 0 || orat < ratio) take = true;
+            else if (orat == ratio) {
+                if (ox0 != isx0) take = ox0 > isx0;
+                else if (bland) take = (ovar < var);
+                else if (opiv != piv) take = opiv > piv;
+                else take = oi < idx;
+            }
+        }
+        if (take) { ratio = orat; piv = opiv; isx0 = ox0; var = ovar; idx = oi; }
+    }
+}
+
+// within-lane version of the same orders (a lane may own several rows)
+__device__ __forceinline__ bool ratio_better(double r, double p, int x0, int var, int i, double br, double bp, int bx0,
+                                             int bvar, int bi, bool bland) {
+    if (bi < 0 || r < br) return true;
+    if (r == br) {
+        if (x0 != bx0) return x0 > bx0;
+        if (bland) return var < bvar;
+        if (p != bp) return p > bp;
+        return i < bi;
+    }
+    return false;
+}
+
+// ---- elementary operations -------------------------------------------------------------------------------
+__device__ inline void lp_pivot(Lp &lp, int r, int q) {
+    double *T = lp.T;
+    const int ld = lp.ld, na = lp.na, m = lp.m, lane = lane_id();
+    double *Tr = T + r * ld;
+    const double inv = 1.0 / Tr[q];
+    wave_sync();
+    for (int j = lane; j <= na; j += 64)
+        if (j != q) Tr[j] = Tr[j] * inv;
+    wave_sync();
+    for (int i = lane; i <= m; i += 64) {
+        if (i == r) continue;
+        double *Ti = T + i * ld;
+        const double f = Ti[q];
+        if (f == 0.0) continue;
+        for (int j = 0; j < q; ++j) Ti[j] = fma(-f, Tr[j], Ti[j]);
+        for (int j = q + 1; j <= na; ++j) Ti[j] = fma(-f, Tr[j], Ti[j]);
+        Ti[q] = -f * inv;
+    }
+    wave_sync();
+    if (lane == 0) {
+        Tr[q] = inv;
+        const int t = lp.rowvar[r];
+        lp.rowvar[r] = lp.colvar[q];
+        lp.colvar[q] = t;
+    }
+    wave_sync();
+    lp.iters++;
+}
+
+__device__ inline void lp_drop_col(Lp &lp, int q) {
+    const int na = lp.na, lane = lane_id();
+    if (q != na) {
+        for (int i = lane; i <= lp.m; i += 64) lp.T[i * lp.ld + q] = lp.T[i * lp.ld + na];
+        if (lane == 0) lp.colvar[q] = lp.colvar[na];
+    }
+    lp.na = na - 1;
+    wave_sync();
+}
+
+// largest |T[i][q]| > TOL_PIV over rows of the given kind (ties: lowest row); -1 if none
+__device__ inline int lp_best_row(const Lp &lp, int q, int kind) {
+    double best = TOL_PIV;
+    int r = -1;
+    for (int i = lane_id(); i < lp.m; i += 64)
+        if (lp.rowkind[i] == kind) {
+            const double a = fabs(lp.T[i * lp.ld + q]);
+            if (a > best) { best = a; r = i; }
+        }
+    reduce_max_first(best, r);
+    return r;
+}
+// largest |T[r][j]| > TOL_PIV over alive columns (ties: lowest column); -1 if none
+__device__ inline int lp_best_col(const Lp &lp, int r) {
+    double best = TOL_PIV;
+    int q = -1;
+    for (int j = 1 + lane_id(); j <= lp.na; j += 64) {
+        const double a = fabs(lp.T[r * lp.ld + j]);
+        if (a > best) { best = a; q = j; }
+    }
+    reduce_max_first(best, q);
+    return q;
+}
+
+// primal simplex.  phase1_row >= 0: minimise x0 (basic in that row); else minimise the cost row.
+// returns 0 optimal, 2 unbounded, 3 iteration limit, 4 x0 left the basis (phase 1)
+__device__ inline int lp_primal(Lp &lp, int phase1_row) {
+    const int m = lp.m, ld = lp.ld, lane = lane_id();
+    double *T = lp.T;
+    int deg = 0;
+    for (;;) {
+        if (lp.iters > lp.max_iter) return 3;
+        const bool bland = deg > DEG_SWITCH;
+        const int crow = phase1_row >= 0 ? phase1_row : m;
+        const double sgn = phase1_row >= 0 ? -1.0 : 1.0;
+        if (phase1_row >= 0 && T[phase1_row * ld] <= TOL_FEAS) return 0;
+        // pricing
+        double best = -TOL_COST;
+        int key = 0, q = -1;
+        for (int j = 1 + lane; j <= lp.na; j += 64) {
+            const double d = sgn * T[crow * ld + j];
+            if (d < -TOL_COST) {
+                if (bland) {
+                    const int v = lp.colvar[j];
+                    if (q < 0 || v < key) { q = j; key = v; }
+                } else if (d < best) { best = d; q = j; }
+            }
+        }
+        if (bland) best = 0.0;
+        reduce_min_first(best, key, q);
+        if (q < 0) return 0;
+        // ratio test
+        double rmin = 0.0, rpiv = 0.0;
+        int rx0 = 0, rvar = 0, r = -1;
+        for (int i = lane; i < m; i += 64) {
+            const int kind = lp.rowkind[i];
+            if (kind != RK_INEQ && kind != RK_X0) continue;
+            const double a = T[i * ld + q];
+            if (a <= TOL_PIV) continue;
+            double beta = T[i * ld];
+            if (beta < 0.0) beta = 0.0;
+            const double ratio = beta / a;
+            const int x0 = kind == RK_X0, var = lp.rowvar[i];
+            if (ratio_better(ratio, a, x0, var, i, rmin, rpiv, rx0, rvar, r, bland)) { rmin = ratio; rpiv = a; rx0 = x0; rvar = var; r = i; }
+        }
+        reduce_ratio(rmin, rpiv, rx0, rvar, r, bland);
+        if (r < 0) return 2;
+        deg = (rmin <= 0.0) ? deg + 1 : 0;
+        lp_pivot(lp, r, q);
+        if (rx0) {
+            if (lane == 0) lp.rowkind[r] = RK_INEQ;
+            lp_drop_col(lp, q);
+            return 4;
+        }
+    }
+}
+
+// Solves the LP whose scaled tableau, rowkind (RK_INEQ / RK_EQ / RK_DEAD), rowvar (= n + i) and colvar (= j - 1)
+// are already in LDS.  has_cost: run phase 2 on row m.  Returns LP_*.
+__device__ inline int lp_solve(Lp &lp, bool has_cost) {
+    const int m = lp.m, n = lp.n, ld = lp.ld, lane = lane_id();
+    double *T = lp.T;
+    bool unbounded_if_feasible = false;
+    wave_sync();
+    // stage A
+    for (int v = 0; v < n; ++v) {
+        int q = -1;
+        for (int j = 1 + lane; j <= lp.na; j += 64)
+            if (lp.colvar[j] == v) q = j;
+        {
+            double dummy = (q >= 0) ? 1.0 : 0.0;
+            reduce_max_first(dummy, q);
+        }
+        int r = lp_best_row(lp, q, RK_EQ);
+        const bool was_eq = r >= 0;
+        if (r < 0) r = lp_best_row(lp, q, RK_INEQ);
+        if (r < 0) {
+            if (has_cost && fabs(T[m * ld + q]) > TOL_COST) unbounded_if_feasible = true;
+            lp_drop_col(lp, q);
+            continue;
+        }
+        lp_pivot(lp, r, q);
+        if (lane == 0) lp.rowkind[r] = RK_FREE;
+        if (was_eq) lp_drop_col(lp, q);
+        else wave_sync();
+    }
+    // stage B
+    for (int i = 0; i < m; ++i) {
+        if (lp.rowkind[i] != RK_EQ) continue;
+        const int q = lp_best_col(lp, i);
+        if (q < 0) {
+            if (fabs(T[i * ld]) > TOL_FEAS) return LP_INFEASIBLE;
+            wave_sync();
+            if (lane == 0) lp.rowkind[i] = RK_DEAD;
+            wave_sync();
+            continue;
+        }
+        lp_pivot(lp, i, q);
+        if (lane == 0) lp.rowkind[i] = RK_INEQ;
+        lp_drop_col(lp, q);
+    }
+    // phase 1
+    {
+        double mn = -TOL_FEAS;
+        int key = 0, r = -1;
+        for (int i = lane; i < m; i += 64)
+            if (lp.rowkind[i] == RK_INEQ && T[i * ld] < mn) { mn = T[i * ld]; r = i; }
+        reduce_min_first(mn, key, r);
+        if (r >= 0) {
+            const int q = ++lp.na;
+            for (int i = lane; i <= m; i += 64) T[i * ld + q] = (i < m && lp.rowkind[i] == RK_INEQ) ? -1.0 : 0.0;
+            if (lane == 0) lp.colvar[q] = n + m;
+            wave_sync();
+            lp_pivot(lp, r, q);
+            if (lane == 0) lp.rowkind[r] = RK_X0;
+            wave_sync();
+            const int st = lp_primal(lp, r);
+            if (st == 3) return LP_ITERLIMIT;
+            if (st != 4) {
+                if (T[r * ld] > TOL_FEAS) return LP_INFEASIBLE;
+                const int qq = lp_best_col(lp, r);
+                wave_sync();
+                if (qq < 0) {
+                    if (lane == 0) lp.rowkind[r] = RK_DEAD;
+                    wave_sync();
+                } else {
+                    lp_pivot(lp, r, qq);
+                    if (lane == 0) lp.rowkind[r] = RK_INEQ;
+                    lp_drop_col(lp, qq);
+                }
+            }
+        }
+    }
+    if (has_cost) {
+        if (unbounded_if_feasible) return LP_UNBOUNDED;
+        const int st = lp_primal(lp, -1);
+        if (st == 2) return LP_UNBOUNDED;
+        if (st == 3) return LP_ITERLIMIT;
+    }
+    return LP_OPTIMAL;
+}
+
+// Row scaling by a power of two of the largest |coefficient| (exact), zero-row handling and bookkeeping init.
+// The caller has written T[i][0] = b_i, T[i][1..n] = A_i and rowkind[i] = RK_EQ / RK_INEQ for i < m and the cost
+// row.  Returns false if a zero row is inconsistent (0 <= b_i violated).
+__device__ inline bool lp_prepare(Lp &lp) {
+    const int m = lp.m, n = lp.n, ld = lp.ld, lane = lane_id();
+    int bad = 0;
+    wave_sync();
+    for (int i = lane; i < m; i += 64) {
+        double *Ti = lp.T + i * ld;
+        double mx = 0.0;
+        for (int j = 1; j <= n; ++j) { const double a = fabs(Ti[j]); if (a > mx) mx = a; }
+        lp.rowvar[i] = n + i;
+        if (lp.rowkind[i] == RK_DEAD) continue;
+        if (!(mx > 0.0)) {
+            if (lp.rowkind[i] == RK_EQ ? fabs(Ti[0]) > TOL_FEAS : Ti[0] < -TOL_FEAS) bad = 1;
+            lp.rowkind[i] = RK_DEAD;
+            continue;
+        }
+        int e;
+        (void)frexp(mx, &e);
+        const double s = ldexp(1.0, -e);
+        for (int j = 0; j <= n; ++j) Ti[j] = Ti[j] * s;
+    }
+    for (int j = 1 + lane; j <= n; j += 64) lp.colvar[j] = j - 1;
+    lp.na = n;
+    lp.iters = 0;
+    lp.max_iter = 50 * (m + n) + 100;
+    const bool any_bad = __any(bad);
+    wave_sync();
+    return !any_bad;
+}
+
+}  // namespace mpc

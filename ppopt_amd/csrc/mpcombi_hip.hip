@@ -1,0 +1,623 @@
+// mpcombi_hip.hip -- C ABI (include/mpcombi.h) over the gfx950 kernels in kernels.hpp.
+//
+// Build:  hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -shared mpcombi_hip.hip -o libmpcombi_hip.so
+//
+// Host side of the hot path: owns the device-resident program blocks, the frontier (to_check), the pruned list
+// (murder_list) and the per-level result buffers; launches the kernels on one HIP stream and times them with HIP
+// events.  No CPU fallback exists: without a usable HIP device every entry point fails with MPC_ERR_HIP.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/mpcombi.h"
+#include "kernels.hpp"
+
+using namespace mpc;
+
+namespace {
+
+thread_local std::string g_error;
+
+struct DevBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+    hipError_t ensure(size_t bytes, hipStream_t st, bool keep = false) {
+        if (bytes <= cap) return hipSuccess;
+        size_t want = std::max(bytes, cap + cap / 2);
+        want = (want + 255) & ~size_t(255);
+        void *q = nullptr;
+        hipError_t e = hipMalloc(&q, want);
+        if (e != hipSuccess) return e;
+        if (keep && p && cap) {
+            e = hipMemcpyAsync(q, p, cap, hipMemcpyDeviceToDevice, st);
+            if (e != hipSuccess) return e;
+            e = hipStreamSynchronize(st);
+            if (e != hipSuccess) return e;
+        }
+        if (p) (void)hipFree(p);
+        p = q;
+        cap = want;
+        return hipSuccess;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+    template <class T> T *as() const { return reinterpret_cast<T *>(p); }
+};
+
+int odd_at_least(int v) { return (v % 2) ? v : v + 1; }
+
+}  // namespace
+
+struct mpc_handle {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    int n_cu = 256;
+    std::string error;
+    // problem
+    int n_x = 0, n_t = 0, n_c = 0, n_eq = 0, n_tc = 0, is_qp = 0, kkt_mode = 0;
+    DevBuf blocks;            // all read-only problem blocks, one allocation
+    DevProblem Pv{}, Pr{};    // verdict / region kernel views (same blocks, different LDS layouts)
+    int lds_v = 0, lds_r = 0; // dynamic LDS bytes per wavefront
+    int grid_v = 0, grid_r = 0;
+    long long rec_d = 0, rec_i = 0;
+    // frontier / pruned
+    DevBuf frontier, children, status, pruned, pruned_new, flag, pos, opt_list, childmask, count, offset, recd, reci, ctr, scratch;
+    long long n = 0;
+    int k = 0;
+    long long n_pruned = 0;
+    // level results
+    bool level_done = false;
+    long long n_opt = 0, n_children = 0, n_pruned_new = 0, n_regions = 0;
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+};
+
+namespace {
+
+int fail(mpc_handle *h, int code, const std::string &msg) {
+    if (h) h->error = msg; else g_error = msg;
+    return code;
+}
+
+#define HIP_TRY(h, expr)                                                                                   \
+    do {                                                                                                   \
+        hipError_t e__ = (expr);                                                                           \
+        if (e__ != hipSuccess)                                                                             \
+            return fail(h, MPC_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e__));               \
+    } while (0)
+
+// dense host helpers (one-off program setup; fp64)
+bool cholesky(std::vector<double> &M, int n) {
+    double dmax = 0;
+    for (int i = 0; i < n; ++i) dmax = std::max(dmax, std::fabs(M[(size_t)i * n + i]));
+    for (int j = 0; j < n; ++j) {
+        double d = M[(size_t)j * n + j];
+        for (int l = 0; l < j; ++l) d -= M[(size_t)j * n + l] * M[(size_t)j * n + l];
+        if (!(d > 1e-10 * dmax)) return false;
+        const double s = std::sqrt(d);
+        M[(size_t)j * n + j] = s;
+        for (int i = j + 1; i < n; ++i) {
+            double v = M[(size_t)i * n + j];
+            for (int l = 0; l < j; ++l) v -= M[(size_t)i * n + l] * M[(size_t)j * n + l];
+            M[(size_t)i * n + j] = v / s;
+        }
+    }
+    return true;
+}
+// x := Q^-1 x given the lower Cholesky factor
+void chol_apply(const std::vector<double> &L, int n, double *x) {
+    for (int i = 0; i < n; ++i) {
+        double v = x[i];
+        for (int l = 0; l < i; ++l) v -= L[(size_t)i * n + l] * x[l];
+        x[i] = v / L[(size_t)i * n + i];
+    }
+    for (int i = n - 1; i >= 0; --i) {
+        double v = x[i];
+        for (int l = i + 1; l < n; ++l) v -= L[(size_t)l * n + i] * x[l];
+        x[i] = v / L[(size_t)i * n + i];
+    }
+}
+
+struct Layout { int off_T, off_K, off_L, off_E, off_X, n_doubles, off_as, off_inact, off_colvar, off_rowvar, off_rowkind, off_kept, n_ints, bytes; };
+
+Layout make_layout(int size_T, int size_K, int size_L, int size_E, int size_X, int kmax, int n_c, int ld_max, int rows_max, int rows_t) {
+    Layout l{};
+    int o = 0;
+    auto take = [&](int sz) { int r = o; o += (sz + 1) & ~1; return r; };
+    l.off_T = take(size_T); l.off_K = take(size_K); l.off_L = take(size_L); l.off_E = take(size_E); l.off_X = take(size_X);
+    l.n_doubles = o;
+    int q = 0;
+    auto itake = [&](int sz) { int r = q; q += sz; return r; };
+    l.off_as = itake(kmax + 1); l.off_inact = itake(n_c + 1); l.off_colvar = itake(ld_max + 2);
+    l.off_rowvar = itake(rows_max + 3); l.off_rowkind = itake(rows_max + 3); l.off_kept = itake(rows_t + 1);
+    l.n_ints = q;
+    l.bytes = (l.n_doubles * 8 + l.n_ints * 4 + 15) & ~15;
+    return l;
+}
+
+void apply_layout(DevProblem &P, const Layout &l) {
+    P.off_T = l.off_T; P.off_K = l.off_K; P.off_L = l.off_L; P.off_E = l.off_E; P.off_X = l.off_X; P.n_doubles = l.n_doubles;
+    P.off_as = l.off_as; P.off_inact = l.off_inact; P.off_colvar = l.off_colvar; P.off_rowvar = l.off_rowvar;
+    P.off_rowkind = l.off_rowkind; P.off_kept = l.off_kept; P.n_ints = l.n_ints;
+}
+
+int waves_per_cu(int lds_bytes) { return std::max(1, std::min(16, (160 * 1024) / std::max(lds_bytes, 1))); }
+
+}  // namespace
+
+extern "C" {
+
+int mpc_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+const char *mpc_version(void) { return "mpcombi-hip 0.1 (gfx950)"; }
+const char *mpc_last_global_error(void) { return g_error.c_str(); }
+const char *mpc_last_error(const mpc_handle *h) { return h ? h->error.c_str() : g_error.c_str(); }
+
+int mpc_create(const mpc_problem *p, int32_t device, void *stream, mpc_handle **out) {
+    if (!p || !out) return fail(nullptr, MPC_ERR_INVALID, "null argument");
+    *out = nullptr;
+    const int nx = p->n_x, nt = p->n_t, nc = p->n_c, ne = p->n_eq, ntc = p->n_tc;
+    if (nx < 1 || nt < 1 || nc < 1 || ne < 0 || ne > nc || ntc < 0) return fail(nullptr, MPC_ERR_INVALID, "bad dimensions");
+    if (nc > MPC_MAX_NC) return fail(nullptr, MPC_ERR_INVALID, "n_c > 128 is not supported (active sets are 128-bit masks)");
+    if (nc + ntc + 2 > MPC_MAX_ROWS * 4) return fail(nullptr, MPC_ERR_INVALID, "too many rows");
+    if (nt > 64 || nx > 256) return fail(nullptr, MPC_ERR_INVALID, "n_t > 64 or n_x > 256 is not supported");
+    if (!p->A || !p->b || !p->F || !p->c || !p->H || (ntc > 0 && (!p->A_t || !p->b_t))) return fail(nullptr, MPC_ERR_INVALID, "null matrix");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return fail(nullptr, MPC_ERR_HIP, "no HIP device available (libmpcombi_hip has no CPU fallback)");
+    if (device < 0 || device >= ndev) return fail(nullptr, MPC_ERR_INVALID, "device index out of range");
+    mpc_handle *h = new mpc_handle();
+    h->device = device;
+    HIP_TRY(nullptr, hipSetDevice(device));
+    hipDeviceProp_t prop;
+    HIP_TRY(nullptr, hipGetDeviceProperties(&prop, device));
+    h->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    if (stream) { h->stream = reinterpret_cast<hipStream_t>(stream); h->own_stream = false; }
+    else { HIP_TRY(nullptr, hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking)); h->own_stream = true; }
+    for (auto &e : h->ev) HIP_TRY(nullptr, hipEventCreate(&e));
+    h->n_x = nx; h->n_t = nt; h->n_c = nc; h->n_eq = ne; h->n_tc = ntc; h->is_qp = p->Q != nullptr;
+
+    const int nr = nt + 1;
+    // ---- host-side one-off blocks ----------------------------------------------------------------------
+    std::vector<double> W, UV, Gt, X0H;
+    int mode = 1;
+    if (p->Q) {
+        std::vector<double> L(p->Q, p->Q + (size_t)nx * nx);
+        for (int i = 0; i < nx; ++i) for (int j = 0; j < i; ++j) { const double s = 0.5 * (L[(size_t)i * nx + j] + L[(size_t)j * nx + i]); L[(size_t)i * nx + j] = s; L[(size_t)j * nx + i] = s; }
+        if (cholesky(L, nx)) {
+            mode = 0;
+            Gt.assign((size_t)nc * nx, 0.0);
+            for (int i = 0; i < nc; ++i) { std::copy(p->A + (size_t)i * nx, p->A + (size_t)(i + 1) * nx, Gt.begin() + (size_t)i * nx); chol_apply(L, nx, &Gt[(size_t)i * nx]); }
+            W.assign((size_t)nc * nc, 0.0);
+            for (int i = 0; i < nc; ++i) for (int j = 0; j <= i; ++j) {
+                double s = 0; for (int l = 0; l < nx; ++l) s += p->A[(size_t)i * nx + l] * Gt[(size_t)j * nx + l];
+                W[(size_t)i * nc + j] = s; W[(size_t)j * nc + i] = s;
+            }
+            // columns of [c | H] through Q^-1
+            std::vector<double> QiCH((size_t)nx * nr), col(nx);
+            for (int t = 0; t < nr; ++t) {
+                for (int i = 0; i < nx; ++i) col[i] = t == 0 ? p->c[i] : p->H[(size_t)i * nt + t - 1];
+                chol_apply(L, nx, col.data());
+                for (int i = 0; i < nx; ++i) QiCH[(size_t)i * nr + t] = col[i];
+            }
+            X0H.assign((size_t)nx * nr, 0.0);
+            for (size_t i = 0; i < X0H.size(); ++i) X0H[i] = -QiCH[i];
+            UV.assign((size_t)nc * nr, 0.0);
+            for (int i = 0; i < nc; ++i) for (int t = 0; t < nr; ++t) {
+                double s = 0; for (int l = 0; l < nx; ++l) s += p->A[(size_t)i * nx + l] * QiCH[(size_t)l * nr + t];
+                UV[(size_t)i * nr + t] = s + (t == 0 ? p->b[i] : p->F[(size_t)i * nt + t - 1]);
+            }
+        }
+    }
+    h->kkt_mode = mode;
+    const int cols = 1 + nx + nt, rows_x = nc + ntc;
+    std::vector<double> base((size_t)rows_x * cols, 0.0);
+    for (int i = 0; i < nc; ++i) {
+        base[(size_t)i * cols] = p->b[i];
+        for (int j = 0; j < nx; ++j) base[(size_t)i * cols + 1 + j] = p->A[(size_t)i * nx + j];
+        for (int j = 0; j < nt; ++j) base[(size_t)i * cols + 1 + nx + j] = -p->F[(size_t)i * nt + j];
+    }
+    for (int i = 0; i < ntc; ++i) {
+        base[(size_t)(nc + i) * cols] = p->b_t[i];
+        for (int j = 0; j < nt; ++j) base[(size_t)(nc + i) * cols + 1 + nx + j] = p->A_t[(size_t)i * nt + j];
+    }
+    // ---- one device allocation for every read-only block -------------------------------------------------
+    std::vector<double> host;
+    auto put = [&](const double *src, size_t cnt) { size_t off = host.size(); host.insert(host.end(), src, src + cnt); while (host.size() % 2) host.push_back(0.0); return off; };
+    std::vector<double> zeros((size_t)std::max(nx * nx, 1), 0.0);
+    const size_t oA = put(p->A, (size_t)nc * nx), ob = put(p->b, nc), oF = put(p->F, (size_t)nc * nt), oc = put(p->c, nx), oH = put(p->H, (size_t)nx * nt);
+    const size_t oQ = put(p->Q ? p->Q : zeros.data(), (size_t)nx * nx);
+    const size_t oAt = put(ntc ? p->A_t : zeros.data(), (size_t)std::max(ntc * nt, 1)), obt = put(ntc ? p->b_t : zeros.data(), std::max(ntc, 1));
+    const size_t oW = put(mode == 0 ? W.data() : zeros.data(), mode == 0 ? W.size() : 1), oUV = put(mode == 0 ? UV.data() : zeros.data(), mode == 0 ? UV.size() : 1);
+    const size_t oGt = put(mode == 0 ? Gt.data() : zeros.data(), mode == 0 ? Gt.size() : 1), oX0H = put(mode == 0 ? X0H.data() : zeros.data(), mode == 0 ? X0H.size() : 1);
+    const size_t obase = put(base.data(), base.size());
+    HIP_TRY(nullptr, h->blocks.ensure(host.size() * sizeof(double), h->stream));
+    HIP_TRY(nullptr, hipMemcpyAsync(h->blocks.p, host.data(), host.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(nullptr, hipStreamSynchronize(h->stream));
+    const double *d = h->blocks.as<double>();
+    DevProblem P{};
+    P.n_x = nx; P.n_t = nt; P.n_c = nc; P.n_eq = ne; P.n_tc = ntc; P.is_qp = h->is_qp; P.kkt_mode = mode;
+    P.A = d + oA; P.b = d + ob; P.F = d + oF; P.c = d + oc; P.H = d + oH; P.Q = d + oQ; P.A_t = d + oAt; P.b_t = d + obt;
+    P.W = d + oW; P.UV = d + oUV; P.Gt = d + oGt; P.X0H = d + oX0H; P.base = d + obase;
+    // ---- LDS layouts ---------------------------------------------------------------------------------------
+    const int kmax = std::min(nc, nx);
+    const int rows_t = nc - ne + ntc;
+    P.kmax = kmax;
+    P.ld_x = odd_at_least(nx + nt + 3);
+    P.ld_t = odd_at_least(nt + 4);
+    const int size_K = mode == 0 ? kmax * kmax + kmax : std::max({(nx + kmax) * (nx + kmax) + (nx + kmax) * nr, kmax * nx, nx * nx});
+    const int size_L = std::max(kmax * nr, 1), size_X = nx * nr;
+    const int T_v = std::max((rows_x + 1) * P.ld_x, (rows_t + 1) * P.ld_t);
+    const int T_r = std::max((rows_t + 2) * P.ld_t, rows_t * nr);
+    const Layout lv = make_layout(T_v, size_K, size_L, 0, mode == 1 ? size_X : 0, kmax, nc, std::max(P.ld_x, P.ld_t), rows_x + 1, rows_t);
+    const Layout lr = make_layout(T_r, size_K, size_L, rows_t * nr, size_X, kmax, nc, P.ld_t, rows_t + 2, rows_t);
+    h->Pv = P; apply_layout(h->Pv, lv); h->lds_v = lv.bytes;
+    h->Pr = P; apply_layout(h->Pr, lr); h->lds_r = lr.bytes;
+    if (h->lds_v > 160 * 1024 || h->lds_r > 160 * 1024) { delete h; return fail(nullptr, MPC_ERR_INVALID, "problem does not fit the 160 KiB LDS of one CU"); }
+    if (h->lds_v > 48 * 1024) HIP_TRY(nullptr, hipFuncSetAttribute(reinterpret_cast<const void *>(k_verdict), hipFuncAttributeMaxDynamicSharedMemorySize, h->lds_v));
+    if (h->lds_r > 48 * 1024) HIP_TRY(nullptr, hipFuncSetAttribute(reinterpret_cast<const void *>(k_region), hipFuncAttributeMaxDynamicSharedMemorySize, h->lds_r));
+    h->grid_v = h->n_cu * waves_per_cu(h->lds_v);
+    h->grid_r = h->n_cu * waves_per_cu(h->lds_r);
+    h->rec_d = (long long)nx * nt + nx + (long long)nc * nt + nc + (long long)(nc + ntc) * nt + (nc + ntc);
+    h->rec_i = 5 + (long long)nc + ntc + nc + nc + nc;
+    HIP_TRY(nullptr, h->ctr.ensure(sizeof(LevelCounters), h->stream));
+    HIP_TRY(nullptr, h->scratch.ensure(256, h->stream));
+    *out = h;
+    return MPC_OK;
+}
+
+int mpc_destroy(mpc_handle *h) {
+    if (!h) return MPC_OK;
+    (void)hipSetDevice(h->device);
+    (void)hipStreamSynchronize(h->stream);
+    for (DevBuf *b : {&h->blocks, &h->frontier, &h->children, &h->status, &h->pruned, &h->pruned_new, &h->flag, &h->pos, &h->opt_list,
+                      &h->childmask, &h->count, &h->offset, &h->recd, &h->reci, &h->ctr, &h->scratch}) b->release();
+    for (auto &e : h->ev) if (e) (void)hipEventDestroy(e);
+    if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
+    delete h;
+    return MPC_OK;
+}
+
+int64_t mpc_region_doubles(const mpc_handle *h) { return h ? h->rec_d : 0; }
+int64_t mpc_region_ints(const mpc_handle *h) { return h ? h->rec_i : 0; }
+int32_t mpc_lds_bytes(const mpc_handle *h, int32_t which) { return !h ? 0 : (which == 0 ? h->lds_v : h->lds_r); }
+void *mpc_stream(const mpc_handle *h) { return h ? reinterpret_cast<void *>(h->stream) : nullptr; }
+
+// ---- frontier ----------------------------------------------------------------------------------------------
+static int frontier_reset(mpc_handle *h, long long n, int k) {
+    if (n < 0 || k < 0 || k > h->n_c) return fail(h, MPC_ERR_INVALID, "bad frontier shape");
+    if (n > 0x7fffffffLL / std::max(k + 1, 1)) return fail(h, MPC_ERR_INVALID, "frontier too large for 32-bit offsets");
+    HIP_TRY(h, hipSetDevice(h->device));
+    HIP_TRY(h, h->frontier.ensure((size_t)std::max<long long>(n, 1) * std::max(k, 1) * sizeof(int32_t), h->stream));
+    h->n = n; h->k = k; h->level_done = false;
+    return MPC_OK;
+}
+
+int mpc_frontier_root(mpc_handle *h) {
+    if (!h) return MPC_ERR_INVALID;
+    const int cnt = h->n_c - h->n_eq;
+    int rc = frontier_reset(h, cnt, h->n_eq + 1);
+    if (rc) return rc;
+    if (cnt > 0) hipLaunchKernelGGL(k_root_frontier, dim3((cnt + 63) / 64), dim3(64), 0, h->stream, h->n_eq, h->n_c, h->frontier.as<int32_t>());
+    HIP_TRY(h, hipGetLastError());
+    return MPC_OK;
+}
+
+int mpc_frontier_set(mpc_handle *h, const int32_t *cand, int64_t n, int32_t k) {
+    if (!h || (!cand && n > 0 && k > 0)) return MPC_ERR_INVALID;
+    int rc = frontier_reset(h, n, k);
+    if (rc) return rc;
+    if (n > 0 && k > 0) {
+        HIP_TRY(h, hipMemcpyAsync(h->frontier.p, cand, (size_t)n * k * sizeof(int32_t), hipMemcpyHostToDevice, h->stream));
+        HIP_TRY(h, hipStreamSynchronize(h->stream));
+    }
+    return MPC_OK;
+}
+
+int mpc_frontier_set_device(mpc_handle *h, const int32_t *cand, int64_t n, int32_t k) {
+    if (!h || (!cand && n > 0 && k > 0)) return MPC_ERR_INVALID;
+    int rc = frontier_reset(h, n, k);
+    if (rc) return rc;
+    if (n > 0 && k > 0) HIP_TRY(h, hipMemcpyAsync(h->frontier.p, cand, (size_t)n * k * sizeof(int32_t), hipMemcpyDeviceToDevice, h->stream));
+    return MPC_OK;
+}
+
+int mpc_frontier_info(const mpc_handle *h, int64_t *n, int32_t *k) {
+    if (!h) return MPC_ERR_INVALID;
+    if (n) *n = h->n;
+    if (k) *k = h->k;
+    return MPC_OK;
+}
+
+int mpc_frontier_get(mpc_handle *h, int32_t *cand, int64_t cap) {
+    if (!h || !cand) return MPC_ERR_INVALID;
+    if (cap < h->n) return fail(h, MPC_ERR_CAPACITY, "frontier buffer too small");
+    HIP_TRY(h, hipSetDevice(h->device));
+    if (h->n > 0 && h->k > 0) {
+        HIP_TRY(h, hipMemcpyAsync(cand, h->frontier.p, (size_t)h->n * h->k * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(h, hipStreamSynchronize(h->stream));
+    }
+    return MPC_OK;
+}
+
+int mpc_pruned_clear(mpc_handle *h) { if (!h) return MPC_ERR_INVALID; h->n_pruned = 0; return MPC_OK; }
+
+static int pruned_add(mpc_handle *h, const uint64_t *masks, int64_t m, hipMemcpyKind kind) {
+    if (!h || (m > 0 && !masks) || m < 0) return MPC_ERR_INVALID;
+    if (m == 0) return MPC_OK;
+    HIP_TRY(h, hipSetDevice(h->device));
+    HIP_TRY(h, h->pruned.ensure((size_t)(h->n_pruned + m) * MPC_MASK_WORDS * sizeof(uint64_t), h->stream, true));
+    HIP_TRY(h, hipMemcpyAsync(h->pruned.as<uint64_t>() + (size_t)h->n_pruned * MPC_MASK_WORDS, masks, (size_t)m * MPC_MASK_WORDS * sizeof(uint64_t), kind, h->stream));
+    if (kind == hipMemcpyHostToDevice) HIP_TRY(h, hipStreamSynchronize(h->stream));
+    h->n_pruned += m;
+    return MPC_OK;
+}
+int mpc_pruned_add(mpc_handle *h, const uint64_t *masks, int64_t m) { return pruned_add(h, masks, m, hipMemcpyHostToDevice); }
+int mpc_pruned_add_device(mpc_handle *h, const uint64_t *masks, int64_t m) { return pruned_add(h, masks, m, hipMemcpyDeviceToDevice); }
+int64_t mpc_pruned_count(const mpc_handle *h) { return h ? h->n_pruned : 0; }
+int mpc_pruned_get(mpc_handle *h, uint64_t *masks, int64_t cap) {
+    if (!h || !masks) return MPC_ERR_INVALID;
+    if (cap < h->n_pruned) return fail(h, MPC_ERR_CAPACITY, "pruned buffer too small");
+    if (h->n_pruned > 0) {
+        HIP_TRY(h, hipSetDevice(h->device));
+        HIP_TRY(h, hipMemcpyAsync(masks, h->pruned.p, (size_t)h->n_pruned * MPC_MASK_WORDS * sizeof(uint64_t), hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(h, hipStreamSynchronize(h->stream));
+    }
+    return MPC_OK;
+}
+
+// ---- one level ------------------------------------------------------------------------------------------------
+int mpc_level_run(mpc_handle *h, int32_t gen_children, mpc_level_stats *stats) {
+    if (!h) return MPC_ERR_INVALID;
+    HIP_TRY(h, hipSetDevice(h->device));
+    const long long n = h->n;
+    const int k = h->k;
+    hipStream_t st = h->stream;
+    h->n_opt = h->n_children = h->n_pruned_new = h->n_regions = 0;
+    LevelCounters host_ctr;
+    std::memset(&host_ctr, 0, sizeof(host_ctr));
+    float ms[3] = {0, 0, 0};
+    if (n > 0) {
+        const size_t nn = (size_t)n;
+        HIP_TRY(h, h->status.ensure(nn, st));
+        HIP_TRY(h, h->flag.ensure(nn * sizeof(int32_t), st));
+        HIP_TRY(h, h->pos.ensure(nn * sizeof(int32_t), st));
+        HIP_TRY(h, h->opt_list.ensure(nn * sizeof(int32_t), st));
+        HIP_TRY(h, h->pruned_new.ensure(nn * MPC_MASK_WORDS * sizeof(uint64_t), st));
+        HIP_TRY(h, hipMemsetAsync(h->ctr.p, 0, sizeof(LevelCounters), st));
+        LevelCounters *ctr = h->ctr.as<LevelCounters>();
+        int32_t *total = h->scratch.as<int32_t>();
+        const int blocks256 = (int)((n + 255) / 256);
+        // verdict
+        HIP_TRY(h, hipEventRecord(h->ev[0], st));
+        hipLaunchKernelGGL(k_verdict, dim3((unsigned)std::min<long long>(n, h->grid_v)), dim3(64), h->lds_v, st, h->Pv,
+                           h->frontier.as<int32_t>(), n, k, h->status.as<uint8_t>(), ctr);
+        HIP_TRY(h, hipGetLastError());
+        HIP_TRY(h, hipEventRecord(h->ev[1], st));
+        // optimal candidates -> region kernel
+        hipLaunchKernelGGL(k_flag_status, dim3(blocks256), dim3(256), 0, st, h->status.as<uint8_t>(), n, ST_OPT_PENDING, h->flag.as<int32_t>());
+        hipLaunchKernelGGL(k_scan_exclusive, dim3(1), dim3(1024), 0, st, h->flag.as<int32_t>(), h->pos.as<int32_t>(), n, total);
+        hipLaunchKernelGGL(k_scatter_index, dim3(blocks256), dim3(256), 0, st, h->flag.as<int32_t>(), h->pos.as<int32_t>(), n, h->opt_list.as<int32_t>());
+        HIP_TRY(h, hipGetLastError());
+        int32_t n_opt = 0;
+        HIP_TRY(h, hipMemcpyAsync(&n_opt, total, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+        HIP_TRY(h, hipStreamSynchronize(st));
+        h->n_opt = n_opt;
+        if (n_opt > 0) {
+            HIP_TRY(h, h->recd.ensure((size_t)n_opt * h->rec_d * sizeof(double), st));
+            HIP_TRY(h, h->reci.ensure((size_t)n_opt * h->rec_i * sizeof(int32_t), st));
+            hipLaunchKernelGGL(k_region, dim3((unsigned)std::min<long long>(n_opt, h->grid_r)), dim3(64), h->lds_r, st, h->Pr,
+                               h->frontier.as<int32_t>(), k, h->opt_list.as<int32_t>(), n_opt, h->status.as<uint8_t>(),
+                               h->recd.as<double>(), h->reci.as<int32_t>(), h->rec_d, h->rec_i, ctr);
+            HIP_TRY(h, hipGetLastError());
+        }
+        HIP_TRY(h, hipEventRecord(h->ev[2], st));
+        // pruned masks of this level + children
+        hipLaunchKernelGGL(k_pruned_append, dim3(blocks256), dim3(256), 0, st, h->frontier.as<int32_t>(), n, k, h->status.as<uint8_t>(),
+                           h->pruned_new.as<unsigned long long>(), ctr);
+        if (gen_children) {
+            HIP_TRY(h, h->childmask.ensure(nn * 2 * sizeof(uint64_t), st));
+            HIP_TRY(h, h->count.ensure(nn * sizeof(int32_t), st));
+            HIP_TRY(h, h->offset.ensure(nn * sizeof(int32_t), st));
+            hipLaunchKernelGGL(k_children_count, dim3((unsigned)n), dim3(64), 0, st, h->Pv, h->frontier.as<int32_t>(), n, k, h->status.as<uint8_t>(),
+                               h->pruned.as<unsigned long long>(), (long long)h->n_pruned, h->childmask.as<unsigned long long>(), h->count.as<int32_t>());
+            hipLaunchKernelGGL(k_scan_exclusive, dim3(1), dim3(1024), 0, st, h->count.as<int32_t>(), h->offset.as<int32_t>(), n, total);
+            HIP_TRY(h, hipGetLastError());
+            int32_t n_children = 0;
+            HIP_TRY(h, hipMemcpyAsync(&n_children, total, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+            HIP_TRY(h, hipStreamSynchronize(st));
+            h->n_children = n_children;
+            if (n_children > 0) {
+                HIP_TRY(h, h->children.ensure((size_t)n_children * (k + 1) * sizeof(int32_t), st));
+                hipLaunchKernelGGL(k_children_write, dim3((unsigned)n), dim3(64), 0, st, h->frontier.as<int32_t>(), n, k,
+                                   h->childmask.as<unsigned long long>(), h->offset.as<int32_t>(), h->children.as<int32_t>());
+                HIP_TRY(h, hipGetLastError());
+            }
+        }
+        hipLaunchKernelGGL(k_histogram, dim3(std::min(blocks256, 1024)), dim3(256), 0, st, h->status.as<uint8_t>(), n, ctr);
+        HIP_TRY(h, hipGetLastError());
+        HIP_TRY(h, hipEventRecord(h->ev[3], st));
+        HIP_TRY(h, hipMemcpyAsync(&host_ctr, ctr, sizeof(LevelCounters), hipMemcpyDeviceToHost, st));
+        HIP_TRY(h, hipStreamSynchronize(st));
+        HIP_TRY(h, hipEventElapsedTime(&ms[0], h->ev[0], h->ev[1]));
+        HIP_TRY(h, hipEventElapsedTime(&ms[1], h->ev[1], h->ev[2]));
+        HIP_TRY(h, hipEventElapsedTime(&ms[2], h->ev[2], h->ev[3]));
+        h->n_pruned_new = host_ctr.n_pruned_new;
+        h->n_regions = (long long)host_ctr.status[ST_REGION];
+    }
+    h->level_done = true;
+    if (stats) {
+        std::memset(stats, 0, sizeof(*stats));
+        stats->n = n; stats->k = k; stats->kkt_mode = h->kkt_mode;
+        for (int i = 0; i < 6; ++i) stats->n_status[i] = (int64_t)host_ctr.status[i];
+        stats->n_regions = h->n_regions; stats->n_children = h->n_children; stats->n_pruned_new = h->n_pruned_new;
+        stats->lp_pivots = (int64_t)host_ctr.pivots;
+        stats->ms_verdict = ms[0]; stats->ms_region = ms[1]; stats->ms_children = ms[2]; stats->ms_total = ms[0] + ms[1] + ms[2];
+    }
+    return MPC_OK;
+}
+
+int mpc_level_status(mpc_handle *h, uint8_t *status) {
+    if (!h || !status) return MPC_ERR_INVALID;
+    if (!h->level_done) return fail(h, MPC_ERR_STATE, "mpc_level_run has not been called for this frontier");
+    if (h->n > 0) {
+        HIP_TRY(h, hipSetDevice(h->device));
+        HIP_TRY(h, hipMemcpyAsync(status, h->status.p, (size_t)h->n, hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(h, hipStreamSynchronize(h->stream));
+    }
+    return MPC_OK;
+}
+
+int mpc_level_regions(mpc_handle *h, double *rec_d, int32_t *rec_i, int64_t *cand_index, int64_t cap) {
+    if (!h) return MPC_ERR_INVALID;
+    if (!h->level_done) return fail(h, MPC_ERR_STATE, "mpc_level_run has not been called for this frontier");
+    if (cap < h->n_regions) return fail(h, MPC_ERR_CAPACITY, "region buffer too small");
+    if (h->n_regions == 0) return MPC_OK;
+    if (!rec_d || !rec_i) return MPC_ERR_INVALID;
+    HIP_TRY(h, hipSetDevice(h->device));
+    // records were written per OPTIMAL candidate (frontier order); keep those whose final status is REGION
+    std::vector<double> d((size_t)h->n_opt * h->rec_d);
+    std::vector<int32_t> ii((size_t)h->n_opt * h->rec_i), list((size_t)h->n_opt);
+    std::vector<uint8_t> st((size_t)h->n);
+    HIP_TRY(h, hipMemcpyAsync(d.data(), h->recd.p, d.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(ii.data(), h->reci.p, ii.size() * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(list.data(), h->opt_list.p, list.size() * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(st.data(), h->status.p, st.size(), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    long long w = 0;
+    for (long long i = 0; i < h->n_opt; ++i) {
+        if (st[list[i]] != ST_REGION) continue;
+        std::memcpy(rec_d + w * h->rec_d, d.data() + i * h->rec_d, h->rec_d * sizeof(double));
+        std::memcpy(rec_i + w * h->rec_i, ii.data() + i * h->rec_i, h->rec_i * sizeof(int32_t));
+        if (cand_index) cand_index[w] = list[i];
+        ++w;
+    }
+    return MPC_OK;
+}
+
+static int copy_out(mpc_handle *h, void *dst, const void *src, size_t bytes, hipMemcpyKind kind) {
+    if (bytes == 0) return MPC_OK;
+    HIP_TRY(h, hipSetDevice(h->device));
+    HIP_TRY(h, hipMemcpyAsync(dst, src, bytes, kind, h->stream));
+    if (kind == hipMemcpyDeviceToHost) HIP_TRY(h, hipStreamSynchronize(h->stream));
+    return MPC_OK;
+}
+
+int mpc_level_children(mpc_handle *h, int32_t *out, int64_t cap) {
+    if (!h || (!out && cap > 0)) return MPC_ERR_INVALID;
+    if (!h->level_done) return fail(h, MPC_ERR_STATE, "mpc_level_run has not been called for this frontier");
+    if (cap < h->n_children) return fail(h, MPC_ERR_CAPACITY, "children buffer too small");
+    return copy_out(h, out, h->children.p, (size_t)h->n_children * (h->k + 1) * sizeof(int32_t), hipMemcpyDeviceToHost);
+}
+int mpc_level_children_device(mpc_handle *h, int32_t *out, int64_t cap) {
+    if (!h || (!out && cap > 0)) return MPC_ERR_INVALID;
+    if (!h->level_done) return fail(h, MPC_ERR_STATE, "mpc_level_run has not been called for this frontier");
+    if (cap < h->n_children) return fail(h, MPC_ERR_CAPACITY, "children buffer too small");
+    return copy_out(h, out, h->children.p, (size_t)h->n_children * (h->k + 1) * sizeof(int32_t), hipMemcpyDeviceToDevice);
+}
+int mpc_level_pruned_new(mpc_handle *h, uint64_t *out, int64_t cap) {
+    if (!h || (!out && cap > 0)) return MPC_ERR_INVALID;
+    if (!h->level_done) return fail(h, MPC_ERR_STATE, "mpc_level_run has not been called for this frontier");
+    if (cap < h->n_pruned_new) return fail(h, MPC_ERR_CAPACITY, "pruned buffer too small");
+    return copy_out(h, out, h->pruned_new.p, (size_t)h->n_pruned_new * MPC_MASK_WORDS * sizeof(uint64_t), hipMemcpyDeviceToHost);
+}
+int mpc_level_pruned_new_device(mpc_handle *h, uint64_t *out, int64_t cap) {
+    if (!h || (!out && cap > 0)) return MPC_ERR_INVALID;
+    if (!h->level_done) return fail(h, MPC_ERR_STATE, "mpc_level_run has not been called for this frontier");
+    if (cap < h->n_pruned_new) return fail(h, MPC_ERR_CAPACITY, "pruned buffer too small");
+    return copy_out(h, out, h->pruned_new.p, (size_t)h->n_pruned_new * MPC_MASK_WORDS * sizeof(uint64_t), hipMemcpyDeviceToDevice);
+}
+
+int mpc_frontier_advance(mpc_handle *h) {
+    if (!h) return MPC_ERR_INVALID;
+    if (!h->level_done) return fail(h, MPC_ERR_STATE, "mpc_level_run has not been called for this frontier");
+    if (h->n_pruned_new > 0) {
+        int rc = pruned_add(h, h->pruned_new.as<uint64_t>(), h->n_pruned_new, hipMemcpyDeviceToDevice);
+        if (rc) return rc;
+    }
+    std::swap(h->frontier, h->children);
+    h->n = h->n_children;
+    h->k = h->k + 1;
+    h->level_done = false;
+    h->n_children = 0; h->n_pruned_new = 0; h->n_regions = 0; h->n_opt = 0;
+    return MPC_OK;
+}
+
+int mpc_check_level(mpc_handle *h, const int32_t *cand, int64_t n, int32_t k, const uint64_t *pruned_masks, int64_t m,
+                    int32_t gen_children, uint8_t *status, int64_t *n_regions, double *rec_d, int32_t *rec_i,
+                    int64_t *region_cand, int64_t region_cap, int64_t *n_children, int32_t *children, int64_t children_cap) {
+    if (!h) return MPC_ERR_INVALID;
+    int rc = mpc_frontier_set(h, cand, n, k);
+    if (rc) return rc;
+    mpc_pruned_clear(h);
+    rc = mpc_pruned_add(h, pruned_masks, m);
+    if (rc) return rc;
+    mpc_level_stats stats;
+    rc = mpc_level_run(h, gen_children, &stats);
+    if (rc) return rc;
+    if (status) { rc = mpc_level_status(h, status); if (rc) return rc; }
+    if (n_regions) *n_regions = stats.n_regions;
+    if (n_children) *n_children = stats.n_children;
+    if (stats.n_regions > region_cap || stats.n_children > children_cap) return fail(h, MPC_ERR_CAPACITY, "output buffers too small");
+    if (stats.n_regions > 0) { rc = mpc_level_regions(h, rec_d, rec_i, region_cand, region_cap); if (rc) return rc; }
+    if (stats.n_children > 0) { rc = mpc_level_children(h, children, children_cap); if (rc) return rc; }
+    return MPC_OK;
+}
+
+// ---- batched LPs ------------------------------------------------------------------------------------------------
+int mpc_lp_solve_batch(int32_t device, int64_t n_lp, int32_t m, int32_t n, const double *A, int32_t shared_A, const double *b,
+                       int32_t shared_b, const double *c, int32_t shared_c, const uint8_t *eq, int32_t *status, double *x,
+                       double *obj, int32_t *iters) {
+    if (n_lp < 0 || m < 1 || n < 1 || !A || !b || !eq || !status) return fail(nullptr, MPC_ERR_INVALID, "bad argument");
+    if (n_lp == 0) return MPC_OK;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return fail(nullptr, MPC_ERR_HIP, "no HIP device available (libmpcombi_hip has no CPU fallback)");
+    if (device < 0 || device >= ndev) return fail(nullptr, MPC_ERR_INVALID, "device index out of range");
+    HIP_TRY(nullptr, hipSetDevice(device));
+    const int ld = odd_at_least(n + 3);
+    const size_t lds = (((size_t)(m + 1) * ld * 8 + (size_t)(ld + 1 + 2 * (m + 2)) * 4) + 15) & ~size_t(15);
+    if (lds > 160 * 1024) return fail(nullptr, MPC_ERR_INVALID, "LP does not fit the 160 KiB LDS of one CU");
+    if (lds > 48 * 1024) HIP_TRY(nullptr, hipFuncSetAttribute(reinterpret_cast<const void *>(k_lp_batch), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipDeviceProp_t prop;
+    HIP_TRY(nullptr, hipGetDeviceProperties(&prop, device));
+    const size_t szA = (shared_A ? 1 : (size_t)n_lp) * m * n * 8, szb = (shared_b ? 1 : (size_t)n_lp) * m * 8;
+    const size_t szc = c ? (shared_c ? 1 : (size_t)n_lp) * n * 8 : 0, szeq = (size_t)n_lp * m;
+    double *dA = nullptr, *db = nullptr, *dc = nullptr, *dx = nullptr, *dobj = nullptr;
+    uint8_t *deq = nullptr;
+    int32_t *dst = nullptr, *dit = nullptr;
+    unsigned int *dwork = nullptr;
+    int rc = MPC_OK;
+    hipError_t e = hipSuccess;
+    auto chk = [&](hipError_t err) { if (e == hipSuccess && err != hipSuccess) e = err; return err == hipSuccess; };
+    chk(hipMalloc((void **)&dA, szA)); chk(hipMalloc((void **)&db, szb));
+    if (c) chk(hipMalloc((void **)&dc, szc));
+    chk(hipMalloc((void **)&deq, szeq)); chk(hipMalloc((void **)&dst, (size_t)n_lp * 4)); chk(hipMalloc((void **)&dit, (size_t)n_lp * 4));
+    chk(hipMalloc((void **)&dx, (size_t)n_lp * n * 8)); chk(hipMalloc((void **)&dobj, (size_t)n_lp * 8)); chk(hipMalloc((void **)&dwork, 4));
+    if (e == hipSuccess) {
+        chk(hipMemcpy(dA, A, szA, hipMemcpyHostToDevice)); chk(hipMemcpy(db, b, szb, hipMemcpyHostToDevice));
+        if (c) chk(hipMemcpy(dc, c, szc, hipMemcpyHostToDevice));
+        chk(hipMemcpy(deq, eq, szeq, hipMemcpyHostToDevice)); chk(hipMemset(dwork, 0, 4));
+    }
+    if (e == hipSuccess) {
+        const int grid = (int)std::min<long long>(n_lp, (long long)std::max(prop.multiProcessorCount, 1) * waves_per_cu((int)lds));
+        hipLaunchKernelGGL(k_lp_batch, dim3(grid), dim3(64), lds, 0, (long long)n_lp, m, n, ld, dA, shared_A, db, shared_b, dc, shared_c, deq, dst, dx, dobj, dit, dwork);
+        chk(hipGetLastError());
+        chk(hipDeviceSynchronize());
+        chk(hipMemcpy(status, dst, (size_t)n_lp * 4, hipMemcpyDeviceToHost));
+        if (x) chk(hipMemcpy(x, dx, (size_t)n_lp * n * 8, hipMemcpyDeviceToHost));
+        if (obj) chk(hipMemcpy(obj, dobj, (size_t)n_lp * 8, hipMemcpyDeviceToHost));
+        if (iters) chk(hipMemcpy(iters, dit, (size_t)n_lp * 4, hipMemcpyDeviceToHost));
+    }
+    if (e != hipSuccess) rc = fail(nullptr, MPC_ERR_HIP, std::string("mpc_lp_solve_batch: ") + hipGetErrorString(e));
+    for (void *q : {(void *)dA, (void *)db, (void *)dc, (void *)deq, (void *)dst, (void *)dit, (void *)dx, (void *)dobj, (void *)dwork}) if (q) (void)hipFree(q);
+    return rc;
+}
+
+}  // extern "C"
