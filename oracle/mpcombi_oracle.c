@@ -30,12 +30,17 @@
  *   phase 2  primal simplex on the real objective
  * Tolerances mirror the 1e-7 primal feasibility tolerance of GLPK/HiGHS on rows scaled to O(1).
  * ---------------------------------------------------------------------------------------------- */
-#define TOL_FEAS 1e-7
+static double g_tol_feas = 1e-7; /* primal feasibility tolerance; orc_set_feas_tol() changes it for the
+                                    * knife-edge classification in the tests (decisions that flip with it) */
+#define TOL_FEAS g_tol_feas
 #define TOL_PIV 1e-9
 #define TOL_COST 1e-9
+#define HARRIS_DELTA 1e-9
 #define DEG_SWITCH 12
+#define GROWTH_SAFE 1e3   /* largest tolerated |column max / pivot| before the basis is refactored */
+#define MAX_REFACTOR 2
 
-enum { RK_INEQ = 0, RK_EQ = 1, RK_FREE = 2, RK_DEAD = 3, RK_X0 = 4 };
+enum { RK_INEQ = 0, RK_EQ = 1, RK_FREE = 2, RK_DEAD = 3, RK_X0 = 4, RK_PRI = 5 };
 
 typedef struct {
     int m, n, ld, na;
@@ -44,7 +49,8 @@ typedef struct {
     int *rowvar;
     unsigned char *rowkind;
     unsigned char *is_eq;
-    int iters;
+    int iters, max_iter;
+    double growth; /* max over ratio-test pivots of (largest |entry| of the pivot column) / |pivot| */
 } lp_t;
 
 #define TT(lp, i, j) ((lp)->T[(size_t)(i) * (lp)->ld + (j)])
@@ -80,12 +86,14 @@ static void lp_drop_col(lp_t *lp, int q) {
 
 /* primal simplex iterations on cost row `crow` (== m for the real objective, or the x0 row in phase 1,
  * where the "reduced cost" of column j is -T[crow][j]).  Returns 0 optimal, 2 unbounded, 3 limit,
- * 4 (phase 1 only) x0 left the basis. */
-static int lp_primal(lp_t *lp, int phase1_row, int max_iter) {
+ * 4 (phase 1 only) x0 left the basis.
+ * Ratio test: Harris two-pass (pass 1 bounds the step with beta + HARRIS_DELTA, pass 2 takes the largest pivot
+ * among the rows whose own ratio does not exceed that bound); textbook rule with Bland's tie-break while stalled. */
+static int lp_primal(lp_t *lp, int phase1_row) {
     const int m = lp->m;
     int deg = 0;
     for (;;) {
-        if (lp->iters > max_iter) return 3;
+        if (lp->iters > lp->max_iter) return 3;
         const int bland = deg > DEG_SWITCH;
         const int crow = phase1_row >= 0 ? phase1_row : m;
         const double sgn = phase1_row >= 0 ? -1.0 : 1.0;
@@ -104,6 +112,20 @@ static int lp_primal(lp_t *lp, int phase1_row, int max_iter) {
         }
         if (q < 0) return 0;
         /* ratio test */
+        double colmax = 0.0, tmax = 0.0;
+        int any = 0;
+        for (int i = 0; i < m; ++i) {
+            const int kind = lp->rowkind[i];
+            if (kind == RK_DEAD) continue;
+            const double a = TT(lp, i, q);
+            if (fabs(a) > colmax) colmax = fabs(a);
+            if ((kind != RK_INEQ && kind != RK_X0) || a <= TOL_PIV) continue;
+            double beta = TT(lp, i, 0);
+            if (beta < 0.0) beta = 0.0;
+            const double t = (beta + HARRIS_DELTA) / a;
+            if (!any || t < tmax) { tmax = t; any = 1; }
+        }
+        if (!any) return 2;
         int r = -1;
         double rmin = 0.0, rpiv = 0.0;
         for (int i = 0; i < m; ++i) {
@@ -115,16 +137,24 @@ static int lp_primal(lp_t *lp, int phase1_row, int max_iter) {
             if (beta < 0.0) beta = 0.0;
             const double ratio = beta / a;
             int take = 0;
-            if (r < 0 || ratio < rmin) take = 1;
-            else if (ratio == rmin) {
-                if (kind == RK_X0) take = 1;
+            if (bland) {
+                if (r < 0 || ratio < rmin) take = 1;
+                else if (ratio == rmin) {
+                    if (kind == RK_X0) take = 1;
+                    else if (lp->rowkind[r] == RK_X0) take = 0;
+                    else take = lp->rowvar[i] < lp->rowvar[r];
+                }
+            } else {
+                if (ratio > tmax) continue;
+                if (r < 0) take = 1;
+                else if (kind == RK_X0) take = 1;
                 else if (lp->rowkind[r] == RK_X0) take = 0;
-                else if (bland) take = lp->rowvar[i] < lp->rowvar[r];
                 else take = a > rpiv;
             }
             if (take) { r = i; rmin = ratio; rpiv = a; }
         }
         if (r < 0) return 2;
+        if (colmax / rpiv > lp->growth) lp->growth = colmax / rpiv;
         deg = (rmin <= 0.0) ? deg + 1 : 0;
         const int leaving_x0 = lp->rowkind[r] == RK_X0;
         lp_pivot(lp, r, q);
@@ -136,116 +166,145 @@ static int lp_primal(lp_t *lp, int phase1_row, int max_iter) {
     }
 }
 
+static int lp_best_row(const lp_t *lp, int q, int kind) {
+    int r = -1; double best = TOL_PIV;
+    for (int i = 0; i < lp->m; ++i)
+        if (lp->rowkind[i] == kind) { const double a = fabs(TT(lp, i, q)); if (a > best) { best = a; r = i; } }
+    return r;
+}
+
+/* one pass: stage A, stage B, phase 1, phase 2 on the tableau as loaded */
+static int lp_run(lp_t *lp, int has_cost) {
+    const int m = lp->m, n = lp->n;
+    int unbounded_if_feasible = 0;
+    /* stage A: structural (free) variables enter the basis */
+    for (int v = 0; v < n; ++v) {
+        int q = -1;
+        for (int j = 1; j <= lp->na; ++j) if (lp->colvar[j] == v) { q = j; break; }
+        int r = lp_best_row(lp, q, RK_EQ);
+        const int was_eq = r >= 0;
+        if (r < 0) r = lp_best_row(lp, q, RK_PRI);
+        if (r < 0) r = lp_best_row(lp, q, RK_INEQ);
+        if (r < 0) { /* variable does not appear in any usable row */
+            if (has_cost && fabs(TT(lp, m, q)) > TOL_COST) unbounded_if_feasible = 1;
+            lp_drop_col(lp, q);
+            continue;
+        }
+        lp_pivot(lp, r, q);
+        lp->rowkind[r] = RK_FREE;
+        if (was_eq) lp_drop_col(lp, q);
+    }
+    for (int i = 0; i < m; ++i) if (lp->rowkind[i] == RK_PRI) lp->rowkind[i] = RK_INEQ;
+    /* stage B: remaining equality rows leave the basis */
+    for (int i = 0; i < m; ++i) {
+        if (lp->rowkind[i] != RK_EQ) continue;
+        int q = -1; double best = TOL_PIV;
+        for (int j = 1; j <= lp->na; ++j) { const double a = fabs(TT(lp, i, j)); if (a > best) { best = a; q = j; } }
+        if (q < 0) {
+            if (fabs(TT(lp, i, 0)) > TOL_FEAS) return ORC_LP_INFEASIBLE;
+            lp->rowkind[i] = RK_DEAD;
+            continue;
+        }
+        lp_pivot(lp, i, q);
+        lp->rowkind[i] = RK_INEQ;
+        lp_drop_col(lp, q);
+    }
+    /* phase 1 */
+    {
+        int r = -1; double mn = -TOL_FEAS;
+        for (int i = 0; i < m; ++i)
+            if (lp->rowkind[i] == RK_INEQ && TT(lp, i, 0) < mn) { mn = TT(lp, i, 0); r = i; }
+        if (r >= 0) {
+            const int q = ++lp->na;
+            lp->colvar[q] = n + m;
+            for (int i = 0; i <= m; ++i) TT(lp, i, q) = (i < m && lp->rowkind[i] == RK_INEQ) ? -1.0 : 0.0;
+            lp_pivot(lp, r, q);
+            lp->rowkind[r] = RK_X0;
+            const int st = lp_primal(lp, r);
+            if (st == 3) return ORC_LP_ITERLIMIT;
+            if (st != 4) {
+                /* x0 still basic */
+                if (TT(lp, r, 0) > TOL_FEAS) return ORC_LP_INFEASIBLE;
+                int qq = -1; double best = TOL_PIV;
+                for (int j = 1; j <= lp->na; ++j) { const double a = fabs(TT(lp, r, j)); if (a > best) { best = a; qq = j; } }
+                if (qq < 0) lp->rowkind[r] = RK_DEAD;
+                else { lp_pivot(lp, r, qq); lp->rowkind[r] = RK_INEQ; lp_drop_col(lp, qq); }
+            }
+        }
+    }
+    /* phase 2 */
+    if (has_cost) {
+        if (unbounded_if_feasible) return ORC_LP_UNBOUNDED;
+        const int st = lp_primal(lp, -1);
+        if (st == 2) return ORC_LP_UNBOUNDED;
+        if (st == 3) return ORC_LP_ITERLIMIT;
+    }
+    return ORC_LP_OPTIMAL;
+}
+
+/* (re)load the tableau from the problem data: power-of-two row scaling, zero rows, bookkeeping.
+ * pri[i] != 0 marks an inequality row whose slack should be made nonbasic by stage A (basis refactorisation). */
+static int lp_load(lp_t *lp, const double *A, const double *b, const double *c, const unsigned char *pri) {
+    const int m = lp->m, n = lp->n;
+    int consistent = 1;
+    memset(lp->T, 0, sizeof(double) * (size_t)(m + 1) * lp->ld);
+    for (int j = 1; j <= n; ++j) lp->colvar[j] = j - 1;
+    lp->na = n;
+    lp->growth = 0.0;
+    for (int i = 0; i < m; ++i) {
+        double mx = 0.0;
+        for (int j = 0; j < n; ++j) { const double a = fabs(A[(size_t)i * n + j]); if (a > mx) mx = a; }
+        lp->rowvar[i] = n + i;
+        lp->rowkind[i] = lp->is_eq[i] ? RK_EQ : (pri && pri[i] ? RK_PRI : RK_INEQ);
+        if (!(mx > 0.0)) {
+            /* 0 <= b_i (or 0 == b_i) */
+            if (lp->is_eq[i] ? fabs(b[i]) > TOL_FEAS : b[i] < -TOL_FEAS) consistent = 0;
+            lp->rowkind[i] = RK_DEAD;
+            continue;
+        }
+        int e; frexp(mx, &e);
+        const double s = ldexp(1.0, -e);
+        TT(lp, i, 0) = b[i] * s;
+        for (int j = 0; j < n; ++j) TT(lp, i, j + 1) = A[(size_t)i * n + j] * s;
+    }
+    if (c) for (int j = 0; j < n; ++j) TT(lp, m, j + 1) = c[j];
+    return consistent;
+}
+
+void orc_set_feas_tol(double tol) { g_tol_feas = tol; }
+
 int orc_lp_solve(int m, int n, const double *A, const double *b, const double *c, int neq, const int32_t *eq,
                  double *x, double *obj, int32_t *iters) {
     lp_t lp;
     int status = ORC_LP_OPTIMAL;
-    int unbounded_if_feasible = 0;
     lp.m = m; lp.n = n; lp.ld = n + 3; lp.na = n; lp.iters = 0;
     lp.T = (double *)calloc((size_t)(m + 1) * lp.ld, sizeof(double));
     lp.colvar = (int *)calloc((size_t)n + 3, sizeof(int));
     lp.rowvar = (int *)calloc((size_t)m + 1, sizeof(int));
     lp.rowkind = (unsigned char *)calloc((size_t)m + 1, 1);
     lp.is_eq = (unsigned char *)calloc((size_t)m + 1, 1);
-    const int max_iter = 50 * (m + n) + 100;
+    unsigned char *pri = (unsigned char *)calloc((size_t)m + 1, 1);
+    lp.max_iter = 50 * (m + n) + 100;
     for (int i = 0; i < neq; ++i)
         if (eq[i] >= 0 && eq[i] < m) lp.is_eq[eq[i]] = 1;
-    for (int j = 1; j <= n; ++j) lp.colvar[j] = j - 1;
-    /* load + power-of-two row scaling */
-    for (int i = 0; i < m; ++i) {
-        double mx = 0.0;
-        for (int j = 0; j < n; ++j) { const double a = fabs(A[(size_t)i * n + j]); if (a > mx) mx = a; }
-        lp.rowvar[i] = n + i;
-        lp.rowkind[i] = lp.is_eq[i] ? RK_EQ : RK_INEQ;
-        if (!(mx > 0.0)) {
-            /* 0 <= b_i (or 0 == b_i) */
-            if (lp.is_eq[i] ? fabs(b[i]) > TOL_FEAS : b[i] < -TOL_FEAS) status = ORC_LP_INFEASIBLE;
-            lp.rowkind[i] = RK_DEAD;
-            continue;
-        }
-        int e; frexp(mx, &e);
-        const double s = ldexp(1.0, -e);
-        TT(&lp, i, 0) = b[i] * s;
-        for (int j = 0; j < n; ++j) TT(&lp, i, j + 1) = A[(size_t)i * n + j] * s;
+    for (int attempt = 0;; ++attempt) {
+        if (!lp_load(&lp, A, b, c, attempt ? pri : NULL)) { status = ORC_LP_INFEASIBLE; break; }
+        status = lp_run(&lp, c != NULL);
+        if (status == ORC_LP_ITERLIMIT || !(lp.growth > GROWTH_SAFE) || attempt >= MAX_REFACTOR) break;
+        /* numerically doubtful pivot sequence: rebuild the final basis from the original data and continue */
+        memset(pri, 0, (size_t)m + 1);
+        for (int j = 1; j <= lp.na; ++j) { const int v = lp.colvar[j]; if (v >= n && v < n + m) pri[v - n] = 1; }
     }
-    if (c) for (int j = 0; j < n; ++j) TT(&lp, m, j + 1) = c[j];
-    if (status != ORC_LP_OPTIMAL) goto done;
-
-    /* stage A: structural (free) variables enter the basis */
-    for (int v = 0; v < n; ++v) {
-        int q = -1;
-        for (int j = 1; j <= lp.na; ++j) if (lp.colvar[j] == v) { q = j; break; }
-        int r = -1; double best = TOL_PIV;
-        for (int i = 0; i < m; ++i)
-            if (lp.rowkind[i] == RK_EQ) { const double a = fabs(TT(&lp, i, q)); if (a > best) { best = a; r = i; } }
-        if (r < 0) {
-            best = TOL_PIV;
+    if (status == ORC_LP_OPTIMAL) {
+        if (x) {
+            for (int j = 0; j < n; ++j) x[j] = 0.0;
             for (int i = 0; i < m; ++i)
-                if (lp.rowkind[i] == RK_INEQ) { const double a = fabs(TT(&lp, i, q)); if (a > best) { best = a; r = i; } }
+                if (lp.rowkind[i] == RK_FREE) x[lp.rowvar[i]] = TT(&lp, i, 0);
         }
-        if (r < 0) { /* variable does not appear in any usable row */
-            if (fabs(TT(&lp, m, q)) > TOL_COST) unbounded_if_feasible = 1;
-            lp_drop_col(&lp, q);
-            continue;
-        }
-        const int was_eq = lp.rowkind[r] == RK_EQ;
-        lp_pivot(&lp, r, q);
-        lp.rowkind[r] = RK_FREE;
-        if (was_eq) lp_drop_col(&lp, q);
+        if (obj) *obj = -TT(&lp, m, 0);
     }
-    /* stage B: remaining equality rows leave the basis */
-    for (int i = 0; i < m; ++i) {
-        if (lp.rowkind[i] != RK_EQ) continue;
-        int q = -1; double best = TOL_PIV;
-        for (int j = 1; j <= lp.na; ++j) { const double a = fabs(TT(&lp, i, j)); if (a > best) { best = a; q = j; } }
-        if (q < 0) {
-            if (fabs(TT(&lp, i, 0)) > TOL_FEAS) { status = ORC_LP_INFEASIBLE; goto done; }
-            lp.rowkind[i] = RK_DEAD;
-            continue;
-        }
-        lp_pivot(&lp, i, q);
-        lp.rowkind[i] = RK_INEQ;
-        lp_drop_col(&lp, q);
-    }
-    /* phase 1 */
-    {
-        int r = -1; double mn = -TOL_FEAS;
-        for (int i = 0; i < m; ++i)
-            if (lp.rowkind[i] == RK_INEQ && TT(&lp, i, 0) < mn) { mn = TT(&lp, i, 0); r = i; }
-        if (r >= 0) {
-            const int q = ++lp.na;
-            lp.colvar[q] = n + m;
-            for (int i = 0; i <= m; ++i) TT(&lp, i, q) = (i < m && lp.rowkind[i] == RK_INEQ) ? -1.0 : 0.0;
-            lp_pivot(&lp, r, q);
-            lp.rowkind[r] = RK_X0;
-            const int st = lp_primal(&lp, r, max_iter);
-            if (st == 3) { status = ORC_LP_ITERLIMIT; goto done; }
-            if (st != 4) {
-                /* x0 still basic */
-                if (TT(&lp, r, 0) > TOL_FEAS) { status = ORC_LP_INFEASIBLE; goto done; }
-                int qq = -1; double best = TOL_PIV;
-                for (int j = 1; j <= lp.na; ++j) { const double a = fabs(TT(&lp, r, j)); if (a > best) { best = a; qq = j; } }
-                if (qq < 0) lp.rowkind[r] = RK_DEAD;
-                else { lp_pivot(&lp, r, qq); lp.rowkind[r] = RK_INEQ; lp_drop_col(&lp, qq); }
-            }
-        }
-    }
-    /* phase 2 */
-    if (c) {
-        if (unbounded_if_feasible) { status = ORC_LP_UNBOUNDED; goto done; }
-        const int st = lp_primal(&lp, -1, max_iter);
-        if (st == 2) { status = ORC_LP_UNBOUNDED; goto done; }
-        if (st == 3) { status = ORC_LP_ITERLIMIT; goto done; }
-    }
-    if (x) {
-        for (int j = 0; j < n; ++j) x[j] = 0.0;
-        for (int i = 0; i < m; ++i)
-            if (lp.rowkind[i] == RK_FREE) x[lp.rowvar[i]] = TT(&lp, i, 0);
-    }
-    if (obj) *obj = -TT(&lp, m, 0);
-done:
     if (iters) *iters = lp.iters;
-    free(lp.T); free(lp.colvar); free(lp.rowvar); free(lp.rowkind); free(lp.is_eq);
+    free(lp.T); free(lp.colvar); free(lp.rowvar); free(lp.rowkind); free(lp.is_eq); free(pri);
     return status;
 }
 

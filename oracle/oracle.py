@@ -47,6 +47,8 @@ def lib():
         L.orc_lp_solve.restype = ctypes.c_int
         L.orc_lp_solve.argtypes = [ctypes.c_int, ctypes.c_int, _c_double_p, _c_double_p, _c_double_p, ctypes.c_int,
                                    _c_int32_p, _c_double_p, _c_double_p, _c_int32_p]
+        L.orc_set_feas_tol.restype = None
+        L.orc_set_feas_tol.argtypes = [ctypes.c_double]
         L.orc_is_full_rank.restype = ctypes.c_int
         L.orc_is_full_rank.argtypes = [_c_double_p, ctypes.c_int, _c_int32_p, ctypes.c_int]
         L.orc_singular_values.restype = ctypes.c_int
@@ -101,6 +103,11 @@ def lp_solve(c, A, b, equality_constraints=None) -> Tuple[int, Optional[numpy.nd
         cp = _dp(cc)
     st = lib().orc_lp_solve(m, n, _dp(A), _dp(b), cp, len(eq), _ip(eq), _dp(x), ctypes.byref(obj), ctypes.byref(it))
     return st, (x if st == 0 else None), obj.value, it.value
+
+
+def set_feas_tol(tol: float = 1e-7):
+    """Primal feasibility tolerance of the oracle simplex (used to classify knife-edge decisions)."""
+    lib().orc_set_feas_tol(float(tol))
 
 
 def singular_values(M) -> numpy.ndarray:
@@ -197,6 +204,10 @@ class OracleProblem:
         return {'A': A_x.copy(), 'b': b_x.copy().reshape(-1, 1), 'C': A_l.copy(), 'd': b_l.copy().reshape(-1, 1),
                 'E': E.copy(), 'f': f.copy().reshape(-1, 1), 'active_set': act.tolist(), 'omega_set': om.tolist(),
                 'lambda_set': la.tolist(), 'regular_set': [ridx.tolist(), rcon.tolist()]}
+
+    def full_process(self, active_set) -> int:
+        a = self._as(active_set)
+        return int(lib().orc_full_process(ctypes.byref(self.cs), _ip(a), len(a), None, None))
 
     def gen_cr_from_active_set(self, active_set):
         a = self._as(active_set)

@@ -41,7 +41,7 @@ struct DevProblem {
     int kmax;           // largest cardinality with a solvable KKT (= min(n_c, n_x))
     int ld_x, ld_t;     // odd tableau strides of the (x,theta) LP and of the theta-space LPs
     int off_T, off_K, off_L, off_E, off_X, n_doubles;  // T tableau, K kkt matrix, L multipliers, E region rows, X x-law
-    int off_as, off_inact, off_colvar, off_rowvar, off_rowkind, off_kept, n_ints;
+    int off_as, off_inact, off_colvar, off_rowvar, off_rowkind, off_kept, off_pri, n_ints;
 };
 
 struct LevelCounters {
@@ -52,7 +52,7 @@ struct LevelCounters {
 
 struct Smem {
     double *T, *K, *L, *E, *X;
-    int *as, *inact, *colvar, *rowvar, *rowkind, *kept;
+    int *as, *inact, *colvar, *rowvar, *rowkind, *kept, *pri;
 };
 
 __device__ __forceinline__ Smem carve(const DevProblem &P, double *base) {
@@ -69,6 +69,7 @@ __device__ __forceinline__ Smem carve(const DevProblem &P, double *base) {
     s.rowvar = ib + P.off_rowvar;
     s.rowkind = ib + P.off_rowkind;
     s.kept = ib + P.off_kept;
+    s.pri = ib + P.off_pri;
     return s;
 }
 
@@ -112,6 +113,14 @@ __device__ inline int kkt_solve(const DevProblem &P, int k, Smem &s) {
         return 0;
     }
     if (P.kkt_mode == 0) {
+        {
+            // is_full_rank(A, as) on the rows themselves (exact structural dependencies show up as ~1e-16 pivots)
+            double *M = s.K;
+            for (int idx = lane; idx < k * nx; idx += 64) M[idx] = P.A[s.as[idx / nx] * nx + idx % nx];
+            wave_sync();
+            if (!full_row_rank(M, k, nx)) return 1;
+            wave_sync();
+        }
         double *S = s.K, *diag = s.K + k * k;
         for (int idx = lane; idx < k * k; idx += 64) {
             const int i = idx / k, j = idx % k;
@@ -123,7 +132,7 @@ __device__ inline int kkt_solve(const DevProblem &P, int k, Smem &s) {
             s.L[idx] = -P.UV[s.as[i] * nr + t];
         }
         wave_sync();
-        return chol_solve(S, k, s.L, nr, diag) ? 0 : 1;
+        return chol_solve(S, k, s.L, nr, diag) ? 0 : 2;
     }
     // mode 1: rank test on A_as, then the dense KKT system
     {
@@ -229,19 +238,19 @@ __global__ void __launch_bounds__(64) k_verdict(DevProblem P, const int32_t *__r
             // optimality: feasibility of the theta-space polytope {lambda(theta) >= 0, slack(theta) >= 0, A_t theta <= b_t}
             Lp lp;
             lp.T = s.T; lp.ld = P.ld_t; lp.colvar = s.colvar; lp.rowvar = s.rowvar; lp.rowkind = s.rowkind;
-            lp.n = nt;
-            const int m = build_theta_rows(P, k, nin, s, s.T, P.ld_t, P.kkt_mode == 1);
-            lp.m = m;
-            for (int i = lane; i <= m; i += 64) {
-                double *Ti = s.T + i * P.ld_t;
-                if (i == m) { for (int j = 0; j <= nt + 1; ++j) Ti[j] = 0.0; continue; }
-                double mx = 0.0;
-                for (int j = 1; j <= nt; ++j) mx = fmax(mx, fabs(Ti[j]));
-                if (!(mx > ZERO_ROW_ATOL)) for (int j = 1; j <= nt; ++j) Ti[j] = 0.0;
-                s.rowkind[i] = RK_INEQ;
-            }
-            int r = LP_INFEASIBLE;
-            if (lp_prepare(lp)) r = lp_solve(lp, false);
+            lp.n = nt; lp.m = (k - P.n_eq) + nin + P.n_tc; lp.iters = 0;
+            const int m = lp.m;
+            const int r = lp_solve(lp, false, s.pri, [&](const int *pri) {
+                build_theta_rows(P, k, nin, s, s.T, P.ld_t, P.kkt_mode == 1);
+                for (int i = lane; i <= m; i += 64) {
+                    double *Ti = s.T + i * P.ld_t;
+                    if (i == m) { for (int j = 0; j <= nt + 1; ++j) Ti[j] = 0.0; continue; }
+                    double mx = 0.0;
+                    for (int j = 1; j <= nt; ++j) mx = fmax(mx, fabs(Ti[j]));
+                    if (!(mx > ZERO_ROW_ATOL)) for (int j = 1; j <= nt; ++j) Ti[j] = 0.0;
+                    s.rowkind[i] = (pri && pri[i]) ? RK_PRI : RK_INEQ;
+                }
+            });
             pivots += lp.iters;
             if (r == LP_OPTIMAL) st = ST_OPT_PENDING;
             else if (r == LP_ITERLIMIT) st = ST_LP_LIMIT;
@@ -250,18 +259,17 @@ __global__ void __launch_bounds__(64) k_verdict(DevProblem P, const int32_t *__r
             // feasibility of {A x - F theta <= b, A_t theta <= b_t, rows `as` active}   (mplp_program.py:439-444)
             Lp lp;
             lp.T = s.T; lp.ld = P.ld_x; lp.colvar = s.colvar; lp.rowvar = s.rowvar; lp.rowkind = s.rowkind;
-            lp.n = nx + nt;
-            lp.m = P.n_c + P.n_tc;
-            const int cols = 1 + nx + nt;
-            wave_sync();
-            for (int i = 0; i < lp.m; ++i)
-                for (int j = lane; j < cols; j += 64) s.T[i * P.ld_x + j] = P.base[i * cols + j];
-            for (int j = lane; j <= cols; j += 64) s.T[lp.m * P.ld_x + j] = 0.0;
-            for (int i = lane; i < lp.m; i += 64) s.rowkind[i] = RK_INEQ;
-            wave_sync();
-            for (int i = lane; i < k; i += 64) s.rowkind[s.as[i]] = RK_EQ;
-            int r = LP_INFEASIBLE;
-            if (lp_prepare(lp)) r = lp_solve(lp, false);
+            lp.n = nx + nt; lp.m = P.n_c + P.n_tc; lp.iters = 0;
+            const int cols = 1 + nx + nt, mm = lp.m;
+            const int r = lp_solve(lp, false, s.pri, [&](const int *pri) {
+                wave_sync();
+                for (int i = 0; i < mm; ++i)
+                    for (int j = lane; j < cols; j += 64) s.T[i * P.ld_x + j] = P.base[i * cols + j];
+                for (int j = lane; j <= cols; j += 64) s.T[mm * P.ld_x + j] = 0.0;
+                for (int i = lane; i < mm; i += 64) s.rowkind[i] = (pri && pri[i]) ? RK_PRI : RK_INEQ;
+                wave_sync();
+                for (int i = lane; i < k; i += 64) s.rowkind[s.as[i]] = RK_EQ;
+            });
             pivots += lp.iters;
             if (r == LP_OPTIMAL) st = singular ? ST_SINGULAR : ST_FEASIBLE;
             else if (r == LP_ITERLIMIT) st = ST_LP_LIMIT;
@@ -365,24 +373,24 @@ __global__ void __launch_bounds__(64) k_region(DevProblem P, const int32_t *__re
                 // Chebyshev ball: min -r s.t. E theta + ||E_i|| r <= f, -r <= 0   (chebyshev_ball.py:41-60)
                 Lp lp;
                 lp.T = s.T; lp.ld = P.ld_t; lp.colvar = s.colvar; lp.rowvar = s.rowvar; lp.rowkind = s.rowkind;
-                lp.n = nt + 1; lp.m = nk + 1;
-                wave_sync();
-                for (int i = lane; i <= nk + 1; i += 64) {
-                    double *Ti = s.T + i * P.ld_t;
-                    if (i < nk) {
-                        double ss = 0.0;
-                        Ti[0] = s.E[i * ldE];
-                        for (int j = 0; j < nt; ++j) { const double v = s.E[i * ldE + 1 + j]; Ti[1 + j] = v; ss = fma(v, v, ss); }
-                        Ti[1 + nt] = sqrt(ss);
-                        Ti[2 + nt] = 0.0;
-                    } else {
-                        for (int j = 0; j <= nt + 2; ++j) Ti[j] = 0.0;
-                        Ti[1 + nt] = -1.0;  // row nk: -r <= 0 ; row nk+1 (cost): min -r
+                lp.n = nt + 1; lp.m = nk + 1; lp.iters = 0;
+                const int r = lp_solve(lp, true, s.pri, [&](const int *pri) {
+                    wave_sync();
+                    for (int i = lane; i <= nk + 1; i += 64) {
+                        double *Ti = s.T + i * P.ld_t;
+                        if (i < nk) {
+                            double ss = 0.0;
+                            Ti[0] = s.E[i * ldE];
+                            for (int j = 0; j < nt; ++j) { const double v = s.E[i * ldE + 1 + j]; Ti[1 + j] = v; ss = fma(v, v, ss); }
+                            Ti[1 + nt] = sqrt(ss);
+                            Ti[2 + nt] = 0.0;
+                        } else {
+                            for (int j = 0; j <= nt + 2; ++j) Ti[j] = 0.0;
+                            Ti[1 + nt] = -1.0;  // row nk: -r <= 0 ; row nk+1 (cost): min -r
+                        }
+                        s.rowkind[i] = (pri && i <= nk && pri[i]) ? RK_PRI : RK_INEQ;
                     }
-                    s.rowkind[i] = RK_INEQ;
-                }
-                int r = LP_INFEASIBLE;
-                if (lp_prepare(lp)) r = lp_solve(lp, true);
+                });
                 pivots += lp.iters;
                 double radius = 0.0;
                 if (r == LP_OPTIMAL) {
@@ -398,16 +406,16 @@ __global__ void __launch_bounds__(64) k_region(DevProblem P, const int32_t *__re
                 // one feasibility LP per kept row with that row as an equality (mpqp_utils.py:143-178)
                 double *Eo = rd + nx * nt + nx + nc * nt + nc, *fo = Eo + (nc + ntc) * nt;
                 for (int row = 0; row < nk && st == ST_REGION; ++row) {
-                    lp.n = nt; lp.m = nk;
-                    wave_sync();
-                    for (int i = lane; i <= nk; i += 64) {
-                        double *Ti = s.T + i * P.ld_t;
-                        if (i < nk) { for (int j = 0; j <= nt; ++j) Ti[j] = s.E[i * ldE + j]; Ti[nt + 1] = 0.0; }
-                        else for (int j = 0; j <= nt + 1; ++j) Ti[j] = 0.0;
-                        s.rowkind[i] = (i == row) ? RK_EQ : RK_INEQ;
-                    }
-                    int rr = LP_INFEASIBLE;
-                    if (lp_prepare(lp)) rr = lp_solve(lp, false);
+                    lp.n = nt; lp.m = nk; lp.iters = 0;
+                    const int rr = lp_solve(lp, false, s.pri, [&](const int *pri) {
+                        wave_sync();
+                        for (int i = lane; i <= nk; i += 64) {
+                            double *Ti = s.T + i * P.ld_t;
+                            if (i < nk) { for (int j = 0; j <= nt; ++j) Ti[j] = s.E[i * ldE + j]; Ti[nt + 1] = 0.0; }
+                            else for (int j = 0; j <= nt + 1; ++j) Ti[j] = 0.0;
+                            s.rowkind[i] = (i == row) ? RK_EQ : ((pri && i < nk && pri[i]) ? RK_PRI : RK_INEQ);
+                        }
+                    });
                     pivots += lp.iters;
                     if (rr == LP_ITERLIMIT) { st = ST_LP_LIMIT; break; }
                     if (rr != LP_OPTIMAL) continue;
@@ -580,7 +588,7 @@ __global__ void __launch_bounds__(64) k_lp_batch(long long n_lp, int m, int n, i
     double *T = smem;
     int *ib = reinterpret_cast<int *>(smem + (size_t)(m + 1) * ld);
     Lp lp;
-    lp.T = T; lp.ld = ld; lp.colvar = ib; lp.rowvar = ib + ld + 1; lp.rowkind = ib + ld + 1 + m + 1;
+    lp.T = T; lp.ld = ld; lp.colvar = ib; lp.rowvar = ib + ld + 1; lp.rowkind = ib + ld + 1 + m + 2;
     for (;;) {
         unsigned int w = 0;
         if (lane == 0) w = atomicAdd(work, 1u);
@@ -589,14 +597,19 @@ __global__ void __launch_bounds__(64) k_lp_batch(long long n_lp, int m, int n, i
         const double *Aw = A + (shared_A ? 0 : (size_t)w * m * n);
         const double *bw = b + (shared_b ? 0 : (size_t)w * m);
         const double *cw = c ? c + (shared_c ? 0 : (size_t)w * n) : nullptr;
-        lp.m = m; lp.n = n;
-        wave_sync();
-        for (int i = 0; i < m; ++i)
-            for (int j = lane; j < n; j += 64) T[i * ld + 1 + j] = Aw[(size_t)i * n + j];
-        for (int i = lane; i < m; i += 64) { T[i * ld] = bw[i]; T[i * ld + n + 1] = 0.0; lp.rowkind[i] = eq[(size_t)w * m + i] ? RK_EQ : RK_INEQ; }
-        for (int j = lane; j <= n + 1; j += 64) T[m * ld + j] = (cw && j >= 1 && j <= n) ? cw[j - 1] : 0.0;
-        int r = LP_INFEASIBLE;
-        if (lp_prepare(lp)) r = lp_solve(lp, cw != nullptr);
+        lp.m = m; lp.n = n; lp.iters = 0;
+        int *pri_buf = lp.rowkind + m + 2;
+        const int r = lp_solve(lp, cw != nullptr, pri_buf, [&](const int *pri) {
+            wave_sync();
+            for (int i = 0; i < m; ++i)
+                for (int j = lane; j < n; j += 64) T[i * ld + 1 + j] = Aw[(size_t)i * n + j];
+            for (int i = lane; i < m; i += 64) {
+                T[i * ld] = bw[i];
+                T[i * ld + n + 1] = 0.0;
+                lp.rowkind[i] = eq[(size_t)w * m + i] ? RK_EQ : ((pri && pri[i]) ? RK_PRI : RK_INEQ);
+            }
+            for (int j = lane; j <= n + 1; j += 64) T[m * ld + j] = (cw && j >= 1 && j <= n) ? cw[j - 1] : 0.0;
+        });
         if (x) {
             for (int j = lane; j < n; j += 64) x[(size_t)w * n + j] = 0.0;
             wave_sync();

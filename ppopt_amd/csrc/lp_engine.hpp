@@ -12,8 +12,10 @@
 //   stage A  free structural variables enter the basis (equality rows first, largest |coefficient|);
 //            a fixed (equality) slack that becomes nonbasic has its column deleted
 //   stage B  equality rows still basic leave the basis (or are redundant / inconsistent)
-//   phase 1  x0 method, Dantzig pricing, Bland's rule while stalled at a degenerate vertex
+//   phase 1  x0 method, Dantzig pricing, Harris two-pass ratio test; Bland's rule while stalled at a degenerate vertex
 //   phase 2  primal simplex on the cost row
+//   safety   if a ratio-test pivot was smaller than 1e-3 of its column, the final basis is rebuilt from the original
+//            data (stage A restricted to the rows that were nonbasic) and the method continues from there
 // Reference boundary this replaces: Solver.solve_lp -> GLPK (solver.py:211, cvxopt_interface.py:153-208).
 #pragma once
 #include <hip/hip_runtime.h>
@@ -23,9 +25,12 @@ namespace mpc {
 constexpr double TOL_FEAS = 1e-7;
 constexpr double TOL_PIV = 1e-9;
 constexpr double TOL_COST = 1e-9;
+constexpr double HARRIS_DELTA = 1e-9;
 constexpr int DEG_SWITCH = 12;
+constexpr double GROWTH_SAFE = 1e3;  // largest tolerated |column max / pivot| before the basis is refactored
+constexpr int MAX_REFACTOR = 2;
 
-enum : int { RK_INEQ = 0, RK_EQ = 1, RK_FREE = 2, RK_DEAD = 3, RK_X0 = 4 };
+enum : int { RK_INEQ = 0, RK_EQ = 1, RK_FREE = 2, RK_DEAD = 3, RK_X0 = 4, RK_PRI = 5 };
 enum : int { LP_OPTIMAL = 0, LP_INFEASIBLE = 1, LP_UNBOUNDED = 2, LP_ITERLIMIT = 3 };
 
 struct Lp {
@@ -39,6 +44,7 @@ struct Lp {
     int na;        // alive nonbasic columns 1..na
     int iters;
     int max_iter;
+    double growth;  // max over ratio-test pivots of (largest |entry| of the pivot column) / |pivot|
 };
 
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
@@ -67,7 +73,22 @@ __device__ __forceinline__ void reduce_min_first(double &v, int &key2, int &idx)
         if (take) { v = ov; key2 = ok; idx = oi; }
     }
 }
-// ratio test: smallest ratio; ties -> x0 row first, then (bland ? lowest basic var : largest pivot), then lowest row
+// ratio test, textbook order: smallest ratio; ties -> x0 row first, then lowest basic variable (Bland)
+__device__ __forceinline__ bool bland_better(double r, int x0, int var, double br, int bx0, int bvar, int bi) {
+    if (bi < 0 || r < br) return true;
+    if (r == br) {
+        if (x0 != bx0) return x0 > bx0;
+        return var < bvar;
+    }
+    return false;
+}
+// ratio test, Harris pass 2: x0 row first, then the largest pivot, then the lowest row
+__device__ __forceinline__ bool harris_better(double p, int x0, int i, double bp, int bx0, int bi) {
+    if (bi < 0) return true;
+    if (x0 != bx0) return x0 > bx0;
+    if (p != bp) return p > bp;
+    return i < bi;
+}
 __device__ __forceinline__ void reduce_ratio(double &ratio, double &piv, int &isx0, int &var, int &idx, bool bland) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
@@ -77,30 +98,19 @@ __device__ __forceinline__ void reduce_ratio(double &ratio, double &piv, int &is
         const int ovar = __shfl_xor(var, off);
         const int oi = __shfl_xor(idx, off);
         bool take = false;
-        if (oi >= 0) {
-            if (idx < 0 || orat < ratio) take = true;
-            else if (orat == ratio) {
-                if (ox0 != isx0) take = ox0 > isx0;
-                else if (bland) take = (ovar < var);
-                else if (opiv != piv) take = opiv > piv;
-                else take = oi < idx;
-            }
-        }
+        if (oi >= 0) take = bland ? bland_better(orat, ox0, ovar, ratio, isx0, var, idx) : harris_better(opiv, ox0, oi, piv, isx0, idx);
         if (take) { ratio = orat; piv = opiv; isx0 = ox0; var = ovar; idx = oi; }
     }
 }
-
-// within-lane version of the same orders (a lane may own several rows)
-__device__ __forceinline__ bool ratio_better(double r, double p, int x0, int var, int i, double br, double bp, int bx0,
-                                             int bvar, int bi, bool bland) {
-    if (bi < 0 || r < br) return true;
-    if (r == br) {
-        if (x0 != bx0) return x0 > bx0;
-        if (bland) return var < bvar;
-        if (p != bp) return p > bp;
-        return i < bi;
-    }
-    return false;
+__device__ __forceinline__ double wave_min(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = fmin(v, __shfl_xor(v, off));
+    return v;
+}
+__device__ __forceinline__ double wave_max(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = fmax(v, __shfl_xor(v, off));
+    return v;
 }
 
 // ---- elementary operations -------------------------------------------------------------------------------
@@ -194,7 +204,21 @@ __device__ inline int lp_primal(Lp &lp, int phase1_row) {
         if (bland) best = 0.0;
         reduce_min_first(best, key, q);
         if (q < 0) return 0;
-        // ratio test
+        // ratio test (Harris two-pass; textbook + Bland while stalled)
+        double colmax = 0.0, tmax = INFINITY;
+        for (int i = lane; i < m; i += 64) {
+            const int kind = lp.rowkind[i];
+            if (kind == RK_DEAD) continue;
+            const double a = T[i * ld + q];
+            colmax = fmax(colmax, fabs(a));
+            if ((kind != RK_INEQ && kind != RK_X0) || a <= TOL_PIV) continue;
+            double beta = T[i * ld];
+            if (beta < 0.0) beta = 0.0;
+            tmax = fmin(tmax, (beta + HARRIS_DELTA) / a);
+        }
+        colmax = wave_max(colmax);
+        tmax = wave_min(tmax);
+        if (tmax == INFINITY) return 2;
         double rmin = 0.0, rpiv = 0.0;
         int rx0 = 0, rvar = 0, r = -1;
         for (int i = lane; i < m; i += 64) {
@@ -206,10 +230,14 @@ __device__ inline int lp_primal(Lp &lp, int phase1_row) {
             if (beta < 0.0) beta = 0.0;
             const double ratio = beta / a;
             const int x0 = kind == RK_X0, var = lp.rowvar[i];
-            if (ratio_better(ratio, a, x0, var, i, rmin, rpiv, rx0, rvar, r, bland)) { rmin = ratio; rpiv = a; rx0 = x0; rvar = var; r = i; }
+            bool take;
+            if (bland) take = bland_better(ratio, x0, var, rmin, rx0, rvar, r);
+            else take = !(ratio > tmax) && harris_better(a, x0, i, rpiv, rx0, r);
+            if (take) { rmin = ratio; rpiv = a; rx0 = x0; rvar = var; r = i; }
         }
         reduce_ratio(rmin, rpiv, rx0, rvar, r, bland);
         if (r < 0) return 2;
+        lp.growth = fmax(lp.growth, colmax / rpiv);
         deg = (rmin <= 0.0) ? deg + 1 : 0;
         lp_pivot(lp, r, q);
         if (rx0) {
@@ -220,9 +248,9 @@ __device__ inline int lp_primal(Lp &lp, int phase1_row) {
     }
 }
 
-// Solves the LP whose scaled tableau, rowkind (RK_INEQ / RK_EQ / RK_DEAD), rowvar (= n + i) and colvar (= j - 1)
-// are already in LDS.  has_cost: run phase 2 on row m.  Returns LP_*.
-__device__ inline int lp_solve(Lp &lp, bool has_cost) {
+// One pass (stage A, stage B, phase 1, phase 2) on the scaled tableau, rowkind (RK_INEQ / RK_PRI / RK_EQ / RK_DEAD),
+// rowvar (= n + i) and colvar (= j - 1) already in LDS.  has_cost: run phase 2 on row m.  Returns LP_*.
+__device__ inline int lp_run(Lp &lp, bool has_cost) {
     const int m = lp.m, n = lp.n, ld = lp.ld, lane = lane_id();
     double *T = lp.T;
     bool unbounded_if_feasible = false;
@@ -238,6 +266,7 @@ __device__ inline int lp_solve(Lp &lp, bool has_cost) {
         }
         int r = lp_best_row(lp, q, RK_EQ);
         const bool was_eq = r >= 0;
+        if (r < 0) r = lp_best_row(lp, q, RK_PRI);
         if (r < 0) r = lp_best_row(lp, q, RK_INEQ);
         if (r < 0) {
             if (has_cost && fabs(T[m * ld + q]) > TOL_COST) unbounded_if_feasible = true;
@@ -249,6 +278,9 @@ __device__ inline int lp_solve(Lp &lp, bool has_cost) {
         if (was_eq) lp_drop_col(lp, q);
         else wave_sync();
     }
+    for (int i = lane; i < m; i += 64)
+        if (lp.rowkind[i] == RK_PRI) lp.rowkind[i] = RK_INEQ;
+    wave_sync();
     // stage B
     for (int i = 0; i < m; ++i) {
         if (lp.rowkind[i] != RK_EQ) continue;
@@ -330,11 +362,35 @@ __device__ inline bool lp_prepare(Lp &lp) {
     }
     for (int j = 1 + lane; j <= n; j += 64) lp.colvar[j] = j - 1;
     lp.na = n;
-    lp.iters = 0;
+    lp.growth = 0.0;
     lp.max_iter = 50 * (m + n) + 100;
     const bool any_bad = __any(bad);
     wave_sync();
     return !any_bad;
+}
+
+// Full solve.  `load(pri)` (re)writes the unscaled tableau and rowkind from the problem data; when pri != nullptr it
+// marks inequality row i as RK_PRI if pri[i] != 0 (its slack was nonbasic in the basis being rebuilt).
+// pri_buf: LDS int[m] scratch.  The caller sets lp.iters = 0 beforehand; pivots accumulate over refactorisations.
+template <class Load>
+__device__ inline int lp_solve(Lp &lp, bool has_cost, int *pri_buf, Load load) {
+    const int lane = lane_id();
+    int status = LP_OPTIMAL;
+    for (int attempt = 0;; ++attempt) {
+        load(attempt ? pri_buf : nullptr);
+        if (!lp_prepare(lp)) return LP_INFEASIBLE;
+        status = lp_run(lp, has_cost);
+        if (status == LP_ITERLIMIT || !(lp.growth > GROWTH_SAFE) || attempt >= MAX_REFACTOR) break;
+        wave_sync();
+        for (int i = lane; i < lp.m; i += 64) pri_buf[i] = 0;
+        wave_sync();
+        for (int j = 1 + lane; j <= lp.na; j += 64) {
+            const int v = lp.colvar[j];
+            if (v >= lp.n && v < lp.n + lp.m) pri_buf[v - lp.n] = 1;
+        }
+        wave_sync();
+    }
+    return status;
 }
 
 }  // namespace mpc

@@ -122,7 +122,7 @@ void chol_apply(const std::vector<double> &L, int n, double *x) {
     }
 }
 
-struct Layout { int off_T, off_K, off_L, off_E, off_X, n_doubles, off_as, off_inact, off_colvar, off_rowvar, off_rowkind, off_kept, n_ints, bytes; };
+struct Layout { int off_T, off_K, off_L, off_E, off_X, n_doubles, off_as, off_inact, off_colvar, off_rowvar, off_rowkind, off_kept, off_pri, n_ints, bytes; };
 
 Layout make_layout(int size_T, int size_K, int size_L, int size_E, int size_X, int kmax, int n_c, int ld_max, int rows_max, int rows_t) {
     Layout l{};
@@ -133,7 +133,7 @@ Layout make_layout(int size_T, int size_K, int size_L, int size_E, int size_X, i
     int q = 0;
     auto itake = [&](int sz) { int r = q; q += sz; return r; };
     l.off_as = itake(kmax + 1); l.off_inact = itake(n_c + 1); l.off_colvar = itake(ld_max + 2);
-    l.off_rowvar = itake(rows_max + 3); l.off_rowkind = itake(rows_max + 3); l.off_kept = itake(rows_t + 1);
+    l.off_rowvar = itake(rows_max + 3); l.off_rowkind = itake(rows_max + 3); l.off_kept = itake(rows_t + 1); l.off_pri = itake(rows_max + 3);
     l.n_ints = q;
     l.bytes = (l.n_doubles * 8 + l.n_ints * 4 + 15) & ~15;
     return l;
@@ -142,7 +142,7 @@ Layout make_layout(int size_T, int size_K, int size_L, int size_E, int size_X, i
 void apply_layout(DevProblem &P, const Layout &l) {
     P.off_T = l.off_T; P.off_K = l.off_K; P.off_L = l.off_L; P.off_E = l.off_E; P.off_X = l.off_X; P.n_doubles = l.n_doubles;
     P.off_as = l.off_as; P.off_inact = l.off_inact; P.off_colvar = l.off_colvar; P.off_rowvar = l.off_rowvar;
-    P.off_rowkind = l.off_rowkind; P.off_kept = l.off_kept; P.n_ints = l.n_ints;
+    P.off_rowkind = l.off_rowkind; P.off_kept = l.off_kept; P.off_pri = l.off_pri; P.n_ints = l.n_ints;
 }
 
 int waves_per_cu(int lds_bytes) { return std::max(1, std::min(16, (160 * 1024) / std::max(lds_bytes, 1))); }
@@ -252,7 +252,7 @@ int mpc_create(const mpc_problem *p, int32_t device, void *stream, mpc_handle **
     P.kmax = kmax;
     P.ld_x = odd_at_least(nx + nt + 3);
     P.ld_t = odd_at_least(nt + 4);
-    const int size_K = mode == 0 ? kmax * kmax + kmax : std::max({(nx + kmax) * (nx + kmax) + (nx + kmax) * nr, kmax * nx, nx * nx});
+    const int size_K = mode == 0 ? std::max(kmax * kmax + kmax, kmax * nx) : std::max({(nx + kmax) * (nx + kmax) + (nx + kmax) * nr, kmax * nx, nx * nx});
     const int size_L = std::max(kmax * nr, 1), size_X = nx * nr;
     const int T_v = std::max((rows_x + 1) * P.ld_x, (rows_t + 1) * P.ld_t);
     const int T_r = std::max((rows_t + 2) * P.ld_t, rows_t * nr);
@@ -582,7 +582,7 @@ int mpc_lp_solve_batch(int32_t device, int64_t n_lp, int32_t m, int32_t n, const
     if (device < 0 || device >= ndev) return fail(nullptr, MPC_ERR_INVALID, "device index out of range");
     HIP_TRY(nullptr, hipSetDevice(device));
     const int ld = odd_at_least(n + 3);
-    const size_t lds = (((size_t)(m + 1) * ld * 8 + (size_t)(ld + 1 + 2 * (m + 2)) * 4) + 15) & ~size_t(15);
+    const size_t lds = (((size_t)(m + 1) * ld * 8 + (size_t)(ld + 1 + 3 * (m + 2)) * 4) + 15) & ~size_t(15);
     if (lds > 160 * 1024) return fail(nullptr, MPC_ERR_INVALID, "LP does not fit the 160 KiB LDS of one CU");
     if (lds > 48 * 1024) HIP_TRY(nullptr, hipFuncSetAttribute(reinterpret_cast<const void *>(k_lp_batch), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipDeviceProp_t prop;

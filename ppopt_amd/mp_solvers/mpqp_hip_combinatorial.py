@@ -1,0 +1,93 @@
+"""The parallel combinatorial algorithm (Gupta et al. 2011) with the per-candidate work on the MI355X.
+
+Same level-synchronous structure and pruning semantics as the reference driver
+(mp_solvers/mpqp_parrallel_combinatorial.py:67-150):
+
+    to_check = children(equality_indices)                      driver :98
+    for depth in range(max_depth):                             driver :102
+        outputs = pool.map(full_process, to_check)             driver :110-116  -> Engine.level_run (device kernels)
+        murder_list += pruned ; to_check = children ; regions  driver :127-135  -> Engine.frontier_advance
+    finally the base active set itself                         driver :142-146
+
+The frontier, the pruned list and the children never leave HBM between levels; per level the host reads back a
+small statistics block and the region records.  With ``num_gpus > 1`` (one process per GPU under
+``torch.distributed``) every rank processes the slice ``to_check[rank::world]`` and the ranks exchange children,
+pruned sets and regions once per level (ppopt_amd/distributed.py).
+
+Differences from the reference that are visible to a user:
+  * ``shuffle(to_check)`` (driver :114) is dropped -- candidate order is deterministic, and so is the region order;
+  * a numerically singular KKT matrix is a per-candidate status (no region, children expanded) instead of the
+    ``numpy.linalg.LinAlgError`` that aborts the reference solve (mpqp_program.py:187).
+"""
+import time
+from typing import Dict, List, Optional
+
+import numpy
+
+from .. import _lib
+from ..critical_region import CriticalRegion
+from ..solution import Solution
+from ..utils.constraint_utilities import remove_duplicate_rows
+
+
+def unpack_region(rec_d: numpy.ndarray, rec_i: numpy.ndarray, n_x: int, n_t: int, n_c: int, n_tc: int) -> CriticalRegion:
+    """One device region record (layout: include/mpcombi.h, mpc_level_regions) -> CriticalRegion."""
+    k, nE, n_om, n_la, n_re = (int(v) for v in rec_i[:5])
+    o = 0
+    A = rec_d[o:o + n_x * n_t].reshape(n_x, n_t).copy(); o += n_x * n_t
+    b = rec_d[o:o + n_x].reshape(-1, 1).copy(); o += n_x
+    C = rec_d[o:o + n_c * n_t].reshape(n_c, n_t)[:k].copy(); o += n_c * n_t
+    d = rec_d[o:o + n_c][:k].reshape(-1, 1).copy(); o += n_c
+    E = rec_d[o:o + (n_c + n_tc) * n_t].reshape(n_c + n_tc, n_t)[:nE].copy(); o += (n_c + n_tc) * n_t
+    f = rec_d[o:o + n_c + n_tc][:nE].reshape(-1, 1).copy()
+    q = 5
+    active = rec_i[q:q + n_c][:k].tolist(); q += n_c
+    omega = rec_i[q:q + n_tc][:n_om].tolist(); q += n_tc
+    lam = rec_i[q:q + n_c][:n_la].tolist(); q += n_c
+    ridx = rec_i[q:q + n_c][:n_re].tolist(); q += n_c
+    rcon = rec_i[q:q + n_c][:n_re].tolist()
+    if n_t > 1:
+        # exact-duplicate rows go last, as in gen_cr_from_active_set (mpqp_utils.py:191)
+        E, f = remove_duplicate_rows(E, f)
+    return CriticalRegion(A, b, C, d, E, f, active, omega, lam, [ridx, rcon])
+
+
+def solve(program, num_cores: int = -1, device: int = 0, profile: Optional[List[Dict]] = None,
+          collect_regions: bool = True, max_levels: Optional[int] = None) -> Solution:
+    """Solves the mpLP/mpQP on one GPU.  ``num_cores`` is accepted for signature compatibility with the reference
+    drivers and ignored.  ``profile``: optional list that receives one dict of statistics per level."""
+    eng = program.engine(device)
+    n_x, n_t, n_c, n_tc = eng.n_x, eng.n_t, eng.n_c, eng.n_tc
+    solution = Solution(program, [])
+    max_depth = max(n_x, n_t) - eng.n_eq
+    if max_levels is not None:
+        max_depth = min(max_depth, max_levels)
+    eng.pruned_clear()
+    eng.frontier_root()
+    for depth in range(max_depth):
+        gen_children = depth + 1 != max_depth
+        t0 = time.perf_counter()
+        st = eng.level_run(gen_children)
+        if collect_regions and st.n_regions:
+            rd, ri, _ = eng.level_regions()
+            for j in range(len(rd)):
+                solution.add_region(unpack_region(rd[j], ri[j], n_x, n_t, n_c, n_tc))
+        if profile is not None:
+            profile.append({'depth': depth + 1, 'k': int(st.k), 'candidates': int(st.n),
+                            'status': [int(v) for v in st.n_status], 'regions': int(st.n_regions),
+                            'children': int(st.n_children), 'pruned_new': int(st.n_pruned_new),
+                            'lp_pivots': int(st.lp_pivots), 'ms_verdict': float(st.ms_verdict),
+                            'ms_region': float(st.ms_region), 'ms_children': float(st.ms_children),
+                            'ms_wall': (time.perf_counter() - t0) * 1e3})
+        if not gen_children or st.n_children == 0:
+            break
+        eng.frontier_advance()
+    # the base active set (= the equality rows) is tested last, like the reference (driver :142-146)
+    base = numpy.arange(eng.n_eq, dtype=numpy.int32).reshape(1, -1)
+    status, rd, ri, _, _ = eng.check_level(base, numpy.zeros((0, 2), dtype=numpy.uint64), False)
+    if profile is not None:
+        profile.append({'depth': 0, 'k': eng.n_eq, 'candidates': 1, 'status': numpy.bincount(status, minlength=6).tolist(),
+                        'regions': len(rd)})
+    if collect_regions and len(rd):
+        solution.add_region(unpack_region(rd[0], ri[0], n_x, n_t, n_c, n_tc))
+    return solution

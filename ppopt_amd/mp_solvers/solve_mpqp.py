@@ -1,0 +1,57 @@
+"""Algorithm dispatch: ``solve_mpqp(problem, algorithm)`` (reference: mp_solvers/solve_mpqp.py:23-114).
+
+The enum keeps every member of the reference's ``mpqp_algorithm`` so that user code keeps importing and selecting
+algorithms the same way.  The three combinatorial members run on the MI355X (they differ in the reference only in
+how the CPU work is scheduled and pruned; all give the same region set); the graph and geometric
+members are other algorithms, outside the scope of this package, and raise ``NotImplementedError``.
+"""
+from enum import Enum
+
+import numpy
+
+from ..mplp_program import MPLP_Program
+from ..mpqp_program import MPQP_Program
+from ..solution import Solution
+from . import mpqp_hip_combinatorial
+
+
+class mpqp_algorithm(Enum):
+    combinatorial = 'combinatorial'
+    combinatorial_parallel = 'p combinatorial'
+    combinatorial_parallel_exp = 'p combinatorial exp'
+    graph = 'graph'
+    graph_exp = 'graph exp'
+    graph_parallel = 'p graph'
+    graph_parallel_exp = 'p graph exp'
+    combinatorial_graph = 'combinatorial graph'
+    geometric = 'geometric'
+    geometric_parallel = 'p geometric'
+    geometric_parallel_exp = 'p geometric exp'
+
+    def __str__(self):
+        return self.name
+
+    @staticmethod
+    def all_algos():
+        return ''.join(f'mpqp_algorithm.{a}\n' for a in mpqp_algorithm)
+
+
+_COMBINATORIAL = (mpqp_algorithm.combinatorial, mpqp_algorithm.combinatorial_parallel,
+                  mpqp_algorithm.combinatorial_parallel_exp)
+
+
+def solve_mpqp(problem: MPQP_Program, algorithm: mpqp_algorithm = mpqp_algorithm.combinatorial) -> Solution:
+    if not isinstance(algorithm, mpqp_algorithm):
+        raise TypeError('You must pass an algorithm from mpqp_algorithm as the continuous algorithm. These can be '
+                        'found by importing the following \n\nfrom ppopt_amd.mp_solvers.solve_mpqp import '
+                        f'mpqp_algorithm\n\nWith the following choices\n{mpqp_algorithm.all_algos()}')
+    if algorithm not in _COMBINATORIAL:
+        raise NotImplementedError(f'{algorithm} is not part of the MI355X combinatorial path; use one of '
+                                  f'{[str(a) for a in _COMBINATORIAL]}')
+    solution = mpqp_hip_combinatorial.solve(problem)
+    # overlap flags exactly as the reference sets them (solve_mpqp.py:103-112)
+    if isinstance(problem, MPQP_Program) and min(numpy.linalg.eigvalsh(problem.Q)) <= 0:
+        solution.is_overlapping = True
+    if isinstance(problem, MPLP_Program):
+        solution.is_overlapping = True
+    return solution

@@ -1,0 +1,198 @@
+"""MPLP_Program: host-side mirror of the reference program class for the combinatorial path.
+
+    min_x  theta' H' x + c' x   s.t.  A x <= b + F theta  (rows ``equality_indices`` as equalities),  A_t theta <= b_t
+
+Same constructor signature, the same presolve (and therefore the same row indexing) and the same per-active-set
+methods as the reference (mplp_program.py:27-678).  What differs is where the work happens: every LP goes through
+the deterministic-solver plug, whose only product backend is the MI355X (ppopt_amd.solver.Solver), and
+``check_feasibility`` / ``check_optimality`` / ``gen_cr_from_active_set`` run on the device through the C ABI.
+"""
+import warnings
+from typing import List, Optional, Tuple
+
+import numpy
+
+from .solver import Solver
+from .utils.chebyshev_ball import chebyshev_ball
+from .utils.constraint_utilities import (constraint_norm, find_implicit_equalities, find_redundant_constraints,
+                                         generate_reduced_equality_constraints, is_full_rank,
+                                         process_program_constraints)
+from .utils.general_utils import make_column, ppopt_block, select_not_in_list
+
+
+class MPLP_Program:
+    def __init__(self, A, b, c, H, A_t, b_t, F, c_c=None, c_t=None, Q_t=None, equality_indices=None, solver=None,
+                 post_process=True):
+        self.A, self.b, self.c, self.H = A, b, c, H
+        self.A_t, self.b_t, self.F = A_t, b_t, F
+        self.c_c = numpy.array([[0.0]]) if c_c is None else c_c
+        self.c_t = numpy.zeros((self.num_t(), 1)) if c_t is None else c_t
+        self.Q_t = numpy.zeros((self.num_t(), self.num_t())) if Q_t is None else Q_t
+        self.equality_indices = list(equality_indices) if equality_indices is not None and len(equality_indices) else []
+        self.solver = Solver() if solver is None else solver
+        self._engine = None
+
+        self.base_constraint_processing()
+        for msg in self.warnings():
+            warnings.warn(msg, UserWarning)
+        if post_process:
+            self.post_process()
+
+    # ---- presolve (mplp_program.py:110-134, 276-322) -------------------------------------------------------
+    def base_constraint_processing(self):
+        if len(self.equality_indices) != 0:
+            eq = self.equality_indices
+            self.A = numpy.vstack([self.A[eq], select_not_in_list(self.A, eq)])
+            self.b = numpy.vstack([self.b[eq], select_not_in_list(self.b, eq)])
+            self.F = numpy.vstack([self.F[eq], select_not_in_list(self.F, eq)])
+            self.equality_indices = list(range(len(eq)))
+        self.constraint_datatype_conversion()
+        self.A, self.b, self.F, self.A_t, self.b_t = process_program_constraints(self.A, self.b, self.F, self.A_t,
+                                                                                 self.b_t)
+        self.scale_constraints()
+        self.A, self.b, self.F, self.equality_indices = find_implicit_equalities(self.A, self.b, self.F,
+                                                                                 self.equality_indices)
+        self.A, self.b, self.F, self.equality_indices = generate_reduced_equality_constraints(
+            self.A, self.b, self.F, self.equality_indices)
+        self._engine = None
+
+    def post_process(self):
+        self.process_constraints()
+
+    def constraint_datatype_conversion(self) -> None:
+        for name in ('A', 'c', 'b', 'F', 'A_t', 'b_t', 'H', 'c_c', 'c_t', 'Q_t'):
+            setattr(self, name, numpy.asarray(getattr(self, name)).astype('float64'))
+
+    def scale_constraints(self) -> None:
+        """Rows of [A | -F] (and b) to unit L2 norm."""
+        norm = constraint_norm(numpy.hstack([self.A, -self.F]))
+        self.A, self.b, self.F = self.A / norm, self.b / norm, self.F / norm
+        self._engine = None
+
+    def process_constraints(self) -> None:
+        """Removes rows that cannot be active: one LP per non-equality row of [[A, -F], [0, A_t]]."""
+        PA = ppopt_block([[self.A, -self.F], [numpy.zeros((self.A_t.shape[0], self.A.shape[1])), self.A_t]])
+        Pb = ppopt_block([[self.b], [self.b_t]])
+        saved = find_redundant_constraints(PA, Pb, self.equality_indices, solver=self.solver)
+        n_c = self.num_constraints()
+        upper = [i for i in saved if i < n_c]
+        lower = [i - n_c for i in saved if i >= n_c]
+        self.A, self.F, self.b = self.A[upper], self.F[upper], self.b[upper]
+        self.A_t, self.b_t = self.A_t[lower], self.b_t[lower]
+        self._engine = None
+
+    # ---- sizes ------------------------------------------------------------------------------------------------
+    def num_x(self) -> int:
+        return self.A.shape[1]
+
+    def num_t(self) -> int:
+        return self.F.shape[1]
+
+    def num_constraints(self) -> int:
+        return self.A.shape[0]
+
+    def num_inequality_constraints(self) -> int:
+        return self.A.shape[0] - len(self.equality_indices)
+
+    def num_equality_constraints(self) -> int:
+        return len(self.equality_indices)
+
+    def evaluate_objective(self, x: numpy.ndarray, theta_point: numpy.ndarray) -> float:
+        v = theta_point.T @ self.H.T @ x + self.c.T @ x + self.c_c + self.c_t.T @ theta_point \
+            + 0.5 * theta_point.T @ self.Q_t @ theta_point
+        return float(v[0, 0])
+
+    # ---- diagnostics (mplp_program.py:162-218) ------------------------------------------------------------------
+    def warnings(self) -> List[str]:
+        out = []
+        if self.b.ndim != 2:
+            out.append(f'The b matrix is not a column vector b{self.b.shape}')
+            self.b = make_column(self.b)
+            out.append('This has been corrected')
+        if self.c.ndim != 2:
+            out.append(f'The c vector is not a column vector c{self.c.shape}')
+            self.c = make_column(self.c)
+            out.append('This has been corrected')
+        if self.A.shape[1] != self.c.shape[0]:
+            out.append(f'The A and b matrices disagree in number of parameters A{self.A.shape}, c{self.c.shape}')
+        if self.A.shape[0] != self.b.shape[0]:
+            out.append(f'The A and b matrices disagree in vertical dimension A{self.A.shape}, b{self.b.shape}')
+        if self.A_t.shape[0] != self.b_t.shape[0]:
+            out.append(f'The A and b matrices disagree in vertical dimension A{self.A_t.shape}, b{self.b_t.shape}')
+        if self.A.shape[0] != self.F.shape[0]:
+            out.append(f'The A and F matrices disagree in vertical dimension A{self.A.shape}, F {self.F.shape}')
+        if self.F.shape[1] != self.A_t.shape[1]:
+            out.append(f'The F and A_t matrices disagree in dimension A_t {self.A_t.shape}, F {self.F.shape}, '
+                       f'inconsistent number of parameters')
+        if not out:
+            if self.feasible_space_chebychev_ball() is None:
+                out.append('The chebychev ball has either a radius of zero, or the problem is not feasible!')
+            if not self._lp_feasible(self.equality_indices):
+                out.append('The multiparametric program, as stated, is not feasible!')
+        return out
+
+    def feasible_space_chebychev_ball(self):
+        PA = numpy.vstack([numpy.hstack([self.A, -self.F]),
+                           numpy.hstack([numpy.zeros((self.A_t.shape[0], self.num_x())), self.A_t])])
+        Pb = numpy.vstack([self.b, self.b_t])
+        return chebyshev_ball(PA, Pb, equality_constraints=self.equality_indices, solver=self.solver)
+
+    def feasible_theta_point(self) -> Optional[numpy.ndarray]:
+        sol = self.feasible_space_chebychev_ball()
+        return None if sol is None else sol.sol[self.num_x():self.num_x() + self.num_t()].reshape(-1, 1)
+
+    def valid_parameter_realization(self, theta_point) -> bool:
+        return bool(numpy.all(self.A_t @ theta_point <= self.b_t))
+
+    def solve_theta(self, theta_point: numpy.ndarray):
+        """The LP at a fixed theta (mplp_program.py:324-352)."""
+        if not self.valid_parameter_realization(theta_point):
+            return None
+        sol = self.solver.solve_lp(self.H @ theta_point + self.c, self.A, self.b + self.F @ theta_point,
+                                   self.equality_indices)
+        if sol is not None:
+            sol.obj += float((self.c_c + self.c_t.T @ theta_point + 0.5 * theta_point.T @ self.Q_t @ theta_point)[0, 0])
+        return sol
+
+    # ---- per-active-set primitives ----------------------------------------------------------------------------------
+    def _lp_feasible(self, active_set) -> bool:
+        PA = ppopt_block([[self.A, -self.F], [numpy.zeros((self.A_t.shape[0], self.num_x())), self.A_t]])
+        Pb = ppopt_block([[self.b], [self.b_t]])
+        return self.solver.solve_lp(numpy.zeros((self.num_x() + self.num_t(), 1)), PA, Pb, list(active_set)) is not None
+
+    def engine(self, device: int = 0):
+        """The device-resident twin of this program (created on first use; dropped when the rows change)."""
+        from . import _lib
+        if self._engine is None or self._engine.device != device:
+            Q = getattr(self, 'Q', None)
+            self._engine = _lib.Engine(self.A, self.b, self.F, self.c, self.H, Q, self.A_t, self.b_t,
+                                       len(self.equality_indices), device=device)
+        return self._engine
+
+    def _device_status(self, active_set) -> int:
+        eng = self.engine()
+        cand = numpy.asarray(list(active_set), dtype=numpy.int32).reshape(1, -1)
+        status, *_ = eng.check_level(cand, numpy.zeros((0, 2), dtype=numpy.uint64), False)
+        return int(status[0])
+
+    def check_active_set_rank(self, active_set: List[int]) -> bool:
+        return is_full_rank(self.A, list(active_set))
+
+    def check_feasibility(self, active_set: List[int], check_rank=True) -> bool:
+        """Rank test + feasibility of {Ax <= b + F theta, A_t theta <= b_t, rows active_set active}
+        (mplp_program.py:411-444).  With the rank test it is the device verdict; without it, the LP alone."""
+        if not check_rank:
+            return self._lp_feasible(active_set)
+        from . import _lib
+        return self._device_status(active_set) != _lib.INFEASIBLE
+
+    def check_optimality(self, active_set) -> bool:
+        """True when some theta makes the active set optimal (mplp_program.py:446-569, mpqp_program.py:203-322; the
+        reference returns a dict or None and the drivers only use its truth value)."""
+        from . import _lib
+        return self._device_status(active_set) in (_lib.OPTIMAL_NO_REGION, _lib.REGION)
+
+    def optimal_control_law(self, active_set: List[int]) -> Tuple:
+        """(A_x, b_x, A_l, b_l) via the pseudo-inverse of the active rows (mplp_program.py:372-395)."""
+        aux = numpy.linalg.pinv(self.A[active_set])
+        return aux @ self.F[active_set], aux @ self.b[active_set], -aux.T @ self.H, -aux.T @ self.c

@@ -1,0 +1,90 @@
+"""Shared test helpers.  GPU tests are marked ``@pytest.mark.gpu``; everything else runs on CPU.
+
+The CPU oracle (oracle/) is the checker here and nowhere else.  Golden vectors under tests/golden/ were produced
+by importing the real reference (oracle/ref_harness/gen_goldens.py); tests never read /root/reference.
+"""
+import os
+import sys
+
+import numpy
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+GOLDEN = os.path.join(ROOT, 'tests', 'golden')
+
+
+def pytest_configure(config):
+    config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
+
+
+def load_golden(name):
+    return numpy.load(os.path.join(GOLDEN, name + '.npz'))
+
+
+def golden_regions(g):
+    """{active-set tuple: dict of fields} from the packed R_* arrays of a golden file."""
+    out = {}
+    for i in range(len(g['R_k'])):
+        k, ne = int(g['R_k'][i]), int(g['R_nE'][i])
+        unpad = lambda a: [int(v) for v in a if v >= 0]
+        out[tuple(int(v) for v in g['R_active'][i][:k])] = {
+            'A': g['R_A'][i], 'b': g['R_b'][i], 'C': g['R_C'][i][:k], 'd': g['R_d'][i][:k],
+            'E': g['R_E'][i][:ne], 'f': g['R_f'][i][:ne], 'omega_set': unpad(g['R_omega'][i]),
+            'lambda_set': unpad(g['R_lambda'][i]), 'regular_set': [unpad(g['R_regular_idx'][i]),
+                                                                   unpad(g['R_regular_con'][i])]}
+    return out
+
+
+def rel_err(a, b):
+    a, b = numpy.asarray(a, float).ravel(), numpy.asarray(b, float).ravel()
+    if a.size == 0 and b.size == 0:
+        return 0.0
+    return float(numpy.max(numpy.abs(a - b) / (1.0 + numpy.abs(b))))
+
+
+def rows_match(E1, f1, E2, f2, tol=1e-8):
+    """Set equality of the rows [E | f] under a tolerance (order and exact duplicates ignored)."""
+    R1 = numpy.hstack([numpy.asarray(E1), numpy.asarray(f1).reshape(-1, 1)])
+    R2 = numpy.hstack([numpy.asarray(E2), numpy.asarray(f2).reshape(-1, 1)])
+    def covered(X, Y):
+        return all(numpy.min(numpy.max(numpy.abs(Y - x) / (1.0 + numpy.abs(x)), axis=1)) <= tol for x in X)
+    if len(R1) == 0 or len(R2) == 0:
+        return len(R1) == len(R2)
+    return covered(R1, R2) and covered(R2, R1)
+
+
+def kkt_condition(P, active_set):
+    """cond of the KKT matrix of mpqp_program.py:182 for a presolved problem object with .A/.Q."""
+    a = list(active_set)
+    A_hat = P.A[a]
+    k = len(a)
+    if not getattr(P, 'is_qp', True):
+        return float(numpy.linalg.cond(A_hat)) if k == P.n_x else float('inf')
+    M = numpy.block([[A_hat, numpy.zeros((k, k))], [P.Q, A_hat.T]])
+    return float(numpy.linalg.cond(M))
+
+
+def is_knife_edge(P, active_set, cond_limit=1e8):
+    """A verdict is 'knife-edge' when it is not a property of the problem but of a tolerance: the oracle's own verdict
+    changes when its 1e-7 feasibility tolerance moves by two decades either way, or the KKT matrix is ill-conditioned."""
+    from oracle import oracle as orc
+    verdicts = set()
+    try:
+        for tol in (1e-9, 1e-7, 1e-5):
+            orc.set_feas_tol(tol)
+            verdicts.add(P.full_process(active_set))
+    finally:
+        orc.set_feas_tol(1e-7)
+    if len(verdicts) > 1:
+        return True
+    return kkt_condition(P, active_set) > cond_limit
+
+
+@pytest.fixture(scope='session')
+def oracle():
+    from oracle import oracle as orc
+    orc.build()
+    return orc

@@ -1,0 +1,251 @@
+"""Parity of the HIP path with the oracle and with the reference goldens, on a real MI355X, through the C ABI.
+
+Bars (BASELINE.json north_star): region count and active-set indices bit-exact, region coefficients within 1e-8.
+Every per-candidate verdict must equal the reference's verdict unless the candidate is knife-edge in the sense of
+conftest.is_knife_edge (the oracle's own verdict flips with the LP tolerance, or the KKT matrix has condition > 1e8);
+the number of knife-edge exceptions is bounded.
+"""
+import warnings
+
+import numpy
+import pytest
+
+from conftest import golden_regions, is_knife_edge, load_golden, rel_err, rows_match
+
+pytestmark = pytest.mark.gpu
+
+FULL = ['c1_transport_mplp', 'transport_mpqp', 'dblint_n3', 'c2_dblint_n5', 'rand_4_2_10_s0', 'rand_5_3_8_s3',
+        'rand_6_3_12_s1', 'quadtank_n2', 'quadtank_n3']
+PARTIAL = ['c4_rand_20_8_20_s0', 'c3_quadtank_n10']
+COEF_TOL = 1e-8  # north_star: "within 1e-8 on region affine coefficients"
+
+
+def engine_from_golden(g):
+    from ppopt_amd import _lib
+    Q = g['raw_Q'] if 'raw_Q' in g.files else None
+    return _lib.Engine(g['proc_A'], g['proc_b'], g['proc_F'], g['raw_c'], g['raw_H'], Q, g['proc_A_t'], g['proc_b_t'],
+                       len(g['proc_eq']))
+
+
+def run_levels(eng, max_levels=None):
+    """The driver loop of mpqp_hip_combinatorial.solve, keeping per-level candidates, statuses and region records."""
+    from ppopt_amd.mp_solvers.mpqp_hip_combinatorial import unpack_region
+    max_depth = max(eng.n_x, eng.n_t) - eng.n_eq
+    if max_levels is not None:
+        max_depth = min(max_depth, max_levels)
+    eng.pruned_clear()
+    eng.frontier_root()
+    levels, regions = [], []
+    for depth in range(max_depth):
+        gen = depth + 1 != max_depth
+        st = eng.level_run(gen)
+        cands, status = eng.frontier_get(), eng.level_status()
+        rd, ri, idx = eng.level_regions()
+        assert numpy.array_equal(numpy.nonzero(status == 3)[0], idx)
+        regions.extend(unpack_region(rd[j], ri[j], eng.n_x, eng.n_t, eng.n_c, eng.n_tc) for j in range(len(rd)))
+        levels.append((cands, status, st))
+        if not gen or st.n_children == 0:
+            break
+        eng.frontier_advance()
+    return levels, regions
+
+
+def test_lp_batch_bit_identical_to_oracle(oracle):
+    """The generic one-wavefront simplex follows the oracle's pivot rules exactly: same status, same pivot count, the
+    same optimum to the last bit, and the reference's verdict (golden lp_cases)."""
+    from ppopt_amd import _lib
+    g = load_golden('lp_cases')
+    for i in range(int(g['n'])):
+        A, b, c, eq = g[f'lp{i}_A'], g[f'lp{i}_b'], g[f'lp{i}_c'], g[f'lp{i}_eq']
+        flags = numpy.zeros((1, A.shape[0]), dtype=numpy.uint8)
+        flags[0, eq] = 1
+        st, x, obj, it = _lib.lp_solve_batch(A[None], b.reshape(1, -1), c.reshape(1, -1), flags)
+        ost, ox, oobj, oit = oracle.lp_solve(c, A, b, eq)
+        assert st[0] == ost and it[0] == oit, i
+        assert (st[0] == 0) == bool(g[f'lp{i}_ok']), i
+        if ost == 0:
+            assert obj[0] == oobj and numpy.array_equal(x[0], ox), i
+
+
+def test_lp_batch_shared_matrix_many_instances(oracle):
+    """Presolve shape: one (A, b), a different equality row per instance (constraint_utilities.py:186-200)."""
+    from ppopt_amd import _lib
+    g = load_golden('c2_dblint_n5')
+    PA = numpy.vstack([numpy.hstack([g['proc_A'], -g['proc_F']]),
+                       numpy.hstack([numpy.zeros((g['proc_A_t'].shape[0], g['proc_A'].shape[1])), g['proc_A_t']])])
+    Pb = numpy.concatenate([g['proc_b'].ravel(), g['proc_b_t'].ravel()])
+    eq0 = [int(v) for v in g['proc_eq']]
+    m = PA.shape[0]
+    flags = numpy.zeros((m, m), dtype=numpy.uint8)
+    flags[:, eq0] = 1
+    flags[numpy.arange(m), numpy.arange(m)] = 1
+    st, _, _, it = _lib.lp_solve_batch(PA, Pb, None, flags)
+    for i in range(m):
+        ost, _, _, oit = oracle.lp_solve(None, PA, Pb, sorted(set(eq0 + [i])))
+        assert st[i] == ost and it[i] == oit, i
+
+
+@pytest.mark.parametrize('name', FULL + PARTIAL)
+def test_level_trace_and_regions_match_reference(oracle, name):
+    g = load_golden(name)
+    P = oracle.problem_from_golden(g)
+    eng = engine_from_golden(g)
+    nl = int(g['n_levels'])
+    levels, regions = run_levels(eng, None if bool(g['complete']) else nl)
+    total = mismatches = 0
+    diverged = False
+    for i, (cands, status, st) in enumerate(levels[:nl]):
+        gc, gv = g[f'L{i}_cands'], g[f'L{i}_verdict']
+        ref = {tuple(r): int(v) for r, v in zip(gc.tolist(), gv.tolist())}
+        if not diverged and not numpy.array_equal(cands, gc):
+            diverged = True  # only possible after a knife-edge verdict changed the pruning upstream
+        for cand, v in zip(cands.tolist(), status.tolist()):
+            key = tuple(cand)
+            if key not in ref:
+                continue
+            total += 1
+            if ref[key] != v:
+                assert is_knife_edge(P, cand), f'{name} level {i}: {cand} gpu {v} reference {ref[key]} (robust candidate)'
+                mismatches += 1
+    assert total >= 0.98 * sum(len(g[f'L{i}_verdict']) for i in range(nl))
+    assert mismatches <= max(2, total // 500), f'{mismatches} knife-edge verdicts out of {total}'
+    if mismatches == 0:
+        assert not diverged
+    # regions: bit-exact active sets and index sets, coefficients within 1e-8
+    ref = golden_regions(g)
+    got = {tuple(r.active_set): r for r in regions}
+    levels_k = {len(k) for k in ref if len(k) > len(g['proc_eq'])}
+    only_ref = [k for k in ref if k not in got and len(k) > len(g['proc_eq'])]
+    only_gpu = [k for k in got if k not in ref and len(k) in levels_k and bool(g['complete'])]
+    for key in only_ref + only_gpu:
+        assert is_knife_edge(P, list(key)), f'{name}: region set differs at robust active set {key}'
+    assert len(only_ref) + len(only_gpu) <= 2
+    for key, r in got.items():
+        if key not in ref:
+            continue
+        q = ref[key]
+        for fld in ('A', 'b', 'C', 'd'):
+            assert rel_err(getattr(r, fld), q[fld]) <= COEF_TOL, (name, key, fld)
+        same_sets = (r.omega_set == q['omega_set'] and r.lambda_set == q['lambda_set'] and r.regular_set == q['regular_set'])
+        if not same_sets:
+            assert is_knife_edge(P, list(key), cond_limit=1e6), f'{name}: facet sets differ at robust region {key}'
+            continue
+        assert rows_match(r.E, r.f, q['E'], q['f'], COEF_TOL), (name, key)
+    eng.close()
+
+
+def test_solve_mpqp_region_counts_like_reference_tests():
+    """tests/other_tests/test_solve_mpqp.py:9-22 (transport mpQP: 4 regions for every combinatorial variant) and
+    doc/mplp_tut (3 regions): the public API end to end -- constructor presolve on the device LP plug included."""
+    from ppopt_amd import MPLP_Program, MPQP_Program, problem_generator as pg
+    from ppopt_amd.mp_solvers.solve_mpqp import mpqp_algorithm, solve_mpqp
+    d = pg.transport_mpqp_data()
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        prog = MPQP_Program(d['A'], d['b'], d['c'], d['H'], d['Q'], d['A_t'], d['b_t'], d['F'])
+        for algo in (mpqp_algorithm.combinatorial, mpqp_algorithm.combinatorial_parallel, mpqp_algorithm.combinatorial_parallel_exp):
+            sol = solve_mpqp(prog, algo)
+            assert sol is not None and len(sol.critical_regions) == 4
+        assert sol.is_overlapping
+        d = pg.transport_mplp_data()
+        lp = MPLP_Program(d['A'], d['b'], d['c'], d['H'], d['A_t'], d['b_t'], d['F'])
+        assert len(solve_mpqp(lp, mpqp_algorithm.combinatorial)) == 3
+    # the solution is usable: x*(theta) of the region containing theta satisfies the constraints
+    th = numpy.array([[200.0], [300.0]])
+    x = sol.evaluate(th)
+    assert x is not None and numpy.all(prog.A @ x <= prog.b + prog.F @ th + 1e-6)
+
+
+@pytest.mark.parametrize('name', ['c2_dblint_n5', 'c4_rand_20_8_20_s0', 'c1_transport_mplp'])
+def test_device_presolve_matches_reference(name):
+    """The constructor's presolve with its LPs on the device reproduces the reference's processed matrices."""
+    from test_host_logic import build_program
+    from ppopt_amd import Solver
+    g = load_golden(name)
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        prog = build_program(g, Solver())
+    assert prog.equality_indices == [int(v) for v in g['proc_eq']]
+    for fld in ('A', 'b', 'F', 'A_t', 'b_t'):
+        assert getattr(prog, fld).shape == g['proc_' + fld].shape
+        assert numpy.allclose(getattr(prog, fld), g['proc_' + fld], rtol=1e-13, atol=1e-13)
+
+
+def test_program_primitives_on_device(oracle):
+    """check_feasibility / check_optimality of the program object (reference: other_tests/test_mpqp_utils.py:5-21)."""
+    from ppopt_amd import MPQP_Program
+    A = numpy.array([[1.0], [-1.0]]); b = numpy.array([[5.0], [0.0]]); F = numpy.array([[1.0], [1.0]])
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        prob = MPQP_Program(A, b, numpy.array([[0.0]]), numpy.zeros((1, 1)), numpy.array([[1.0]]), numpy.array([[-1.0], [1.0]]),
+                            numpy.array([[0.0], [1.0]]), F)
+    assert prob.check_optimality([]) and not prob.check_optimality([0])
+    assert prob.check_optimality([1]) and not prob.check_optimality([0, 1])
+    assert prob.check_feasibility([]) and prob.check_feasibility([0])
+
+
+def test_host_buffer_operator_equals_resident_pipeline():
+    """mpc_check_level (host buffers in/out, the pool.map drop-in) gives the same statuses, regions and children as
+    the frontier-resident calls, including child pruning against a caller-supplied pruned list."""
+    from ppopt_amd import _lib
+    g = load_golden('rand_6_3_12_s1')
+    eng = engine_from_golden(g)
+    levels, _ = run_levels(eng, 3)
+    cands, status, st = levels[2]
+    pruned = [tuple(c) for lv in levels[:2] for c, v in zip(lv[0].tolist(), lv[1].tolist()) if v in (0, 2)]
+    s2, rd, ri, idx, kids = eng.check_level(cands, _lib.sets_to_masks(pruned), True)
+    assert numpy.array_equal(s2, status)
+    assert numpy.array_equal(kids, g['L3_cands'])
+    assert len(rd) == int(st.n_regions) and numpy.array_equal(idx, numpy.nonzero(status == 3)[0])
+    eng.close()
+
+
+def test_full_size_properties_c4():
+    """Config 4 at depth 4 (~2e5 candidates, beyond what the oracle finishes quickly): size-independent properties.
+    Every child extends its parent by one larger index; no child is a superset of a pruned set; statuses partition the
+    level; region records are self-consistent (unit-norm E rows, active set == candidate, C rows == |active set|);
+    the run is deterministic."""
+    from ppopt_amd import _lib
+    g = load_golden('c4_rand_20_8_20_s0')
+    eng = engine_from_golden(g)
+    levels, regions = run_levels(eng, 4)
+    pruned = set()
+    for li, (cands, status, st) in enumerate(levels):
+        assert sum(st.n_status) == len(cands) and numpy.all(status <= 5)
+        assert numpy.all(numpy.diff(cands, axis=1) > 0)
+        if li + 1 < len(levels):
+            nxt = levels[li + 1][0]
+            parents = {tuple(c) for c, v in zip(cands.tolist(), status.tolist()) if v in (1, 3, 4, 5)}
+            assert all(tuple(c[:-1]) in parents for c in nxt.tolist())
+            masks = _lib.sets_to_masks(sorted(pruned)) if pruned else numpy.zeros((0, 2), dtype=numpy.uint64)
+            cm = _lib.sets_to_masks(nxt.tolist())
+            for pm in masks:
+                assert not numpy.any(numpy.all((cm & pm) == pm, axis=1))
+            pruned |= {tuple(c) for c, v in zip(cands.tolist(), status.tolist()) if v in (0, 2)}
+    assert len(regions) == sum(int(l[2].n_regions) for l in levels)
+    for r in regions:
+        assert numpy.allclose(numpy.linalg.norm(r.E, axis=1), 1.0, atol=1e-12)
+        assert r.C.shape[0] == len(r.active_set) and r.A.shape == (eng.n_x, eng.n_t)
+        assert numpy.all(r.f + 1e-7 >= r.E @ numpy.zeros((eng.n_t, 1)) - 1e30)
+    levels2, regions2 = run_levels(eng, 4)
+    for a, b in zip(levels, levels2):
+        assert numpy.array_equal(a[0], b[0]) and numpy.array_equal(a[1], b[1])
+    assert all(numpy.array_equal(r.E, s.E) and r.active_set == s.active_set for r, s in zip(regions, regions2))
+    eng.close()
+
+
+def test_control_allocation_singular_kkt_is_a_status():
+    """Config 5: the reference raises LinAlgError (mpqp_program.py:187).  Here a singular KKT matrix is status 4, never a
+    region, and the solve completes; regions only come from active sets with at least rank(Q)-many... i.e. a solvable KKT."""
+    from ppopt_amd import _lib
+    g = load_golden('c5_control_allocation')
+    eng = engine_from_golden(g)
+    levels, regions = run_levels(eng)
+    assert levels[0][2].n_status[_lib.SINGULAR_KKT] == len(levels[0][0])  # every singleton has a singular KKT matrix
+    Q, A = g['raw_Q'], g['proc_A']
+    for r in regions:
+        a = r.active_set
+        M = numpy.block([[A[a], numpy.zeros((len(a), len(a)))], [Q, A[a].T]])
+        assert numpy.linalg.cond(M) < 1e12
+    assert len(regions) > 100
+    eng.close()

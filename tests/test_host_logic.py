@@ -1,0 +1,139 @@
+"""Host layer on CPU: presolve parity with the reference (golden vectors), constraint utilities, generators, result
+objects, dispatch.  Programs are built with the oracle as the deterministic-solver plug (``solver=`` argument of the
+constructor, the reference's own plug point) because the product LP backend needs the GPU."""
+import numpy
+import pytest
+
+from conftest import load_golden
+from ppopt_amd import MPLP_Program, MPQP_Program, CriticalRegion, Solution
+from ppopt_amd import problem_generator as pg
+from ppopt_amd.utils import constraint_utilities as cu
+from ppopt_amd.utils.general_utils import make_column, ppopt_block, select_not_in_list
+
+PRESOLVE = ['c1_transport_mplp', 'transport_mpqp', 'dblint_n3', 'c2_dblint_n5', 'rand_4_2_10_s0', 'rand_5_3_8_s3',
+            'rand_6_3_12_s1', 'quadtank_n2', 'quadtank_n3', 'c5_control_allocation', 'c4_rand_20_8_20_s0',
+            'c3_quadtank_n10']
+
+
+def build_program(g, solver):
+    raw = {k[4:]: g[k] for k in g.files if k.startswith('raw_')}
+    eq = [int(v) for v in raw['eq']]
+    if bool(g['is_mplp']):
+        return MPLP_Program(raw['A'], raw['b'], raw['c'], raw['H'], raw['A_t'], raw['b_t'], raw['F'],
+                            equality_indices=eq, solver=solver)
+    return MPQP_Program(raw['A'], raw['b'], raw['c'], raw['H'], raw['Q'], raw['A_t'], raw['b_t'], raw['F'],
+                        equality_indices=eq, solver=solver)
+
+
+@pytest.mark.parametrize('name', PRESOLVE)
+def test_presolve_matches_reference(oracle, name):
+    """raw constructor inputs -> processed (A, b, F, A_t, b_t, equality_indices) exactly as the reference's
+    constructor produces them (mplp_program.py:60-134, 285-306): this fixes the meaning of every active-set index."""
+    g = load_golden(name)
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        prog = build_program(g, oracle.OracleSolver())
+    assert prog.equality_indices == [int(v) for v in g['proc_eq']]
+    for fld in ('A', 'b', 'F', 'A_t', 'b_t'):
+        ref = g['proc_' + fld]
+        got = getattr(prog, fld)
+        assert got.shape == ref.shape, fld
+        assert numpy.allclose(got, ref, rtol=1e-13, atol=1e-13), fld
+
+
+def test_generators_reproduce_golden_inputs():
+    """The problem builders regenerate, bit for bit, the raw matrices the goldens were produced from."""
+    cases = {'rand_4_2_10_s0': pg.generate_mpqp_data(4, 2, 10, 0), 'rand_6_3_12_s1': pg.generate_mpqp_data(6, 3, 12, 1),
+             'c4_rand_20_8_20_s0': pg.generate_mpqp_data(20, 8, 20, 0), 'c2_dblint_n5': pg.double_integrator_data(5),
+             'c3_quadtank_n10': pg.quad_tank_data(10), 'c5_control_allocation': pg.control_allocation_data(),
+             'c1_transport_mplp': pg.transport_mplp_data(), 'transport_mpqp': pg.transport_mpqp_data()}
+    for name, d in cases.items():
+        g = load_golden(name)
+        for fld in ('A', 'b', 'c', 'H', 'Q', 'A_t', 'b_t', 'F'):
+            if d[fld] is None:
+                assert 'raw_' + fld not in g.files
+            else:
+                assert numpy.array_equal(d[fld], g['raw_' + fld]), (name, fld)
+
+
+def test_scale_and_zero_rows():
+    """other_tests/test_constraint_utilities.py: scaling to unit norm, zero / duplicate row handling"""
+    A = numpy.array([[3.0, 4.0], [0.0, 2.0]]); b = numpy.array([[5.0], [4.0]])
+    As, bs = cu.scale_constraint(A, b)
+    assert numpy.allclose(numpy.linalg.norm(As, axis=1), 1) and numpy.allclose(bs.ravel(), [1.0, 2.0])
+    A = numpy.array([[1.0, 0], [0, 0], [1.0, 0], [0, 1e-9]]); b = numpy.array([[1.0], [2.0], [1.0], [3.0]])
+    A1, b1 = cu.remove_zero_rows(A, b)
+    assert A1.shape[0] == 3
+    A2, b2 = cu.remove_duplicate_rows(A, b)
+    assert A2.shape[0] == 3 and numpy.array_equal(A2[0], [1.0, 0])
+    assert cu.numerically_nonzero_rows(A) == [0, 2]
+    A3, b3 = cu.remove_numerically_zero_rows(A, b)
+    assert A3.shape[0] == 2
+    kept, gone = cu.get_indices_of_zero_rows(A)
+    assert kept == [0, 2] and gone == [1, 3]
+
+
+def test_implicit_equalities_and_reduction():
+    """other_tests/test_constraint_utilities.py:153-196 style known answers"""
+    A = numpy.array([[1.0, 1.0], [-1.0, -1.0], [1.0, 0.0], [2.0, 0.0]]); b = numpy.array([[1.0], [-1.0], [3.0], [6.0]])
+    assert cu.detect_implicit_equalities(A, b) == [[0, 1]]
+    F = numpy.zeros((4, 1))
+    A2, b2, F2, eq = cu.find_implicit_equalities(A, b, F, [])
+    assert eq == [0] and A2.shape[0] == 3 and numpy.array_equal(A2[0], [1.0, 1.0])
+    # dependent equalities are reduced (the reference's loop never examines the last row)
+    Ae = numpy.array([[1.0, 0.0], [2.0, 0.0], [0.0, 1.0], [1.0, 1.0]]); be = numpy.ones((4, 1)); Fe = numpy.zeros((4, 1))
+    A3, b3, F3, eq3 = cu.generate_reduced_equality_constraints(Ae, be, Fe, [0, 1, 2])
+    assert eq3 == [0] and A3.shape[0] == 2
+    # rows without x move to the parametric block
+    A4 = numpy.array([[1.0, 0.0], [0.0, 0.0]]); b4 = numpy.array([[1.0], [2.0]]); F4 = numpy.array([[0.0], [1.0]])
+    A5, b5, F5, At5, bt5 = cu.process_program_constraints(A4, b4, F4, numpy.array([[1.0]]), numpy.array([[5.0]]))
+    assert A5.shape[0] == 1 and At5.shape[0] == 2 and numpy.allclose(At5[1], [-1.0]) and bt5[1, 0] == 2.0
+
+
+def test_block_helpers():
+    a, b = numpy.ones((2, 2)), numpy.zeros((2, 1))
+    assert numpy.array_equal(ppopt_block([[a, b], [b.T @ a, numpy.array([[7.0]])]]), numpy.block([[a, b], [b.T @ a, numpy.array([[7.0]])]]))
+    assert numpy.array_equal(ppopt_block([a, b]), numpy.hstack([a, b]))
+    assert make_column([1, 2, 3]).shape == (3, 1)
+    assert select_not_in_list(numpy.arange(10).reshape(5, 2), [1, 3]).tolist() == [[0, 1], [4, 5], [8, 9]]
+
+
+def test_critical_region_and_solution():
+    """other_tests/test_critical_region.py, mpqp_solver_tests/test_solution.py: the square region of test_fixtures.py:66-75"""
+    E = numpy.vstack([numpy.eye(2), -numpy.eye(2)]); f = make_column([1, 1, 0, 0])
+    cr = CriticalRegion(numpy.eye(2), numpy.zeros((2, 1)), numpy.eye(2), numpy.zeros((2, 1)), E, f, [])
+    th = make_column([0.5, 0.5])
+    assert numpy.array_equal(cr.evaluate(th), th) and numpy.array_equal(cr.lagrange_multipliers(th), th)
+    assert cr.is_inside(th) and not cr.is_inside(make_column([2.0, 0.5]))
+    assert cr.get_constraints()[0] is E and 'Critical region with active set []' in repr(cr)
+
+    class _P:
+        def num_t(self): return 2
+        def evaluate_objective(self, x, t): return float((x.T @ x)[0, 0])
+    sol = Solution(_P(), [])
+    assert len(sol) == 0 and sol.evaluate(th) is None and sol.get_region(th) is None
+    sol.add_region(cr)
+    assert len(sol) == 1 and sol.get_region(th) is cr and numpy.array_equal(sol.evaluate(th), th)
+    sol.is_overlapping = True
+    cr2 = CriticalRegion(0.5 * numpy.eye(2), numpy.zeros((2, 1)), numpy.eye(2), numpy.zeros((2, 1)), E, f, [1])
+    sol.add_region(cr2)
+    assert sol.get_region(th) is cr2 and sol.evaluate_objective(th) == pytest.approx(0.125)
+    assert sol.theta_dim() == 2
+
+
+def test_solve_mpqp_rejects_non_enum_and_out_of_scope():
+    """other_tests/test_solve_mpqp.py:94-100: a string instead of the enum raises TypeError"""
+    from ppopt_amd.mp_solvers.solve_mpqp import mpqp_algorithm, solve_mpqp
+    with pytest.raises(TypeError):
+        solve_mpqp(None, algorithm='cambinatorial')
+    with pytest.raises(NotImplementedError):
+        solve_mpqp(None, algorithm=mpqp_algorithm.geometric)
+    assert {a.value for a in mpqp_algorithm} >= {'combinatorial', 'p combinatorial', 'p combinatorial exp', 'graph'}
+    assert 'mpqp_algorithm.combinatorial' in mpqp_algorithm.all_algos()
+
+
+def test_mask_round_trip():
+    from ppopt_amd._lib import masks_to_sets, sets_to_masks
+    sets = [(0,), (5, 63, 64), (127,), (1, 2, 3, 70, 100)]
+    assert masks_to_sets(sets_to_masks(sets)) == sets

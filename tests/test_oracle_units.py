@@ -1,0 +1,134 @@
+"""Known-answer tests the reference holds for the primitives on the path, replayed on the oracle and on the host
+mirrors.  Each case cites the reference test it restates (paths relative to /root/reference/tests)."""
+import numpy
+import pytest
+
+from ppopt_amd.mp_solvers.solver_utils import CombinationTester, generate_children_sets
+from ppopt_amd.utils import constraint_utilities as cu
+
+
+def _transport(Q=True):
+    A = numpy.array([[1, 1, 0, 0], [0, 0, 1, 1], [-1, 0, -1, 0], [0, -1, 0, -1], [-1, 0, 0, 0], [0, -1, 0, 0],
+                     [0, 0, -1, 0], [0, 0, 0, -1]], float)
+    b = numpy.array([350, 600, 0, 0, 0, 0, 0, 0], float).reshape(8, 1)
+    F = numpy.array([[0, 0], [0, 0], [-1, 0], [0, -1], [0, 0], [0, 0], [0, 0], [0, 0]], float)
+    return A, b, F
+
+
+def test_is_full_rank_cases(oracle):
+    """other_tests/test_constraint_utilities.py:81-111"""
+    A = numpy.eye(5)
+    assert cu.is_full_rank(A) and cu.is_full_rank(A, [0, 1, 2]) and cu.is_full_rank(A, [])
+    B = numpy.array([[1, 0, 0], [1, 0, 0], [0, 0, 1]], float)
+    assert not cu.is_full_rank(B)
+    assert not cu.is_full_rank(B, [0, 1])
+    assert cu.is_full_rank(B, [0, 2])
+    for M, rows, expect in ((A, [0, 1, 2], True), (B, [0, 1], False), (B, [0, 2], True), (B, [0, 1, 2], False)):
+        idx = numpy.array(rows, dtype=numpy.int32)
+        Mc = numpy.ascontiguousarray(M)
+        got = oracle.lib().orc_is_full_rank(Mc.ctypes.data_as(oracle._c_double_p), M.shape[1],
+                                            idx.ctypes.data_as(oracle._c_int32_p), len(rows)) == 1
+        assert got == expect
+
+
+def test_singular_values_match_lapack(oracle):
+    rng = numpy.random.default_rng(0)
+    for m, n in ((3, 5), (6, 6), (9, 4), (20, 20)):
+        M = rng.normal(size=(m, n))
+        assert numpy.allclose(oracle.singular_values(M), numpy.linalg.svd(M, compute_uv=False), rtol=1e-12, atol=1e-13)
+    M = numpy.array([[1.0, 2.0, 3.0], [2.0, 4.0, 6.0], [1.0, 0.0, 1.0]])
+    sv = oracle.singular_values(M)
+    assert sv[-1] <= 1e-15 * sv[0]
+
+
+def test_combination_tester_truth_table():
+    """mpqp_solver_tests/test_mpqp_combinatorial.py:9-20 with the fixture of test_fixtures.py:164-173"""
+    c = CombinationTester()
+    for s in ([1], [2], [3], [1, 5]):
+        c.add_combo(s)
+    for s in ([1], [2], [3], [1, 5], [1, 5, 2]):
+        assert not c.check(s)
+    for s in ([0, 4], [5], [5, 6], [5, 8]):
+        assert c.check(s)
+    n = len(c.combos)
+    c.add_combo([])
+    assert len(c.combos) == n + 1
+
+
+def test_generate_children_known_answers(oracle):
+    """mpqp_solver_tests/test_mpqp_combinatorial.py:37-82"""
+    blank, filled = CombinationTester(), CombinationTester()
+    for s in ([1], [2], [3], [1, 5]):
+        filled.add_combo(s)
+    assert generate_children_sets([], 8, blank) == [[i] for i in range(8)]
+    assert generate_children_sets([1, 2, 3, 5], 8, blank) == [[1, 2, 3, 5, 6], [1, 2, 3, 5, 7]]
+    assert generate_children_sets([], 8, filled) == [[0], [4], [5], [6], [7]]
+    assert generate_children_sets([0], 8, filled) == [[0, 4], [0, 5], [0, 6], [0, 7]]
+    assert generate_children_sets([0], 3, blank) == [[0, 1], [0, 2]]
+    assert generate_children_sets([0, 1], 3, blank) == [[0, 1, 2]]
+    assert generate_children_sets([0], 8) == [[0, i] for i in range(1, 8)]
+    # the same through the oracle's C routine
+    A, b, F = _transport()
+    P = oracle.OracleProblem(A, b, F, numpy.ones(4), numpy.zeros((4, 2)), numpy.eye(4), numpy.vstack([numpy.eye(2), -numpy.eye(2)]),
+                             numpy.array([1000, 1000, 0, 0.0]), 0)
+    kids = P.generate_children(numpy.array([[0]], dtype=numpy.int32), numpy.array([1], dtype=numpy.uint8), [(1,), (2,), (3,), (1, 5)])
+    assert kids.tolist() == [[0, 4], [0, 5], [0, 6], [0, 7]]
+    kids = P.generate_children(numpy.array([[1, 2, 3, 5]], dtype=numpy.int32), numpy.array([3], dtype=numpy.uint8), [])
+    assert kids.tolist() == [[1, 2, 3, 5, 6], [1, 2, 3, 5, 7]]
+    kids = P.generate_children(numpy.array([[0], [1]], dtype=numpy.int32), numpy.array([0, 2], dtype=numpy.uint8), [])
+    assert len(kids) == 0
+
+
+def test_chebyshev_unit_box(oracle):
+    """other_tests/test_chebyshev_ball.py:6-21: the unit box has centre 0 and radius 1"""
+    from ppopt_amd.utils.chebyshev_ball import chebyshev_ball
+    A = numpy.vstack([numpy.eye(3), -numpy.eye(3)])
+    b = numpy.ones((6, 1))
+    sol = chebyshev_ball(A, b, solver=oracle.OracleSolver())
+    assert numpy.allclose(sol.sol, [0, 0, 0, 1.0])
+    # an equality row has no radius term (chebyshev_ball.py:52-54)
+    sol = chebyshev_ball(A, b, equality_constraints=[0], solver=oracle.OracleSolver())
+    assert abs(sol.sol[0] - 1.0) <= 1e-9 and abs(sol.sol[-1] - 1.0) <= 1e-9
+
+
+def test_check_optimality_1d_truth_table(oracle):
+    """other_tests/test_mpqp_utils.py:17-21 on `simple_mpqp_problem` (test_fixtures.py:51-63; the problem is already
+    in presolved form apart from the row scaling, which does not change the answers)"""
+    A = numpy.array([[1.0], [-1.0]]); b = numpy.array([5.0, 0.0]); F = numpy.array([[1.0], [1.0]])
+    nrm = numpy.linalg.norm(numpy.hstack([A, -F]), axis=1)
+    P = oracle.OracleProblem(A / nrm[:, None], b / nrm, F / nrm[:, None], numpy.zeros(1), numpy.zeros((1, 1)), numpy.eye(1),
+                             numpy.array([[-1.0], [1.0]]), numpy.array([0.0, 1.0]), 0)
+    assert P.check_optimality([])
+    assert not P.check_optimality([0])
+    assert P.check_optimality([1])
+    assert not P.check_optimality([0, 1])
+
+
+def test_check_feasibility_cases(oracle):
+    """other_tests/test_mpqp_utils.py:5-14 on `quadratic_program` (test_fixtures.py:91-108: scaled, not reduced)"""
+    A, b, F = _transport()
+    nrm = numpy.linalg.norm(numpy.hstack([A, -F]), axis=1, keepdims=True)
+    P = oracle.OracleProblem(A / nrm, b / nrm, F / nrm, 25 * numpy.ones(4), numpy.zeros((4, 2)),
+                             2.0 * numpy.diag([153.0, 162, 162, 126]), numpy.vstack([numpy.eye(2), -numpy.eye(2)]),
+                             numpy.array([1000, 1000, 0, 0.0]), 0)
+    assert P.check_feasibility([])
+    assert P.check_feasibility([0])
+    # :13-14 `not check_feasibility([6, 7, 8], False)`: without the rank test the indices address the stacked LP
+    # [[A, -F], [0, A_t]], so 8 is the first parametric row (theta_0 = 1000 cannot be supplied with x_2 = x_3 = 0)
+    PA = numpy.vstack([numpy.hstack([P.A, -P.F]), numpy.hstack([numpy.zeros((4, 4)), P.A_t])])
+    st, _, _, _ = oracle.lp_solve(None, PA, numpy.concatenate([P.b, P.b_t]), [6, 7, 8])
+    assert st != 0
+    # mpqp_solver_tests/test_mpqp_combinatorial.py:85-87: [[], [1], [2]] feasible, [0,1,2,3,4] not
+    assert [s for s in ([], [1], [2], [0, 1, 2, 3, 4]) if P.check_feasibility(s)] == [[], [1], [2]]
+
+
+def test_gen_cr_transport_active_sets(oracle):
+    """other_tests/test_mpqp_utils.py:24-30: four active sets of the transport mpQP give a region"""
+    A, b, F = _transport()
+    nrm = numpy.linalg.norm(numpy.hstack([A, -F]), axis=1, keepdims=True)
+    P = oracle.OracleProblem(A / nrm, b / nrm, F / nrm, 25 * numpy.ones(4), numpy.zeros((4, 2)),
+                             2.0 * numpy.diag([153.0, 162, 162, 126]), numpy.vstack([numpy.eye(2), -numpy.eye(2)]),
+                             numpy.array([1000, 1000, 0, 0.0]), 0)
+    for s in ([2, 3], [0, 2, 3], [0, 2, 3, 4]):
+        v, reg = P.gen_cr_from_active_set(s)
+        assert v == oracle.REGION and reg is not None

@@ -11,6 +11,8 @@ def run(name, max_levels=None):
     max_depth = max(eng.n_x, eng.n_t) - eng.n_eq
     eng.frontier_root()
     tot = 0; mism = 0; t0 = time.time(); ms = 0.0; piv = 0; nreg = 0
+    extra = int(sys.argv[sys.argv.index('--extra') + 1]) if '--extra' in sys.argv else 1
+    if not bool(g['complete']): max_depth = min(max_depth, nl + extra)
     for depth in range(max_depth):
         gen = depth + 1 != max_depth
         st = eng.level_run(gen)
@@ -48,4 +50,5 @@ for i in range(int(g['n'])):
         if bad < 6: print('LP', i, 'gpu', st[0], obj[0], it[0], 'oracle', ost, oobj, oit, 'ref ok', ok)
 print('lp_cases mismatches (status/iters/obj bitwise vs oracle):', bad)
 for name in sys.argv[1:]:
+    if name == '--extra': break
     run(name)
