@@ -1,0 +1,227 @@
+#!/usr/bin/env python3
+"""Benchmark of the combinatorial mpQP hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W [--workload c4|c3|c2]
+
+A "step" is one complete pass of the parallel combinatorial algorithm over the workload program: every BFS level
+(verdict -> region -> child generation on the device, region records copied back and turned into CriticalRegion
+objects) plus the final base-set check.  The program's presolved matrices are resident in HBM before the timed region
+starts.  Metric: candidate active sets checked per second, whole job (BASELINE.json); regions/s is reported next to it.
+
+N > 1 is launched by the driver as  python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...  : one
+process per GPU, the frontier of every level sharded over the ranks, one RCCL exchange per level
+(ppopt_amd/distributed.py).  The problem is one program, so total work is fixed: scaling is "strong".
+
+rank 0 prints ONE JSON line.  Besides the contract keys it carries
+  roofline      algorithmic HBM bytes of the dominant kernel over its HIP-event time (SURVEY.md §8(d) formula)
+  cpu_baseline  the CPU oracle (C port of the reference algorithm, OpenMP) timed on a bounded sample of the same
+                candidates on this box's host cores -- a reported baseline, not the target.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+import warnings
+
+import numpy
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+WORKLOADS = {
+    # name: (description, builder, max_levels)
+    'c4': ('random dense mpQP generate_mpqp(n_x=20, n_theta=8, m=20, seed=0): 60 rows, 47 after presolve; '
+           'BFS levels 1-5 (1,151,349 candidate active sets)', lambda pg: pg.generate_mpqp_data(20, 8, 20, 0), 5),
+    'c3': ('quad-tank MPC mpQP, 4 states / 2 inputs, N=10 condensed (n_x=20, n_theta=4, 80 rows after presolve); '
+           'BFS levels 1-4 (1,076,342 candidates)', lambda pg: pg.quad_tank_data(10), 4),
+    'c2': ('double-integrator explicit-MPC mpQP, N=5 (n_x=15, n_theta=2, 32 rows, 10 equalities); full tree '
+           '(4,795 candidates, 9 regions)', lambda pg: pg.double_integrator_data(5), None),
+}
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def build_program(name, device=0):
+    from ppopt_amd import MPQP_Program, Solver, problem_generator as pg
+    d = WORKLOADS[name][1](pg)
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        return MPQP_Program(d['A'], d['b'], d['c'], d['H'], d['Q'], d['A_t'], d['b_t'], d['F'],
+                            equality_indices=d['equality_indices'], solver=Solver(device=device))
+
+
+def algorithmic_bytes(prog, k, rho, n_e):
+    """B_alg per candidate: shared problem block streamed once per wavefront + candidate indices +
+    status/child count + (regions per candidate) x region record."""
+    nx, nt, nc, ntc = prog.num_x(), prog.num_t(), prog.num_constraints(), prog.A_t.shape[0]
+    P = 8 * (nc * (nx + nt + 1) + nx * nx + nx * nt + nx + ntc * (nt + 1))
+    R = 8 * (nt + 1) * (nx + k + n_e) + 4 * (2 * k + n_e)
+    return P + 4 * k + 8 + rho * R
+
+
+def cpu_baseline(prog, frontiers, target_candidates):
+    """Times the CPU oracle on an evenly strided sample of every level's candidates (same mix as the workload)."""
+    from oracle import oracle as orc
+    orc.build()
+    P = orc.OracleProblem(prog.A, prog.b, prog.F, prog.c, prog.H, getattr(prog, 'Q', None), prog.A_t, prog.b_t,
+                          len(prog.equality_indices))
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+    total = sum(len(f) for f in frontiers)
+    frac = min(1.0, target_candidates / max(total, 1))
+    samples = []
+    for f in frontiers:
+        take = max(1, int(round(frac * len(f))))
+        idx = numpy.linspace(0, len(f) - 1, take).astype(numpy.int64)
+        samples.append(numpy.ascontiguousarray(f[idx]))
+    P.check_level(samples[0][:min(8, len(samples[0]))], cores, False)  # warm the thread pool
+    t0 = time.perf_counter()
+    n = 0
+    regions = 0
+    for s in samples:
+        status, _ = P.check_level(s, cores, False)
+        n += len(s)
+        regions += int((status == orc.REGION).sum())
+    dt = time.perf_counter() - t0
+    return {'value': n / dt, 'unit': 'candidate active sets checked/s', 'cores': cores, 'kind': 'port',
+            'sample': f'{n} candidates ({100 * frac:.1f}% of every BFS level, evenly strided), {dt:.1f} s, '
+                      f'{regions} regions; oracle/mpcombi_oracle.c (C port of the reference algorithm, OpenMP)',
+            'regions_per_s': regions / dt}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=5)
+    ap.add_argument('--warmup', type=int, default=1)
+    ap.add_argument('--workload', default='c4', choices=sorted(WORKLOADS))
+    ap.add_argument('--cpu-sample', type=int, default=60000, help='candidates in the CPU baseline sample (0 = skip)')
+    args = ap.parse_args()
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    distributed = world > 1
+    if distributed and args.gpus != world:
+        raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}')
+    if args.gpus > 1 and not distributed:
+        raise SystemExit('launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 '
+                         'bench.py --gpus N ...')
+
+    import torch
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs an MI355X: torch.cuda.is_available() is False (there is no CPU fallback)')
+    torch.cuda.set_device(local_rank)
+    import torch.distributed as dist
+    if distributed:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local_rank))
+
+    import __graft_entry__ as entry
+    if rank == 0:
+        entry.build()
+    if distributed:
+        dist.barrier()
+    from ppopt_amd.mp_solvers import mpqp_hip_combinatorial
+    from ppopt_amd.distributed import HipLevelEngine, solve_distributed
+
+    descr, _, max_levels = WORKLOADS[args.workload]
+    prog = build_program(args.workload, local_rank)
+    engine = HipLevelEngine(prog, local_rank) if distributed else None
+
+    def step(profile):
+        if distributed:
+            return solve_distributed(engine, prog, profile=profile, max_levels=max_levels)
+        return mpqp_hip_combinatorial.solve(prog, device=local_rank, profile=profile, max_levels=max_levels)
+
+    for _ in range(args.warmup):
+        step([])
+
+    def fence():
+        if distributed:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    profiles = []
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        prof = []
+        sol = step(prof)
+        profiles.append(prof)
+    fence()
+    elapsed = time.perf_counter() - t0
+    if distributed:
+        t = torch.tensor([elapsed], dtype=torch.float64, device='cuda')
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # ---- accounting (identical on every rank; rank 0 reports) ----------------------------------------------
+    prof = profiles[-1]
+    levels = [p for p in prof if p['depth'] > 0]
+    candidates = sum(p['candidates'] for p in prof)
+    regions = len(sol.critical_regions)
+    steps = max(args.steps, 1)
+    # per-launch HIP-event times of this rank, summed over all timed steps
+    ms = {kname: sum(p.get(kname, 0.0) for pr in profiles for p in pr) for kname in ('ms_verdict', 'ms_region', 'ms_children')}
+    local_cands = sum(p.get('local_candidates', p['candidates']) for pr in profiles for p in pr if p['depth'] > 0)
+    n_e = float(numpy.mean([r.E.shape[0] for r in sol.critical_regions])) if regions else 0.0
+    rho = regions / max(candidates, 1)
+    bytes_verdict = 0.0
+    for pr in profiles:
+        for p in pr:
+            if p['depth'] > 0:
+                bytes_verdict += algorithmic_bytes(prog, p['k'], rho, n_e) * p.get('local_candidates', p['candidates'])
+    dominant = max(ms, key=ms.get)
+    achieved = bytes_verdict / max(ms['ms_verdict'], 1e-9) / 1e6  # GB/s
+    launches = sum(1 for pr in profiles for p in pr if p['depth'] > 0)
+    out = {
+        'metric': 'candidate active-sets checked/sec (combinatorial mpQP)',
+        'value': candidates * steps / elapsed,
+        'unit': 'candidates/s',
+        'n_gpus': world,
+        'steps': args.steps,
+        'warmup': args.warmup,
+        'ms_per_step': 1e3 * elapsed / steps,
+        'higher_is_better': True,
+        'scaling': 'strong',
+        'vs_baseline': None,
+        'dtype': 'f64',
+        'data': 'synthetic',
+        'config': {'workload': f'{args.workload}: {descr}', 'n_x': prog.num_x(), 'n_theta': prog.num_t(),
+                   'n_c': prog.num_constraints(), 'n_eq': len(prog.equality_indices), 'n_tc': int(prog.A_t.shape[0]),
+                   'candidates_per_step': candidates, 'regions_per_step': regions,
+                   'parallelism': f'frontier sharded over {world} GPU(s), one exchange per BFS level' if distributed else 'single GPU'},
+        'regions_per_s': regions * steps / elapsed,
+        'levels': [{'k': p['k'], 'candidates': p['candidates'], 'status': p['status'], 'regions': p['regions']} for p in levels],
+        'kernel_ms_per_step': {k: v / steps for k, v in ms.items()},
+        'roofline': {'bound': 'hbm', 'kernel': 'k_verdict', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                     'frac': achieved / HBM_PEAK_GBS, 'traffic': None,
+                     'launches': launches, 'avg_launch_ms': ms['ms_verdict'] / max(launches, 1),
+                     'algorithmic_bytes_per_candidate': bytes_verdict / max(local_cands, 1),
+                     'dominant_kernel_by_time': dominant,
+                     'note': 'B_alg = P + 4k + 8 + rho*R (SURVEY.md 8(d)); the path is LDS / fp64-issue bound, not HBM bound: '
+                             'the shared problem block is served from L2 after first touch'},
+    }
+    if rank == 0 and not distributed and args.cpu_sample > 0:
+        # frontiers of every level for the CPU sample: one extra untimed pass
+        eng = prog.engine(local_rank)
+        eng.pruned_clear()
+        eng.frontier_root()
+        frontiers = []
+        for i, p in enumerate(levels):
+            frontiers.append(eng.frontier_get())
+            gen = i + 1 != len(levels)
+            eng.level_run(gen)
+            if gen:
+                eng.frontier_advance()
+        out['cpu_baseline'] = cpu_baseline(prog, frontiers, args.cpu_sample)
+    else:
+        out['cpu_baseline'] = None
+    if rank == 0:
+        print(json.dumps(out))
+    if distributed:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -18,7 +18,9 @@
  * Conventions: plain pointers and sizes, row-major float64, int32 indices, caller-owned buffers that are
  * copied at creation; integer return codes (0 = MPC_OK), never C++ exceptions; per-candidate numerical
  * trouble is a status value, not an error.  A handle is bound to one device and one stream and is not
- * re-entrant; use one handle per GPU.
+ * re-entrant; use one handle per GPU.  Calls that read or write caller-owned memory (host or device pointers) have
+ * completed on the handle's stream when they return; device pointers handed in must be ready (the caller synchronises
+ * its own stream first).
  */
 #ifndef MPCOMBI_H
 #define MPCOMBI_H

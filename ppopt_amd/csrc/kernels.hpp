@@ -41,7 +41,7 @@ struct DevProblem {
     int kmax;           // largest cardinality with a solvable KKT (= min(n_c, n_x))
     int ld_x, ld_t;     // odd tableau strides of the (x,theta) LP and of the theta-space LPs
     int off_T, off_K, off_L, off_E, off_X, n_doubles;  // T tableau, K kkt matrix, L multipliers, E region rows, X x-law
-    int off_as, off_inact, off_colvar, off_rowvar, off_rowkind, off_kept, off_pri, n_ints;
+    int off_as, off_inact, off_colvar, off_rowvar, off_rowkind, off_kept, off_pri, off_stored, n_ints;
 };
 
 struct LevelCounters {
@@ -52,7 +52,7 @@ struct LevelCounters {
 
 struct Smem {
     double *T, *K, *L, *E, *X;
-    int *as, *inact, *colvar, *rowvar, *rowkind, *kept, *pri;
+    int *as, *inact, *colvar, *rowvar, *rowkind, *kept, *pri, *stored;
 };
 
 __device__ __forceinline__ Smem carve(const DevProblem &P, double *base) {
@@ -70,6 +70,7 @@ __device__ __forceinline__ Smem carve(const DevProblem &P, double *base) {
     s.rowkind = ib + P.off_rowkind;
     s.kept = ib + P.off_kept;
     s.pri = ib + P.off_pri;
+    s.stored = ib + P.off_stored;
     return s;
 }
 
@@ -424,11 +425,23 @@ __global__ void __launch_bounds__(64) k_region(DevProblem P, const int32_t *__re
                         if (o < nlam) ri[5 + nc + ntc + n_la] = s.as[e + o];
                         else if (o < nlam + nin) { ri[5 + nc + ntc + nc + n_re] = o - nlam; ri[5 + nc + ntc + nc + nc + n_re] = s.inact[o - nlam]; }
                         else ri[5 + nc + n_om] = o - nlam - nin;
-                        fo[nE] = s.E[row * ldE];
                     }
-                    for (int j = lane; j < nt; j += 64) Eo[nE * nt + j] = s.E[row * ldE + 1 + j];
                     if (o < nlam) n_la++; else if (o < nlam + nin) n_re++; else n_om++;
+                    // exact duplicates of an earlier kept row are not stored again (remove_duplicate_rows, mpqp_utils.py:191;
+                    // the index sets above are unaffected, as in the reference); stored[0..nE) = master rows already written
+                    bool dup = false;
+                    for (int j = lane; j < nE; j += 64) {
+                        const int pr = s.stored[j];
+                        bool same = true;
+                        for (int t = 0; t <= nt; ++t) same = same && (s.E[pr * ldE + t] == s.E[row * ldE + t]);
+                        dup = dup || same;
+                    }
+                    if (__any(dup)) continue;
+                    wave_sync();
+                    if (lane == 0) { fo[nE] = s.E[row * ldE]; s.stored[nE] = row; }
+                    for (int j = lane; j < nt; j += 64) Eo[nE * nt + j] = s.E[row * ldE + 1 + j];
                     nE++;
+                    wave_sync();
                 }
             }
         }

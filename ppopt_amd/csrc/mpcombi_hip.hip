@@ -122,7 +122,7 @@ void chol_apply(const std::vector<double> &L, int n, double *x) {
     }
 }
 
-struct Layout { int off_T, off_K, off_L, off_E, off_X, n_doubles, off_as, off_inact, off_colvar, off_rowvar, off_rowkind, off_kept, off_pri, n_ints, bytes; };
+struct Layout { int off_T, off_K, off_L, off_E, off_X, n_doubles, off_as, off_inact, off_colvar, off_rowvar, off_rowkind, off_kept, off_pri, off_stored, n_ints, bytes; };
 
 Layout make_layout(int size_T, int size_K, int size_L, int size_E, int size_X, int kmax, int n_c, int ld_max, int rows_max, int rows_t) {
     Layout l{};
@@ -133,7 +133,7 @@ Layout make_layout(int size_T, int size_K, int size_L, int size_E, int size_X, i
     int q = 0;
     auto itake = [&](int sz) { int r = q; q += sz; return r; };
     l.off_as = itake(kmax + 1); l.off_inact = itake(n_c + 1); l.off_colvar = itake(ld_max + 2);
-    l.off_rowvar = itake(rows_max + 3); l.off_rowkind = itake(rows_max + 3); l.off_kept = itake(rows_t + 1); l.off_pri = itake(rows_max + 3);
+    l.off_rowvar = itake(rows_max + 3); l.off_rowkind = itake(rows_max + 3); l.off_kept = itake(rows_t + 1); l.off_pri = itake(rows_max + 3); l.off_stored = itake(rows_t + 1);
     l.n_ints = q;
     l.bytes = (l.n_doubles * 8 + l.n_ints * 4 + 15) & ~15;
     return l;
@@ -142,7 +142,7 @@ Layout make_layout(int size_T, int size_K, int size_L, int size_E, int size_X, i
 void apply_layout(DevProblem &P, const Layout &l) {
     P.off_T = l.off_T; P.off_K = l.off_K; P.off_L = l.off_L; P.off_E = l.off_E; P.off_X = l.off_X; P.n_doubles = l.n_doubles;
     P.off_as = l.off_as; P.off_inact = l.off_inact; P.off_colvar = l.off_colvar; P.off_rowvar = l.off_rowvar;
-    P.off_rowkind = l.off_rowkind; P.off_kept = l.off_kept; P.off_pri = l.off_pri; P.n_ints = l.n_ints;
+    P.off_rowkind = l.off_rowkind; P.off_kept = l.off_kept; P.off_pri = l.off_pri; P.off_stored = l.off_stored; P.n_ints = l.n_ints;
 }
 
 int waves_per_cu(int lds_bytes) { return std::max(1, std::min(16, (160 * 1024) / std::max(lds_bytes, 1))); }
@@ -325,7 +325,10 @@ int mpc_frontier_set_device(mpc_handle *h, const int32_t *cand, int64_t n, int32
     if (!h || (!cand && n > 0 && k > 0)) return MPC_ERR_INVALID;
     int rc = frontier_reset(h, n, k);
     if (rc) return rc;
-    if (n > 0 && k > 0) HIP_TRY(h, hipMemcpyAsync(h->frontier.p, cand, (size_t)n * k * sizeof(int32_t), hipMemcpyDeviceToDevice, h->stream));
+    if (n > 0 && k > 0) {
+        HIP_TRY(h, hipMemcpyAsync(h->frontier.p, cand, (size_t)n * k * sizeof(int32_t), hipMemcpyDeviceToDevice, h->stream));
+        HIP_TRY(h, hipStreamSynchronize(h->stream));  // caller-owned source
+    }
     return MPC_OK;
 }
 
@@ -355,7 +358,7 @@ static int pruned_add(mpc_handle *h, const uint64_t *masks, int64_t m, hipMemcpy
     HIP_TRY(h, hipSetDevice(h->device));
     HIP_TRY(h, h->pruned.ensure((size_t)(h->n_pruned + m) * MPC_MASK_WORDS * sizeof(uint64_t), h->stream, true));
     HIP_TRY(h, hipMemcpyAsync(h->pruned.as<uint64_t>() + (size_t)h->n_pruned * MPC_MASK_WORDS, masks, (size_t)m * MPC_MASK_WORDS * sizeof(uint64_t), kind, h->stream));
-    if (kind == hipMemcpyHostToDevice) HIP_TRY(h, hipStreamSynchronize(h->stream));
+    if (masks != h->pruned_new.p) HIP_TRY(h, hipStreamSynchronize(h->stream));  // caller-owned source
     h->n_pruned += m;
     return MPC_OK;
 }
@@ -506,7 +509,7 @@ static int copy_out(mpc_handle *h, void *dst, const void *src, size_t bytes, hip
     if (bytes == 0) return MPC_OK;
     HIP_TRY(h, hipSetDevice(h->device));
     HIP_TRY(h, hipMemcpyAsync(dst, src, bytes, kind, h->stream));
-    if (kind == hipMemcpyDeviceToHost) HIP_TRY(h, hipStreamSynchronize(h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));  // caller-owned memory: complete before returning
     return MPC_OK;
 }
 

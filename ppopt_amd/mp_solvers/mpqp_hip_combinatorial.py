@@ -27,29 +27,38 @@ import numpy
 from .. import _lib
 from ..critical_region import CriticalRegion
 from ..solution import Solution
-from ..utils.constraint_utilities import remove_duplicate_rows
+
+
+def unpack_regions(rec_d: numpy.ndarray, rec_i: numpy.ndarray, n_x: int, n_t: int, n_c: int, n_tc: int) -> List[CriticalRegion]:
+    """Device region records (layout: include/mpcombi.h, mpc_level_regions) -> CriticalRegion objects.  The
+    matrices are sliced for all records at once; E/f arrive already free of exact duplicates (k_region)."""
+    n = len(rec_d)
+    if n == 0:
+        return []
+    o = 0
+    A = rec_d[:, o:o + n_x * n_t].reshape(n, n_x, n_t); o += n_x * n_t
+    b = rec_d[:, o:o + n_x].reshape(n, n_x, 1); o += n_x
+    C = rec_d[:, o:o + n_c * n_t].reshape(n, n_c, n_t); o += n_c * n_t
+    d = rec_d[:, o:o + n_c].reshape(n, n_c, 1); o += n_c
+    E = rec_d[:, o:o + (n_c + n_tc) * n_t].reshape(n, n_c + n_tc, n_t); o += (n_c + n_tc) * n_t
+    f = rec_d[:, o:o + n_c + n_tc].reshape(n, n_c + n_tc, 1)
+    hdr = rec_i[:, :5].tolist()
+    q = 5
+    act = rec_i[:, q:q + n_c].tolist(); q += n_c
+    om = rec_i[:, q:q + n_tc].tolist(); q += n_tc
+    la = rec_i[:, q:q + n_c].tolist(); q += n_c
+    ridx = rec_i[:, q:q + n_c].tolist(); q += n_c
+    rcon = rec_i[:, q:q + n_c].tolist()
+    out = []
+    for j in range(n):
+        k, nE, n_om, n_la, n_re = hdr[j]
+        out.append(CriticalRegion(A[j], b[j], C[j, :k], d[j, :k], E[j, :nE], f[j, :nE], act[j][:k], om[j][:n_om],
+                                  la[j][:n_la], [ridx[j][:n_re], rcon[j][:n_re]]))
+    return out
 
 
 def unpack_region(rec_d: numpy.ndarray, rec_i: numpy.ndarray, n_x: int, n_t: int, n_c: int, n_tc: int) -> CriticalRegion:
-    """One device region record (layout: include/mpcombi.h, mpc_level_regions) -> CriticalRegion."""
-    k, nE, n_om, n_la, n_re = (int(v) for v in rec_i[:5])
-    o = 0
-    A = rec_d[o:o + n_x * n_t].reshape(n_x, n_t).copy(); o += n_x * n_t
-    b = rec_d[o:o + n_x].reshape(-1, 1).copy(); o += n_x
-    C = rec_d[o:o + n_c * n_t].reshape(n_c, n_t)[:k].copy(); o += n_c * n_t
-    d = rec_d[o:o + n_c][:k].reshape(-1, 1).copy(); o += n_c
-    E = rec_d[o:o + (n_c + n_tc) * n_t].reshape(n_c + n_tc, n_t)[:nE].copy(); o += (n_c + n_tc) * n_t
-    f = rec_d[o:o + n_c + n_tc][:nE].reshape(-1, 1).copy()
-    q = 5
-    active = rec_i[q:q + n_c][:k].tolist(); q += n_c
-    omega = rec_i[q:q + n_tc][:n_om].tolist(); q += n_tc
-    lam = rec_i[q:q + n_c][:n_la].tolist(); q += n_c
-    ridx = rec_i[q:q + n_c][:n_re].tolist(); q += n_c
-    rcon = rec_i[q:q + n_c][:n_re].tolist()
-    if n_t > 1:
-        # exact-duplicate rows go last, as in gen_cr_from_active_set (mpqp_utils.py:191)
-        E, f = remove_duplicate_rows(E, f)
-    return CriticalRegion(A, b, C, d, E, f, active, omega, lam, [ridx, rcon])
+    return unpack_regions(rec_d.reshape(1, -1), rec_i.reshape(1, -1), n_x, n_t, n_c, n_tc)[0]
 
 
 def solve(program, num_cores: int = -1, device: int = 0, profile: Optional[List[Dict]] = None,
@@ -70,8 +79,7 @@ def solve(program, num_cores: int = -1, device: int = 0, profile: Optional[List[
         st = eng.level_run(gen_children)
         if collect_regions and st.n_regions:
             rd, ri, _ = eng.level_regions()
-            for j in range(len(rd)):
-                solution.add_region(unpack_region(rd[j], ri[j], n_x, n_t, n_c, n_tc))
+            solution.critical_regions.extend(unpack_regions(rd, ri, n_x, n_t, n_c, n_tc))
         if profile is not None:
             profile.append({'depth': depth + 1, 'k': int(st.k), 'candidates': int(st.n),
                             'status': [int(v) for v in st.n_status], 'regions': int(st.n_regions),
