@@ -287,7 +287,9 @@ class Engine:
         pm = numpy.ascontiguousarray(pruned_masks, dtype=numpy.uint64).reshape(-1, MASK_WORDS)
         status = numpy.zeros(n, dtype=numpy.uint8)
         nreg, nch = ctypes.c_int64(0), ctypes.c_int64(0)
-        rcap, ccap = 0, 0
+        # small levels: capacities that cannot be exceeded, so one call suffices; large levels: ask first
+        rcap = n if n <= 4096 else 0
+        ccap = n * self.n_c if (gen_children and n <= 4096) else 0
         for _ in range(2):
             d = numpy.zeros((max(rcap, 1), self.rec_d))
             i = numpy.zeros((max(rcap, 1), self.rec_i), dtype=numpy.int32)
