@@ -81,6 +81,9 @@ typedef struct {
     int64_t n_pruned_new;  /* masks appended to the pruned list by this level         */
     int64_t lp_pivots;     /* simplex pivots executed by this level (all LPs)         */
     float ms_verdict, ms_region, ms_children, ms_total; /* HIP-event times on the handle's stream */
+    int64_t n_xtheta_lp;   /* candidates whose feasibility needed the large (x,theta) LP */
+    int64_t n_xtheta_fallback; /* ... of which the vertex warm start was abandoned for a from-scratch solve */
+    int64_t wave_cycles[4];    /* k_verdict wavefront cycles in: KKT solve, theta LP, (x,theta) LP, (reserved) */
 } mpc_level_stats;
 
 /* ---- library / device ------------------------------------------------------------------------------ */

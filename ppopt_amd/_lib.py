@@ -38,7 +38,9 @@ class LevelStats(ctypes.Structure):
     _fields_ = [('n', ctypes.c_int64), ('k', ctypes.c_int32), ('kkt_mode', ctypes.c_int32),
                 ('n_status', ctypes.c_int64 * 6), ('n_regions', ctypes.c_int64), ('n_children', ctypes.c_int64),
                 ('n_pruned_new', ctypes.c_int64), ('lp_pivots', ctypes.c_int64), ('ms_verdict', ctypes.c_float),
-                ('ms_region', ctypes.c_float), ('ms_children', ctypes.c_float), ('ms_total', ctypes.c_float)]
+                ('ms_region', ctypes.c_float), ('ms_children', ctypes.c_float), ('ms_total', ctypes.c_float),
+                ('n_xtheta_lp', ctypes.c_int64), ('n_xtheta_fallback', ctypes.c_int64),
+                ('wave_cycles', ctypes.c_int64 * 4)]
 
 
 _lib = None

@@ -37,6 +37,10 @@ struct DevProblem {
     const double *Gt;   // n_c x n_x            row i = (Q^-1 A_i')'
     const double *X0H;  // n_x x (n_t+1)        [-Q^-1 c | -Q^-1 H]
     const double *base; // (n_c+n_tc) x (1+n_x+n_t)   [b | A | -F ; b_t | 0 | A_t]
+    // pre-crashed dictionary of the (x,theta) LP at a feasible vertex of the base polytope (built once per program):
+    // basic slack rows d0_rows (n_d0r) in terms of the nonbasic inequality slacks d0_cols (n_d0c); program
+    // equalities are already eliminated.  d0: n_d0r x (1 + n_d0c), column 0 = value at the vertex.
+    const double *d0; const int *d0_rows; const int *d0_cols; int n_d0r, n_d0c, has_d0;
     // LDS layout (offsets in doubles from the start of dynamic LDS; ints follow the doubles)
     int kmax;           // largest cardinality with a solvable KKT (= min(n_c, n_x))
     int ld_x, ld_t;     // odd tableau strides of the (x,theta) LP and of the theta-space LPs
@@ -47,6 +51,9 @@ struct DevProblem {
 struct LevelCounters {
     unsigned long long status[8];
     unsigned long long pivots;
+    unsigned long long xtheta_lps;  // candidates that needed the large (x,theta) LP
+    unsigned long long xtheta_fallbacks;  // ... of which the warm start from the pre-crashed vertex was abandoned
+    unsigned long long cycles[4];   // wave-cycles (s_memtime) spent in: KKT solve, theta LP, (x,theta) LP, region build
     unsigned int work_verdict, work_region, n_opt, n_pruned_new;
 };
 
@@ -215,6 +222,52 @@ __device__ inline int build_theta_rows(const DevProblem &P, int k, int nin, Smem
     return nlam + nin + P.n_tc;
 }
 
+// (x,theta) feasibility with the rows `as` active, started from the program's pre-crashed dictionary D0 (a feasible
+// vertex of the base polytope): the slack of every active row is fixed at zero -- its column is deleted if it is
+// nonbasic, otherwise it is pivoted out of the basis first -- and phase 1 repairs what that broke.  k - n_eq pivots
+// replace the n_x + n_t crash pivots of the from-scratch LP, on a tableau without the free-variable rows.
+// Returns LP_OPTIMAL / LP_INFEASIBLE / LP_ITERLIMIT, or -1 when a pivot was numerically doubtful (caller falls back).
+__device__ inline int xtheta_from_vertex(const DevProblem &P, int k, Smem &s, Lp &lp) {
+    const int lane = lane_id(), nv = P.n_x + P.n_t, mr = P.n_d0r, nc0 = P.n_d0c, cols = 1 + nc0, ld = P.ld_x;
+    lp.T = s.T; lp.ld = ld; lp.colvar = s.colvar; lp.rowvar = s.rowvar; lp.rowkind = s.rowkind;
+    lp.n = nv; lp.m = mr; lp.na = nc0; lp.growth = 0.0; lp.iters = 0; lp.max_iter = 50 * (mr + nc0) + 100;
+    double *T = s.T;
+    wave_sync();
+    for (int idx = lane; idx < mr * cols; idx += 64) T[(idx / cols) * ld + idx % cols] = P.d0[idx];
+    for (int j = lane; j <= nc0 + 1; j += 64) T[mr * ld + j] = 0.0;
+    for (int i = lane; i < mr; i += 64) { s.rowkind[i] = RK_INEQ; s.rowvar[i] = nv + P.d0_rows[i]; }
+    for (int j = lane; j < nc0; j += 64) s.colvar[1 + j] = nv + P.d0_cols[j];
+    wave_sync();
+    for (int a = P.n_eq; a < k; ++a) {
+        const int v = nv + s.as[a];
+        int q = -1;
+        for (int j = 1 + lane; j <= lp.na; j += 64) if (s.colvar[j] == v) q = j;
+        { double dummy = q >= 0 ? 1.0 : 0.0; reduce_max_first(dummy, q); }
+        if (q >= 0) { lp_drop_col(lp, q); continue; }
+        int r = -1;
+        for (int i = lane; i < mr; i += 64) if (s.rowvar[i] == v && s.rowkind[i] == RK_INEQ) r = i;
+        { double dummy = r >= 0 ? 1.0 : 0.0; reduce_max_first(dummy, r); }
+        if (r < 0) return -1;
+        q = lp_best_col(lp, r);
+        if (q < 0) {
+            if (fabs(T[r * ld]) > TOL_FEAS) return LP_INFEASIBLE;
+            wave_sync();
+            if (lane == 0) s.rowkind[r] = RK_DEAD;
+            wave_sync();
+            continue;
+        }
+        double colmax = 0.0;
+        for (int i = lane; i < mr; i += 64) if (s.rowkind[i] != RK_DEAD) colmax = fmax(colmax, fabs(T[i * ld + q]));
+        colmax = wave_max(colmax);
+        lp.growth = fmax(lp.growth, colmax / fabs(T[r * ld + q]));
+        lp_pivot(lp, r, q);
+        lp_drop_col(lp, q);
+    }
+    const int st = lp_phase1(lp);
+    if (st != LP_ITERLIMIT && lp.growth > GROWTH_SAFE) return -1;
+    return st;
+}
+
 // ------------------------------------------------------------------------------------------------------------
 // k_verdict: status per candidate: INFEASIBLE / FEASIBLE / SINGULAR / LP_LIMIT / OPT_PENDING
 // ------------------------------------------------------------------------------------------------------------
@@ -223,7 +276,8 @@ __global__ void __launch_bounds__(64) k_verdict(DevProblem P, const int32_t *__r
     extern __shared__ __attribute__((aligned(16))) double smem[];
     Smem s = carve(P, smem);
     const int lane = lane_id(), nt = P.n_t, nx = P.n_x;
-    unsigned long long pivots = 0;
+    unsigned long long pivots = 0, n_xlp = 0, n_fallback = 0;
+    long long cyc_kkt = 0, cyc_theta = 0, cyc_x = 0;
     for (;;) {
         unsigned int c = 0;
         if (lane == 0) c = atomicAdd(&ctr->work_verdict, 1u);
@@ -231,17 +285,25 @@ __global__ void __launch_bounds__(64) k_verdict(DevProblem P, const int32_t *__r
         if (c >= n) break;
         const int nin = load_active_set(P, cands + (size_t)c * k, k, s);
         int st = -1;
+        const long long t0 = clock64();
         const int kk = kkt_solve(P, k, s);
+        const long long t1 = clock64();
+        cyc_kkt += t1 - t0;
         bool singular = false;
         if (kk == 1) st = ST_INFEASIBLE;
         else if (kk == 2) singular = true;
         else if (kk == 0) {
-            // optimality: feasibility of the theta-space polytope {lambda(theta) >= 0, slack(theta) >= 0, A_t theta <= b_t}
+            // Two-stage LP over theta only (rows of mpqp_utils.py:111-121 evaluated at the KKT point x*(theta), l*(theta)):
+            //   stage 1  {slack(theta) >= 0, A_t theta <= b_t} non-empty  =>  (x*(theta), theta) is a point of the (x,theta)
+            //            polytope with the rows `as` active: the candidate is FEASIBLE without the large LP
+            //   stage 2  the multiplier rows lambda(theta) >= 0, carried passively through stage 1, are switched on and
+            //            phase 1 continues from the same dictionary: non-empty  <=>  optimal (check_optimality)
             Lp lp;
             lp.T = s.T; lp.ld = P.ld_t; lp.colvar = s.colvar; lp.rowvar = s.rowvar; lp.rowkind = s.rowkind;
-            lp.n = nt; lp.m = (k - P.n_eq) + nin + P.n_tc; lp.iters = 0;
+            const int nlam = k - P.n_eq;
+            lp.n = nt; lp.m = nlam + nin + P.n_tc; lp.iters = 0;
             const int m = lp.m;
-            const int r = lp_solve(lp, false, s.pri, [&](const int *pri) {
+            auto load = [&](const int *pri, int lam_kind) {
                 build_theta_rows(P, k, nin, s, s.T, P.ld_t, P.kkt_mode == 1);
                 for (int i = lane; i <= m; i += 64) {
                     double *Ti = s.T + i * P.ld_t;
@@ -249,36 +311,59 @@ __global__ void __launch_bounds__(64) k_verdict(DevProblem P, const int32_t *__r
                     double mx = 0.0;
                     for (int j = 1; j <= nt; ++j) mx = fmax(mx, fabs(Ti[j]));
                     if (!(mx > ZERO_ROW_ATOL)) for (int j = 1; j <= nt; ++j) Ti[j] = 0.0;
-                    s.rowkind[i] = (pri && pri[i]) ? RK_PRI : RK_INEQ;
+                    s.rowkind[i] = (pri && pri[i]) ? RK_PRI : (i < nlam ? lam_kind : RK_INEQ);
                 }
-            });
+            };
+            const int r1 = lp_solve(lp, false, s.pri, [&](const int *pri) { load(pri, RK_PASSIVE); });
+            if (r1 == LP_ITERLIMIT) st = ST_LP_LIMIT;
+            else if (r1 == LP_OPTIMAL) {
+                wave_sync();
+                for (int i = lane; i < nlam; i += 64) s.rowkind[i] = RK_INEQ;
+                wave_sync();
+                lp.growth = 0.0;
+                int r2 = lp_phase1(lp);
+                if (r2 != LP_ITERLIMIT && lp.growth > GROWTH_SAFE)  // doubtful pivots: decide from a fresh solve over all rows
+                    r2 = lp_solve(lp, false, s.pri, [&](const int *pri) { load(pri, RK_INEQ); });
+                st = r2 == LP_OPTIMAL ? ST_OPT_PENDING : (r2 == LP_ITERLIMIT ? ST_LP_LIMIT : ST_FEASIBLE);
+            }
             pivots += lp.iters;
-            if (r == LP_OPTIMAL) st = ST_OPT_PENDING;
-            else if (r == LP_ITERLIMIT) st = ST_LP_LIMIT;
         }
+        const long long t2 = clock64();
+        cyc_theta += t2 - t1;
         if (st < 0) {
             // feasibility of {A x - F theta <= b, A_t theta <= b_t, rows `as` active}   (mplp_program.py:439-444)
             Lp lp;
-            lp.T = s.T; lp.ld = P.ld_x; lp.colvar = s.colvar; lp.rowvar = s.rowvar; lp.rowkind = s.rowkind;
-            lp.n = nx + nt; lp.m = P.n_c + P.n_tc; lp.iters = 0;
-            const int cols = 1 + nx + nt, mm = lp.m;
-            const int r = lp_solve(lp, false, s.pri, [&](const int *pri) {
-                wave_sync();
-                for (int i = 0; i < mm; ++i)
-                    for (int j = lane; j < cols; j += 64) s.T[i * P.ld_x + j] = P.base[i * cols + j];
-                for (int j = lane; j <= cols; j += 64) s.T[mm * P.ld_x + j] = 0.0;
-                for (int i = lane; i < mm; i += 64) s.rowkind[i] = (pri && pri[i]) ? RK_PRI : RK_INEQ;
-                wave_sync();
-                for (int i = lane; i < k; i += 64) s.rowkind[s.as[i]] = RK_EQ;
-            });
-            pivots += lp.iters;
+            n_xlp++;
+            int r = -1;
+            if (P.has_d0) {
+                r = xtheta_from_vertex(P, k, s, lp);
+                pivots += lp.iters;
+                if (r < 0) n_fallback++;
+            }
+            if (r < 0) {
+                lp.T = s.T; lp.ld = P.ld_x; lp.colvar = s.colvar; lp.rowvar = s.rowvar; lp.rowkind = s.rowkind;
+                lp.n = nx + nt; lp.m = P.n_c + P.n_tc; lp.iters = 0;
+                const int cols = 1 + nx + nt, mm = lp.m;
+                r = lp_solve(lp, false, s.pri, [&](const int *pri) {
+                    wave_sync();
+                    for (int i = 0; i < mm; ++i)
+                        for (int j = lane; j < cols; j += 64) s.T[i * P.ld_x + j] = P.base[i * cols + j];
+                    for (int j = lane; j <= cols; j += 64) s.T[mm * P.ld_x + j] = 0.0;
+                    for (int i = lane; i < mm; i += 64) s.rowkind[i] = (pri && pri[i]) ? RK_PRI : RK_INEQ;
+                    wave_sync();
+                    for (int i = lane; i < k; i += 64) s.rowkind[s.as[i]] = RK_EQ;
+                });
+                pivots += lp.iters;
+            }
             if (r == LP_OPTIMAL) st = singular ? ST_SINGULAR : ST_FEASIBLE;
             else if (r == LP_ITERLIMIT) st = ST_LP_LIMIT;
             else st = ST_INFEASIBLE;
         }
+        cyc_x += clock64() - t2;
         if (lane == 0) status[c] = (uint8_t)st;
     }
-    if (lane == 0) atomicAdd(&ctr->pivots, pivots);
+    if (lane == 0) { atomicAdd(&ctr->cycles[0], (unsigned long long)cyc_kkt); atomicAdd(&ctr->cycles[1], (unsigned long long)cyc_theta); atomicAdd(&ctr->cycles[2], (unsigned long long)cyc_x);
+        atomicAdd(&ctr->pivots, pivots); atomicAdd(&ctr->xtheta_lps, n_xlp); atomicAdd(&ctr->xtheta_fallbacks, n_fallback); }
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -473,25 +558,54 @@ __global__ void k_histogram(const uint8_t *__restrict__ status, long long n, Lev
     if (threadIdx.x < 8 && h[threadIdx.x]) atomicAdd(&ctr->status[threadIdx.x], (unsigned long long)h[threadIdx.x]);
 }
 
-// exclusive scan of int32 values by ONE workgroup of 1024 threads; total written to *total
-__global__ void __launch_bounds__(1024) k_scan_exclusive(const int32_t *__restrict__ in, int32_t *__restrict__ out, long long n,
-                                                        int32_t *__restrict__ total) {
-    __shared__ long long part[1024];
-    const int t = threadIdx.x;
-    const long long chunk = (n + 1023) / 1024, lo = t * chunk, hi = lo + chunk < n ? lo + chunk : n;
-    long long sum = 0;
-    for (long long i = lo; i < hi; ++i) sum += in[i];
-    part[t] = sum;
+// Exclusive scan of int32 values in three launches: per-block sums (1024 items per block), a single-block scan of
+// the block sums, and the per-block scan with its offset.  total = sum of all values.
+constexpr int SCAN_BLOCK = 1024;
+__device__ __forceinline__ int block_exclusive_scan_1024(int v, int *total_out) {
+    __shared__ int wsum[16];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    int incl = v;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) { const int o = __shfl_up(incl, off); if (lane >= off) incl += o; }
+    if (lane == 63) wsum[w] = incl;
     __syncthreads();
-    for (int off = 1; off < 1024; off <<= 1) {
-        const long long v = t >= off ? part[t - off] : 0;
+    if (w == 0) {
+        int t = lane < 16 ? wsum[lane] : 0, ti = t;
+#pragma unroll
+        for (int off = 1; off < 16; off <<= 1) { const int o = __shfl_up(ti, off); if (lane >= off) ti += o; }
+        if (lane < 16) wsum[lane] = ti - t;
+        if (lane == 15 && total_out) *total_out = ti;
+    }
+    __syncthreads();
+    return incl - v + wsum[w];
+}
+__global__ void __launch_bounds__(1024) k_scan_block_sums(const int32_t *__restrict__ in, long long n, int32_t *__restrict__ sums) {
+    __shared__ int tot;
+    const long long i = blockIdx.x * (long long)SCAN_BLOCK + threadIdx.x;
+    (void)block_exclusive_scan_1024(i < n ? in[i] : 0, &tot);
+    __syncthreads();
+    if (threadIdx.x == 0) sums[blockIdx.x] = tot;
+}
+// one block: exclusive scan of up to nb block sums in place (chunked), total -> *total
+__global__ void __launch_bounds__(1024) k_scan_sums(int32_t *__restrict__ sums, int nb, int32_t *__restrict__ total) {
+    __shared__ int tot;
+    int carry = 0;
+    for (int base = 0; base < nb; base += SCAN_BLOCK) {
+        const int i = base + threadIdx.x;
+        const int v = i < nb ? sums[i] : 0;
+        const int ex = block_exclusive_scan_1024(v, &tot);
         __syncthreads();
-        part[t] += v;
+        if (i < nb) sums[i] = ex + carry;
+        carry += tot;
         __syncthreads();
     }
-    long long run = part[t] - sum;
-    for (long long i = lo; i < hi; ++i) { const int32_t v = in[i]; out[i] = (int32_t)run; run += v; }
-    if (t == 1023) *total = (int32_t)part[1023];
+    if (threadIdx.x == 0) *total = carry;
+}
+__global__ void __launch_bounds__(1024) k_scan_apply(const int32_t *__restrict__ in, int32_t *__restrict__ out, long long n,
+                                                    const int32_t *__restrict__ sums) {
+    const long long i = blockIdx.x * (long long)SCAN_BLOCK + threadIdx.x;
+    const int ex = block_exclusive_scan_1024(i < n ? in[i] : 0, nullptr);
+    if (i < n) out[i] = ex + sums[blockIdx.x];
 }
 
 __global__ void k_flag_status(const uint8_t *__restrict__ status, long long n, int which, int32_t *__restrict__ flag) {
@@ -507,7 +621,10 @@ __global__ void k_scatter_index(const int32_t *__restrict__ flag, const int32_t 
 __device__ __forceinline__ bool expands(int st) { return st == ST_FEASIBLE || st == ST_REGION || st == ST_SINGULAR || st == ST_LP_LIMIT; }
 
 // children of one parent per wavefront: bit i of childmask = [as + {i}] survives CombinationTester.check and the
-// mpLP filter (driver lines 49-51); count[c] = popcount
+// mpLP filter (driver lines 49-51); count[c] = popcount.
+// The superset test is organised by pruned set, not by child: for a pruned mask p, d = p & ~parent is empty (every
+// child contains p: all culled) or a single bit i > last(parent) (exactly child i contains p) or irrelevant.  Lanes
+// stride over the pruned list, each accumulating the 128-bit set of culled children, then the wave ORs them together.
 __global__ void __launch_bounds__(64) k_children_count(DevProblem P, const int32_t *__restrict__ cands, long long n, int k,
                                                        const uint8_t *__restrict__ status,
                                                        const unsigned long long *__restrict__ pruned, long long n_pruned,
@@ -517,29 +634,28 @@ __global__ void __launch_bounds__(64) k_children_count(DevProblem P, const int32
     if (c >= n) return;
     const int st = status[c];
     unsigned long long m0 = 0, m1 = 0;
-    int total = 0;
     if (expands(st)) {
         const int32_t *as = cands + (size_t)c * k;
         unsigned long long p0 = 0, p1 = 0;
         for (int i = 0; i < k; ++i) { const int v = as[i]; if (v < 64) p0 |= 1ull << v; else p1 |= 1ull << (v - 64); }
         const int start = k > 0 ? as[k - 1] + 1 : 0;
-        for (int half = 0; half < 2; ++half) {
-            const int i = half * 64 + lane;
-            bool ok = i >= start && i < P.n_c;
-            if (ok && !P.is_qp && st == ST_FEASIBLE && i >= (k + 1) + P.n_c - P.n_x) ok = false;
-            const unsigned long long c0 = p0 | (half == 0 ? 1ull << lane : 0ull), c1 = p1 | (half == 1 ? 1ull << lane : 0ull);
-            if (__any(ok)) {
-                for (long long j = 0; j < n_pruned; ++j) {
-                    const unsigned long long q0 = pruned[2 * j], q1 = pruned[2 * j + 1];
-                    if ((c0 & q0) == q0 && (c1 & q1) == q1) ok = false;
-                }
-            }
-            const unsigned long long bal = __ballot(ok);
-            if (half == 0) m0 = bal; else m1 = bal;
-            total += __popcll(bal);
+        // candidates for children: indices start .. n_c-1 (mpLP filter for non-optimal parents)
+        int stop = P.n_c;
+        if (!P.is_qp && st == ST_FEASIBLE) stop = min(stop, (k + 1) + P.n_c - P.n_x);
+        unsigned long long a0 = 0, a1 = 0;  // allowed children
+        for (int i = start; i < stop; ++i) { if (i < 64) a0 |= 1ull << i; else a1 |= 1ull << (i - 64); }
+        unsigned long long kill0 = 0, kill1 = 0;
+        for (long long j = lane; j < n_pruned; j += 64) {
+            const unsigned long long d0 = pruned[2 * j] & ~p0, d1 = pruned[2 * j + 1] & ~p1;
+            const int bits = __popcll(d0) + __popcll(d1);
+            if (bits == 0) { kill0 = ~0ull; kill1 = ~0ull; }
+            else if (bits == 1) { kill0 |= d0; kill1 |= d1; }
         }
+        for (int off = 32; off > 0; off >>= 1) { kill0 |= __shfl_xor(kill0, off); kill1 |= __shfl_xor(kill1, off); }
+        m0 = a0 & ~kill0;
+        m1 = a1 & ~kill1;
     }
-    if (lane == 0) { childmask[2 * c] = m0; childmask[2 * c + 1] = m1; count[c] = total; }
+    if (lane == 0) { childmask[2 * c] = m0; childmask[2 * c + 1] = m1; count[c] = __popcll(m0) + __popcll(m1); }
 }
 
 __global__ void __launch_bounds__(64) k_children_write(const int32_t *__restrict__ cands, long long n, int k,
@@ -595,7 +711,7 @@ __global__ void __launch_bounds__(64) k_lp_batch(long long n_lp, int m, int n, i
                                                  const double *__restrict__ b, int shared_b, const double *__restrict__ c,
                                                  int shared_c, const uint8_t *__restrict__ eq, int32_t *__restrict__ status,
                                                  double *__restrict__ x, double *__restrict__ obj, int32_t *__restrict__ iters,
-                                                 unsigned int *work) {
+                                                 int32_t *__restrict__ tight, unsigned int *work) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int lane = lane_id();
     double *T = smem;
@@ -629,6 +745,15 @@ __global__ void __launch_bounds__(64) k_lp_batch(long long n_lp, int m, int n, i
             if (r == LP_OPTIMAL)
                 for (int i = lane; i < m; i += 64)
                     if (lp.rowkind[i] == RK_FREE) x[(size_t)w * n + lp.rowvar[i]] = T[i * ld];
+        }
+        if (tight) {
+            // rows whose slack is nonbasic in the final dictionary (the vertex's active rows, equalities included)
+            for (int i = lane; i < m; i += 64) tight[(size_t)w * m + i] = 1;
+            wave_sync();
+            for (int i = lane; i < m; i += 64) {
+                const int v = lp.rowvar[i];
+                if (v >= n && v < n + m) tight[(size_t)w * m + (v - n)] = 0;
+            }
         }
         if (lane == 0) {
             status[w] = r;

@@ -29,8 +29,11 @@ constexpr double HARRIS_DELTA = 1e-9;
 constexpr int DEG_SWITCH = 12;
 constexpr double GROWTH_SAFE = 1e3;  // largest tolerated |column max / pivot| before the basis is refactored
 constexpr int MAX_REFACTOR = 2;
+constexpr int X0_VAR = 1 << 20;  // id of the phase-1 artificial: larger than every structural / slack id
 
-enum : int { RK_INEQ = 0, RK_EQ = 1, RK_FREE = 2, RK_DEAD = 3, RK_X0 = 4, RK_PRI = 5 };
+// RK_PASSIVE: a row carried through every pivot but not enforced (no ratio test, no feasibility test) until the
+// caller turns it into RK_INEQ and calls lp_phase1 again (two-stage LPs, see k_verdict)
+enum : int { RK_INEQ = 0, RK_EQ = 1, RK_FREE = 2, RK_DEAD = 3, RK_X0 = 4, RK_PRI = 5, RK_PASSIVE = 6 };
 enum : int { LP_OPTIMAL = 0, LP_INFEASIBLE = 1, LP_UNBOUNDED = 2, LP_ITERLIMIT = 3 };
 
 struct Lp {
@@ -248,6 +251,43 @@ __device__ inline int lp_primal(Lp &lp, int phase1_row) {
     }
 }
 
+// Phase 1 on the current dictionary (re-entrant): drives every RK_INEQ row to beta >= -TOL_FEAS with the x0 method.
+// Returns LP_OPTIMAL (feasible), LP_INFEASIBLE or LP_ITERLIMIT.
+__device__ inline int lp_phase1(Lp &lp) {
+    const int m = lp.m, ld = lp.ld, lane = lane_id();
+    double *T = lp.T;
+        double mn = -TOL_FEAS;
+        int key = 0, r = -1;
+        for (int i = lane; i < m; i += 64)
+            if (lp.rowkind[i] == RK_INEQ && T[i * ld] < mn) { mn = T[i * ld]; r = i; }
+        reduce_min_first(mn, key, r);
+        if (r >= 0) {
+            const int q = ++lp.na;
+            for (int i = lane; i <= m; i += 64) T[i * ld + q] = (i < m && lp.rowkind[i] == RK_INEQ) ? -1.0 : 0.0;
+            if (lane == 0) lp.colvar[q] = X0_VAR;
+            wave_sync();
+            lp_pivot(lp, r, q);
+            if (lane == 0) lp.rowkind[r] = RK_X0;
+            wave_sync();
+            const int st = lp_primal(lp, r);
+            if (st == 3) return LP_ITERLIMIT;
+            if (st != 4) {
+                if (T[r * ld] > TOL_FEAS) return LP_INFEASIBLE;
+                const int qq = lp_best_col(lp, r);
+                wave_sync();
+                if (qq < 0) {
+                    if (lane == 0) lp.rowkind[r] = RK_DEAD;
+                    wave_sync();
+                } else {
+                    lp_pivot(lp, r, qq);
+                    if (lane == 0) lp.rowkind[r] = RK_INEQ;
+                    lp_drop_col(lp, qq);
+                }
+            }
+        }
+    return LP_OPTIMAL;
+}
+
 // One pass (stage A, stage B, phase 1, phase 2) on the scaled tableau, rowkind (RK_INEQ / RK_PRI / RK_EQ / RK_DEAD),
 // rowvar (= n + i) and colvar (= j - 1) already in LDS.  has_cost: run phase 2 on row m.  Returns LP_*.
 __device__ inline int lp_run(Lp &lp, bool has_cost) {
@@ -296,37 +336,9 @@ __device__ inline int lp_run(Lp &lp, bool has_cost) {
         if (lane == 0) lp.rowkind[i] = RK_INEQ;
         lp_drop_col(lp, q);
     }
-    // phase 1
     {
-        double mn = -TOL_FEAS;
-        int key = 0, r = -1;
-        for (int i = lane; i < m; i += 64)
-            if (lp.rowkind[i] == RK_INEQ && T[i * ld] < mn) { mn = T[i * ld]; r = i; }
-        reduce_min_first(mn, key, r);
-        if (r >= 0) {
-            const int q = ++lp.na;
-            for (int i = lane; i <= m; i += 64) T[i * ld + q] = (i < m && lp.rowkind[i] == RK_INEQ) ? -1.0 : 0.0;
-            if (lane == 0) lp.colvar[q] = n + m;
-            wave_sync();
-            lp_pivot(lp, r, q);
-            if (lane == 0) lp.rowkind[r] = RK_X0;
-            wave_sync();
-            const int st = lp_primal(lp, r);
-            if (st == 3) return LP_ITERLIMIT;
-            if (st != 4) {
-                if (T[r * ld] > TOL_FEAS) return LP_INFEASIBLE;
-                const int qq = lp_best_col(lp, r);
-                wave_sync();
-                if (qq < 0) {
-                    if (lane == 0) lp.rowkind[r] = RK_DEAD;
-                    wave_sync();
-                } else {
-                    lp_pivot(lp, r, qq);
-                    if (lane == 0) lp.rowkind[r] = RK_INEQ;
-                    lp_drop_col(lp, qq);
-                }
-            }
-        }
+        const int st1 = lp_phase1(lp);
+        if (st1 != LP_OPTIMAL) return st1;
     }
     if (has_cost) {
         if (unbounded_if_feasible) return LP_UNBOUNDED;
@@ -350,6 +362,7 @@ __device__ inline bool lp_prepare(Lp &lp) {
         for (int j = 1; j <= n; ++j) { const double a = fabs(Ti[j]); if (a > mx) mx = a; }
         lp.rowvar[i] = n + i;
         if (lp.rowkind[i] == RK_DEAD) continue;
+        if (!(mx > 0.0) && lp.rowkind[i] == RK_PASSIVE) continue;  // decided when the row is activated
         if (!(mx > 0.0)) {
             if (lp.rowkind[i] == RK_EQ ? fabs(Ti[0]) > TOL_FEAS : Ti[0] < -TOL_FEAS) bad = 1;
             lp.rowkind[i] = RK_DEAD;

@@ -61,12 +61,13 @@ struct mpc_handle {
     // problem
     int n_x = 0, n_t = 0, n_c = 0, n_eq = 0, n_tc = 0, is_qp = 0, kkt_mode = 0;
     DevBuf blocks;            // all read-only problem blocks, one allocation
+    DevBuf iblocks;           // integer blocks (row / column maps of the pre-crashed dictionary)
     DevProblem Pv{}, Pr{};    // verdict / region kernel views (same blocks, different LDS layouts)
     int lds_v = 0, lds_r = 0; // dynamic LDS bytes per wavefront
     int grid_v = 0, grid_r = 0;
     long long rec_d = 0, rec_i = 0;
     // frontier / pruned
-    DevBuf frontier, children, status, pruned, pruned_new, flag, pos, opt_list, childmask, count, offset, recd, reci, ctr, scratch;
+    DevBuf frontier, children, status, pruned, pruned_new, flag, pos, opt_list, childmask, count, offset, recd, reci, ctr, scratch, sums;
     long long n = 0;
     int k = 0;
     long long n_pruned = 0;
@@ -147,7 +148,35 @@ void apply_layout(DevProblem &P, const Layout &l) {
 
 int waves_per_cu(int lds_bytes) { return std::max(1, std::min(16, (160 * 1024) / std::max(lds_bytes, 1))); }
 
+// LU with partial pivoting of the n x n matrix M (row major, overwritten); perm receives the row order.
+bool lu_factor(std::vector<double> &M, int n, std::vector<int> &perm) {
+    perm.resize(n);
+    for (int i = 0; i < n; ++i) perm[i] = i;
+    double scale = 0;
+    for (double v : M) scale = std::max(scale, std::fabs(v));
+    for (int c = 0; c < n; ++c) {
+        int p = c;
+        for (int i = c + 1; i < n; ++i) if (std::fabs(M[(size_t)i * n + c]) > std::fabs(M[(size_t)p * n + c])) p = i;
+        if (!(std::fabs(M[(size_t)p * n + c]) > 1e-12 * scale)) return false;
+        if (p != c) { for (int j = 0; j < n; ++j) std::swap(M[(size_t)p * n + j], M[(size_t)c * n + j]); std::swap(perm[p], perm[c]); }
+        for (int i = c + 1; i < n; ++i) {
+            const double f = M[(size_t)i * n + c] / M[(size_t)c * n + c];
+            M[(size_t)i * n + c] = f;
+            if (f != 0.0) for (int j = c + 1; j < n; ++j) M[(size_t)i * n + j] -= f * M[(size_t)c * n + j];
+        }
+    }
+    return true;
+}
+void lu_solve_host(const std::vector<double> &LU, const std::vector<int> &perm, int n, const double *rhs, double *x) {
+    for (int i = 0; i < n; ++i) { double v = rhs[perm[i]]; for (int l = 0; l < i; ++l) v -= LU[(size_t)i * n + l] * x[l]; x[i] = v; }
+    for (int i = n - 1; i >= 0; --i) { double v = x[i]; for (int l = i + 1; l < n; ++l) v -= LU[(size_t)i * n + l] * x[l]; x[i] = v / LU[(size_t)i * n + i]; }
+}
+
 }  // namespace
+
+static int lp_batch_impl(int32_t device, int64_t n_lp, int32_t m, int32_t n, const double *A, int32_t shared_A, const double *b,
+                         int32_t shared_b, const double *c, int32_t shared_c, const uint8_t *eq, int32_t *status, double *x,
+                         double *obj, int32_t *iters, int32_t *tight);
 
 extern "C" {
 
@@ -228,6 +257,52 @@ int mpc_create(const mpc_problem *p, int32_t device, void *stream, mpc_handle **
         base[(size_t)(nc + i) * cols] = p->b_t[i];
         for (int j = 0; j < nt; ++j) base[(size_t)(nc + i) * cols + 1 + nx + j] = p->A_t[(size_t)i * nt + j];
     }
+    // ---- pre-crashed dictionary D0 of the (x,theta) LP (see xtheta_from_vertex in kernels.hpp) --------------------
+    // A feasible vertex of the base polytope {A x - F theta <= b (first n_eq rows =), A_t theta <= b_t} is found once by
+    // the device simplex; the dictionary at that vertex is then rebuilt from the original rows by a fresh LU, so its
+    // entries carry factorisation-level accuracy, not the accumulated error of the pivot sequence.
+    std::vector<double> d0;
+    std::vector<int> d0_rows, d0_cols;
+    {
+        const int nv = nx + nt;
+        std::vector<double> Alp((size_t)rows_x * nv), blp(rows_x);
+        for (int i = 0; i < rows_x; ++i) { blp[i] = base[(size_t)i * cols]; for (int j = 0; j < nv; ++j) Alp[(size_t)i * nv + j] = base[(size_t)i * cols + 1 + j]; }
+        std::vector<uint8_t> eqf(rows_x, 0);
+        for (int i = 0; i < ne; ++i) eqf[i] = 1;
+        std::vector<int32_t> tight(rows_x, 0);
+        int32_t lp_status = -1;
+        int rc0 = rows_x > nv ? lp_batch_impl(device, 1, rows_x, nv, Alp.data(), 1, blp.data(), 1, nullptr, 1, eqf.data(), &lp_status, nullptr, nullptr, nullptr, tight.data()) : MPC_ERR_INVALID;
+        HIP_TRY(nullptr, hipSetDevice(device));
+        std::vector<int> B;
+        for (int i = 0; i < rows_x; ++i) if (tight[i]) B.push_back(i);
+        bool ok = rc0 == MPC_OK && lp_status == LP_OPTIMAL && (int)B.size() == nv;
+        std::vector<double> MT;
+        std::vector<int> perm;
+        if (ok) {
+            MT.assign((size_t)nv * nv, 0.0);  // M^T, M = rows B of [A | -F ; 0 | A_t]
+            for (int r = 0; r < nv; ++r) for (int j = 0; j < nv; ++j) MT[(size_t)j * nv + r] = Alp[(size_t)B[r] * nv + j];
+            ok = lu_factor(MT, nv, perm);
+        }
+        if (ok) {
+            std::vector<char> inB(rows_x, 0);
+            for (int r : B) inB[r] = 1;
+            std::vector<int> colpos;  // positions in B of the inequality rows (the alive nonbasic columns)
+            for (int r = 0; r < nv; ++r) if (B[r] >= ne) { colpos.push_back(r); d0_cols.push_back(B[r]); }
+            std::vector<double> y(nv);
+            const int nc0 = (int)d0_cols.size();
+            for (int i = 0; i < rows_x && ok; ++i) {
+                if (inB[i]) continue;
+                lu_solve_host(MT, perm, nv, &Alp[(size_t)i * nv], y.data());  // y = a_i M^-1
+                double beta = blp[i];
+                for (int r = 0; r < nv; ++r) beta -= y[r] * blp[B[r]];
+                if (beta < -1e-7) ok = false;
+                d0_rows.push_back(i);
+                d0.push_back(beta);
+                for (int q = 0; q < nc0; ++q) d0.push_back(-y[colpos[q]]);
+            }
+        }
+        if (!ok) { d0.clear(); d0_rows.clear(); d0_cols.clear(); }
+    }
     // ---- one device allocation for every read-only block -------------------------------------------------
     std::vector<double> host;
     auto put = [&](const double *src, size_t cnt) { size_t off = host.size(); host.insert(host.end(), src, src + cnt); while (host.size() % 2) host.push_back(0.0); return off; };
@@ -238,6 +313,7 @@ int mpc_create(const mpc_problem *p, int32_t device, void *stream, mpc_handle **
     const size_t oW = put(mode == 0 ? W.data() : zeros.data(), mode == 0 ? W.size() : 1), oUV = put(mode == 0 ? UV.data() : zeros.data(), mode == 0 ? UV.size() : 1);
     const size_t oGt = put(mode == 0 ? Gt.data() : zeros.data(), mode == 0 ? Gt.size() : 1), oX0H = put(mode == 0 ? X0H.data() : zeros.data(), mode == 0 ? X0H.size() : 1);
     const size_t obase = put(base.data(), base.size());
+    const size_t od0 = put(d0.empty() ? zeros.data() : d0.data(), d0.empty() ? 1 : d0.size());
     HIP_TRY(nullptr, h->blocks.ensure(host.size() * sizeof(double), h->stream));
     HIP_TRY(nullptr, hipMemcpyAsync(h->blocks.p, host.data(), host.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
     HIP_TRY(nullptr, hipStreamSynchronize(h->stream));
@@ -246,6 +322,17 @@ int mpc_create(const mpc_problem *p, int32_t device, void *stream, mpc_handle **
     P.n_x = nx; P.n_t = nt; P.n_c = nc; P.n_eq = ne; P.n_tc = ntc; P.is_qp = h->is_qp; P.kkt_mode = mode;
     P.A = d + oA; P.b = d + ob; P.F = d + oF; P.c = d + oc; P.H = d + oH; P.Q = d + oQ; P.A_t = d + oAt; P.b_t = d + obt;
     P.W = d + oW; P.UV = d + oUV; P.Gt = d + oGt; P.X0H = d + oX0H; P.base = d + obase;
+    P.d0 = d + od0; P.has_d0 = d0.empty() ? 0 : 1; P.n_d0r = (int)d0_rows.size(); P.n_d0c = (int)d0_cols.size();
+    {
+        std::vector<int> maps(d0_rows);
+        maps.insert(maps.end(), d0_cols.begin(), d0_cols.end());
+        if (maps.empty()) maps.push_back(0);
+        HIP_TRY(nullptr, h->iblocks.ensure(maps.size() * sizeof(int), h->stream));
+        HIP_TRY(nullptr, hipMemcpyAsync(h->iblocks.p, maps.data(), maps.size() * sizeof(int), hipMemcpyHostToDevice, h->stream));
+        HIP_TRY(nullptr, hipStreamSynchronize(h->stream));
+        P.d0_rows = h->iblocks.as<int>();
+        P.d0_cols = h->iblocks.as<int>() + d0_rows.size();
+    }
     // ---- LDS layouts ---------------------------------------------------------------------------------------
     const int kmax = std::min(nc, nx);
     const int rows_t = nc - ne + ntc;
@@ -277,8 +364,8 @@ int mpc_destroy(mpc_handle *h) {
     if (!h) return MPC_OK;
     (void)hipSetDevice(h->device);
     (void)hipStreamSynchronize(h->stream);
-    for (DevBuf *b : {&h->blocks, &h->frontier, &h->children, &h->status, &h->pruned, &h->pruned_new, &h->flag, &h->pos, &h->opt_list,
-                      &h->childmask, &h->count, &h->offset, &h->recd, &h->reci, &h->ctr, &h->scratch}) b->release();
+    for (DevBuf *b : {&h->blocks, &h->iblocks, &h->frontier, &h->children, &h->status, &h->pruned, &h->pruned_new, &h->flag, &h->pos, &h->opt_list,
+                      &h->childmask, &h->count, &h->offset, &h->recd, &h->reci, &h->ctr, &h->scratch, &h->sums}) b->release();
     for (auto &e : h->ev) if (e) (void)hipEventDestroy(e);
     if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
@@ -376,6 +463,17 @@ int mpc_pruned_get(mpc_handle *h, uint64_t *masks, int64_t cap) {
     return MPC_OK;
 }
 
+// exclusive scan of n int32 values on the handle's stream (three launches); *total_dev receives the sum
+static int launch_scan(mpc_handle *h, const int32_t *in, int32_t *out, long long n, int32_t *total_dev) {
+    const int nb = (int)((n + SCAN_BLOCK - 1) / SCAN_BLOCK);
+    HIP_TRY(h, h->sums.ensure((size_t)std::max(nb, 1) * sizeof(int32_t), h->stream));
+    hipLaunchKernelGGL(k_scan_block_sums, dim3(nb), dim3(SCAN_BLOCK), 0, h->stream, in, n, h->sums.as<int32_t>());
+    hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(SCAN_BLOCK), 0, h->stream, h->sums.as<int32_t>(), nb, total_dev);
+    hipLaunchKernelGGL(k_scan_apply, dim3(nb), dim3(SCAN_BLOCK), 0, h->stream, in, out, n, h->sums.as<int32_t>());
+    HIP_TRY(h, hipGetLastError());
+    return MPC_OK;
+}
+
 // ---- one level ------------------------------------------------------------------------------------------------
 int mpc_level_run(mpc_handle *h, int32_t gen_children, mpc_level_stats *stats) {
     if (!h) return MPC_ERR_INVALID;
@@ -406,7 +504,7 @@ int mpc_level_run(mpc_handle *h, int32_t gen_children, mpc_level_stats *stats) {
         HIP_TRY(h, hipEventRecord(h->ev[1], st));
         // optimal candidates -> region kernel
         hipLaunchKernelGGL(k_flag_status, dim3(blocks256), dim3(256), 0, st, h->status.as<uint8_t>(), n, ST_OPT_PENDING, h->flag.as<int32_t>());
-        hipLaunchKernelGGL(k_scan_exclusive, dim3(1), dim3(1024), 0, st, h->flag.as<int32_t>(), h->pos.as<int32_t>(), n, total);
+        { int rcs = launch_scan(h, h->flag.as<int32_t>(), h->pos.as<int32_t>(), n, total); if (rcs) return rcs; }
         hipLaunchKernelGGL(k_scatter_index, dim3(blocks256), dim3(256), 0, st, h->flag.as<int32_t>(), h->pos.as<int32_t>(), n, h->opt_list.as<int32_t>());
         HIP_TRY(h, hipGetLastError());
         int32_t n_opt = 0;
@@ -431,7 +529,7 @@ int mpc_level_run(mpc_handle *h, int32_t gen_children, mpc_level_stats *stats) {
             HIP_TRY(h, h->offset.ensure(nn * sizeof(int32_t), st));
             hipLaunchKernelGGL(k_children_count, dim3((unsigned)n), dim3(64), 0, st, h->Pv, h->frontier.as<int32_t>(), n, k, h->status.as<uint8_t>(),
                                h->pruned.as<unsigned long long>(), (long long)h->n_pruned, h->childmask.as<unsigned long long>(), h->count.as<int32_t>());
-            hipLaunchKernelGGL(k_scan_exclusive, dim3(1), dim3(1024), 0, st, h->count.as<int32_t>(), h->offset.as<int32_t>(), n, total);
+            { int rcs = launch_scan(h, h->count.as<int32_t>(), h->offset.as<int32_t>(), n, total); if (rcs) return rcs; }
             HIP_TRY(h, hipGetLastError());
             int32_t n_children = 0;
             HIP_TRY(h, hipMemcpyAsync(&n_children, total, sizeof(int32_t), hipMemcpyDeviceToHost, st));
@@ -462,6 +560,9 @@ int mpc_level_run(mpc_handle *h, int32_t gen_children, mpc_level_stats *stats) {
         for (int i = 0; i < 6; ++i) stats->n_status[i] = (int64_t)host_ctr.status[i];
         stats->n_regions = h->n_regions; stats->n_children = h->n_children; stats->n_pruned_new = h->n_pruned_new;
         stats->lp_pivots = (int64_t)host_ctr.pivots;
+        stats->n_xtheta_lp = (int64_t)host_ctr.xtheta_lps;
+        stats->n_xtheta_fallback = (int64_t)host_ctr.xtheta_fallbacks;
+        for (int i = 0; i < 4; ++i) stats->wave_cycles[i] = (int64_t)host_ctr.cycles[i];
         stats->ms_verdict = ms[0]; stats->ms_region = ms[1]; stats->ms_children = ms[2]; stats->ms_total = ms[0] + ms[1] + ms[2];
     }
     return MPC_OK;
@@ -574,10 +675,12 @@ int mpc_check_level(mpc_handle *h, const int32_t *cand, int64_t n, int32_t k, co
     return MPC_OK;
 }
 
+}  // extern "C"
+
 // ---- batched LPs ------------------------------------------------------------------------------------------------
-int mpc_lp_solve_batch(int32_t device, int64_t n_lp, int32_t m, int32_t n, const double *A, int32_t shared_A, const double *b,
-                       int32_t shared_b, const double *c, int32_t shared_c, const uint8_t *eq, int32_t *status, double *x,
-                       double *obj, int32_t *iters) {
+static int lp_batch_impl(int32_t device, int64_t n_lp, int32_t m, int32_t n, const double *A, int32_t shared_A, const double *b,
+                         int32_t shared_b, const double *c, int32_t shared_c, const uint8_t *eq, int32_t *status, double *x,
+                         double *obj, int32_t *iters, int32_t *tight) {
     if (n_lp < 0 || m < 1 || n < 1 || !A || !b || !eq || !status) return fail(nullptr, MPC_ERR_INVALID, "bad argument");
     if (n_lp == 0) return MPC_OK;
     int ndev = 0;
@@ -594,7 +697,7 @@ int mpc_lp_solve_batch(int32_t device, int64_t n_lp, int32_t m, int32_t n, const
     const size_t szc = c ? (shared_c ? 1 : (size_t)n_lp) * n * 8 : 0, szeq = (size_t)n_lp * m;
     double *dA = nullptr, *db = nullptr, *dc = nullptr, *dx = nullptr, *dobj = nullptr;
     uint8_t *deq = nullptr;
-    int32_t *dst = nullptr, *dit = nullptr;
+    int32_t *dst = nullptr, *dit = nullptr, *dtight = nullptr;
     unsigned int *dwork = nullptr;
     int rc = MPC_OK;
     hipError_t e = hipSuccess;
@@ -603,6 +706,7 @@ int mpc_lp_solve_batch(int32_t device, int64_t n_lp, int32_t m, int32_t n, const
     if (c) chk(hipMalloc((void **)&dc, szc));
     chk(hipMalloc((void **)&deq, szeq)); chk(hipMalloc((void **)&dst, (size_t)n_lp * 4)); chk(hipMalloc((void **)&dit, (size_t)n_lp * 4));
     chk(hipMalloc((void **)&dx, (size_t)n_lp * n * 8)); chk(hipMalloc((void **)&dobj, (size_t)n_lp * 8)); chk(hipMalloc((void **)&dwork, 4));
+    if (tight) chk(hipMalloc((void **)&dtight, (size_t)n_lp * m * 4));
     if (e == hipSuccess) {
         chk(hipMemcpy(dA, A, szA, hipMemcpyHostToDevice)); chk(hipMemcpy(db, b, szb, hipMemcpyHostToDevice));
         if (c) chk(hipMemcpy(dc, c, szc, hipMemcpyHostToDevice));
@@ -610,17 +714,22 @@ int mpc_lp_solve_batch(int32_t device, int64_t n_lp, int32_t m, int32_t n, const
     }
     if (e == hipSuccess) {
         const int grid = (int)std::min<long long>(n_lp, (long long)std::max(prop.multiProcessorCount, 1) * waves_per_cu((int)lds));
-        hipLaunchKernelGGL(k_lp_batch, dim3(grid), dim3(64), lds, 0, (long long)n_lp, m, n, ld, dA, shared_A, db, shared_b, dc, shared_c, deq, dst, dx, dobj, dit, dwork);
+        hipLaunchKernelGGL(k_lp_batch, dim3(grid), dim3(64), lds, 0, (long long)n_lp, m, n, ld, dA, shared_A, db, shared_b, dc, shared_c, deq, dst, dx, dobj, dit, dtight, dwork);
         chk(hipGetLastError());
         chk(hipDeviceSynchronize());
         chk(hipMemcpy(status, dst, (size_t)n_lp * 4, hipMemcpyDeviceToHost));
         if (x) chk(hipMemcpy(x, dx, (size_t)n_lp * n * 8, hipMemcpyDeviceToHost));
         if (obj) chk(hipMemcpy(obj, dobj, (size_t)n_lp * 8, hipMemcpyDeviceToHost));
         if (iters) chk(hipMemcpy(iters, dit, (size_t)n_lp * 4, hipMemcpyDeviceToHost));
+        if (tight) chk(hipMemcpy(tight, dtight, (size_t)n_lp * m * 4, hipMemcpyDeviceToHost));
     }
     if (e != hipSuccess) rc = fail(nullptr, MPC_ERR_HIP, std::string("mpc_lp_solve_batch: ") + hipGetErrorString(e));
-    for (void *q : {(void *)dA, (void *)db, (void *)dc, (void *)deq, (void *)dst, (void *)dit, (void *)dx, (void *)dobj, (void *)dwork}) if (q) (void)hipFree(q);
+    for (void *q : {(void *)dA, (void *)db, (void *)dc, (void *)deq, (void *)dst, (void *)dit, (void *)dx, (void *)dobj, (void *)dwork, (void *)dtight}) if (q) (void)hipFree(q);
     return rc;
 }
 
-}  // extern "C"
+extern "C" int mpc_lp_solve_batch(int32_t device, int64_t n_lp, int32_t m, int32_t n, const double *A, int32_t shared_A, const double *b,
+                                  int32_t shared_b, const double *c, int32_t shared_c, const uint8_t *eq, int32_t *status, double *x,
+                                  double *obj, int32_t *iters) {
+    return lp_batch_impl(device, n_lp, m, n, A, shared_A, b, shared_b, c, shared_c, eq, status, x, obj, iters, nullptr);
+}

@@ -84,7 +84,7 @@ def solve(program, num_cores: int = -1, device: int = 0, profile: Optional[List[
             profile.append({'depth': depth + 1, 'k': int(st.k), 'candidates': int(st.n),
                             'status': [int(v) for v in st.n_status], 'regions': int(st.n_regions),
                             'children': int(st.n_children), 'pruned_new': int(st.n_pruned_new),
-                            'lp_pivots': int(st.lp_pivots), 'ms_verdict': float(st.ms_verdict),
+                            'lp_pivots': int(st.lp_pivots), 'xtheta_lps': int(st.n_xtheta_lp), 'xtheta_fallbacks': int(st.n_xtheta_fallback), 'ms_verdict': float(st.ms_verdict),
                             'ms_region': float(st.ms_region), 'ms_children': float(st.ms_children),
                             'ms_wall': (time.perf_counter() - t0) * 1e3})
         if not gen_children or st.n_children == 0:
