@@ -41,6 +41,10 @@ struct DevProblem {
     // basic slack rows d0_rows (n_d0r) in terms of the nonbasic inequality slacks d0_cols (n_d0c); program
     // equalities are already eliminated.  d0: n_d0r x (1 + n_d0c), column 0 = value at the vertex.
     const double *d0; const int *d0_rows; const int *d0_cols; int n_d0r, n_d0c, has_d0;
+    const double *d0T;  // the same dictionary stored column-major ((1 + n_d0c) x n_d0r): lane i reads row i coalesced
+    // vertex of the parameter polytope {A_t theta <= b_t} (kernels2.hpp): theta = tv_theta - tv_minv * sigma, sigma = slacks
+    // of its n_t tight rows; tv_rows = the remaining n_tpre rows of A_t already expressed in sigma ([value | coefficients])
+    const double *tv_theta, *tv_minv, *tv_rows; int n_tpre, has_tv;
     // LDS layout (offsets in doubles from the start of dynamic LDS; ints follow the doubles)
     int kmax;           // largest cardinality with a solvable KKT (= min(n_c, n_x))
     int ld_x, ld_t;     // odd tableau strides of the (x,theta) LP and of the theta-space LPs
@@ -54,7 +58,7 @@ struct LevelCounters {
     unsigned long long xtheta_lps;  // candidates that needed the large (x,theta) LP
     unsigned long long xtheta_fallbacks;  // ... of which the warm start from the pre-crashed vertex was abandoned
     unsigned long long cycles[4];   // wave-cycles (s_memtime) spent in: KKT solve, theta LP, (x,theta) LP, region build
-    unsigned int work_verdict, work_region, n_opt, n_pruned_new;
+    unsigned int work_verdict, work_region, n_opt, n_pruned_new, work_retry, work_x;
 };
 
 struct Smem {
@@ -271,8 +275,10 @@ __device__ inline int xtheta_from_vertex(const DevProblem &P, int k, Smem &s, Lp
 // ------------------------------------------------------------------------------------------------------------
 // k_verdict: status per candidate: INFEASIBLE / FEASIBLE / SINGULAR / LP_LIMIT / OPT_PENDING
 // ------------------------------------------------------------------------------------------------------------
+// list != nullptr: process only the candidates list[0..n) (the retry list of k_verdict2), work counter ctr->work_region
 __global__ void __launch_bounds__(64) k_verdict(DevProblem P, const int32_t *__restrict__ cands, long long n, int k,
-                                                uint8_t *__restrict__ status, LevelCounters *__restrict__ ctr) {
+                                                uint8_t *__restrict__ status, LevelCounters *__restrict__ ctr,
+                                                const int32_t *__restrict__ list) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     Smem s = carve(P, smem);
     const int lane = lane_id(), nt = P.n_t, nx = P.n_x;
@@ -280,9 +286,10 @@ __global__ void __launch_bounds__(64) k_verdict(DevProblem P, const int32_t *__r
     long long cyc_kkt = 0, cyc_theta = 0, cyc_x = 0;
     for (;;) {
         unsigned int c = 0;
-        if (lane == 0) c = atomicAdd(&ctr->work_verdict, 1u);
-        c = __shfl(c, 0);
+        if (lane == 0) c = atomicAdd(list ? &ctr->work_retry : &ctr->work_verdict, 1u);
+        c = (unsigned)__builtin_amdgcn_readfirstlane((int)c);
         if (c >= n) break;
+        if (list) c = (unsigned)list[c];
         const int nin = load_active_set(P, cands + (size_t)c * k, k, s);
         int st = -1;
         const long long t0 = clock64();
@@ -381,7 +388,7 @@ __global__ void __launch_bounds__(64) k_region(DevProblem P, const int32_t *__re
     for (;;) {
         unsigned int w = 0;
         if (lane == 0) w = atomicAdd(&ctr->work_region, 1u);
-        w = __shfl(w, 0);
+        w = (unsigned)__builtin_amdgcn_readfirstlane((int)w);
         if (w >= (unsigned)n_opt) break;
         const int c = opt_list[w];
         const int nin = load_active_set(P, cands + (size_t)c * k, k, s);
@@ -608,9 +615,9 @@ __global__ void __launch_bounds__(1024) k_scan_apply(const int32_t *__restrict__
     if (i < n) out[i] = ex + sums[blockIdx.x];
 }
 
-__global__ void k_flag_status(const uint8_t *__restrict__ status, long long n, int which, int32_t *__restrict__ flag) {
+__global__ void k_flag_status(const uint8_t *__restrict__ status, long long n, int lo, int hi, int32_t *__restrict__ flag) {
     const long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
-    if (i < n) flag[i] = status[i] == which;
+    if (i < n) flag[i] = status[i] >= lo && status[i] <= hi;
 }
 __global__ void k_scatter_index(const int32_t *__restrict__ flag, const int32_t *__restrict__ pos, long long n,
                                 int32_t *__restrict__ list) {
@@ -721,7 +728,7 @@ __global__ void __launch_bounds__(64) k_lp_batch(long long n_lp, int m, int n, i
     for (;;) {
         unsigned int w = 0;
         if (lane == 0) w = atomicAdd(work, 1u);
-        w = __shfl(w, 0);
+        w = (unsigned)__builtin_amdgcn_readfirstlane((int)w);
         if (w >= n_lp) break;
         const double *Aw = A + (shared_A ? 0 : (size_t)w * m * n);
         const double *bw = b + (shared_b ? 0 : (size_t)w * m);

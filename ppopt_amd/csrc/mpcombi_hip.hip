@@ -11,11 +11,13 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <cstdlib>
 #include <string>
 #include <vector>
 
 #include "../../include/mpcombi.h"
 #include "kernels.hpp"
+#include "kernels2.hpp"
 
 using namespace mpc;
 
@@ -64,6 +66,13 @@ struct mpc_handle {
     DevBuf iblocks;           // integer blocks (row / column maps of the pre-crashed dictionary)
     DevProblem Pv{}, Pr{};    // verdict / region kernel views (same blocks, different LDS layouts)
     int lds_v = 0, lds_r = 0; // dynamic LDS bytes per wavefront
+    int force_v1 = 0;         // MPC_FORCE_V1=1 in the environment: never use k_verdict2 (A/B comparisons, tests)
+    int fast = 0;             // 1: register-engine kernels (k_theta2 / k_x2) with k_verdict as the retry path
+    int fast_t = 0, fast_x = 0; // instantiation selectors
+    long long n_needx = 0;
+    DevProblem Pf{};          // view for k_verdict2 (small LDS layout: no tableau)
+    int lds_f = 0, grid_f = 0;
+    DevBuf retry_list, pf_dev;
     int grid_v = 0, grid_r = 0;
     long long rec_d = 0, rec_i = 0;
     // frontier / pruned
@@ -212,6 +221,7 @@ int mpc_create(const mpc_problem *p, int32_t device, void *stream, mpc_handle **
     else { HIP_TRY(nullptr, hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking)); h->own_stream = true; }
     for (auto &e : h->ev) HIP_TRY(nullptr, hipEventCreate(&e));
     h->n_x = nx; h->n_t = nt; h->n_c = nc; h->n_eq = ne; h->n_tc = ntc; h->is_qp = p->Q != nullptr;
+    { const char *ev = std::getenv("MPC_FORCE_V1"); h->force_v1 = ev && ev[0] == '1'; }
 
     const int nr = nt + 1;
     // ---- host-side one-off blocks ----------------------------------------------------------------------
@@ -303,6 +313,64 @@ int mpc_create(const mpc_problem *p, int32_t device, void *stream, mpc_handle **
         }
         if (!ok) { d0.clear(); d0_rows.clear(); d0_cols.clear(); }
     }
+    // ---- vertex of the parameter polytope {A_t theta <= b_t} (kernels2.hpp) ----------------------------------------
+    std::vector<double> tv_theta, tv_minv, tv_rows, d0T;
+    {
+        bool ok = ntc >= nt;
+        std::vector<int32_t> tight(std::max(ntc, 1), 0);
+        int32_t lp_status = -1;
+        if (ok) {
+            std::vector<uint8_t> eqf(ntc, 0);
+            int rc0 = ntc > nt ? lp_batch_impl(device, 1, ntc, nt, p->A_t, 1, p->b_t, 1, nullptr, 1, eqf.data(), &lp_status, nullptr, nullptr, nullptr, tight.data()) : MPC_ERR_INVALID;
+            HIP_TRY(nullptr, hipSetDevice(device));
+            ok = rc0 == MPC_OK && lp_status == LP_OPTIMAL;
+        }
+        std::vector<int> B;
+        for (int i = 0; i < ntc && ok; ++i) if (tight[i]) B.push_back(i);
+        ok = ok && (int)B.size() == nt;
+        std::vector<double> M, MTf;
+        std::vector<int> perm;
+        if (ok) {
+            M.assign((size_t)nt * nt, 0.0);
+            for (int r = 0; r < nt; ++r) for (int j = 0; j < nt; ++j) M[(size_t)r * nt + j] = p->A_t[(size_t)B[r] * nt + j];
+            std::vector<double> LU(M);
+            ok = lu_factor(LU, nt, perm);
+            if (ok) {
+                tv_minv.assign((size_t)nt * nt, 0.0);
+                std::vector<double> e(nt), x(nt);
+                for (int j = 0; j < nt; ++j) {   // column j of M^-1
+                    std::fill(e.begin(), e.end(), 0.0); e[j] = 1.0;
+                    lu_solve_host(LU, perm, nt, e.data(), x.data());
+                    for (int t = 0; t < nt; ++t) tv_minv[(size_t)t * nt + j] = x[t];
+                }
+                std::vector<double> bB(nt);
+                for (int r = 0; r < nt; ++r) bB[r] = p->b_t[B[r]];
+                tv_theta.assign(nt, 0.0);
+                lu_solve_host(LU, perm, nt, bB.data(), tv_theta.data());
+                std::vector<char> inB(ntc, 0);
+                for (int r : B) inB[r] = 1;
+                for (int i = 0; i < ntc; ++i) {
+                    if (inB[i]) continue;
+                    double mx = 0; for (int t = 0; t < nt; ++t) mx = std::max(mx, std::fabs(p->A_t[(size_t)i * nt + t]));
+                    double sc = 1.0;
+                    if (mx > 1e-8) { int ex; std::frexp(mx, &ex); sc = std::ldexp(1.0, -ex); }
+                    double beta = p->b_t[i] * sc;
+                    for (int t = 0; t < nt; ++t) beta -= (mx > 1e-8 ? p->A_t[(size_t)i * nt + t] * sc : 0.0) * tv_theta[t];
+                    tv_rows.push_back(beta);
+                    for (int j = 0; j < nt; ++j) {
+                        double acc = 0; for (int t = 0; t < nt; ++t) acc += (mx > 1e-8 ? p->A_t[(size_t)i * nt + t] * sc : 0.0) * tv_minv[(size_t)t * nt + j];
+                        tv_rows.push_back(-acc);
+                    }
+                }
+            }
+        }
+        if (!ok) { tv_theta.clear(); tv_minv.clear(); tv_rows.clear(); }
+        if (!d0.empty()) {
+            const int mr = (int)d0_rows.size(), cc = 1 + (int)d0_cols.size();
+            d0T.assign((size_t)mr * cc, 0.0);
+            for (int i = 0; i < mr; ++i) for (int j = 0; j < cc; ++j) d0T[(size_t)j * mr + i] = d0[(size_t)i * cc + j];
+        }
+    }
     // ---- one device allocation for every read-only block -------------------------------------------------
     std::vector<double> host;
     auto put = [&](const double *src, size_t cnt) { size_t off = host.size(); host.insert(host.end(), src, src + cnt); while (host.size() % 2) host.push_back(0.0); return off; };
@@ -314,6 +382,10 @@ int mpc_create(const mpc_problem *p, int32_t device, void *stream, mpc_handle **
     const size_t oGt = put(mode == 0 ? Gt.data() : zeros.data(), mode == 0 ? Gt.size() : 1), oX0H = put(mode == 0 ? X0H.data() : zeros.data(), mode == 0 ? X0H.size() : 1);
     const size_t obase = put(base.data(), base.size());
     const size_t od0 = put(d0.empty() ? zeros.data() : d0.data(), d0.empty() ? 1 : d0.size());
+    const size_t od0T = put(d0T.empty() ? zeros.data() : d0T.data(), d0T.empty() ? 1 : d0T.size());
+    const size_t otvt = put(tv_theta.empty() ? zeros.data() : tv_theta.data(), tv_theta.empty() ? 1 : tv_theta.size());
+    const size_t otvm = put(tv_minv.empty() ? zeros.data() : tv_minv.data(), tv_minv.empty() ? 1 : tv_minv.size());
+    const size_t otvr = put(tv_rows.empty() ? zeros.data() : tv_rows.data(), tv_rows.empty() ? 1 : tv_rows.size());
     HIP_TRY(nullptr, h->blocks.ensure(host.size() * sizeof(double), h->stream));
     HIP_TRY(nullptr, hipMemcpyAsync(h->blocks.p, host.data(), host.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
     HIP_TRY(nullptr, hipStreamSynchronize(h->stream));
@@ -322,6 +394,8 @@ int mpc_create(const mpc_problem *p, int32_t device, void *stream, mpc_handle **
     P.n_x = nx; P.n_t = nt; P.n_c = nc; P.n_eq = ne; P.n_tc = ntc; P.is_qp = h->is_qp; P.kkt_mode = mode;
     P.A = d + oA; P.b = d + ob; P.F = d + oF; P.c = d + oc; P.H = d + oH; P.Q = d + oQ; P.A_t = d + oAt; P.b_t = d + obt;
     P.W = d + oW; P.UV = d + oUV; P.Gt = d + oGt; P.X0H = d + oX0H; P.base = d + obase;
+    P.d0T = d + od0T; P.tv_theta = d + otvt; P.tv_minv = d + otvm; P.tv_rows = d + otvr;
+    P.has_tv = tv_theta.empty() ? 0 : 1; P.n_tpre = tv_theta.empty() ? 0 : ntc - nt;
     P.d0 = d + od0; P.has_d0 = d0.empty() ? 0 : 1; P.n_d0r = (int)d0_rows.size(); P.n_d0c = (int)d0_cols.size();
     {
         std::vector<int> maps(d0_rows);
@@ -351,6 +425,24 @@ int mpc_create(const mpc_problem *p, int32_t device, void *stream, mpc_handle **
     if (h->lds_v > 48 * 1024) HIP_TRY(nullptr, hipFuncSetAttribute(reinterpret_cast<const void *>(k_verdict), hipFuncAttributeMaxDynamicSharedMemorySize, h->lds_v));
     if (h->lds_r > 48 * 1024) HIP_TRY(nullptr, hipFuncSetAttribute(reinterpret_cast<const void *>(k_region), hipFuncAttributeMaxDynamicSharedMemorySize, h->lds_r));
     h->grid_v = h->n_cu * waves_per_cu(h->lds_v);
+    // fast path (k_verdict2): needs the theta vertex, the pre-crashed dictionary and sizes inside the instantiations
+    {
+        const int rows_th = rows_t - nt, rows_x = P.n_d0r;
+        const int slots_t = rows_th <= 64 ? 1 : (rows_th <= 128 ? 2 : 0), slots_x = rows_x <= 64 ? 1 : (rows_x <= 128 ? 2 : 0);
+        const int tsel = nt <= 4 ? 0 : (nt <= 10 ? 1 : -1);
+        const int xsel = P.n_d0c <= 14 ? 0 : (P.n_d0c <= 30 ? 1 : -1);
+        if (P.has_tv && P.has_d0 && slots_t && slots_x && tsel >= 0 && xsel >= 0) {
+            h->fast = 1;
+            h->fast_t = tsel * 2 + (slots_t - 1);
+            h->fast_x = xsel * 2 + (slots_x - 1);
+            const Layout lf = make_layout(2, size_K, size_L, 0, mode == 1 ? size_X : 0, kmax, nc, 2, 2, 2);
+            h->Pf = P; apply_layout(h->Pf, lf); h->lds_f = lf.bytes;
+            h->grid_f = h->n_cu * std::min(16, waves_per_cu(h->lds_f));
+            HIP_TRY(nullptr, h->pf_dev.ensure(sizeof(DevProblem), h->stream));
+            HIP_TRY(nullptr, hipMemcpyAsync(h->pf_dev.p, &h->Pf, sizeof(DevProblem), hipMemcpyHostToDevice, h->stream));
+            HIP_TRY(nullptr, hipStreamSynchronize(h->stream));
+        }
+    }
     h->grid_r = h->n_cu * waves_per_cu(h->lds_r);
     h->rec_d = (long long)nx * nt + nx + (long long)nc * nt + nc + (long long)(nc + ntc) * nt + (nc + ntc);
     h->rec_i = 5 + (long long)nc + ntc + nc + nc + nc;
@@ -365,7 +457,7 @@ int mpc_destroy(mpc_handle *h) {
     (void)hipSetDevice(h->device);
     (void)hipStreamSynchronize(h->stream);
     for (DevBuf *b : {&h->blocks, &h->iblocks, &h->frontier, &h->children, &h->status, &h->pruned, &h->pruned_new, &h->flag, &h->pos, &h->opt_list,
-                      &h->childmask, &h->count, &h->offset, &h->recd, &h->reci, &h->ctr, &h->scratch, &h->sums}) b->release();
+                      &h->childmask, &h->count, &h->offset, &h->recd, &h->reci, &h->ctr, &h->scratch, &h->sums, &h->retry_list, &h->pf_dev}) b->release();
     for (auto &e : h->ev) if (e) (void)hipEventDestroy(e);
     if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
@@ -482,6 +574,7 @@ int mpc_level_run(mpc_handle *h, int32_t gen_children, mpc_level_stats *stats) {
     const int k = h->k;
     hipStream_t st = h->stream;
     h->n_opt = h->n_children = h->n_pruned_new = h->n_regions = 0;
+    h->n_needx = 0;
     LevelCounters host_ctr;
     std::memset(&host_ctr, 0, sizeof(host_ctr));
     float ms[3] = {0, 0, 0};
@@ -498,12 +591,61 @@ int mpc_level_run(mpc_handle *h, int32_t gen_children, mpc_level_stats *stats) {
         const int blocks256 = (int)((n + 255) / 256);
         // verdict
         HIP_TRY(h, hipEventRecord(h->ev[0], st));
-        hipLaunchKernelGGL(k_verdict, dim3((unsigned)std::min<long long>(n, h->grid_v)), dim3(64), h->lds_v, st, h->Pv,
-                           h->frontier.as<int32_t>(), n, k, h->status.as<uint8_t>(), ctr);
-        HIP_TRY(h, hipGetLastError());
+        if (h->fast && !h->force_v1) {
+            const int32_t *fr = h->frontier.as<int32_t>();
+            uint8_t *stp = h->status.as<uint8_t>();
+            const DevProblem *pf = h->pf_dev.as<DevProblem>();
+            // compacts the candidates whose status lies in [lo, hi] into h->retry_list; returns their number
+            auto compact = [&](int lo, int hi, int32_t *count) -> int {
+                hipLaunchKernelGGL(k_flag_status, dim3(blocks256), dim3(256), 0, st, h->status.as<uint8_t>(), n, lo, hi, h->flag.as<int32_t>());
+                int rcs = launch_scan(h, h->flag.as<int32_t>(), h->pos.as<int32_t>(), n, total);
+                if (rcs) return rcs;
+                HIP_TRY(h, h->retry_list.ensure(nn * sizeof(int32_t), st));
+                hipLaunchKernelGGL(k_scatter_index, dim3(blocks256), dim3(256), 0, st, h->flag.as<int32_t>(), h->pos.as<int32_t>(), n, h->retry_list.as<int32_t>());
+                HIP_TRY(h, hipMemcpyAsync(count, total, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+                HIP_TRY(h, hipStreamSynchronize(st));
+                return MPC_OK;
+            };
+            {   // KKT + two-stage theta LP
+                const dim3 g((unsigned)std::min<long long>(n, h->grid_f)), b(64);
+                switch (h->fast_t) {
+                    case 0: hipLaunchKernelGGL((k_theta2<4, 1>), g, b, h->lds_f, st, pf, fr, n, k, stp, ctr); break;
+                    case 1: hipLaunchKernelGGL((k_theta2<4, 2>), g, b, h->lds_f, st, pf, fr, n, k, stp, ctr); break;
+                    case 2: hipLaunchKernelGGL((k_theta2<10, 1>), g, b, h->lds_f, st, pf, fr, n, k, stp, ctr); break;
+                    default: hipLaunchKernelGGL((k_theta2<10, 2>), g, b, h->lds_f, st, pf, fr, n, k, stp, ctr); break;
+                }
+                HIP_TRY(h, hipGetLastError());
+            }
+            int32_t n_needx = 0;
+            { int rcs = compact(ST_NEEDX, ST_NEEDX_SING, &n_needx); if (rcs) return rcs; }
+            h->n_needx = n_needx;
+            if (n_needx > 0) {   // (x,theta) feasibility for the candidates the theta stage left open
+                const dim3 g((unsigned)std::min<long long>(n_needx, (long long)h->n_cu * 16)), b(64);
+                const int32_t *lst = h->retry_list.as<int32_t>();
+                switch (h->fast_x) {
+                    case 0: hipLaunchKernelGGL((k_x2<16, 1>), g, b, 0, st, pf, fr, k, lst, n_needx, stp, ctr); break;
+                    case 1: hipLaunchKernelGGL((k_x2<16, 2>), g, b, 0, st, pf, fr, k, lst, n_needx, stp, ctr); break;
+                    case 2: hipLaunchKernelGGL((k_x2<32, 1>), g, b, 0, st, pf, fr, k, lst, n_needx, stp, ctr); break;
+                    default: hipLaunchKernelGGL((k_x2<32, 2>), g, b, 0, st, pf, fr, k, lst, n_needx, stp, ctr); break;
+                }
+                HIP_TRY(h, hipGetLastError());
+            }
+            // numerically doubtful candidates (status 7) go through the LDS engine, which can refactorise its basis
+            int32_t n_retry = 0;
+            { int rcs = compact(ST_RETRY, ST_RETRY, &n_retry); if (rcs) return rcs; }
+            if (n_retry > 0) {
+                hipLaunchKernelGGL(k_verdict, dim3((unsigned)std::min<long long>(n_retry, h->grid_v)), dim3(64), h->lds_v, st, h->Pv,
+                                   h->frontier.as<int32_t>(), (long long)n_retry, k, h->status.as<uint8_t>(), ctr, h->retry_list.as<int32_t>());
+                HIP_TRY(h, hipGetLastError());
+            }
+        } else {
+            hipLaunchKernelGGL(k_verdict, dim3((unsigned)std::min<long long>(n, h->grid_v)), dim3(64), h->lds_v, st, h->Pv,
+                               h->frontier.as<int32_t>(), n, k, h->status.as<uint8_t>(), ctr, (const int32_t *)nullptr);
+            HIP_TRY(h, hipGetLastError());
+        }
         HIP_TRY(h, hipEventRecord(h->ev[1], st));
         // optimal candidates -> region kernel
-        hipLaunchKernelGGL(k_flag_status, dim3(blocks256), dim3(256), 0, st, h->status.as<uint8_t>(), n, ST_OPT_PENDING, h->flag.as<int32_t>());
+        hipLaunchKernelGGL(k_flag_status, dim3(blocks256), dim3(256), 0, st, h->status.as<uint8_t>(), n, ST_OPT_PENDING, ST_OPT_PENDING, h->flag.as<int32_t>());
         { int rcs = launch_scan(h, h->flag.as<int32_t>(), h->pos.as<int32_t>(), n, total); if (rcs) return rcs; }
         hipLaunchKernelGGL(k_scatter_index, dim3(blocks256), dim3(256), 0, st, h->flag.as<int32_t>(), h->pos.as<int32_t>(), n, h->opt_list.as<int32_t>());
         HIP_TRY(h, hipGetLastError());
@@ -560,7 +702,7 @@ int mpc_level_run(mpc_handle *h, int32_t gen_children, mpc_level_stats *stats) {
         for (int i = 0; i < 6; ++i) stats->n_status[i] = (int64_t)host_ctr.status[i];
         stats->n_regions = h->n_regions; stats->n_children = h->n_children; stats->n_pruned_new = h->n_pruned_new;
         stats->lp_pivots = (int64_t)host_ctr.pivots;
-        stats->n_xtheta_lp = (int64_t)host_ctr.xtheta_lps;
+        stats->n_xtheta_lp = (int64_t)host_ctr.xtheta_lps + h->n_needx;
         stats->n_xtheta_fallback = (int64_t)host_ctr.xtheta_fallbacks;
         for (int i = 0; i < 4; ++i) stats->wave_cycles[i] = (int64_t)host_ctr.cycles[i];
         stats->ms_verdict = ms[0]; stats->ms_region = ms[1]; stats->ms_children = ms[2]; stats->ms_total = ms[0] + ms[1] + ms[2];
