@@ -83,7 +83,8 @@ typedef struct {
     float ms_verdict, ms_region, ms_children, ms_total; /* HIP-event times on the handle's stream */
     int64_t n_xtheta_lp;   /* candidates whose feasibility needed the large (x,theta) LP */
     int64_t n_xtheta_fallback; /* ... of which the vertex warm start was abandoned for a from-scratch solve */
-    int64_t wave_cycles[4];    /* k_verdict wavefront cycles in: KKT solve, theta LP, (x,theta) LP, (reserved) */
+    int64_t wave_cycles[4];    /* wavefront cycles in: KKT solve, theta LP, (x,theta) LP, region build */
+    int64_t n_region_retry;    /* optimal candidates re-solved by the LDS-engine region kernel */
 } mpc_level_stats;
 
 /* ---- library / device ------------------------------------------------------------------------------ */
@@ -131,6 +132,16 @@ int mpc_level_status(mpc_handle *h, uint8_t *status_host);                      
  * i.e. every field of CriticalRegion (critical_region.py:34-48); E/f are the non-redundant unit-norm rows
  * before exact-duplicate removal. */
 int mpc_level_regions(mpc_handle *h, double *rec_d_host, int32_t *rec_i_host, int64_t *cand_index_host, int64_t cap);
+/* The same regions in compact form (what the device writes; no padding to n_c):
+ *   head_d (fd doubles each): A_x[n_x*n_t] b_x[n_x] A_l[k*n_t] b_l[k]
+ *   head_i (fi ints each):    3 cand nE n_omega n_lambda n_regular e_off 0 | active[k] | omega[n_tc] | lambda[k]
+ *                             | regular_idx[n_c-k] | regular_con[n_c-k]            (unused = -1)
+ *   erows  (n_t+1 doubles each): f, E[0..n_t)  -- region i owns rows e_off .. e_off+nE-1
+ * mpc_compact_strides gives fd, fi for the current frontier (they depend on its cardinality k) and an upper bound
+ * of the number of rows this level's regions own. */
+int mpc_compact_strides(const mpc_handle *h, int64_t *fd, int64_t *fi, int64_t *max_rows);
+int mpc_level_regions_compact(mpc_handle *h, double *head_d, int32_t *head_i, int64_t cap_regions, double *erows,
+                              int64_t cap_rows, int64_t *n_regions, int64_t *n_rows);
 int mpc_level_children(mpc_handle *h, int32_t *children_host, int64_t cap);     /* n_children x (k+1) */
 int mpc_level_children_device(mpc_handle *h, int32_t *children_dev, int64_t cap);
 int mpc_level_pruned_new(mpc_handle *h, uint64_t *masks_host, int64_t cap);

@@ -40,7 +40,7 @@ class LevelStats(ctypes.Structure):
                 ('n_pruned_new', ctypes.c_int64), ('lp_pivots', ctypes.c_int64), ('ms_verdict', ctypes.c_float),
                 ('ms_region', ctypes.c_float), ('ms_children', ctypes.c_float), ('ms_total', ctypes.c_float),
                 ('n_xtheta_lp', ctypes.c_int64), ('n_xtheta_fallback', ctypes.c_int64),
-                ('wave_cycles', ctypes.c_int64 * 4)]
+                ('wave_cycles', ctypes.c_int64 * 4), ('n_region_retry', ctypes.c_int64)]
 
 
 _lib = None
@@ -80,6 +80,8 @@ def load():
         'mpc_level_run': (ctypes.c_int, [H, ctypes.c_int32, ctypes.POINTER(LevelStats)]),
         'mpc_level_status': (ctypes.c_int, [H, _u8p]),
         'mpc_level_regions': (ctypes.c_int, [H, _dp, _ip, _lp, ctypes.c_int64]),
+        'mpc_compact_strides': (ctypes.c_int, [H, _lp, _lp, _lp]),
+        'mpc_level_regions_compact': (ctypes.c_int, [H, _dp, _ip, ctypes.c_int64, _dp, ctypes.c_int64, _lp, _lp]),
         'mpc_level_children': (ctypes.c_int, [H, _ip, ctypes.c_int64]),
         'mpc_level_children_device': (ctypes.c_int, [H, ctypes.c_void_p, ctypes.c_int64]),
         'mpc_level_pruned_new': (ctypes.c_int, [H, _u64p, ctypes.c_int64]),
@@ -103,8 +105,8 @@ EXPORTED_SYMBOLS = ['mpc_device_count', 'mpc_version', 'mpc_last_global_error', 
                     'mpc_last_error', 'mpc_region_doubles', 'mpc_region_ints', 'mpc_lds_bytes', 'mpc_stream',
                     'mpc_frontier_root', 'mpc_frontier_set', 'mpc_frontier_set_device', 'mpc_frontier_info',
                     'mpc_frontier_get', 'mpc_pruned_clear', 'mpc_pruned_add', 'mpc_pruned_add_device',
-                    'mpc_pruned_count', 'mpc_pruned_get', 'mpc_level_run', 'mpc_level_status', 'mpc_level_regions',
-                    'mpc_level_children', 'mpc_level_children_device', 'mpc_level_pruned_new',
+                    'mpc_pruned_count', 'mpc_pruned_get', 'mpc_level_run', 'mpc_level_status', 'mpc_level_regions', 'mpc_compact_strides',
+                    'mpc_level_regions_compact', 'mpc_level_children', 'mpc_level_children_device', 'mpc_level_pruned_new',
                     'mpc_level_pruned_new_device', 'mpc_frontier_advance', 'mpc_check_level', 'mpc_lp_solve_batch']
 
 
@@ -257,6 +259,24 @@ class Engine:
             self._check(self._L.mpc_level_regions(self._h, d.ctypes.data_as(_dp), i.ctypes.data_as(_ip),
                                                   idx.ctypes.data_as(_lp), nr), 'mpc_level_regions')
         return d, i, idx
+
+    def level_regions_compact(self):
+        """Regions of the level in the device's compact form: (head_d [n, fd], head_i [n, fi], erows [R, n_t+1], k)."""
+        nr = int(self._last.n_regions)
+        fd, fi, mr = ctypes.c_int64(0), ctypes.c_int64(0), ctypes.c_int64(0)
+        self._check(self._L.mpc_compact_strides(self._h, ctypes.byref(fd), ctypes.byref(fi), ctypes.byref(mr)),
+                    'mpc_compact_strides')
+        k = int(self._last.k)
+        rows_cap = int(mr.value) if nr else 0
+        hd = numpy.empty((nr, fd.value))
+        hi = numpy.empty((nr, fi.value), dtype=numpy.int32)
+        er = numpy.empty((max(rows_cap, 1), self.n_t + 1))
+        n1, n2 = ctypes.c_int64(0), ctypes.c_int64(0)
+        if nr:
+            self._check(self._L.mpc_level_regions_compact(self._h, hd.ctypes.data_as(_dp), hi.ctypes.data_as(_ip), nr,
+                                                          er.ctypes.data_as(_dp), rows_cap, ctypes.byref(n1),
+                                                          ctypes.byref(n2)), 'mpc_level_regions_compact')
+        return hd[:n1.value], hi[:n1.value], er[:n2.value], k
 
     def level_children(self) -> numpy.ndarray:
         n = int(self._last.n_children)

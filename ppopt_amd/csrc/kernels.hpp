@@ -58,7 +58,7 @@ struct LevelCounters {
     unsigned long long xtheta_lps;  // candidates that needed the large (x,theta) LP
     unsigned long long xtheta_fallbacks;  // ... of which the warm start from the pre-crashed vertex was abandoned
     unsigned long long cycles[4];   // wave-cycles (s_memtime) spent in: KKT solve, theta LP, (x,theta) LP, region build
-    unsigned int work_verdict, work_region, n_opt, n_pruned_new, work_retry, work_x;
+    unsigned int work_verdict, work_region, n_opt, n_pruned_new, work_retry, work_x, e_rows, work_r2;
 };
 
 struct Smem {

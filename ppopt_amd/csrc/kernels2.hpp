@@ -224,4 +224,246 @@ __global__ void __launch_bounds__(64, (NXC * SLOTS >= 64 ? 2 : 3)) k_x2(const De
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// k_region2: gen_cr_from_active_set (utils/mpqp_utils.py:89-195) on the register engine, compact output.
+//
+//   rows      built exactly as the reference builds them (multiplier rows, inactive rows through the x-law, A_t rows),
+//             zero rows dropped, unit L2 norm; master copy E|f in LDS, dictionary rows at the theta vertex in VGPRs
+//   full dim  Chebyshev LP  max r : E theta + ||E_i|| r <= f  (phase 1 + phase 2 on a cost row)
+//   facets    the reference solves one LP per row ("is {E theta <= f, E_i theta = f_i} non-empty?", lines 143-178).
+//             Here ONE feasible dictionary is kept and walked: r is driven back to 0, then for every row its slack is
+//             either already zero at the current vertex (kept), or minimised by a short primal run from the current
+//             vertex (kept iff the minimum is <= 1e-7); every slack that is zero at a visited vertex is marked kept on
+//             the way, so most rows need no run of their own.  Same decision, 5-10x fewer pivots.
+//   output    compact: fixed "head" per optimal candidate (x-law, multipliers, index sets) + E|f rows appended to a row
+//             pool (atomic bump allocation), exact duplicate rows removed (mpqp_utils.py:191).
+// head_d (stride fd): A_x[n_x*n_t] b_x[n_x] A_l[k*n_t] b_l[k]
+// head_i (stride fi): status cand nE n_om n_la n_re e_off 0 | active[k] | omega[n_tc] | lambda[k] | reg_idx[n_c-k] | reg_con[n_c-k]
+// pool row: f, E[0..n_t)
+template <int NT, int SLOTS>
+__global__ void __launch_bounds__(64, (NT * SLOTS >= 20 ? 2 : 3)) k_region2(
+    const DevProblem *__restrict__ Pg, const int32_t *__restrict__ cands, int k, const int32_t *__restrict__ opt_list, int n_opt,
+    uint8_t *__restrict__ status, double *__restrict__ head_d, int32_t *__restrict__ head_i, int fd, int fi,
+    double *__restrict__ epool, LevelCounters *__restrict__ ctr) {
+    const DevProblem &P = *Pg;
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    Smem s = carve(P, smem);
+    const int lane = lane_id(), nt = P.n_t, nr = nt + 1, nx = P.n_x, nc = P.n_c, ntc = P.n_tc, e = P.n_eq;
+    constexpr int NC = NT + 3;      // value | n_t sigma columns | r | one spare slot for x0
+    constexpr int ID_SIGMA = 4096, ID_R = 8192;
+    unsigned long long pivots = 0;
+    long long cyc = 0;
+    for (;;) {
+        unsigned int w = 0;
+        if (lane == 0) w = atomicAdd(&ctr->work_r2, 1u);
+        w = (unsigned)__builtin_amdgcn_readfirstlane((int)w);
+        if (w >= (unsigned)n_opt) break;
+        const long long t0 = clock64();
+        const int c = opt_list[w];
+        const int nin = load_active_set(P, cands + (size_t)c * k, k, s);
+        double *hd = head_d + (size_t)w * fd;
+        int32_t *hi = head_i + (size_t)w * fi;
+        for (int i = lane; i < fi; i += 64) hi[i] = i < 8 ? 0 : -1;
+        int st = ST_REGION;
+        const int kk = kkt_solve(P, k, s);
+        if (kk != 0) st = kk == 1 ? ST_INFEASIBLE : ST_SINGULAR;
+        int nE = 0, n_om = 0, n_la = 0, n_re = 0, e_off = 0;
+        bool retry = false;
+        if (st == ST_REGION) {
+            if (P.kkt_mode == 0) x_law_schur(P, k, s);
+            const int nlam = k - e, m = nlam + nin + ntc, ldE = nr;
+            RegLp<NC, SLOTS> lp;
+            lp.m = m + 1; lp.iters = 0; lp.max_iter = 50 * (m + nt) + 200; lp.growth = 0.0;
+            lp.alive = (1u << (nt + 2)) - 2u;          // columns 1..nt (sigma) and nt+1 (r)
+            lp.cv = lane <= nt ? ID_SIGMA + lane : ID_R;
+            wave_sync();
+#pragma unroll
+            for (int sl = 0; sl < SLOTS; ++sl) {
+                const int i = lane + 64 * sl;
+                double h = 0.0, g[NT];
+#pragma unroll
+                for (int t = 0; t < NT; ++t) g[t] = 0.0;
+                if (i < nlam) {
+                    h = s.L[(e + i) * nr];
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) if (t < nt) g[t] = -s.L[(e + i) * nr + 1 + t];
+                } else if (i < nlam + nin) {
+                    const int ci = s.inact[i - nlam];
+                    double acc[NT + 1];
+#pragma unroll
+                    for (int t = 0; t <= NT; ++t) acc[t] = 0.0;
+                    for (int l = 0; l < nx; ++l) {
+                        const double a = P.A[ci * nx + l];
+#pragma unroll
+                        for (int t = 0; t <= NT; ++t) if (t <= nt) acc[t] = fma(a, s.X[l * nr + t], acc[t]);
+                    }
+                    h = P.b[ci] - acc[0];
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) if (t < nt) g[t] = acc[1 + t] - P.F[ci * nt + t];
+                } else if (i < m) {
+                    h = P.b_t[i - nlam - nin];
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) if (t < nt) g[t] = P.A_t[(i - nlam - nin) * nt + t];
+                }
+                bool keep = false;
+                double ss = 0.0;
+#pragma unroll
+                for (int t = 0; t < NT; ++t) { if (!(fabs(g[t]) <= ZERO_ROW_ATOL)) keep = true; ss = fma(g[t], g[t], ss); }
+                keep = keep && i < m;
+                double nrm = 0.0;
+                if (keep) {
+                    const double inv = 1.0 / sqrt(ss);
+                    h *= inv;
+                    double s2 = 0.0;
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) { g[t] *= inv; s2 = fma(g[t], g[t], s2); }
+                    nrm = sqrt(s2);
+                    s.E[i * ldE] = h;
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) if (t < nt) s.E[i * ldE + 1 + t] = g[t];
+                }
+                if (i < m) s.kept[i] = keep ? 0 : 3;   // 0 undecided, 1 kept, 2 redundant, 3 dropped (numerically zero row)
+                lp.var[sl] = i;
+                lp.kind[sl] = keep ? RK_INEQ : RK_DEAD;
+                double b0 = h;
+#pragma unroll
+                for (int t = 0; t < NT; ++t) if (t < nt) b0 = fma(-g[t], P.tv_theta[t], b0);
+                lp.t[sl][0] = keep ? b0 : 0.0;
+#pragma unroll
+                for (int j = 0; j < NT; ++j) {
+                    double acc = 0.0;
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) if (t < nt && j < nt) acc = fma(g[t], P.tv_minv[t * nt + j], acc);
+                    lp.t[sl][1 + j] = keep ? -acc : 0.0;
+                }
+                // the r column sits at index nt+1 (runtime): select chain over the compile-time slots
+#pragma unroll
+                for (int j = 1; j < NC; ++j) if (j == nt + 1) lp.t[sl][j] = nrm; else if (j > nt + 1) lp.t[sl][j] = 0.0;
+                if (i == m) {   // cost row: minimise -r
+                    lp.kind[sl] = RK_COST;
+#pragma unroll
+                    for (int j = 0; j < NC; ++j) lp.t[sl][j] = (j == nt + 1) ? -1.0 : 0.0;
+                }
+            }
+            wave_sync();
+            // ---- full dimensionality: Chebyshev ball ---------------------------------------------------------------
+            int r1 = lp.phase1();
+            int r2 = 0;
+            if (r1 == LP_OPTIMAL) r2 = lp.primal(-1, m);
+            double radius = 0.0;
+            int rrow = -1;
+            {
+#pragma unroll
+                for (int sl = SLOTS - 1; sl >= 0; --sl) {
+                    const unsigned long long br = __ballot(lp.var[sl] == ID_R && lp.kind[sl] == RK_INEQ);
+                    if (br) rrow = __ffsll((long long)br) - 1 + 64 * sl;
+                }
+                if (rrow >= 0) radius = lp.beta(rrow);
+            }
+            if (r1 == LP_ITERLIMIT || r2 == 3) st = ST_LP_LIMIT;
+            else if (lp.growth > GROWTH_SAFE) retry = true;
+            else if (r1 != LP_OPTIMAL || r2 == 2 || !(radius > FULL_DIM_RADIUS)) st = ST_OPT_NO_REGION;
+            // ---- facets: walk the feasible dictionary ------------------------------------------------------------------
+            if (st == ST_REGION && !retry) {
+                lp.set_kind(m, RK_DEAD);                              // the cost row is no longer needed
+                int rz = LP_OPTIMAL;
+                if (rrow >= 0) rz = lp.drive_to_zero(rrow);           // r back to 0 (slacks only grow: stays feasible)
+                else {
+                    const unsigned long long bc = __ballot(lp.cv == ID_R && lane >= 1 && lane < NC && ((lp.alive >> lane) & 1u));
+                    if (bc) lp.drop_col(__ffsll((long long)bc) - 1);
+                }
+                if (rz != LP_OPTIMAL) retry = true;
+                auto mark_tight = [&]() {
+                    // every slack that is zero at the current vertex belongs to a kept row
+                    if (lane >= 1 && lane < NC && ((lp.alive >> lane) & 1u) && lp.cv < m) s.kept[lp.cv] = 1;
+#pragma unroll
+                    for (int sl = 0; sl < SLOTS; ++sl)
+                        if (lp.kind[sl] == RK_INEQ && lp.var[sl] < m && lp.t[sl][0] <= TOL_FEAS) s.kept[lp.var[sl]] = 1;
+                    wave_sync();
+                };
+                if (!retry) mark_tight();
+                for (int cidx = 0; cidx < m && !retry && st == ST_REGION; ++cidx) {
+                    if (s.kept[cidx] != 0) continue;
+                    int row = -1;
+#pragma unroll
+                    for (int sl = SLOTS - 1; sl >= 0; --sl) {
+                        const unsigned long long br = __ballot(lp.var[sl] == cidx && lp.kind[sl] == RK_INEQ);
+                        if (br) row = __ffsll((long long)br) - 1 + 64 * sl;
+                    }
+                    if (row < 0) { retry = true; break; }
+                    lp.set_kind(row, RK_X0);
+                    const int pr = lp.primal(row, -1, false);
+                    if (pr == 3) { st = ST_LP_LIMIT; break; }
+                    bool kept_c = pr == 4;
+                    if (pr != 4) { kept_c = lp.beta(row) <= TOL_FEAS; lp.set_kind(row, RK_INEQ); }
+                    wave_sync();
+                    if (lane == 0) s.kept[cidx] = kept_c ? 1 : 2;
+                    wave_sync();
+                    mark_tight();
+                }
+                if (lp.growth > GROWTH_SAFE) retry = true;
+            }
+            pivots += lp.iters;
+            // ---- record ----------------------------------------------------------------------------------------------
+            if (st == ST_REGION && !retry) {
+                int32_t *act = hi + 8, *om = act + k, *la = om + ntc, *ridx = la + k, *rcon = ridx + (nc - k);
+                // duplicate rows: row i is dropped from E if an earlier kept row has identical (f, E)
+                bool dup[SLOTS], kp[SLOTS];
+#pragma unroll
+                for (int sl = 0; sl < SLOTS; ++sl) { const int i = lane + 64 * sl; kp[sl] = i < m && s.kept[i] == 1; dup[sl] = false; }
+                for (int j = 0; j < m; ++j) {
+                    if (s.kept[j] != 1) continue;
+#pragma unroll
+                    for (int sl = 0; sl < SLOTS; ++sl) {
+                        const int i = lane + 64 * sl;
+                        if (kp[sl] && i > j) {
+                            bool same = true;
+                            for (int t = 0; t <= nt; ++t) same = same && (s.E[i * ldE + t] == s.E[j * ldE + t]);
+                            dup[sl] = dup[sl] || same;
+                        }
+                    }
+                }
+                int base_la = 0, base_re = 0, base_om = 0, base_e = 0;
+                unsigned long long bE[SLOTS];
+#pragma unroll
+                for (int sl = 0; sl < SLOTS; ++sl) bE[sl] = __ballot(kp[sl] && !dup[sl]);
+#pragma unroll
+                for (int sl = 0; sl < SLOTS; ++sl) nE += __popcll(bE[sl]);
+                if (lane == 0) e_off = (int)atomicAdd(&ctr->e_rows, (unsigned)nE);
+                e_off = __builtin_amdgcn_readfirstlane(e_off);
+                const unsigned long long below = (1ull << lane) - 1ull;
+#pragma unroll
+                for (int sl = 0; sl < SLOTS; ++sl) {
+                    const int i = lane + 64 * sl;
+                    const int cls = i < nlam ? 0 : (i < nlam + nin ? 1 : 2);
+                    const unsigned long long b0 = __ballot(kp[sl] && cls == 0), b1 = __ballot(kp[sl] && cls == 1), b2 = __ballot(kp[sl] && cls == 2);
+                    if (kp[sl] && cls == 0) la[base_la + __popcll(b0 & below)] = s.as[e + i];
+                    if (kp[sl] && cls == 1) { const int p = base_re + __popcll(b1 & below); ridx[p] = i - nlam; rcon[p] = s.inact[i - nlam]; }
+                    if (kp[sl] && cls == 2) om[base_om + __popcll(b2 & below)] = i - nlam - nin;
+                    base_la += __popcll(b0); base_re += __popcll(b1); base_om += __popcll(b2);
+                    if (kp[sl] && !dup[sl]) {
+                        double *dst = epool + (size_t)(e_off + base_e + __popcll(bE[sl] & below)) * nr;
+                        for (int t = 0; t <= nt; ++t) dst[t] = s.E[i * ldE + t];
+                    }
+                    base_e += __popcll(bE[sl]);
+                }
+                n_la = base_la; n_re = base_re; n_om = base_om;
+                for (int idx = lane; idx < nx * nt; idx += 64) hd[idx] = s.X[(idx / nt) * nr + 1 + idx % nt];
+                for (int i = lane; i < nx; i += 64) hd[nx * nt + i] = s.X[i * nr];
+                double *Al = hd + nx * nt + nx, *bl = Al + k * nt;
+                for (int idx = lane; idx < k * nt; idx += 64) Al[idx] = s.L[(idx / nt) * nr + 1 + idx % nt];
+                for (int i = lane; i < k; i += 64) bl[i] = s.L[i * nr];
+                for (int i = lane; i < k; i += 64) act[i] = s.as[i];
+            }
+        }
+        if (retry) st = ST_RETRY;
+        if (lane == 0) {
+            hi[0] = st; hi[1] = c; hi[2] = nE; hi[3] = n_om; hi[4] = n_la; hi[5] = n_re; hi[6] = e_off; hi[7] = 0;
+            status[c] = (uint8_t)st;
+        }
+        cyc += clock64() - t0;
+    }
+    if (lane == 0) { atomicAdd(&ctr->pivots, pivots); atomicAdd(&ctr->cycles[3], (unsigned long long)cyc); }
+}
+
 }  // namespace mpc

@@ -165,7 +165,9 @@ struct RegLp {
 
     // primal simplex; phase1_row >= 0: minimise x0 (basic in that row), else minimise the RK_COST row `cost_row`.
     // 0 optimal, 2 unbounded, 3 iteration limit, 4 x0 left the basis
-    __device__ __forceinline__ int primal(int phase1_row, int cost_row) {
+    // drop_on_leave: when the minimised variable leaves the basis its column is deleted (it stays fixed at zero);
+    // false = it stays a regular nonbasic variable (facet tests in k_region2).
+    __device__ __forceinline__ int primal(int phase1_row, int cost_row, bool drop_on_leave = true) {
         const int lane = lane_id();
         int deg = 0;
         for (;;) {
@@ -245,7 +247,7 @@ struct RegLp {
             deg = (rmin <= 0.0) ? deg + 1 : 0;
             const bool leaving_x0 = get_kind(r) == RK_X0;
             pivot(r, q);
-            if (leaving_x0) { set_kind(r, RK_INEQ); drop_col(q); return 4; }
+            if (leaving_x0) { set_kind(r, RK_INEQ); if (drop_on_leave) drop_col(q); return 4; }
         }
     }
 

@@ -50,6 +50,24 @@ struct DevBuf {
     template <class T> T *as() const { return reinterpret_cast<T *>(p); }
 };
 
+// pinned (page-locked) host staging: device-to-host copies run at link speed and never page-fault
+struct HostBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+    hipError_t ensure(size_t bytes) {
+        if (bytes <= cap) return hipSuccess;
+        size_t want = std::max(bytes, cap + cap / 2);
+        want = (want + 4095) & ~size_t(4095);
+        if (p) (void)hipHostFree(p);
+        p = nullptr; cap = 0;
+        hipError_t e = hipHostMalloc(&p, want, hipHostMallocDefault);
+        if (e == hipSuccess) cap = want;
+        return e;
+    }
+    void release() { if (p) (void)hipHostFree(p); p = nullptr; cap = 0; }
+    template <class T> T *as() const { return reinterpret_cast<T *>(p); }
+};
+
 int odd_at_least(int v) { return (v % 2) ? v : v + 1; }
 
 }  // namespace
@@ -72,7 +90,13 @@ struct mpc_handle {
     long long n_needx = 0;
     DevProblem Pf{};          // view for k_verdict2 (small LDS layout: no tableau)
     int lds_f = 0, grid_f = 0;
-    DevBuf retry_list, pf_dev;
+    DevBuf retry_list, pf_dev, pr2_dev, headd, headi, epool;
+    DevProblem Pr2{};         // view for k_region2
+    int lds_r2 = 0, grid_r2 = 0, fast_r = -1;   // fast_r: k_region2 instantiation, -1 = none (n_t == 1 or too many rows)
+    bool used_region2 = false;
+    long long n_rretry = 0, n_erows = 0;
+    int fd = 0, fi = 0;
+    HostBuf st_list, st_status, st_hd, st_hi, st_pool, st_fxd, st_fxi, st_rlist;   // pinned staging for region fetches
     int grid_v = 0, grid_r = 0;
     long long rec_d = 0, rec_i = 0;
     // frontier / pruned
@@ -441,6 +465,17 @@ int mpc_create(const mpc_problem *p, int32_t device, void *stream, mpc_handle **
             HIP_TRY(nullptr, h->pf_dev.ensure(sizeof(DevProblem), h->stream));
             HIP_TRY(nullptr, hipMemcpyAsync(h->pf_dev.p, &h->Pf, sizeof(DevProblem), hipMemcpyHostToDevice, h->stream));
             HIP_TRY(nullptr, hipStreamSynchronize(h->stream));
+            // k_region2: all rows_t region rows plus the cost row, n_t >= 2 (the one-parameter variant stays on k_region)
+            const int slots_r = rows_t + 1 <= 64 ? 1 : (rows_t + 1 <= 128 ? 2 : 0);
+            if (nt >= 2 && slots_r) {
+                h->fast_r = tsel * 2 + (slots_r - 1);
+                const Layout l2 = make_layout(2, size_K, size_L, rows_t * nr, size_X, kmax, nc, 2, 2, rows_t);
+                h->Pr2 = P; apply_layout(h->Pr2, l2); h->lds_r2 = l2.bytes;
+                h->grid_r2 = h->n_cu * std::min(12, waves_per_cu(h->lds_r2));
+                HIP_TRY(nullptr, h->pr2_dev.ensure(sizeof(DevProblem), h->stream));
+                HIP_TRY(nullptr, hipMemcpyAsync(h->pr2_dev.p, &h->Pr2, sizeof(DevProblem), hipMemcpyHostToDevice, h->stream));
+                HIP_TRY(nullptr, hipStreamSynchronize(h->stream));
+            }
         }
     }
     h->grid_r = h->n_cu * waves_per_cu(h->lds_r);
@@ -457,7 +492,8 @@ int mpc_destroy(mpc_handle *h) {
     (void)hipSetDevice(h->device);
     (void)hipStreamSynchronize(h->stream);
     for (DevBuf *b : {&h->blocks, &h->iblocks, &h->frontier, &h->children, &h->status, &h->pruned, &h->pruned_new, &h->flag, &h->pos, &h->opt_list,
-                      &h->childmask, &h->count, &h->offset, &h->recd, &h->reci, &h->ctr, &h->scratch, &h->sums, &h->retry_list, &h->pf_dev}) b->release();
+                      &h->childmask, &h->count, &h->offset, &h->recd, &h->reci, &h->ctr, &h->scratch, &h->sums, &h->retry_list, &h->pf_dev, &h->pr2_dev, &h->headd, &h->headi, &h->epool}) b->release();
+    for (HostBuf *b : {&h->st_list, &h->st_status, &h->st_hd, &h->st_hi, &h->st_pool, &h->st_fxd, &h->st_fxi, &h->st_rlist}) b->release();
     for (auto &e : h->ev) if (e) (void)hipEventDestroy(e);
     if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
@@ -589,23 +625,23 @@ int mpc_level_run(mpc_handle *h, int32_t gen_children, mpc_level_stats *stats) {
         LevelCounters *ctr = h->ctr.as<LevelCounters>();
         int32_t *total = h->scratch.as<int32_t>();
         const int blocks256 = (int)((n + 255) / 256);
+        // compacts the candidates whose status lies in [lo, hi] into h->retry_list; returns their number
+        auto compact = [&](int lo, int hi, int32_t *count) -> int {
+            hipLaunchKernelGGL(k_flag_status, dim3(blocks256), dim3(256), 0, st, h->status.as<uint8_t>(), n, lo, hi, h->flag.as<int32_t>());
+            int rcs = launch_scan(h, h->flag.as<int32_t>(), h->pos.as<int32_t>(), n, total);
+            if (rcs) return rcs;
+            HIP_TRY(h, h->retry_list.ensure(nn * sizeof(int32_t), st));
+            hipLaunchKernelGGL(k_scatter_index, dim3(blocks256), dim3(256), 0, st, h->flag.as<int32_t>(), h->pos.as<int32_t>(), n, h->retry_list.as<int32_t>());
+            HIP_TRY(h, hipMemcpyAsync(count, total, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+            HIP_TRY(h, hipStreamSynchronize(st));
+            return MPC_OK;
+        };
         // verdict
         HIP_TRY(h, hipEventRecord(h->ev[0], st));
         if (h->fast && !h->force_v1) {
             const int32_t *fr = h->frontier.as<int32_t>();
             uint8_t *stp = h->status.as<uint8_t>();
             const DevProblem *pf = h->pf_dev.as<DevProblem>();
-            // compacts the candidates whose status lies in [lo, hi] into h->retry_list; returns their number
-            auto compact = [&](int lo, int hi, int32_t *count) -> int {
-                hipLaunchKernelGGL(k_flag_status, dim3(blocks256), dim3(256), 0, st, h->status.as<uint8_t>(), n, lo, hi, h->flag.as<int32_t>());
-                int rcs = launch_scan(h, h->flag.as<int32_t>(), h->pos.as<int32_t>(), n, total);
-                if (rcs) return rcs;
-                HIP_TRY(h, h->retry_list.ensure(nn * sizeof(int32_t), st));
-                hipLaunchKernelGGL(k_scatter_index, dim3(blocks256), dim3(256), 0, st, h->flag.as<int32_t>(), h->pos.as<int32_t>(), n, h->retry_list.as<int32_t>());
-                HIP_TRY(h, hipMemcpyAsync(count, total, sizeof(int32_t), hipMemcpyDeviceToHost, st));
-                HIP_TRY(h, hipStreamSynchronize(st));
-                return MPC_OK;
-            };
             {   // KKT + two-stage theta LP
                 const dim3 g((unsigned)std::min<long long>(n, h->grid_f)), b(64);
                 switch (h->fast_t) {
@@ -653,7 +689,39 @@ int mpc_level_run(mpc_handle *h, int32_t gen_children, mpc_level_stats *stats) {
         HIP_TRY(h, hipMemcpyAsync(&n_opt, total, sizeof(int32_t), hipMemcpyDeviceToHost, st));
         HIP_TRY(h, hipStreamSynchronize(st));
         h->n_opt = n_opt;
-        if (n_opt > 0) {
+        h->used_region2 = false; h->n_rretry = 0; h->n_erows = 0;
+        h->fd = h->n_x * h->n_t + h->n_x + k * h->n_t + k;
+        h->fi = 8 + k + h->n_tc + k + 2 * (h->n_c - k);
+        if (n_opt > 0 && h->fast && h->fast_r >= 0 && !h->force_v1) {
+            const int rows_t_ = h->n_c - h->n_eq + h->n_tc;
+            HIP_TRY(h, h->headd.ensure((size_t)n_opt * h->fd * sizeof(double), st));
+            HIP_TRY(h, h->headi.ensure((size_t)n_opt * h->fi * sizeof(int32_t), st));
+            HIP_TRY(h, h->epool.ensure((size_t)n_opt * rows_t_ * (h->n_t + 1) * sizeof(double), st));
+            const dim3 g((unsigned)std::min<long long>(n_opt, h->grid_r2)), b(64);
+            const DevProblem *pr = h->pr2_dev.as<DevProblem>();
+#define MPC_LAUNCH_R2(NT_, SL_) hipLaunchKernelGGL((k_region2<NT_, SL_>), g, b, h->lds_r2, st, pr, h->frontier.as<int32_t>(), k, h->opt_list.as<int32_t>(), n_opt, \
+                                                   h->status.as<uint8_t>(), h->headd.as<double>(), h->headi.as<int32_t>(), h->fd, h->fi, h->epool.as<double>(), ctr)
+            switch (h->fast_r) {
+                case 0: MPC_LAUNCH_R2(4, 1); break;
+                case 1: MPC_LAUNCH_R2(4, 2); break;
+                case 2: MPC_LAUNCH_R2(10, 1); break;
+                default: MPC_LAUNCH_R2(10, 2); break;
+            }
+#undef MPC_LAUNCH_R2
+            HIP_TRY(h, hipGetLastError());
+            h->used_region2 = true;
+            int32_t n_rr = 0;
+            { int rcs = compact(ST_RETRY, ST_RETRY, &n_rr); if (rcs) return rcs; }
+            h->n_rretry = n_rr;
+            if (n_rr > 0) {   // numerically doubtful regions: the LDS-engine kernel, fixed-stride records
+                HIP_TRY(h, h->recd.ensure((size_t)n_rr * h->rec_d * sizeof(double), st));
+                HIP_TRY(h, h->reci.ensure((size_t)n_rr * h->rec_i * sizeof(int32_t), st));
+                hipLaunchKernelGGL(k_region, dim3((unsigned)std::min<long long>(n_rr, h->grid_r)), dim3(64), h->lds_r, st, h->Pr,
+                                   h->frontier.as<int32_t>(), k, h->retry_list.as<int32_t>(), n_rr, h->status.as<uint8_t>(),
+                                   h->recd.as<double>(), h->reci.as<int32_t>(), h->rec_d, h->rec_i, ctr);
+                HIP_TRY(h, hipGetLastError());
+            }
+        } else if (n_opt > 0) {
             HIP_TRY(h, h->recd.ensure((size_t)n_opt * h->rec_d * sizeof(double), st));
             HIP_TRY(h, h->reci.ensure((size_t)n_opt * h->rec_i * sizeof(int32_t), st));
             hipLaunchKernelGGL(k_region, dim3((unsigned)std::min<long long>(n_opt, h->grid_r)), dim3(64), h->lds_r, st, h->Pr,
@@ -693,6 +761,7 @@ int mpc_level_run(mpc_handle *h, int32_t gen_children, mpc_level_stats *stats) {
         HIP_TRY(h, hipEventElapsedTime(&ms[1], h->ev[1], h->ev[2]));
         HIP_TRY(h, hipEventElapsedTime(&ms[2], h->ev[2], h->ev[3]));
         h->n_pruned_new = host_ctr.n_pruned_new;
+        h->n_erows = host_ctr.e_rows;
         h->n_regions = (long long)host_ctr.status[ST_REGION];
     }
     h->level_done = true;
@@ -705,6 +774,7 @@ int mpc_level_run(mpc_handle *h, int32_t gen_children, mpc_level_stats *stats) {
         stats->n_xtheta_lp = (int64_t)host_ctr.xtheta_lps + h->n_needx;
         stats->n_xtheta_fallback = (int64_t)host_ctr.xtheta_fallbacks;
         for (int i = 0; i < 4; ++i) stats->wave_cycles[i] = (int64_t)host_ctr.cycles[i];
+        stats->n_region_retry = h->n_rretry;
         stats->ms_verdict = ms[0]; stats->ms_region = ms[1]; stats->ms_children = ms[2]; stats->ms_total = ms[0] + ms[1] + ms[2];
     }
     return MPC_OK;
@@ -721,29 +791,154 @@ int mpc_level_status(mpc_handle *h, uint8_t *status) {
     return MPC_OK;
 }
 
+int mpc_compact_strides(const mpc_handle *h, int64_t *fd, int64_t *fi, int64_t *max_rows) {
+    if (!h) return MPC_ERR_INVALID;
+    if (fd) *fd = h->n_x * h->n_t + h->n_x + h->k * h->n_t + h->k;
+    if (fi) *fi = 8 + h->k + h->n_tc + h->k + 2 * (h->n_c - h->k);
+    if (max_rows) {
+        const long long rows_t = h->n_c - h->n_eq + h->n_tc;
+        *max_rows = h->used_region2 ? h->n_erows + h->n_rretry * rows_t : h->n_regions * rows_t;
+    }
+    return MPC_OK;
+}
+
+// Regions of the level in compact form, frontier order, written straight into the caller's arrays.
+int mpc_level_regions_compact(mpc_handle *h, double *head_d, int32_t *head_i, int64_t cap_regions, double *erows, int64_t cap_rows,
+                              int64_t *n_regions, int64_t *n_rows) {
+    if (!h) return MPC_ERR_INVALID;
+    if (!h->level_done) return fail(h, MPC_ERR_STATE, "mpc_level_run has not been called for this frontier");
+    if (n_regions) *n_regions = h->n_regions;
+    if (n_rows) *n_rows = 0;
+    if (cap_regions < h->n_regions) return fail(h, MPC_ERR_CAPACITY, "region buffers too small");
+    if (h->n_regions == 0 || h->n_opt == 0) return MPC_OK;
+    if (!head_d || !head_i || !erows) return MPC_ERR_INVALID;
+    HIP_TRY(h, hipSetDevice(h->device));
+    const int nx = h->n_x, nt = h->n_t, nc = h->n_c, ntc = h->n_tc, k = h->k, nr = nt + 1, fd = h->fd, fi = h->fi;
+    const long long n_opt = h->n_opt, rows_t = nc - h->n_eq + ntc;
+    const long long n_fixed = h->used_region2 ? h->n_rretry : n_opt;
+    hipStream_t s = h->stream;
+    HIP_TRY(h, h->st_list.ensure((size_t)n_opt * sizeof(int32_t)));
+    HIP_TRY(h, h->st_status.ensure((size_t)h->n));
+    HIP_TRY(h, hipMemcpyAsync(h->st_list.p, h->opt_list.p, (size_t)n_opt * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    HIP_TRY(h, hipMemcpyAsync(h->st_status.p, h->status.p, (size_t)h->n, hipMemcpyDeviceToHost, s));
+    if (n_fixed > 0) {
+        HIP_TRY(h, h->st_fxd.ensure((size_t)n_fixed * h->rec_d * sizeof(double)));
+        HIP_TRY(h, h->st_fxi.ensure((size_t)n_fixed * h->rec_i * sizeof(int32_t)));
+        HIP_TRY(h, hipMemcpyAsync(h->st_fxd.p, h->recd.p, (size_t)n_fixed * h->rec_d * sizeof(double), hipMemcpyDeviceToHost, s));
+        HIP_TRY(h, hipMemcpyAsync(h->st_fxi.p, h->reci.p, (size_t)n_fixed * h->rec_i * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    }
+    if (h->used_region2) {
+        HIP_TRY(h, h->st_hd.ensure((size_t)n_opt * fd * sizeof(double)));
+        HIP_TRY(h, h->st_hi.ensure((size_t)n_opt * fi * sizeof(int32_t)));
+        HIP_TRY(h, h->st_pool.ensure((size_t)std::max<long long>(h->n_erows, 1) * nr * sizeof(double)));
+        HIP_TRY(h, hipMemcpyAsync(h->st_hd.p, h->headd.p, (size_t)n_opt * fd * sizeof(double), hipMemcpyDeviceToHost, s));
+        HIP_TRY(h, hipMemcpyAsync(h->st_hi.p, h->headi.p, (size_t)n_opt * fi * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+        if (h->n_erows > 0) HIP_TRY(h, hipMemcpyAsync(h->st_pool.p, h->epool.p, (size_t)h->n_erows * nr * sizeof(double), hipMemcpyDeviceToHost, s));
+        if (h->n_rretry > 0) {
+            HIP_TRY(h, h->st_rlist.ensure((size_t)h->n_rretry * sizeof(int32_t)));
+            HIP_TRY(h, hipMemcpyAsync(h->st_rlist.p, h->retry_list.p, (size_t)h->n_rretry * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+        }
+    }
+    HIP_TRY(h, hipStreamSynchronize(s));
+    const int32_t *list = h->st_list.as<int32_t>(), *rlist = h->st_rlist.as<int32_t>();
+    const uint8_t *st = h->st_status.as<uint8_t>();
+    const double *fxd = h->st_fxd.as<double>(), *hd = h->st_hd.as<double>(), *pool = h->st_pool.as<double>();
+    const int32_t *fxi = h->st_fxi.as<int32_t>(), *hi = h->st_hi.as<int32_t>();
+    long long wreg = 0, wrow = 0;
+    bool overflow = false;
+    // fixed record (mpcombi.h layout) -> compact head + rows
+    auto from_fixed = [&](const double *rd, const int32_t *ri, int cand) {
+        const int kk = ri[0], nE = ri[1], n_om = ri[2], n_la = ri[3], n_re = ri[4];
+        if (wrow + nE > cap_rows) { overflow = true; return; }
+        double *od = head_d + (size_t)wreg * fd;
+        int32_t *oi = head_i + (size_t)wreg * fi;
+        std::fill(od, od + fd, 0.0); std::fill(oi, oi + fi, -1);
+        std::memcpy(od, rd, sizeof(double) * (nx * nt + nx));
+        const double *Al = rd + nx * nt + nx, *bl = Al + (size_t)nc * nt, *E = bl + nc, *f = E + (size_t)(nc + ntc) * nt;
+        std::memcpy(od + nx * nt + nx, Al, sizeof(double) * kk * nt);
+        std::memcpy(od + nx * nt + nx + k * nt, bl, sizeof(double) * kk);
+        oi[0] = ST_REGION; oi[1] = cand; oi[2] = nE; oi[3] = n_om; oi[4] = n_la; oi[5] = n_re; oi[6] = (int32_t)wrow; oi[7] = 0;
+        int32_t *act = oi + 8, *om = act + k, *la = om + ntc, *ridx = la + k, *rcon = ridx + (nc - k);
+        std::memcpy(act, ri + 5, sizeof(int32_t) * kk);
+        std::memcpy(om, ri + 5 + nc, sizeof(int32_t) * n_om);
+        std::memcpy(la, ri + 5 + nc + ntc, sizeof(int32_t) * n_la);
+        std::memcpy(ridx, ri + 5 + nc + ntc + nc, sizeof(int32_t) * n_re);
+        std::memcpy(rcon, ri + 5 + nc + ntc + nc + nc, sizeof(int32_t) * n_re);
+        for (int r = 0; r < nE; ++r) {
+            double *row = erows + (size_t)(wrow + r) * nr;
+            row[0] = f[r];
+            for (int t = 0; t < nt; ++t) row[1 + t] = E[(size_t)r * nt + t];
+        }
+        wrow += nE; ++wreg;
+    };
+    long long rpos = 0;
+    for (long long w = 0; w < n_opt && !overflow && wreg < cap_regions; ++w) {
+        const int cand = list[w];
+        if (!h->used_region2) {
+            if (st[cand] == ST_REGION) from_fixed(fxd + (size_t)w * h->rec_d, fxi + (size_t)w * h->rec_i, cand);
+            continue;
+        }
+        const int32_t *src_i = hi + (size_t)w * fi;
+        if (src_i[0] == ST_REGION) {
+            const int nE = src_i[2], off = src_i[6];
+            if (wrow + nE > cap_rows) { overflow = true; break; }
+            std::memcpy(head_d + (size_t)wreg * fd, hd + (size_t)w * fd, sizeof(double) * fd);
+            int32_t *oi = head_i + (size_t)wreg * fi;
+            std::memcpy(oi, src_i, sizeof(int32_t) * fi);
+            oi[6] = (int32_t)wrow;
+            std::memcpy(erows + (size_t)wrow * nr, pool + (size_t)off * nr, sizeof(double) * nE * nr);
+            wrow += nE; ++wreg;
+        } else if (src_i[0] == ST_RETRY) {
+            while (rpos < h->n_rretry && rlist[rpos] != cand) ++rpos;
+            if (rpos < h->n_rretry && st[cand] == ST_REGION) from_fixed(fxd + (size_t)rpos * h->rec_d, fxi + (size_t)rpos * h->rec_i, cand);
+        }
+    }
+    (void)rows_t;
+    if (overflow) return fail(h, MPC_ERR_CAPACITY, "row buffer too small (see mpc_compact_strides max_rows)");
+    if (n_regions) *n_regions = wreg;
+    if (n_rows) *n_rows = wrow;
+    return MPC_OK;
+}
+
 int mpc_level_regions(mpc_handle *h, double *rec_d, int32_t *rec_i, int64_t *cand_index, int64_t cap) {
     if (!h) return MPC_ERR_INVALID;
     if (!h->level_done) return fail(h, MPC_ERR_STATE, "mpc_level_run has not been called for this frontier");
     if (cap < h->n_regions) return fail(h, MPC_ERR_CAPACITY, "region buffer too small");
     if (h->n_regions == 0) return MPC_OK;
     if (!rec_d || !rec_i) return MPC_ERR_INVALID;
-    HIP_TRY(h, hipSetDevice(h->device));
-    // records were written per OPTIMAL candidate (frontier order); keep those whose final status is REGION
-    std::vector<double> d((size_t)h->n_opt * h->rec_d);
-    std::vector<int32_t> ii((size_t)h->n_opt * h->rec_i), list((size_t)h->n_opt);
-    std::vector<uint8_t> st((size_t)h->n);
-    HIP_TRY(h, hipMemcpyAsync(d.data(), h->recd.p, d.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-    HIP_TRY(h, hipMemcpyAsync(ii.data(), h->reci.p, ii.size() * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
-    HIP_TRY(h, hipMemcpyAsync(list.data(), h->opt_list.p, list.size() * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
-    HIP_TRY(h, hipMemcpyAsync(st.data(), h->status.p, st.size(), hipMemcpyDeviceToHost, h->stream));
-    HIP_TRY(h, hipStreamSynchronize(h->stream));
-    long long w = 0;
-    for (long long i = 0; i < h->n_opt; ++i) {
-        if (st[list[i]] != ST_REGION) continue;
-        std::memcpy(rec_d + w * h->rec_d, d.data() + i * h->rec_d, h->rec_d * sizeof(double));
-        std::memcpy(rec_i + w * h->rec_i, ii.data() + i * h->rec_i, h->rec_i * sizeof(int32_t));
-        if (cand_index) cand_index[w] = list[i];
-        ++w;
+    // fetch in compact form, then expand into the fixed-stride records of the header
+    const int nx = h->n_x, nt = h->n_t, nc = h->n_c, ntc = h->n_tc, k = h->k, nr = nt + 1, fd = h->fd, fi = h->fi;
+    int64_t max_rows = 0, nreg = 0, nrows = 0;
+    mpc_compact_strides(h, nullptr, nullptr, &max_rows);
+    std::vector<double> c_hd((size_t)h->n_regions * fd), c_er((size_t)std::max<int64_t>(max_rows, 1) * nr);
+    std::vector<int32_t> c_hi((size_t)h->n_regions * fi);
+    int rc = mpc_level_regions_compact(h, c_hd.data(), c_hi.data(), h->n_regions, c_er.data(), max_rows, &nreg, &nrows);
+    if (rc) return rc;
+    for (int64_t w = 0; w < nreg; ++w) {
+        double *rd = rec_d + w * h->rec_d;
+        int32_t *ri = rec_i + w * h->rec_i;
+        std::fill(rd, rd + h->rec_d, 0.0);
+        std::fill(ri, ri + h->rec_i, -1);
+        const double *sd = c_hd.data() + w * fd;
+        const int32_t *si = c_hi.data() + w * fi;
+        const int nE = si[2], n_om = si[3], n_la = si[4], n_re = si[5], off = si[6];
+        std::memcpy(rd, sd, sizeof(double) * (nx * nt + nx));
+        double *Al = rd + nx * nt + nx, *bl = Al + (size_t)nc * nt, *E = bl + nc, *f = E + (size_t)(nc + ntc) * nt;
+        std::memcpy(Al, sd + nx * nt + nx, sizeof(double) * k * nt);
+        std::memcpy(bl, sd + nx * nt + nx + k * nt, sizeof(double) * k);
+        for (int r = 0; r < nE; ++r) {
+            const double *row = c_er.data() + (size_t)(off + r) * nr;
+            f[r] = row[0];
+            for (int t = 0; t < nt; ++t) E[(size_t)r * nt + t] = row[1 + t];
+        }
+        ri[0] = k; ri[1] = nE; ri[2] = n_om; ri[3] = n_la; ri[4] = n_re;
+        const int32_t *act = si + 8, *om = act + k, *la = om + ntc, *ridx = la + k, *rcon = ridx + (nc - k);
+        std::memcpy(ri + 5, act, sizeof(int32_t) * k);
+        std::memcpy(ri + 5 + nc, om, sizeof(int32_t) * n_om);
+        std::memcpy(ri + 5 + nc + ntc, la, sizeof(int32_t) * n_la);
+        std::memcpy(ri + 5 + nc + ntc + nc, ridx, sizeof(int32_t) * n_re);
+        std::memcpy(ri + 5 + nc + ntc + nc + nc, rcon, sizeof(int32_t) * n_re);
+        if (cand_index) cand_index[w] = si[1];
     }
     return MPC_OK;
 }

@@ -1,0 +1,119 @@
+"""Structure-of-arrays storage for the regions of one BFS level.
+
+The device returns the regions of a level as three dense arrays (include/mpcombi.h, mpc_level_regions_compact).
+``RegionBatch`` keeps them as they are; ``BatchCriticalRegion`` is a ``CriticalRegion`` whose fields are numpy
+views / lists cut out of those arrays the first time they are read (and cached, and assignable, like ordinary
+attributes).  A Solution with 10^4 regions is therefore 10^4 small Python objects and three arrays, not 6*10^4 arrays
+built eagerly inside the solve.
+"""
+from typing import List
+
+import numpy
+
+from .critical_region import CriticalRegion
+
+
+class RegionBatch:
+    def __init__(self, head_d: numpy.ndarray, head_i: numpy.ndarray, erows: numpy.ndarray, n_x: int, n_t: int, n_c: int,
+                 n_tc: int, k: int):
+        self.hd, self.hi, self.er = head_d, head_i, erows
+        self.n_x, self.n_t, self.n_c, self.n_tc, self.k = n_x, n_t, n_c, n_tc, k
+        self.oA, self.ob = 0, n_x * n_t
+        self.oC, self.od = self.ob + n_x, self.ob + n_x + k * n_t
+        self.iact, self.iom = 8, 8 + k
+        self.ila = self.iom + n_tc
+        self.iri = self.ila + k
+        self.irc = self.iri + (n_c - k)
+
+    def __len__(self):
+        return len(self.hd)
+
+    def regions(self) -> List['BatchCriticalRegion']:
+        return [BatchCriticalRegion(self, j) for j in range(len(self.hd))]
+
+
+class _Lazy:
+    """Non-overriding-on-read descriptor: computes the field from the batch on first access, then behaves like a
+    plain instance attribute (also for assignment)."""
+
+    def __init__(self, fn):
+        self.fn = fn
+        self.key = fn.__name__
+
+    def __get__(self, obj, cls):
+        if obj is None:
+            return self
+        d = obj.__dict__
+        if self.key not in d:
+            d[self.key] = self.fn(obj)
+        return d[self.key]
+
+    def __set__(self, obj, value):
+        obj.__dict__[self.key] = value
+
+
+class BatchCriticalRegion(CriticalRegion):
+    """A CriticalRegion backed by row ``j`` of a RegionBatch (same fields, same index conventions)."""
+
+    def __init__(self, batch: RegionBatch, j: int):  # no dataclass __init__: fields come from the batch
+        self._batch = batch
+        self._j = j
+
+    def _hdr(self):
+        return self._batch.hi[self._j]
+
+    @_Lazy
+    def A(self):
+        B = self._batch
+        return B.hd[self._j, B.oA:B.ob].reshape(B.n_x, B.n_t)
+
+    @_Lazy
+    def b(self):
+        B = self._batch
+        return B.hd[self._j, B.ob:B.oC].reshape(B.n_x, 1)
+
+    @_Lazy
+    def C(self):
+        B = self._batch
+        return B.hd[self._j, B.oC:B.od].reshape(B.k, B.n_t)
+
+    @_Lazy
+    def d(self):
+        B = self._batch
+        return B.hd[self._j, B.od:B.od + B.k].reshape(B.k, 1)
+
+    @_Lazy
+    def E(self):
+        B, h = self._batch, self._hdr()
+        return B.er[h[6]:h[6] + h[2], 1:]
+
+    @_Lazy
+    def f(self):
+        B, h = self._batch, self._hdr()
+        return B.er[h[6]:h[6] + h[2], :1]
+
+    @_Lazy
+    def active_set(self):
+        B = self._batch
+        return B.hi[self._j, B.iact:B.iact + B.k].tolist()
+
+    @_Lazy
+    def omega_set(self):
+        B, h = self._batch, self._hdr()
+        return B.hi[self._j, B.iom:B.iom + h[3]].tolist()
+
+    @_Lazy
+    def lambda_set(self):
+        B, h = self._batch, self._hdr()
+        return B.hi[self._j, B.ila:B.ila + h[4]].tolist()
+
+    @_Lazy
+    def regular_set(self):
+        B, h = self._batch, self._hdr()
+        return [B.hi[self._j, B.iri:B.iri + h[5]].tolist(), B.hi[self._j, B.irc:B.irc + h[5]].tolist()]
+
+    def materialize(self) -> 'BatchCriticalRegion':
+        """Touches every field (so that nothing refers to the batch lazily any more)."""
+        for name in ('A', 'b', 'C', 'd', 'E', 'f', 'active_set', 'omega_set', 'lambda_set', 'regular_set'):
+            getattr(self, name)
+        return self

@@ -42,7 +42,18 @@ def run_levels(eng, max_levels=None):
         cands, status = eng.frontier_get(), eng.level_status()
         rd, ri, idx = eng.level_regions()
         assert numpy.array_equal(numpy.nonzero(status == 3)[0], idx)
-        regions.extend(unpack_region(rd[j], ri[j], eng.n_x, eng.n_t, eng.n_c, eng.n_tc) for j in range(len(rd)))
+        fixed = [unpack_region(rd[j], ri[j], eng.n_x, eng.n_t, eng.n_c, eng.n_tc) for j in range(len(rd))]
+        # the compact form (what the driver uses) must describe the same regions as the fixed-stride records
+        from ppopt_amd.region_batch import RegionBatch
+        hd, hi, er, kk = eng.level_regions_compact()
+        lazy = RegionBatch(hd, hi, er, eng.n_x, eng.n_t, eng.n_c, eng.n_tc, kk).regions()
+        assert len(lazy) == len(fixed) and numpy.array_equal(hi[:, 1], idx)
+        for a, b in zip(fixed, lazy):
+            assert a.active_set == b.active_set and a.omega_set == b.omega_set and a.lambda_set == b.lambda_set
+            assert a.regular_set == b.regular_set
+            for fld in ('A', 'b', 'C', 'd', 'E', 'f'):
+                assert numpy.array_equal(getattr(a, fld), getattr(b, fld)), fld
+        regions.extend(lazy)
         levels.append((cands, status, st))
         if not gen or st.n_children == 0:
             break

@@ -137,3 +137,30 @@ def test_mask_round_trip():
     from ppopt_amd._lib import masks_to_sets, sets_to_masks
     sets = [(0,), (5, 63, 64), (127,), (1, 2, 3, 70, 100)]
     assert masks_to_sets(sets_to_masks(sets)) == sets
+
+
+def test_region_batch_lazy_fields():
+    """BatchCriticalRegion cuts its fields out of the compact arrays of include/mpcombi.h on first access."""
+    from ppopt_amd.region_batch import RegionBatch
+    n_x, n_t, n_c, n_tc, k = 3, 2, 5, 4, 2
+    fd = n_x * n_t + n_x + k * n_t + k
+    fi = 8 + k + n_tc + k + 2 * (n_c - k)
+    hd = numpy.arange(2 * fd, dtype=float).reshape(2, fd)
+    hi = -numpy.ones((2, fi), dtype=numpy.int32)
+    hi[0, :8] = [3, 7, 2, 1, 1, 2, 0, 0]; hi[1, :8] = [3, 9, 1, 0, 2, 0, 2, 0]
+    hi[0, 8:10] = [1, 4]; hi[0, 10] = 2; hi[0, 14] = 4; hi[0, 16:18] = [0, 2]; hi[0, 19:21] = [0, 3]
+    hi[1, 8:10] = [0, 2]; hi[1, 14:16] = [0, 2]
+    er = numpy.arange(9, dtype=float).reshape(3, 3)
+    regs = RegionBatch(hd, hi, er, n_x, n_t, n_c, n_tc, k).regions()
+    r0, r1 = regs
+    assert isinstance(r0, CriticalRegion) and r0.active_set == [1, 4] and r1.active_set == [0, 2]
+    assert r0.A.shape == (3, 2) and r0.A[0, 1] == 1.0 and r0.b.shape == (3, 1) and r0.b[0, 0] == 6.0
+    assert r0.C.shape == (2, 2) and r0.d.shape == (2, 1) and r1.A[0, 0] == fd
+    assert r0.E.shape == (2, 2) and numpy.array_equal(r0.f.ravel(), [0.0, 3.0]) and numpy.array_equal(r0.E[1], [4.0, 5.0])
+    assert r1.E.shape == (1, 2) and r1.f[0, 0] == 6.0
+    assert r0.omega_set == [2] and r0.lambda_set == [4] and r0.regular_set == [[0, 2], [0, 3]]
+    assert r1.omega_set == [] and r1.lambda_set == [0, 2] and r1.regular_set == [[], []]
+    r0.A = numpy.zeros((3, 2))            # assignable like a dataclass field
+    assert numpy.all(r0.A == 0) and 'Critical region with active set [1, 4]' in repr(r0)
+    th = numpy.ones((2, 1))
+    assert r1.evaluate(th).shape == (3, 1) and r1.materialize() is r1
