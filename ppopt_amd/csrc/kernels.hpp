@@ -45,6 +45,7 @@ struct DevProblem {
     // vertex of the parameter polytope {A_t theta <= b_t} (kernels2.hpp): theta = tv_theta - tv_minv * sigma, sigma = slacks
     // of its n_t tight rows; tv_rows = the remaining n_tpre rows of A_t already expressed in sigma ([value | coefficients])
     const double *tv_theta, *tv_minv, *tv_rows; int n_tpre, has_tv;
+    const int *tv_tight;  // the n_t rows of A_t that are tight at the vertex (sigma_j is the slack of row tv_tight[j])
     // LDS layout (offsets in doubles from the start of dynamic LDS; ints follow the doubles)
     int kmax;           // largest cardinality with a solvable KKT (= min(n_c, n_x))
     int ld_x, ld_t;     // odd tableau strides of the (x,theta) LP and of the theta-space LPs
@@ -376,11 +377,17 @@ __global__ void __launch_bounds__(64) k_verdict(DevProblem P, const int32_t *__r
 // ------------------------------------------------------------------------------------------------------------
 // k_region: one optimal candidate per wavefront -> region record or OPT_NO_REGION
 // ------------------------------------------------------------------------------------------------------------
+// MODE 0 (RG_FULL)      one wavefront does everything for a candidate (throughput form)
+// MODE 1 (RG_FACET)     one wavefront per (candidate, region row): rebuilds the rows and solves only that row's facet LP,
+//                       result -> facet_flags[slot * rows_t + row] (1 kept, 0 redundant, 2 LP limit)   (latency form, step 1)
+// MODE 2 (RG_ASSEMBLE)  one wavefront per candidate: rows + Chebyshev LP, facet decisions read from facet_flags (step 2)
+constexpr int RG_FULL = 0, RG_FACET = 1, RG_ASSEMBLE = 2;
+template <int MODE>
 __global__ void __launch_bounds__(64) k_region(DevProblem P, const int32_t *__restrict__ cands, int k,
                                                const int32_t *__restrict__ opt_list, int n_opt,
                                                uint8_t *__restrict__ status, double *__restrict__ rec_d,
                                                int32_t *__restrict__ rec_i, long long sd, long long si,
-                                               LevelCounters *__restrict__ ctr) {
+                                               LevelCounters *__restrict__ ctr, uint8_t *__restrict__ facet_flags) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     Smem s = carve(P, smem);
     const int lane = lane_id(), nt = P.n_t, nr = nt + 1, nx = P.n_x, nc = P.n_c, ntc = P.n_tc, e = P.n_eq;
@@ -389,13 +396,18 @@ __global__ void __launch_bounds__(64) k_region(DevProblem P, const int32_t *__re
         unsigned int w = 0;
         if (lane == 0) w = atomicAdd(&ctr->work_region, 1u);
         w = (unsigned)__builtin_amdgcn_readfirstlane((int)w);
-        if (w >= (unsigned)n_opt) break;
+        const int rows_all = P.n_c - P.n_eq + P.n_tc;
+        if (w >= (unsigned)(MODE == RG_FACET ? n_opt * rows_all : n_opt)) break;
+        const int my_row = MODE == RG_FACET ? (int)(w % (unsigned)rows_all) : -1;
+        if (MODE == RG_FACET) w = w / (unsigned)rows_all;
         const int c = opt_list[w];
         const int nin = load_active_set(P, cands + (size_t)c * k, k, s);
         double *rd = rec_d + (size_t)w * sd;
         int32_t *ri = rec_i + (size_t)w * si;
-        for (long long i = lane; i < sd; i += 64) rd[i] = 0.0;
-        for (long long i = lane; i < si; i += 64) ri[i] = -1;
+        if (MODE != RG_FACET) {
+            for (long long i = lane; i < sd; i += 64) rd[i] = 0.0;
+            for (long long i = lane; i < si; i += 64) ri[i] = -1;
+        }
         int st = ST_REGION;
         const int kk = kkt_solve(P, k, s);
         if (kk != 0) st = kk == 1 ? ST_INFEASIBLE : ST_SINGULAR;  // cannot happen after k_verdict said optimal
@@ -429,7 +441,9 @@ __global__ void __launch_bounds__(64) k_region(DevProblem P, const int32_t *__re
                 nk += __popcll(bal);
             }
             wave_sync();
-            if (nt == 1) {
+            if (nt == 1 && MODE == RG_FACET) {
+                // nothing to do: the one-parameter variant has no LPs
+            } else if (nt == 1) {
                 // one parameter: interval arithmetic, no LPs (mpqp_utils.py:198-320)
                 double mn = -INFINITY, mx = INFINITY;
                 for (int r = lane; r < nk; r += 64) {
@@ -467,7 +481,8 @@ __global__ void __launch_bounds__(64) k_region(DevProblem P, const int32_t *__re
                 Lp lp;
                 lp.T = s.T; lp.ld = P.ld_t; lp.colvar = s.colvar; lp.rowvar = s.rowvar; lp.rowkind = s.rowkind;
                 lp.n = nt + 1; lp.m = nk + 1; lp.iters = 0;
-                const int r = lp_solve(lp, true, s.pri, [&](const int *pri) {
+                int r = LP_OPTIMAL;
+                if (MODE != RG_FACET) r = lp_solve(lp, true, s.pri, [&](const int *pri) {
                     wave_sync();
                     for (int i = lane; i <= nk + 1; i += 64) {
                         double *Ti = s.T + i * P.ld_t;
@@ -494,13 +509,19 @@ __global__ void __launch_bounds__(64) k_region(DevProblem P, const int32_t *__re
                     reduce_max_first(dummy, found);
                     radius = found >= 0 ? s.T[found * P.ld_t] : 0.0;
                 }
+                if (MODE == RG_FACET) radius = 1.0;
                 if (r == LP_ITERLIMIT) st = ST_LP_LIMIT;
                 else if (r != LP_OPTIMAL || !(radius > FULL_DIM_RADIUS)) st = ST_OPT_NO_REGION;
                 // one feasibility LP per kept row with that row as an equality (mpqp_utils.py:143-178)
                 double *Eo = rd + nx * nt + nx + nc * nt + nc, *fo = Eo + (nc + ntc) * nt;
                 for (int row = 0; row < nk && st == ST_REGION; ++row) {
+                    if (MODE == RG_FACET && row != my_row) continue;
                     lp.n = nt; lp.m = nk; lp.iters = 0;
-                    const int rr = lp_solve(lp, false, s.pri, [&](const int *pri) {
+                    int rr;
+                    if (MODE == RG_ASSEMBLE) {
+                        const int fl = facet_flags[(size_t)w * rows_all + row];
+                        rr = fl == 1 ? LP_OPTIMAL : (fl == 2 ? LP_ITERLIMIT : LP_INFEASIBLE);
+                    } else rr = lp_solve(lp, false, s.pri, [&](const int *pri) {
                         wave_sync();
                         for (int i = lane; i <= nk; i += 64) {
                             double *Ti = s.T + i * P.ld_t;
@@ -510,6 +531,10 @@ __global__ void __launch_bounds__(64) k_region(DevProblem P, const int32_t *__re
                         }
                     });
                     pivots += lp.iters;
+                    if (MODE == RG_FACET) {
+                        if (lane == 0) facet_flags[(size_t)w * rows_all + row] = rr == LP_OPTIMAL ? 1 : (rr == LP_ITERLIMIT ? 2 : 0);
+                        break;
+                    }
                     if (rr == LP_ITERLIMIT) { st = ST_LP_LIMIT; break; }
                     if (rr != LP_OPTIMAL) continue;
                     const int o = s.kept[row];
@@ -537,6 +562,7 @@ __global__ void __launch_bounds__(64) k_region(DevProblem P, const int32_t *__re
                 }
             }
         }
+        if (MODE == RG_FACET) continue;
         if (st == ST_REGION) {
             // x-law, multipliers, header
             for (int idx = lane; idx < nx * nt; idx += 64) rd[idx] = s.X[(idx / nt) * nr + 1 + idx % nt];

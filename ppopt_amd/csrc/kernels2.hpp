@@ -361,7 +361,39 @@ __global__ void __launch_bounds__(64, (NT * SLOTS >= 20 ? 2 : 3)) k_region2(
                 if (rrow >= 0) radius = lp.beta(rrow);
             }
             if (r1 == LP_ITERLIMIT || r2 == 3) st = ST_LP_LIMIT;
-            else if (lp.growth > GROWTH_SAFE) retry = true;
+            else if (lp.growth > GROWTH_SAFE) {
+                // The walk used small pivots, so the tableau's radius is not trusted.  Full dimensionality only needs a
+                // LOWER bound above 1e-8: evaluate the inscribed radius of the LP's centre directly on the master rows.
+                double th[NT];
+#pragma unroll
+                for (int t = 0; t < NT; ++t) th[t] = t < nt ? P.tv_theta[t] : 0.0;
+                for (int j = 0; j < nt; ++j) {
+                    double sj = 0.0;
+#pragma unroll
+                    for (int sl = SLOTS - 1; sl >= 0; --sl) {
+                        const unsigned long long br = __ballot(lp.var[sl] == ID_SIGMA + 1 + j && lp.kind[sl] == RK_INEQ);
+                        if (br) { double c0[SLOTS];
+#pragma unroll
+                            for (int q = 0; q < SLOTS; ++q) c0[q] = lp.t[q][0];
+                            sj = lp.row_entry(__ffsll((long long)br) - 1 + 64 * sl, c0); }
+                    }
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) if (t < nt) th[t] = fma(-P.tv_minv[t * nt + j], sj, th[t]);
+                }
+                double rv = INFINITY;
+#pragma unroll
+                for (int sl = 0; sl < SLOTS; ++sl) {
+                    const int i = lane + 64 * sl;
+                    if (i < m && s.kept[i] != 3) {
+                        double sl_i = s.E[i * ldE];
+#pragma unroll
+                        for (int t = 0; t < NT; ++t) if (t < nt) sl_i = fma(-s.E[i * ldE + 1 + t], th[t], sl_i);
+                        rv = fmin(rv, sl_i);   // rows have unit norm
+                    }
+                }
+                rv = dpp_wave_min(rv);
+                if (!(r1 == LP_OPTIMAL && r2 != 2 && rv > 2 * FULL_DIM_RADIUS)) retry = true;
+            }
             else if (r1 != LP_OPTIMAL || r2 == 2 || !(radius > FULL_DIM_RADIUS)) st = ST_OPT_NO_REGION;
             // ---- facets: walk the feasible dictionary ------------------------------------------------------------------
             if (st == ST_REGION && !retry) {
@@ -381,7 +413,71 @@ __global__ void __launch_bounds__(64, (NT * SLOTS >= 20 ? 2 : 3)) k_region2(
                         if (lp.kind[sl] == RK_INEQ && lp.var[sl] < m && lp.t[sl][0] <= TOL_FEAS) s.kept[lp.var[sl]] = 1;
                     wave_sync();
                 };
+                // constraint (value h, coefficients g) behind a variable id: a region row or the slack of a vertex row of A_t
+                auto row_of = [&](int id, double &h, double (&g)[NT]) {
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) g[t] = 0.0;
+                    h = 0.0;
+                    if (id < m) {
+                        h = s.E[id * ldE];
+#pragma unroll
+                        for (int t = 0; t < NT; ++t) if (t < nt) g[t] = s.E[id * ldE + 1 + t];
+                    } else if (id > ID_SIGMA && id <= ID_SIGMA + nt) {
+                        const int tr = P.tv_tight[id - ID_SIGMA - 1];
+                        h = P.b_t[tr];
+#pragma unroll
+                        for (int t = 0; t < NT; ++t) if (t < nt) g[t] = P.A_t[tr * nt + t];
+                    }
+                };
+                // Rebuilds the dictionary at the current basis from the master rows (a fresh n_t x n_t LU in LDS): removes
+                // the round-off a long pivot sequence has accumulated.  Columns are renumbered 1..n_t.
+                auto refactor = [&]() -> bool {
+                    const unsigned al = (unsigned)uni((int)lp.alive);
+                    if (__popc(al) != nt) return false;
+                    double *Bm = s.K, *R = s.K + nt * nt;
+                    wave_sync();
+                    if (lane >= 1 && lane < NC && ((al >> lane) & 1u)) {
+                        const int c = __popc(al & ((1u << lane) - 1u));   // basis position of this column
+                        double h, g[NT];
+                        row_of(lp.cv, h, g);
+                        s.colvar[c] = lp.cv;
+#pragma unroll
+                        for (int t = 0; t < NT; ++t) if (t < nt) Bm[c * nt + t] = g[t];
+                        R[c * (nt + 1)] = h;
+                        for (int cc = 0; cc < nt; ++cc) R[c * (nt + 1) + 1 + cc] = cc == c ? 1.0 : 0.0;
+                    }
+                    wave_sync();
+                    if (!lu_solve(Bm, nt, R, nt + 1, 1e-12)) return false;
+                    bool ok = true;
+#pragma unroll
+                    for (int sl = 0; sl < SLOTS; ++sl) {
+                        double h, g[NT];
+                        row_of(lp.var[sl], h, g);
+                        const bool live = lp.kind[sl] == RK_INEQ;
+                        double b0 = h;
+#pragma unroll
+                        for (int t = 0; t < NT; ++t) if (t < nt) b0 = fma(-g[t], R[t * (nt + 1)], b0);
+                        lp.t[sl][0] = live ? b0 : 0.0;
+                        if (live && b0 < -10 * TOL_FEAS) ok = false;
+#pragma unroll
+                        for (int j = 1; j < NC; ++j) {
+                            double acc = 0.0;
+                            if (j <= nt) {
+#pragma unroll
+                                for (int t = 0; t < NT; ++t) if (t < nt) acc = fma(g[t], R[t * (nt + 1) + j], acc);
+                            }
+                            lp.t[sl][j] = live ? -acc : 0.0;
+                        }
+                    }
+                    lp.cv = (lane >= 1 && lane <= nt) ? s.colvar[lane - 1] : -1;
+                    lp.alive = (1u << (nt + 1)) - 2u;
+                    lp.growth = 0.0;
+                    wave_sync();
+                    return !__any(!ok);
+                };
+                if (!retry && lp.growth > GROWTH_SAFE && !refactor()) retry = true;   // the Chebyshev walk ended on small pivots
                 if (!retry) mark_tight();
+                int refactors = 0;
                 for (int cidx = 0; cidx < m && !retry && st == ST_REGION; ++cidx) {
                     if (s.kept[cidx] != 0) continue;
                     int row = -1;
@@ -396,12 +492,18 @@ __global__ void __launch_bounds__(64, (NT * SLOTS >= 20 ? 2 : 3)) k_region2(
                     if (pr == 3) { st = ST_LP_LIMIT; break; }
                     bool kept_c = pr == 4;
                     if (pr != 4) { kept_c = lp.beta(row) <= TOL_FEAS; lp.set_kind(row, RK_INEQ); }
+                    if (lp.growth > GROWTH_SAFE) {
+                        // doubtful pivots: this decision is discarded, the dictionary is rebuilt and the row is tested again
+                        if (++refactors > 8 || !refactor()) { retry = true; break; }
+                        mark_tight();
+                        --cidx;
+                        continue;
+                    }
                     wave_sync();
                     if (lane == 0) s.kept[cidx] = kept_c ? 1 : 2;
                     wave_sync();
                     mark_tight();
                 }
-                if (lp.growth > GROWTH_SAFE) retry = true;
             }
             pivots += lp.iters;
             // ---- record ----------------------------------------------------------------------------------------------

@@ -90,7 +90,7 @@ struct mpc_handle {
     long long n_needx = 0;
     DevProblem Pf{};          // view for k_verdict2 (small LDS layout: no tableau)
     int lds_f = 0, grid_f = 0;
-    DevBuf retry_list, pf_dev, pr2_dev, headd, headi, epool;
+    DevBuf retry_list, pf_dev, pr2_dev, headd, headi, epool, facet_flags;
     DevProblem Pr2{};         // view for k_region2
     int lds_r2 = 0, grid_r2 = 0, fast_r = -1;   // fast_r: k_region2 instantiation, -1 = none (n_t == 1 or too many rows)
     bool used_region2 = false;
@@ -339,6 +339,7 @@ int mpc_create(const mpc_problem *p, int32_t device, void *stream, mpc_handle **
     }
     // ---- vertex of the parameter polytope {A_t theta <= b_t} (kernels2.hpp) ----------------------------------------
     std::vector<double> tv_theta, tv_minv, tv_rows, d0T;
+    std::vector<int> tv_tight;
     {
         bool ok = ntc >= nt;
         std::vector<int32_t> tight(std::max(ntc, 1), 0);
@@ -388,7 +389,7 @@ int mpc_create(const mpc_problem *p, int32_t device, void *stream, mpc_handle **
                 }
             }
         }
-        if (!ok) { tv_theta.clear(); tv_minv.clear(); tv_rows.clear(); }
+        if (!ok) { tv_theta.clear(); tv_minv.clear(); tv_rows.clear(); } else tv_tight = B;
         if (!d0.empty()) {
             const int mr = (int)d0_rows.size(), cc = 1 + (int)d0_cols.size();
             d0T.assign((size_t)mr * cc, 0.0);
@@ -424,12 +425,14 @@ int mpc_create(const mpc_problem *p, int32_t device, void *stream, mpc_handle **
     {
         std::vector<int> maps(d0_rows);
         maps.insert(maps.end(), d0_cols.begin(), d0_cols.end());
+        maps.insert(maps.end(), tv_tight.begin(), tv_tight.end());
         if (maps.empty()) maps.push_back(0);
         HIP_TRY(nullptr, h->iblocks.ensure(maps.size() * sizeof(int), h->stream));
         HIP_TRY(nullptr, hipMemcpyAsync(h->iblocks.p, maps.data(), maps.size() * sizeof(int), hipMemcpyHostToDevice, h->stream));
         HIP_TRY(nullptr, hipStreamSynchronize(h->stream));
         P.d0_rows = h->iblocks.as<int>();
         P.d0_cols = h->iblocks.as<int>() + d0_rows.size();
+        P.tv_tight = h->iblocks.as<int>() + d0_rows.size() + d0_cols.size();
     }
     // ---- LDS layouts ---------------------------------------------------------------------------------------
     const int kmax = std::min(nc, nx);
@@ -447,7 +450,11 @@ int mpc_create(const mpc_problem *p, int32_t device, void *stream, mpc_handle **
     h->Pr = P; apply_layout(h->Pr, lr); h->lds_r = lr.bytes;
     if (h->lds_v > 160 * 1024 || h->lds_r > 160 * 1024) { delete h; return fail(nullptr, MPC_ERR_INVALID, "problem does not fit the 160 KiB LDS of one CU"); }
     if (h->lds_v > 48 * 1024) HIP_TRY(nullptr, hipFuncSetAttribute(reinterpret_cast<const void *>(k_verdict), hipFuncAttributeMaxDynamicSharedMemorySize, h->lds_v));
-    if (h->lds_r > 48 * 1024) HIP_TRY(nullptr, hipFuncSetAttribute(reinterpret_cast<const void *>(k_region), hipFuncAttributeMaxDynamicSharedMemorySize, h->lds_r));
+    if (h->lds_r > 48 * 1024) {
+        HIP_TRY(nullptr, hipFuncSetAttribute(reinterpret_cast<const void *>(k_region<RG_FULL>), hipFuncAttributeMaxDynamicSharedMemorySize, h->lds_r));
+        HIP_TRY(nullptr, hipFuncSetAttribute(reinterpret_cast<const void *>(k_region<RG_FACET>), hipFuncAttributeMaxDynamicSharedMemorySize, h->lds_r));
+        HIP_TRY(nullptr, hipFuncSetAttribute(reinterpret_cast<const void *>(k_region<RG_ASSEMBLE>), hipFuncAttributeMaxDynamicSharedMemorySize, h->lds_r));
+    }
     h->grid_v = h->n_cu * waves_per_cu(h->lds_v);
     // fast path (k_verdict2): needs the theta vertex, the pre-crashed dictionary and sizes inside the instantiations
     {
@@ -469,7 +476,7 @@ int mpc_create(const mpc_problem *p, int32_t device, void *stream, mpc_handle **
             const int slots_r = rows_t + 1 <= 64 ? 1 : (rows_t + 1 <= 128 ? 2 : 0);
             if (nt >= 2 && slots_r) {
                 h->fast_r = tsel * 2 + (slots_r - 1);
-                const Layout l2 = make_layout(2, size_K, size_L, rows_t * nr, size_X, kmax, nc, 2, 2, rows_t);
+                const Layout l2 = make_layout(2, std::max(size_K, nt * (2 * nt + 1)), size_L, rows_t * nr, size_X, kmax, nc, nt + 2, 2, rows_t);
                 h->Pr2 = P; apply_layout(h->Pr2, l2); h->lds_r2 = l2.bytes;
                 h->grid_r2 = h->n_cu * std::min(12, waves_per_cu(h->lds_r2));
                 HIP_TRY(nullptr, h->pr2_dev.ensure(sizeof(DevProblem), h->stream));
@@ -492,7 +499,7 @@ int mpc_destroy(mpc_handle *h) {
     (void)hipSetDevice(h->device);
     (void)hipStreamSynchronize(h->stream);
     for (DevBuf *b : {&h->blocks, &h->iblocks, &h->frontier, &h->children, &h->status, &h->pruned, &h->pruned_new, &h->flag, &h->pos, &h->opt_list,
-                      &h->childmask, &h->count, &h->offset, &h->recd, &h->reci, &h->ctr, &h->scratch, &h->sums, &h->retry_list, &h->pf_dev, &h->pr2_dev, &h->headd, &h->headi, &h->epool}) b->release();
+                      &h->childmask, &h->count, &h->offset, &h->recd, &h->reci, &h->ctr, &h->scratch, &h->sums, &h->retry_list, &h->pf_dev, &h->pr2_dev, &h->headd, &h->headi, &h->epool, &h->facet_flags}) b->release();
     for (HostBuf *b : {&h->st_list, &h->st_status, &h->st_hd, &h->st_hi, &h->st_pool, &h->st_fxd, &h->st_fxi, &h->st_rlist}) b->release();
     for (auto &e : h->ev) if (e) (void)hipEventDestroy(e);
     if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
@@ -598,6 +605,33 @@ static int launch_scan(mpc_handle *h, const int32_t *in, int32_t *out, long long
     hipLaunchKernelGGL(k_scan_block_sums, dim3(nb), dim3(SCAN_BLOCK), 0, h->stream, in, n, h->sums.as<int32_t>());
     hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(SCAN_BLOCK), 0, h->stream, h->sums.as<int32_t>(), nb, total_dev);
     hipLaunchKernelGGL(k_scan_apply, dim3(nb), dim3(SCAN_BLOCK), 0, h->stream, in, out, n, h->sums.as<int32_t>());
+    HIP_TRY(h, hipGetLastError());
+    return MPC_OK;
+}
+
+// LDS-engine region kernel over `list` (n_list optimal candidates), fixed-stride records at slots 0..n_list-1.
+// Few candidates: one wavefront per (candidate, facet) and an assembly pass (latency form); many: one per candidate.
+static int launch_region_v1(mpc_handle *h, const int32_t *list, long long n_list, int k, LevelCounters *ctr) {
+    hipStream_t st = h->stream;
+    HIP_TRY(h, h->recd.ensure((size_t)n_list * h->rec_d * sizeof(double), st));
+    HIP_TRY(h, h->reci.ensure((size_t)n_list * h->rec_i * sizeof(int32_t), st));
+    const long long rows_t = h->n_c - h->n_eq + h->n_tc;
+    const bool split = h->n_t > 1 && n_list <= 2LL * h->grid_r;
+    HIP_TRY(h, hipMemsetAsync(&ctr->work_region, 0, sizeof(unsigned int), st));
+    if (split) {
+        HIP_TRY(h, h->facet_flags.ensure((size_t)n_list * rows_t, st));
+        hipLaunchKernelGGL((k_region<RG_FACET>), dim3((unsigned)std::min<long long>(n_list * rows_t, 4LL * h->grid_r)), dim3(64), h->lds_r, st, h->Pr,
+                           h->frontier.as<int32_t>(), k, list, (int)n_list, h->status.as<uint8_t>(), h->recd.as<double>(), h->reci.as<int32_t>(),
+                           h->rec_d, h->rec_i, ctr, h->facet_flags.as<uint8_t>());
+        HIP_TRY(h, hipMemsetAsync(&ctr->work_region, 0, sizeof(unsigned int), st));
+        hipLaunchKernelGGL((k_region<RG_ASSEMBLE>), dim3((unsigned)std::min<long long>(n_list, h->grid_r)), dim3(64), h->lds_r, st, h->Pr,
+                           h->frontier.as<int32_t>(), k, list, (int)n_list, h->status.as<uint8_t>(), h->recd.as<double>(), h->reci.as<int32_t>(),
+                           h->rec_d, h->rec_i, ctr, h->facet_flags.as<uint8_t>());
+    } else {
+        hipLaunchKernelGGL((k_region<RG_FULL>), dim3((unsigned)std::min<long long>(n_list, h->grid_r)), dim3(64), h->lds_r, st, h->Pr,
+                           h->frontier.as<int32_t>(), k, list, (int)n_list, h->status.as<uint8_t>(), h->recd.as<double>(), h->reci.as<int32_t>(),
+                           h->rec_d, h->rec_i, ctr, (uint8_t *)nullptr);
+    }
     HIP_TRY(h, hipGetLastError());
     return MPC_OK;
 }
@@ -714,20 +748,12 @@ int mpc_level_run(mpc_handle *h, int32_t gen_children, mpc_level_stats *stats) {
             { int rcs = compact(ST_RETRY, ST_RETRY, &n_rr); if (rcs) return rcs; }
             h->n_rretry = n_rr;
             if (n_rr > 0) {   // numerically doubtful regions: the LDS-engine kernel, fixed-stride records
-                HIP_TRY(h, h->recd.ensure((size_t)n_rr * h->rec_d * sizeof(double), st));
-                HIP_TRY(h, h->reci.ensure((size_t)n_rr * h->rec_i * sizeof(int32_t), st));
-                hipLaunchKernelGGL(k_region, dim3((unsigned)std::min<long long>(n_rr, h->grid_r)), dim3(64), h->lds_r, st, h->Pr,
-                                   h->frontier.as<int32_t>(), k, h->retry_list.as<int32_t>(), n_rr, h->status.as<uint8_t>(),
-                                   h->recd.as<double>(), h->reci.as<int32_t>(), h->rec_d, h->rec_i, ctr);
-                HIP_TRY(h, hipGetLastError());
+                int rcs = launch_region_v1(h, h->retry_list.as<int32_t>(), n_rr, k, ctr);
+                if (rcs) return rcs;
             }
         } else if (n_opt > 0) {
-            HIP_TRY(h, h->recd.ensure((size_t)n_opt * h->rec_d * sizeof(double), st));
-            HIP_TRY(h, h->reci.ensure((size_t)n_opt * h->rec_i * sizeof(int32_t), st));
-            hipLaunchKernelGGL(k_region, dim3((unsigned)std::min<long long>(n_opt, h->grid_r)), dim3(64), h->lds_r, st, h->Pr,
-                               h->frontier.as<int32_t>(), k, h->opt_list.as<int32_t>(), n_opt, h->status.as<uint8_t>(),
-                               h->recd.as<double>(), h->reci.as<int32_t>(), h->rec_d, h->rec_i, ctr);
-            HIP_TRY(h, hipGetLastError());
+            int rcs = launch_region_v1(h, h->opt_list.as<int32_t>(), n_opt, k, ctr);
+            if (rcs) return rcs;
         }
         HIP_TRY(h, hipEventRecord(h->ev[2], st));
         // pruned masks of this level + children
