@@ -85,6 +85,7 @@ typedef struct {
     int64_t n_xtheta_fallback; /* ... of which the vertex warm start was abandoned for a from-scratch solve */
     int64_t wave_cycles[4];    /* wavefront cycles in: KKT solve, theta LP, (x,theta) LP, region build */
     int64_t n_region_retry;    /* optimal candidates re-solved by the LDS-engine region kernel */
+    int64_t n_x_cached;        /* (x,theta) solves that started from the parent's dictionary cached in HBM */
 } mpc_level_stats;
 
 /* ---- library / device ------------------------------------------------------------------------------ */

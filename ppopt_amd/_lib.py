@@ -40,7 +40,8 @@ class LevelStats(ctypes.Structure):
                 ('n_pruned_new', ctypes.c_int64), ('lp_pivots', ctypes.c_int64), ('ms_verdict', ctypes.c_float),
                 ('ms_region', ctypes.c_float), ('ms_children', ctypes.c_float), ('ms_total', ctypes.c_float),
                 ('n_xtheta_lp', ctypes.c_int64), ('n_xtheta_fallback', ctypes.c_int64),
-                ('wave_cycles', ctypes.c_int64 * 4), ('n_region_retry', ctypes.c_int64)]
+                ('wave_cycles', ctypes.c_int64 * 4), ('n_region_retry', ctypes.c_int64),
+                ('n_x_cached', ctypes.c_int64)]
 
 
 _lib = None

@@ -58,6 +58,7 @@ struct LevelCounters {
     unsigned long long pivots;
     unsigned long long xtheta_lps;  // candidates that needed the large (x,theta) LP
     unsigned long long xtheta_fallbacks;  // ... of which the warm start from the pre-crashed vertex was abandoned
+    unsigned long long x_cached;    // (x,theta) solves that started from the parent's cached dictionary
     unsigned long long cycles[4];   // wave-cycles (s_memtime) spent in: KKT solve, theta LP, (x,theta) LP, region build
     unsigned int work_verdict, work_region, n_opt, n_pruned_new, work_retry, work_x, e_rows, work_r2;
 };
@@ -691,14 +692,18 @@ __global__ void __launch_bounds__(64) k_children_count(DevProblem P, const int32
     if (lane == 0) { childmask[2 * c] = m0; childmask[2 * c + 1] = m1; count[c] = __popcll(m0) + __popcll(m1); }
 }
 
+// stored / parent_slot (both optional): child -> index of its parent when the parent left its (x,theta) dictionary in the
+// dictionary cache (k_x2), else -1
 __global__ void __launch_bounds__(64) k_children_write(const int32_t *__restrict__ cands, long long n, int k,
                                                        const unsigned long long *__restrict__ childmask,
-                                                       const int32_t *__restrict__ offset, int32_t *__restrict__ out) {
+                                                       const int32_t *__restrict__ offset, int32_t *__restrict__ out,
+                                                       const uint8_t *__restrict__ stored, int32_t *__restrict__ parent_slot) {
     const long long c = blockIdx.x;
     const int lane = lane_id();
     if (c >= n) return;
     const int32_t *as = cands + (size_t)c * k;
     int base = offset[c];
+    const int ps = (stored && stored[c]) ? (int)c : -1;
     for (int half = 0; half < 2; ++half) {
         const unsigned long long mk = childmask[2 * c + half];
         if (!mk) continue;
@@ -708,6 +713,7 @@ __global__ void __launch_bounds__(64) k_children_write(const int32_t *__restrict
             int32_t *o = out + (size_t)pos * (k + 1);
             for (int i = 0; i < k; ++i) o[i] = as[i];
             o[k] = half * 64 + lane;
+            if (parent_slot) parent_slot[pos] = ps;
         }
         base += __popcll(mk);
     }

@@ -153,15 +153,28 @@ __global__ void __launch_bounds__(64, (NT * SLOTS >= 20 ? 3 : 4)) k_theta2(const
 }
 
 
-// (x,theta) feasibility of the candidates list[0..n_list) from the pre-crashed vertex dictionary, in registers.
-// No LDS: the kernel needs only the active set and D0.
+// (x,theta) feasibility of the candidates list[0..n_list), in registers, no LDS.
+//
+// Dictionary cache (the 288 GB of HBM put to work): a candidate that is feasible leaves its final dictionary -- the
+// program's pre-crashed vertex dictionary with the candidate's rows activated -- in HBM (dict_cur, slot = its index in the
+// level).  A child (= parent + one larger row) whose parent has a slot loads that dictionary with coalesced column
+// reads and activates ONE row instead of starting from D0 and activating all k.  The kernel then streams ~2 x 9 KB per
+// candidate (config 4) and is bound by HBM bandwidth rather than by pivots.
+// dict layout per slot: doubles [NXC][mr] (column j of row i at j*mr + i) ; ints var[mr] kind[mr] cv[NXC] alive growth_hi growth_lo
+struct DictCache {
+    const int32_t *parent_slot;   // per candidate of this level (nullptr: no cache to read)
+    const double *prev_d; const int32_t *prev_i;
+    double *cur_d; int32_t *cur_i; uint8_t *stored;   // cur_d == nullptr: do not store
+    long long stride_d, stride_i;
+    int dict_only;   // 1: the candidates are already decided (theta stage); only their dictionary is wanted for the children
+};
 template <int NXC, int SLOTS>
-__global__ void __launch_bounds__(64, (NXC * SLOTS >= 64 ? 2 : 3)) k_x2(const DevProblem *__restrict__ Pg, const int32_t *__restrict__ cands, int k,
+__global__ void __launch_bounds__(64, (NXC * SLOTS >= 32 ? 2 : 3)) k_x2(const DevProblem *__restrict__ Pg, const int32_t *__restrict__ cands, int k,
                                               const int32_t *__restrict__ list, int n_list, uint8_t *__restrict__ status,
-                                              LevelCounters *__restrict__ ctr) {
+                                              LevelCounters *__restrict__ ctr, DictCache dc) {
     const DevProblem &P = *Pg;
     const int lane = lane_id(), nv = P.n_x + P.n_t, e = P.n_eq;
-    unsigned long long pivots = 0, n_retry = 0;
+    unsigned long long pivots = 0, n_retry = 0, n_cached = 0;
     long long cyc_x = 0;
     for (;;) {
         unsigned int w = 0;
@@ -171,6 +184,7 @@ __global__ void __launch_bounds__(64, (NXC * SLOTS >= 64 ? 2 : 3)) k_x2(const De
         const int c = list[w];
         const int32_t *as = cands + (size_t)c * k;
         const bool singular = status[c] == ST_NEEDX_SING;
+        const bool dict_only = dc.dict_only != 0;
         bool retry = false;
         int st = -1;
         const long long t2 = clock64();
@@ -179,23 +193,37 @@ __global__ void __launch_bounds__(64, (NXC * SLOTS >= 64 ? 2 : 3)) k_x2(const De
             RegLp<NXC, SLOTS> lx;
             const int mr = P.n_d0r, nc0 = P.n_d0c;
             lx.m = mr; lx.iters = 0; lx.max_iter = 50 * (mr + nc0) + 100; lx.growth = 0.0;
-            lx.alive = (nc0 >= 31 ? 0xfffffffeu : ((1u << (nc0 + 1)) - 2u));
-            lx.cv = (lane >= 1 && lane <= nc0) ? nv + P.d0_cols[lane - 1] : -1;
+            const int ps = dc.parent_slot ? dc.parent_slot[c] : -1;
+            // one load path for both sources (two paths make the register allocator keep two tableaux): the parent's
+            // dictionary from the cache (only the child's own, last, row is new) or the program's D0 (all rows new)
+            const bool cached = ps >= 0;
+            const double *src_d = cached ? dc.prev_d + (size_t)ps * dc.stride_d : P.d0T;
+            const int32_t *src_i = cached ? dc.prev_i + (size_t)ps * dc.stride_i : P.d0_rows;
+            const int jmax = cached ? NXC - 1 : nc0, voff = cached ? 0 : nv;
+            const int first = cached ? k - 1 : e;   // first active row that still has to be switched on
+            lx.alive = cached ? (unsigned)src_i[2 * mr + NXC] : (nc0 >= 31 ? 0xfffffffeu : ((1u << (nc0 + 1)) - 2u));
+            if (cached) { lx.growth = __hiloint2double(src_i[2 * mr + NXC + 1], src_i[2 * mr + NXC + 2]); n_cached++; }
+            {
+                int cvv = -1;
+                if (cached) { if (lane < NXC) cvv = src_i[2 * mr + lane]; }
+                else if (lane >= 1 && lane <= nc0) cvv = nv + P.d0_cols[lane - 1];
+                lx.cv = cvv;
+            }
 #pragma unroll
             for (int sl = 0; sl < SLOTS; ++sl) {
                 const int i = lane + 64 * sl;
-                lx.kind[sl] = i < mr ? RK_INEQ : RK_DEAD;
-                lx.var[sl] = i < mr ? nv + P.d0_rows[i] : -1;
+                lx.var[sl] = i < mr ? voff + src_i[i] : -1;
+                lx.kind[sl] = i < mr ? (cached ? src_i[mr + i] : RK_INEQ) : RK_DEAD;
 #pragma unroll
-                for (int j = 0; j < NXC; ++j) lx.t[sl][j] = (i < mr && j <= nc0) ? P.d0T[(size_t)j * mr + i] : 0.0;
+                for (int j = 0; j < NXC; ++j) lx.t[sl][j] = (i < mr && j <= jmax) ? src_d[(size_t)j * mr + i] : 0.0;
             }
             // every active row is switched on at the feasible vertex: a nonbasic slack is simply fixed at zero (column
             // deleted); a basic one is driven to zero by a primal simplex run that keeps all other rows feasible, so no
             // phase 1 is needed afterwards.  "Its minimum is positive" <=> the candidate is infeasible.
             int r = LP_OPTIMAL;
-            for (int a = e; a < k && r == LP_OPTIMAL; ++a) {
+            for (int a = first; a < k && r == LP_OPTIMAL; ++a) {
                 const int v = nv + as[a];
-                const unsigned long long bc = __ballot(lx.cv == v && lane >= 1 && lane <= nc0 && ((lx.alive >> lane) & 1u));
+                const unsigned long long bc = __ballot(lx.cv == v && lane >= 1 && lane < NXC && ((lx.alive >> lane) & 1u));
                 if (bc) lx.drop_col(__ffsll((long long)bc) - 1);
                 int row = -1;
 #pragma unroll
@@ -205,6 +233,28 @@ __global__ void __launch_bounds__(64, (NXC * SLOTS >= 64 ? 2 : 3)) k_x2(const De
                 }
                 if (row >= 0) r = lx.drive_to_zero(row);
                 else if (!bc) retry = true;
+            }
+            if (!retry && r == LP_OPTIMAL && !(lx.growth > GROWTH_SAFE) && dc.cur_d) {
+                // leave the dictionary for the children
+                double *od = dc.cur_d + (size_t)c * dc.stride_d;
+                int32_t *oi = dc.cur_i + (size_t)c * dc.stride_i;
+#pragma unroll
+                for (int sl = 0; sl < SLOTS; ++sl) {
+                    const int i = lane + 64 * sl;
+                    if (i < mr) {
+                        oi[i] = lx.var[sl];
+                        oi[mr + i] = lx.kind[sl];
+#pragma unroll
+                        for (int j = 0; j < NXC; ++j) od[(size_t)j * mr + i] = lx.t[sl][j];
+                    }
+                }
+                if (lane < NXC) oi[2 * mr + lane] = lx.cv;
+                if (lane == 0) {
+                    oi[2 * mr + NXC] = (int)lx.alive;
+                    oi[2 * mr + NXC + 1] = __double2hiint(lx.growth);
+                    oi[2 * mr + NXC + 2] = __double2loint(lx.growth);
+                    dc.stored[c] = 1;
+                }
             }
             pivots += lx.iters;
             if (!retry && r != LP_ITERLIMIT && lx.growth > GROWTH_SAFE) retry = true;
@@ -216,11 +266,11 @@ __global__ void __launch_bounds__(64, (NXC * SLOTS >= 64 ? 2 : 3)) k_x2(const De
         }
         cyc_x += clock64() - t2;
         if (retry) { st = ST_RETRY; n_retry++; }
-        if (lane == 0) status[c] = (uint8_t)st;
+        if (lane == 0 && !dict_only) status[c] = (uint8_t)st;
     }
     if (lane == 0) {
         atomicAdd(&ctr->cycles[2], (unsigned long long)cyc_x);
-        atomicAdd(&ctr->pivots, pivots); atomicAdd(&ctr->xtheta_fallbacks, n_retry);
+        atomicAdd(&ctr->pivots, pivots); atomicAdd(&ctr->xtheta_fallbacks, n_retry); atomicAdd(&ctr->x_cached, n_cached);
     }
 }
 

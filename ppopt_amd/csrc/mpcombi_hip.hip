@@ -91,6 +91,13 @@ struct mpc_handle {
     DevProblem Pf{};          // view for k_verdict2 (small LDS layout: no tableau)
     int lds_f = 0, grid_f = 0;
     DevBuf retry_list, pf_dev, pr2_dev, headd, headi, epool, facet_flags;
+    // (x,theta) dictionary cache: [0]/[1] ping-pong between the level being read (parents) and the level being written
+    DevBuf dict_d[2], dict_i[2], dict_stored[2], parent_slot, parent_slot_next;
+    int dict_cur = 0;
+    bool have_prev_dict = false, have_parent_slot = false, storing = false;
+    long long dict_stride_d = 0, dict_stride_i = 0;
+    double dict_budget_gb = 48.0;
+
     DevProblem Pr2{};         // view for k_region2
     int lds_r2 = 0, grid_r2 = 0, fast_r = -1;   // fast_r: k_region2 instantiation, -1 = none (n_t == 1 or too many rows)
     bool used_region2 = false;
@@ -246,6 +253,7 @@ int mpc_create(const mpc_problem *p, int32_t device, void *stream, mpc_handle **
     for (auto &e : h->ev) HIP_TRY(nullptr, hipEventCreate(&e));
     h->n_x = nx; h->n_t = nt; h->n_c = nc; h->n_eq = ne; h->n_tc = ntc; h->is_qp = p->Q != nullptr;
     { const char *ev = std::getenv("MPC_FORCE_V1"); h->force_v1 = ev && ev[0] == '1'; }
+    { const char *ev = std::getenv("MPC_DICT_BUDGET_GB"); if (ev) h->dict_budget_gb = std::atof(ev); }
 
     const int nr = nt + 1;
     // ---- host-side one-off blocks ----------------------------------------------------------------------
@@ -499,7 +507,8 @@ int mpc_destroy(mpc_handle *h) {
     (void)hipSetDevice(h->device);
     (void)hipStreamSynchronize(h->stream);
     for (DevBuf *b : {&h->blocks, &h->iblocks, &h->frontier, &h->children, &h->status, &h->pruned, &h->pruned_new, &h->flag, &h->pos, &h->opt_list,
-                      &h->childmask, &h->count, &h->offset, &h->recd, &h->reci, &h->ctr, &h->scratch, &h->sums, &h->retry_list, &h->pf_dev, &h->pr2_dev, &h->headd, &h->headi, &h->epool, &h->facet_flags}) b->release();
+                      &h->childmask, &h->count, &h->offset, &h->recd, &h->reci, &h->ctr, &h->scratch, &h->sums, &h->retry_list, &h->pf_dev, &h->pr2_dev, &h->headd, &h->headi, &h->epool, &h->facet_flags, &h->dict_d[0], &h->dict_d[1], &h->dict_i[0], &h->dict_i[1],
+                      &h->dict_stored[0], &h->dict_stored[1], &h->parent_slot, &h->parent_slot_next}) b->release();
     for (HostBuf *b : {&h->st_list, &h->st_status, &h->st_hd, &h->st_hi, &h->st_pool, &h->st_fxd, &h->st_fxi, &h->st_rlist}) b->release();
     for (auto &e : h->ev) if (e) (void)hipEventDestroy(e);
     if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
@@ -519,6 +528,7 @@ static int frontier_reset(mpc_handle *h, long long n, int k) {
     HIP_TRY(h, hipSetDevice(h->device));
     HIP_TRY(h, h->frontier.ensure((size_t)std::max<long long>(n, 1) * std::max(k, 1) * sizeof(int32_t), h->stream));
     h->n = n; h->k = k; h->level_done = false;
+    h->have_prev_dict = false; h->have_parent_slot = false;   // a frontier set from outside has no cached parent dictionaries
     return MPC_OK;
 }
 
@@ -686,20 +696,55 @@ int mpc_level_run(mpc_handle *h, int32_t gen_children, mpc_level_stats *stats) {
                 }
                 HIP_TRY(h, hipGetLastError());
             }
+            // ---- (x,theta) stage with the dictionary cache -------------------------------------------------------------
+            const int nxc = h->fast_x >= 2 ? 32 : 16;
+            h->dict_stride_d = (long long)nxc * h->Pf.n_d0r;
+            h->dict_stride_i = 2LL * h->Pf.n_d0r + nxc + 4;
+            DictCache dc{};
+            dc.stride_d = h->dict_stride_d; dc.stride_i = h->dict_stride_i;
+            if (h->have_prev_dict && h->have_parent_slot) {
+                dc.parent_slot = h->parent_slot.as<int32_t>();
+                dc.prev_d = h->dict_d[1 - h->dict_cur].as<double>();
+                dc.prev_i = h->dict_i[1 - h->dict_cur].as<int32_t>();
+            }
+            h->storing = false;
+            const double need_gb = (double)nn * (h->dict_stride_d * 8.0 + h->dict_stride_i * 4.0) / 1e9;
+            if (gen_children && need_gb <= h->dict_budget_gb) {
+                HIP_TRY(h, h->dict_d[h->dict_cur].ensure(nn * h->dict_stride_d * sizeof(double), st));
+                HIP_TRY(h, h->dict_i[h->dict_cur].ensure(nn * h->dict_stride_i * sizeof(int32_t), st));
+                HIP_TRY(h, h->dict_stored[h->dict_cur].ensure(nn, st));
+                HIP_TRY(h, hipMemsetAsync(h->dict_stored[h->dict_cur].p, 0, nn, st));
+                dc.cur_d = h->dict_d[h->dict_cur].as<double>(); dc.cur_i = h->dict_i[h->dict_cur].as<int32_t>();
+                dc.stored = h->dict_stored[h->dict_cur].as<uint8_t>();
+                h->storing = true;
+            }
+            auto launch_x = [&](int n_items, const DictCache &d) -> int {
+                HIP_TRY(h, hipMemsetAsync(&ctr->work_x, 0, sizeof(unsigned int), st));
+                const dim3 gg((unsigned)std::min<long long>(n_items, (long long)h->n_cu * 16)), bb(64);
+                const int32_t *ls = h->retry_list.as<int32_t>();
+                switch (h->fast_x) {
+                    case 0: hipLaunchKernelGGL((k_x2<16, 1>), gg, bb, 0, st, pf, fr, k, ls, n_items, stp, ctr, d); break;
+                    case 1: hipLaunchKernelGGL((k_x2<16, 2>), gg, bb, 0, st, pf, fr, k, ls, n_items, stp, ctr, d); break;
+                    case 2: hipLaunchKernelGGL((k_x2<32, 1>), gg, bb, 0, st, pf, fr, k, ls, n_items, stp, ctr, d); break;
+                    default: hipLaunchKernelGGL((k_x2<32, 2>), gg, bb, 0, st, pf, fr, k, ls, n_items, stp, ctr, d); break;
+                }
+                HIP_TRY(h, hipGetLastError());
+                return MPC_OK;
+            };
+            if (h->storing) {
+                // candidates the theta stage already decided (feasible / optimal) expand too: their children get a
+                // dictionary to start from (status untouched)
+                DictCache d2 = dc; d2.dict_only = 1;
+                for (int which : {ST_FEASIBLE, ST_OPT_PENDING}) {
+                    int32_t n_dict = 0;
+                    { int rcs = compact(which, which, &n_dict); if (rcs) return rcs; }
+                    if (n_dict > 0) { int rcs = launch_x(n_dict, d2); if (rcs) return rcs; }
+                }
+            }
             int32_t n_needx = 0;
             { int rcs = compact(ST_NEEDX, ST_NEEDX_SING, &n_needx); if (rcs) return rcs; }
             h->n_needx = n_needx;
-            if (n_needx > 0) {   // (x,theta) feasibility for the candidates the theta stage left open
-                const dim3 g((unsigned)std::min<long long>(n_needx, (long long)h->n_cu * 16)), b(64);
-                const int32_t *lst = h->retry_list.as<int32_t>();
-                switch (h->fast_x) {
-                    case 0: hipLaunchKernelGGL((k_x2<16, 1>), g, b, 0, st, pf, fr, k, lst, n_needx, stp, ctr); break;
-                    case 1: hipLaunchKernelGGL((k_x2<16, 2>), g, b, 0, st, pf, fr, k, lst, n_needx, stp, ctr); break;
-                    case 2: hipLaunchKernelGGL((k_x2<32, 1>), g, b, 0, st, pf, fr, k, lst, n_needx, stp, ctr); break;
-                    default: hipLaunchKernelGGL((k_x2<32, 2>), g, b, 0, st, pf, fr, k, lst, n_needx, stp, ctr); break;
-                }
-                HIP_TRY(h, hipGetLastError());
-            }
+            if (n_needx > 0) { int rcs = launch_x(n_needx, dc); if (rcs) return rcs; }   // feasibility for the candidates left open
             // numerically doubtful candidates (status 7) go through the LDS engine, which can refactorise its basis
             int32_t n_retry = 0;
             { int rcs = compact(ST_RETRY, ST_RETRY, &n_retry); if (rcs) return rcs; }
@@ -773,8 +818,10 @@ int mpc_level_run(mpc_handle *h, int32_t gen_children, mpc_level_stats *stats) {
             h->n_children = n_children;
             if (n_children > 0) {
                 HIP_TRY(h, h->children.ensure((size_t)n_children * (k + 1) * sizeof(int32_t), st));
+                HIP_TRY(h, h->parent_slot_next.ensure((size_t)n_children * sizeof(int32_t), st));
                 hipLaunchKernelGGL(k_children_write, dim3((unsigned)n), dim3(64), 0, st, h->frontier.as<int32_t>(), n, k,
-                                   h->childmask.as<unsigned long long>(), h->offset.as<int32_t>(), h->children.as<int32_t>());
+                                   h->childmask.as<unsigned long long>(), h->offset.as<int32_t>(), h->children.as<int32_t>(),
+                                   h->storing ? h->dict_stored[h->dict_cur].as<uint8_t>() : (const uint8_t *)nullptr, h->parent_slot_next.as<int32_t>());
                 HIP_TRY(h, hipGetLastError());
             }
         }
@@ -801,6 +848,7 @@ int mpc_level_run(mpc_handle *h, int32_t gen_children, mpc_level_stats *stats) {
         stats->n_xtheta_fallback = (int64_t)host_ctr.xtheta_fallbacks;
         for (int i = 0; i < 4; ++i) stats->wave_cycles[i] = (int64_t)host_ctr.cycles[i];
         stats->n_region_retry = h->n_rretry;
+        stats->n_x_cached = (int64_t)host_ctr.x_cached;
         stats->ms_verdict = ms[0]; stats->ms_region = ms[1]; stats->ms_children = ms[2]; stats->ms_total = ms[0] + ms[1] + ms[2];
     }
     return MPC_OK;
@@ -1010,6 +1058,11 @@ int mpc_frontier_advance(mpc_handle *h) {
         if (rc) return rc;
     }
     std::swap(h->frontier, h->children);
+    std::swap(h->parent_slot, h->parent_slot_next);
+    h->have_parent_slot = true;
+    h->have_prev_dict = h->storing;
+    h->dict_cur = 1 - h->dict_cur;
+    h->storing = false;
     h->n = h->n_children;
     h->k = h->k + 1;
     h->level_done = false;

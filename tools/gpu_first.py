@@ -28,7 +28,7 @@ def run(name, max_levels=None):
                 mism += len(d)
                 for j in d[:4]:
                     print(name, 'level', depth, 'cand', cands[j], 'gpu', status[j], 'ref', gv[j])
-        print(f'  L{depth}: n={st.n} k={st.k} hist={list(st.n_status)} children={st.n_children} pruned_new={st.n_pruned_new} pivots={st.lp_pivots} xlp={st.n_xtheta_lp}/{st.n_xtheta_fallback} rretry={st.n_region_retry} cyc(kkt/th/x)={[int(v)//max(int(st.n),1) for v in st.wave_cycles[:3]]} ms v/r/c = {st.ms_verdict:.3f}/{st.ms_region:.3f}/{st.ms_children:.3f}')
+        print(f'  L{depth}: n={st.n} k={st.k} hist={list(st.n_status)} children={st.n_children} pruned_new={st.n_pruned_new} pivots={st.lp_pivots} xlp={st.n_xtheta_lp}/{st.n_xtheta_fallback}/c{st.n_x_cached} rretry={st.n_region_retry} cyc(kkt/th/x)={[int(v)//max(int(st.n),1) for v in st.wave_cycles[:3]]} ms v/r/c = {st.ms_verdict:.3f}/{st.ms_region:.3f}/{st.ms_children:.3f}')
         if not gen or st.n_children == 0: break
         eng.frontier_advance()
     wall = time.time() - t0
