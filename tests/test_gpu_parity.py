@@ -260,3 +260,49 @@ def test_control_allocation_singular_kkt_is_a_status():
         assert numpy.linalg.cond(M) < 1e12
     assert len(regions) > 100
     eng.close()
+
+
+def _dist_worker(name, out):
+    import os
+    import torch
+    import torch.distributed as dist
+    from ppopt_amd.distributed import HipLevelEngine, solve_distributed
+    from test_host_logic import build_program
+    from ppopt_amd import Solver
+    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+    os.environ.setdefault('MASTER_PORT', str(29600 + os.getpid() % 1000))
+    torch.cuda.set_device(0)
+    dist.init_process_group('nccl', rank=0, world_size=1, device_id=torch.device('cuda', 0))
+    try:
+        g = load_golden(name)
+        with warnings.catch_warnings():
+            warnings.simplefilter('ignore')
+            prog = build_program(g, Solver())
+        eng = HipLevelEngine(prog, 0)
+        prof = []
+        sol = solve_distributed(eng, prog, profile=prof)
+        out['sets'] = sorted(tuple(r.active_set) for r in sol.critical_regions)
+        out['levels'] = [(p['candidates'], p['status'][:5]) for p in prof if p['depth'] > 0]
+        eng.close()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('name', ['rand_4_2_10_s0', 'c2_dblint_n5'])
+def test_distributed_path_on_one_gpu(name):
+    """The multi-GPU driver (HipLevelEngine + RCCL exchange) with a world of one rank: same candidates, same verdicts,
+    same regions as the reference.  (The N > 1 exchange itself is covered by the gloo tests on CPU.)"""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context('spawn')
+    with ctx.Manager() as mgr:
+        out = mgr.dict()
+        p = ctx.Process(target=_dist_worker, args=(name, out))
+        p.start()
+        p.join(300)
+        assert p.exitcode == 0
+        res = dict(out)
+    g = load_golden(name)
+    assert res['sets'] == sorted(golden_regions(g))
+    for i, (n, hist) in enumerate(res['levels']):
+        assert n == len(g[f'L{i}_verdict'])
+        assert hist == numpy.bincount(g[f'L{i}_verdict'], minlength=5).tolist()
