@@ -36,6 +36,7 @@ struct DevProblem {
     const double *UV;   // n_c x (n_t+1)        [A Q^-1 c + b | A Q^-1 H + F]
     const double *Gt;   // n_c x n_x            row i = (Q^-1 A_i')'
     const double *X0H;  // n_x x (n_t+1)        [-Q^-1 c | -Q^-1 H]
+    const double *AAT;  // n_c x n_c            A A'  (Gram matrix of the rows: fast rank screen, kernels2.hpp)
     const double *base; // (n_c+n_tc) x (1+n_x+n_t)   [b | A | -F ; b_t | 0 | A_t]
     // pre-crashed dictionary of the (x,theta) LP at a feasible vertex of the base polytope (built once per program):
     // basic slack rows d0_rows (n_d0r) in terms of the nonbasic inequality slacks d0_cols (n_d0c); program
@@ -59,7 +60,7 @@ struct LevelCounters {
     unsigned long long xtheta_lps;  // candidates that needed the large (x,theta) LP
     unsigned long long xtheta_fallbacks;  // ... of which the warm start from the pre-crashed vertex was abandoned
     unsigned long long x_cached;    // (x,theta) solves that started from the parent's cached dictionary
-    unsigned long long cycles[4];   // wave-cycles (s_memtime) spent in: KKT solve, theta LP, (x,theta) LP, region build
+    unsigned long long cycles[6];   // wave-cycles (s_memtime) spent in: KKT solve, theta LP, (x,theta) LP, region build; [4] theta rows, [5] theta stage 2
     unsigned int work_verdict, work_region, n_opt, n_pruned_new, work_retry, work_x, e_rows, work_r2;
 };
 

@@ -17,16 +17,136 @@ constexpr int ST_RETRY = 7;       // numerically doubtful: re-solve with the LDS
 constexpr int ST_NEEDX = 8;       // theta stage could not show feasibility: (x,theta) LP needed (k_x2)
 constexpr int ST_NEEDX_SING = 9;  // the same, and the KKT matrix was singular (a feasible outcome is ST_SINGULAR)
 
+
+// ------------------------------------------------------------------------------------------------------------------
+// k_kkt_thread: the mode-0 KKT solve with ONE THREAD per candidate (K = cardinality, compile time, everything in VGPRs).
+//
+// A k x k Cholesky with k <= 8 has no work for 64 lanes; done by a wavefront it is ~45 dependent LDS phases.  Here every
+// lane solves its own candidate with fully unrolled register code: same operations in the same order as chol_solve
+// (kkt.hpp), so L is bit-identical to what kkt_solve leaves in LDS.
+//   rank test   is_full_rank(A, as) (constraint_utilities.py:222): the Gram matrix A_as A_as' (gathered from AAT) is
+//               eliminated; if the product of its relative pivots (= prod sin^2 of the angles between each row and the
+//               span of the earlier ones) is > 1e-10 and every pivot > 1e-8 of its diagonal, the rows are independent
+//               with a 1e6 margin over the exact test's 1e-11 threshold -> code 0/2.  Anything closer is left to the exact
+//               complete-pivoting elimination of kkt_solve (code KK_UNDECIDED).
+//   output      code[c] in {0 ok, 2 singular, KK_UNDECIDED};  Lout[c*K*nr + i*nr + t] = [b_l | A_l]
+constexpr int KK_UNDECIDED = 255;
+template <int K>
+__global__ void __launch_bounds__(256) k_kkt_thread(const DevProblem *__restrict__ Pg, const int32_t *__restrict__ cands, long long n,
+                                                     uint8_t *__restrict__ code, double *__restrict__ Lout) {
+    const DevProblem &P = *Pg;
+    const long long c = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (c >= n) return;
+    const int nc = P.n_c, nr = P.n_t + 1;
+    int as[K];
+#pragma unroll
+    for (int i = 0; i < K; ++i) as[i] = cands[c * K + i];
+    double S[K][K];
+    // ---- Gram test ----------------------------------------------------------------------------------------------
+    {
+        double gmax = 0.0, g0[K];
+#pragma unroll
+        for (int i = 0; i < K; ++i) {
+#pragma unroll
+            for (int j = 0; j <= i; ++j) S[i][j] = P.AAT[as[i] * nc + as[j]];
+            g0[i] = S[i][i];
+            gmax = fmax(gmax, g0[i]);
+        }
+        bool clear = gmax > 0.0;
+        double vol = 1.0;
+        const double ginv = 1.0 / gmax;
+#pragma unroll
+        for (int j = 0; j < K; ++j) {
+            const double d = S[j][j];
+            clear = clear && (d > 1e-8 * g0[j]);
+            vol *= d * ginv;
+            const double dinv = 1.0 / d;
+#pragma unroll
+            for (int i = j + 1; i < K; ++i) {
+                const double f = S[i][j] * dinv;
+#pragma unroll
+                for (int cc = j + 1; cc <= i; ++cc) S[i][cc] = fma(-f, S[cc][j], S[i][cc]);
+            }
+        }
+        clear = clear && (vol > 1e-10);
+        if (!clear) { code[c] = (uint8_t)KK_UNDECIDED; return; }
+    }
+    // ---- S = W[as,as] = L L'  (chol_solve arithmetic) ---------------------------------------------------------------
+    double diag0[K], invd[K];
+#pragma unroll
+    for (int i = 0; i < K; ++i) {
+#pragma unroll
+        for (int j = 0; j <= i; ++j) S[i][j] = P.W[as[i] * nc + as[j]];
+        diag0[i] = S[i][i];
+    }
+    bool ok = true;
+#pragma unroll
+    for (int j = 0; j < K; ++j) {
+        const double d = S[j][j];
+        ok = ok && (d > RANK_TOL_CHOL * diag0[j]);
+        const double l = sqrt(d), inv = 1.0 / l;
+#pragma unroll
+        for (int i = j + 1; i < K; ++i) S[i][j] = S[i][j] * inv;
+        S[j][j] = l;
+        invd[j] = 1.0 / l;
+#pragma unroll
+        for (int i = j + 1; i < K; ++i) {
+#pragma unroll
+            for (int cc = j + 1; cc <= i; ++cc) S[i][cc] = fma(-S[i][j], S[cc][j], S[i][cc]);
+        }
+    }
+    if (!ok) { code[c] = 2; return; }
+    double *out = Lout + (size_t)c * K * nr;
+    for (int t = 0; t < nr; ++t) {
+        double R[K];
+#pragma unroll
+        for (int i = 0; i < K; ++i) R[i] = -P.UV[as[i] * nr + t];
+#pragma unroll
+        for (int j = 0; j < K; ++j) {
+            R[j] = R[j] * invd[j];
+#pragma unroll
+            for (int i = j + 1; i < K; ++i) R[i] = fma(-S[i][j], R[j], R[i]);
+        }
+#pragma unroll
+        for (int j = K - 1; j >= 0; --j) {
+            R[j] = R[j] * invd[j];
+#pragma unroll
+            for (int i = 0; i < j; ++i) R[i] = fma(-S[j][i], R[j], R[i]);
+        }
+#pragma unroll
+        for (int i = 0; i < K; ++i) out[i * nr + t] = R[i];
+    }
+    code[c] = 0;
+}
+
+// the KKT result of candidate c: from k_kkt_thread's output when it decided, else solved here
+__device__ inline int kkt_fetch_or_solve(const DevProblem &P, int k, Smem &s, const uint8_t *kkcode, const double *Lin, size_t c) {
+    if (kkcode) {
+        const int code = kkcode[c];
+        if (code != KK_UNDECIDED) {
+            if (code == 0) {
+                const int cnt = k * (P.n_t + 1);
+                const double *src = Lin + c * (size_t)cnt;
+                for (int idx = lane_id(); idx < cnt; idx += 64) s.L[idx] = src[idx];
+                wave_sync();
+            }
+            return code;
+        }
+    }
+    return kkt_solve(P, k, s);
+}
+
 template <int NT, int SLOTS>
 __global__ void __launch_bounds__(64, (NT * SLOTS >= 20 ? 3 : 4)) k_theta2(const DevProblem *__restrict__ Pg, const int32_t *__restrict__ cands, long long n, int k,
-                                                    uint8_t *__restrict__ status, LevelCounters *__restrict__ ctr) {
+                                                    uint8_t *__restrict__ status, LevelCounters *__restrict__ ctr,
+                                                    const uint8_t *__restrict__ kkcode, const double *__restrict__ Lin) {
     // the program descriptor stays in memory (scalar loads on demand) instead of ~90 live SGPRs
     const DevProblem &P = *Pg;
     extern __shared__ __attribute__((aligned(16))) double smem[];
     Smem s = carve(P, smem);
     const int lane = lane_id(), nt = P.n_t, nr = nt + 1, nv = P.n_x + P.n_t, e = P.n_eq;
     unsigned long long pivots = 0, n_retry = 0;
-    long long cyc_kkt = 0, cyc_theta = 0;
+    long long cyc_kkt = 0, cyc_theta = 0, cyc_rows = 0, cyc_s2 = 0;
     for (;;) {
         unsigned int c = 0;
         if (lane == 0) c = atomicAdd(&ctr->work_verdict, 1u);
@@ -35,7 +155,7 @@ __global__ void __launch_bounds__(64, (NT * SLOTS >= 20 ? 3 : 4)) k_theta2(const
         const int nin = load_active_set(P, cands + (size_t)c * k, k, s);
         int st = -1;
         const long long t0 = clock64();
-        const int kk = kkt_solve(P, k, s);
+        const int kk = kkt_fetch_or_solve(P, k, s, kkcode, Lin, c);
         const long long t1 = clock64();
         cyc_kkt += t1 - t0;
         bool singular = false, retry = false;
@@ -127,7 +247,9 @@ __global__ void __launch_bounds__(64, (NT * SLOTS >= 20 ? 3 : 4)) k_theta2(const
                 }
                 lp.t[sl][NT + 1] = 0.0;
             }
+            cyc_rows += clock64() - t1;
             const int r1 = lp.phase1();
+            const long long t15 = clock64();
             if (r1 == LP_ITERLIMIT) st = ST_LP_LIMIT;
             else if (lp.growth > GROWTH_SAFE) retry = true;
             else if (r1 == LP_OPTIMAL) {
@@ -139,6 +261,7 @@ __global__ void __launch_bounds__(64, (NT * SLOTS >= 20 ? 3 : 4)) k_theta2(const
                 else st = r2 == LP_OPTIMAL ? ST_OPT_PENDING : ST_FEASIBLE;
             }
             pivots += lp.iters;
+            cyc_s2 += clock64() - t15;
         }
         const long long t2 = clock64();
         cyc_theta += t2 - t1;
@@ -148,6 +271,7 @@ __global__ void __launch_bounds__(64, (NT * SLOTS >= 20 ? 3 : 4)) k_theta2(const
     }
     if (lane == 0) {
         atomicAdd(&ctr->cycles[0], (unsigned long long)cyc_kkt); atomicAdd(&ctr->cycles[1], (unsigned long long)cyc_theta);
+        atomicAdd(&ctr->cycles[4], (unsigned long long)cyc_rows); atomicAdd(&ctr->cycles[5], (unsigned long long)cyc_s2);
         atomicAdd(&ctr->pivots, pivots); atomicAdd(&ctr->xtheta_fallbacks, n_retry);
     }
 }
@@ -294,7 +418,7 @@ template <int NT, int SLOTS>
 __global__ void __launch_bounds__(64, (NT * SLOTS >= 20 ? 2 : 3)) k_region2(
     const DevProblem *__restrict__ Pg, const int32_t *__restrict__ cands, int k, const int32_t *__restrict__ opt_list, int n_opt,
     uint8_t *__restrict__ status, double *__restrict__ head_d, int32_t *__restrict__ head_i, int fd, int fi,
-    double *__restrict__ epool, LevelCounters *__restrict__ ctr) {
+    double *__restrict__ epool, LevelCounters *__restrict__ ctr, const uint8_t *__restrict__ kkcode, const double *__restrict__ Lin) {
     const DevProblem &P = *Pg;
     extern __shared__ __attribute__((aligned(16))) double smem[];
     Smem s = carve(P, smem);
@@ -315,7 +439,7 @@ __global__ void __launch_bounds__(64, (NT * SLOTS >= 20 ? 2 : 3)) k_region2(
         int32_t *hi = head_i + (size_t)w * fi;
         for (int i = lane; i < fi; i += 64) hi[i] = i < 8 ? 0 : -1;
         int st = ST_REGION;
-        const int kk = kkt_solve(P, k, s);
+        const int kk = kkt_fetch_or_solve(P, k, s, kkcode, Lin, (size_t)c);
         if (kk != 0) st = kk == 1 ? ST_INFEASIBLE : ST_SINGULAR;
         int nE = 0, n_om = 0, n_la = 0, n_re = 0, e_off = 0;
         bool retry = false;

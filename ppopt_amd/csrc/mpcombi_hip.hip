@@ -84,13 +84,15 @@ struct mpc_handle {
     DevBuf iblocks;           // integer blocks (row / column maps of the pre-crashed dictionary)
     DevProblem Pv{}, Pr{};    // verdict / region kernel views (same blocks, different LDS layouts)
     int lds_v = 0, lds_r = 0; // dynamic LDS bytes per wavefront
+    int debug_cycles = 0;     // MPC_DEBUG_CYCLES=1: per-level cycle breakdown on stderr
+    int no_kkt_thread = 0;    // MPC_NO_KKT_THREAD=1: KKT solves stay inside the wave kernels (A/B)
     int force_v1 = 0;         // MPC_FORCE_V1=1 in the environment: never use k_verdict2 (A/B comparisons, tests)
     int fast = 0;             // 1: register-engine kernels (k_theta2 / k_x2) with k_verdict as the retry path
     int fast_t = 0, fast_x = 0; // instantiation selectors
     long long n_needx = 0;
     DevProblem Pf{};          // view for k_verdict2 (small LDS layout: no tableau)
     int lds_f = 0, grid_f = 0;
-    DevBuf retry_list, pf_dev, pr2_dev, headd, headi, epool, facet_flags;
+    DevBuf retry_list, pf_dev, pr2_dev, headd, headi, epool, facet_flags, kkt_code, kkt_L;
     // (x,theta) dictionary cache: [0]/[1] ping-pong between the level being read (parents) and the level being written
     DevBuf dict_d[2], dict_i[2], dict_stored[2], parent_slot, parent_slot_next;
     int dict_cur = 0;
@@ -253,6 +255,8 @@ int mpc_create(const mpc_problem *p, int32_t device, void *stream, mpc_handle **
     for (auto &e : h->ev) HIP_TRY(nullptr, hipEventCreate(&e));
     h->n_x = nx; h->n_t = nt; h->n_c = nc; h->n_eq = ne; h->n_tc = ntc; h->is_qp = p->Q != nullptr;
     { const char *ev = std::getenv("MPC_FORCE_V1"); h->force_v1 = ev && ev[0] == '1'; }
+    { const char *ev = std::getenv("MPC_DEBUG_CYCLES"); h->debug_cycles = ev && ev[0] == '1'; }
+    { const char *ev = std::getenv("MPC_NO_KKT_THREAD"); h->no_kkt_thread = ev && ev[0] == '1'; }
     { const char *ev = std::getenv("MPC_DICT_BUDGET_GB"); if (ev) h->dict_budget_gb = std::atof(ev); }
 
     const int nr = nt + 1;
@@ -413,6 +417,12 @@ int mpc_create(const mpc_problem *p, int32_t device, void *stream, mpc_handle **
     const size_t oAt = put(ntc ? p->A_t : zeros.data(), (size_t)std::max(ntc * nt, 1)), obt = put(ntc ? p->b_t : zeros.data(), std::max(ntc, 1));
     const size_t oW = put(mode == 0 ? W.data() : zeros.data(), mode == 0 ? W.size() : 1), oUV = put(mode == 0 ? UV.data() : zeros.data(), mode == 0 ? UV.size() : 1);
     const size_t oGt = put(mode == 0 ? Gt.data() : zeros.data(), mode == 0 ? Gt.size() : 1), oX0H = put(mode == 0 ? X0H.data() : zeros.data(), mode == 0 ? X0H.size() : 1);
+    std::vector<double> AAT((size_t)nc * nc, 0.0);
+    for (int i = 0; i < nc; ++i) for (int j = 0; j <= i; ++j) {
+        double sdot = 0; for (int l = 0; l < nx; ++l) sdot += p->A[(size_t)i * nx + l] * p->A[(size_t)j * nx + l];
+        AAT[(size_t)i * nc + j] = sdot; AAT[(size_t)j * nc + i] = sdot;
+    }
+    const size_t oAAT = put(AAT.data(), AAT.size());
     const size_t obase = put(base.data(), base.size());
     const size_t od0 = put(d0.empty() ? zeros.data() : d0.data(), d0.empty() ? 1 : d0.size());
     const size_t od0T = put(d0T.empty() ? zeros.data() : d0T.data(), d0T.empty() ? 1 : d0T.size());
@@ -426,7 +436,7 @@ int mpc_create(const mpc_problem *p, int32_t device, void *stream, mpc_handle **
     DevProblem P{};
     P.n_x = nx; P.n_t = nt; P.n_c = nc; P.n_eq = ne; P.n_tc = ntc; P.is_qp = h->is_qp; P.kkt_mode = mode;
     P.A = d + oA; P.b = d + ob; P.F = d + oF; P.c = d + oc; P.H = d + oH; P.Q = d + oQ; P.A_t = d + oAt; P.b_t = d + obt;
-    P.W = d + oW; P.UV = d + oUV; P.Gt = d + oGt; P.X0H = d + oX0H; P.base = d + obase;
+    P.W = d + oW; P.UV = d + oUV; P.Gt = d + oGt; P.X0H = d + oX0H; P.base = d + obase; P.AAT = d + oAAT;
     P.d0T = d + od0T; P.tv_theta = d + otvt; P.tv_minv = d + otvm; P.tv_rows = d + otvr;
     P.has_tv = tv_theta.empty() ? 0 : 1; P.n_tpre = tv_theta.empty() ? 0 : ntc - nt;
     P.d0 = d + od0; P.has_d0 = d0.empty() ? 0 : 1; P.n_d0r = (int)d0_rows.size(); P.n_d0c = (int)d0_cols.size();
@@ -507,7 +517,7 @@ int mpc_destroy(mpc_handle *h) {
     (void)hipSetDevice(h->device);
     (void)hipStreamSynchronize(h->stream);
     for (DevBuf *b : {&h->blocks, &h->iblocks, &h->frontier, &h->children, &h->status, &h->pruned, &h->pruned_new, &h->flag, &h->pos, &h->opt_list,
-                      &h->childmask, &h->count, &h->offset, &h->recd, &h->reci, &h->ctr, &h->scratch, &h->sums, &h->retry_list, &h->pf_dev, &h->pr2_dev, &h->headd, &h->headi, &h->epool, &h->facet_flags, &h->dict_d[0], &h->dict_d[1], &h->dict_i[0], &h->dict_i[1],
+                      &h->childmask, &h->count, &h->offset, &h->recd, &h->reci, &h->ctr, &h->scratch, &h->sums, &h->retry_list, &h->pf_dev, &h->pr2_dev, &h->headd, &h->headi, &h->epool, &h->facet_flags, &h->kkt_code, &h->kkt_L, &h->dict_d[0], &h->dict_d[1], &h->dict_i[0], &h->dict_i[1],
                       &h->dict_stored[0], &h->dict_stored[1], &h->parent_slot, &h->parent_slot_next}) b->release();
     for (HostBuf *b : {&h->st_list, &h->st_status, &h->st_hd, &h->st_hi, &h->st_pool, &h->st_fxd, &h->st_fxi, &h->st_rlist}) b->release();
     for (auto &e : h->ev) if (e) (void)hipEventDestroy(e);
@@ -681,18 +691,31 @@ int mpc_level_run(mpc_handle *h, int32_t gen_children, mpc_level_stats *stats) {
             return MPC_OK;
         };
         // verdict
+        const uint8_t *kkc = nullptr;
+        const double *kkl = nullptr;
         HIP_TRY(h, hipEventRecord(h->ev[0], st));
         if (h->fast && !h->force_v1) {
             const int32_t *fr = h->frontier.as<int32_t>();
             uint8_t *stp = h->status.as<uint8_t>();
             const DevProblem *pf = h->pf_dev.as<DevProblem>();
-            {   // KKT + two-stage theta LP
+            // KKT solves, one thread per candidate (Schur/Cholesky mode, cardinality 1..8); the wave kernels fetch the result
+            if (h->kkt_mode == 0 && k >= 1 && k <= 8 && !h->no_kkt_thread) {
+                HIP_TRY(h, h->kkt_code.ensure(nn, st));
+                HIP_TRY(h, h->kkt_L.ensure(nn * (size_t)k * (h->n_t + 1) * sizeof(double), st));
+                kkc = h->kkt_code.as<uint8_t>(); kkl = h->kkt_L.as<double>();
+                const dim3 g((unsigned)blocks256), b(256);
+#define MPC_LAUNCH_KKT(K_) case K_: hipLaunchKernelGGL((k_kkt_thread<K_>), g, b, 0, st, pf, fr, n, h->kkt_code.as<uint8_t>(), h->kkt_L.as<double>()); break
+                switch (k) { MPC_LAUNCH_KKT(1); MPC_LAUNCH_KKT(2); MPC_LAUNCH_KKT(3); MPC_LAUNCH_KKT(4); MPC_LAUNCH_KKT(5); MPC_LAUNCH_KKT(6); MPC_LAUNCH_KKT(7); MPC_LAUNCH_KKT(8); }
+#undef MPC_LAUNCH_KKT
+                HIP_TRY(h, hipGetLastError());
+            }
+            {   // two-stage theta LP
                 const dim3 g((unsigned)std::min<long long>(n, h->grid_f)), b(64);
                 switch (h->fast_t) {
-                    case 0: hipLaunchKernelGGL((k_theta2<4, 1>), g, b, h->lds_f, st, pf, fr, n, k, stp, ctr); break;
-                    case 1: hipLaunchKernelGGL((k_theta2<4, 2>), g, b, h->lds_f, st, pf, fr, n, k, stp, ctr); break;
-                    case 2: hipLaunchKernelGGL((k_theta2<10, 1>), g, b, h->lds_f, st, pf, fr, n, k, stp, ctr); break;
-                    default: hipLaunchKernelGGL((k_theta2<10, 2>), g, b, h->lds_f, st, pf, fr, n, k, stp, ctr); break;
+                    case 0: hipLaunchKernelGGL((k_theta2<4, 1>), g, b, h->lds_f, st, pf, fr, n, k, stp, ctr, kkc, kkl); break;
+                    case 1: hipLaunchKernelGGL((k_theta2<4, 2>), g, b, h->lds_f, st, pf, fr, n, k, stp, ctr, kkc, kkl); break;
+                    case 2: hipLaunchKernelGGL((k_theta2<10, 1>), g, b, h->lds_f, st, pf, fr, n, k, stp, ctr, kkc, kkl); break;
+                    default: hipLaunchKernelGGL((k_theta2<10, 2>), g, b, h->lds_f, st, pf, fr, n, k, stp, ctr, kkc, kkl); break;
                 }
                 HIP_TRY(h, hipGetLastError());
             }
@@ -779,7 +802,7 @@ int mpc_level_run(mpc_handle *h, int32_t gen_children, mpc_level_stats *stats) {
             const dim3 g((unsigned)std::min<long long>(n_opt, h->grid_r2)), b(64);
             const DevProblem *pr = h->pr2_dev.as<DevProblem>();
 #define MPC_LAUNCH_R2(NT_, SL_) hipLaunchKernelGGL((k_region2<NT_, SL_>), g, b, h->lds_r2, st, pr, h->frontier.as<int32_t>(), k, h->opt_list.as<int32_t>(), n_opt, \
-                                                   h->status.as<uint8_t>(), h->headd.as<double>(), h->headi.as<int32_t>(), h->fd, h->fi, h->epool.as<double>(), ctr)
+                                                   h->status.as<uint8_t>(), h->headd.as<double>(), h->headi.as<int32_t>(), h->fd, h->fi, h->epool.as<double>(), ctr, kkc, kkl)
             switch (h->fast_r) {
                 case 0: MPC_LAUNCH_R2(4, 1); break;
                 case 1: MPC_LAUNCH_R2(4, 2); break;
@@ -833,6 +856,10 @@ int mpc_level_run(mpc_handle *h, int32_t gen_children, mpc_level_stats *stats) {
         HIP_TRY(h, hipEventElapsedTime(&ms[0], h->ev[0], h->ev[1]));
         HIP_TRY(h, hipEventElapsedTime(&ms[1], h->ev[1], h->ev[2]));
         HIP_TRY(h, hipEventElapsedTime(&ms[2], h->ev[2], h->ev[3]));
+        if (h->debug_cycles)
+            std::fprintf(stderr, "[mpc] k=%d n=%lld cycles/cand: kkt %.0f theta %.0f (rows %.0f, stage2 %.0f) x %.0f region %.0f; pivots %.2f\n", k, n,
+                         host_ctr.cycles[0] / (double)n, host_ctr.cycles[1] / (double)n, host_ctr.cycles[4] / (double)n, host_ctr.cycles[5] / (double)n,
+                         host_ctr.cycles[2] / (double)n, host_ctr.cycles[3] / (double)n, host_ctr.pivots / (double)n);
         h->n_pruned_new = host_ctr.n_pruned_new;
         h->n_erows = host_ctr.e_rows;
         h->n_regions = (long long)host_ctr.status[ST_REGION];
