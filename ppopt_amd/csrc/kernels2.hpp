@@ -136,22 +136,40 @@ __device__ inline int kkt_fetch_or_solve(const DevProblem &P, int k, Smem &s, co
     return kkt_solve(P, k, s);
 }
 
+// hot read-only blocks of k_theta2, passed BY VALUE: the pointers are known to be global memory (global_load / s_load
+// instead of flat_load) and cost no descriptor reload inside the candidate loop.  All blocks are zero padded to the
+// kernel's compile-time NT so that the row build has no `t < n_t` guards:
+//   UVp      n_c x (NT+1)      [A Q^-1 c + b | A Q^-1 H + F | 0]
+//   tvp      NT*NT + NT        tv_minv (row stride NT) then tv_theta
+//   tv_rows  n_tpre x (NT+1)   the non-tight rows of A_t at the theta vertex
+struct ThetaArgs {
+    const double *W, *UVp, *tvp, *tv_rows;
+    int chunk;   // candidates taken from the work queue per atomic
+};
+
 template <int NT, int SLOTS>
 __global__ void __launch_bounds__(64, (NT * SLOTS >= 20 ? 3 : 4)) k_theta2(const DevProblem *__restrict__ Pg, const int32_t *__restrict__ cands, long long n, int k,
                                                     uint8_t *__restrict__ status, LevelCounters *__restrict__ ctr,
-                                                    const uint8_t *__restrict__ kkcode, const double *__restrict__ Lin) {
+                                                    const uint8_t *__restrict__ kkcode, const double *__restrict__ Lin, ThetaArgs ta) {
     // the program descriptor stays in memory (scalar loads on demand) instead of ~90 live SGPRs
     const DevProblem &P = *Pg;
     extern __shared__ __attribute__((aligned(16))) double smem[];
     Smem s = carve(P, smem);
-    const int lane = lane_id(), nt = P.n_t, nr = nt + 1, nv = P.n_x + P.n_t, e = P.n_eq;
+    constexpr int LS = NT + 1;
+    const int lane = lane_id(), nt = P.n_t, nr = nt + 1, e = P.n_eq, nc = P.n_c, mode = P.kkt_mode, npre = P.n_tpre;
+    // LDS: tv_minv | tv_theta | multipliers with padded row stride (zeros beyond n_t)
+    double *tvm = s.T, *tvt = s.T + NT * NT, *Lp = s.T + NT * NT + NT;
+    for (int idx = lane; idx < NT * NT + NT; idx += 64) s.T[idx] = ta.tvp[idx];
+    wave_sync();
     unsigned long long pivots = 0, n_retry = 0;
     long long cyc_kkt = 0, cyc_theta = 0, cyc_rows = 0, cyc_s2 = 0;
     for (;;) {
-        unsigned int c = 0;
-        if (lane == 0) c = atomicAdd(&ctr->work_verdict, 1u);
-        c = (unsigned)__builtin_amdgcn_readfirstlane((int)c);
-        if (c >= n) break;
+        unsigned int c0 = 0;
+        if (lane == 0) c0 = atomicAdd(&ctr->work_verdict, (unsigned)ta.chunk);
+        c0 = (unsigned)__builtin_amdgcn_readfirstlane((int)c0);
+        if (c0 >= n) break;
+        const unsigned c1 = (unsigned)min((long long)c0 + ta.chunk, n);
+      for (unsigned c = c0; c < c1; ++c) {
         const int nin = load_active_set(P, cands + (size_t)c * k, k, s);
         int st = -1;
         const long long t0 = clock64();
@@ -163,8 +181,13 @@ __global__ void __launch_bounds__(64, (NT * SLOTS >= 20 ? 3 : 4)) k_theta2(const
         else if (kk == 2) singular = true;
         else if (kk == 0) {
             // ---- theta-space two-stage LP, rows expressed at the vertex of {A_t theta <= b_t} ----------------------
+            for (int idx = lane; idx < k * LS; idx += 64) {
+                const int a = idx / LS, t = idx - a * LS;
+                Lp[idx] = t <= nt ? s.L[a * nr + t] : 0.0;
+            }
+            wave_sync();
             RegLp<NT + 2, SLOTS> lp;
-            const int nlam = k - e, npre = P.n_tpre, m = nlam + nin + npre;
+            const int nlam = k - e, m = nlam + nin + npre;
             lp.m = m; lp.iters = 0; lp.max_iter = 50 * (m + nt) + 100; lp.growth = 0.0;
             lp.alive = (nt >= 31 ? 0xfffffffeu : ((1u << (nt + 1)) - 2u));
             lp.cv = nt + m + lane - 1;
@@ -178,19 +201,30 @@ __global__ void __launch_bounds__(64, (NT * SLOTS >= 20 ? 3 : 4)) k_theta2(const
                 lp.kind[sl] = i < nlam ? RK_PASSIVE : (i < m ? RK_INEQ : RK_DEAD);
                 bool pre = false;
                 if (i < nlam) {
-                    h = s.L[(e + i) * nr];
+                    h = Lp[(e + i) * LS];
 #pragma unroll
-                    for (int t = 0; t < NT; ++t) if (t < nt) g[t] = -s.L[(e + i) * nr + 1 + t];
+                    for (int t = 0; t < NT; ++t) g[t] = -Lp[(e + i) * LS + 1 + t];
                 } else if (i < nlam + nin) {
                     const int ci = s.inact[i - nlam];
-                    if (P.kkt_mode == 0) {
-                        double acc[NT + 1];
+                    if (mode == 0) {
+                        // row = UV[ci] + sum_a W[ci, as[a]] * L[a]   (all loads issued up front)
+                        double acc[NT + 1], w[8];
+                        const double *Wrow = ta.W + (size_t)ci * nc;
 #pragma unroll
-                        for (int t = 0; t <= NT; ++t) acc[t] = t <= nt ? P.UV[ci * nr + t] : 0.0;
-                        for (int a = 0; a < k; ++a) {
-                            const double w = P.W[ci * P.n_c + s.as[a]];
+                        for (int a = 0; a < 8; ++a) { const int asv = s.as[a]; w[a] = Wrow[a < k ? asv : 0]; }
 #pragma unroll
-                            for (int t = 0; t <= NT; ++t) if (t <= nt) acc[t] = fma(w, s.L[a * nr + t], acc[t]);
+                        for (int t = 0; t <= NT; ++t) acc[t] = ta.UVp[ci * LS + t];
+#pragma unroll
+                        for (int a = 0; a < 8; ++a) {
+                            if (a < k) {
+#pragma unroll
+                                for (int t = 0; t <= NT; ++t) acc[t] = fma(w[a], Lp[a * LS + t], acc[t]);
+                            }
+                        }
+                        for (int a = 8; a < k; ++a) {
+                            const double wa = Wrow[s.as[a]];
+#pragma unroll
+                            for (int t = 0; t <= NT; ++t) acc[t] = fma(wa, Lp[a * LS + t], acc[t]);
                         }
                         h = acc[0];
 #pragma unroll
@@ -210,10 +244,9 @@ __global__ void __launch_bounds__(64, (NT * SLOTS >= 20 ? 3 : 4)) k_theta2(const
                     }
                 } else if (i < m) {
                     pre = true;
-                    const double *row = P.tv_rows + (size_t)(i - nlam - nin) * nr;
-                    lp.t[sl][0] = row[0];
+                    const double *row = ta.tv_rows + (size_t)(i - nlam - nin) * LS;
 #pragma unroll
-                    for (int t = 0; t < NT; ++t) lp.t[sl][1 + t] = t < nt ? row[1 + t] : 0.0;
+                    for (int t = 0; t <= NT; ++t) lp.t[sl][t] = row[t];
                 }
                 if (!pre) {
                     double mx = 0.0;
@@ -233,17 +266,19 @@ __global__ void __launch_bounds__(64, (NT * SLOTS >= 20 ? 3 : 4)) k_theta2(const
                         for (int t = 0; t < NT; ++t) g[t] *= sc;
                     }
                     // theta = theta_v - Minv sigma:  value at the vertex and coefficients of the tight-row slacks sigma
-                    double b0 = h;
+                    double b0 = h, cf[NT];
 #pragma unroll
-                    for (int t = 0; t < NT; ++t) if (t < nt) b0 = fma(-g[t], P.tv_theta[t], b0);
+                    for (int t = 0; t < NT; ++t) b0 = fma(-g[t], tvt[t], b0);
+#pragma unroll
+                    for (int j = 0; j < NT; ++j) cf[j] = 0.0;
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) {
+#pragma unroll
+                        for (int j = 0; j < NT; ++j) cf[j] = fma(g[t], tvm[t * NT + j], cf[j]);
+                    }
                     lp.t[sl][0] = b0;
 #pragma unroll
-                    for (int j = 0; j < NT; ++j) {
-                        double acc = 0.0;
-#pragma unroll
-                        for (int t = 0; t < NT; ++t) if (t < nt && j < nt) acc = fma(g[t], P.tv_minv[t * nt + j], acc);
-                        lp.t[sl][1 + j] = -acc;
-                    }
+                    for (int j = 0; j < NT; ++j) lp.t[sl][1 + j] = -cf[j];
                 }
                 lp.t[sl][NT + 1] = 0.0;
             }
@@ -268,6 +303,7 @@ __global__ void __launch_bounds__(64, (NT * SLOTS >= 20 ? 3 : 4)) k_theta2(const
         if (st < 0 && !retry) st = singular ? ST_NEEDX_SING : ST_NEEDX;  // feasibility still open: (x,theta) LP, k_x2
         if (retry) { st = ST_RETRY; n_retry++; }
         if (lane == 0) status[c] = (uint8_t)st;
+      }
     }
     if (lane == 0) {
         atomicAdd(&ctr->cycles[0], (unsigned long long)cyc_kkt); atomicAdd(&ctr->cycles[1], (unsigned long long)cyc_theta);

@@ -4,11 +4,15 @@
 // t[s][1..NC-1] = coefficients of the nonbasic columns (NC-1 slots for at most NC-2 variables: phase 1 puts its
 // artificial x0 into whichever slot is free).  All column loops
 // are unrolled at compile time (NC is a template parameter) so every tableau entry is a named register.
-//   * the pivot row is broadcast column by column with v_readlane (uniform lane index) -> SGPRs
-//   * the pivot column of each lane's row is extracted with a uniform select chain
-//   * pricing reads the cost row out of ONE lane with v_readlane: no cross-lane reduction at all
-//   * the ratio test is the only cross-lane step: three DPP (row_shr) reductions finished with v_readlane
-//   * a deleted column is a cleared bit in a uniform mask; the var id of column j lives in lane j of `cv`
+//   * a row is an LLVM vector (8 or 16 doubles; two halves for 32 columns): a column chosen at run time is read or
+//     written with ONE indexed VGPR access (s_set_gpr_idx) because the index is wave-uniform -- no select chains
+//   * the pivot row is scaled inside its own lane, then broadcast column by column with v_readlane -> SGPRs; every other
+//     lane does one fma per column (the pivot lane's multiplier is forced to 0, column q is first replaced by e_r)
+//   * pricing is a scan over the cost row inside the lane that owns it, one v_readlane returns the column
+//   * the ratio test is the only cross-lane step: two f64 DPP (row_shr) reductions + ballots, one f32 reduction for the
+//     growth monitor; reciprocals are v_rcp_f64 + two Newton steps instead of IEEE divisions
+//   * a deleted column is a cleared bit in a uniform mask AND zeroed in every row, so pricing needs no liveness test;
+//     the var id of column j lives in lane j of `cv`
 // The LPs solved here have no free variables: the caller supplies dictionaries that are already expressed at a vertex
 // (theta-space LPs at a vertex of {A_t theta <= b_t}; the (x,theta) LP at the program's pre-crashed vertex), so only
 // "equality rows leave the basis", phase 1 (x0 method) and phase 2 are needed.  Pivot rules, tolerances and the
@@ -70,97 +74,178 @@ __device__ __forceinline__ unsigned long long f64_key(double v) {
     return (b & 0x8000000000000000ull) ? ~b : (b | 0x8000000000000000ull);
 }
 
+__device__ __forceinline__ double fast_rcp(double x) {
+    double r = __builtin_amdgcn_rcp(x);
+    double e = fma(-x, r, 1.0);
+    r = fma(r, e, r);
+    e = fma(-x, r, 1.0);
+    return fma(r, e, r);
+}
+__device__ __forceinline__ float dpp_wave_max_f32(float v) {
+    v = fmaxf(v, __int_as_float(dpp_i32<0x111>(__float_as_int(v)))); v = fmaxf(v, __int_as_float(dpp_i32<0x112>(__float_as_int(v))));
+    v = fmaxf(v, __int_as_float(dpp_i32<0x114>(__float_as_int(v)))); v = fmaxf(v, __int_as_float(dpp_i32<0x118>(__float_as_int(v))));
+    const int b = __float_as_int(v);
+    return fmaxf(fmaxf(__int_as_float(__builtin_amdgcn_readlane(b, 15)), __int_as_float(__builtin_amdgcn_readlane(b, 31))),
+                 fmaxf(__int_as_float(__builtin_amdgcn_readlane(b, 47)), __int_as_float(__builtin_amdgcn_readlane(b, 63))));
+}
+__device__ __forceinline__ int dpp_wave_min_i32(int v) {
+    v = min(v, dpp_i32<0x111>(v)); v = min(v, dpp_i32<0x112>(v)); v = min(v, dpp_i32<0x114>(v)); v = min(v, dpp_i32<0x118>(v));
+    return min(min(__builtin_amdgcn_readlane(v, 15), __builtin_amdgcn_readlane(v, 31)), min(__builtin_amdgcn_readlane(v, 47), __builtin_amdgcn_readlane(v, 63)));
+}
+
+template <int W> struct RowVec;
+template <> struct RowVec<8> { typedef double type __attribute__((ext_vector_type(8))); };
+template <> struct RowVec<16> { typedef double type __attribute__((ext_vector_type(16))); };
+
+// One tableau row in VGPRs.  operator[] with a compile-time index (unrolled loops) is a plain register; getq / setq take
+// a WAVE-UNIFORM run-time index.
+template <int NC>
+struct RegRow {
+    static constexpr int W = NC <= 8 ? 8 : 16;
+    static constexpr int H = (NC + W - 1) / W;
+    static_assert(H <= 2, "at most 32 columns");
+    typename RowVec<W>::type v[H];
+    __device__ __forceinline__ double get(int j) const { return v[j / W][j % W]; }
+    __device__ __forceinline__ void set(int j, double x) { v[j / W][j % W] = x; }
+    __device__ __forceinline__ double getq(int q) const {
+        if (H == 1) return v[0][q];
+        return q < W ? v[0][q] : v[H - 1][q - W];
+    }
+    __device__ __forceinline__ void setq(int q, double x) {
+        if (H == 1) v[0][q] = x;
+        else if (q < W) v[0][q] = x;
+        else v[H - 1][q - W] = x;
+    }
+    struct Ref {
+        RegRow &row; int j;
+        __device__ __forceinline__ operator double() const { return row.get(j); }
+        __device__ __forceinline__ Ref &operator=(double x) { row.set(j, x); return *this; }
+    };
+    __device__ __forceinline__ Ref operator[](int j) { return Ref{*this, j}; }
+    __device__ __forceinline__ double operator[](int j) const { return get(j); }
+};
+
 template <int NC, int SLOTS>
 struct RegLp {
-    static constexpr int XC = NC - 1;  // column reserved for x0
-    double t[SLOTS][NC];
+    RegRow<NC> t[SLOTS];
     int kind[SLOTS];
     int var[SLOTS];
     int cv;           // lane j holds the variable id of column j
-    unsigned alive;   // uniform bit mask of live columns (bits 1..NC-1)
+    unsigned alive;   // uniform bit mask of live columns (bits 1..NC-1); dead columns are zero in every row
     int m;            // rows in use (row index = lane + 64*slot)
     int iters, max_iter;
     double growth;
 
-    __device__ __forceinline__ double col(int s, int q) const {
-        double f = 0.0;
-#pragma unroll
-        for (int j = 1; j < NC; ++j) f = (j == q) ? t[s][j] : f;
-        return f;
-    }
     __device__ __forceinline__ double row_entry(int r, const double (&c)[SLOTS]) const {
         const int rl = r & 63;
         if (SLOTS == 1) return readlane_f64(c[0], rl);
         return readlane_f64((r >> 6) ? c[SLOTS - 1] : c[0], rl);
     }
+    __device__ __forceinline__ int row_entry_i(int r, const int (&c)[SLOTS]) const {
+        const int rl = r & 63;
+        if (SLOTS == 1) return __builtin_amdgcn_readlane(c[0], rl);
+        return __builtin_amdgcn_readlane((r >> 6) ? c[SLOTS - 1] : c[0], rl);
+    }
 
-    __device__ __forceinline__ void pivot(int r_in, int q_in) {
-        const int lane = lane_id(), r = uni(r_in), q = uni(q_in);
-        double f[SLOTS];
+    // Pivot on (r, q): f = column q before the pivot, inv = 1 / f[r].
+    __device__ __forceinline__ void pivot_core(int r, int q, const double (&f)[SLOTS], double inv) {
+        const int lane = lane_id();
+        double fz[SLOTS];
 #pragma unroll
-        for (int s = 0; s < SLOTS; ++s) f[s] = col(s, q);
-        const double inv = 1.0 / row_entry(r, f);
+        for (int s = 0; s < SLOTS; ++s) {
+            const bool is_r = (lane + 64 * s) == r;
+            t[s].setq(q, is_r ? 1.0 : 0.0);          // column q := e_r; the generic update then yields inv / -f*inv
+            fz[s] = is_r ? 0.0 : f[s];               // the pivot lane's own row is only scaled
+            if (is_r) {
 #pragma unroll
-        for (int j = 0; j < NC; ++j) {
-            double cj[SLOTS];
+                for (int j = 0; j < NC; ++j) t[s].set(j, t[s].get(j) * inv);
+            }
+        }
+        if (SLOTS == 1 || (r >> 6) == 0) {
 #pragma unroll
-            for (int s = 0; s < SLOTS; ++s) cj[s] = t[s][j];
-            const double trj = row_entry(r, cj) * inv;
+            for (int j = 0; j < NC; ++j) {
+                const double trj = readlane_f64(t[0].get(j), r & 63);
 #pragma unroll
-            for (int s = 0; s < SLOTS; ++s) {
-                const bool is_r = (lane + 64 * s) == r;
-                double nv;
-                if (j == q) nv = is_r ? inv : -f[s] * inv;
-                else nv = is_r ? trj : fma(-f[s], trj, t[s][j]);
-                t[s][j] = nv;
+                for (int s = 0; s < SLOTS; ++s) t[s].set(j, fma(-fz[s], trj, t[s].get(j)));
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < NC; ++j) {
+                const double trj = readlane_f64(t[SLOTS - 1].get(j), r & 63);
+#pragma unroll
+                for (int s = 0; s < SLOTS; ++s) t[s].set(j, fma(-fz[s], trj, t[s].get(j)));
             }
         }
         const int vq = __builtin_amdgcn_readlane(cv, q);
-        int vr = 0;
-#pragma unroll
-        for (int s = 0; s < SLOTS; ++s) if ((r >> 6) == s) vr = __builtin_amdgcn_readlane(var[s], r & 63);
+        const int vr = row_entry_i(r, var);
 #pragma unroll
         for (int s = 0; s < SLOTS; ++s) if ((lane + 64 * s) == r) var[s] = vq;
         if (lane == q) cv = vr;
         iters++;
     }
+    __device__ __forceinline__ void pivot(int r_in, int q_in) {
+        const int r = uni(r_in), q = uni(q_in);
+        double f[SLOTS];
+#pragma unroll
+        for (int s = 0; s < SLOTS; ++s) f[s] = t[s].getq(q);
+        pivot_core(r, q, f, fast_rcp(row_entry(r, f)));
+    }
 
-    __device__ __forceinline__ void drop_col(int q) { alive = (unsigned)uni((int)(alive & ~(1u << q))); }
+    __device__ __forceinline__ void drop_col(int q_in) {
+        const int q = uni(q_in);
+        alive = (unsigned)uni((int)(alive & ~(1u << q)));
+#pragma unroll
+        for (int s = 0; s < SLOTS; ++s) t[s].setq(q, 0.0);
+    }
 
     __device__ __forceinline__ void set_kind(int r, int k) {
         const int lane = lane_id();
 #pragma unroll
         for (int s = 0; s < SLOTS; ++s) if ((lane + 64 * s) == r) kind[s] = k;
     }
-    __device__ __forceinline__ int get_kind(int r) const {
-        int k = 0;
-#pragma unroll
-        for (int s = 0; s < SLOTS; ++s) if ((r >> 6) == s) k = __builtin_amdgcn_readlane(kind[s], r & 63);
-        return k;
-    }
+    __device__ __forceinline__ int get_kind(int r) const { return row_entry_i(r, kind); }
     __device__ __forceinline__ double beta(int r) const {
         double c0[SLOTS];
 #pragma unroll
-        for (int s = 0; s < SLOTS; ++s) c0[s] = t[s][0];
+        for (int s = 0; s < SLOTS; ++s) c0[s] = t[s].get(0);
         return row_entry(r, c0);
     }
 
-    // largest |entry| > TOL_PIV of row r over the live columns (ties: lowest column); -1 if none
+    // largest |entry| > TOL_PIV of row r (ties: lowest column); -1 if none.  Scan inside the owning lane.
     __device__ __forceinline__ int best_col(int r_in) const {
         const int r = uni(r_in);
-        const unsigned alive = (unsigned)uni((int)this->alive);
-        int q = -1;
-        double best = TOL_PIV;
+        int q[SLOTS];
 #pragma unroll
-        for (int j = 1; j < NC; ++j) {
-            if (!((alive >> j) & 1u)) continue;
-            double cj[SLOTS];
+        for (int s = 0; s < SLOTS; ++s) {
+            q[s] = -1;
+            double best = TOL_PIV;
 #pragma unroll
-            for (int s = 0; s < SLOTS; ++s) cj[s] = t[s][j];
-            const double a = fabs(row_entry(r, cj));
-            if (a > best) { best = a; q = j; }
+            for (int j = 1; j < NC; ++j) {
+                const double a = fabs(t[s].get(j));
+                if (a > best) { best = a; q[s] = j; }
+            }
         }
-        return q;
+        return row_entry_i(r, q);
+    }
+
+    // Dantzig pricing of row `crow` (phase 1: the row of x0, minimise; else the cost row): scan inside the owning lane.
+    // P1: entries > TOL_COST are improving; else entries < -TOL_COST.  Returns the column or -1; *mask = improving columns.
+    template <bool P1>
+    __device__ __forceinline__ int price(int crow, unsigned *mask) const {
+        int q[SLOTS], mk[SLOTS];
+#pragma unroll
+        for (int s = 0; s < SLOTS; ++s) {
+            q[s] = -1; mk[s] = 0;
+            double best = TOL_COST;
+#pragma unroll
+            for (int j = 1; j < NC; ++j) {
+                const double g = P1 ? t[s].get(j) : -t[s].get(j);
+                if (g > TOL_COST) mk[s] |= (1 << j);
+                if (g > best) { best = g; q[s] = j; }
+            }
+        }
+        *mask = (unsigned)row_entry_i(crow, mk);
+        return row_entry_i(crow, q);
     }
 
     // primal simplex; phase1_row >= 0: minimise x0 (basic in that row), else minimise the RK_COST row `cost_row`.
@@ -173,50 +258,42 @@ struct RegLp {
         for (;;) {
             if (iters > max_iter) return 3;
             const bool bland = deg > DEG_SWITCH;
-            const unsigned alive = (unsigned)uni((int)this->alive);
             const int crow = uni(phase1_row >= 0 ? phase1_row : cost_row);
-            const double sgn = phase1_row >= 0 ? -1.0 : 1.0;
             if (phase1_row >= 0 && beta(phase1_row) <= TOL_FEAS) return 0;
-            // pricing: the cost row lives in one lane -> uniform scan with v_readlane
-            int q = -1, best_var = 0;
-            double best = -TOL_COST;
-#pragma unroll
-            for (int j = 1; j < NC; ++j) {
-                if (!((alive >> j) & 1u)) continue;
-                double cj[SLOTS];
-#pragma unroll
-                for (int s = 0; s < SLOTS; ++s) cj[s] = t[s][j];
-                const double d = sgn * row_entry(crow, cj);
-                if (d < -TOL_COST) {
-                    if (bland) {
-                        const int v = __builtin_amdgcn_readlane(cv, j);
-                        if (q < 0 || v < best_var) { q = j; best_var = v; }
-                    } else if (d < best) { best = d; q = j; }
-                }
-            }
+            unsigned improving = 0;
+            int q = phase1_row >= 0 ? price<true>(crow, &improving) : price<false>(crow, &improving);
             if (q < 0) return 0;
+            if (bland) {   // smallest variable id among the improving columns
+                const bool mine = lane >= 1 && lane < NC && ((improving >> lane) & 1u);
+                const int vmin = dpp_wave_min_i32(mine ? cv : 0x7fffffff);
+                q = __ffsll((long long)__ballot(mine && cv == vmin)) - 1;
+            }
+            q = uni(q);
             // ratio test (Harris two-pass; textbook + Bland while stalled)
             double a[SLOTS], ratio[SLOTS];
             bool elig[SLOTS];
-            double colmax = 0.0, tmax = INFINITY;
+            float cmf = 0.0f;
+            double tmax = INFINITY;
 #pragma unroll
             for (int s = 0; s < SLOTS; ++s) {
                 const int i = lane + 64 * s;
-                a[s] = col(s, q);
+                a[s] = t[s].getq(q);
                 const bool used = i < m && kind[s] != RK_DEAD;
-                if (used) colmax = fmax(colmax, fabs(a[s]));
+                if (used) cmf = fmaxf(cmf, fabsf((float)a[s]));
                 elig[s] = used && (kind[s] == RK_INEQ || kind[s] == RK_X0) && a[s] > TOL_PIV;
                 ratio[s] = 0.0;
                 if (elig[s]) {
-                    const double b0 = fmax(t[s][0], 0.0);
-                    ratio[s] = b0 / a[s];
-                    tmax = fmin(tmax, (b0 + HARRIS_DELTA) / a[s]);
+                    const double b0 = fmax(t[s].get(0), 0.0), ia = fast_rcp(a[s]);
+                    ratio[s] = b0 * ia;
+                    tmax = fmin(tmax, (b0 + HARRIS_DELTA) * ia);
                 }
             }
-            colmax = dpp_wave_max(colmax);
+            const float colmax = dpp_wave_max_f32(cmf);
             tmax = dpp_wave_min(tmax);
             if (tmax == INFINITY) return 2;
-            int r;
+            int r = -1;
+            bool leaving_x0 = false;
+            double rpiv = 0.0;
             if (bland) {
                 double rm = INFINITY;
 #pragma unroll
@@ -230,23 +307,38 @@ struct RegLp {
                         if (key_better(kk, lane + 64 * s, key, idx)) { key = kk; idx = lane + 64 * s; }
                     }
                 r = dpp_wave_argmax(key, idx);
+                if (r < 0) return 2;
+                rpiv = row_entry(r, a);
+                leaving_x0 = get_kind(r) == RK_X0;
             } else {
-                unsigned long long key = 0; int idx = -1;
+                // among the rows inside the Harris bound: the x0 row if it is one of them, else the largest pivot
+                bool pass[SLOTS];
 #pragma unroll
-                for (int s = 0; s < SLOTS; ++s)
-                    if (elig[s] && !(ratio[s] > tmax)) {
-                        // a > 0: its bit pattern orders like the value; x0 row first
-                        const unsigned long long kk = (unsigned long long)__double_as_longlong(a[s]) | ((unsigned long long)(kind[s] == RK_X0) << 63);
-                        if (key_better(kk, lane + 64 * s, key, idx)) { key = kk; idx = lane + 64 * s; }
+                for (int s = 0; s < SLOTS; ++s) pass[s] = elig[s] && !(ratio[s] > tmax);
+#pragma unroll
+                for (int s = SLOTS - 1; s >= 0; --s) {
+                    const unsigned long long bx = __ballot(pass[s] && kind[s] == RK_X0);
+                    if (bx) { r = __ffsll((long long)bx) - 1 + 64 * s; leaving_x0 = true; }
+                }
+                if (leaving_x0) rpiv = row_entry(r, a);
+                else {
+                    double am = 0.0;
+#pragma unroll
+                    for (int s = 0; s < SLOTS; ++s) if (pass[s]) am = fmax(am, a[s]);
+                    rpiv = dpp_wave_max(am);
+#pragma unroll
+                    for (int s = SLOTS - 1; s >= 0; --s) {
+                        const unsigned long long br = __ballot(pass[s] && a[s] == rpiv);
+                        if (br) r = __ffsll((long long)br) - 1 + 64 * s;
                     }
-                r = dpp_wave_argmax(key, idx);
+                    if (r < 0) return 2;
+                }
             }
-            if (r < 0) return 2;
-            const double rpiv = row_entry(r, a), rmin = row_entry(r, ratio);
-            growth = fmax(growth, colmax / rpiv);
+            r = uni(r);
+            const double rmin = row_entry(r, ratio), inv = fast_rcp(rpiv);
+            growth = fmax(growth, (double)(colmax * (float)inv));
             deg = (rmin <= 0.0) ? deg + 1 : 0;
-            const bool leaving_x0 = get_kind(r) == RK_X0;
-            pivot(r, q);
+            pivot_core(r, q, a, inv);
             if (leaving_x0) { set_kind(r, RK_INEQ); if (drop_on_leave) drop_col(q); return 4; }
         }
     }
@@ -271,26 +363,30 @@ struct RegLp {
     // Phase 1 on the current dictionary (re-entrant).  LP_OPTIMAL (feasible) / LP_INFEASIBLE / LP_ITERLIMIT.
     __device__ __forceinline__ int phase1() {
         const int lane = lane_id();
-        unsigned long long key = 0; int idx = -1;
+        // most negative basic value (ties: lowest row)
+        bool neg[SLOTS];
+        double vmin = INFINITY;
 #pragma unroll
-        for (int s = 0; s < SLOTS; ++s)
-            if (lane + 64 * s < m && kind[s] == RK_INEQ && t[s][0] < -TOL_FEAS) {
-                const unsigned long long kk = f64_key(-t[s][0]);  // most negative value = largest key
-                if (key_better(kk, lane + 64 * s, key, idx)) { key = kk; idx = lane + 64 * s; }
-            }
-        const int r = dpp_wave_argmax(key, idx);
-        if (r < 0) return LP_OPTIMAL;
+        for (int s = 0; s < SLOTS; ++s) {
+            neg[s] = lane + 64 * s < m && kind[s] == RK_INEQ && t[s].get(0) < -TOL_FEAS;
+            if (neg[s]) vmin = fmin(vmin, t[s].get(0));
+        }
+        vmin = dpp_wave_min(vmin);
+        if (vmin == INFINITY) return LP_OPTIMAL;
+        int r = -1;
+#pragma unroll
+        for (int s = SLOTS - 1; s >= 0; --s) {
+            const unsigned long long br = __ballot(neg[s] && t[s].get(0) == vmin);
+            if (br) r = __ffsll((long long)br) - 1 + 64 * s;
+        }
+        r = uni(r);
         // x0 takes a free column slot.  (Not a fixed one: when x0 left the basis in an earlier phase 1 it was deleted from
         // the column it had moved to, and the slot it first entered through now holds a live slack.)
         const unsigned al = (unsigned)uni((int)alive);
-        const int xc = __ffs((int)(~al & ~1u & ((NC >= 32 ? 0u : (1u << NC)) - 1u))) - 1;
+        const int xc = uni(__ffs((int)(~al & ~1u & ((NC >= 32 ? 0u : (1u << NC)) - 1u))) - 1);
         alive = al | (1u << xc);
 #pragma unroll
-        for (int s = 0; s < SLOTS; ++s) {
-            const double v = (lane + 64 * s < m && kind[s] == RK_INEQ) ? -1.0 : 0.0;
-#pragma unroll
-            for (int j = 1; j < NC; ++j) t[s][j] = (j == xc) ? v : t[s][j];
-        }
+        for (int s = 0; s < SLOTS; ++s) t[s].setq(xc, (lane + 64 * s < m && kind[s] == RK_INEQ) ? -1.0 : 0.0);
         if (lane == xc) cv = X0_VAR;
         pivot(r, xc);
         return drive_to_zero(r);

@@ -92,7 +92,8 @@ struct mpc_handle {
     long long n_needx = 0;
     DevProblem Pf{};          // view for k_verdict2 (small LDS layout: no tableau)
     int lds_f = 0, grid_f = 0;
-    DevBuf retry_list, pf_dev, pr2_dev, headd, headi, epool, facet_flags, kkt_code, kkt_L;
+    DevBuf retry_list, pf_dev, pr2_dev, headd, headi, epool, facet_flags, kkt_code, kkt_L, theta_blocks;
+    ThetaArgs targs{};
     // (x,theta) dictionary cache: [0]/[1] ping-pong between the level being read (parents) and the level being written
     DevBuf dict_d[2], dict_i[2], dict_stored[2], parent_slot, parent_slot_next;
     int dict_cur = 0;
@@ -484,7 +485,25 @@ int mpc_create(const mpc_problem *p, int32_t device, void *stream, mpc_handle **
             h->fast = 1;
             h->fast_t = tsel * 2 + (slots_t - 1);
             h->fast_x = xsel * 2 + (slots_x - 1);
-            const Layout lf = make_layout(2, size_K, size_L, 0, mode == 1 ? size_X : 0, kmax, nc, 2, 2, 2);
+            // zero-padded blocks of k_theta2 (ThetaArgs) for its compile-time NT
+            const int NTP = tsel == 0 ? 4 : 10, LS = NTP + 1;
+            {
+                std::vector<double> tb;
+                const size_t oUVp = tb.size(); tb.resize(tb.size() + (size_t)nc * LS, 0.0);
+                if (mode == 0) for (int i = 0; i < nc; ++i) for (int t = 0; t < nr; ++t) tb[oUVp + (size_t)i * LS + t] = UV[(size_t)i * nr + t];
+                const size_t otvp = tb.size(); tb.resize(tb.size() + (size_t)NTP * NTP + NTP, 0.0);
+                for (int t = 0; t < nt; ++t) for (int j = 0; j < nt; ++j) tb[otvp + (size_t)t * NTP + j] = tv_minv[(size_t)t * nt + j];
+                for (int t = 0; t < nt; ++t) tb[otvp + (size_t)NTP * NTP + t] = tv_theta[t];
+                const int npre = ntc - nt;
+                const size_t otvr = tb.size(); tb.resize(tb.size() + (size_t)std::max(npre, 1) * LS, 0.0);
+                for (int i = 0; i < npre; ++i) for (int t = 0; t < nr; ++t) tb[otvr + (size_t)i * LS + t] = tv_rows[(size_t)i * nr + t];
+                HIP_TRY(nullptr, h->theta_blocks.ensure(tb.size() * sizeof(double), h->stream));
+                HIP_TRY(nullptr, hipMemcpyAsync(h->theta_blocks.p, tb.data(), tb.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
+                HIP_TRY(nullptr, hipStreamSynchronize(h->stream));
+                const double *tbd = h->theta_blocks.as<double>();
+                h->targs.W = P.W; h->targs.UVp = tbd + oUVp; h->targs.tvp = tbd + otvp; h->targs.tv_rows = tbd + otvr; h->targs.chunk = 1;
+            }
+            const Layout lf = make_layout(NTP * NTP + NTP + kmax * LS, size_K, size_L, 0, mode == 1 ? size_X : 0, kmax, nc, 2, 2, 2);
             h->Pf = P; apply_layout(h->Pf, lf); h->lds_f = lf.bytes;
             h->grid_f = h->n_cu * std::min(16, waves_per_cu(h->lds_f));
             HIP_TRY(nullptr, h->pf_dev.ensure(sizeof(DevProblem), h->stream));
@@ -517,7 +536,7 @@ int mpc_destroy(mpc_handle *h) {
     (void)hipSetDevice(h->device);
     (void)hipStreamSynchronize(h->stream);
     for (DevBuf *b : {&h->blocks, &h->iblocks, &h->frontier, &h->children, &h->status, &h->pruned, &h->pruned_new, &h->flag, &h->pos, &h->opt_list,
-                      &h->childmask, &h->count, &h->offset, &h->recd, &h->reci, &h->ctr, &h->scratch, &h->sums, &h->retry_list, &h->pf_dev, &h->pr2_dev, &h->headd, &h->headi, &h->epool, &h->facet_flags, &h->kkt_code, &h->kkt_L, &h->dict_d[0], &h->dict_d[1], &h->dict_i[0], &h->dict_i[1],
+                      &h->childmask, &h->count, &h->offset, &h->recd, &h->reci, &h->ctr, &h->scratch, &h->sums, &h->retry_list, &h->pf_dev, &h->pr2_dev, &h->headd, &h->headi, &h->epool, &h->facet_flags, &h->kkt_code, &h->kkt_L, &h->theta_blocks, &h->dict_d[0], &h->dict_d[1], &h->dict_i[0], &h->dict_i[1],
                       &h->dict_stored[0], &h->dict_stored[1], &h->parent_slot, &h->parent_slot_next}) b->release();
     for (HostBuf *b : {&h->st_list, &h->st_status, &h->st_hd, &h->st_hi, &h->st_pool, &h->st_fxd, &h->st_fxi, &h->st_rlist}) b->release();
     for (auto &e : h->ev) if (e) (void)hipEventDestroy(e);
@@ -710,12 +729,14 @@ int mpc_level_run(mpc_handle *h, int32_t gen_children, mpc_level_stats *stats) {
                 HIP_TRY(h, hipGetLastError());
             }
             {   // two-stage theta LP
-                const dim3 g((unsigned)std::min<long long>(n, h->grid_f)), b(64);
+                ThetaArgs ta = h->targs;
+                ta.chunk = (int)std::max<long long>(1, std::min<long long>(16, n / ((long long)h->grid_f * 8)));
+                const dim3 g((unsigned)std::min<long long>((n + ta.chunk - 1) / ta.chunk, h->grid_f)), b(64);
                 switch (h->fast_t) {
-                    case 0: hipLaunchKernelGGL((k_theta2<4, 1>), g, b, h->lds_f, st, pf, fr, n, k, stp, ctr, kkc, kkl); break;
-                    case 1: hipLaunchKernelGGL((k_theta2<4, 2>), g, b, h->lds_f, st, pf, fr, n, k, stp, ctr, kkc, kkl); break;
-                    case 2: hipLaunchKernelGGL((k_theta2<10, 1>), g, b, h->lds_f, st, pf, fr, n, k, stp, ctr, kkc, kkl); break;
-                    default: hipLaunchKernelGGL((k_theta2<10, 2>), g, b, h->lds_f, st, pf, fr, n, k, stp, ctr, kkc, kkl); break;
+                    case 0: hipLaunchKernelGGL((k_theta2<4, 1>), g, b, h->lds_f, st, pf, fr, n, k, stp, ctr, kkc, kkl, ta); break;
+                    case 1: hipLaunchKernelGGL((k_theta2<4, 2>), g, b, h->lds_f, st, pf, fr, n, k, stp, ctr, kkc, kkl, ta); break;
+                    case 2: hipLaunchKernelGGL((k_theta2<10, 1>), g, b, h->lds_f, st, pf, fr, n, k, stp, ctr, kkc, kkl, ta); break;
+                    default: hipLaunchKernelGGL((k_theta2<10, 2>), g, b, h->lds_f, st, pf, fr, n, k, stp, ctr, kkc, kkl, ta); break;
                 }
                 HIP_TRY(h, hipGetLastError());
             }
