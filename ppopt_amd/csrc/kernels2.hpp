@@ -327,47 +327,78 @@ struct DictCache {
     double *cur_d; int32_t *cur_i; uint8_t *stored;   // cur_d == nullptr: do not store
     long long stride_d, stride_i;
     int dict_only;   // 1: the candidates are already decided (theta stage); only their dictionary is wanted for the children
+    int chunk;       // work items per queue atomic (<= 64)
 };
+#ifndef X2_WAVES
+#define X2_WAVES 3
+#endif
 template <int NXC, int SLOTS>
-__global__ void __launch_bounds__(64, (NXC * SLOTS >= 32 ? 2 : 3)) k_x2(const DevProblem *__restrict__ Pg, const int32_t *__restrict__ cands, int k,
+__global__ void __launch_bounds__(64, (NXC * SLOTS >= 32 ? X2_WAVES : 3)) k_x2(const DevProblem *__restrict__ Pg, const int32_t *__restrict__ cands, int k,
                                               const int32_t *__restrict__ list, int n_list, uint8_t *__restrict__ status,
                                               LevelCounters *__restrict__ ctr, DictCache dc) {
     const DevProblem &P = *Pg;
     const int lane = lane_id(), nv = P.n_x + P.n_t, e = P.n_eq;
+    const int mr = P.n_d0r, nc0 = P.n_d0c;
+    const double *d0T = P.d0T;
+    const int32_t *d0_rows = P.d0_rows, *d0_cols = P.d0_cols;
+    const bool dict_only = dc.dict_only != 0;
     unsigned long long pivots = 0, n_retry = 0, n_cached = 0;
     long long cyc_x = 0;
+    int sink = 0;
     for (;;) {
-        unsigned int w = 0;
-        if (lane == 0) w = atomicAdd(&ctr->work_x, 1u);
-        w = (unsigned)__builtin_amdgcn_readfirstlane((int)w);
-        if (w >= (unsigned)n_list) break;
-        const int c = list[w];
+        unsigned int w0 = 0;
+        if (lane == 0) w0 = atomicAdd(&ctr->work_x, (unsigned)dc.chunk);
+        w0 = (unsigned)__builtin_amdgcn_readfirstlane((int)w0);
+        if (w0 >= (unsigned)n_list) break;
+        const int cnt = min(dc.chunk, n_list - (int)w0);
+        // the chunk's bookkeeping in one batch: lane u holds candidate, parent slot and status of item u
+        int my_c = 0, my_ps = -1, my_st = 0;
+        if (lane < cnt) {
+            my_c = list[w0 + lane];
+            my_ps = dc.parent_slot ? dc.parent_slot[my_c] : -1;
+            my_st = status[my_c];
+        }
+      for (int u = 0; u < cnt; ++u) {
+        const int c = __builtin_amdgcn_readlane(my_c, u);
+        const int ps = __builtin_amdgcn_readlane(my_ps, u);
         const int32_t *as = cands + (size_t)c * k;
-        const bool singular = status[c] == ST_NEEDX_SING;
-        const bool dict_only = dc.dict_only != 0;
+        const bool singular = __builtin_amdgcn_readlane(my_st, u) == ST_NEEDX_SING;
         bool retry = false;
         int st = -1;
         const long long t2 = clock64();
         {
+            // the next item's dictionary is pulled towards the L2 while this one is solved (one 128-byte line per lane)
+            if (u + 1 < cnt) {
+                const int psn = __builtin_amdgcn_readlane(my_ps, u + 1);
+                if (psn >= 0) {
+                    const int32_t *nx = reinterpret_cast<const int32_t *>(dc.prev_d + (size_t)psn * dc.stride_d);
+                    const long long words = dc.stride_d * 2;
+                    if ((long long)lane * 32 < words) sink ^= nx[lane * 32];
+                    if ((long long)(lane + 64) * 32 < words) sink ^= nx[(lane + 64) * 32];
+                }
+            }
             // ---- (x,theta) feasibility from the pre-crashed vertex dictionary ------------------------------------------
             RegLp<NXC, SLOTS> lx;
-            const int mr = P.n_d0r, nc0 = P.n_d0c;
             lx.m = mr; lx.iters = 0; lx.max_iter = 50 * (mr + nc0) + 100; lx.growth = 0.0;
-            const int ps = dc.parent_slot ? dc.parent_slot[c] : -1;
             // one load path for both sources (two paths make the register allocator keep two tableaux): the parent's
             // dictionary from the cache (only the child's own, last, row is new) or the program's D0 (all rows new)
             const bool cached = ps >= 0;
-            const double *src_d = cached ? dc.prev_d + (size_t)ps * dc.stride_d : P.d0T;
-            const int32_t *src_i = cached ? dc.prev_i + (size_t)ps * dc.stride_i : P.d0_rows;
+            const double *src_d = cached ? dc.prev_d + (size_t)ps * dc.stride_d : d0T;
+            const int32_t *src_i = cached ? dc.prev_i + (size_t)ps * dc.stride_i : d0_rows;
             const int jmax = cached ? NXC - 1 : nc0, voff = cached ? 0 : nv;
             const int first = cached ? k - 1 : e;   // first active row that still has to be switched on
-            lx.alive = cached ? (unsigned)src_i[2 * mr + NXC] : (nc0 >= 31 ? 0xfffffffeu : ((1u << (nc0 + 1)) - 2u));
-            if (cached) { lx.growth = __hiloint2double(src_i[2 * mr + NXC + 1], src_i[2 * mr + NXC + 2]); n_cached++; }
             {
+                // cv and, behind it in the cached record, alive / growth: one load, fields taken out of their lanes
                 int cvv = -1;
-                if (cached) { if (lane < NXC) cvv = src_i[2 * mr + lane]; }
-                else if (lane >= 1 && lane <= nc0) cvv = nv + P.d0_cols[lane - 1];
-                lx.cv = cvv;
+                if (cached) { if (lane < NXC + 3) cvv = src_i[2 * mr + lane]; }
+                else if (lane >= 1 && lane <= nc0) cvv = nv + d0_cols[lane - 1];
+                lx.alive = nc0 >= 31 ? 0xfffffffeu : ((1u << (nc0 + 1)) - 2u);
+                if (cached) {
+                    lx.alive = (unsigned)__builtin_amdgcn_readlane(cvv, NXC);
+                    lx.growth = __hiloint2double(__builtin_amdgcn_readlane(cvv, NXC + 1), __builtin_amdgcn_readlane(cvv, NXC + 2));
+                    n_cached++;
+                }
+                lx.cv = lane < NXC ? cvv : -1;
             }
 #pragma unroll
             for (int sl = 0; sl < SLOTS; ++sl) {
@@ -427,7 +458,9 @@ __global__ void __launch_bounds__(64, (NXC * SLOTS >= 32 ? 2 : 3)) k_x2(const De
         cyc_x += clock64() - t2;
         if (retry) { st = ST_RETRY; n_retry++; }
         if (lane == 0 && !dict_only) status[c] = (uint8_t)st;
+      }
     }
+    if (sink == 0x5a5a5a5a) n_cached++;   // keeps the prefetch loads alive; practically never true
     if (lane == 0) {
         atomicAdd(&ctr->cycles[2], (unsigned long long)cyc_x);
         atomicAdd(&ctr->pivots, pivots); atomicAdd(&ctr->xtheta_fallbacks, n_retry); atomicAdd(&ctr->x_cached, n_cached);

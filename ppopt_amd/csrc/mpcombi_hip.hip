@@ -762,9 +762,12 @@ int mpc_level_run(mpc_handle *h, int32_t gen_children, mpc_level_stats *stats) {
                 dc.stored = h->dict_stored[h->dict_cur].as<uint8_t>();
                 h->storing = true;
             }
-            auto launch_x = [&](int n_items, const DictCache &d) -> int {
+            auto launch_x = [&](int n_items, const DictCache &d0) -> int {
                 HIP_TRY(h, hipMemsetAsync(&ctr->work_x, 0, sizeof(unsigned int), st));
-                const dim3 gg((unsigned)std::min<long long>(n_items, (long long)h->n_cu * 16)), bb(64);
+                DictCache d = d0;
+                const long long grid_x = (long long)h->n_cu * 16;
+                d.chunk = (int)std::max<long long>(1, std::min<long long>(16, n_items / (grid_x * 8)));
+                const dim3 gg((unsigned)std::min<long long>((n_items + d.chunk - 1) / d.chunk, grid_x)), bb(64);
                 const int32_t *ls = h->retry_list.as<int32_t>();
                 switch (h->fast_x) {
                     case 0: hipLaunchKernelGGL((k_x2<16, 1>), gg, bb, 0, st, pf, fr, k, ls, n_items, stp, ctr, d); break;
