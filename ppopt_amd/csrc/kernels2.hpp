@@ -140,7 +140,7 @@ __device__ inline int kkt_fetch_or_solve(const DevProblem &P, int k, Smem &s, co
 // instead of flat_load) and cost no descriptor reload inside the candidate loop.  All blocks are zero padded to the
 // kernel's compile-time NT so that the row build has no `t < n_t` guards:
 //   UVp      n_c x (NT+1)      [A Q^-1 c + b | A Q^-1 H + F | 0]
-//   tvp      NT*NT + NT        tv_minv (row stride NT) then tv_theta
+//   tvp      NT*NT + 3*NT      tv_minv (row stride NT), tv_theta, then the bounding box of {A_t theta <= b_t}: lo, hi
 //   tv_rows  n_tpre x (NT+1)   the non-tight rows of A_t at the theta vertex
 struct ThetaArgs {
     const double *W, *UVp, *tvp, *tv_rows;
@@ -158,11 +158,12 @@ __global__ void __launch_bounds__(64, (NT * SLOTS >= 20 ? 3 : 4)) k_theta2(const
     constexpr int LS = NT + 1;
     const int lane = lane_id(), nt = P.n_t, nr = nt + 1, e = P.n_eq, nc = P.n_c, mode = P.kkt_mode, npre = P.n_tpre;
     // LDS: tv_minv | tv_theta | multipliers with padded row stride (zeros beyond n_t)
-    double *tvm = s.T, *tvt = s.T + NT * NT, *Lp = s.T + NT * NT + NT;
-    for (int idx = lane; idx < NT * NT + NT; idx += 64) s.T[idx] = ta.tvp[idx];
+    double *tvm = s.T, *tvt = s.T + NT * NT, *blo = tvt + NT, *bhi = blo + NT, *Lp = s.T + NT * NT + 3 * NT;
+    for (int idx = lane; idx < NT * NT + 3 * NT; idx += 64) s.T[idx] = ta.tvp[idx];
     wave_sync();
     unsigned long long pivots = 0, n_retry = 0;
     long long cyc_kkt = 0, cyc_theta = 0, cyc_rows = 0, cyc_s2 = 0;
+    unsigned long long n_box1 = 0, n_box2 = 0;
     for (;;) {
         unsigned int c0 = 0;
         if (lane == 0) c0 = atomicAdd(&ctr->work_verdict, (unsigned)ta.chunk);
@@ -191,6 +192,7 @@ __global__ void __launch_bounds__(64, (NT * SLOTS >= 20 ? 3 : 4)) k_theta2(const
             lp.m = m; lp.iters = 0; lp.max_iter = 50 * (m + nt) + 100; lp.growth = 0.0;
             lp.alive = (nt >= 31 ? 0xfffffffeu : ((1u << (nt + 1)) - 2u));
             lp.cv = nt + m + lane - 1;
+            bool box_lam = false, box_slack = false;
 #pragma unroll
             for (int sl = 0; sl < SLOTS; ++sl) {
                 const int i = lane + 64 * sl;
@@ -265,6 +267,17 @@ __global__ void __launch_bounds__(64, (NT * SLOTS >= 20 ? 3 : 4)) k_theta2(const
 #pragma unroll
                         for (int t = 0; t < NT; ++t) g[t] *= sc;
                     }
+                    // the largest slack h - g theta this row can have over the bounding box of the parameter polytope: if even
+                    // that is negative the row alone makes the theta LP infeasible (margin 10 x the LP's tolerance)
+                    {
+                        double smax = h;
+#pragma unroll
+                        for (int t = 0; t < NT; ++t) {
+                            const double term = g[t] > 0.0 ? g[t] * blo[t] : (g[t] < 0.0 ? g[t] * bhi[t] : 0.0);
+                            smax -= term;
+                        }
+                        if (i < m && smax < -10 * TOL_FEAS) { if (i < nlam) box_lam = true; else box_slack = true; }
+                    }
                     // theta = theta_v - Minv sigma:  value at the vertex and coefficients of the tight-row slacks sigma
                     double b0 = h, cf[NT];
 #pragma unroll
@@ -283,10 +296,14 @@ __global__ void __launch_bounds__(64, (NT * SLOTS >= 20 ? 3 : 4)) k_theta2(const
                 lp.t[sl][NT + 1] = 0.0;
             }
             cyc_rows += clock64() - t1;
-            const int r1 = lp.phase1();
+            const bool inf1 = __any(box_slack), inf2 = __any(box_lam);
+            n_box1 += inf1; n_box2 += (!inf1 && inf2);
+            // inf1: a stage-1 row cannot hold anywhere in the parameter set -> stage 1 infeasible, no LP needed
+            const int r1 = inf1 ? LP_INFEASIBLE : lp.phase1();
             const long long t15 = clock64();
             if (r1 == LP_ITERLIMIT) st = ST_LP_LIMIT;
             else if (lp.growth > GROWTH_SAFE) retry = true;
+            else if (r1 == LP_OPTIMAL && inf2) st = ST_FEASIBLE;   // feasible, and a multiplier row rules out optimality
             else if (r1 == LP_OPTIMAL) {
 #pragma unroll
                 for (int sl = 0; sl < SLOTS; ++sl) if (lp.kind[sl] == RK_PASSIVE) lp.kind[sl] = RK_INEQ;
@@ -308,6 +325,7 @@ __global__ void __launch_bounds__(64, (NT * SLOTS >= 20 ? 3 : 4)) k_theta2(const
     if (lane == 0) {
         atomicAdd(&ctr->cycles[0], (unsigned long long)cyc_kkt); atomicAdd(&ctr->cycles[1], (unsigned long long)cyc_theta);
         atomicAdd(&ctr->cycles[4], (unsigned long long)cyc_rows); atomicAdd(&ctr->cycles[5], (unsigned long long)cyc_s2);
+        atomicAdd(&ctr->cycles[6], n_box1); atomicAdd(&ctr->cycles[7], n_box2);
         atomicAdd(&ctr->pivots, pivots); atomicAdd(&ctr->xtheta_fallbacks, n_retry);
     }
 }

@@ -491,9 +491,25 @@ int mpc_create(const mpc_problem *p, int32_t device, void *stream, mpc_handle **
                 std::vector<double> tb;
                 const size_t oUVp = tb.size(); tb.resize(tb.size() + (size_t)nc * LS, 0.0);
                 if (mode == 0) for (int i = 0; i < nc; ++i) for (int t = 0; t < nr; ++t) tb[oUVp + (size_t)i * LS + t] = UV[(size_t)i * nr + t];
-                const size_t otvp = tb.size(); tb.resize(tb.size() + (size_t)NTP * NTP + NTP, 0.0);
+                const size_t otvp = tb.size(); tb.resize(tb.size() + (size_t)NTP * NTP + 3 * NTP, 0.0);
                 for (int t = 0; t < nt; ++t) for (int j = 0; j < nt; ++j) tb[otvp + (size_t)t * NTP + j] = tv_minv[(size_t)t * nt + j];
                 for (int t = 0; t < nt; ++t) tb[otvp + (size_t)NTP * NTP + t] = tv_theta[t];
+                {   // bounding box of the parameter polytope: 2 n_t LPs on the device (an unbounded direction gives +-inf)
+                    std::vector<double> cc((size_t)2 * nt * nt, 0.0), obj(2 * nt, 0.0);
+                    for (int t = 0; t < nt; ++t) { cc[(size_t)(2 * t) * nt + t] = 1.0; cc[(size_t)(2 * t + 1) * nt + t] = -1.0; }
+                    std::vector<uint8_t> eqz((size_t)2 * nt * ntc, 0);
+                    std::vector<int32_t> stt(2 * nt, -1);
+                    int rcb = lp_batch_impl(device, 2 * nt, ntc, nt, p->A_t, 1, p->b_t, 1, cc.data(), 0, eqz.data(), stt.data(), nullptr, obj.data(), nullptr, nullptr);
+                    HIP_TRY(nullptr, hipSetDevice(device));
+                    for (int t = 0; t < nt; ++t) {
+                        const bool ok_lo = rcb == MPC_OK && stt[2 * t] == LP_OPTIMAL, ok_hi = rcb == MPC_OK && stt[2 * t + 1] == LP_OPTIMAL;
+                        // the LP optimum carries the simplex tolerance: widen the box a little (the screen only needs an outer box)
+                        const double lo = ok_lo ? obj[2 * t] : -INFINITY, hi = ok_hi ? -obj[2 * t + 1] : INFINITY;
+                        const double pad = 1e-6 * (1.0 + std::max(std::fabs(ok_lo ? lo : 0.0), std::fabs(ok_hi ? hi : 0.0)));
+                        tb[otvp + (size_t)NTP * NTP + NTP + t] = lo - pad;
+                        tb[otvp + (size_t)NTP * NTP + 2 * NTP + t] = hi + pad;
+                    }
+                }
                 const int npre = ntc - nt;
                 const size_t otvr = tb.size(); tb.resize(tb.size() + (size_t)std::max(npre, 1) * LS, 0.0);
                 for (int i = 0; i < npre; ++i) for (int t = 0; t < nr; ++t) tb[otvr + (size_t)i * LS + t] = tv_rows[(size_t)i * nr + t];
@@ -503,7 +519,7 @@ int mpc_create(const mpc_problem *p, int32_t device, void *stream, mpc_handle **
                 const double *tbd = h->theta_blocks.as<double>();
                 h->targs.W = P.W; h->targs.UVp = tbd + oUVp; h->targs.tvp = tbd + otvp; h->targs.tv_rows = tbd + otvr; h->targs.chunk = 1;
             }
-            const Layout lf = make_layout(NTP * NTP + NTP + kmax * LS, size_K, size_L, 0, mode == 1 ? size_X : 0, kmax, nc, 2, 2, 2);
+            const Layout lf = make_layout(NTP * NTP + 3 * NTP + kmax * LS, size_K, size_L, 0, mode == 1 ? size_X : 0, kmax, nc, 2, 2, 2);
             h->Pf = P; apply_layout(h->Pf, lf); h->lds_f = lf.bytes;
             h->grid_f = h->n_cu * std::min(16, waves_per_cu(h->lds_f));
             HIP_TRY(nullptr, h->pf_dev.ensure(sizeof(DevProblem), h->stream));
@@ -881,9 +897,9 @@ int mpc_level_run(mpc_handle *h, int32_t gen_children, mpc_level_stats *stats) {
         HIP_TRY(h, hipEventElapsedTime(&ms[1], h->ev[1], h->ev[2]));
         HIP_TRY(h, hipEventElapsedTime(&ms[2], h->ev[2], h->ev[3]));
         if (h->debug_cycles)
-            std::fprintf(stderr, "[mpc] k=%d n=%lld cycles/cand: kkt %.0f theta %.0f (rows %.0f, stage2 %.0f) x %.0f region %.0f; pivots %.2f\n", k, n,
+            std::fprintf(stderr, "[mpc] k=%d n=%lld cycles/cand: kkt %.0f theta %.0f (rows %.0f, stage2 %.0f) x %.0f region %.0f; pivots %.2f; box screen %.3f / %.3f\n", k, n,
                          host_ctr.cycles[0] / (double)n, host_ctr.cycles[1] / (double)n, host_ctr.cycles[4] / (double)n, host_ctr.cycles[5] / (double)n,
-                         host_ctr.cycles[2] / (double)n, host_ctr.cycles[3] / (double)n, host_ctr.pivots / (double)n);
+                         host_ctr.cycles[2] / (double)n, host_ctr.cycles[3] / (double)n, host_ctr.pivots / (double)n, host_ctr.cycles[6] / (double)n, host_ctr.cycles[7] / (double)n);
         h->n_pruned_new = host_ctr.n_pruned_new;
         h->n_erows = host_ctr.e_rows;
         h->n_regions = (long long)host_ctr.status[ST_REGION];
