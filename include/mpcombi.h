@@ -143,6 +143,18 @@ int mpc_level_regions(mpc_handle *h, double *rec_d_host, int32_t *rec_i_host, in
 int mpc_compact_strides(const mpc_handle *h, int64_t *fd, int64_t *fi, int64_t *max_rows);
 int mpc_level_regions_compact(mpc_handle *h, double *head_d, int32_t *head_i, int64_t cap_regions, double *erows,
                               int64_t cap_rows, int64_t *n_regions, int64_t *n_rows);
+/* The same data without any host-side repacking: ALL slots the region kernel wrote (one per optimal candidate, frontier
+ * order), copied straight into the caller's arrays.  head_i[slot][0] is the candidate's final status: only slots with
+ * MPC_REGION are regions (the others were optimal but lower dimensional); rows are referenced through e_off and are
+ * not in slot order.  n_slots <= cap_slots = mpc_level_slots(h); cap_rows from mpc_compact_strides.  With arrays from
+ * mpc_host_alloc the copies are direct DMA transfers. */
+int64_t mpc_level_slots(const mpc_handle *h);
+int mpc_level_regions_slots(mpc_handle *h, double *head_d, int32_t *head_i, int64_t cap_slots, double *erows,
+                            int64_t cap_rows, int64_t *n_slots, int64_t *n_rows);
+/* Page-locked host memory from a recycling pool (blocks return to the pool on mpc_host_free and are handed out again
+ * without re-pinning).  For result arrays that are filled by mpc_level_regions_slots. */
+int mpc_host_alloc(uint64_t bytes, void **out);
+int mpc_host_free(void *p);
 int mpc_level_children(mpc_handle *h, int32_t *children_host, int64_t cap);     /* n_children x (k+1) */
 int mpc_level_children_device(mpc_handle *h, int32_t *children_dev, int64_t cap);
 int mpc_level_pruned_new(mpc_handle *h, uint64_t *masks_host, int64_t cap);

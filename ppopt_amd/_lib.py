@@ -4,6 +4,7 @@ This is the only doorway from the Python host code to the device kernels.  There
 shared library is missing, or no HIP device is usable, every call raises ``MpcError``.
 """
 import ctypes
+import weakref
 import os
 from typing import Optional
 
@@ -83,6 +84,10 @@ def load():
         'mpc_level_regions': (ctypes.c_int, [H, _dp, _ip, _lp, ctypes.c_int64]),
         'mpc_compact_strides': (ctypes.c_int, [H, _lp, _lp, _lp]),
         'mpc_level_regions_compact': (ctypes.c_int, [H, _dp, _ip, ctypes.c_int64, _dp, ctypes.c_int64, _lp, _lp]),
+        'mpc_level_slots': (ctypes.c_int64, [H]),
+        'mpc_level_regions_slots': (ctypes.c_int, [H, _dp, _ip, ctypes.c_int64, _dp, ctypes.c_int64, _lp, _lp]),
+        'mpc_host_alloc': (ctypes.c_int, [ctypes.c_uint64, ctypes.POINTER(ctypes.c_void_p)]),
+        'mpc_host_free': (ctypes.c_int, [ctypes.c_void_p]),
         'mpc_level_children': (ctypes.c_int, [H, _ip, ctypes.c_int64]),
         'mpc_level_children_device': (ctypes.c_int, [H, ctypes.c_void_p, ctypes.c_int64]),
         'mpc_level_pruned_new': (ctypes.c_int, [H, _u64p, ctypes.c_int64]),
@@ -107,8 +112,23 @@ EXPORTED_SYMBOLS = ['mpc_device_count', 'mpc_version', 'mpc_last_global_error', 
                     'mpc_frontier_root', 'mpc_frontier_set', 'mpc_frontier_set_device', 'mpc_frontier_info',
                     'mpc_frontier_get', 'mpc_pruned_clear', 'mpc_pruned_add', 'mpc_pruned_add_device',
                     'mpc_pruned_count', 'mpc_pruned_get', 'mpc_level_run', 'mpc_level_status', 'mpc_level_regions', 'mpc_compact_strides',
-                    'mpc_level_regions_compact', 'mpc_level_children', 'mpc_level_children_device', 'mpc_level_pruned_new',
+                    'mpc_level_regions_compact', 'mpc_level_slots', 'mpc_level_regions_slots', 'mpc_host_alloc', 'mpc_host_free', 'mpc_level_children', 'mpc_level_children_device', 'mpc_level_pruned_new',
                     'mpc_level_pruned_new_device', 'mpc_frontier_advance', 'mpc_check_level', 'mpc_lp_solve_batch']
+
+
+def pinned_empty(shape, dtype) -> numpy.ndarray:
+    """An uninitialised array in pooled page-locked host memory (mpc_host_alloc); the block goes back to the pool when
+    the last view of the array is gone."""
+    L = load()
+    dtype = numpy.dtype(dtype)
+    count = int(numpy.prod(shape))
+    nbytes = max(count * dtype.itemsize, 1)
+    ptr = ctypes.c_void_p()
+    if L.mpc_host_alloc(nbytes, ctypes.byref(ptr)) != 0:
+        raise MemoryError(f'mpc_host_alloc({nbytes}) failed')
+    buf = (ctypes.c_char * nbytes).from_address(ptr.value)
+    weakref.finalize(buf, L.mpc_host_free, ctypes.c_void_p(ptr.value))
+    return numpy.frombuffer(buf, dtype=dtype, count=count).reshape(shape)
 
 
 def _f64(a):
@@ -278,6 +298,27 @@ class Engine:
                                                           er.ctypes.data_as(_dp), rows_cap, ctypes.byref(n1),
                                                           ctypes.byref(n2)), 'mpc_level_regions_compact')
         return hd[:n1.value], hi[:n1.value], er[:n2.value], k
+
+    def level_regions_slots(self):
+        """All slots the region kernel wrote for this level, copied by DMA into pooled page-locked arrays:
+        (head_d [S, fd], head_i [S, fi], erows [R, n_t+1], k, region_slots) -- region_slots = the slots that are regions."""
+        nr = int(self._last.n_regions)
+        fd, fi, mr = ctypes.c_int64(0), ctypes.c_int64(0), ctypes.c_int64(0)
+        self._check(self._L.mpc_compact_strides(self._h, ctypes.byref(fd), ctypes.byref(fi), ctypes.byref(mr)),
+                    'mpc_compact_strides')
+        k = int(self._last.k)
+        ns = int(self._L.mpc_level_slots(self._h)) if nr else 0
+        rows_cap = int(mr.value) if nr else 0
+        hd = pinned_empty((ns, fd.value), numpy.float64)
+        hi = pinned_empty((ns, fi.value), numpy.int32)
+        er = pinned_empty((max(rows_cap, 1), self.n_t + 1), numpy.float64)
+        n1, n2 = ctypes.c_int64(0), ctypes.c_int64(0)
+        if nr:
+            self._check(self._L.mpc_level_regions_slots(self._h, hd.ctypes.data_as(_dp), hi.ctypes.data_as(_ip), ns,
+                                                        er.ctypes.data_as(_dp), rows_cap, ctypes.byref(n1),
+                                                        ctypes.byref(n2)), 'mpc_level_regions_slots')
+        hi = hi[:n1.value]
+        return hd[:n1.value], hi, er[:n2.value], k, numpy.flatnonzero(hi[:, 0] == REGION)
 
     def level_children(self) -> numpy.ndarray:
         n = int(self._last.n_children)

@@ -10,6 +10,9 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <unordered_map>
+#include <map>
+#include <mutex>
 #include <cstring>
 #include <cstdlib>
 #include <string>
@@ -1038,6 +1041,146 @@ int mpc_level_regions_compact(mpc_handle *h, double *head_d, int32_t *head_i, in
     if (overflow) return fail(h, MPC_ERR_CAPACITY, "row buffer too small (see mpc_compact_strides max_rows)");
     if (n_regions) *n_regions = wreg;
     if (n_rows) *n_rows = wrow;
+    return MPC_OK;
+}
+
+int64_t mpc_level_slots(const mpc_handle *h) { return h ? h->n_opt : 0; }
+
+int mpc_level_regions_slots(mpc_handle *h, double *head_d, int32_t *head_i, int64_t cap_slots, double *erows, int64_t cap_rows,
+                            int64_t *n_slots, int64_t *n_rows) {
+    if (!h) return MPC_ERR_INVALID;
+    if (!h->level_done) return fail(h, MPC_ERR_STATE, "mpc_level_run has not been called for this frontier");
+    if (n_slots) *n_slots = 0;
+    if (n_rows) *n_rows = 0;
+    if (h->n_regions == 0 || h->n_opt == 0) return MPC_OK;
+    if (cap_slots < h->n_opt) return fail(h, MPC_ERR_CAPACITY, "slot buffers too small (mpc_level_slots)");
+    if (!head_d || !head_i || !erows) return MPC_ERR_INVALID;
+    HIP_TRY(h, hipSetDevice(h->device));
+    const int nx = h->n_x, nt = h->n_t, nc = h->n_c, ntc = h->n_tc, k = h->k, nr = nt + 1, fd = h->fd, fi = h->fi;
+    const long long n_opt = h->n_opt, rows_t = nc - h->n_eq + ntc;
+    const long long n_fixed = h->used_region2 ? h->n_rretry : n_opt;
+    const long long rows_need = h->used_region2 ? h->n_erows + h->n_rretry * rows_t : h->n_regions * rows_t;
+    if (cap_rows < rows_need) return fail(h, MPC_ERR_CAPACITY, "row buffer too small (see mpc_compact_strides max_rows)");
+    hipStream_t s = h->stream;
+    if (n_fixed > 0) {
+        HIP_TRY(h, h->st_fxd.ensure((size_t)n_fixed * h->rec_d * sizeof(double)));
+        HIP_TRY(h, h->st_fxi.ensure((size_t)n_fixed * h->rec_i * sizeof(int32_t)));
+        HIP_TRY(h, h->st_list.ensure((size_t)n_opt * sizeof(int32_t)));
+        HIP_TRY(h, h->st_status.ensure((size_t)h->n));
+        HIP_TRY(h, hipMemcpyAsync(h->st_fxd.p, h->recd.p, (size_t)n_fixed * h->rec_d * sizeof(double), hipMemcpyDeviceToHost, s));
+        HIP_TRY(h, hipMemcpyAsync(h->st_fxi.p, h->reci.p, (size_t)n_fixed * h->rec_i * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+        HIP_TRY(h, hipMemcpyAsync(h->st_list.p, h->opt_list.p, (size_t)n_opt * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+        HIP_TRY(h, hipMemcpyAsync(h->st_status.p, h->status.p, (size_t)h->n, hipMemcpyDeviceToHost, s));
+    }
+    long long wrow = 0;
+    if (h->used_region2) {
+        HIP_TRY(h, hipMemcpyAsync(head_d, h->headd.p, (size_t)n_opt * fd * sizeof(double), hipMemcpyDeviceToHost, s));
+        HIP_TRY(h, hipMemcpyAsync(head_i, h->headi.p, (size_t)n_opt * fi * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+        if (h->n_erows > 0) HIP_TRY(h, hipMemcpyAsync(erows, h->epool.p, (size_t)h->n_erows * nr * sizeof(double), hipMemcpyDeviceToHost, s));
+        wrow = h->n_erows;
+        if (h->n_rretry > 0) {
+            HIP_TRY(h, h->st_rlist.ensure((size_t)h->n_rretry * sizeof(int32_t)));
+            HIP_TRY(h, hipMemcpyAsync(h->st_rlist.p, h->retry_list.p, (size_t)h->n_rretry * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+        }
+    }
+    HIP_TRY(h, hipStreamSynchronize(s));
+    if (n_fixed > 0) {
+        // the candidates solved by the LDS-engine kernel come as fixed-stride records: written into their slots here
+        const int32_t *list = h->st_list.as<int32_t>(), *rlist = h->st_rlist.as<int32_t>();
+        const uint8_t *st = h->st_status.as<uint8_t>();
+        const double *fxd = h->st_fxd.as<double>();
+        const int32_t *fxi = h->st_fxi.as<int32_t>();
+        long long rpos = 0;
+        for (long long w = 0; w < n_opt; ++w) {
+            const int cand = list[w];
+            int32_t *oi = head_i + (size_t)w * fi;
+            long long src = -1;
+            if (!h->used_region2) src = w;
+            else if (oi[0] == ST_RETRY) {
+                while (rpos < h->n_rretry && rlist[rpos] != cand) ++rpos;
+                if (rpos < h->n_rretry) src = rpos;
+            } else continue;
+            std::fill(oi, oi + fi, -1);
+            oi[0] = st[cand]; oi[1] = cand; oi[2] = oi[3] = oi[4] = oi[5] = oi[6] = oi[7] = 0;
+            if (src < 0 || st[cand] != ST_REGION) continue;
+            const double *rd = fxd + (size_t)src * h->rec_d;
+            const int32_t *ri = fxi + (size_t)src * h->rec_i;
+            const int kk = ri[0], nE = ri[1], n_om = ri[2], n_la = ri[3], n_re = ri[4];
+            double *od = head_d + (size_t)w * fd;
+            std::fill(od, od + fd, 0.0);
+            std::memcpy(od, rd, sizeof(double) * (nx * nt + nx));
+            const double *Al = rd + nx * nt + nx, *bl = Al + (size_t)nc * nt, *E = bl + nc, *f = E + (size_t)(nc + ntc) * nt;
+            std::memcpy(od + nx * nt + nx, Al, sizeof(double) * kk * nt);
+            std::memcpy(od + nx * nt + nx + k * nt, bl, sizeof(double) * kk);
+            oi[2] = nE; oi[3] = n_om; oi[4] = n_la; oi[5] = n_re; oi[6] = (int32_t)wrow;
+            int32_t *act = oi + 8, *om = act + k, *la = om + ntc, *ridx = la + k, *rcon = ridx + (nc - k);
+            std::memcpy(act, ri + 5, sizeof(int32_t) * kk);
+            std::memcpy(om, ri + 5 + nc, sizeof(int32_t) * n_om);
+            std::memcpy(la, ri + 5 + nc + ntc, sizeof(int32_t) * n_la);
+            std::memcpy(ridx, ri + 5 + nc + ntc + nc, sizeof(int32_t) * n_re);
+            std::memcpy(rcon, ri + 5 + nc + ntc + nc + nc, sizeof(int32_t) * n_re);
+            for (int r = 0; r < nE; ++r) {
+                double *row = erows + (size_t)(wrow + r) * nr;
+                row[0] = f[r];
+                for (int t = 0; t < nt; ++t) row[1 + t] = E[(size_t)r * nt + t];
+            }
+            wrow += nE;
+        }
+    }
+    if (n_slots) *n_slots = n_opt;
+    if (n_rows) *n_rows = wrow;
+    return MPC_OK;
+}
+
+// ---- pooled page-locked host memory ---------------------------------------------------------------------------------
+namespace {
+std::mutex g_pool_mutex;
+std::multimap<size_t, void *> g_pool_free;          // size -> block
+std::unordered_map<void *, size_t> g_pool_live;     // block -> size
+size_t g_pool_free_bytes = 0;
+constexpr size_t POOL_MAX_FREE = size_t(2) << 30;
+}  // namespace
+
+int mpc_host_alloc(uint64_t bytes, void **out) {
+    if (!out) return MPC_ERR_INVALID;
+    *out = nullptr;
+    const size_t gran = bytes >= (size_t(1) << 20) ? (size_t(1) << 20) : (size_t(64) << 10);
+    const size_t need = std::max<size_t>(((size_t)bytes + gran - 1) / gran * gran, gran);
+    {
+        std::lock_guard<std::mutex> lk(g_pool_mutex);
+        auto it = g_pool_free.lower_bound(need);
+        if (it != g_pool_free.end() && it->first <= need + need / 2) {
+            *out = it->second;
+            g_pool_live[it->second] = it->first;
+            g_pool_free_bytes -= it->first;
+            g_pool_free.erase(it);
+            return MPC_OK;
+        }
+    }
+    void *p = nullptr;
+    if (hipHostMalloc(&p, need, hipHostMallocPortable) != hipSuccess) return fail(nullptr, MPC_ERR_HIP, "hipHostMalloc failed");
+    std::lock_guard<std::mutex> lk(g_pool_mutex);
+    g_pool_live[p] = need;
+    *out = p;
+    return MPC_OK;
+}
+
+int mpc_host_free(void *p) {
+    if (!p) return MPC_OK;
+    size_t sz = 0;
+    {
+        std::lock_guard<std::mutex> lk(g_pool_mutex);
+        auto it = g_pool_live.find(p);
+        if (it == g_pool_live.end()) return MPC_ERR_INVALID;
+        sz = it->second;
+        g_pool_live.erase(it);
+        if (g_pool_free_bytes + sz <= POOL_MAX_FREE) {
+            g_pool_free.emplace(sz, p);
+            g_pool_free_bytes += sz;
+            return MPC_OK;
+        }
+    }
+    (void)hipHostFree(p);
     return MPC_OK;
 }
 

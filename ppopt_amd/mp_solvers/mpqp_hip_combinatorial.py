@@ -79,8 +79,8 @@ def solve(program, num_cores: int = -1, device: int = 0, profile: Optional[List[
         t0 = time.perf_counter()
         st = eng.level_run(gen_children)
         if collect_regions and st.n_regions:
-            hd, hi, er, kk = eng.level_regions_compact()
-            solution.critical_regions.extend(RegionBatch(hd, hi, er, n_x, n_t, n_c, n_tc, kk).regions())
+            hd, hi, er, kk, slots = eng.level_regions_slots()
+            solution.critical_regions.extend(RegionBatch(hd, hi, er, n_x, n_t, n_c, n_tc, kk, slots).regions())
         if profile is not None:
             profile.append({'depth': depth + 1, 'k': int(st.k), 'candidates': int(st.n),
                             'status': [int(v) for v in st.n_status], 'regions': int(st.n_regions),

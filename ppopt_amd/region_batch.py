@@ -15,8 +15,10 @@ from .critical_region import CriticalRegion
 
 class RegionBatch:
     def __init__(self, head_d: numpy.ndarray, head_i: numpy.ndarray, erows: numpy.ndarray, n_x: int, n_t: int, n_c: int,
-                 n_tc: int, k: int):
+                 n_tc: int, k: int, slots=None):
         self.hd, self.hi, self.er = head_d, head_i, erows
+        # rows of head_d / head_i that are regions (mpc_level_regions_slots returns one slot per optimal candidate)
+        self.slots = numpy.arange(len(head_d)) if slots is None else numpy.asarray(slots)
         self.n_x, self.n_t, self.n_c, self.n_tc, self.k = n_x, n_t, n_c, n_tc, k
         self.oA, self.ob = 0, n_x * n_t
         self.oC, self.od = self.ob + n_x, self.ob + n_x + k * n_t
@@ -26,10 +28,10 @@ class RegionBatch:
         self.irc = self.iri + (n_c - k)
 
     def __len__(self):
-        return len(self.hd)
+        return len(self.slots)
 
     def regions(self) -> List['BatchCriticalRegion']:
-        return [BatchCriticalRegion(self, j) for j in range(len(self.hd))]
+        return [BatchCriticalRegion(self, j) for j in self.slots.tolist()]
 
 
 class _Lazy:

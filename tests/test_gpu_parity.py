@@ -53,6 +53,15 @@ def run_levels(eng, max_levels=None):
             assert a.regular_set == b.regular_set
             for fld in ('A', 'b', 'C', 'd', 'E', 'f'):
                 assert numpy.array_equal(getattr(a, fld), getattr(b, fld)), fld
+        # ... and so must the slot form (no host repacking, pooled page-locked arrays)
+        shd, shi, ser, skk, slots = eng.level_regions_slots()
+        slot_regs = RegionBatch(shd, shi, ser, eng.n_x, eng.n_t, eng.n_c, eng.n_tc, skk, slots).regions()
+        assert len(slot_regs) == len(fixed) and numpy.array_equal(shi[slots, 1], idx)
+        for a, b in zip(fixed, slot_regs):
+            assert a.active_set == b.active_set and a.omega_set == b.omega_set and a.lambda_set == b.lambda_set
+            assert a.regular_set == b.regular_set
+            for fld in ('A', 'b', 'C', 'd', 'E', 'f'):
+                assert numpy.array_equal(getattr(a, fld), getattr(b, fld)), fld
         regions.extend(lazy)
         levels.append((cands, status, st))
         if not gen or st.n_children == 0:
