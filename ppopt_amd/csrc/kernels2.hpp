@@ -338,7 +338,8 @@ __global__ void __launch_bounds__(64, (NT * SLOTS >= 20 ? 3 : 4)) k_theta2(const
 // level).  A child (= parent + one larger row) whose parent has a slot loads that dictionary with coalesced column
 // reads and activates ONE row instead of starting from D0 and activating all k.  The kernel then streams ~2 x 9 KB per
 // candidate (config 4) and is bound by HBM bandwidth rather than by pivots.
-// dict layout per slot: doubles [NXC][mr] (column j of row i at j*mr + i) ; ints var[mr] kind[mr] cv[NXC] alive growth_hi growth_lo
+// dict layout per slot: doubles [NXC][mr] (column j of row i at j*mr + i) then the same tableau row-major [mr][NXC];
+// ints var[mr] kind[mr] cv[NXC] alive growth_hi growth_lo
 struct DictCache {
     const int32_t *parent_slot;   // per candidate of this level (nullptr: no cache to read)
     const double *prev_d; const int32_t *prev_i;
@@ -347,6 +348,113 @@ struct DictCache {
     int dict_only;   // 1: the candidates are already decided (theta stage); only their dictionary is wanted for the children
     int chunk;       // work items per queue atomic (<= 64)
 };
+// k_xq: the last level's quick (x,theta) test.  No dictionary is stored on the last level, so a candidate only needs a
+// DECISION: the first simplex iteration from the parent's dictionary, evaluated on the three vectors it touches -- the
+// values, the new row (row-major copy) and the entering column -- instead of the whole tableau (~1.3 KB instead of
+// ~9 KB per candidate).  Exactly the decision of k_x2 when that iteration is conclusive (slack already nonbasic /
+// already zero / no improving column / the new row itself leaves the basis); otherwise the candidate keeps its NEEDX
+// status and goes to k_x2.  Few registers -> 8 waves per SIMD hide the three dependent HBM round trips.
+template <int SLOTS>
+__global__ void __launch_bounds__(64, 8) k_xq(const DevProblem *__restrict__ Pg, const int32_t *__restrict__ cands, int k,
+                                               const int32_t *__restrict__ list, int n_list, uint8_t *__restrict__ status,
+                                               LevelCounters *__restrict__ ctr, DictCache dc, int NXC) {
+    const DevProblem &P = *Pg;
+    const int lane = lane_id(), nv = P.n_x + P.n_t, mr = P.n_d0r;
+    unsigned long long pivots = 0, n_quick = 0;
+    for (;;) {
+        unsigned int w0 = 0;
+        if (lane == 0) w0 = atomicAdd(&ctr->work_q, (unsigned)dc.chunk);
+        w0 = (unsigned)__builtin_amdgcn_readfirstlane((int)w0);
+        if (w0 >= (unsigned)n_list) break;
+        const int cnt = min(dc.chunk, n_list - (int)w0);
+        int my_c = 0, my_ps = -1, my_st = 0, my_v = 0;
+        if (lane < cnt) {
+            my_c = list[w0 + lane];
+            my_ps = dc.parent_slot[my_c];
+            my_st = status[my_c];
+            my_v = nv + cands[(size_t)my_c * k + (k - 1)];
+        }
+        for (int u = 0; u < cnt; ++u) {
+            const int c = __builtin_amdgcn_readlane(my_c, u);
+            const int ps = __builtin_amdgcn_readlane(my_ps, u);
+            if (ps < 0) continue;
+            const bool singular = __builtin_amdgcn_readlane(my_st, u) == ST_NEEDX_SING;
+            const int v = __builtin_amdgcn_readlane(my_v, u);
+            const int32_t *pi = dc.prev_i + (size_t)ps * dc.stride_i;
+            const double *pd = dc.prev_d + (size_t)ps * dc.stride_d;
+            int qvar[SLOTS], qkind[SLOTS];
+            double qb[SLOTS];
+#pragma unroll
+            for (int sl = 0; sl < SLOTS; ++sl) {
+                const int i = lane + 64 * sl;
+                qvar[sl] = i < mr ? pi[i] : -1;
+                qkind[sl] = i < mr ? pi[mr + i] : RK_DEAD;
+                qb[sl] = i < mr ? pd[i] : 0.0;
+            }
+            const int qcv = lane < NXC + 3 ? pi[2 * mr + lane] : -1;
+            const unsigned al = (unsigned)__builtin_amdgcn_readlane(qcv, NXC);
+            const double growth0 = __hiloint2double(__builtin_amdgcn_readlane(qcv, NXC + 1), __builtin_amdgcn_readlane(qcv, NXC + 2));
+            const unsigned long long bc = __ballot(qcv == v && lane >= 1 && lane < NXC && ((al >> lane) & 1u));
+            int feas = -1;   // 1 feasible, 0 infeasible, -1 undecided
+            if (bc) feas = 1;
+            else {
+                int row = -1;
+#pragma unroll
+                for (int sl = SLOTS - 1; sl >= 0; --sl) {
+                    const unsigned long long br = __ballot(qvar[sl] == v && qkind[sl] == RK_INEQ);
+                    if (br) row = __ffsll((long long)br) - 1 + 64 * sl;
+                }
+                if (row >= 0) {
+                    row = uni(row);
+                    const double br0 = readlane_f64((SLOTS == 1 || row < 64) ? qb[0] : qb[SLOTS - 1], row & 63);
+                    if (br0 <= TOL_FEAS) feas = 1;
+                    else {
+                        const double g = (lane >= 1 && lane < NXC) ? pd[(size_t)NXC * mr + (size_t)row * NXC + lane] : 0.0;
+                        const double gm = dpp_wave_max(g > TOL_COST ? g : 0.0);
+                        if (!(gm > TOL_COST)) feas = 0;
+                        else {
+                            const int q = uni(__ffsll((long long)__ballot(g == gm && lane >= 1 && lane < NXC)) - 1);
+                            double a[SLOTS], ratio[SLOTS];
+                            bool elig[SLOTS];
+                            float cmf = 0.0f;
+                            double tmax = INFINITY;
+#pragma unroll
+                            for (int sl = 0; sl < SLOTS; ++sl) {
+                                const int i = lane + 64 * sl;
+                                a[sl] = i < mr ? pd[(size_t)q * mr + i] : 0.0;
+                                const bool used = i < mr && qkind[sl] != RK_DEAD;
+                                if (used) cmf = fmaxf(cmf, fabsf((float)a[sl]));
+                                elig[sl] = used && qkind[sl] == RK_INEQ && a[sl] > TOL_PIV;
+                                ratio[sl] = 0.0;
+                                if (elig[sl]) {
+                                    const double b0 = fmax(qb[sl], 0.0), ia = fast_rcp(a[sl]);
+                                    ratio[sl] = b0 * ia;
+                                    tmax = fmin(tmax, (b0 + HARRIS_DELTA) * ia);
+                                }
+                            }
+                            const float colmax = dpp_wave_max_f32(cmf);
+                            tmax = dpp_wave_min(tmax);
+                            bool mine = false;
+#pragma unroll
+                            for (int sl = 0; sl < SLOTS; ++sl) mine = mine || (lane + 64 * sl == row && elig[sl] && !(ratio[sl] > tmax));
+                            if (__any(mine)) {
+                                const double rpiv = readlane_f64((SLOTS == 1 || row < 64) ? a[0] : a[SLOTS - 1], row & 63);
+                                const double gr = fmax(growth0, (double)(colmax * (float)fast_rcp(rpiv)));
+                                if (!(gr > GROWTH_SAFE)) { feas = 1; pivots++; }
+                            }
+                        }
+                    }
+                }
+            }
+            if (feas >= 0) {
+                n_quick++;
+                if (lane == 0) status[c] = (uint8_t)(feas ? (singular ? ST_SINGULAR : ST_FEASIBLE) : ST_INFEASIBLE);
+            }
+        }
+    }
+    if (lane == 0) { atomicAdd(&ctr->pivots, pivots); atomicAdd(&ctr->x_cached, n_quick); atomicAdd(&ctr->xtheta_lps, n_quick); }
+}
+
 #ifndef X2_WAVES
 #define X2_WAVES 3
 #endif
@@ -390,7 +498,7 @@ __global__ void __launch_bounds__(64, (NXC * SLOTS >= 32 ? X2_WAVES : 3)) k_x2(c
                 const int psn = __builtin_amdgcn_readlane(my_ps, u + 1);
                 if (psn >= 0) {
                     const int32_t *nx = reinterpret_cast<const int32_t *>(dc.prev_d + (size_t)psn * dc.stride_d);
-                    const long long words = dc.stride_d * 2;
+                    const long long words = (long long)NXC * mr * 2;
                     if ((long long)lane * 32 < words) sink ^= nx[lane * 32];
                     if ((long long)(lane + 64) * 32 < words) sink ^= nx[(lane + 64) * 32];
                 }
@@ -455,6 +563,10 @@ __global__ void __launch_bounds__(64, (NXC * SLOTS >= 32 ? X2_WAVES : 3)) k_x2(c
                         oi[mr + i] = lx.kind[sl];
 #pragma unroll
                         for (int j = 0; j < NXC; ++j) od[(size_t)j * mr + i] = lx.t[sl][j];
+                        // row-major copy for the last level's quick test (a lane writes its row contiguously)
+                        double *orow = od + (size_t)NXC * mr + (size_t)i * NXC;
+#pragma unroll
+                        for (int j = 0; j < NXC; ++j) orow[j] = lx.t[sl][j];
                     }
                 }
                 if (lane < NXC) oi[2 * mr + lane] = lx.cv;

@@ -88,6 +88,7 @@ struct mpc_handle {
     DevProblem Pv{}, Pr{};    // verdict / region kernel views (same blocks, different LDS layouts)
     int lds_v = 0, lds_r = 0; // dynamic LDS bytes per wavefront
     int debug_cycles = 0;     // MPC_DEBUG_CYCLES=1: per-level cycle breakdown on stderr
+    int no_xquick = 0;        // MPC_NO_XQUICK=1: no quick (x,theta) test on the last level (A/B)
     int no_kkt_thread = 0;    // MPC_NO_KKT_THREAD=1: KKT solves stay inside the wave kernels (A/B)
     int force_v1 = 0;         // MPC_FORCE_V1=1 in the environment: never use k_verdict2 (A/B comparisons, tests)
     int fast = 0;             // 1: register-engine kernels (k_theta2 / k_x2) with k_verdict as the retry path
@@ -260,6 +261,7 @@ int mpc_create(const mpc_problem *p, int32_t device, void *stream, mpc_handle **
     h->n_x = nx; h->n_t = nt; h->n_c = nc; h->n_eq = ne; h->n_tc = ntc; h->is_qp = p->Q != nullptr;
     { const char *ev = std::getenv("MPC_FORCE_V1"); h->force_v1 = ev && ev[0] == '1'; }
     { const char *ev = std::getenv("MPC_DEBUG_CYCLES"); h->debug_cycles = ev && ev[0] == '1'; }
+    { const char *ev = std::getenv("MPC_NO_XQUICK"); h->no_xquick = ev && ev[0] == '1'; }
     { const char *ev = std::getenv("MPC_NO_KKT_THREAD"); h->no_kkt_thread = ev && ev[0] == '1'; }
     { const char *ev = std::getenv("MPC_DICT_BUDGET_GB"); if (ev) h->dict_budget_gb = std::atof(ev); }
 
@@ -761,7 +763,7 @@ int mpc_level_run(mpc_handle *h, int32_t gen_children, mpc_level_stats *stats) {
             }
             // ---- (x,theta) stage with the dictionary cache -------------------------------------------------------------
             const int nxc = h->fast_x >= 2 ? 32 : 16;
-            h->dict_stride_d = (long long)nxc * h->Pf.n_d0r;
+            h->dict_stride_d = 2LL * nxc * h->Pf.n_d0r;   // column-major tableau + row-major copy
             h->dict_stride_i = 2LL * h->Pf.n_d0r + nxc + 4;
             DictCache dc{};
             dc.stride_d = h->dict_stride_d; dc.stride_i = h->dict_stride_i;
@@ -810,6 +812,20 @@ int mpc_level_run(mpc_handle *h, int32_t gen_children, mpc_level_stats *stats) {
             int32_t n_needx = 0;
             { int rcs = compact(ST_NEEDX, ST_NEEDX_SING, &n_needx); if (rcs) return rcs; }
             h->n_needx = n_needx;
+            if (n_needx > 0 && !h->storing && dc.parent_slot && !h->no_xquick) {
+                // last level: decisions only -- the quick test on three vectors of the parent's dictionary first
+                DictCache dq = dc;
+                const long long grid_q = (long long)h->n_cu * 32;
+                dq.chunk = (int)std::max<long long>(1, std::min<long long>(16, n_needx / (grid_q * 4)));
+                const dim3 gg((unsigned)std::min<long long>((n_needx + dq.chunk - 1) / dq.chunk, grid_q)), bb(64);
+                const int32_t *ls = h->retry_list.as<int32_t>();
+                if (h->fast_x & 1) hipLaunchKernelGGL((k_xq<2>), gg, bb, 0, st, pf, fr, k, ls, n_needx, stp, ctr, dq, nxc);
+                else hipLaunchKernelGGL((k_xq<1>), gg, bb, 0, st, pf, fr, k, ls, n_needx, stp, ctr, dq, nxc);
+                HIP_TRY(h, hipGetLastError());
+                int32_t n_left = 0;
+                { int rcs = compact(ST_NEEDX, ST_NEEDX_SING, &n_left); if (rcs) return rcs; }
+                n_needx = n_left;
+            }
             if (n_needx > 0) { int rcs = launch_x(n_needx, dc); if (rcs) return rcs; }   // feasibility for the candidates left open
             // numerically doubtful candidates (status 7) go through the LDS engine, which can refactorise its basis
             int32_t n_retry = 0;
@@ -900,9 +916,9 @@ int mpc_level_run(mpc_handle *h, int32_t gen_children, mpc_level_stats *stats) {
         HIP_TRY(h, hipEventElapsedTime(&ms[1], h->ev[1], h->ev[2]));
         HIP_TRY(h, hipEventElapsedTime(&ms[2], h->ev[2], h->ev[3]));
         if (h->debug_cycles)
-            std::fprintf(stderr, "[mpc] k=%d n=%lld cycles/cand: kkt %.0f theta %.0f (rows %.0f, stage2 %.0f) x %.0f region %.0f; pivots %.2f; box screen %.3f / %.3f\n", k, n,
+            std::fprintf(stderr, "[mpc] k=%d n=%lld cycles/cand: kkt %.0f theta %.0f (rows %.0f, stage2 %.0f) x %.0f region %.0f; pivots %.2f; box screen %.3f / %.3f; x quick %.3f\n", k, n,
                          host_ctr.cycles[0] / (double)n, host_ctr.cycles[1] / (double)n, host_ctr.cycles[4] / (double)n, host_ctr.cycles[5] / (double)n,
-                         host_ctr.cycles[2] / (double)n, host_ctr.cycles[3] / (double)n, host_ctr.pivots / (double)n, host_ctr.cycles[6] / (double)n, host_ctr.cycles[7] / (double)n);
+                         host_ctr.cycles[2] / (double)n, host_ctr.cycles[3] / (double)n, host_ctr.pivots / (double)n, host_ctr.cycles[6] / (double)n, host_ctr.cycles[7] / (double)n, host_ctr.xtheta_lps / (double)n);
         h->n_pruned_new = host_ctr.n_pruned_new;
         h->n_erows = host_ctr.e_rows;
         h->n_regions = (long long)host_ctr.status[ST_REGION];
@@ -914,7 +930,7 @@ int mpc_level_run(mpc_handle *h, int32_t gen_children, mpc_level_stats *stats) {
         for (int i = 0; i < 6; ++i) stats->n_status[i] = (int64_t)host_ctr.status[i];
         stats->n_regions = h->n_regions; stats->n_children = h->n_children; stats->n_pruned_new = h->n_pruned_new;
         stats->lp_pivots = (int64_t)host_ctr.pivots;
-        stats->n_xtheta_lp = (int64_t)host_ctr.xtheta_lps + h->n_needx;
+        stats->n_xtheta_lp = (h->fast && !h->force_v1) ? h->n_needx : (int64_t)host_ctr.xtheta_lps;
         stats->n_xtheta_fallback = (int64_t)host_ctr.xtheta_fallbacks;
         for (int i = 0; i < 4; ++i) stats->wave_cycles[i] = (int64_t)host_ctr.cycles[i];
         stats->n_region_retry = h->n_rretry;
