@@ -95,12 +95,13 @@ def main():
     ap.add_argument('--warmup', type=int, default=1)
     ap.add_argument('--workload', default='c4', choices=sorted(WORKLOADS))
     ap.add_argument('--cpu-sample', type=int, default=60000, help='candidates in the CPU baseline sample (0 = skip)')
+    ap.add_argument('--dist-single', action='store_true', help='run the multi-GPU driver with a process group of one rank (self-test)')
     args = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-    distributed = world > 1
+    distributed = world > 1 or args.dist_single
     if distributed and args.gpus != world:
         raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}')
     if args.gpus > 1 and not distributed:
@@ -114,6 +115,7 @@ def main():
     import torch.distributed as dist
     if distributed:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29533')
         dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local_rank))
 
     import __graft_entry__ as entry

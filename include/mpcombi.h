@@ -112,6 +112,9 @@ void *mpc_stream(const mpc_handle *h);
 int mpc_frontier_root(mpc_handle *h);
 int mpc_frontier_set(mpc_handle *h, const int32_t *cand_host, int64_t n, int32_t k);
 int mpc_frontier_set_device(mpc_handle *h, const int32_t *cand_dev, int64_t n, int32_t k);
+/* keep candidates rank, rank+world, ... of the resident frontier (multi-GPU: the ranks hold identical frontiers up to the
+ * level at which they split; the kept candidates still find their parents' dictionaries in this GPU's cache) */
+int mpc_frontier_shard(mpc_handle *h, int32_t rank, int32_t world);
 int mpc_frontier_info(const mpc_handle *h, int64_t *n, int32_t *k);
 int mpc_frontier_get(mpc_handle *h, int32_t *cand_host, int64_t cap);
 int mpc_pruned_clear(mpc_handle *h);

@@ -84,6 +84,7 @@ def load():
         'mpc_level_regions': (ctypes.c_int, [H, _dp, _ip, _lp, ctypes.c_int64]),
         'mpc_compact_strides': (ctypes.c_int, [H, _lp, _lp, _lp]),
         'mpc_level_regions_compact': (ctypes.c_int, [H, _dp, _ip, ctypes.c_int64, _dp, ctypes.c_int64, _lp, _lp]),
+        'mpc_frontier_shard': (ctypes.c_int, [H, ctypes.c_int32, ctypes.c_int32]),
         'mpc_level_slots': (ctypes.c_int64, [H]),
         'mpc_level_regions_slots': (ctypes.c_int, [H, _dp, _ip, ctypes.c_int64, _dp, ctypes.c_int64, _lp, _lp]),
         'mpc_host_alloc': (ctypes.c_int, [ctypes.c_uint64, ctypes.POINTER(ctypes.c_void_p)]),
@@ -112,7 +113,7 @@ EXPORTED_SYMBOLS = ['mpc_device_count', 'mpc_version', 'mpc_last_global_error', 
                     'mpc_frontier_root', 'mpc_frontier_set', 'mpc_frontier_set_device', 'mpc_frontier_info',
                     'mpc_frontier_get', 'mpc_pruned_clear', 'mpc_pruned_add', 'mpc_pruned_add_device',
                     'mpc_pruned_count', 'mpc_pruned_get', 'mpc_level_run', 'mpc_level_status', 'mpc_level_regions', 'mpc_compact_strides',
-                    'mpc_level_regions_compact', 'mpc_level_slots', 'mpc_level_regions_slots', 'mpc_host_alloc', 'mpc_host_free', 'mpc_level_children', 'mpc_level_children_device', 'mpc_level_pruned_new',
+                    'mpc_level_regions_compact', 'mpc_frontier_shard', 'mpc_level_slots', 'mpc_level_regions_slots', 'mpc_host_alloc', 'mpc_host_free', 'mpc_level_children', 'mpc_level_children_device', 'mpc_level_pruned_new',
                     'mpc_level_pruned_new_device', 'mpc_frontier_advance', 'mpc_check_level', 'mpc_lp_solve_batch']
 
 
@@ -246,6 +247,9 @@ class Engine:
 
     def pruned_add_device(self, ptr: int, m: int):
         self._check(self._L.mpc_pruned_add_device(self._h, ctypes.c_void_p(ptr), m), 'mpc_pruned_add_device')
+
+    def frontier_shard(self, rank: int, world: int):
+        self._check(self._L.mpc_frontier_shard(self._h, rank, world), 'mpc_frontier_shard')
 
     def pruned_count(self) -> int:
         return int(self._L.mpc_pruned_count(self._h))

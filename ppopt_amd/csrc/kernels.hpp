@@ -735,6 +735,15 @@ __global__ void k_pruned_append(const int32_t *__restrict__ cands, long long n, 
     out[2 * (size_t)pos + 1] = p1;
 }
 
+// keeps rows start, start+stride, ... of a row-major int matrix (frontier sharding, mpc_frontier_shard)
+__global__ void k_take_rows(const int32_t *__restrict__ src, long long n_new, int width, long long start, long long stride,
+                            int32_t *__restrict__ dst) {
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n_new * width) return;
+    const long long r = idx / width;
+    dst[idx] = src[(start + r * stride) * width + (idx - r * width)];
+}
+
 __global__ void k_root_frontier(int n_eq, int n_c, int32_t *out) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     const int cnt = n_c - n_eq;

@@ -614,6 +614,34 @@ int mpc_frontier_set_device(mpc_handle *h, const int32_t *cand, int64_t n, int32
     return MPC_OK;
 }
 
+int mpc_frontier_shard(mpc_handle *h, int32_t rank, int32_t world) {
+    if (!h || world < 1 || rank < 0 || rank >= world) return MPC_ERR_INVALID;
+    if (world == 1) return MPC_OK;
+    HIP_TRY(h, hipSetDevice(h->device));
+    const long long n = h->n, n_new = n > rank ? (n - rank + world - 1) / world : 0;
+    const int k = h->k;
+    hipStream_t st = h->stream;
+    if (n_new > 0 && k > 0) {
+        HIP_TRY(h, h->children.ensure((size_t)n_new * k * sizeof(int32_t), st));
+        const long long tot = n_new * k;
+        hipLaunchKernelGGL(k_take_rows, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, h->frontier.as<int32_t>(), n_new, k, (long long)rank,
+                           (long long)world, h->children.as<int32_t>());
+        HIP_TRY(h, hipGetLastError());
+        std::swap(h->frontier, h->children);
+        if (h->have_parent_slot) {
+            HIP_TRY(h, h->parent_slot_next.ensure((size_t)n_new * sizeof(int32_t), st));
+            hipLaunchKernelGGL(k_take_rows, dim3((unsigned)((n_new + 255) / 256)), dim3(256), 0, st, h->parent_slot.as<int32_t>(), n_new, 1, (long long)rank,
+                               (long long)world, h->parent_slot_next.as<int32_t>());
+            HIP_TRY(h, hipGetLastError());
+            std::swap(h->parent_slot, h->parent_slot_next);
+        }
+        HIP_TRY(h, hipStreamSynchronize(st));
+    }
+    h->n = n_new;
+    h->level_done = false;
+    return MPC_OK;
+}
+
 int mpc_frontier_info(const mpc_handle *h, int64_t *n, int32_t *k) {
     if (!h) return MPC_ERR_INVALID;
     if (n) *n = h->n;

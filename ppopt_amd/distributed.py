@@ -1,33 +1,37 @@
-"""Multi-GPU level exchange: one process per GPU under ``torch.distributed`` (backend "nccl" = RCCL over xGMI).
+"""Multi-GPU driver: one process per GPU under ``torch.distributed`` (backend "nccl" = RCCL over xGMI).
 
 The reference's only parallel construct is ``pool.map(full_process, to_check)`` over the independent candidates of one
-BFS level, followed by a merge in the parent (mp_solvers/mpqp_parrallel_combinatorial.py:110-135).  Here every rank
-holds the same frontier, processes the slice ``frontier[rank::world]`` on its own GPU, and the merge is one exchange
-step per level:
+BFS level, followed by a merge in the parent (mp_solvers/mpqp_parrallel_combinatorial.py:110-135).  The candidates of a
+level are independent, and a child set has exactly ONE generating parent (the set without its largest index), so the
+tree can be split by subtrees without ever producing a candidate twice:
 
-    all_gather(counts)  ->  all_gather(children, padded)   next frontier       (driver :128  future_list.extend)
-                            all_gather(pruned masks)        murder_list update  (driver :127  add_combos)
-                            all_gather(region records)      solution            (driver :129-131)
-
-RCCL has no all-gather-v, so counts are exchanged first and payloads are padded to the largest contribution.  The
-per-level volume is KBs to a few MBs: the step is latency-bound, far below the ~153 GB/s of one xGMI link.  There is
-no collective inside the per-candidate work.
+  * replicated phase   while a level is small (< shard_min x world candidates) every rank processes all of it.  The ranks
+                       run the same deterministic kernels on the same data, so they stay identical without talking.
+  * split              at the first level that is large enough every rank keeps the candidates rank, rank+world, ... of
+                       the (still identical) frontier -- mpc_frontier_shard.  Their parents' dictionaries are in every
+                       GPU's cache, so the split costs nothing.
+  * sharded phase      each rank expands only its own candidates; children stay on the GPU that holds their parent's
+                       dictionary.  The one thing the ranks must share is the pruned list (the reference's murder_list,
+                       solver_utils.py:15-55): per level one all-gather of the newly pruned masks (KBs) and one of a small
+                       statistics row.  No frontier, no dictionary and no region ever crosses xGMI inside the loop.
+  * regions            collected locally; after the last level the sharded levels' regions are all-gathered (padded:
+                       RCCL has no all-gather-v) so that every rank returns the complete Solution.
 
 The exchange is written against a small engine interface on torch tensors so that the same code runs on CUDA tensors
 with RCCL (``HipLevelEngine``) and -- in the CPU tests -- on CPU tensors with gloo and an oracle-backed engine.
 """
-from typing import Dict, List, Optional, Tuple
+from typing import Dict, List, Optional
 
 import numpy
 import torch
 import torch.distributed as dist
 
-from .critical_region import CriticalRegion
+from .region_batch import RegionBatch
 from .solution import Solution
 
 
 class HipLevelEngine:
-    """`_lib.Engine` with torch.cuda tensors at the boundary.  Device pointers are passed to the C ABI as plain
+    """`_lib.Engine` behind the interface solve_distributed drives.  Device pointers are passed to the C ABI as plain
     integers.  The engine runs on its own HIP stream; ordering with torch / RCCL work is explicit: torch's stream is
     synchronised before a tensor is handed in, and every C-ABI call that touches caller memory has completed when it
     returns (include/mpcombi.h)."""
@@ -41,38 +45,26 @@ class HipLevelEngine:
                                len(program.equality_indices), device=device_index)
         e = self.eng
         self.n_x, self.n_t, self.n_c, self.n_tc, self.n_eq = e.n_x, e.n_t, e.n_c, e.n_tc, e.n_eq
-        self.rec_d, self.rec_i = e.rec_d, e.rec_i
         self._stats = None
-        self._k = 0
 
     def clear_pruned(self):
         self.eng.pruned_clear()
 
-    def add_pruned(self, masks: torch.Tensor):
-        if masks.numel():
-            m = masks.contiguous()
-            torch.cuda.current_stream(self.device).synchronize()
-            self.eng.pruned_add_device(m.data_ptr(), m.shape[0])
+    def root(self):
+        self.eng.frontier_root()
 
-    def set_frontier(self, cands: torch.Tensor):
-        c = cands.contiguous()
-        self._k = c.shape[1]
-        torch.cuda.current_stream(self.device).synchronize()
-        self.eng.frontier_set_device(c.data_ptr(), c.shape[0], c.shape[1])
+    def frontier_size(self):
+        return self.eng.frontier_info()
+
+    def shard(self, rank: int, world: int):
+        self.eng.frontier_shard(rank, world)
 
     def run(self, gen_children: bool) -> Dict:
         st = self.eng.level_run(gen_children)
         self._stats = st
-        return {'n': int(st.n), 'status': [int(v) for v in st.n_status], 'n_regions': int(st.n_regions),
+        return {'n': int(st.n), 'k': int(st.k), 'status': [int(v) for v in st.n_status], 'n_regions': int(st.n_regions),
                 'n_children': int(st.n_children), 'n_pruned_new': int(st.n_pruned_new), 'lp_pivots': int(st.lp_pivots),
                 'ms_verdict': float(st.ms_verdict), 'ms_region': float(st.ms_region), 'ms_children': float(st.ms_children)}
-
-    def children(self) -> torch.Tensor:
-        n = int(self._stats.n_children)
-        out = torch.empty((n, self._k + 1), dtype=torch.int32, device=self.device)
-        if n:
-            self.eng.level_children_device(out.data_ptr(), n)
-        return out
 
     def pruned_new(self) -> torch.Tensor:
         m = int(self._stats.n_pruned_new)
@@ -81,101 +73,132 @@ class HipLevelEngine:
             self.eng.level_pruned_new_device(out.data_ptr(), m)
         return out
 
-    def regions(self) -> Tuple[torch.Tensor, torch.Tensor]:
-        rd, ri, _ = self.eng.level_regions()
-        return torch.from_numpy(rd).to(self.device), torch.from_numpy(ri).to(self.device)
+    def add_pruned(self, masks: torch.Tensor):
+        if masks.numel():
+            m = masks.contiguous()
+            torch.cuda.current_stream(self.device).synchronize()
+            self.eng.pruned_add_device(m.data_ptr(), m.shape[0])
+
+    def advance(self):
+        self.eng.frontier_advance()
+
+    def regions(self):
+        """(head_d, head_i, erows, k, slots) of the level just run (include/mpcombi.h, mpc_level_regions_slots)."""
+        return self.eng.level_regions_slots()
+
+    def check_base(self):
+        """The base active set (the equality rows alone): (status histogram, region pieces or None)."""
+        from .mp_solvers.mpqp_hip_combinatorial import unpack_regions
+        base = numpy.arange(self.n_eq, dtype=numpy.int32).reshape(1, -1)
+        status, rd, ri, _, _ = self.eng.check_level(base, numpy.zeros((0, 2), dtype=numpy.uint64), False)
+        regs = unpack_regions(rd, ri, self.n_x, self.n_t, self.n_c, self.n_tc) if len(rd) else []
+        return numpy.bincount(status, minlength=6).tolist(), regs
 
     def close(self):
         self.eng.close()
 
 
-def shard(frontier: torch.Tensor, rank: int, world: int) -> torch.Tensor:
-    """Rank r takes rows r, r+world, ...  (interleaved so that every rank sees the same mix of candidates)."""
-    return frontier[rank::world].contiguous()
-
-
-def allgather_rows(t: torch.Tensor, counts: List[int], group=None) -> torch.Tensor:
-    """All-gather of a 2-D tensor whose row count differs per rank: pad to the largest count, gather, trim, and
-    concatenate in rank order."""
+def allgather_rows(t: torch.Tensor, counts: List[int], group=None) -> List[torch.Tensor]:
+    """All-gather of a 2-D tensor whose row count differs per rank: pad to the largest count, gather, trim.  Returns the
+    per-rank pieces in rank order."""
     world = len(counts)
     if world == 1:
-        return t
+        return [t]
     mx = max(max(counts), 1)
     pad = torch.zeros((mx, t.shape[1]), dtype=t.dtype, device=t.device)
     if t.shape[0]:
         pad[:t.shape[0]] = t
     parts = [torch.empty_like(pad) for _ in range(world)]
     dist.all_gather(parts, pad, group=group)
-    return torch.cat([p[:c] for p, c in zip(parts, counts)], dim=0)
+    return [p[:c] for p, c in zip(parts, counts)]
 
 
-def exchange_level(kids: torch.Tensor, pruned: torch.Tensor, rd: torch.Tensor, ri: torch.Tensor, stats: Dict, group=None):
-    """The per-level merge.  Returns (all children, all pruned masks, all region records, summed statistics)."""
-    world = dist.get_world_size(group) if dist.is_initialized() else 1
-    dev = kids.device
-    mine = torch.tensor([kids.shape[0], pruned.shape[0], rd.shape[0], stats['n'], stats['lp_pivots'], *stats['status']],
-                        dtype=torch.int64, device=dev)
-    if world == 1:
-        table = mine.unsqueeze(0)
-    else:
-        parts = [torch.empty_like(mine) for _ in range(world)]
-        dist.all_gather(parts, mine, group=group)
-        table = torch.stack(parts)
-    table = table.cpu().tolist()
-    kids_all = allgather_rows(kids, [r[0] for r in table], group)
-    pruned_all = allgather_rows(pruned, [r[1] for r in table], group)
-    rd_all = allgather_rows(rd, [r[2] for r in table], group)
-    ri_all = allgather_rows(ri, [r[2] for r in table], group)
-    total = {'n': sum(r[3] for r in table), 'lp_pivots': sum(r[4] for r in table),
-             'status': [sum(r[5 + j] for r in table) for j in range(len(stats['status']))],
-             'n_regions': sum(r[2] for r in table), 'n_children': sum(r[0] for r in table),
-             'n_pruned_new': sum(r[1] for r in table)}
-    return kids_all, pruned_all, rd_all, ri_all, total
+def allgather_table(row: List[int], device, group=None) -> List[List[int]]:
+    """One small integer row per rank -> the table of all rows (rank order)."""
+    mine = torch.tensor(row, dtype=torch.int64, device=device)
+    world = dist.get_world_size(group)
+    parts = [torch.empty_like(mine) for _ in range(world)]
+    dist.all_gather(parts, mine, group=group)
+    return torch.stack(parts).cpu().tolist()
 
 
 def solve_distributed(engine, program=None, group=None, profile: Optional[List[Dict]] = None,
-                      collect_regions: bool = True, max_levels: Optional[int] = None) -> Solution:
-    """The level loop of the parallel combinatorial algorithm with the frontier sharded over the ranks of ``group``.
+                      collect_regions: bool = True, max_levels: Optional[int] = None, shard_min: int = 1024) -> Solution:
+    """The level loop of the parallel combinatorial algorithm over the ranks of ``group`` (see the module docstring).
     Every rank returns the complete Solution.  Works without an initialised process group (world size 1)."""
-    from .mp_solvers.mpqp_hip_combinatorial import unpack_regions
-    rank = dist.get_rank(group) if dist.is_initialized() else 0
-    world = dist.get_world_size(group) if dist.is_initialized() else 1
-    e, n_c = engine.n_eq, engine.n_c
+    active = dist.is_available() and dist.is_initialized()
+    rank = dist.get_rank(group) if active else 0
+    world = dist.get_world_size(group) if active else 1
+    e = engine.n_eq
     max_depth = max(engine.n_x, engine.n_t) - e
     if max_levels is not None:
         max_depth = min(max_depth, max_levels)
-    root = numpy.array([[*range(e), i] for i in range(e, n_c)], dtype=numpy.int32).reshape(-1, e + 1)
-    frontier = torch.from_numpy(root).to(engine.device)
     solution = Solution(program, [])
     engine.clear_pruned()
+    engine.root()
+    sharded = False
+    mine: List = []   # (level, pieces) of the sharded levels: this rank's regions, gathered after the loop
     for depth in range(max_depth):
         gen_children = depth + 1 != max_depth
-        engine.set_frontier(shard(frontier, rank, world))
+        n, k = engine.frontier_size()
+        if not sharded and world > 1 and n >= shard_min * world:
+            engine.shard(rank, world)
+            sharded = True
         st = engine.run(gen_children)
-        kids = engine.children() if gen_children else torch.empty((0, frontier.shape[1] + 1), dtype=torch.int32, device=engine.device)
-        rd, ri = engine.regions()
-        kids, pruned, rd, ri, total = exchange_level(kids, engine.pruned_new(), rd, ri, st, group)
-        engine.add_pruned(pruned)
-        if collect_regions and rd.shape[0]:
-            solution.critical_regions.extend(unpack_regions(rd.cpu().numpy(), ri.cpu().numpy(), engine.n_x, engine.n_t,
-                                                            engine.n_c, engine.n_tc))
+        total = st
+        if sharded:
+            table = allgather_table([st['n'], st['n_children'], st['n_pruned_new'], st['n_regions'], st['lp_pivots'],
+                                     *st['status']], engine.device, group)
+            total = {'n': sum(r[0] for r in table), 'n_children': sum(r[1] for r in table),
+                     'n_pruned_new': sum(r[2] for r in table), 'n_regions': sum(r[3] for r in table),
+                     'lp_pivots': sum(r[4] for r in table),
+                     'status': [sum(r[5 + j] for r in table) for j in range(len(st['status']))]}
+            if gen_children and total['n_pruned_new']:
+                # the other ranks' newly pruned sets join this rank's list (its own are added by advance())
+                parts = allgather_rows(engine.pruned_new(), [r[2] for r in table], group)
+                others = [p for r, p in enumerate(parts) if r != rank and p.shape[0]]
+                if others:
+                    engine.add_pruned(torch.cat(others, dim=0))
+        if collect_regions:
+            pieces = engine.regions() if st['n_regions'] else None
+            if sharded:
+                mine.append((depth, int(k), total['n_regions'], pieces))
+            elif pieces is not None:
+                hd, hi, er, kk, slots = pieces
+                solution.critical_regions.extend(RegionBatch(hd, hi, er, engine.n_x, engine.n_t, engine.n_c, engine.n_tc, kk, slots).regions())
         if profile is not None:
-            profile.append({'depth': depth + 1, 'k': int(frontier.shape[1]), 'candidates': total['n'],
-                            'status': total['status'], 'regions': total['n_regions'], 'children': total['n_children'],
+            profile.append({'depth': depth + 1, 'k': int(k), 'candidates': total['n'], 'status': total['status'],
+                            'regions': total['n_regions'], 'children': total['n_children'],
                             'pruned_new': total['n_pruned_new'], 'lp_pivots': total['lp_pivots'],
                             'ms_verdict': st.get('ms_verdict', 0.0), 'ms_region': st.get('ms_region', 0.0),
-                            'ms_children': st.get('ms_children', 0.0), 'local_candidates': st['n']})
-        if not gen_children or kids.shape[0] == 0:
+                            'ms_children': st.get('ms_children', 0.0), 'local_candidates': st['n'], 'sharded': sharded})
+        if not gen_children or total['n_children'] == 0:
             break
-        frontier = kids
+        engine.advance()
+    # regions of the sharded levels: padded all-gathers of the three arrays, level by level, rank order
+    for depth, k, n_total, pieces in mine:
+        if n_total == 0:
+            continue
+        fd = engine.n_x * engine.n_t + engine.n_x + k * engine.n_t + k
+        fi = 8 + k + engine.n_tc + k + 2 * (engine.n_c - k)
+        if pieces is None:
+            hd, hi, er = numpy.zeros((0, fd)), numpy.zeros((0, fi), dtype=numpy.int32), numpy.zeros((0, engine.n_t + 1))
+        else:
+            hd, hi, er, _, slots = pieces
+            hd, hi = hd[slots], hi[slots]
+        table = allgather_table([len(hd), len(er)], engine.device, group)
+        dev = engine.device
+        hd_p = allgather_rows(torch.from_numpy(numpy.ascontiguousarray(hd)).to(dev), [r[0] for r in table], group)
+        hi_p = allgather_rows(torch.from_numpy(numpy.ascontiguousarray(hi)).to(dev), [r[0] for r in table], group)
+        er_p = allgather_rows(torch.from_numpy(numpy.ascontiguousarray(er)).to(dev), [r[1] for r in table], group)
+        for a, b, c in zip(hd_p, hi_p, er_p):
+            if a.shape[0]:
+                solution.critical_regions.extend(RegionBatch(a.cpu().numpy(), b.cpu().numpy(), c.cpu().numpy(), engine.n_x, engine.n_t,
+                                                             engine.n_c, engine.n_tc, k).regions())
     # the base active set, on every rank (one candidate; identical result everywhere)
-    base = torch.arange(e, dtype=torch.int32, device=engine.device).reshape(1, e)
-    engine.set_frontier(base)
-    st = engine.run(False)
-    rd, ri = engine.regions()
+    hist, regs = engine.check_base()
     if profile is not None:
-        profile.append({'depth': 0, 'k': e, 'candidates': 1, 'status': st['status'], 'regions': st['n_regions']})
-    if collect_regions and rd.shape[0]:
-        solution.critical_regions.extend(unpack_regions(rd.cpu().numpy(), ri.cpu().numpy(), engine.n_x, engine.n_t,
-                                                        engine.n_c, engine.n_tc))
+        profile.append({'depth': 0, 'k': e, 'candidates': 1, 'status': hist, 'regions': len(regs)})
+    if collect_regions:
+        solution.critical_regions.extend(regs)
     return solution

@@ -13,6 +13,32 @@ import torch.multiprocessing as mp
 from conftest import ROOT, golden_regions, load_golden
 
 
+def pack_compact(regs, n_x, n_t, n_c, n_tc, k):
+    """CriticalRegion objects -> the compact slot arrays of include/mpcombi.h (test infrastructure)."""
+    fd = n_x * n_t + n_x + k * n_t + k
+    fi = 8 + k + n_tc + k + 2 * (n_c - k)
+    hd = numpy.zeros((len(regs), fd))
+    hi = numpy.full((len(regs), fi), -1, dtype=numpy.int32)
+    rows = []
+    for j, r in enumerate(regs):
+        hd[j, :n_x * n_t] = r.A.ravel()
+        hd[j, n_x * n_t:n_x * n_t + n_x] = r.b.ravel()
+        o = n_x * n_t + n_x
+        hd[j, o:o + k * n_t] = r.C.ravel()
+        hd[j, o + k * n_t:o + k * n_t + k] = r.d.ravel()
+        nE = r.E.shape[0]
+        hi[j, :8] = [3, 0, nE, len(r.omega_set), len(r.lambda_set), len(r.regular_set[0]), len(rows), 0]
+        q = 8
+        hi[j, q:q + k] = r.active_set; q += k
+        hi[j, q:q + len(r.omega_set)] = r.omega_set; q += n_tc
+        hi[j, q:q + len(r.lambda_set)] = r.lambda_set; q += k
+        hi[j, q:q + len(r.regular_set[0])] = r.regular_set[0]; q += n_c - k
+        hi[j, q:q + len(r.regular_set[1])] = r.regular_set[1]
+        rows.extend(numpy.hstack([r.f.reshape(-1, 1), r.E]).tolist())
+    er = numpy.array(rows).reshape(-1, n_t + 1)
+    return hd, hi, er, k, numpy.arange(len(regs))
+
+
 class OracleLevelEngine:
     """CPU stand-in for HipLevelEngine (test infrastructure): same methods, CPU tensors, oracle arithmetic."""
 
@@ -26,43 +52,65 @@ class OracleLevelEngine:
     def clear_pruned(self):
         self.pruned = []
 
+    def root(self):
+        e = self.n_eq
+        self.cands = numpy.array([[*range(e), i] for i in range(e, self.n_c)], dtype=numpy.int32).reshape(-1, e + 1)
+
+    def frontier_size(self):
+        return self.cands.shape
+
+    def shard(self, rank, world):
+        self.cands = numpy.ascontiguousarray(self.cands[rank::world])
+
     def add_pruned(self, masks):
         from ppopt_amd._lib import masks_to_sets
         self.pruned.extend(masks_to_sets(masks.numpy().view(numpy.uint64)))
 
-    def set_frontier(self, cands):
-        self.cands = cands.numpy().astype(numpy.int32)
-
-    def run(self, gen_children):
+    def _check(self, cands):
         import ctypes
         from oracle import oracle as orc
-        n, k = self.cands.shape
-        self.status = numpy.zeros(n, dtype=numpy.uint8)
-        self.d = numpy.zeros((n, self.rec_d))
-        self.i = numpy.zeros((n, self.rec_i), dtype=numpy.int32)
+        n, k = cands.shape
+        status = numpy.zeros(n, dtype=numpy.uint8)
+        d = numpy.zeros((n, self.rec_d))
+        i = numpy.zeros((n, self.rec_i), dtype=numpy.int32)
         if n:
-            c = numpy.ascontiguousarray(self.cands)
+            c = numpy.ascontiguousarray(cands)
             orc.lib().orc_check_level(ctypes.byref(self.P.cs), orc._ip(c), n, k, 1,
-                                      self.status.ctypes.data_as(orc._c_uint8_p), orc._dp(self.d), orc._ip(self.i))
+                                      status.ctypes.data_as(orc._c_uint8_p), orc._dp(d), orc._ip(i))
+        return status, d, i
+
+    def run(self, gen_children):
+        n, k = self.cands.shape
+        self.status, self.d, self.i = self._check(self.cands)
         self.kids = self.P.generate_children(self.cands, self.status, self.pruned, mplp_filter=not self.P.is_qp) \
             if gen_children and n else numpy.zeros((0, k + 1), dtype=numpy.int32)
         self.new = [tuple(int(v) for v in self.cands[j]) for j in numpy.nonzero((self.status == 0) | (self.status == 2))[0]]
-        return {'n': n, 'status': numpy.bincount(self.status, minlength=6).tolist(), 'n_regions': int((self.status == 3).sum()),
+        return {'n': n, 'k': k, 'status': numpy.bincount(self.status, minlength=6).tolist(), 'n_regions': int((self.status == 3).sum()),
                 'n_children': len(self.kids), 'n_pruned_new': len(self.new), 'lp_pivots': 0}
-
-    def children(self):
-        return torch.from_numpy(self.kids)
 
     def pruned_new(self):
         from ppopt_amd._lib import sets_to_masks
         return torch.from_numpy(sets_to_masks(self.new).view(numpy.int64).reshape(-1, 2))
 
+    def advance(self):
+        self.pruned.extend(self.new)
+        self.cands = self.kids
+
+    def _unpack(self, status, d, i):
+        from ppopt_amd.mp_solvers.mpqp_hip_combinatorial import unpack_regions
+        sel = status == 3
+        return unpack_regions(d[sel], i[sel], self.n_x, self.n_t, self.n_c, self.n_tc)
+
     def regions(self):
-        sel = self.status == 3
-        return torch.from_numpy(self.d[sel]), torch.from_numpy(self.i[sel])
+        return pack_compact(self._unpack(self.status, self.d, self.i), self.n_x, self.n_t, self.n_c, self.n_tc, self.cands.shape[1])
+
+    def check_base(self):
+        base = numpy.arange(self.n_eq, dtype=numpy.int32).reshape(1, -1)
+        status, d, i = self._check(base)
+        return numpy.bincount(status, minlength=6).tolist(), self._unpack(status, d, i)
 
 
-def _worker(rank, world, port, name, out):
+def _worker(rank, world, port, name, shard_min, out):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, 'tests'))
     os.environ['MASTER_ADDR'] = '127.0.0.1'
@@ -74,33 +122,43 @@ def _worker(rank, world, port, name, out):
         g = load_golden(name)
         eng = OracleLevelEngine(orc.problem_from_golden(g))
         profile = []
-        sol = solve_distributed(eng, profile=profile)
+        sol = solve_distributed(eng, profile=profile, shard_min=shard_min)
         out[rank] = ([tuple(r.active_set) for r in sol.critical_regions],
                      [(p['candidates'], p['status']) for p in profile if p['depth'] > 0],
-                     [p.get('local_candidates') for p in profile if p['depth'] > 0])
+                     [p.get('local_candidates') for p in profile if p['depth'] > 0],
+                     [p.get('sharded') for p in profile if p['depth'] > 0])
     finally:
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize('name', ['dblint_n3', 'rand_4_2_10_s0', 'c1_transport_mplp'])
-def test_two_rank_exchange_reproduces_reference(name):
+@pytest.mark.parametrize('name,shard_min', [('dblint_n3', 1), ('rand_4_2_10_s0', 1), ('c1_transport_mplp', 1),
+                                            ('rand_4_2_10_s0', 20), ('dblint_n3', 10 ** 9)])
+def test_two_rank_split_reproduces_reference(name, shard_min):
+    """shard_min=1: split at the root; 20: replicated first levels, then split; 1e9: never split (pure replication)."""
     world = 2
     port = 29500 + (os.getpid() % 2000)
     with mp.Manager() as mgr:
         out = mgr.dict()
-        mp.spawn(_worker, args=(world, port, name, out), nprocs=world, join=True)
+        mp.spawn(_worker, args=(world, port, name, shard_min, out), nprocs=world, join=True)
         res = dict(out)
     g = load_golden(name)
     ref = sorted(golden_regions(g))
     for rank in range(world):
-        sets, levels, local = res[rank]
+        sets, levels, local, sharded = res[rank]
         assert sorted(sets) == ref, f'rank {rank}'
         for i, (n, hist) in enumerate(levels):
             assert n == len(g[f'L{i}_verdict'])
             assert hist[:5] == numpy.bincount(g[f'L{i}_verdict'], minlength=5).tolist()
-    # the shards really were disjoint halves
-    for a, b, (n, _) in zip(res[0][2], res[1][2], res[0][1]):
-        assert a + b == n and abs(a - b) <= 1
+    # sharded levels are disjoint covers of the level; replicated levels are processed in full by both ranks
+    for a, b, (n, _), sh in zip(res[0][2], res[1][2], res[0][1], res[0][3]):
+        if sh:
+            assert a + b == n
+        else:
+            assert a == n and b == n
+    if shard_min == 1:
+        assert all(res[0][3])
+    if shard_min == 10 ** 9:
+        assert not any(res[0][3])
 
 
 def test_single_process_path_without_process_group(oracle):

@@ -315,3 +315,58 @@ def test_distributed_path_on_one_gpu(name):
     for i, (n, hist) in enumerate(res['levels']):
         assert n == len(g[f'L{i}_verdict'])
         assert hist == numpy.bincount(g[f'L{i}_verdict'], minlength=5).tolist()
+
+
+@pytest.mark.parametrize('name,split_level', [('c2_dblint_n5', 1), ('rand_5_3_8_s3', 0), ('quadtank_n2', 2)])
+def test_two_way_split_on_one_gpu(name, split_level):
+    """The multi-GPU scheme of ppopt_amd/distributed.py played by two handles on one GPU: identical replicated levels, then
+    mpc_frontier_shard, then per level only the newly pruned masks are exchanged.  The union must be what one handle
+    computes alone (same candidates per level, same verdict histogram, same regions), and the kept candidates must still
+    find their parents' dictionaries (n_x_cached)."""
+    from ppopt_amd.region_batch import RegionBatch
+    g = load_golden(name)
+    solo = engine_from_golden(g)
+    levels, solo_regions = run_levels(solo)
+    solo.close()
+    engs = [engine_from_golden(g), engine_from_golden(g)]
+    for e in engs:
+        e.pruned_clear()
+        e.frontier_root()
+    max_depth = max(engs[0].n_x, engs[0].n_t) - engs[0].n_eq
+    regions, sharded = [], False
+    for depth in range(max_depth):
+        gen = depth + 1 != max_depth
+        if depth == split_level:
+            for r, e in enumerate(engs):
+                e.frontier_shard(r, 2)
+            sharded = True
+        sts = [e.level_run(gen) for e in engs]
+        n = sum(int(s.n) for s in sts) if sharded else int(sts[0].n)
+        hist = [sum(int(s.n_status[j]) for s in sts) if sharded else int(sts[0].n_status[j]) for j in range(6)]
+        ref_c, ref_s, _ = levels[depth]
+        assert n == len(ref_c) and hist == numpy.bincount(ref_s, minlength=6).tolist(), (name, depth)
+        if sharded and depth > split_level:
+            # every candidate of a sharded level except the rank's first-level ones starts from a cached dictionary
+            for s in sts:
+                assert int(s.n_x_cached) > 0 or int(s.n_xtheta_lp) == 0
+        for e, s in zip(engs if sharded else engs[:1], sts):
+            if int(s.n_regions):
+                hd, hi, er, kk, slots = e.level_regions_slots()
+                regions.extend(RegionBatch(hd, hi, er, e.n_x, e.n_t, e.n_c, e.n_tc, kk, slots).regions())
+        if sharded and gen:
+            new = [e.level_pruned_new() for e in engs]
+            engs[0].pruned_add(new[1])
+            engs[1].pruned_add(new[0])
+        kids = sum(int(s.n_children) for s in sts) if sharded else int(sts[0].n_children)
+        if not gen or kids == 0:
+            break
+        for e in engs:
+            e.frontier_advance()
+    for e in engs:
+        e.close()
+    a = {tuple(r.active_set): r for r in solo_regions}
+    b = {tuple(r.active_set): r for r in regions}
+    assert sorted(a) == sorted(b)
+    for key in a:
+        for fld in ('A', 'b', 'C', 'd', 'E', 'f'):
+            assert numpy.array_equal(getattr(a[key], fld), getattr(b[key], fld)), (key, fld)
