@@ -173,19 +173,48 @@ def main():
     candidates = sum(p['candidates'] for p in prof)
     regions = len(sol.critical_regions)
     steps = max(args.steps, 1)
-    # per-launch HIP-event times of this rank, summed over all timed steps
-    ms = {kname: sum(p.get(kname, 0.0) for pr in profiles for p in pr) for kname in ('ms_verdict', 'ms_region', 'ms_children')}
-    local_cands = sum(p.get('local_candidates', p['candidates']) for pr in profiles for p in pr if p['depth'] > 0)
+    all_levels = [p for pr in profiles for p in pr if p['depth'] > 0]
+    # per-stage HIP-event times of this rank, summed over all timed steps
+    ms = {kname: sum(p.get(kname, 0.0) for p in all_levels) for kname in ('ms_verdict', 'ms_region', 'ms_children')}
+    local_cands = sum(p.get('local_candidates', p['candidates']) for p in all_levels)
     n_e = float(numpy.mean([r.E.shape[0] for r in sol.critical_regions])) if regions else 0.0
     rho = regions / max(candidates, 1)
-    bytes_verdict = 0.0
-    for pr in profiles:
-        for p in pr:
-            if p['depth'] > 0:
-                bytes_verdict += algorithmic_bytes(prog, p['k'], rho, n_e) * p.get('local_candidates', p['candidates'])
-    dominant = max(ms, key=ms.get)
-    achieved = bytes_verdict / max(ms['ms_verdict'], 1e-9) / 1e6  # GB/s
-    launches = sum(1 for pr in profiles for p in pr if p['depth'] > 0)
+    nx, nt, nc = prog.num_x(), prog.num_t(), prog.num_constraints()
+    # SURVEY.md 8(d) figure for the whole path (every kernel of a level together)
+    bytes_path = sum(algorithmic_bytes(prog, p['k'], rho, n_e) * p.get('local_candidates', p['candidates']) for p in all_levels)
+    ms_path = ms['ms_verdict'] + ms['ms_region'] + ms['ms_children']
+    # the three heavy kernels, each timed by its own HIP events inside mpc_level_run (one launch per level):
+    #   k_theta2  per candidate: active set (4k) + KKT code (1) + multipliers from k_kkt_thread (8 k (n_t+1)) + status (1);
+    #             the shared blocks W, UV (8 n_c (n_c + n_t + 1)) once per launch
+    #   k_x2      per candidate: the parent's dictionary record read (+ the record written for the children) + 4 (list) + 4k + 1
+    #   k_region2 per optimal candidate: 4k + multipliers + the region record it writes
+    kern = {}
+    def add(name, key, units_key, bytes_fn):
+        tot_ms = sum(p.get(key, 0.0) for p in all_levels)
+        launches = sum(1 for p in all_levels if p.get(key, 0.0) > 0.0)
+        units = sum(p.get(units_key, 0) for p in all_levels if p.get(key, 0.0) > 0.0)
+        nbytes = sum(bytes_fn(p) for p in all_levels if p.get(key, 0.0) > 0.0)
+        kern[name] = {'total_ms': tot_ms, 'launches': launches, 'avg_launch_ms': tot_ms / max(launches, 1), 'units': units,
+                      'algorithmic_bytes': nbytes, 'achieved_GBs': nbytes / max(tot_ms, 1e-9) / 1e6}
+    add('k_theta2', 'ms_theta', 'local_candidates' if distributed else 'candidates',
+        lambda p: p.get('local_candidates', p['candidates']) * (4 * p['k'] + 2 + 8 * p['k'] * (nt + 1)) + 8 * nc * (nc + nt + 1))
+    add('k_x2', 'ms_x', 'n_x_items',
+        lambda p: p['n_x_items'] * (p['dict_read_bytes'] + p['dict_write_bytes'] + 4 + 4 * p['k'] + 1))
+    R = lambda k: 8 * (nt + 1) * (nx + k + n_e) + 4 * (8 + 2 * k + prog.A_t.shape[0] + 2 * (nc - k))
+    add('k_region2', 'ms_region2', 'n_opt', lambda p: p['n_opt'] * (4 * p['k'] + 8 * p['k'] * (nt + 1) + R(p['k'])))
+    # the kernel the roofline object describes: the one with the largest total time; k_x2 -- the only stage that streams
+    # real HBM traffic -- when it is within 10% of that
+    dominant = max(kern, key=lambda k: kern[k]['total_ms'])
+    if kern['k_x2']['total_ms'] >= 0.9 * kern[dominant]['total_ms']:
+        dominant = 'k_x2'
+    dom = kern[dominant]
+    traffic = None
+    tpath = os.path.join(ROOT, 'profiles', 'r01_pmc_traffic.json')
+    if os.path.exists(tpath):
+        try:
+            traffic = json.load(open(tpath)).get(args.workload, {}).get(dominant)
+        except (OSError, ValueError):
+            traffic = None
     out = {
         'metric': 'candidate active-sets checked/sec (combinatorial mpQP)',
         'value': candidates * steps / elapsed,
@@ -199,21 +228,27 @@ def main():
         'vs_baseline': None,
         'dtype': 'f64',
         'data': 'synthetic',
-        'config': {'workload': f'{args.workload}: {descr}', 'n_x': prog.num_x(), 'n_theta': prog.num_t(),
-                   'n_c': prog.num_constraints(), 'n_eq': len(prog.equality_indices), 'n_tc': int(prog.A_t.shape[0]),
+        'config': {'workload': f'{args.workload}: {descr}', 'n_x': nx, 'n_theta': nt,
+                   'n_c': nc, 'n_eq': len(prog.equality_indices), 'n_tc': int(prog.A_t.shape[0]),
                    'candidates_per_step': candidates, 'regions_per_step': regions,
-                   'parallelism': f'frontier sharded over {world} GPU(s), one exchange per BFS level' if distributed else 'single GPU'},
+                   'parallelism': (f'{world} GPU(s): small levels replicated, one split, then subtree-local levels that exchange '
+                                   f'only pruned masks') if distributed else 'single GPU'},
         'regions_per_s': regions * steps / elapsed,
         'levels': [{'k': p['k'], 'candidates': p['candidates'], 'status': p['status'], 'regions': p['regions']} for p in levels],
         'kernel_ms_per_step': {k: v / steps for k, v in ms.items()},
         'step_ms': [round(v, 2) for v in step_ms],
-        'roofline': {'bound': 'hbm', 'kernel': 'k_verdict', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                     'frac': achieved / HBM_PEAK_GBS, 'traffic': None,
-                     'launches': launches, 'avg_launch_ms': ms['ms_verdict'] / max(launches, 1),
-                     'algorithmic_bytes_per_candidate': bytes_verdict / max(local_cands, 1),
-                     'dominant_kernel_by_time': dominant,
-                     'note': 'B_alg = P + 4k + 8 + rho*R (SURVEY.md 8(d)); the path is LDS / fp64-issue bound, not HBM bound: '
-                             'the shared problem block is served from L2 after first touch'},
+        'roofline': {'bound': 'hbm', 'kernel': dominant, 'achieved': dom['achieved_GBs'], 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                     'frac': dom['achieved_GBs'] / HBM_PEAK_GBS, 'traffic': traffic,
+                     'launches': dom['launches'], 'avg_launch_ms': dom['avg_launch_ms'],
+                     'algorithmic_bytes_per_launch': dom['algorithmic_bytes'] / max(dom['launches'], 1),
+                     'kernels': kern,
+                     'path': {'algorithmic_bytes_per_candidate': bytes_path / max(local_cands, 1),
+                              'achieved_GBs': bytes_path / max(ms_path, 1e-9) / 1e6,
+                              'note': 'SURVEY.md 8(d): B_alg = P + 4k + 8 + rho*R per candidate over all kernels of a level'},
+                     'note': 'fp64 simplex pivots in registers: the kernels are VALU-issue / latency bound, far from the HBM '
+                             'roof; k_x2 streams one cached dictionary per candidate and is the only one that moves real '
+                             'HBM traffic. traffic = FETCH_SIZE+WRITE_SIZE per launch from the rocprofv3 --pmc passes in '
+                             'profiles/ (same command), null if not collected for this workload.'},
     }
     # CriticalRegion objects returned by the solve are views into per-level arrays that are cut out on first access;
     # the time to touch every field of every region is reported separately (not part of `value`)

@@ -86,6 +86,12 @@ typedef struct {
     int64_t wave_cycles[4];    /* wavefront cycles in: KKT solve, theta LP, (x,theta) LP, region build */
     int64_t n_region_retry;    /* optimal candidates re-solved by the LDS-engine region kernel */
     int64_t n_x_cached;        /* (x,theta) solves that started from the parent's dictionary cached in HBM */
+    /* HIP-event time of single launches of this level (0 when the kernel did not run): k_theta2, the main k_x2 launch
+     * (over n_x_items candidates), k_region2 (over n_opt candidates) */
+    float ms_theta, ms_x, ms_region2, pad_;
+    int64_t n_x_items, n_opt;
+    int64_t dict_read_bytes;   /* bytes of one cached dictionary record as k_x2 reads it (0: no cache on this level)   */
+    int64_t dict_write_bytes;  /* bytes of one record as k_x2 stores it for the next level (0: nothing stored)         */
 } mpc_level_stats;
 
 /* ---- library / device ------------------------------------------------------------------------------ */

@@ -122,6 +122,7 @@ struct mpc_handle {
     bool level_done = false;
     long long n_opt = 0, n_children = 0, n_pruned_new = 0, n_regions = 0;
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t kev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // around k_theta2 / the main k_x2 launch / k_region2
 };
 
 namespace {
@@ -258,6 +259,7 @@ int mpc_create(const mpc_problem *p, int32_t device, void *stream, mpc_handle **
     if (stream) { h->stream = reinterpret_cast<hipStream_t>(stream); h->own_stream = false; }
     else { HIP_TRY(nullptr, hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking)); h->own_stream = true; }
     for (auto &e : h->ev) HIP_TRY(nullptr, hipEventCreate(&e));
+    for (auto &e : h->kev) HIP_TRY(nullptr, hipEventCreate(&e));
     h->n_x = nx; h->n_t = nt; h->n_c = nc; h->n_eq = ne; h->n_tc = ntc; h->is_qp = p->Q != nullptr;
     { const char *ev = std::getenv("MPC_FORCE_V1"); h->force_v1 = ev && ev[0] == '1'; }
     { const char *ev = std::getenv("MPC_DEBUG_CYCLES"); h->debug_cycles = ev && ev[0] == '1'; }
@@ -561,6 +563,7 @@ int mpc_destroy(mpc_handle *h) {
                       &h->dict_stored[0], &h->dict_stored[1], &h->parent_slot, &h->parent_slot_next}) b->release();
     for (HostBuf *b : {&h->st_list, &h->st_status, &h->st_hd, &h->st_hi, &h->st_pool, &h->st_fxd, &h->st_fxi, &h->st_rlist}) b->release();
     for (auto &e : h->ev) if (e) (void)hipEventDestroy(e);
+    for (auto &e : h->kev) if (e) (void)hipEventDestroy(e);
     if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
     return MPC_OK;
@@ -735,7 +738,9 @@ int mpc_level_run(mpc_handle *h, int32_t gen_children, mpc_level_stats *stats) {
     h->n_needx = 0;
     LevelCounters host_ctr;
     std::memset(&host_ctr, 0, sizeof(host_ctr));
-    float ms[3] = {0, 0, 0};
+    float ms[3] = {0, 0, 0}, kms[3] = {0, 0, 0};
+    bool kernel_timed[3] = {false, false, false};
+    long long n_x_items = 0;
     if (n > 0) {
         const size_t nn = (size_t)n;
         HIP_TRY(h, h->status.ensure(nn, st));
@@ -781,12 +786,15 @@ int mpc_level_run(mpc_handle *h, int32_t gen_children, mpc_level_stats *stats) {
                 ThetaArgs ta = h->targs;
                 ta.chunk = (int)std::max<long long>(1, std::min<long long>(16, n / ((long long)h->grid_f * 8)));
                 const dim3 g((unsigned)std::min<long long>((n + ta.chunk - 1) / ta.chunk, h->grid_f)), b(64);
+                HIP_TRY(h, hipEventRecord(h->kev[0], st));
                 switch (h->fast_t) {
                     case 0: hipLaunchKernelGGL((k_theta2<4, 1>), g, b, h->lds_f, st, pf, fr, n, k, stp, ctr, kkc, kkl, ta); break;
                     case 1: hipLaunchKernelGGL((k_theta2<4, 2>), g, b, h->lds_f, st, pf, fr, n, k, stp, ctr, kkc, kkl, ta); break;
                     case 2: hipLaunchKernelGGL((k_theta2<10, 1>), g, b, h->lds_f, st, pf, fr, n, k, stp, ctr, kkc, kkl, ta); break;
                     default: hipLaunchKernelGGL((k_theta2<10, 2>), g, b, h->lds_f, st, pf, fr, n, k, stp, ctr, kkc, kkl, ta); break;
                 }
+                HIP_TRY(h, hipEventRecord(h->kev[1], st));
+                kernel_timed[0] = true;
                 HIP_TRY(h, hipGetLastError());
             }
             // ---- (x,theta) stage with the dictionary cache -------------------------------------------------------------
@@ -854,7 +862,14 @@ int mpc_level_run(mpc_handle *h, int32_t gen_children, mpc_level_stats *stats) {
                 { int rcs = compact(ST_NEEDX, ST_NEEDX_SING, &n_left); if (rcs) return rcs; }
                 n_needx = n_left;
             }
-            if (n_needx > 0) { int rcs = launch_x(n_needx, dc); if (rcs) return rcs; }   // feasibility for the candidates left open
+            if (n_needx > 0) {   // feasibility for the candidates left open
+                HIP_TRY(h, hipEventRecord(h->kev[2], st));
+                int rcs = launch_x(n_needx, dc);
+                if (rcs) return rcs;
+                HIP_TRY(h, hipEventRecord(h->kev[3], st));
+                kernel_timed[1] = true;
+                n_x_items = n_needx;
+            }
             // numerically doubtful candidates (status 7) go through the LDS engine, which can refactorise its basis
             int32_t n_retry = 0;
             { int rcs = compact(ST_RETRY, ST_RETRY, &n_retry); if (rcs) return rcs; }
@@ -890,6 +905,7 @@ int mpc_level_run(mpc_handle *h, int32_t gen_children, mpc_level_stats *stats) {
             const DevProblem *pr = h->pr2_dev.as<DevProblem>();
 #define MPC_LAUNCH_R2(NT_, SL_) hipLaunchKernelGGL((k_region2<NT_, SL_>), g, b, h->lds_r2, st, pr, h->frontier.as<int32_t>(), k, h->opt_list.as<int32_t>(), n_opt, \
                                                    h->status.as<uint8_t>(), h->headd.as<double>(), h->headi.as<int32_t>(), h->fd, h->fi, h->epool.as<double>(), ctr, kkc, kkl)
+            HIP_TRY(h, hipEventRecord(h->kev[4], st));
             switch (h->fast_r) {
                 case 0: MPC_LAUNCH_R2(4, 1); break;
                 case 1: MPC_LAUNCH_R2(4, 2); break;
@@ -897,6 +913,8 @@ int mpc_level_run(mpc_handle *h, int32_t gen_children, mpc_level_stats *stats) {
                 default: MPC_LAUNCH_R2(10, 2); break;
             }
 #undef MPC_LAUNCH_R2
+            HIP_TRY(h, hipEventRecord(h->kev[5], st));
+            kernel_timed[2] = true;
             HIP_TRY(h, hipGetLastError());
             h->used_region2 = true;
             int32_t n_rr = 0;
@@ -943,6 +961,7 @@ int mpc_level_run(mpc_handle *h, int32_t gen_children, mpc_level_stats *stats) {
         HIP_TRY(h, hipEventElapsedTime(&ms[0], h->ev[0], h->ev[1]));
         HIP_TRY(h, hipEventElapsedTime(&ms[1], h->ev[1], h->ev[2]));
         HIP_TRY(h, hipEventElapsedTime(&ms[2], h->ev[2], h->ev[3]));
+        for (int i = 0; i < 3; ++i) if (kernel_timed[i]) HIP_TRY(h, hipEventElapsedTime(&kms[i], h->kev[2 * i], h->kev[2 * i + 1]));
         if (h->debug_cycles)
             std::fprintf(stderr, "[mpc] k=%d n=%lld cycles/cand: kkt %.0f theta %.0f (rows %.0f, stage2 %.0f) x %.0f region %.0f; pivots %.2f; box screen %.3f / %.3f; x quick %.3f\n", k, n,
                          host_ctr.cycles[0] / (double)n, host_ctr.cycles[1] / (double)n, host_ctr.cycles[4] / (double)n, host_ctr.cycles[5] / (double)n,
@@ -963,6 +982,11 @@ int mpc_level_run(mpc_handle *h, int32_t gen_children, mpc_level_stats *stats) {
         for (int i = 0; i < 4; ++i) stats->wave_cycles[i] = (int64_t)host_ctr.cycles[i];
         stats->n_region_retry = h->n_rretry;
         stats->n_x_cached = (int64_t)host_ctr.x_cached;
+        stats->ms_theta = kms[0]; stats->ms_x = kms[1]; stats->ms_region2 = kms[2];
+        stats->n_x_items = n_x_items;
+        stats->n_opt = h->n_opt;
+        stats->dict_read_bytes = (h->fast && h->have_prev_dict && h->have_parent_slot) ? (h->dict_stride_d / 2) * 8 + h->dict_stride_i * 4 : 0;
+        stats->dict_write_bytes = (h->fast && h->storing) ? h->dict_stride_d * 8 + h->dict_stride_i * 4 : 0;
         stats->ms_verdict = ms[0]; stats->ms_region = ms[1]; stats->ms_children = ms[2]; stats->ms_total = ms[0] + ms[1] + ms[2];
     }
     return MPC_OK;
