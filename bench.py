@@ -92,9 +92,9 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=5)
-    ap.add_argument('--warmup', type=int, default=1)
+    ap.add_argument('--warmup', type=int, default=2)
     ap.add_argument('--workload', default='c4', choices=sorted(WORKLOADS))
-    ap.add_argument('--cpu-sample', type=int, default=60000, help='candidates in the CPU baseline sample (0 = skip)')
+    ap.add_argument('--cpu-sample', type=int, default=300000, help='candidates in the CPU baseline sample (0 = skip)')
     ap.add_argument('--dist-single', action='store_true', help='run the multi-GPU driver with a process group of one rank (self-test)')
     args = ap.parse_args()
 
