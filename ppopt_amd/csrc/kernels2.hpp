@@ -18,8 +18,20 @@ constexpr int ST_NEEDX = 8;       // theta stage could not show feasibility: (x,
 constexpr int ST_NEEDX_SING = 9;  // the same, and the KKT matrix was singular (a feasible outcome is ST_SINGULAR)
 
 
+// hot read-only blocks of k_theta2, passed BY VALUE: the pointers are known to be global memory (global_load / s_load
+// instead of flat_load) and cost no descriptor reload inside the candidate loop.  All blocks are zero padded to the
+// kernel's compile-time NT so that the row build has no `t < n_t` guards:
+//   UVp      n_c x (NT+1)      [A Q^-1 c + b | A Q^-1 H + F | 0]
+//   tvp      NT*NT + 3*NT      tv_minv (row stride NT), tv_theta, then the bounding box of {A_t theta <= b_t}: lo, hi
+//   tv_rows  n_tpre x (NT+1)   the non-tight rows of A_t at the theta vertex
+struct ThetaArgs {
+    const double *W, *UVp, *tvp, *tv_rows;
+    int chunk;   // candidates taken from the work queue per atomic
+};
+
 // ------------------------------------------------------------------------------------------------------------------
-// k_kkt_thread: the mode-0 KKT solve with ONE THREAD per candidate (K = cardinality, compile time, everything in VGPRs).
+// k_kkt_thread: the mode-0 KKT solve AND the box screen of the theta stage with ONE THREAD per candidate (K = cardinality
+// and NT >= n_theta are compile-time, everything lives in VGPRs).
 //
 // A k x k Cholesky with k <= 8 has no work for 64 lanes; done by a wavefront it is ~45 dependent LDS phases.  Here every
 // lane solves its own candidate with fully unrolled register code: same operations in the same order as chol_solve
@@ -29,15 +41,25 @@ constexpr int ST_NEEDX_SING = 9;  // the same, and the KKT matrix was singular (
 //               span of the earlier ones) is > 1e-10 and every pivot > 1e-8 of its diagonal, the rows are independent
 //               with a 1e6 margin over the exact test's 1e-11 threshold -> code 0/2.  Anything closer is left to the exact
 //               complete-pivoting elimination of kkt_solve (code KK_UNDECIDED).
-//   output      code[c] in {0 ok, 2 singular, KK_UNDECIDED};  Lout[c*K*nr + i*nr + t] = [b_l | A_l]
+//   multipliers L = -S^-1 UV[as], S = W[as,as]
+//   box screen  the theta-space rows of the inactive constraints, h - g theta >= 0 with [h | -g] = UV[ci] + sum_a
+//               W[ci,as_a] L[a], are formed one after the other (the row index is wave-uniform: UV by scalar loads, W
+//               gathers hit one 376-byte row) and tested against the bounding box of the parameter set exactly as
+//               k_theta2 does: the first row that cannot hold anywhere in the box proves stage 1 of the theta LP
+//               infeasible -> status ST_NEEDX, the candidate never reaches k_theta2.
+//   output      code[c] in {0 ok, 2 singular, KK_UNDECIDED};  status[c] = ST_NEEDX (screened) or ST_TODO;
+//               Lout[c*K*nr + i*nr + t] = [b_l | A_l] for the candidates that go on to k_theta2
 constexpr int KK_UNDECIDED = 255;
-template <int K>
+constexpr int ST_TODO = 10;       // internal: waiting for k_theta2
+template <int K, int NT>
 __global__ void __launch_bounds__(256) k_kkt_thread(const DevProblem *__restrict__ Pg, const int32_t *__restrict__ cands, long long n,
-                                                     uint8_t *__restrict__ code, double *__restrict__ Lout) {
+                                                     uint8_t *__restrict__ code, double *__restrict__ Lout, uint8_t *__restrict__ status,
+                                                     ThetaArgs ta, LevelCounters *__restrict__ ctr) {
     const DevProblem &P = *Pg;
     const long long c = (long long)blockIdx.x * 256 + threadIdx.x;
     if (c >= n) return;
-    const int nc = P.n_c, nr = P.n_t + 1;
+    constexpr int LS = NT + 1;
+    const int nc = P.n_c, nt = P.n_t, nr = nt + 1;
     int as[K];
 #pragma unroll
     for (int i = 0; i < K; ++i) as[i] = cands[c * K + i];
@@ -69,14 +91,14 @@ __global__ void __launch_bounds__(256) k_kkt_thread(const DevProblem *__restrict
             }
         }
         clear = clear && (vol > 1e-10);
-        if (!clear) { code[c] = (uint8_t)KK_UNDECIDED; return; }
+        if (!clear) { code[c] = (uint8_t)KK_UNDECIDED; status[c] = (uint8_t)ST_TODO; return; }
     }
     // ---- S = W[as,as] = L L'  (chol_solve arithmetic) ---------------------------------------------------------------
     double diag0[K], invd[K];
 #pragma unroll
     for (int i = 0; i < K; ++i) {
 #pragma unroll
-        for (int j = 0; j <= i; ++j) S[i][j] = P.W[as[i] * nc + as[j]];
+        for (int j = 0; j <= i; ++j) S[i][j] = ta.W[as[i] * nc + as[j]];
         diag0[i] = S[i][i];
     }
     bool ok = true;
@@ -95,12 +117,14 @@ __global__ void __launch_bounds__(256) k_kkt_thread(const DevProblem *__restrict
             for (int cc = j + 1; cc <= i; ++cc) S[i][cc] = fma(-S[i][j], S[cc][j], S[i][cc]);
         }
     }
-    if (!ok) { code[c] = 2; return; }
-    double *out = Lout + (size_t)c * K * nr;
-    for (int t = 0; t < nr; ++t) {
+    if (!ok) { code[c] = 2; status[c] = (uint8_t)ST_TODO; return; }
+    // ---- multipliers, all n_t + 1 right-hand sides (zero beyond n_t) ------------------------------------------------------
+    double Lr[K][LS];
+#pragma unroll
+    for (int t = 0; t < LS; ++t) {
         double R[K];
 #pragma unroll
-        for (int i = 0; i < K; ++i) R[i] = -P.UV[as[i] * nr + t];
+        for (int i = 0; i < K; ++i) R[i] = -ta.UVp[as[i] * LS + t];
 #pragma unroll
         for (int j = 0; j < K; ++j) {
             R[j] = R[j] * invd[j];
@@ -114,9 +138,63 @@ __global__ void __launch_bounds__(256) k_kkt_thread(const DevProblem *__restrict
             for (int i = 0; i < j; ++i) R[i] = fma(-S[j][i], R[j], R[i]);
         }
 #pragma unroll
-        for (int i = 0; i < K; ++i) out[i * nr + t] = R[i];
+        for (int i = 0; i < K; ++i) Lr[i][t] = R[i];
+    }
+    // ---- box screen over the inactive rows (k_theta2's test, same arithmetic) -------------------------------------------
+    const double *blo = ta.tvp + NT * NT + NT, *bhi = blo + NT;
+    bool fired = false;
+    for (int ci = 0; ci < nc; ++ci) {
+        bool active = false;
+#pragma unroll
+        for (int a = 0; a < K; ++a) active = active || (as[a] == ci);
+        double acc[LS];
+#pragma unroll
+        for (int t = 0; t < LS; ++t) acc[t] = ta.UVp[ci * LS + t];
+        const double *Wrow = ta.W + (size_t)ci * nc;
+#pragma unroll
+        for (int a = 0; a < K; ++a) {
+            const double w = Wrow[as[a]];
+#pragma unroll
+            for (int t = 0; t < LS; ++t) acc[t] = fma(w, Lr[a][t], acc[t]);
+        }
+        double h = acc[0], g[NT], mx = 0.0;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) { g[t] = -acc[1 + t]; mx = fmax(mx, fabs(g[t])); }
+        if (!(mx > ZERO_ROW_ATOL)) {
+#pragma unroll
+            for (int t = 0; t < NT; ++t) g[t] = 0.0;
+            mx = 0.0;
+        }
+        if (mx > 0.0) {
+            int ex;
+            (void)frexp(mx, &ex);
+            const double sc = ldexp(1.0, -ex);
+            h *= sc;
+#pragma unroll
+            for (int t = 0; t < NT; ++t) g[t] *= sc;
+        }
+        double smax = h;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const double term = g[t] > 0.0 ? g[t] * blo[t] : (g[t] < 0.0 ? g[t] * bhi[t] : 0.0);
+            smax -= term;
+        }
+        if (!active && smax < -10 * TOL_FEAS) fired = true;
+        if ((ci & 3) == 3 && __all(fired)) break;
+    }
+    if (fired) {
+        code[c] = 0;
+        status[c] = (uint8_t)ST_NEEDX;
+        return;
+    }
+    double *out = Lout + (size_t)c * K * nr;
+#pragma unroll
+    for (int i = 0; i < K; ++i) {
+#pragma unroll
+        for (int t = 0; t < LS; ++t) if (t < nr) out[i * nr + t] = Lr[i][t];
     }
     code[c] = 0;
+    status[c] = (uint8_t)ST_TODO;
 }
 
 // the KKT result of candidate c: from k_kkt_thread's output when it decided, else solved here
@@ -136,21 +214,12 @@ __device__ inline int kkt_fetch_or_solve(const DevProblem &P, int k, Smem &s, co
     return kkt_solve(P, k, s);
 }
 
-// hot read-only blocks of k_theta2, passed BY VALUE: the pointers are known to be global memory (global_load / s_load
-// instead of flat_load) and cost no descriptor reload inside the candidate loop.  All blocks are zero padded to the
-// kernel's compile-time NT so that the row build has no `t < n_t` guards:
-//   UVp      n_c x (NT+1)      [A Q^-1 c + b | A Q^-1 H + F | 0]
-//   tvp      NT*NT + 3*NT      tv_minv (row stride NT), tv_theta, then the bounding box of {A_t theta <= b_t}: lo, hi
-//   tv_rows  n_tpre x (NT+1)   the non-tight rows of A_t at the theta vertex
-struct ThetaArgs {
-    const double *W, *UVp, *tvp, *tv_rows;
-    int chunk;   // candidates taken from the work queue per atomic
-};
-
 template <int NT, int SLOTS>
 __global__ void __launch_bounds__(64, (NT * SLOTS >= 20 ? 3 : 4)) k_theta2(const DevProblem *__restrict__ Pg, const int32_t *__restrict__ cands, long long n, int k,
                                                     uint8_t *__restrict__ status, LevelCounters *__restrict__ ctr,
-                                                    const uint8_t *__restrict__ kkcode, const double *__restrict__ Lin, ThetaArgs ta) {
+                                                    const uint8_t *__restrict__ kkcode, const double *__restrict__ Lin, ThetaArgs ta,
+                                                    const int32_t *__restrict__ list) {
+    // list != nullptr: the candidates list[0..n) that k_kkt_thread's screen left open; else all candidates 0..n
     // the program descriptor stays in memory (scalar loads on demand) instead of ~90 live SGPRs
     const DevProblem &P = *Pg;
     extern __shared__ __attribute__((aligned(16))) double smem[];
@@ -170,7 +239,8 @@ __global__ void __launch_bounds__(64, (NT * SLOTS >= 20 ? 3 : 4)) k_theta2(const
         c0 = (unsigned)__builtin_amdgcn_readfirstlane((int)c0);
         if (c0 >= n) break;
         const unsigned c1 = (unsigned)min((long long)c0 + ta.chunk, n);
-      for (unsigned c = c0; c < c1; ++c) {
+      for (unsigned w = c0; w < c1; ++w) {
+        const unsigned c = list ? (unsigned)list[w] : w;
         const int nin = load_active_set(P, cands + (size_t)c * k, k, s);
         int st = -1;
         const long long t0 = clock64();

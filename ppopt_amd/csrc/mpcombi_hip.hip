@@ -96,7 +96,7 @@ struct mpc_handle {
     long long n_needx = 0;
     DevProblem Pf{};          // view for k_verdict2 (small LDS layout: no tableau)
     int lds_f = 0, grid_f = 0;
-    DevBuf retry_list, pf_dev, pr2_dev, headd, headi, epool, facet_flags, kkt_code, kkt_L, theta_blocks;
+    DevBuf retry_list, theta_list, pf_dev, pr2_dev, headd, headi, epool, facet_flags, kkt_code, kkt_L, theta_blocks;
     ThetaArgs targs{};
     // (x,theta) dictionary cache: [0]/[1] ping-pong between the level being read (parents) and the level being written
     DevBuf dict_d[2], dict_i[2], dict_stored[2], parent_slot, parent_slot_next;
@@ -559,7 +559,7 @@ int mpc_destroy(mpc_handle *h) {
     (void)hipSetDevice(h->device);
     (void)hipStreamSynchronize(h->stream);
     for (DevBuf *b : {&h->blocks, &h->iblocks, &h->frontier, &h->children, &h->status, &h->pruned, &h->pruned_new, &h->flag, &h->pos, &h->opt_list,
-                      &h->childmask, &h->count, &h->offset, &h->recd, &h->reci, &h->ctr, &h->scratch, &h->sums, &h->retry_list, &h->pf_dev, &h->pr2_dev, &h->headd, &h->headi, &h->epool, &h->facet_flags, &h->kkt_code, &h->kkt_L, &h->theta_blocks, &h->dict_d[0], &h->dict_d[1], &h->dict_i[0], &h->dict_i[1],
+                      &h->childmask, &h->count, &h->offset, &h->recd, &h->reci, &h->ctr, &h->scratch, &h->sums, &h->retry_list, &h->pf_dev, &h->pr2_dev, &h->headd, &h->headi, &h->epool, &h->facet_flags, &h->kkt_code, &h->kkt_L, &h->theta_blocks, &h->theta_list, &h->dict_d[0], &h->dict_d[1], &h->dict_i[0], &h->dict_i[1],
                       &h->dict_stored[0], &h->dict_stored[1], &h->parent_slot, &h->parent_slot_next}) b->release();
     for (HostBuf *b : {&h->st_list, &h->st_status, &h->st_hd, &h->st_hi, &h->st_pool, &h->st_fxd, &h->st_fxi, &h->st_rlist}) b->release();
     for (auto &e : h->ev) if (e) (void)hipEventDestroy(e);
@@ -771,27 +771,38 @@ int mpc_level_run(mpc_handle *h, int32_t gen_children, mpc_level_stats *stats) {
             const int32_t *fr = h->frontier.as<int32_t>();
             uint8_t *stp = h->status.as<uint8_t>();
             const DevProblem *pf = h->pf_dev.as<DevProblem>();
-            // KKT solves, one thread per candidate (Schur/Cholesky mode, cardinality 1..8); the wave kernels fetch the result
+            // KKT solves + box screen, one thread per candidate (Schur/Cholesky mode, cardinality 1..8); the wave kernels
+            // fetch the multipliers of the candidates the screen left open
+            long long n_theta = n;
+            const int32_t *theta_list = nullptr;
             if (h->kkt_mode == 0 && k >= 1 && k <= 8 && !h->no_kkt_thread) {
                 HIP_TRY(h, h->kkt_code.ensure(nn, st));
                 HIP_TRY(h, h->kkt_L.ensure(nn * (size_t)k * (h->n_t + 1) * sizeof(double), st));
                 kkc = h->kkt_code.as<uint8_t>(); kkl = h->kkt_L.as<double>();
                 const dim3 g((unsigned)blocks256), b(256);
-#define MPC_LAUNCH_KKT(K_) case K_: hipLaunchKernelGGL((k_kkt_thread<K_>), g, b, 0, st, pf, fr, n, h->kkt_code.as<uint8_t>(), h->kkt_L.as<double>()); break
+                const ThetaArgs ta = h->targs;
+#define MPC_LAUNCH_KKT(K_) case K_: if (h->fast_t >= 2) hipLaunchKernelGGL((k_kkt_thread<K_, 10>), g, b, 0, st, pf, fr, n, h->kkt_code.as<uint8_t>(), h->kkt_L.as<double>(), stp, ta, ctr); \
+                                    else hipLaunchKernelGGL((k_kkt_thread<K_, 4>), g, b, 0, st, pf, fr, n, h->kkt_code.as<uint8_t>(), h->kkt_L.as<double>(), stp, ta, ctr); break
                 switch (k) { MPC_LAUNCH_KKT(1); MPC_LAUNCH_KKT(2); MPC_LAUNCH_KKT(3); MPC_LAUNCH_KKT(4); MPC_LAUNCH_KKT(5); MPC_LAUNCH_KKT(6); MPC_LAUNCH_KKT(7); MPC_LAUNCH_KKT(8); }
 #undef MPC_LAUNCH_KKT
                 HIP_TRY(h, hipGetLastError());
+                int32_t n_todo = 0;
+                { int rcs = compact(ST_TODO, ST_TODO, &n_todo); if (rcs) return rcs; }
+                n_theta = n_todo;
+                HIP_TRY(h, h->theta_list.ensure(nn * sizeof(int32_t), st));
+                std::swap(h->theta_list, h->retry_list);   // compact() filled retry_list; keep it as the theta list
+                theta_list = h->theta_list.as<int32_t>();
             }
-            {   // two-stage theta LP
+            if (n_theta > 0) {   // two-stage theta LP
                 ThetaArgs ta = h->targs;
-                ta.chunk = (int)std::max<long long>(1, std::min<long long>(16, n / ((long long)h->grid_f * 8)));
-                const dim3 g((unsigned)std::min<long long>((n + ta.chunk - 1) / ta.chunk, h->grid_f)), b(64);
+                ta.chunk = (int)std::max<long long>(1, std::min<long long>(16, n_theta / ((long long)h->grid_f * 8)));
+                const dim3 g((unsigned)std::min<long long>((n_theta + ta.chunk - 1) / ta.chunk, h->grid_f)), b(64);
                 HIP_TRY(h, hipEventRecord(h->kev[0], st));
                 switch (h->fast_t) {
-                    case 0: hipLaunchKernelGGL((k_theta2<4, 1>), g, b, h->lds_f, st, pf, fr, n, k, stp, ctr, kkc, kkl, ta); break;
-                    case 1: hipLaunchKernelGGL((k_theta2<4, 2>), g, b, h->lds_f, st, pf, fr, n, k, stp, ctr, kkc, kkl, ta); break;
-                    case 2: hipLaunchKernelGGL((k_theta2<10, 1>), g, b, h->lds_f, st, pf, fr, n, k, stp, ctr, kkc, kkl, ta); break;
-                    default: hipLaunchKernelGGL((k_theta2<10, 2>), g, b, h->lds_f, st, pf, fr, n, k, stp, ctr, kkc, kkl, ta); break;
+                    case 0: hipLaunchKernelGGL((k_theta2<4, 1>), g, b, h->lds_f, st, pf, fr, n_theta, k, stp, ctr, kkc, kkl, ta, theta_list); break;
+                    case 1: hipLaunchKernelGGL((k_theta2<4, 2>), g, b, h->lds_f, st, pf, fr, n_theta, k, stp, ctr, kkc, kkl, ta, theta_list); break;
+                    case 2: hipLaunchKernelGGL((k_theta2<10, 1>), g, b, h->lds_f, st, pf, fr, n_theta, k, stp, ctr, kkc, kkl, ta, theta_list); break;
+                    default: hipLaunchKernelGGL((k_theta2<10, 2>), g, b, h->lds_f, st, pf, fr, n_theta, k, stp, ctr, kkc, kkl, ta, theta_list); break;
                 }
                 HIP_TRY(h, hipEventRecord(h->kev[1], st));
                 kernel_timed[0] = true;
