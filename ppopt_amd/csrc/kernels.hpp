@@ -61,7 +61,7 @@ struct LevelCounters {
     unsigned long long xtheta_fallbacks;  // ... of which the warm start from the pre-crashed vertex was abandoned
     unsigned long long x_cached;    // (x,theta) solves that started from the parent's cached dictionary
     unsigned long long cycles[8];   // wave-cycles (s_memtime) spent in: KKT solve, theta LP, (x,theta) LP, region build; [4] theta rows, [5] theta stage 2; [6],[7] candidates decided by the box screen (stage 1 / multiplier row)
-    unsigned int work_verdict, work_region, n_opt, n_pruned_new, work_retry, work_x, e_rows, work_r2, work_q, pad_;
+    unsigned int work_verdict, work_region, n_opt, n_pruned_new, work_retry, work_x, e_rows, work_r2, work_q, n_retry_theta;
 };
 
 struct Smem {
@@ -733,6 +733,12 @@ __global__ void k_pruned_append(const int32_t *__restrict__ cands, long long n, 
     const unsigned int pos = atomicAdd(&ctr->n_pruned_new, 1u);
     out[2 * (size_t)pos] = p0;
     out[2 * (size_t)pos + 1] = p1;
+}
+
+// status[list[w]] = tmp[list[w]]  (results of a retry kernel that ran on a side stream)
+__global__ void k_apply_status(const int32_t *__restrict__ list, int n_list, const uint8_t *__restrict__ tmp, uint8_t *__restrict__ status) {
+    const int w = blockIdx.x * blockDim.x + threadIdx.x;
+    if (w < n_list) { const int c = list[w]; status[c] = tmp[c]; }
 }
 
 // keeps rows start, start+stride, ... of a row-major int matrix (frontier sharding, mpc_frontier_shard)

@@ -395,7 +395,7 @@ __global__ void __launch_bounds__(64, (NT * SLOTS >= 20 ? 3 : 4)) k_theta2(const
     if (lane == 0) {
         atomicAdd(&ctr->cycles[0], (unsigned long long)cyc_kkt); atomicAdd(&ctr->cycles[1], (unsigned long long)cyc_theta);
         atomicAdd(&ctr->cycles[4], (unsigned long long)cyc_rows); atomicAdd(&ctr->cycles[5], (unsigned long long)cyc_s2);
-        atomicAdd(&ctr->cycles[6], n_box1); atomicAdd(&ctr->cycles[7], n_box2);
+        atomicAdd(&ctr->cycles[6], n_box1); atomicAdd(&ctr->cycles[7], n_box2); atomicAdd(&ctr->n_retry_theta, (unsigned)n_retry);
         atomicAdd(&ctr->pivots, pivots); atomicAdd(&ctr->xtheta_fallbacks, n_retry);
     }
 }

@@ -78,6 +78,8 @@ int odd_at_least(int v) { return (v % 2) ? v : v + 1; }
 struct mpc_handle {
     int device = 0;
     hipStream_t stream = nullptr;
+    hipStream_t stream2 = nullptr;   // side stream: retry kernels of few long-running wavefronts overlap the main pipeline
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     bool own_stream = false;
     int n_cu = 256;
     std::string error;
@@ -96,7 +98,7 @@ struct mpc_handle {
     long long n_needx = 0;
     DevProblem Pf{};          // view for k_verdict2 (small LDS layout: no tableau)
     int lds_f = 0, grid_f = 0;
-    DevBuf retry_list, theta_list, pf_dev, pr2_dev, headd, headi, epool, facet_flags, kkt_code, kkt_L, theta_blocks;
+    DevBuf retry_list, theta_list, vretry_list, status_tmp, pf_dev, pr2_dev, headd, headi, epool, facet_flags, kkt_code, kkt_L, theta_blocks;
     ThetaArgs targs{};
     // (x,theta) dictionary cache: [0]/[1] ping-pong between the level being read (parents) and the level being written
     DevBuf dict_d[2], dict_i[2], dict_stored[2], parent_slot, parent_slot_next;
@@ -260,6 +262,9 @@ int mpc_create(const mpc_problem *p, int32_t device, void *stream, mpc_handle **
     else { HIP_TRY(nullptr, hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking)); h->own_stream = true; }
     for (auto &e : h->ev) HIP_TRY(nullptr, hipEventCreate(&e));
     for (auto &e : h->kev) HIP_TRY(nullptr, hipEventCreate(&e));
+    HIP_TRY(nullptr, hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking));
+    HIP_TRY(nullptr, hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
+    HIP_TRY(nullptr, hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
     h->n_x = nx; h->n_t = nt; h->n_c = nc; h->n_eq = ne; h->n_tc = ntc; h->is_qp = p->Q != nullptr;
     { const char *ev = std::getenv("MPC_FORCE_V1"); h->force_v1 = ev && ev[0] == '1'; }
     { const char *ev = std::getenv("MPC_DEBUG_CYCLES"); h->debug_cycles = ev && ev[0] == '1'; }
@@ -559,11 +564,14 @@ int mpc_destroy(mpc_handle *h) {
     (void)hipSetDevice(h->device);
     (void)hipStreamSynchronize(h->stream);
     for (DevBuf *b : {&h->blocks, &h->iblocks, &h->frontier, &h->children, &h->status, &h->pruned, &h->pruned_new, &h->flag, &h->pos, &h->opt_list,
-                      &h->childmask, &h->count, &h->offset, &h->recd, &h->reci, &h->ctr, &h->scratch, &h->sums, &h->retry_list, &h->pf_dev, &h->pr2_dev, &h->headd, &h->headi, &h->epool, &h->facet_flags, &h->kkt_code, &h->kkt_L, &h->theta_blocks, &h->theta_list, &h->dict_d[0], &h->dict_d[1], &h->dict_i[0], &h->dict_i[1],
+                      &h->childmask, &h->count, &h->offset, &h->recd, &h->reci, &h->ctr, &h->scratch, &h->sums, &h->retry_list, &h->pf_dev, &h->pr2_dev, &h->headd, &h->headi, &h->epool, &h->facet_flags, &h->kkt_code, &h->kkt_L, &h->theta_blocks, &h->theta_list, &h->vretry_list, &h->status_tmp, &h->dict_d[0], &h->dict_d[1], &h->dict_i[0], &h->dict_i[1],
                       &h->dict_stored[0], &h->dict_stored[1], &h->parent_slot, &h->parent_slot_next}) b->release();
     for (HostBuf *b : {&h->st_list, &h->st_status, &h->st_hd, &h->st_hi, &h->st_pool, &h->st_fxd, &h->st_fxi, &h->st_rlist}) b->release();
     for (auto &e : h->ev) if (e) (void)hipEventDestroy(e);
     for (auto &e : h->kev) if (e) (void)hipEventDestroy(e);
+    if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
+    if (h->ev_join) (void)hipEventDestroy(h->ev_join);
+    if (h->stream2) { (void)hipStreamSynchronize(h->stream2); (void)hipStreamDestroy(h->stream2); }
     if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
     return MPC_OK;
@@ -808,6 +816,24 @@ int mpc_level_run(mpc_handle *h, int32_t gen_children, mpc_level_stats *stats) {
                 kernel_timed[0] = true;
                 HIP_TRY(h, hipGetLastError());
             }
+            // The theta kernel's numerically doubtful candidates (status 7) are re-solved by the LDS engine, which can
+            // refactorise its basis: a few hundred long-running wavefronts.  They run on the side stream while the (x,theta)
+            // stage fills the GPU; their results are applied to the status array after the join.
+            int32_t n_early = 0;
+            if (n_theta > 0) {
+                { int rcs = compact(ST_RETRY, ST_RETRY, &n_early); if (rcs) return rcs; }
+                if (n_early > 0) {
+                    HIP_TRY(h, h->vretry_list.ensure(nn * sizeof(int32_t), st));
+                    HIP_TRY(h, h->status_tmp.ensure(nn, st));
+                    std::swap(h->vretry_list, h->retry_list);
+                    HIP_TRY(h, hipEventRecord(h->ev_fork, st));
+                    HIP_TRY(h, hipStreamWaitEvent(h->stream2, h->ev_fork, 0));
+                    hipLaunchKernelGGL(k_verdict, dim3((unsigned)std::min<long long>(n_early, h->grid_v)), dim3(64), h->lds_v, h->stream2, h->Pv,
+                                       h->frontier.as<int32_t>(), (long long)n_early, k, h->status_tmp.as<uint8_t>(), ctr, h->vretry_list.as<int32_t>());
+                    HIP_TRY(h, hipGetLastError());
+                    HIP_TRY(h, hipEventRecord(h->ev_join, h->stream2));
+                }
+            }
             // ---- (x,theta) stage with the dictionary cache -------------------------------------------------------------
             const int nxc = h->fast_x >= 2 ? 32 : 16;
             h->dict_stride_d = 2LL * nxc * h->Pf.n_d0r;   // column-major tableau + row-major copy
@@ -881,8 +907,16 @@ int mpc_level_run(mpc_handle *h, int32_t gen_children, mpc_level_stats *stats) {
                 kernel_timed[1] = true;
                 n_x_items = n_needx;
             }
-            // numerically doubtful candidates (status 7) go through the LDS engine, which can refactorise its basis
+            // doubtful candidates of the (x,theta) stage (rare) take the same route on the main stream
             int32_t n_retry = 0;
+            if (n_early > 0) {
+                // the early retries still carry status 7: mark them so that this compaction does not pick them up again
+                HIP_TRY(h, hipStreamWaitEvent(st, h->ev_join, 0));
+                hipLaunchKernelGGL(k_apply_status, dim3((unsigned)((n_early + 255) / 256)), dim3(256), 0, st, h->vretry_list.as<int32_t>(), (int)n_early,
+                                   h->status_tmp.as<uint8_t>(), stp);
+                HIP_TRY(h, hipGetLastError());
+                HIP_TRY(h, hipMemsetAsync(&ctr->work_retry, 0, sizeof(unsigned int), st));
+            }
             { int rcs = compact(ST_RETRY, ST_RETRY, &n_retry); if (rcs) return rcs; }
             if (n_retry > 0) {
                 hipLaunchKernelGGL(k_verdict, dim3((unsigned)std::min<long long>(n_retry, h->grid_v)), dim3(64), h->lds_v, st, h->Pv,
@@ -974,9 +1008,9 @@ int mpc_level_run(mpc_handle *h, int32_t gen_children, mpc_level_stats *stats) {
         HIP_TRY(h, hipEventElapsedTime(&ms[2], h->ev[2], h->ev[3]));
         for (int i = 0; i < 3; ++i) if (kernel_timed[i]) HIP_TRY(h, hipEventElapsedTime(&kms[i], h->kev[2 * i], h->kev[2 * i + 1]));
         if (h->debug_cycles)
-            std::fprintf(stderr, "[mpc] k=%d n=%lld cycles/cand: kkt %.0f theta %.0f (rows %.0f, stage2 %.0f) x %.0f region %.0f; pivots %.2f; box screen %.3f / %.3f; x quick %.3f\n", k, n,
+            std::fprintf(stderr, "[mpc] k=%d n=%lld cycles/cand: kkt %.0f theta %.0f (rows %.0f, stage2 %.0f) x %.0f region %.0f; pivots %.2f; box screen %.3f / %.3f; x quick %.3f; retries theta %u of %llu\n", k, n,
                          host_ctr.cycles[0] / (double)n, host_ctr.cycles[1] / (double)n, host_ctr.cycles[4] / (double)n, host_ctr.cycles[5] / (double)n,
-                         host_ctr.cycles[2] / (double)n, host_ctr.cycles[3] / (double)n, host_ctr.pivots / (double)n, host_ctr.cycles[6] / (double)n, host_ctr.cycles[7] / (double)n, host_ctr.xtheta_lps / (double)n);
+                         host_ctr.cycles[2] / (double)n, host_ctr.cycles[3] / (double)n, host_ctr.pivots / (double)n, host_ctr.cycles[6] / (double)n, host_ctr.cycles[7] / (double)n, host_ctr.xtheta_lps / (double)n, host_ctr.n_retry_theta, (unsigned long long)host_ctr.xtheta_fallbacks);
         h->n_pruned_new = host_ctr.n_pruned_new;
         h->n_erows = host_ctr.e_rows;
         h->n_regions = (long long)host_ctr.status[ST_REGION];
