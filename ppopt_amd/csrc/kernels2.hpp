@@ -712,6 +712,7 @@ __global__ void __launch_bounds__(64, (SLOTS >= 2 ? 2 : 3)) k_region2(
         if (kk != 0) st = kk == 1 ? ST_INFEASIBLE : ST_SINGULAR;
         int nE = 0, n_om = 0, n_la = 0, n_re = 0, e_off = 0;
         bool retry = false;
+        int reason = 0;
         if (st == ST_REGION) {
             if (P.kkt_mode == 0) x_law_schur(P, k, s);
             const int nlam = k - e, m = nlam + nin + ntc, ldE = nr;
@@ -835,7 +836,7 @@ __global__ void __launch_bounds__(64, (SLOTS >= 2 ? 2 : 3)) k_region2(
                     }
                 }
                 rv = dpp_wave_min(rv);
-                if (!(r1 == LP_OPTIMAL && r2 != 2 && rv > 2 * FULL_DIM_RADIUS)) retry = true;
+                if (!(r1 == LP_OPTIMAL && r2 != 2 && rv > 2 * FULL_DIM_RADIUS)) { retry = true; reason = 1; }
             }
             else if (r1 != LP_OPTIMAL || r2 == 2 || !(radius > FULL_DIM_RADIUS)) st = ST_OPT_NO_REGION;
             // ---- facets: walk the feasible dictionary ------------------------------------------------------------------
@@ -847,7 +848,7 @@ __global__ void __launch_bounds__(64, (SLOTS >= 2 ? 2 : 3)) k_region2(
                     const unsigned long long bc = __ballot(lp.cv == ID_R && lane >= 1 && lane < NC && ((lp.alive >> lane) & 1u));
                     if (bc) lp.drop_col(__ffsll((long long)bc) - 1);
                 }
-                if (rz != LP_OPTIMAL) retry = true;
+                if (rz != LP_OPTIMAL) { retry = true; reason = 2; }
                 auto mark_tight = [&]() {
                     // every slack that is zero at the current vertex belongs to a kept row
                     if (lane >= 1 && lane < NC && ((lp.alive >> lane) & 1u) && lp.cv < m) s.kept[lp.cv] = 1;
@@ -918,9 +919,10 @@ __global__ void __launch_bounds__(64, (SLOTS >= 2 ? 2 : 3)) k_region2(
                     wave_sync();
                     return !__any(!ok);
                 };
-                if (!retry && lp.growth > GROWTH_SAFE && !refactor()) retry = true;   // the Chebyshev walk ended on small pivots
+                if (!retry && lp.growth > GROWTH_SAFE && !refactor()) { retry = true; reason = 3; }   // the Chebyshev walk ended on small pivots
                 if (!retry) mark_tight();
                 int refactors = 0;
+                bool retested = false;   // the current row is being tested a second time, from a freshly factorised dictionary
                 for (int cidx = 0; cidx < m && !retry && st == ST_REGION; ++cidx) {
                     if (s.kept[cidx] != 0) continue;
                     int row = -1;
@@ -929,22 +931,32 @@ __global__ void __launch_bounds__(64, (SLOTS >= 2 ? 2 : 3)) k_region2(
                         const unsigned long long br = __ballot(lp.var[sl] == cidx && lp.kind[sl] == RK_INEQ);
                         if (br) row = __ffsll((long long)br) - 1 + 64 * sl;
                     }
-                    if (row < 0) { retry = true; break; }
+                    if (row < 0) { retry = true; reason = 4; break; }
                     lp.set_kind(row, RK_X0);
                     const int pr = lp.primal(row, -1, false);
                     if (pr == 3) { st = ST_LP_LIMIT; break; }
                     bool kept_c = pr == 4;
                     if (pr != 4) { kept_c = lp.beta(row) <= TOL_FEAS; lp.set_kind(row, RK_INEQ); }
+                    bool rebuild = false;
                     if (lp.growth > GROWTH_SAFE) {
-                        // doubtful pivots: this decision is discarded, the dictionary is rebuilt and the row is tested again
-                        if (++refactors > 8 || !refactor()) { retry = true; break; }
-                        mark_tight();
-                        --cidx;
-                        continue;
+                        if (!retested || lp.growth > 1e6) {
+                            // doubtful pivots: this decision is discarded, the dictionary is rebuilt and the row is tested again
+                            if (retested || ++refactors > 64 || !refactor()) { retry = true; reason = retested ? 5 : 6; break; }
+                            mark_tight();
+                            retested = true;
+                            --cidx;
+                            continue;
+                        }
+                        // The alarm came back although this short run started from a freshly factorised dictionary: the small
+                        // pivot belongs to this row, nothing has accumulated (error <= eps * growth <= 1e-10).  The decision
+                        // stands (the LDS engine accepts under the same condition) and the dictionary is rebuilt before going on.
+                        rebuild = true;
                     }
+                    retested = false;
                     wave_sync();
                     if (lane == 0) s.kept[cidx] = kept_c ? 1 : 2;
                     wave_sync();
+                    if (rebuild && (++refactors > 64 || !refactor())) { retry = true; reason = 6; break; }
                     mark_tight();
                 }
             }
@@ -1003,7 +1015,7 @@ __global__ void __launch_bounds__(64, (SLOTS >= 2 ? 2 : 3)) k_region2(
         }
         if (retry) st = ST_RETRY;
         if (lane == 0) {
-            hi[0] = st; hi[1] = c; hi[2] = nE; hi[3] = n_om; hi[4] = n_la; hi[5] = n_re; hi[6] = e_off; hi[7] = 0;
+            hi[0] = st; hi[1] = c; hi[2] = nE; hi[3] = n_om; hi[4] = n_la; hi[5] = n_re; hi[6] = e_off; hi[7] = reason;
             status[c] = (uint8_t)st;
         }
         cyc += clock64() - t0;

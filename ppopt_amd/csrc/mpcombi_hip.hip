@@ -1197,6 +1197,12 @@ int mpc_level_regions_slots(mpc_handle *h, double *head_d, int32_t *head_i, int6
         }
     }
     HIP_TRY(h, hipStreamSynchronize(s));
+    if (h->debug_cycles && h->used_region2) {
+        long long hist[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (long long w = 0; w < n_opt; ++w) { const int32_t *oi = head_i + (size_t)w * fi; if (oi[0] == ST_RETRY) hist[oi[7] & 7]++; }
+        std::fprintf(stderr, "[mpc] k=%d region retries by reason: chebyshev %lld, r->0 %lld, refactor-after-chebyshev %lld, row lost %lld, >8 refactors %lld, refactor failed %lld\n",
+                     k, hist[1], hist[2], hist[3], hist[4], hist[5], hist[6]);
+    }
     if (n_fixed > 0) {
         // the candidates solved by the LDS-engine kernel come as fixed-stride records: written into their slots here
         const int32_t *list = h->st_list.as<int32_t>(), *rlist = h->st_rlist.as<int32_t>();
