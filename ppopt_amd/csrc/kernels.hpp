@@ -60,6 +60,7 @@ struct LevelCounters {
     unsigned long long xtheta_lps;  // candidates that needed the large (x,theta) LP
     unsigned long long xtheta_fallbacks;  // ... of which the warm start from the pre-crashed vertex was abandoned
     unsigned long long x_cached;    // (x,theta) solves that started from the parent's cached dictionary
+    unsigned long long rcycles[6];  // k_region2: rows, chebyshev, facets, record wave-cycles; refactors; facet pivots
     unsigned long long cycles[8];   // wave-cycles (s_memtime) spent in: KKT solve, theta LP, (x,theta) LP, region build; [4] theta rows, [5] theta stage 2; [6],[7] candidates decided by the box screen (stage 1 / multiplier row)
     unsigned int work_verdict, work_region, n_opt, n_pruned_new, work_retry, work_x, e_rows, work_r2, work_q, n_retry_theta;
 };

@@ -695,7 +695,7 @@ __global__ void __launch_bounds__(64, (SLOTS >= 2 ? 2 : 3)) k_region2(
     constexpr int NC = NT + 3;      // value | n_t sigma columns | r | one spare slot for x0
     constexpr int ID_SIGMA = 4096, ID_R = 8192;
     unsigned long long pivots = 0;
-    long long cyc = 0;
+    long long cyc = 0, rc_rows = 0, rc_cheb = 0, rc_facet = 0, rc_tot = 0, rc_refac = 0, rc_fpiv = 0;
     for (;;) {
         unsigned int w = 0;
         if (lane == 0) w = atomicAdd(&ctr->work_r2, 1u);
@@ -790,6 +790,8 @@ __global__ void __launch_bounds__(64, (SLOTS >= 2 ? 2 : 3)) k_region2(
                 }
             }
             wave_sync();
+            const long long tr1 = clock64();
+            rc_rows += tr1 - t0;
             // ---- full dimensionality: Chebyshev ball ---------------------------------------------------------------
             int r1 = lp.phase1();
             int r2 = 0;
@@ -839,6 +841,9 @@ __global__ void __launch_bounds__(64, (SLOTS >= 2 ? 2 : 3)) k_region2(
                 if (!(r1 == LP_OPTIMAL && r2 != 2 && rv > 2 * FULL_DIM_RADIUS)) { retry = true; reason = 1; }
             }
             else if (r1 != LP_OPTIMAL || r2 == 2 || !(radius > FULL_DIM_RADIUS)) st = ST_OPT_NO_REGION;
+            const long long tr2 = clock64();
+            rc_cheb += tr2 - tr1;
+            const int it_cheb = lp.iters;
             // ---- facets: walk the feasible dictionary ------------------------------------------------------------------
             if (st == ST_REGION && !retry) {
                 lp.set_kind(m, RK_DEAD);                              // the cost row is no longer needed
@@ -878,6 +883,7 @@ __global__ void __launch_bounds__(64, (SLOTS >= 2 ? 2 : 3)) k_region2(
                 auto refactor = [&]() -> bool {
                     const unsigned al = (unsigned)uni((int)lp.alive);
                     if (__popc(al) != nt) return false;
+                    rc_refac++;
                     double *Bm = s.K, *R = s.K + nt * nt;
                     wave_sync();
                     if (lane >= 1 && lane < NC && ((al >> lane) & 1u)) {
@@ -949,8 +955,9 @@ __global__ void __launch_bounds__(64, (SLOTS >= 2 ? 2 : 3)) k_region2(
                         }
                         // The alarm came back although this short run started from a freshly factorised dictionary: the small
                         // pivot belongs to this row, nothing has accumulated (error <= eps * growth <= 1e-10).  The decision
-                        // stands (the LDS engine accepts under the same condition) and the dictionary is rebuilt before going on.
-                        rebuild = true;
+                        // stands (the LDS engine accepts under the same condition); the run's pivots stay in the dictionary, the
+                        // growth monitor starts again, and the next alarm rebuilds it.
+                        lp.growth = 0.0;
                     }
                     retested = false;
                     wave_sync();
@@ -961,6 +968,9 @@ __global__ void __launch_bounds__(64, (SLOTS >= 2 ? 2 : 3)) k_region2(
                 }
             }
             pivots += lp.iters;
+            const long long tr3 = clock64();
+            rc_facet += tr3 - tr2;
+            rc_fpiv += lp.iters - it_cheb;
             // ---- record ----------------------------------------------------------------------------------------------
             if (st == ST_REGION && !retry) {
                 int32_t *act = hi + 8, *om = act + k, *la = om + ntc, *ridx = la + k, *rcon = ridx + (nc - k);
@@ -1013,6 +1023,7 @@ __global__ void __launch_bounds__(64, (SLOTS >= 2 ? 2 : 3)) k_region2(
                 for (int i = lane; i < k; i += 64) act[i] = s.as[i];
             }
         }
+        rc_tot += clock64() - t0;
         if (retry) st = ST_RETRY;
         if (lane == 0) {
             hi[0] = st; hi[1] = c; hi[2] = nE; hi[3] = n_om; hi[4] = n_la; hi[5] = n_re; hi[6] = e_off; hi[7] = reason;
@@ -1020,7 +1031,12 @@ __global__ void __launch_bounds__(64, (SLOTS >= 2 ? 2 : 3)) k_region2(
         }
         cyc += clock64() - t0;
     }
-    if (lane == 0) { atomicAdd(&ctr->pivots, pivots); atomicAdd(&ctr->cycles[3], (unsigned long long)cyc); }
+    if (lane == 0) {
+        atomicAdd(&ctr->pivots, pivots); atomicAdd(&ctr->cycles[3], (unsigned long long)cyc);
+        atomicAdd(&ctr->rcycles[0], (unsigned long long)rc_rows); atomicAdd(&ctr->rcycles[1], (unsigned long long)rc_cheb);
+        atomicAdd(&ctr->rcycles[2], (unsigned long long)rc_facet); atomicAdd(&ctr->rcycles[3], (unsigned long long)rc_tot);
+        atomicAdd(&ctr->rcycles[4], (unsigned long long)rc_refac); atomicAdd(&ctr->rcycles[5], (unsigned long long)rc_fpiv);
+    }
 }
 
 }  // namespace mpc

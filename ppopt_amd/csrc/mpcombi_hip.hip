@@ -1011,6 +1011,10 @@ int mpc_level_run(mpc_handle *h, int32_t gen_children, mpc_level_stats *stats) {
             std::fprintf(stderr, "[mpc] k=%d n=%lld cycles/cand: kkt %.0f theta %.0f (rows %.0f, stage2 %.0f) x %.0f region %.0f; pivots %.2f; box screen %.3f / %.3f; x quick %.3f; retries theta %u of %llu\n", k, n,
                          host_ctr.cycles[0] / (double)n, host_ctr.cycles[1] / (double)n, host_ctr.cycles[4] / (double)n, host_ctr.cycles[5] / (double)n,
                          host_ctr.cycles[2] / (double)n, host_ctr.cycles[3] / (double)n, host_ctr.pivots / (double)n, host_ctr.cycles[6] / (double)n, host_ctr.cycles[7] / (double)n, host_ctr.xtheta_lps / (double)n, host_ctr.n_retry_theta, (unsigned long long)host_ctr.xtheta_fallbacks);
+        if (h->debug_cycles && h->n_opt > 0)
+            std::fprintf(stderr, "[mpc] k=%d region2 per optimal candidate (%lld): rows %.0f chebyshev %.0f facets %.0f total %.0f cycles; refactors %.2f facet pivots %.1f\n", k,
+                         h->n_opt, host_ctr.rcycles[0] / (double)h->n_opt, host_ctr.rcycles[1] / (double)h->n_opt, host_ctr.rcycles[2] / (double)h->n_opt,
+                         host_ctr.rcycles[3] / (double)h->n_opt, host_ctr.rcycles[4] / (double)h->n_opt, host_ctr.rcycles[5] / (double)h->n_opt);
         h->n_pruned_new = host_ctr.n_pruned_new;
         h->n_erows = host_ctr.e_rows;
         h->n_regions = (long long)host_ctr.status[ST_REGION];
