@@ -11,7 +11,7 @@ from typing import Optional
 import numpy
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'csrc', 'libmpcombi_hip.so')
+LIB_PATH = os.environ.get('MPC_LIB_PATH') or os.path.join(_HERE, 'csrc', 'libmpcombi_hip.so')   # MPC_LIB_PATH: A/B builds
 
 MPC_OK, MPC_ERR_INVALID, MPC_ERR_HIP, MPC_ERR_CAPACITY, MPC_ERR_STATE = range(5)
 INFEASIBLE, FEASIBLE, OPTIMAL_NO_REGION, REGION, SINGULAR_KKT, LP_LIMIT = range(6)

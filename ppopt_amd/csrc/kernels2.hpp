@@ -538,6 +538,7 @@ __global__ void __launch_bounds__(64, (NXC * SLOTS >= 32 ? X2_WAVES : 3)) k_x2(c
     const double *d0T = P.d0T;
     const int32_t *d0_rows = P.d0_rows, *d0_cols = P.d0_cols;
     const bool dict_only = dc.dict_only != 0;
+    const bool last_only = !dict_only && dc.cur_d == nullptr;   // nothing is stored: only the verdict is wanted
     unsigned long long pivots = 0, n_retry = 0, n_cached = 0;
     long long cyc_x = 0;
     int sink = 0;
@@ -618,7 +619,7 @@ __global__ void __launch_bounds__(64, (NXC * SLOTS >= 32 ? X2_WAVES : 3)) k_x2(c
                     const unsigned long long br = __ballot(lx.var[sl] == v && lx.kind[sl] == RK_INEQ);
                     if (br) row = __ffsll((long long)br) - 1 + 64 * sl;
                 }
-                if (row >= 0) r = lx.drive_to_zero(row);
+                if (row >= 0) r = lx.drive_to_zero(row, last_only && a + 1 == k);   // last level, last row: the decision is enough
                 else if (!bc) retry = true;
             }
             if (!retry && r == LP_OPTIMAL && !(lx.growth > GROWTH_SAFE) && dc.cur_d) {

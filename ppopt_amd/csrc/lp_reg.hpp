@@ -252,7 +252,9 @@ struct RegLp {
     // 0 optimal, 2 unbounded, 3 iteration limit, 4 x0 left the basis
     // drop_on_leave: when the minimised variable leaves the basis its column is deleted (it stays fixed at zero);
     // false = it stays a regular nonbasic variable (facet tests in k_region2).
-    __device__ __forceinline__ int primal(int phase1_row, int cost_row, bool drop_on_leave = true) {
+    // decide_only: the caller only wants to know whether x0 can leave (last level: the dictionary is not kept) -- the
+    // final pivot is skipped, the tableau is left one pivot behind.
+    __device__ __forceinline__ int primal(int phase1_row, int cost_row, bool drop_on_leave = true, bool decide_only = false) {
         const int lane = lane_id();
         int deg = 0;
         for (;;) {
@@ -338,8 +340,10 @@ struct RegLp {
             const double rmin = row_entry(r, ratio), inv = fast_rcp(rpiv);
             growth = fmax(growth, (double)(colmax * (float)inv));
             deg = (rmin <= 0.0) ? deg + 1 : 0;
-            pivot_core(r, q, a, inv);
-            if (leaving_x0) { set_kind(r, RK_INEQ); if (drop_on_leave) drop_col(q); return 4; }
+            const bool skip = leaving_x0 && decide_only;
+            if (!skip) pivot_core(r, q, a, inv);
+            else iters++;
+            if (leaving_x0) { set_kind(r, RK_INEQ); if (drop_on_leave && !skip) drop_col(q); return 4; }
         }
     }
 
@@ -347,12 +351,13 @@ struct RegLp {
     // simplex run whose objective is that variable (the x0 machinery with the row's own slack in the role of x0).
     // Used to activate a constraint at a feasible vertex.  LP_OPTIMAL (done, column deleted) / LP_INFEASIBLE (its
     // minimum over the polytope is positive) / LP_ITERLIMIT.
-    __device__ __forceinline__ int drive_to_zero(int r) {
+    __device__ __forceinline__ int drive_to_zero(int r, bool decide_only = false) {
         set_kind(r, RK_X0);
-        const int st = primal(r, -1);
+        const int st = primal(r, -1, true, decide_only);
         if (st == 3) return LP_ITERLIMIT;
         if (st != 4) {
             if (beta(r) > TOL_FEAS) return LP_INFEASIBLE;
+            if (decide_only) return LP_OPTIMAL;
             const int qq = best_col(r);
             if (qq < 0) set_kind(r, RK_DEAD);
             else { pivot(r, qq); set_kind(r, RK_INEQ); drop_col(qq); }
