@@ -491,14 +491,14 @@ int mpc_create(const mpc_problem *p, int32_t device, void *stream, mpc_handle **
     {
         const int rows_th = rows_t - nt, rows_x = P.n_d0r;
         const int slots_t = rows_th <= 64 ? 1 : (rows_th <= 128 ? 2 : 0), slots_x = rows_x <= 64 ? 1 : (rows_x <= 128 ? 2 : 0);
-        const int tsel = nt <= 4 ? 0 : (nt <= 10 ? 1 : -1);
+        const int tsel = nt <= 4 ? 0 : (nt <= 8 ? 1 : (nt <= 10 ? 2 : -1));   // kernels are instantiated for n_theta <= 4, 8, 10
         const int xsel = P.n_d0c <= 14 ? 0 : (P.n_d0c <= 30 ? 1 : -1);
         if (P.has_tv && P.has_d0 && slots_t && slots_x && tsel >= 0 && xsel >= 0) {
             h->fast = 1;
             h->fast_t = tsel * 2 + (slots_t - 1);
             h->fast_x = xsel * 2 + (slots_x - 1);
             // zero-padded blocks of k_theta2 (ThetaArgs) for its compile-time NT
-            const int NTP = tsel == 0 ? 4 : 10, LS = NTP + 1;
+            const int NTP = tsel == 0 ? 4 : (tsel == 1 ? 8 : 10), LS = NTP + 1;
             {
                 std::vector<double> tb;
                 const size_t oUVp = tb.size(); tb.resize(tb.size() + (size_t)nc * LS, 0.0);
@@ -789,7 +789,8 @@ int mpc_level_run(mpc_handle *h, int32_t gen_children, mpc_level_stats *stats) {
                 kkc = h->kkt_code.as<uint8_t>(); kkl = h->kkt_L.as<double>();
                 const dim3 g((unsigned)blocks256), b(256);
                 const ThetaArgs ta = h->targs;
-#define MPC_LAUNCH_KKT(K_) case K_: if (h->fast_t >= 2) hipLaunchKernelGGL((k_kkt_thread<K_, 10>), g, b, 0, st, pf, fr, n, h->kkt_code.as<uint8_t>(), h->kkt_L.as<double>(), stp, ta, ctr); \
+#define MPC_LAUNCH_KKT(K_) case K_: if (h->fast_t >= 4) hipLaunchKernelGGL((k_kkt_thread<K_, 10>), g, b, 0, st, pf, fr, n, h->kkt_code.as<uint8_t>(), h->kkt_L.as<double>(), stp, ta, ctr); \
+                                    else if (h->fast_t >= 2) hipLaunchKernelGGL((k_kkt_thread<K_, 8>), g, b, 0, st, pf, fr, n, h->kkt_code.as<uint8_t>(), h->kkt_L.as<double>(), stp, ta, ctr); \
                                     else hipLaunchKernelGGL((k_kkt_thread<K_, 4>), g, b, 0, st, pf, fr, n, h->kkt_code.as<uint8_t>(), h->kkt_L.as<double>(), stp, ta, ctr); break
                 switch (k) { MPC_LAUNCH_KKT(1); MPC_LAUNCH_KKT(2); MPC_LAUNCH_KKT(3); MPC_LAUNCH_KKT(4); MPC_LAUNCH_KKT(5); MPC_LAUNCH_KKT(6); MPC_LAUNCH_KKT(7); MPC_LAUNCH_KKT(8); }
 #undef MPC_LAUNCH_KKT
@@ -809,7 +810,9 @@ int mpc_level_run(mpc_handle *h, int32_t gen_children, mpc_level_stats *stats) {
                 switch (h->fast_t) {
                     case 0: hipLaunchKernelGGL((k_theta2<4, 1>), g, b, h->lds_f, st, pf, fr, n_theta, k, stp, ctr, kkc, kkl, ta, theta_list); break;
                     case 1: hipLaunchKernelGGL((k_theta2<4, 2>), g, b, h->lds_f, st, pf, fr, n_theta, k, stp, ctr, kkc, kkl, ta, theta_list); break;
-                    case 2: hipLaunchKernelGGL((k_theta2<10, 1>), g, b, h->lds_f, st, pf, fr, n_theta, k, stp, ctr, kkc, kkl, ta, theta_list); break;
+                    case 2: hipLaunchKernelGGL((k_theta2<8, 1>), g, b, h->lds_f, st, pf, fr, n_theta, k, stp, ctr, kkc, kkl, ta, theta_list); break;
+                    case 3: hipLaunchKernelGGL((k_theta2<8, 2>), g, b, h->lds_f, st, pf, fr, n_theta, k, stp, ctr, kkc, kkl, ta, theta_list); break;
+                    case 4: hipLaunchKernelGGL((k_theta2<10, 1>), g, b, h->lds_f, st, pf, fr, n_theta, k, stp, ctr, kkc, kkl, ta, theta_list); break;
                     default: hipLaunchKernelGGL((k_theta2<10, 2>), g, b, h->lds_f, st, pf, fr, n_theta, k, stp, ctr, kkc, kkl, ta, theta_list); break;
                 }
                 HIP_TRY(h, hipEventRecord(h->kev[1], st));
@@ -954,7 +957,9 @@ int mpc_level_run(mpc_handle *h, int32_t gen_children, mpc_level_stats *stats) {
             switch (h->fast_r) {
                 case 0: MPC_LAUNCH_R2(4, 1); break;
                 case 1: MPC_LAUNCH_R2(4, 2); break;
-                case 2: MPC_LAUNCH_R2(10, 1); break;
+                case 2: MPC_LAUNCH_R2(8, 1); break;
+                case 3: MPC_LAUNCH_R2(8, 2); break;
+                case 4: MPC_LAUNCH_R2(10, 1); break;
                 default: MPC_LAUNCH_R2(10, 2); break;
             }
 #undef MPC_LAUNCH_R2
