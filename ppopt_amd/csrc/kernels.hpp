@@ -62,7 +62,7 @@ struct LevelCounters {
     unsigned long long x_cached;    // (x,theta) solves that started from the parent's cached dictionary
     unsigned long long rcycles[6];  // k_region2: rows, chebyshev, facets, record wave-cycles; refactors; facet pivots
     unsigned long long cycles[8];   // wave-cycles (s_memtime) spent in: KKT solve, theta LP, (x,theta) LP, region build; [4] theta rows, [5] theta stage 2; [6],[7] candidates decided by the box screen (stage 1 / multiplier row)
-    unsigned int work_verdict, work_region, n_opt, n_pruned_new, work_retry, work_x, e_rows, work_r2, work_q, n_retry_theta;
+    unsigned int work_verdict, work_region, n_opt, n_pruned_new, work_retry, work_x, e_rows, work_r2, work_q, n_retry_theta, n_rretry;
 };
 
 struct Smem {
@@ -642,6 +642,66 @@ __global__ void __launch_bounds__(1024) k_scan_apply(const int32_t *__restrict__
     const long long i = blockIdx.x * (long long)SCAN_BLOCK + threadIdx.x;
     const int ex = block_exclusive_scan_1024(i < n ? in[i] : 0, nullptr);
     if (i < n) out[i] = ex + sums[blockIdx.x];
+}
+
+// ---- deterministic multi-class partition by status -----------------------------------------------------------------------
+// spec: 16 nibbles, nibble s = class (0..3) of status s, 15 = not listed.  Three launches produce up to four index lists in
+// frontier order (lists + c*n) and their lengths, instead of one flag/scan/scatter round per class.
+constexpr int PART_CLASSES = 4;
+__device__ __forceinline__ int part_class(unsigned long long spec, int st) { return (int)((spec >> (4 * (st & 15))) & 15ull); }
+__global__ void __launch_bounds__(1024) k_part_count(const uint8_t *__restrict__ status, long long n, unsigned long long spec,
+                                                     int32_t *__restrict__ blockcounts, int nb) {
+    __shared__ int wc[16][PART_CLASSES];
+    const long long i = blockIdx.x * 1024LL + threadIdx.x;
+    const int cls = i < n ? part_class(spec, status[i]) : 15;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+#pragma unroll
+    for (int c = 0; c < PART_CLASSES; ++c) {
+        const unsigned long long m = __ballot(cls == c);
+        if (lane == 0) wc[wave][c] = __popcll(m);
+    }
+    __syncthreads();
+    if (threadIdx.x < PART_CLASSES) {
+        int tot = 0;
+        for (int w = 0; w < 16; ++w) tot += wc[w][threadIdx.x];
+        blockcounts[threadIdx.x * nb + blockIdx.x] = tot;
+    }
+}
+// grid = PART_CLASSES blocks: exclusive scan of each class's block counts in place, totals[c] = list length
+__global__ void __launch_bounds__(1024) k_part_sums(int32_t *__restrict__ blockcounts, int nb, int32_t *__restrict__ totals) {
+    __shared__ int tot;
+    int32_t *sums = blockcounts + (size_t)blockIdx.x * nb;
+    int carry = 0;
+    for (int base = 0; base < nb; base += SCAN_BLOCK) {
+        const int i = base + threadIdx.x;
+        const int v = i < nb ? sums[i] : 0;
+        const int ex = block_exclusive_scan_1024(v, &tot);
+        __syncthreads();
+        if (i < nb) sums[i] = ex + carry;
+        carry += tot;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) totals[blockIdx.x] = carry;
+}
+__global__ void __launch_bounds__(1024) k_part_scatter(const uint8_t *__restrict__ status, long long n, unsigned long long spec,
+                                                       const int32_t *__restrict__ blockbase, int nb, int32_t *__restrict__ lists) {
+    __shared__ int wc[16][PART_CLASSES];
+    const long long i = blockIdx.x * 1024LL + threadIdx.x;
+    const int cls = i < n ? part_class(spec, status[i]) : 15;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    int within = 0;
+#pragma unroll
+    for (int c = 0; c < PART_CLASSES; ++c) {
+        const unsigned long long m = __ballot(cls == c);
+        if (lane == 0) wc[wave][c] = __popcll(m);
+        if (cls == c) within = __popcll(m & ((1ull << lane) - 1ull));
+    }
+    __syncthreads();
+    if (cls < PART_CLASSES) {
+        int before = 0;
+        for (int w = 0; w < wave; ++w) before += wc[w][cls];
+        lists[(size_t)cls * n + blockbase[cls * nb + blockIdx.x] + before + within] = (int32_t)i;
+    }
 }
 
 __global__ void k_flag_status(const uint8_t *__restrict__ status, long long n, int lo, int hi, int32_t *__restrict__ flag) {

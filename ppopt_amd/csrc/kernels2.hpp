@@ -1025,7 +1025,7 @@ __global__ void __launch_bounds__(64, (SLOTS >= 2 ? 2 : 3)) k_region2(
             }
         }
         rc_tot += clock64() - t0;
-        if (retry) st = ST_RETRY;
+        if (retry) { st = ST_RETRY; if (lane == 0) atomicAdd(&ctr->n_rretry, 1u); }
         if (lane == 0) {
             hi[0] = st; hi[1] = c; hi[2] = nE; hi[3] = n_om; hi[4] = n_la; hi[5] = n_re; hi[6] = e_off; hi[7] = reason;
             status[c] = (uint8_t)st;

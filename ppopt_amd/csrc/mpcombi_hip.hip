@@ -98,7 +98,7 @@ struct mpc_handle {
     long long n_needx = 0;
     DevProblem Pf{};          // view for k_verdict2 (small LDS layout: no tableau)
     int lds_f = 0, grid_f = 0;
-    DevBuf retry_list, theta_list, vretry_list, status_tmp, pf_dev, pr2_dev, headd, headi, epool, facet_flags, kkt_code, kkt_L, theta_blocks;
+    DevBuf retry_list, theta_list, vretry_list, status_tmp, part_counts, part_lists, pf_dev, pr2_dev, headd, headi, epool, facet_flags, kkt_code, kkt_L, theta_blocks;
     ThetaArgs targs{};
     // (x,theta) dictionary cache: [0]/[1] ping-pong between the level being read (parents) and the level being written
     DevBuf dict_d[2], dict_i[2], dict_stored[2], parent_slot, parent_slot_next;
@@ -564,7 +564,7 @@ int mpc_destroy(mpc_handle *h) {
     (void)hipSetDevice(h->device);
     (void)hipStreamSynchronize(h->stream);
     for (DevBuf *b : {&h->blocks, &h->iblocks, &h->frontier, &h->children, &h->status, &h->pruned, &h->pruned_new, &h->flag, &h->pos, &h->opt_list,
-                      &h->childmask, &h->count, &h->offset, &h->recd, &h->reci, &h->ctr, &h->scratch, &h->sums, &h->retry_list, &h->pf_dev, &h->pr2_dev, &h->headd, &h->headi, &h->epool, &h->facet_flags, &h->kkt_code, &h->kkt_L, &h->theta_blocks, &h->theta_list, &h->vretry_list, &h->status_tmp, &h->dict_d[0], &h->dict_d[1], &h->dict_i[0], &h->dict_i[1],
+                      &h->childmask, &h->count, &h->offset, &h->recd, &h->reci, &h->ctr, &h->scratch, &h->sums, &h->retry_list, &h->pf_dev, &h->pr2_dev, &h->headd, &h->headi, &h->epool, &h->facet_flags, &h->kkt_code, &h->kkt_L, &h->theta_blocks, &h->theta_list, &h->vretry_list, &h->status_tmp, &h->part_counts, &h->part_lists, &h->dict_d[0], &h->dict_d[1], &h->dict_i[0], &h->dict_i[1],
                       &h->dict_stored[0], &h->dict_stored[1], &h->parent_slot, &h->parent_slot_next}) b->release();
     for (HostBuf *b : {&h->st_list, &h->st_status, &h->st_hd, &h->st_hi, &h->st_pool, &h->st_fxd, &h->st_fxi, &h->st_rlist}) b->release();
     for (auto &e : h->ev) if (e) (void)hipEventDestroy(e);
@@ -771,6 +771,25 @@ int mpc_level_run(mpc_handle *h, int32_t gen_children, mpc_level_stats *stats) {
             HIP_TRY(h, hipStreamSynchronize(st));
             return MPC_OK;
         };
+        // deterministic partition of the candidates into up to four lists by status (spec: status -> class nibble, 15 = none);
+        // the lists are h->part_lists + c * n, their lengths come back in counts[]
+        const int nb1024 = (int)((n + 1023) / 1024);
+        auto partition = [&](std::initializer_list<std::pair<int, int>> classes, int32_t counts[PART_CLASSES]) -> int {
+            unsigned long long spec = ~0ull;
+            for (const auto &sc : classes) spec = (spec & ~(15ull << (4 * sc.first))) | ((unsigned long long)sc.second << (4 * sc.first));
+            HIP_TRY(h, h->part_counts.ensure((size_t)PART_CLASSES * nb1024 * sizeof(int32_t), st));
+            HIP_TRY(h, h->part_lists.ensure((size_t)PART_CLASSES * nn * sizeof(int32_t), st));
+            hipLaunchKernelGGL(k_part_count, dim3(nb1024), dim3(1024), 0, st, h->status.as<uint8_t>(), n, spec, h->part_counts.as<int32_t>(), nb1024);
+            hipLaunchKernelGGL(k_part_sums, dim3(PART_CLASSES), dim3(1024), 0, st, h->part_counts.as<int32_t>(), nb1024, total);
+            hipLaunchKernelGGL(k_part_scatter, dim3(nb1024), dim3(1024), 0, st, h->status.as<uint8_t>(), n, spec, h->part_counts.as<int32_t>(), nb1024,
+                               h->part_lists.as<int32_t>());
+            HIP_TRY(h, hipGetLastError());
+            HIP_TRY(h, hipMemcpyAsync(counts, total, PART_CLASSES * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+            HIP_TRY(h, hipStreamSynchronize(st));
+            return MPC_OK;
+        };
+        auto part_list = [&](int c) -> int32_t * { return h->part_lists.as<int32_t>() + (size_t)c * nn; };
+        int32_t n_opt_fast = -1;   // >= 0: the fast path has already built h->opt_list
         // verdict
         const uint8_t *kkc = nullptr;
         const double *kkl = nullptr;
@@ -819,23 +838,24 @@ int mpc_level_run(mpc_handle *h, int32_t gen_children, mpc_level_stats *stats) {
                 kernel_timed[0] = true;
                 HIP_TRY(h, hipGetLastError());
             }
-            // The theta kernel's numerically doubtful candidates (status 7) are re-solved by the LDS engine, which can
-            // refactorise its basis: a few hundred long-running wavefronts.  They run on the side stream while the (x,theta)
-            // stage fills the GPU; their results are applied to the status array after the join.
-            int32_t n_early = 0;
-            if (n_theta > 0) {
-                { int rcs = compact(ST_RETRY, ST_RETRY, &n_early); if (rcs) return rcs; }
-                if (n_early > 0) {
-                    HIP_TRY(h, h->vretry_list.ensure(nn * sizeof(int32_t), st));
-                    HIP_TRY(h, h->status_tmp.ensure(nn, st));
-                    std::swap(h->vretry_list, h->retry_list);
-                    HIP_TRY(h, hipEventRecord(h->ev_fork, st));
-                    HIP_TRY(h, hipStreamWaitEvent(h->stream2, h->ev_fork, 0));
-                    hipLaunchKernelGGL(k_verdict, dim3((unsigned)std::min<long long>(n_early, h->grid_v)), dim3(64), h->lds_v, h->stream2, h->Pv,
-                                       h->frontier.as<int32_t>(), (long long)n_early, k, h->status_tmp.as<uint8_t>(), ctr, h->vretry_list.as<int32_t>());
-                    HIP_TRY(h, hipGetLastError());
-                    HIP_TRY(h, hipEventRecord(h->ev_join, h->stream2));
-                }
+            // One partition after the theta stage: [0] numerically doubtful (status 7), [1] feasible and [2] optimal (decided
+            // in theta space; they only need a dictionary for their children), [3] feasibility still open.
+            int32_t cntA[PART_CLASSES] = {0, 0, 0, 0};
+            { int rcs = partition({{ST_RETRY, 0}, {ST_FEASIBLE, 1}, {ST_OPT_PENDING, 2}, {ST_NEEDX, 3}, {ST_NEEDX_SING, 3}}, cntA); if (rcs) return rcs; }
+            // The doubtful candidates are re-solved by the LDS engine, which can refactorise its basis: a few hundred
+            // long-running wavefronts.  They run on the side stream while the (x,theta) stage fills the GPU; their results are
+            // applied to the status array after the join.
+            const int32_t n_early = cntA[0];
+            if (n_early > 0) {
+                HIP_TRY(h, h->vretry_list.ensure(nn * sizeof(int32_t), st));
+                HIP_TRY(h, h->status_tmp.ensure(nn, st));
+                HIP_TRY(h, hipMemcpyAsync(h->vretry_list.p, part_list(0), (size_t)n_early * sizeof(int32_t), hipMemcpyDeviceToDevice, st));
+                HIP_TRY(h, hipEventRecord(h->ev_fork, st));
+                HIP_TRY(h, hipStreamWaitEvent(h->stream2, h->ev_fork, 0));
+                hipLaunchKernelGGL(k_verdict, dim3((unsigned)std::min<long long>(n_early, h->grid_v)), dim3(64), h->lds_v, h->stream2, h->Pv,
+                                   h->frontier.as<int32_t>(), (long long)n_early, k, h->status_tmp.as<uint8_t>(), ctr, h->vretry_list.as<int32_t>());
+                HIP_TRY(h, hipGetLastError());
+                HIP_TRY(h, hipEventRecord(h->ev_join, h->stream2));
             }
             // ---- (x,theta) stage with the dictionary cache -------------------------------------------------------------
             const int nxc = h->fast_x >= 2 ? 32 : 16;
@@ -859,13 +879,12 @@ int mpc_level_run(mpc_handle *h, int32_t gen_children, mpc_level_stats *stats) {
                 dc.stored = h->dict_stored[h->dict_cur].as<uint8_t>();
                 h->storing = true;
             }
-            auto launch_x = [&](int n_items, const DictCache &d0) -> int {
+            auto launch_x = [&](const int32_t *ls, int n_items, const DictCache &d0) -> int {
                 HIP_TRY(h, hipMemsetAsync(&ctr->work_x, 0, sizeof(unsigned int), st));
                 DictCache d = d0;
                 const long long grid_x = (long long)h->n_cu * 16;
                 d.chunk = (int)std::max<long long>(1, std::min<long long>(16, n_items / (grid_x * 8)));
                 const dim3 gg((unsigned)std::min<long long>((n_items + d.chunk - 1) / d.chunk, grid_x)), bb(64);
-                const int32_t *ls = h->retry_list.as<int32_t>();
                 switch (h->fast_x) {
                     case 0: hipLaunchKernelGGL((k_x2<16, 1>), gg, bb, 0, st, pf, fr, k, ls, n_items, stp, ctr, d); break;
                     case 1: hipLaunchKernelGGL((k_x2<16, 2>), gg, bb, 0, st, pf, fr, k, ls, n_items, stp, ctr, d); break;
@@ -879,14 +898,11 @@ int mpc_level_run(mpc_handle *h, int32_t gen_children, mpc_level_stats *stats) {
                 // candidates the theta stage already decided (feasible / optimal) expand too: their children get a
                 // dictionary to start from (status untouched)
                 DictCache d2 = dc; d2.dict_only = 1;
-                for (int which : {ST_FEASIBLE, ST_OPT_PENDING}) {
-                    int32_t n_dict = 0;
-                    { int rcs = compact(which, which, &n_dict); if (rcs) return rcs; }
-                    if (n_dict > 0) { int rcs = launch_x(n_dict, d2); if (rcs) return rcs; }
-                }
+                for (int c : {1, 2})
+                    if (cntA[c] > 0) { int rcs = launch_x(part_list(c), cntA[c], d2); if (rcs) return rcs; }
             }
-            int32_t n_needx = 0;
-            { int rcs = compact(ST_NEEDX, ST_NEEDX_SING, &n_needx); if (rcs) return rcs; }
+            int32_t n_needx = cntA[3];
+            const int32_t *needx_list = part_list(3);
             h->n_needx = n_needx;
             if (n_needx > 0 && !h->storing && dc.parent_slot && !h->no_xquick) {
                 // last level: decisions only -- the quick test on three vectors of the parent's dictionary first
@@ -894,17 +910,17 @@ int mpc_level_run(mpc_handle *h, int32_t gen_children, mpc_level_stats *stats) {
                 const long long grid_q = (long long)h->n_cu * 32;
                 dq.chunk = (int)std::max<long long>(1, std::min<long long>(16, n_needx / (grid_q * 4)));
                 const dim3 gg((unsigned)std::min<long long>((n_needx + dq.chunk - 1) / dq.chunk, grid_q)), bb(64);
-                const int32_t *ls = h->retry_list.as<int32_t>();
-                if (h->fast_x & 1) hipLaunchKernelGGL((k_xq<2>), gg, bb, 0, st, pf, fr, k, ls, n_needx, stp, ctr, dq, nxc);
-                else hipLaunchKernelGGL((k_xq<1>), gg, bb, 0, st, pf, fr, k, ls, n_needx, stp, ctr, dq, nxc);
+                if (h->fast_x & 1) hipLaunchKernelGGL((k_xq<2>), gg, bb, 0, st, pf, fr, k, needx_list, n_needx, stp, ctr, dq, nxc);
+                else hipLaunchKernelGGL((k_xq<1>), gg, bb, 0, st, pf, fr, k, needx_list, n_needx, stp, ctr, dq, nxc);
                 HIP_TRY(h, hipGetLastError());
                 int32_t n_left = 0;
                 { int rcs = compact(ST_NEEDX, ST_NEEDX_SING, &n_left); if (rcs) return rcs; }
                 n_needx = n_left;
+                needx_list = h->retry_list.as<int32_t>();
             }
             if (n_needx > 0) {   // feasibility for the candidates left open
                 HIP_TRY(h, hipEventRecord(h->kev[2], st));
-                int rcs = launch_x(n_needx, dc);
+                int rcs = launch_x(needx_list, n_needx, dc);
                 if (rcs) return rcs;
                 HIP_TRY(h, hipEventRecord(h->kev[3], st));
                 kernel_timed[1] = true;
@@ -920,12 +936,19 @@ int mpc_level_run(mpc_handle *h, int32_t gen_children, mpc_level_stats *stats) {
                 HIP_TRY(h, hipGetLastError());
                 HIP_TRY(h, hipMemsetAsync(&ctr->work_retry, 0, sizeof(unsigned int), st));
             }
-            { int rcs = compact(ST_RETRY, ST_RETRY, &n_retry); if (rcs) return rcs; }
+            // second partition: [0] doubtful candidates of the (x,theta) stage, [2] the optimal candidates for the region stage
+            int32_t cntB[PART_CLASSES] = {0, 0, 0, 0};
+            { int rcs = partition({{ST_RETRY, 0}, {ST_OPT_PENDING, 2}}, cntB); if (rcs) return rcs; }
+            n_retry = cntB[0];
             if (n_retry > 0) {
                 hipLaunchKernelGGL(k_verdict, dim3((unsigned)std::min<long long>(n_retry, h->grid_v)), dim3(64), h->lds_v, st, h->Pv,
-                                   h->frontier.as<int32_t>(), (long long)n_retry, k, h->status.as<uint8_t>(), ctr, h->retry_list.as<int32_t>());
+                                   h->frontier.as<int32_t>(), (long long)n_retry, k, h->status.as<uint8_t>(), ctr, part_list(0));
                 HIP_TRY(h, hipGetLastError());
+                { int rcs = partition({{ST_OPT_PENDING, 2}}, cntB); if (rcs) return rcs; }   // they may have turned out optimal
             }
+            n_opt_fast = cntB[2];
+            if (n_opt_fast > 0)
+                HIP_TRY(h, hipMemcpyAsync(h->opt_list.p, part_list(2), (size_t)n_opt_fast * sizeof(int32_t), hipMemcpyDeviceToDevice, st));
         } else {
             hipLaunchKernelGGL(k_verdict, dim3((unsigned)std::min<long long>(n, h->grid_v)), dim3(64), h->lds_v, st, h->Pv,
                                h->frontier.as<int32_t>(), n, k, h->status.as<uint8_t>(), ctr, (const int32_t *)nullptr);
@@ -933,13 +956,15 @@ int mpc_level_run(mpc_handle *h, int32_t gen_children, mpc_level_stats *stats) {
         }
         HIP_TRY(h, hipEventRecord(h->ev[1], st));
         // optimal candidates -> region kernel
-        hipLaunchKernelGGL(k_flag_status, dim3(blocks256), dim3(256), 0, st, h->status.as<uint8_t>(), n, ST_OPT_PENDING, ST_OPT_PENDING, h->flag.as<int32_t>());
-        { int rcs = launch_scan(h, h->flag.as<int32_t>(), h->pos.as<int32_t>(), n, total); if (rcs) return rcs; }
-        hipLaunchKernelGGL(k_scatter_index, dim3(blocks256), dim3(256), 0, st, h->flag.as<int32_t>(), h->pos.as<int32_t>(), n, h->opt_list.as<int32_t>());
-        HIP_TRY(h, hipGetLastError());
-        int32_t n_opt = 0;
-        HIP_TRY(h, hipMemcpyAsync(&n_opt, total, sizeof(int32_t), hipMemcpyDeviceToHost, st));
-        HIP_TRY(h, hipStreamSynchronize(st));
+        int32_t n_opt = n_opt_fast;
+        if (n_opt < 0) {
+            hipLaunchKernelGGL(k_flag_status, dim3(blocks256), dim3(256), 0, st, h->status.as<uint8_t>(), n, ST_OPT_PENDING, ST_OPT_PENDING, h->flag.as<int32_t>());
+            { int rcs = launch_scan(h, h->flag.as<int32_t>(), h->pos.as<int32_t>(), n, total); if (rcs) return rcs; }
+            hipLaunchKernelGGL(k_scatter_index, dim3(blocks256), dim3(256), 0, st, h->flag.as<int32_t>(), h->pos.as<int32_t>(), n, h->opt_list.as<int32_t>());
+            HIP_TRY(h, hipGetLastError());
+            HIP_TRY(h, hipMemcpyAsync(&n_opt, total, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+            HIP_TRY(h, hipStreamSynchronize(st));
+        }
         h->n_opt = n_opt;
         h->used_region2 = false; h->n_rretry = 0; h->n_erows = 0;
         h->fd = h->n_x * h->n_t + h->n_x + k * h->n_t + k;
@@ -967,8 +992,12 @@ int mpc_level_run(mpc_handle *h, int32_t gen_children, mpc_level_stats *stats) {
             kernel_timed[2] = true;
             HIP_TRY(h, hipGetLastError());
             h->used_region2 = true;
+            // candidates k_region2 gave up on (counted by the kernel; normally none): the LDS-engine kernel, fixed-stride records
+            unsigned int n_rr_dev = 0;
+            HIP_TRY(h, hipMemcpyAsync(&n_rr_dev, &ctr->n_rretry, sizeof(unsigned int), hipMemcpyDeviceToHost, st));
+            HIP_TRY(h, hipStreamSynchronize(st));
             int32_t n_rr = 0;
-            { int rcs = compact(ST_RETRY, ST_RETRY, &n_rr); if (rcs) return rcs; }
+            if (n_rr_dev > 0) { int rcs = compact(ST_RETRY, ST_RETRY, &n_rr); if (rcs) return rcs; }
             h->n_rretry = n_rr;
             if (n_rr > 0) {   // numerically doubtful regions: the LDS-engine kernel, fixed-stride records
                 int rcs = launch_region_v1(h, h->retry_list.as<int32_t>(), n_rr, k, ctr);
