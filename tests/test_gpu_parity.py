@@ -5,6 +5,7 @@ Every per-candidate verdict must equal the reference's verdict unless the candid
 conftest.is_knife_edge (the oracle's own verdict flips with the LP tolerance, or the KKT matrix has condition > 1e8);
 the number of knife-edge exceptions is bounded.
 """
+import os
 import warnings
 
 import numpy
@@ -345,7 +346,7 @@ def test_two_way_split_on_one_gpu(name, split_level):
         hist = [sum(int(s.n_status[j]) for s in sts) if sharded else int(sts[0].n_status[j]) for j in range(6)]
         ref_c, ref_s, _ = levels[depth]
         assert n == len(ref_c) and hist == numpy.bincount(ref_s, minlength=6).tolist(), (name, depth)
-        if sharded and depth > split_level:
+        if sharded and depth > split_level and os.environ.get('MPC_FORCE_V1') != '1':
             # every candidate of a sharded level except the rank's first-level ones starts from a cached dictionary
             for s in sts:
                 assert int(s.n_x_cached) > 0 or int(s.n_xtheta_lp) == 0
