@@ -525,6 +525,9 @@ __global__ void __launch_bounds__(64, 8) k_xq(const DevProblem *__restrict__ Pg,
     if (lane == 0) { atomicAdd(&ctr->pivots, pivots); atomicAdd(&ctr->x_cached, n_quick); atomicAdd(&ctr->xtheta_lps, n_quick); }
 }
 
+#ifndef R2W
+#define R2W 3
+#endif
 #ifndef X2_WAVES
 #define X2_WAVES 3
 #endif
@@ -685,7 +688,7 @@ __global__ void __launch_bounds__(64, (NXC * SLOTS >= 32 ? X2_WAVES : 3)) k_x2(c
 // head_i (stride fi): status cand nE n_om n_la n_re e_off 0 | active[k] | omega[n_tc] | lambda[k] | reg_idx[n_c-k] | reg_con[n_c-k]
 // pool row: f, E[0..n_t)
 template <int NT, int SLOTS>
-__global__ void __launch_bounds__(64, (SLOTS >= 2 ? 2 : 3)) k_region2(
+__global__ void __launch_bounds__(64, (SLOTS >= 2 ? 2 : R2W)) k_region2(
     const DevProblem *__restrict__ Pg, const int32_t *__restrict__ cands, int k, const int32_t *__restrict__ opt_list, int n_opt,
     uint8_t *__restrict__ status, double *__restrict__ head_d, int32_t *__restrict__ head_i, int fd, int fi,
     double *__restrict__ epool, LevelCounters *__restrict__ ctr, const uint8_t *__restrict__ kkcode, const double *__restrict__ Lin) {

@@ -6,6 +6,7 @@ views / lists cut out of those arrays the first time they are read (and cached, 
 attributes).  A Solution with 10^4 regions is therefore 10^4 small Python objects and three arrays, not 6*10^4 arrays
 built eagerly inside the solve.
 """
+import itertools
 from typing import List
 
 import numpy
@@ -31,7 +32,7 @@ class RegionBatch:
         return len(self.slots)
 
     def regions(self) -> List['BatchCriticalRegion']:
-        return [BatchCriticalRegion(self, j) for j in self.slots.tolist()]
+        return list(map(BatchCriticalRegion, itertools.repeat(self), self.slots.tolist()))
 
 
 class _Lazy:
