@@ -132,7 +132,7 @@ def main():
 
     def step(profile):
         if distributed:
-            return solve_distributed(engine, prog, profile=profile, max_levels=max_levels)
+            return solve_distributed(engine, prog, profile=profile, max_levels=max_levels, force_shard=args.dist_single)
         return mpqp_hip_combinatorial.solve(prog, device=local_rank, profile=profile, max_levels=max_levels)
 
     # warm-up solves are held together and released together, so that the allocators (the engine's device buffers, the

@@ -5,7 +5,7 @@ BFS level, followed by a merge in the parent (mp_solvers/mpqp_parrallel_combinat
 level are independent, and a child set has exactly ONE generating parent (the set without its largest index), so the
 tree can be split by subtrees without ever producing a candidate twice:
 
-  * replicated phase   while a level is small (< shard_min x world candidates) every rank processes all of it.  The ranks
+  * replicated phase   while a level is small (< shard_min x world candidates, shard_min = 128) every rank processes all of it.  The ranks
                        run the same deterministic kernels on the same data, so they stay identical without talking.
   * split              at the first level that is large enough every rank keeps the candidates rank, rank+world, ... of
                        the (still identical) frontier -- mpc_frontier_shard.  Their parents' dictionaries are in every
@@ -116,6 +116,19 @@ def allgather_rows(t: torch.Tensor, counts: List[int], group=None) -> List[torch
     return [p[:c] for p, c in zip(parts, counts)]
 
 
+def to_host(t: torch.Tensor) -> numpy.ndarray:
+    """Device tensor -> numpy array in pooled page-locked memory (DMA copy); CPU tensors are returned as they are."""
+    if not t.is_cuda:
+        return t.numpy()
+    from . import _lib
+    arr = _lib.pinned_empty(tuple(t.shape), _NP_DTYPE[t.dtype])
+    torch.from_numpy(arr).copy_(t)
+    return arr
+
+
+_NP_DTYPE = {torch.float64: numpy.float64, torch.int32: numpy.int32, torch.int64: numpy.int64}
+
+
 def allgather_table(row: List[int], device, group=None) -> List[List[int]]:
     """One small integer row per rank -> the table of all rows (rank order)."""
     mine = torch.tensor(row, dtype=torch.int64, device=device)
@@ -126,7 +139,7 @@ def allgather_table(row: List[int], device, group=None) -> List[List[int]]:
 
 
 def solve_distributed(engine, program=None, group=None, profile: Optional[List[Dict]] = None,
-                      collect_regions: bool = True, max_levels: Optional[int] = None, shard_min: int = 1024) -> Solution:
+                      collect_regions: bool = True, max_levels: Optional[int] = None, shard_min: int = 128, force_shard: bool = False) -> Solution:
     """The level loop of the parallel combinatorial algorithm over the ranks of ``group`` (see the module docstring).
     Every rank returns the complete Solution.  Works without an initialised process group (world size 1)."""
     active = dist.is_available() and dist.is_initialized()
@@ -144,7 +157,7 @@ def solve_distributed(engine, program=None, group=None, profile: Optional[List[D
     for depth in range(max_depth):
         gen_children = depth + 1 != max_depth
         n, k = engine.frontier_size()
-        if not sharded and world > 1 and n >= shard_min * world:
+        if not sharded and (world > 1 or force_shard) and n >= shard_min * world:   # force_shard: self-test with one rank
             engine.shard(rank, world)
             sharded = True
         st = engine.run(gen_children)
@@ -198,7 +211,7 @@ def solve_distributed(engine, program=None, group=None, profile: Optional[List[D
         er_p = allgather_rows(torch.from_numpy(numpy.ascontiguousarray(er)).to(dev), [r[1] for r in table], group)
         for a, b, c in zip(hd_p, hi_p, er_p):
             if a.shape[0]:
-                solution.critical_regions.extend(RegionBatch(a.cpu().numpy(), b.cpu().numpy(), c.cpu().numpy(), engine.n_x, engine.n_t,
+                solution.critical_regions.extend(RegionBatch(to_host(a), to_host(b), to_host(c), engine.n_x, engine.n_t,
                                                              engine.n_c, engine.n_tc, k).regions())
     # the base active set, on every rank (one candidate; identical result everywhere)
     hist, regs = engine.check_base()

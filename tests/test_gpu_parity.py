@@ -290,7 +290,7 @@ def _dist_worker(name, out):
             prog = build_program(g, Solver())
         eng = HipLevelEngine(prog, 0)
         prof = []
-        sol = solve_distributed(eng, prog, profile=prof)
+        sol = solve_distributed(eng, prog, profile=prof, force_shard=True, shard_min=8)
         out['sets'] = sorted(tuple(r.active_set) for r in sol.critical_regions)
         out['levels'] = [(p['candidates'], p['status'][:5]) for p in prof if p['depth'] > 0]
         eng.close()
