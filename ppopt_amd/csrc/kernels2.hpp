@@ -691,7 +691,11 @@ template <int NT, int SLOTS>
 __global__ void __launch_bounds__(64, (SLOTS >= 2 ? 2 : R2W)) k_region2(
     const DevProblem *__restrict__ Pg, const int32_t *__restrict__ cands, int k, const int32_t *__restrict__ opt_list, int n_opt,
     uint8_t *__restrict__ status, double *__restrict__ head_d, int32_t *__restrict__ head_i, int fd, int fi,
-    double *__restrict__ epool, LevelCounters *__restrict__ ctr, const uint8_t *__restrict__ kkcode, const double *__restrict__ Lin) {
+    double *__restrict__ epool, LevelCounters *__restrict__ ctr, const uint8_t *__restrict__ kkcode, const double *__restrict__ Lin,
+    int W, uint8_t *__restrict__ kept_g, int ldk, unsigned int *__restrict__ done_g) {
+    // W > 1 (few optimal candidates, idle CUs): W wavefronts share one candidate.  Each builds the same dictionary and runs
+    // the same Chebyshev LP (deterministic, identical), then tests only the rows it owns (row % W == part).  The flags go
+    // to kept_g; the wavefront that finishes last (done_g counter) merges them and writes the record.
     const DevProblem &P = *Pg;
     extern __shared__ __attribute__((aligned(16))) double smem[];
     Smem s = carve(P, smem);
@@ -701,10 +705,14 @@ __global__ void __launch_bounds__(64, (SLOTS >= 2 ? 2 : R2W)) k_region2(
     unsigned long long pivots = 0;
     long long cyc = 0, rc_rows = 0, rc_cheb = 0, rc_facet = 0, rc_tot = 0, rc_refac = 0, rc_fpiv = 0;
     for (;;) {
-        unsigned int w = 0;
-        if (lane == 0) w = atomicAdd(&ctr->work_r2, 1u);
-        w = (unsigned)__builtin_amdgcn_readfirstlane((int)w);
-        if (w >= (unsigned)n_opt) break;
+        unsigned int item = 0;
+        if (lane == 0) item = atomicAdd(&ctr->work_r2, 1u);
+        item = (unsigned)__builtin_amdgcn_readfirstlane((int)item);
+        if (item >= (unsigned)n_opt * (unsigned)W) break;
+        const unsigned int w = item / (unsigned)W;
+        const int part = (int)(item - w * (unsigned)W);
+        auto own = [&](int row) -> bool { return W == 1 || row % W == part; };
+        bool is_last = true;
         const long long t0 = clock64();
         const int c = opt_list[w];
         const int nin = load_active_set(P, cands + (size_t)c * k, k, s);
@@ -860,10 +868,10 @@ __global__ void __launch_bounds__(64, (SLOTS >= 2 ? 2 : R2W)) k_region2(
                 if (rz != LP_OPTIMAL) { retry = true; reason = 2; }
                 auto mark_tight = [&]() {
                     // every slack that is zero at the current vertex belongs to a kept row
-                    if (lane >= 1 && lane < NC && ((lp.alive >> lane) & 1u) && lp.cv < m) s.kept[lp.cv] = 1;
+                    if (lane >= 1 && lane < NC && ((lp.alive >> lane) & 1u) && lp.cv < m && own(lp.cv)) s.kept[lp.cv] = 1;
 #pragma unroll
                     for (int sl = 0; sl < SLOTS; ++sl)
-                        if (lp.kind[sl] == RK_INEQ && lp.var[sl] < m && lp.t[sl][0] <= TOL_FEAS) s.kept[lp.var[sl]] = 1;
+                        if (lp.kind[sl] == RK_INEQ && lp.var[sl] < m && lp.t[sl][0] <= TOL_FEAS && own(lp.var[sl])) s.kept[lp.var[sl]] = 1;
                     wave_sync();
                 };
                 // constraint (value h, coefficients g) behind a variable id: a region row or the slack of a vertex row of A_t
@@ -934,7 +942,7 @@ __global__ void __launch_bounds__(64, (SLOTS >= 2 ? 2 : R2W)) k_region2(
                 int refactors = 0;
                 bool retested = false;   // the current row is being tested a second time, from a freshly factorised dictionary
                 for (int cidx = 0; cidx < m && !retry && st == ST_REGION; ++cidx) {
-                    if (s.kept[cidx] != 0) continue;
+                    if (s.kept[cidx] != 0 || !own(cidx)) continue;
                     int row = -1;
 #pragma unroll
                     for (int sl = SLOTS - 1; sl >= 0; --sl) {
@@ -975,8 +983,27 @@ __global__ void __launch_bounds__(64, (SLOTS >= 2 ? 2 : R2W)) k_region2(
             const long long tr3 = clock64();
             rc_facet += tr3 - tr2;
             rc_fpiv += lp.iters - it_cheb;
+            if (W > 1) {
+                // publish the flags of the owned rows, then find out whether this wavefront is the last of its candidate
+                for (int i = lane; i < m; i += 64) if (own(i)) kept_g[(size_t)w * ldk + i] = (uint8_t)s.kept[i];
+                const unsigned fb = (retry ? 1u : 0u) | (st == ST_LP_LIMIT ? 2u : 0u);
+                if (fb && lane == 0) atomicOr(&done_g[2 * w + 1], fb);
+                __threadfence();
+                unsigned prev = 0;
+                if (lane == 0) prev = atomicAdd(&done_g[2 * w], 1u);
+                prev = (unsigned)__builtin_amdgcn_readfirstlane((int)prev);
+                is_last = prev == (unsigned)(W - 1);
+                if (is_last) {
+                    __threadfence();
+                    for (int i = lane; i < m; i += 64) if (!own(i) && s.kept[i] != 3) s.kept[i] = kept_g[(size_t)w * ldk + i];
+                    const unsigned fall = __hip_atomic_load(&done_g[2 * w + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (fall & 1u) retry = true;
+                    if ((fall & 2u) && st == ST_REGION) st = ST_LP_LIMIT;
+                    wave_sync();
+                }
+            }
             // ---- record ----------------------------------------------------------------------------------------------
-            if (st == ST_REGION && !retry) {
+            if (is_last && st == ST_REGION && !retry) {
                 int32_t *act = hi + 8, *om = act + k, *la = om + ntc, *ridx = la + k, *rcon = ridx + (nc - k);
                 // duplicate rows: row i is dropped from E if an earlier kept row has identical (f, E)
                 bool dup[SLOTS], kp[SLOTS];
@@ -1028,8 +1055,8 @@ __global__ void __launch_bounds__(64, (SLOTS >= 2 ? 2 : R2W)) k_region2(
             }
         }
         rc_tot += clock64() - t0;
-        if (retry) { st = ST_RETRY; if (lane == 0) atomicAdd(&ctr->n_rretry, 1u); }
-        if (lane == 0) {
+        if (retry) { st = ST_RETRY; if (lane == 0 && is_last) atomicAdd(&ctr->n_rretry, 1u); }
+        if (lane == 0 && is_last) {
             hi[0] = st; hi[1] = c; hi[2] = nE; hi[3] = n_om; hi[4] = n_la; hi[5] = n_re; hi[6] = e_off; hi[7] = reason;
             status[c] = (uint8_t)st;
         }

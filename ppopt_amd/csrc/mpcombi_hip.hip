@@ -90,6 +90,7 @@ struct mpc_handle {
     DevProblem Pv{}, Pr{};    // verdict / region kernel views (same blocks, different LDS layouts)
     int lds_v = 0, lds_r = 0; // dynamic LDS bytes per wavefront
     int debug_cycles = 0;     // MPC_DEBUG_CYCLES=1: per-level cycle breakdown on stderr
+    int no_rsplit = 0;        // MPC_NO_RSPLIT=1: one wavefront per candidate in k_region2 whatever the load (A/B)
     int no_xquick = 0;        // MPC_NO_XQUICK=1: no quick (x,theta) test on the last level (A/B)
     int no_kkt_thread = 0;    // MPC_NO_KKT_THREAD=1: KKT solves stay inside the wave kernels (A/B)
     int force_v1 = 0;         // MPC_FORCE_V1=1 in the environment: never use k_verdict2 (A/B comparisons, tests)
@@ -98,7 +99,7 @@ struct mpc_handle {
     long long n_needx = 0;
     DevProblem Pf{};          // view for k_verdict2 (small LDS layout: no tableau)
     int lds_f = 0, grid_f = 0;
-    DevBuf retry_list, theta_list, vretry_list, status_tmp, part_counts, part_lists, pf_dev, pr2_dev, headd, headi, epool, facet_flags, kkt_code, kkt_L, theta_blocks;
+    DevBuf retry_list, theta_list, vretry_list, status_tmp, part_counts, part_lists, kept_g, done_g, pf_dev, pr2_dev, headd, headi, epool, facet_flags, kkt_code, kkt_L, theta_blocks;
     ThetaArgs targs{};
     // (x,theta) dictionary cache: [0]/[1] ping-pong between the level being read (parents) and the level being written
     DevBuf dict_d[2], dict_i[2], dict_stored[2], parent_slot, parent_slot_next;
@@ -268,6 +269,7 @@ int mpc_create(const mpc_problem *p, int32_t device, void *stream, mpc_handle **
     h->n_x = nx; h->n_t = nt; h->n_c = nc; h->n_eq = ne; h->n_tc = ntc; h->is_qp = p->Q != nullptr;
     { const char *ev = std::getenv("MPC_FORCE_V1"); h->force_v1 = ev && ev[0] == '1'; }
     { const char *ev = std::getenv("MPC_DEBUG_CYCLES"); h->debug_cycles = ev && ev[0] == '1'; }
+    { const char *ev = std::getenv("MPC_NO_RSPLIT"); h->no_rsplit = ev && ev[0] == '1'; }
     { const char *ev = std::getenv("MPC_NO_XQUICK"); h->no_xquick = ev && ev[0] == '1'; }
     { const char *ev = std::getenv("MPC_NO_KKT_THREAD"); h->no_kkt_thread = ev && ev[0] == '1'; }
     { const char *ev = std::getenv("MPC_DICT_BUDGET_GB"); if (ev) h->dict_budget_gb = std::atof(ev); }
@@ -564,7 +566,7 @@ int mpc_destroy(mpc_handle *h) {
     (void)hipSetDevice(h->device);
     (void)hipStreamSynchronize(h->stream);
     for (DevBuf *b : {&h->blocks, &h->iblocks, &h->frontier, &h->children, &h->status, &h->pruned, &h->pruned_new, &h->flag, &h->pos, &h->opt_list,
-                      &h->childmask, &h->count, &h->offset, &h->recd, &h->reci, &h->ctr, &h->scratch, &h->sums, &h->retry_list, &h->pf_dev, &h->pr2_dev, &h->headd, &h->headi, &h->epool, &h->facet_flags, &h->kkt_code, &h->kkt_L, &h->theta_blocks, &h->theta_list, &h->vretry_list, &h->status_tmp, &h->part_counts, &h->part_lists, &h->dict_d[0], &h->dict_d[1], &h->dict_i[0], &h->dict_i[1],
+                      &h->childmask, &h->count, &h->offset, &h->recd, &h->reci, &h->ctr, &h->scratch, &h->sums, &h->retry_list, &h->pf_dev, &h->pr2_dev, &h->headd, &h->headi, &h->epool, &h->facet_flags, &h->kkt_code, &h->kkt_L, &h->theta_blocks, &h->theta_list, &h->vretry_list, &h->status_tmp, &h->part_counts, &h->part_lists, &h->kept_g, &h->done_g, &h->dict_d[0], &h->dict_d[1], &h->dict_i[0], &h->dict_i[1],
                       &h->dict_stored[0], &h->dict_stored[1], &h->parent_slot, &h->parent_slot_next}) b->release();
     for (HostBuf *b : {&h->st_list, &h->st_status, &h->st_hd, &h->st_hi, &h->st_pool, &h->st_fxd, &h->st_fxi, &h->st_rlist}) b->release();
     for (auto &e : h->ev) if (e) (void)hipEventDestroy(e);
@@ -974,10 +976,19 @@ int mpc_level_run(mpc_handle *h, int32_t gen_children, mpc_level_stats *stats) {
             HIP_TRY(h, h->headd.ensure((size_t)n_opt * h->fd * sizeof(double), st));
             HIP_TRY(h, h->headi.ensure((size_t)n_opt * h->fi * sizeof(int32_t), st));
             HIP_TRY(h, h->epool.ensure((size_t)n_opt * rows_t_ * (h->n_t + 1) * sizeof(double), st));
-            const dim3 g((unsigned)std::min<long long>(n_opt, h->grid_r2)), b(64);
+            // few optimal candidates: several wavefronts per candidate (the facet tests are split among them)
+            const int W = h->no_rsplit ? 1 : ((long long)n_opt * 4 <= h->grid_r2 ? 4 : ((long long)n_opt * 2 <= h->grid_r2 ? 2 : 1));
+            const int ldk = (rows_t_ + 1 + 63) & ~63;
+            if (W > 1) {
+                HIP_TRY(h, h->kept_g.ensure((size_t)n_opt * ldk, st));
+                HIP_TRY(h, h->done_g.ensure((size_t)n_opt * 2 * sizeof(unsigned int), st));
+                HIP_TRY(h, hipMemsetAsync(h->done_g.p, 0, (size_t)n_opt * 2 * sizeof(unsigned int), st));
+            }
+            const dim3 g((unsigned)std::min<long long>((long long)n_opt * W, h->grid_r2)), b(64);
             const DevProblem *pr = h->pr2_dev.as<DevProblem>();
 #define MPC_LAUNCH_R2(NT_, SL_) hipLaunchKernelGGL((k_region2<NT_, SL_>), g, b, h->lds_r2, st, pr, h->frontier.as<int32_t>(), k, h->opt_list.as<int32_t>(), n_opt, \
-                                                   h->status.as<uint8_t>(), h->headd.as<double>(), h->headi.as<int32_t>(), h->fd, h->fi, h->epool.as<double>(), ctr, kkc, kkl)
+                                                   h->status.as<uint8_t>(), h->headd.as<double>(), h->headi.as<int32_t>(), h->fd, h->fi, h->epool.as<double>(), ctr, kkc, kkl, \
+                                                   W, h->kept_g.as<uint8_t>(), ldk, h->done_g.as<unsigned int>())
             HIP_TRY(h, hipEventRecord(h->kev[4], st));
             switch (h->fast_r) {
                 case 0: MPC_LAUNCH_R2(4, 1); break;
