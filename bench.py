@@ -59,8 +59,9 @@ def algorithmic_bytes(prog, k, rho, n_e):
     return P + 4 * k + 8 + rho * R
 
 
-def cpu_baseline(prog, frontiers, target_candidates):
-    """Times the CPU oracle on an evenly strided sample of every level's candidates (same mix as the workload)."""
+def cpu_baseline(prog, frontiers, gpu_status, target_candidates):
+    """Times the CPU oracle on an evenly strided sample of every level's candidates (same mix as the workload) and
+    compares its verdicts with the GPU's for the same candidates."""
     from oracle import oracle as orc
     orc.build()
     P = orc.OracleProblem(prog.A, prog.b, prog.F, prog.c, prog.H, getattr(prog, 'Q', None), prog.A_t, prog.b_t,
@@ -68,24 +69,30 @@ def cpu_baseline(prog, frontiers, target_candidates):
     cores = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
     total = sum(len(f) for f in frontiers)
     frac = min(1.0, target_candidates / max(total, 1))
-    samples = []
+    samples, picks = [], []
     for f in frontiers:
         take = max(1, int(round(frac * len(f))))
         idx = numpy.linspace(0, len(f) - 1, take).astype(numpy.int64)
         samples.append(numpy.ascontiguousarray(f[idx]))
+        picks.append(idx)
     P.check_level(samples[0][:min(8, len(samples[0]))], cores, False)  # warm the thread pool
     t0 = time.perf_counter()
     n = 0
     regions = 0
-    for s in samples:
+    differ = 0
+    for s, idx, gst in zip(samples, picks, gpu_status):
         status, _ = P.check_level(s, cores, False)
         n += len(s)
         regions += int((status == orc.REGION).sum())
+        differ += int((status != gst[idx]).sum())
     dt = time.perf_counter() - t0
     return {'value': n / dt, 'unit': 'candidate active sets checked/s', 'cores': cores, 'kind': 'port',
             'sample': f'{n} candidates ({100 * frac:.1f}% of every BFS level, evenly strided), {dt:.1f} s, '
                       f'{regions} regions; oracle/mpcombi_oracle.c (C port of the reference algorithm, OpenMP)',
-            'regions_per_s': regions / dt}
+            'regions_per_s': regions / dt,
+            'verdicts_differing_from_gpu': differ,
+            'note': 'a differing verdict is a candidate whose decision sits on a tolerance (tests/conftest.py::is_knife_edge); '
+                    'the parity tests bound their number'}
 
 
 def main():
@@ -262,14 +269,15 @@ def main():
         eng = prog.engine(local_rank)
         eng.pruned_clear()
         eng.frontier_root()
-        frontiers = []
+        frontiers, gpu_status = [], []
         for i, p in enumerate(levels):
             frontiers.append(eng.frontier_get())
             gen = i + 1 != len(levels)
             eng.level_run(gen)
+            gpu_status.append(eng.level_status())
             if gen:
                 eng.frontier_advance()
-        out['cpu_baseline'] = cpu_baseline(prog, frontiers, args.cpu_sample)
+        out['cpu_baseline'] = cpu_baseline(prog, frontiers, gpu_status, args.cpu_sample)
     else:
         out['cpu_baseline'] = None
     if rank == 0:

@@ -371,3 +371,47 @@ def test_two_way_split_on_one_gpu(name, split_level):
     for key in a:
         for fld in ('A', 'b', 'C', 'd', 'E', 'f'):
             assert numpy.array_equal(getattr(a[key], fld), getattr(b[key], fld)), (key, fld)
+
+
+@pytest.mark.parametrize('name,levels_, per_level', [('c4_rand_20_8_20_s0', 5, 600), ('c3_quadtank_n10', 4, 500)])
+def test_sampled_deep_levels_match_oracle(oracle, name, levels_, per_level):
+    """Parity below the depth the golden files cover: an evenly strided sample of every level of the bench workloads (the
+    dictionary cache, the screens and the quick tests are all in play there) is re-checked by the CPU oracle -- verdicts
+    bit-exact unless the candidate is knife-edge, and for sampled regions the same facet sets and coefficients."""
+    g = load_golden(name)
+    P = oracle.problem_from_golden(g)
+    eng = engine_from_golden(g)
+    eng.pruned_clear()
+    eng.frontier_root()
+    total = mism = 0
+    for depth in range(levels_):
+        gen = depth + 1 != levels_
+        st = eng.level_run(gen)
+        cands, status = eng.frontier_get(), eng.level_status()
+        idx = numpy.unique(numpy.linspace(0, len(cands) - 1, min(per_level, len(cands))).astype(numpy.int64))
+        # regions are rare on the deep levels: add some to the sample
+        ridx = numpy.flatnonzero(status == 3)
+        idx = numpy.unique(numpy.concatenate([idx, ridx[:: max(1, len(ridx) // 40)]]))
+        ostat, orecs = P.check_level(numpy.ascontiguousarray(cands[idx]), 0, True)
+        hd, hi, er, kk, slots = eng.level_regions_slots()
+        from ppopt_amd.region_batch import RegionBatch
+        mine = {tuple(r.active_set): r for r in RegionBatch(hd, hi, er, eng.n_x, eng.n_t, eng.n_c, eng.n_tc, kk, slots).regions()}
+        for j, (c, v, ov) in enumerate(zip(cands[idx].tolist(), status[idx].tolist(), ostat.tolist())):
+            total += 1
+            if v != ov:
+                assert is_knife_edge(P, c), f'{name} level {depth}: {c} gpu {v} oracle {ov} (robust candidate)'
+                mism += 1
+                continue
+            if v == 3:
+                q, r = orecs[j], mine[tuple(c)]
+                for fld in ('A', 'b', 'C', 'd'):
+                    assert rel_err(getattr(r, fld), q[fld]) <= COEF_TOL, (name, c, fld)
+                if r.omega_set == q['omega_set'] and r.lambda_set == q['lambda_set'] and r.regular_set == q['regular_set']:
+                    assert rows_match(r.E, r.f, q['E'], q['f'], COEF_TOL), (name, c)
+                else:
+                    assert is_knife_edge(P, c, cond_limit=1e6), f'{name}: facet sets differ at robust region {c}'
+        if not gen or st.n_children == 0:
+            break
+        eng.frontier_advance()
+    assert mism <= max(2, total // 500), f'{mism} knife-edge verdicts out of {total}'
+    eng.close()
