@@ -102,6 +102,7 @@ def main():
     ap.add_argument('--warmup', type=int, default=2)
     ap.add_argument('--workload', default='c4', choices=sorted(WORKLOADS))
     ap.add_argument('--cpu-sample', type=int, default=300000, help='candidates in the CPU baseline sample (0 = skip)')
+    ap.add_argument('--locate', type=int, default=100000, help='points of the point-location extra (0 = skip)')
     ap.add_argument('--dist-single', action='store_true', help='run the multi-GPU driver with a process group of one rank (self-test)')
     args = ap.parse_args()
 
@@ -264,6 +265,39 @@ def main():
         if hasattr(cr, 'materialize'):
             cr.materialize()
     out['materialize_all_regions_ms'] = 1e3 * (time.perf_counter() - t_mat)
+    if rank == 0 and not distributed and args.locate > 0 and regions:
+        # consumer of the path: point location + evaluation of x*(theta) over the solution, batched on the GPU;
+        # beside it the reference's loop (Solution.get_region, numpy per region) on a few points.  Not part of `value`.
+        rng = numpy.random.default_rng(0)
+        nt = prog.num_t()
+        # sample around the Chebyshev centres of random regions so that a good share of the points lies inside the solution
+        picks = rng.integers(0, regions, size=args.locate)
+        ef, row_off, xlaw = sol._stacked()
+        centres = numpy.zeros((64, nt))
+        from ppopt_amd.utils.chebyshev_ball import chebyshev_ball
+        for j in range(64):
+            cr = sol.critical_regions[int(picks[j])]
+            cb = chebyshev_ball(cr.E, cr.f, solver=prog.solver)
+            centres[j] = cb.sol[:nt] if cb is not None else 0.0
+        th = centres[rng.integers(0, 64, size=args.locate)] + 0.05 * rng.standard_normal((args.locate, nt))
+        loc = sol.locator(local_rank)
+        loc.query(th[:1024])
+        tq = time.perf_counter()
+        x_b, idx_b = sol.evaluate_batch(th)
+        wall = time.perf_counter() - tq
+        n_host = 20
+        th0 = time.perf_counter()
+        host_idx = []
+        for p in range(n_host):
+            cr = sol.get_region(th[p].reshape(-1, 1))
+            host_idx.append(-1 if cr is None else next(i for i, r in enumerate(sol.critical_regions) if r is cr))
+        host_dt = time.perf_counter() - th0
+        out['point_location'] = {'points': int(args.locate), 'regions': regions, 'rows': int(row_off[-1]),
+                                 'located': int((idx_b >= 0).sum()), 'kernel_ms': loc.last_ms,
+                                 'points_per_s_kernel': args.locate / max(loc.last_ms, 1e-9) * 1e3,
+                                 'points_per_s_wall': args.locate / wall,
+                                 'host_loop_points_per_s': n_host / host_dt,
+                                 'host_loop_agrees': bool(numpy.array_equal(numpy.array(host_idx), idx_b[:n_host]))}
     if rank == 0 and not distributed and args.cpu_sample > 0:
         # frontiers of every level for the CPU sample: one extra untimed pass
         eng = prog.engine(local_rank)

@@ -89,6 +89,11 @@ def load():
         'mpc_frontier_shard': (ctypes.c_int, [H, ctypes.c_int32, ctypes.c_int32]),
         'mpc_level_slots': (ctypes.c_int64, [H]),
         'mpc_level_regions_slots': (ctypes.c_int, [H, _dp, _ip, ctypes.c_int64, _dp, ctypes.c_int64, _lp, _lp]),
+        'mpc_locator_create': (ctypes.c_int, [ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int64, _lp, _dp, _dp, _dp, _dp, _dp,
+                                               ctypes.POINTER(ctypes.c_void_p)]),
+        'mpc_locator_query': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, _dp, ctypes.c_double, ctypes.c_int32, _lp, _dp,
+                                              ctypes.POINTER(ctypes.c_float)]),
+        'mpc_locator_destroy': (ctypes.c_int, [ctypes.c_void_p]),
         'mpc_host_alloc': (ctypes.c_int, [ctypes.c_uint64, ctypes.POINTER(ctypes.c_void_p)]),
         'mpc_host_free': (ctypes.c_int, [ctypes.c_void_p]),
         'mpc_level_children': (ctypes.c_int, [H, _ip, ctypes.c_int64]),
@@ -115,7 +120,7 @@ EXPORTED_SYMBOLS = ['mpc_device_count', 'mpc_version', 'mpc_last_global_error', 
                     'mpc_frontier_root', 'mpc_frontier_set', 'mpc_frontier_set_device', 'mpc_frontier_info',
                     'mpc_frontier_get', 'mpc_pruned_clear', 'mpc_pruned_add', 'mpc_pruned_add_device',
                     'mpc_pruned_count', 'mpc_pruned_get', 'mpc_level_run', 'mpc_level_status', 'mpc_level_regions', 'mpc_compact_strides',
-                    'mpc_level_regions_compact', 'mpc_frontier_shard', 'mpc_level_slots', 'mpc_level_regions_slots', 'mpc_host_alloc', 'mpc_host_free', 'mpc_level_children', 'mpc_level_children_device', 'mpc_level_pruned_new',
+                    'mpc_level_regions_compact', 'mpc_frontier_shard', 'mpc_level_slots', 'mpc_level_regions_slots', 'mpc_host_alloc', 'mpc_host_free', 'mpc_locator_create', 'mpc_locator_query', 'mpc_locator_destroy', 'mpc_level_children', 'mpc_level_children_device', 'mpc_level_pruned_new',
                     'mpc_level_pruned_new_device', 'mpc_frontier_advance', 'mpc_check_level', 'mpc_lp_solve_batch']
 
 
@@ -405,3 +410,51 @@ def lp_solve_batch(A, b, c, eq_flags, device: int = 0):
     if rc != MPC_OK:
         raise MpcError(f'mpc_lp_solve_batch failed ({rc}): {L.mpc_last_global_error().decode()}')
     return status, x, obj, it
+
+
+class Locator:
+    """Batched point location over stacked critical regions (include/mpcombi.h, mpc_locator_*).
+    ef_rows: [total_rows, n_t+1] = [f | E] stacked; row_off: [n_regions+1]; xlaw: [n_regions, n_x, n_t+1] = [b | A]."""
+
+    def __init__(self, row_off, ef_rows, xlaw, Q=None, c=None, H=None, device: int = 0):
+        self._L = load()
+        self.row_off = numpy.ascontiguousarray(row_off, dtype=numpy.int64)
+        self.ef = _f64(ef_rows)
+        self.xlaw = _f64(xlaw)
+        self.n_regions = len(self.row_off) - 1
+        self.n_x, self.n_t = int(self.xlaw.shape[1]), int(self.xlaw.shape[2]) - 1
+        opt = [None if a is None else _f64(a) for a in (Q, c, H)]
+        self._keep = opt
+        ptr = ctypes.c_void_p()
+        rc = self._L.mpc_locator_create(device, self.n_x, self.n_t, self.n_regions, self.row_off.ctypes.data_as(_lp),
+                                        self.ef.ctypes.data_as(_dp), self.xlaw.ctypes.data_as(_dp),
+                                        *[None if a is None else a.ctypes.data_as(_dp) for a in opt], ctypes.byref(ptr))
+        if rc != MPC_OK:
+            raise MpcError(f'mpc_locator_create failed ({rc}): {self._L.mpc_last_global_error().decode()}')
+        self._h = ptr
+        self.last_ms = 0.0
+
+    def query(self, theta: numpy.ndarray, tol: float = 1e-5, overlapping: bool = False, want_x: bool = True):
+        """theta [m, n_t] -> (region index [m] (-1: none), x [m, n_x] or None)."""
+        th = _f64(theta).reshape(-1, self.n_t)
+        m = len(th)
+        region = numpy.empty(m, dtype=numpy.int64)
+        x = numpy.empty((m, self.n_x)) if want_x else None
+        ms = ctypes.c_float(0.0)
+        rc = self._L.mpc_locator_query(self._h, m, th.ctypes.data_as(_dp), float(tol), int(bool(overlapping)),
+                                       region.ctypes.data_as(_lp), None if x is None else x.ctypes.data_as(_dp), ctypes.byref(ms))
+        if rc != MPC_OK:
+            raise MpcError(f'mpc_locator_query failed ({rc}): {self._L.mpc_last_global_error().decode()}')
+        self.last_ms = float(ms.value)
+        return region, x
+
+    def close(self):
+        if getattr(self, '_h', None):
+            self._L.mpc_locator_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

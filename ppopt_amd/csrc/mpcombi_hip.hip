@@ -21,6 +21,7 @@
 #include "../../include/mpcombi.h"
 #include "kernels.hpp"
 #include "kernels2.hpp"
+#include "locate.hpp"
 
 using namespace mpc;
 
@@ -1526,4 +1527,89 @@ extern "C" int mpc_lp_solve_batch(int32_t device, int64_t n_lp, int32_t m, int32
                                   int32_t shared_b, const double *c, int32_t shared_c, const uint8_t *eq, int32_t *status, double *x,
                                   double *obj, int32_t *iters) {
     return lp_batch_impl(device, n_lp, m, n, A, shared_A, b, shared_b, c, shared_c, eq, status, x, obj, iters, nullptr);
+}
+
+// ---- point location ---------------------------------------------------------------------------------------------------
+struct mpc_locator {
+    int device = 0, n_x = 0, n_t = 0;
+    long long n_regions = 0, n_rows = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    DevBuf row_off, ef, xlaw, Q, c, H, theta, region, x;
+    bool hasQ = false, hasc = false, hasH = false;
+};
+
+extern "C" int mpc_locator_create(int32_t device, int32_t n_x, int32_t n_t, int64_t n_regions, const int64_t *row_off, const double *ef_rows,
+                                  const double *xlaw, const double *Q, const double *c, const double *H, mpc_locator **out) {
+    if (!out || n_x < 1 || n_t < 1 || n_t > 16 || n_regions < 0 || (n_regions > 0 && (!row_off || !ef_rows || !xlaw)))
+        return fail(nullptr, MPC_ERR_INVALID, "mpc_locator_create: bad arguments (1 <= n_t <= 16)");
+    HIP_TRY(nullptr, hipSetDevice(device));
+    mpc_locator *L = new mpc_locator();
+    L->device = device; L->n_x = n_x; L->n_t = n_t; L->n_regions = n_regions;
+    HIP_TRY(nullptr, hipStreamCreateWithFlags(&L->stream, hipStreamNonBlocking));
+    HIP_TRY(nullptr, hipEventCreate(&L->e0));
+    HIP_TRY(nullptr, hipEventCreate(&L->e1));
+    const long long rows = n_regions ? row_off[n_regions] : 0;
+    L->n_rows = rows;
+    auto up = [&](DevBuf &b, const void *src, size_t bytes) -> hipError_t {
+        hipError_t e = b.ensure(std::max<size_t>(bytes, 8), L->stream);
+        if (e != hipSuccess || !bytes) return e;
+        return hipMemcpyAsync(b.p, src, bytes, hipMemcpyHostToDevice, L->stream);
+    };
+    const long long zero = 0;
+    HIP_TRY(nullptr, up(L->row_off, n_regions ? (const void *)row_off : (const void *)&zero, (size_t)(n_regions + 1) * sizeof(int64_t)));
+    HIP_TRY(nullptr, up(L->ef, ef_rows, (size_t)rows * (n_t + 1) * sizeof(double)));
+    HIP_TRY(nullptr, up(L->xlaw, xlaw, (size_t)n_regions * n_x * (n_t + 1) * sizeof(double)));
+    if (Q) { HIP_TRY(nullptr, up(L->Q, Q, (size_t)n_x * n_x * sizeof(double))); L->hasQ = true; }
+    if (c) { HIP_TRY(nullptr, up(L->c, c, (size_t)n_x * sizeof(double))); L->hasc = true; }
+    if (H) { HIP_TRY(nullptr, up(L->H, H, (size_t)n_x * n_t * sizeof(double))); L->hasH = true; }
+    HIP_TRY(nullptr, hipStreamSynchronize(L->stream));
+    *out = L;
+    return MPC_OK;
+}
+
+extern "C" int mpc_locator_query(mpc_locator *L, int64_t m, const double *theta, double tol, int32_t overlapping, int64_t *region, double *x,
+                                 float *ms_locate) {
+    if (!L || m < 0 || (m > 0 && (!theta || !region))) return MPC_ERR_INVALID;
+    if (ms_locate) *ms_locate = 0.0f;
+    if (m == 0) return MPC_OK;
+    HIP_TRY(nullptr, hipSetDevice(L->device));
+    hipStream_t st = L->stream;
+    const int nt = L->n_t, nx = L->n_x;
+    HIP_TRY(nullptr, L->theta.ensure((size_t)m * nt * sizeof(double), st));
+    HIP_TRY(nullptr, L->region.ensure((size_t)m * sizeof(long long), st));
+    HIP_TRY(nullptr, hipMemcpyAsync(L->theta.p, theta, (size_t)m * nt * sizeof(double), hipMemcpyHostToDevice, st));
+    const dim3 g((unsigned)((m + 255) / 256)), b(256);
+    const double *Q = L->hasQ ? L->Q.as<double>() : nullptr, *c = L->hasc ? L->c.as<double>() : nullptr, *H = L->hasH ? L->H.as<double>() : nullptr;
+    HIP_TRY(nullptr, hipEventRecord(L->e0, st));
+#define MPC_LOCATE(NT_) hipLaunchKernelGGL((k_locate<NT_>), g, b, 0, st, (long long)m, nt, nx, L->n_regions, L->row_off.as<long long>(), L->ef.as<double>(), \
+                                           L->xlaw.as<double>(), Q, c, H, L->theta.as<double>(), tol, (int)overlapping, L->region.as<long long>())
+    if (nt <= 4) MPC_LOCATE(4); else if (nt <= 8) MPC_LOCATE(8); else MPC_LOCATE(16);
+#undef MPC_LOCATE
+    HIP_TRY(nullptr, hipGetLastError());
+    HIP_TRY(nullptr, hipEventRecord(L->e1, st));
+    HIP_TRY(nullptr, hipMemcpyAsync(region, L->region.p, (size_t)m * sizeof(long long), hipMemcpyDeviceToHost, st));
+    if (x) {
+        HIP_TRY(nullptr, L->x.ensure((size_t)m * nx * sizeof(double), st));
+        const long long tot = (long long)m * nx;
+        hipLaunchKernelGGL(k_evaluate, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, (long long)m, nt, nx, L->xlaw.as<double>(), L->theta.as<double>(),
+                           L->region.as<long long>(), L->x.as<double>());
+        HIP_TRY(nullptr, hipGetLastError());
+        HIP_TRY(nullptr, hipMemcpyAsync(x, L->x.p, (size_t)m * nx * sizeof(double), hipMemcpyDeviceToHost, st));
+    }
+    HIP_TRY(nullptr, hipStreamSynchronize(st));
+    if (ms_locate) HIP_TRY(nullptr, hipEventElapsedTime(ms_locate, L->e0, L->e1));
+    return MPC_OK;
+}
+
+extern "C" int mpc_locator_destroy(mpc_locator *L) {
+    if (!L) return MPC_OK;
+    (void)hipSetDevice(L->device);
+    if (L->stream) (void)hipStreamSynchronize(L->stream);
+    for (DevBuf *b : {&L->row_off, &L->ef, &L->xlaw, &L->Q, &L->c, &L->H, &L->theta, &L->region, &L->x}) b->release();
+    if (L->e0) (void)hipEventDestroy(L->e0);
+    if (L->e1) (void)hipEventDestroy(L->e1);
+    if (L->stream) (void)hipStreamDestroy(L->stream);
+    delete L;
+    return MPC_OK;
 }

@@ -42,6 +42,70 @@ class Solution:
         x = self.evaluate(theta_point)
         return None if x is None else self.program.evaluate_objective(x, theta_point)
 
+    # ---- batched point location on the device (the loop of get_region / evaluate over many parameter points) --------------
+    def _stacked(self):
+        """([f | E] rows of all regions, row offsets, [b | A] of all regions), in list order."""
+        from .region_batch import BatchCriticalRegion
+        regs = self.critical_regions
+        n_t = self.program.num_t() if self.program is not None else regs[0].E.shape[1]
+        ef_parts, cnt, xl_parts = [], [], []
+        i = 0
+        while i < len(regs):
+            r = regs[i]
+            if isinstance(r, BatchCriticalRegion) and '_batch' in r.__dict__:
+                # a run of regions backed by the same level arrays: cut everything out with index arithmetic
+                B = r._batch
+                j = i
+                while j < len(regs) and isinstance(regs[j], BatchCriticalRegion) and regs[j].__dict__.get('_batch') is B:
+                    j += 1
+                slots = numpy.fromiter((q._j for q in regs[i:j]), dtype=numpy.int64, count=j - i)
+                nE, off = B.hi[slots, 2].astype(numpy.int64), B.hi[slots, 6].astype(numpy.int64)
+                rows = numpy.repeat(off - numpy.concatenate([[0], numpy.cumsum(nE)[:-1]]), nE) + numpy.arange(int(nE.sum()))
+                ef_parts.append(B.er[rows])
+                cnt.append(nE)
+                A = B.hd[slots, B.oA:B.ob].reshape(len(slots), B.n_x, B.n_t)
+                b = B.hd[slots, B.ob:B.oC].reshape(len(slots), B.n_x, 1)
+                xl_parts.append(numpy.concatenate([b, A], axis=2))
+                i = j
+            else:
+                ef_parts.append(numpy.hstack([numpy.asarray(r.f, dtype=float).reshape(-1, 1), numpy.asarray(r.E, dtype=float).reshape(-1, n_t)]))
+                cnt.append(numpy.array([ef_parts[-1].shape[0]], dtype=numpy.int64))
+                xl_parts.append(numpy.concatenate([numpy.asarray(r.b, dtype=float).reshape(1, -1, 1),
+                                                   numpy.asarray(r.A, dtype=float).reshape(1, -1, n_t)], axis=2))
+                i += 1
+        counts = numpy.concatenate(cnt) if cnt else numpy.zeros(0, dtype=numpy.int64)
+        row_off = numpy.concatenate([[0], numpy.cumsum(counts)]).astype(numpy.int64)
+        return numpy.vstack(ef_parts), row_off, numpy.concatenate(xl_parts, axis=0)
+
+    def locator(self, device: int = 0):
+        """The device-resident copy of the regions; rebuilt when the region list has changed."""
+        from . import _lib
+        key = (len(self.critical_regions), id(self.critical_regions[0]) if self.critical_regions else 0,
+               id(self.critical_regions[-1]) if self.critical_regions else 0, device)
+        if getattr(self, '_locator_key', None) != key:
+            if getattr(self, '_locator', None) is not None:
+                self._locator.close()
+            ef, row_off, xlaw = self._stacked()
+            P = self.program
+            self._locator = _lib.Locator(row_off, ef, xlaw, getattr(P, 'Q', None), getattr(P, 'c', None), getattr(P, 'H', None), device)
+            self._locator_key = key
+        return self._locator
+
+    def get_region_batch(self, theta_points: numpy.ndarray, device: int = 0) -> numpy.ndarray:
+        """Index into critical_regions of get_region(theta) for every row of theta_points (-1: no region)
+        (solution.py:60-112, all points at once on the GPU)."""
+        if not self.critical_regions:
+            return numpy.full(len(numpy.atleast_2d(theta_points)), -1, dtype=numpy.int64)
+        return self.locator(device).query(theta_points, self.point_location_tolerance, self.is_overlapping, want_x=False)[0]
+
+    def evaluate_batch(self, theta_points: numpy.ndarray, device: int = 0):
+        """(x* [m, n_x] (NaN rows where no region contains the point), region index [m])  -- evaluate() for many points."""
+        th = numpy.atleast_2d(numpy.asarray(theta_points, dtype=float))
+        if not self.critical_regions:
+            return numpy.full((len(th), 0), numpy.nan), numpy.full(len(th), -1, dtype=numpy.int64)
+        region, x = self.locator(device).query(th, self.point_location_tolerance, self.is_overlapping, want_x=True)
+        return x, region
+
     def theta_dim(self) -> int:
         return self.program.num_t()
 

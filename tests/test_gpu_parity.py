@@ -415,3 +415,86 @@ def test_sampled_deep_levels_match_oracle(oracle, name, levels_, per_level):
         eng.frontier_advance()
     assert mism <= max(2, total // 500), f'{mism} knife-edge verdicts out of {total}'
     eng.close()
+
+
+def _theta_samples(prog, m, seed):
+    """Points in (and a little around) the bounding box of the parameter set {A_t theta <= b_t}."""
+    from scipy.optimize import linprog
+    nt = prog.num_t()
+    lo, hi = numpy.zeros(nt), numpy.zeros(nt)
+    for t in range(nt):
+        c = numpy.zeros(nt); c[t] = 1.0
+        a = linprog(c, A_ub=prog.A_t, b_ub=prog.b_t.ravel(), bounds=(None, None)).fun
+        b = linprog(-c, A_ub=prog.A_t, b_ub=prog.b_t.ravel(), bounds=(None, None)).fun
+        lo[t] = a if a is not None else -1000.0      # unbounded direction: a finite window
+        hi[t] = -b if b is not None else lo[t] + 1000.0
+    rng = numpy.random.default_rng(seed)
+    w = hi - lo
+    return lo - 0.05 * w + rng.random((m, nt)) * 1.1 * w
+
+
+@pytest.mark.parametrize('name,overlapping', [('c2_dblint_n5', False), ('rand_5_3_8_s3', False), ('transport_mpqp', True),
+                                              ('quadtank_n2', False), ('c1_transport_mplp', True), ('rand_6_3_12_s1', True)])
+def test_point_location_matches_host_loop(name, overlapping):
+    """Solution.get_region_batch / evaluate_batch (device) == the reference's loop Solution.get_region / evaluate
+    (solution.py:45-112) for every sampled parameter point: same region index (first match, or lowest objective with
+    ties to the later region when regions may overlap), x* within 1e-12, None <-> -1 / NaN."""
+    from ppopt_amd import Solver
+    from ppopt_amd.mp_solvers import mpqp_hip_combinatorial
+    from test_host_logic import build_program
+    g = load_golden(name)
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        prog = build_program(g, Solver())
+    sol = mpqp_hip_combinatorial.solve(prog)
+    sol.is_overlapping = overlapping
+    assert len(sol.critical_regions) > 0
+    th = _theta_samples(prog, 400, 7)
+    x, idx = sol.evaluate_batch(th)
+    assert numpy.array_equal(idx, sol.get_region_batch(th))
+    n_in = 0
+    for p in range(len(th)):
+        tp = th[p].reshape(-1, 1)
+        cr = sol.get_region(tp)
+        if cr is None:
+            assert idx[p] == -1 and numpy.all(numpy.isnan(x[p]))
+            continue
+        n_in += 1
+        want = next(i for i, r in enumerate(sol.critical_regions) if r is cr)
+        if idx[p] != want:
+            # only possible when the two regions' objectives agree to round-off (overlap mode) or theta sits on a facet
+            assert overlapping and idx[p] >= 0
+            o1 = prog.evaluate_objective(sol.critical_regions[idx[p]].evaluate(tp), tp)
+            o2 = prog.evaluate_objective(cr.evaluate(tp), tp)
+            assert abs(o1 - o2) <= 1e-9 * (1.0 + abs(o2)), (name, p)
+            continue
+        assert numpy.allclose(x[p], cr.evaluate(tp).ravel(), rtol=1e-12, atol=1e-12)
+    assert n_in >= 50   # the sample really exercises the regions
+
+
+def test_point_location_full_size_c4():
+    """9,432 regions of the bench workload, 20,000 points: every located point satisfies its region's rows, x* is primal
+    feasible for the program, points reported as outside violate every region (checked on a subsample), and first-match
+    order is respected (no earlier region contains the point)."""
+    import bench
+    from ppopt_amd.mp_solvers import mpqp_hip_combinatorial
+    prog = bench.build_program('c4')
+    sol = mpqp_hip_combinatorial.solve(prog, max_levels=5)
+    th = _theta_samples(prog, 20000, 3)
+    x, idx = sol.evaluate_batch(th)
+    ef, row_off, xlaw = sol._stacked()
+    tol = sol.point_location_tolerance
+    found = numpy.flatnonzero(idx >= 0)
+    assert len(found) > 100   # the five-level solution covers only part of the parameter set
+    for p in found[:300].tolist():
+        r = int(idx[p])
+        rows = ef[row_off[r]:row_off[r + 1]]
+        assert numpy.all(rows[:, 1:] @ th[p] - rows[:, 0] < tol)
+        assert numpy.all(prog.A @ x[p] <= prog.b.ravel() + prog.F @ th[p] + 1e-6)
+        for q in range(r):
+            rq = ef[row_off[q]:row_off[q + 1]]
+            assert not numpy.all(rq[:, 1:] @ th[p] - rq[:, 0] < tol), (p, q, r)
+    for p in numpy.flatnonzero(idx < 0)[:20].tolist():
+        v = ef[:, 1:] @ th[p] - ef[:, 0]
+        inside_any = numpy.logical_and.reduceat(v < tol, row_off[:-1])
+        assert not inside_any.any()

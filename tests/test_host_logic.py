@@ -164,3 +164,35 @@ def test_region_batch_lazy_fields():
     assert numpy.all(r0.A == 0) and 'Critical region with active set [1, 4]' in repr(r0)
     th = numpy.ones((2, 1))
     assert r1.evaluate(th).shape == (3, 1) and r1.materialize() is r1
+
+
+def test_solution_stacks_regions_for_the_locator():
+    """Solution._stacked (input of mpc_locator_create): [f | E] rows, row offsets and [b | A] of every region in list
+    order -- cut out of the level arrays for batch-backed regions, field by field for plain CriticalRegion objects."""
+    from ppopt_amd.region_batch import RegionBatch
+    from ppopt_amd.solution import Solution
+    rng = numpy.random.default_rng(1)
+    n_x, n_t, n_c, n_tc, k = 3, 2, 5, 4, 2
+    fd = n_x * n_t + n_x + k * n_t + k
+    fi = 8 + k + n_tc + k + 2 * (n_c - k)
+    hd = rng.random((4, fd))
+    hi = -numpy.ones((4, fi), dtype=numpy.int32)
+    er = rng.random((9, n_t + 1))
+    # slots 0, 2, 3 are regions owning rows [5:8], [0:2], [2:5] of the pool (not in slot order); slot 1 is not a region
+    for j, (st, nE, off) in enumerate([(3, 3, 5), (2, 0, 0), (3, 2, 0), (3, 3, 2)]):
+        hi[j, :8] = [st, j, nE, 0, 0, 0, off, 0]
+        hi[j, 8:10] = [0, 1]
+    batch_regs = RegionBatch(hd, hi, er, n_x, n_t, n_c, n_tc, k, numpy.array([0, 2, 3])).regions()
+    plain = CriticalRegion(rng.random((n_x, n_t)), rng.random((n_x, 1)), rng.random((k, n_t)), rng.random((k, 1)),
+                           rng.random((4, n_t)), rng.random((4, 1)), [0, 1], [], [], [[], []])
+
+    class P:
+        def num_t(self):
+            return n_t
+    sol = Solution(P(), [batch_regs[0], plain, batch_regs[1], batch_regs[2]])
+    ef, row_off, xlaw = sol._stacked()
+    assert row_off.tolist() == [0, 3, 7, 9, 12] and ef.shape == (12, n_t + 1) and xlaw.shape == (4, n_x, n_t + 1)
+    for i, r in enumerate(sol.critical_regions):
+        rows = ef[row_off[i]:row_off[i + 1]]
+        assert numpy.array_equal(rows[:, :1], r.f) and numpy.array_equal(rows[:, 1:], r.E)
+        assert numpy.array_equal(xlaw[i][:, :1], r.b) and numpy.array_equal(xlaw[i][:, 1:], r.A)
