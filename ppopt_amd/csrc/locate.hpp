@@ -13,12 +13,19 @@
 
 namespace mpc {
 
+// Rows are staged through LDS in tiles of LOC_TILE rows, loaded cooperatively (coalesced) by the 256 points of a block;
+// with each row come the region it belongs to and the index of the first row of the next region, so that a wavefront
+// which has no lane left inside a region jumps over the rest of its rows.
+constexpr int LOC_TILE = 256;
 template <int NT>
-__global__ void __launch_bounds__(256) k_locate(long long m, int nt, int nx, long long n_regions, const long long *__restrict__ row_off,
+__global__ void __launch_bounds__(256) k_locate(long long m, int nt, int nx, long long n_regions, long long n_rows,
+                                                const int32_t *__restrict__ row_region, const int32_t *__restrict__ row_end,
                                                 const double *__restrict__ ef, const double *__restrict__ xlaw,
                                                 const double *__restrict__ Q, const double *__restrict__ cvec, const double *__restrict__ H,
                                                 const double *__restrict__ theta, double tol, int overlapping,
                                                 long long *__restrict__ region_out) {
+    __shared__ double tile[LOC_TILE][NT + 1];
+    __shared__ int trid[LOC_TILE], tend[LOC_TILE];
     const long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const int nr = nt + 1;
     double th[NT];
@@ -26,32 +33,24 @@ __global__ void __launch_bounds__(256) k_locate(long long m, int nt, int nx, lon
     for (int t = 0; t < NT; ++t) th[t] = (p < m && t < nt) ? theta[p * nt + t] : 0.0;
     long long found = -1;
     double best = INFINITY;
-    bool alive = p < m;
-    for (long long r = 0; r < n_regions; ++r) {
-        if (!overlapping && !__any(alive)) break;   // first-match mode: this wavefront is done
-        bool inside = alive;
-        const long long r0 = row_off[r], r1 = row_off[r + 1];
-        for (long long row = r0; row < r1; ++row) {
-            const double *e = ef + row * nr;
-            double v = -e[0];
-#pragma unroll
-            for (int t = 0; t < NT; ++t) if (t < nt) v = fma(e[1 + t], th[t], v);
-            inside = inside && (v < tol);
-            if (!__any(inside)) break;
-        }
-        if (!inside) continue;
-        if (!overlapping) { found = r; alive = false; continue; }
-        // overlapping regions: objective 1/2 x'Qx + theta'H'x + c'x at x = A theta + b (terms without x are the same for every region)
-        const double *xl = xlaw + (size_t)r * nx * nr;
+    bool alive = p < m, inside = false;
+    int cur = -1;
+    long long i = 0;   // next row of this wavefront (wave-uniform)
+    // the point is inside every row of region `cur`: first match, or candidate for the lowest objective
+    auto commit = [&]() {
+        if (cur < 0 || !inside) return;
+        if (!overlapping) { found = cur; alive = false; return; }
+        // objective 1/2 x'Qx + theta'H'x + c'x at x = A theta + b (terms without x are the same for every region)
+        const double *xl = xlaw + (size_t)cur * nx * nr;
         double obj = 0.0;
-        for (int i = 0; i < nx; ++i) {
-            double xi = xl[i * nr];
+        for (int a = 0; a < nx; ++a) {
+            double xa = xl[a * nr];
 #pragma unroll
-            for (int t = 0; t < NT; ++t) if (t < nt) xi = fma(xl[i * nr + 1 + t], th[t], xi);
-            double g = cvec ? cvec[i] : 0.0;
+            for (int t = 0; t < NT; ++t) if (t < nt) xa = fma(xl[a * nr + 1 + t], th[t], xa);
+            double g = cvec ? cvec[a] : 0.0;
             if (H) {
 #pragma unroll
-                for (int t = 0; t < NT; ++t) if (t < nt) g = fma(H[i * nt + t], th[t], g);
+                for (int t = 0; t < NT; ++t) if (t < nt) g = fma(H[a * nt + t], th[t], g);
             }
             if (Q) {
                 double qx = 0.0;
@@ -59,14 +58,45 @@ __global__ void __launch_bounds__(256) k_locate(long long m, int nt, int nx, lon
                     double xj = xl[j * nr];
 #pragma unroll
                     for (int t = 0; t < NT; ++t) if (t < nt) xj = fma(xl[j * nr + 1 + t], th[t], xj);
-                    qx = fma(Q[i * nx + j], xj, qx);
+                    qx = fma(Q[a * nx + j], xj, qx);
                 }
                 g = fma(0.5, qx, g);
             }
-            obj = fma(g, xi, obj);
+            obj = fma(g, xa, obj);
         }
-        if (obj <= best) { best = obj; found = r; }
+        if (obj <= best) { best = obj; found = cur; }
+    };
+    for (long long tile0 = 0; tile0 < n_rows; tile0 += LOC_TILE) {
+        __syncthreads();
+        {
+            const long long row = tile0 + threadIdx.x;
+            if (row < n_rows) {
+#pragma unroll
+                for (int t = 0; t <= NT; ++t) tile[threadIdx.x][t] = t <= nt ? ef[row * nr + t] : 0.0;
+                trid[threadIdx.x] = row_region[row];
+                tend[threadIdx.x] = row_end[row];
+            }
+        }
+        __syncthreads();
+        const long long tile1 = tile0 + LOC_TILE < n_rows ? tile0 + LOC_TILE : n_rows;
+        while (i < tile1) {
+            const int li = (int)(i - tile0);
+            const int rid = trid[li];
+            if (rid != cur) {
+                commit();
+                cur = rid;
+                inside = overlapping ? (p < m) : alive;
+                if (!overlapping && !__any(alive)) { i = n_rows; break; }   // every lane has its region
+            }
+            double v = -tile[li][0];
+#pragma unroll
+            for (int t = 0; t < NT; ++t) v = fma(tile[li][1 + t], th[t], v);
+            inside = inside && (v < tol);
+            if (!__any(inside)) { i = tend[li]; continue; }   // nobody is left in this region: on to the next one
+            ++i;
+        }
     }
+    commit();
     if (p < m) region_out[p] = found;
 }
 

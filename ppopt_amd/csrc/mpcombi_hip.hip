@@ -1535,7 +1535,7 @@ struct mpc_locator {
     long long n_regions = 0, n_rows = 0;
     hipStream_t stream = nullptr;
     hipEvent_t e0 = nullptr, e1 = nullptr;
-    DevBuf row_off, ef, xlaw, Q, c, H, theta, region, x;
+    DevBuf row_off, row_region, row_end, ef, xlaw, Q, c, H, theta, region, x;
     bool hasQ = false, hasc = false, hasH = false;
 };
 
@@ -1559,6 +1559,11 @@ extern "C" int mpc_locator_create(int32_t device, int32_t n_x, int32_t n_t, int6
     const long long zero = 0;
     HIP_TRY(nullptr, up(L->row_off, n_regions ? (const void *)row_off : (const void *)&zero, (size_t)(n_regions + 1) * sizeof(int64_t)));
     HIP_TRY(nullptr, up(L->ef, ef_rows, (size_t)rows * (n_t + 1) * sizeof(double)));
+    std::vector<int32_t> rr((size_t)std::max<long long>(rows, 1)), re((size_t)std::max<long long>(rows, 1));
+    for (long long r = 0; r < n_regions; ++r)
+        for (long long i = row_off[r]; i < row_off[r + 1]; ++i) { rr[(size_t)i] = (int32_t)r; re[(size_t)i] = (int32_t)row_off[r + 1]; }
+    HIP_TRY(nullptr, up(L->row_region, rr.data(), (size_t)rows * sizeof(int32_t)));
+    HIP_TRY(nullptr, up(L->row_end, re.data(), (size_t)rows * sizeof(int32_t)));
     HIP_TRY(nullptr, up(L->xlaw, xlaw, (size_t)n_regions * n_x * (n_t + 1) * sizeof(double)));
     if (Q) { HIP_TRY(nullptr, up(L->Q, Q, (size_t)n_x * n_x * sizeof(double))); L->hasQ = true; }
     if (c) { HIP_TRY(nullptr, up(L->c, c, (size_t)n_x * sizeof(double))); L->hasc = true; }
@@ -1582,8 +1587,9 @@ extern "C" int mpc_locator_query(mpc_locator *L, int64_t m, const double *theta,
     const dim3 g((unsigned)((m + 255) / 256)), b(256);
     const double *Q = L->hasQ ? L->Q.as<double>() : nullptr, *c = L->hasc ? L->c.as<double>() : nullptr, *H = L->hasH ? L->H.as<double>() : nullptr;
     HIP_TRY(nullptr, hipEventRecord(L->e0, st));
-#define MPC_LOCATE(NT_) hipLaunchKernelGGL((k_locate<NT_>), g, b, 0, st, (long long)m, nt, nx, L->n_regions, L->row_off.as<long long>(), L->ef.as<double>(), \
-                                           L->xlaw.as<double>(), Q, c, H, L->theta.as<double>(), tol, (int)overlapping, L->region.as<long long>())
+#define MPC_LOCATE(NT_) hipLaunchKernelGGL((k_locate<NT_>), g, b, 0, st, (long long)m, nt, nx, L->n_regions, L->n_rows, L->row_region.as<int32_t>(), \
+                                           L->row_end.as<int32_t>(), L->ef.as<double>(), L->xlaw.as<double>(), Q, c, H, L->theta.as<double>(), tol, \
+                                           (int)overlapping, L->region.as<long long>())
     if (nt <= 4) MPC_LOCATE(4); else if (nt <= 8) MPC_LOCATE(8); else MPC_LOCATE(16);
 #undef MPC_LOCATE
     HIP_TRY(nullptr, hipGetLastError());
@@ -1606,7 +1612,7 @@ extern "C" int mpc_locator_destroy(mpc_locator *L) {
     if (!L) return MPC_OK;
     (void)hipSetDevice(L->device);
     if (L->stream) (void)hipStreamSynchronize(L->stream);
-    for (DevBuf *b : {&L->row_off, &L->ef, &L->xlaw, &L->Q, &L->c, &L->H, &L->theta, &L->region, &L->x}) b->release();
+    for (DevBuf *b : {&L->row_off, &L->row_region, &L->row_end, &L->ef, &L->xlaw, &L->Q, &L->c, &L->H, &L->theta, &L->region, &L->x}) b->release();
     if (L->e0) (void)hipEventDestroy(L->e0);
     if (L->e1) (void)hipEventDestroy(L->e1);
     if (L->stream) (void)hipStreamDestroy(L->stream);
