@@ -408,7 +408,7 @@ __global__ void __launch_bounds__(64, (NT * SLOTS >= 20 ? 3 : 4)) k_theta2(const
 // level).  A child (= parent + one larger row) whose parent has a slot loads that dictionary with coalesced column
 // reads and activates ONE row instead of starting from D0 and activating all k.  The kernel then streams ~2 x 9 KB per
 // candidate (config 4) and is bound by HBM bandwidth rather than by pivots.
-// dict layout per slot: doubles [NXC][mr] (column j of row i at j*mr + i) then the same tableau row-major [mr][NXC];
+// dict layout per slot: doubles [NXC][mr] (column j of row i at j*mr + i);
 // ints var[mr] kind[mr] cv[NXC] alive growth_hi growth_lo
 struct DictCache {
     const int32_t *parent_slot;   // per candidate of this level (nullptr: no cache to read)
@@ -420,7 +420,7 @@ struct DictCache {
 };
 // k_xq: the last level's quick (x,theta) test.  No dictionary is stored on the last level, so a candidate only needs a
 // DECISION: the first simplex iteration from the parent's dictionary, evaluated on the three vectors it touches -- the
-// values, the new row (row-major copy) and the entering column -- instead of the whole tableau (~1.3 KB instead of
+// values, the new row (a strided read of one entry per column) and the entering column -- instead of the whole tableau (~1.3 KB instead of
 // ~9 KB per candidate).  Exactly the decision of k_x2 when that iteration is conclusive (slack already nonbasic /
 // already zero / no improving column / the new row itself leaves the basis); otherwise the candidate keeps its NEEDX
 // status and goes to k_x2.  Few registers -> 8 waves per SIMD hide the three dependent HBM round trips.
@@ -479,7 +479,7 @@ __global__ void __launch_bounds__(64, 8) k_xq(const DevProblem *__restrict__ Pg,
                     const double br0 = readlane_f64((SLOTS == 1 || row < 64) ? qb[0] : qb[SLOTS - 1], row & 63);
                     if (br0 <= TOL_FEAS) feas = 1;
                     else {
-                        const double g = (lane >= 1 && lane < NXC) ? pd[(size_t)NXC * mr + (size_t)row * NXC + lane] : 0.0;
+                        const double g = (lane >= 1 && lane < NXC) ? pd[(size_t)lane * mr + row] : 0.0;
                         const double gm = dpp_wave_max(g > TOL_COST ? g : 0.0);
                         if (!(gm > TOL_COST)) feas = 0;
                         else {
@@ -637,10 +637,6 @@ __global__ void __launch_bounds__(64, (NXC * SLOTS >= 32 ? X2_WAVES : 3)) k_x2(c
                         oi[mr + i] = lx.kind[sl];
 #pragma unroll
                         for (int j = 0; j < NXC; ++j) od[(size_t)j * mr + i] = lx.t[sl][j];
-                        // row-major copy for the last level's quick test (a lane writes its row contiguously)
-                        double *orow = od + (size_t)NXC * mr + (size_t)i * NXC;
-#pragma unroll
-                        for (int j = 0; j < NXC; ++j) orow[j] = lx.t[sl][j];
                     }
                 }
                 if (lane < NXC) oi[2 * mr + lane] = lx.cv;

@@ -862,7 +862,7 @@ int mpc_level_run(mpc_handle *h, int32_t gen_children, mpc_level_stats *stats) {
             }
             // ---- (x,theta) stage with the dictionary cache -------------------------------------------------------------
             const int nxc = h->fast_x >= 2 ? 32 : 16;
-            h->dict_stride_d = 2LL * nxc * h->Pf.n_d0r;   // column-major tableau + row-major copy
+            h->dict_stride_d = (long long)nxc * h->Pf.n_d0r;   // column-major tableau
             h->dict_stride_i = 2LL * h->Pf.n_d0r + nxc + 4;
             DictCache dc{};
             dc.stride_d = h->dict_stride_d; dc.stride_i = h->dict_stride_i;
@@ -1080,7 +1080,7 @@ int mpc_level_run(mpc_handle *h, int32_t gen_children, mpc_level_stats *stats) {
         stats->ms_theta = kms[0]; stats->ms_x = kms[1]; stats->ms_region2 = kms[2];
         stats->n_x_items = n_x_items;
         stats->n_opt = h->n_opt;
-        stats->dict_read_bytes = (h->fast && h->have_prev_dict && h->have_parent_slot) ? (h->dict_stride_d / 2) * 8 + h->dict_stride_i * 4 : 0;
+        stats->dict_read_bytes = (h->fast && h->have_prev_dict && h->have_parent_slot) ? h->dict_stride_d * 8 + h->dict_stride_i * 4 : 0;
         stats->dict_write_bytes = (h->fast && h->storing) ? h->dict_stride_d * 8 + h->dict_stride_i * 4 : 0;
         stats->ms_verdict = ms[0]; stats->ms_region = ms[1]; stats->ms_children = ms[2]; stats->ms_total = ms[0] + ms[1] + ms[2];
     }
