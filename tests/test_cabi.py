@@ -59,3 +59,16 @@ def test_product_never_imports_the_oracle():
                 if re.search(r'(^|\s)(from|import)\s+oracle\b', txt, flags=re.M) or 'mpcombi_oracle' in txt:
                     bad.append(os.path.join(dirpath, fn))
     assert not bad, bad
+
+
+def test_vgpr_index_mode_regions_are_closed_and_branch_free():
+    """The register simplex reads / writes a run-time tableau column through the VGPR index mode (lp_reg.hpp).  In the
+    ISA every s_set_gpr_idx_on must be closed by its _off within a few instructions and without control flow in between
+    (tools/check_gpr_idx.py has the story).  Compiles the library's device code once (about a minute)."""
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location('check_gpr_idx', os.path.join(ROOT, 'tools', 'check_gpr_idx.py'))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    total, longest, bad = mod.audit(mod.assembly())
+    assert total > 100 and longest <= 16 and not bad, (total, longest, bad[:5])
