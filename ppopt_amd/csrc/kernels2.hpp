@@ -13,6 +13,12 @@
 
 namespace mpc {
 
+// The theta LP of a candidate is a short run (a handful of pivots) from rows that were just built from the program data:
+// nothing has accumulated, so the error of its final dictionary is bounded by eps * growth * pivots.  It is handed to the
+// refactorising LDS engine only beyond 1e6 (error <= 1e-9, two decades below the feasibility tolerance) -- the LDS engine
+// accepts a freshly refactorised run under the same reasoning.  Dictionaries that live across levels (k_x2's cache) and the
+// long facet walks of k_region2 keep the 1e3 threshold of lp_engine.hpp.
+constexpr double GROWTH_FRESH = 1e6;
 constexpr int ST_RETRY = 7;       // numerically doubtful: re-solve with the LDS engine (k_verdict)
 constexpr int ST_NEEDX = 8;       // theta stage could not show feasibility: (x,theta) LP needed (k_x2)
 constexpr int ST_NEEDX_SING = 9;  // the same, and the KKT matrix was singular (a feasible outcome is ST_SINGULAR)
@@ -372,14 +378,14 @@ __global__ void __launch_bounds__(64, (NT * SLOTS >= 20 ? 3 : 4)) k_theta2(const
             const int r1 = inf1 ? LP_INFEASIBLE : lp.phase1();
             const long long t15 = clock64();
             if (r1 == LP_ITERLIMIT) st = ST_LP_LIMIT;
-            else if (lp.growth > GROWTH_SAFE) retry = true;
+            else if (lp.growth > GROWTH_FRESH) retry = true;
             else if (r1 == LP_OPTIMAL && inf2) st = ST_FEASIBLE;   // feasible, and a multiplier row rules out optimality
             else if (r1 == LP_OPTIMAL) {
 #pragma unroll
                 for (int sl = 0; sl < SLOTS; ++sl) if (lp.kind[sl] == RK_PASSIVE) lp.kind[sl] = RK_INEQ;
                 const int r2 = lp.phase1();
                 if (r2 == LP_ITERLIMIT) st = ST_LP_LIMIT;
-                else if (lp.growth > GROWTH_SAFE) retry = true;
+                else if (lp.growth > GROWTH_FRESH) retry = true;
                 else st = r2 == LP_OPTIMAL ? ST_OPT_PENDING : ST_FEASIBLE;
             }
             pivots += lp.iters;
