@@ -425,11 +425,13 @@ struct DictCache {
     int chunk;       // work items per queue atomic (<= 64)
 };
 // k_xq: the last level's quick (x,theta) test.  No dictionary is stored on the last level, so a candidate only needs a
-// DECISION: the first simplex iteration from the parent's dictionary, evaluated on the three vectors it touches -- the
-// values, the new row (a strided read of one entry per column) and the entering column -- instead of the whole tableau (~1.3 KB instead of
-// ~9 KB per candidate).  Exactly the decision of k_x2 when that iteration is conclusive (slack already nonbasic /
-// already zero / no improving column / the new row itself leaves the basis); otherwise the candidate keeps its NEEDX
-// status and goes to k_x2.  Few registers -> 8 waves per SIMD hide the three dependent HBM round trips.
+// DECISION: up to XQ_ITERS simplex iterations from the parent's dictionary in product form (revised simplex with an eta
+// file), reading only the vectors they touch -- the values, the new row, and per iteration one entering column and one
+// pivot row (~0.3 KB each) -- instead of the whole tableau (~9 KB per candidate).  Exactly the decision of k_x2 when the run
+// ends within those iterations (slack already nonbasic / already zero / no improving column / the new row leaves the
+// basis); otherwise the candidate keeps its NEEDX status and goes to k_x2.  Few registers -> 8 waves per SIMD hide the
+// dependent HBM round trips.
+constexpr int XQ_ITERS = 4;
 template <int SLOTS>
 __global__ void __launch_bounds__(64, 8) k_xq(const DevProblem *__restrict__ Pg, const int32_t *__restrict__ cands, int k,
                                                const int32_t *__restrict__ list, int n_list, uint8_t *__restrict__ status,
@@ -472,6 +474,7 @@ __global__ void __launch_bounds__(64, 8) k_xq(const DevProblem *__restrict__ Pg,
             const double growth0 = __hiloint2double(__builtin_amdgcn_readlane(qcv, NXC + 1), __builtin_amdgcn_readlane(qcv, NXC + 2));
             const unsigned long long bc = __ballot(qcv == v && lane >= 1 && lane < NXC && ((al >> lane) & 1u));
             int feas = -1;   // 1 feasible, 0 infeasible, -1 undecided
+            int piv_local = 0;
             if (bc) feas = 1;
             else {
                 int row = -1;
@@ -482,48 +485,109 @@ __global__ void __launch_bounds__(64, 8) k_xq(const DevProblem *__restrict__ Pg,
                 }
                 if (row >= 0) {
                     row = uni(row);
-                    const double br0 = readlane_f64((SLOTS == 1 || row < 64) ? qb[0] : qb[SLOTS - 1], row & 63);
-                    if (br0 <= TOL_FEAS) feas = 1;
-                    else {
-                        const double g = (lane >= 1 && lane < NXC) ? pd[(size_t)lane * mr + row] : 0.0;
+                    // value of entry `r` of a vector whose element i lives in lane i & 63, slot i >> 6
+                    auto at = [&](const double (&vec)[SLOTS], int r) -> double {
+                        return readlane_f64((SLOTS == 1 || r < 64) ? vec[0] : vec[SLOTS - 1], r & 63);
+                    };
+                    // Up to XQ_ITERS simplex iterations in product form: the tableau is never formed.  Per pivot p the entering
+                    // column as it was (E[p], one entry per row) and the scaled pivot row (R[p], one entry per column) are kept;
+                    // a column or row needed later is read from the parent's dictionary and brought up to date through them,
+                    // with the operations pivot_core (lp_reg.hpp) would have applied to it -- bit for bit k_x2's arithmetic.
+                    double E[XQ_ITERS][SLOTS], R[XQ_ITERS];
+                    int rp[XQ_ITERS], qp[XQ_ITERS];
+                    double invp[XQ_ITERS];
+                    double xrow = (lane < NXC) ? pd[(size_t)lane * mr + row] : 0.0;   // the new row, entry j in lane j
+                    double growth = growth0;
+#pragma unroll
+                    for (int it = 0; it < XQ_ITERS; ++it) {
+                        if (at(qb, row) <= TOL_FEAS) { feas = 1; break; }
+                        const double g = (lane >= 1 && lane < NXC) ? xrow : 0.0;
                         const double gm = dpp_wave_max(g > TOL_COST ? g : 0.0);
-                        if (!(gm > TOL_COST)) feas = 0;
-                        else {
-                            const int q = uni(__ffsll((long long)__ballot(g == gm && lane >= 1 && lane < NXC)) - 1);
-                            double a[SLOTS], ratio[SLOTS];
-                            bool elig[SLOTS];
-                            float cmf = 0.0f;
-                            double tmax = INFINITY;
+                        if (!(gm > TOL_COST)) { feas = 0; break; }
+                        const int q = uni(__ffsll((long long)__ballot(g == gm && lane >= 1 && lane < NXC)) - 1);
+                        // entering column at the current time
+                        double a[SLOTS], ratio[SLOTS];
 #pragma unroll
-                            for (int sl = 0; sl < SLOTS; ++sl) {
-                                const int i = lane + 64 * sl;
-                                a[sl] = i < mr ? pd[(size_t)q * mr + i] : 0.0;
-                                const bool used = i < mr && qkind[sl] != RK_DEAD;
-                                if (used) cmf = fmaxf(cmf, fabsf((float)a[sl]));
-                                elig[sl] = used && qkind[sl] == RK_INEQ && a[sl] > TOL_PIV;
-                                ratio[sl] = 0.0;
-                                if (elig[sl]) {
-                                    const double b0 = fmax(qb[sl], 0.0), ia = fast_rcp(a[sl]);
-                                    ratio[sl] = b0 * ia;
-                                    tmax = fmin(tmax, (b0 + HARRIS_DELTA) * ia);
-                                }
+                        for (int sl = 0; sl < SLOTS; ++sl) { const int i = lane + 64 * sl; a[sl] = i < mr ? pd[(size_t)q * mr + i] : 0.0; }
+#pragma unroll
+                        for (int p_ = 0; p_ < it; ++p_) {
+                            if (q == qp[p_]) {
+#pragma unroll
+                                for (int sl = 0; sl < SLOTS; ++sl) a[sl] = (lane + 64 * sl == rp[p_]) ? 1.0 : 0.0;
                             }
-                            const float colmax = dpp_wave_max_f32(cmf);
-                            tmax = dpp_wave_min(tmax);
-                            bool mine = false;
+                            const double x = at(a, rp[p_]) * invp[p_];
 #pragma unroll
-                            for (int sl = 0; sl < SLOTS; ++sl) mine = mine || (lane + 64 * sl == row && elig[sl] && !(ratio[sl] > tmax));
-                            if (__any(mine)) {
-                                const double rpiv = readlane_f64((SLOTS == 1 || row < 64) ? a[0] : a[SLOTS - 1], row & 63);
-                                const double gr = fmax(growth0, (double)(colmax * (float)fast_rcp(rpiv)));
-                                if (!(gr > GROWTH_SAFE)) { feas = 1; pivots++; }
+                            for (int sl = 0; sl < SLOTS; ++sl) a[sl] = (lane + 64 * sl == rp[p_]) ? x : fma(-E[p_][sl], x, a[sl]);
+                        }
+                        bool elig[SLOTS];
+                        float cmf = 0.0f;
+                        double tmax = INFINITY;
+#pragma unroll
+                        for (int sl = 0; sl < SLOTS; ++sl) {
+                            const int i = lane + 64 * sl;
+                            const bool used = i < mr && qkind[sl] != RK_DEAD;
+                            if (used) cmf = fmaxf(cmf, fabsf((float)a[sl]));
+                            elig[sl] = used && qkind[sl] == RK_INEQ && a[sl] > TOL_PIV;
+                            ratio[sl] = 0.0;
+                            if (elig[sl]) {
+                                const double b0 = fmax(qb[sl], 0.0), ia = fast_rcp(a[sl]);
+                                ratio[sl] = b0 * ia;
+                                tmax = fmin(tmax, (b0 + HARRIS_DELTA) * ia);
                             }
                         }
+                        const float colmax = dpp_wave_max_f32(cmf);
+                        tmax = dpp_wave_min(tmax);
+                        if (tmax == INFINITY) break;   // unbounded direction: left to k_x2
+                        bool pass[SLOTS], mine = false;
+#pragma unroll
+                        for (int sl = 0; sl < SLOTS; ++sl) { pass[sl] = elig[sl] && !(ratio[sl] > tmax); mine = mine || (lane + 64 * sl == row && pass[sl]); }
+                        int l = -1;
+                        double rpiv;
+                        if (__any(mine)) { l = row; rpiv = at(a, row); }
+                        else {
+                            double am = 0.0;
+#pragma unroll
+                            for (int sl = 0; sl < SLOTS; ++sl) if (pass[sl]) am = fmax(am, a[sl]);
+                            rpiv = dpp_wave_max(am);
+#pragma unroll
+                            for (int sl = SLOTS - 1; sl >= 0; --sl) {
+                                const unsigned long long bl = __ballot(pass[sl] && a[sl] == rpiv);
+                                if (bl) l = __ffsll((long long)bl) - 1 + 64 * sl;
+                            }
+                            if (l < 0) break;
+                            l = uni(l);
+                        }
+                        const double inv = fast_rcp(rpiv);
+                        growth = fmax(growth, (double)(colmax * (float)inv));
+                        if (growth > GROWTH_SAFE) break;            // k_x2 repeats the run and flags it
+                        piv_local++;
+                        if (l == row) { feas = 1; break; }          // the new row's slack leaves the basis at zero
+                        if (it + 1 == XQ_ITERS) break;
+                        // pivot (l, q): remember it, update the values and the new row
+                        rp[it] = l; qp[it] = q; invp[it] = inv;
+#pragma unroll
+                        for (int sl = 0; sl < SLOTS; ++sl) E[it][sl] = a[sl];
+                        const double xb = at(qb, l) * inv;
+#pragma unroll
+                        for (int sl = 0; sl < SLOTS; ++sl) qb[sl] = (lane + 64 * sl == l) ? xb : fma(-a[sl], xb, qb[sl]);
+                        double rowl = (lane < NXC) ? pd[(size_t)lane * mr + l] : 0.0;   // pivot row l at the current time, entry j in lane j
+#pragma unroll
+                        for (int p_ = 0; p_ < it; ++p_) {
+                            if (l == rp[p_]) rowl = R[p_];
+                            else {
+                                const double xr = at(E[p_], l);
+                                rowl = fma(-xr, R[p_], lane == qp[p_] ? 0.0 : rowl);
+                            }
+                        }
+                        R[it] = (lane == q) ? inv : rowl * inv;
+                        const double xr = at(a, row);
+                        xrow = fma(-xr, R[it], lane == q ? 0.0 : xrow);
                     }
                 }
             }
             if (feas >= 0) {
                 n_quick++;
+                pivots += piv_local;
                 if (lane == 0) status[c] = (uint8_t)(feas ? (singular ? ST_SINGULAR : ST_FEASIBLE) : ST_INFEASIBLE);
             }
         }
