@@ -210,11 +210,8 @@ def main():
         lambda p: p['n_x_items'] * (p['dict_read_bytes'] + p['dict_write_bytes'] + 4 + 4 * p['k'] + 1))
     R = lambda k: 8 * (nt + 1) * (nx + k + n_e) + 4 * (8 + 2 * k + prog.A_t.shape[0] + 2 * (nc - k))
     add('k_region2', 'ms_region2', 'n_opt', lambda p: p['n_opt'] * (4 * p['k'] + 8 * p['k'] * (nt + 1) + R(p['k'])))
-    # the kernel the roofline object describes: k_x2, the stage that streams real HBM traffic (with k_xq it is the longest
-    # stage of a level), unless another kernel takes more than 1.25x its time; all three are listed under `kernels`
+    # the kernel the roofline object describes: the one with the largest total time (the others are listed under `kernels`)
     dominant = max(kern, key=lambda k: kern[k]['total_ms'])
-    if kern['k_x2']['total_ms'] * 1.25 >= kern[dominant]['total_ms']:
-        dominant = 'k_x2'
     dom = kern[dominant]
     traffic = None
     tpath = os.path.join(ROOT, 'profiles', 'r01_pmc_traffic.json')
@@ -253,10 +250,10 @@ def main():
                      'path': {'algorithmic_bytes_per_candidate': bytes_path / max(local_cands, 1),
                               'achieved_GBs': bytes_path / max(ms_path, 1e-9) / 1e6,
                               'note': 'SURVEY.md 8(d): B_alg = P + 4k + 8 + rho*R per candidate over all kernels of a level'},
-                     'note': 'fp64 simplex pivots in registers: the kernels are VALU-issue / latency bound, far from the HBM '
-                             'roof; k_x2 streams one cached dictionary per candidate and is the only one that moves real '
-                             'HBM traffic. traffic = FETCH_SIZE+WRITE_SIZE per launch from the rocprofv3 --pmc passes in '
-                             'profiles/ (same command), null if not collected for this workload.'},
+                     'note': 'fp64 simplex pivots in registers: k_region2 and k_theta2 are VALU-issue / dependent-latency bound and move '
+                             'almost no HBM traffic, so their fraction of the HBM roof is small by nature; k_x2 (see kernels) streams one '
+                             'cached dictionary per candidate and is the kernel the HBM roof applies to. traffic = FETCH_SIZE(x2)+WRITE_SIZE '
+                             'per launch from the rocprofv3 --pmc passes in profiles/ (same command), null if not collected.'},
     }
     # CriticalRegion objects returned by the solve are views into per-level arrays that are cut out on first access;
     # the time to touch every field of every region is reported separately (not part of `value`)

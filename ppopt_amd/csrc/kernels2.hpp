@@ -431,9 +431,15 @@ struct DictCache {
 // ends within those iterations (slack already nonbasic / already zero / no improving column / the new row leaves the
 // basis); otherwise the candidate keeps its NEEDX status and goes to k_x2.  Few registers -> 8 waves per SIMD hide the
 // dependent HBM round trips.
-constexpr int XQ_ITERS = 4;
+#ifndef XQ_WAVES
+#define XQ_WAVES 8
+#endif
+#ifndef XQ_ITERS_N
+#define XQ_ITERS_N 8
+#endif
+constexpr int XQ_ITERS = XQ_ITERS_N;
 template <int SLOTS>
-__global__ void __launch_bounds__(64, 8) k_xq(const DevProblem *__restrict__ Pg, const int32_t *__restrict__ cands, int k,
+__global__ void __launch_bounds__(64, XQ_WAVES) k_xq(const DevProblem *__restrict__ Pg, const int32_t *__restrict__ cands, int k,
                                                const int32_t *__restrict__ list, int n_list, uint8_t *__restrict__ status,
                                                LevelCounters *__restrict__ ctr, DictCache dc, int NXC) {
     const DevProblem &P = *Pg;
