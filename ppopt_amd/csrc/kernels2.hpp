@@ -944,6 +944,17 @@ __global__ void __launch_bounds__(64, (SLOTS >= 2 ? 2 : R2W)) k_region2(
 #pragma unroll
                     for (int sl = 0; sl < SLOTS; ++sl)
                         if (lp.kind[sl] == RK_INEQ && lp.var[sl] < m && lp.t[sl][0] <= TOL_FEAS && own(lp.var[sl])) s.kept[lp.var[sl]] = 1;
+                    // ... and every basic slack whose row has no improving column is at ITS minimum here: the run that would
+                    // test this row starts at its optimum (zero pivots), so a positive value means the row is redundant
+#pragma unroll
+                    for (int sl = 0; sl < SLOTS; ++sl) {
+                        if (lp.kind[sl] == RK_INEQ && lp.var[sl] < m && lp.t[sl][0] > TOL_FEAS && own(lp.var[sl])) {
+                            double mx = 0.0;
+#pragma unroll
+                            for (int j = 1; j < NC; ++j) mx = fmax(mx, (double)lp.t[sl][j]);
+                            if (!(mx > TOL_COST) && s.kept[lp.var[sl]] == 0) s.kept[lp.var[sl]] = 2;
+                        }
+                    }
                     wave_sync();
                 };
                 // constraint (value h, coefficients g) behind a variable id: a region row or the slack of a vertex row of A_t
