@@ -957,6 +957,23 @@ __global__ void __launch_bounds__(64, (SLOTS >= 2 ? 2 : R2W)) k_region2(
                     }
                     wave_sync();
                 };
+                // the same two certificates at the intermediate vertices of a run (no barrier: the flags are read after the
+                // run's closing mark_tight)
+                auto mark_vertex = [&]() {
+                    if (lane >= 1 && lane < NC && ((lp.alive >> lane) & 1u) && lp.cv < m && own(lp.cv)) s.kept[lp.cv] = 1;
+#pragma unroll
+                    for (int sl = 0; sl < SLOTS; ++sl) {
+                        if (lp.kind[sl] == RK_INEQ && lp.var[sl] < m && own(lp.var[sl])) {
+                            if (lp.t[sl][0] <= TOL_FEAS) s.kept[lp.var[sl]] = 1;
+                            else {
+                                double mx = 0.0;
+#pragma unroll
+                                for (int j = 1; j < NC; ++j) mx = fmax(mx, (double)lp.t[sl][j]);
+                                if (!(mx > TOL_COST) && s.kept[lp.var[sl]] == 0) s.kept[lp.var[sl]] = 2;
+                            }
+                        }
+                    }
+                };
                 // constraint (value h, coefficients g) behind a variable id: a region row or the slack of a vertex row of A_t
                 auto row_of = [&](int id, double &h, double (&g)[NT]) {
 #pragma unroll
@@ -1034,7 +1051,7 @@ __global__ void __launch_bounds__(64, (SLOTS >= 2 ? 2 : R2W)) k_region2(
                     }
                     if (row < 0) { retry = true; reason = 4; break; }
                     lp.set_kind(row, RK_X0);
-                    const int pr = lp.primal(row, -1, false);
+                    const int pr = lp.primal_hook(row, -1, false, false, mark_vertex);
                     if (pr == 3) { st = ST_LP_LIMIT; break; }
                     bool kept_c = pr == 4;
                     if (pr != 4) { kept_c = lp.beta(row) <= TOL_FEAS; lp.set_kind(row, RK_INEQ); }

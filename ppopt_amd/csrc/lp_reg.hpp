@@ -254,7 +254,13 @@ struct RegLp {
     // false = it stays a regular nonbasic variable (facet tests in k_region2).
     // decide_only: the caller only wants to know whether x0 can leave (last level: the dictionary is not kept) -- the
     // final pivot is skipped, the tableau is left one pivot behind.
+    struct NoHook { __device__ __forceinline__ void operator()() const {} };
     __device__ __forceinline__ int primal(int phase1_row, int cost_row, bool drop_on_leave = true, bool decide_only = false) {
+        return primal_hook(phase1_row, cost_row, drop_on_leave, decide_only, NoHook());
+    }
+    // the same with a callable that is invoked after every pivot (the dictionary then sits at a new feasible vertex)
+    template <class Hook>
+    __device__ __forceinline__ int primal_hook(int phase1_row, int cost_row, bool drop_on_leave, bool decide_only, Hook after_pivot) {
         const int lane = lane_id();
         int deg = 0;
         for (;;) {
@@ -341,7 +347,7 @@ struct RegLp {
             growth = fmax(growth, (double)(colmax * (float)inv));
             deg = (rmin <= 0.0) ? deg + 1 : 0;
             const bool skip = leaving_x0 && decide_only;
-            if (!skip) pivot_core(r, q, a, inv);
+            if (!skip) { pivot_core(r, q, a, inv); after_pivot(); }
             else iters++;
             if (leaving_x0) { set_kind(r, RK_INEQ); if (drop_on_leave && !skip) drop_col(q); return 4; }
         }
