@@ -204,8 +204,8 @@ def main():
         nbytes = sum(bytes_fn(p) for p in all_levels if p.get(key, 0.0) > 0.0)
         kern[name] = {'total_ms': tot_ms, 'launches': launches, 'avg_launch_ms': tot_ms / max(launches, 1), 'units': units,
                       'algorithmic_bytes': nbytes, 'achieved_GBs': nbytes / max(tot_ms, 1e-9) / 1e6}
-    add('k_theta2', 'ms_theta', 'local_candidates' if distributed else 'candidates',
-        lambda p: p.get('local_candidates', p['candidates']) * (4 * p['k'] + 2 + 8 * p['k'] * (nt + 1)) + 8 * nc * (nc + nt + 1))
+    add('k_theta2', 'ms_theta', 'n_theta_items',
+        lambda p: p['n_theta_items'] * (4 * p['k'] + 2 + 8 * p['k'] * (nt + 1)) + 8 * nc * (nc + nt + 1))
     add('k_x2', 'ms_x', 'n_x_items',
         lambda p: p['n_x_items'] * (p['dict_read_bytes'] + p['dict_write_bytes'] + 4 + 4 * p['k'] + 1))
     R = lambda k: 8 * (nt + 1) * (nx + k + n_e) + 4 * (8 + 2 * k + prog.A_t.shape[0] + 2 * (nc - k))

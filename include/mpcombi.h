@@ -92,6 +92,7 @@ typedef struct {
     int64_t n_x_items, n_opt;
     int64_t dict_read_bytes;   /* bytes of one cached dictionary record as k_x2 reads it (0: no cache on this level)   */
     int64_t dict_write_bytes;  /* bytes of one record as k_x2 stores it for the next level (0: nothing stored)         */
+    int64_t n_theta_items;     /* candidates k_theta2 processed (those the thread kernel's screen left open)             */
 } mpc_level_stats;
 
 /* ---- library / device ------------------------------------------------------------------------------ */

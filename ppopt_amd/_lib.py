@@ -44,7 +44,8 @@ class LevelStats(ctypes.Structure):
                 ('wave_cycles', ctypes.c_int64 * 4), ('n_region_retry', ctypes.c_int64),
                 ('n_x_cached', ctypes.c_int64), ('ms_theta', ctypes.c_float), ('ms_x', ctypes.c_float),
                 ('ms_region2', ctypes.c_float), ('pad_', ctypes.c_float), ('n_x_items', ctypes.c_int64),
-                ('n_opt', ctypes.c_int64), ('dict_read_bytes', ctypes.c_int64), ('dict_write_bytes', ctypes.c_int64)]
+                ('n_opt', ctypes.c_int64), ('dict_read_bytes', ctypes.c_int64), ('dict_write_bytes', ctypes.c_int64),
+                ('n_theta_items', ctypes.c_int64)]
 
 
 _lib = None

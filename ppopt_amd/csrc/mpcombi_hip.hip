@@ -751,7 +751,7 @@ int mpc_level_run(mpc_handle *h, int32_t gen_children, mpc_level_stats *stats) {
     std::memset(&host_ctr, 0, sizeof(host_ctr));
     float ms[3] = {0, 0, 0}, kms[3] = {0, 0, 0};
     bool kernel_timed[3] = {false, false, false};
-    long long n_x_items = 0;
+    long long n_x_items = 0, n_theta_items = 0;
     if (n > 0) {
         const size_t nn = (size_t)n;
         HIP_TRY(h, h->status.ensure(nn, st));
@@ -839,6 +839,7 @@ int mpc_level_run(mpc_handle *h, int32_t gen_children, mpc_level_stats *stats) {
                 }
                 HIP_TRY(h, hipEventRecord(h->kev[1], st));
                 kernel_timed[0] = true;
+                n_theta_items = n_theta;
                 HIP_TRY(h, hipGetLastError());
             }
             // One partition after the theta stage: [0] numerically doubtful (status 7), [1] feasible and [2] optimal (decided
@@ -1079,6 +1080,7 @@ int mpc_level_run(mpc_handle *h, int32_t gen_children, mpc_level_stats *stats) {
         stats->n_x_cached = (int64_t)host_ctr.x_cached;
         stats->ms_theta = kms[0]; stats->ms_x = kms[1]; stats->ms_region2 = kms[2];
         stats->n_x_items = n_x_items;
+        stats->n_theta_items = n_theta_items;
         stats->n_opt = h->n_opt;
         stats->dict_read_bytes = (h->fast && h->have_prev_dict && h->have_parent_slot) ? h->dict_stride_d * 8 + h->dict_stride_i * 4 : 0;
         stats->dict_write_bytes = (h->fast && h->storing) ? h->dict_stride_d * 8 + h->dict_stride_i * 4 : 0;

@@ -66,7 +66,7 @@ class HipLevelEngine:
                 'n_children': int(st.n_children), 'n_pruned_new': int(st.n_pruned_new), 'lp_pivots': int(st.lp_pivots),
                 'ms_verdict': float(st.ms_verdict), 'ms_region': float(st.ms_region), 'ms_children': float(st.ms_children),
                 'ms_theta': float(st.ms_theta), 'ms_x': float(st.ms_x), 'ms_region2': float(st.ms_region2),
-                'n_x_items': int(st.n_x_items), 'n_opt': int(st.n_opt), 'dict_read_bytes': int(st.dict_read_bytes),
+                'n_x_items': int(st.n_x_items), 'n_opt': int(st.n_opt), 'n_theta_items': int(st.n_theta_items), 'dict_read_bytes': int(st.dict_read_bytes),
                 'dict_write_bytes': int(st.dict_write_bytes)}
 
     def pruned_new(self) -> torch.Tensor:
@@ -188,7 +188,7 @@ def solve_distributed(engine, program=None, group=None, profile: Optional[List[D
                             'pruned_new': total['n_pruned_new'], 'lp_pivots': total['lp_pivots'],
                             'ms_verdict': st.get('ms_verdict', 0.0), 'ms_region': st.get('ms_region', 0.0),
                             'ms_children': st.get('ms_children', 0.0), 'local_candidates': st['n'], 'sharded': sharded,
-                            **{key: st.get(key, 0) for key in ('ms_theta', 'ms_x', 'ms_region2', 'n_x_items', 'n_opt',
+                            **{key: st.get(key, 0) for key in ('ms_theta', 'ms_x', 'ms_region2', 'n_x_items', 'n_opt', 'n_theta_items',
                                                                'dict_read_bytes', 'dict_write_bytes')}})
         if not gen_children or total['n_children'] == 0:
             break

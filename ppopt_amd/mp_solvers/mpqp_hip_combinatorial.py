@@ -88,7 +88,7 @@ def solve(program, num_cores: int = -1, device: int = 0, profile: Optional[List[
                             'lp_pivots': int(st.lp_pivots), 'xtheta_lps': int(st.n_xtheta_lp), 'xtheta_fallbacks': int(st.n_xtheta_fallback), 'ms_verdict': float(st.ms_verdict),
                             'ms_region': float(st.ms_region), 'ms_children': float(st.ms_children),
                             'ms_theta': float(st.ms_theta), 'ms_x': float(st.ms_x), 'ms_region2': float(st.ms_region2),
-                            'n_x_items': int(st.n_x_items), 'n_opt': int(st.n_opt),
+                            'n_x_items': int(st.n_x_items), 'n_opt': int(st.n_opt), 'n_theta_items': int(st.n_theta_items),
                             'dict_read_bytes': int(st.dict_read_bytes), 'dict_write_bytes': int(st.dict_write_bytes),
                             'ms_wall': (time.perf_counter() - t0) * 1e3})
         if not gen_children or st.n_children == 0:
