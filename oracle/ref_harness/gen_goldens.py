@@ -270,6 +270,9 @@ REGISTRY = {
     'rand_4_2_10_s0': (lambda: pg.generate_mpqp_data(4, 2, 10, 0), dict(check_full_process=True)),
     'rand_5_3_8_s3': (lambda: pg.generate_mpqp_data(5, 3, 8, 3), {}),
     'rand_6_3_12_s1': (lambda: pg.generate_mpqp_data(6, 3, 12, 1), {}),
+    # random mpLPs (the reference's generate_mplp: the random mpQP without its Q): the dense-KKT / vertex-only branch
+    'mplp_rand_4_2_10_s0': (lambda: {**pg.generate_mpqp_data(4, 2, 10, 0), 'Q': None}, dict(check_full_process=True)),
+    'mplp_rand_5_3_12_s2': (lambda: {**pg.generate_mpqp_data(5, 3, 12, 2), 'Q': None}, {}),
     'quadtank_n2': (lambda: pg.quad_tank_data(2), {}),
     'quadtank_n3': (lambda: pg.quad_tank_data(3), {}),
     'c5_control_allocation': (lambda: pg.control_allocation_data(), {}),

@@ -15,7 +15,7 @@ from conftest import golden_regions, is_knife_edge, load_golden, rel_err, rows_m
 
 pytestmark = pytest.mark.gpu
 
-FULL = ['c1_transport_mplp', 'transport_mpqp', 'dblint_n3', 'c2_dblint_n5', 'rand_4_2_10_s0', 'rand_5_3_8_s3',
+FULL = ['c1_transport_mplp', 'mplp_rand_4_2_10_s0', 'mplp_rand_5_3_12_s2', 'transport_mpqp', 'dblint_n3', 'c2_dblint_n5', 'rand_4_2_10_s0', 'rand_5_3_8_s3',
         'rand_6_3_12_s1', 'quadtank_n2', 'quadtank_n3']
 PARTIAL = ['c4_rand_20_8_20_s0', 'c3_quadtank_n10']
 COEF_TOL = 1e-8  # north_star: "within 1e-8 on region affine coefficients"

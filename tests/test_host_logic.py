@@ -10,7 +10,7 @@ from ppopt_amd import problem_generator as pg
 from ppopt_amd.utils import constraint_utilities as cu
 from ppopt_amd.utils.general_utils import make_column, ppopt_block, select_not_in_list
 
-PRESOLVE = ['c1_transport_mplp', 'transport_mpqp', 'dblint_n3', 'c2_dblint_n5', 'rand_4_2_10_s0', 'rand_5_3_8_s3',
+PRESOLVE = ['c1_transport_mplp', 'mplp_rand_4_2_10_s0', 'mplp_rand_5_3_12_s2', 'transport_mpqp', 'dblint_n3', 'c2_dblint_n5', 'rand_4_2_10_s0', 'rand_5_3_8_s3',
             'rand_6_3_12_s1', 'quadtank_n2', 'quadtank_n3', 'c5_control_allocation', 'c4_rand_20_8_20_s0',
             'c3_quadtank_n10']
 
