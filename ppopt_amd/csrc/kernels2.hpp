@@ -422,6 +422,10 @@ struct DictCache {
     double *cur_d; int32_t *cur_i; uint8_t *stored;   // cur_d == nullptr: do not store
     long long stride_d, stride_i;
     int dict_only;   // 1: the candidates are already decided (theta stage); only their dictionary is wanted for the children
+    // two optional list segments that are processed BEFORE `list` in the same launch, dictionary-only (the candidates the
+    // theta stage found feasible / optimal: status untouched, they only leave a dictionary for their children)
+    const int32_t *pre1, *pre2;
+    int n_pre1, n_pre2;
     int chunk;       // work items per queue atomic (<= 64)
 };
 // k_xq: the last level's quick (x,theta) test.  No dictionary is stored on the last level, so a candidate only needs a
@@ -616,8 +620,9 @@ __global__ void __launch_bounds__(64, (NXC * SLOTS >= 32 ? X2_WAVES : 3)) k_x2(c
     const int mr = P.n_d0r, nc0 = P.n_d0c;
     const double *d0T = P.d0T;
     const int32_t *d0_rows = P.d0_rows, *d0_cols = P.d0_cols;
-    const bool dict_only = dc.dict_only != 0;
-    const bool last_only = !dict_only && dc.cur_d == nullptr;   // nothing is stored: only the verdict is wanted
+    const bool all_dict_only = dc.dict_only != 0;
+    const bool last_only = !all_dict_only && dc.cur_d == nullptr;   // nothing is stored: only the verdict is wanted
+    const int n_pre = dc.n_pre1 + dc.n_pre2, n_items = n_pre + n_list;
     unsigned long long pivots = 0, n_retry = 0, n_cached = 0;
     long long cyc_x = 0;
     int sink = 0;
@@ -625,16 +630,18 @@ __global__ void __launch_bounds__(64, (NXC * SLOTS >= 32 ? X2_WAVES : 3)) k_x2(c
         unsigned int w0 = 0;
         if (lane == 0) w0 = atomicAdd(&ctr->work_x, (unsigned)dc.chunk);
         w0 = (unsigned)__builtin_amdgcn_readfirstlane((int)w0);
-        if (w0 >= (unsigned)n_list) break;
-        const int cnt = min(dc.chunk, n_list - (int)w0);
+        if (w0 >= (unsigned)n_items) break;
+        const int cnt = min(dc.chunk, n_items - (int)w0);
         // the chunk's bookkeeping in one batch: lane u holds candidate, parent slot and status of item u
         int my_c = 0, my_ps = -1, my_st = 0;
         if (lane < cnt) {
-            my_c = list[w0 + lane];
+            const int idx = (int)w0 + lane;
+            my_c = idx < dc.n_pre1 ? dc.pre1[idx] : (idx < n_pre ? dc.pre2[idx - dc.n_pre1] : list[idx - n_pre]);
             my_ps = dc.parent_slot ? dc.parent_slot[my_c] : -1;
             my_st = status[my_c];
         }
       for (int u = 0; u < cnt; ++u) {
+        const bool dict_only = all_dict_only || (int)w0 + u < n_pre;
         const int c = __builtin_amdgcn_readlane(my_c, u);
         const int ps = __builtin_amdgcn_readlane(my_ps, u);
         const int32_t *as = cands + (size_t)c * k;

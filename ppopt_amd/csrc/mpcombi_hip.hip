@@ -886,9 +886,9 @@ int mpc_level_run(mpc_handle *h, int32_t gen_children, mpc_level_stats *stats) {
             auto launch_x = [&](const int32_t *ls, int n_items, const DictCache &d0) -> int {
                 HIP_TRY(h, hipMemsetAsync(&ctr->work_x, 0, sizeof(unsigned int), st));
                 DictCache d = d0;
-                const long long grid_x = (long long)h->n_cu * 16;
-                d.chunk = (int)std::max<long long>(1, std::min<long long>(16, n_items / (grid_x * 8)));
-                const dim3 gg((unsigned)std::min<long long>((n_items + d.chunk - 1) / d.chunk, grid_x)), bb(64);
+                const long long grid_x = (long long)h->n_cu * 16, n_all = (long long)n_items + d.n_pre1 + d.n_pre2;
+                d.chunk = (int)std::max<long long>(1, std::min<long long>(16, n_all / (grid_x * 8)));
+                const dim3 gg((unsigned)std::min<long long>((n_all + d.chunk - 1) / d.chunk, grid_x)), bb(64);
                 switch (h->fast_x) {
                     case 0: hipLaunchKernelGGL((k_x2<16, 1>), gg, bb, 0, st, pf, fr, k, ls, n_items, stp, ctr, d); break;
                     case 1: hipLaunchKernelGGL((k_x2<16, 2>), gg, bb, 0, st, pf, fr, k, ls, n_items, stp, ctr, d); break;
@@ -900,10 +900,9 @@ int mpc_level_run(mpc_handle *h, int32_t gen_children, mpc_level_stats *stats) {
             };
             if (h->storing) {
                 // candidates the theta stage already decided (feasible / optimal) expand too: their children get a
-                // dictionary to start from (status untouched)
-                DictCache d2 = dc; d2.dict_only = 1;
-                for (int c : {1, 2})
-                    if (cntA[c] > 0) { int rcs = launch_x(part_list(c), cntA[c], d2); if (rcs) return rcs; }
+                // dictionary to start from (status untouched).  They ride in front of the open candidates in the same launch.
+                dc.pre1 = part_list(1); dc.n_pre1 = cntA[1];
+                dc.pre2 = part_list(2); dc.n_pre2 = cntA[2];
             }
             int32_t n_needx = cntA[3];
             const int32_t *needx_list = part_list(3);
@@ -922,13 +921,13 @@ int mpc_level_run(mpc_handle *h, int32_t gen_children, mpc_level_stats *stats) {
                 n_needx = n_left;
                 needx_list = h->retry_list.as<int32_t>();
             }
-            if (n_needx > 0) {   // feasibility for the candidates left open
+            if (n_needx + dc.n_pre1 + dc.n_pre2 > 0) {   // feasibility for the candidates left open (+ dictionary-only items)
                 HIP_TRY(h, hipEventRecord(h->kev[2], st));
                 int rcs = launch_x(needx_list, n_needx, dc);
                 if (rcs) return rcs;
                 HIP_TRY(h, hipEventRecord(h->kev[3], st));
                 kernel_timed[1] = true;
-                n_x_items = n_needx;
+                n_x_items = n_needx + dc.n_pre1 + dc.n_pre2;
             }
             // doubtful candidates of the (x,theta) stage (rare) take the same route on the main stream
             int32_t n_retry = 0;
