@@ -111,7 +111,7 @@ __device__ inline int load_active_set(const DevProblem &P, const int32_t *cand, 
 
 // KKT solve.  On success L (k x (n_t+1)) holds [b_l | A_l]; in mode 1 X (n_x x (n_t+1)) also holds [b_x | A_x].
 // returns 0 ok, 1 rank deficient active set, 2 singular KKT, 3 mpLP active set that is not a vertex
-__device__ inline int kkt_solve(const DevProblem &P, int k, Smem &s) {
+__device__ inline int kkt_solve(const DevProblem &P, int k, Smem &s, bool *ill = nullptr) {
     const int lane = lane_id(), nr = P.n_t + 1, nx = P.n_x, nc = P.n_c;
     if (k > nx) return 1;
     if (k == 0) {
@@ -148,7 +148,7 @@ __device__ inline int kkt_solve(const DevProblem &P, int k, Smem &s) {
             s.L[idx] = -P.UV[s.as[i] * nr + t];
         }
         wave_sync();
-        return chol_solve(S, k, s.L, nr, diag) ? 0 : 2;
+        return chol_solve(S, k, s.L, nr, diag, ill) ? 0 : 2;
     }
     // mode 1: rank test on A_as, then the dense KKT system
     {
@@ -310,6 +310,7 @@ __global__ void __launch_bounds__(64) k_verdict(DevProblem P, const int32_t *__r
             //   stage 2  the multiplier rows lambda(theta) >= 0, carried passively through stage 1, are switched on and
             //            phase 1 continues from the same dictionary: non-empty  <=>  optimal (check_optimality)
             Lp lp;
+            lp.noscale = true;
             lp.T = s.T; lp.ld = P.ld_t; lp.colvar = s.colvar; lp.rowvar = s.rowvar; lp.rowkind = s.rowkind;
             const int nlam = k - P.n_eq;
             lp.n = nt; lp.m = nlam + nin + P.n_tc; lp.iters = 0;
@@ -412,7 +413,8 @@ __global__ void __launch_bounds__(64) k_region(DevProblem P, const int32_t *__re
             for (long long i = lane; i < si; i += 64) ri[i] = -1;
         }
         int st = ST_REGION;
-        const int kk = kkt_solve(P, k, s);
+        bool ill = false;
+        const int kk = kkt_solve(P, k, s, &ill);
         if (kk != 0) st = kk == 1 ? ST_INFEASIBLE : ST_SINGULAR;  // cannot happen after k_verdict said optimal
         int nE = 0, n_om = 0, n_la = 0, n_re = 0;
         if (st == ST_REGION) {
@@ -566,6 +568,9 @@ __global__ void __launch_bounds__(64) k_region(DevProblem P, const int32_t *__re
             }
         }
         if (MODE == RG_FACET) continue;
+        // "optimal but lower-dimensional" from an ill-conditioned Schur system is not trusted: the candidate is expanded
+        // like a feasible, non-optimal one instead of being pruned together with its supersets
+        if (ill && st == ST_OPT_NO_REGION) st = ST_FEASIBLE;
         if (st == ST_REGION) {
             // x-law, multipliers, header
             for (int idx = lane; idx < nx * nt; idx += 64) rd[idx] = s.X[(idx / nt) * nr + 1 + idx % nt];

@@ -19,6 +19,15 @@ namespace mpc {
 // accepts a freshly refactorised run under the same reasoning.  Dictionaries that live across levels (k_x2's cache) and the
 // long facet walks of k_region2 keep the 1e3 threshold of lp_engine.hpp.
 constexpr double GROWTH_FRESH = 1e6;
+#ifndef THETA_SCALE_MODE
+#define THETA_SCALE_MODE 0
+#endif
+// power-of-two scale of a theta-space row whose largest coefficient has binary exponent ex
+__device__ __forceinline__ double theta_row_scale(int ex) {
+    if (THETA_SCALE_MODE == 1) return 1.0;
+    if (THETA_SCALE_MODE == 2 && ex > 0) return 1.0;
+    return ldexp(1.0, -ex);
+}
 constexpr int ST_RETRY = 7;       // numerically doubtful: re-solve with the LDS engine (k_verdict)
 constexpr int ST_NEEDX = 8;       // theta stage could not show feasibility: (x,theta) LP needed (k_x2)
 constexpr int ST_NEEDX_SING = 9;  // the same, and the KKT matrix was singular (a feasible outcome is ST_SINGULAR)
@@ -56,6 +65,7 @@ struct ThetaArgs {
 //   output      code[c] in {0 ok, 2 singular, KK_UNDECIDED};  status[c] = ST_NEEDX (screened) or ST_TODO;
 //               Lout[c*K*nr + i*nr + t] = [b_l | A_l] for the candidates that go on to k_theta2
 constexpr int KK_UNDECIDED = 255;
+constexpr int KK_ILL = 64;        // solved, but the Schur system is ill-conditioned (CHOL_ILL_TOL, kkt.hpp)
 constexpr int ST_TODO = 10;       // internal: waiting for k_theta2
 template <int K, int NT>
 __global__ void __launch_bounds__(256) k_kkt_thread(const DevProblem *__restrict__ Pg, const int32_t *__restrict__ cands, long long n,
@@ -107,11 +117,12 @@ __global__ void __launch_bounds__(256) k_kkt_thread(const DevProblem *__restrict
         for (int j = 0; j <= i; ++j) S[i][j] = ta.W[as[i] * nc + as[j]];
         diag0[i] = S[i][i];
     }
-    bool ok = true;
+    bool ok = true, ill = false;
 #pragma unroll
     for (int j = 0; j < K; ++j) {
         const double d = S[j][j];
         ok = ok && (d > RANK_TOL_CHOL * diag0[j]);
+        ill = ill || !(d > CHOL_ILL_TOL * diag0[j]);
         const double l = sqrt(d), inv = 1.0 / l;
 #pragma unroll
         for (int i = j + 1; i < K; ++i) S[i][j] = S[i][j] * inv;
@@ -171,10 +182,11 @@ __global__ void __launch_bounds__(256) k_kkt_thread(const DevProblem *__restrict
             for (int t = 0; t < NT; ++t) g[t] = 0.0;
             mx = 0.0;
         }
+        double sc = 1.0;
         if (mx > 0.0) {
             int ex;
             (void)frexp(mx, &ex);
-            const double sc = ldexp(1.0, -ex);
+            sc = theta_row_scale(ex);
             h *= sc;
 #pragma unroll
             for (int t = 0; t < NT; ++t) g[t] *= sc;
@@ -185,11 +197,11 @@ __global__ void __launch_bounds__(256) k_kkt_thread(const DevProblem *__restrict
             const double term = g[t] > 0.0 ? g[t] * blo[t] : (g[t] < 0.0 ? g[t] * bhi[t] : 0.0);
             smax -= term;
         }
-        if (!active && smax < -10 * TOL_FEAS) fired = true;
+        if (!active && smax < -10 * TOL_FEAS * sc) fired = true;   // the margin is meant in the row's own units
         if ((ci & 3) == 3 && __all(fired)) break;
     }
     if (fired) {
-        code[c] = 0;
+        code[c] = ill ? KK_ILL : 0;
         status[c] = (uint8_t)ST_NEEDX;
         return;
     }
@@ -199,15 +211,17 @@ __global__ void __launch_bounds__(256) k_kkt_thread(const DevProblem *__restrict
 #pragma unroll
         for (int t = 0; t < LS; ++t) if (t < nr) out[i * nr + t] = Lr[i][t];
     }
-    code[c] = 0;
+    code[c] = ill ? KK_ILL : 0;
     status[c] = (uint8_t)ST_TODO;
 }
 
 // the KKT result of candidate c: from k_kkt_thread's output when it decided, else solved here
-__device__ inline int kkt_fetch_or_solve(const DevProblem &P, int k, Smem &s, const uint8_t *kkcode, const double *Lin, size_t c) {
+__device__ inline int kkt_fetch_or_solve(const DevProblem &P, int k, Smem &s, const uint8_t *kkcode, const double *Lin, size_t c,
+                                         bool *ill = nullptr) {
     if (kkcode) {
-        const int code = kkcode[c];
+        int code = kkcode[c];
         if (code != KK_UNDECIDED) {
+            if (code == KK_ILL) { if (ill) *ill = true; code = 0; }
             if (code == 0) {
                 const int cnt = k * (P.n_t + 1);
                 const double *src = Lin + c * (size_t)cnt;
@@ -217,7 +231,7 @@ __device__ inline int kkt_fetch_or_solve(const DevProblem &P, int k, Smem &s, co
             return code;
         }
     }
-    return kkt_solve(P, k, s);
+    return kkt_solve(P, k, s, ill);
 }
 
 template <int NT, int SLOTS>
@@ -263,7 +277,7 @@ __global__ void __launch_bounds__(64, (NT * SLOTS >= 20 ? 3 : 4)) k_theta2(const
                 Lp[idx] = t <= nt ? s.L[a * nr + t] : 0.0;
             }
             wave_sync();
-            RegLp<NT + 2, SLOTS> lp;
+            RegLp<NT + 2, SLOTS, true> lp;
             const int nlam = k - e, m = nlam + nin + npre;
             lp.m = m; lp.iters = 0; lp.max_iter = 50 * (m + nt) + 100; lp.growth = 0.0;
             lp.alive = (nt >= 31 ? 0xfffffffeu : ((1u << (nt + 1)) - 2u));
@@ -277,6 +291,7 @@ __global__ void __launch_bounds__(64, (NT * SLOTS >= 20 ? 3 : 4)) k_theta2(const
                 for (int t = 0; t < NT; ++t) g[t] = 0.0;
                 lp.var[sl] = nt + i;
                 lp.kind[sl] = i < nlam ? RK_PASSIVE : (i < m ? RK_INEQ : RK_DEAD);
+                lp.w[sl] = 1.0; lp.winv[sl] = 1.0;
                 bool pre = false;
                 if (i < nlam) {
                     h = Lp[(e + i) * LS];
@@ -335,10 +350,12 @@ __global__ void __launch_bounds__(64, (NT * SLOTS >= 20 ? 3 : 4)) k_theta2(const
                         for (int t = 0; t < NT; ++t) g[t] = 0.0;
                         mx = 0.0;
                     }
+                    double sc = 1.0;
                     if (mx > 0.0) {
                         int ex;
                         (void)frexp(mx, &ex);
-                        const double sc = ldexp(1.0, -ex);
+                        sc = theta_row_scale(ex);
+                        lp.w[sl] = sc; lp.winv[sl] = 1.0 / sc;
                         h *= sc;
 #pragma unroll
                         for (int t = 0; t < NT; ++t) g[t] *= sc;
@@ -352,7 +369,7 @@ __global__ void __launch_bounds__(64, (NT * SLOTS >= 20 ? 3 : 4)) k_theta2(const
                             const double term = g[t] > 0.0 ? g[t] * blo[t] : (g[t] < 0.0 ? g[t] * bhi[t] : 0.0);
                             smax -= term;
                         }
-                        if (i < m && smax < -10 * TOL_FEAS) { if (i < nlam) box_lam = true; else box_slack = true; }
+                        if (i < m && smax < -10 * TOL_FEAS * sc) { if (i < nlam) box_lam = true; else box_slack = true; }
                     }
                     // theta = theta_v - Minv sigma:  value at the vertex and coefficients of the tight-row slacks sigma
                     double b0 = h, cf[NT];
@@ -799,7 +816,8 @@ __global__ void __launch_bounds__(64, (SLOTS >= 2 ? 2 : R2W)) k_region2(
         int32_t *hi = head_i + (size_t)w * fi;
         for (int i = lane; i < fi; i += 64) hi[i] = i < 8 ? 0 : -1;
         int st = ST_REGION;
-        const int kk = kkt_fetch_or_solve(P, k, s, kkcode, Lin, (size_t)c);
+        bool ill = false;
+        const int kk = kkt_fetch_or_solve(P, k, s, kkcode, Lin, (size_t)c, &ill);
         if (kk != 0) st = kk == 1 ? ST_INFEASIBLE : ST_SINGULAR;
         int nE = 0, n_om = 0, n_la = 0, n_re = 0, e_off = 0;
         bool retry = false;
@@ -1162,6 +1180,9 @@ __global__ void __launch_bounds__(64, (SLOTS >= 2 ? 2 : R2W)) k_region2(
             }
         }
         rc_tot += clock64() - t0;
+        // "optimal but lower-dimensional" from an ill-conditioned Schur system is not trusted: the candidate is expanded like a
+        // feasible, non-optimal one instead of being pruned together with its supersets
+        if (ill && st == ST_OPT_NO_REGION && !retry) st = ST_FEASIBLE;
         if (retry) { st = ST_RETRY; if (lane == 0 && is_last) atomicAdd(&ctr->n_rretry, 1u); }
         if (lane == 0 && is_last) {
             hi[0] = st; hi[1] = c; hi[2] = nE; hi[3] = n_om; hi[4] = n_la; hi[5] = n_re; hi[6] = e_off; hi[7] = reason;

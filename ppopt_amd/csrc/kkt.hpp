@@ -19,11 +19,15 @@ constexpr double KKT_SING_TOL = 1e-12;   // LU pivot relative to the largest ent
 
 // In-place lower Cholesky of the k x k LDS matrix S (row stride k) and solution of S X = R for the k x nr LDS
 // block R.  diag0[i] holds the original diagonal.  Returns false when a pivot falls below RANK_TOL_CHOL.
-__device__ inline bool chol_solve(double *S, int k, double *R, int nr, const double *diag0) {
+// ill (optional): set when a pivot is below CHOL_ILL_TOL of its diagonal -- cond(S) >~ 1e9, the multipliers carry a relative
+// error >~ 1e-7 (S = A_as Q^-1 A_as' squares the conditioning of A_as) and decisions at the 1e-7 tolerance are not reliable.
+constexpr double CHOL_ILL_TOL = 1e-9;
+__device__ inline bool chol_solve(double *S, int k, double *R, int nr, const double *diag0, bool *ill = nullptr) {
     const int lane = lane_id();
     for (int j = 0; j < k; ++j) {
         const double d = S[j * k + j];
         if (!(d > RANK_TOL_CHOL * diag0[j])) return false;
+        if (ill && !(d > CHOL_ILL_TOL * diag0[j])) *ill = true;
         const double l = sqrt(d), inv = 1.0 / l;
         wave_sync();
         for (int i = j + 1 + lane; i < k; i += 64) S[i * k + j] = S[i * k + j] * inv;

@@ -48,6 +48,7 @@ struct Lp {
     int iters;
     int max_iter;
     double growth;  // max over ratio-test pivots of (largest |entry| of the pivot column) / |pivot|
+    bool noscale = false;  // rows keep their units (theta-space LP: the 1e-7 tolerance is meant in the units of lambda / the slacks)
 };
 
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
@@ -368,6 +369,7 @@ __device__ inline bool lp_prepare(Lp &lp) {
             lp.rowkind[i] = RK_DEAD;
             continue;
         }
+        if (lp.noscale) continue;
         int e;
         (void)frexp(mx, &e);
         const double s = ldexp(1.0, -e);

@@ -125,9 +125,13 @@ struct RegRow {
     __device__ __forceinline__ double operator[](int j) const { return get(j); }
 };
 
-template <int NC, int SLOTS>
+// WEIGHTED: row i carries a power-of-two scale w (its entries are w times the constraint as posed).  Phase 1 then measures
+// infeasibility in the constraint's own units: x0 enters row i with coefficient -w, so "x0 <= 1e-7" means every constraint
+// holds within 1e-7 as posed, however much the row was scaled for the pivoting.
+template <int NC, int SLOTS, bool WEIGHTED = false>
 struct RegLp {
     RegRow<NC> t[SLOTS];
+    double w[SLOTS], winv[SLOTS];   // only read when WEIGHTED
     int kind[SLOTS];
     int var[SLOTS];
     int cv;           // lane j holds the variable id of column j
@@ -379,15 +383,17 @@ struct RegLp {
         double vmin = INFINITY;
 #pragma unroll
         for (int s = 0; s < SLOTS; ++s) {
-            neg[s] = lane + 64 * s < m && kind[s] == RK_INEQ && t[s].get(0) < -TOL_FEAS;
-            if (neg[s]) vmin = fmin(vmin, t[s].get(0));
+            const double v0 = WEIGHTED ? t[s].get(0) * winv[s] : t[s].get(0);   // value in the constraint's own units
+            neg[s] = lane + 64 * s < m && kind[s] == RK_INEQ && v0 < -TOL_FEAS;
+            if (neg[s]) vmin = fmin(vmin, v0);
         }
         vmin = dpp_wave_min(vmin);
         if (vmin == INFINITY) return LP_OPTIMAL;
         int r = -1;
 #pragma unroll
         for (int s = SLOTS - 1; s >= 0; --s) {
-            const unsigned long long br = __ballot(neg[s] && t[s].get(0) == vmin);
+            const double v0 = WEIGHTED ? t[s].get(0) * winv[s] : t[s].get(0);
+            const unsigned long long br = __ballot(neg[s] && v0 == vmin);
             if (br) r = __ffsll((long long)br) - 1 + 64 * s;
         }
         r = uni(r);
@@ -397,7 +403,7 @@ struct RegLp {
         const int xc = uni(__ffs((int)(~al & ~1u & ((NC >= 32 ? 0u : (1u << NC)) - 1u))) - 1);
         alive = al | (1u << xc);
 #pragma unroll
-        for (int s = 0; s < SLOTS; ++s) t[s].setq(xc, (lane + 64 * s < m && kind[s] == RK_INEQ) ? -1.0 : 0.0);
+        for (int s = 0; s < SLOTS; ++s) t[s].setq(xc, (lane + 64 * s < m && kind[s] == RK_INEQ) ? (WEIGHTED ? -w[s] : -1.0) : 0.0);
         if (lane == xc) cv = X0_VAR;
         pivot(r, xc);
         return drive_to_zero(r);
