@@ -622,6 +622,9 @@ __global__ void __launch_bounds__(64, XQ_WAVES) k_xq(const DevProblem *__restric
     if (lane == 0) { atomicAdd(&ctr->pivots, pivots); atomicAdd(&ctr->x_cached, n_quick); atomicAdd(&ctr->xtheta_lps, n_quick); }
 }
 
+#ifndef R2_CERT
+#define R2_CERT 1
+#endif
 #ifndef R2W
 #define R2W 3
 #endif
@@ -963,21 +966,27 @@ __global__ void __launch_bounds__(64, (SLOTS >= 2 ? 2 : R2W)) k_region2(
                     if (bc) lp.drop_col(__ffsll((long long)bc) - 1);
                 }
                 if (rz != LP_OPTIMAL) { retry = true; reason = 2; }
+                constexpr double KEEP_TOL = TOL_FEAS;
                 auto mark_tight = [&]() {
                     // every slack that is zero at the current vertex belongs to a kept row
                     if (lane >= 1 && lane < NC && ((lp.alive >> lane) & 1u) && lp.cv < m && own(lp.cv)) s.kept[lp.cv] = 1;
 #pragma unroll
                     for (int sl = 0; sl < SLOTS; ++sl)
-                        if (lp.kind[sl] == RK_INEQ && lp.var[sl] < m && lp.t[sl][0] <= TOL_FEAS && own(lp.var[sl])) s.kept[lp.var[sl]] = 1;
+                        if (lp.kind[sl] == RK_INEQ && lp.var[sl] < m && lp.t[sl][0] <= KEEP_TOL && own(lp.var[sl])) s.kept[lp.var[sl]] = 1;
                     // ... and every basic slack whose row has no improving column is at ITS minimum here: the run that would
                     // test this row starts at its optimum (zero pivots), so a positive value means the row is redundant
 #pragma unroll
                     for (int sl = 0; sl < SLOTS; ++sl) {
-                        if (lp.kind[sl] == RK_INEQ && lp.var[sl] < m && lp.t[sl][0] > TOL_FEAS && own(lp.var[sl])) {
+                        if (lp.kind[sl] == RK_INEQ && lp.var[sl] < m && lp.t[sl][0] > KEEP_TOL && own(lp.var[sl])) {
                             double mx = 0.0;
 #pragma unroll
                             for (int j = 1; j < NC; ++j) mx = fmax(mx, (double)lp.t[sl][j]);
-                            if (!(mx > TOL_COST) && s.kept[lp.var[sl]] == 0) s.kept[lp.var[sl]] = 2;
+                            if (R2_CERT && !(mx > TOL_COST) && s.kept[lp.var[sl]] == 0) {
+                                s.kept[lp.var[sl]] = 2;
+#ifdef R2_DEBUG
+                                printf("row %d: certificate at a final vertex, beta=%.3e mx=%.3e\n", lp.var[sl], (double)lp.t[sl][0], mx);
+#endif
+                            }
                         }
                     }
                     wave_sync();
@@ -985,16 +994,22 @@ __global__ void __launch_bounds__(64, (SLOTS >= 2 ? 2 : R2W)) k_region2(
                 // the same two certificates at the intermediate vertices of a run (no barrier: the flags are read after the
                 // run's closing mark_tight)
                 auto mark_vertex = [&]() {
+                    if (lp.growth > GROWTH_SAFE) return;   // a doubtful pivot has happened in this run: no certificates from it
                     if (lane >= 1 && lane < NC && ((lp.alive >> lane) & 1u) && lp.cv < m && own(lp.cv)) s.kept[lp.cv] = 1;
 #pragma unroll
                     for (int sl = 0; sl < SLOTS; ++sl) {
                         if (lp.kind[sl] == RK_INEQ && lp.var[sl] < m && own(lp.var[sl])) {
-                            if (lp.t[sl][0] <= TOL_FEAS) s.kept[lp.var[sl]] = 1;
+                            if (lp.t[sl][0] <= KEEP_TOL) s.kept[lp.var[sl]] = 1;
                             else {
                                 double mx = 0.0;
 #pragma unroll
                                 for (int j = 1; j < NC; ++j) mx = fmax(mx, (double)lp.t[sl][j]);
-                                if (!(mx > TOL_COST) && s.kept[lp.var[sl]] == 0) s.kept[lp.var[sl]] = 2;
+                                if (R2_CERT && !(mx > TOL_COST) && s.kept[lp.var[sl]] == 0) {
+                                    s.kept[lp.var[sl]] = 2;
+#ifdef R2_DEBUG
+                                    printf("row %d: certificate at an intermediate vertex, beta=%.3e mx=%.3e\n", lp.var[sl], (double)lp.t[sl][0], mx);
+#endif
+                                }
                             }
                         }
                     }
@@ -1079,10 +1094,13 @@ __global__ void __launch_bounds__(64, (SLOTS >= 2 ? 2 : R2W)) k_region2(
                     const int pr = lp.primal_hook(row, -1, false, false, mark_vertex);
                     if (pr == 3) { st = ST_LP_LIMIT; break; }
                     bool kept_c = pr == 4;
-                    if (pr != 4) { kept_c = lp.beta(row) <= TOL_FEAS; lp.set_kind(row, RK_INEQ); }
+                    if (pr != 4) { kept_c = lp.beta(row) <= KEEP_TOL; lp.set_kind(row, RK_INEQ); }
                     bool rebuild = false;
                     if (lp.growth > GROWTH_SAFE) {
-                        if (!retested || lp.growth > 1e6) {
+                        // second alarm on the same row: a "redundant" verdict stands only with a margin far above what the small
+                        // pivot can have cost (error ~ eps * growth * |entries| <= 1e-8), a "kept" verdict stands as it is
+                        const bool clear_cut = kept_c || lp.beta(row) > 1e3 * TOL_FEAS;
+                        if (!retested || lp.growth > 1e6 || !clear_cut) {
                             // doubtful pivots: this decision is discarded, the dictionary is rebuilt and the row is tested again
                             if (retested || ++refactors > 64 || !refactor()) { retry = true; reason = retested ? 5 : 6; break; }
                             mark_tight();
@@ -1091,13 +1109,15 @@ __global__ void __launch_bounds__(64, (SLOTS >= 2 ? 2 : R2W)) k_region2(
                             continue;
                         }
                         // The alarm came back although this short run started from a freshly factorised dictionary: the small
-                        // pivot belongs to this row, nothing has accumulated (error <= eps * growth <= 1e-10).  The decision
-                        // stands (the LDS engine accepts under the same condition); the run's pivots stay in the dictionary, the
-                        // growth monitor starts again, and the next alarm rebuilds it.
+                        // pivot belongs to this row, nothing has accumulated.  A clear-cut decision stands; the run's pivots stay in
+                        // the dictionary, the growth monitor starts again, and the next alarm rebuilds it.
                         lp.growth = 0.0;
                     }
                     retested = false;
                     wave_sync();
+#ifdef R2_DEBUG
+                    if (lane == 0) printf("row %d: LP pr=%d beta=%.3e growth=%.3e kept=%d iters=%d\n", cidx, pr, lp.beta(row), lp.growth, (int)kept_c, lp.iters);
+#endif
                     if (lane == 0) s.kept[cidx] = kept_c ? 1 : 2;
                     wave_sync();
                     if (rebuild && (++refactors > 64 || !refactor())) { retry = true; reason = 6; break; }

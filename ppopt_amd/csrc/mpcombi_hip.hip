@@ -587,7 +587,7 @@ void *mpc_stream(const mpc_handle *h) { return h ? reinterpret_cast<void *>(h->s
 
 // ---- frontier ----------------------------------------------------------------------------------------------
 static int frontier_reset(mpc_handle *h, long long n, int k) {
-    if (n < 0 || k < 0 || k > h->n_c) return fail(h, MPC_ERR_INVALID, "bad frontier shape");
+    if (n < 0 || k < 0 || (n > 0 && k > h->n_c)) return fail(h, MPC_ERR_INVALID, "bad frontier shape");
     if (n > 0x7fffffffLL / std::max(k + 1, 1)) return fail(h, MPC_ERR_INVALID, "frontier too large for 32-bit offsets");
     HIP_TRY(h, hipSetDevice(h->device));
     HIP_TRY(h, h->frontier.ensure((size_t)std::max<long long>(n, 1) * std::max(k, 1) * sizeof(int32_t), h->stream));

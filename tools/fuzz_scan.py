@@ -27,6 +27,9 @@ for it in range(n_prob):
         seed = int(rng.integers(0, 10 ** 6))
         d = pg.generate_mpqp_data(nx, nt, m, seed)
         tag = (nx, nt, m, seed)
+        if kind == 'mpqp_eq':   # the first one or two rows become equalities
+            d['equality_indices'] = list(range(int(rng.integers(1, 3))))
+            tag = tag + (len(d['equality_indices']),)
     with warnings.catch_warnings():
         warnings.simplefilter('ignore')
         if kind == 'mplp':
