@@ -16,11 +16,18 @@ rng = numpy.random.default_rng(int(sys.argv[3]) if len(sys.argv) > 3 else 99)
 tot = diff = nreg = regdiff = coefbad = 0
 kinds = {}
 for it in range(n_prob):
+    print('program', it, flush=True) if kind == 'big' else None
     if kind == 'mpc':
         choice = int(rng.integers(0, 2))
         N = int(rng.integers(2, 5))
         d = pg.double_integrator_data(N, x_bound=float(rng.uniform(2, 6)), u_bound=float(rng.uniform(0.5, 2))) if choice == 0 else pg.quad_tank_data(int(rng.integers(2, 4)))
         tag = ('dblint', N) if choice == 0 else ('quadtank',)
+    elif kind == 'big':   # shapes near the limits of the kernel instantiations (two tableau rows per lane, n_theta 9-10, 32 columns)
+        nx, nt = int(rng.integers(10, 27)), int(rng.integers(3, 11))
+        m = int(rng.integers(nx + 5, 2 * nx + 40))
+        seed = int(rng.integers(0, 10 ** 6))
+        d = pg.generate_mpqp_data(nx, nt, m, seed)
+        tag = (nx, nt, m, seed)
     else:
         nx, nt = int(rng.integers(3, 9)), int(rng.integers(1, 7))
         m = int(rng.integers(nx + 3, 3 * nx + 4))
@@ -47,8 +54,11 @@ for it in range(n_prob):
         gen = depth != max_depth
         st = eng.level_run(gen)
         gc, gs = eng.frontier_get(), eng.level_status()
-        if len(gc) > 6000 or len(gc) == 0:
+        if len(gc) == 0 or (kind != 'big' and len(gc) > 6000) or len(gc) > 400000:
             break
+        if len(gc) > 4000:   # big levels: an evenly strided sample plus some of the regions
+            pick = numpy.unique(numpy.concatenate([numpy.linspace(0, len(gc) - 1, 3000).astype(numpy.int64), numpy.flatnonzero(gs == 3)[:300]]))
+            gc, gs = numpy.ascontiguousarray(gc[pick]), gs[pick]
         ost, oregs = P.check_level(gc, 0, True)
         tot += len(gc)
         for c, v, ov in zip(gc.tolist(), gs.tolist(), ost.tolist()):
