@@ -566,3 +566,56 @@ def test_random_shapes_match_oracle(oracle, nx, nt, m, seed, mplp, max_levels):
             assert rows_match(r.E, r.f, q['E'], q['f'], tol), key
         else:
             assert is_knife_edge(P, list(key), cond_limit=1e6), f'facet sets differ at robust region {key}'
+
+
+def _two_rank_worker(rank, world, port, name, out):
+    import torch
+    import torch.distributed as dist
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    from ppopt_amd import Solver
+    from ppopt_amd.distributed import HipLevelEngine, solve_distributed
+    from test_host_logic import build_program
+    torch.cuda.set_device(0)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        g = load_golden(name)
+        with warnings.catch_warnings():
+            warnings.simplefilter('ignore')
+            prog = build_program(g, Solver())
+        eng = HipLevelEngine(prog, 0)
+        prof = []
+        sol = solve_distributed(eng, prog, profile=prof, shard_min=8)
+        out[rank] = (sorted(tuple(r.active_set) for r in sol.critical_regions),
+                     [(p['candidates'], p['local_candidates'], p['sharded'], p['status'][:5]) for p in prof if p['depth'] > 0])
+        eng.close()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('name', ['c2_dblint_n5', 'rand_6_3_12_s1'])
+def test_two_ranks_share_one_gpu(name):
+    """The multi-GPU driver with a REAL world of two ranks, both on this GPU (gloo carries the device tensors; RCCL needs one
+    device per rank): replicated first levels, the split, subtree-local levels with the pruned-mask exchange, the final
+    region gather.  Every rank must return the reference's complete region set, and the shards must cover the levels."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context('spawn')
+    port = 29650 + os.getpid() % 300
+    with ctx.Manager() as mgr:
+        out = mgr.dict()
+        ps = [ctx.Process(target=_two_rank_worker, args=(r, 2, port, name, out)) for r in range(2)]
+        for p in ps:
+            p.start()
+        for p in ps:
+            p.join(600)
+        assert [p.exitcode for p in ps] == [0, 0]
+        res = dict(out)
+    g = load_golden(name)
+    ref = sorted(golden_regions(g))
+    for rank in range(2):
+        sets, levels = res[rank]
+        assert sets == ref, f'rank {rank}'
+    for i, ((n0, l0, sh0, h0), (n1, l1, sh1, h1)) in enumerate(zip(res[0][1], res[1][1])):
+        assert n0 == n1 == len(g[f'L{i}_verdict']) and h0 == h1 == numpy.bincount(g[f'L{i}_verdict'], minlength=5).tolist()
+        assert sh0 == sh1 and (l0 + l1 == n0 if sh0 else l0 == l1 == n0)
+    assert any(sh for _, _, sh, _ in res[0][1])
