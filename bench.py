@@ -119,12 +119,18 @@ def main():
     import torch
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs an MI355X: torch.cuda.is_available() is False (there is no CPU fallback)')
+    if os.environ.get('PPOPT_BENCH_BACKEND', 'nccl') != 'nccl':
+        local_rank = 0   # self-test: every rank on device 0
     torch.cuda.set_device(local_rank)
     import torch.distributed as dist
     if distributed:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29533')
-        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local_rank))
+        backend = os.environ.get('PPOPT_BENCH_BACKEND', 'nccl')   # 'gloo': several ranks on ONE GPU (self-test of this script)
+        if backend == 'nccl':
+            dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local_rank))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     import __graft_entry__ as entry
     if rank == 0:
