@@ -373,7 +373,7 @@ def test_two_way_split_on_one_gpu(name, split_level):
             assert numpy.array_equal(getattr(a[key], fld), getattr(b[key], fld)), (key, fld)
 
 
-@pytest.mark.parametrize('name,levels_, per_level', [('c4_rand_20_8_20_s0', 5, 600), ('c3_quadtank_n10', 4, 500)])
+@pytest.mark.parametrize('name,levels_, per_level', [('c4_rand_20_8_20_s0', 6, 600), ('c3_quadtank_n10', 4, 500)])
 def test_sampled_deep_levels_match_oracle(oracle, name, levels_, per_level):
     """Parity below the depth the golden files cover: an evenly strided sample of every level of the bench workloads (the
     dictionary cache, the screens and the quick tests are all in play there) is re-checked by the CPU oracle -- verdicts
