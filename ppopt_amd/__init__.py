@@ -6,7 +6,9 @@ Device layer (HIP, gfx950): csrc/ behind the C ABI of include/mpcombi.h, loaded 
 from .critical_region import CriticalRegion
 from .mplp_program import MPLP_Program
 from .mpqp_program import MPQP_Program
+from .mpmilp_program import MPMILP_Program
+from .mpmiqp_program import MPMIQP_Program
 from .solution import Solution
 from .solver import Solver, SolverOutput
 
-__all__ = ['CriticalRegion', 'MPLP_Program', 'MPQP_Program', 'Solution', 'Solver', 'SolverOutput']
+__all__ = ['CriticalRegion', 'MPLP_Program', 'MPQP_Program', 'MPMILP_Program', 'MPMIQP_Program', 'Solution', 'Solver', 'SolverOutput']

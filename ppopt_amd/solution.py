@@ -106,6 +106,10 @@ class Solution:
         region, x = self.locator(device).query(th, self.point_location_tolerance, self.is_overlapping, want_x=True)
         return x, region
 
+    def is_mixed_integer_sol(self) -> bool:
+        from .mpmilp_program import MPMILP_Program
+        return isinstance(self.program, MPMILP_Program)
+
     def theta_dim(self) -> int:
         return self.program.num_t()
 

@@ -1,0 +1,201 @@
+"""Mixed-integer caller of the path on the MI355X against goldens captured from the
+reference's own mixed-integer test problems (tests/golden/mi_*.npz, oracle/ref_harness/gen_mi_goldens.py).
+
+Checked per problem: the mixed-integer presolve, every partial binary fixation, the list of feasible fixations, every
+substituted continuous program and its region set, the final Solution (after the 1-D overlap reduction where the
+reference applies it) and Solution.evaluate / evaluate_objective at sampled parameter points.  The region counts the
+reference's tests assert (tests/mpmiqp_solver_tests/test_mpmiqp.py:86-140) are restated at the end."""
+import glob
+import os
+import warnings
+
+import numpy
+import pytest
+
+from conftest import rows_match
+
+pytestmark = pytest.mark.gpu
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+MI_FILES = sorted(glob.glob(os.path.join(GOLDEN, 'mi_*.npz')))
+IDS = [os.path.basename(p)[3:-4] for p in MI_FILES]
+TOL = 1e-8
+
+
+def build(g, post_process=True):
+    from ppopt_amd import MPMILP_Program, MPMIQP_Program
+    kw = {}
+    for key in ('c_c', 'c_t', 'Q_t'):
+        if 'raw_' + key in g.files:
+            kw[key] = g['raw_' + key]
+    if 'raw_equality_indices' in g.files:
+        kw['equality_indices'] = g['raw_equality_indices'].tolist()
+    bins = g['raw_binary_indices'].tolist()
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        if str(g['cls']) == 'MPMIQP_Program':
+            return MPMIQP_Program(g['raw_A'], g['raw_b'], g['raw_c'], g['raw_H'], g['raw_Q'], g['raw_A_t'],
+                                  g['raw_b_t'], g['raw_F'], bins, post_process=post_process, **kw)
+        return MPMILP_Program(g['raw_A'], g['raw_b'], g['raw_c'], g['raw_H'], g['raw_A_t'], g['raw_b_t'], g['raw_F'],
+                              bins, post_process=post_process, **kw)
+
+
+def region_map(g, prefix):
+    out = {}
+    for i in range(int(g[prefix + 'n'])):
+        k, ne = int(g[prefix + 'k'][i]), int(g[prefix + 'nE'][i])
+        out[tuple(g[prefix + 'as'][i, :k].tolist())] = dict(
+            A=g[prefix + 'A'][i], b=g[prefix + 'b'][i], C=g[prefix + 'C'][i, :k], d=g[prefix + 'd'][i, :k],
+            E=g[prefix + 'E'][i, :ne], f=g[prefix + 'f'][i, :ne])
+    return out
+
+
+def same_rows(E1, f1, E2, f2):
+    """Row sets equal under 1e-8, order and numerically duplicate rows ignored: the reference removes only EXACT
+    duplicates (constraint_utilities.py:125-134), so whether two copies of a facet that differ in the last bit
+    collapse is rounding noise of either side, not a property of the region."""
+    return rows_match(E1, f1, E2, f2, TOL)
+
+
+@pytest.mark.parametrize('path', MI_FILES, ids=IDS)
+def test_mixed_integer_presolve(path):
+    g = numpy.load(path)
+    prog = build(g)
+    for key in ('A', 'b', 'F', 'A_t', 'b_t', 'c', 'H'):
+        assert getattr(prog, key).shape == g['proc_' + key].shape, key
+        numpy.testing.assert_allclose(getattr(prog, key), g['proc_' + key], atol=1e-12, rtol=0, err_msg=key)
+    assert list(prog.equality_indices) == g['proc_eq'].tolist()
+    assert prog.binary_indices == g['binary_indices'].tolist()
+    assert prog.cont_indices == g['cont_indices'].tolist()
+
+
+@pytest.mark.parametrize('path', MI_FILES, ids=IDS)
+def test_binary_fixations(path):
+    from ppopt_amd.mp_solvers.mitree import MITree
+    g = numpy.load(path)
+    prog = build(g)
+    for fix, want in zip(g['bin_fix'].tolist(), g['bin_feas'].tolist()):
+        partial = [v for v in fix if v >= 0]
+        assert prog.check_bin_feasibility(partial) == want, partial
+    assert prog.feasible_combinations() == g['combos'].tolist()
+    tree = MITree(prog, depth=0)
+    assert tree.count_nodes() == int(g['n_nodes'])
+    assert [leaf.fixed_bins for leaf in tree.get_full_leafs()] == g['combos'].tolist()
+
+
+@pytest.mark.parametrize('path', MI_FILES, ids=IDS)
+def test_substituted_programs_and_their_regions(path):
+    from ppopt_amd.mp_solvers.solve_mpqp import mpqp_algorithm, solve_mpqp
+    g = numpy.load(path)
+    prog = build(g)
+    for i, fix in enumerate(g['combos'].tolist()):
+        with warnings.catch_warnings():
+            warnings.simplefilter('ignore')
+            sub = prog.generate_substituted_problem(fix)
+        for key in ('A', 'b', 'F', 'A_t', 'b_t', 'c', 'H', 'c_c', 'c_t'):
+            want = g[f'S{i}_{key}']
+            assert getattr(sub, key).shape == want.shape, (fix, key)
+            numpy.testing.assert_allclose(getattr(sub, key), want, atol=1e-12, rtol=0, err_msg=f'{fix} {key}')
+        if f'S{i}_Q' in g.files:
+            numpy.testing.assert_allclose(sub.Q, g[f'S{i}_Q'], atol=1e-12, rtol=0)
+        assert list(sub.equality_indices) == g[f'S{i}_eq'].tolist()
+        sol = solve_mpqp(sub, mpqp_algorithm.combinatorial)
+        want = region_map(g, f'S{i}_R_')
+        got = {tuple(r.active_set): r for r in sol.critical_regions}
+        assert sorted(got) == sorted(want), fix
+        for key, ref in want.items():
+            r = got[key]
+            numpy.testing.assert_allclose(r.A, ref['A'], atol=TOL, rtol=0)
+            numpy.testing.assert_allclose(r.b.flatten(), ref['b'], atol=TOL, rtol=0)
+            numpy.testing.assert_allclose(r.C, ref['C'], atol=TOL, rtol=0)
+            numpy.testing.assert_allclose(r.d.flatten(), ref['d'], atol=TOL, rtol=0)
+            assert same_rows(r.E, r.f, ref['E'], ref['f']), (fix, key)
+
+
+@pytest.mark.parametrize('path', MI_FILES, ids=IDS)
+def test_solve_mpmiqp_matches_reference(path):
+    from ppopt_amd.mp_solvers.solve_mpmiqp import solve_mpmiqp
+    g = numpy.load(path)
+    prog = build(g)
+    sol = solve_mpmiqp(prog, num_cores=1)
+    assert sol.is_mixed_integer_sol()
+    assert len(sol) == int(g['F_n'])
+    assert bool(sol.is_overlapping) == bool(g['F_overlapping'])
+    want = []
+    for i in range(int(g['F_n'])):
+        k, ne = int(g['F_k'][i]), int(g['F_nE'][i])
+        want.append((tuple(g['F_y'][i].tolist()), tuple(g['F_as'][i, :k].tolist()), g['F_E'][i, :ne], g['F_f'][i, :ne],
+                     g['F_A'][i], g['F_b'][i]))
+    used = set()
+    for r in sol.critical_regions:
+        assert r.y_indices == prog.binary_indices and r.x_indices == prog.cont_indices
+        hit = None
+        for j, (y, aset, E, f, A, b) in enumerate(want):
+            if j in used or y != tuple(r.y_fixation) or aset != tuple(r.active_set):
+                continue
+            if same_rows(r.E, r.f, E, f) and numpy.allclose(r.A, A, atol=TOL) and numpy.allclose(r.b.flatten(), b, atol=TOL):
+                hit = j
+                break
+        assert hit is not None, (r.y_fixation, r.active_set, r.E, r.f)
+        used.add(hit)
+    assert len(used) == len(want)
+    # the evaluation the reference's tests exercise: Solution.evaluate / evaluate_objective
+    for th, ok, x, obj in zip(g['T_theta'], g['T_ok'], g['T_x'], g['T_obj']):
+        got = sol.evaluate(th.reshape(-1, 1))
+        assert (got is not None) == bool(ok), th
+        if ok:
+            assert abs(sol.evaluate_objective(th.reshape(-1, 1)) - obj) <= 1e-7 * max(1.0, abs(obj)), th
+            if not bool(g['F_overlapping']):
+                numpy.testing.assert_allclose(got.flatten(), x, atol=1e-7, rtol=1e-9)
+
+
+def _load(name):
+    return numpy.load(os.path.join(GOLDEN, f'mi_{name}.npz'))
+
+
+def test_region_counts_the_reference_asserts():
+    """tests/mpmiqp_solver_tests/test_mpmiqp.py:86-132."""
+    from ppopt_amd.mp_solvers.solve_mpmiqp import solve_mpmiqp
+    from ppopt_amd.utils.region_overlap_utils import get_bounds_1d
+    for name, count in (('bard_mpMILP_adapted_degenerate', 5), ('mpMILP_1d', 3), ('pappas_multi_objective', 3)):
+        assert len(solve_mpmiqp(build(_load(name)), num_cores=1)) == count, name
+    sol = solve_mpmiqp(build(_load('bard_mpMILP_adapted_degenerate')), num_cores=1)
+    assert numpy.isclose(sol.evaluate_objective(numpy.array([[2.]])), 2)
+    assert numpy.isclose(sol.evaluate_objective(numpy.array([[3.]])), 1)
+    sol = solve_mpmiqp(build(_load('bard_mpMILP_adapted_2')), num_cores=1)
+    for th, val in ((2., 2), (3., 1), (8., 1), (9., 3)):
+        assert numpy.isclose(sol.evaluate_objective(numpy.array([[th]])), val)
+    sol = solve_mpmiqp(build(_load('mpMILP_1d')), num_cores=1)
+    for th, val in ((2., 2), (45., 40), (60., 50)):
+        assert numpy.isclose(sol.evaluate_objective(numpy.array([[th]])), val)
+    for cr in sol.critical_regions:
+        lb, ub = get_bounds_1d(cr.E, cr.f)
+        assert any(numpy.isclose(lb, a) and numpy.isclose(ub, b) for a, b in [(0, 40), (40, 50), (50, 100)])
+
+
+def test_explicit_solution_agrees_with_the_milp_at_a_point():
+    """tests/mpmiqp_solver_tests/test_mpmiqp.py:60-76,134-155: evaluate() against the MILP solved at that theta
+    (on the device, as the batch of LPs over the fixations)."""
+    from ppopt_amd.mp_solvers.solve_mpmiqp import solve_mpmiqp
+    for name, theta in (('mpMILP_market_problem', [[0.0], [500.0]]), ('acevedo_mpmilp', [[0.5]] * 3),
+                        ('pappas_multi_objective_2', [[90.0]])):
+        prog = build(_load(name))
+        sol = solve_mpmiqp(prog, num_cores=1)
+        th = numpy.array(theta)
+        det = prog.solve_theta(th)
+        assert det is not None
+        assert numpy.isclose(det.obj, sol.evaluate_objective(th)), name
+        assert numpy.allclose(det.sol, sol.evaluate(th).flatten(), atol=1e-6), name
+
+
+def test_sub_problem_shape_and_wrong_algorithm():
+    """test_mpmiqp.py:20-25,78-84."""
+    from ppopt_amd.mp_solvers.solve_mpmiqp import solve_mpmiqp
+    prog = build(_load('simple_mpMILP'))
+    sub = prog.generate_substituted_problem([0, 1])
+    assert sub.A.shape == (2, 1) and sub.equality_indices == [0]
+    assert prog.check_bin_feasibility([0, 0]) and prog.check_bin_feasibility([1, 0])
+    assert prog.check_bin_feasibility([0, 1]) and not prog.check_bin_feasibility([1, 1])
+    with pytest.raises(TypeError):
+        solve_mpmiqp(prog, 'enum')
+    solve_mpmiqp(build(_load('simple_mpMIQP')), num_cores=1).evaluate(numpy.array([[1.2]]))
