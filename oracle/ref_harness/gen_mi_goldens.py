@@ -92,6 +92,19 @@ NAMES = ['simple_mpMILP', 'simple_mpMIQP', 'mpMILP_market_problem', 'mpMIQP_mark
          'acevedo_mpmilp', 'pappas_multi_objective', 'pappas_multi_objective_2']
 
 
+# synthetic mixed-integer mpQPs of ppopt_amd.problem_generator.generate_mpmiqp_data (own code): (x, t, m, n_bin, seed)
+SYNTHETIC = {'rand_6_3_12_b5_s0': (6, 3, 12, 5, 0), 'rand_4_2_8_b3_s1': (4, 2, 8, 3, 1)}
+
+
+def synthetic_program(x, t, m, nb, seed):
+    import importlib.util
+    spec = importlib.util.spec_from_file_location('pg', os.path.join(ROOT, 'ppopt_amd', 'problem_generator.py'))
+    pg = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(pg)
+    d = pg.generate_mpmiqp_data(x, t, m, nb, seed)
+    return MPMIQP_Program(d['A'], d['b'], d['c'], d['H'], d['Q'], d['A_t'], d['b_t'], d['F'], d['binary_indices'])
+
+
 def capture_ctor_args(fixture_fn):
     """Runs the fixture body with the constructors wrapped so that the raw arguments are recorded."""
     rec = {}
@@ -171,7 +184,10 @@ def theta_box(prog):
 
 def generate(name):
     print(f'== {name}', flush=True)
-    fixture_fn = getattr(ref_fixtures, name)._get_wrapped_function()
+    if name in SYNTHETIC:
+        fixture_fn = lambda: synthetic_program(*SYNTHETIC[name])
+    else:
+        fixture_fn = getattr(ref_fixtures, name)._get_wrapped_function()
     prog, rec = capture_ctor_args(fixture_fn)
     out = {'cls': numpy.array(rec['cls'])}
     for k, v in rec['args'].items():
@@ -244,5 +260,5 @@ def generate(name):
 
 
 if __name__ == '__main__':
-    for nm in (sys.argv[1:] or NAMES):
+    for nm in (sys.argv[1:] or [*NAMES, *SYNTHETIC]):
         generate(nm)

@@ -29,30 +29,128 @@ namespace {
 
 thread_local std::string g_error;
 
+// ---- process-wide recycling of device blocks, pinned host blocks, streams and events -----------------------------------
+// A caller that solves many small programs one after the other (the mixed-integer enumeration: one mpc_create /
+// mpc_destroy per binary fixation) would otherwise pay ~50 hipMalloc/hipFree, 8 hipHostMalloc/hipHostFree and two
+// stream creations per program -- 12 ms, several times the kernel time of such a program.  Blocks are kept in size
+// classes (powers of two up to 1 MiB, MiB multiples above) and handed to the next handle on the same device; a block
+// is only returned to the pool once the work that used it has completed (destroy synchronises its streams first).
+std::mutex g_dev_pool_mutex;
+std::multimap<std::pair<int, size_t>, void *> g_dev_pool_free;   // (device, size) -> block
+size_t g_dev_pool_bytes = 0;
+constexpr size_t DEV_POOL_MAX_BYTES = size_t(4) << 30, DEV_POOL_MAX_BLOCK = size_t(512) << 20;
+
+size_t dev_size_class(size_t bytes) {
+    if (bytes <= 256) return 256;
+    if (bytes <= (size_t(1) << 20)) { size_t c = 256; while (c < bytes) c <<= 1; return c; }
+    return (bytes + (size_t(1) << 20) - 1) & ~((size_t(1) << 20) - 1);
+}
+hipError_t dev_pool_take(size_t cls, void **out) {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    {
+        std::lock_guard<std::mutex> lk(g_dev_pool_mutex);
+        auto it = g_dev_pool_free.find({dev, cls});
+        if (it != g_dev_pool_free.end()) { *out = it->second; g_dev_pool_bytes -= cls; g_dev_pool_free.erase(it); return hipSuccess; }
+    }
+    hipError_t e = hipMalloc(out, cls);
+    if (e != hipSuccess) {   // out of memory: give the pool back to the driver and try once more
+        std::vector<void *> drop;
+        { std::lock_guard<std::mutex> lk(g_dev_pool_mutex); for (auto &kv : g_dev_pool_free) if (kv.first.first == dev) drop.push_back(kv.second);
+          for (auto it = g_dev_pool_free.begin(); it != g_dev_pool_free.end();) { if (it->first.first == dev) { g_dev_pool_bytes -= it->first.second; it = g_dev_pool_free.erase(it); } else ++it; } }
+        for (void *q : drop) (void)hipFree(q);
+        (void)hipGetLastError();
+        e = hipMalloc(out, cls);
+    }
+    return e;
+}
+void dev_pool_give(void *p, size_t cls) {
+    if (!p) return;
+    if (cls <= DEV_POOL_MAX_BLOCK && cls == dev_size_class(cls)) {
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        std::lock_guard<std::mutex> lk(g_dev_pool_mutex);
+        if (g_dev_pool_bytes + cls <= DEV_POOL_MAX_BYTES) { g_dev_pool_free.emplace(std::make_pair(dev, cls), p); g_dev_pool_bytes += cls; return; }
+    }
+    (void)hipFree(p);
+}
+
 struct DevBuf {
     void *p = nullptr;
     size_t cap = 0;
     hipError_t ensure(size_t bytes, hipStream_t st, bool keep = false) {
         if (bytes <= cap) return hipSuccess;
-        size_t want = std::max(bytes, cap + cap / 2);
-        want = (want + 255) & ~size_t(255);
+        const size_t want = dev_size_class(std::max(bytes, cap + cap / 2));
         void *q = nullptr;
-        hipError_t e = hipMalloc(&q, want);
+        hipError_t e = dev_pool_take(want, &q);
         if (e != hipSuccess) return e;
-        if (keep && p && cap) {
-            e = hipMemcpyAsync(q, p, cap, hipMemcpyDeviceToDevice, st);
+        if (p) {
+            if (keep && cap) {
+                e = hipMemcpyAsync(q, p, cap, hipMemcpyDeviceToDevice, st);
+                if (e != hipSuccess) return e;
+            }
+            // the old block may still be read by work queued on this stream: it goes back to the pool only afterwards
+            e = st ? hipStreamSynchronize(st) : hipDeviceSynchronize();
             if (e != hipSuccess) return e;
-            e = hipStreamSynchronize(st);
-            if (e != hipSuccess) return e;
+            dev_pool_give(p, cap);
         }
-        if (p) (void)hipFree(p);
         p = q;
         cap = want;
         return hipSuccess;
     }
-    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+    // the caller has synchronised whatever used the block
+    void release() { if (p) dev_pool_give(p, cap); p = nullptr; cap = 0; }
     template <class T> T *as() const { return reinterpret_cast<T *>(p); }
 };
+
+// pooled page-locked host memory (also behind mpc_host_alloc / mpc_host_free)
+std::mutex g_pool_mutex;
+std::multimap<size_t, void *> g_pool_free;          // size -> block
+std::unordered_map<void *, size_t> g_pool_live;     // block -> size
+size_t g_pool_free_bytes = 0;
+constexpr size_t POOL_MAX_FREE = size_t(2) << 30;
+
+hipError_t host_pool_take(size_t bytes, void **out, size_t *got) {
+    const size_t gran = bytes >= (size_t(1) << 20) ? (size_t(1) << 20) : (size_t(64) << 10);
+    const size_t need = std::max<size_t>((bytes + gran - 1) / gran * gran, gran);
+    {
+        std::lock_guard<std::mutex> lk(g_pool_mutex);
+        auto it = g_pool_free.lower_bound(need);
+        if (it != g_pool_free.end() && it->first <= need + need / 2) {
+            *out = it->second;
+            if (got) *got = it->first;
+            g_pool_live[it->second] = it->first;
+            g_pool_free_bytes -= it->first;
+            g_pool_free.erase(it);
+            return hipSuccess;
+        }
+    }
+    void *p = nullptr;
+    hipError_t e = hipHostMalloc(&p, need, hipHostMallocPortable);
+    if (e != hipSuccess) return e;
+    std::lock_guard<std::mutex> lk(g_pool_mutex);
+    g_pool_live[p] = need;
+    *out = p;
+    if (got) *got = need;
+    return hipSuccess;
+}
+bool host_pool_give(void *p) {
+    size_t sz = 0;
+    {
+        std::lock_guard<std::mutex> lk(g_pool_mutex);
+        auto it = g_pool_live.find(p);
+        if (it == g_pool_live.end()) return false;
+        sz = it->second;
+        g_pool_live.erase(it);
+        if (g_pool_free_bytes + sz <= POOL_MAX_FREE) {
+            g_pool_free.emplace(sz, p);
+            g_pool_free_bytes += sz;
+            return true;
+        }
+    }
+    (void)hipHostFree(p);
+    return true;
+}
 
 // pinned (page-locked) host staging: device-to-host copies run at link speed and never page-fault
 struct HostBuf {
@@ -60,17 +158,69 @@ struct HostBuf {
     size_t cap = 0;
     hipError_t ensure(size_t bytes) {
         if (bytes <= cap) return hipSuccess;
-        size_t want = std::max(bytes, cap + cap / 2);
-        want = (want + 4095) & ~size_t(4095);
-        if (p) (void)hipHostFree(p);
-        p = nullptr; cap = 0;
-        hipError_t e = hipHostMalloc(&p, want, hipHostMallocDefault);
-        if (e == hipSuccess) cap = want;
-        return e;
+        const size_t want = std::max(bytes, cap + cap / 2);
+        release();
+        return host_pool_take(want, &p, &cap);
     }
-    void release() { if (p) (void)hipHostFree(p); p = nullptr; cap = 0; }
+    void release() { if (p) (void)host_pool_give(p); p = nullptr; cap = 0; }
     template <class T> T *as() const { return reinterpret_cast<T *>(p); }
 };
+
+// streams and events
+std::mutex g_sync_pool_mutex;
+std::map<int, std::vector<hipStream_t>> g_stream_pool;
+std::map<std::pair<int, int>, std::vector<hipEvent_t>> g_event_pool;   // (device, timing?) -> events
+std::map<int, int> g_cu_count;
+
+hipError_t pooled_stream(hipStream_t *out) {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    {
+        std::lock_guard<std::mutex> lk(g_sync_pool_mutex);
+        auto &v = g_stream_pool[dev];
+        if (!v.empty()) { *out = v.back(); v.pop_back(); return hipSuccess; }
+    }
+    return hipStreamCreateWithFlags(out, hipStreamNonBlocking);
+}
+void return_stream(hipStream_t s) {   // synchronised by the caller
+    if (!s) return;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    std::lock_guard<std::mutex> lk(g_sync_pool_mutex);
+    auto &v = g_stream_pool[dev];
+    if (v.size() < 64) v.push_back(s); else (void)hipStreamDestroy(s);
+}
+hipError_t pooled_event(hipEvent_t *out, bool timing) {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    {
+        std::lock_guard<std::mutex> lk(g_sync_pool_mutex);
+        auto &v = g_event_pool[{dev, timing ? 1 : 0}];
+        if (!v.empty()) { *out = v.back(); v.pop_back(); return hipSuccess; }
+    }
+    return timing ? hipEventCreate(out) : hipEventCreateWithFlags(out, hipEventDisableTiming);
+}
+void return_event(hipEvent_t e, bool timing) {
+    if (!e) return;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    std::lock_guard<std::mutex> lk(g_sync_pool_mutex);
+    auto &v = g_event_pool[{dev, timing ? 1 : 0}];
+    if (v.size() < 512) v.push_back(e); else (void)hipEventDestroy(e);
+}
+int cu_count(int device) {
+    {
+        std::lock_guard<std::mutex> lk(g_sync_pool_mutex);
+        auto it = g_cu_count.find(device);
+        if (it != g_cu_count.end()) return it->second;
+    }
+    hipDeviceProp_t prop;
+    int n = 256;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) n = prop.multiProcessorCount;
+    std::lock_guard<std::mutex> lk(g_sync_pool_mutex);
+    g_cu_count[device] = n;
+    return n;
+}
 
 int odd_at_least(int v) { return (v % 2) ? v : v + 1; }
 
@@ -257,16 +407,14 @@ int mpc_create(const mpc_problem *p, int32_t device, void *stream, mpc_handle **
     mpc_handle *h = new mpc_handle();
     h->device = device;
     HIP_TRY(nullptr, hipSetDevice(device));
-    hipDeviceProp_t prop;
-    HIP_TRY(nullptr, hipGetDeviceProperties(&prop, device));
-    h->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    h->n_cu = cu_count(device);
     if (stream) { h->stream = reinterpret_cast<hipStream_t>(stream); h->own_stream = false; }
-    else { HIP_TRY(nullptr, hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking)); h->own_stream = true; }
-    for (auto &e : h->ev) HIP_TRY(nullptr, hipEventCreate(&e));
-    for (auto &e : h->kev) HIP_TRY(nullptr, hipEventCreate(&e));
-    HIP_TRY(nullptr, hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking));
-    HIP_TRY(nullptr, hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
-    HIP_TRY(nullptr, hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
+    else { HIP_TRY(nullptr, pooled_stream(&h->stream)); h->own_stream = true; }
+    for (auto &e : h->ev) HIP_TRY(nullptr, pooled_event(&e, true));
+    for (auto &e : h->kev) HIP_TRY(nullptr, pooled_event(&e, true));
+    HIP_TRY(nullptr, pooled_stream(&h->stream2));
+    HIP_TRY(nullptr, pooled_event(&h->ev_fork, false));
+    HIP_TRY(nullptr, pooled_event(&h->ev_join, false));
     h->n_x = nx; h->n_t = nt; h->n_c = nc; h->n_eq = ne; h->n_tc = ntc; h->is_qp = p->Q != nullptr;
     { const char *ev = std::getenv("MPC_FORCE_V1"); h->force_v1 = ev && ev[0] == '1'; }
     { const char *ev = std::getenv("MPC_DEBUG_CYCLES"); h->debug_cycles = ev && ev[0] == '1'; }
@@ -566,16 +714,17 @@ int mpc_destroy(mpc_handle *h) {
     if (!h) return MPC_OK;
     (void)hipSetDevice(h->device);
     (void)hipStreamSynchronize(h->stream);
+    if (h->stream2) (void)hipStreamSynchronize(h->stream2);
     for (DevBuf *b : {&h->blocks, &h->iblocks, &h->frontier, &h->children, &h->status, &h->pruned, &h->pruned_new, &h->flag, &h->pos, &h->opt_list,
                       &h->childmask, &h->count, &h->offset, &h->recd, &h->reci, &h->ctr, &h->scratch, &h->sums, &h->retry_list, &h->pf_dev, &h->pr2_dev, &h->headd, &h->headi, &h->epool, &h->facet_flags, &h->kkt_code, &h->kkt_L, &h->theta_blocks, &h->theta_list, &h->vretry_list, &h->status_tmp, &h->part_counts, &h->part_lists, &h->kept_g, &h->done_g, &h->dict_d[0], &h->dict_d[1], &h->dict_i[0], &h->dict_i[1],
                       &h->dict_stored[0], &h->dict_stored[1], &h->parent_slot, &h->parent_slot_next}) b->release();
     for (HostBuf *b : {&h->st_list, &h->st_status, &h->st_hd, &h->st_hi, &h->st_pool, &h->st_fxd, &h->st_fxi, &h->st_rlist}) b->release();
-    for (auto &e : h->ev) if (e) (void)hipEventDestroy(e);
-    for (auto &e : h->kev) if (e) (void)hipEventDestroy(e);
-    if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
-    if (h->ev_join) (void)hipEventDestroy(h->ev_join);
-    if (h->stream2) { (void)hipStreamSynchronize(h->stream2); (void)hipStreamDestroy(h->stream2); }
-    if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
+    for (auto &e : h->ev) return_event(e, true);
+    for (auto &e : h->kev) return_event(e, true);
+    return_event(h->ev_fork, false);
+    return_event(h->ev_join, false);
+    return_stream(h->stream2);
+    if (h->own_stream) return_stream(h->stream);
     delete h;
     return MPC_OK;
 }
@@ -1302,56 +1451,17 @@ int mpc_level_regions_slots(mpc_handle *h, double *head_d, int32_t *head_i, int6
     return MPC_OK;
 }
 
-// ---- pooled page-locked host memory ---------------------------------------------------------------------------------
-namespace {
-std::mutex g_pool_mutex;
-std::multimap<size_t, void *> g_pool_free;          // size -> block
-std::unordered_map<void *, size_t> g_pool_live;     // block -> size
-size_t g_pool_free_bytes = 0;
-constexpr size_t POOL_MAX_FREE = size_t(2) << 30;
-}  // namespace
-
+// ---- pooled page-locked host memory (host_pool_* above) ------------------------------------------------------------------
 int mpc_host_alloc(uint64_t bytes, void **out) {
     if (!out) return MPC_ERR_INVALID;
     *out = nullptr;
-    const size_t gran = bytes >= (size_t(1) << 20) ? (size_t(1) << 20) : (size_t(64) << 10);
-    const size_t need = std::max<size_t>(((size_t)bytes + gran - 1) / gran * gran, gran);
-    {
-        std::lock_guard<std::mutex> lk(g_pool_mutex);
-        auto it = g_pool_free.lower_bound(need);
-        if (it != g_pool_free.end() && it->first <= need + need / 2) {
-            *out = it->second;
-            g_pool_live[it->second] = it->first;
-            g_pool_free_bytes -= it->first;
-            g_pool_free.erase(it);
-            return MPC_OK;
-        }
-    }
-    void *p = nullptr;
-    if (hipHostMalloc(&p, need, hipHostMallocPortable) != hipSuccess) return fail(nullptr, MPC_ERR_HIP, "hipHostMalloc failed");
-    std::lock_guard<std::mutex> lk(g_pool_mutex);
-    g_pool_live[p] = need;
-    *out = p;
+    if (host_pool_take((size_t)bytes, out, nullptr) != hipSuccess) return fail(nullptr, MPC_ERR_HIP, "hipHostMalloc failed");
     return MPC_OK;
 }
 
 int mpc_host_free(void *p) {
     if (!p) return MPC_OK;
-    size_t sz = 0;
-    {
-        std::lock_guard<std::mutex> lk(g_pool_mutex);
-        auto it = g_pool_live.find(p);
-        if (it == g_pool_live.end()) return MPC_ERR_INVALID;
-        sz = it->second;
-        g_pool_live.erase(it);
-        if (g_pool_free_bytes + sz <= POOL_MAX_FREE) {
-            g_pool_free.emplace(sz, p);
-            g_pool_free_bytes += sz;
-            return MPC_OK;
-        }
-    }
-    (void)hipHostFree(p);
-    return MPC_OK;
+    return host_pool_give(p) ? MPC_OK : MPC_ERR_INVALID;
 }
 
 int mpc_level_regions(mpc_handle *h, double *rec_d, int32_t *rec_i, int64_t *cand_index, int64_t cap) {
@@ -1487,29 +1597,29 @@ static int lp_batch_impl(int32_t device, int64_t n_lp, int32_t m, int32_t n, con
     const size_t lds = (((size_t)(m + 1) * ld * 8 + (size_t)(ld + 1 + 3 * (m + 2)) * 4) + 15) & ~size_t(15);
     if (lds > 160 * 1024) return fail(nullptr, MPC_ERR_INVALID, "LP does not fit the 160 KiB LDS of one CU");
     if (lds > 48 * 1024) HIP_TRY(nullptr, hipFuncSetAttribute(reinterpret_cast<const void *>(k_lp_batch), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipDeviceProp_t prop;
-    HIP_TRY(nullptr, hipGetDeviceProperties(&prop, device));
+    const int n_cu = cu_count(device);
     const size_t szA = (shared_A ? 1 : (size_t)n_lp) * m * n * 8, szb = (shared_b ? 1 : (size_t)n_lp) * m * 8;
     const size_t szc = c ? (shared_c ? 1 : (size_t)n_lp) * n * 8 : 0, szeq = (size_t)n_lp * m;
-    double *dA = nullptr, *db = nullptr, *dc = nullptr, *dx = nullptr, *dobj = nullptr;
-    uint8_t *deq = nullptr;
-    int32_t *dst = nullptr, *dit = nullptr, *dtight = nullptr;
-    unsigned int *dwork = nullptr;
+    DevBuf bA, bb, bc, beq, bst, bit, bx, bobj, bwork, btight;   // pooled blocks (see dev_pool_take)
     int rc = MPC_OK;
     hipError_t e = hipSuccess;
     auto chk = [&](hipError_t err) { if (e == hipSuccess && err != hipSuccess) e = err; return err == hipSuccess; };
-    chk(hipMalloc((void **)&dA, szA)); chk(hipMalloc((void **)&db, szb));
-    if (c) chk(hipMalloc((void **)&dc, szc));
-    chk(hipMalloc((void **)&deq, szeq)); chk(hipMalloc((void **)&dst, (size_t)n_lp * 4)); chk(hipMalloc((void **)&dit, (size_t)n_lp * 4));
-    chk(hipMalloc((void **)&dx, (size_t)n_lp * n * 8)); chk(hipMalloc((void **)&dobj, (size_t)n_lp * 8)); chk(hipMalloc((void **)&dwork, 4));
-    if (tight) chk(hipMalloc((void **)&dtight, (size_t)n_lp * m * 4));
+    chk(bA.ensure(szA, nullptr)); chk(bb.ensure(szb, nullptr));
+    if (c) chk(bc.ensure(szc, nullptr));
+    chk(beq.ensure(szeq, nullptr)); chk(bst.ensure((size_t)n_lp * 4, nullptr)); chk(bit.ensure((size_t)n_lp * 4, nullptr));
+    chk(bx.ensure((size_t)n_lp * n * 8, nullptr)); chk(bobj.ensure((size_t)n_lp * 8, nullptr)); chk(bwork.ensure(4, nullptr));
+    if (tight) chk(btight.ensure((size_t)n_lp * m * 4, nullptr));
+    double *dA = bA.as<double>(), *db = bb.as<double>(), *dc = c ? bc.as<double>() : nullptr, *dx = bx.as<double>(), *dobj = bobj.as<double>();
+    uint8_t *deq = beq.as<uint8_t>();
+    int32_t *dst = bst.as<int32_t>(), *dit = bit.as<int32_t>(), *dtight = tight ? btight.as<int32_t>() : nullptr;
+    unsigned int *dwork = bwork.as<unsigned int>();
     if (e == hipSuccess) {
         chk(hipMemcpy(dA, A, szA, hipMemcpyHostToDevice)); chk(hipMemcpy(db, b, szb, hipMemcpyHostToDevice));
         if (c) chk(hipMemcpy(dc, c, szc, hipMemcpyHostToDevice));
         chk(hipMemcpy(deq, eq, szeq, hipMemcpyHostToDevice)); chk(hipMemset(dwork, 0, 4));
     }
     if (e == hipSuccess) {
-        const int grid = (int)std::min<long long>(n_lp, (long long)std::max(prop.multiProcessorCount, 1) * waves_per_cu((int)lds));
+        const int grid = (int)std::min<long long>(n_lp, (long long)std::max(n_cu, 1) * waves_per_cu((int)lds));
         hipLaunchKernelGGL(k_lp_batch, dim3(grid), dim3(64), lds, 0, (long long)n_lp, m, n, ld, dA, shared_A, db, shared_b, dc, shared_c, deq, dst, dx, dobj, dit, dtight, dwork);
         chk(hipGetLastError());
         chk(hipDeviceSynchronize());
@@ -1519,8 +1629,8 @@ static int lp_batch_impl(int32_t device, int64_t n_lp, int32_t m, int32_t n, con
         if (iters) chk(hipMemcpy(iters, dit, (size_t)n_lp * 4, hipMemcpyDeviceToHost));
         if (tight) chk(hipMemcpy(tight, dtight, (size_t)n_lp * m * 4, hipMemcpyDeviceToHost));
     }
-    if (e != hipSuccess) rc = fail(nullptr, MPC_ERR_HIP, std::string("mpc_lp_solve_batch: ") + hipGetErrorString(e));
-    for (void *q : {(void *)dA, (void *)db, (void *)dc, (void *)deq, (void *)dst, (void *)dit, (void *)dx, (void *)dobj, (void *)dwork, (void *)dtight}) if (q) (void)hipFree(q);
+    if (e != hipSuccess) { rc = fail(nullptr, MPC_ERR_HIP, std::string("mpc_lp_solve_batch: ") + hipGetErrorString(e)); (void)hipDeviceSynchronize(); }
+    for (DevBuf *q : {&bA, &bb, &bc, &beq, &bst, &bit, &bx, &bobj, &bwork, &btight}) q->release();
     return rc;
 }
 

@@ -192,3 +192,11 @@ def control_allocation_data() -> Dict:
     A_t = numpy.vstack([-numpy.eye(m), numpy.eye(m)])
     b_t = numpy.vstack([-cmd_min.reshape((m, 1)), cmd_max.reshape((m, 1))])
     return _pack(A, b, c, H, Q, A_t, b_t, F)
+
+
+def generate_mpmiqp_data(x: int = 6, t: int = 3, m: int = 12, n_bin: int = 4, seed: Optional[int] = None) -> Dict:
+    """Random dense mixed-integer mpQP for measurements (not in the reference): ``generate_mpqp_data`` on
+    x + n_bin variables whose last n_bin are declared binary.  Adds the key ``binary_indices``."""
+    d = generate_mpqp_data(x + n_bin, t, m, seed)
+    d['binary_indices'] = list(range(x, x + n_bin))
+    return d

@@ -46,7 +46,7 @@ class _ObjectiveOnly:
 
 
 def test_goldens_present():
-    assert len(MI_FILES) == 11
+    assert len(MI_FILES) == 13
 
 
 def test_binary_fixations_order_is_tree_leaf_order():
