@@ -103,6 +103,7 @@ def main():
     ap.add_argument('--workload', default='c4', choices=sorted(WORKLOADS))
     ap.add_argument('--cpu-sample', type=int, default=300000, help='candidates in the CPU baseline sample (0 = skip)')
     ap.add_argument('--locate', type=int, default=100000, help='points of the point-location extra (0 = skip)')
+    ap.add_argument('--mi', type=int, default=1, help='mixed-integer enumeration extra on a synthetic mpMIQP (0 = skip)')
     ap.add_argument('--dist-single', action='store_true', help='run the multi-GPU driver with a process group of one rank (self-test)')
     args = ap.parse_args()
 
@@ -301,6 +302,31 @@ def main():
                                  'points_per_s_wall': args.locate / wall,
                                  'host_loop_points_per_s': n_host / host_dt,
                                  'host_loop_agrees': bool(numpy.array_equal(numpy.array(host_idx), idx_b[:n_host]))}
+    if rank == 0 and not distributed and args.mi > 0:
+        # caller of the path: mixed-integer enumeration, one continuous sub-program per binary fixation.
+        # Synthetic mpMIQP generate_mpmiqp_data(8, 4, 16, n_bin=6, seed=1): 64 feasible fixations, sub-programs 8/4/29.
+        # The reference (HiGHS stand-ins, one core, build container) takes 109 s on the 32-fixation sibling
+        # (6, 3, 12, n_bin=5, seed=0; tests/golden/mi_rand_6_3_12_b5_s0.npz).  Not part of `value`.
+        import warnings
+        from ppopt_amd import MPMIQP_Program
+        from ppopt_amd.mp_solvers.solve_mpmiqp import solve_mpmiqp
+        from ppopt_amd.problem_generator import generate_mpmiqp_data
+        dmi = generate_mpmiqp_data(8, 4, 16, 6, 1)
+        with warnings.catch_warnings():
+            warnings.simplefilter('ignore')
+            pmi = MPMIQP_Program(dmi['A'], dmi['b'], dmi['c'], dmi['H'], dmi['Q'], dmi['A_t'], dmi['b_t'], dmi['F'],
+                                 dmi['binary_indices'])
+            solve_mpmiqp(pmi)
+            best, n_reg = float('inf'), 0
+            for _ in range(3):
+                tq = time.perf_counter()
+                smi = solve_mpmiqp(pmi)
+                best = min(best, time.perf_counter() - tq)
+                n_reg = len(smi)
+        n_fix = len(pmi.feasible_combinations())
+        out['mi_enumeration'] = {'workload': 'generate_mpmiqp_data(8,4,16,n_bin=6,seed=1)', 'fixations': n_fix,
+                                 'regions': n_reg, 'ms': 1e3 * best, 'sub_programs_per_s': n_fix / best,
+                                 'regions_per_s': n_reg / best}
     if rank == 0 and not distributed and args.cpu_sample > 0:
         # frontiers of every level for the CPU sample: one extra untimed pass
         eng = prog.engine(local_rank)

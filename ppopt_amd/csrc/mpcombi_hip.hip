@@ -1613,23 +1613,27 @@ static int lp_batch_impl(int32_t device, int64_t n_lp, int32_t m, int32_t n, con
     uint8_t *deq = beq.as<uint8_t>();
     int32_t *dst = bst.as<int32_t>(), *dit = bit.as<int32_t>(), *dtight = tight ? btight.as<int32_t>() : nullptr;
     unsigned int *dwork = bwork.as<unsigned int>();
+    // own (pooled) stream: callers on other threads / handles keep running (no device-wide synchronisation)
+    hipStream_t st = nullptr;
+    chk(pooled_stream(&st));
     if (e == hipSuccess) {
-        chk(hipMemcpy(dA, A, szA, hipMemcpyHostToDevice)); chk(hipMemcpy(db, b, szb, hipMemcpyHostToDevice));
-        if (c) chk(hipMemcpy(dc, c, szc, hipMemcpyHostToDevice));
-        chk(hipMemcpy(deq, eq, szeq, hipMemcpyHostToDevice)); chk(hipMemset(dwork, 0, 4));
+        chk(hipMemcpyAsync(dA, A, szA, hipMemcpyHostToDevice, st)); chk(hipMemcpyAsync(db, b, szb, hipMemcpyHostToDevice, st));
+        if (c) chk(hipMemcpyAsync(dc, c, szc, hipMemcpyHostToDevice, st));
+        chk(hipMemcpyAsync(deq, eq, szeq, hipMemcpyHostToDevice, st)); chk(hipMemsetAsync(dwork, 0, 4, st));
     }
     if (e == hipSuccess) {
         const int grid = (int)std::min<long long>(n_lp, (long long)std::max(n_cu, 1) * waves_per_cu((int)lds));
-        hipLaunchKernelGGL(k_lp_batch, dim3(grid), dim3(64), lds, 0, (long long)n_lp, m, n, ld, dA, shared_A, db, shared_b, dc, shared_c, deq, dst, dx, dobj, dit, dtight, dwork);
+        hipLaunchKernelGGL(k_lp_batch, dim3(grid), dim3(64), lds, st, (long long)n_lp, m, n, ld, dA, shared_A, db, shared_b, dc, shared_c, deq, dst, dx, dobj, dit, dtight, dwork);
         chk(hipGetLastError());
-        chk(hipDeviceSynchronize());
-        chk(hipMemcpy(status, dst, (size_t)n_lp * 4, hipMemcpyDeviceToHost));
-        if (x) chk(hipMemcpy(x, dx, (size_t)n_lp * n * 8, hipMemcpyDeviceToHost));
-        if (obj) chk(hipMemcpy(obj, dobj, (size_t)n_lp * 8, hipMemcpyDeviceToHost));
-        if (iters) chk(hipMemcpy(iters, dit, (size_t)n_lp * 4, hipMemcpyDeviceToHost));
-        if (tight) chk(hipMemcpy(tight, dtight, (size_t)n_lp * m * 4, hipMemcpyDeviceToHost));
+        chk(hipMemcpyAsync(status, dst, (size_t)n_lp * 4, hipMemcpyDeviceToHost, st));
+        if (x) chk(hipMemcpyAsync(x, dx, (size_t)n_lp * n * 8, hipMemcpyDeviceToHost, st));
+        if (obj) chk(hipMemcpyAsync(obj, dobj, (size_t)n_lp * 8, hipMemcpyDeviceToHost, st));
+        if (iters) chk(hipMemcpyAsync(iters, dit, (size_t)n_lp * 4, hipMemcpyDeviceToHost, st));
+        if (tight) chk(hipMemcpyAsync(tight, dtight, (size_t)n_lp * m * 4, hipMemcpyDeviceToHost, st));
     }
+    if (st) { hipError_t es = hipStreamSynchronize(st); if (e == hipSuccess && es != hipSuccess) e = es; }
     if (e != hipSuccess) { rc = fail(nullptr, MPC_ERR_HIP, std::string("mpc_lp_solve_batch: ") + hipGetErrorString(e)); (void)hipDeviceSynchronize(); }
+    if (st) return_stream(st);
     for (DevBuf *q : {&bA, &bb, &bc, &beq, &bst, &bit, &bx, &bobj, &bwork, &btight}) q->release();
     return rc;
 }

@@ -169,6 +169,12 @@ class MPLP_Program:
                                        len(self.equality_indices), device=device)
         return self._engine
 
+    def release_engine(self) -> None:
+        """Gives the device handle back (its blocks return to the library's pool); a later call re-creates it."""
+        if self._engine is not None:
+            self._engine.close()
+            self._engine = None
+
     def _device_status(self, active_set) -> int:
         eng = self.engine()
         cand = numpy.asarray(list(active_set), dtype=numpy.int32).reshape(1, -1)

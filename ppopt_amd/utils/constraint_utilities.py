@@ -29,16 +29,15 @@ def detect_implicit_equalities(A: numpy.ndarray, b: numpy.ndarray) -> List[List[
     blk = numpy.hstack([A, b.reshape(-1, 1)]).astype(float)
     blk = blk / numpy.linalg.norm(blk, axis=1, keepdims=True)
     blk = blk / numpy.linalg.norm(blk, axis=1, keepdims=True)
-    pairs = []
-    m = blk.shape[0]
-    for i in range(m):
-        for j in range(i, m):
-            votes = int(abs(blk[i] @ blk[j] + 1) <= 1e-8)
-            votes += int(numpy.linalg.norm(blk[i] - blk[j], 2) <= 1e-12)
-            votes += int(numpy.allclose(blk[i], -blk[j]))
-            if votes >= 2:
-                pairs.append([i, j])
-    return pairs
+    # all pairs at once (the reference loops over them, :70-95): Gram matrix, pairwise distances, element-wise closeness
+    with numpy.errstate(invalid='ignore'):
+        vote_dot = numpy.abs(blk @ blk.T + 1.0) <= 1e-8
+        diff = blk[:, None, :] - blk[None, :, :]
+        vote_same = numpy.sqrt(numpy.sum(diff * diff, axis=2)) <= 1e-12
+        vote_close = numpy.all(numpy.abs(blk[:, None, :] + blk[None, :, :]) <= 1e-8 + 1e-5 * numpy.abs(blk[None, :, :]), axis=2)
+    votes = vote_dot.astype(numpy.int8) + vote_same + vote_close
+    hit = numpy.triu(votes >= 2)
+    return [[int(i), int(j)] for i, j in numpy.argwhere(hit)]
 
 
 def remove_zero_rows(A: numpy.ndarray, b: numpy.ndarray) -> List[numpy.ndarray]:

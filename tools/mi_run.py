@@ -31,6 +31,8 @@ for rep in range(3):
     print(f'rep {rep}: presolve {1e3*(t1-t0):.1f} ms, fixations {1e3*(t2-t1):.1f} ms ({len(combos)} of {1 << nb} feasible), '
           f'substitute+presolve {1e3*(t3-t2):.1f} ms, solve {1e3*(t4-t3):.1f} ms, {n_reg} regions; '
           f'n_c of subs {sorted(set(s.num_constraints() for s in subs))}')
-t0 = time.perf_counter()
-sol = solve_mpmiqp(prog, num_cores=1)
-print(f'solve_mpmiqp: {1e3*(time.perf_counter()-t0):.1f} ms, {len(sol)} regions')
+for cores in (1, 1, 2, 4, 8, 8):
+    t0 = time.perf_counter()
+    sol = solve_mpmiqp(prog, num_cores=cores)
+    dt = time.perf_counter() - t0
+    print(f'solve_mpmiqp(num_cores={cores}): {1e3*dt:.1f} ms, {len(sol)} regions, {len(combos)/dt:.0f} sub-programs/s')
