@@ -63,6 +63,7 @@ struct LevelCounters {
     unsigned long long rcycles[6];  // k_region2: rows, chebyshev, facets, record wave-cycles; refactors; facet pivots
     unsigned long long cycles[8];   // wave-cycles (s_memtime) spent in: KKT solve, theta LP, (x,theta) LP, region build; [4] theta rows, [5] theta stage 2; [6],[7] candidates decided by the box screen (stage 1 / multiplier row)
     unsigned int work_verdict, work_region, n_opt, n_pruned_new, work_retry, work_x, e_rows, work_r2, work_q, n_retry_theta, n_rretry;
+    unsigned long long r_box;       // k_region2: region rows removed by the bounding-box screen
 };
 
 struct Smem {

@@ -786,12 +786,14 @@ __global__ void __launch_bounds__(64, (NXC * SLOTS >= 32 ? X2_WAVES : 3)) k_x2(c
 // head_d (stride fd): A_x[n_x*n_t] b_x[n_x] A_l[k*n_t] b_l[k]
 // head_i (stride fi): status cand nE n_om n_la n_re e_off 0 | active[k] | omega[n_tc] | lambda[k] | reg_idx[n_c-k] | reg_con[n_c-k]
 // pool row: f, E[0..n_t)
+constexpr double BOX_REDUNDANT_MARGIN = 1e-6;   // unit-norm row units; ten times the LP feasibility tolerance
+
 template <int NT, int SLOTS>
 __global__ void __launch_bounds__(64, (SLOTS >= 2 ? 2 : R2W)) k_region2(
     const DevProblem *__restrict__ Pg, const int32_t *__restrict__ cands, int k, const int32_t *__restrict__ opt_list, int n_opt,
     uint8_t *__restrict__ status, double *__restrict__ head_d, int32_t *__restrict__ head_i, int fd, int fi,
     double *__restrict__ epool, LevelCounters *__restrict__ ctr, const uint8_t *__restrict__ kkcode, const double *__restrict__ Lin,
-    int W, uint8_t *__restrict__ kept_g, int ldk, unsigned int *__restrict__ done_g) {
+    int W, uint8_t *__restrict__ kept_g, int ldk, unsigned int *__restrict__ done_g, const double *__restrict__ box) {
     // W > 1 (few optimal candidates, idle CUs): W wavefronts share one candidate.  Each builds the same dictionary and runs
     // the same Chebyshev LP (deterministic, identical), then tests only the rows it owns (row % W == part).  The flags go
     // to kept_g; the wavefront that finishes last (done_g counter) merges them and writes the record.
@@ -802,7 +804,7 @@ __global__ void __launch_bounds__(64, (SLOTS >= 2 ? 2 : R2W)) k_region2(
     constexpr int NC = NT + 3;      // value | n_t sigma columns | r | one spare slot for x0
     constexpr int ID_SIGMA = 4096, ID_R = 8192;
     unsigned long long pivots = 0;
-    long long cyc = 0, rc_rows = 0, rc_cheb = 0, rc_facet = 0, rc_tot = 0, rc_refac = 0, rc_fpiv = 0;
+    long long cyc = 0, rc_rows = 0, rc_cheb = 0, rc_facet = 0, rc_tot = 0, rc_refac = 0, rc_fpiv = 0, rc_box = 0;
     for (;;) {
         unsigned int item = 0;
         if (lane == 0) item = atomicAdd(&ctr->work_r2, 1u);
@@ -878,7 +880,21 @@ __global__ void __launch_bounds__(64, (SLOTS >= 2 ? 2 : R2W)) k_region2(
 #pragma unroll
                     for (int t = 0; t < NT; ++t) if (t < nt) s.E[i * ldE + 1 + t] = g[t];
                 }
-                if (i < m) s.kept[i] = keep ? 0 : 3;   // 0 undecided, 1 kept, 2 redundant, 3 dropped (numerically zero row)
+                // Box screen: the region lies inside the parameter polytope, hence inside its (outward padded) bounding box
+                // [lo, hi].  A row whose left-hand side cannot reach f_i - 1e-6 anywhere in the box is never tight on the
+                // region: the reference's LP "row i as an equality" is infeasible for it (strongly redundant, dropped), and
+                // it cannot bring the Chebyshev radius below 1e-8 either (a ball of radius min(r', 1e-6) around the centre
+                // found without it satisfies it).  Such rows leave the LP before the first pivot.
+                bool boxred = false;
+                if (keep && box && i < nlam + nin) {
+                    double mx = 0.0;
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) if (g[t] != 0.0) mx = fma(g[t], g[t] > 0.0 ? box[NT + t] : box[t], mx);
+                    boxred = mx < h - BOX_REDUNDANT_MARGIN;
+                }
+                if (i < m) s.kept[i] = keep ? (boxred ? 2 : 0) : 3;   // 0 undecided, 1 kept, 2 redundant, 3 dropped (numerically zero row)
+                rc_box += __popcll(__ballot(boxred));
+                if (boxred) keep = false;
                 lp.var[sl] = i;
                 lp.kind[sl] = keep ? RK_INEQ : RK_DEAD;
                 double b0 = h;
@@ -1215,6 +1231,7 @@ __global__ void __launch_bounds__(64, (SLOTS >= 2 ? 2 : R2W)) k_region2(
         atomicAdd(&ctr->rcycles[0], (unsigned long long)rc_rows); atomicAdd(&ctr->rcycles[1], (unsigned long long)rc_cheb);
         atomicAdd(&ctr->rcycles[2], (unsigned long long)rc_facet); atomicAdd(&ctr->rcycles[3], (unsigned long long)rc_tot);
         atomicAdd(&ctr->rcycles[4], (unsigned long long)rc_refac); atomicAdd(&ctr->rcycles[5], (unsigned long long)rc_fpiv);
+        atomicAdd(&ctr->r_box, (unsigned long long)rc_box);
     }
 }
 

@@ -241,6 +241,7 @@ struct mpc_handle {
     DevProblem Pv{}, Pr{};    // verdict / region kernel views (same blocks, different LDS layouts)
     int lds_v = 0, lds_r = 0; // dynamic LDS bytes per wavefront
     int debug_cycles = 0;     // MPC_DEBUG_CYCLES=1: per-level cycle breakdown on stderr
+    int no_rbox = 0;          // MPC_NO_RBOX=1: no bounding-box screen of the region rows in k_region2 (A/B)
     int no_rsplit = 0;        // MPC_NO_RSPLIT=1: one wavefront per candidate in k_region2 whatever the load (A/B)
     int no_xquick = 0;        // MPC_NO_XQUICK=1: no quick (x,theta) test on the last level (A/B)
     int no_kkt_thread = 0;    // MPC_NO_KKT_THREAD=1: KKT solves stay inside the wave kernels (A/B)
@@ -419,6 +420,7 @@ int mpc_create(const mpc_problem *p, int32_t device, void *stream, mpc_handle **
     { const char *ev = std::getenv("MPC_FORCE_V1"); h->force_v1 = ev && ev[0] == '1'; }
     { const char *ev = std::getenv("MPC_DEBUG_CYCLES"); h->debug_cycles = ev && ev[0] == '1'; }
     { const char *ev = std::getenv("MPC_NO_RSPLIT"); h->no_rsplit = ev && ev[0] == '1'; }
+    { const char *ev = std::getenv("MPC_NO_RBOX"); h->no_rbox = ev && ev[0] == '1'; }
     { const char *ev = std::getenv("MPC_NO_XQUICK"); h->no_xquick = ev && ev[0] == '1'; }
     { const char *ev = std::getenv("MPC_NO_KKT_THREAD"); h->no_kkt_thread = ev && ev[0] == '1'; }
     { const char *ev = std::getenv("MPC_DICT_BUDGET_GB"); if (ev) h->dict_budget_gb = std::atof(ev); }
@@ -694,7 +696,7 @@ int mpc_create(const mpc_problem *p, int32_t device, void *stream, mpc_handle **
                 h->fast_r = tsel * 2 + (slots_r - 1);
                 const Layout l2 = make_layout(2, std::max(size_K, nt * (2 * nt + 1)), size_L, rows_t * nr, size_X, kmax, nc, nt + 2, 2, rows_t);
                 h->Pr2 = P; apply_layout(h->Pr2, l2); h->lds_r2 = l2.bytes;
-                h->grid_r2 = h->n_cu * std::min(12, waves_per_cu(h->lds_r2));
+                h->grid_r2 = h->n_cu * std::min(4 * (slots_r >= 2 ? 2 : R2W), waves_per_cu(h->lds_r2));   // waves per SIMD of the launch bounds
                 HIP_TRY(nullptr, h->pr2_dev.ensure(sizeof(DevProblem), h->stream));
                 HIP_TRY(nullptr, hipMemcpyAsync(h->pr2_dev.p, &h->Pr2, sizeof(DevProblem), hipMemcpyHostToDevice, h->stream));
                 HIP_TRY(nullptr, hipStreamSynchronize(h->stream));
@@ -1138,7 +1140,8 @@ int mpc_level_run(mpc_handle *h, int32_t gen_children, mpc_level_stats *stats) {
             const DevProblem *pr = h->pr2_dev.as<DevProblem>();
 #define MPC_LAUNCH_R2(NT_, SL_) hipLaunchKernelGGL((k_region2<NT_, SL_>), g, b, h->lds_r2, st, pr, h->frontier.as<int32_t>(), k, h->opt_list.as<int32_t>(), n_opt, \
                                                    h->status.as<uint8_t>(), h->headd.as<double>(), h->headi.as<int32_t>(), h->fd, h->fi, h->epool.as<double>(), ctr, kkc, kkl, \
-                                                   W, h->kept_g.as<uint8_t>(), ldk, h->done_g.as<unsigned int>())
+                                                   W, h->kept_g.as<uint8_t>(), ldk, h->done_g.as<unsigned int>(), \
+                                                   h->no_rbox ? (const double *)nullptr : h->targs.tvp + (size_t)NT_ * NT_ + NT_)
             HIP_TRY(h, hipEventRecord(h->kev[4], st));
             switch (h->fast_r) {
                 case 0: MPC_LAUNCH_R2(4, 1); break;
@@ -1207,9 +1210,9 @@ int mpc_level_run(mpc_handle *h, int32_t gen_children, mpc_level_stats *stats) {
                          host_ctr.cycles[0] / (double)n, host_ctr.cycles[1] / (double)n, host_ctr.cycles[4] / (double)n, host_ctr.cycles[5] / (double)n,
                          host_ctr.cycles[2] / (double)n, host_ctr.cycles[3] / (double)n, host_ctr.pivots / (double)n, host_ctr.cycles[6] / (double)n, host_ctr.cycles[7] / (double)n, host_ctr.xtheta_lps / (double)n, host_ctr.n_retry_theta, (unsigned long long)host_ctr.xtheta_fallbacks);
         if (h->debug_cycles && h->n_opt > 0)
-            std::fprintf(stderr, "[mpc] k=%d region2 per optimal candidate (%lld): rows %.0f chebyshev %.0f facets %.0f total %.0f cycles; refactors %.2f facet pivots %.1f\n", k,
+            std::fprintf(stderr, "[mpc] k=%d region2 per optimal candidate (%lld): rows %.0f chebyshev %.0f facets %.0f total %.0f cycles; refactors %.2f facet pivots %.1f box-screened rows %.1f\n", k,
                          h->n_opt, host_ctr.rcycles[0] / (double)h->n_opt, host_ctr.rcycles[1] / (double)h->n_opt, host_ctr.rcycles[2] / (double)h->n_opt,
-                         host_ctr.rcycles[3] / (double)h->n_opt, host_ctr.rcycles[4] / (double)h->n_opt, host_ctr.rcycles[5] / (double)h->n_opt);
+                         host_ctr.rcycles[3] / (double)h->n_opt, host_ctr.rcycles[4] / (double)h->n_opt, host_ctr.rcycles[5] / (double)h->n_opt, host_ctr.r_box / (double)h->n_opt);
         h->n_pruned_new = host_ctr.n_pruned_new;
         h->n_erows = host_ctr.e_rows;
         h->n_regions = (long long)host_ctr.status[ST_REGION];
