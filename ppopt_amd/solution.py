@@ -52,11 +52,12 @@ class Solution:
         i = 0
         while i < len(regs):
             r = regs[i]
-            if isinstance(r, BatchCriticalRegion) and '_batch' in r.__dict__:
+            if isinstance(r, BatchCriticalRegion) and '_batch' in r.__dict__ and r.y_fixation is None:
                 # a run of regions backed by the same level arrays: cut everything out with index arithmetic
                 B = r._batch
                 j = i
-                while j < len(regs) and isinstance(regs[j], BatchCriticalRegion) and regs[j].__dict__.get('_batch') is B:
+                while j < len(regs) and isinstance(regs[j], BatchCriticalRegion) and regs[j].__dict__.get('_batch') is B \
+                        and regs[j].y_fixation is None:
                     j += 1
                 slots = numpy.fromiter((q._j for q in regs[i:j]), dtype=numpy.int64, count=j - i)
                 nE, off = B.hi[slots, 2].astype(numpy.int64), B.hi[slots, 6].astype(numpy.int64)
@@ -70,8 +71,16 @@ class Solution:
             else:
                 ef_parts.append(numpy.hstack([numpy.asarray(r.f, dtype=float).reshape(-1, 1), numpy.asarray(r.E, dtype=float).reshape(-1, n_t)]))
                 cnt.append(numpy.array([ef_parts[-1].shape[0]], dtype=numpy.int64))
-                xl_parts.append(numpy.concatenate([numpy.asarray(r.b, dtype=float).reshape(1, -1, 1),
-                                                   numpy.asarray(r.A, dtype=float).reshape(1, -1, n_t)], axis=2))
+                bx, Ax = numpy.asarray(r.b, dtype=float).reshape(-1, 1), numpy.asarray(r.A, dtype=float).reshape(-1, n_t)
+                if r.y_fixation is not None:
+                    # region of a mixed-integer solution (whose E, f may have been replaced by the overlap reduction): the
+                    # law of the full variable vector, binaries as constant rows (critical_region.py:64-77)
+                    n_full = len(r.x_indices) + len(r.y_indices)
+                    b_full, A_full = numpy.zeros((n_full, 1)), numpy.zeros((n_full, n_t))
+                    b_full[r.x_indices], A_full[r.x_indices] = bx, Ax
+                    b_full[r.y_indices, 0] = r.y_fixation
+                    bx, Ax = b_full, A_full
+                xl_parts.append(numpy.concatenate([bx[None], Ax[None]], axis=2))
                 i += 1
         counts = numpy.concatenate(cnt) if cnt else numpy.zeros(0, dtype=numpy.int64)
         row_off = numpy.concatenate([[0], numpy.cumsum(counts)]).astype(numpy.int64)

@@ -199,3 +199,61 @@ def test_sub_problem_shape_and_wrong_algorithm():
     with pytest.raises(TypeError):
         solve_mpmiqp(prog, 'enum')
     solve_mpmiqp(build(_load('simple_mpMIQP')), num_cores=1).evaluate(numpy.array([[1.2]]))
+
+
+@pytest.mark.parametrize('path', MI_FILES, ids=IDS)
+def test_batched_point_location_on_mixed_integer_solutions(path):
+    """Solution.evaluate_batch on a mixed-integer solution (full variable vector, binaries spliced in; overlapping
+    regions resolved by the objective on the device) against the host loop of get_region / evaluate."""
+    from ppopt_amd.mp_solvers.solve_mpmiqp import solve_mpmiqp
+    g = numpy.load(path)
+    prog = build(g)
+    sol = solve_mpmiqp(prog, num_cores=1)
+    thetas = g['T_theta']
+    x_b, idx_b = sol.evaluate_batch(thetas)
+    assert x_b.shape == (len(thetas), prog.num_x())
+    for th, xb, ib in zip(thetas, x_b, idx_b):
+        cr = sol.get_region(th.reshape(-1, 1))
+        if cr is None:
+            assert ib == -1 and numpy.all(numpy.isnan(xb))
+            continue
+        want = cr.evaluate(th.reshape(-1, 1)).flatten()
+        got_obj = prog.evaluate_objective(xb.reshape(-1, 1), th.reshape(-1, 1))
+        want_obj = prog.evaluate_objective(want.reshape(-1, 1), th.reshape(-1, 1))
+        assert ib >= 0
+        assert abs(got_obj - want_obj) <= 1e-7 * max(1.0, abs(want_obj))       # same objective; ties may pick a twin
+        if sol.critical_regions[int(ib)] is cr:
+            numpy.testing.assert_allclose(xb, want, atol=1e-8, rtol=1e-10)
+
+
+def test_upop_point_location_object():
+    """upop.PointLocation (tests/upop_tests/test_point_location.py:9-32): evaluate() equals Solution.evaluate(), with
+    and without the overlap flag; exact E theta <= f semantics; batch and single-point forms agree."""
+    import copy
+    from ppopt_amd import MPQP_Program
+    from ppopt_amd.mp_solvers.solve_mpqp import mpqp_algorithm, solve_mpqp
+    from ppopt_amd.problem_generator import transport_mpqp_data
+    from ppopt_amd.upop import PointLocation
+    d = transport_mpqp_data()
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        prog = MPQP_Program(d['A'], d['b'], d['c'], d['H'], d['Q'], d['A_t'], d['b_t'], d['F'])
+    sol = solve_mpqp(prog, mpqp_algorithm.combinatorial)
+    theta = numpy.array([[200.0], [200.0]])
+    for overlapping in (False, True):
+        s2 = copy.copy(sol)
+        s2.is_overlapping = overlapping
+        pl = PointLocation(s2)
+        assert pl.is_inside(theta)
+        assert numpy.allclose(pl.evaluate(theta), sol.evaluate(theta))
+        assert sol.critical_regions[pl.locate(theta)].is_inside(theta)
+    pl = PointLocation(sol)
+    rng = numpy.random.default_rng(3)
+    pts = rng.uniform(-50, 1100, size=(500, 2))
+    idx = pl.locate_batch(pts)
+    x, idx2 = pl.evaluate_batch(pts)
+    assert numpy.array_equal(idx, idx2)
+    for p, i in zip(pts[:60], idx[:60]):
+        inside = [j for j, r in enumerate(sol.critical_regions) if numpy.all(r.E @ p.reshape(-1, 1) <= r.f)]
+        assert (i == -1 and not inside) or (i == inside[0])
+    assert pl.evaluate(numpy.array([[-500.0], [-500.0]])) is None and not pl.is_inside(numpy.array([[-500.0], [-500.0]]))
