@@ -720,6 +720,77 @@ __global__ void k_scatter_index(const int32_t *__restrict__ flag, const int32_t 
     if (i < n && flag[i]) list[pos[i]] = (int32_t)i;
 }
 
+// ---- small levels: the same bookkeeping in ONE single-block launch each -------------------------------------------------------
+// A level of a few thousand candidates is launch-latency bound (about 45 dependent device operations of 5-10 us each);
+// below SMALL_LEVEL_N candidates compaction, partition and scan run as one block of 1024 threads that walks the array
+// in chunks of 1024 (order preserved, so the lists are identical to the multi-block versions).
+constexpr int SMALL_LEVEL_N = 16384;
+__global__ void __launch_bounds__(1024) k_compact_small(const uint8_t *__restrict__ status, int n, int lo, int hi,
+                                                        int32_t *__restrict__ list, int32_t *__restrict__ total) {
+    __shared__ int wc[16];
+    __shared__ int base;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (threadIdx.x == 0) base = 0;
+    __syncthreads();
+    for (int start = 0; start < n; start += 1024) {
+        const int i = start + (int)threadIdx.x;
+        const bool f = i < n && status[i] >= lo && status[i] <= hi;
+        const unsigned long long m = __ballot(f);
+        if (lane == 0) wc[wave] = __popcll(m);
+        __syncthreads();
+        int before = base;
+        for (int w = 0; w < wave; ++w) before += wc[w];
+        if (f) list[before + __popcll(m & ((1ull << lane) - 1ull))] = i;
+        __syncthreads();
+        if (threadIdx.x == 0) { int t = 0; for (int w = 0; w < 16; ++w) t += wc[w]; base += t; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *total = base;
+}
+__global__ void __launch_bounds__(1024) k_partition_small(const uint8_t *__restrict__ status, int n, unsigned long long spec,
+                                                          int32_t *__restrict__ lists, long long stride, int32_t *__restrict__ totals) {
+    __shared__ int wc[16][PART_CLASSES];
+    __shared__ int base[PART_CLASSES];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (threadIdx.x < PART_CLASSES) base[threadIdx.x] = 0;
+    __syncthreads();
+    for (int start = 0; start < n; start += 1024) {
+        const int i = start + (int)threadIdx.x;
+        const int cls = i < n ? part_class(spec, status[i]) : 15;
+        int within = 0;
+#pragma unroll
+        for (int c = 0; c < PART_CLASSES; ++c) {
+            const unsigned long long m = __ballot(cls == c);
+            if (lane == 0) wc[wave][c] = __popcll(m);
+            if (cls == c) within = __popcll(m & ((1ull << lane) - 1ull));
+        }
+        __syncthreads();
+        if (cls < PART_CLASSES) {
+            int before = base[cls];
+            for (int w = 0; w < wave; ++w) before += wc[w][cls];
+            lists[(size_t)cls * stride + before + within] = i;
+        }
+        __syncthreads();
+        if (threadIdx.x < PART_CLASSES) { int t = 0; for (int w = 0; w < 16; ++w) t += wc[w][threadIdx.x]; base[threadIdx.x] += t; }
+        __syncthreads();
+    }
+    if (threadIdx.x < PART_CLASSES) totals[threadIdx.x] = base[threadIdx.x];
+}
+__global__ void __launch_bounds__(1024) k_scan_small(const int32_t *__restrict__ in, int32_t *__restrict__ out, int n,
+                                                     int32_t *__restrict__ total) {
+    __shared__ int tot;
+    int carry = 0;
+    for (int start = 0; start < n; start += SCAN_BLOCK) {
+        const int i = start + (int)threadIdx.x;
+        const int ex = block_exclusive_scan_1024(i < n ? in[i] : 0, &tot);
+        __syncthreads();
+        if (i < n) out[i] = ex + carry;
+        carry += tot;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *total = carry;
+}
+
 __device__ __forceinline__ bool expands(int st) { return st == ST_FEASIBLE || st == ST_REGION || st == ST_SINGULAR || st == ST_LP_LIMIT; }
 
 // children of one parent per wavefront: bit i of childmask = [as + {i}] survives CombinationTester.check and the

@@ -269,6 +269,8 @@ struct mpc_handle {
     int grid_v = 0, grid_r = 0;
     long long rec_d = 0, rec_i = 0;
     // frontier / pruned
+    int32_t *tot_host = nullptr, *tot_dev = nullptr;   // 16 counters in pinned host memory that the kernels write directly: list lengths need no copy
+    const int32_t *opt_ptr = nullptr;                  // list of the optimal candidates of the level (a view, not a copy)
     DevBuf frontier, children, status, pruned, pruned_new, flag, pos, opt_list, childmask, count, offset, recd, reci, ctr, scratch, sums;
     long long n = 0;
     int k = 0;
@@ -708,6 +710,14 @@ int mpc_create(const mpc_problem *p, int32_t device, void *stream, mpc_handle **
     h->rec_i = 5 + (long long)nc + ntc + nc + nc + nc;
     HIP_TRY(nullptr, h->ctr.ensure(sizeof(LevelCounters), h->stream));
     HIP_TRY(nullptr, h->scratch.ensure(256, h->stream));
+    {
+        void *hp = nullptr, *dp = nullptr;
+        HIP_TRY(nullptr, host_pool_take(4096, &hp, nullptr));
+        HIP_TRY(nullptr, hipHostGetDevicePointer(&dp, hp, 0));
+        h->tot_host = static_cast<int32_t *>(hp);
+        h->tot_dev = static_cast<int32_t *>(dp);
+        std::memset(hp, 0, 64);
+    }
     *out = h;
     return MPC_OK;
 }
@@ -720,6 +730,7 @@ int mpc_destroy(mpc_handle *h) {
     for (DevBuf *b : {&h->blocks, &h->iblocks, &h->frontier, &h->children, &h->status, &h->pruned, &h->pruned_new, &h->flag, &h->pos, &h->opt_list,
                       &h->childmask, &h->count, &h->offset, &h->recd, &h->reci, &h->ctr, &h->scratch, &h->sums, &h->retry_list, &h->pf_dev, &h->pr2_dev, &h->headd, &h->headi, &h->epool, &h->facet_flags, &h->kkt_code, &h->kkt_L, &h->theta_blocks, &h->theta_list, &h->vretry_list, &h->status_tmp, &h->part_counts, &h->part_lists, &h->kept_g, &h->done_g, &h->dict_d[0], &h->dict_d[1], &h->dict_i[0], &h->dict_i[1],
                       &h->dict_stored[0], &h->dict_stored[1], &h->parent_slot, &h->parent_slot_next}) b->release();
+    if (h->tot_host) { (void)host_pool_give(h->tot_host); h->tot_host = h->tot_dev = nullptr; }
     for (HostBuf *b : {&h->st_list, &h->st_status, &h->st_hd, &h->st_hi, &h->st_pool, &h->st_fxd, &h->st_fxi, &h->st_rlist}) b->release();
     for (auto &e : h->ev) return_event(e, true);
     for (auto &e : h->kev) return_event(e, true);
@@ -853,6 +864,11 @@ int mpc_pruned_get(mpc_handle *h, uint64_t *masks, int64_t cap) {
 
 // exclusive scan of n int32 values on the handle's stream (three launches); *total_dev receives the sum
 static int launch_scan(mpc_handle *h, const int32_t *in, int32_t *out, long long n, int32_t *total_dev) {
+    if (n <= SMALL_LEVEL_N) {   // one single-block launch
+        hipLaunchKernelGGL(k_scan_small, dim3(1), dim3(SCAN_BLOCK), 0, h->stream, in, out, (int)n, total_dev);
+        HIP_TRY(h, hipGetLastError());
+        return MPC_OK;
+    }
     const int nb = (int)((n + SCAN_BLOCK - 1) / SCAN_BLOCK);
     HIP_TRY(h, h->sums.ensure((size_t)std::max(nb, 1) * sizeof(int32_t), h->stream));
     hipLaunchKernelGGL(k_scan_block_sums, dim3(nb), dim3(SCAN_BLOCK), 0, h->stream, in, n, h->sums.as<int32_t>());
@@ -912,17 +928,23 @@ int mpc_level_run(mpc_handle *h, int32_t gen_children, mpc_level_stats *stats) {
         HIP_TRY(h, h->pruned_new.ensure(nn * MPC_MASK_WORDS * sizeof(uint64_t), st));
         HIP_TRY(h, hipMemsetAsync(h->ctr.p, 0, sizeof(LevelCounters), st));
         LevelCounters *ctr = h->ctr.as<LevelCounters>();
-        int32_t *total = h->scratch.as<int32_t>();
+        int32_t *total = h->tot_dev;          // device alias of h->tot_host: valid on the host after the next synchronisation
+        const bool small = n <= SMALL_LEVEL_N;
         const int blocks256 = (int)((n + 255) / 256);
         // compacts the candidates whose status lies in [lo, hi] into h->retry_list; returns their number
         auto compact = [&](int lo, int hi, int32_t *count) -> int {
-            hipLaunchKernelGGL(k_flag_status, dim3(blocks256), dim3(256), 0, st, h->status.as<uint8_t>(), n, lo, hi, h->flag.as<int32_t>());
-            int rcs = launch_scan(h, h->flag.as<int32_t>(), h->pos.as<int32_t>(), n, total);
-            if (rcs) return rcs;
             HIP_TRY(h, h->retry_list.ensure(nn * sizeof(int32_t), st));
-            hipLaunchKernelGGL(k_scatter_index, dim3(blocks256), dim3(256), 0, st, h->flag.as<int32_t>(), h->pos.as<int32_t>(), n, h->retry_list.as<int32_t>());
-            HIP_TRY(h, hipMemcpyAsync(count, total, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+            if (small) {
+                hipLaunchKernelGGL(k_compact_small, dim3(1), dim3(1024), 0, st, h->status.as<uint8_t>(), (int)n, lo, hi, h->retry_list.as<int32_t>(), total);
+            } else {
+                hipLaunchKernelGGL(k_flag_status, dim3(blocks256), dim3(256), 0, st, h->status.as<uint8_t>(), n, lo, hi, h->flag.as<int32_t>());
+                int rcs = launch_scan(h, h->flag.as<int32_t>(), h->pos.as<int32_t>(), n, total);
+                if (rcs) return rcs;
+                hipLaunchKernelGGL(k_scatter_index, dim3(blocks256), dim3(256), 0, st, h->flag.as<int32_t>(), h->pos.as<int32_t>(), n, h->retry_list.as<int32_t>());
+            }
+            HIP_TRY(h, hipGetLastError());
             HIP_TRY(h, hipStreamSynchronize(st));
+            *count = h->tot_host[0];
             return MPC_OK;
         };
         // deterministic partition of the candidates into up to four lists by status (spec: status -> class nibble, 15 = none);
@@ -933,13 +955,17 @@ int mpc_level_run(mpc_handle *h, int32_t gen_children, mpc_level_stats *stats) {
             for (const auto &sc : classes) spec = (spec & ~(15ull << (4 * sc.first))) | ((unsigned long long)sc.second << (4 * sc.first));
             HIP_TRY(h, h->part_counts.ensure((size_t)PART_CLASSES * nb1024 * sizeof(int32_t), st));
             HIP_TRY(h, h->part_lists.ensure((size_t)PART_CLASSES * nn * sizeof(int32_t), st));
-            hipLaunchKernelGGL(k_part_count, dim3(nb1024), dim3(1024), 0, st, h->status.as<uint8_t>(), n, spec, h->part_counts.as<int32_t>(), nb1024);
-            hipLaunchKernelGGL(k_part_sums, dim3(PART_CLASSES), dim3(1024), 0, st, h->part_counts.as<int32_t>(), nb1024, total);
-            hipLaunchKernelGGL(k_part_scatter, dim3(nb1024), dim3(1024), 0, st, h->status.as<uint8_t>(), n, spec, h->part_counts.as<int32_t>(), nb1024,
-                               h->part_lists.as<int32_t>());
+            if (small) {
+                hipLaunchKernelGGL(k_partition_small, dim3(1), dim3(1024), 0, st, h->status.as<uint8_t>(), (int)n, spec, h->part_lists.as<int32_t>(), (long long)n, total);
+            } else {
+                hipLaunchKernelGGL(k_part_count, dim3(nb1024), dim3(1024), 0, st, h->status.as<uint8_t>(), n, spec, h->part_counts.as<int32_t>(), nb1024);
+                hipLaunchKernelGGL(k_part_sums, dim3(PART_CLASSES), dim3(1024), 0, st, h->part_counts.as<int32_t>(), nb1024, total);
+                hipLaunchKernelGGL(k_part_scatter, dim3(nb1024), dim3(1024), 0, st, h->status.as<uint8_t>(), n, spec, h->part_counts.as<int32_t>(), nb1024,
+                                   h->part_lists.as<int32_t>());
+            }
             HIP_TRY(h, hipGetLastError());
-            HIP_TRY(h, hipMemcpyAsync(counts, total, PART_CLASSES * sizeof(int32_t), hipMemcpyDeviceToHost, st));
             HIP_TRY(h, hipStreamSynchronize(st));
+            for (int c = 0; c < PART_CLASSES; ++c) counts[c] = h->tot_host[c];
             return MPC_OK;
         };
         auto part_list = [&](int c) -> int32_t * { return h->part_lists.as<int32_t>() + (size_t)c * nn; };
@@ -1101,8 +1127,7 @@ int mpc_level_run(mpc_handle *h, int32_t gen_children, mpc_level_stats *stats) {
                 { int rcs = partition({{ST_OPT_PENDING, 2}}, cntB); if (rcs) return rcs; }   // they may have turned out optimal
             }
             n_opt_fast = cntB[2];
-            if (n_opt_fast > 0)
-                HIP_TRY(h, hipMemcpyAsync(h->opt_list.p, part_list(2), (size_t)n_opt_fast * sizeof(int32_t), hipMemcpyDeviceToDevice, st));
+            h->opt_ptr = part_list(2);   // stays valid until the next level's partition (the region fetch reads it before that)
         } else {
             hipLaunchKernelGGL(k_verdict, dim3((unsigned)std::min<long long>(n, h->grid_v)), dim3(64), h->lds_v, st, h->Pv,
                                h->frontier.as<int32_t>(), n, k, h->status.as<uint8_t>(), ctr, (const int32_t *)nullptr);
@@ -1112,12 +1137,13 @@ int mpc_level_run(mpc_handle *h, int32_t gen_children, mpc_level_stats *stats) {
         // optimal candidates -> region kernel
         int32_t n_opt = n_opt_fast;
         if (n_opt < 0) {
+            h->opt_ptr = h->opt_list.as<int32_t>();
             hipLaunchKernelGGL(k_flag_status, dim3(blocks256), dim3(256), 0, st, h->status.as<uint8_t>(), n, ST_OPT_PENDING, ST_OPT_PENDING, h->flag.as<int32_t>());
             { int rcs = launch_scan(h, h->flag.as<int32_t>(), h->pos.as<int32_t>(), n, total); if (rcs) return rcs; }
             hipLaunchKernelGGL(k_scatter_index, dim3(blocks256), dim3(256), 0, st, h->flag.as<int32_t>(), h->pos.as<int32_t>(), n, h->opt_list.as<int32_t>());
             HIP_TRY(h, hipGetLastError());
-            HIP_TRY(h, hipMemcpyAsync(&n_opt, total, sizeof(int32_t), hipMemcpyDeviceToHost, st));
             HIP_TRY(h, hipStreamSynchronize(st));
+            n_opt = h->tot_host[0];
         }
         h->n_opt = n_opt;
         h->used_region2 = false; h->n_rretry = 0; h->n_erows = 0;
@@ -1138,7 +1164,7 @@ int mpc_level_run(mpc_handle *h, int32_t gen_children, mpc_level_stats *stats) {
             }
             const dim3 g((unsigned)std::min<long long>((long long)n_opt * W, h->grid_r2)), b(64);
             const DevProblem *pr = h->pr2_dev.as<DevProblem>();
-#define MPC_LAUNCH_R2(NT_, SL_) hipLaunchKernelGGL((k_region2<NT_, SL_>), g, b, h->lds_r2, st, pr, h->frontier.as<int32_t>(), k, h->opt_list.as<int32_t>(), n_opt, \
+#define MPC_LAUNCH_R2(NT_, SL_) hipLaunchKernelGGL((k_region2<NT_, SL_>), g, b, h->lds_r2, st, pr, h->frontier.as<int32_t>(), k, h->opt_ptr, n_opt, \
                                                    h->status.as<uint8_t>(), h->headd.as<double>(), h->headi.as<int32_t>(), h->fd, h->fi, h->epool.as<double>(), ctr, kkc, kkl, \
                                                    W, h->kept_g.as<uint8_t>(), ldk, h->done_g.as<unsigned int>(), \
                                                    h->no_rbox ? (const double *)nullptr : h->targs.tvp + (size_t)NT_ * NT_ + NT_)
@@ -1168,7 +1194,7 @@ int mpc_level_run(mpc_handle *h, int32_t gen_children, mpc_level_stats *stats) {
                 if (rcs) return rcs;
             }
         } else if (n_opt > 0) {
-            int rcs = launch_region_v1(h, h->opt_list.as<int32_t>(), n_opt, k, ctr);
+            int rcs = launch_region_v1(h, h->opt_ptr, n_opt, k, ctr);
             if (rcs) return rcs;
         }
         HIP_TRY(h, hipEventRecord(h->ev[2], st));
@@ -1183,9 +1209,8 @@ int mpc_level_run(mpc_handle *h, int32_t gen_children, mpc_level_stats *stats) {
                                h->pruned.as<unsigned long long>(), (long long)h->n_pruned, h->childmask.as<unsigned long long>(), h->count.as<int32_t>());
             { int rcs = launch_scan(h, h->count.as<int32_t>(), h->offset.as<int32_t>(), n, total); if (rcs) return rcs; }
             HIP_TRY(h, hipGetLastError());
-            int32_t n_children = 0;
-            HIP_TRY(h, hipMemcpyAsync(&n_children, total, sizeof(int32_t), hipMemcpyDeviceToHost, st));
             HIP_TRY(h, hipStreamSynchronize(st));
+            const int32_t n_children = h->tot_host[0];
             h->n_children = n_children;
             if (n_children > 0) {
                 HIP_TRY(h, h->children.ensure((size_t)n_children * (k + 1) * sizeof(int32_t), st));
@@ -1279,7 +1304,7 @@ int mpc_level_regions_compact(mpc_handle *h, double *head_d, int32_t *head_i, in
     hipStream_t s = h->stream;
     HIP_TRY(h, h->st_list.ensure((size_t)n_opt * sizeof(int32_t)));
     HIP_TRY(h, h->st_status.ensure((size_t)h->n));
-    HIP_TRY(h, hipMemcpyAsync(h->st_list.p, h->opt_list.p, (size_t)n_opt * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    HIP_TRY(h, hipMemcpyAsync(h->st_list.p, h->opt_ptr, (size_t)n_opt * sizeof(int32_t), hipMemcpyDeviceToHost, s));
     HIP_TRY(h, hipMemcpyAsync(h->st_status.p, h->status.p, (size_t)h->n, hipMemcpyDeviceToHost, s));
     if (n_fixed > 0) {
         HIP_TRY(h, h->st_fxd.ensure((size_t)n_fixed * h->rec_d * sizeof(double)));
@@ -1385,7 +1410,7 @@ int mpc_level_regions_slots(mpc_handle *h, double *head_d, int32_t *head_i, int6
         HIP_TRY(h, h->st_status.ensure((size_t)h->n));
         HIP_TRY(h, hipMemcpyAsync(h->st_fxd.p, h->recd.p, (size_t)n_fixed * h->rec_d * sizeof(double), hipMemcpyDeviceToHost, s));
         HIP_TRY(h, hipMemcpyAsync(h->st_fxi.p, h->reci.p, (size_t)n_fixed * h->rec_i * sizeof(int32_t), hipMemcpyDeviceToHost, s));
-        HIP_TRY(h, hipMemcpyAsync(h->st_list.p, h->opt_list.p, (size_t)n_opt * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+        HIP_TRY(h, hipMemcpyAsync(h->st_list.p, h->opt_ptr, (size_t)n_opt * sizeof(int32_t), hipMemcpyDeviceToHost, s));
         HIP_TRY(h, hipMemcpyAsync(h->st_status.p, h->status.p, (size_t)h->n, hipMemcpyDeviceToHost, s));
     }
     long long wrow = 0;
