@@ -1061,7 +1061,7 @@ int mpc_level_run(mpc_handle *h, int32_t gen_children, mpc_level_stats *stats) {
                 h->storing = true;
             }
             auto launch_x = [&](const int32_t *ls, int n_items, const DictCache &d0) -> int {
-                HIP_TRY(h, hipMemsetAsync(&ctr->work_x, 0, sizeof(unsigned int), st));
+                // ctr->work_x is zero: the counters were cleared at the start of the level and this is the level's only k_x2 launch
                 DictCache d = d0;
                 const long long grid_x = (long long)h->n_cu * 16, n_all = (long long)n_items + d.n_pre1 + d.n_pre2;
                 d.chunk = (int)std::max<long long>(1, std::min<long long>(16, n_all / (grid_x * 8)));
