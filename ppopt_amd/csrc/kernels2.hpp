@@ -459,6 +459,139 @@ struct DictCache {
 #define XQ_ITERS_N 8
 #endif
 constexpr int XQ_ITERS = XQ_ITERS_N;
+// The decision of one candidate of k_xq: `pd` / `pi` are its parent's dictionary record (doubles / ints), in HBM (k_xq) or
+// staged in LDS (k_xq_grouped); v is the variable id of the candidate's new row.  Returns 1 feasible, 0 infeasible,
+// -1 undecided (left to k_x2); piv_local counts the pivots.
+template <int SLOTS, class PD, class PI>
+__device__ __forceinline__ int xq_decide(PD pd, PI pi, int mr, int NXC, int v, int lane, int &piv_local) {
+    int qvar[SLOTS], qkind[SLOTS];
+    double qb[SLOTS];
+#pragma unroll
+    for (int sl = 0; sl < SLOTS; ++sl) {
+        const int i = lane + 64 * sl;
+        qvar[sl] = i < mr ? pi[i] : -1;
+        qkind[sl] = i < mr ? pi[mr + i] : RK_DEAD;
+        qb[sl] = i < mr ? pd[i] : 0.0;
+    }
+    const int qcv = lane < NXC + 3 ? pi[2 * mr + lane] : -1;
+    const unsigned al = (unsigned)__builtin_amdgcn_readlane(qcv, NXC);
+    const double growth0 = __hiloint2double(__builtin_amdgcn_readlane(qcv, NXC + 1), __builtin_amdgcn_readlane(qcv, NXC + 2));
+    const unsigned long long bc = __ballot(qcv == v && lane >= 1 && lane < NXC && ((al >> lane) & 1u));
+    int feas = -1;   // 1 feasible, 0 infeasible, -1 undecided
+    piv_local = 0;
+    if (bc) feas = 1;
+    else {
+        int row = -1;
+#pragma unroll
+        for (int sl = SLOTS - 1; sl >= 0; --sl) {
+            const unsigned long long br = __ballot(qvar[sl] == v && qkind[sl] == RK_INEQ);
+            if (br) row = __ffsll((long long)br) - 1 + 64 * sl;
+        }
+        if (row >= 0) {
+            row = uni(row);
+            // value of entry `r` of a vector whose element i lives in lane i & 63, slot i >> 6
+            auto at = [&](const double (&vec)[SLOTS], int r) -> double {
+                return readlane_f64((SLOTS == 1 || r < 64) ? vec[0] : vec[SLOTS - 1], r & 63);
+            };
+            // Up to XQ_ITERS simplex iterations in product form: the tableau is never formed.  Per pivot p the entering
+            // column as it was (E[p], one entry per row) and the scaled pivot row (R[p], one entry per column) are kept;
+            // a column or row needed later is read from the parent's dictionary and brought up to date through them,
+            // with the operations pivot_core (lp_reg.hpp) would have applied to it -- bit for bit k_x2's arithmetic.
+            double E[XQ_ITERS][SLOTS], R[XQ_ITERS];
+            int rp[XQ_ITERS], qp[XQ_ITERS];
+            double invp[XQ_ITERS];
+            double xrow = (lane < NXC) ? pd[(size_t)lane * mr + row] : 0.0;   // the new row, entry j in lane j
+            double growth = growth0;
+#pragma unroll
+            for (int it = 0; it < XQ_ITERS; ++it) {
+                if (at(qb, row) <= TOL_FEAS) { feas = 1; break; }
+                const double g = (lane >= 1 && lane < NXC) ? xrow : 0.0;
+                const double gm = dpp_wave_max(g > TOL_COST ? g : 0.0);
+                if (!(gm > TOL_COST)) { feas = 0; break; }
+                const int q = uni(__ffsll((long long)__ballot(g == gm && lane >= 1 && lane < NXC)) - 1);
+                // entering column at the current time
+                double a[SLOTS], ratio[SLOTS];
+#pragma unroll
+                for (int sl = 0; sl < SLOTS; ++sl) { const int i = lane + 64 * sl; a[sl] = i < mr ? pd[(size_t)q * mr + i] : 0.0; }
+#pragma unroll
+                for (int p_ = 0; p_ < it; ++p_) {
+                    if (q == qp[p_]) {
+#pragma unroll
+                        for (int sl = 0; sl < SLOTS; ++sl) a[sl] = (lane + 64 * sl == rp[p_]) ? 1.0 : 0.0;
+                    }
+                    const double x = at(a, rp[p_]) * invp[p_];
+#pragma unroll
+                    for (int sl = 0; sl < SLOTS; ++sl) a[sl] = (lane + 64 * sl == rp[p_]) ? x : fma(-E[p_][sl], x, a[sl]);
+                }
+                bool elig[SLOTS];
+                float cmf = 0.0f;
+                double tmax = INFINITY;
+#pragma unroll
+                for (int sl = 0; sl < SLOTS; ++sl) {
+                    const int i = lane + 64 * sl;
+                    const bool used = i < mr && qkind[sl] != RK_DEAD;
+                    if (used) cmf = fmaxf(cmf, fabsf((float)a[sl]));
+                    elig[sl] = used && qkind[sl] == RK_INEQ && a[sl] > TOL_PIV;
+                    ratio[sl] = 0.0;
+                    if (elig[sl]) {
+                        const double b0 = fmax(qb[sl], 0.0), ia = fast_rcp(a[sl]);
+                        ratio[sl] = b0 * ia;
+                        tmax = fmin(tmax, (b0 + HARRIS_DELTA) * ia);
+                    }
+                }
+                const float colmax = dpp_wave_max_f32(cmf);
+                tmax = dpp_wave_min(tmax);
+                if (tmax == INFINITY) break;   // unbounded direction: left to k_x2
+                bool pass[SLOTS], mine = false;
+#pragma unroll
+                for (int sl = 0; sl < SLOTS; ++sl) { pass[sl] = elig[sl] && !(ratio[sl] > tmax); mine = mine || (lane + 64 * sl == row && pass[sl]); }
+                int l = -1;
+                double rpiv;
+                if (__any(mine)) { l = row; rpiv = at(a, row); }
+                else {
+                    double am = 0.0;
+#pragma unroll
+                    for (int sl = 0; sl < SLOTS; ++sl) if (pass[sl]) am = fmax(am, a[sl]);
+                    rpiv = dpp_wave_max(am);
+#pragma unroll
+                    for (int sl = SLOTS - 1; sl >= 0; --sl) {
+                        const unsigned long long bl = __ballot(pass[sl] && a[sl] == rpiv);
+                        if (bl) l = __ffsll((long long)bl) - 1 + 64 * sl;
+                    }
+                    if (l < 0) break;
+                    l = uni(l);
+                }
+                const double inv = fast_rcp(rpiv);
+                growth = fmax(growth, (double)(colmax * (float)inv));
+                if (growth > GROWTH_SAFE) break;            // k_x2 repeats the run and flags it
+                piv_local++;
+                if (l == row) { feas = 1; break; }          // the new row's slack leaves the basis at zero
+                if (it + 1 == XQ_ITERS) break;
+                // pivot (l, q): remember it, update the values and the new row
+                rp[it] = l; qp[it] = q; invp[it] = inv;
+#pragma unroll
+                for (int sl = 0; sl < SLOTS; ++sl) E[it][sl] = a[sl];
+                const double xb = at(qb, l) * inv;
+#pragma unroll
+                for (int sl = 0; sl < SLOTS; ++sl) qb[sl] = (lane + 64 * sl == l) ? xb : fma(-a[sl], xb, qb[sl]);
+                double rowl = (lane < NXC) ? pd[(size_t)lane * mr + l] : 0.0;   // pivot row l at the current time, entry j in lane j
+#pragma unroll
+                for (int p_ = 0; p_ < it; ++p_) {
+                    if (l == rp[p_]) rowl = R[p_];
+                    else {
+                        const double xr = at(E[p_], l);
+                        rowl = fma(-xr, R[p_], lane == qp[p_] ? 0.0 : rowl);
+                    }
+                }
+                R[it] = (lane == q) ? inv : rowl * inv;
+                const double xr = at(a, row);
+                xrow = fma(-xr, R[it], lane == q ? 0.0 : xrow);
+            }
+        }
+    }
+    return feas;
+}
+
 template <int SLOTS>
 __global__ void __launch_bounds__(64, XQ_WAVES) k_xq(const DevProblem *__restrict__ Pg, const int32_t *__restrict__ cands, int k,
                                                const int32_t *__restrict__ list, int n_list, uint8_t *__restrict__ status,
@@ -487,137 +620,79 @@ __global__ void __launch_bounds__(64, XQ_WAVES) k_xq(const DevProblem *__restric
             const int v = __builtin_amdgcn_readlane(my_v, u);
             const int32_t *pi = dc.prev_i + (size_t)ps * dc.stride_i;
             const double *pd = dc.prev_d + (size_t)ps * dc.stride_d;
-            int qvar[SLOTS], qkind[SLOTS];
-            double qb[SLOTS];
-#pragma unroll
-            for (int sl = 0; sl < SLOTS; ++sl) {
-                const int i = lane + 64 * sl;
-                qvar[sl] = i < mr ? pi[i] : -1;
-                qkind[sl] = i < mr ? pi[mr + i] : RK_DEAD;
-                qb[sl] = i < mr ? pd[i] : 0.0;
-            }
-            const int qcv = lane < NXC + 3 ? pi[2 * mr + lane] : -1;
-            const unsigned al = (unsigned)__builtin_amdgcn_readlane(qcv, NXC);
-            const double growth0 = __hiloint2double(__builtin_amdgcn_readlane(qcv, NXC + 1), __builtin_amdgcn_readlane(qcv, NXC + 2));
-            const unsigned long long bc = __ballot(qcv == v && lane >= 1 && lane < NXC && ((al >> lane) & 1u));
-            int feas = -1;   // 1 feasible, 0 infeasible, -1 undecided
             int piv_local = 0;
-            if (bc) feas = 1;
-            else {
-                int row = -1;
-#pragma unroll
-                for (int sl = SLOTS - 1; sl >= 0; --sl) {
-                    const unsigned long long br = __ballot(qvar[sl] == v && qkind[sl] == RK_INEQ);
-                    if (br) row = __ffsll((long long)br) - 1 + 64 * sl;
-                }
-                if (row >= 0) {
-                    row = uni(row);
-                    // value of entry `r` of a vector whose element i lives in lane i & 63, slot i >> 6
-                    auto at = [&](const double (&vec)[SLOTS], int r) -> double {
-                        return readlane_f64((SLOTS == 1 || r < 64) ? vec[0] : vec[SLOTS - 1], r & 63);
-                    };
-                    // Up to XQ_ITERS simplex iterations in product form: the tableau is never formed.  Per pivot p the entering
-                    // column as it was (E[p], one entry per row) and the scaled pivot row (R[p], one entry per column) are kept;
-                    // a column or row needed later is read from the parent's dictionary and brought up to date through them,
-                    // with the operations pivot_core (lp_reg.hpp) would have applied to it -- bit for bit k_x2's arithmetic.
-                    double E[XQ_ITERS][SLOTS], R[XQ_ITERS];
-                    int rp[XQ_ITERS], qp[XQ_ITERS];
-                    double invp[XQ_ITERS];
-                    double xrow = (lane < NXC) ? pd[(size_t)lane * mr + row] : 0.0;   // the new row, entry j in lane j
-                    double growth = growth0;
-#pragma unroll
-                    for (int it = 0; it < XQ_ITERS; ++it) {
-                        if (at(qb, row) <= TOL_FEAS) { feas = 1; break; }
-                        const double g = (lane >= 1 && lane < NXC) ? xrow : 0.0;
-                        const double gm = dpp_wave_max(g > TOL_COST ? g : 0.0);
-                        if (!(gm > TOL_COST)) { feas = 0; break; }
-                        const int q = uni(__ffsll((long long)__ballot(g == gm && lane >= 1 && lane < NXC)) - 1);
-                        // entering column at the current time
-                        double a[SLOTS], ratio[SLOTS];
-#pragma unroll
-                        for (int sl = 0; sl < SLOTS; ++sl) { const int i = lane + 64 * sl; a[sl] = i < mr ? pd[(size_t)q * mr + i] : 0.0; }
-#pragma unroll
-                        for (int p_ = 0; p_ < it; ++p_) {
-                            if (q == qp[p_]) {
-#pragma unroll
-                                for (int sl = 0; sl < SLOTS; ++sl) a[sl] = (lane + 64 * sl == rp[p_]) ? 1.0 : 0.0;
-                            }
-                            const double x = at(a, rp[p_]) * invp[p_];
-#pragma unroll
-                            for (int sl = 0; sl < SLOTS; ++sl) a[sl] = (lane + 64 * sl == rp[p_]) ? x : fma(-E[p_][sl], x, a[sl]);
-                        }
-                        bool elig[SLOTS];
-                        float cmf = 0.0f;
-                        double tmax = INFINITY;
-#pragma unroll
-                        for (int sl = 0; sl < SLOTS; ++sl) {
-                            const int i = lane + 64 * sl;
-                            const bool used = i < mr && qkind[sl] != RK_DEAD;
-                            if (used) cmf = fmaxf(cmf, fabsf((float)a[sl]));
-                            elig[sl] = used && qkind[sl] == RK_INEQ && a[sl] > TOL_PIV;
-                            ratio[sl] = 0.0;
-                            if (elig[sl]) {
-                                const double b0 = fmax(qb[sl], 0.0), ia = fast_rcp(a[sl]);
-                                ratio[sl] = b0 * ia;
-                                tmax = fmin(tmax, (b0 + HARRIS_DELTA) * ia);
-                            }
-                        }
-                        const float colmax = dpp_wave_max_f32(cmf);
-                        tmax = dpp_wave_min(tmax);
-                        if (tmax == INFINITY) break;   // unbounded direction: left to k_x2
-                        bool pass[SLOTS], mine = false;
-#pragma unroll
-                        for (int sl = 0; sl < SLOTS; ++sl) { pass[sl] = elig[sl] && !(ratio[sl] > tmax); mine = mine || (lane + 64 * sl == row && pass[sl]); }
-                        int l = -1;
-                        double rpiv;
-                        if (__any(mine)) { l = row; rpiv = at(a, row); }
-                        else {
-                            double am = 0.0;
-#pragma unroll
-                            for (int sl = 0; sl < SLOTS; ++sl) if (pass[sl]) am = fmax(am, a[sl]);
-                            rpiv = dpp_wave_max(am);
-#pragma unroll
-                            for (int sl = SLOTS - 1; sl >= 0; --sl) {
-                                const unsigned long long bl = __ballot(pass[sl] && a[sl] == rpiv);
-                                if (bl) l = __ffsll((long long)bl) - 1 + 64 * sl;
-                            }
-                            if (l < 0) break;
-                            l = uni(l);
-                        }
-                        const double inv = fast_rcp(rpiv);
-                        growth = fmax(growth, (double)(colmax * (float)inv));
-                        if (growth > GROWTH_SAFE) break;            // k_x2 repeats the run and flags it
-                        piv_local++;
-                        if (l == row) { feas = 1; break; }          // the new row's slack leaves the basis at zero
-                        if (it + 1 == XQ_ITERS) break;
-                        // pivot (l, q): remember it, update the values and the new row
-                        rp[it] = l; qp[it] = q; invp[it] = inv;
-#pragma unroll
-                        for (int sl = 0; sl < SLOTS; ++sl) E[it][sl] = a[sl];
-                        const double xb = at(qb, l) * inv;
-#pragma unroll
-                        for (int sl = 0; sl < SLOTS; ++sl) qb[sl] = (lane + 64 * sl == l) ? xb : fma(-a[sl], xb, qb[sl]);
-                        double rowl = (lane < NXC) ? pd[(size_t)lane * mr + l] : 0.0;   // pivot row l at the current time, entry j in lane j
-#pragma unroll
-                        for (int p_ = 0; p_ < it; ++p_) {
-                            if (l == rp[p_]) rowl = R[p_];
-                            else {
-                                const double xr = at(E[p_], l);
-                                rowl = fma(-xr, R[p_], lane == qp[p_] ? 0.0 : rowl);
-                            }
-                        }
-                        R[it] = (lane == q) ? inv : rowl * inv;
-                        const double xr = at(a, row);
-                        xrow = fma(-xr, R[it], lane == q ? 0.0 : xrow);
-                    }
-                }
-            }
+            const int feas = xq_decide<SLOTS>(pd, pi, mr, NXC, v, lane, piv_local);
             if (feas >= 0) {
                 n_quick++;
                 pivots += piv_local;
                 if (lane == 0) status[c] = (uint8_t)(feas ? (singular ? ST_SINGULAR : ST_FEASIBLE) : ST_INFEASIBLE);
             }
         }
+    }
+    if (lane == 0) { atomicAdd(&ctr->pivots, pivots); atomicAdd(&ctr->x_cached, n_quick); atomicAdd(&ctr->xtheta_lps, n_quick); }
+}
+
+// k_xq_grouped: the same decisions with the parent's dictionary read ONCE per parent.  The candidates of a level are
+// ordered by parent (children of one parent are consecutive in the frontier, hence in the list), so the list falls into
+// groups with a common parent record.  One workgroup of four wavefronts takes a group: all 256 threads copy the record
+// (16 KB at config 4) from HBM into LDS with coalesced loads, then the wavefronts share the group's candidates and run
+// xq_decide against LDS -- the dependent round trips of the product-form iterations cost an LDS access instead of an HBM
+// access, and HBM sees one streaming read per parent instead of scattered 64-byte sectors per candidate and iteration.
+// gstart[g] = position in `list` of the first candidate of group g (k_group_flags + scan + scatter), *n_groups_p groups.
+__global__ void k_group_flags(const int32_t *__restrict__ list, int n_list, const int32_t *__restrict__ parent_slot,
+                              int32_t *__restrict__ flag) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n_list) flag[i] = (i == 0 || parent_slot[list[i]] != parent_slot[list[i - 1]]) ? 1 : 0;
+}
+template <int SLOTS>
+__global__ void __launch_bounds__(256, XQ_WAVES) k_xq_grouped(const DevProblem *__restrict__ Pg, const int32_t *__restrict__ cands, int k,
+                                                          const int32_t *__restrict__ list, int n_list, uint8_t *__restrict__ status,
+                                                          LevelCounters *__restrict__ ctr, DictCache dc, int NXC,
+                                                          const int32_t *__restrict__ gstart, const int32_t *__restrict__ n_groups_p) {
+    extern __shared__ __attribute__((aligned(16))) double xq_smem[];
+    __shared__ unsigned int item_s;
+    const DevProblem &P = *Pg;
+    double *sd = xq_smem;
+    int32_t *si = reinterpret_cast<int32_t *>(xq_smem + dc.stride_d);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nv = P.n_x + P.n_t, mr = P.n_d0r;
+    const unsigned n_groups = (unsigned)*n_groups_p;
+    const int nd = (int)dc.stride_d, ni = (int)dc.stride_i;
+    unsigned long long pivots = 0, n_quick = 0;
+    for (;;) {
+        if (tid == 0) item_s = atomicAdd(&ctr->work_q, 1u);
+        __syncthreads();
+        const unsigned g = item_s;
+        if (g >= n_groups) break;
+        const int first = gstart[g], last = g + 1 < n_groups ? gstart[g + 1] : n_list;
+        const int ps = dc.parent_slot[list[first]];
+        if (ps >= 0) {
+            const double *pd = dc.prev_d + (size_t)ps * dc.stride_d;
+            const int32_t *pi = dc.prev_i + (size_t)ps * dc.stride_i;
+            if ((nd & 1) == 0) {
+                const double2 *p2 = reinterpret_cast<const double2 *>(pd);
+                double2 *s2 = reinterpret_cast<double2 *>(sd);
+                for (int i = tid; i < nd / 2; i += 256) s2[i] = p2[i];
+            } else {
+                for (int i = tid; i < nd; i += 256) sd[i] = pd[i];
+            }
+            for (int i = tid; i < ni; i += 256) si[i] = pi[i];
+        }
+        __syncthreads();
+        if (ps >= 0) {
+            for (int u = first + wave; u < last; u += 4) {
+                const int c = list[u];
+                const bool singular = status[c] == ST_NEEDX_SING;
+                const int v = nv + cands[(size_t)c * k + (k - 1)];
+                int piv_local = 0;
+                const int feas = xq_decide<SLOTS>(sd, si, mr, NXC, v, lane, piv_local);
+                if (feas >= 0) {
+                    n_quick++;
+                    pivots += piv_local;
+                    if (lane == 0) status[c] = (uint8_t)(feas ? (singular ? ST_SINGULAR : ST_FEASIBLE) : ST_INFEASIBLE);
+                }
+            }
+        }
+        __syncthreads();
     }
     if (lane == 0) { atomicAdd(&ctr->pivots, pivots); atomicAdd(&ctr->x_cached, n_quick); atomicAdd(&ctr->xtheta_lps, n_quick); }
 }

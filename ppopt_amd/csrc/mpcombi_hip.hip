@@ -241,6 +241,9 @@ struct mpc_handle {
     DevProblem Pv{}, Pr{};    // verdict / region kernel views (same blocks, different LDS layouts)
     int lds_v = 0, lds_r = 0; // dynamic LDS bytes per wavefront
     int debug_cycles = 0;     // MPC_DEBUG_CYCLES=1: per-level cycle breakdown on stderr
+    int force_xqgroup = 0;    // MPC_FORCE_XQGROUP=1: k_xq_grouped whatever the number of siblings (tests)
+    long long last_level_n = 0;   // candidates of the previous level (= the parents of this one)
+    int no_xqgroup = 0;       // MPC_NO_XQGROUP=1: the last level's quick test reads the parent records from HBM per candidate (A/B)
     int no_rbox = 0;          // MPC_NO_RBOX=1: no bounding-box screen of the region rows in k_region2 (A/B)
     int no_rsplit = 0;        // MPC_NO_RSPLIT=1: one wavefront per candidate in k_region2 whatever the load (A/B)
     int no_xquick = 0;        // MPC_NO_XQUICK=1: no quick (x,theta) test on the last level (A/B)
@@ -251,7 +254,7 @@ struct mpc_handle {
     long long n_needx = 0;
     DevProblem Pf{};          // view for k_verdict2 (small LDS layout: no tableau)
     int lds_f = 0, grid_f = 0;
-    DevBuf retry_list, theta_list, vretry_list, status_tmp, part_counts, part_lists, kept_g, done_g, pf_dev, pr2_dev, headd, headi, epool, facet_flags, kkt_code, kkt_L, theta_blocks;
+    DevBuf retry_list, theta_list, vretry_list, status_tmp, part_counts, part_lists, kept_g, done_g, pf_dev, pr2_dev, headd, headi, epool, facet_flags, kkt_code, kkt_L, theta_blocks, xq_groups;
     ThetaArgs targs{};
     // (x,theta) dictionary cache: [0]/[1] ping-pong between the level being read (parents) and the level being written
     DevBuf dict_d[2], dict_i[2], dict_stored[2], parent_slot, parent_slot_next;
@@ -423,6 +426,8 @@ int mpc_create(const mpc_problem *p, int32_t device, void *stream, mpc_handle **
     { const char *ev = std::getenv("MPC_DEBUG_CYCLES"); h->debug_cycles = ev && ev[0] == '1'; }
     { const char *ev = std::getenv("MPC_NO_RSPLIT"); h->no_rsplit = ev && ev[0] == '1'; }
     { const char *ev = std::getenv("MPC_NO_RBOX"); h->no_rbox = ev && ev[0] == '1'; }
+    { const char *ev = std::getenv("MPC_NO_XQGROUP"); h->no_xqgroup = ev && ev[0] == '1'; }
+    { const char *ev = std::getenv("MPC_FORCE_XQGROUP"); h->force_xqgroup = ev && ev[0] == '1'; }
     { const char *ev = std::getenv("MPC_NO_XQUICK"); h->no_xquick = ev && ev[0] == '1'; }
     { const char *ev = std::getenv("MPC_NO_KKT_THREAD"); h->no_kkt_thread = ev && ev[0] == '1'; }
     { const char *ev = std::getenv("MPC_DICT_BUDGET_GB"); if (ev) h->dict_budget_gb = std::atof(ev); }
@@ -728,7 +733,7 @@ int mpc_destroy(mpc_handle *h) {
     (void)hipStreamSynchronize(h->stream);
     if (h->stream2) (void)hipStreamSynchronize(h->stream2);
     for (DevBuf *b : {&h->blocks, &h->iblocks, &h->frontier, &h->children, &h->status, &h->pruned, &h->pruned_new, &h->flag, &h->pos, &h->opt_list,
-                      &h->childmask, &h->count, &h->offset, &h->recd, &h->reci, &h->ctr, &h->scratch, &h->sums, &h->retry_list, &h->pf_dev, &h->pr2_dev, &h->headd, &h->headi, &h->epool, &h->facet_flags, &h->kkt_code, &h->kkt_L, &h->theta_blocks, &h->theta_list, &h->vretry_list, &h->status_tmp, &h->part_counts, &h->part_lists, &h->kept_g, &h->done_g, &h->dict_d[0], &h->dict_d[1], &h->dict_i[0], &h->dict_i[1],
+                      &h->childmask, &h->count, &h->offset, &h->recd, &h->reci, &h->ctr, &h->scratch, &h->sums, &h->retry_list, &h->pf_dev, &h->pr2_dev, &h->headd, &h->headi, &h->epool, &h->facet_flags, &h->kkt_code, &h->kkt_L, &h->theta_blocks, &h->xq_groups, &h->theta_list, &h->vretry_list, &h->status_tmp, &h->part_counts, &h->part_lists, &h->kept_g, &h->done_g, &h->dict_d[0], &h->dict_d[1], &h->dict_i[0], &h->dict_i[1],
                       &h->dict_stored[0], &h->dict_stored[1], &h->parent_slot, &h->parent_slot_next}) b->release();
     if (h->tot_host) { (void)host_pool_give(h->tot_host); h->tot_host = h->tot_dev = nullptr; }
     for (HostBuf *b : {&h->st_list, &h->st_status, &h->st_hd, &h->st_hi, &h->st_pool, &h->st_fxd, &h->st_fxi, &h->st_rlist}) b->release();
@@ -1090,7 +1095,26 @@ int mpc_level_run(mpc_handle *h, int32_t gen_children, mpc_level_stats *stats) {
                 const long long grid_q = (long long)h->n_cu * 32;
                 dq.chunk = (int)std::max<long long>(1, std::min<long long>(16, n_needx / (grid_q * 4)));
                 const dim3 gg((unsigned)std::min<long long>((n_needx + dq.chunk - 1) / dq.chunk, grid_q)), bb(64);
-                if (h->fast_x & 1) hipLaunchKernelGGL((k_xq<2>), gg, bb, 0, st, pf, fr, k, needx_list, n_needx, stp, ctr, dq, nxc);
+                const size_t lds_q = (size_t)h->dict_stride_d * sizeof(double) + (size_t)h->dict_stride_i * sizeof(int32_t);
+                // Worth it when a parent has many open children (config 3: 12.6 per parent, -0.5 ms; config 4: 7.1 per parent, where
+                // the per-candidate reads of k_xq are cheaper than one 16 KB copy per parent, +0.45 ms): threshold 10.
+                const bool many_siblings = h->last_level_n > 0 && (long long)n_needx >= 10 * h->last_level_n;
+                if (!h->no_xqgroup && (many_siblings || h->force_xqgroup) && n_needx >= 4096 && lds_q <= 64 * 1024) {
+                    // grouped by parent: the record is staged in LDS once per parent (k_xq_grouped)
+                    HIP_TRY(h, h->xq_groups.ensure((size_t)n_needx * sizeof(int32_t), st));
+                    const int nbq = (n_needx + 255) / 256;
+                    hipLaunchKernelGGL(k_group_flags, dim3(nbq), dim3(256), 0, st, needx_list, n_needx, dq.parent_slot, h->flag.as<int32_t>());
+                    { int rcs = launch_scan(h, h->flag.as<int32_t>(), h->pos.as<int32_t>(), n_needx, h->scratch.as<int32_t>()); if (rcs) return rcs; }
+                    hipLaunchKernelGGL(k_scatter_index, dim3(nbq), dim3(256), 0, st, h->flag.as<int32_t>(), h->pos.as<int32_t>(), (long long)n_needx, h->xq_groups.as<int32_t>());
+                    const int per_cu = std::max(1, std::min(XQ_WAVES, (int)((160 * 1024) / (lds_q + 64))));
+                    const dim3 gq((unsigned)std::min<long long>(n_needx, (long long)h->n_cu * per_cu)), bq(256);
+                    if (lds_q > 48 * 1024) {
+                        HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void *>(k_xq_grouped<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_q));
+                        HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void *>(k_xq_grouped<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_q));
+                    }
+                    if (h->fast_x & 1) hipLaunchKernelGGL((k_xq_grouped<2>), gq, bq, lds_q, st, pf, fr, k, needx_list, n_needx, stp, ctr, dq, nxc, h->xq_groups.as<int32_t>(), h->scratch.as<int32_t>());
+                    else hipLaunchKernelGGL((k_xq_grouped<1>), gq, bq, lds_q, st, pf, fr, k, needx_list, n_needx, stp, ctr, dq, nxc, h->xq_groups.as<int32_t>(), h->scratch.as<int32_t>());
+                } else if (h->fast_x & 1) hipLaunchKernelGGL((k_xq<2>), gg, bb, 0, st, pf, fr, k, needx_list, n_needx, stp, ctr, dq, nxc);
                 else hipLaunchKernelGGL((k_xq<1>), gg, bb, 0, st, pf, fr, k, needx_list, n_needx, stp, ctr, dq, nxc);
                 HIP_TRY(h, hipGetLastError());
                 int32_t n_left = 0;
@@ -1243,6 +1267,7 @@ int mpc_level_run(mpc_handle *h, int32_t gen_children, mpc_level_stats *stats) {
         h->n_regions = (long long)host_ctr.status[ST_REGION];
     }
     h->level_done = true;
+    h->last_level_n = n;
     if (stats) {
         std::memset(stats, 0, sizeof(*stats));
         stats->n = n; stats->k = k; stats->kkt_mode = h->kkt_mode;
