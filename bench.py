@@ -343,10 +343,18 @@ def main():
         out['cpu_baseline'] = cpu_baseline(prog, frontiers, gpu_status, args.cpu_sample)
     else:
         out['cpu_baseline'] = None
-    if rank == 0:
-        print(json.dumps(out))
     if distributed:
         dist.destroy_process_group()
+    # The JSON line is the LAST thing on stdout: RCCL writes its version banner through C stdio, which is block-buffered
+    # when stdout is a pipe and would otherwise be flushed at exit, after the line.
+    sys.stdout.flush()
+    try:
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+    except OSError:
+        pass
+    if rank == 0:
+        print(json.dumps(out), flush=True)
 
 
 if __name__ == '__main__':

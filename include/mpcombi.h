@@ -168,6 +168,13 @@ int mpc_host_free(void *p);
 int mpc_level_children(mpc_handle *h, int32_t *children_host, int64_t cap);     /* n_children x (k+1) */
 int mpc_level_children_device(mpc_handle *h, int32_t *children_dev, int64_t cap);
 int mpc_level_pruned_new(mpc_handle *h, uint64_t *masks_host, int64_t cap);
+/* The slot arrays of mpc_level_regions_slots copied device -> device into caller-owned DEVICE buffers (the multi-GPU
+ * driver all-gathers them over RCCL without a host round trip; reference: the parent's merge of the workers' regions,
+ * mpqp_parrallel_combinatorial.py:127-131).  cap_slots >= mpc_level_slots(h), cap_rows from mpc_compact_strides.
+ * MPC_ERR_STATE when some record of the level is not in slot form on the device (regions re-solved by the LDS-engine
+ * kernel): the caller then uses mpc_level_regions_slots. */
+int mpc_level_regions_device(mpc_handle *h, double *head_d_dev, int32_t *head_i_dev, double *erows_dev, int64_t cap_slots,
+                             int64_t cap_rows, int64_t *n_slots, int64_t *n_rows);
 int mpc_level_pruned_new_device(mpc_handle *h, uint64_t *masks_dev, int64_t cap);
 /* frontier := children of this level; pruned list += sets pruned by this level  (driver :127-135) */
 int mpc_frontier_advance(mpc_handle *h);

@@ -101,6 +101,8 @@ def load():
         'mpc_level_children_device': (ctypes.c_int, [H, ctypes.c_void_p, ctypes.c_int64]),
         'mpc_level_pruned_new': (ctypes.c_int, [H, _u64p, ctypes.c_int64]),
         'mpc_level_pruned_new_device': (ctypes.c_int, [H, ctypes.c_void_p, ctypes.c_int64]),
+        'mpc_level_regions_device': (ctypes.c_int, [H, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64,
+                                                    ctypes.c_int64, _lp, _lp]),
         'mpc_frontier_advance': (ctypes.c_int, [H]),
         'mpc_check_level': (ctypes.c_int, [H, _ip, ctypes.c_int64, ctypes.c_int32, _u64p, ctypes.c_int64, ctypes.c_int32,
                                            _u8p, _lp, _dp, _ip, _lp, ctypes.c_int64, _lp, _ip, ctypes.c_int64]),
@@ -122,7 +124,7 @@ EXPORTED_SYMBOLS = ['mpc_device_count', 'mpc_version', 'mpc_last_global_error', 
                     'mpc_frontier_get', 'mpc_pruned_clear', 'mpc_pruned_add', 'mpc_pruned_add_device',
                     'mpc_pruned_count', 'mpc_pruned_get', 'mpc_level_run', 'mpc_level_status', 'mpc_level_regions', 'mpc_compact_strides',
                     'mpc_level_regions_compact', 'mpc_frontier_shard', 'mpc_level_slots', 'mpc_level_regions_slots', 'mpc_host_alloc', 'mpc_host_free', 'mpc_locator_create', 'mpc_locator_query', 'mpc_locator_destroy', 'mpc_level_children', 'mpc_level_children_device', 'mpc_level_pruned_new',
-                    'mpc_level_pruned_new_device', 'mpc_frontier_advance', 'mpc_check_level', 'mpc_lp_solve_batch']
+                    'mpc_level_pruned_new_device', 'mpc_level_regions_device', 'mpc_frontier_advance', 'mpc_check_level', 'mpc_lp_solve_batch']
 
 
 def pinned_empty(shape, dtype) -> numpy.ndarray:
@@ -348,6 +350,25 @@ class Engine:
         if m:
             self._check(self._L.mpc_level_pruned_new(self._h, out.ctypes.data_as(_u64p), m), 'mpc_level_pruned_new')
         return out
+
+    def level_region_shapes(self):
+        """(slots, fd, fi, row capacity) of the level just run: the shapes level_regions_device fills."""
+        fd, fi, mr = ctypes.c_int64(0), ctypes.c_int64(0), ctypes.c_int64(0)
+        self._check(self._L.mpc_compact_strides(self._h, ctypes.byref(fd), ctypes.byref(fi), ctypes.byref(mr)),
+                    'mpc_compact_strides')
+        ns = int(self._L.mpc_level_slots(self._h)) if int(self._last.n_regions) else 0
+        return ns, int(fd.value), int(fi.value), int(mr.value) if ns else 0
+
+    def level_regions_device(self, hd_ptr: int, hi_ptr: int, er_ptr: int, cap_slots: int, cap_rows: int):
+        """Slot arrays device -> device into caller-owned device buffers; (n_slots, n_rows), or None when some record
+        of the level only exists in the host route's form (then use level_regions_slots)."""
+        n1, n2 = ctypes.c_int64(0), ctypes.c_int64(0)
+        rc = self._L.mpc_level_regions_device(self._h, ctypes.c_void_p(hd_ptr), ctypes.c_void_p(hi_ptr),
+                                              ctypes.c_void_p(er_ptr), cap_slots, cap_rows, ctypes.byref(n1), ctypes.byref(n2))
+        if rc == 4:      # MPC_ERR_STATE
+            return None
+        self._check(rc, 'mpc_level_regions_device')
+        return int(n1.value), int(n2.value)
 
     def level_pruned_new_device(self, ptr: int, cap: int):
         self._check(self._L.mpc_level_pruned_new_device(self._h, ctypes.c_void_p(ptr), cap),

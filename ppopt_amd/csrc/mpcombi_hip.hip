@@ -1586,6 +1586,29 @@ int mpc_level_pruned_new(mpc_handle *h, uint64_t *out, int64_t cap) {
     if (cap < h->n_pruned_new) return fail(h, MPC_ERR_CAPACITY, "pruned buffer too small");
     return copy_out(h, out, h->pruned_new.p, (size_t)h->n_pruned_new * MPC_MASK_WORDS * sizeof(uint64_t), hipMemcpyDeviceToHost);
 }
+int mpc_level_regions_device(mpc_handle *h, double *head_d_dev, int32_t *head_i_dev, double *erows_dev, int64_t cap_slots,
+                             int64_t cap_rows, int64_t *n_slots, int64_t *n_rows) {
+    if (!h) return MPC_ERR_INVALID;
+    if (!h->level_done) return fail(h, MPC_ERR_STATE, "mpc_level_run has not been called for this frontier");
+    if (n_slots) *n_slots = 0;
+    if (n_rows) *n_rows = 0;
+    if (h->n_regions == 0 || h->n_opt == 0) return MPC_OK;
+    // only the common case lives entirely on the device: every region came from k_region2; otherwise the caller takes the
+    // host route (mpc_level_regions_slots)
+    if (!h->used_region2 || h->n_rretry > 0) return fail(h, MPC_ERR_STATE, "records of this level are not all in slot form on the device");
+    if (cap_slots < h->n_opt || cap_rows < h->n_erows) return fail(h, MPC_ERR_CAPACITY, "slot / row buffers too small");
+    if (!head_d_dev || !head_i_dev || (!erows_dev && h->n_erows > 0)) return MPC_ERR_INVALID;
+    HIP_TRY(h, hipSetDevice(h->device));
+    hipStream_t s = h->stream;
+    HIP_TRY(h, hipMemcpyAsync(head_d_dev, h->headd.p, (size_t)h->n_opt * h->fd * sizeof(double), hipMemcpyDeviceToDevice, s));
+    HIP_TRY(h, hipMemcpyAsync(head_i_dev, h->headi.p, (size_t)h->n_opt * h->fi * sizeof(int32_t), hipMemcpyDeviceToDevice, s));
+    if (h->n_erows > 0) HIP_TRY(h, hipMemcpyAsync(erows_dev, h->epool.p, (size_t)h->n_erows * (h->n_t + 1) * sizeof(double), hipMemcpyDeviceToDevice, s));
+    HIP_TRY(h, hipStreamSynchronize(s));
+    if (n_slots) *n_slots = h->n_opt;
+    if (n_rows) *n_rows = h->n_erows;
+    return MPC_OK;
+}
+
 int mpc_level_pruned_new_device(mpc_handle *h, uint64_t *out, int64_t cap) {
     if (!h || (!out && cap > 0)) return MPC_ERR_INVALID;
     if (!h->level_done) return fail(h, MPC_ERR_STATE, "mpc_level_run has not been called for this frontier");

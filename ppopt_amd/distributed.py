@@ -89,6 +89,20 @@ class HipLevelEngine:
         """(head_d, head_i, erows, k, slots) of the level just run (include/mpcombi.h, mpc_level_regions_slots)."""
         return self.eng.level_regions_slots()
 
+    def regions_tensors(self):
+        """(head_d, head_i, erows) of the level just run as tensors on this GPU, every slot (the gather filters the region
+        slots afterwards): device-to-device copies of the kernel's output, no host round trip.  Levels with records
+        that only exist in host form (regions re-solved by the LDS-engine kernel) go through the host."""
+        ns, fd, fi, rows = self.eng.level_region_shapes()
+        hd = torch.empty((ns, fd), dtype=torch.float64, device=self.device)
+        hi = torch.empty((ns, fi), dtype=torch.int32, device=self.device)
+        er = torch.empty((max(rows, 1), self.n_t + 1), dtype=torch.float64, device=self.device)
+        got = self.eng.level_regions_device(hd.data_ptr(), hi.data_ptr(), er.data_ptr(), ns, rows) if ns else (0, 0)
+        if got is None:
+            h_hd, h_hi, h_er, _, _ = self.eng.level_regions_slots()
+            return tuple(torch.from_numpy(numpy.ascontiguousarray(a)).to(self.device) for a in (h_hd, h_hi, h_er))
+        return hd[:got[0]], hi[:got[0]], er[:got[1]]
+
     def check_base(self):
         """The base active set (the equality rows alone): (status histogram, region pieces or None)."""
         from .mp_solvers.mpqp_hip_combinatorial import unpack_regions
@@ -114,6 +128,34 @@ def allgather_rows(t: torch.Tensor, counts: List[int], group=None) -> List[torch
     parts = [torch.empty_like(pad) for _ in range(world)]
     dist.all_gather(parts, pad, group=group)
     return [p[:c] for p, c in zip(parts, counts)]
+
+
+def allgather_rows_start(t: torch.Tensor, counts: List[int], group=None):
+    """allgather_rows without waiting: returns (per-rank pieces, work handle or None).  The pieces are valid after
+    ``work.wait()``; RCCL runs the transfer on its own stream, so the next level's kernels overlap it."""
+    world = len(counts)
+    if world == 1:
+        return [t], None
+    mx = max(max(counts), 1)
+    pad = t
+    if t.shape[0] != mx:
+        pad = torch.zeros((mx, t.shape[1]), dtype=t.dtype, device=t.device)
+        if t.shape[0]:
+            pad[:t.shape[0]] = t
+    parts = [torch.empty_like(pad) for _ in range(world)]
+    work = dist.all_gather(parts, pad.contiguous(), group=group, async_op=True)
+    return [p[:c] for p, c in zip(parts, counts)], work
+
+
+def _region_tensors(engine):
+    """(head_d, head_i, erows) tensors of the level just run on the engine's device (all slots)."""
+    if hasattr(engine, 'regions_tensors'):
+        return engine.regions_tensors()
+    hd, hi, er, _, _ = engine.regions()
+    return tuple(torch.from_numpy(numpy.ascontiguousarray(a)).to(engine.device) for a in (hd, hi, er))
+
+
+REGION_STATUS = 3
 
 
 def to_host(t: torch.Tensor) -> numpy.ndarray:
@@ -153,7 +195,7 @@ def solve_distributed(engine, program=None, group=None, profile: Optional[List[D
     engine.clear_pruned()
     engine.root()
     sharded = False
-    mine: List = []   # (level, pieces) of the sharded levels: this rank's regions, gathered after the loop
+    mine: List = []   # (k, three pending all-gathers) per sharded level with regions
     for depth in range(max_depth):
         gen_children = depth + 1 != max_depth
         n, k = engine.frontier_size()
@@ -162,26 +204,39 @@ def solve_distributed(engine, program=None, group=None, profile: Optional[List[D
             sharded = True
         st = engine.run(gen_children)
         total = st
+        tensors = None
         if sharded:
+            if collect_regions and st['n_regions']:
+                tensors = _region_tensors(engine)
+            n_slots, n_rows = (int(tensors[0].shape[0]), int(tensors[2].shape[0])) if tensors is not None else (0, 0)
             table = allgather_table([st['n'], st['n_children'], st['n_pruned_new'], st['n_regions'], st['lp_pivots'],
-                                     *st['status']], engine.device, group)
+                                     n_slots, n_rows, *st['status']], engine.device, group)
             total = {'n': sum(r[0] for r in table), 'n_children': sum(r[1] for r in table),
                      'n_pruned_new': sum(r[2] for r in table), 'n_regions': sum(r[3] for r in table),
                      'lp_pivots': sum(r[4] for r in table),
-                     'status': [sum(r[5 + j] for r in table) for j in range(len(st['status']))]}
+                     'status': [sum(r[7 + j] for r in table) for j in range(len(st['status']))]}
             if gen_children and total['n_pruned_new']:
                 # the other ranks' newly pruned sets join this rank's list (its own are added by advance())
                 parts = allgather_rows(engine.pruned_new(), [r[2] for r in table], group)
                 others = [p for r, p in enumerate(parts) if r != rank and p.shape[0]]
                 if others:
                     engine.add_pruned(torch.cat(others, dim=0))
-        if collect_regions:
-            pieces = engine.regions() if st['n_regions'] else None
-            if sharded:
-                mine.append((depth, int(k), total['n_regions'], pieces))
-            elif pieces is not None:
-                hd, hi, er, kk, slots = pieces
-                solution.critical_regions.extend(RegionBatch(hd, hi, er, engine.n_x, engine.n_t, engine.n_c, engine.n_tc, kk, slots).regions())
+            if collect_regions and total['n_regions']:
+                # this level's regions start their way to every rank now (device buffers, asynchronous all-gathers) and are
+                # collected after the last level
+                kk = int(k)
+                fd = engine.n_x * engine.n_t + engine.n_x + kk * engine.n_t + kk
+                fi = 8 + kk + engine.n_tc + kk + 2 * (engine.n_c - kk)
+                if tensors is None:
+                    dev = engine.device
+                    tensors = (torch.zeros((0, fd), dtype=torch.float64, device=dev), torch.zeros((0, fi), dtype=torch.int32, device=dev),
+                               torch.zeros((0, engine.n_t + 1), dtype=torch.float64, device=dev))
+                mine.append((kk, [allgather_rows_start(tensors[0], [r[5] for r in table], group),
+                                  allgather_rows_start(tensors[1], [r[5] for r in table], group),
+                                  allgather_rows_start(tensors[2], [r[6] for r in table], group)]))
+        elif collect_regions and st['n_regions']:
+            hd, hi, er, kk, slots = engine.regions()
+            solution.critical_regions.extend(RegionBatch(hd, hi, er, engine.n_x, engine.n_t, engine.n_c, engine.n_tc, kk, slots).regions())
         if profile is not None:
             profile.append({'depth': depth + 1, 'k': int(k), 'candidates': total['n'], 'status': total['status'],
                             'regions': total['n_regions'], 'children': total['n_children'],
@@ -193,26 +248,17 @@ def solve_distributed(engine, program=None, group=None, profile: Optional[List[D
         if not gen_children or total['n_children'] == 0:
             break
         engine.advance()
-    # regions of the sharded levels: padded all-gathers of the three arrays, level by level, rank order
-    for depth, k, n_total, pieces in mine:
-        if n_total == 0:
-            continue
-        fd = engine.n_x * engine.n_t + engine.n_x + k * engine.n_t + k
-        fi = 8 + k + engine.n_tc + k + 2 * (engine.n_c - k)
-        if pieces is None:
-            hd, hi, er = numpy.zeros((0, fd)), numpy.zeros((0, fi), dtype=numpy.int32), numpy.zeros((0, engine.n_t + 1))
-        else:
-            hd, hi, er, _, slots = pieces
-            hd, hi = hd[slots], hi[slots]
-        table = allgather_table([len(hd), len(er)], engine.device, group)
-        dev = engine.device
-        hd_p = allgather_rows(torch.from_numpy(numpy.ascontiguousarray(hd)).to(dev), [r[0] for r in table], group)
-        hi_p = allgather_rows(torch.from_numpy(numpy.ascontiguousarray(hi)).to(dev), [r[0] for r in table], group)
-        er_p = allgather_rows(torch.from_numpy(numpy.ascontiguousarray(er)).to(dev), [r[1] for r in table], group)
-        for a, b, c in zip(hd_p, hi_p, er_p):
+    # regions of the sharded levels: wait for the gathers, one device-to-host copy per piece, rank order
+    for kk, gathers in mine:
+        for _, work in gathers:
+            if work is not None:
+                work.wait()
+        for a, b, c in zip(gathers[0][0], gathers[1][0], gathers[2][0]):
             if a.shape[0]:
-                solution.critical_regions.extend(RegionBatch(to_host(a), to_host(b), to_host(c), engine.n_x, engine.n_t,
-                                                             engine.n_c, engine.n_tc, k).regions())
+                hd, hi, er = to_host(a), to_host(b), to_host(c)
+                slots = numpy.flatnonzero(hi[:, 0] == REGION_STATUS)
+                solution.critical_regions.extend(RegionBatch(hd, hi, er, engine.n_x, engine.n_t, engine.n_c, engine.n_tc, kk,
+                                                             slots).regions())
     # the base active set, on every rank (one candidate; identical result everywhere)
     hist, regs = engine.check_base()
     if profile is not None:
