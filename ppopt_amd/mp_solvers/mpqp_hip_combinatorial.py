@@ -24,7 +24,6 @@ from typing import Dict, List, Optional
 
 import numpy
 
-from .. import _lib
 from ..critical_region import CriticalRegion
 from ..region_batch import RegionBatch
 from ..solution import Solution

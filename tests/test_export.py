@@ -4,7 +4,6 @@ Solutions are rebuilt from golden region sets of the reference, so no device is 
 import os
 import shutil
 import subprocess
-import types
 
 import numpy
 import pytest

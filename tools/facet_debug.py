@@ -3,7 +3,6 @@ sys.path.insert(0, '.'); sys.path.insert(0, 'tests')
 import numpy
 from scipy.optimize import linprog
 from ppopt_amd import MPQP_Program, Solver, problem_generator as pg
-from ppopt_amd.region_batch import RegionBatch
 from oracle import oracle as orc
 orc.build()
 nx, nt, m, seed, ne = (int(v) for v in sys.argv[1:6])

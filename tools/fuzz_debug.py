@@ -1,7 +1,7 @@
 import sys, warnings
 sys.path.insert(0, '.'); sys.path.insert(0, 'tests')
 import numpy
-from ppopt_amd import MPLP_Program, MPQP_Program, Solver, problem_generator as pg
+from ppopt_amd import MPQP_Program, Solver, problem_generator as pg
 from oracle import oracle as orc
 from conftest import is_knife_edge, kkt_condition
 nx, nt, m, seed = (int(v) for v in sys.argv[1:5])

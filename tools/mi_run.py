@@ -6,7 +6,6 @@ import time
 import warnings
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import numpy  # noqa: E402
 
 from ppopt_amd import MPMIQP_Program  # noqa: E402
 from ppopt_amd.mp_solvers.solve_mpmiqp import solve_mpmiqp  # noqa: E402

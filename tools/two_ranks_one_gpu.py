@@ -1,6 +1,6 @@
 """Two ranks of the multi-GPU driver on ONE GPU (gloo carries the device tensors): an end-to-end check of the sharded path
 with world_size 2 where only a single device is available.  Prints the region count per rank and compares with one rank."""
-import os, sys, warnings
+import os, sys
 sys.path.insert(0, '.')
 import torch, torch.distributed as dist, torch.multiprocessing as mp
 
