@@ -701,7 +701,7 @@ __global__ void __launch_bounds__(256, XQ_WAVES) k_xq_grouped(const DevProblem *
 #define R2_CERT 1
 #endif
 #ifndef R2W
-#define R2W 3
+#define R2W 2
 #endif
 #ifndef X2_WAVES
 #define X2_WAVES 3
