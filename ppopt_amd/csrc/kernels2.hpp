@@ -234,8 +234,11 @@ __device__ inline int kkt_fetch_or_solve(const DevProblem &P, int k, Smem &s, co
     return kkt_solve(P, k, s, ill);
 }
 
+#ifndef TH_WAVES_S2
+#define TH_WAVES_S2 4
+#endif
 template <int NT, int SLOTS>
-__global__ void __launch_bounds__(64, (NT * SLOTS >= 20 ? 3 : 4)) k_theta2(const DevProblem *__restrict__ Pg, const int32_t *__restrict__ cands, long long n, int k,
+__global__ void __launch_bounds__(64, (NT * SLOTS >= 20 ? 3 : (SLOTS >= 2 ? TH_WAVES_S2 : 4))) k_theta2(const DevProblem *__restrict__ Pg, const int32_t *__restrict__ cands, long long n, int k,
                                                     uint8_t *__restrict__ status, LevelCounters *__restrict__ ctr,
                                                     const uint8_t *__restrict__ kkcode, const double *__restrict__ Lin, ThetaArgs ta,
                                                     const int32_t *__restrict__ list) {
