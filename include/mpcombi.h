@@ -161,6 +161,13 @@ int mpc_level_regions_compact(mpc_handle *h, double *head_d, int32_t *head_i, in
 int64_t mpc_level_slots(const mpc_handle *h);
 int mpc_level_regions_slots(mpc_handle *h, double *head_d, int32_t *head_i, int64_t cap_slots, double *erows,
                             int64_t cap_rows, int64_t *n_slots, int64_t *n_rows);
+/* mpc_level_regions_slots that returns as soon as head_i has arrived: head_d and erows (the large arrays) are still
+ * being written by DMA on the handle's stream when it returns and are complete after the next call that synchronises
+ * the handle -- mpc_sync, or any mpc_level_run.  The arrays must be page-locked (mpc_host_alloc) and must stay alive until
+ * then.  When some record needs host-side repacking the call behaves like mpc_level_regions_slots. */
+int mpc_level_regions_slots_async(mpc_handle *h, double *head_d, int32_t *head_i, int64_t cap_slots, double *erows,
+                                  int64_t cap_rows, int64_t *n_slots, int64_t *n_rows);
+int mpc_sync(mpc_handle *h);   /* waits for everything queued on the handle's stream */
 /* Page-locked host memory from a recycling pool (blocks return to the pool on mpc_host_free and are handed out again
  * without re-pinning).  For result arrays that are filled by mpc_level_regions_slots. */
 int mpc_host_alloc(uint64_t bytes, void **out);

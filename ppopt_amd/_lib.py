@@ -90,6 +90,8 @@ def load():
         'mpc_frontier_shard': (ctypes.c_int, [H, ctypes.c_int32, ctypes.c_int32]),
         'mpc_level_slots': (ctypes.c_int64, [H]),
         'mpc_level_regions_slots': (ctypes.c_int, [H, _dp, _ip, ctypes.c_int64, _dp, ctypes.c_int64, _lp, _lp]),
+        'mpc_level_regions_slots_async': (ctypes.c_int, [H, _dp, _ip, ctypes.c_int64, _dp, ctypes.c_int64, _lp, _lp]),
+        'mpc_sync': (ctypes.c_int, [H]),
         'mpc_locator_create': (ctypes.c_int, [ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int64, _lp, _dp, _dp, _dp, _dp, _dp,
                                                ctypes.POINTER(ctypes.c_void_p)]),
         'mpc_locator_query': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, _dp, ctypes.c_double, ctypes.c_int32, _lp, _dp,
@@ -123,7 +125,7 @@ EXPORTED_SYMBOLS = ['mpc_device_count', 'mpc_version', 'mpc_last_global_error', 
                     'mpc_frontier_root', 'mpc_frontier_set', 'mpc_frontier_set_device', 'mpc_frontier_info',
                     'mpc_frontier_get', 'mpc_pruned_clear', 'mpc_pruned_add', 'mpc_pruned_add_device',
                     'mpc_pruned_count', 'mpc_pruned_get', 'mpc_level_run', 'mpc_level_status', 'mpc_level_regions', 'mpc_compact_strides',
-                    'mpc_level_regions_compact', 'mpc_frontier_shard', 'mpc_level_slots', 'mpc_level_regions_slots', 'mpc_host_alloc', 'mpc_host_free', 'mpc_locator_create', 'mpc_locator_query', 'mpc_locator_destroy', 'mpc_level_children', 'mpc_level_children_device', 'mpc_level_pruned_new',
+                    'mpc_level_regions_compact', 'mpc_frontier_shard', 'mpc_level_slots', 'mpc_level_regions_slots', 'mpc_level_regions_slots_async', 'mpc_sync', 'mpc_host_alloc', 'mpc_host_free', 'mpc_locator_create', 'mpc_locator_query', 'mpc_locator_destroy', 'mpc_level_children', 'mpc_level_children_device', 'mpc_level_pruned_new',
                     'mpc_level_pruned_new_device', 'mpc_level_regions_device', 'mpc_frontier_advance', 'mpc_check_level', 'mpc_lp_solve_batch']
 
 
@@ -313,9 +315,15 @@ class Engine:
                                                           ctypes.byref(n2)), 'mpc_level_regions_compact')
         return hd[:n1.value], hi[:n1.value], er[:n2.value], k
 
-    def level_regions_slots(self):
+    def sync(self):
+        """Waits for everything queued on the handle's stream (completes an asynchronous slot fetch)."""
+        self._check(self._L.mpc_sync(self._h), 'mpc_sync')
+
+    def level_regions_slots(self, early_return: bool = False):
         """All slots the region kernel wrote for this level, copied by DMA into pooled page-locked arrays:
-        (head_d [S, fd], head_i [S, fi], erows [R, n_t+1], k, region_slots) -- region_slots = the slots that are regions."""
+        (head_d [S, fd], head_i [S, fi], erows [R, n_t+1], k, region_slots) -- region_slots = the slots that are regions.
+        ``early_return``: come back when head_i is there; head_d and erows are complete after ``sync()`` (or the next
+        ``level_run``) -- the caller must not read them before."""
         nr = int(self._last.n_regions)
         fd, fi, mr = ctypes.c_int64(0), ctypes.c_int64(0), ctypes.c_int64(0)
         self._check(self._L.mpc_compact_strides(self._h, ctypes.byref(fd), ctypes.byref(fi), ctypes.byref(mr)),
@@ -328,9 +336,9 @@ class Engine:
         er = pinned_empty((max(rows_cap, 1), self.n_t + 1), numpy.float64)
         n1, n2 = ctypes.c_int64(0), ctypes.c_int64(0)
         if nr:
-            self._check(self._L.mpc_level_regions_slots(self._h, hd.ctypes.data_as(_dp), hi.ctypes.data_as(_ip), ns,
-                                                        er.ctypes.data_as(_dp), rows_cap, ctypes.byref(n1),
-                                                        ctypes.byref(n2)), 'mpc_level_regions_slots')
+            fetch = self._L.mpc_level_regions_slots_async if early_return else self._L.mpc_level_regions_slots
+            self._check(fetch(self._h, hd.ctypes.data_as(_dp), hi.ctypes.data_as(_ip), ns, er.ctypes.data_as(_dp), rows_cap,
+                              ctypes.byref(n1), ctypes.byref(n2)), 'mpc_level_regions_slots')
         hi = hi[:n1.value]
         return hd[:n1.value], hi, er[:n2.value], k, numpy.flatnonzero(hi[:, 0] == REGION)
 

@@ -281,6 +281,7 @@ struct mpc_handle {
     // level results
     bool level_done = false;
     long long n_opt = 0, n_children = 0, n_pruned_new = 0, n_regions = 0;
+    hipEvent_t ev_hi = nullptr;   // completion of the head_i copy of an asynchronous slot fetch
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     hipEvent_t kev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // around k_theta2 / the main k_x2 launch / k_region2
 };
@@ -419,6 +420,7 @@ int mpc_create(const mpc_problem *p, int32_t device, void *stream, mpc_handle **
     for (auto &e : h->ev) HIP_TRY(nullptr, pooled_event(&e, true));
     for (auto &e : h->kev) HIP_TRY(nullptr, pooled_event(&e, true));
     HIP_TRY(nullptr, pooled_stream(&h->stream2));
+    HIP_TRY(nullptr, pooled_event(&h->ev_hi, false));
     HIP_TRY(nullptr, pooled_event(&h->ev_fork, false));
     HIP_TRY(nullptr, pooled_event(&h->ev_join, false));
     h->n_x = nx; h->n_t = nt; h->n_c = nc; h->n_eq = ne; h->n_tc = ntc; h->is_qp = p->Q != nullptr;
@@ -739,6 +741,7 @@ int mpc_destroy(mpc_handle *h) {
     for (HostBuf *b : {&h->st_list, &h->st_status, &h->st_hd, &h->st_hi, &h->st_pool, &h->st_fxd, &h->st_fxi, &h->st_rlist}) b->release();
     for (auto &e : h->ev) return_event(e, true);
     for (auto &e : h->kev) return_event(e, true);
+    return_event(h->ev_hi, false);
     return_event(h->ev_fork, false);
     return_event(h->ev_join, false);
     return_stream(h->stream2);
@@ -1412,8 +1415,8 @@ int mpc_level_regions_compact(mpc_handle *h, double *head_d, int32_t *head_i, in
 
 int64_t mpc_level_slots(const mpc_handle *h) { return h ? h->n_opt : 0; }
 
-int mpc_level_regions_slots(mpc_handle *h, double *head_d, int32_t *head_i, int64_t cap_slots, double *erows, int64_t cap_rows,
-                            int64_t *n_slots, int64_t *n_rows) {
+static int level_regions_slots_impl(mpc_handle *h, double *head_d, int32_t *head_i, int64_t cap_slots, double *erows, int64_t cap_rows,
+                                    int64_t *n_slots, int64_t *n_rows, bool may_return_early) {
     if (!h) return MPC_ERR_INVALID;
     if (!h->level_done) return fail(h, MPC_ERR_STATE, "mpc_level_run has not been called for this frontier");
     if (n_slots) *n_slots = 0;
@@ -1439,6 +1442,18 @@ int mpc_level_regions_slots(mpc_handle *h, double *head_d, int32_t *head_i, int6
         HIP_TRY(h, hipMemcpyAsync(h->st_status.p, h->status.p, (size_t)h->n, hipMemcpyDeviceToHost, s));
     }
     long long wrow = 0;
+    if (h->used_region2 && n_fixed == 0 && may_return_early) {
+        // every record is in slot form on the device: the small integer heads first, then the two large arrays; the call
+        // returns when the heads have arrived, the rest is in flight on the handle's stream (mpc_sync completes it)
+        HIP_TRY(h, hipMemcpyAsync(head_i, h->headi.p, (size_t)n_opt * fi * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+        HIP_TRY(h, hipEventRecord(h->ev_hi, s));
+        HIP_TRY(h, hipMemcpyAsync(head_d, h->headd.p, (size_t)n_opt * fd * sizeof(double), hipMemcpyDeviceToHost, s));
+        if (h->n_erows > 0) HIP_TRY(h, hipMemcpyAsync(erows, h->epool.p, (size_t)h->n_erows * nr * sizeof(double), hipMemcpyDeviceToHost, s));
+        HIP_TRY(h, hipEventSynchronize(h->ev_hi));
+        if (n_slots) *n_slots = n_opt;
+        if (n_rows) *n_rows = h->n_erows;
+        return MPC_OK;
+    }
     if (h->used_region2) {
         HIP_TRY(h, hipMemcpyAsync(head_d, h->headd.p, (size_t)n_opt * fd * sizeof(double), hipMemcpyDeviceToHost, s));
         HIP_TRY(h, hipMemcpyAsync(head_i, h->headi.p, (size_t)n_opt * fi * sizeof(int32_t), hipMemcpyDeviceToHost, s));
@@ -1501,6 +1516,21 @@ int mpc_level_regions_slots(mpc_handle *h, double *head_d, int32_t *head_i, int6
     }
     if (n_slots) *n_slots = n_opt;
     if (n_rows) *n_rows = wrow;
+    return MPC_OK;
+}
+
+int mpc_level_regions_slots(mpc_handle *h, double *head_d, int32_t *head_i, int64_t cap_slots, double *erows, int64_t cap_rows,
+                            int64_t *n_slots, int64_t *n_rows) {
+    return level_regions_slots_impl(h, head_d, head_i, cap_slots, erows, cap_rows, n_slots, n_rows, false);
+}
+int mpc_level_regions_slots_async(mpc_handle *h, double *head_d, int32_t *head_i, int64_t cap_slots, double *erows, int64_t cap_rows,
+                                  int64_t *n_slots, int64_t *n_rows) {
+    return level_regions_slots_impl(h, head_d, head_i, cap_slots, erows, cap_rows, n_slots, n_rows, true);
+}
+int mpc_sync(mpc_handle *h) {
+    if (!h) return MPC_ERR_INVALID;
+    HIP_TRY(h, hipSetDevice(h->device));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
     return MPC_OK;
 }
 

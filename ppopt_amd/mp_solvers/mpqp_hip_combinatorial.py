@@ -78,7 +78,9 @@ def solve(program, num_cores: int = -1, device: int = 0, profile: Optional[List[
         t0 = time.perf_counter()
         st = eng.level_run(gen_children)
         if collect_regions and st.n_regions:
-            hd, hi, er, kk, slots = eng.level_regions_slots()
+            # the integer heads are waited for (the region objects are built from them); the two large arrays keep
+            # arriving by DMA while Python builds the objects -- eng.sync() below completes them
+            hd, hi, er, kk, slots = eng.level_regions_slots(early_return=True)
             solution.critical_regions.extend(RegionBatch(hd, hi, er, n_x, n_t, n_c, n_tc, kk, slots).regions())
         if profile is not None:
             profile.append({'depth': depth + 1, 'k': int(st.k), 'candidates': int(st.n),
@@ -93,6 +95,7 @@ def solve(program, num_cores: int = -1, device: int = 0, profile: Optional[List[
         if not gen_children or st.n_children == 0:
             break
         eng.frontier_advance()
+    eng.sync()
     # the base active set (= the equality rows) is tested last, like the reference (driver :142-146)
     base = numpy.arange(eng.n_eq, dtype=numpy.int32).reshape(1, -1)
     status, rd, ri, _, _ = eng.check_level(base, numpy.zeros((0, 2), dtype=numpy.uint64), False)
