@@ -720,6 +720,12 @@ __global__ void k_scatter_index(const int32_t *__restrict__ flag, const int32_t 
     if (i < n && flag[i]) list[pos[i]] = (int32_t)i;
 }
 
+// copies a few words of device memory into pinned host memory (a read-back without a copy command: on this runtime a
+// hipMemcpyAsync costs the host ~16 us, a launch ~3 us)
+__global__ void k_publish_words(const unsigned int *__restrict__ src, unsigned int *__restrict__ dst, int n) {
+    for (int i = threadIdx.x; i < n; i += blockDim.x) dst[i] = src[i];
+}
+
 // ---- small levels: the same bookkeeping in ONE single-block launch each -------------------------------------------------------
 // A level of a few thousand candidates is launch-latency bound (about 45 dependent device operations of 5-10 us each);
 // below SMALL_LEVEL_N candidates compaction, partition and scan run as one block of 1024 threads that walks the array

@@ -1210,9 +1210,10 @@ int mpc_level_run(mpc_handle *h, int32_t gen_children, mpc_level_stats *stats) {
             HIP_TRY(h, hipGetLastError());
             h->used_region2 = true;
             // candidates k_region2 gave up on (counted by the kernel; normally none): the LDS-engine kernel, fixed-stride records
-            unsigned int n_rr_dev = 0;
-            HIP_TRY(h, hipMemcpyAsync(&n_rr_dev, &ctr->n_rretry, sizeof(unsigned int), hipMemcpyDeviceToHost, st));
+            hipLaunchKernelGGL(k_publish_words, dim3(1), dim3(64), 0, st, &ctr->n_rretry, reinterpret_cast<unsigned int *>(h->tot_dev + 8), 1);
+            HIP_TRY(h, hipGetLastError());
             HIP_TRY(h, hipStreamSynchronize(st));
+            const unsigned int n_rr_dev = (unsigned int)h->tot_host[8];
             int32_t n_rr = 0;
             if (n_rr_dev > 0) { int rcs = compact(ST_RETRY, ST_RETRY, &n_rr); if (rcs) return rcs; }
             h->n_rretry = n_rr;
@@ -1251,8 +1252,12 @@ int mpc_level_run(mpc_handle *h, int32_t gen_children, mpc_level_stats *stats) {
         hipLaunchKernelGGL(k_histogram, dim3(std::min(blocks256, 1024)), dim3(256), 0, st, h->status.as<uint8_t>(), n, ctr);
         HIP_TRY(h, hipGetLastError());
         HIP_TRY(h, hipEventRecord(h->ev[3], st));
-        HIP_TRY(h, hipMemcpyAsync(&host_ctr, ctr, sizeof(LevelCounters), hipMemcpyDeviceToHost, st));
+        static_assert(sizeof(LevelCounters) % 4 == 0 && sizeof(LevelCounters) + 64 <= 4096, "LevelCounters must fit the pinned block");
+        hipLaunchKernelGGL(k_publish_words, dim3(1), dim3(128), 0, st, reinterpret_cast<const unsigned int *>(ctr),
+                           reinterpret_cast<unsigned int *>(h->tot_dev + 16), (int)(sizeof(LevelCounters) / 4));
+        HIP_TRY(h, hipGetLastError());
         HIP_TRY(h, hipStreamSynchronize(st));
+        std::memcpy(&host_ctr, h->tot_host + 16, sizeof(LevelCounters));
         HIP_TRY(h, hipEventElapsedTime(&ms[0], h->ev[0], h->ev[1]));
         HIP_TRY(h, hipEventElapsedTime(&ms[1], h->ev[1], h->ev[2]));
         HIP_TRY(h, hipEventElapsedTime(&ms[2], h->ev[2], h->ev[3]));
