@@ -200,3 +200,19 @@ def generate_mpmiqp_data(x: int = 6, t: int = 3, m: int = 12, n_bin: int = 4, se
     d = generate_mpqp_data(x + n_bin, t, m, seed)
     d['binary_indices'] = list(range(x, x + n_bin))
     return d
+
+
+def generate_mpqp(x: int = 2, t: int = 2, m: int = 10, seed: Optional[int] = None):
+    """The random mpQP as a program object, like the reference's ``generate_mpqp`` (problem_generator.py:25-78); the
+    constructor's presolve runs on the device."""
+    from .mpqp_program import MPQP_Program
+    d = generate_mpqp_data(x, t, m, seed)
+    return MPQP_Program(d['A'], d['b'], d['c'], d['H'], d['Q'], d['A_t'], d['b_t'], d['F'])
+
+
+def generate_mplp(x: int = 2, t: int = 2, m: int = 10, seed: Optional[int] = None):
+    """The random mpLP of the reference (problem_generator.py:9-22): the presolved rows of ``generate_mpqp`` without the
+    quadratic term."""
+    from .mplp_program import MPLP_Program
+    q = generate_mpqp(x, t, m, seed)
+    return MPLP_Program(q.A, q.b, q.c, q.H, q.A_t, q.b_t, q.F)

@@ -257,3 +257,25 @@ def test_upop_point_location_object():
         inside = [j for j, r in enumerate(sol.critical_regions) if numpy.all(r.E @ p.reshape(-1, 1) <= r.f)]
         assert (i == -1 and not inside) or (i == inside[0])
     assert pl.evaluate(numpy.array([[-500.0], [-500.0]])) is None and not pl.is_inside(numpy.array([[-500.0], [-500.0]]))
+
+
+def test_program_generators_return_solvable_programs():
+    """generate_mpqp / generate_mplp as in the reference's problem_generator.py (tests/other_tests/test_problem_generator.py)."""
+    from ppopt_amd import MPLP_Program, MPQP_Program
+    from ppopt_amd.mp_solvers.solve_mpqp import mpqp_algorithm, solve_mpqp
+    from ppopt_amd.problem_generator import generate_mplp, generate_mpqp
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        qp = generate_mpqp(4, 2, 10, seed=0)
+        lp = generate_mplp(4, 2, 10, seed=0)
+    assert isinstance(qp, MPQP_Program) and isinstance(lp, MPLP_Program) and not isinstance(lp, MPQP_Program)
+    assert qp.num_x() == 4 and qp.num_t() == 2 and lp.num_x() == 4
+    g = numpy.load(os.path.join(GOLDEN, 'rand_4_2_10_s0.npz'))
+    numpy.testing.assert_allclose(qp.A, g['proc_A'], atol=1e-12)
+    assert len(solve_mpqp(qp, mpqp_algorithm.combinatorial)) == int(len(g['R_k']))
+    assert len(solve_mpqp(lp, mpqp_algorithm.combinatorial)) > 0
+    # the reference's own checks (tests/other_tests/test_problem_generator.py:4-11)
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        assert generate_mplp(2, 2, 40, seed=3).feasible_theta_point() is not None
+        assert generate_mpqp(2, 2, 40, seed=3).feasible_theta_point() is not None
