@@ -154,6 +154,73 @@ class MPLP_Program:
             sol.obj += float((self.c_c + self.c_t.T @ theta_point + 0.5 * theta_point.T @ self.Q_t @ theta_point)[0, 0])
         return sol
 
+    def display_warnings(self) -> None:
+        print(self.warnings())
+
+    def solve_theta_variable(self):
+        """theta left as a variable: min c'x s.t. [A | -F][x; theta] <= b (mplp_program.py:355-370)."""
+        c_prime = numpy.vstack([self.c, numpy.zeros((self.num_t(), 1))])
+        return self.solver.solve_lp(c_prime, numpy.hstack([self.A, -self.F]), self.b, self.equality_indices)
+
+    def solve_theta_batch(self, theta_points: numpy.ndarray):
+        """``solve_theta`` for many parameter points in one device launch (theta_points [m, n_theta]); entries are
+        SolverOutput or None, in order."""
+        from . import _lib
+        th = numpy.ascontiguousarray(theta_points, dtype=numpy.float64).reshape(-1, self.num_t())
+        inside = numpy.all(th @ self.A_t.T <= self.b_t.reshape(1, -1), axis=1)
+        out = [None] * len(th)
+        if not inside.any():
+            return out
+        pts = th[inside]
+        b = self.b.reshape(1, -1) + pts @ self.F.T                       # [m, n_c]
+        c = self.c.reshape(1, -1) + pts @ self.H.T                       # [m, n_x]
+        flags = numpy.zeros((len(pts), self.num_constraints()), dtype=numpy.uint8)
+        flags[:, list(self.equality_indices)] = 1
+        status, x, obj, _ = _lib.lp_solve_batch(self.A, b, c, flags, device=self.solver.device)
+        from .solver import SolverOutput
+        for j, i in enumerate(numpy.flatnonzero(inside)):
+            if status[j] != _lib.LP_OPTIMAL:
+                continue
+            t = pts[j].reshape(-1, 1)
+            slack = b[j] - self.A @ x[j]
+            const = float((self.c_c + self.c_t.T @ t + 0.5 * t.T @ self.Q_t @ t)[0, 0])
+            out[i] = SolverOutput(float(obj[j]) + const, x[j].copy(), slack, numpy.flatnonzero(numpy.abs(slack) <= 1e-10), None)
+        return out
+
+    def gen_optimal_active_set(self) -> Optional[List[int]]:
+        """An optimal active set found by sampling around the Chebyshev centre of the feasible space
+        (mplp_program.py:588-618); the up to 500 sample LPs are one device batch instead of a loop."""
+        sol = self.feasible_space_chebychev_ball()
+        if sol is None:
+            return None
+        prng = numpy.random.default_rng()
+        centre = sol.sol[self.num_x():self.num_x() + self.num_t()].reshape(1, -1)
+        radius = float(sol.sol[-1])
+        samples = centre + prng.uniform(-radius, radius, (500, self.num_t()))
+        for res in self.solve_theta_batch(samples):
+            if res is not None and res.active_set.size <= self.num_x():
+                return res.active_set.tolist()
+        return None
+
+    def sample_theta_space(self, num_samples: int = 100) -> Optional[list]:
+        """Random walk through the feasible parameter space collecting the active sets met (mplp_program.py:632-664);
+        every step depends on the previous one, so the LPs are solved one at a time."""
+        sol = self.feasible_space_chebychev_ball()
+        if sol is None:
+            return None
+        prng = numpy.random.default_rng()
+        theta = sol.sol[self.num_x():self.num_x() + self.num_t()].reshape(-1, 1)
+        radius = float(sol.sol[-1])
+        found = []
+        for _ in range(num_samples):
+            step = prng.standard_normal(self.num_t()).reshape(-1, 1)
+            new_theta = theta + prng.random() * radius * step / numpy.linalg.norm(step, 2)
+            res = self.solve_theta(new_theta)
+            if res is not None:
+                found.append(tuple(res.active_set.tolist()))
+                theta = new_theta
+        return [list(a) for a in set(found)]
+
     # ---- per-active-set primitives ----------------------------------------------------------------------------------
     def _lp_feasible(self, active_set) -> bool:
         PA = ppopt_block([[self.A, -self.F], [numpy.zeros((self.A_t.shape[0], self.num_x())), self.A_t]])

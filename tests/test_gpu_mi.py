@@ -279,3 +279,28 @@ def test_program_generators_return_solvable_programs():
         warnings.simplefilter('ignore')
         assert generate_mplp(2, 2, 40, seed=3).feasible_theta_point() is not None
         assert generate_mpqp(2, 2, 40, seed=3).feasible_theta_point() is not None
+
+
+def test_sampling_helpers_of_the_program_classes():
+    """solve_theta_variable / solve_theta_batch / gen_optimal_active_set / sample_theta_space (mplp_program.py:355-664)
+    on the transport mpLP of the tutorial: every sampled active set belongs to a region of the solved problem."""
+    from ppopt_amd import MPLP_Program
+    from ppopt_amd.mp_solvers.solve_mpqp import mpqp_algorithm, solve_mpqp
+    from ppopt_amd.problem_generator import transport_mplp_data
+    d = transport_mplp_data()
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        prog = MPLP_Program(d['A'], d['b'], d['c'], d['H'], d['A_t'], d['b_t'], d['F'])
+    sol = solve_mpqp(prog, mpqp_algorithm.combinatorial)
+    region_sets = {tuple(r.active_set) for r in sol.critical_regions}
+    assert prog.solve_theta_variable() is not None
+    th = prog.feasible_theta_point()
+    one = prog.solve_theta(th)
+    many = prog.solve_theta_batch(numpy.vstack([th.T, th.T + 1e9]))
+    assert many[1] is None and abs(many[0].obj - one.obj) <= 1e-9 * max(1.0, abs(one.obj))
+    numpy.testing.assert_allclose(many[0].sol, one.sol, atol=1e-9)
+    numpy.testing.assert_allclose(sol.evaluate(th).flatten(), one.sol, atol=1e-7)
+    a = prog.gen_optimal_active_set()
+    assert a is not None and tuple(a) in region_sets
+    walked = prog.sample_theta_space(20)
+    assert walked and all(len(w) >= prog.num_x() for w in walked)
