@@ -115,6 +115,94 @@ class Solution:
         region, x = self.locator(device).query(th, self.point_location_tolerance, self.is_overlapping, want_x=True)
         return x, region
 
+    # ---- verification without a QP solver: the KKT conditions of the program at theta ----------------------------------------
+    def kkt_residuals(self, region: CriticalRegion, theta_point: numpy.ndarray) -> dict:
+        """Largest violation of each optimality condition of the program at ``theta_point`` by the region's laws
+        x* = A theta + b, lambda* = C theta + d: primal feasibility, multiplier sign, stationarity, complementarity
+        (all scaled by 1 + the magnitude of the quantities involved)."""
+        P = self.program
+        th = numpy.asarray(theta_point, dtype=float).reshape(-1, 1)
+        x = numpy.asarray(region.A) @ th + numpy.asarray(region.b).reshape(-1, 1)
+        lam = numpy.asarray(region.C) @ th + numpy.asarray(region.d).reshape(-1, 1)
+        aset = list(region.active_set)
+        n_eq = len(P.equality_indices)
+        rhs = P.b + P.F @ th
+        slack = rhs - P.A @ x
+        scale = 1.0 + numpy.abs(rhs)
+        primal = float(numpy.max(numpy.concatenate([(-slack / scale)[n_eq:].ravel(), (numpy.abs(slack) / scale)[:n_eq].ravel(), [0.0]])))
+        grad = P.H @ th + P.c + P.A[aset].T @ lam
+        if hasattr(P, 'Q'):
+            grad = grad + P.Q @ x
+        stationarity = float(numpy.max(numpy.abs(grad)) / (1.0 + numpy.max(numpy.abs(P.c)) + numpy.max(numpy.abs(lam), initial=0.0)))
+        ineq = [j for j, i in enumerate(aset) if i >= n_eq]
+        sign = float(max(0.0, -numpy.min(lam[ineq], initial=0.0)) / (1.0 + numpy.max(numpy.abs(lam), initial=0.0)))
+        compl = float(numpy.max(numpy.abs(slack[aset]) / scale[aset], initial=0.0))
+        return {'primal': primal, 'multiplier_sign': sign, 'stationarity': stationarity, 'complementarity': compl}
+
+    def verify_theta(self, theta_point: numpy.ndarray, tol: float = 1e-6) -> bool:
+        """Is the explicit solution optimal for the program at ``theta_point``?  The reference compares with a
+        deterministic solve (solution.py:149-174); here the region's own x*(theta), lambda*(theta) are put through the
+        KKT conditions, which are sufficient for the convex programs of this package and need no QP solver.  A point
+        in no region verifies when the program is infeasible there (one LP on the device)."""
+        region = self.get_region(theta_point)
+        if region is None:
+            P = self.program
+            th = numpy.asarray(theta_point, dtype=float).reshape(-1, 1)
+            if not P.valid_parameter_realization(th):
+                return True
+            feasible = P.solver.solve_lp(None, P.A, P.b + P.F @ th, P.equality_indices) is not None
+            return not feasible
+        if region.y_fixation is not None:
+            raise NotImplementedError('verify_theta covers continuous programs')
+        return max(self.kkt_residuals(region, theta_point).values()) <= tol
+
+    def chebyshev_centres(self, device: int = 0):
+        """(centres [R, n_theta], radii [R]) of all regions: the Chebyshev LPs of every region (chebyshev_ball.py:10-63)
+        as ONE batch on the device, rows padded to the largest region."""
+        from . import _lib
+        regs = self.critical_regions
+        n_t = self.program.num_t()
+        rows = max(numpy.asarray(r.E).shape[0] for r in regs) + 1
+        A = numpy.zeros((len(regs), rows, n_t + 1))
+        b = numpy.ones((len(regs), rows))
+        for i, r in enumerate(regs):
+            E = numpy.asarray(r.E, dtype=float).reshape(-1, n_t)
+            m = E.shape[0]
+            A[i, :m, :n_t] = E
+            A[i, :m, n_t] = numpy.linalg.norm(E, axis=1)
+            b[i, :m] = numpy.asarray(r.f, dtype=float).reshape(-1)
+            A[i, m, n_t] = -1.0            # -r <= 0
+            b[i, m] = 0.0
+        c = numpy.zeros(n_t + 1)
+        c[n_t] = -1.0
+        status, x, _, _ = _lib.lp_solve_batch(A, b, c, numpy.zeros((len(regs), rows), dtype=numpy.uint8), device=device)
+        radii = numpy.where(status == _lib.LP_OPTIMAL, x[:, n_t], numpy.nan)
+        return x[:, :n_t], radii
+
+    def verify_solution(self, tol: float = 1e-6, device: int = 0) -> bool:
+        """Every region is optimal at its own Chebyshev centre and, without overlaps, is the region found there
+        (solution.py:114-147 with the KKT conditions in place of the deterministic solve)."""
+        if not self.critical_regions:
+            return True
+        centres, radii = self.chebyshev_centres(device)
+        if numpy.any(~numpy.isfinite(radii)):
+            return False
+        located = self.get_region_batch(centres, device)
+        for i, region in enumerate(self.critical_regions):
+            if max(self.kkt_residuals(region, centres[i]).values()) > tol:
+                return False
+            if not self.is_overlapping and located[i] != i:
+                # a thin region (radius below the point-location tolerance) may be preceded in the list by a neighbour that
+                # contains the centre within that tolerance: consistent as long as both give the same objective there
+                if located[i] < 0:
+                    return False
+                th = centres[i].reshape(-1, 1)
+                here = self.program.evaluate_objective(region.evaluate(th), th)
+                there = self.program.evaluate_objective(self.critical_regions[int(located[i])].evaluate(th), th)
+                if abs(here - there) > tol * (1.0 + abs(here)):
+                    return False
+        return True
+
     def is_mixed_integer_sol(self) -> bool:
         from .mpmilp_program import MPMILP_Program
         return isinstance(self.program, MPMILP_Program)

@@ -304,3 +304,26 @@ def test_sampling_helpers_of_the_program_classes():
     assert a is not None and tuple(a) in region_sets
     walked = prog.sample_theta_space(20)
     assert walked and all(len(w) >= prog.num_x() for w in walked)
+
+
+def test_verify_solution_and_verify_theta_through_the_kkt_conditions():
+    """Solution.verify_solution / verify_theta (solution.py:114-174) without a QP solver: KKT conditions at the Chebyshev
+    centres (one LP batch) and at sampled points; a corrupted law must be caught."""
+    from ppopt_amd import MPQP_Program
+    from ppopt_amd.mp_solvers.solve_mpqp import mpqp_algorithm, solve_mpqp
+    from ppopt_amd.problem_generator import generate_mpqp_data, transport_mpqp_data
+    for d in (transport_mpqp_data(), generate_mpqp_data(6, 3, 12, 1)):
+        with warnings.catch_warnings():
+            warnings.simplefilter('ignore')
+            prog = MPQP_Program(d['A'], d['b'], d['c'], d['H'], d['Q'], d['A_t'], d['b_t'], d['F'])
+        sol = solve_mpqp(prog, mpqp_algorithm.combinatorial)
+        centres, radii = sol.chebyshev_centres()
+        assert numpy.all(radii > 1e-8)
+        for cr, c in zip(sol.critical_regions[:10], centres[:10]):
+            assert cr.is_inside(c.reshape(-1, 1), 0.0)
+        assert sol.verify_solution()
+        assert all(sol.verify_theta(c.reshape(-1, 1)) for c in centres[:20])
+        assert sol.verify_theta(numpy.full((prog.num_t(), 1), 1e9))          # outside Theta
+        bad = sol.critical_regions[0]
+        bad.b = numpy.asarray(bad.b) + 1e-3
+        assert not sol.verify_solution()
