@@ -327,3 +327,36 @@ def test_verify_solution_and_verify_theta_through_the_kkt_conditions():
         bad = sol.critical_regions[0]
         bad.b = numpy.asarray(bad.b) + 1e-3
         assert not sol.verify_solution()
+
+
+@pytest.mark.parametrize('shape', [(5, 3, 10, 4), (6, 2, 14, 7), (4, 4, 9, 11)], ids=['5_3_10', '6_2_14', '4_4_9'])
+def test_regions_cover_exactly_the_feasible_parameters(shape):
+    """Completeness property of a fully solved program, no oracle involved: a parameter point lies in some critical
+    region iff the program is feasible there (one LP per point, all points one device batch); points within 1e-4 of the
+    boundary of the feasible set are not judged."""
+    from ppopt_amd import MPQP_Program, _lib
+    from ppopt_amd.mp_solvers.solve_mpqp import mpqp_algorithm, solve_mpqp
+    from ppopt_amd.problem_generator import generate_mpqp_data
+    nx, nt, m, seed = shape
+    d = generate_mpqp_data(nx, nt, m, seed)
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        prog = MPQP_Program(d['A'], d['b'], d['c'], d['H'], d['Q'], d['A_t'], d['b_t'], d['F'])
+    sol = solve_mpqp(prog, mpqp_algorithm.combinatorial)
+    assert len(sol) > 0 and sol.verify_solution()
+    rng = numpy.random.default_rng(seed)
+    box = float(numpy.max(numpy.abs(prog.b_t)))
+    pts = rng.uniform(-box, box, size=(4000, nt))
+    pts = pts[numpy.all(pts @ prog.A_t.T <= prog.b_t.reshape(1, -1), axis=1)]
+    located = sol.get_region_batch(pts) >= 0
+
+    def feasible(shrink):
+        rhs = prog.b.reshape(1, -1) + pts @ prog.F.T - shrink
+        flags = numpy.zeros((len(pts), prog.num_constraints()), dtype=numpy.uint8)
+        status, _, _, _ = _lib.lp_solve_batch(prog.A, rhs, None, flags)
+        return status == _lib.LP_OPTIMAL
+
+    inner, outer = feasible(1e-4), feasible(-1e-4)
+    assert inner.sum() > 100
+    assert numpy.all(located[inner]), 'a feasible parameter point lies in no region'
+    assert not numpy.any(located[~outer]), 'a region contains an infeasible parameter point'
