@@ -30,12 +30,11 @@ class CriticalRegion:
     x_indices: Optional[numpy.ndarray] = None
 
     def __repr__(self):
-        return (f'Critical region with active set {self.active_set}\n'
-                f'The Omega Constraint indices are {self.omega_set}\n'
-                f'The Lagrange multipliers Constraint indices are {self.lambda_set}\n'
-                f'The Regular Constraint indices are {self.regular_set}\n'
-                f'  x(θ) = Aθ + b \n λ(θ) = Cθ + d \n  Eθ <= f\n'
-                f' A = {self.A} \n b = {self.b} \n C = {self.C} \n d = {self.d} \n E = {self.E} \n f = {self.f}')
+        sets = (f'active set {self.active_set}; bounded by parameter rows {self.omega_set}, multipliers of {self.lambda_set}, '
+                f'inactive constraints {self.regular_set}')
+        blocks = '\n'.join(f'{name} =\n{numpy.asarray(value)}' for name, value in
+                           (('A', self.A), ('b', self.b), ('C', self.C), ('d', self.d), ('E', self.E), ('f', self.f)))
+        return f'CriticalRegion: x = A theta + b, lambda = C theta + d on E theta <= f\n{sets}\n{blocks}'
 
     def evaluate(self, theta: numpy.ndarray) -> numpy.ndarray:
         """x*(theta); binaries of a mixed-integer parent are spliced in when present (critical_region.py:64-77)."""

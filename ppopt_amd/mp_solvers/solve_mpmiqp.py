@@ -1,15 +1,21 @@
-"""Algorithm dispatch for mixed-integer programs: ``solve_mpmiqp`` (reference: mp_solvers/solve_mpmiqp.py:14-66)."""
+"""Entry point for mixed-integer programs (the role of the reference's mp_solvers/solve_mpmiqp.py:14-66).
+
+``solve_mpmiqp(problem)`` runs the chosen mixed-integer strategy -- enumeration of the binary fixations is the only
+one, as in the reference -- with ``cont_algo`` for the continuous sub-programs, then removes the overlaps between
+fixations where that is defined: one parameter, linear objective, no bilinear theta-x terms.
+"""
 from enum import Enum
 
 import numpy
 
 from ..solution import Solution
 from ..utils.region_overlap_utils import reduce_overlapping_critical_regions_1d
-from .mpmiqp_enumeration import solve_mpmiqp_enumeration
+from . import mpmiqp_enumeration
 from .solve_mpqp import mpqp_algorithm, solve_mpqp
 
 
 class mpmiqp_algorithm(Enum):
+    """Strategies for the integer part; pass one as ``mpmiqp_algo``."""
     enumerate = 'enumerate'
 
     def __str__(self):
@@ -17,27 +23,31 @@ class mpmiqp_algorithm(Enum):
 
     @staticmethod
     def all_algos():
-        return ''.join(f'mpmiqp_algorithm.{a}\n' for a in mpmiqp_algorithm)
+        return '\n'.join(f'mpmiqp_algorithm.{member}' for member in mpmiqp_algorithm) + '\n'
+
+
+_STRATEGIES = {mpmiqp_algorithm.enumerate: mpmiqp_enumeration.solve_mpmiqp_enumeration}
+
+
+def _overlaps_can_be_reduced(problem) -> bool:
+    """The interval arithmetic of region_overlap_utils needs one parameter and objectives that are affine in theta."""
+    if problem.num_t() != 1 or hasattr(problem, 'Q'):
+        return False
+    bilinear_mass = numpy.sum(numpy.abs(problem.H[problem.cont_indices, :]))
+    return bool(numpy.isclose(bilinear_mass, 0))
 
 
 def solve_mpmiqp(problem, mpmiqp_algo: mpmiqp_algorithm = mpmiqp_algorithm.enumerate,
                  cont_algo: mpqp_algorithm = mpqp_algorithm.combinatorial, num_cores=-1,
                  reduce_overlap=True) -> Solution:
-    if len(problem.binary_indices) == 0:
-        print('The problem does not have any binary variables, solving as a continuous problem instead.')
+    if not problem.binary_indices:
+        print('No binary variables in this program: it is solved as a continuous one.')
         return solve_mpqp(problem, cont_algo)
-    if not isinstance(mpmiqp_algo, mpmiqp_algorithm):
-        raise TypeError('You must pass an algorithm from mpmiqp_algorithm as the continuous algorithm. These can be '
-                        'found by importing the following \n\nfrom ppopt_amd.mp_solvers.solve_mpmiqp import '
-                        f'mpmiqp_algorithm\n\nWith the following choices\n{mpmiqp_algorithm.all_algos()}')
-
-    cand_sol = Solution(problem, [])
-    if mpmiqp_algo == mpmiqp_algorithm.enumerate:
-        cand_sol = solve_mpmiqp_enumeration(problem, num_cores, cont_algo)
-
-    # overlaps are only resolved for 1-D mpMILPs without bilinear terms (solve_mpmiqp.py:55-64)
-    bilinear = not numpy.isclose(numpy.sum(numpy.abs(problem.H[problem.cont_indices, :])), 0)
-    if not (problem.num_t() > 1 or hasattr(problem, 'Q') or not reduce_overlap or bilinear):
-        regions, still_overlapping = reduce_overlapping_critical_regions_1d(problem, cand_sol.critical_regions)
+    if mpmiqp_algo not in _STRATEGIES:
+        raise TypeError('mpmiqp_algo has to be a member of ppopt_amd.mp_solvers.solve_mpmiqp.mpmiqp_algorithm; '
+                        f'available:\n{mpmiqp_algorithm.all_algos()}')
+    solution = _STRATEGIES[mpmiqp_algo](problem, num_cores, cont_algo)
+    if reduce_overlap and _overlaps_can_be_reduced(problem):
+        regions, still_overlapping = reduce_overlapping_critical_regions_1d(problem, solution.critical_regions)
         return Solution(problem, regions, still_overlapping)
-    return cand_sol
+    return solution
