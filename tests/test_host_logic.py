@@ -106,7 +106,7 @@ def test_critical_region_and_solution():
     th = make_column([0.5, 0.5])
     assert numpy.array_equal(cr.evaluate(th), th) and numpy.array_equal(cr.lagrange_multipliers(th), th)
     assert cr.is_inside(th) and not cr.is_inside(make_column([2.0, 0.5]))
-    assert cr.get_constraints()[0] is E and 'Critical region with active set []' in repr(cr)
+    assert cr.get_constraints()[0] is E and 'active set []' in repr(cr)
 
     class _P:
         def num_t(self): return 2
