@@ -161,7 +161,7 @@ def test_region_batch_lazy_fields():
     assert r0.omega_set == [2] and r0.lambda_set == [4] and r0.regular_set == [[0, 2], [0, 3]]
     assert r1.omega_set == [] and r1.lambda_set == [0, 2] and r1.regular_set == [[], []]
     r0.A = numpy.zeros((3, 2))            # assignable like a dataclass field
-    assert numpy.all(r0.A == 0) and 'Critical region with active set [1, 4]' in repr(r0)
+    assert numpy.all(r0.A == 0) and 'active set [1, 4]' in repr(r0)
     th = numpy.ones((2, 1))
     assert r1.evaluate(th).shape == (3, 1) and r1.materialize() is r1
 
