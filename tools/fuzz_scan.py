@@ -45,6 +45,9 @@ for it in range(n_prob):
             prog = MPQP_Program(d['A'], d['b'], d['c'], d['H'], d['Q'], d['A_t'], d['b_t'], d['F'], equality_indices=d.get('equality_indices'), solver=Solver())
     Q = None if kind == 'mplp' else prog.Q
     P = orc.OracleProblem(prog.A, prog.b, prog.F, prog.c, prog.H, Q, prog.A_t, prog.b_t, len(prog.equality_indices))
+    if prog.num_constraints() > 128:      # outside the device path (size limits)
+        print('skipped', tag, 'n_c', prog.num_constraints(), flush=True)
+        continue
     eng = prog.engine(0)
     eng.pruned_clear(); eng.frontier_root()
     depth = 0
