@@ -8,6 +8,7 @@
 // need no crash pivots) and the pre-crashed dictionary D0 of the (x,theta) LP; n_t <= NT, D0 columns <= NXC - 2,
 // rows <= 64 * SLOTS.
 #pragma once
+#include <type_traits>
 #include "kernels.hpp"
 #include "lp_reg.hpp"
 
@@ -42,6 +43,7 @@ constexpr int ST_NEEDX_SING = 9;  // the same, and the KKT matrix was singular (
 struct ThetaArgs {
     const double *W, *UVp, *tvp, *tv_rows;
     int chunk;   // candidates taken from the work queue per atomic
+    int cbuf_off;   // offset (in doubles, from the start of dynamic LDS) of the row-compaction scratch of k_theta2<.,2>; 0 = none
 };
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -286,6 +288,9 @@ __global__ void __launch_bounds__(64, (NT * SLOTS >= 20 ? 3 : (SLOTS >= 2 ? TH_W
             lp.alive = (nt >= 31 ? 0xfffffffeu : ((1u << (nt + 1)) - 2u));
             lp.cv = nt + m + lane - 1;
             bool box_lam = false, box_slack = false;
+            bool live[SLOTS];   // rows the LP needs: present and not satisfied everywhere in the bounding box
+#pragma unroll
+            for (int sl = 0; sl < SLOTS; ++sl) live[sl] = (lane + 64 * sl) < (k - e) + nin + npre;
 #pragma unroll
             for (int sl = 0; sl < SLOTS; ++sl) {
                 const int i = lane + 64 * sl;
@@ -373,6 +378,14 @@ __global__ void __launch_bounds__(64, (NT * SLOTS >= 20 ? 3 : (SLOTS >= 2 ? TH_W
                             smax -= term;
                         }
                         if (i < m && smax < -10 * TOL_FEAS * sc) { if (i < nlam) box_lam = true; else box_slack = true; }
+                        if (SLOTS >= 2) {
+                            // ... and the smallest: a row whose slack stays above 1e-6 (row units) over the whole box can never
+                            // limit a step of a walk that stays inside the parameter polytope
+                            double smin = h;
+#pragma unroll
+                            for (int t = 0; t < NT; ++t) smin -= g[t] > 0.0 ? g[t] * bhi[t] : (g[t] < 0.0 ? g[t] * blo[t] : 0.0);
+                            if (smin > 10 * TOL_FEAS * sc * 10) live[sl] = false;
+                        }
                     }
                     // theta = theta_v - Minv sigma:  value at the vertex and coefficients of the tight-row slacks sigma
                     double b0 = h, cf[NT];
@@ -395,20 +408,67 @@ __global__ void __launch_bounds__(64, (NT * SLOTS >= 20 ? 3 : (SLOTS >= 2 ? TH_W
             const bool inf1 = __any(box_slack), inf2 = __any(box_lam);
             n_box1 += inf1; n_box2 += (!inf1 && inf2);
             // inf1: a stage-1 row cannot hold anywhere in the parameter set -> stage 1 infeasible, no LP needed
-            const int r1 = inf1 ? LP_INFEASIBLE : lp.phase1();
-            const long long t15 = clock64();
-            if (r1 == LP_ITERLIMIT) st = ST_LP_LIMIT;
-            else if (lp.growth > GROWTH_FRESH) retry = true;
-            else if (r1 == LP_OPTIMAL && inf2) st = ST_FEASIBLE;   // feasible, and a multiplier row rules out optimality
-            else if (r1 == LP_OPTIMAL) {
+            long long t15 = 0;
+            int lp_iters = 0;
+            auto stages = [&](auto &q, auto slots_c) {
+                constexpr int S = decltype(slots_c)::value;
+                const int r1 = inf1 ? LP_INFEASIBLE : q.phase1();
+                t15 = clock64();
+                if (r1 == LP_ITERLIMIT) st = ST_LP_LIMIT;
+                else if (q.growth > GROWTH_FRESH) retry = true;
+                else if (r1 == LP_OPTIMAL && inf2) st = ST_FEASIBLE;   // feasible, and a multiplier row rules out optimality
+                else if (r1 == LP_OPTIMAL) {
 #pragma unroll
-                for (int sl = 0; sl < SLOTS; ++sl) if (lp.kind[sl] == RK_PASSIVE) lp.kind[sl] = RK_INEQ;
-                const int r2 = lp.phase1();
-                if (r2 == LP_ITERLIMIT) st = ST_LP_LIMIT;
-                else if (lp.growth > GROWTH_FRESH) retry = true;
-                else st = r2 == LP_OPTIMAL ? ST_OPT_PENDING : ST_FEASIBLE;
+                    for (int sl = 0; sl < S; ++sl) if (q.kind[sl] == RK_PASSIVE) q.kind[sl] = RK_INEQ;
+                    const int r2 = q.phase1();
+                    if (r2 == LP_ITERLIMIT) st = ST_LP_LIMIT;
+                    else if (q.growth > GROWTH_FRESH) retry = true;
+                    else st = r2 == LP_OPTIMAL ? ST_OPT_PENDING : ST_FEASIBLE;
+                }
+                lp_iters = q.iters;
+            };
+            bool compacted = false;
+            if constexpr (SLOTS == 2) {
+                // Two tableau rows per lane cost twice the per-pivot work of one.  Rows that are satisfied over the whole
+                // bounding box never take part in a ratio test, so when the others fit into 64 lanes (98 % of the open
+                // candidates at config 3) they are packed, in their order, into a one-row-per-lane LP through LDS.
+                const unsigned long long b0 = __ballot(live[0]), b1 = __ballot(live[1]);
+                const int n_live = __popcll(b0) + __popcll(b1);
+                if (ta.cbuf_off > 0 && n_live <= 64 && !inf1) {
+                    constexpr int CS = NT + 4;
+                    double *cb = smem + ta.cbuf_off;
+                    int *cbi = reinterpret_cast<int *>(cb + 64 * CS);
+                    const unsigned long long below = (1ull << lane) - 1ull;
+#pragma unroll
+                    for (int sl = 0; sl < 2; ++sl) {
+                        if (live[sl]) {
+                            const int pos = sl == 0 ? __popcll(b0 & below) : __popcll(b0) + __popcll(b1 & below);
+#pragma unroll
+                            for (int j = 0; j < NT + 2; ++j) cb[pos * CS + j] = lp.t[sl][j];
+                            cb[pos * CS + NT + 2] = lp.w[sl];
+                            cb[pos * CS + NT + 3] = lp.winv[sl];
+                            cbi[2 * pos] = lp.var[sl];
+                            cbi[2 * pos + 1] = lp.kind[sl];
+                        }
+                    }
+                    wave_sync();
+                    RegLp<NT + 2, 1, true> lp1;
+                    lp1.m = n_live; lp1.iters = 0; lp1.max_iter = lp.max_iter; lp1.growth = 0.0;
+                    lp1.alive = lp.alive; lp1.cv = lp.cv;
+                    const bool has = lane < n_live;
+#pragma unroll
+                    for (int j = 0; j < NT + 2; ++j) lp1.t[0][j] = has ? cb[lane * CS + j] : 0.0;
+                    lp1.w[0] = has ? cb[lane * CS + NT + 2] : 1.0;
+                    lp1.winv[0] = has ? cb[lane * CS + NT + 3] : 1.0;
+                    lp1.var[0] = has ? cbi[2 * lane] : -1;
+                    lp1.kind[0] = has ? cbi[2 * lane + 1] : RK_DEAD;
+                    wave_sync();
+                    stages(lp1, std::integral_constant<int, 1>{});
+                    compacted = true;
+                }
             }
-            pivots += lp.iters;
+            if (!compacted) stages(lp, std::integral_constant<int, SLOTS>{});
+            pivots += lp_iters;
             cyc_s2 += clock64() - t15;
         }
         const long long t2 = clock64();

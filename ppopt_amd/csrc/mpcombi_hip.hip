@@ -695,6 +695,12 @@ int mpc_create(const mpc_problem *p, int32_t device, void *stream, mpc_handle **
             }
             const Layout lf = make_layout(NTP * NTP + 3 * NTP + kmax * LS, size_K, size_L, 0, mode == 1 ? size_X : 0, kmax, nc, 2, 2, 2);
             h->Pf = P; apply_layout(h->Pf, lf); h->lds_f = lf.bytes;
+            h->targs.cbuf_off = 0;
+            if (slots_t == 2) {   // scratch of the live-row compaction of k_theta2<., 2>: 64 rows of NT+4 doubles and 2 ints
+                h->targs.cbuf_off = h->lds_f / 8;
+                h->lds_f += 64 * (NTP + 4) * 8 + 64 * 2 * 4;
+                h->lds_f = (h->lds_f + 15) & ~15;
+            }
             h->grid_f = h->n_cu * std::min(16, waves_per_cu(h->lds_f));
             HIP_TRY(nullptr, h->pf_dev.ensure(sizeof(DevProblem), h->stream));
             HIP_TRY(nullptr, hipMemcpyAsync(h->pf_dev.p, &h->Pf, sizeof(DevProblem), hipMemcpyHostToDevice, h->stream));
