@@ -526,7 +526,9 @@ constexpr int XQ_ITERS = XQ_ITERS_N;
 // staged in LDS (k_xq_grouped); v is the variable id of the candidate's new row.  Returns 1 feasible, 0 infeasible,
 // -1 undecided (left to k_x2); piv_local counts the pivots.
 template <int SLOTS, class PD, class PI>
-__device__ __forceinline__ int xq_decide(PD pd, PI pi, int mr, int NXC, int v, int lane, int &piv_local) {
+__device__ __forceinline__ int xq_decide(PD pd, PI pi, int mr, int NXC, int ncol, int v, int lane, int &piv_local) {
+    // NXC: column slots of the record layout; ncol <= NXC: the slots that are ever used (value column + D0 columns) -- only those
+    // are stored and read
     int qvar[SLOTS], qkind[SLOTS];
     double qb[SLOTS];
 #pragma unroll
@@ -539,7 +541,7 @@ __device__ __forceinline__ int xq_decide(PD pd, PI pi, int mr, int NXC, int v, i
     const int qcv = lane < NXC + 3 ? pi[2 * mr + lane] : -1;
     const unsigned al = (unsigned)__builtin_amdgcn_readlane(qcv, NXC);
     const double growth0 = __hiloint2double(__builtin_amdgcn_readlane(qcv, NXC + 1), __builtin_amdgcn_readlane(qcv, NXC + 2));
-    const unsigned long long bc = __ballot(qcv == v && lane >= 1 && lane < NXC && ((al >> lane) & 1u));
+    const unsigned long long bc = __ballot(qcv == v && lane >= 1 && lane < ncol && ((al >> lane) & 1u));
     int feas = -1;   // 1 feasible, 0 infeasible, -1 undecided
     piv_local = 0;
     if (bc) feas = 1;
@@ -563,15 +565,15 @@ __device__ __forceinline__ int xq_decide(PD pd, PI pi, int mr, int NXC, int v, i
             double E[XQ_ITERS][SLOTS], R[XQ_ITERS];
             int rp[XQ_ITERS], qp[XQ_ITERS];
             double invp[XQ_ITERS];
-            double xrow = (lane < NXC) ? pd[(size_t)lane * mr + row] : 0.0;   // the new row, entry j in lane j
+            double xrow = (lane < ncol) ? pd[(size_t)lane * mr + row] : 0.0;   // the new row, entry j in lane j
             double growth = growth0;
 #pragma unroll
             for (int it = 0; it < XQ_ITERS; ++it) {
                 if (at(qb, row) <= TOL_FEAS) { feas = 1; break; }
-                const double g = (lane >= 1 && lane < NXC) ? xrow : 0.0;
+                const double g = (lane >= 1 && lane < ncol) ? xrow : 0.0;
                 const double gm = dpp_wave_max(g > TOL_COST ? g : 0.0);
                 if (!(gm > TOL_COST)) { feas = 0; break; }
-                const int q = uni(__ffsll((long long)__ballot(g == gm && lane >= 1 && lane < NXC)) - 1);
+                const int q = uni(__ffsll((long long)__ballot(g == gm && lane >= 1 && lane < ncol)) - 1);
                 // entering column at the current time
                 double a[SLOTS], ratio[SLOTS];
 #pragma unroll
@@ -637,7 +639,7 @@ __device__ __forceinline__ int xq_decide(PD pd, PI pi, int mr, int NXC, int v, i
                 const double xb = at(qb, l) * inv;
 #pragma unroll
                 for (int sl = 0; sl < SLOTS; ++sl) qb[sl] = (lane + 64 * sl == l) ? xb : fma(-a[sl], xb, qb[sl]);
-                double rowl = (lane < NXC) ? pd[(size_t)lane * mr + l] : 0.0;   // pivot row l at the current time, entry j in lane j
+                double rowl = (lane < ncol) ? pd[(size_t)lane * mr + l] : 0.0;   // pivot row l at the current time, entry j in lane j
 #pragma unroll
                 for (int p_ = 0; p_ < it; ++p_) {
                     if (l == rp[p_]) rowl = R[p_];
@@ -684,7 +686,7 @@ __global__ void __launch_bounds__(64, XQ_WAVES) k_xq(const DevProblem *__restric
             const int32_t *pi = dc.prev_i + (size_t)ps * dc.stride_i;
             const double *pd = dc.prev_d + (size_t)ps * dc.stride_d;
             int piv_local = 0;
-            const int feas = xq_decide<SLOTS>(pd, pi, mr, NXC, v, lane, piv_local);
+            const int feas = xq_decide<SLOTS>(pd, pi, mr, NXC, P.n_d0c + 1, v, lane, piv_local);
             if (feas >= 0) {
                 n_quick++;
                 pivots += piv_local;
@@ -719,7 +721,7 @@ __global__ void __launch_bounds__(256, XQ_WAVES) k_xq_grouped(const DevProblem *
     int32_t *si = reinterpret_cast<int32_t *>(xq_smem + dc.stride_d);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nv = P.n_x + P.n_t, mr = P.n_d0r;
     const unsigned n_groups = (unsigned)*n_groups_p;
-    const int nd = (int)dc.stride_d, ni = (int)dc.stride_i;
+    const int nd = min(((P.n_d0c + 1) * mr + 1) & ~1, (int)dc.stride_d), ni = (int)dc.stride_i;   // the used columns only (even count: 16-byte copies)
     unsigned long long pivots = 0, n_quick = 0;
     for (;;) {
         if (tid == 0) item_s = atomicAdd(&ctr->work_q, 1u);
@@ -747,7 +749,7 @@ __global__ void __launch_bounds__(256, XQ_WAVES) k_xq_grouped(const DevProblem *
                 const bool singular = status[c] == ST_NEEDX_SING;
                 const int v = nv + cands[(size_t)c * k + (k - 1)];
                 int piv_local = 0;
-                const int feas = xq_decide<SLOTS>(sd, si, mr, NXC, v, lane, piv_local);
+                const int feas = xq_decide<SLOTS>(sd, si, mr, NXC, P.n_d0c + 1, v, lane, piv_local);
                 if (feas >= 0) {
                     n_quick++;
                     pivots += piv_local;
@@ -813,7 +815,7 @@ __global__ void __launch_bounds__(64, (NXC * SLOTS >= 32 ? X2_WAVES : 3)) k_x2(c
                 const int psn = __builtin_amdgcn_readlane(my_ps, u + 1);
                 if (psn >= 0) {
                     const int32_t *nx = reinterpret_cast<const int32_t *>(dc.prev_d + (size_t)psn * dc.stride_d);
-                    const long long words = (long long)NXC * mr * 2;
+                    const long long words = (long long)(nc0 + 1) * mr * 2;
                     if ((long long)lane * 32 < words) sink ^= nx[lane * 32];
                     if ((long long)(lane + 64) * 32 < words) sink ^= nx[(lane + 64) * 32];
                 }
@@ -826,7 +828,7 @@ __global__ void __launch_bounds__(64, (NXC * SLOTS >= 32 ? X2_WAVES : 3)) k_x2(c
             const bool cached = ps >= 0;
             const double *src_d = cached ? dc.prev_d + (size_t)ps * dc.stride_d : d0T;
             const int32_t *src_i = cached ? dc.prev_i + (size_t)ps * dc.stride_i : d0_rows;
-            const int jmax = cached ? NXC - 1 : nc0, voff = cached ? 0 : nv;
+            const int jmax = nc0, voff = cached ? 0 : nv;   // column slots beyond nc0 are never used: neither stored nor read
             const int first = cached ? k - 1 : e;   // first active row that still has to be switched on
             {
                 // cv and, behind it in the cached record, alive / growth: one load, fields taken out of their lanes
@@ -877,7 +879,7 @@ __global__ void __launch_bounds__(64, (NXC * SLOTS >= 32 ? X2_WAVES : 3)) k_x2(c
                         oi[i] = lx.var[sl];
                         oi[mr + i] = lx.kind[sl];
 #pragma unroll
-                        for (int j = 0; j < NXC; ++j) od[(size_t)j * mr + i] = lx.t[sl][j];
+                        for (int j = 0; j < NXC; ++j) if (j <= nc0) od[(size_t)j * mr + i] = lx.t[sl][j];
                     }
                 }
                 if (lane < NXC) oi[2 * mr + lane] = lx.cv;

@@ -1297,8 +1297,10 @@ int mpc_level_run(mpc_handle *h, int32_t gen_children, mpc_level_stats *stats) {
         stats->n_x_items = n_x_items;
         stats->n_theta_items = n_theta_items;
         stats->n_opt = h->n_opt;
-        stats->dict_read_bytes = (h->fast && h->have_prev_dict && h->have_parent_slot) ? h->dict_stride_d * 8 + h->dict_stride_i * 4 : 0;
-        stats->dict_write_bytes = (h->fast && h->storing) ? h->dict_stride_d * 8 + h->dict_stride_i * 4 : 0;
+        // bytes of one dictionary record that are actually moved: the used columns (value + D0 columns) and the integer part
+        const long long rec_bytes = (long long)(h->Pf.n_d0c + 1) * h->Pf.n_d0r * 8 + h->dict_stride_i * 4;
+        stats->dict_read_bytes = (h->fast && h->have_prev_dict && h->have_parent_slot) ? rec_bytes : 0;
+        stats->dict_write_bytes = (h->fast && h->storing) ? rec_bytes : 0;
         stats->ms_verdict = ms[0]; stats->ms_region = ms[1]; stats->ms_children = ms[2]; stats->ms_total = ms[0] + ms[1] + ms[2];
     }
     return MPC_OK;
