@@ -519,7 +519,7 @@ struct DictCache {
 #define XQ_WAVES 8
 #endif
 #ifndef XQ_ITERS_N
-#define XQ_ITERS_N 8
+#define XQ_ITERS_N 16
 #endif
 constexpr int XQ_ITERS = XQ_ITERS_N;
 // The decision of one candidate of k_xq: `pd` / `pi` are its parent's dictionary record (doubles / ints), in HBM (k_xq) or
