@@ -209,13 +209,18 @@ int mpc_lp_solve_batch(int32_t device, int64_t n_lp, int32_t m, int32_t n, const
  *   row_off   n_regions + 1 offsets into ef_rows;  ef_rows  total_rows x (n_t+1): [f | E] of every region, stacked
  *   xlaw      n_regions x n_x x (n_t+1): [b | A] of every region
  *   Q, c, H   objective of the program (n_x x n_x, n_x, n_x x n_t; any may be NULL) -- only used with overlapping != 0
- * mpc_locator_query: theta m x n_t (host).  region[p] = index of the first region with all(E theta - f < tol)
- * (overlapping == 0) or of the containing region with the lowest objective, ties to the later one (overlapping != 0);
- * -1 if none.  x (m x n_x, may be NULL) = A theta + b of that region, NaN where there is none. */
+ * mpc_locator_query: theta m x n_t (host).  region[p] = index of the first region that contains the point (flags without
+ * MPC_LOCATE_OVERLAPPING) or of the containing region with the lowest objective, ties to the later one (with it); -1 if
+ * none.  "Contains" is all(E theta - f < tol), the strict test of CriticalRegion.is_inside (critical_region.py:83-86), or
+ * with MPC_LOCATE_INCLUSIVE all(E theta <= f + tol): with tol = 0 the test `A @ theta <= b` of the reference's
+ * PointLocation (upop/point_location.py:46,59), under which points on a facet belong to the region.
+ * x (m x n_x, may be NULL) = A theta + b of that region, NaN where there is none. */
+#define MPC_LOCATE_OVERLAPPING 1
+#define MPC_LOCATE_INCLUSIVE 2
 typedef struct mpc_locator mpc_locator;
 int mpc_locator_create(int32_t device, int32_t n_x, int32_t n_t, int64_t n_regions, const int64_t *row_off, const double *ef_rows,
                        const double *xlaw, const double *Q, const double *c, const double *H, mpc_locator **out);
-int mpc_locator_query(mpc_locator *loc, int64_t m, const double *theta, double tol, int32_t overlapping, int64_t *region,
+int mpc_locator_query(mpc_locator *loc, int64_t m, const double *theta, double tol, int32_t flags, int64_t *region,
                       double *x, float *ms_locate);
 int mpc_locator_destroy(mpc_locator *loc);
 

@@ -14,6 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('MPC_LIB_PATH') or os.path.join(_HERE, 'csrc', 'libmpcombi_hip.so')   # MPC_LIB_PATH: A/B builds
 
 MPC_OK, MPC_ERR_INVALID, MPC_ERR_HIP, MPC_ERR_CAPACITY, MPC_ERR_STATE = range(5)
+MPC_LOCATE_OVERLAPPING, MPC_LOCATE_INCLUSIVE = 1, 2   # flags of mpc_locator_query
 INFEASIBLE, FEASIBLE, OPTIMAL_NO_REGION, REGION, SINGULAR_KKT, LP_LIMIT = range(6)
 LP_OPTIMAL, LP_INFEASIBLE, LP_UNBOUNDED, LP_ITERLIMIT = range(4)
 MASK_WORDS = 2
@@ -412,9 +413,10 @@ class Engine:
         return status, d[:nreg.value], i[:nreg.value], idx[:nreg.value], ch[:nch.value]
 
 
-def lp_solve_batch(A, b, c, eq_flags, device: int = 0):
+def lp_solve_batch(A, b, c, eq_flags, device: int = 0, want_x: bool = True):
     """Batched LPs on the device.  A: (n_lp, m, n) or (m, n) shared; b likewise; c (n_lp, n) / (n,) / None;
-    eq_flags: (n_lp, m) bool.  Returns (status, x, obj, iterations)."""
+    eq_flags: (n_lp, m) bool.  Returns (status, x, obj, iterations); x is None with ``want_x=False`` (nothing is
+    allocated or copied back for it)."""
     L = load()
     A = _f64(A)
     eq_flags = numpy.ascontiguousarray(eq_flags, dtype=numpy.uint8)
@@ -431,12 +433,12 @@ def lp_solve_batch(A, b, c, eq_flags, device: int = 0):
         shared_c = int(c.size == n)
         cp = c.ctypes.data_as(_dp)
     status = numpy.zeros(n_lp, dtype=numpy.int32)
-    x = numpy.zeros((n_lp, n))
+    x = numpy.zeros((n_lp, n)) if want_x else None
     obj = numpy.zeros(n_lp)
     it = numpy.zeros(n_lp, dtype=numpy.int32)
     rc = L.mpc_lp_solve_batch(int(device), n_lp, m, n, A.ctypes.data_as(_dp), int(shared_A), b.ctypes.data_as(_dp),
                               int(shared_b), cp, shared_c, eq_flags.ctypes.data_as(_u8p), status.ctypes.data_as(_ip),
-                              x.ctypes.data_as(_dp), obj.ctypes.data_as(_dp), it.ctypes.data_as(_ip))
+                              None if x is None else x.ctypes.data_as(_dp), obj.ctypes.data_as(_dp), it.ctypes.data_as(_ip))
     if rc != MPC_OK:
         raise MpcError(f'mpc_lp_solve_batch failed ({rc}): {L.mpc_last_global_error().decode()}')
     return status, x, obj, it
@@ -464,14 +466,17 @@ class Locator:
         self._h = ptr
         self.last_ms = 0.0
 
-    def query(self, theta: numpy.ndarray, tol: float = 1e-5, overlapping: bool = False, want_x: bool = True):
-        """theta [m, n_t] -> (region index [m] (-1: none), x [m, n_x] or None)."""
+    def query(self, theta: numpy.ndarray, tol: float = 1e-5, overlapping: bool = False, want_x: bool = True,
+              inclusive: bool = False):
+        """theta [m, n_t] -> (region index [m] (-1: none), x [m, n_x] or None).  ``inclusive``: membership is
+        ``E theta <= f + tol`` (MPC_LOCATE_INCLUSIVE) instead of the strict ``E theta - f < tol``."""
         th = _f64(theta).reshape(-1, self.n_t)
         m = len(th)
         region = numpy.empty(m, dtype=numpy.int64)
         x = numpy.empty((m, self.n_x)) if want_x else None
         ms = ctypes.c_float(0.0)
-        rc = self._L.mpc_locator_query(self._h, m, th.ctypes.data_as(_dp), float(tol), int(bool(overlapping)),
+        rc = self._L.mpc_locator_query(self._h, m, th.ctypes.data_as(_dp), float(tol),
+                                       (MPC_LOCATE_OVERLAPPING if overlapping else 0) | (MPC_LOCATE_INCLUSIVE if inclusive else 0),
                                        region.ctypes.data_as(_lp), None if x is None else x.ctypes.data_as(_dp), ctypes.byref(ms))
         if rc != MPC_OK:
             raise MpcError(f'mpc_locator_query failed ({rc}): {self._L.mpc_last_global_error().decode()}')

@@ -22,7 +22,7 @@ __global__ void __launch_bounds__(256) k_locate(long long m, int nt, int nx, lon
                                                 const int32_t *__restrict__ row_region, const int32_t *__restrict__ row_end,
                                                 const double *__restrict__ ef, const double *__restrict__ xlaw,
                                                 const double *__restrict__ Q, const double *__restrict__ cvec, const double *__restrict__ H,
-                                                const double *__restrict__ theta, double tol, int overlapping,
+                                                const double *__restrict__ theta, double tol, int overlapping, int inclusive,
                                                 long long *__restrict__ region_out) {
     __shared__ double tile[LOC_TILE][NT + 1];
     __shared__ int trid[LOC_TILE], tend[LOC_TILE];
@@ -88,10 +88,19 @@ __global__ void __launch_bounds__(256) k_locate(long long m, int nt, int nx, lon
                 inside = overlapping ? (p < m) : alive;
                 if (!overlapping && !__any(alive)) { i = n_rows; break; }   // every lane has its region
             }
-            double v = -tile[li][0];
+            if (inclusive) {
+                // E theta <= f + tol with the product formed first and then compared, like `A @ theta <= b` of the reference's
+                // PointLocation (upop/point_location.py:46,59): a point exactly on a facet belongs to the region
+                double v = 0.0;
 #pragma unroll
-            for (int t = 0; t < NT; ++t) v = fma(tile[li][1 + t], th[t], v);
-            inside = inside && (v < tol);
+                for (int t = 0; t < NT; ++t) v = fma(tile[li][1 + t], th[t], v);
+                inside = inside && (v <= tile[li][0] + tol);
+            } else {
+                double v = -tile[li][0];
+#pragma unroll
+                for (int t = 0; t < NT; ++t) v = fma(tile[li][1 + t], th[t], v);
+                inside = inside && (v < tol);
+            }
             if (!__any(inside)) { i = tend[li]; continue; }   // nobody is left in this region: on to the next one
             ++i;
         }

@@ -383,6 +383,7 @@ void lu_solve_host(const std::vector<double> &LU, const std::vector<int> &perm, 
 
 }  // namespace
 
+static int create_fill(const mpc_problem *p, int32_t device, void *stream, mpc_handle *h);
 static int lp_batch_impl(int32_t device, int64_t n_lp, int32_t m, int32_t n, const double *A, int32_t shared_A, const double *b,
                          int32_t shared_b, const double *c, int32_t shared_c, const uint8_t *eq, int32_t *status, double *x,
                          double *obj, int32_t *iters, int32_t *tight);
@@ -411,7 +412,20 @@ int mpc_create(const mpc_problem *p, int32_t device, void *stream, mpc_handle **
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return fail(nullptr, MPC_ERR_HIP, "no HIP device available (libmpcombi_hip has no CPU fallback)");
     if (device < 0 || device >= ndev) return fail(nullptr, MPC_ERR_INVALID, "device index out of range");
+    // every failure from here on goes through one cleanup path: mpc_destroy returns the handle's streams, events, device
+    // blocks and pinned block to the pools (a caller that creates one handle per binary fixation must not leak on OOM)
     mpc_handle *h = new mpc_handle();
+    const int rc_fill = create_fill(p, device, stream, h);
+    if (rc_fill != MPC_OK) { (void)mpc_destroy(h); return rc_fill; }
+    *out = h;
+    return MPC_OK;
+}
+
+}  // extern "C"
+
+// fills a fresh handle; on failure the caller destroys it (error text in the thread-local g_error, see mpc_last_global_error)
+static int create_fill(const mpc_problem *p, int32_t device, void *stream, mpc_handle *h) {
+    const int nx = p->n_x, nt = p->n_t, nc = p->n_c, ne = p->n_eq, ntc = p->n_tc;
     h->device = device;
     HIP_TRY(nullptr, hipSetDevice(device));
     h->n_cu = cu_count(device);
@@ -641,7 +655,7 @@ int mpc_create(const mpc_problem *p, int32_t device, void *stream, mpc_handle **
     const Layout lr = make_layout(T_r, size_K, size_L, rows_t * nr, size_X, kmax, nc, P.ld_t, rows_t + 2, rows_t);
     h->Pv = P; apply_layout(h->Pv, lv); h->lds_v = lv.bytes;
     h->Pr = P; apply_layout(h->Pr, lr); h->lds_r = lr.bytes;
-    if (h->lds_v > 160 * 1024 || h->lds_r > 160 * 1024) { delete h; return fail(nullptr, MPC_ERR_INVALID, "problem does not fit the 160 KiB LDS of one CU"); }
+    if (h->lds_v > 160 * 1024 || h->lds_r > 160 * 1024) return fail(nullptr, MPC_ERR_INVALID, "problem does not fit the 160 KiB LDS of one CU");
     if (h->lds_v > 48 * 1024) HIP_TRY(nullptr, hipFuncSetAttribute(reinterpret_cast<const void *>(k_verdict), hipFuncAttributeMaxDynamicSharedMemorySize, h->lds_v));
     if (h->lds_r > 48 * 1024) {
         HIP_TRY(nullptr, hipFuncSetAttribute(reinterpret_cast<const void *>(k_region<RG_FULL>), hipFuncAttributeMaxDynamicSharedMemorySize, h->lds_r));
@@ -731,9 +745,10 @@ int mpc_create(const mpc_problem *p, int32_t device, void *stream, mpc_handle **
         h->tot_dev = static_cast<int32_t *>(dp);
         std::memset(hp, 0, 64);
     }
-    *out = h;
     return MPC_OK;
 }
+
+extern "C" {
 
 int mpc_destroy(mpc_handle *h) {
     if (!h) return MPC_OK;
@@ -1773,6 +1788,10 @@ struct mpc_locator {
     bool hasQ = false, hasc = false, hasH = false;
 };
 
+static int locator_fill(mpc_locator *L, int64_t n_regions, const int64_t *row_off, const double *ef_rows, const double *xlaw, const double *Q,
+                        const double *c, const double *H);
+extern "C" int mpc_locator_destroy(mpc_locator *L);
+
 extern "C" int mpc_locator_create(int32_t device, int32_t n_x, int32_t n_t, int64_t n_regions, const int64_t *row_off, const double *ef_rows,
                                   const double *xlaw, const double *Q, const double *c, const double *H, mpc_locator **out) {
     if (!out || n_x < 1 || n_t < 1 || n_t > 16 || n_regions < 0 || (n_regions > 0 && (!row_off || !ef_rows || !xlaw)))
@@ -1780,6 +1799,15 @@ extern "C" int mpc_locator_create(int32_t device, int32_t n_x, int32_t n_t, int6
     HIP_TRY(nullptr, hipSetDevice(device));
     mpc_locator *L = new mpc_locator();
     L->device = device; L->n_x = n_x; L->n_t = n_t; L->n_regions = n_regions;
+    const int rc_fill = locator_fill(L, n_regions, row_off, ef_rows, xlaw, Q, c, H);
+    if (rc_fill != MPC_OK) { (void)mpc_locator_destroy(L); return rc_fill; }   // one cleanup path: nothing leaks on failure
+    *out = L;
+    return MPC_OK;
+}
+
+static int locator_fill(mpc_locator *L, int64_t n_regions, const int64_t *row_off, const double *ef_rows, const double *xlaw, const double *Q,
+                        const double *c, const double *H) {
+    const int n_x = L->n_x, n_t = L->n_t;
     HIP_TRY(nullptr, hipStreamCreateWithFlags(&L->stream, hipStreamNonBlocking));
     HIP_TRY(nullptr, hipEventCreate(&L->e0));
     HIP_TRY(nullptr, hipEventCreate(&L->e1));
@@ -1803,11 +1831,10 @@ extern "C" int mpc_locator_create(int32_t device, int32_t n_x, int32_t n_t, int6
     if (c) { HIP_TRY(nullptr, up(L->c, c, (size_t)n_x * sizeof(double))); L->hasc = true; }
     if (H) { HIP_TRY(nullptr, up(L->H, H, (size_t)n_x * n_t * sizeof(double))); L->hasH = true; }
     HIP_TRY(nullptr, hipStreamSynchronize(L->stream));
-    *out = L;
     return MPC_OK;
 }
 
-extern "C" int mpc_locator_query(mpc_locator *L, int64_t m, const double *theta, double tol, int32_t overlapping, int64_t *region, double *x,
+extern "C" int mpc_locator_query(mpc_locator *L, int64_t m, const double *theta, double tol, int32_t flags, int64_t *region, double *x,
                                  float *ms_locate) {
     if (!L || m < 0 || (m > 0 && (!theta || !region))) return MPC_ERR_INVALID;
     if (ms_locate) *ms_locate = 0.0f;
@@ -1823,7 +1850,7 @@ extern "C" int mpc_locator_query(mpc_locator *L, int64_t m, const double *theta,
     HIP_TRY(nullptr, hipEventRecord(L->e0, st));
 #define MPC_LOCATE(NT_) hipLaunchKernelGGL((k_locate<NT_>), g, b, 0, st, (long long)m, nt, nx, L->n_regions, L->n_rows, L->row_region.as<int32_t>(), \
                                            L->row_end.as<int32_t>(), L->ef.as<double>(), L->xlaw.as<double>(), Q, c, H, L->theta.as<double>(), tol, \
-                                           (int)overlapping, L->region.as<long long>())
+                                           (int)(flags & MPC_LOCATE_OVERLAPPING), (int)((flags & MPC_LOCATE_INCLUSIVE) != 0), L->region.as<long long>())
     if (nt <= 4) MPC_LOCATE(4); else if (nt <= 8) MPC_LOCATE(8); else MPC_LOCATE(16);
 #undef MPC_LOCATE
     HIP_TRY(nullptr, hipGetLastError());

@@ -69,9 +69,19 @@ class HipLevelEngine:
                 'n_x_items': int(st.n_x_items), 'n_opt': int(st.n_opt), 'n_theta_items': int(st.n_theta_items), 'dict_read_bytes': int(st.dict_read_bytes),
                 'dict_write_bytes': int(st.dict_write_bytes)}
 
+    def _fresh(self, shape, dtype) -> torch.Tensor:
+        """A tensor the ENGINE's stream may write.  torch's caching allocator only orders the reuse of a block against
+        torch's own streams: a recycled block can still be the source of work queued earlier on torch's current stream
+        (the padding copy that feeds the previous level's all-gather), which the engine's private stream knows nothing
+        about.  Waiting for the current stream closes that window (blocks last used by RCCL's stream are held back by
+        the allocator itself until that use has completed)."""
+        t = torch.empty(shape, dtype=dtype, device=self.device)
+        torch.cuda.current_stream(self.device).synchronize()
+        return t
+
     def pruned_new(self) -> torch.Tensor:
         m = int(self._stats.n_pruned_new)
-        out = torch.empty((m, 2), dtype=torch.int64, device=self.device)
+        out = self._fresh((m, 2), torch.int64)
         if m:
             self.eng.level_pruned_new_device(out.data_ptr(), m)
         return out
@@ -94,9 +104,9 @@ class HipLevelEngine:
         slots afterwards): device-to-device copies of the kernel's output, no host round trip.  Levels with records
         that only exist in host form (regions re-solved by the LDS-engine kernel) go through the host."""
         ns, fd, fi, rows = self.eng.level_region_shapes()
-        hd = torch.empty((ns, fd), dtype=torch.float64, device=self.device)
-        hi = torch.empty((ns, fi), dtype=torch.int32, device=self.device)
-        er = torch.empty((max(rows, 1), self.n_t + 1), dtype=torch.float64, device=self.device)
+        hd = self._fresh((ns, fd), torch.float64)
+        hi = self._fresh((ns, fi), torch.int32)
+        er = self._fresh((max(rows, 1), self.n_t + 1), torch.float64)
         got = self.eng.level_regions_device(hd.data_ptr(), hi.data_ptr(), er.data_ptr(), ns, rows) if ns else (0, 0)
         if got is None:
             h_hd, h_hi, h_er, _, _ = self.eng.level_regions_slots()

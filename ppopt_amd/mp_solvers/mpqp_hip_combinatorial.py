@@ -10,9 +10,11 @@ Same level-synchronous structure and pruning semantics as the reference driver
     finally the base active set itself                         driver :142-146
 
 The frontier, the pruned list and the children never leave HBM between levels; per level the host reads back a
-small statistics block and the region records.  With ``num_gpus > 1`` (one process per GPU under
-``torch.distributed``) every rank processes the slice ``to_check[rank::world]`` and the ranks exchange children,
-pruned sets and regions once per level (ppopt_amd/distributed.py).
+small statistics block and the region records.  ``solve`` drives ONE GPU (``device``).  The multi-GPU form of the same
+loop is ``ppopt_amd.distributed.solve_distributed`` (one process per GPU under ``torch.distributed``): small levels are
+processed by every rank, the first large level is split ``to_check[rank::world]``, afterwards children stay on the GPU
+of their parent and the ranks exchange only the newly pruned sets per level and the regions at the end -- children are
+never moved between ranks.
 
 Differences from the reference that are visible to a user:
   * ``shuffle(to_check)`` (driver :114) is dropped -- candidate order is deterministic, and so is the region order;

@@ -48,7 +48,8 @@ def solve_mpqp(problem: MPQP_Program, algorithm: mpqp_algorithm = mpqp_algorithm
     if algorithm not in _COMBINATORIAL:
         raise NotImplementedError(f'{algorithm} is not part of the MI355X combinatorial path; use one of '
                                   f'{[str(a) for a in _COMBINATORIAL]}')
-    solution = mpqp_hip_combinatorial.solve(problem)
+    # the device the program's presolve LPs ran on (Solver(device=...)) is the device the solve runs on
+    solution = mpqp_hip_combinatorial.solve(problem, device=int(getattr(getattr(problem, 'solver', None), 'device', 0) or 0))
     # overlap flags exactly as the reference sets them (solve_mpqp.py:103-112)
     if isinstance(problem, MPQP_Program) and min(numpy.linalg.eigvalsh(problem.Q)) <= 0:
         solution.is_overlapping = True

@@ -227,9 +227,12 @@ class MPLP_Program:
         Pb = ppopt_block([[self.b], [self.b_t]])
         return self.solver.solve_lp(numpy.zeros((self.num_x() + self.num_t(), 1)), PA, Pb, list(active_set)) is not None
 
-    def engine(self, device: int = 0):
-        """The device-resident twin of this program (created on first use; dropped when the rows change)."""
+    def engine(self, device: Optional[int] = None):
+        """The device-resident twin of this program (created on first use; dropped when the rows change).  Default
+        device: the one the program's solver runs its presolve LPs on (``Solver(device=...)``)."""
         from . import _lib
+        if device is None:
+            device = int(getattr(self.solver, 'device', 0) or 0)
         if self._engine is None or self._engine.device != device:
             Q = getattr(self, 'Q', None)
             self._engine = _lib.Engine(self.A, self.b, self.F, self.c, self.H, Q, self.A_t, self.b_t,

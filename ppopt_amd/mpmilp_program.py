@@ -6,9 +6,10 @@
 Same constructor, presolve and methods as the reference.  The reference hands its mixed-integer feasibility
 questions to Gurobi one at a time (process_constraints: one MILP per row, mpmilp_program.py:129-137;
 check_bin_feasibility: one MILP per tree node, :203-237).  Here every such question is the same thing -- "does the LP
-of some full binary fixation have a solution" -- and the LPs of ALL fixations (times all rows, for the presolve) go
-to the MI355X in one ``mpc_lp_solve_batch`` launch (ppopt_amd.solver.Solver.solve_milp_batch); partial fixations are
-then answered from the cached table of leaf verdicts without further device work.
+of some full binary fixation have a solution" -- and the LPs of the fixations (times the rows, for the presolve) go
+to the MI355X as ``mpc_lp_solve_batch`` launches of bounded size (ppopt_amd.solver.Solver.milp_leaf_feasibility /
+milp_any_feasible; beyond 10 binaries whole subtrees are pruned through their LP relaxation); partial fixations are then
+answered from the cached table of leaf verdicts without further device work.
 """
 from typing import List, Optional
 
@@ -18,7 +19,6 @@ from .mplp_program import MPLP_Program
 from .solver import Solver, SolverOutput
 from .utils.constraint_utilities import detect_implicit_equalities
 from .utils.general_utils import ppopt_block
-from . import _lib
 
 
 class MPMILP_Program(MPLP_Program):
@@ -66,9 +66,11 @@ class MPMILP_Program(MPLP_Program):
         rows = [i + n_eq for i in range(self.num_inequality_constraints())]
         saved = []
         if rows:
-            status, _, _ = self.solver.solve_milp_batch(None, PA, Pb, [[*self.equality_indices, r] for r in rows],
-                                                        self.binary_indices)
-            feasible = (status == _lib.LP_OPTIMAL).any(axis=1)
+            # a fixation under which the program itself is infeasible stays infeasible with one more row tightened: only
+            # the feasible leaves are candidates, and a row is settled by the first leaf that admits it
+            leaves = numpy.flatnonzero(self.solver.milp_leaf_feasibility(PA, Pb, self.equality_indices, self.binary_indices))
+            feasible = self.solver.milp_any_feasible(PA, Pb, [[*self.equality_indices, r] for r in rows],
+                                                     self.binary_indices, leaves)
             saved = [r for r, ok in zip(rows, feasible) if ok]
         upper = [*self.equality_indices, *[i for i in saved if i < self.A.shape[0]]]
         self.A, self.F, self.b = self.A[upper], self.F[upper], self.b[upper]
@@ -78,12 +80,11 @@ class MPMILP_Program(MPLP_Program):
     # ---- binary fixations ------------------------------------------------------------------------------------------------
     def leaf_feasibility(self) -> numpy.ndarray:
         """bool[2^n_bin]: is the LP over (x_cont, theta) feasible with the binaries fixed to that combination
-        (row order of Solver.binary_fixations).  One device launch, cached until the constraints change."""
+        (row order of Solver.binary_fixations).  Device batches of LPs (Solver.milp_leaf_feasibility: all leaves at once
+        for few binaries, level by level with relaxation pruning for many), cached until the constraints change."""
         if self._leaf_table is None:
             PA, Pb = self._stacked_constraints()
-            status, _, _ = self.solver.solve_milp_batch(None, PA, Pb, [list(self.equality_indices)],
-                                                        self.binary_indices)
-            self._leaf_table = status[0] == _lib.LP_OPTIMAL
+            self._leaf_table = self.solver.milp_leaf_feasibility(PA, Pb, list(self.equality_indices), self.binary_indices)
         return self._leaf_table
 
     def check_bin_feasibility(self, partial_fixed_bins: Optional[List] = None) -> bool:
@@ -102,8 +103,10 @@ class MPMILP_Program(MPLP_Program):
 
     def feasible_combinations(self) -> List[List[int]]:
         """All feasible full fixations, in the order the reference's tree walk lists its leaves."""
-        fix = Solver.binary_fixations(len(self.binary_indices))
-        return [row.tolist() for row, ok in zip(fix, self.leaf_feasibility()) if ok]
+        nb = len(self.binary_indices)
+        leaves = numpy.flatnonzero(self.leaf_feasibility())
+        shifts = numpy.arange(nb - 1, -1, -1, dtype=numpy.int64)[None, :]
+        return ((leaves[:, None] >> shifts) & 1).tolist()
 
     # ---- substituted / relaxed continuous programs (mpmilp_program.py:145-185, 239-269) ---------------------------------------
     def _substituted_rows(self, fixed_combination):

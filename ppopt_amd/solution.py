@@ -100,19 +100,22 @@ class Solution:
             self._locator_key = key
         return self._locator
 
-    def get_region_batch(self, theta_points: numpy.ndarray, device: int = 0) -> numpy.ndarray:
+    def get_region_batch(self, theta_points: numpy.ndarray, device: int = 0, inclusive: bool = False) -> numpy.ndarray:
         """Index into critical_regions of get_region(theta) for every row of theta_points (-1: no region)
-        (solution.py:60-112, all points at once on the GPU)."""
+        (solution.py:60-112, all points at once on the GPU).  ``inclusive``: membership is ``E theta <= f + tol`` instead
+        of get_region's strict ``E theta - f < tol`` (used by upop.PointLocation with tol = 0)."""
         if not self.critical_regions:
             return numpy.full(len(numpy.atleast_2d(theta_points)), -1, dtype=numpy.int64)
-        return self.locator(device).query(theta_points, self.point_location_tolerance, self.is_overlapping, want_x=False)[0]
+        return self.locator(device).query(theta_points, self.point_location_tolerance, self.is_overlapping, want_x=False,
+                                          inclusive=inclusive)[0]
 
-    def evaluate_batch(self, theta_points: numpy.ndarray, device: int = 0):
+    def evaluate_batch(self, theta_points: numpy.ndarray, device: int = 0, inclusive: bool = False):
         """(x* [m, n_x] (NaN rows where no region contains the point), region index [m])  -- evaluate() for many points."""
         th = numpy.atleast_2d(numpy.asarray(theta_points, dtype=float))
         if not self.critical_regions:
             return numpy.full((len(th), 0), numpy.nan), numpy.full(len(th), -1, dtype=numpy.int64)
-        region, x = self.locator(device).query(th, self.point_location_tolerance, self.is_overlapping, want_x=True)
+        region, x = self.locator(device).query(th, self.point_location_tolerance, self.is_overlapping, want_x=True,
+                                               inclusive=inclusive)
         return x, region
 
     # ---- verification without a QP solver: the KKT conditions of the program at theta ----------------------------------------

@@ -80,21 +80,24 @@ class Solver:
 
     # ---- binary MILPs as LP batches (solver.py:248-282; the reference hands these to Gurobi) -------------------------
     MAX_BINARIES = 20
+    # host bytes one device batch of fixation LPs may take (equality flags + the solution block when it is asked for)
+    MILP_BATCH_BYTES = 256 << 20
+    # up to this many binaries every leaf is posed directly; beyond, prefixes are pruned through their LP relaxation
+    MILP_DIRECT_BINARIES = 10
 
     @staticmethod
-    def binary_fixations(n_bin: int) -> numpy.ndarray:
-        """All 2^n_bin fixations, [2^n_bin, n_bin], first binary most significant: row order == the order in which
-        MITree.get_full_leafs lists leaves (0-branch before 1-branch at every depth, mitree.py:84-102)."""
-        idx = numpy.arange(1 << n_bin, dtype=numpy.int64)[:, None]
+    def binary_fixations(n_bin: int, first: int = 0, count: Optional[int] = None) -> numpy.ndarray:
+        """Fixations first .. first+count-1 of the 2^n_bin (all by default), [count, n_bin], first binary most
+        significant: row order == the order in which MITree.get_full_leafs lists leaves (0-branch before 1-branch at
+        every depth, mitree.py:84-102)."""
+        count = (1 << n_bin) - first if count is None else count
+        idx = numpy.arange(first, first + count, dtype=numpy.int64)[:, None]
         shifts = numpy.arange(n_bin - 1, -1, -1, dtype=numpy.int64)[None, :]
-        return ((idx >> shifts) & 1).astype(numpy.int32)
+        return ((idx >> shifts) & 1).astype(numpy.int8)
 
-    def solve_milp_batch(self, c, A, b, equality_sets: List[Sequence[int]], bin_vars: Sequence[int]):
-        """For every equality set, the LP of every binary fixation: returns (status, x, obj) shaped
-        [n_sets, 2^n_bin(, n)] -- status == 0 where that fixation's LP has an optimal solution.
-
-        The fixation is expressed through equality flags on appended rows  y_j <= 1  and  -y_j <= 0  (flagging the
-        first fixes y_j = 1, the second y_j = 0), so that all instances share one matrix and one right-hand side."""
+    def _milp_blocks(self, A, b, bin_vars):
+        """The shared LP data of every fixation: rows  y_j <= 1  and  -y_j <= 0  appended (flagging the first as an
+        equality fixes y_j = 1, the second y_j = 0, neither leaves y_j relaxed to [0, 1])."""
         A = numpy.ascontiguousarray(A, dtype=numpy.float64)
         m, n = A.shape
         bins = list(bin_vars or [])
@@ -104,35 +107,140 @@ class Solver:
         bb = numpy.ascontiguousarray(b, dtype=numpy.float64).reshape(-1)
         up = numpy.zeros((nb, n))
         up[numpy.arange(nb), bins] = 1.0
-        A_aug = numpy.vstack([A, up, -up])
-        b_aug = numpy.concatenate([bb, numpy.ones(nb), numpy.zeros(nb)])
-        fix = self.binary_fixations(nb)                                   # [2^nb, nb]
-        n_fix, n_sets = fix.shape[0], len(equality_sets)
-        flags = numpy.zeros((n_sets, n_fix, m + 2 * nb), dtype=numpy.uint8)
+        return numpy.vstack([A, up, -up]), numpy.concatenate([bb, numpy.ones(nb), numpy.zeros(nb)]), m, n, bins
+
+    def _fixation_lps(self, A_aug, b_aug, m, nb, set_flags, set_idx, fix, c=None, want_x=False):
+        """LPs ``(equality set set_idx[i], fixation fix[i])`` for i in range(len(fix)); fix entries 0 / 1 / -1 (relaxed).
+        Posed in device batches of at most MILP_BATCH_BYTES host bytes.  Returns (status, obj, x or None)."""
+        n_items, n = len(fix), A_aug.shape[1]
+        status = numpy.empty(n_items, dtype=numpy.int32)
+        obj = numpy.empty(n_items)
+        x = numpy.empty((n_items, n)) if want_x else None
+        per_item = (m + 2 * nb) + 16 + (8 * n if want_x else 0)
+        step = max(1, int(self.MILP_BATCH_BYTES // per_item))
+        for lo in range(0, n_items, step):
+            hi = min(n_items, lo + step)
+            flags = numpy.zeros((hi - lo, m + 2 * nb), dtype=numpy.uint8)
+            flags[:, :m] = set_flags[set_idx[lo:hi]]
+            flags[:, m:m + nb] = fix[lo:hi] == 1
+            flags[:, m + nb:] = fix[lo:hi] == 0
+            st, xx, ob, _ = _lib.lp_solve_batch(A_aug, b_aug, c, flags, device=self.device, want_x=want_x)
+            status[lo:hi], obj[lo:hi] = st, ob
+            if want_x:
+                x[lo:hi] = xx
+        return status, obj, x
+
+    @staticmethod
+    def _set_flags(equality_sets, m):
+        flags = numpy.zeros((len(equality_sets), m), dtype=numpy.uint8)
         for i, eq in enumerate(equality_sets):
-            flags[i, :, list(eq)] = 1
-        flags[:, :, m:m + nb] = (fix == 1)[None]
-        flags[:, :, m + nb:] = (fix == 0)[None]
+            flags[i, list(eq)] = 1
+        return flags
+
+    def milp_leaf_feasibility(self, A, b, equality_constraints: Sequence[int], bin_vars: Sequence[int]) -> numpy.ndarray:
+        """bool[2^n_bin]: does the LP of that full fixation (row order of ``binary_fixations``) have a solution.
+
+        Few binaries: every leaf is one LP of a single batch.  Many: the tree is walked level by level from depth
+        MILP_DIRECT_BINARIES -- a prefix whose LP relaxation (remaining binaries in [0, 1]) is infeasible has no feasible
+        leaf and is dropped with its whole subtree, so the work follows the number of feasible nodes (like the
+        reference's tree walk, mitree.py:22-64), not 2^n_bin, and every batch respects MILP_BATCH_BYTES."""
+        A_aug, b_aug, m, n, bins = self._milp_blocks(A, b, bin_vars)
+        nb = len(bins)
+        sf = self._set_flags([list(equality_constraints or [])], m)
+        table = numpy.zeros(1 << nb, dtype=bool)
+        depth = min(nb, self.MILP_DIRECT_BINARIES)
+        prefixes = numpy.arange(1 << depth, dtype=numpy.int64)          # values of the first `depth` binaries
+        while True:
+            fix = numpy.full((len(prefixes), nb), -1, dtype=numpy.int8)
+            if depth:
+                fix[:, :depth] = (prefixes[:, None] >> numpy.arange(depth - 1, -1, -1, dtype=numpy.int64)[None, :]) & 1
+            st, _, _ = self._fixation_lps(A_aug, b_aug, m, nb, sf, numpy.zeros(len(prefixes), dtype=numpy.int64), fix)
+            prefixes = prefixes[st == _lib.LP_OPTIMAL]
+            if depth == nb or len(prefixes) == 0:
+                break
+            prefixes = numpy.stack([prefixes << 1, (prefixes << 1) | 1], axis=1).reshape(-1)
+            depth += 1
+        table[prefixes] = True
+        return table
+
+    def milp_any_feasible(self, A, b, equality_sets: List[Sequence[int]], bin_vars: Sequence[int],
+                          leaves: Optional[numpy.ndarray] = None) -> numpy.ndarray:
+        """bool[n_sets]: is the mixed-integer system feasible with that set of rows as equalities -- i.e. does some
+        fixation among ``leaves`` (indices into ``binary_fixations``; all by default) give a feasible LP.  The (set, leaf)
+        pairs go to the device in batches bounded by MILP_BATCH_BYTES, leaf-major, and a set leaves the work list as
+        soon as one of its LPs is feasible."""
+        A_aug, b_aug, m, n, bins = self._milp_blocks(A, b, bin_vars)
+        nb, n_sets = len(bins), len(equality_sets)
+        sf = self._set_flags(equality_sets, m)
+        leaves = numpy.arange(1 << nb, dtype=numpy.int64) if leaves is None else numpy.asarray(leaves, dtype=numpy.int64)
+        found = numpy.zeros(n_sets, dtype=bool)
+        per_item = (m + 2 * nb) + 16
+        budget_items = max(1, int(self.MILP_BATCH_BYTES // per_item))
+        shifts = numpy.arange(nb - 1, -1, -1, dtype=numpy.int64)[None, :]
+        pos = 0
+        while pos < len(leaves) and not found.all():
+            open_sets = numpy.flatnonzero(~found)
+            n_leaves = max(1, min(len(leaves) - pos, budget_items // len(open_sets)))
+            lv = leaves[pos:pos + n_leaves]
+            pos += n_leaves
+            fix_l = ((lv[:, None] >> shifts) & 1).astype(numpy.int8) if nb else numpy.zeros((len(lv), 0), dtype=numpy.int8)
+            set_idx = numpy.repeat(open_sets, len(lv))
+            fix = numpy.tile(fix_l, (len(open_sets), 1))
+            st, _, _ = self._fixation_lps(A_aug, b_aug, m, nb, sf, set_idx, fix)
+            ok = (st == _lib.LP_OPTIMAL).reshape(len(open_sets), len(lv)).any(axis=1)
+            found[open_sets[ok]] = True
+        return found
+
+    def solve_milp_batch(self, c, A, b, equality_sets: List[Sequence[int]], bin_vars: Sequence[int], want_x: bool = True):
+        """For every equality set, the LP of every binary fixation: returns (status, x, obj) shaped
+        [n_sets, 2^n_bin(, n)] -- status == 0 where that fixation's LP has an optimal solution; ``x`` is None with
+        ``want_x=False``.  Dense in (set, fixation): meant for few binaries; ``milp_leaf_feasibility``,
+        ``milp_any_feasible`` and ``solve_milp`` answer the questions of the mixed-integer programs within a bounded
+        footprint.  The device batches themselves respect MILP_BATCH_BYTES."""
+        A_aug, b_aug, m, n, bins = self._milp_blocks(A, b, bin_vars)
+        nb, n_sets = len(bins), len(equality_sets)
+        n_fix = 1 << nb
+        dense = n_sets * n_fix * (8 * n if want_x else 12)
+        if dense > 16 * self.MILP_BATCH_BYTES:
+            raise MemoryError(f'solve_milp_batch: {n_sets} sets x {n_fix} fixations is {dense >> 20} MiB of results; '
+                              'use milp_leaf_feasibility / milp_any_feasible / solve_milp')
+        fix = self.binary_fixations(nb)
+        sf = self._set_flags(equality_sets, m)
         cc = None if c is None else numpy.ascontiguousarray(c, dtype=numpy.float64).reshape(-1)
-        status, x, obj, _ = _lib.lp_solve_batch(A_aug, b_aug, cc, flags.reshape(n_sets * n_fix, -1),
-                                                device=self.device)
-        x = x.reshape(n_sets, n_fix, n)
-        x[:, :, bins] = fix[None]
+        status, obj, x = self._fixation_lps(A_aug, b_aug, m, nb, sf, numpy.repeat(numpy.arange(n_sets), n_fix),
+                                            numpy.tile(fix, (n_sets, 1)), cc, want_x)
+        if want_x:
+            x = x.reshape(n_sets, n_fix, n)
+            x[:, :, bins] = fix[None]
         return status.reshape(n_sets, n_fix), x, obj.reshape(n_sets, n_fix)
 
     def solve_milp(self, c: Optional[numpy.ndarray], A: Optional[numpy.ndarray], b: Optional[numpy.ndarray],
                    equality_constraints: Optional[Sequence[int]] = None, bin_vars: Optional[Sequence[int]] = None,
                    verbose: bool = False, get_duals: bool = True) -> Optional[SolverOutput]:
         """min c'[x,y] s.t. A[x,y] <= b, rows ``equality_constraints`` as equalities, y binary, x free.  ``None``
-        unless some fixation has an optimal LP; the best objective wins, the first fixation on ties."""
+        unless some fixation has an optimal LP; the best objective wins, the first fixation on ties.  Only the
+        feasible leaves (``milp_leaf_feasibility``) are posed with the objective, in bounded batches; one more LP
+        returns the minimiser of the winner."""
         if A is None or A.shape[0] == 0 or A.shape[1] == 0:
             return None
-        status, x, obj = self.solve_milp_batch(c, A, b, [list(equality_constraints or [])], bin_vars)
-        ok = status[0] == _lib.LP_OPTIMAL
-        if not ok.any():
+        eq = list(equality_constraints or [])
+        leaves = numpy.flatnonzero(self.milp_leaf_feasibility(A, b, eq, bin_vars))
+        if len(leaves) == 0:
             return None
-        best = int(numpy.argmin(numpy.where(ok, obj[0], numpy.inf)))
-        sol = x[0, best].copy()
+        A_aug, b_aug, m, n, bins = self._milp_blocks(A, b, bin_vars)
+        nb = len(bins)
+        sf = self._set_flags([eq], m)
+        cc = None if c is None else numpy.ascontiguousarray(c, dtype=numpy.float64).reshape(-1)
+        shifts = numpy.arange(nb - 1, -1, -1, dtype=numpy.int64)[None, :]
+        fix = ((leaves[:, None] >> shifts) & 1).astype(numpy.int8)
+        status, obj, _ = self._fixation_lps(A_aug, b_aug, m, nb, sf, numpy.zeros(len(leaves), dtype=numpy.int64), fix, cc)
+        ok = status == _lib.LP_OPTIMAL
+        if not ok.any():
+            return None      # every feasible leaf is unbounded below
+        best = int(numpy.argmin(numpy.where(ok, obj, numpy.inf)))
+        _, _, x = self._fixation_lps(A_aug, b_aug, m, nb, sf, numpy.zeros(1, dtype=numpy.int64), fix[best:best + 1], cc, True)
+        sol = x[0].copy()
+        sol[bins] = fix[best]
         bb = numpy.asarray(b, dtype=numpy.float64).reshape(-1)
         slack = bb - numpy.asarray(A, dtype=numpy.float64) @ sol
-        return SolverOutput(float(obj[0, best]), sol, slack, numpy.nonzero(numpy.abs(slack) <= 1e-10)[0], None)
+        return SolverOutput(float(obj[best]), sol, slack, numpy.nonzero(numpy.abs(slack) <= 1e-10)[0], None)

@@ -1,7 +1,8 @@
 """PointLocation: the compiled point-location object of the reference (upop/point_location.py:10-120), backed by the
 MI355X locator (csrc/locate.hpp, ``mpc_locator_*``) instead of numba on the host.
 
-Same semantics: a point is inside a region when ``E theta <= f`` holds exactly (no tolerance, :46,:59); without overlaps
+Same semantics: a point is inside a region when ``E theta <= f`` holds (inclusive, no tolerance, :46,:59 -- a point on a
+facet, a vertex of the parameter box or theta = 0 on a ``-theta <= 0`` row belongs to the region); without overlaps
 the first region in list order wins, with overlaps the containing region with the lowest objective (ties to the later
 one, :72-78).  ``locate`` / ``evaluate`` / ``is_inside`` take one column vector like the reference; ``locate_batch`` /
 ``evaluate_batch`` take [m, n_theta] arrays and are what the device is for.
@@ -17,7 +18,7 @@ class PointLocation:
     def __init__(self, solution: Solution, device: int = 0):
         self.solution = solution
         self.num_regions = len(solution.critical_regions)
-        # a shallow twin with zero tolerance so that the locator applies E theta <= f as posed
+        # a shallow twin with zero tolerance, queried in the locator's inclusive mode: E theta <= f as posed
         self._exact = Solution(solution.program, solution.critical_regions, solution.is_overlapping, 0.0)
         self._device = device
         self._loc = self._exact.locator(device) if self.num_regions else None
@@ -27,12 +28,12 @@ class PointLocation:
         thetas = numpy.ascontiguousarray(thetas, dtype=numpy.float64).reshape(-1, self.solution.program.num_t())
         if self._loc is None:
             return numpy.full(len(thetas), -1, dtype=numpy.int64)
-        return self._exact.get_region_batch(thetas, self._device)
+        return self._exact.get_region_batch(thetas, self._device, inclusive=True)
 
     def evaluate_batch(self, thetas: numpy.ndarray):
         """(x* [m, n_x] with NaN rows where no region contains the point, region index [m])."""
         thetas = numpy.ascontiguousarray(thetas, dtype=numpy.float64).reshape(-1, self.solution.program.num_t())
-        return self._exact.evaluate_batch(thetas, self._device)
+        return self._exact.evaluate_batch(thetas, self._device, inclusive=True)
 
     def locate(self, theta: numpy.ndarray) -> int:
         return int(self.locate_batch(numpy.asarray(theta, dtype=numpy.float64).reshape(1, -1))[0])

@@ -259,6 +259,68 @@ def test_upop_point_location_object():
     assert pl.evaluate(numpy.array([[-500.0], [-500.0]])) is None and not pl.is_inside(numpy.array([[-500.0], [-500.0]]))
 
 
+def test_upop_point_location_boundary_points_are_inside():
+    """`A @ theta <= b` of the reference's PointLocation (upop/point_location.py:46,59) is inclusive: points exactly on a
+    facet, on a vertex of the parameter box and theta = 0 on a `-theta <= 0` row are located (the locator's strict
+    `E theta - f < tol` with tol = 0 would report -1 for all of them), and Solution.get_region keeps the strict test."""
+    from ppopt_amd import MPQP_Program
+    from ppopt_amd.mp_solvers.solve_mpqp import mpqp_algorithm, solve_mpqp
+    from ppopt_amd.problem_generator import transport_mpqp_data
+    from ppopt_amd.upop import PointLocation
+    d = transport_mpqp_data()
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        prog = MPQP_Program(d['A'], d['b'], d['c'], d['H'], d['Q'], d['A_t'], d['b_t'], d['F'])
+    sol = solve_mpqp(prog, mpqp_algorithm.combinatorial)
+    pl = PointLocation(sol)
+
+    def host(theta):   # the reference's get_region_no_overlap, on the host
+        for j, r in enumerate(sol.critical_regions):
+            if numpy.all(r.E @ theta.reshape(-1, 1) <= r.f):
+                return j
+        return -1
+
+    # the vertices of the parameter box {A_t theta <= b_t} that the program leaves feasible, and theta = 0
+    pts = [numpy.zeros(2)]
+    At, bt = prog.A_t, prog.b_t.ravel()
+    for i in range(len(bt)):
+        for j in range(i + 1, len(bt)):
+            M = At[[i, j]]
+            if abs(numpy.linalg.det(M)) > 1e-9:
+                v = numpy.linalg.solve(M, bt[[i, j]])
+                if numpy.all(At @ v <= bt + 1e-9):
+                    pts.append(v)
+    # points exactly on a facet: a vertex of a region (two of its rows tight), axis-aligned rows give exact arithmetic
+    for r in sol.critical_regions:
+        E, f = numpy.asarray(r.E), numpy.asarray(r.f).ravel()
+        for i in range(len(f)):
+            nz = numpy.flatnonzero(numpy.abs(E[i]) > 1e-12)
+            if len(nz) == 1:                   # axis-aligned facet  e * theta_t <= f
+                t = nz[0]
+                base = numpy.array([200.0, 200.0])
+                base[t] = f[i] / E[i, t]
+                pts.append(base)
+    pts = numpy.array(pts)
+    got = pl.locate_batch(pts)
+    want = numpy.array([host(p) for p in pts])
+    assert numpy.array_equal(got, want), (got, want)
+    assert (want >= 0).sum() >= 3                                     # the boundary points really are inside something
+    strict = pl._exact.get_region_batch(pts)                          # same tolerance 0, strict test
+    assert (strict[want >= 0] == -1).any()                            # ... and the strict test would have lost some
+    # single-point API on the box vertex theta = 0 (row -theta <= 0 tight)
+    assert pl.is_inside(numpy.zeros((2, 1))) == (host(numpy.zeros(2)) >= 0)
+    assert pl.locate(numpy.zeros((2, 1))) == host(numpy.zeros(2))
+    x0 = pl.evaluate(numpy.zeros((2, 1)))
+    if host(numpy.zeros(2)) >= 0:
+        assert numpy.allclose(x0, sol.critical_regions[host(numpy.zeros(2))].evaluate(numpy.zeros((2, 1))))
+    # Solution.get_region stays strict with its own tolerance (solution.py:60-112, critical_region.py:83-86)
+    th = pts[:8]
+    idx = sol.get_region_batch(th)
+    for p, i in zip(th, idx):
+        cr = sol.get_region(p.reshape(-1, 1))
+        assert (cr is None and i == -1) or sol.critical_regions[int(i)] is cr
+
+
 def test_program_generators_return_solvable_programs():
     """generate_mpqp / generate_mplp as in the reference's problem_generator.py (tests/other_tests/test_problem_generator.py)."""
     from ppopt_amd import MPLP_Program, MPQP_Program
@@ -360,3 +422,71 @@ def test_regions_cover_exactly_the_feasible_parameters(shape):
     assert inner.sum() > 100
     assert numpy.all(located[inner]), 'a feasible parameter point lies in no region'
     assert not numpy.any(located[~outer]), 'a region contains an infeasible parameter point'
+
+
+def test_failed_create_does_not_leak_device_memory():
+    """mpc_create that fails after its first allocations (a program whose tableau exceeds the 160 KiB LDS) gives every
+    block, stream and event back: repeating it does not consume device memory."""
+    import torch
+    from ppopt_amd import _lib
+    rng = numpy.random.default_rng(0)
+    nx, nt, nc, ntc = 200, 8, 128, 16
+    A, b, F = rng.standard_normal((nc, nx)), numpy.ones(nc), rng.standard_normal((nc, nt))
+    At = numpy.vstack([numpy.eye(nt), -numpy.eye(nt)])
+    args = (A, b, F, numpy.zeros(nx), numpy.zeros((nx, nt)), numpy.eye(nx), At, numpy.ones(ntc), 0)
+
+    def attempt():
+        with pytest.raises(_lib.MpcError, match='LDS'):
+            _lib.Engine(*args)
+
+    for _ in range(3):
+        attempt()                                  # fills the recycling pools
+    free0, _ = torch.cuda.mem_get_info(0)
+    for _ in range(40):
+        attempt()
+    free1, _ = torch.cuda.mem_get_info(0)
+    assert free0 - free1 <= (8 << 20), (free0, free1)
+
+
+def test_solver_device_is_the_device_of_the_solve():
+    """Solver(device=d): presolve LPs, the engine and solve_mpqp all use device d (here d = 0 explicitly, and an
+    out-of-range device fails loudly instead of silently landing on GPU 0)."""
+    from ppopt_amd import MPQP_Program, Solver, _lib
+    from ppopt_amd.mp_solvers.solve_mpqp import mpqp_algorithm, solve_mpqp
+    from ppopt_amd.problem_generator import transport_mpqp_data
+    d = transport_mpqp_data()
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        prog = MPQP_Program(d['A'], d['b'], d['c'], d['H'], d['Q'], d['A_t'], d['b_t'], d['F'], solver=Solver(device=0))
+    sol = solve_mpqp(prog, mpqp_algorithm.combinatorial)
+    assert len(sol.critical_regions) == 4 and prog.engine().device == 0
+    n_dev = _lib.load().mpc_device_count()
+    prog.solver = Solver(device=n_dev)             # one past the last device
+    prog.release_engine()
+    with pytest.raises(_lib.MpcError):
+        solve_mpqp(prog, mpqp_algorithm.combinatorial)
+
+
+def test_many_binaries_stay_within_the_batch_budget():
+    """14 binaries under a cardinality constraint: the leaf table is built level by level with relaxation pruning (470
+    feasible leaves of 16,384), presolve and solve_theta run in batches bounded by MILP_BATCH_BYTES."""
+    from ppopt_amd import Solver
+    nb = 14
+    n = 1 + nb
+    A = numpy.zeros((3, n))
+    A[0, 1:] = 1.0
+    A[1, 0] = 1.0
+    A[1, 1:] = -(0.5 ** numpy.arange(nb))
+    A[2, 0] = -1.0
+    b = numpy.array([3.0, 0.0, 0.0])
+    S = Solver()
+    S.MILP_BATCH_BYTES = 64 << 10
+    table = S.milp_leaf_feasibility(A, b, [], list(range(1, n)))
+    ones = numpy.array([bin(i).count('1') for i in range(1 << nb)])
+    assert numpy.array_equal(table, ones <= 3) and int(table.sum()) == 470
+    got = S.milp_any_feasible(A, b, [[0], [1], [2], [0, 2]], list(range(1, n)), numpy.flatnonzero(table))
+    assert got.tolist() == [True, True, True, True]
+    c = numpy.zeros(n)
+    c[0] = -1.0
+    out = S.solve_milp(c, A, b, [], list(range(1, n)))
+    assert abs(out.obj + 1.75) <= 1e-9 and out.sol[1:].tolist() == [1, 1, 1] + [0] * (nb - 3)

@@ -104,3 +104,96 @@ def test_mitree_from_leaf_table():
         tree = MITree(Fake(nb, g['combos'].tolist()))
         assert tree.count_nodes() == int(g['n_nodes']), path
         assert [leaf.fixed_bins for leaf in tree.get_full_leafs()] == g['combos'].tolist(), path
+
+
+# ---- bounded-footprint MILP batches (Solver.milp_leaf_feasibility / milp_any_feasible / solve_milp) ------------------------
+def _scipy_lp_batch(counter):
+    """Stand-in for the device LP batch (ppopt_amd._lib.lp_solve_batch) so that the HOST logic -- chunking, relaxation
+    pruning, early exit per row -- is testable without a GPU.  Checker only; the product path has no CPU solver."""
+    from scipy.optimize import linprog
+
+    def lp_solve_batch(A, b, c, eq_flags, device=0, want_x=True):
+        n_lp, m = eq_flags.shape
+        n = A.shape[1]
+        counter['lps'] += n_lp
+        counter['max_flag_bytes'] = max(counter['max_flag_bytes'], eq_flags.nbytes)
+        status = numpy.zeros(n_lp, dtype=numpy.int32)
+        x = numpy.zeros((n_lp, n)) if want_x else None
+        obj = numpy.zeros(n_lp)
+        for i in range(n_lp):
+            eq = eq_flags[i].astype(bool)
+            res = linprog(numpy.zeros(n) if c is None else c, A_ub=A[~eq], b_ub=b[~eq], A_eq=A[eq] if eq.any() else None,
+                          b_eq=b[eq] if eq.any() else None, bounds=(None, None), method='highs-ds')
+            status[i] = 0 if res.status == 0 else (2 if res.status == 3 else 1)
+            if res.status == 0:
+                obj[i] = res.fun
+                if want_x:
+                    x[i] = res.x
+        return status, x, obj, numpy.zeros(n_lp, dtype=numpy.int32)
+    return lp_solve_batch
+
+
+def _cardinality_milp(nb, max_ones):
+    """x in R^1, y in {0,1}^nb:  sum(y) <= max_ones,  x <= sum_j 2^-j y_j,  -x <= 0   (every leaf with few ones is feasible)."""
+    n = 1 + nb
+    A = numpy.zeros((3, n))
+    A[0, 1:] = 1.0
+    A[1, 0] = 1.0
+    A[1, 1:] = -(0.5 ** numpy.arange(nb))
+    A[2, 0] = -1.0
+    b = numpy.array([float(max_ones), 0.0, 0.0])
+    return A, b, list(range(1, n))
+
+
+def test_milp_leaf_feasibility_prunes_through_relaxations(monkeypatch):
+    from ppopt_amd import solver as solver_mod
+    counter = {'lps': 0, 'max_flag_bytes': 0}
+    monkeypatch.setattr(solver_mod._lib, 'lp_solve_batch', _scipy_lp_batch(counter))
+    nb = 9
+    A, b, bins = _cardinality_milp(nb, 2)
+    S = Solver()
+    S.MILP_DIRECT_BINARIES = 3          # walk the tree from depth 3 on
+    S.MILP_BATCH_BYTES = 2048           # and force many small device batches
+    table = S.milp_leaf_feasibility(A, b, [], bins)
+    ones = numpy.array([bin(i).count('1') for i in range(1 << nb)])
+    assert numpy.array_equal(table, ones <= 2)
+    assert counter['lps'] < (1 << nb)                   # fewer LPs than leaves: whole subtrees were never posed
+    assert counter['max_flag_bytes'] <= 2048
+    # the direct form (few binaries) gives the same table
+    S2 = Solver()
+    assert numpy.array_equal(S2.milp_leaf_feasibility(A, b, [], bins), table)
+
+
+def test_milp_any_feasible_and_solve_milp_with_bounded_batches(monkeypatch):
+    from ppopt_amd import solver as solver_mod
+    counter = {'lps': 0, 'max_flag_bytes': 0}
+    monkeypatch.setattr(solver_mod._lib, 'lp_solve_batch', _scipy_lp_batch(counter))
+    nb = 5
+    A, b, bins = _cardinality_milp(nb, 2)
+    S = Solver()
+    S.MILP_BATCH_BYTES = 512
+    leaves = numpy.flatnonzero(S.milp_leaf_feasibility(A, b, [], bins))
+    # row 0 tight: sum(y) == 2 has leaves; row 1 tight: x == sum 2^-j y_j fine; row 2 tight: x == 0 fine; rows {0} with max_ones
+    got = S.milp_any_feasible(A, b, [[0], [1], [2], [1, 2]], bins, leaves)
+    assert got.tolist() == [True, True, True, True]
+    A2 = numpy.vstack([A, [[1.0] + [0.0] * nb]])          # x <= -1 can never hold as an equality (x >= 0)
+    b2 = numpy.concatenate([b, [-1.0]])
+    assert S.milp_any_feasible(A2, b2, [[3], [0]], bins).tolist() == [False, False]   # the system itself is infeasible
+    b2[-1] = 5.0                                          # x <= 5: never tight (x <= sum 2^-j y_j < 2)
+    lv2 = numpy.flatnonzero(S.milp_leaf_feasibility(A2, b2, [], bins))
+    assert S.milp_any_feasible(A2, b2, [[3], [0]], bins, lv2).tolist() == [False, True]
+    assert counter['max_flag_bytes'] <= 512
+    # solve_milp: min -x -> x = largest sum of two weights = 1 + 1/2, y = (1, 1, 0, 0, 0); first fixation wins ties
+    c = numpy.zeros(1 + nb)
+    c[0] = -1.0
+    out = S.solve_milp(c, A, b, [], bins)
+    assert abs(out.obj + 1.5) <= 1e-9 and out.sol[1:].tolist() == [1, 1, 0, 0, 0] and abs(out.sol[0] - 1.5) <= 1e-9
+    assert S.solve_milp(c, A2, numpy.concatenate([b, [-1.0]]), [], bins) is None
+    # dense form agrees on status, and refuses outputs beyond its footprint instead of exhausting the host
+    st, x, obj = S.solve_milp_batch(None, A, b, [[], [0]], bins)
+    ones = numpy.array([bin(i).count('1') for i in range(1 << nb)])
+    assert numpy.array_equal(st[0] == 0, ones <= 2) and numpy.array_equal(st[1] == 0, ones == 2)
+    assert x.shape == (2, 1 << nb, 1 + nb) and numpy.array_equal(x[0][:, 1:], Solver.binary_fixations(nb))
+    S.MILP_BATCH_BYTES = 16
+    with pytest.raises(MemoryError):
+        S.solve_milp_batch(None, A, b, [[]] * 64, bins)
