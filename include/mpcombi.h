@@ -93,6 +93,7 @@ typedef struct {
     int64_t dict_read_bytes;   /* bytes of one cached dictionary record as k_x2 reads it (0: no cache on this level)   */
     int64_t dict_write_bytes;  /* bytes of one record as k_x2 stores it for the next level (0: nothing stored)         */
     int64_t n_theta_items;     /* candidates k_theta2 processed (those the thread kernel's screen left open)             */
+    int64_t n_region_rows;     /* rows [f | E] the region kernel appended to the row pool (streamed levels: rows of erows in use) */
 } mpc_level_stats;
 
 /* ---- library / device ------------------------------------------------------------------------------ */
@@ -136,6 +137,31 @@ int mpc_pruned_get(mpc_handle *h, uint64_t *masks_host, int64_t cap);
  * reference's worker semantics (workers hold the murder_list of the previous levels, driver :110-131). */
 int mpc_level_run(mpc_handle *h, int32_t gen_children, mpc_level_stats *stats);
 int mpc_level_status(mpc_handle *h, uint8_t *status_host);                       /* n bytes, frontier order */
+/* The same level driven by the handle's worker thread: mpc_level_start returns at once, mpc_level_wait joins it and returns
+ * what mpc_level_run would have returned.  Between the two only mpc_level_stream_info / mpc_level_chunk_wait may be called
+ * on the handle.  (Reference: the parent process is free while pool.map runs, driver :116, and merges results as they come.)
+ * flags & MPC_LEVEL_STREAM: the region records of the level are STREAMED to the host while the region kernel runs -- the
+ * kernel writes head_d / head_i / erows (layout of mpc_level_regions_slots, one slot per optimal candidate) straight into
+ * page-locked host memory and raises one flag per chunk of slots, so the caller builds its region objects chunk by chunk
+ * under the kernel instead of fetching everything afterwards.
+ *   mpc_level_stream_info  blocks until the region stage of the running level has been launched; hands over the three
+ *                          arrays (the CALLER owns them from then on: mpc_host_free), the number of slots, the row
+ *                          capacity of erows, the chunk size (slots) and the number of chunks.  n_slots == 0: this level
+ *                          does not stream (no optimal candidate, a shape outside the register-engine region kernel, or
+ *                          more than 1 GiB of records) -- fetch with mpc_level_regions_slots after mpc_level_wait.
+ *   mpc_level_chunk_wait   blocks until every slot of chunk j (slots j*chunk .. ) is complete in host memory.  head_d and
+ *                          erows of a chunk are complete with its flag as well.
+ *   mpc_level_stream_fixup after mpc_level_wait, when stats.n_region_retry > 0: fills the slots of the candidates that were
+ *                          re-solved by the LDS-engine kernel (their head_i[0] was MPC_STREAM_RETRY while streaming); rows
+ *                          are appended behind stats.n_region_rows, *n_rows = rows in use afterwards. */
+#define MPC_LEVEL_STREAM 1
+#define MPC_STREAM_RETRY 7
+int mpc_level_start(mpc_handle *h, int32_t gen_children, int32_t flags);
+int mpc_level_stream_info(mpc_handle *h, double **head_d, int32_t **head_i, double **erows, int64_t *n_slots, int64_t *cap_rows,
+                          int32_t *chunk, int32_t *n_chunks);
+int mpc_level_chunk_wait(mpc_handle *h, int32_t j);
+int mpc_level_wait(mpc_handle *h, mpc_level_stats *stats);
+int mpc_level_stream_fixup(mpc_handle *h, double *head_d, int32_t *head_i, double *erows, int64_t *n_rows);
 /* Region records of this level in frontier order.  cand_index[i] = position of region i's candidate.
  *   rec_d (mpc_region_doubles each): A_x[n_x*n_t] b_x[n_x] A_l[n_c*n_t] b_l[n_c] E[(n_c+n_tc)*n_t] f[n_c+n_tc]
  *   rec_i (mpc_region_ints each):    k n_E n_omega n_lambda n_regular | active[n_c] | omega[n_tc] | lambda[n_c]

@@ -15,6 +15,7 @@ LIB_PATH = os.environ.get('MPC_LIB_PATH') or os.path.join(_HERE, 'csrc', 'libmpc
 
 MPC_OK, MPC_ERR_INVALID, MPC_ERR_HIP, MPC_ERR_CAPACITY, MPC_ERR_STATE = range(5)
 MPC_LOCATE_OVERLAPPING, MPC_LOCATE_INCLUSIVE = 1, 2   # flags of mpc_locator_query
+MPC_LEVEL_STREAM = 1                                   # flag of mpc_level_start
 INFEASIBLE, FEASIBLE, OPTIMAL_NO_REGION, REGION, SINGULAR_KKT, LP_LIMIT = range(6)
 LP_OPTIMAL, LP_INFEASIBLE, LP_UNBOUNDED, LP_ITERLIMIT = range(4)
 MASK_WORDS = 2
@@ -46,7 +47,7 @@ class LevelStats(ctypes.Structure):
                 ('n_x_cached', ctypes.c_int64), ('ms_theta', ctypes.c_float), ('ms_x', ctypes.c_float),
                 ('ms_region2', ctypes.c_float), ('pad_', ctypes.c_float), ('n_x_items', ctypes.c_int64),
                 ('n_opt', ctypes.c_int64), ('dict_read_bytes', ctypes.c_int64), ('dict_write_bytes', ctypes.c_int64),
-                ('n_theta_items', ctypes.c_int64)]
+                ('n_theta_items', ctypes.c_int64), ('n_region_rows', ctypes.c_int64)]
 
 
 _lib = None
@@ -85,6 +86,12 @@ def load():
         'mpc_pruned_get': (ctypes.c_int, [H, _u64p, ctypes.c_int64]),
         'mpc_level_run': (ctypes.c_int, [H, ctypes.c_int32, ctypes.POINTER(LevelStats)]),
         'mpc_level_status': (ctypes.c_int, [H, _u8p]),
+        'mpc_level_start': (ctypes.c_int, [H, ctypes.c_int32, ctypes.c_int32]),
+        'mpc_level_stream_info': (ctypes.c_int, [H, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_void_p),
+                                                 ctypes.POINTER(ctypes.c_void_p), _lp, _lp, _ip, _ip]),
+        'mpc_level_chunk_wait': (ctypes.c_int, [H, ctypes.c_int32]),
+        'mpc_level_wait': (ctypes.c_int, [H, ctypes.POINTER(LevelStats)]),
+        'mpc_level_stream_fixup': (ctypes.c_int, [H, _dp, _ip, _dp, _lp]),
         'mpc_level_regions': (ctypes.c_int, [H, _dp, _ip, _lp, ctypes.c_int64]),
         'mpc_compact_strides': (ctypes.c_int, [H, _lp, _lp, _lp]),
         'mpc_level_regions_compact': (ctypes.c_int, [H, _dp, _ip, ctypes.c_int64, _dp, ctypes.c_int64, _lp, _lp]),
@@ -125,7 +132,7 @@ EXPORTED_SYMBOLS = ['mpc_device_count', 'mpc_version', 'mpc_last_global_error', 
                     'mpc_last_error', 'mpc_region_doubles', 'mpc_region_ints', 'mpc_lds_bytes', 'mpc_stream',
                     'mpc_frontier_root', 'mpc_frontier_set', 'mpc_frontier_set_device', 'mpc_frontier_info',
                     'mpc_frontier_get', 'mpc_pruned_clear', 'mpc_pruned_add', 'mpc_pruned_add_device',
-                    'mpc_pruned_count', 'mpc_pruned_get', 'mpc_level_run', 'mpc_level_status', 'mpc_level_regions', 'mpc_compact_strides',
+                    'mpc_pruned_count', 'mpc_pruned_get', 'mpc_level_run', 'mpc_level_status', 'mpc_level_start', 'mpc_level_stream_info', 'mpc_level_chunk_wait', 'mpc_level_wait', 'mpc_level_stream_fixup', 'mpc_level_regions', 'mpc_compact_strides',
                     'mpc_level_regions_compact', 'mpc_frontier_shard', 'mpc_level_slots', 'mpc_level_regions_slots', 'mpc_level_regions_slots_async', 'mpc_sync', 'mpc_host_alloc', 'mpc_host_free', 'mpc_locator_create', 'mpc_locator_query', 'mpc_locator_destroy', 'mpc_level_children', 'mpc_level_children_device', 'mpc_level_pruned_new',
                     'mpc_level_pruned_new_device', 'mpc_level_regions_device', 'mpc_frontier_advance', 'mpc_check_level', 'mpc_lp_solve_batch']
 
@@ -142,6 +149,18 @@ def pinned_empty(shape, dtype) -> numpy.ndarray:
         raise MemoryError(f'mpc_host_alloc({nbytes}) failed')
     buf = (ctypes.c_char * nbytes).from_address(ptr.value)
     weakref.finalize(buf, L.mpc_host_free, ctypes.c_void_p(ptr.value))
+    return numpy.frombuffer(buf, dtype=dtype, count=count).reshape(shape)
+
+
+def pinned_adopt(ptr: int, shape, dtype) -> numpy.ndarray:
+    """An array over a page-locked block the library has handed over (mpc_level_stream_info): same ownership rule as
+    pinned_empty -- the block returns to the pool with the last view."""
+    L = load()
+    dtype = numpy.dtype(dtype)
+    count = int(numpy.prod(shape))
+    nbytes = max(count * dtype.itemsize, 1)
+    buf = (ctypes.c_char * nbytes).from_address(ptr)
+    weakref.finalize(buf, L.mpc_host_free, ctypes.c_void_p(ptr))
     return numpy.frombuffer(buf, dtype=dtype, count=count).reshape(shape)
 
 
@@ -280,6 +299,42 @@ class Engine:
         self._check(self._L.mpc_level_run(self._h, int(bool(gen_children)), ctypes.byref(st)), 'mpc_level_run')
         self._last = st
         return st
+
+    # -- the same level on the handle's worker thread, region records streamed to the host (include/mpcombi.h) ----------
+    def level_start(self, gen_children: bool, stream: bool = True):
+        self._check(self._L.mpc_level_start(self._h, int(bool(gen_children)), MPC_LEVEL_STREAM if stream else 0), 'mpc_level_start')
+
+    def level_stream_info(self):
+        """Blocks until the running level's region stage has been launched.  None when the level does not stream, else
+        (head_d [S, fd], head_i [S, fi], erows [cap_rows, n_t+1], chunk, n_chunks) -- arrays the region kernel is writing;
+        chunk j (slots j*chunk ...) may be read after ``level_chunk_wait(j)``."""
+        hd, hi, er = ctypes.c_void_p(), ctypes.c_void_p(), ctypes.c_void_p()
+        ns, cr, ch, nch = ctypes.c_int64(0), ctypes.c_int64(0), ctypes.c_int32(0), ctypes.c_int32(0)
+        self._check(self._L.mpc_level_stream_info(self._h, ctypes.byref(hd), ctypes.byref(hi), ctypes.byref(er), ctypes.byref(ns),
+                                                  ctypes.byref(cr), ctypes.byref(ch), ctypes.byref(nch)), 'mpc_level_stream_info')
+        if ns.value == 0:
+            return None
+        n, k = self.frontier_info()
+        fd = self.n_x * self.n_t + self.n_x + k * self.n_t + k
+        fi = 8 + k + self.n_tc + k + 2 * (self.n_c - k)
+        return (pinned_adopt(hd.value, (ns.value, fd), numpy.float64), pinned_adopt(hi.value, (ns.value, fi), numpy.int32),
+                pinned_adopt(er.value, (max(cr.value, 1), self.n_t + 1), numpy.float64), int(ch.value), int(nch.value))
+
+    def level_chunk_wait(self, j: int):
+        self._check(self._L.mpc_level_chunk_wait(self._h, int(j)), 'mpc_level_chunk_wait')
+
+    def level_wait(self) -> LevelStats:
+        st = LevelStats()
+        self._check(self._L.mpc_level_wait(self._h, ctypes.byref(st)), 'mpc_level_wait')
+        self._last = st
+        return st
+
+    def level_stream_fixup(self, hd, hi, er) -> int:
+        """Fills the slots of candidates the LDS-engine kernel re-solved (stats.n_region_retry > 0); returns the rows in use."""
+        nrows = ctypes.c_int64(0)
+        self._check(self._L.mpc_level_stream_fixup(self._h, hd.ctypes.data_as(_dp), hi.ctypes.data_as(_ip), er.ctypes.data_as(_dp),
+                                                   ctypes.byref(nrows)), 'mpc_level_stream_fixup')
+        return int(nrows.value)
 
     def level_status(self) -> numpy.ndarray:
         n, _ = self.frontier_info()

@@ -928,12 +928,24 @@ __global__ void __launch_bounds__(64, (NXC * SLOTS >= 32 ? X2_WAVES : 3)) k_x2(c
 // pool row: f, E[0..n_t)
 constexpr double BOX_REDUNDANT_MARGIN = 1e-6;   // unit-norm row units; ten times the LP feasibility tolerance
 
+// Streaming of the region records to the host WHILE the kernel runs (single-GPU solve loop).  head_d / head_i / epool then
+// point into page-locked host memory (zero-copy stores over PCIe, no device-to-host copy afterwards) and the slots are
+// grouped in chunks of 2^shift: the wavefront that completes the last slot of a chunk raises flags[chunk] in host memory,
+// after a system-scope release, so the host can build that chunk's region objects while later chunks are still computed.
+// count == nullptr: no streaming (records stay in device memory).
+struct RegionStream {
+    unsigned int *count;   // [n_chunks] slots completed per chunk (device memory, zeroed before the launch)
+    int32_t *flags;        // [n_chunks] host-mapped: 1 = every slot of the chunk is complete and visible to the host
+    int shift;             // log2(chunk size)
+    int n_slots;           // == n_opt
+};
+
 template <int NT, int SLOTS>
 __global__ void __launch_bounds__(64, (SLOTS >= 2 ? 2 : R2W)) k_region2(
     const DevProblem *__restrict__ Pg, const int32_t *__restrict__ cands, int k, const int32_t *__restrict__ opt_list, int n_opt,
     uint8_t *__restrict__ status, double *__restrict__ head_d, int32_t *__restrict__ head_i, int fd, int fi,
     double *__restrict__ epool, LevelCounters *__restrict__ ctr, const uint8_t *__restrict__ kkcode, const double *__restrict__ Lin,
-    int W, uint8_t *__restrict__ kept_g, int ldk, unsigned int *__restrict__ done_g, const double *__restrict__ box) {
+    int W, uint8_t *__restrict__ kept_g, int ldk, unsigned int *__restrict__ done_g, const double *__restrict__ box, RegionStream rs) {
     // W > 1 (few optimal candidates, idle CUs): W wavefronts share one candidate.  Each builds the same dictionary and runs
     // the same Chebyshev LP (deterministic, identical), then tests only the rows it owns (row % W == part).  The flags go
     // to kept_g; the wavefront that finishes last (done_g counter) merges them and writes the record.
@@ -1340,11 +1352,15 @@ __global__ void __launch_bounds__(64, (SLOTS >= 2 ? 2 : R2W)) k_region2(
                     if (kp[sl] && cls == 1) { const int p = base_re + __popcll(b1 & below); ridx[p] = i - nlam; rcon[p] = s.inact[i - nlam]; }
                     if (kp[sl] && cls == 2) om[base_om + __popcll(b2 & below)] = i - nlam - nin;
                     base_la += __popcll(b0); base_re += __popcll(b1); base_om += __popcll(b2);
-                    if (kp[sl] && !dup[sl]) {
-                        double *dst = epool + (size_t)(e_off + base_e + __popcll(bE[sl] & below)) * nr;
-                        for (int t = 0; t <= nt; ++t) dst[t] = s.E[i * ldE + t];
-                    }
+                    // the region's rows are one contiguous run of the pool: list the kept rows in order, then write the run with
+                    // consecutive lanes on consecutive doubles (coalesced; the pool may be host memory behind PCIe)
+                    if (kp[sl] && !dup[sl]) s.stored[base_e + __popcll(bE[sl] & below)] = i;
                     base_e += __popcll(bE[sl]);
+                }
+                wave_sync();
+                {
+                    double *dst = epool + (size_t)e_off * nr;
+                    for (int idx = lane; idx < nE * nr; idx += 64) { const int rr = idx / nr; dst[idx] = s.E[s.stored[rr] * ldE + (idx - rr * nr)]; }
                 }
                 n_la = base_la; n_re = base_re; n_om = base_om;
                 for (int idx = lane; idx < nx * nt; idx += 64) hd[idx] = s.X[(idx / nt) * nr + 1 + idx % nt];
@@ -1363,6 +1379,19 @@ __global__ void __launch_bounds__(64, (SLOTS >= 2 ? 2 : R2W)) k_region2(
         if (lane == 0 && is_last) {
             hi[0] = st; hi[1] = c; hi[2] = nE; hi[3] = n_om; hi[4] = n_la; hi[5] = n_re; hi[6] = e_off; hi[7] = reason;
             status[c] = (uint8_t)st;
+        }
+        if (rs.count && is_last) {
+            // every store of this slot's record is released to system scope before the slot is counted; the wavefront that
+            // completes the chunk tells the host (its flag store follows all counted slots' releases)
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+            if (lane == 0) {
+                const int ch = (int)(w >> rs.shift);
+                const unsigned int full = (unsigned int)min(1 << rs.shift, rs.n_slots - (ch << rs.shift));
+                if (atomicAdd(&rs.count[ch], 1u) + 1u == full) {
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "");
+                    __hip_atomic_store(&rs.flags[ch], 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+                }
+            }
         }
         cyc += clock64() - t0;
     }

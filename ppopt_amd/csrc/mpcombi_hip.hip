@@ -13,6 +13,9 @@
 #include <unordered_map>
 #include <map>
 #include <mutex>
+#include <condition_variable>
+#include <thread>
+#include <atomic>
 #include <cstring>
 #include <cstdlib>
 #include <string>
@@ -281,6 +284,24 @@ struct mpc_handle {
     // level results
     bool level_done = false;
     long long n_opt = 0, n_children = 0, n_pruned_new = 0, n_regions = 0;
+    // ---- region records streamed to the host while the region kernel runs (mpc_level_start with MPC_LEVEL_STREAM) ----
+    struct StreamOut {
+        void *hd = nullptr, *hi = nullptr, *er = nullptr;   // page-locked blocks the region kernel writes (zero-copy)
+        long long n_slots = 0, cap_rows = 0;
+        int shift = 8, n_chunks = 0;
+        bool active = false;    // this level's records are in these blocks, not in headd / headi / epool
+        bool taken = false;     // the caller owns the blocks (mpc_level_stream_info handed them over)
+    } so;
+    HostBuf st_flags;           // chunk flags (host memory the kernel writes)
+    DevBuf chunk_count;
+    // ---- worker thread behind mpc_level_start / mpc_level_wait ---------------------------------------------------------
+    std::thread worker;
+    std::mutex wm;
+    std::condition_variable wcv;
+    int w_req = 0;              // 0 idle, 1 run a level, 2 exit
+    bool w_busy = false, w_stream_ready = false;
+    int w_gen = 0, w_flags = 0, w_rc = 0;
+    mpc_level_stats w_stats{};
     hipEvent_t ev_hi = nullptr;   // completion of the head_i copy of an asynchronous slot fetch
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     hipEvent_t kev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // around k_theta2 / the main k_x2 launch / k_region2
@@ -384,6 +405,7 @@ void lu_solve_host(const std::vector<double> &LU, const std::vector<int> &perm, 
 }  // namespace
 
 static int create_fill(const mpc_problem *p, int32_t device, void *stream, mpc_handle *h);
+static void stream_release(mpc_handle *h);
 static int lp_batch_impl(int32_t device, int64_t n_lp, int32_t m, int32_t n, const double *A, int32_t shared_A, const double *b,
                          int32_t shared_b, const double *c, int32_t shared_c, const uint8_t *eq, int32_t *status, double *x,
                          double *obj, int32_t *iters, int32_t *tight);
@@ -752,6 +774,11 @@ extern "C" {
 
 int mpc_destroy(mpc_handle *h) {
     if (!h) return MPC_OK;
+    if (h->worker.joinable()) {
+        { std::unique_lock<std::mutex> lk(h->wm); h->wcv.wait(lk, [&] { return !h->w_busy; }); h->w_req = 2; }
+        h->wcv.notify_all();
+        h->worker.join();
+    }
     (void)hipSetDevice(h->device);
     (void)hipStreamSynchronize(h->stream);
     if (h->stream2) (void)hipStreamSynchronize(h->stream2);
@@ -759,7 +786,9 @@ int mpc_destroy(mpc_handle *h) {
                       &h->childmask, &h->count, &h->offset, &h->recd, &h->reci, &h->ctr, &h->scratch, &h->sums, &h->retry_list, &h->pf_dev, &h->pr2_dev, &h->headd, &h->headi, &h->epool, &h->facet_flags, &h->kkt_code, &h->kkt_L, &h->theta_blocks, &h->xq_groups, &h->theta_list, &h->vretry_list, &h->status_tmp, &h->part_counts, &h->part_lists, &h->kept_g, &h->done_g, &h->dict_d[0], &h->dict_d[1], &h->dict_i[0], &h->dict_i[1],
                       &h->dict_stored[0], &h->dict_stored[1], &h->parent_slot, &h->parent_slot_next}) b->release();
     if (h->tot_host) { (void)host_pool_give(h->tot_host); h->tot_host = h->tot_dev = nullptr; }
-    for (HostBuf *b : {&h->st_list, &h->st_status, &h->st_hd, &h->st_hi, &h->st_pool, &h->st_fxd, &h->st_fxi, &h->st_rlist}) b->release();
+    for (HostBuf *b : {&h->st_list, &h->st_status, &h->st_hd, &h->st_hi, &h->st_pool, &h->st_fxd, &h->st_fxi, &h->st_rlist, &h->st_flags}) b->release();
+    stream_release(h);
+    h->chunk_count.release();
     for (auto &e : h->ev) return_event(e, true);
     for (auto &e : h->kev) return_event(e, true);
     return_event(h->ev_hi, false);
@@ -935,9 +964,22 @@ static int launch_region_v1(mpc_handle *h, const int32_t *list, long long n_list
 }
 
 // ---- one level ------------------------------------------------------------------------------------------------
-int mpc_level_run(mpc_handle *h, int32_t gen_children, mpc_level_stats *stats) {
+// tells a caller blocked in mpc_level_stream_info that the region stage of the running level has been launched (or that
+// this level does not stream)
+static void stream_ready(mpc_handle *h) {
+    std::lock_guard<std::mutex> lk(h->wm);
+    h->w_stream_ready = true;
+    h->wcv.notify_all();
+}
+static void stream_release(mpc_handle *h) {   // blocks of a streamed level nobody took
+    if (!h->so.taken) { if (h->so.hd) (void)host_pool_give(h->so.hd); if (h->so.hi) (void)host_pool_give(h->so.hi); if (h->so.er) (void)host_pool_give(h->so.er); }
+    h->so = mpc_handle::StreamOut();
+}
+
+static int level_run_impl(mpc_handle *h, int32_t gen_children, int32_t flags, mpc_level_stats *stats) {
     if (!h) return MPC_ERR_INVALID;
     HIP_TRY(h, hipSetDevice(h->device));
+    stream_release(h);
     const long long n = h->n;
     const int k = h->k;
     hipStream_t st = h->stream;
@@ -1212,10 +1254,39 @@ int mpc_level_run(mpc_handle *h, int32_t gen_children, mpc_level_stats *stats) {
             }
             const dim3 g((unsigned)std::min<long long>((long long)n_opt * W, h->grid_r2)), b(64);
             const DevProblem *pr = h->pr2_dev.as<DevProblem>();
+            // where the records go: device buffers (fetched / gathered later), or -- streaming -- page-locked host blocks the
+            // kernel writes directly, in chunks the host consumes while the kernel is still running
+            double *out_hd = h->headd.as<double>(), *out_er = h->epool.as<double>();
+            int32_t *out_hi = h->headi.as<int32_t>();
+            RegionStream rs{};
+            const size_t bytes_hd = (size_t)n_opt * h->fd * sizeof(double), bytes_hi = (size_t)n_opt * h->fi * sizeof(int32_t),
+                         bytes_er = (size_t)n_opt * rows_t_ * (h->n_t + 1) * sizeof(double);
+            if ((flags & MPC_LEVEL_STREAM) && bytes_hd + bytes_hi + bytes_er <= (size_t(1) << 30)) {
+                auto &so = h->so;
+                so.shift = 8;
+                while (so.shift > 4 && ((long long)n_opt >> so.shift) < 8) --so.shift;   // at least ~8 chunks, 16..256 slots each
+                so.n_chunks = (int)(((long long)n_opt + (1ll << so.shift) - 1) >> so.shift);
+                so.n_slots = n_opt; so.cap_rows = (long long)n_opt * rows_t_;
+                HIP_TRY(h, host_pool_take(bytes_hd, &so.hd, nullptr));
+                HIP_TRY(h, host_pool_take(bytes_hi, &so.hi, nullptr));
+                HIP_TRY(h, host_pool_take(std::max<size_t>(bytes_er, 8), &so.er, nullptr));
+                HIP_TRY(h, h->st_flags.ensure((size_t)so.n_chunks * sizeof(int32_t)));
+                std::memset(h->st_flags.p, 0, (size_t)so.n_chunks * sizeof(int32_t));
+                HIP_TRY(h, h->chunk_count.ensure((size_t)so.n_chunks * sizeof(unsigned int), st));
+                HIP_TRY(h, hipMemsetAsync(h->chunk_count.p, 0, (size_t)so.n_chunks * sizeof(unsigned int), st));
+                void *d_hd = nullptr, *d_hi = nullptr, *d_er = nullptr, *d_fl = nullptr;
+                HIP_TRY(h, hipHostGetDevicePointer(&d_hd, so.hd, 0));
+                HIP_TRY(h, hipHostGetDevicePointer(&d_hi, so.hi, 0));
+                HIP_TRY(h, hipHostGetDevicePointer(&d_er, so.er, 0));
+                HIP_TRY(h, hipHostGetDevicePointer(&d_fl, h->st_flags.p, 0));
+                out_hd = static_cast<double *>(d_hd); out_hi = static_cast<int32_t *>(d_hi); out_er = static_cast<double *>(d_er);
+                rs.count = h->chunk_count.as<unsigned int>(); rs.flags = static_cast<int32_t *>(d_fl); rs.shift = so.shift; rs.n_slots = n_opt;
+                so.active = true;
+            }
 #define MPC_LAUNCH_R2(NT_, SL_) hipLaunchKernelGGL((k_region2<NT_, SL_>), g, b, h->lds_r2, st, pr, h->frontier.as<int32_t>(), k, h->opt_ptr, n_opt, \
-                                                   h->status.as<uint8_t>(), h->headd.as<double>(), h->headi.as<int32_t>(), h->fd, h->fi, h->epool.as<double>(), ctr, kkc, kkl, \
+                                                   h->status.as<uint8_t>(), out_hd, out_hi, h->fd, h->fi, out_er, ctr, kkc, kkl, \
                                                    W, h->kept_g.as<uint8_t>(), ldk, h->done_g.as<unsigned int>(), \
-                                                   h->no_rbox ? (const double *)nullptr : h->targs.tvp + (size_t)NT_ * NT_ + NT_)
+                                                   h->no_rbox ? (const double *)nullptr : h->targs.tvp + (size_t)NT_ * NT_ + NT_, rs)
             HIP_TRY(h, hipEventRecord(h->kev[4], st));
             switch (h->fast_r) {
                 case 0: MPC_LAUNCH_R2(4, 1); break;
@@ -1230,6 +1301,7 @@ int mpc_level_run(mpc_handle *h, int32_t gen_children, mpc_level_stats *stats) {
             kernel_timed[2] = true;
             HIP_TRY(h, hipGetLastError());
             h->used_region2 = true;
+            stream_ready(h);   // the caller of mpc_level_stream_info may start consuming chunks
             // candidates k_region2 gave up on (counted by the kernel; normally none): the LDS-engine kernel, fixed-stride records
             hipLaunchKernelGGL(k_publish_words, dim3(1), dim3(64), 0, st, &ctr->n_rretry, reinterpret_cast<unsigned int *>(h->tot_dev + 8), 1);
             HIP_TRY(h, hipGetLastError());
@@ -1297,6 +1369,7 @@ int mpc_level_run(mpc_handle *h, int32_t gen_children, mpc_level_stats *stats) {
     }
     h->level_done = true;
     h->last_level_n = n;
+    stream_ready(h);
     if (stats) {
         std::memset(stats, 0, sizeof(*stats));
         stats->n = n; stats->k = k; stats->kkt_mode = h->kkt_mode;
@@ -1311,6 +1384,7 @@ int mpc_level_run(mpc_handle *h, int32_t gen_children, mpc_level_stats *stats) {
         stats->ms_theta = kms[0]; stats->ms_x = kms[1]; stats->ms_region2 = kms[2];
         stats->n_x_items = n_x_items;
         stats->n_theta_items = n_theta_items;
+        stats->n_region_rows = h->n_erows;
         stats->n_opt = h->n_opt;
         // bytes of one dictionary record that are actually moved: the used columns (value + D0 columns) and the integer part
         const long long rec_bytes = (long long)(h->Pf.n_d0c + 1) * h->Pf.n_d0r * 8 + h->dict_stride_i * 4;
@@ -1319,6 +1393,86 @@ int mpc_level_run(mpc_handle *h, int32_t gen_children, mpc_level_stats *stats) {
         stats->ms_verdict = ms[0]; stats->ms_region = ms[1]; stats->ms_children = ms[2]; stats->ms_total = ms[0] + ms[1] + ms[2];
     }
     return MPC_OK;
+}
+
+int mpc_level_run(mpc_handle *h, int32_t gen_children, mpc_level_stats *stats) {
+    if (!h) return MPC_ERR_INVALID;
+    { std::lock_guard<std::mutex> lk(h->wm); if (h->w_busy) return fail(h, MPC_ERR_STATE, "a level started with mpc_level_start is still running"); }
+    return level_run_impl(h, gen_children, 0, stats);
+}
+
+// ---- the same level, driven by the handle's worker thread ---------------------------------------------------------------
+static void worker_main(mpc_handle *h) {
+    for (;;) {
+        int gen = 0, flags = 0;
+        {
+            std::unique_lock<std::mutex> lk(h->wm);
+            h->wcv.wait(lk, [&] { return h->w_req != 0; });
+            if (h->w_req == 2) return;
+            gen = h->w_gen; flags = h->w_flags; h->w_req = 0;
+        }
+        mpc_level_stats st;
+        std::memset(&st, 0, sizeof(st));
+        const int rc = level_run_impl(h, gen, flags, &st);
+        {
+            std::lock_guard<std::mutex> lk(h->wm);
+            h->w_rc = rc; h->w_stats = st; h->w_busy = false; h->w_stream_ready = true;
+        }
+        h->wcv.notify_all();
+    }
+}
+
+int mpc_level_start(mpc_handle *h, int32_t gen_children, int32_t flags) {
+    if (!h) return MPC_ERR_INVALID;
+    std::unique_lock<std::mutex> lk(h->wm);
+    if (h->w_busy) return fail(h, MPC_ERR_STATE, "mpc_level_start: the previous level has not been waited for");
+    if (!h->worker.joinable()) h->worker = std::thread(worker_main, h);
+    h->w_gen = gen_children; h->w_flags = flags; h->w_busy = true; h->w_stream_ready = false; h->w_req = 1;
+    lk.unlock();
+    h->wcv.notify_all();
+    return MPC_OK;
+}
+
+int mpc_level_stream_info(mpc_handle *h, double **head_d, int32_t **head_i, double **erows, int64_t *n_slots, int64_t *cap_rows,
+                          int32_t *chunk, int32_t *n_chunks) {
+    if (!h) return MPC_ERR_INVALID;
+    std::unique_lock<std::mutex> lk(h->wm);
+    h->wcv.wait(lk, [&] { return h->w_stream_ready; });
+    auto &so = h->so;
+    const bool on = so.active && !so.taken;
+    if (head_d) *head_d = on ? static_cast<double *>(so.hd) : nullptr;
+    if (head_i) *head_i = on ? static_cast<int32_t *>(so.hi) : nullptr;
+    if (erows) *erows = on ? static_cast<double *>(so.er) : nullptr;
+    if (n_slots) *n_slots = on ? so.n_slots : 0;
+    if (cap_rows) *cap_rows = on ? so.cap_rows : 0;
+    if (chunk) *chunk = on ? (1 << so.shift) : 0;
+    if (n_chunks) *n_chunks = on ? so.n_chunks : 0;
+    if (on) so.taken = true;   // the three blocks now belong to the caller (mpc_host_free)
+    return MPC_OK;
+}
+
+int mpc_level_chunk_wait(mpc_handle *h, int32_t j) {
+    if (!h || !h->so.active || j < 0 || j >= h->so.n_chunks) return MPC_ERR_INVALID;
+    const int32_t *flag = h->st_flags.as<int32_t>() + j;
+    for (unsigned spin = 0;; ++spin) {
+        if (__atomic_load_n(flag, __ATOMIC_ACQUIRE)) return MPC_OK;
+        if ((spin & 1023u) == 1023u) {
+            // the level has ended (normally or with an error) without raising the flag: do not wait for ever
+            bool busy;
+            { std::lock_guard<std::mutex> lk(h->wm); busy = h->w_busy; }
+            if (!busy) return __atomic_load_n(flag, __ATOMIC_ACQUIRE) ? MPC_OK : fail(h, MPC_ERR_STATE, "mpc_level_chunk_wait: the level ended without completing this chunk");
+        }
+        __builtin_ia32_pause();
+    }
+}
+
+int mpc_level_wait(mpc_handle *h, mpc_level_stats *stats) {
+    if (!h) return MPC_ERR_INVALID;
+    std::unique_lock<std::mutex> lk(h->wm);
+    if (!h->worker.joinable()) return fail(h, MPC_ERR_STATE, "mpc_level_wait without mpc_level_start");
+    h->wcv.wait(lk, [&] { return !h->w_busy; });
+    if (stats) *stats = h->w_stats;
+    return h->w_rc;
 }
 
 int mpc_level_status(mpc_handle *h, uint8_t *status) {
@@ -1350,6 +1504,7 @@ int mpc_level_regions_compact(mpc_handle *h, double *head_d, int32_t *head_i, in
     if (!h->level_done) return fail(h, MPC_ERR_STATE, "mpc_level_run has not been called for this frontier");
     if (n_regions) *n_regions = h->n_regions;
     if (n_rows) *n_rows = 0;
+    if (h->so.active) return fail(h, MPC_ERR_STATE, "the records of this level were streamed to the host (mpc_level_stream_info)");
     if (cap_regions < h->n_regions) return fail(h, MPC_ERR_CAPACITY, "region buffers too small");
     if (h->n_regions == 0 || h->n_opt == 0) return MPC_OK;
     if (!head_d || !head_i || !erows) return MPC_ERR_INVALID;
@@ -1443,10 +1598,13 @@ int mpc_level_regions_compact(mpc_handle *h, double *head_d, int32_t *head_i, in
 
 int64_t mpc_level_slots(const mpc_handle *h) { return h ? h->n_opt : 0; }
 
+// in_place: the level's records were streamed into head_d / head_i / erows (host memory) by the region kernel itself; only
+// the slots of candidates re-solved by the LDS-engine kernel still have to be filled in
 static int level_regions_slots_impl(mpc_handle *h, double *head_d, int32_t *head_i, int64_t cap_slots, double *erows, int64_t cap_rows,
-                                    int64_t *n_slots, int64_t *n_rows, bool may_return_early) {
+                                    int64_t *n_slots, int64_t *n_rows, bool may_return_early, bool in_place = false) {
     if (!h) return MPC_ERR_INVALID;
     if (!h->level_done) return fail(h, MPC_ERR_STATE, "mpc_level_run has not been called for this frontier");
+    if (h->so.active && !in_place) return fail(h, MPC_ERR_STATE, "the records of this level were streamed to the host (mpc_level_stream_info)");
     if (n_slots) *n_slots = 0;
     if (n_rows) *n_rows = 0;
     if (h->n_regions == 0 || h->n_opt == 0) return MPC_OK;
@@ -1470,7 +1628,7 @@ static int level_regions_slots_impl(mpc_handle *h, double *head_d, int32_t *head
         HIP_TRY(h, hipMemcpyAsync(h->st_status.p, h->status.p, (size_t)h->n, hipMemcpyDeviceToHost, s));
     }
     long long wrow = 0;
-    if (h->used_region2 && n_fixed == 0 && may_return_early) {
+    if (h->used_region2 && n_fixed == 0 && may_return_early && !in_place) {
         // every record is in slot form on the device: the small integer heads first, then the two large arrays; the call
         // returns when the heads have arrived, the rest is in flight on the handle's stream (mpc_sync completes it)
         HIP_TRY(h, hipMemcpyAsync(head_i, h->headi.p, (size_t)n_opt * fi * sizeof(int32_t), hipMemcpyDeviceToHost, s));
@@ -1483,9 +1641,11 @@ static int level_regions_slots_impl(mpc_handle *h, double *head_d, int32_t *head
         return MPC_OK;
     }
     if (h->used_region2) {
-        HIP_TRY(h, hipMemcpyAsync(head_d, h->headd.p, (size_t)n_opt * fd * sizeof(double), hipMemcpyDeviceToHost, s));
-        HIP_TRY(h, hipMemcpyAsync(head_i, h->headi.p, (size_t)n_opt * fi * sizeof(int32_t), hipMemcpyDeviceToHost, s));
-        if (h->n_erows > 0) HIP_TRY(h, hipMemcpyAsync(erows, h->epool.p, (size_t)h->n_erows * nr * sizeof(double), hipMemcpyDeviceToHost, s));
+        if (!in_place) {
+            HIP_TRY(h, hipMemcpyAsync(head_d, h->headd.p, (size_t)n_opt * fd * sizeof(double), hipMemcpyDeviceToHost, s));
+            HIP_TRY(h, hipMemcpyAsync(head_i, h->headi.p, (size_t)n_opt * fi * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+            if (h->n_erows > 0) HIP_TRY(h, hipMemcpyAsync(erows, h->epool.p, (size_t)h->n_erows * nr * sizeof(double), hipMemcpyDeviceToHost, s));
+        }
         wrow = h->n_erows;
         if (h->n_rretry > 0) {
             HIP_TRY(h, h->st_rlist.ensure((size_t)h->n_rretry * sizeof(int32_t)));
@@ -1554,6 +1714,13 @@ int mpc_level_regions_slots(mpc_handle *h, double *head_d, int32_t *head_i, int6
 int mpc_level_regions_slots_async(mpc_handle *h, double *head_d, int32_t *head_i, int64_t cap_slots, double *erows, int64_t cap_rows,
                                   int64_t *n_slots, int64_t *n_rows) {
     return level_regions_slots_impl(h, head_d, head_i, cap_slots, erows, cap_rows, n_slots, n_rows, true);
+}
+int mpc_level_stream_fixup(mpc_handle *h, double *head_d, int32_t *head_i, double *erows, int64_t *n_rows) {
+    if (!h || !head_d || !head_i || !erows) return MPC_ERR_INVALID;
+    if (!h->so.active) return fail(h, MPC_ERR_STATE, "mpc_level_stream_fixup: this level was not streamed");
+    { std::lock_guard<std::mutex> lk(h->wm); if (h->w_busy) return fail(h, MPC_ERR_STATE, "the level is still running"); }
+    int64_t ns = 0;
+    return level_regions_slots_impl(h, head_d, head_i, h->so.n_slots, erows, h->so.cap_rows, &ns, n_rows, false, true);
 }
 int mpc_sync(mpc_handle *h) {
     if (!h) return MPC_ERR_INVALID;
@@ -1653,7 +1820,7 @@ int mpc_level_regions_device(mpc_handle *h, double *head_d_dev, int32_t *head_i_
     if (h->n_regions == 0 || h->n_opt == 0) return MPC_OK;
     // only the common case lives entirely on the device: every region came from k_region2; otherwise the caller takes the
     // host route (mpc_level_regions_slots)
-    if (!h->used_region2 || h->n_rretry > 0) return fail(h, MPC_ERR_STATE, "records of this level are not all in slot form on the device");
+    if (!h->used_region2 || h->n_rretry > 0 || h->so.active) return fail(h, MPC_ERR_STATE, "records of this level are not all in slot form on the device");
     if (cap_slots < h->n_opt || cap_rows < h->n_erows) return fail(h, MPC_ERR_CAPACITY, "slot / row buffers too small");
     if (!head_d_dev || !head_i_dev || (!erows_dev && h->n_erows > 0)) return MPC_ERR_INVALID;
     HIP_TRY(h, hipSetDevice(h->device));

@@ -21,6 +21,7 @@ Differences from the reference that are visible to a user:
   * a numerically singular KKT matrix is a per-candidate status (no region, children expanded) instead of the
     ``numpy.linalg.LinAlgError`` that aborts the reference solve (mpqp_program.py:187).
 """
+import os
 import time
 from typing import Dict, List, Optional
 
@@ -63,10 +64,17 @@ def unpack_region(rec_d: numpy.ndarray, rec_i: numpy.ndarray, n_x: int, n_t: int
     return unpack_regions(rec_d.reshape(1, -1), rec_i.reshape(1, -1), n_x, n_t, n_c, n_tc)[0]
 
 
+REGION_STATUS = 3   # MPC_REGION
+
+
 def solve(program, num_cores: int = -1, device: int = 0, profile: Optional[List[Dict]] = None,
-          collect_regions: bool = True, max_levels: Optional[int] = None) -> Solution:
+          collect_regions: bool = True, max_levels: Optional[int] = None, stream: Optional[bool] = None) -> Solution:
     """Solves the mpLP/mpQP on one GPU.  ``num_cores`` is accepted for signature compatibility with the reference
-    drivers and ignored.  ``profile``: optional list that receives one dict of statistics per level."""
+    drivers and ignored.  ``profile``: optional list that receives one dict of statistics per level.  ``stream``: region
+    records are streamed to the host while the region kernel runs (default; ``MPC_NO_STREAM=1`` or False = fetch after
+    each level)."""
+    if stream is None:
+        stream = os.environ.get('MPC_NO_STREAM', '0') != '1'
     eng = program.engine(device)
     n_x, n_t, n_c, n_tc = eng.n_x, eng.n_t, eng.n_c, eng.n_tc
     solution = Solution(program, [])
@@ -78,12 +86,39 @@ def solve(program, num_cores: int = -1, device: int = 0, profile: Optional[List[
     for depth in range(max_depth):
         gen_children = depth + 1 != max_depth
         t0 = time.perf_counter()
-        st = eng.level_run(gen_children)
-        if collect_regions and st.n_regions:
-            # the integer heads are waited for (the region objects are built from them); the two large arrays keep
-            # arriving by DMA while Python builds the objects -- eng.sync() below completes them
-            hd, hi, er, kk, slots = eng.level_regions_slots(early_return=True)
-            solution.critical_regions.extend(RegionBatch(hd, hi, er, n_x, n_t, n_c, n_tc, kk, slots).regions())
+        if collect_regions and stream:
+            # The level runs on the handle's worker thread; its region kernel writes the records straight into page-locked
+            # host arrays and raises a flag per chunk of slots, so the region objects of a chunk are built while the kernel
+            # is still working on the later ones -- no fetch afterwards, nothing waits for Python.
+            eng.level_start(gen_children, stream=True)
+            info = eng.level_stream_info()
+            new_regions: List[CriticalRegion] = []
+            batch = None
+            if info is not None:
+                hd, hi, er, chunk, n_chunks = info
+                batch = RegionBatch(hd, hi, er, n_x, n_t, n_c, n_tc, eng.frontier_info()[1], ())
+                status_col = hi[:, 0]
+                for j in range(n_chunks):
+                    eng.level_chunk_wait(j)
+                    lo = j * chunk
+                    new_regions.extend(batch.regions_of((lo + numpy.flatnonzero(status_col[lo:lo + chunk] == REGION_STATUS)).tolist()))
+            st = eng.level_wait()
+            if st.n_regions and info is None:
+                # a level outside the streaming path (LDS-engine region kernel, very large record sets)
+                hd, hi, er, kk, slots = eng.level_regions_slots()
+                new_regions = RegionBatch(hd, hi, er, n_x, n_t, n_c, n_tc, kk, slots).regions()
+            elif st.n_region_retry and batch is not None:
+                # some candidates were re-solved by the LDS-engine kernel after the stream: fill their slots, list the level again
+                eng.level_stream_fixup(hd, hi, er)
+                new_regions = batch.regions_of(numpy.flatnonzero(hi[:, 0] == REGION_STATUS).tolist())
+            solution.critical_regions.extend(new_regions)
+        else:
+            st = eng.level_run(gen_children)
+            if collect_regions and st.n_regions:
+                # the integer heads are waited for (the region objects are built from them); the two large arrays keep
+                # arriving by DMA while Python builds the objects -- eng.sync() below completes them
+                hd, hi, er, kk, slots = eng.level_regions_slots(early_return=True)
+                solution.critical_regions.extend(RegionBatch(hd, hi, er, n_x, n_t, n_c, n_tc, kk, slots).regions())
         if profile is not None:
             profile.append({'depth': depth + 1, 'k': int(st.k), 'candidates': int(st.n),
                             'status': [int(v) for v in st.n_status], 'regions': int(st.n_regions),

@@ -34,6 +34,10 @@ class RegionBatch:
     def regions(self) -> List['BatchCriticalRegion']:
         return list(map(BatchCriticalRegion, itertools.repeat(self), self.slots.tolist()))
 
+    def regions_of(self, slots) -> List['BatchCriticalRegion']:
+        """Region objects of the given slots (a streamed level hands its slots over chunk by chunk)."""
+        return list(map(BatchCriticalRegion, itertools.repeat(self), slots))
+
 
 class _Lazy:
     """Non-overriding-on-read descriptor: computes the field from the batch on first access, then behaves like a

@@ -30,7 +30,7 @@ def test_library_exports_every_declared_symbol():
 
 def test_struct_layout_matches_header():
     assert ctypes.sizeof(_lib.MpcProblem) == 5 * 4 + 4 + 8 * 8  # five int32 (+pad) and eight pointers
-    assert ctypes.sizeof(_lib.LevelStats) == 8 + 4 + 4 + 6 * 8 + 4 * 8 + 4 * 4 + 8 + 8 + 4 * 8 + 8 + 8 + 4 * 4 + 5 * 8
+    assert ctypes.sizeof(_lib.LevelStats) == 8 + 4 + 4 + 6 * 8 + 4 * 8 + 4 * 4 + 8 + 8 + 4 * 8 + 8 + 8 + 4 * 4 + 6 * 8
 
 
 def test_no_cpu_fallback_without_gpu():
