@@ -515,8 +515,13 @@ struct DictCache {
 // ends within those iterations (slack already nonbasic / already zero / no improving column / the new row leaves the
 // basis); otherwise the candidate keeps its NEEDX status and goes to k_x2.  Few registers -> 8 waves per SIMD hide the
 // dependent HBM round trips.
+// 6 rather than 8: the eta file of 16 iterations does not fit 64 registers (292 bytes of scratch per lane at 8 waves per
+// SIMD, 220 at 6); measured on config 4 / config 3, verdict stage: 8 waves 4.50 / 7.47 ms, 6 waves 4.39 / --, 4 waves 4.46 / 6.88
 #ifndef XQ_WAVES
-#define XQ_WAVES 8
+#define XQ_WAVES 6
+#endif
+#ifndef XQG_WAVES
+#define XQG_WAVES 4   // k_xq_grouped (config 3): spill-free at 128 registers
 #endif
 #ifndef XQ_ITERS_N
 #define XQ_ITERS_N 16
@@ -710,7 +715,7 @@ __global__ void k_group_flags(const int32_t *__restrict__ list, int n_list, cons
     if (i < n_list) flag[i] = (i == 0 || parent_slot[list[i]] != parent_slot[list[i - 1]]) ? 1 : 0;
 }
 template <int SLOTS>
-__global__ void __launch_bounds__(256, XQ_WAVES) k_xq_grouped(const DevProblem *__restrict__ Pg, const int32_t *__restrict__ cands, int k,
+__global__ void __launch_bounds__(256, XQG_WAVES) k_xq_grouped(const DevProblem *__restrict__ Pg, const int32_t *__restrict__ cands, int k,
                                                           const int32_t *__restrict__ list, int n_list, uint8_t *__restrict__ status,
                                                           LevelCounters *__restrict__ ctr, DictCache dc, int NXC,
                                                           const int32_t *__restrict__ gstart, const int32_t *__restrict__ n_groups_p) {

@@ -1172,7 +1172,7 @@ static int level_run_impl(mpc_handle *h, int32_t gen_children, int32_t flags, mp
                     hipLaunchKernelGGL(k_group_flags, dim3(nbq), dim3(256), 0, st, needx_list, n_needx, dq.parent_slot, h->flag.as<int32_t>());
                     { int rcs = launch_scan(h, h->flag.as<int32_t>(), h->pos.as<int32_t>(), n_needx, h->scratch.as<int32_t>()); if (rcs) return rcs; }
                     hipLaunchKernelGGL(k_scatter_index, dim3(nbq), dim3(256), 0, st, h->flag.as<int32_t>(), h->pos.as<int32_t>(), (long long)n_needx, h->xq_groups.as<int32_t>());
-                    const int per_cu = std::max(1, std::min(XQ_WAVES, (int)((160 * 1024) / (lds_q + 64))));
+                    const int per_cu = std::max(1, std::min(XQG_WAVES, (int)((160 * 1024) / (lds_q + 64))));
                     const dim3 gq((unsigned)std::min<long long>(n_needx, (long long)h->n_cu * per_cu)), bq(256);
                     if (lds_q > 48 * 1024) {
                         HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void *>(k_xq_grouped<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_q));

@@ -619,3 +619,38 @@ def test_two_ranks_share_one_gpu(name):
         assert n0 == n1 == len(g[f'L{i}_verdict']) and h0 == h1 == numpy.bincount(g[f'L{i}_verdict'], minlength=5).tolist()
         assert sh0 == sh1 and (l0 + l1 == n0 if sh0 else l0 == l1 == n0)
     assert any(sh for _, _, sh, _ in res[0][1])
+
+
+@pytest.mark.parametrize('name', ['c4', 'c2', 'transport_mpqp', 'c1_transport_mplp', 'mi_1d'])
+def test_streamed_regions_equal_fetched_regions(name):
+    """The streamed solve loop (region kernel writing into page-locked host memory, objects built chunk by chunk while it
+    runs) returns exactly the regions of the fetch-after-each-level loop: same order, bit-identical fields.  Covers levels
+    that do not stream (mpLP / one parameter: LDS-engine region kernel)."""
+    import bench
+    from ppopt_amd import MPLP_Program, MPQP_Program, Solver
+    from ppopt_amd.mp_solvers import mpqp_hip_combinatorial
+    from test_host_logic import build_program
+    ml = None
+    if name in ('c4', 'c2'):
+        prog, ml = bench.build_program(name), bench.WORKLOADS[name][2]
+    elif name == 'mi_1d':
+        rng = numpy.random.default_rng(5)   # one parameter: the 1-D region variant
+        A = numpy.vstack([numpy.eye(3), -numpy.eye(3), rng.standard_normal((4, 3))])
+        b = numpy.concatenate([numpy.ones(6) * 2, numpy.ones(4) * 1.5]).reshape(-1, 1)
+        F = rng.standard_normal((10, 1)) * 0.5
+        with warnings.catch_warnings():
+            warnings.simplefilter('ignore')
+            prog = MPQP_Program(A, b, rng.standard_normal((3, 1)), rng.standard_normal((3, 1)), numpy.eye(3) * 2, numpy.array([[1.0], [-1.0]]),
+                                numpy.array([[1.0], [1.0]]), F)
+    else:
+        with warnings.catch_warnings():
+            warnings.simplefilter('ignore')
+            prog = build_program(load_golden(name), Solver())
+    a = mpqp_hip_combinatorial.solve(prog, max_levels=ml, stream=True)
+    b_ = mpqp_hip_combinatorial.solve(prog, max_levels=ml, stream=False)
+    assert len(a.critical_regions) == len(b_.critical_regions) > 0
+    for r1, r2 in zip(a.critical_regions, b_.critical_regions):
+        assert r1.active_set == r2.active_set and r1.omega_set == r2.omega_set and r1.lambda_set == r2.lambda_set
+        assert r1.regular_set == r2.regular_set
+        for fld in ('A', 'b', 'C', 'd', 'E', 'f'):
+            assert numpy.array_equal(getattr(r1, fld), getattr(r2, fld)), fld
