@@ -51,8 +51,8 @@ extern "C" {
 #define MPC_LP_UNBOUNDED 2
 #define MPC_LP_ITERLIMIT 3
 
-#define MPC_MASK_WORDS 2        /* active sets as bit masks: n_c <= 128 */
-#define MPC_MAX_NC 128
+#define MPC_MASK_WORDS 2        /* active sets as bit masks of 64-bit words: 2 words for n_c <= 128, 4 for n_c <= 256 (mpc_mask_words) */
+#define MPC_MAX_NC 256
 #define MPC_MAX_ROWS 192        /* n_c + n_tc + 1 */
 
 typedef struct mpc_handle mpc_handle;
@@ -126,7 +126,8 @@ int mpc_frontier_shard(mpc_handle *h, int32_t rank, int32_t world);
 int mpc_frontier_info(const mpc_handle *h, int64_t *n, int32_t *k);
 int mpc_frontier_get(mpc_handle *h, int32_t *cand_host, int64_t cap);
 int mpc_pruned_clear(mpc_handle *h);
-int mpc_pruned_add(mpc_handle *h, const uint64_t *masks_host, int64_t m);        /* m x MPC_MASK_WORDS */
+int32_t mpc_mask_words(const mpc_handle *h);                                    /* words of one active-set mask for this program */
+int mpc_pruned_add(mpc_handle *h, const uint64_t *masks_host, int64_t m);        /* m x mpc_mask_words(h) */
 int mpc_pruned_add_device(mpc_handle *h, const uint64_t *masks_dev, int64_t m);
 int64_t mpc_pruned_count(const mpc_handle *h);
 int mpc_pruned_get(mpc_handle *h, uint64_t *masks_host, int64_t cap);
@@ -213,7 +214,7 @@ int mpc_level_pruned_new_device(mpc_handle *h, uint64_t *masks_dev, int64_t cap)
 int mpc_frontier_advance(mpc_handle *h);
 
 /* ---- the batched operator with host buffers (drop-in for pool.map(full_process)) ---------------------- */
-/* Uploads cand (n x k) and the pruned masks (m x MPC_MASK_WORDS; replaces the handle's list), runs the level
+/* Uploads cand (n x k) and the pruned masks (m x mpc_mask_words(h); replaces the handle's list), runs the level
  * and downloads status, regions and children.  On MPC_ERR_CAPACITY *n_regions / *n_children hold the
  * required capacities. */
 int mpc_check_level(mpc_handle *h, const int32_t *cand, int64_t n, int32_t k, const uint64_t *pruned_masks, int64_t m,

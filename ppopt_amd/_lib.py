@@ -70,6 +70,7 @@ def load():
         'mpc_create': (ctypes.c_int, [ctypes.POINTER(MpcProblem), ctypes.c_int32, ctypes.c_void_p, ctypes.POINTER(H)]),
         'mpc_destroy': (ctypes.c_int, [H]),
         'mpc_last_error': (ctypes.c_char_p, [H]),
+        'mpc_mask_words': (ctypes.c_int32, [H]),
         'mpc_region_doubles': (ctypes.c_int64, [H]),
         'mpc_region_ints': (ctypes.c_int64, [H]),
         'mpc_lds_bytes': (ctypes.c_int32, [H, ctypes.c_int32]),
@@ -129,7 +130,7 @@ def load():
 
 
 EXPORTED_SYMBOLS = ['mpc_device_count', 'mpc_version', 'mpc_last_global_error', 'mpc_create', 'mpc_destroy',
-                    'mpc_last_error', 'mpc_region_doubles', 'mpc_region_ints', 'mpc_lds_bytes', 'mpc_stream',
+                    'mpc_last_error', 'mpc_mask_words', 'mpc_region_doubles', 'mpc_region_ints', 'mpc_lds_bytes', 'mpc_stream',
                     'mpc_frontier_root', 'mpc_frontier_set', 'mpc_frontier_set_device', 'mpc_frontier_info',
                     'mpc_frontier_get', 'mpc_pruned_clear', 'mpc_pruned_add', 'mpc_pruned_add_device',
                     'mpc_pruned_count', 'mpc_pruned_get', 'mpc_level_run', 'mpc_level_status', 'mpc_level_start', 'mpc_level_stream_info', 'mpc_level_chunk_wait', 'mpc_level_wait', 'mpc_level_stream_fixup', 'mpc_level_regions', 'mpc_compact_strides',
@@ -168,20 +169,21 @@ def _f64(a):
     return numpy.ascontiguousarray(a, dtype=numpy.float64)
 
 
-def sets_to_masks(sets) -> numpy.ndarray:
-    """Active sets (iterables of row indices < 128) -> (m, 2) uint64 bit masks."""
-    out = numpy.zeros((len(sets), MASK_WORDS), dtype=numpy.uint64)
+def sets_to_masks(sets, words: int = MASK_WORDS) -> numpy.ndarray:
+    """Active sets (iterables of row indices < 64 * words) -> (m, words) uint64 bit masks (include/mpcombi.h,
+    mpc_mask_words: 2 words for programs with n_c <= 128, 4 up to 256)."""
+    out = numpy.zeros((len(sets), words), dtype=numpy.uint64)
     for i, s in enumerate(sets):
         for v in s:
             out[i, int(v) >> 6] |= numpy.uint64(1) << numpy.uint64(int(v) & 63)
     return out
 
 
-def masks_to_sets(masks: numpy.ndarray):
+def masks_to_sets(masks: numpy.ndarray, words: int = MASK_WORDS):
     out = []
-    for row in numpy.asarray(masks, dtype=numpy.uint64).reshape(-1, MASK_WORDS):
+    for row in numpy.asarray(masks, dtype=numpy.uint64).reshape(-1, words):
         s = []
-        for w in range(MASK_WORDS):
+        for w in range(words):
             v = int(row[w])
             while v:
                 low = v & -v
@@ -218,6 +220,7 @@ class Engine:
                           ctypes.byref(self._h))
         if rc != MPC_OK:
             raise MpcError(f'mpc_create failed ({rc}): {L.mpc_last_global_error().decode()}')
+        self.mask_words = int(L.mpc_mask_words(self._h))
         self.rec_d = int(L.mpc_region_doubles(self._h))
         self.rec_i = int(L.mpc_region_ints(self._h))
         self.device = int(device)
@@ -273,7 +276,7 @@ class Engine:
         self._check(self._L.mpc_pruned_clear(self._h), 'mpc_pruned_clear')
 
     def pruned_add(self, masks: numpy.ndarray):
-        masks = numpy.ascontiguousarray(masks, dtype=numpy.uint64).reshape(-1, MASK_WORDS)
+        masks = numpy.ascontiguousarray(masks, dtype=numpy.uint64).reshape(-1, self.mask_words)
         if len(masks):
             self._check(self._L.mpc_pruned_add(self._h, masks.ctypes.data_as(_u64p), len(masks)), 'mpc_pruned_add')
 
@@ -288,7 +291,7 @@ class Engine:
 
     def pruned_get(self) -> numpy.ndarray:
         m = self.pruned_count()
-        out = numpy.zeros((m, MASK_WORDS), dtype=numpy.uint64)
+        out = numpy.zeros((m, self.mask_words), dtype=numpy.uint64)
         if m:
             self._check(self._L.mpc_pruned_get(self._h, out.ctypes.data_as(_u64p), m), 'mpc_pruned_get')
         return out
@@ -410,7 +413,7 @@ class Engine:
 
     def level_pruned_new(self) -> numpy.ndarray:
         m = int(self._last.n_pruned_new)
-        out = numpy.zeros((m, MASK_WORDS), dtype=numpy.uint64)
+        out = numpy.zeros((m, self.mask_words), dtype=numpy.uint64)
         if m:
             self._check(self._L.mpc_level_pruned_new(self._h, out.ctypes.data_as(_u64p), m), 'mpc_level_pruned_new')
         return out
@@ -445,7 +448,7 @@ class Engine:
     def check_level(self, cands: numpy.ndarray, pruned_masks: numpy.ndarray, gen_children: bool):
         cands = numpy.ascontiguousarray(cands, dtype=numpy.int32)
         n, k = cands.shape
-        pm = numpy.ascontiguousarray(pruned_masks, dtype=numpy.uint64).reshape(-1, MASK_WORDS)
+        pm = numpy.ascontiguousarray(pruned_masks, dtype=numpy.uint64).reshape(-1, self.mask_words)
         status = numpy.zeros(n, dtype=numpy.uint8)
         nreg, nch = ctypes.c_int64(0), ctypes.c_int64(0)
         # small levels: capacities that cannot be exceeded, so one call suffices; large levels: ask first

@@ -799,11 +799,24 @@ __global__ void __launch_bounds__(1024) k_scan_small(const int32_t *__restrict__
 
 __device__ __forceinline__ bool expands(int st) { return st == ST_FEASIBLE || st == ST_REGION || st == ST_SINGULAR || st == ST_LP_LIMIT; }
 
+// Active sets as bit masks of MW 64-bit words (MW = 2: n_c <= 128, MW = 4: n_c <= 256; mpc_mask_words).
+template <int MW>
+__device__ __forceinline__ void set_mask(const int32_t *as, int k, unsigned long long (&p)[MW]) {
+#pragma unroll
+    for (int w = 0; w < MW; ++w) p[w] = 0;
+    for (int i = 0; i < k; ++i) {
+        const int v = as[i];
+#pragma unroll
+        for (int w = 0; w < MW; ++w) if ((v >> 6) == w) p[w] |= 1ull << (v & 63);
+    }
+}
+
 // children of one parent per wavefront: bit i of childmask = [as + {i}] survives CombinationTester.check and the
 // mpLP filter (driver lines 49-51); count[c] = popcount.
 // The superset test is organised by pruned set, not by child: for a pruned mask p, d = p & ~parent is empty (every
 // child contains p: all culled) or a single bit i > last(parent) (exactly child i contains p) or irrelevant.  Lanes
-// stride over the pruned list, each accumulating the 128-bit set of culled children, then the wave ORs them together.
+// stride over the pruned list, each accumulating the bit set of culled children, then the wave ORs them together.
+template <int MW>
 __global__ void __launch_bounds__(64) k_children_count(DevProblem P, const int32_t *__restrict__ cands, long long n, int k,
                                                        const uint8_t *__restrict__ status,
                                                        const unsigned long long *__restrict__ pruned, long long n_pruned,
@@ -812,34 +825,53 @@ __global__ void __launch_bounds__(64) k_children_count(DevProblem P, const int32
     const int lane = lane_id();
     if (c >= n) return;
     const int st = status[c];
-    unsigned long long m0 = 0, m1 = 0;
+    unsigned long long m[MW];
+#pragma unroll
+    for (int w = 0; w < MW; ++w) m[w] = 0;
     if (expands(st)) {
         const int32_t *as = cands + (size_t)c * k;
-        unsigned long long p0 = 0, p1 = 0;
-        for (int i = 0; i < k; ++i) { const int v = as[i]; if (v < 64) p0 |= 1ull << v; else p1 |= 1ull << (v - 64); }
+        unsigned long long p[MW], a[MW], kill[MW];
+        set_mask<MW>(as, k, p);
         const int start = k > 0 ? as[k - 1] + 1 : 0;
         // candidates for children: indices start .. n_c-1 (mpLP filter for non-optimal parents)
         int stop = P.n_c;
         if (!P.is_qp && st == ST_FEASIBLE) stop = min(stop, (k + 1) + P.n_c - P.n_x);
-        unsigned long long a0 = 0, a1 = 0;  // allowed children
-        for (int i = start; i < stop; ++i) { if (i < 64) a0 |= 1ull << i; else a1 |= 1ull << (i - 64); }
-        unsigned long long kill0 = 0, kill1 = 0;
-        for (long long j = lane; j < n_pruned; j += 64) {
-            const unsigned long long d0 = pruned[2 * j] & ~p0, d1 = pruned[2 * j + 1] & ~p1;
-            const int bits = __popcll(d0) + __popcll(d1);
-            if (bits == 0) { kill0 = ~0ull; kill1 = ~0ull; }
-            else if (bits == 1) { kill0 |= d0; kill1 |= d1; }
+#pragma unroll
+        for (int w = 0; w < MW; ++w) {   // allowed children: bits start .. stop-1
+            const int lo = max(start - 64 * w, 0), hi = min(stop - 64 * w, 64);
+            a[w] = hi > lo ? ((hi >= 64 ? ~0ull : ((1ull << hi) - 1ull)) & ~((1ull << lo) - 1ull)) : 0ull;
+            kill[w] = 0;
         }
-        for (int off = 32; off > 0; off >>= 1) { kill0 |= __shfl_xor(kill0, off); kill1 |= __shfl_xor(kill1, off); }
-        m0 = a0 & ~kill0;
-        m1 = a1 & ~kill1;
+        for (long long j = lane; j < n_pruned; j += 64) {
+            unsigned long long d[MW];
+            int bits = 0;
+#pragma unroll
+            for (int w = 0; w < MW; ++w) { d[w] = pruned[MW * j + w] & ~p[w]; bits += __popcll(d[w]); }
+            if (bits == 0) {
+#pragma unroll
+                for (int w = 0; w < MW; ++w) kill[w] = ~0ull;
+            } else if (bits == 1) {
+#pragma unroll
+                for (int w = 0; w < MW; ++w) kill[w] |= d[w];
+            }
+        }
+#pragma unroll
+        for (int w = 0; w < MW; ++w) {
+            for (int off = 32; off > 0; off >>= 1) kill[w] |= __shfl_xor(kill[w], off);
+            m[w] = a[w] & ~kill[w];
+        }
     }
-    if (lane == 0) { childmask[2 * c] = m0; childmask[2 * c + 1] = m1; count[c] = __popcll(m0) + __popcll(m1); }
+    if (lane == 0) {
+        int cnt = 0;
+#pragma unroll
+        for (int w = 0; w < MW; ++w) { childmask[MW * c + w] = m[w]; cnt += __popcll(m[w]); }
+        count[c] = cnt;
+    }
 }
 
 // stored / parent_slot (both optional): child -> index of its parent when the parent left its (x,theta) dictionary in the
 // dictionary cache (k_x2), else -1
-__global__ void __launch_bounds__(64) k_children_write(const int32_t *__restrict__ cands, long long n, int k,
+__global__ void __launch_bounds__(64) k_children_write(const int32_t *__restrict__ cands, long long n, int k, int mw,
                                                        const unsigned long long *__restrict__ childmask,
                                                        const int32_t *__restrict__ offset, int32_t *__restrict__ out,
                                                        const uint8_t *__restrict__ stored, int32_t *__restrict__ parent_slot) {
@@ -849,8 +881,8 @@ __global__ void __launch_bounds__(64) k_children_write(const int32_t *__restrict
     const int32_t *as = cands + (size_t)c * k;
     int base = offset[c];
     const int ps = (stored && stored[c]) ? (int)c : -1;
-    for (int half = 0; half < 2; ++half) {
-        const unsigned long long mk = childmask[2 * c + half];
+    for (int half = 0; half < mw; ++half) {
+        const unsigned long long mk = childmask[(size_t)mw * c + half];
         if (!mk) continue;
         const bool mine = (mk >> lane) & 1ull;
         const int pos = base + __popcll(mk & ((1ull << lane) - 1ull));
@@ -865,18 +897,18 @@ __global__ void __launch_bounds__(64) k_children_write(const int32_t *__restrict
 }
 
 // masks of the candidates pruned by this level (INFEASIBLE, OPT_NO_REGION), appended at pruned[n_pruned_old + ...]
+template <int MW>
 __global__ void k_pruned_append(const int32_t *__restrict__ cands, long long n, int k, const uint8_t *__restrict__ status,
                                 unsigned long long *__restrict__ out, LevelCounters *ctr) {
     const long long c = blockIdx.x * (long long)blockDim.x + threadIdx.x;
     if (c >= n) return;
     const int st = status[c];
     if (st != ST_INFEASIBLE && st != ST_OPT_NO_REGION) return;
-    unsigned long long p0 = 0, p1 = 0;
-    const int32_t *as = cands + (size_t)c * k;
-    for (int i = 0; i < k; ++i) { const int v = as[i]; if (v < 64) p0 |= 1ull << v; else p1 |= 1ull << (v - 64); }
+    unsigned long long p[MW];
+    set_mask<MW>(cands + (size_t)c * k, k, p);
     const unsigned int pos = atomicAdd(&ctr->n_pruned_new, 1u);
-    out[2 * (size_t)pos] = p0;
-    out[2 * (size_t)pos + 1] = p1;
+#pragma unroll
+    for (int w = 0; w < MW; ++w) out[MW * (size_t)pos + w] = p[w];
 }
 
 // status[list[w]] = tmp[list[w]]  (results of a retry kernel that ran on a side stream)

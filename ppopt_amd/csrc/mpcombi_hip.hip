@@ -239,6 +239,7 @@ struct mpc_handle {
     std::string error;
     // problem
     int n_x = 0, n_t = 0, n_c = 0, n_eq = 0, n_tc = 0, is_qp = 0, kkt_mode = 0;
+    int mw = MPC_MASK_WORDS;   // 64-bit words of an active-set mask: 2 (n_c <= 128) or 4 (n_c <= 256)
     DevBuf blocks;            // all read-only problem blocks, one allocation
     DevBuf iblocks;           // integer blocks (row / column maps of the pre-crashed dictionary)
     DevProblem Pv{}, Pr{};    // verdict / region kernel views (same blocks, different LDS layouts)
@@ -427,7 +428,7 @@ int mpc_create(const mpc_problem *p, int32_t device, void *stream, mpc_handle **
     *out = nullptr;
     const int nx = p->n_x, nt = p->n_t, nc = p->n_c, ne = p->n_eq, ntc = p->n_tc;
     if (nx < 1 || nt < 1 || nc < 1 || ne < 0 || ne > nc || ntc < 0) return fail(nullptr, MPC_ERR_INVALID, "bad dimensions");
-    if (nc > MPC_MAX_NC) return fail(nullptr, MPC_ERR_INVALID, "n_c > 128 is not supported (active sets are 128-bit masks)");
+    if (nc > MPC_MAX_NC) return fail(nullptr, MPC_ERR_INVALID, "n_c > 256 is not supported (active sets are bit masks of at most four words)");
     if (nc + ntc + 2 > MPC_MAX_ROWS * 4) return fail(nullptr, MPC_ERR_INVALID, "too many rows");
     if (nt > 64 || nx > 256) return fail(nullptr, MPC_ERR_INVALID, "n_t > 64 or n_x > 256 is not supported");
     if (!p->A || !p->b || !p->F || !p->c || !p->H || (ntc > 0 && (!p->A_t || !p->b_t))) return fail(nullptr, MPC_ERR_INVALID, "null matrix");
@@ -460,6 +461,7 @@ static int create_fill(const mpc_problem *p, int32_t device, void *stream, mpc_h
     HIP_TRY(nullptr, pooled_event(&h->ev_fork, false));
     HIP_TRY(nullptr, pooled_event(&h->ev_join, false));
     h->n_x = nx; h->n_t = nt; h->n_c = nc; h->n_eq = ne; h->n_tc = ntc; h->is_qp = p->Q != nullptr;
+    h->mw = nc <= 64 * MPC_MASK_WORDS ? MPC_MASK_WORDS : 4;
     { const char *ev = std::getenv("MPC_FORCE_V1"); h->force_v1 = ev && ev[0] == '1'; }
     { const char *ev = std::getenv("MPC_DEBUG_CYCLES"); h->debug_cycles = ev && ev[0] == '1'; }
     { const char *ev = std::getenv("MPC_NO_RSPLIT"); h->no_rsplit = ev && ev[0] == '1'; }
@@ -800,6 +802,7 @@ int mpc_destroy(mpc_handle *h) {
     return MPC_OK;
 }
 
+int32_t mpc_mask_words(const mpc_handle *h) { return h ? h->mw : MPC_MASK_WORDS; }
 int64_t mpc_region_doubles(const mpc_handle *h) { return h ? h->rec_d : 0; }
 int64_t mpc_region_ints(const mpc_handle *h) { return h ? h->rec_i : 0; }
 int32_t mpc_lds_bytes(const mpc_handle *h, int32_t which) { return !h ? 0 : (which == 0 ? h->lds_v : h->lds_r); }
@@ -900,8 +903,8 @@ static int pruned_add(mpc_handle *h, const uint64_t *masks, int64_t m, hipMemcpy
     if (!h || (m > 0 && !masks) || m < 0) return MPC_ERR_INVALID;
     if (m == 0) return MPC_OK;
     HIP_TRY(h, hipSetDevice(h->device));
-    HIP_TRY(h, h->pruned.ensure((size_t)(h->n_pruned + m) * MPC_MASK_WORDS * sizeof(uint64_t), h->stream, true));
-    HIP_TRY(h, hipMemcpyAsync(h->pruned.as<uint64_t>() + (size_t)h->n_pruned * MPC_MASK_WORDS, masks, (size_t)m * MPC_MASK_WORDS * sizeof(uint64_t), kind, h->stream));
+    HIP_TRY(h, h->pruned.ensure((size_t)(h->n_pruned + m) * h->mw * sizeof(uint64_t), h->stream, true));
+    HIP_TRY(h, hipMemcpyAsync(h->pruned.as<uint64_t>() + (size_t)h->n_pruned * h->mw, masks, (size_t)m * h->mw * sizeof(uint64_t), kind, h->stream));
     if (masks != h->pruned_new.p) HIP_TRY(h, hipStreamSynchronize(h->stream));  // caller-owned source
     h->n_pruned += m;
     return MPC_OK;
@@ -914,7 +917,7 @@ int mpc_pruned_get(mpc_handle *h, uint64_t *masks, int64_t cap) {
     if (cap < h->n_pruned) return fail(h, MPC_ERR_CAPACITY, "pruned buffer too small");
     if (h->n_pruned > 0) {
         HIP_TRY(h, hipSetDevice(h->device));
-        HIP_TRY(h, hipMemcpyAsync(masks, h->pruned.p, (size_t)h->n_pruned * MPC_MASK_WORDS * sizeof(uint64_t), hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(h, hipMemcpyAsync(masks, h->pruned.p, (size_t)h->n_pruned * h->mw * sizeof(uint64_t), hipMemcpyDeviceToHost, h->stream));
         HIP_TRY(h, hipStreamSynchronize(h->stream));
     }
     return MPC_OK;
@@ -996,7 +999,7 @@ static int level_run_impl(mpc_handle *h, int32_t gen_children, int32_t flags, mp
         HIP_TRY(h, h->flag.ensure(nn * sizeof(int32_t), st));
         HIP_TRY(h, h->pos.ensure(nn * sizeof(int32_t), st));
         HIP_TRY(h, h->opt_list.ensure(nn * sizeof(int32_t), st));
-        HIP_TRY(h, h->pruned_new.ensure(nn * MPC_MASK_WORDS * sizeof(uint64_t), st));
+        HIP_TRY(h, h->pruned_new.ensure(nn * h->mw * sizeof(uint64_t), st));
         HIP_TRY(h, hipMemsetAsync(h->ctr.p, 0, sizeof(LevelCounters), st));
         LevelCounters *ctr = h->ctr.as<LevelCounters>();
         int32_t *total = h->tot_dev;          // device alias of h->tot_host: valid on the host after the next synchronisation
@@ -1320,14 +1323,18 @@ static int level_run_impl(mpc_handle *h, int32_t gen_children, int32_t flags, mp
         }
         HIP_TRY(h, hipEventRecord(h->ev[2], st));
         // pruned masks of this level + children
-        hipLaunchKernelGGL(k_pruned_append, dim3(blocks256), dim3(256), 0, st, h->frontier.as<int32_t>(), n, k, h->status.as<uint8_t>(),
-                           h->pruned_new.as<unsigned long long>(), ctr);
+        if (h->mw == 2) hipLaunchKernelGGL(k_pruned_append<2>, dim3(blocks256), dim3(256), 0, st, h->frontier.as<int32_t>(), n, k, h->status.as<uint8_t>(),
+                                           h->pruned_new.as<unsigned long long>(), ctr);
+        else hipLaunchKernelGGL(k_pruned_append<4>, dim3(blocks256), dim3(256), 0, st, h->frontier.as<int32_t>(), n, k, h->status.as<uint8_t>(),
+                                h->pruned_new.as<unsigned long long>(), ctr);
         if (gen_children) {
-            HIP_TRY(h, h->childmask.ensure(nn * 2 * sizeof(uint64_t), st));
+            HIP_TRY(h, h->childmask.ensure(nn * h->mw * sizeof(uint64_t), st));
             HIP_TRY(h, h->count.ensure(nn * sizeof(int32_t), st));
             HIP_TRY(h, h->offset.ensure(nn * sizeof(int32_t), st));
-            hipLaunchKernelGGL(k_children_count, dim3((unsigned)n), dim3(64), 0, st, h->Pv, h->frontier.as<int32_t>(), n, k, h->status.as<uint8_t>(),
-                               h->pruned.as<unsigned long long>(), (long long)h->n_pruned, h->childmask.as<unsigned long long>(), h->count.as<int32_t>());
+            if (h->mw == 2) hipLaunchKernelGGL(k_children_count<2>, dim3((unsigned)n), dim3(64), 0, st, h->Pv, h->frontier.as<int32_t>(), n, k, h->status.as<uint8_t>(),
+                                               h->pruned.as<unsigned long long>(), (long long)h->n_pruned, h->childmask.as<unsigned long long>(), h->count.as<int32_t>());
+            else hipLaunchKernelGGL(k_children_count<4>, dim3((unsigned)n), dim3(64), 0, st, h->Pv, h->frontier.as<int32_t>(), n, k, h->status.as<uint8_t>(),
+                                    h->pruned.as<unsigned long long>(), (long long)h->n_pruned, h->childmask.as<unsigned long long>(), h->count.as<int32_t>());
             { int rcs = launch_scan(h, h->count.as<int32_t>(), h->offset.as<int32_t>(), n, total); if (rcs) return rcs; }
             HIP_TRY(h, hipGetLastError());
             HIP_TRY(h, hipStreamSynchronize(st));
@@ -1336,7 +1343,7 @@ static int level_run_impl(mpc_handle *h, int32_t gen_children, int32_t flags, mp
             if (n_children > 0) {
                 HIP_TRY(h, h->children.ensure((size_t)n_children * (k + 1) * sizeof(int32_t), st));
                 HIP_TRY(h, h->parent_slot_next.ensure((size_t)n_children * sizeof(int32_t), st));
-                hipLaunchKernelGGL(k_children_write, dim3((unsigned)n), dim3(64), 0, st, h->frontier.as<int32_t>(), n, k,
+                hipLaunchKernelGGL(k_children_write, dim3((unsigned)n), dim3(64), 0, st, h->frontier.as<int32_t>(), n, k, h->mw,
                                    h->childmask.as<unsigned long long>(), h->offset.as<int32_t>(), h->children.as<int32_t>(),
                                    h->storing ? h->dict_stored[h->dict_cur].as<uint8_t>() : (const uint8_t *)nullptr, h->parent_slot_next.as<int32_t>());
                 HIP_TRY(h, hipGetLastError());
@@ -1809,7 +1816,7 @@ int mpc_level_pruned_new(mpc_handle *h, uint64_t *out, int64_t cap) {
     if (!h || (!out && cap > 0)) return MPC_ERR_INVALID;
     if (!h->level_done) return fail(h, MPC_ERR_STATE, "mpc_level_run has not been called for this frontier");
     if (cap < h->n_pruned_new) return fail(h, MPC_ERR_CAPACITY, "pruned buffer too small");
-    return copy_out(h, out, h->pruned_new.p, (size_t)h->n_pruned_new * MPC_MASK_WORDS * sizeof(uint64_t), hipMemcpyDeviceToHost);
+    return copy_out(h, out, h->pruned_new.p, (size_t)h->n_pruned_new * h->mw * sizeof(uint64_t), hipMemcpyDeviceToHost);
 }
 int mpc_level_regions_device(mpc_handle *h, double *head_d_dev, int32_t *head_i_dev, double *erows_dev, int64_t cap_slots,
                              int64_t cap_rows, int64_t *n_slots, int64_t *n_rows) {
@@ -1838,7 +1845,7 @@ int mpc_level_pruned_new_device(mpc_handle *h, uint64_t *out, int64_t cap) {
     if (!h || (!out && cap > 0)) return MPC_ERR_INVALID;
     if (!h->level_done) return fail(h, MPC_ERR_STATE, "mpc_level_run has not been called for this frontier");
     if (cap < h->n_pruned_new) return fail(h, MPC_ERR_CAPACITY, "pruned buffer too small");
-    return copy_out(h, out, h->pruned_new.p, (size_t)h->n_pruned_new * MPC_MASK_WORDS * sizeof(uint64_t), hipMemcpyDeviceToDevice);
+    return copy_out(h, out, h->pruned_new.p, (size_t)h->n_pruned_new * h->mw * sizeof(uint64_t), hipMemcpyDeviceToDevice);
 }
 
 int mpc_frontier_advance(mpc_handle *h) {

@@ -81,7 +81,7 @@ class HipLevelEngine:
 
     def pruned_new(self) -> torch.Tensor:
         m = int(self._stats.n_pruned_new)
-        out = self._fresh((m, 2), torch.int64)
+        out = self._fresh((m, self.eng.mask_words), torch.int64)
         if m:
             self.eng.level_pruned_new_device(out.data_ptr(), m)
         return out

@@ -654,3 +654,69 @@ def test_streamed_regions_equal_fetched_regions(name):
         assert r1.regular_set == r2.regular_set
         for fld in ('A', 'b', 'C', 'd', 'E', 'f'):
             assert numpy.array_equal(getattr(r1, fld), getattr(r2, fld)), fld
+
+
+def test_more_than_128_constraints(oracle):
+    """n_c = 140 (> 128): active sets and pruned sets are four-word masks (mpc_mask_words == 4) and the program runs on the
+    LDS-engine kernels (more rows than the register engine holds).  140 planes tangent to a sphere, none redundant.
+    Levels 1-2: every verdict against the oracle; the children of level 2 (superset pruning through the masks) equal the
+    oracle's generate_children_sets + CombinationTester; level 3: a strided sample of verdicts and every sampled region."""
+    from ppopt_amd import MPQP_Program, _lib
+    from ppopt_amd.region_batch import RegionBatch
+    n = 140
+    i = numpy.arange(n) + 0.5
+    phi, z = numpy.pi * (1 + 5 ** 0.5) * i, 1 - 2 * i / n
+    r = numpy.sqrt(1 - z * z)
+    A = numpy.stack([r * numpy.cos(phi), r * numpy.sin(phi), z], axis=1)
+    rng = numpy.random.default_rng(11)
+    F = 0.05 * rng.standard_normal((n, 2))
+    A_t = numpy.vstack([numpy.eye(2), -numpy.eye(2)])
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        prog = MPQP_Program(A, numpy.ones((n, 1)), rng.standard_normal((3, 1)), rng.standard_normal((3, 2)), numpy.eye(3), A_t,
+                            numpy.ones((4, 1)), F)
+    assert prog.num_constraints() == n       # presolve keeps every tangent plane
+    eng = prog.engine()
+    assert eng.mask_words == 4
+    P = oracle.OracleProblem(prog.A, prog.b, prog.F, prog.c, prog.H, prog.Q, prog.A_t, prog.b_t, 0)
+    eng.pruned_clear()
+    eng.frontier_root()
+    pruned = []
+    for depth in range(3):
+        gen = depth != 2
+        st = eng.level_run(gen)
+        cands, status = eng.frontier_get(), eng.level_status()
+        if depth < 2:
+            ostat, _ = P.check_level(cands, 0, True)
+            bad = numpy.flatnonzero(ostat != status)
+            assert all(is_knife_edge(P, cands[j].tolist()) for j in bad) and len(bad) <= 2, (depth, len(bad))
+            kids = eng.level_children()
+            # reference semantics: the children are filtered with the pruned sets of the PREVIOUS levels only
+            want = P.generate_children(cands, status, pruned, mplp_filter=False)
+            assert numpy.array_equal(kids, want), depth
+            new = _lib.masks_to_sets(eng.level_pruned_new(), 4)
+            assert sorted(new) == sorted(tuple(c) for c, v in zip(cands.tolist(), status.tolist()) if v in (0, 2))
+            pruned.extend(new)
+            if depth == 1:
+                assert any(max(p) >= 128 for p in pruned)        # the upper mask words are really in use
+        else:
+            idx = numpy.unique(numpy.concatenate([numpy.linspace(0, len(cands) - 1, 1500).astype(numpy.int64),
+                                                  numpy.flatnonzero(status == 3)[::7]]))
+            ostat, orecs = P.check_level(numpy.ascontiguousarray(cands[idx]), 0, True)
+            hd, hi, er, kk, slots = eng.level_regions_slots()
+            mine = {tuple(q.active_set): q for q in RegionBatch(hd, hi, er, eng.n_x, eng.n_t, eng.n_c, eng.n_tc, kk, slots).regions()}
+            mism = 0
+            for j, (c, v, ov) in enumerate(zip(cands[idx].tolist(), status[idx].tolist(), ostat.tolist())):
+                if v != ov:
+                    assert is_knife_edge(P, c), (c, v, ov)
+                    mism += 1
+                elif v == 3:
+                    q, rr = orecs[j], mine[tuple(c)]
+                    for fld in ('A', 'b', 'C', 'd'):
+                        assert rel_err(getattr(rr, fld), q[fld]) <= COEF_TOL, (c, fld)
+                    if rr.omega_set == q['omega_set'] and rr.lambda_set == q['lambda_set'] and rr.regular_set == q['regular_set']:
+                        assert rows_match(rr.E, rr.f, q['E'], q['f'], COEF_TOL), c
+            assert mism <= 3 and (status == 3).sum() > 20
+        if gen:
+            eng.frontier_advance()
+    prog.release_engine()
