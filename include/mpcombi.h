@@ -137,6 +137,7 @@ int mpc_pruned_get(mpc_handle *h, uint64_t *masks_host, int64_t cap);
  * Sets pruned by this level become visible to child generation only after mpc_frontier_advance, which is the
  * reference's worker semantics (workers hold the murder_list of the previous levels, driver :110-131). */
 int mpc_level_run(mpc_handle *h, int32_t gen_children, mpc_level_stats *stats);
+int mpc_level_run_ex(mpc_handle *h, int32_t gen_children, int32_t flags, mpc_level_stats *stats);   /* flags: MPC_LEVEL_GRAPH */
 int mpc_level_status(mpc_handle *h, uint8_t *status_host);                       /* n bytes, frontier order */
 /* The same level driven by the handle's worker thread: mpc_level_start returns at once, mpc_level_wait joins it and returns
  * what mpc_level_run would have returned.  Between the two only mpc_level_stream_info / mpc_level_chunk_wait may be called
@@ -156,6 +157,12 @@ int mpc_level_status(mpc_handle *h, uint8_t *status_host);                      
  *                          re-solved by the LDS-engine kernel (their head_i[0] was MPC_STREAM_RETRY while streaming); rows
  *                          are appended behind stats.n_region_rows, *n_rows = rows in use afterwards. */
 #define MPC_LEVEL_STREAM 1
+/* MPC_LEVEL_GRAPH (gen_children must be 0): the question of the connected-graph traversals (mp_solvers/mpqp_combi_graph.py:
+ * 48-66, feasability_check) instead of full_process -- rank test, KKT solve, "is the critical region non-empty" (the theta
+ * LP over multiplier, slack and A_t rows), region.  The (x,theta) feasibility LP is not posed.  Statuses: MPC_INFEASIBLE =
+ * rank deficient, MPC_FEASIBLE = full rank, empty region, MPC_OPTIMAL_NO_REGION = non-empty but lower dimensional,
+ * MPC_REGION.  Nothing is appended to the pruned list. */
+#define MPC_LEVEL_GRAPH 4
 #define MPC_STREAM_RETRY 7
 int mpc_level_start(mpc_handle *h, int32_t gen_children, int32_t flags);
 int mpc_level_stream_info(mpc_handle *h, double **head_d, int32_t **head_i, double **erows, int64_t *n_slots, int64_t *cap_rows,

@@ -15,7 +15,7 @@ LIB_PATH = os.environ.get('MPC_LIB_PATH') or os.path.join(_HERE, 'csrc', 'libmpc
 
 MPC_OK, MPC_ERR_INVALID, MPC_ERR_HIP, MPC_ERR_CAPACITY, MPC_ERR_STATE = range(5)
 MPC_LOCATE_OVERLAPPING, MPC_LOCATE_INCLUSIVE = 1, 2   # flags of mpc_locator_query
-MPC_LEVEL_STREAM = 1                                   # flag of mpc_level_start
+MPC_LEVEL_STREAM, MPC_LEVEL_GRAPH = 1, 4               # flags of mpc_level_start / mpc_level_run_ex
 INFEASIBLE, FEASIBLE, OPTIMAL_NO_REGION, REGION, SINGULAR_KKT, LP_LIMIT = range(6)
 LP_OPTIMAL, LP_INFEASIBLE, LP_UNBOUNDED, LP_ITERLIMIT = range(4)
 MASK_WORDS = 2
@@ -86,6 +86,7 @@ def load():
         'mpc_pruned_count': (ctypes.c_int64, [H]),
         'mpc_pruned_get': (ctypes.c_int, [H, _u64p, ctypes.c_int64]),
         'mpc_level_run': (ctypes.c_int, [H, ctypes.c_int32, ctypes.POINTER(LevelStats)]),
+        'mpc_level_run_ex': (ctypes.c_int, [H, ctypes.c_int32, ctypes.c_int32, ctypes.POINTER(LevelStats)]),
         'mpc_level_status': (ctypes.c_int, [H, _u8p]),
         'mpc_level_start': (ctypes.c_int, [H, ctypes.c_int32, ctypes.c_int32]),
         'mpc_level_stream_info': (ctypes.c_int, [H, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_void_p),
@@ -133,7 +134,7 @@ EXPORTED_SYMBOLS = ['mpc_device_count', 'mpc_version', 'mpc_last_global_error', 
                     'mpc_last_error', 'mpc_mask_words', 'mpc_region_doubles', 'mpc_region_ints', 'mpc_lds_bytes', 'mpc_stream',
                     'mpc_frontier_root', 'mpc_frontier_set', 'mpc_frontier_set_device', 'mpc_frontier_info',
                     'mpc_frontier_get', 'mpc_pruned_clear', 'mpc_pruned_add', 'mpc_pruned_add_device',
-                    'mpc_pruned_count', 'mpc_pruned_get', 'mpc_level_run', 'mpc_level_status', 'mpc_level_start', 'mpc_level_stream_info', 'mpc_level_chunk_wait', 'mpc_level_wait', 'mpc_level_stream_fixup', 'mpc_level_regions', 'mpc_compact_strides',
+                    'mpc_pruned_count', 'mpc_pruned_get', 'mpc_level_run', 'mpc_level_run_ex', 'mpc_level_status', 'mpc_level_start', 'mpc_level_stream_info', 'mpc_level_chunk_wait', 'mpc_level_wait', 'mpc_level_stream_fixup', 'mpc_level_regions', 'mpc_compact_strides',
                     'mpc_level_regions_compact', 'mpc_frontier_shard', 'mpc_level_slots', 'mpc_level_regions_slots', 'mpc_level_regions_slots_async', 'mpc_sync', 'mpc_host_alloc', 'mpc_host_free', 'mpc_locator_create', 'mpc_locator_query', 'mpc_locator_destroy', 'mpc_level_children', 'mpc_level_children_device', 'mpc_level_pruned_new',
                     'mpc_level_pruned_new_device', 'mpc_level_regions_device', 'mpc_frontier_advance', 'mpc_check_level', 'mpc_lp_solve_batch']
 
@@ -297,9 +298,11 @@ class Engine:
         return out
 
     # -- one level --------------------------------------------------------------------------------------------------
-    def level_run(self, gen_children: bool) -> LevelStats:
+    def level_run(self, gen_children: bool, graph: bool = False) -> LevelStats:
+        """One level over the resident frontier.  ``graph``: the question of the connected-graph traversal (MPC_LEVEL_GRAPH)."""
         st = LevelStats()
-        self._check(self._L.mpc_level_run(self._h, int(bool(gen_children)), ctypes.byref(st)), 'mpc_level_run')
+        self._check(self._L.mpc_level_run_ex(self._h, int(bool(gen_children)), MPC_LEVEL_GRAPH if graph else 0, ctypes.byref(st)),
+                    'mpc_level_run')
         self._last = st
         return st
 

@@ -911,6 +911,12 @@ __global__ void k_pruned_append(const int32_t *__restrict__ cands, long long n, 
     for (int w = 0; w < MW; ++w) out[MW * (size_t)pos + w] = p[w];
 }
 
+// graph mode (MPC_LEVEL_GRAPH): the (x,theta) feasibility question is not posed -- "feasibility open" becomes "no region"
+__global__ void k_close_open(const int32_t *__restrict__ list, int n_list, uint8_t *__restrict__ status) {
+    const int w = blockIdx.x * blockDim.x + threadIdx.x;
+    if (w < n_list) { const int c = list[w]; status[c] = (uint8_t)(status[c] == 9 ? ST_SINGULAR : ST_FEASIBLE); }   // 9 = ST_NEEDX_SING
+}
+
 // status[list[w]] = tmp[list[w]]  (results of a retry kernel that ran on a side stream)
 __global__ void k_apply_status(const int32_t *__restrict__ list, int n_list, const uint8_t *__restrict__ tmp, uint8_t *__restrict__ status) {
     const int w = blockIdx.x * blockDim.x + threadIdx.x;

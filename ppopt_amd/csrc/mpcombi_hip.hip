@@ -1158,6 +1158,13 @@ static int level_run_impl(mpc_handle *h, int32_t gen_children, int32_t flags, mp
             int32_t n_needx = cntA[3];
             const int32_t *needx_list = part_list(3);
             h->n_needx = n_needx;
+            if ((flags & MPC_LEVEL_GRAPH) && n_needx > 0) {
+                // connected-graph traversal: only "is the critical region non-empty" is asked; the candidates whose theta stage
+                // left feasibility open simply have no region
+                hipLaunchKernelGGL(k_close_open, dim3((unsigned)((n_needx + 255) / 256)), dim3(256), 0, st, needx_list, (int)n_needx, stp);
+                HIP_TRY(h, hipGetLastError());
+                n_needx = 0;
+            }
             if (n_needx > 0 && !h->storing && dc.parent_slot && !h->no_xquick) {
                 // last level: decisions only -- the quick test on three vectors of the parent's dictionary first
                 DictCache dq = dc;
@@ -1323,7 +1330,8 @@ static int level_run_impl(mpc_handle *h, int32_t gen_children, int32_t flags, mp
         }
         HIP_TRY(h, hipEventRecord(h->ev[2], st));
         // pruned masks of this level + children
-        if (h->mw == 2) hipLaunchKernelGGL(k_pruned_append<2>, dim3(blocks256), dim3(256), 0, st, h->frontier.as<int32_t>(), n, k, h->status.as<uint8_t>(),
+        if (flags & MPC_LEVEL_GRAPH) { /* no pruning in the graph traversal */ }
+        else if (h->mw == 2) hipLaunchKernelGGL(k_pruned_append<2>, dim3(blocks256), dim3(256), 0, st, h->frontier.as<int32_t>(), n, k, h->status.as<uint8_t>(),
                                            h->pruned_new.as<unsigned long long>(), ctr);
         else hipLaunchKernelGGL(k_pruned_append<4>, dim3(blocks256), dim3(256), 0, st, h->frontier.as<int32_t>(), n, k, h->status.as<uint8_t>(),
                                 h->pruned_new.as<unsigned long long>(), ctr);
@@ -1402,10 +1410,12 @@ static int level_run_impl(mpc_handle *h, int32_t gen_children, int32_t flags, mp
     return MPC_OK;
 }
 
-int mpc_level_run(mpc_handle *h, int32_t gen_children, mpc_level_stats *stats) {
+int mpc_level_run(mpc_handle *h, int32_t gen_children, mpc_level_stats *stats) { return mpc_level_run_ex(h, gen_children, 0, stats); }
+int mpc_level_run_ex(mpc_handle *h, int32_t gen_children, int32_t flags, mpc_level_stats *stats) {
     if (!h) return MPC_ERR_INVALID;
+    if ((flags & MPC_LEVEL_GRAPH) && gen_children) return fail(h, MPC_ERR_INVALID, "MPC_LEVEL_GRAPH has no children");
     { std::lock_guard<std::mutex> lk(h->wm); if (h->w_busy) return fail(h, MPC_ERR_STATE, "a level started with mpc_level_start is still running"); }
-    return level_run_impl(h, gen_children, 0, stats);
+    return level_run_impl(h, gen_children, flags & ~MPC_LEVEL_STREAM, stats);
 }
 
 // ---- the same level, driven by the handle's worker thread ---------------------------------------------------------------

@@ -2,8 +2,10 @@
 
 The enum keeps every member of the reference's ``mpqp_algorithm`` so that user code keeps importing and selecting
 algorithms the same way.  The three combinatorial members run on the MI355X (they differ in the reference only in
-how the CPU work is scheduled and pruned; all give the same region set); the graph and geometric
-members are other algorithms, outside the scope of this package, and raise ``NotImplementedError``.
+how the CPU work is scheduled and pruned; all give the same region set), and so does
+``combinatorial_graph`` and the four ``graph`` members (the connected-graph traversals of mpqp_combi_graph.py and
+mpqp_graph.py on the same device kernels, mpqp_hip_combi_graph.py; mpQPs only); the geometric members need a QP solver,
+are outside the scope of this package, and raise ``NotImplementedError``.
 """
 from enum import Enum
 
@@ -12,7 +14,7 @@ import numpy
 from ..mplp_program import MPLP_Program
 from ..mpqp_program import MPQP_Program
 from ..solution import Solution
-from . import mpqp_hip_combinatorial
+from . import mpqp_hip_combi_graph, mpqp_hip_combinatorial
 
 
 class mpqp_algorithm(Enum):
@@ -38,6 +40,7 @@ class mpqp_algorithm(Enum):
 
 _COMBINATORIAL = (mpqp_algorithm.combinatorial, mpqp_algorithm.combinatorial_parallel,
                   mpqp_algorithm.combinatorial_parallel_exp)
+_GRAPH = (mpqp_algorithm.graph, mpqp_algorithm.graph_exp, mpqp_algorithm.graph_parallel, mpqp_algorithm.graph_parallel_exp)
 
 
 def solve_mpqp(problem: MPQP_Program, algorithm: mpqp_algorithm = mpqp_algorithm.combinatorial) -> Solution:
@@ -45,11 +48,17 @@ def solve_mpqp(problem: MPQP_Program, algorithm: mpqp_algorithm = mpqp_algorithm
         raise TypeError('You must pass an algorithm from mpqp_algorithm as the continuous algorithm. These can be '
                         'found by importing the following \n\nfrom ppopt_amd.mp_solvers.solve_mpqp import '
                         f'mpqp_algorithm\n\nWith the following choices\n{mpqp_algorithm.all_algos()}')
-    if algorithm not in _COMBINATORIAL:
-        raise NotImplementedError(f'{algorithm} is not part of the MI355X combinatorial path; use one of '
-                                  f'{[str(a) for a in _COMBINATORIAL]}')
     # the device the program's presolve LPs ran on (Solver(device=...)) is the device the solve runs on
-    solution = mpqp_hip_combinatorial.solve(problem, device=int(getattr(getattr(problem, 'solver', None), 'device', 0) or 0))
+    device = int(getattr(getattr(problem, 'solver', None), 'device', 0) or 0)
+    if algorithm is mpqp_algorithm.combinatorial_graph:
+        solution = mpqp_hip_combi_graph.solve(problem, device=device)
+    elif algorithm in _GRAPH:
+        solution = mpqp_hip_combi_graph.solve_graph(problem, device=device)
+    elif algorithm not in _COMBINATORIAL:
+        raise NotImplementedError(f'{algorithm} is not part of the MI355X combinatorial path; use one of '
+                                  f'{[str(a) for a in (*_COMBINATORIAL, mpqp_algorithm.combinatorial_graph, *_GRAPH)]}')
+    else:
+        solution = mpqp_hip_combinatorial.solve(problem, device=device)
     # overlap flags exactly as the reference sets them (solve_mpqp.py:103-112)
     if isinstance(problem, MPQP_Program) and min(numpy.linalg.eigvalsh(problem.Q)) <= 0:
         solution.is_overlapping = True

@@ -720,3 +720,48 @@ def test_more_than_128_constraints(oracle):
         if gen:
             eng.frontier_advance()
     prog.release_engine()
+
+
+@pytest.mark.parametrize('name', ['transport_mpqp', 'dblint_n3', 'c2_dblint_n5', 'rand_4_2_10_s0', 'rand_5_3_8_s3', 'rand_6_3_12_s1',
+                                  'quadtank_n2', 'quadtank_n3'])
+def test_connected_graph_traversal_finds_the_same_regions(name):
+    """mpqp_algorithm.combinatorial_graph (reference: mpqp_combi_graph.py, the connected-graph traversal) on the device: the
+    same region set as the complete combinatorial solve of the golden file -- same active sets, coefficients within 1e-8,
+    same facet rows -- while examining far fewer active sets than the combinatorial tree has."""
+    from ppopt_amd import Solver
+    from ppopt_amd.mp_solvers import mpqp_hip_combi_graph
+    from ppopt_amd.mp_solvers.solve_mpqp import mpqp_algorithm, solve_mpqp
+    from test_host_logic import build_program
+    g = load_golden(name)
+    assert bool(g['complete'])
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        prog = build_program(g, Solver())
+    ref = golden_regions(g)
+    prof = []
+    sol = mpqp_hip_combi_graph.solve(prog, profile=prof)
+    got = {tuple(r.active_set): r for r in sol.critical_regions}
+    assert len(got) == len(sol.critical_regions)                 # no region twice
+    assert set(got) == set(ref), (sorted(set(got) ^ set(ref))[:5])
+    for key, r in got.items():
+        q = ref[key]
+        for fld in ('A', 'b', 'C', 'd'):
+            assert rel_err(getattr(r, fld), q[fld]) <= COEF_TOL, (name, key, fld)
+        if r.omega_set == q['omega_set'] and r.lambda_set == q['lambda_set'] and r.regular_set == q['regular_set']:
+            assert rows_match(r.E, r.f, q['E'], q['f'], COEF_TOL), (name, key)
+    assert sum(p['candidates'] for p in prof) > len(ref)
+    # mpqp_algorithm.graph (mpqp_graph.py): moves through facets of full-dimensional regions only; it may miss regions (the
+    # reference says so, mpqp_graph.py:50), but never invents one, and what it finds is identical
+    prof2 = []
+    sol_g = mpqp_hip_combi_graph.solve_graph(prog, profile=prof2)
+    got_g = {tuple(r.active_set): r for r in sol_g.critical_regions}
+    assert len(got_g) == len(sol_g.critical_regions) and set(got_g) <= set(ref)
+    assert len(got_g) >= 0.9 * len(ref), (len(got_g), len(ref))
+    for key, r in got_g.items():
+        for fld in ('A', 'b', 'C', 'd', 'E', 'f'):
+            assert numpy.array_equal(getattr(r, fld), getattr(got[key], fld)), (name, key, fld)
+    print(name, 'regions', len(ref), 'combinatorial tree', sum(len(g[f'L{i}_cands']) for i in range(int(g['n_levels']))),
+          'combinatorial_graph', sum(p['candidates'] for p in prof), 'graph', sum(p['candidates'] for p in prof2), len(got_g))
+    # through the public entry point
+    sol2 = solve_mpqp(prog, mpqp_algorithm.combinatorial_graph)
+    assert sorted(tuple(r.active_set) for r in sol2.critical_regions) == sorted(ref)
