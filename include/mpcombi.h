@@ -220,6 +220,24 @@ int mpc_level_pruned_new_device(mpc_handle *h, uint64_t *masks_dev, int64_t cap)
 /* frontier := children of this level; pruned list += sets pruned by this level  (driver :127-135) */
 int mpc_frontier_advance(mpc_handle *h);
 
+/* ---- connected-graph traversals with the bookkeeping on the device ----------------------------------------------------- */
+/* Reference: mp_solvers/mpqp_combi_graph.py:68-145 (variant 0: sets S / E, explore_subset / explore_superset around every
+ * active set whose critical region is non-empty) and mp_solvers/mpqp_graph.py:38-108 (variant 1: attempted, generate_reduce,
+ * generate_extra through the facet constraints of every full-dimensional region).  The traversal advances a whole WAVE of
+ * active sets at a time; the wave, the set of everything ever queued and the neighbours emitted by the wave stay in HBM as
+ * sorted arrays of masks (mpc_mask_words words each), so the order of the regions is deterministic.
+ *   mpc_graph_begin       seeds (host masks, duplicates allowed) -> first wave
+ *   mpc_graph_wave        the groups of the current wave, one (or, beyond 4M masks, several) per cardinality; n_groups == 0:
+ *                         the traversal is complete
+ *   mpc_graph_group_run   one group = one frontier of the level kernels (MPC_LEVEL_GRAPH verdicts for variant 0, full verdicts
+ *                         for variant 1); afterwards mpc_level_status / mpc_level_regions_slots etc. describe that group; the
+ *                         group's neighbours are appended to the pending list
+ *   mpc_graph_wave_close  pending -> sorted, deduplicated, minus everything queued before = the next wave */
+int mpc_graph_begin(mpc_handle *h, const uint64_t *seed_masks_host, int64_t n_seeds, int32_t variant);
+int mpc_graph_wave(mpc_handle *h, int32_t *k_list, int64_t *count_list, int32_t cap, int32_t *n_groups, int64_t *n_wave, int64_t *n_visited);
+int mpc_graph_group_run(mpc_handle *h, int32_t group, mpc_level_stats *stats);
+int mpc_graph_wave_close(mpc_handle *h, int64_t *n_next, int64_t *n_visited);
+
 /* ---- the batched operator with host buffers (drop-in for pool.map(full_process)) ---------------------- */
 /* Uploads cand (n x k) and the pruned masks (m x mpc_mask_words(h); replaces the handle's list), runs the level
  * and downloads status, regions and children.  On MPC_ERR_CAPACITY *n_regions / *n_children hold the

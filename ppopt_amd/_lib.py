@@ -116,6 +116,10 @@ def load():
         'mpc_level_regions_device': (ctypes.c_int, [H, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64,
                                                     ctypes.c_int64, _lp, _lp]),
         'mpc_frontier_advance': (ctypes.c_int, [H]),
+        'mpc_graph_begin': (ctypes.c_int, [H, _u64p, ctypes.c_int64, ctypes.c_int32]),
+        'mpc_graph_wave': (ctypes.c_int, [H, _ip, _lp, ctypes.c_int32, _ip, _lp, _lp]),
+        'mpc_graph_group_run': (ctypes.c_int, [H, ctypes.c_int32, ctypes.POINTER(LevelStats)]),
+        'mpc_graph_wave_close': (ctypes.c_int, [H, _lp, _lp]),
         'mpc_check_level': (ctypes.c_int, [H, _ip, ctypes.c_int64, ctypes.c_int32, _u64p, ctypes.c_int64, ctypes.c_int32,
                                            _u8p, _lp, _dp, _ip, _lp, ctypes.c_int64, _lp, _ip, ctypes.c_int64]),
         'mpc_lp_solve_batch': (ctypes.c_int, [ctypes.c_int32, ctypes.c_int64, ctypes.c_int32, ctypes.c_int32, _dp,
@@ -136,7 +140,7 @@ EXPORTED_SYMBOLS = ['mpc_device_count', 'mpc_version', 'mpc_last_global_error', 
                     'mpc_frontier_get', 'mpc_pruned_clear', 'mpc_pruned_add', 'mpc_pruned_add_device',
                     'mpc_pruned_count', 'mpc_pruned_get', 'mpc_level_run', 'mpc_level_run_ex', 'mpc_level_status', 'mpc_level_start', 'mpc_level_stream_info', 'mpc_level_chunk_wait', 'mpc_level_wait', 'mpc_level_stream_fixup', 'mpc_level_regions', 'mpc_compact_strides',
                     'mpc_level_regions_compact', 'mpc_frontier_shard', 'mpc_level_slots', 'mpc_level_regions_slots', 'mpc_level_regions_slots_async', 'mpc_sync', 'mpc_host_alloc', 'mpc_host_free', 'mpc_locator_create', 'mpc_locator_query', 'mpc_locator_destroy', 'mpc_level_children', 'mpc_level_children_device', 'mpc_level_pruned_new',
-                    'mpc_level_pruned_new_device', 'mpc_level_regions_device', 'mpc_frontier_advance', 'mpc_check_level', 'mpc_lp_solve_batch']
+                    'mpc_level_pruned_new_device', 'mpc_level_regions_device', 'mpc_frontier_advance', 'mpc_graph_begin', 'mpc_graph_wave', 'mpc_graph_group_run', 'mpc_graph_wave_close', 'mpc_check_level', 'mpc_lp_solve_batch']
 
 
 def pinned_empty(shape, dtype) -> numpy.ndarray:
@@ -341,6 +345,33 @@ class Engine:
         self._check(self._L.mpc_level_stream_fixup(self._h, hd.ctypes.data_as(_dp), hi.ctypes.data_as(_ip), er.ctypes.data_as(_dp),
                                                    ctypes.byref(nrows)), 'mpc_level_stream_fixup')
         return int(nrows.value)
+
+    # -- connected-graph traversal with the bookkeeping on the device (include/mpcombi.h, mpc_graph_*) -------------------
+    def graph_begin(self, seed_masks: numpy.ndarray, variant: int):
+        m = numpy.ascontiguousarray(seed_masks, dtype=numpy.uint64).reshape(-1, self.mask_words)
+        self._check(self._L.mpc_graph_begin(self._h, m.ctypes.data_as(_u64p), len(m), int(variant)), 'mpc_graph_begin')
+
+    def graph_wave(self):
+        """[(cardinality, number of active sets)] of the current wave (empty: the traversal is complete), sets queued so far."""
+        cap = 600
+        ks = numpy.zeros(cap, dtype=numpy.int32)
+        cs = numpy.zeros(cap, dtype=numpy.int64)
+        ng = ctypes.c_int32(0)
+        nw, nv = ctypes.c_int64(0), ctypes.c_int64(0)
+        self._check(self._L.mpc_graph_wave(self._h, ks.ctypes.data_as(_ip), cs.ctypes.data_as(_lp), cap, ctypes.byref(ng), ctypes.byref(nw),
+                                           ctypes.byref(nv)), 'mpc_graph_wave')
+        return list(zip(ks[:ng.value].tolist(), cs[:ng.value].tolist())), int(nv.value)
+
+    def graph_group_run(self, group: int) -> LevelStats:
+        st = LevelStats()
+        self._check(self._L.mpc_graph_group_run(self._h, int(group), ctypes.byref(st)), 'mpc_graph_group_run')
+        self._last = st
+        return st
+
+    def graph_wave_close(self):
+        nn, nv = ctypes.c_int64(0), ctypes.c_int64(0)
+        self._check(self._L.mpc_graph_wave_close(self._h, ctypes.byref(nn), ctypes.byref(nv)), 'mpc_graph_wave_close')
+        return int(nn.value), int(nv.value)
 
     def level_status(self) -> numpy.ndarray:
         n, _ = self.frontier_info()

@@ -25,6 +25,8 @@
 #include "kernels.hpp"
 #include "kernels2.hpp"
 #include "locate.hpp"
+#include "graph.hpp"
+#include <rocprim/device/device_radix_sort.hpp>
 
 using namespace mpc;
 
@@ -303,6 +305,15 @@ struct mpc_handle {
     bool w_busy = false, w_stream_ready = false;
     int w_gen = 0, w_flags = 0, w_rc = 0;
     mpc_level_stats w_stats{};
+    // ---- connected-graph traversal: wave, visited set and pending neighbours resident on the device (graph.hpp) ----------
+    struct GraphState {
+        bool active = false;
+        int variant = 0;                 // 0 combinatorial_graph, 1 graph
+        DevBuf wave, visited, pending, tmp_a, tmp_b, sort_tmp, card, idx, card2, idx2, facet, cnt, off, hist;
+        long long n_wave = 0, n_visited = 0, n_pending = 0;
+        std::vector<int> gk;             // groups of the current wave: cardinality,
+        std::vector<long long> goff, gcnt;   // first mask and number of masks
+    } g;
     hipEvent_t ev_hi = nullptr;   // completion of the head_i copy of an asynchronous slot fetch
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     hipEvent_t kev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // around k_theta2 / the main k_x2 launch / k_region2
@@ -791,6 +802,7 @@ int mpc_destroy(mpc_handle *h) {
     for (HostBuf *b : {&h->st_list, &h->st_status, &h->st_hd, &h->st_hi, &h->st_pool, &h->st_fxd, &h->st_fxi, &h->st_rlist, &h->st_flags}) b->release();
     stream_release(h);
     h->chunk_count.release();
+    for (DevBuf *b : {&h->g.wave, &h->g.visited, &h->g.pending, &h->g.tmp_a, &h->g.tmp_b, &h->g.sort_tmp, &h->g.card, &h->g.idx, &h->g.card2, &h->g.idx2, &h->g.facet, &h->g.cnt, &h->g.off, &h->g.hist}) b->release();
     for (auto &e : h->ev) return_event(e, true);
     for (auto &e : h->kev) return_event(e, true);
     return_event(h->ev_hi, false);
@@ -1876,6 +1888,207 @@ int mpc_frontier_advance(mpc_handle *h) {
     h->level_done = false;
     h->n_children = 0; h->n_pruned_new = 0; h->n_regions = 0; h->n_opt = 0;
     return MPC_OK;
+}
+
+}  // extern "C"
+
+// ---- connected-graph traversal, bookkeeping on the device (graph.hpp) ---------------------------------------------------------
+namespace {
+struct GDec2 { __host__ __device__ rocprim::tuple<unsigned long long &, unsigned long long &> operator()(GMask<2> &k) const {
+    return rocprim::tuple<unsigned long long &, unsigned long long &>(k.w[1], k.w[0]); } };
+struct GDec4 { __host__ __device__ rocprim::tuple<unsigned long long &, unsigned long long &, unsigned long long &, unsigned long long &> operator()(GMask<4> &k) const {
+    return rocprim::tuple<unsigned long long &, unsigned long long &, unsigned long long &, unsigned long long &>(k.w[3], k.w[2], k.w[1], k.w[0]); } };
+template <int MW> struct GDec;
+template <> struct GDec<2> { typedef GDec2 type; };
+template <> struct GDec<4> { typedef GDec4 type; };
+constexpr long long G_CHUNK = 1ll << 22;   // masks per group run (bounds the level buffers and the 32-bit neighbour offsets)
+
+template <int MW>
+int g_sort(mpc_handle *h, const GMask<MW> *in, GMask<MW> *out, long long n) {
+    if (n <= 0) return MPC_OK;
+    size_t bytes = 0;
+    typename GDec<MW>::type dec;
+    HIP_TRY(h, rocprim::radix_sort_keys(nullptr, bytes, const_cast<GMask<MW> *>(in), out, (size_t)n, dec, 0u, 64u * MW, h->stream));
+    HIP_TRY(h, h->g.sort_tmp.ensure(std::max<size_t>(bytes, 16), h->stream));
+    bytes = h->g.sort_tmp.cap;
+    HIP_TRY(h, rocprim::radix_sort_keys(h->g.sort_tmp.p, bytes, const_cast<GMask<MW> *>(in), out, (size_t)n, dec, 0u, 64u * MW, h->stream));
+    return MPC_OK;
+}
+
+// pending (n_pending masks, any order, duplicates) -> next wave (sorted by cardinality, then mask) and visited := visited + new
+template <int MW>
+int g_close(mpc_handle *h) {
+    auto &g = h->g;
+    hipStream_t st = h->stream;
+    const long long n = g.n_pending;
+    g.gk.clear(); g.goff.clear(); g.gcnt.clear();
+    g.n_wave = 0;
+    g.n_pending = 0;
+    if (n == 0) return MPC_OK;
+    typedef GMask<MW> M;
+    const unsigned nb = (unsigned)((n + 255) / 256);
+    HIP_TRY(h, g.tmp_a.ensure((size_t)n * sizeof(M), st));
+    { int rc = g_sort<MW>(h, g.pending.as<M>(), g.tmp_a.as<M>(), n); if (rc) return rc; }
+    HIP_TRY(h, h->flag.ensure((size_t)n * sizeof(int32_t), st));
+    HIP_TRY(h, h->pos.ensure((size_t)n * sizeof(int32_t), st));
+    hipLaunchKernelGGL(k_g_newflags<MW>, dim3(nb), dim3(256), 0, st, g.tmp_a.as<M>(), n, g.visited.as<M>(), g.n_visited, h->flag.as<int32_t>());
+    { int rc = launch_scan(h, h->flag.as<int32_t>(), h->pos.as<int32_t>(), n, h->tot_dev); if (rc) return rc; }
+    HIP_TRY(h, hipGetLastError());
+    HIP_TRY(h, hipStreamSynchronize(st));
+    const long long n_new = h->tot_host[0];
+    if (n_new == 0) return MPC_OK;
+    // visited ++ new, sorted
+    HIP_TRY(h, g.tmp_b.ensure((size_t)(g.n_visited + n_new) * sizeof(M), st));
+    if (g.n_visited > 0) HIP_TRY(h, hipMemcpyAsync(g.tmp_b.p, g.visited.p, (size_t)g.n_visited * sizeof(M), hipMemcpyDeviceToDevice, st));
+    M *fresh = g.tmp_b.as<M>() + g.n_visited;   // the new masks, sorted by mask
+    hipLaunchKernelGGL(k_g_compact<MW>, dim3(nb), dim3(256), 0, st, g.tmp_a.as<M>(), n, h->flag.as<int32_t>(), h->pos.as<int32_t>(), fresh);
+    HIP_TRY(h, hipGetLastError());
+    // next wave: the new masks in (cardinality, mask) order -- a stable sort of their cardinalities carries the permutation
+    const unsigned nbn = (unsigned)((n_new + 255) / 256);
+    for (DevBuf *b : {&g.card, &g.idx, &g.card2, &g.idx2}) HIP_TRY(h, b->ensure((size_t)n_new * sizeof(unsigned int), st));
+    hipLaunchKernelGGL(k_g_card<MW>, dim3(nbn), dim3(256), 0, st, fresh, n_new, g.card.as<unsigned int>(), g.idx.as<unsigned int>());
+    {
+        size_t bytes = 0;
+        HIP_TRY(h, rocprim::radix_sort_pairs(nullptr, bytes, g.card.as<unsigned int>(), g.card2.as<unsigned int>(), g.idx.as<unsigned int>(), g.idx2.as<unsigned int>(),
+                                             (size_t)n_new, 0u, 9u, st));
+        HIP_TRY(h, g.sort_tmp.ensure(std::max<size_t>(bytes, 16), st));
+        bytes = g.sort_tmp.cap;
+        HIP_TRY(h, rocprim::radix_sort_pairs(g.sort_tmp.p, bytes, g.card.as<unsigned int>(), g.card2.as<unsigned int>(), g.idx.as<unsigned int>(), g.idx2.as<unsigned int>(),
+                                             (size_t)n_new, 0u, 9u, st));
+    }
+    HIP_TRY(h, g.wave.ensure((size_t)n_new * sizeof(M), st));
+    hipLaunchKernelGGL(k_g_gather<MW>, dim3(nbn), dim3(256), 0, st, fresh, g.idx2.as<unsigned int>(), n_new, g.wave.as<M>());
+    HIP_TRY(h, g.hist.ensure(257 * sizeof(int32_t), st));
+    HIP_TRY(h, hipMemsetAsync(g.hist.p, 0, 257 * sizeof(int32_t), st));
+    hipLaunchKernelGGL(k_g_hist, dim3(nbn), dim3(256), 0, st, g.card2.as<unsigned int>(), n_new, g.hist.as<int32_t>());
+    HIP_TRY(h, hipGetLastError());
+    int32_t hist[257];
+    HIP_TRY(h, hipMemcpyAsync(hist, g.hist.p, sizeof(hist), hipMemcpyDeviceToHost, st));
+    // visited := sort(visited ++ new)   (tmp_b -> visited)
+    HIP_TRY(h, g.visited.ensure((size_t)(g.n_visited + n_new) * sizeof(M), st));
+    { int rc = g_sort<MW>(h, g.tmp_b.as<M>(), g.visited.as<M>(), g.n_visited + n_new); if (rc) return rc; }
+    HIP_TRY(h, hipStreamSynchronize(st));
+    g.n_visited += n_new;
+    g.n_wave = n_new;
+    long long off = 0;
+    for (int k = 0; k <= 256; ++k) {
+        long long c = hist[k];
+        while (c > 0) { const long long take = std::min(c, G_CHUNK); g.gk.push_back(k); g.goff.push_back(off); g.gcnt.push_back(take); off += take; c -= take; }
+    }
+    return MPC_OK;
+}
+
+template <int MW>
+int g_group_run(mpc_handle *h, int gi, mpc_level_stats *stats) {
+    auto &g = h->g;
+    typedef GMask<MW> M;
+    hipStream_t st = h->stream;
+    const int k = g.gk[gi];
+    const long long off = g.goff[gi], cnt = g.gcnt[gi];
+    const M *masks = g.wave.as<M>() + off;
+    const unsigned nb = (unsigned)((cnt + 255) / 256);
+    const bool too_many_rows = k > std::min(h->n_x, h->n_c);   // more rows than variables: rank deficient by counting (is_full_rank)
+    mpc_level_stats ls;
+    std::memset(&ls, 0, sizeof(ls));
+    ls.n = cnt; ls.k = k;
+    if (too_many_rows) ls.n_status[ST_INFEASIBLE] = cnt;
+    else {
+        int rc = frontier_reset(h, cnt, k);
+        if (rc) return rc;
+        if (k > 0) hipLaunchKernelGGL(k_g_frontier<MW>, dim3(nb), dim3(256), 0, st, masks, cnt, k, h->frontier.as<int32_t>());
+        HIP_TRY(h, hipGetLastError());
+        rc = level_run_impl(h, 0, g.variant == 0 ? MPC_LEVEL_GRAPH : 0, &ls);
+        if (rc) return rc;
+    }
+    if (stats) *stats = ls;
+    // facet constraints of the regions (variant 1)
+    const M *facet = nullptr;
+    if (g.variant == 1 && !too_many_rows && ls.n_regions > 0) {
+        HIP_TRY(h, g.facet.ensure((size_t)cnt * sizeof(M), st));
+        HIP_TRY(h, hipMemsetAsync(g.facet.p, 0, (size_t)cnt * sizeof(M), st));
+        if (h->used_region2 && h->n_opt > 0)
+            hipLaunchKernelGGL(k_g_facets_slots<MW>, dim3((unsigned)((h->n_opt + 255) / 256)), dim3(256), 0, st, h->headi.as<int32_t>(), h->fi, h->n_opt, k, h->n_c,
+                               h->n_tc, g.facet.as<M>());
+        const int32_t *list = h->used_region2 ? h->retry_list.as<int32_t>() : h->opt_ptr;
+        const long long n_list = h->used_region2 ? h->n_rretry : h->n_opt;
+        if (n_list > 0)
+            hipLaunchKernelGGL(k_g_facets_fixed<MW>, dim3((unsigned)((n_list + 255) / 256)), dim3(256), 0, st, h->reci.as<int32_t>(), h->rec_i, list, n_list,
+                               h->status.as<uint8_t>(), h->n_c, h->n_tc, g.facet.as<M>());
+        HIP_TRY(h, hipGetLastError());
+        facet = g.facet.as<M>();
+    } else if (g.variant == 1) {
+        HIP_TRY(h, g.facet.ensure((size_t)cnt * sizeof(M), st));
+        HIP_TRY(h, hipMemsetAsync(g.facet.p, 0, (size_t)cnt * sizeof(M), st));
+        facet = g.facet.as<M>();
+    }
+    // neighbours: count -> scan -> emit behind what the earlier groups of this wave have emitted
+    M eq, all;
+    for (int j = 0; j < MW; ++j) { eq.w[j] = 0; all.w[j] = 0; }
+    for (int i = 0; i < h->n_eq; ++i) eq.w[i >> 6] |= 1ull << (i & 63);
+    for (int i = 0; i < h->n_c; ++i) all.w[i >> 6] |= 1ull << (i & 63);
+    const uint8_t *status = too_many_rows ? nullptr : h->status.as<uint8_t>();
+    HIP_TRY(h, g.cnt.ensure((size_t)cnt * sizeof(int32_t), st));
+    HIP_TRY(h, g.off.ensure((size_t)cnt * sizeof(int32_t), st));
+    hipLaunchKernelGGL(k_g_count<MW>, dim3(nb), dim3(256), 0, st, masks, cnt, status, (int)ST_INFEASIBLE, g.variant, eq, all, facet, g.cnt.as<int32_t>());
+    { int rc = launch_scan(h, g.cnt.as<int32_t>(), g.off.as<int32_t>(), cnt, h->tot_dev); if (rc) return rc; }
+    HIP_TRY(h, hipGetLastError());
+    HIP_TRY(h, hipStreamSynchronize(st));
+    const long long total = h->tot_host[0];
+    if (total > 0) {
+        HIP_TRY(h, g.pending.ensure((size_t)(g.n_pending + total) * sizeof(M), st, true));
+        hipLaunchKernelGGL(k_g_emit<MW>, dim3(nb), dim3(256), 0, st, masks, cnt, status, (int)ST_INFEASIBLE, g.variant, eq, all, facet, g.off.as<int32_t>(),
+                           g.pending.as<M>() + g.n_pending);
+        HIP_TRY(h, hipGetLastError());
+        g.n_pending += total;
+    }
+    return MPC_OK;
+}
+}  // namespace
+
+extern "C" {
+
+int mpc_graph_begin(mpc_handle *h, const uint64_t *seed_masks, int64_t n_seeds, int32_t variant) {
+    if (!h || (n_seeds > 0 && !seed_masks) || n_seeds < 0 || variant < 0 || variant > 1) return MPC_ERR_INVALID;
+    { std::lock_guard<std::mutex> lk(h->wm); if (h->w_busy) return fail(h, MPC_ERR_STATE, "a level started with mpc_level_start is still running"); }
+    HIP_TRY(h, hipSetDevice(h->device));
+    auto &g = h->g;
+    g.active = true; g.variant = variant; g.n_wave = g.n_visited = 0; g.n_pending = n_seeds;
+    if (n_seeds > 0) {
+        HIP_TRY(h, g.pending.ensure((size_t)n_seeds * h->mw * sizeof(uint64_t), h->stream));
+        HIP_TRY(h, hipMemcpyAsync(g.pending.p, seed_masks, (size_t)n_seeds * h->mw * sizeof(uint64_t), hipMemcpyHostToDevice, h->stream));
+        HIP_TRY(h, hipStreamSynchronize(h->stream));
+    }
+    return h->mw == 2 ? g_close<2>(h) : g_close<4>(h);
+}
+
+int mpc_graph_wave(mpc_handle *h, int32_t *k_list, int64_t *count_list, int32_t cap, int32_t *n_groups, int64_t *n_wave, int64_t *n_visited) {
+    if (!h || !n_groups) return MPC_ERR_INVALID;
+    if (!h->g.active) return fail(h, MPC_ERR_STATE, "mpc_graph_begin has not been called");
+    const int ng = (int)h->g.gk.size();
+    *n_groups = ng;
+    if (n_wave) *n_wave = h->g.n_wave;
+    if (n_visited) *n_visited = h->g.n_visited;
+    if (cap < ng) return ng == 0 ? MPC_OK : fail(h, MPC_ERR_CAPACITY, "group arrays too small");
+    for (int i = 0; i < ng; ++i) { if (k_list) k_list[i] = h->g.gk[i]; if (count_list) count_list[i] = h->g.gcnt[i]; }
+    return MPC_OK;
+}
+
+int mpc_graph_group_run(mpc_handle *h, int32_t group, mpc_level_stats *stats) {
+    if (!h) return MPC_ERR_INVALID;
+    if (!h->g.active || group < 0 || group >= (int)h->g.gk.size()) return fail(h, MPC_ERR_STATE, "no such group in the current wave");
+    { std::lock_guard<std::mutex> lk(h->wm); if (h->w_busy) return fail(h, MPC_ERR_STATE, "a level started with mpc_level_start is still running"); }
+    HIP_TRY(h, hipSetDevice(h->device));
+    return h->mw == 2 ? g_group_run<2>(h, group, stats) : g_group_run<4>(h, group, stats);
+}
+
+int mpc_graph_wave_close(mpc_handle *h, int64_t *n_next, int64_t *n_visited) {
+    if (!h) return MPC_ERR_INVALID;
+    if (!h->g.active) return fail(h, MPC_ERR_STATE, "mpc_graph_begin has not been called");
+    HIP_TRY(h, hipSetDevice(h->device));
+    const int rc = h->mw == 2 ? g_close<2>(h) : g_close<4>(h);
+    if (n_next) *n_next = h->g.n_wave;
+    if (n_visited) *n_visited = h->g.n_visited;
+    return rc;
 }
 
 int mpc_check_level(mpc_handle *h, const int32_t *cand, int64_t n, int32_t k, const uint64_t *pruned_masks, int64_t m,

@@ -13,15 +13,18 @@ instead of the combinatorial tree, which makes complete solutions possible where
 combinatorial algorithm are out of reach (config 3: 20 levels over 80 rows).
 
 Here ``S`` is processed a whole wave at a time: the wave is split by cardinality, every group is one frontier of the
-device engine (rank test, KKT solve, "is the region non-empty" LP, region kernel: mpc_level_run_ex with MPC_LEVEL_GRAPH --
-the same kernels as the combinatorial path without its (x,theta) stage), and the neighbours of the whole wave are formed,
-deduplicated and checked against ``E`` with array operations on the 128/256-bit masks of the sets.  The reference pops
-``S`` in arbitrary (hash) order; the set of examined active sets and the resulting regions do not depend on the order.
+device engine (rank test, KKT solve, "is the region non-empty" LP, region kernel: MPC_LEVEL_GRAPH -- the same kernels as
+the combinatorial path without its (x,theta) stage).  ``S`` and ``E`` live on the device as sorted arrays of 128/256-bit
+masks: the neighbours of a wave are emitted by a kernel, radix-sorted, deduplicated and checked against ``E`` by binary
+search (csrc/graph.hpp, mpc_graph_*); ``MPC_GRAPH_HOST=1`` keeps the same bookkeeping in numpy arrays on the host
+instead (cross-check).  The reference pops ``S`` in arbitrary (hash) order; the set of examined active sets and the
+resulting regions do not depend on the order.
 
 Seeds: the reference starts from ``program.sample_theta_space(1)`` -- one QP solve at a random parameter point.  This
 package has no QP solver; the traversal is seeded with the active sets of the regions the first levels of the
 combinatorial algorithm find (level by level until one has a region), which is deterministic, or with ``seeds``.
 """
+import os
 from typing import Dict, Iterable, List, Optional
 
 import numpy
@@ -153,6 +156,9 @@ def _traverse(program, device, seeds, profile, max_candidates, graph_question: b
         seeds = _seed_active_sets(program, eng)
     if not seeds:
         return solution
+    if os.environ.get('MPC_GRAPH_HOST', '0') != '1':
+        return _traverse_device(eng, solution, _sets_to_masks(seeds, words), profile, max_candidates, graph_question)
+    # ---- the same traversal with the bookkeeping in host arrays (A/B and cross-check of the device bookkeeping) ----------
     book = _SetBook(words)
     todo = book.add(_sets_to_masks(seeds, words))
     examined = 0
@@ -200,6 +206,34 @@ def _traverse(program, device, seeds, profile, max_candidates, graph_question: b
         if max_candidates is not None and examined >= max_candidates:
             break
         todo = new
+    return solution
+
+
+def _traverse_device(eng, solution: Solution, seed_masks: numpy.ndarray, profile, max_candidates, graph_question: bool) -> Solution:
+    """The wave loop with the wave, the visited set and the neighbours resident on the device (csrc/graph.hpp): per wave one
+    device frontier per cardinality, then one sort / deduplicate / subtract pass.  The host only collects the regions."""
+    n_x, n_t, n_c, n_tc = eng.n_x, eng.n_t, eng.n_c, eng.n_tc
+    eng.graph_begin(seed_masks, 0 if graph_question else 1)
+    examined = 0
+    while True:
+        groups, _ = eng.graph_wave()
+        if not groups:
+            break
+        n_regions, hist = 0, numpy.zeros(6, dtype=numpy.int64)
+        for gi in range(len(groups)):
+            st = eng.graph_group_run(gi)
+            hist += numpy.array([int(v) for v in st.n_status], dtype=numpy.int64)
+            if st.n_regions:
+                hd, hi, er, kk, slots = eng.level_regions_slots()
+                solution.critical_regions.extend(RegionBatch(hd, hi, er, n_x, n_t, n_c, n_tc, kk, slots).regions())
+                n_regions += int(st.n_regions)
+        n_wave = sum(c for _, c in groups)
+        examined += n_wave
+        n_next, _ = eng.graph_wave_close()
+        if profile is not None:
+            profile.append({'candidates': int(n_wave), 'regions': n_regions, 'status': hist.tolist(), 'queued': int(n_next)})
+        if max_candidates is not None and examined >= max_candidates:
+            break
     return solution
 
 

@@ -760,6 +760,19 @@ def test_connected_graph_traversal_finds_the_same_regions(name):
     for key, r in got_g.items():
         for fld in ('A', 'b', 'C', 'd', 'E', 'f'):
             assert numpy.array_equal(getattr(r, fld), getattr(got[key], fld)), (name, key, fld)
+    # the bookkeeping on the device examines exactly the active sets the host bookkeeping examines
+    import os
+    os.environ['MPC_GRAPH_HOST'] = '1'
+    try:
+        ph, ph2 = [], []
+        sh = mpqp_hip_combi_graph.solve(prog, profile=ph)
+        sh2 = mpqp_hip_combi_graph.solve_graph(prog, profile=ph2)
+    finally:
+        del os.environ['MPC_GRAPH_HOST']
+    assert [p['candidates'] for p in ph] == [p['candidates'] for p in prof] and [p['regions'] for p in ph] == [p['regions'] for p in prof]
+    assert [p['candidates'] for p in ph2] == [p['candidates'] for p in prof2] and [p['regions'] for p in ph2] == [p['regions'] for p in prof2]
+    assert sorted(tuple(r.active_set) for r in sh.critical_regions) == sorted(got)
+    assert sorted(tuple(r.active_set) for r in sh2.critical_regions) == sorted(got_g)
     print(name, 'regions', len(ref), 'combinatorial tree', sum(len(g[f'L{i}_cands']) for i in range(int(g['n_levels']))),
           'combinatorial_graph', sum(p['candidates'] for p in prof), 'graph', sum(p['candidates'] for p in prof2), len(got_g))
     # through the public entry point
