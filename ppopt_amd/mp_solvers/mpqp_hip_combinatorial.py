@@ -65,6 +65,9 @@ def unpack_region(rec_d: numpy.ndarray, rec_i: numpy.ndarray, n_x: int, n_t: int
 
 
 REGION_STATUS = 3   # MPC_REGION
+# levels below this size are run synchronously and fetched afterwards: the hand-overs to the worker thread cost more than the
+# overlap gains there (sub-programs of the mixed-integer enumeration, the first levels of every solve)
+STREAM_MIN_CANDIDATES = 8192
 
 
 def solve(program, num_cores: int = -1, device: int = 0, profile: Optional[List[Dict]] = None,
@@ -86,7 +89,7 @@ def solve(program, num_cores: int = -1, device: int = 0, profile: Optional[List[
     for depth in range(max_depth):
         gen_children = depth + 1 != max_depth
         t0 = time.perf_counter()
-        if collect_regions and stream:
+        if collect_regions and stream and eng.frontier_info()[0] >= STREAM_MIN_CANDIDATES:
             # The level runs on the handle's worker thread; its region kernel writes the records straight into page-locked
             # host arrays and raises a flag per chunk of slots, so the region objects of a chunk are built while the kernel
             # is still working on the later ones -- no fetch afterwards, nothing waits for Python.

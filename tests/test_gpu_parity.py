@@ -778,3 +778,30 @@ def test_connected_graph_traversal_finds_the_same_regions(name):
     # through the public entry point
     sol2 = solve_mpqp(prog, mpqp_algorithm.combinatorial_graph)
     assert sorted(tuple(r.active_set) for r in sol2.critical_regions) == sorted(ref)
+
+
+def test_graph_traversal_complete_solution_of_config4():
+    """mpqp_algorithm.graph on the bench program (n_x = 20, n_theta = 8, 47 rows): the COMPLETE explicit solution -- about
+    2.3e5 regions from 1.0e6 examined active sets; the combinatorial tree has more candidates than that in its first five
+    levels.  Checked without an oracle: the regions of levels 1-5 of the combinatorial path are all there, no active set
+    twice, every random parameter point of the box lies in a region (the program is feasible on the whole box), and the
+    located laws satisfy the KKT conditions."""
+    import bench
+    from ppopt_amd.mp_solvers import mpqp_hip_combi_graph, mpqp_hip_combinatorial
+    prog = bench.build_program('c4')
+    prof = []
+    sol = mpqp_hip_combi_graph.solve_graph(prog, profile=prof)
+    keys = [tuple(r.active_set) for r in sol.critical_regions]
+    assert len(set(keys)) == len(keys) and 220000 <= len(keys) <= 235000, len(keys)
+    assert sum(p['candidates'] for p in prof) < 1.2e6
+    tree = mpqp_hip_combinatorial.solve(prog, max_levels=5)
+    assert {tuple(r.active_set) for r in tree.critical_regions} <= set(keys)
+    th = _theta_samples(prog, 4000, 2)
+    th = th[numpy.all(prog.A_t @ th.T <= prog.b_t - 1e-9, axis=0)]  # strictly inside the parameter box
+    assert len(th) > 1000
+    x, idx = sol.evaluate_batch(th)
+    assert (idx >= 0).all()
+    for p in range(0, len(th), 40):
+        r = sol.kkt_residuals(sol.critical_regions[int(idx[p])], th[p].reshape(-1, 1))
+        assert max(r.values()) <= 1e-8, (p, r)
+    prog.release_engine()
