@@ -255,6 +255,15 @@ int mpc_lp_solve_batch(int32_t device, int64_t n_lp, int32_t m, int32_t n, const
                        const double *b, int32_t shared_b, const double *c, int32_t shared_c, const uint8_t *eq,
                        int32_t *status, double *x, double *obj, int32_t *iters);
 
+/* ---- the QP of the program at fixed parameter points, batched: one wavefront per point --------------------------------- */
+/* Replaces MPQP_Program.solve_theta (mpqp_program.py:109-143 -> Solver.solve_qp, quad_prog_interface.py:16-89) for programs
+ * with positive definite Q:  min 1/2 x'Qx + (c + H theta)'x  s.t.  A x <= b + F theta, first n_eq rows as equalities.
+ * theta m x n_t (host).  status[p]: 0 optimal, 1 infeasible at that point, 3 iteration limit.  x (m x n_x, NaN where not
+ * optimal), lambda (m x n_c multipliers, >= 0 on inequality rows), active (m x n_c bytes: 1 = the constraint is tight) and
+ * iters (complementary pivots) may be NULL.  The constants c_c + c_t'theta + 1/2 theta'Q_t theta are the caller's. */
+int mpc_qp_solve_batch(mpc_handle *h, int64_t m, const double *theta_host, int32_t *status, double *x, double *lambda,
+                       uint8_t *active, int32_t *iters);
+
 /* ---- consumer of the path: point location over a solution's critical regions, batched ---------------------------- */
 /* Replaces the loop of Solution.get_region / Solution.evaluate (solution.py:45-112, CriticalRegion.is_inside
  * critical_region.py:83-86) for many parameter points at once.

@@ -116,6 +116,7 @@ def load():
         'mpc_level_regions_device': (ctypes.c_int, [H, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64,
                                                     ctypes.c_int64, _lp, _lp]),
         'mpc_frontier_advance': (ctypes.c_int, [H]),
+        'mpc_qp_solve_batch': (ctypes.c_int, [H, ctypes.c_int64, _dp, _ip, _dp, _dp, _u8p, _ip]),
         'mpc_graph_begin': (ctypes.c_int, [H, _u64p, ctypes.c_int64, ctypes.c_int32]),
         'mpc_graph_wave': (ctypes.c_int, [H, _ip, _lp, ctypes.c_int32, _ip, _lp, _lp]),
         'mpc_graph_group_run': (ctypes.c_int, [H, ctypes.c_int32, ctypes.POINTER(LevelStats)]),
@@ -140,7 +141,7 @@ EXPORTED_SYMBOLS = ['mpc_device_count', 'mpc_version', 'mpc_last_global_error', 
                     'mpc_frontier_get', 'mpc_pruned_clear', 'mpc_pruned_add', 'mpc_pruned_add_device',
                     'mpc_pruned_count', 'mpc_pruned_get', 'mpc_level_run', 'mpc_level_run_ex', 'mpc_level_status', 'mpc_level_start', 'mpc_level_stream_info', 'mpc_level_chunk_wait', 'mpc_level_wait', 'mpc_level_stream_fixup', 'mpc_level_regions', 'mpc_compact_strides',
                     'mpc_level_regions_compact', 'mpc_frontier_shard', 'mpc_level_slots', 'mpc_level_regions_slots', 'mpc_level_regions_slots_async', 'mpc_sync', 'mpc_host_alloc', 'mpc_host_free', 'mpc_locator_create', 'mpc_locator_query', 'mpc_locator_destroy', 'mpc_level_children', 'mpc_level_children_device', 'mpc_level_pruned_new',
-                    'mpc_level_pruned_new_device', 'mpc_level_regions_device', 'mpc_frontier_advance', 'mpc_graph_begin', 'mpc_graph_wave', 'mpc_graph_group_run', 'mpc_graph_wave_close', 'mpc_check_level', 'mpc_lp_solve_batch']
+                    'mpc_level_pruned_new_device', 'mpc_level_regions_device', 'mpc_frontier_advance', 'mpc_qp_solve_batch', 'mpc_graph_begin', 'mpc_graph_wave', 'mpc_graph_group_run', 'mpc_graph_wave_close', 'mpc_check_level', 'mpc_lp_solve_batch']
 
 
 def pinned_empty(shape, dtype) -> numpy.ndarray:
@@ -345,6 +346,19 @@ class Engine:
         self._check(self._L.mpc_level_stream_fixup(self._h, hd.ctypes.data_as(_dp), hi.ctypes.data_as(_ip), er.ctypes.data_as(_dp),
                                                    ctypes.byref(nrows)), 'mpc_level_stream_fixup')
         return int(nrows.value)
+
+    def qp_solve_batch(self, thetas: numpy.ndarray):
+        """The program's QP at every row of ``thetas`` [m, n_t] (positive definite Q), one wavefront per point:
+        (status [m] (0 optimal, 1 infeasible, 3 iteration limit), x [m, n_x], lambda [m, n_c], active [m, n_c] bool)."""
+        th = _f64(thetas).reshape(-1, self.n_t)
+        m = len(th)
+        status = numpy.zeros(m, dtype=numpy.int32)
+        x = numpy.zeros((m, self.n_x))
+        lam = numpy.zeros((m, self.n_c))
+        act = numpy.zeros((m, self.n_c), dtype=numpy.uint8)
+        self._check(self._L.mpc_qp_solve_batch(self._h, m, th.ctypes.data_as(_dp), status.ctypes.data_as(_ip), x.ctypes.data_as(_dp),
+                                               lam.ctypes.data_as(_dp), act.ctypes.data_as(_u8p), None), 'mpc_qp_solve_batch')
+        return status, x, lam, act.astype(bool)
 
     # -- connected-graph traversal with the bookkeeping on the device (include/mpcombi.h, mpc_graph_*) -------------------
     def graph_begin(self, seed_masks: numpy.ndarray, variant: int):

@@ -26,6 +26,7 @@
 #include "kernels2.hpp"
 #include "locate.hpp"
 #include "graph.hpp"
+#include "qp.hpp"
 #include <rocprim/device/device_radix_sort.hpp>
 
 using namespace mpc;
@@ -2176,6 +2177,52 @@ extern "C" int mpc_lp_solve_batch(int32_t device, int64_t n_lp, int32_t m, int32
 }
 
 // ---- point location ---------------------------------------------------------------------------------------------------
+// ---- the QP of the program at fixed parameter points (qp.hpp) ------------------------------------------------------------------
+extern "C" int mpc_qp_solve_batch(mpc_handle *h, int64_t m, const double *theta, int32_t *status, double *x, double *lambda, uint8_t *active,
+                                  int32_t *iters) {
+    if (!h || m < 0 || (m > 0 && (!theta || !status))) return MPC_ERR_INVALID;
+    if (!h->is_qp || h->kkt_mode != 0) return fail(h, MPC_ERR_INVALID, "mpc_qp_solve_batch needs a positive definite Q");
+    if (m == 0) return MPC_OK;
+    { std::lock_guard<std::mutex> lk(h->wm); if (h->w_busy) return fail(h, MPC_ERR_STATE, "a level started with mpc_level_start is still running"); }
+    HIP_TRY(h, hipSetDevice(h->device));
+    hipStream_t st = h->stream;
+    const int nc = h->n_c, nt = h->n_t, nx = h->n_x;
+    const int ld = odd_at_least(nc + 3);
+    const size_t lds = ((size_t)(nc + 1) * ld + nc) * sizeof(double) + (size_t)(ld + 1 + 2 * (nc + 2) + 2) * sizeof(int32_t) + 16;
+    if (lds > 160 * 1024) return fail(h, MPC_ERR_INVALID, "the QP tableau (n_c x n_c) does not fit the 160 KiB LDS of one CU");
+    if (lds > 48 * 1024) HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void *>(k_qp_batch), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    DevBuf d_th, d_st, d_x, d_l, d_a, d_it;
+    auto cleanup = [&]() { for (DevBuf *b : {&d_th, &d_st, &d_x, &d_l, &d_a, &d_it}) b->release(); };
+    int rc = MPC_OK;
+    do {
+#define QP_TRY(expr) { hipError_t e__ = (expr); if (e__ != hipSuccess) { rc = fail(h, MPC_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e__)); break; } }
+        QP_TRY(d_th.ensure((size_t)m * nt * sizeof(double), st));
+        QP_TRY(d_st.ensure((size_t)m * sizeof(int32_t), st));
+        QP_TRY(d_it.ensure((size_t)m * sizeof(int32_t), st));
+        if (x) QP_TRY(d_x.ensure((size_t)m * nx * sizeof(double), st));
+        if (lambda) QP_TRY(d_l.ensure((size_t)m * nc * sizeof(double), st));
+        if (active) QP_TRY(d_a.ensure((size_t)m * nc, st));
+        QP_TRY(hipMemcpyAsync(d_th.p, theta, (size_t)m * nt * sizeof(double), hipMemcpyHostToDevice, st));
+        QP_TRY(hipMemsetAsync(h->scratch.p, 0, sizeof(unsigned int), st));
+        const int per_cu = std::max(1, std::min(16, (int)((160 * 1024) / lds)));
+        const dim3 g((unsigned)std::min<long long>(m, (long long)h->n_cu * per_cu)), b(64);
+        hipLaunchKernelGGL(k_qp_batch, g, b, lds, st, (long long)m, nc, h->n_eq, nt, nx, ld, h->Pv.W, h->Pv.UV, h->Pv.X0H, h->Pv.Gt, d_th.as<double>(),
+                           d_st.as<int32_t>(), x ? d_x.as<double>() : (double *)nullptr, lambda ? d_l.as<double>() : (double *)nullptr,
+                           active ? d_a.as<uint8_t>() : (uint8_t *)nullptr, d_it.as<int32_t>(), h->scratch.as<unsigned int>());
+        QP_TRY(hipGetLastError());
+        QP_TRY(hipMemcpyAsync(status, d_st.p, (size_t)m * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+        if (iters) QP_TRY(hipMemcpyAsync(iters, d_it.p, (size_t)m * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+        if (x) QP_TRY(hipMemcpyAsync(x, d_x.p, (size_t)m * nx * sizeof(double), hipMemcpyDeviceToHost, st));
+        if (lambda) QP_TRY(hipMemcpyAsync(lambda, d_l.p, (size_t)m * nc * sizeof(double), hipMemcpyDeviceToHost, st));
+        if (active) QP_TRY(hipMemcpyAsync(active, d_a.p, (size_t)m * nc, hipMemcpyDeviceToHost, st));
+        QP_TRY(hipStreamSynchronize(st));
+#undef QP_TRY
+    } while (0);
+    if (rc != MPC_OK) (void)hipStreamSynchronize(st);
+    cleanup();
+    return rc;
+}
+
 struct mpc_locator {
     int device = 0, n_x = 0, n_t = 0;
     long long n_regions = 0, n_rows = 0;

@@ -7,6 +7,7 @@ from typing import List, Optional, Tuple
 import numpy
 
 from .mplp_program import MPLP_Program
+from .solver import SolverOutput
 
 
 class MPQP_Program(MPLP_Program):
@@ -48,6 +49,26 @@ class MPQP_Program(MPLP_Program):
         nx = self.num_x()
         return mats[:nx], consts[:nx], mats[nx:], consts[nx:]
 
-    def solve_theta(self, theta_point: numpy.ndarray):
-        """The QP at a fixed theta needs a QP backend, which is outside the combinatorial path."""
-        raise NotImplementedError('solve_theta needs a QP solver; only the LP plug is part of the combinatorial path')
+    def solve_theta(self, theta_point: numpy.ndarray) -> Optional[SolverOutput]:
+        """The QP at a fixed theta (mpqp_program.py:109-143): SolverOutput (obj, sol, slack, active_set, dual) or None when
+        theta violates A_t theta <= b_t or the QP is infeasible there.  Solved on the device (``solve_theta_batch``)."""
+        th = numpy.asarray(theta_point, dtype=float).reshape(-1, 1)
+        if not numpy.all(self.A_t @ th <= self.b_t):
+            return None
+        return self.solve_theta_batch(th.reshape(1, -1))[0]
+
+    def solve_theta_batch(self, theta_points: numpy.ndarray) -> List[Optional[SolverOutput]]:
+        """``solve_theta`` for many parameter points in one device launch (theta_points [m, n_theta]): the KKT conditions as a
+        linear complementarity problem in the multipliers, Lemke's method, one wavefront per point (csrc/qp.hpp).  Needs a
+        positive definite Q.  Points outside A_t theta <= b_t are solved like any other (the single-point form filters them)."""
+        th = numpy.ascontiguousarray(theta_points, dtype=numpy.float64).reshape(-1, self.num_t())
+        status, x, lam, act = self.engine().qp_solve_batch(th)
+        out: List[Optional[SolverOutput]] = []
+        for p in range(len(th)):
+            if status[p] != 0:
+                out.append(None)
+                continue
+            tp, xp = th[p].reshape(-1, 1), x[p].reshape(-1, 1)
+            slack = (self.b + self.F @ tp - self.A @ xp).ravel()
+            out.append(SolverOutput(self.evaluate_objective(xp, tp), x[p].copy(), slack, numpy.flatnonzero(act[p]), lam[p].copy()))
+        return out

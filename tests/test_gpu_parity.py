@@ -805,3 +805,57 @@ def test_graph_traversal_complete_solution_of_config4():
         r = sol.kkt_residuals(sol.critical_regions[int(idx[p])], th[p].reshape(-1, 1))
         assert max(r.values()) <= 1e-8, (p, r)
     prog.release_engine()
+
+
+@pytest.mark.parametrize('name', ['transport_mpqp', 'c2_dblint_n5', 'rand_5_3_8_s3', 'rand_6_3_12_s1', 'quadtank_n3'])
+def test_qp_at_parameter_points_matches_the_explicit_solution(name):
+    """MPQP_Program.solve_theta / solve_theta_batch (mpqp_program.py:109-143; here Lemke's method on the device, one wavefront
+    per point): at sampled parameter points the QP's minimiser equals the explicit solution's x*(theta), the reported active
+    set is the region's (where the point is not on a boundary), multipliers are non-negative and satisfy stationarity, and
+    points in no region are exactly the points where the QP is infeasible.  c2 has ten equality rows (free multipliers)."""
+    from ppopt_amd import Solver
+    from ppopt_amd.mp_solvers import mpqp_hip_combinatorial
+    from test_host_logic import build_program
+    g = load_golden(name)
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        prog = build_program(g, Solver())
+    sol = mpqp_hip_combinatorial.solve(prog)
+    th = _theta_samples(prog, 300, 5)
+    inside_box = numpy.all(prog.A_t @ th.T <= prog.b_t, axis=0)
+    res = prog.solve_theta_batch(th)
+    x_exp, idx = sol.evaluate_batch(th)
+    n_checked = 0
+    for p in range(len(th)):
+        tp = th[p].reshape(-1, 1)
+        single = prog.solve_theta(tp)
+        if not inside_box[p]:
+            assert single is None
+            continue
+        assert (single is None) == (res[p] is None)
+        if idx[p] < 0:
+            # in no region (strict test with the location tolerance): infeasible, or within the tolerance of the boundary of the feasible set
+            if res[p] is not None:
+                assert numpy.min(res[p].slack) < 1e-4
+            continue
+        assert res[p] is not None, (name, p)
+        r = res[p]
+        assert numpy.allclose(r.sol, x_exp[p], rtol=1e-8, atol=1e-8), (name, p)
+        assert numpy.allclose(single.sol, r.sol) and abs(single.obj - r.obj) <= 1e-9 * (1 + abs(r.obj))
+        cr = sol.critical_regions[int(idx[p])]
+        n_eq = len(prog.equality_indices)
+        lam = r.dual
+        assert numpy.all(lam[n_eq:] >= -1e-9)
+        grad = prog.Q @ r.sol.reshape(-1, 1) + prog.H @ tp + prog.c + prog.A.T @ lam.reshape(-1, 1)
+        assert numpy.max(numpy.abs(grad)) <= 1e-7 * (1 + numpy.max(numpy.abs(lam)))
+        assert numpy.all(r.slack >= -1e-8) and numpy.max(numpy.abs(r.slack[r.active_set]), initial=0.0) <= 1e-8
+        margin = numpy.min(numpy.asarray(cr.f).ravel() - numpy.asarray(cr.E) @ th[p])
+        if margin > 1e-6:                       # well inside its region: the QP's active set is the region's
+            assert sorted(r.active_set.tolist()) == sorted(cr.active_set), (name, p)
+            n_checked += 1
+        assert abs(r.obj - prog.evaluate_objective(x_exp[p].reshape(-1, 1), tp)) <= 1e-8 * (1 + abs(r.obj))
+    assert n_checked >= 30
+    # the reference's sampling walk (mplp_program.py:632-664) now works for mpQPs: every active set it meets is a region's
+    found = prog.sample_theta_space(20)
+    keys = {tuple(r.active_set) for r in sol.critical_regions}
+    assert found and all(tuple(a) in keys for a in found)
