@@ -157,6 +157,12 @@ int mpc_level_status(mpc_handle *h, uint8_t *status_host);                      
  *                          re-solved by the LDS-engine kernel (their head_i[0] was MPC_STREAM_RETRY while streaming); rows
  *                          are appended behind stats.n_region_rows, *n_rows = rows in use afterwards. */
 #define MPC_LEVEL_STREAM 1
+/* MPC_LEVEL_THEN_BASE (mpc_level_start, with gen_children == 0): behind this -- the last -- level the worker also checks the
+ * base active set, the equality rows alone (driver :142-146), while the caller still consumes the level's streamed records;
+ * mpc_base_result returns its status and fixed-stride region record (layout of mpc_level_regions) once, MPC_ERR_STATE when
+ * the check did not run (the caller then uses mpc_check_level).  Frontier, level results and the pruned list of the handle
+ * then belong to the base set. */
+#define MPC_LEVEL_THEN_BASE 8
 /* MPC_LEVEL_GRAPH (gen_children must be 0): the question of the connected-graph traversals (mp_solvers/mpqp_combi_graph.py:
  * 48-66, feasability_check) instead of full_process -- rank test, KKT solve, "is the critical region non-empty" (the theta
  * LP over multiplier, slack and A_t rows), region.  The (x,theta) feasibility LP is not posed.  Statuses: MPC_INFEASIBLE =
@@ -170,6 +176,7 @@ int mpc_level_stream_info(mpc_handle *h, double **head_d, int32_t **head_i, doub
 int mpc_level_chunk_wait(mpc_handle *h, int32_t j);
 int mpc_level_wait(mpc_handle *h, mpc_level_stats *stats);
 int mpc_level_stream_fixup(mpc_handle *h, double *head_d, int32_t *head_i, double *erows, int64_t *n_rows);
+int mpc_base_result(mpc_handle *h, uint8_t *status, int64_t *n_regions, double *rec_d, int32_t *rec_i);
 /* Region records of this level in frontier order.  cand_index[i] = position of region i's candidate.
  *   rec_d (mpc_region_doubles each): A_x[n_x*n_t] b_x[n_x] A_l[n_c*n_t] b_l[n_c] E[(n_c+n_tc)*n_t] f[n_c+n_tc]
  *   rec_i (mpc_region_ints each):    k n_E n_omega n_lambda n_regular | active[n_c] | omega[n_tc] | lambda[n_c]

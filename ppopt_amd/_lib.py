@@ -15,7 +15,7 @@ LIB_PATH = os.environ.get('MPC_LIB_PATH') or os.path.join(_HERE, 'csrc', 'libmpc
 
 MPC_OK, MPC_ERR_INVALID, MPC_ERR_HIP, MPC_ERR_CAPACITY, MPC_ERR_STATE = range(5)
 MPC_LOCATE_OVERLAPPING, MPC_LOCATE_INCLUSIVE = 1, 2   # flags of mpc_locator_query
-MPC_LEVEL_STREAM, MPC_LEVEL_GRAPH = 1, 4               # flags of mpc_level_start / mpc_level_run_ex
+MPC_LEVEL_STREAM, MPC_LEVEL_GRAPH, MPC_LEVEL_THEN_BASE = 1, 4, 8   # flags of mpc_level_start / mpc_level_run_ex
 INFEASIBLE, FEASIBLE, OPTIMAL_NO_REGION, REGION, SINGULAR_KKT, LP_LIMIT = range(6)
 LP_OPTIMAL, LP_INFEASIBLE, LP_UNBOUNDED, LP_ITERLIMIT = range(4)
 MASK_WORDS = 2
@@ -94,6 +94,7 @@ def load():
         'mpc_level_chunk_wait': (ctypes.c_int, [H, ctypes.c_int32]),
         'mpc_level_wait': (ctypes.c_int, [H, ctypes.POINTER(LevelStats)]),
         'mpc_level_stream_fixup': (ctypes.c_int, [H, _dp, _ip, _dp, _lp]),
+        'mpc_base_result': (ctypes.c_int, [H, _u8p, _lp, _dp, _ip]),
         'mpc_level_regions': (ctypes.c_int, [H, _dp, _ip, _lp, ctypes.c_int64]),
         'mpc_compact_strides': (ctypes.c_int, [H, _lp, _lp, _lp]),
         'mpc_level_regions_compact': (ctypes.c_int, [H, _dp, _ip, ctypes.c_int64, _dp, ctypes.c_int64, _lp, _lp]),
@@ -139,7 +140,7 @@ EXPORTED_SYMBOLS = ['mpc_device_count', 'mpc_version', 'mpc_last_global_error', 
                     'mpc_last_error', 'mpc_mask_words', 'mpc_region_doubles', 'mpc_region_ints', 'mpc_lds_bytes', 'mpc_stream',
                     'mpc_frontier_root', 'mpc_frontier_set', 'mpc_frontier_set_device', 'mpc_frontier_info',
                     'mpc_frontier_get', 'mpc_pruned_clear', 'mpc_pruned_add', 'mpc_pruned_add_device',
-                    'mpc_pruned_count', 'mpc_pruned_get', 'mpc_level_run', 'mpc_level_run_ex', 'mpc_level_status', 'mpc_level_start', 'mpc_level_stream_info', 'mpc_level_chunk_wait', 'mpc_level_wait', 'mpc_level_stream_fixup', 'mpc_level_regions', 'mpc_compact_strides',
+                    'mpc_pruned_count', 'mpc_pruned_get', 'mpc_level_run', 'mpc_level_run_ex', 'mpc_level_status', 'mpc_level_start', 'mpc_level_stream_info', 'mpc_level_chunk_wait', 'mpc_level_wait', 'mpc_level_stream_fixup', 'mpc_base_result', 'mpc_level_regions', 'mpc_compact_strides',
                     'mpc_level_regions_compact', 'mpc_frontier_shard', 'mpc_level_slots', 'mpc_level_regions_slots', 'mpc_level_regions_slots_async', 'mpc_sync', 'mpc_host_alloc', 'mpc_host_free', 'mpc_locator_create', 'mpc_locator_query', 'mpc_locator_destroy', 'mpc_level_children', 'mpc_level_children_device', 'mpc_level_pruned_new',
                     'mpc_level_pruned_new_device', 'mpc_level_regions_device', 'mpc_frontier_advance', 'mpc_qp_solve_batch', 'mpc_graph_begin', 'mpc_graph_wave', 'mpc_graph_group_run', 'mpc_graph_wave_close', 'mpc_check_level', 'mpc_lp_solve_batch']
 
@@ -312,8 +313,21 @@ class Engine:
         return st
 
     # -- the same level on the handle's worker thread, region records streamed to the host (include/mpcombi.h) ----------
-    def level_start(self, gen_children: bool, stream: bool = True):
-        self._check(self._L.mpc_level_start(self._h, int(bool(gen_children)), MPC_LEVEL_STREAM if stream else 0), 'mpc_level_start')
+    def level_start(self, gen_children: bool, stream: bool = True, then_base: bool = False):
+        self._check(self._L.mpc_level_start(self._h, int(bool(gen_children)),
+                                            (MPC_LEVEL_STREAM if stream else 0) | (MPC_LEVEL_THEN_BASE if then_base else 0)), 'mpc_level_start')
+
+    def base_result(self):
+        """(status, rec_d [1, rec_d] or empty, rec_i) of the base-set check the worker ran behind the last level
+        (``level_start(..., then_base=True)``), or None when it did not run."""
+        status = numpy.zeros(1, dtype=numpy.uint8)
+        nreg = ctypes.c_int64(0)
+        d = numpy.zeros((1, self.rec_d))
+        i = numpy.zeros((1, self.rec_i), dtype=numpy.int32)
+        rc = self._L.mpc_base_result(self._h, status.ctypes.data_as(_u8p), ctypes.byref(nreg), d.ctypes.data_as(_dp), i.ctypes.data_as(_ip))
+        if rc != MPC_OK:
+            return None
+        return status, d[:nreg.value], i[:nreg.value]
 
     def level_stream_info(self):
         """Blocks until the running level's region stage has been launched.  None when the level does not stream, else

@@ -297,6 +297,8 @@ struct mpc_handle {
         bool taken = false;     // the caller owns the blocks (mpc_level_stream_info handed them over)
     } so;
     HostBuf st_flags;           // chunk flags (host memory the kernel writes)
+    int cw_chunks = 0;          // chunks of the most recent streamed level (mpc_level_chunk_wait keeps working while the worker
+                                // already runs the base-set check behind that level, which resets `so`)
     DevBuf chunk_count;
     // ---- worker thread behind mpc_level_start / mpc_level_wait ---------------------------------------------------------
     std::thread worker;
@@ -305,6 +307,12 @@ struct mpc_handle {
     int w_req = 0;              // 0 idle, 1 run a level, 2 exit
     bool w_busy = false, w_stream_ready = false;
     int w_gen = 0, w_flags = 0, w_rc = 0;
+    // result of the base-set check the worker ran behind the last level (MPC_LEVEL_THEN_BASE)
+    bool base_valid = false;
+    uint8_t base_status = 0;
+    long long base_regions = 0;
+    std::vector<double> base_rec_d;
+    std::vector<int32_t> base_rec_i;
     mpc_level_stats w_stats{};
     // ---- connected-graph traversal: wave, visited set and pending neighbours resident on the device (graph.hpp) ----------
     struct GraphState {
@@ -1295,6 +1303,7 @@ static int level_run_impl(mpc_handle *h, int32_t gen_children, int32_t flags, mp
                 HIP_TRY(h, host_pool_take(std::max<size_t>(bytes_er, 8), &so.er, nullptr));
                 HIP_TRY(h, h->st_flags.ensure((size_t)so.n_chunks * sizeof(int32_t)));
                 std::memset(h->st_flags.p, 0, (size_t)so.n_chunks * sizeof(int32_t));
+                h->cw_chunks = so.n_chunks;
                 HIP_TRY(h, h->chunk_count.ensure((size_t)so.n_chunks * sizeof(unsigned int), st));
                 HIP_TRY(h, hipMemsetAsync(h->chunk_count.p, 0, (size_t)so.n_chunks * sizeof(unsigned int), st));
                 void *d_hd = nullptr, *d_hi = nullptr, *d_er = nullptr, *d_fl = nullptr;
@@ -1444,6 +1453,23 @@ static void worker_main(mpc_handle *h) {
         mpc_level_stats st;
         std::memset(&st, 0, sizeof(st));
         const int rc = level_run_impl(h, gen, flags, &st);
+        h->base_valid = false;
+        if (rc == MPC_OK && (flags & MPC_LEVEL_THEN_BASE) && !gen && st.n_region_retry == 0 && !(h->so.active && !h->so.taken)) {
+            // The base active set (the equality rows alone; driver :142-146) right behind the last level, while the caller
+            // is still turning the streamed records into objects.  Any failure simply leaves the check to the caller.
+            std::vector<int32_t> base((size_t)std::max(h->n_eq, 1));
+            for (int i = 0; i < h->n_eq; ++i) base[(size_t)i] = i;
+            mpc_level_stats bs;
+            std::memset(&bs, 0, sizeof(bs));
+            h->base_rec_d.assign((size_t)h->rec_d, 0.0);
+            h->base_rec_i.assign((size_t)h->rec_i, -1);
+            int64_t cand = 0;
+            int rb = mpc_frontier_set(h, base.data(), 1, h->n_eq);
+            if (rb == MPC_OK) { h->n_pruned = 0; rb = level_run_impl(h, 0, 0, &bs); }
+            if (rb == MPC_OK) rb = mpc_level_status(h, &h->base_status);
+            if (rb == MPC_OK && bs.n_regions > 0) rb = mpc_level_regions(h, h->base_rec_d.data(), h->base_rec_i.data(), &cand, 1);
+            if (rb == MPC_OK) { h->base_regions = bs.n_regions; h->base_valid = true; }
+        }
         {
             std::lock_guard<std::mutex> lk(h->wm);
             h->w_rc = rc; h->w_stats = st; h->w_busy = false; h->w_stream_ready = true;
@@ -1482,7 +1508,7 @@ int mpc_level_stream_info(mpc_handle *h, double **head_d, int32_t **head_i, doub
 }
 
 int mpc_level_chunk_wait(mpc_handle *h, int32_t j) {
-    if (!h || !h->so.active || j < 0 || j >= h->so.n_chunks) return MPC_ERR_INVALID;
+    if (!h || j < 0 || j >= h->cw_chunks || !h->st_flags.p) return MPC_ERR_INVALID;
     const int32_t *flag = h->st_flags.as<int32_t>() + j;
     for (unsigned spin = 0;; ++spin) {
         if (__atomic_load_n(flag, __ATOMIC_ACQUIRE)) return MPC_OK;
@@ -1503,6 +1529,20 @@ int mpc_level_wait(mpc_handle *h, mpc_level_stats *stats) {
     h->wcv.wait(lk, [&] { return !h->w_busy; });
     if (stats) *stats = h->w_stats;
     return h->w_rc;
+}
+
+int mpc_base_result(mpc_handle *h, uint8_t *status, int64_t *n_regions, double *rec_d, int32_t *rec_i) {
+    if (!h) return MPC_ERR_INVALID;
+    { std::lock_guard<std::mutex> lk(h->wm); if (h->w_busy) return fail(h, MPC_ERR_STATE, "the level is still running"); }
+    if (!h->base_valid) return fail(h, MPC_ERR_STATE, "no base-set result (mpc_level_start without MPC_LEVEL_THEN_BASE, or the check was left to the caller)");
+    if (status) *status = h->base_status;
+    if (n_regions) *n_regions = h->base_regions;
+    if (h->base_regions > 0) {
+        if (rec_d) std::memcpy(rec_d, h->base_rec_d.data(), sizeof(double) * h->base_rec_d.size());
+        if (rec_i) std::memcpy(rec_i, h->base_rec_i.data(), sizeof(int32_t) * h->base_rec_i.size());
+    }
+    h->base_valid = false;
+    return MPC_OK;
 }
 
 int mpc_level_status(mpc_handle *h, uint8_t *status) {

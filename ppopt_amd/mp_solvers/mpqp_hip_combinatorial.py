@@ -86,6 +86,7 @@ def solve(program, num_cores: int = -1, device: int = 0, profile: Optional[List[
         max_depth = min(max_depth, max_levels)
     eng.pruned_clear()
     eng.frontier_root()
+    base_behind_level = False
     for depth in range(max_depth):
         gen_children = depth + 1 != max_depth
         t0 = time.perf_counter()
@@ -93,7 +94,8 @@ def solve(program, num_cores: int = -1, device: int = 0, profile: Optional[List[
             # The level runs on the handle's worker thread; its region kernel writes the records straight into page-locked
             # host arrays and raises a flag per chunk of slots, so the region objects of a chunk are built while the kernel
             # is still working on the later ones -- no fetch afterwards, nothing waits for Python.
-            eng.level_start(gen_children, stream=True)
+            eng.level_start(gen_children, stream=True, then_base=not gen_children)
+            base_behind_level = not gen_children
             info = eng.level_stream_info()
             new_regions: List[CriticalRegion] = []
             batch = None
@@ -137,8 +139,12 @@ def solve(program, num_cores: int = -1, device: int = 0, profile: Optional[List[
         eng.frontier_advance()
     eng.sync()
     # the base active set (= the equality rows) is tested last, like the reference (driver :142-146)
-    base = numpy.arange(eng.n_eq, dtype=numpy.int32).reshape(1, -1)
-    status, rd, ri, _, _ = eng.check_level(base, numpy.zeros((0, 2), dtype=numpy.uint64), False)
+    res = eng.base_result() if base_behind_level else None      # the worker may have checked it behind the last level
+    if res is None:
+        base = numpy.arange(eng.n_eq, dtype=numpy.int32).reshape(1, -1)
+        status, rd, ri, _, _ = eng.check_level(base, numpy.zeros((0, 2), dtype=numpy.uint64), False)
+    else:
+        status, rd, ri = res
     if profile is not None:
         profile.append({'depth': 0, 'k': eng.n_eq, 'candidates': 1, 'status': numpy.bincount(status, minlength=6).tolist(),
                         'regions': len(rd)})
