@@ -285,9 +285,19 @@ int mpc_qp_solve_batch(mpc_handle *h, int64_t m, const double *theta_host, int32
  * x (m x n_x, may be NULL) = A theta + b of that region, NaN where there is none. */
 #define MPC_LOCATE_OVERLAPPING 1
 #define MPC_LOCATE_INCLUSIVE 2
+/* MPC_LOCATE_WALK: locate by walking through adjacent regions instead of scanning the list (needs
+ * mpc_locator_set_adjacency; ignored with the two flags above).  Same result as the scan -- the first region of the list that
+ * contains the point within tol -- at a cost that follows the length of the walk, not the number of regions; points the walk
+ * cannot resolve (no neighbour behind any violated row, step limit) are tested against every region in parallel. */
+#define MPC_LOCATE_WALK 4
 typedef struct mpc_locator mpc_locator;
 int mpc_locator_create(int32_t device, int32_t n_x, int32_t n_t, int64_t n_regions, const int64_t *row_off, const double *ef_rows,
                        const double *xlaw, const double *Q, const double *c, const double *H, mpc_locator **out);
+/* Facet adjacency of a complete, non-overlapping solution: masks n_regions x mask_words (active set of every region, all
+ * different), row_info one int per stacked row = kind << 16 | id with kind 0: multiplier row of active constraint id (behind
+ * it: the region without id), 1: row of inactive constraint id (behind it: the region with id added), 2: row of the
+ * parameter set (behind it: nothing), 3: unknown. */
+int mpc_locator_set_adjacency(mpc_locator *loc, int32_t mask_words, int32_t n_c, const uint64_t *masks, const int32_t *row_info);
 int mpc_locator_query(mpc_locator *loc, int64_t m, const double *theta, double tol, int32_t flags, int64_t *region,
                       double *x, float *ms_locate);
 int mpc_locator_destroy(mpc_locator *loc);

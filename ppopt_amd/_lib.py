@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('MPC_LIB_PATH') or os.path.join(_HERE, 'csrc', 'libmpcombi_hip.so')   # MPC_LIB_PATH: A/B builds
 
 MPC_OK, MPC_ERR_INVALID, MPC_ERR_HIP, MPC_ERR_CAPACITY, MPC_ERR_STATE = range(5)
-MPC_LOCATE_OVERLAPPING, MPC_LOCATE_INCLUSIVE = 1, 2   # flags of mpc_locator_query
+MPC_LOCATE_OVERLAPPING, MPC_LOCATE_INCLUSIVE, MPC_LOCATE_WALK = 1, 2, 4   # flags of mpc_locator_query
 MPC_LEVEL_STREAM, MPC_LEVEL_GRAPH, MPC_LEVEL_THEN_BASE = 1, 4, 8   # flags of mpc_level_start / mpc_level_run_ex
 INFEASIBLE, FEASIBLE, OPTIMAL_NO_REGION, REGION, SINGULAR_KKT, LP_LIMIT = range(6)
 LP_OPTIMAL, LP_INFEASIBLE, LP_UNBOUNDED, LP_ITERLIMIT = range(4)
@@ -108,6 +108,7 @@ def load():
         'mpc_locator_query': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, _dp, ctypes.c_double, ctypes.c_int32, _lp, _dp,
                                               ctypes.POINTER(ctypes.c_float)]),
         'mpc_locator_destroy': (ctypes.c_int, [ctypes.c_void_p]),
+        'mpc_locator_set_adjacency': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, _u64p, _ip]),
         'mpc_host_alloc': (ctypes.c_int, [ctypes.c_uint64, ctypes.POINTER(ctypes.c_void_p)]),
         'mpc_host_free': (ctypes.c_int, [ctypes.c_void_p]),
         'mpc_level_children': (ctypes.c_int, [H, _ip, ctypes.c_int64]),
@@ -141,7 +142,7 @@ EXPORTED_SYMBOLS = ['mpc_device_count', 'mpc_version', 'mpc_last_global_error', 
                     'mpc_frontier_root', 'mpc_frontier_set', 'mpc_frontier_set_device', 'mpc_frontier_info',
                     'mpc_frontier_get', 'mpc_pruned_clear', 'mpc_pruned_add', 'mpc_pruned_add_device',
                     'mpc_pruned_count', 'mpc_pruned_get', 'mpc_level_run', 'mpc_level_run_ex', 'mpc_level_status', 'mpc_level_start', 'mpc_level_stream_info', 'mpc_level_chunk_wait', 'mpc_level_wait', 'mpc_level_stream_fixup', 'mpc_base_result', 'mpc_level_regions', 'mpc_compact_strides',
-                    'mpc_level_regions_compact', 'mpc_frontier_shard', 'mpc_level_slots', 'mpc_level_regions_slots', 'mpc_level_regions_slots_async', 'mpc_sync', 'mpc_host_alloc', 'mpc_host_free', 'mpc_locator_create', 'mpc_locator_query', 'mpc_locator_destroy', 'mpc_level_children', 'mpc_level_children_device', 'mpc_level_pruned_new',
+                    'mpc_level_regions_compact', 'mpc_frontier_shard', 'mpc_level_slots', 'mpc_level_regions_slots', 'mpc_level_regions_slots_async', 'mpc_sync', 'mpc_host_alloc', 'mpc_host_free', 'mpc_locator_create', 'mpc_locator_query', 'mpc_locator_destroy', 'mpc_locator_set_adjacency', 'mpc_level_children', 'mpc_level_children_device', 'mpc_level_pruned_new',
                     'mpc_level_pruned_new_device', 'mpc_level_regions_device', 'mpc_frontier_advance', 'mpc_qp_solve_batch', 'mpc_graph_begin', 'mpc_graph_wave', 'mpc_graph_group_run', 'mpc_graph_wave_close', 'mpc_check_level', 'mpc_lp_solve_batch']
 
 
@@ -585,9 +586,19 @@ class Locator:
             raise MpcError(f'mpc_locator_create failed ({rc}): {self._L.mpc_last_global_error().decode()}')
         self._h = ptr
         self.last_ms = 0.0
+        self.has_adjacency = False
+
+    def set_adjacency(self, masks: numpy.ndarray, row_info: numpy.ndarray, n_c: int) -> bool:
+        """Facet adjacency for the walk (mpc_locator_set_adjacency): masks [n_regions, words] uint64, row_info [total_rows]
+        int32 = kind << 16 | id.  False when the library refuses it (two regions with one active set)."""
+        m = numpy.ascontiguousarray(masks, dtype=numpy.uint64)
+        ri = numpy.ascontiguousarray(row_info, dtype=numpy.int32)
+        rc = self._L.mpc_locator_set_adjacency(self._h, int(m.shape[1]), int(n_c), m.ctypes.data_as(_u64p), ri.ctypes.data_as(_ip))
+        self.has_adjacency = rc == MPC_OK
+        return self.has_adjacency
 
     def query(self, theta: numpy.ndarray, tol: float = 1e-5, overlapping: bool = False, want_x: bool = True,
-              inclusive: bool = False):
+              inclusive: bool = False, walk: bool = False):
         """theta [m, n_t] -> (region index [m] (-1: none), x [m, n_x] or None).  ``inclusive``: membership is
         ``E theta <= f + tol`` (MPC_LOCATE_INCLUSIVE) instead of the strict ``E theta - f < tol``."""
         th = _f64(theta).reshape(-1, self.n_t)
@@ -596,7 +607,8 @@ class Locator:
         x = numpy.empty((m, self.n_x)) if want_x else None
         ms = ctypes.c_float(0.0)
         rc = self._L.mpc_locator_query(self._h, m, th.ctypes.data_as(_dp), float(tol),
-                                       (MPC_LOCATE_OVERLAPPING if overlapping else 0) | (MPC_LOCATE_INCLUSIVE if inclusive else 0),
+                                       (MPC_LOCATE_OVERLAPPING if overlapping else 0) | (MPC_LOCATE_INCLUSIVE if inclusive else 0)
+                                       | (MPC_LOCATE_WALK if walk and self.has_adjacency else 0),
                                        region.ctypes.data_as(_lp), None if x is None else x.ctypes.data_as(_dp), ctypes.byref(ms))
         if rc != MPC_OK:
             raise MpcError(f'mpc_locator_query failed ({rc}): {self._L.mpc_last_global_error().decode()}')

@@ -109,6 +109,191 @@ __global__ void __launch_bounds__(256) k_locate(long long m, int nt, int nx, lon
     if (p < m) region_out[p] = found;
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// k_locate_walk: point location by walking through ADJACENT regions (complete, non-overlapping solutions with many regions).
+//
+// The list scan above costs every point a pass over all rows of all regions it is not in -- 4.1e6 rows for the 227,349
+// regions of the complete config 4.  The regions of an mpQP solution are glued along their facets, and a facet knows what
+// lies behind it: the row of a multiplier lambda_a >= 0 is shared with the region whose active set lacks a, the row of an
+// inactive constraint c with the region whose active set has c in addition (Bemporad et al. 2002; the reference's graph
+// algorithm moves the same way, mpqp_graph.py:97-106), a row of A_t theta <= b_t with nothing.  One lane per point: test the
+// rows of the current region; if all hold the point is located, otherwise cross the most violated row to the neighbour, whose
+// region index comes from a binary search of its active-set mask in the sorted mask table.  A point that meets a row of the
+// parameter set is outside the solution (-1); a walk that finds no neighbour behind any violated row (not even with a second
+// row exchanged, the degenerate case), meets a region without facet information or reaches the step limit leaves the point
+// UNRESOLVED (-2), and the host hands it to k_locate_few / the list scan.
+// To return the region the scan would return (the FIRST containing region of the list), a located point is also offered to
+// the neighbours across the rows it satisfies by less than 2*tol, if their index is smaller.
+// row_info[row] = kind << 16 | id:  kind 0 multiplier row of active constraint id, 1 inactive constraint id, 2 A_t row, 3 unknown.
+template <int NT, int MW>
+__global__ void __launch_bounds__(256) k_locate_walk(long long m, int nt, long long n_regions, const long long *__restrict__ row_off,
+                                                     const double *__restrict__ ef, const int32_t *__restrict__ row_info,
+                                                     const unsigned long long *__restrict__ masks,          // [n_regions][MW], region order
+                                                     const unsigned long long *__restrict__ sorted_masks,   // [n_regions][MW], ascending
+                                                     const int32_t *__restrict__ sorted_region,             // region of sorted_masks[i]
+                                                     const double *__restrict__ theta, double tol, int start_region, int max_steps,
+                                                     int n_c, long long *__restrict__ region_out) {
+    const long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= m) return;
+    const int nr = nt + 1;
+    double th[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) th[t] = t < nt ? theta[p * nt + t] : 0.0;
+    auto lookup = [&](const unsigned long long (&key)[MW]) -> long long {
+        long long lo = 0, hi = n_regions;
+        while (lo < hi) {
+            const long long mid = (lo + hi) >> 1;
+            bool less = false, decided = false;
+#pragma unroll
+            for (int j = MW - 1; j >= 0; --j) {
+                const unsigned long long v = sorted_masks[mid * MW + j];
+                if (!decided && v != key[j]) { less = v < key[j]; decided = true; }
+            }
+            if (less) lo = mid + 1; else hi = mid;
+        }
+        if (lo >= n_regions) return -1;
+#pragma unroll
+        for (int j = 0; j < MW; ++j) if (sorted_masks[lo * MW + j] != key[j]) return -1;
+        return sorted_region[lo];
+    };
+    // worst row of region r at theta (value and row); returns false if the region has a row of unknown kind
+    auto worst_row = [&](long long r, double &worst, long long &wrow) {
+        worst = -INFINITY; wrow = -1;
+        for (long long i = row_off[r]; i < row_off[r + 1]; ++i) {
+            double v = -ef[i * nr];
+#pragma unroll
+            for (int t = 0; t < NT; ++t) if (t < nt) v = fma(ef[i * nr + 1 + t], th[t], v);
+            if (v > worst) { worst = v; wrow = i; }
+        }
+    };
+    auto neighbour = [&](long long r, long long row) -> long long {   // -1 outside, -2 unknown
+        const int info = row_info[row], kind = info >> 16, id = info & 0xffff;
+        if (kind == 2) return -1;
+        if (kind == 3) return -2;
+        unsigned long long key[MW];
+#pragma unroll
+        for (int j = 0; j < MW; ++j) key[j] = masks[r * MW + j];
+#pragma unroll
+        for (int j = 0; j < MW; ++j) if ((id >> 6) == j) key[j] ^= 1ull << (id & 63);
+        const long long q = lookup(key);
+        return q < 0 ? -2 : q;
+    };
+    long long r = start_region, prev = -1, found = -2;
+    for (int step = 0; step < max_steps; ++step) {
+        // the violated rows of region r in decreasing order of violation, until one has a region behind it.  (Redundancy removal
+        // keeps rows that only touch the region in a lower-dimensional face -- mpqp_utils.py:143-178 keeps weakly redundant
+        // rows -- and nothing lies behind those; a true facet of a complete solution has a neighbour unless it is part of the
+        // boundary of the feasible parameter set.)
+        double bound = INFINITY;
+        long long next = -2;
+        bool any_violated = false, met_omega = false, met_unknown = false;
+        for (;;) {
+            double worst = -INFINITY; long long wrow = -1;
+            for (long long i = row_off[r]; i < row_off[r + 1]; ++i) {
+                double v = -ef[i * nr];
+#pragma unroll
+                for (int t = 0; t < NT; ++t) if (t < nt) v = fma(ef[i * nr + 1 + t], th[t], v);
+                if (v > worst && v < bound) { worst = v; wrow = i; }
+            }
+            if (wrow < 0 || worst < tol) break;          // no (further) violated row
+            any_violated = true;
+            const long long q = neighbour(r, wrow);
+            if (q >= 0 && q != prev) { next = q; break; }   // never straight back: two regions that both see the point behind their common facet
+            if (q == -1) { met_omega = true; if (worst > 10.0 * tol) break; }   // clearly outside the parameter set: no region can contain the point
+            else if ((row_info[wrow] >> 16) >= 3) met_unknown = true;
+            bound = worst;
+        }
+        if (!any_violated) { found = row_off[r + 1] > row_off[r] ? r : -2; break; }
+        if (next >= 0) { prev = r; r = next; continue; }
+        // Every violated row leads nowhere with one row added or removed.  Where the constraint gradients are dependent the
+        // region behind a facet differs by TWO rows (one enters, one leaves): try, for the most violated rows, the neighbour's
+        // active set with one further row exchanged, and take the first that exists and is violated less than this region.
+        if (!met_omega) {
+            double vbound = INFINITY;
+            for (int attempt = 0; attempt < 3 && next < 0; ++attempt) {
+                double worst = -INFINITY; long long wrow = -1;
+                for (long long i = row_off[r]; i < row_off[r + 1]; ++i) {
+                    double v = -ef[i * nr];
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) if (t < nt) v = fma(ef[i * nr + 1 + t], th[t], v);
+                    if (v > worst && v < vbound) { worst = v; wrow = i; }
+                }
+                if (wrow < 0 || worst < tol) break;
+                vbound = worst;
+                const int info = row_info[wrow], kind = info >> 16, id = info & 0xffff;
+                if (kind >= 2) continue;
+                unsigned long long base[MW];
+#pragma unroll
+                for (int j = 0; j < MW; ++j) base[j] = masks[r * MW + j];
+#pragma unroll
+                for (int j = 0; j < MW; ++j) if ((id >> 6) == j) base[j] ^= 1ull << (id & 63);
+                for (int c2 = 0; c2 < n_c && next < 0; ++c2) {
+                    if (c2 == id) continue;
+                    const bool in_set = (base[c2 >> 6] >> (c2 & 63)) & 1ull;
+                    if ((kind == 1) != in_set) continue;          // a row entered: one of the others leaves; a row left: another enters
+                    unsigned long long key[MW];
+#pragma unroll
+                    for (int j = 0; j < MW; ++j) key[j] = base[j];
+                    key[c2 >> 6] ^= 1ull << (c2 & 63);
+                    const long long q = lookup(key);
+                    if (q >= 0 && q != r) {
+                        double w; long long wr;
+                        worst_row(q, w, wr);
+                        if (wr >= 0 && w < worst) next = q;       // strictly less violated: the walk cannot return here through this move
+                    }
+                }
+            }
+        }
+        if (next >= 0) { prev = r; r = next; continue; }
+        found = met_omega ? -1 : -2;
+        break;
+    }
+    if (found >= 0) {
+        // first-match rule of the list scan: an earlier region that also contains the point within the tolerance wins
+        long long best = found;
+        for (long long i = row_off[found]; i < row_off[found + 1]; ++i) {
+            double v = -ef[i * nr];
+#pragma unroll
+            for (int t = 0; t < NT; ++t) if (t < nt) v = fma(ef[i * nr + 1 + t], th[t], v);
+            if (v > -2.0 * tol) {
+                const long long q = neighbour(found, i);
+                if (q >= 0 && q < best) {
+                    double w; long long wr;
+                    worst_row(q, w, wr);
+                    if (wr >= 0 && w < tol) best = q;
+                }
+            }
+        }
+        found = best;
+    }
+    region_out[p] = found;
+}
+
+// The few points the walk left unresolved: one thread per (point, region), the first containing region by atomicMin.
+// Work = points x rows, spread over the whole device -- the list scan would serialise 4e6 rows behind one wavefront.
+template <int NT>
+__global__ void __launch_bounds__(256) k_locate_few(long long n_pts, int nt, long long n_regions, const long long *__restrict__ row_off,
+                                                    const double *__restrict__ ef, const double *__restrict__ theta, double tol,
+                                                    long long *__restrict__ region_out) {
+    const long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long p = blockIdx.y;
+    if (r >= n_regions || p >= n_pts) return;
+    const int nr = nt + 1;
+    double th[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) th[t] = t < nt ? theta[p * nt + t] : 0.0;
+    const long long i0 = row_off[r], i1 = row_off[r + 1];
+    if (i1 <= i0) return;
+    bool inside = true;
+    for (long long i = i0; i < i1 && inside; ++i) {
+        double v = -ef[i * nr];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) if (t < nt) v = fma(ef[i * nr + 1 + t], th[t], v);
+        inside = v < tol;
+    }
+    if (inside) atomicMin(reinterpret_cast<unsigned long long *>(region_out + p), (unsigned long long)r);
+}
+
 // x*(theta) = A theta + b of the region each point was located in (NaN where there is none)
 __global__ void __launch_bounds__(256) k_evaluate(long long m, int nt, int nx, const double *__restrict__ xlaw, const double *__restrict__ theta,
                                                   const long long *__restrict__ region, double *__restrict__ x) {

@@ -2269,6 +2269,11 @@ struct mpc_locator {
     hipStream_t stream = nullptr;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     DevBuf row_off, row_region, row_end, ef, xlaw, Q, c, H, theta, region, x;
+    // adjacency for the walk (mpc_locator_set_adjacency): active-set masks in region order and sorted, facet kind / id per row
+    DevBuf masks, sorted_masks, sorted_region, row_info, theta2, region2;
+    int mask_words = 0, n_c = 0;
+    bool has_adj = false;
+    long long last_unresolved = 0;   // points of the last walk query that went to the list scan
     bool hasQ = false, hasc = false, hasH = false;
 };
 
@@ -2318,6 +2323,43 @@ static int locator_fill(mpc_locator *L, int64_t n_regions, const int64_t *row_of
     return MPC_OK;
 }
 
+extern "C" int mpc_locator_set_adjacency(mpc_locator *L, int32_t mask_words, int32_t n_c, const uint64_t *masks, const int32_t *row_info) {
+    if (!L || !masks || !row_info || (mask_words != 2 && mask_words != 4) || n_c < 1 || n_c > 64 * mask_words) return MPC_ERR_INVALID;
+    HIP_TRY(nullptr, hipSetDevice(L->device));
+    const long long n = L->n_regions, rows = L->n_rows;
+    if (n <= 0) return MPC_OK;
+    const int mw = mask_words;
+    // the mask table sorted ascending (most significant word last), with the region each mask belongs to
+    std::vector<int32_t> order((size_t)n);
+    for (long long i = 0; i < n; ++i) order[(size_t)i] = (int32_t)i;
+    std::sort(order.begin(), order.end(), [&](int32_t a, int32_t b) {
+        for (int j = mw - 1; j >= 0; --j) { const uint64_t va = masks[(size_t)a * mw + j], vb = masks[(size_t)b * mw + j]; if (va != vb) return va < vb; }
+        return a < b;
+    });
+    std::vector<uint64_t> sorted((size_t)n * mw);
+    for (long long i = 0; i < n; ++i) for (int j = 0; j < mw; ++j) sorted[(size_t)i * mw + j] = masks[(size_t)order[(size_t)i] * mw + j];
+    for (long long i = 1; i < n; ++i) {   // two regions with one active set: no unique neighbour, no walk
+        bool same = true;
+        for (int j = 0; j < mw; ++j) same = same && sorted[(size_t)i * mw + j] == sorted[(size_t)(i - 1) * mw + j];
+        if (same) return fail(nullptr, MPC_ERR_INVALID, "mpc_locator_set_adjacency: two regions share one active set");
+    }
+    hipStream_t st = L->stream;
+    auto up = [&](DevBuf &b, const void *src, size_t bytes) -> hipError_t {
+        hipError_t e = b.ensure(std::max<size_t>(bytes, 8), st);
+        if (e != hipSuccess || !bytes) return e;
+        return hipMemcpyAsync(b.p, src, bytes, hipMemcpyHostToDevice, st);
+    };
+    HIP_TRY(nullptr, up(L->masks, masks, (size_t)n * mw * sizeof(uint64_t)));
+    HIP_TRY(nullptr, up(L->sorted_masks, sorted.data(), (size_t)n * mw * sizeof(uint64_t)));
+    HIP_TRY(nullptr, up(L->sorted_region, order.data(), (size_t)n * sizeof(int32_t)));
+    HIP_TRY(nullptr, up(L->row_info, row_info, (size_t)rows * sizeof(int32_t)));
+    HIP_TRY(nullptr, hipStreamSynchronize(st));
+    L->mask_words = mw;
+    L->n_c = n_c;
+    L->has_adj = true;
+    return MPC_OK;
+}
+
 extern "C" int mpc_locator_query(mpc_locator *L, int64_t m, const double *theta, double tol, int32_t flags, int64_t *region, double *x,
                                  float *ms_locate) {
     if (!L || m < 0 || (m > 0 && (!theta || !region))) return MPC_ERR_INVALID;
@@ -2332,14 +2374,59 @@ extern "C" int mpc_locator_query(mpc_locator *L, int64_t m, const double *theta,
     const dim3 g((unsigned)((m + 255) / 256)), b(256);
     const double *Q = L->hasQ ? L->Q.as<double>() : nullptr, *c = L->hasc ? L->c.as<double>() : nullptr, *H = L->hasH ? L->H.as<double>() : nullptr;
     HIP_TRY(nullptr, hipEventRecord(L->e0, st));
-#define MPC_LOCATE(NT_) hipLaunchKernelGGL((k_locate<NT_>), g, b, 0, st, (long long)m, nt, nx, L->n_regions, L->n_rows, L->row_region.as<int32_t>(), \
-                                           L->row_end.as<int32_t>(), L->ef.as<double>(), L->xlaw.as<double>(), Q, c, H, L->theta.as<double>(), tol, \
-                                           (int)(flags & MPC_LOCATE_OVERLAPPING), (int)((flags & MPC_LOCATE_INCLUSIVE) != 0), L->region.as<long long>())
-    if (nt <= 4) MPC_LOCATE(4); else if (nt <= 8) MPC_LOCATE(8); else MPC_LOCATE(16);
+#define MPC_LOCATE(NT_, M_, TH_, OUT_) hipLaunchKernelGGL((k_locate<NT_>), dim3((unsigned)(((M_) + 255) / 256)), b, 0, st, (long long)(M_), nt, nx, L->n_regions, L->n_rows, L->row_region.as<int32_t>(), \
+                                           L->row_end.as<int32_t>(), L->ef.as<double>(), L->xlaw.as<double>(), Q, c, H, TH_, tol, \
+                                           (int)(flags & MPC_LOCATE_OVERLAPPING), (int)((flags & MPC_LOCATE_INCLUSIVE) != 0), OUT_)
+#define MPC_LOCATE_ANY(M_, TH_, OUT_) do { if (nt <= 4) MPC_LOCATE(4, M_, TH_, OUT_); else if (nt <= 8) MPC_LOCATE(8, M_, TH_, OUT_); else MPC_LOCATE(16, M_, TH_, OUT_); } while (0)
+    const bool walk = (flags & MPC_LOCATE_WALK) && L->has_adj && !(flags & (MPC_LOCATE_OVERLAPPING | MPC_LOCATE_INCLUSIVE)) && L->n_regions > 0 && nt <= 16;
+    if (!walk) {
+        MPC_LOCATE_ANY(m, L->theta.as<double>(), L->region.as<long long>());
+        HIP_TRY(nullptr, hipGetLastError());
+        HIP_TRY(nullptr, hipEventRecord(L->e1, st));
+        HIP_TRY(nullptr, hipMemcpyAsync(region, L->region.p, (size_t)m * sizeof(long long), hipMemcpyDeviceToHost, st));
+    } else {
+        // walk through adjacent regions; what the walk cannot resolve goes to the list scan
+        const int max_steps = 384;   // walks are tens of steps long; what is still open then (points outside the solution, mostly) goes to k_locate_few
+#define MPC_WALK(NT_, MW_) hipLaunchKernelGGL((k_locate_walk<NT_, MW_>), g, b, 0, st, (long long)m, nt, L->n_regions, L->row_off.as<long long>(), L->ef.as<double>(), \
+                                              L->row_info.as<int32_t>(), L->masks.as<unsigned long long>(), L->sorted_masks.as<unsigned long long>(), \
+                                              L->sorted_region.as<int32_t>(), L->theta.as<double>(), tol, 0, max_steps, L->n_c, L->region.as<long long>())
+        if (L->mask_words == 2) { if (nt <= 4) MPC_WALK(4, 2); else if (nt <= 8) MPC_WALK(8, 2); else MPC_WALK(16, 2); }
+        else { if (nt <= 4) MPC_WALK(4, 4); else if (nt <= 8) MPC_WALK(8, 4); else MPC_WALK(16, 4); }
+#undef MPC_WALK
+        HIP_TRY(nullptr, hipGetLastError());
+        HIP_TRY(nullptr, hipMemcpyAsync(region, L->region.p, (size_t)m * sizeof(long long), hipMemcpyDeviceToHost, st));
+        HIP_TRY(nullptr, hipStreamSynchronize(st));
+        std::vector<long long> open;
+        for (long long p = 0; p < m; ++p) if (region[p] == -2) open.push_back(p);
+        if (!open.empty()) {
+            const long long mo = (long long)open.size();
+            std::vector<double> tho((size_t)mo * nt);
+            for (long long i = 0; i < mo; ++i) std::memcpy(&tho[(size_t)i * nt], theta + (size_t)open[(size_t)i] * nt, sizeof(double) * nt);
+            std::vector<long long> ro((size_t)mo);
+            HIP_TRY(nullptr, L->theta2.ensure((size_t)mo * nt * sizeof(double), st));
+            HIP_TRY(nullptr, L->region2.ensure((size_t)mo * sizeof(long long), st));
+            HIP_TRY(nullptr, hipMemcpyAsync(L->theta2.p, tho.data(), (size_t)mo * nt * sizeof(double), hipMemcpyHostToDevice, st));
+            if (mo <= 16384) {
+                // few points: every (point, region) pair in parallel, first containing region by atomicMin
+                HIP_TRY(nullptr, hipMemsetAsync(L->region2.p, 0xff, (size_t)mo * sizeof(long long), st));   // = "none yet" (max u64)
+                const dim3 gf((unsigned)((L->n_regions + 255) / 256), (unsigned)mo);
+                if (nt <= 4) hipLaunchKernelGGL((k_locate_few<4>), gf, b, 0, st, mo, nt, L->n_regions, L->row_off.as<long long>(), L->ef.as<double>(), L->theta2.as<double>(), tol, L->region2.as<long long>());
+                else if (nt <= 8) hipLaunchKernelGGL((k_locate_few<8>), gf, b, 0, st, mo, nt, L->n_regions, L->row_off.as<long long>(), L->ef.as<double>(), L->theta2.as<double>(), tol, L->region2.as<long long>());
+                else hipLaunchKernelGGL((k_locate_few<16>), gf, b, 0, st, mo, nt, L->n_regions, L->row_off.as<long long>(), L->ef.as<double>(), L->theta2.as<double>(), tol, L->region2.as<long long>());
+            } else {
+                MPC_LOCATE_ANY(mo, L->theta2.as<double>(), L->region2.as<long long>());
+            }
+            HIP_TRY(nullptr, hipGetLastError());
+            HIP_TRY(nullptr, hipMemcpyAsync(ro.data(), L->region2.p, (size_t)mo * sizeof(long long), hipMemcpyDeviceToHost, st));
+            HIP_TRY(nullptr, hipStreamSynchronize(st));
+            for (long long i = 0; i < mo; ++i) region[open[(size_t)i]] = ro[(size_t)i];   // -1 (all ones) where no region contains the point
+            HIP_TRY(nullptr, hipMemcpyAsync(L->region.p, region, (size_t)m * sizeof(long long), hipMemcpyHostToDevice, st));   // k_evaluate reads it
+        }
+        L->last_unresolved = (long long)open.size();
+        HIP_TRY(nullptr, hipEventRecord(L->e1, st));
+    }
+#undef MPC_LOCATE_ANY
 #undef MPC_LOCATE
-    HIP_TRY(nullptr, hipGetLastError());
-    HIP_TRY(nullptr, hipEventRecord(L->e1, st));
-    HIP_TRY(nullptr, hipMemcpyAsync(region, L->region.p, (size_t)m * sizeof(long long), hipMemcpyDeviceToHost, st));
     if (x) {
         HIP_TRY(nullptr, L->x.ensure((size_t)m * nx * sizeof(double), st));
         const long long tot = (long long)m * nx;
@@ -2357,7 +2444,8 @@ extern "C" int mpc_locator_destroy(mpc_locator *L) {
     if (!L) return MPC_OK;
     (void)hipSetDevice(L->device);
     if (L->stream) (void)hipStreamSynchronize(L->stream);
-    for (DevBuf *b : {&L->row_off, &L->row_region, &L->row_end, &L->ef, &L->xlaw, &L->Q, &L->c, &L->H, &L->theta, &L->region, &L->x}) b->release();
+    for (DevBuf *b : {&L->row_off, &L->row_region, &L->row_end, &L->ef, &L->xlaw, &L->Q, &L->c, &L->H, &L->theta, &L->region, &L->x, &L->masks, &L->sorted_masks,
+                      &L->sorted_region, &L->row_info, &L->theta2, &L->region2}) b->release();
     if (L->e0) (void)hipEventDestroy(L->e0);
     if (L->e1) (void)hipEventDestroy(L->e1);
     if (L->stream) (void)hipStreamDestroy(L->stream);

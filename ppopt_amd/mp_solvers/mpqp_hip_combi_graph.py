@@ -206,6 +206,8 @@ def _traverse(program, device, seeds, profile, max_candidates, graph_question: b
         if max_candidates is not None and examined >= max_candidates:
             break
         todo = new
+    else:
+        solution.is_complete = True
     return solution
 
 
@@ -218,6 +220,7 @@ def _traverse_device(eng, solution: Solution, seed_masks: numpy.ndarray, profile
     while True:
         groups, _ = eng.graph_wave()
         if not groups:
+            solution.is_complete = True      # the traversal ran dry: every reachable region is in the solution
             break
         n_regions, hist = 0, numpy.zeros(6, dtype=numpy.int64)
         for gi in range(len(groups)):

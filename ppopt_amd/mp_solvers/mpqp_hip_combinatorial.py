@@ -150,4 +150,5 @@ def solve(program, num_cores: int = -1, device: int = 0, profile: Optional[List[
                         'regions': len(rd)})
     if collect_regions and len(rd):
         solution.add_region(unpack_region(rd[0], ri[0], n_x, n_t, n_c, n_tc))
+    solution.is_complete = collect_regions and max_levels is None      # every cardinality up to max(n_x, n_theta) was enumerated
     return solution

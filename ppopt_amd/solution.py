@@ -7,6 +7,15 @@ from .critical_region import CriticalRegion
 
 
 class Solution:
+    # Batched point location walks through adjacent regions (csrc/locate.hpp, k_locate_walk) instead of scanning the region
+    # list when the solution is complete, has at least this many regions, is not overlapping and came from the device (facet
+    # information per row); ``use_walk = False`` forces the scan.
+    WALK_MIN_REGIONS = 2048
+    use_walk = True
+    # the regions cover the whole feasible parameter set (set by the solvers that run to completion): the walk is only used
+    # then -- in a partial solution most walks end at a missing neighbour
+    is_complete = False
+
     def __init__(self, program, critical_regions: List[CriticalRegion], is_overlapping: bool = False,
                  point_location_tolerance: float = 1e-5):
         self.program = program
@@ -49,6 +58,9 @@ class Solution:
         regs = self.critical_regions
         n_t = self.program.num_t() if self.program is not None else regs[0].E.shape[1]
         ef_parts, cnt, xl_parts = [], [], []
+        adj_masks, adj_info, adj_ok = [], [], True       # facet adjacency for the walk locator (device-solved regions only)
+        n_c = self.program.num_constraints() if self.program is not None else 0
+        words = 2 if n_c <= 128 else 4
         i = 0
         while i < len(regs):
             r = regs[i]
@@ -67,6 +79,33 @@ class Solution:
                 A = B.hd[slots, B.oA:B.ob].reshape(len(slots), B.n_x, B.n_t)
                 b = B.hd[slots, B.ob:B.oC].reshape(len(slots), B.n_x, 1)
                 xl_parts.append(numpy.concatenate([b, A], axis=2))
+                if adj_ok:
+                    # rows of E in order: kept multiplier rows (lambda_set), kept inactive rows (regular_set[1]), kept A_t rows
+                    # (omega_set); a region that lost exact duplicate rows (fewer rows than entries) gets kind "unknown"
+                    hi = B.hi[slots]
+                    la = hi[:, B.ila:B.ila + B.k]
+                    rc_ = hi[:, B.irc:B.irc + (B.n_c - B.k)]
+                    om = hi[:, B.iom:B.iom + B.n_tc]
+                    pad = numpy.concatenate([numpy.where(la >= 0, la, -1), numpy.where(rc_ >= 0, rc_ + (1 << 16), -1),
+                                             numpy.where(om >= 0, om + (2 << 16), -1)], axis=1)
+                    n_lists = (pad >= 0).sum(axis=1)
+                    good = n_lists == nE
+                    info = pad[pad >= 0]
+                    if not good.all():
+                        # rebuild per region: unknown rows where the counts disagree
+                        parts, pos = [], 0
+                        for q in range(len(slots)):
+                            seg = info[pos:pos + n_lists[q]]
+                            pos += n_lists[q]
+                            parts.append(seg if good[q] else numpy.full(int(nE[q]), 3 << 16, dtype=numpy.int64))
+                        info = numpy.concatenate(parts) if parts else info
+                    adj_info.append(info.astype(numpy.int32))
+                    act = hi[:, B.iact:B.iact + B.k].astype(numpy.int64)
+                    mk = numpy.zeros((len(slots), words), dtype=numpy.uint64)
+                    for col in range(B.k):
+                        numpy.bitwise_or.at(mk, (numpy.arange(len(slots)), act[:, col] >> 6),
+                                            numpy.uint64(1) << (act[:, col] & 63).astype(numpy.uint64))
+                    adj_masks.append(mk)
                 i = j
             else:
                 ef_parts.append(numpy.hstack([numpy.asarray(r.f, dtype=float).reshape(-1, 1), numpy.asarray(r.E, dtype=float).reshape(-1, n_t)]))
@@ -81,9 +120,18 @@ class Solution:
                     b_full[r.y_indices, 0] = r.y_fixation
                     bx, Ax = b_full, A_full
                 xl_parts.append(numpy.concatenate([bx[None], Ax[None]], axis=2))
+                # a hand-built region carries its index sets too, but not necessarily in row order: no walk through it
+                adj_info.append(numpy.full(ef_parts[-1].shape[0], 3 << 16, dtype=numpy.int32))
+                mk = numpy.zeros((1, words), dtype=numpy.uint64)
+                for v in (r.active_set if r.y_fixation is None else []):
+                    mk[0, int(v) >> 6] |= numpy.uint64(1) << numpy.uint64(int(v) & 63)
+                adj_masks.append(mk)
+                if r.y_fixation is not None:
+                    adj_ok = False        # regions of different fixations share active sets
                 i += 1
         counts = numpy.concatenate(cnt) if cnt else numpy.zeros(0, dtype=numpy.int64)
         row_off = numpy.concatenate([[0], numpy.cumsum(counts)]).astype(numpy.int64)
+        self._adjacency = (numpy.concatenate(adj_masks, axis=0), numpy.concatenate(adj_info)) if adj_ok and adj_masks else None
         return numpy.vstack(ef_parts), row_off, numpy.concatenate(xl_parts, axis=0)
 
     def locator(self, device: int = 0):
@@ -97,6 +145,9 @@ class Solution:
             ef, row_off, xlaw = self._stacked()
             P = self.program
             self._locator = _lib.Locator(row_off, ef, xlaw, getattr(P, 'Q', None), getattr(P, 'c', None), getattr(P, 'H', None), device)
+            adj = getattr(self, '_adjacency', None)
+            if adj is not None and len(adj[1]) == int(row_off[-1]) and len(self.critical_regions) >= self.WALK_MIN_REGIONS:
+                self._locator.set_adjacency(adj[0], adj[1], P.num_constraints())
             self._locator_key = key
         return self._locator
 
@@ -107,7 +158,7 @@ class Solution:
         if not self.critical_regions:
             return numpy.full(len(numpy.atleast_2d(theta_points)), -1, dtype=numpy.int64)
         return self.locator(device).query(theta_points, self.point_location_tolerance, self.is_overlapping, want_x=False,
-                                          inclusive=inclusive)[0]
+                                          inclusive=inclusive, walk=self.use_walk and self.is_complete)[0]
 
     def evaluate_batch(self, theta_points: numpy.ndarray, device: int = 0, inclusive: bool = False):
         """(x* [m, n_x] (NaN rows where no region contains the point), region index [m])  -- evaluate() for many points."""
@@ -115,7 +166,7 @@ class Solution:
         if not self.critical_regions:
             return numpy.full((len(th), 0), numpy.nan), numpy.full(len(th), -1, dtype=numpy.int64)
         region, x = self.locator(device).query(th, self.point_location_tolerance, self.is_overlapping, want_x=True,
-                                               inclusive=inclusive)
+                                               inclusive=inclusive, walk=self.use_walk and self.is_complete)
         return x, region
 
     # ---- verification without a QP solver: the KKT conditions of the program at theta ----------------------------------------

@@ -799,11 +799,19 @@ def test_graph_traversal_complete_solution_of_config4():
     th = _theta_samples(prog, 4000, 2)
     th = th[numpy.all(prog.A_t @ th.T <= prog.b_t - 1e-9, axis=0)]  # strictly inside the parameter box
     assert len(th) > 1000
+    assert sol.is_complete and sol.locator().has_adjacency       # located by walking through adjacent regions
     x, idx = sol.evaluate_batch(th)
     assert (idx >= 0).all()
     for p in range(0, len(th), 40):
         r = sol.kkt_residuals(sol.critical_regions[int(idx[p])], th[p].reshape(-1, 1))
         assert max(r.values()) <= 1e-8, (p, r)
+    # the walk returns exactly what the list scan returns (first containing region; -1 outside), also for points around the box
+    wide = _theta_samples(prog, 3000, 4)
+    xw, iw = sol.evaluate_batch(wide)
+    sol.use_walk = False
+    xs, i_s = sol.evaluate_batch(wide)
+    assert numpy.array_equal(iw, i_s) and (i_s < 0).any() and (i_s >= 0).any()
+    assert numpy.array_equal(numpy.isnan(xw), numpy.isnan(xs)) and numpy.allclose(xw[i_s >= 0], xs[i_s >= 0], rtol=0, atol=0)
     prog.release_engine()
 
 
