@@ -50,6 +50,21 @@ def build_program(name, device=0):
                             equality_indices=d['equality_indices'], solver=Solver(device=device))
 
 
+def theta_box(prog):
+    """(lo, hi) of the parameter set when it is a box: read off the rows of A_t theta <= b_t that have a single entry."""
+    nt = prog.num_t()
+    lo, hi = numpy.full(nt, -numpy.inf), numpy.full(nt, numpy.inf)
+    for row, rhs in zip(prog.A_t, prog.b_t.ravel()):
+        nz = numpy.flatnonzero(numpy.abs(row) > 1e-12)
+        if len(nz) == 1:
+            j = int(nz[0])
+            if row[j] > 0:
+                hi[j] = min(hi[j], rhs / row[j])
+            else:
+                lo[j] = max(lo[j], rhs / row[j])
+    return lo, hi
+
+
 def algorithmic_bytes(prog, k, rho, n_e):
     """B_alg per candidate: shared problem block streamed once per wavefront + candidate indices +
     status/child count + (regions per candidate) x region record."""
@@ -355,11 +370,30 @@ def main():
             dtq = time.perf_counter() - tq
             if dtq < best:
                 best, gprof, n_reg = dtq, gp, len(gsol.critical_regions)
+            last = gsol
             del gsol
         n_sets = sum(p['candidates'] for p in gprof)
         out['complete_solution'] = {'algorithm': 'graph (connected-graph traversal, device bookkeeping)', 'regions': n_reg,
                                     'active_sets_examined': n_sets, 'waves': len(gprof), 'ms': 1e3 * best,
                                     'active_sets_per_s': n_sets / best, 'regions_per_s': n_reg / best}
+        if args.locate > 0:
+            # point location over the COMPLETE solution: uniform points of the parameter box, located by walking through
+            # adjacent regions (k_locate_walk); the list scan is timed on a small subsample for comparison
+            lo_b, hi_b = theta_box(prog)
+            rngp = numpy.random.default_rng(1)
+            pts = lo_b + rngp.random((max(args.locate, 1000), prog.num_t())) * (hi_b - lo_b)
+            locw = last.locator(local_rank)
+            last.evaluate_batch(pts[:2048])
+            tq = time.perf_counter(); _, idxw = last.evaluate_batch(pts); wallw = time.perf_counter() - tq
+            kms = locw.last_ms
+            last.use_walk = False
+            sub = pts[:2000]
+            tq = time.perf_counter(); _, idxs = last.evaluate_batch(sub); walls = time.perf_counter() - tq
+            out['complete_solution']['point_location'] = {
+                'points': int(len(pts)), 'located': int((idxw >= 0).sum()), 'walk_kernel_ms': kms, 'walk_points_per_s_kernel': len(pts) / max(kms, 1e-9) * 1e3,
+                'walk_points_per_s_wall': len(pts) / wallw, 'scan_points_per_s_wall': len(sub) / walls, 'scan_sample': int(len(sub)),
+                'walk_equals_scan_on_sample': bool(numpy.array_equal(idxw[:len(sub)], idxs))}
+        del last
     if rank == 0 and not distributed and args.cpu_sample > 0:
         # frontiers of every level for the CPU sample: one extra untimed pass
         eng = prog.engine(local_rank)

@@ -59,7 +59,8 @@ class Solution:
         n_t = self.program.num_t() if self.program is not None else regs[0].E.shape[1]
         ef_parts, cnt, xl_parts = [], [], []
         adj_masks, adj_info, adj_ok = [], [], True       # facet adjacency for the walk locator (device-solved regions only)
-        n_c = self.program.num_constraints() if self.program is not None else 0
+        n_c = self.program.num_constraints() if hasattr(self.program, 'num_constraints') else 0
+        adj_ok = n_c > 0
         words = 2 if n_c <= 128 else 4
         i = 0
         while i < len(regs):
