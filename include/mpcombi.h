@@ -236,8 +236,9 @@ int mpc_frontier_advance(mpc_handle *h);
  *   mpc_graph_begin       seeds (host masks, duplicates allowed) -> first wave
  *   mpc_graph_wave        the groups of the current wave, one (or, beyond 4M masks, several) per cardinality; n_groups == 0:
  *                         the traversal is complete
- *   mpc_graph_group_run   one group = one frontier of the level kernels (MPC_LEVEL_GRAPH verdicts for variant 0, full verdicts
- *                         for variant 1); afterwards mpc_level_status / mpc_level_regions_slots etc. describe that group; the
+ *   mpc_graph_group_run   one group = one frontier of the level kernels (MPC_LEVEL_GRAPH verdicts: neither traversal needs the
+ *                         (x,theta) feasibility LP -- without a pruning list "infeasible" and "not optimal" hand on the same
+ *                         neighbours); afterwards mpc_level_status / mpc_level_regions_slots etc. describe that group; the
  *                         group's neighbours are appended to the pending list
  *   mpc_graph_wave_close  pending -> sorted, deduplicated, minus everything queued before = the next wave */
 int mpc_graph_begin(mpc_handle *h, const uint64_t *seed_masks_host, int64_t n_seeds, int32_t variant);

@@ -2038,7 +2038,10 @@ int g_group_run(mpc_handle *h, int gi, mpc_level_stats *stats) {
         if (rc) return rc;
         if (k > 0) hipLaunchKernelGGL(k_g_frontier<MW>, dim3(nb), dim3(256), 0, st, masks, cnt, k, h->frontier.as<int32_t>());
         HIP_TRY(h, hipGetLastError());
-        rc = level_run_impl(h, 0, g.variant == 0 ? MPC_LEVEL_GRAPH : 0, &ls);
+        // Both traversals only need "rank deficient / no region / non-empty but lower dimensional / region": mpqp_graph.py hands on
+        // the same subsets whether a set is infeasible or feasible but not optimal (:69-91; only its pruning list tells them apart,
+        // and no pruning list is kept here), so the (x,theta) feasibility LP is left out for it as well.
+        rc = level_run_impl(h, 0, MPC_LEVEL_GRAPH, &ls);
         if (rc) return rc;
     }
     if (stats) *stats = ls;

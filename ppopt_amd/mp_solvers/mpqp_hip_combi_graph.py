@@ -174,7 +174,7 @@ def _traverse(program, device, seeds, profile, max_candidates, graph_question: b
                 status[sel] = INFEASIBLE
                 continue
             eng.frontier_set(_masks_to_index_rows(masks[sel], k, n_c))
-            st = eng.level_run(False, graph=graph_question)
+            st = eng.level_run(False, graph=True)    # neither traversal needs the (x,theta) feasibility LP (see solve_graph)
             status[sel] = eng.level_status()
             if st.n_regions:
                 hd, hi, er, kk, slots = eng.level_regions_slots()
@@ -252,10 +252,12 @@ def solve_graph(program, num_cores: int = -1, device: Optional[int] = None, seed
                 profile: Optional[List[Dict]] = None, max_candidates: Optional[int] = None) -> Solution:
     """mpqp_algorithm.graph and its variants (mpqp_graph.py:38-108, Oberdieck et al. 2016): from every full-dimensional
     region the traversal moves to the active sets with one row less and to those with one of the region's facet constraints
-    added; failed active sets only hand on their subsets.  Every visited set gets the full verdict of the combinatorial
-    path (rank, (x,theta) feasibility, optimality, region).  The reference's pruning list only spares evaluations (a
-    superset of an infeasible set is infeasible) and is not kept here -- the semantics of ``use_pruning=False``; like the
-    reference, the method can miss regions whose neighbours differ by more than one row (mpqp_graph.py:50)."""
+    added; failed active sets only hand on their subsets.  The reference's pruning list only spares evaluations (a
+    superset of an infeasible set is infeasible) and is not kept here -- the semantics of ``use_pruning=False``.  Without
+    it, an infeasible set and a feasible but not optimal one are treated alike (mpqp_graph.py:69-91 hand on the same
+    subsets), so the (x,theta) feasibility LP is not posed: every visited set gets the rank test, the KKT solve and the
+    "region non-empty" LP of MPC_LEVEL_GRAPH.  Like the reference, the method can miss regions whose neighbours differ
+    by more than one row (mpqp_graph.py:50)."""
     return _traverse(program, device, seeds, profile, max_candidates, False)
 
 
