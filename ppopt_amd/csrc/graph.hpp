@@ -52,10 +52,13 @@ __global__ void k_g_gather(const GMask<MW> *__restrict__ src, const unsigned int
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) dst[i] = src[perm[i]];
 }
-// histogram of the (sorted) cardinalities: hist[k] = number of masks with k rows (k <= 256)
-__global__ void k_g_hist(const unsigned int *__restrict__ card, long long n, int32_t *__restrict__ hist) {
+// group boundaries of the SORTED cardinalities: first[k] = index of the first mask with k rows (untouched = -1: no such mask).
+// (A histogram with one atomic per mask serialises on the few distinct cardinalities of a wave: 0.46 ms per call.)
+__global__ void k_g_first(const unsigned int *__restrict__ card, long long n, int32_t *__restrict__ first) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) atomicAdd(&hist[card[i] > 256u ? 256u : card[i]], 1);
+    if (i >= n) return;
+    const unsigned int c = card[i] > 256u ? 256u : card[i];
+    if (i == 0 || (card[i - 1] > 256u ? 256u : card[i - 1]) != c) first[c] = (int32_t)i;
 }
 
 // masks with exactly k rows -> sorted index lists (the frontier layout of the level kernels)

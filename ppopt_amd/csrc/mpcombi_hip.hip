@@ -2000,8 +2000,8 @@ int g_close(mpc_handle *h) {
     HIP_TRY(h, g.wave.ensure((size_t)n_new * sizeof(M), st));
     hipLaunchKernelGGL(k_g_gather<MW>, dim3(nbn), dim3(256), 0, st, fresh, g.idx2.as<unsigned int>(), n_new, g.wave.as<M>());
     HIP_TRY(h, g.hist.ensure(257 * sizeof(int32_t), st));
-    HIP_TRY(h, hipMemsetAsync(g.hist.p, 0, 257 * sizeof(int32_t), st));
-    hipLaunchKernelGGL(k_g_hist, dim3(nbn), dim3(256), 0, st, g.card2.as<unsigned int>(), n_new, g.hist.as<int32_t>());
+    HIP_TRY(h, hipMemsetAsync(g.hist.p, 0xff, 257 * sizeof(int32_t), st));   // -1: no mask of that cardinality
+    hipLaunchKernelGGL(k_g_first, dim3(nbn), dim3(256), 0, st, g.card2.as<unsigned int>(), n_new, g.hist.as<int32_t>());
     HIP_TRY(h, hipGetLastError());
     int32_t hist[257];
     HIP_TRY(h, hipMemcpyAsync(hist, g.hist.p, sizeof(hist), hipMemcpyDeviceToHost, st));
@@ -2011,10 +2011,17 @@ int g_close(mpc_handle *h) {
     HIP_TRY(h, hipStreamSynchronize(st));
     g.n_visited += n_new;
     g.n_wave = n_new;
-    long long off = 0;
-    for (int k = 0; k <= 256; ++k) {
-        long long c = hist[k];
-        while (c > 0) { const long long take = std::min(c, G_CHUNK); g.gk.push_back(k); g.goff.push_back(off); g.gcnt.push_back(take); off += take; c -= take; }
+    // hist[k] = index of the first mask with k rows (-1: none); a group ends where the next present cardinality starts
+    long long end = n_new;
+    std::vector<std::pair<int, std::pair<long long, long long>>> groups;   // (k, (first, count)), built from the back
+    for (int k = 256; k >= 0; --k) {
+        if (hist[k] < 0) continue;
+        groups.push_back({k, {hist[k], end - hist[k]}});
+        end = hist[k];
+    }
+    for (auto it = groups.rbegin(); it != groups.rend(); ++it) {
+        long long off = it->second.first, c = it->second.second;
+        while (c > 0) { const long long take = std::min(c, G_CHUNK); g.gk.push_back(it->first); g.goff.push_back(off); g.gcnt.push_back(take); off += take; c -= take; }
     }
     return MPC_OK;
 }
