@@ -1,0 +1,234 @@
+"""The geometric algorithm (Spjøtvold et al.) on the MI355X, wave-parallel like the reference's parallel variant.
+
+Reference: mp_solvers/mpqp_geometric.py:8-62 (serial), mp_solvers/mpqp_parallel_geometric.py:38-108 (one ``pool.map`` over
+the facets of the regions found in the previous round), solver_utils.py:204-325 (``get_facet_centers``, ``fathem_facet``).
+Every region hands on its facets; for each facet the algorithm steps from the facet's Chebyshev centre across the facet
+(distance radius * 1e-6 * 2^j, j = 1, 2, ... while it stays below the radius), solves the QP at that parameter point and
+takes the optimiser's active set as the neighbour's; it needs no assumption on how neighbouring active sets differ, which is
+what makes it the robust choice for degenerate programs (the graph traversals only move by one row).
+
+Here the three kinds of work of a round are three device batches:
+
+    facet centres   one Chebyshev LP per facet  {E theta + ||E_j|| r <= f, row i as an equality, r >= 0}    mpc_lp_solve_batch
+    probes          one QP per still-open facet and step j (linear complementarity form, csrc/qp.hpp)     mpc_qp_solve_batch
+    regions         rank test, KKT solve, "region non-empty" LP, region kernel for the new active sets    MPC_LEVEL_GRAPH
+
+and the bookkeeping (which active sets are known) is the mask book of the graph traversals.  Differences from the
+reference: the shortcut "the probe point already lies in a found region" (fathem_facet :268-272, one point location per
+probe) is replaced by the test that follows it anyway -- the QP's active set is already indexed; the first region comes from
+the first levels of the combinatorial algorithm (deterministic) unless ``active_set`` is given, instead of random sampling
+(gen_optimal_active_set).
+"""
+from typing import Dict, List, Optional
+
+import numpy
+
+from ..region_batch import RegionBatch
+from ..solution import Solution
+from . import mpqp_hip_combi_graph as _g
+
+REGION = 3
+LP_CHUNK_BYTES = 768 << 20      # host bytes of one batch of facet LPs
+
+
+def _facet_centres(E_rows: numpy.ndarray, row_off: numpy.ndarray, device: int):
+    """Chebyshev centre, radius and validity of every facet (= every row) of every region.  E_rows [R, n_t + 1] = [f | E]
+    stacked, row_off [n_regions + 1].  Returns (centre [R, n_t], radius [R], ok [R])."""
+    from .. import _lib
+    n_t = E_rows.shape[1] - 1
+    R = len(E_rows)
+    centre, radius, ok = numpy.zeros((R, n_t)), numpy.zeros(R), numpy.zeros(R, dtype=bool)
+    if R == 0:
+        return centre, radius, ok
+    if n_t == 1:        # solver_utils.py:232-235: the facet of an interval is a point
+        centre[:, 0] = E_rows[:, 0] / E_rows[:, 1]
+        radius[:] = 1.0
+        ok[:] = True
+        return centre, radius, ok
+    counts = numpy.diff(row_off)
+    m_max = int(counts.max())
+    m, n = m_max + 1, n_t + 1                      # rows of a region + the row -r <= 0 ; variables (theta, r)
+    c = numpy.zeros(n)
+    c[-1] = -1.0
+    region_of_row = numpy.repeat(numpy.arange(len(counts)), counts)
+    local = numpy.arange(R) - row_off[region_of_row]
+    per_lp = m * n * 8 + m * 8 + m
+    rows_per_chunk = max(1, int(LP_CHUNK_BYTES // per_lp))
+    r0 = 0
+    while r0 < len(counts):
+        # as many whole regions as fit the byte budget (at least one)
+        r1 = int(numpy.searchsorted(row_off, row_off[r0] + rows_per_chunk, side='right')) - 1
+        r1 = min(len(counts), max(r1, r0 + 1))
+        lo, hi = int(row_off[r0]), int(row_off[r1])
+        r_first, r0 = r0, r1
+        nl = hi - lo
+        if nl == 0:
+            continue
+        # the padded constraint block of each region of the chunk, then one copy per facet
+        blk = numpy.zeros((r1 - r_first, m, n))
+        rhs = numpy.ones((r1 - r_first, m))          # padding rows read 0 <= 1
+        rr = region_of_row[lo:hi] - r_first
+        blk[rr, local[lo:hi], :n_t] = E_rows[lo:hi, 1:]
+        blk[rr, local[lo:hi], n_t] = numpy.linalg.norm(E_rows[lo:hi, 1:], axis=1)
+        rhs[rr, local[lo:hi]] = E_rows[lo:hi, 0]
+        blk[:, m - 1, n_t] = -1.0                      # -r <= 0
+        rhs[:, m - 1] = 0.0
+        A = blk[rr].copy()                             # [nl, m, n]
+        b = rhs[rr].copy()
+        A[numpy.arange(nl), local[lo:hi], n_t] = 0.0   # the facet's own row is an equality without the radius term (chebyshev_ball.py:52-54)
+        flags = numpy.zeros((nl, m), dtype=numpy.uint8)
+        flags[numpy.arange(nl), local[lo:hi]] = 1
+        st, x, _, _ = _lib.lp_solve_batch(A, b, c, flags, device=device)
+        good = st == _lib.LP_OPTIMAL
+        centre[lo:hi] = x[:, :n_t]
+        radius[lo:hi] = x[:, n_t]
+        ok[lo:hi] = good & (numpy.abs(x[:, n_t]) > 1e-12)     # solver_utils.py:245-247: facets of numerically zero radius are skipped
+    return centre, radius, ok
+
+
+def _sub_active_set(program, active: List[int]) -> List[int]:
+    """solver_utils.py:169-202: a full-rank subset of an overdetermined active set (equalities first, then greedily)."""
+    eq = list(program.equality_indices)
+    kept: List[int] = []
+    rank = numpy.linalg.matrix_rank(program.A[eq]) if eq else 0
+    for i in [a for a in active if a not in eq]:
+        r = numpy.linalg.matrix_rank(program.A[[*eq, *kept, i]])
+        if r > rank:
+            kept.append(i)
+            rank = r
+        if rank == program.num_x():
+            break
+    return [*eq, *kept]
+
+
+def solve(program, active_set: Optional[List[int]] = None, num_cores: int = -1, device: Optional[int] = None,
+          profile: Optional[List[Dict]] = None, max_regions: Optional[int] = None) -> Solution:
+    """mpqp_algorithm.geometric / geometric_parallel / geometric_parallel_exp.  ``profile`` receives one dict per round."""
+    from ..mpqp_program import MPQP_Program
+    if not isinstance(program, MPQP_Program):
+        raise NotImplementedError('the geometric algorithm is implemented for mpQPs (it needs the QP at a parameter point)')
+    eng = program.engine(device)
+    dev = eng.device
+    n_x, n_t, n_c, n_tc, n_eq, words = eng.n_x, eng.n_t, eng.n_c, eng.n_tc, eng.n_eq, eng.mask_words
+    solution = Solution(program, [])
+    seeds = [list(active_set)] if active_set is not None else _g._seed_active_sets(program, eng)
+    if not seeds:
+        return solution
+    book = _g._SetBook(words)
+
+    def build_regions(masks: numpy.ndarray):
+        """Region records of the active sets that turn out to be full-dimensional regions: (accepted row indices into
+        ``masks``, list of (RegionBatch, slots)) -- one device frontier per cardinality."""
+        accepted, batches = [], []
+        card = _g._popcount(masks)
+        for k in numpy.unique(card).tolist():
+            sel = numpy.flatnonzero(card == k)
+            if k > min(n_x, n_c):
+                continue
+            eng.frontier_set(_g._masks_to_index_rows(masks[sel], k, n_c))
+            st = eng.level_run(False, graph=True)
+            if st.n_regions:
+                hd, hi, er, kk, slots = eng.level_regions_slots()
+                accepted.append(sel[hi[slots, 1]])
+                batches.append((RegionBatch(hd, hi, er, n_x, n_t, n_c, n_tc, kk, slots), slots))
+        return (numpy.concatenate(accepted) if accepted else numpy.zeros(0, dtype=numpy.int64)), batches
+
+    def rows_of(batches):
+        """Stacked [f | E] rows, row offsets and active-set masks of the regions of ``batches`` (in batch / slot order)."""
+        ef, cnt, mk = [], [], []
+        for B, slots in batches:
+            nE, off = B.hi[slots, 2].astype(numpy.int64), B.hi[slots, 6].astype(numpy.int64)
+            rows = numpy.repeat(off - numpy.concatenate([[0], numpy.cumsum(nE)[:-1]]), nE) + numpy.arange(int(nE.sum()))
+            ef.append(B.er[rows])
+            cnt.append(nE)
+            act = B.hi[slots, B.iact:B.iact + B.k].astype(numpy.int64)
+            m = numpy.zeros((len(slots), words), dtype=numpy.uint64)
+            for col in range(B.k):
+                numpy.bitwise_or.at(m, (numpy.arange(len(slots)), act[:, col] >> 6), numpy.uint64(1) << (act[:, col] & 63).astype(numpy.uint64))
+            mk.append(m)
+        counts = numpy.concatenate(cnt)
+        return numpy.vstack(ef), numpy.concatenate([[0], numpy.cumsum(counts)]).astype(numpy.int64), numpy.concatenate(mk, axis=0)
+
+    seed_masks = book.add(_g._sets_to_masks(seeds, words))
+    _, batches = build_regions(seed_masks)
+    for B, slots in batches:
+        solution.critical_regions.extend(B.regions())
+    while batches:
+        E_rows, row_off, region_masks = rows_of(batches)
+        centre, radius, ok = _facet_centres(E_rows, row_off, dev)
+        facet = numpy.flatnonzero(ok)                             # open facets (row indices into E_rows)
+        owner = numpy.repeat(numpy.arange(len(row_off) - 1), numpy.diff(row_off))
+        normal = E_rows[:, 1:]
+        new_masks_all = []
+        n_qp = 0
+        step = 1
+        while len(facet) and step <= 21:
+            dist = radius[facet] * 1e-6 * (2.0 ** step)          # fathem_facet: dist starts at radius * 1e-6 and doubles before use
+            alive = dist / 2.0 < radius[facet]                    # "while dist < radius" is tested before the doubling
+            facet, dist = facet[alive], dist[alive]
+            if not len(facet):
+                break
+            pts = centre[facet] + normal[facet] * dist[:, None]
+            status, _, _, act = eng.qp_solve_batch(pts)
+            n_qp += len(pts)
+            # infeasible QP or a point outside A_t theta <= b_t (solve_theta returns None): looking outside the feasible space,
+            # the facet is done
+            feasible = (status == 0) & numpy.all(pts @ program.A_t.T <= program.b_t.reshape(1, -1), axis=1)
+            facet, act = facet[feasible], act[feasible]
+            if not len(facet):
+                break
+            too_many = act.sum(axis=1) > n_x
+            for j in numpy.flatnonzero(too_many):                 # overdetermined active set: a full-rank subset (rare)
+                sub = _sub_active_set(program, numpy.flatnonzero(act[j]).tolist())
+                act[j] = False
+                act[j, sub] = True
+            pm = numpy.zeros((len(facet), words), dtype=numpy.uint64)
+            bits = numpy.packbits(act, axis=1, bitorder='little')
+            pad = numpy.zeros((len(facet), words * 8), dtype=numpy.uint8)
+            pad[:, :bits.shape[1]] = bits
+            pm[:] = pad.view(numpy.uint64)
+            own = (pm == region_masks[owner[facet]]).all(axis=1)  # accidental self inclusion: step further
+            known = ~own & _g_known(book, pm)                     # a region (or set) already indexed: the facet is done
+            cand = ~own & ~known
+            keep_open = own.copy()
+            if cand.any():
+                cm = pm[cand]
+                uniq, inv = numpy.unique(_structured(cm, words), return_inverse=True)
+                um = uniq.view(numpy.uint64).reshape(-1, words)
+                acc, nb = build_regions(um)                       # rank test + region kernel for the distinct new active sets
+                is_region = numpy.zeros(len(um), dtype=bool)
+                is_region[acc] = True
+                if len(acc):
+                    book.add(um[acc])
+                    new_masks_all.extend(nb)
+                # a facet whose probe gave a set that is no full-dimensional region keeps stepping (fathem_facet :300-309)
+                keep_open[numpy.flatnonzero(cand)[~is_region[inv]]] = True
+            facet = facet[keep_open]
+            step += 1
+        for B, slots in new_masks_all:
+            solution.critical_regions.extend(B.regions())
+        if profile is not None:
+            profile.append({'regions_in': int(len(row_off) - 1), 'facets': int(len(E_rows)), 'facets_with_centre': int(ok.sum()),
+                            'qps': int(n_qp), 'regions_out': int(sum(len(s) for _, s in new_masks_all))})
+        batches = new_masks_all
+        if max_regions is not None and len(solution.critical_regions) >= max_regions:
+            break
+    else:
+        solution.is_complete = True
+    return solution
+
+
+def _structured(masks: numpy.ndarray, words: int) -> numpy.ndarray:
+    return numpy.ascontiguousarray(masks).view([(f'w{j}', numpy.uint64) for j in range(words)]).reshape(-1)
+
+
+def _g_known(book, masks: numpy.ndarray) -> numpy.ndarray:
+    """bool per mask: already in the book (without adding it)."""
+    if book.exact:
+        return numpy.isin(_structured(masks, book.words), book.k)
+    h = book._hash(masks)
+    pos = numpy.searchsorted(book.h, h)
+    hit = pos < len(book.h)
+    hit[hit] = book.h[pos[hit]] == h[hit]
+    hit[hit] = (book.m[pos[hit]] == masks[hit]).all(axis=1)
+    return hit

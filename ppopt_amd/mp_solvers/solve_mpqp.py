@@ -4,8 +4,8 @@ The enum keeps every member of the reference's ``mpqp_algorithm`` so that user c
 algorithms the same way.  The three combinatorial members run on the MI355X (they differ in the reference only in
 how the CPU work is scheduled and pruned; all give the same region set), and so does
 ``combinatorial_graph`` and the four ``graph`` members (the connected-graph traversals of mpqp_combi_graph.py and
-mpqp_graph.py on the same device kernels, mpqp_hip_combi_graph.py; mpQPs only); the geometric members need a QP solver,
-are outside the scope of this package, and raise ``NotImplementedError``.
+mpqp_graph.py on the same device kernels, mpqp_hip_combi_graph.py) and the three ``geometric`` members (facet centres as
+an LP batch, probes as a QP batch, mpqp_hip_geometric.py); the graph and geometric drivers cover mpQPs.
 """
 from enum import Enum
 
@@ -14,7 +14,7 @@ import numpy
 from ..mplp_program import MPLP_Program
 from ..mpqp_program import MPQP_Program
 from ..solution import Solution
-from . import mpqp_hip_combi_graph, mpqp_hip_combinatorial
+from . import mpqp_hip_combi_graph, mpqp_hip_combinatorial, mpqp_hip_geometric
 
 
 class mpqp_algorithm(Enum):
@@ -40,6 +40,7 @@ class mpqp_algorithm(Enum):
 
 _COMBINATORIAL = (mpqp_algorithm.combinatorial, mpqp_algorithm.combinatorial_parallel,
                   mpqp_algorithm.combinatorial_parallel_exp)
+_GEOMETRIC = (mpqp_algorithm.geometric, mpqp_algorithm.geometric_parallel, mpqp_algorithm.geometric_parallel_exp)
 _GRAPH = (mpqp_algorithm.graph, mpqp_algorithm.graph_exp, mpqp_algorithm.graph_parallel, mpqp_algorithm.graph_parallel_exp)
 
 
@@ -54,9 +55,8 @@ def solve_mpqp(problem: MPQP_Program, algorithm: mpqp_algorithm = mpqp_algorithm
         solution = mpqp_hip_combi_graph.solve(problem, device=device)
     elif algorithm in _GRAPH:
         solution = mpqp_hip_combi_graph.solve_graph(problem, device=device)
-    elif algorithm not in _COMBINATORIAL:
-        raise NotImplementedError(f'{algorithm} is not part of the MI355X combinatorial path; use one of '
-                                  f'{[str(a) for a in (*_COMBINATORIAL, mpqp_algorithm.combinatorial_graph, *_GRAPH)]}')
+    elif algorithm in _GEOMETRIC:
+        solution = mpqp_hip_geometric.solve(problem, device=device)
     else:
         solution = mpqp_hip_combinatorial.solve(problem, device=device)
     # overlap flags exactly as the reference sets them (solve_mpqp.py:103-112)

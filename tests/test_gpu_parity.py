@@ -867,3 +867,34 @@ def test_qp_at_parameter_points_matches_the_explicit_solution(name):
     found = prog.sample_theta_space(20)
     keys = {tuple(r.active_set) for r in sol.critical_regions}
     assert found and all(tuple(a) in keys for a in found)
+
+
+@pytest.mark.parametrize('name', ['transport_mpqp', 'dblint_n3', 'c2_dblint_n5', 'rand_4_2_10_s0', 'rand_5_3_8_s3', 'rand_6_3_12_s1',
+                                  'quadtank_n2', 'quadtank_n3'])
+def test_geometric_algorithm_finds_the_same_regions(name):
+    """mpqp_algorithm.geometric (reference: mpqp_geometric.py / mpqp_parallel_geometric.py; facet centres as a device LP batch,
+    probe QPs as a device batch, regions through the level kernels): the region set of the complete combinatorial golden."""
+    from ppopt_amd import Solver
+    from ppopt_amd.mp_solvers import mpqp_hip_geometric
+    from ppopt_amd.mp_solvers.solve_mpqp import mpqp_algorithm, solve_mpqp
+    from test_host_logic import build_program
+    g = load_golden(name)
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        prog = build_program(g, Solver())
+    ref = golden_regions(g)
+    prof = []
+    sol = mpqp_hip_geometric.solve(prog, profile=prof)
+    got = {tuple(r.active_set): r for r in sol.critical_regions}
+    assert len(got) == len(sol.critical_regions) and sol.is_complete
+    assert set(got) <= set(ref), sorted(set(got) - set(ref))[:5]
+    # the geometric walk only sees what lies behind facets it can step across: on these programs that is everything, up to
+    # regions whose every facet is shorter than the first probe distance
+    assert len(got) >= 0.97 * len(ref), (len(got), len(ref), sorted(set(ref) - set(got))[:5])
+    for key, r in got.items():
+        q = ref[key]
+        for fld in ('A', 'b', 'C', 'd'):
+            assert rel_err(getattr(r, fld), q[fld]) <= COEF_TOL, (name, key, fld)
+    sol2 = solve_mpqp(prog, mpqp_algorithm.geometric_parallel)
+    assert sorted(tuple(r.active_set) for r in sol2.critical_regions) == sorted(got)
+    print(name, 'regions', len(ref), 'geometric', len(got), 'rounds', len(prof), 'facets', sum(p['facets'] for p in prof), 'QPs', sum(p['qps'] for p in prof))

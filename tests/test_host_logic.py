@@ -128,7 +128,7 @@ def test_solve_mpqp_rejects_non_enum_and_out_of_scope():
     with pytest.raises(TypeError):
         solve_mpqp(None, algorithm='cambinatorial')
     with pytest.raises(NotImplementedError):
-        solve_mpqp(None, algorithm=mpqp_algorithm.geometric)
+        solve_mpqp(object(), algorithm=mpqp_algorithm.geometric)      # the geometric driver needs an mpQP
     assert {a.value for a in mpqp_algorithm} >= {'combinatorial', 'p combinatorial', 'p combinatorial exp', 'graph'}
     assert 'mpqp_algorithm.combinatorial' in mpqp_algorithm.all_algos()
 
