@@ -272,6 +272,13 @@ int mpc_lp_solve_batch(int32_t device, int64_t n_lp, int32_t m, int32_t n, const
 int mpc_qp_solve_batch(mpc_handle *h, int64_t m, const double *theta_host, int32_t *status, double *x, double *lambda,
                        uint8_t *active, int32_t *iters);
 
+/* ---- Chebyshev centre and radius of every facet of a batch of polytopes, one wavefront per facet ------------------------- */
+/* Replaces get_facet_centers (mp_solvers/solver_utils.py:204-250; one chebyshev_ball LP per facet, utils/chebyshev_ball.py:10-63)
+ * of the geometric algorithm.  ef_rows: stacked rows [f | E] (n_t + 1 doubles each) of all polytopes, row_off[n_regions + 1];
+ * facet q is row q.  Outputs per row: centre (n_t), radius, status (MPC_LP_*; centre and radius are 0 unless optimal). */
+int mpc_facet_centres(int32_t device, int32_t n_t, int64_t n_regions, const int64_t *row_off, const double *ef_rows, double *centre,
+                      double *radius, int32_t *status);
+
 /* ---- consumer of the path: point location over a solution's critical regions, batched ---------------------------- */
 /* Replaces the loop of Solution.get_region / Solution.evaluate (solution.py:45-112, CriticalRegion.is_inside
  * critical_region.py:83-86) for many parameter points at once.

@@ -119,6 +119,7 @@ def load():
                                                     ctypes.c_int64, _lp, _lp]),
         'mpc_frontier_advance': (ctypes.c_int, [H]),
         'mpc_qp_solve_batch': (ctypes.c_int, [H, ctypes.c_int64, _dp, _ip, _dp, _dp, _u8p, _ip]),
+        'mpc_facet_centres': (ctypes.c_int, [ctypes.c_int32, ctypes.c_int32, ctypes.c_int64, _lp, _dp, _dp, _dp, _ip]),
         'mpc_graph_begin': (ctypes.c_int, [H, _u64p, ctypes.c_int64, ctypes.c_int32]),
         'mpc_graph_wave': (ctypes.c_int, [H, _ip, _lp, ctypes.c_int32, _ip, _lp, _lp]),
         'mpc_graph_group_run': (ctypes.c_int, [H, ctypes.c_int32, ctypes.POINTER(LevelStats)]),
@@ -143,7 +144,7 @@ EXPORTED_SYMBOLS = ['mpc_device_count', 'mpc_version', 'mpc_last_global_error', 
                     'mpc_frontier_get', 'mpc_pruned_clear', 'mpc_pruned_add', 'mpc_pruned_add_device',
                     'mpc_pruned_count', 'mpc_pruned_get', 'mpc_level_run', 'mpc_level_run_ex', 'mpc_level_status', 'mpc_level_start', 'mpc_level_stream_info', 'mpc_level_chunk_wait', 'mpc_level_wait', 'mpc_level_stream_fixup', 'mpc_base_result', 'mpc_level_regions', 'mpc_compact_strides',
                     'mpc_level_regions_compact', 'mpc_frontier_shard', 'mpc_level_slots', 'mpc_level_regions_slots', 'mpc_level_regions_slots_async', 'mpc_sync', 'mpc_host_alloc', 'mpc_host_free', 'mpc_locator_create', 'mpc_locator_query', 'mpc_locator_destroy', 'mpc_locator_set_adjacency', 'mpc_level_children', 'mpc_level_children_device', 'mpc_level_pruned_new',
-                    'mpc_level_pruned_new_device', 'mpc_level_regions_device', 'mpc_frontier_advance', 'mpc_qp_solve_batch', 'mpc_graph_begin', 'mpc_graph_wave', 'mpc_graph_group_run', 'mpc_graph_wave_close', 'mpc_check_level', 'mpc_lp_solve_batch']
+                    'mpc_level_pruned_new_device', 'mpc_level_regions_device', 'mpc_frontier_advance', 'mpc_qp_solve_batch', 'mpc_facet_centres', 'mpc_graph_begin', 'mpc_graph_wave', 'mpc_graph_group_run', 'mpc_graph_wave_close', 'mpc_check_level', 'mpc_lp_solve_batch']
 
 
 def pinned_empty(shape, dtype) -> numpy.ndarray:
@@ -563,6 +564,21 @@ def lp_solve_batch(A, b, c, eq_flags, device: int = 0, want_x: bool = True):
     if rc != MPC_OK:
         raise MpcError(f'mpc_lp_solve_batch failed ({rc}): {L.mpc_last_global_error().decode()}')
     return status, x, obj, it
+
+
+def facet_centres(ef_rows: numpy.ndarray, row_off: numpy.ndarray, device: int = 0):
+    """Chebyshev centre [R, n_t], radius [R] and LP status [R] of every facet (row) of the stacked polytopes
+    (include/mpcombi.h, mpc_facet_centres)."""
+    L = load()
+    ef = _f64(ef_rows)
+    off = numpy.ascontiguousarray(row_off, dtype=numpy.int64)
+    R, n_t = len(ef), ef.shape[1] - 1
+    centre, radius, status = numpy.zeros((R, n_t)), numpy.zeros(R), numpy.zeros(R, dtype=numpy.int32)
+    rc = L.mpc_facet_centres(int(device), n_t, len(off) - 1, off.ctypes.data_as(_lp), ef.ctypes.data_as(_dp), centre.ctypes.data_as(_dp),
+                             radius.ctypes.data_as(_dp), status.ctypes.data_as(_ip))
+    if rc != MPC_OK:
+        raise MpcError(f'mpc_facet_centres failed ({rc}): {L.mpc_last_global_error().decode()}')
+    return centre, radius, status
 
 
 class Locator:

@@ -1001,4 +1001,67 @@ __global__ void __launch_bounds__(64) k_lp_batch(long long n_lp, int m, int n, i
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// k_facet_centres: the Chebyshev centre and radius of EVERY FACET of a batch of polytopes, one wavefront per facet
+// (the geometric algorithm's get_facet_centers, solver_utils.py:204-250 -> chebyshev_ball, utils/chebyshev_ball.py:10-63).
+// ef: stacked rows [f | E] of all regions, row_off[r] .. row_off[r+1] the rows of region r; facet q = global row q.
+// LP over (theta, r):  max r  s.t.  E_j theta + ||E_j|| r <= f_j (j != i),  E_i theta = f_i,  -r <= 0.
+// The tableau is filled in LDS straight from the region's rows: nothing but the rows themselves crosses PCIe.
+// ------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(64) k_facet_centres(long long n_facets, int nt, int m_max, int ld, const double *__restrict__ ef,
+                                                      const long long *__restrict__ row_off, const int32_t *__restrict__ region_of_row,
+                                                      double *__restrict__ centre, double *__restrict__ radius, int32_t *__restrict__ status,
+                                                      unsigned int *work) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    const int lane = lane_id(), n = nt + 1, nr = nt + 1;
+    double *T = smem;
+    int *ib = reinterpret_cast<int *>(smem + (size_t)(m_max + 2) * ld);
+    Lp lp;
+    lp.T = T; lp.ld = ld; lp.colvar = ib; lp.rowvar = ib + ld + 1; lp.rowkind = ib + ld + 1 + (m_max + 1) + 2;
+    for (;;) {
+        unsigned int w = 0;
+        if (lane == 0) w = atomicAdd(work, 1u);
+        w = (unsigned)__builtin_amdgcn_readfirstlane((int)w);
+        if (w >= n_facets) break;
+        const int reg = region_of_row[w];
+        const long long r0 = row_off[reg];
+        const int rows = (int)(row_off[reg + 1] - r0), mine = (int)((long long)w - r0);
+        const int m = rows + 1;                      // the region's rows + the row -r <= 0
+        lp.m = m; lp.n = n; lp.iters = 0;
+        int *pri_buf = lp.rowkind + (m_max + 1) + 2;
+        const int r = lp_solve(lp, true, pri_buf, [&](const int *pri) {
+            wave_sync();
+            for (int i = lane; i < m; i += 64) {
+                double *Ti = T + (size_t)i * ld;
+                if (i < rows) {
+                    const double *row = ef + (size_t)(r0 + i) * nr;
+                    double ss = 0.0;
+                    for (int t = 0; t < nt; ++t) { Ti[1 + t] = row[1 + t]; ss = fma(row[1 + t], row[1 + t], ss); }
+                    Ti[0] = row[0];
+                    Ti[1 + nt] = i == mine ? 0.0 : sqrt(ss);           // the facet's own row: an equality, no radius term
+                    lp.rowkind[i] = i == mine ? RK_EQ : ((pri && pri[i]) ? RK_PRI : RK_INEQ);
+                } else {
+                    for (int t = 0; t < nt; ++t) Ti[1 + t] = 0.0;
+                    Ti[0] = 0.0; Ti[1 + nt] = -1.0;                     // -r <= 0
+                    lp.rowkind[i] = (pri && pri[i]) ? RK_PRI : RK_INEQ;
+                }
+                Ti[n + 1] = 0.0;
+            }
+            for (int j = lane; j <= n + 1; j += 64) T[(size_t)m * ld + j] = j == n ? -1.0 : 0.0;   // minimise -r
+        });
+        for (int j = lane; j < nt; j += 64) centre[(size_t)w * nt + j] = 0.0;
+        if (lane == 0) radius[w] = 0.0;
+        wave_sync();
+        if (r == LP_OPTIMAL)
+            for (int i = lane; i < m; i += 64)
+                if (lp.rowkind[i] == RK_FREE) {
+                    const int v = lp.rowvar[i];
+                    if (v < nt) centre[(size_t)w * nt + v] = T[(size_t)i * ld];
+                    else if (v == nt) radius[w] = T[(size_t)i * ld];
+                }
+        if (lane == 0) status[w] = r;
+        wave_sync();
+    }
+}
+
 }  // namespace mpc

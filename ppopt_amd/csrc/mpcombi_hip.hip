@@ -2165,6 +2165,54 @@ int mpc_check_level(mpc_handle *h, const int32_t *cand, int64_t n, int32_t k, co
 
 }  // extern "C"
 
+// ---- facet centres of a batch of polytopes (geometric algorithm) --------------------------------------------------------------
+extern "C" int mpc_facet_centres(int32_t device, int32_t n_t, int64_t n_regions, const int64_t *row_off, const double *ef_rows, double *centre,
+                                 double *radius, int32_t *status) {
+    if (n_t < 1 || n_regions < 0 || !row_off || !centre || !radius || !status) return fail(nullptr, MPC_ERR_INVALID, "bad argument");
+    const long long rows = n_regions ? row_off[n_regions] : 0;
+    if (rows == 0) return MPC_OK;
+    if (!ef_rows) return fail(nullptr, MPC_ERR_INVALID, "bad argument");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return fail(nullptr, MPC_ERR_HIP, "no HIP device available (libmpcombi_hip has no CPU fallback)");
+    if (device < 0 || device >= ndev) return fail(nullptr, MPC_ERR_INVALID, "device index out of range");
+    HIP_TRY(nullptr, hipSetDevice(device));
+    int m_max = 0;
+    std::vector<int32_t> reg((size_t)rows);
+    for (long long r = 0; r < n_regions; ++r) {
+        m_max = std::max<int>(m_max, (int)(row_off[r + 1] - row_off[r]));
+        for (long long i = row_off[r]; i < row_off[r + 1]; ++i) reg[(size_t)i] = (int32_t)r;
+    }
+    const int n = n_t + 1, ld = odd_at_least(n + 3), m = m_max + 1;
+    const size_t lds = (((size_t)(m + 1) * ld * 8 + (size_t)(ld + 1 + 3 * (m + 2)) * 4) + 15) & ~size_t(15);
+    if (lds > 160 * 1024) return fail(nullptr, MPC_ERR_INVALID, "a region has too many rows for the 160 KiB LDS of one CU");
+    if (lds > 48 * 1024) HIP_TRY(nullptr, hipFuncSetAttribute(reinterpret_cast<const void *>(k_facet_centres), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    DevBuf d_ef, d_off, d_reg, d_c, d_r, d_s, d_w;
+    hipError_t e = hipSuccess;
+    auto chk = [&](hipError_t err) { if (e == hipSuccess && err != hipSuccess) e = err; return err == hipSuccess; };
+    chk(d_ef.ensure((size_t)rows * (n_t + 1) * 8, nullptr)); chk(d_off.ensure((size_t)(n_regions + 1) * 8, nullptr)); chk(d_reg.ensure((size_t)rows * 4, nullptr));
+    chk(d_c.ensure((size_t)rows * n_t * 8, nullptr)); chk(d_r.ensure((size_t)rows * 8, nullptr)); chk(d_s.ensure((size_t)rows * 4, nullptr)); chk(d_w.ensure(256, nullptr));
+    if (e == hipSuccess) {
+        chk(hipMemcpy(d_ef.p, ef_rows, (size_t)rows * (n_t + 1) * 8, hipMemcpyHostToDevice));
+        chk(hipMemcpy(d_off.p, row_off, (size_t)(n_regions + 1) * 8, hipMemcpyHostToDevice));
+        chk(hipMemcpy(d_reg.p, reg.data(), (size_t)rows * 4, hipMemcpyHostToDevice));
+        chk(hipMemset(d_w.p, 0, 4));
+    }
+    if (e == hipSuccess) {
+        const int per_cu = std::max(1, std::min(32, (int)((160 * 1024) / lds)));
+        const dim3 g((unsigned)std::min<long long>(rows, (long long)cu_count(device) * per_cu)), b(64);
+        hipLaunchKernelGGL(k_facet_centres, g, b, lds, nullptr, rows, (int)n_t, m_max, ld, d_ef.as<double>(), d_off.as<long long>(), d_reg.as<int32_t>(),
+                           d_c.as<double>(), d_r.as<double>(), d_s.as<int32_t>(), d_w.as<unsigned int>());
+        chk(hipGetLastError());
+        chk(hipMemcpy(centre, d_c.p, (size_t)rows * n_t * 8, hipMemcpyDeviceToHost));
+        chk(hipMemcpy(radius, d_r.p, (size_t)rows * 8, hipMemcpyDeviceToHost));
+        chk(hipMemcpy(status, d_s.p, (size_t)rows * 4, hipMemcpyDeviceToHost));
+    }
+    (void)hipDeviceSynchronize();
+    for (DevBuf *bf : {&d_ef, &d_off, &d_reg, &d_c, &d_r, &d_s, &d_w}) bf->release();
+    if (e != hipSuccess) return fail(nullptr, MPC_ERR_HIP, std::string("mpc_facet_centres: ") + hipGetErrorString(e));
+    return MPC_OK;
+}
+
 // ---- batched LPs ------------------------------------------------------------------------------------------------
 static int lp_batch_impl(int32_t device, int64_t n_lp, int32_t m, int32_t n, const double *A, int32_t shared_A, const double *b,
                          int32_t shared_b, const double *c, int32_t shared_c, const uint8_t *eq, int32_t *status, double *x,

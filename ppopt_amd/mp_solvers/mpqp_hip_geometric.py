@@ -9,7 +9,7 @@ what makes it the robust choice for degenerate programs (the graph traversals on
 
 Here the three kinds of work of a round are three device batches:
 
-    facet centres   one Chebyshev LP per facet  {E theta + ||E_j|| r <= f, row i as an equality, r >= 0}    mpc_lp_solve_batch
+    facet centres   one Chebyshev LP per facet  {E theta + ||E_j|| r <= f, row i as an equality, r >= 0}    mpc_facet_centres
     probes          one QP per still-open facet and step j (linear complementarity form, csrc/qp.hpp)     mpc_qp_solve_batch
     regions         rank test, KKT solve, "region non-empty" LP, region kernel for the new active sets    MPC_LEVEL_GRAPH
 
@@ -28,7 +28,6 @@ from ..solution import Solution
 from . import mpqp_hip_combi_graph as _g
 
 REGION = 3
-LP_CHUNK_BYTES = 768 << 20      # host bytes of one batch of facet LPs
 
 
 def _facet_centres(E_rows: numpy.ndarray, row_off: numpy.ndarray, device: int):
@@ -45,44 +44,9 @@ def _facet_centres(E_rows: numpy.ndarray, row_off: numpy.ndarray, device: int):
         radius[:] = 1.0
         ok[:] = True
         return centre, radius, ok
-    counts = numpy.diff(row_off)
-    m_max = int(counts.max())
-    m, n = m_max + 1, n_t + 1                      # rows of a region + the row -r <= 0 ; variables (theta, r)
-    c = numpy.zeros(n)
-    c[-1] = -1.0
-    region_of_row = numpy.repeat(numpy.arange(len(counts)), counts)
-    local = numpy.arange(R) - row_off[region_of_row]
-    per_lp = m * n * 8 + m * 8 + m
-    rows_per_chunk = max(1, int(LP_CHUNK_BYTES // per_lp))
-    r0 = 0
-    while r0 < len(counts):
-        # as many whole regions as fit the byte budget (at least one)
-        r1 = int(numpy.searchsorted(row_off, row_off[r0] + rows_per_chunk, side='right')) - 1
-        r1 = min(len(counts), max(r1, r0 + 1))
-        lo, hi = int(row_off[r0]), int(row_off[r1])
-        r_first, r0 = r0, r1
-        nl = hi - lo
-        if nl == 0:
-            continue
-        # the padded constraint block of each region of the chunk, then one copy per facet
-        blk = numpy.zeros((r1 - r_first, m, n))
-        rhs = numpy.ones((r1 - r_first, m))          # padding rows read 0 <= 1
-        rr = region_of_row[lo:hi] - r_first
-        blk[rr, local[lo:hi], :n_t] = E_rows[lo:hi, 1:]
-        blk[rr, local[lo:hi], n_t] = numpy.linalg.norm(E_rows[lo:hi, 1:], axis=1)
-        rhs[rr, local[lo:hi]] = E_rows[lo:hi, 0]
-        blk[:, m - 1, n_t] = -1.0                      # -r <= 0
-        rhs[:, m - 1] = 0.0
-        A = blk[rr].copy()                             # [nl, m, n]
-        b = rhs[rr].copy()
-        A[numpy.arange(nl), local[lo:hi], n_t] = 0.0   # the facet's own row is an equality without the radius term (chebyshev_ball.py:52-54)
-        flags = numpy.zeros((nl, m), dtype=numpy.uint8)
-        flags[numpy.arange(nl), local[lo:hi]] = 1
-        st, x, _, _ = _lib.lp_solve_batch(A, b, c, flags, device=device)
-        good = st == _lib.LP_OPTIMAL
-        centre[lo:hi] = x[:, :n_t]
-        radius[lo:hi] = x[:, n_t]
-        ok[lo:hi] = good & (numpy.abs(x[:, n_t]) > 1e-12)     # solver_utils.py:245-247: facets of numerically zero radius are skipped
+    # one wavefront per facet builds its LP in LDS from the region's rows and solves it (csrc/kernels.hpp, k_facet_centres)
+    centre, radius, status = _lib.facet_centres(E_rows, row_off, device)
+    ok = (status == _lib.LP_OPTIMAL) & (numpy.abs(radius) > 1e-12)   # solver_utils.py:245-247: facets of numerically zero radius are skipped
     return centre, radius, ok
 
 
@@ -107,6 +71,9 @@ def solve(program, active_set: Optional[List[int]] = None, num_cores: int = -1, 
     from ..mpqp_program import MPQP_Program
     if not isinstance(program, MPQP_Program):
         raise NotImplementedError('the geometric algorithm is implemented for mpQPs (it needs the QP at a parameter point)')
+    ev = numpy.linalg.eigvalsh(0.5 * (program.Q + program.Q.T))
+    if not ev.min() > 1e-10 * max(ev.max(), 1.0):
+        raise NotImplementedError('the geometric algorithm needs a positive definite Q (the probes are QPs solved on the device)')
     eng = program.engine(device)
     dev = eng.device
     n_x, n_t, n_c, n_tc, n_eq, words = eng.n_x, eng.n_t, eng.n_c, eng.n_tc, eng.n_eq, eng.mask_words
