@@ -113,8 +113,8 @@ def cpu_baseline(prog, frontiers, gpu_status, target_candidates):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=5)
-    ap.add_argument('--warmup', type=int, default=2)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--workload', default='c4', choices=sorted(WORKLOADS))
     ap.add_argument('--cpu-sample', type=int, default=300000, help='candidates in the CPU baseline sample (0 = skip)')
     ap.add_argument('--locate', type=int, default=100000, help='points of the point-location extra (0 = skip)')

@@ -1493,6 +1493,7 @@ int mpc_level_stream_info(mpc_handle *h, double **head_d, int32_t **head_i, doub
                           int32_t *chunk, int32_t *n_chunks) {
     if (!h) return MPC_ERR_INVALID;
     std::unique_lock<std::mutex> lk(h->wm);
+    if (!h->w_busy && !h->w_stream_ready) return fail(h, MPC_ERR_STATE, "mpc_level_stream_info without a level started by mpc_level_start");
     h->wcv.wait(lk, [&] { return h->w_stream_ready; });
     auto &so = h->so;
     const bool on = so.active && !so.taken;

@@ -196,3 +196,53 @@ def test_solution_stacks_regions_for_the_locator():
         rows = ef[row_off[i]:row_off[i + 1]]
         assert numpy.array_equal(rows[:, :1], r.f) and numpy.array_equal(rows[:, 1:], r.E)
         assert numpy.array_equal(xlaw[i][:, :1], r.b) and numpy.array_equal(xlaw[i][:, 1:], r.A)
+
+
+def test_graph_traversal_bookkeeping_on_the_host():
+    """The mask helpers of the connected-graph traversals (mpqp_hip_combi_graph: the host form of what csrc/graph.hpp does on the
+    device): neighbour rules of mpqp_combi_graph.py:88-143 and mpqp_graph.py:69-108, the visited-set book with hashed keys
+    confirmed on the full mask (and its exact mode after a forced collision)."""
+    import numpy
+    from ppopt_amd.mp_solvers import mpqp_hip_combi_graph as G
+    sets = [[0, 5, 70], [1, 2, 3], [0, 5, 70]]
+    m = G._sets_to_masks(sets, 2)
+    assert G._popcount(m).tolist() == [3, 3, 3]
+    assert G._masks_to_index_rows(m, 3, 100).tolist() == [[0, 5, 70], [1, 2, 3], [0, 5, 70]]
+    bit, eq = G._bit_table(100, 2), G._sets_to_masks([[0]], 2)[0]
+    # combinatorial_graph: rank deficient {0,5,70} -> subsets without dropping the equality row 0; region {1,2,3} -> 3 subsets + 97 supersets
+    nb = G._neighbours(m[:2], numpy.array([True, True]), numpy.array([False, True]), bit, eq)
+    got = sorted(tuple(numpy.flatnonzero(numpy.unpackbits(r.view(numpy.uint8), bitorder='little'))) for r in nb)
+    want = sorted([(0, 70), (0, 5)] + [(2, 3), (1, 3), (1, 2)] + [tuple(sorted({1, 2, 3, j})) for j in range(100) if j not in (1, 2, 3)])
+    assert got == want
+    # graph: supersets only through the facet constraints
+    facets = numpy.zeros((2, 100), dtype=bool)
+    facets[1, [7, 9]] = True
+    nb = G._neighbours(m[:2], numpy.array([False, False]), numpy.array([False, True]), bit, eq, facets)
+    assert sorted(G._popcount(nb).tolist()) == [4, 4] and len(nb) == 2
+    book = G._SetBook(2)
+    assert len(book.add(m)) == 2 and len(book.add(G._sets_to_masks([[1, 2, 3], [4]], 2))) == 1 and len(book.h) == 3
+    rng = numpy.random.default_rng(0)
+    big = rng.integers(0, 2 ** 62, size=(50000, 2), dtype=numpy.int64).astype(numpy.uint64)
+    assert len(book.add(big)) == 50000 and len(book.add(big[:1000])) == 0
+    # a hash collision (forced: every mask hashes to 0) switches the book to exact keys without losing or inventing a set
+    b2 = G._SetBook(2)
+    b2._hash = lambda masks: numpy.zeros(len(masks), dtype=numpy.uint64)
+    first = b2.add(G._sets_to_masks([[1], [2]], 2))
+    assert b2.exact and len(first) == 2
+    assert len(b2.add(G._sets_to_masks([[2], [3]], 2))) == 1
+
+
+def test_geometric_sub_active_set():
+    """solver_utils.py:169-202: a full-rank subset of an overdetermined active set, equalities first."""
+    import numpy
+    from ppopt_amd.mp_solvers.mpqp_hip_geometric import _sub_active_set
+
+    class P:
+        A = numpy.array([[1.0, 0.0], [2.0, 0.0], [0.0, 1.0], [1.0, 1.0]])
+        equality_indices = []
+
+        def num_x(self):
+            return 2
+    assert _sub_active_set(P(), [0, 1, 2, 3]) == [0, 2]
+    P.equality_indices = [3]
+    assert _sub_active_set(P(), [3, 0, 1, 2]) == [3, 0]
