@@ -137,7 +137,7 @@ int mpc_pruned_get(mpc_handle *h, uint64_t *masks_host, int64_t cap);
  * Sets pruned by this level become visible to child generation only after mpc_frontier_advance, which is the
  * reference's worker semantics (workers hold the murder_list of the previous levels, driver :110-131). */
 int mpc_level_run(mpc_handle *h, int32_t gen_children, mpc_level_stats *stats);
-int mpc_level_run_ex(mpc_handle *h, int32_t gen_children, int32_t flags, mpc_level_stats *stats);   /* flags: MPC_LEVEL_GRAPH */
+int mpc_level_run_ex(mpc_handle *h, int32_t gen_children, int32_t flags, mpc_level_stats *stats);   /* flags: MPC_LEVEL_GRAPH, MPC_LEVEL_KEEP_LOWDIM */
 int mpc_level_status(mpc_handle *h, uint8_t *status_host);                       /* n bytes, frontier order */
 /* The same level driven by the handle's worker thread: mpc_level_start returns at once, mpc_level_wait joins it and returns
  * what mpc_level_run would have returned.  Between the two only mpc_level_stream_info / mpc_level_chunk_wait may be called
@@ -169,6 +169,11 @@ int mpc_level_status(mpc_handle *h, uint8_t *status_host);                      
  * rank deficient, MPC_FEASIBLE = full rank, empty region, MPC_OPTIMAL_NO_REGION = non-empty but lower dimensional,
  * MPC_REGION.  Nothing is appended to the pruned list. */
 #define MPC_LEVEL_GRAPH 4
+/* MPC_LEVEL_KEEP_LOWDIM: the rule of the SERIAL driver (mp_solvers/mpqp_combinatorial.py:44-61) and of the _exp parallel driver
+ * (mpqp_parallel_combinatorial_exp.py:38-52): a set that is optimal with a lower-dimensional region is expanded like any
+ * feasible set and is not put on the pruned list.  Without the flag the parallel driver's rule applies (:57-59): such a set is
+ * pruned together with its supersets, which can lose regions on degenerate programs. */
+#define MPC_LEVEL_KEEP_LOWDIM 16
 #define MPC_STREAM_RETRY 7
 int mpc_level_start(mpc_handle *h, int32_t gen_children, int32_t flags);
 int mpc_level_stream_info(mpc_handle *h, double **head_d, int32_t **head_i, double **erows, int64_t *n_slots, int64_t *cap_rows,

@@ -15,7 +15,7 @@ LIB_PATH = os.environ.get('MPC_LIB_PATH') or os.path.join(_HERE, 'csrc', 'libmpc
 
 MPC_OK, MPC_ERR_INVALID, MPC_ERR_HIP, MPC_ERR_CAPACITY, MPC_ERR_STATE = range(5)
 MPC_LOCATE_OVERLAPPING, MPC_LOCATE_INCLUSIVE, MPC_LOCATE_WALK = 1, 2, 4   # flags of mpc_locator_query
-MPC_LEVEL_STREAM, MPC_LEVEL_GRAPH, MPC_LEVEL_THEN_BASE = 1, 4, 8   # flags of mpc_level_start / mpc_level_run_ex
+MPC_LEVEL_STREAM, MPC_LEVEL_GRAPH, MPC_LEVEL_THEN_BASE, MPC_LEVEL_KEEP_LOWDIM = 1, 4, 8, 16   # flags of mpc_level_start / mpc_level_run_ex
 INFEASIBLE, FEASIBLE, OPTIMAL_NO_REGION, REGION, SINGULAR_KKT, LP_LIMIT = range(6)
 LP_OPTIMAL, LP_INFEASIBLE, LP_UNBOUNDED, LP_ITERLIMIT = range(4)
 MASK_WORDS = 2
@@ -306,18 +306,20 @@ class Engine:
         return out
 
     # -- one level --------------------------------------------------------------------------------------------------
-    def level_run(self, gen_children: bool, graph: bool = False) -> LevelStats:
-        """One level over the resident frontier.  ``graph``: the question of the connected-graph traversal (MPC_LEVEL_GRAPH)."""
+    def level_run(self, gen_children: bool, graph: bool = False, keep_lowdim: bool = False) -> LevelStats:
+        """One level over the resident frontier.  ``graph``: the question of the connected-graph traversal (MPC_LEVEL_GRAPH);
+        ``keep_lowdim``: the serial driver's expansion rule (MPC_LEVEL_KEEP_LOWDIM)."""
         st = LevelStats()
-        self._check(self._L.mpc_level_run_ex(self._h, int(bool(gen_children)), MPC_LEVEL_GRAPH if graph else 0, ctypes.byref(st)),
-                    'mpc_level_run')
+        self._check(self._L.mpc_level_run_ex(self._h, int(bool(gen_children)), (MPC_LEVEL_GRAPH if graph else 0)
+                                             | (MPC_LEVEL_KEEP_LOWDIM if keep_lowdim else 0), ctypes.byref(st)), 'mpc_level_run')
         self._last = st
         return st
 
     # -- the same level on the handle's worker thread, region records streamed to the host (include/mpcombi.h) ----------
-    def level_start(self, gen_children: bool, stream: bool = True, then_base: bool = False):
+    def level_start(self, gen_children: bool, stream: bool = True, then_base: bool = False, keep_lowdim: bool = False):
         self._check(self._L.mpc_level_start(self._h, int(bool(gen_children)),
-                                            (MPC_LEVEL_STREAM if stream else 0) | (MPC_LEVEL_THEN_BASE if then_base else 0)), 'mpc_level_start')
+                                            (MPC_LEVEL_STREAM if stream else 0) | (MPC_LEVEL_THEN_BASE if then_base else 0)
+                                            | (MPC_LEVEL_KEEP_LOWDIM if keep_lowdim else 0)), 'mpc_level_start')
 
     def base_result(self):
         """(status, rec_d [1, rec_d] or empty, rec_i) of the base-set check the worker ran behind the last level

@@ -797,7 +797,12 @@ __global__ void __launch_bounds__(1024) k_scan_small(const int32_t *__restrict__
     if (threadIdx.x == 0) *total = carry;
 }
 
-__device__ __forceinline__ bool expands(int st) { return st == ST_FEASIBLE || st == ST_REGION || st == ST_SINGULAR || st == ST_LP_LIMIT; }
+// keep_lowdim: the serial driver's rule (mp_solvers/mpqp_combinatorial.py:44-61, also mpqp_parallel_combinatorial_exp.py:38-52) --
+// every feasible set is expanded, also one that is optimal with a lower-dimensional region; the parallel driver prunes such
+// a set together with its supersets (mpqp_parrallel_combinatorial.py:57-59)
+__device__ __forceinline__ bool expands(int st, int keep_lowdim = 0) {
+    return st == ST_FEASIBLE || st == ST_REGION || st == ST_SINGULAR || st == ST_LP_LIMIT || (keep_lowdim && st == ST_OPT_NO_REGION);
+}
 
 // Active sets as bit masks of MW 64-bit words (MW = 2: n_c <= 128, MW = 4: n_c <= 256; mpc_mask_words).
 template <int MW>
@@ -820,7 +825,7 @@ template <int MW>
 __global__ void __launch_bounds__(64) k_children_count(DevProblem P, const int32_t *__restrict__ cands, long long n, int k,
                                                        const uint8_t *__restrict__ status,
                                                        const unsigned long long *__restrict__ pruned, long long n_pruned,
-                                                       unsigned long long *__restrict__ childmask, int32_t *__restrict__ count) {
+                                                       unsigned long long *__restrict__ childmask, int32_t *__restrict__ count, int keep_lowdim) {
     const long long c = blockIdx.x;
     const int lane = lane_id();
     if (c >= n) return;
@@ -828,7 +833,7 @@ __global__ void __launch_bounds__(64) k_children_count(DevProblem P, const int32
     unsigned long long m[MW];
 #pragma unroll
     for (int w = 0; w < MW; ++w) m[w] = 0;
-    if (expands(st)) {
+    if (expands(st, keep_lowdim)) {
         const int32_t *as = cands + (size_t)c * k;
         unsigned long long p[MW], a[MW], kill[MW];
         set_mask<MW>(as, k, p);
@@ -899,11 +904,11 @@ __global__ void __launch_bounds__(64) k_children_write(const int32_t *__restrict
 // masks of the candidates pruned by this level (INFEASIBLE, OPT_NO_REGION), appended at pruned[n_pruned_old + ...]
 template <int MW>
 __global__ void k_pruned_append(const int32_t *__restrict__ cands, long long n, int k, const uint8_t *__restrict__ status,
-                                unsigned long long *__restrict__ out, LevelCounters *ctr) {
+                                unsigned long long *__restrict__ out, LevelCounters *ctr, int keep_lowdim) {
     const long long c = blockIdx.x * (long long)blockDim.x + threadIdx.x;
     if (c >= n) return;
     const int st = status[c];
-    if (st != ST_INFEASIBLE && st != ST_OPT_NO_REGION) return;
+    if (st != ST_INFEASIBLE && (st != ST_OPT_NO_REGION || keep_lowdim)) return;
     unsigned long long p[MW];
     set_mask<MW>(cands + (size_t)c * k, k, p);
     const unsigned int pos = atomicAdd(&ctr->n_pruned_new, 1u);

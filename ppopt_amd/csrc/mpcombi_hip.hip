@@ -1352,19 +1352,20 @@ static int level_run_impl(mpc_handle *h, int32_t gen_children, int32_t flags, mp
         }
         HIP_TRY(h, hipEventRecord(h->ev[2], st));
         // pruned masks of this level + children
+        const int keep_lowdim = (flags & MPC_LEVEL_KEEP_LOWDIM) ? 1 : 0;
         if (flags & MPC_LEVEL_GRAPH) { /* no pruning in the graph traversal */ }
         else if (h->mw == 2) hipLaunchKernelGGL(k_pruned_append<2>, dim3(blocks256), dim3(256), 0, st, h->frontier.as<int32_t>(), n, k, h->status.as<uint8_t>(),
-                                           h->pruned_new.as<unsigned long long>(), ctr);
+                                           h->pruned_new.as<unsigned long long>(), ctr, keep_lowdim);
         else hipLaunchKernelGGL(k_pruned_append<4>, dim3(blocks256), dim3(256), 0, st, h->frontier.as<int32_t>(), n, k, h->status.as<uint8_t>(),
-                                h->pruned_new.as<unsigned long long>(), ctr);
+                                h->pruned_new.as<unsigned long long>(), ctr, keep_lowdim);
         if (gen_children) {
             HIP_TRY(h, h->childmask.ensure(nn * h->mw * sizeof(uint64_t), st));
             HIP_TRY(h, h->count.ensure(nn * sizeof(int32_t), st));
             HIP_TRY(h, h->offset.ensure(nn * sizeof(int32_t), st));
             if (h->mw == 2) hipLaunchKernelGGL(k_children_count<2>, dim3((unsigned)n), dim3(64), 0, st, h->Pv, h->frontier.as<int32_t>(), n, k, h->status.as<uint8_t>(),
-                                               h->pruned.as<unsigned long long>(), (long long)h->n_pruned, h->childmask.as<unsigned long long>(), h->count.as<int32_t>());
+                                               h->pruned.as<unsigned long long>(), (long long)h->n_pruned, h->childmask.as<unsigned long long>(), h->count.as<int32_t>(), keep_lowdim);
             else hipLaunchKernelGGL(k_children_count<4>, dim3((unsigned)n), dim3(64), 0, st, h->Pv, h->frontier.as<int32_t>(), n, k, h->status.as<uint8_t>(),
-                                    h->pruned.as<unsigned long long>(), (long long)h->n_pruned, h->childmask.as<unsigned long long>(), h->count.as<int32_t>());
+                                    h->pruned.as<unsigned long long>(), (long long)h->n_pruned, h->childmask.as<unsigned long long>(), h->count.as<int32_t>(), keep_lowdim);
             { int rcs = launch_scan(h, h->count.as<int32_t>(), h->offset.as<int32_t>(), n, total); if (rcs) return rcs; }
             HIP_TRY(h, hipGetLastError());
             HIP_TRY(h, hipStreamSynchronize(st));
@@ -1437,7 +1438,7 @@ int mpc_level_run_ex(mpc_handle *h, int32_t gen_children, int32_t flags, mpc_lev
     if (!h) return MPC_ERR_INVALID;
     if ((flags & MPC_LEVEL_GRAPH) && gen_children) return fail(h, MPC_ERR_INVALID, "MPC_LEVEL_GRAPH has no children");
     { std::lock_guard<std::mutex> lk(h->wm); if (h->w_busy) return fail(h, MPC_ERR_STATE, "a level started with mpc_level_start is still running"); }
-    return level_run_impl(h, gen_children, flags & ~MPC_LEVEL_STREAM, stats);
+    return level_run_impl(h, gen_children, flags & ~(MPC_LEVEL_STREAM | MPC_LEVEL_THEN_BASE), stats);
 }
 
 // ---- the same level, driven by the handle's worker thread ---------------------------------------------------------------
@@ -1454,7 +1455,11 @@ static void worker_main(mpc_handle *h) {
         std::memset(&st, 0, sizeof(st));
         const int rc = level_run_impl(h, gen, flags, &st);
         h->base_valid = false;
-        if (rc == MPC_OK && (flags & MPC_LEVEL_THEN_BASE) && !gen && st.n_region_retry == 0 && !(h->so.active && !h->so.taken)) {
+        // only when the level's records were streamed AND the caller already owns the arrays (or the level has no region at all): a
+        // level that did not stream (LDS-engine region kernel ...) is fetched by the caller after mpc_level_wait, from the very state
+        // this check would replace
+        const bool streamed_and_taken = h->so.active && h->so.taken;
+        if (rc == MPC_OK && (flags & MPC_LEVEL_THEN_BASE) && !gen && st.n_region_retry == 0 && (streamed_and_taken || st.n_regions == 0)) {
             // The base active set (the equality rows alone; driver :142-146) right behind the last level, while the caller
             // is still turning the streamed records into objects.  Any failure simply leaves the check to the caller.
             std::vector<int32_t> base((size_t)std::max(h->n_eq, 1));

@@ -16,6 +16,9 @@ processed by every rank, the first large level is split ``to_check[rank::world]`
 of their parent and the ranks exchange only the newly pruned sets per level and the regions at the end -- children are
 never moved between ranks.
 
+``prune_lowdim`` selects between the two pruning rules of the reference's drivers (see ``solve``); ``solve_mpqp`` maps
+``combinatorial_parallel`` to the parallel driver's rule and ``combinatorial`` / ``combinatorial_parallel_exp`` to the serial one.
+
 Differences from the reference that are visible to a user:
   * ``shuffle(to_check)`` (driver :114) is dropped -- candidate order is deterministic, and so is the region order;
   * a numerically singular KKT matrix is a per-candidate status (no region, children expanded) instead of the
@@ -71,11 +74,15 @@ STREAM_MIN_CANDIDATES = 8192
 
 
 def solve(program, num_cores: int = -1, device: int = 0, profile: Optional[List[Dict]] = None,
-          collect_regions: bool = True, max_levels: Optional[int] = None, stream: Optional[bool] = None) -> Solution:
+          collect_regions: bool = True, max_levels: Optional[int] = None, stream: Optional[bool] = None,
+          prune_lowdim: bool = True) -> Solution:
     """Solves the mpLP/mpQP on one GPU.  ``num_cores`` is accepted for signature compatibility with the reference
     drivers and ignored.  ``profile``: optional list that receives one dict of statistics per level.  ``stream``: region
     records are streamed to the host while the region kernel runs (default; ``MPC_NO_STREAM=1`` or False = fetch after
-    each level)."""
+    each level).  ``prune_lowdim``: True = the parallel driver's rule, an active set that is optimal with a lower-dimensional
+    region is pruned together with its supersets (mpqp_parrallel_combinatorial.py:57-59); False = the serial driver's rule
+    (mpqp_combinatorial.py:44-61, also the _exp parallel driver), every feasible set is expanded -- more candidates, and on
+    degenerate programs more regions."""
     if stream is None:
         stream = os.environ.get('MPC_NO_STREAM', '0') != '1'
     eng = program.engine(device)
@@ -94,7 +101,7 @@ def solve(program, num_cores: int = -1, device: int = 0, profile: Optional[List[
             # The level runs on the handle's worker thread; its region kernel writes the records straight into page-locked
             # host arrays and raises a flag per chunk of slots, so the region objects of a chunk are built while the kernel
             # is still working on the later ones -- no fetch afterwards, nothing waits for Python.
-            eng.level_start(gen_children, stream=True, then_base=not gen_children)
+            eng.level_start(gen_children, stream=True, then_base=not gen_children, keep_lowdim=not prune_lowdim)
             base_behind_level = not gen_children
             info = eng.level_stream_info()
             new_regions: List[CriticalRegion] = []
@@ -118,7 +125,7 @@ def solve(program, num_cores: int = -1, device: int = 0, profile: Optional[List[
                 new_regions = batch.regions_of(numpy.flatnonzero(hi[:, 0] == REGION_STATUS).tolist())
             solution.critical_regions.extend(new_regions)
         else:
-            st = eng.level_run(gen_children)
+            st = eng.level_run(gen_children, keep_lowdim=not prune_lowdim)
             if collect_regions and st.n_regions:
                 # the integer heads are waited for (the region objects are built from them); the two large arrays keep
                 # arriving by DMA while Python builds the objects -- eng.sync() below completes them

@@ -58,7 +58,9 @@ def solve_mpqp(problem: MPQP_Program, algorithm: mpqp_algorithm = mpqp_algorithm
     elif algorithm in _GEOMETRIC:
         solution = mpqp_hip_geometric.solve(problem, device=device)
     else:
-        solution = mpqp_hip_combinatorial.solve(problem, device=device)
+        # the serial driver (and the _exp parallel one) expand every feasible set; the parallel driver also prunes the supersets of
+        # sets that are optimal with a lower-dimensional region (driver differences)
+        solution = mpqp_hip_combinatorial.solve(problem, device=device, prune_lowdim=algorithm is mpqp_algorithm.combinatorial_parallel)
     # overlap flags exactly as the reference sets them (solve_mpqp.py:103-112)
     if isinstance(problem, MPQP_Program) and min(numpy.linalg.eigvalsh(problem.Q)) <= 0:
         solution.is_overlapping = True

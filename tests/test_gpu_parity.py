@@ -898,3 +898,23 @@ def test_geometric_algorithm_finds_the_same_regions(name):
     sol2 = solve_mpqp(prog, mpqp_algorithm.geometric_parallel)
     assert sorted(tuple(r.active_set) for r in sol2.critical_regions) == sorted(got)
     print(name, 'regions', len(ref), 'geometric', len(got), 'rounds', len(prof), 'facets', sum(p['facets'] for p in prof), 'QPs', sum(p['qps'] for p in prof))
+
+
+def test_solve_keeps_the_last_level_when_it_does_not_stream():
+    """A program whose region kernel is the LDS-engine one (no streaming): the solve loop fetches the last level's regions after
+    the level -- the base-set check must not have replaced the level's state by then.  (Found by tools/algo_agreement.py: 933 of
+    1116 regions were lost.)  All drivers agree on the complete solution, and both pruning rules of the combinatorial drivers."""
+    from ppopt_amd import MPQP_Program
+    from ppopt_amd.mp_solvers import mpqp_hip_combi_graph, mpqp_hip_combinatorial, mpqp_hip_geometric
+    from ppopt_amd.mp_solvers.solve_mpqp import mpqp_algorithm, solve_mpqp
+    d = __import__('ppopt_amd.problem_generator', fromlist=['x']).generate_mpqp_data(7, 4, 24, 623692)
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        prog = MPQP_Program(d['A'], d['b'], d['c'], d['H'], d['Q'], d['A_t'], d['b_t'], d['F'])
+    a = mpqp_hip_combinatorial.solve(prog, stream=True)
+    b_ = mpqp_hip_combinatorial.solve(prog, stream=False)
+    keys = sorted(tuple(r.active_set) for r in a.critical_regions)
+    assert len(keys) == 1116 and keys == sorted(tuple(r.active_set) for r in b_.critical_regions)
+    for algo in (mpqp_algorithm.combinatorial, mpqp_algorithm.combinatorial_parallel_exp, mpqp_algorithm.graph,
+                 mpqp_algorithm.combinatorial_graph, mpqp_algorithm.geometric):
+        assert sorted(tuple(r.active_set) for r in solve_mpqp(prog, algo).critical_regions) == keys, algo
