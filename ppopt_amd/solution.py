@@ -60,7 +60,7 @@ class Solution:
         ef_parts, cnt, xl_parts = [], [], []
         adj_masks, adj_info, adj_ok = [], [], True       # facet adjacency for the walk locator (device-solved regions only)
         n_c = self.program.num_constraints() if hasattr(self.program, 'num_constraints') else 0
-        adj_ok = n_c > 0
+        adj_ok = n_c > 0 and n_t > 1       # one parameter: regions are intervals built by the 1-D variant, whose two rows carry no facet kinds
         words = 2 if n_c <= 128 else 4
         i = 0
         while i < len(regs):

@@ -918,3 +918,48 @@ def test_solve_keeps_the_last_level_when_it_does_not_stream():
     for algo in (mpqp_algorithm.combinatorial, mpqp_algorithm.combinatorial_parallel_exp, mpqp_algorithm.graph,
                  mpqp_algorithm.combinatorial_graph, mpqp_algorithm.geometric):
         assert sorted(tuple(r.active_set) for r in solve_mpqp(prog, algo).critical_regions) == keys, algo
+
+
+def test_all_drivers_and_consumers_agree_on_random_programs():
+    """Random small mpQPs solved completely by every driver -- combinatorial (both pruning rules), graph, combinatorial_graph,
+    geometric -- must give one set of active sets; on the complete solution the walk locator must return what the list scan
+    returns, and the QP at sampled points the explicit law.  (tools/algo_agreement.py is the long form: 260 programs.)"""
+    from ppopt_amd import MPQP_Program, problem_generator as pg
+    from ppopt_amd.mp_solvers import mpqp_hip_combi_graph as G, mpqp_hip_combinatorial as C, mpqp_hip_geometric as GE
+    from ppopt_amd.solution import Solution
+    rng = numpy.random.default_rng(21)
+    old_min = Solution.WALK_MIN_REGIONS
+    n_walk = 0
+    try:
+        Solution.WALK_MIN_REGIONS = 1
+        for _ in range(14):
+            nx, nt = int(rng.integers(2, 7)), int(rng.integers(1, 5))
+            m = int(rng.integers(nx + 2, 3 * nx + 4))
+            seed = int(rng.integers(0, 10 ** 6))
+            d = pg.generate_mpqp_data(nx, nt, m, seed)
+            with warnings.catch_warnings():
+                warnings.simplefilter('ignore')
+                prog = MPQP_Program(d['A'], d['b'], d['c'], d['H'], d['Q'], d['A_t'], d['b_t'], d['F'])
+            ref = {tuple(r.active_set) for r in C.solve(prog, prune_lowdim=False).critical_regions}
+            tag = (nx, nt, m, seed)
+            assert {tuple(r.active_set) for r in C.solve(prog).critical_regions} == ref, tag
+            gsol = G.solve_graph(prog)
+            assert {tuple(r.active_set) for r in gsol.critical_regions} == ref and gsol.is_complete, tag
+            assert {tuple(r.active_set) for r in G.solve(prog).critical_regions} == ref, tag
+            geo = {tuple(r.active_set) for r in GE.solve(prog).critical_regions}
+            assert geo <= ref and len(geo) >= len(ref) - 1, tag          # a sliver region may stay out of the geometric walk's reach
+            half = 1.05 * numpy.abs(d['b_t']).max()
+            pts = -half + rng.random((800, nt)) * 2 * half
+            gsol.use_walk = True
+            xw, iw = gsol.evaluate_batch(pts)
+            n_walk += int(gsol.locator().has_adjacency)
+            gsol.use_walk = False
+            xs, i_s = gsol.evaluate_batch(pts)
+            assert numpy.array_equal(iw, i_s), tag
+            inside = numpy.flatnonzero(i_s >= 0)[:120]
+            for p, r in zip(inside, prog.solve_theta_batch(pts[inside])):
+                assert r is not None and numpy.max(numpy.abs(r.sol - xs[p]) / (1 + numpy.abs(xs[p]))) <= 1e-7, (tag, p)
+            prog.release_engine()
+    finally:
+        Solution.WALK_MIN_REGIONS = old_min
+    assert n_walk >= 6
