@@ -14,8 +14,10 @@ tree can be split by subtrees without ever producing a candidate twice:
                        dictionary.  The one thing the ranks must share is the pruned list (the reference's murder_list,
                        solver_utils.py:15-55): per level one all-gather of the newly pruned masks (KBs) and one of a small
                        statistics row.  No frontier, no dictionary and no region ever crosses xGMI inside the loop.
-  * regions            collected locally; after the last level the sharded levels' regions are all-gathered (padded:
-                       RCCL has no all-gather-v) so that every rank returns the complete Solution.
+  * regions            every sharded level's regions are all-gathered asynchronously (padded: RCCL has no all-gather-v; RCCL's
+                       stream) as soon as the level is done; they are copied to the host and turned into objects while the NEXT
+                       level runs on the device (the engine's worker thread drives it), so every rank returns the complete
+                       Solution and only the last level's regions are handled after the kernels.
 
 The exchange is written against a small engine interface on torch tensors so that the same code runs on CUDA tensors
 with RCCL (``HipLevelEngine``) and -- in the CPU tests -- on CPU tensors with gloo and an oracle-backed engine.
@@ -62,6 +64,10 @@ class HipLevelEngine:
     def run(self, gen_children: bool) -> Dict:
         st = self.eng.level_run(gen_children)
         self._stats = st
+        return self._as_dict(st)
+
+    @staticmethod
+    def _as_dict(st) -> Dict:
         return {'n': int(st.n), 'k': int(st.k), 'status': [int(v) for v in st.n_status], 'n_regions': int(st.n_regions),
                 'n_children': int(st.n_children), 'n_pruned_new': int(st.n_pruned_new), 'lp_pivots': int(st.lp_pivots),
                 'ms_verdict': float(st.ms_verdict), 'ms_region': float(st.ms_region), 'ms_children': float(st.ms_children),
@@ -78,6 +84,16 @@ class HipLevelEngine:
         t = torch.empty(shape, dtype=dtype, device=self.device)
         torch.cuda.current_stream(self.device).synchronize()
         return t
+
+    def run_start(self, gen_children: bool):
+        """``run`` on the engine's worker thread (mpc_level_start): returns at once, ``run_wait`` joins.  solve_distributed uses
+        the time in between to bring the previous level's gathered regions to the host and build their objects."""
+        self.eng.level_start(gen_children, stream=False)
+
+    def run_wait(self) -> Dict:
+        st = self.eng.level_wait()
+        self._stats = st
+        return self._as_dict(st)
 
     def pruned_new(self) -> torch.Tensor:
         m = int(self._stats.n_pruned_new)
@@ -205,14 +221,38 @@ def solve_distributed(engine, program=None, group=None, profile: Optional[List[D
     engine.clear_pruned()
     engine.root()
     sharded = False
-    mine: List = []   # (k, three pending all-gathers) per sharded level with regions
+    pending = None    # (k, three all-gathers in flight) of the most recent sharded level with regions
+
+    def finish(entry):
+        """Waits for a level's gathers, copies every rank's piece to pinned host memory and lists its regions (rank order)."""
+        kk, gathers = entry
+        for _, work in gathers:
+            if work is not None:
+                work.wait()
+        for a, b, c in zip(gathers[0][0], gathers[1][0], gathers[2][0]):
+            if a.shape[0]:
+                hd, hi, er = to_host(a), to_host(b), to_host(c)
+                slots = numpy.flatnonzero(hi[:, 0] == REGION_STATUS)
+                solution.critical_regions.extend(RegionBatch(hd, hi, er, engine.n_x, engine.n_t, engine.n_c, engine.n_tc, kk,
+                                                             slots).regions())
     for depth in range(max_depth):
         gen_children = depth + 1 != max_depth
         n, k = engine.frontier_size()
         if not sharded and (world > 1 or force_shard) and n >= shard_min * world:   # force_shard: self-test with one rank
             engine.shard(rank, world)
             sharded = True
-        st = engine.run(gen_children)
+        if pending is not None and hasattr(engine, 'run_start'):
+            # the previous sharded level's regions (gathered on RCCL's stream meanwhile) come to the host and become objects
+            # while this level runs on the device
+            engine.run_start(gen_children)
+            finish(pending)
+            pending = None
+            st = engine.run_wait()
+        else:
+            if pending is not None:
+                finish(pending)
+                pending = None
+            st = engine.run(gen_children)
         total = st
         tensors = None
         if sharded:
@@ -241,9 +281,9 @@ def solve_distributed(engine, program=None, group=None, profile: Optional[List[D
                     dev = engine.device
                     tensors = (torch.zeros((0, fd), dtype=torch.float64, device=dev), torch.zeros((0, fi), dtype=torch.int32, device=dev),
                                torch.zeros((0, engine.n_t + 1), dtype=torch.float64, device=dev))
-                mine.append((kk, [allgather_rows_start(tensors[0], [r[5] for r in table], group),
-                                  allgather_rows_start(tensors[1], [r[5] for r in table], group),
-                                  allgather_rows_start(tensors[2], [r[6] for r in table], group)]))
+                pending = (kk, [allgather_rows_start(tensors[0], [r[5] for r in table], group),
+                                allgather_rows_start(tensors[1], [r[5] for r in table], group),
+                                allgather_rows_start(tensors[2], [r[6] for r in table], group)])
         elif collect_regions and st['n_regions']:
             hd, hi, er, kk, slots = engine.regions()
             solution.critical_regions.extend(RegionBatch(hd, hi, er, engine.n_x, engine.n_t, engine.n_c, engine.n_tc, kk, slots).regions())
@@ -258,17 +298,8 @@ def solve_distributed(engine, program=None, group=None, profile: Optional[List[D
         if not gen_children or total['n_children'] == 0:
             break
         engine.advance()
-    # regions of the sharded levels: wait for the gathers, one device-to-host copy per piece, rank order
-    for kk, gathers in mine:
-        for _, work in gathers:
-            if work is not None:
-                work.wait()
-        for a, b, c in zip(gathers[0][0], gathers[1][0], gathers[2][0]):
-            if a.shape[0]:
-                hd, hi, er = to_host(a), to_host(b), to_host(c)
-                slots = numpy.flatnonzero(hi[:, 0] == REGION_STATUS)
-                solution.critical_regions.extend(RegionBatch(hd, hi, er, engine.n_x, engine.n_t, engine.n_c, engine.n_tc, kk,
-                                                             slots).regions())
+    if pending is not None:      # the last sharded level
+        finish(pending)
     # the base active set, on every rank (one candidate; identical result everywhere)
     hist, regs = engine.check_base()
     if profile is not None:
