@@ -243,9 +243,21 @@ class Solution:
         if numpy.any(~numpy.isfinite(radii)):
             return False
         located = self.get_region_batch(centres, device)
+        # the reference's own test where the program offers it: the deterministic solve at the centre (one device batch of QPs
+        # / LPs, MPQP_Program.solve_theta_batch) must give the region's x* -- solution.py:128-145
+        det = None
+        if hasattr(self.program, 'solve_theta_batch') and all(r.y_fixation is None for r in self.critical_regions):
+            try:
+                det = self.program.solve_theta_batch(centres)
+            except Exception:          # e.g. a positive semidefinite Q: the QP batch does not apply, the KKT test below stands alone
+                det = None
         for i, region in enumerate(self.critical_regions):
             if max(self.kkt_residuals(region, centres[i]).values()) > tol:
                 return False
+            if det is not None and det[i] is not None and not self.is_overlapping:
+                xr = region.evaluate(centres[i].reshape(-1, 1)).ravel()
+                if numpy.max(numpy.abs(det[i].sol - xr)) > 1e-5 * (1.0 + numpy.max(numpy.abs(xr))):
+                    return False
             if not self.is_overlapping and located[i] != i:
                 # a thin region (radius below the point-location tolerance) may be preceded in the list by a neighbour that
                 # contains the centre within that tolerance: consistent as long as both give the same objective there
