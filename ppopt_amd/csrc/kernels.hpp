@@ -64,6 +64,7 @@ struct LevelCounters {
     unsigned long long cycles[8];   // wave-cycles (s_memtime) spent in: KKT solve, theta LP, (x,theta) LP, region build; [4] theta rows, [5] theta stage 2; [6],[7] candidates decided by the box screen (stage 1 / multiplier row)
     unsigned int work_verdict, work_region, n_opt, n_pruned_new, work_retry, work_x, e_rows, work_r2, work_q, n_retry_theta, n_rretry;
     unsigned long long r_box;       // k_region2: region rows removed by the bounding-box screen
+    unsigned long long r2_not_t0, r2_t1;  // k_region2: ~(wall clock of the first wavefront's start), wall clock of the last one's end
 };
 
 struct Smem {
@@ -926,6 +927,19 @@ __global__ void k_close_open(const int32_t *__restrict__ list, int n_list, uint8
 __global__ void k_apply_status(const int32_t *__restrict__ list, int n_list, const uint8_t *__restrict__ tmp, uint8_t *__restrict__ status) {
     const int w = blockIdx.x * blockDim.x + threadIdx.x;
     if (w < n_list) { const int c = list[w]; status[c] = tmp[c]; }
+}
+
+// Spare region slots behind the slots of the overlapped region launch (level_run_impl): slot first + j gets status word `st`
+// and candidate list[j] (or -1).  st = 0: unused slot; st = 7 (ST_RETRY): a candidate that turned out optimal after the launch,
+// its record comes from the LDS-engine kernel like that of a candidate k_region2 gave up on.
+__global__ void k_init_slots(int32_t *__restrict__ head_i, int fi, int first, int count, int st, const int32_t *__restrict__ list) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j < count) { int32_t *hi = head_i + (size_t)(first + j) * fi; hi[0] = st; hi[1] = list ? list[j] : -1; }
+}
+// status[list[w]] = st for w in [from, n_list)
+__global__ void k_set_status(const int32_t *__restrict__ list, int from, int n_list, int st, uint8_t *__restrict__ status) {
+    const int w = from + blockIdx.x * blockDim.x + threadIdx.x;
+    if (w < n_list) status[list[w]] = (uint8_t)st;
 }
 
 // keeps rows start, start+stride, ... of a row-major int matrix (frontier sharding, mpc_frontier_shard)

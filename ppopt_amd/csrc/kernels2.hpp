@@ -69,6 +69,7 @@ struct ThetaArgs {
 constexpr int KK_UNDECIDED = 255;
 constexpr int KK_ILL = 64;        // solved, but the Schur system is ill-conditioned (CHOL_ILL_TOL, kkt.hpp)
 constexpr int ST_TODO = 10;       // internal: waiting for k_theta2
+constexpr int ST_RRETRY = 11;     // status[] of a candidate k_region2 gave up on (its slot carries ST_RETRY): re-solved by k_region
 template <int K, int NT>
 __global__ void __launch_bounds__(256) k_kkt_thread(const DevProblem *__restrict__ Pg, const int32_t *__restrict__ cands, long long n,
                                                      uint8_t *__restrict__ code, double *__restrict__ Lout, uint8_t *__restrict__ status,
@@ -962,6 +963,9 @@ __global__ void __launch_bounds__(64, (SLOTS >= 2 ? 2 : R2W)) k_region2(
     constexpr int ID_SIGMA = 4096, ID_R = 8192;
     unsigned long long pivots = 0;
     long long cyc = 0, rc_rows = 0, rc_cheb = 0, rc_facet = 0, rc_tot = 0, rc_refac = 0, rc_fpiv = 0, rc_box = 0;
+    // the kernel's own duration on the constant-rate wall clock (first wavefront in, last wavefront out): the kernel may run on
+    // a side stream under other kernels, where event markers are timestamped when the busy command processor reaches them
+    if (lane == 0) atomicMax(&ctr->r2_not_t0, ~(unsigned long long)wall_clock64());
     for (;;) {
         unsigned int item = 0;
         if (lane == 0) item = atomicAdd(&ctr->work_r2, 1u);
@@ -1383,7 +1387,7 @@ __global__ void __launch_bounds__(64, (SLOTS >= 2 ? 2 : R2W)) k_region2(
         if (retry) { st = ST_RETRY; if (lane == 0 && is_last) atomicAdd(&ctr->n_rretry, 1u); }
         if (lane == 0 && is_last) {
             hi[0] = st; hi[1] = c; hi[2] = nE; hi[3] = n_om; hi[4] = n_la; hi[5] = n_re; hi[6] = e_off; hi[7] = reason;
-            status[c] = (uint8_t)st;
+            status[c] = (uint8_t)(retry ? ST_RRETRY : st);   // distinct from the verdict stages' ST_RETRY, which may be pending on other candidates
         }
         if (rs.count && is_last) {
             // every store of this slot's record is released to system scope before the slot is counted; the wavefront that
@@ -1406,6 +1410,7 @@ __global__ void __launch_bounds__(64, (SLOTS >= 2 ? 2 : R2W)) k_region2(
         atomicAdd(&ctr->rcycles[2], (unsigned long long)rc_facet); atomicAdd(&ctr->rcycles[3], (unsigned long long)rc_tot);
         atomicAdd(&ctr->rcycles[4], (unsigned long long)rc_refac); atomicAdd(&ctr->rcycles[5], (unsigned long long)rc_fpiv);
         atomicAdd(&ctr->r_box, (unsigned long long)rc_box);
+        atomicMax(&ctr->r2_t1, (unsigned long long)wall_clock64());
     }
 }
 

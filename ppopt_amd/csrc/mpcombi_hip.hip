@@ -237,6 +237,12 @@ struct mpc_handle {
     hipStream_t stream = nullptr;
     hipStream_t stream2 = nullptr;   // side stream: retry kernels of few long-running wavefronts overlap the main pipeline
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    hipStream_t stream3 = nullptr;   // region stage of a level, launched under its (x,theta) stage
+    hipEvent_t ev_rfork = nullptr, ev_rjoin = nullptr, ev_rgo = nullptr;
+    bool no_roverlap = false;        // MPC_NO_ROVERLAP=1: region stage after the (x,theta) stage (no overlap)
+    long long roverlap_min = 2048, roverlap_long = 50000;   // MPC_ROVERLAP_MIN / MPC_ROVERLAP_LONG (items of the (x,theta) stage)
+    int wall_khz = 100000;           // rate of wall_clock64() on the device
+    int test_late = 0;               // MPC_TEST_LATE=N (tests): the overlapped launch leaves N optimal candidates to the late path
     bool own_stream = false;
     int n_cu = 256;
     std::string error;
@@ -472,6 +478,7 @@ static int create_fill(const mpc_problem *p, int32_t device, void *stream, mpc_h
     h->device = device;
     HIP_TRY(nullptr, hipSetDevice(device));
     h->n_cu = cu_count(device);
+    { int khz = 0; if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, device) == hipSuccess && khz > 0) h->wall_khz = khz; }
     if (stream) { h->stream = reinterpret_cast<hipStream_t>(stream); h->own_stream = false; }
     else { HIP_TRY(nullptr, pooled_stream(&h->stream)); h->own_stream = true; }
     for (auto &e : h->ev) HIP_TRY(nullptr, pooled_event(&e, true));
@@ -480,6 +487,10 @@ static int create_fill(const mpc_problem *p, int32_t device, void *stream, mpc_h
     HIP_TRY(nullptr, pooled_event(&h->ev_hi, false));
     HIP_TRY(nullptr, pooled_event(&h->ev_fork, false));
     HIP_TRY(nullptr, pooled_event(&h->ev_join, false));
+    HIP_TRY(nullptr, pooled_stream(&h->stream3));
+    HIP_TRY(nullptr, pooled_event(&h->ev_rfork, false));
+    HIP_TRY(nullptr, pooled_event(&h->ev_rjoin, false));
+    HIP_TRY(nullptr, pooled_event(&h->ev_rgo, false));
     h->n_x = nx; h->n_t = nt; h->n_c = nc; h->n_eq = ne; h->n_tc = ntc; h->is_qp = p->Q != nullptr;
     h->mw = nc <= 64 * MPC_MASK_WORDS ? MPC_MASK_WORDS : 4;
     { const char *ev = std::getenv("MPC_FORCE_V1"); h->force_v1 = ev && ev[0] == '1'; }
@@ -490,6 +501,10 @@ static int create_fill(const mpc_problem *p, int32_t device, void *stream, mpc_h
     { const char *ev = std::getenv("MPC_FORCE_XQGROUP"); h->force_xqgroup = ev && ev[0] == '1'; }
     { const char *ev = std::getenv("MPC_NO_XQUICK"); h->no_xquick = ev && ev[0] == '1'; }
     { const char *ev = std::getenv("MPC_NO_KKT_THREAD"); h->no_kkt_thread = ev && ev[0] == '1'; }
+    { const char *ev = std::getenv("MPC_NO_ROVERLAP"); h->no_roverlap = ev && ev[0] == '1'; }
+    { const char *ev = std::getenv("MPC_TEST_LATE"); h->test_late = ev ? std::atoi(ev) : 0; }
+    { const char *ev = std::getenv("MPC_ROVERLAP_MIN"); if (ev) h->roverlap_min = std::atoll(ev); }
+    { const char *ev = std::getenv("MPC_ROVERLAP_LONG"); if (ev) h->roverlap_long = std::atoll(ev); }
     { const char *ev = std::getenv("MPC_DICT_BUDGET_GB"); if (ev) h->dict_budget_gb = std::atof(ev); }
 
     const int nr = nt + 1;
@@ -804,6 +819,7 @@ int mpc_destroy(mpc_handle *h) {
     (void)hipSetDevice(h->device);
     (void)hipStreamSynchronize(h->stream);
     if (h->stream2) (void)hipStreamSynchronize(h->stream2);
+    if (h->stream3) (void)hipStreamSynchronize(h->stream3);
     for (DevBuf *b : {&h->blocks, &h->iblocks, &h->frontier, &h->children, &h->status, &h->pruned, &h->pruned_new, &h->flag, &h->pos, &h->opt_list,
                       &h->childmask, &h->count, &h->offset, &h->recd, &h->reci, &h->ctr, &h->scratch, &h->sums, &h->retry_list, &h->pf_dev, &h->pr2_dev, &h->headd, &h->headi, &h->epool, &h->facet_flags, &h->kkt_code, &h->kkt_L, &h->theta_blocks, &h->xq_groups, &h->theta_list, &h->vretry_list, &h->status_tmp, &h->part_counts, &h->part_lists, &h->kept_g, &h->done_g, &h->dict_d[0], &h->dict_d[1], &h->dict_i[0], &h->dict_i[1],
                       &h->dict_stored[0], &h->dict_stored[1], &h->parent_slot, &h->parent_slot_next}) b->release();
@@ -817,7 +833,11 @@ int mpc_destroy(mpc_handle *h) {
     return_event(h->ev_hi, false);
     return_event(h->ev_fork, false);
     return_event(h->ev_join, false);
+    return_event(h->ev_rfork, false);
+    return_event(h->ev_rjoin, false);
+    return_event(h->ev_rgo, false);
     return_stream(h->stream2);
+    return_stream(h->stream3);
     if (h->own_stream) return_stream(h->stream);
     delete h;
     return MPC_OK;
@@ -1064,10 +1084,97 @@ static int level_run_impl(mpc_handle *h, int32_t gen_children, int32_t flags, mp
             return MPC_OK;
         };
         auto part_list = [&](int c) -> int32_t * { return h->part_lists.as<int32_t>() + (size_t)c * nn; };
+        const uint8_t *kkc = nullptr;   // KKT codes and multipliers of k_kkt_thread (read by k_theta2 / k_region2)
+        const double *kkl = nullptr;
+        // region stage on the register engine: one slot per candidate of h->opt_ptr.  Buffers are prepared on the main stream; the
+        // kernel goes to `rst` (the main stream, or stream3 when the stage runs under the level's (x,theta) stage)
+        h->used_region2 = false; h->n_rretry = 0; h->n_erows = 0;
+        h->fd = h->n_x * h->n_t + h->n_x + k * h->n_t + k;
+        h->fi = 8 + k + h->n_tc + k + 2 * (h->n_c - k);
+        int32_t *region_out_hi = nullptr;   // head_i of the level's slots as the device sees it (device buffer or mapped host block)
+        auto region2_launch = [&](int32_t n_opt, int32_t extra, hipStream_t rst, bool one_wave) -> int {
+            const int rows_t_ = h->n_c - h->n_eq + h->n_tc;
+            const size_t n_tot = (size_t)n_opt + (size_t)extra;   // slots: the launch's candidates + spare ones for late optimal candidates
+            HIP_TRY(h, h->headd.ensure(n_tot * h->fd * sizeof(double), st));
+            HIP_TRY(h, h->headi.ensure(n_tot * h->fi * sizeof(int32_t), st));
+            HIP_TRY(h, h->epool.ensure(n_tot * rows_t_ * (h->n_t + 1) * sizeof(double), st));
+            // few optimal candidates: several wavefronts per candidate (the facet tests are split among them)
+            const int W = (h->no_rsplit || one_wave) ? 1 : ((long long)n_opt * 4 <= h->grid_r2 ? 4 : ((long long)n_opt * 2 <= h->grid_r2 ? 2 : 1));
+            const int ldk = (rows_t_ + 1 + 63) & ~63;
+            if (W > 1) {
+                HIP_TRY(h, h->kept_g.ensure((size_t)n_opt * ldk, st));
+                HIP_TRY(h, h->done_g.ensure((size_t)n_opt * 2 * sizeof(unsigned int), st));
+                HIP_TRY(h, hipMemsetAsync(h->done_g.p, 0, (size_t)n_opt * 2 * sizeof(unsigned int), st));
+            }
+            const dim3 g((unsigned)std::min<long long>((long long)n_opt * W, h->grid_r2)), b(64);
+            const DevProblem *pr = h->pr2_dev.as<DevProblem>();
+            // where the records go: device buffers (fetched / gathered later), or -- streaming -- page-locked host blocks the
+            // kernel writes directly, in chunks the host consumes while the kernel is still running
+            double *out_hd = h->headd.as<double>(), *out_er = h->epool.as<double>();
+            int32_t *out_hi = h->headi.as<int32_t>();
+            RegionStream rs{};
+            const size_t bytes_hd = n_tot * h->fd * sizeof(double), bytes_hi = n_tot * h->fi * sizeof(int32_t),
+                         bytes_er = n_tot * rows_t_ * (h->n_t + 1) * sizeof(double);
+            if ((flags & MPC_LEVEL_STREAM) && bytes_hd + bytes_hi + bytes_er <= (size_t(1) << 30)) {
+                auto &so = h->so;
+                so.shift = 8;
+                while (so.shift > 4 && ((long long)n_opt >> so.shift) < 8) --so.shift;   // at least ~8 chunks, 16..256 slots each
+                so.n_chunks = (int)(((long long)n_opt + (1ll << so.shift) - 1) >> so.shift);
+                so.n_slots = (long long)n_tot; so.cap_rows = (long long)n_tot * rows_t_;   // chunks cover the first n_opt slots
+                HIP_TRY(h, host_pool_take(bytes_hd, &so.hd, nullptr));
+                HIP_TRY(h, host_pool_take(bytes_hi, &so.hi, nullptr));
+                HIP_TRY(h, host_pool_take(std::max<size_t>(bytes_er, 8), &so.er, nullptr));
+                HIP_TRY(h, h->st_flags.ensure((size_t)so.n_chunks * sizeof(int32_t)));
+                std::memset(h->st_flags.p, 0, (size_t)so.n_chunks * sizeof(int32_t));
+                h->cw_chunks = so.n_chunks;
+                HIP_TRY(h, h->chunk_count.ensure((size_t)so.n_chunks * sizeof(unsigned int), st));
+                HIP_TRY(h, hipMemsetAsync(h->chunk_count.p, 0, (size_t)so.n_chunks * sizeof(unsigned int), st));
+                void *d_hd = nullptr, *d_hi = nullptr, *d_er = nullptr, *d_fl = nullptr;
+                HIP_TRY(h, hipHostGetDevicePointer(&d_hd, so.hd, 0));
+                HIP_TRY(h, hipHostGetDevicePointer(&d_hi, so.hi, 0));
+                HIP_TRY(h, hipHostGetDevicePointer(&d_er, so.er, 0));
+                HIP_TRY(h, hipHostGetDevicePointer(&d_fl, h->st_flags.p, 0));
+                out_hd = static_cast<double *>(d_hd); out_hi = static_cast<int32_t *>(d_hi); out_er = static_cast<double *>(d_er);
+                rs.count = h->chunk_count.as<unsigned int>(); rs.flags = static_cast<int32_t *>(d_fl); rs.shift = so.shift; rs.n_slots = n_opt;
+                so.active = true;
+            }
+#define MPC_LAUNCH_R2(NT_, SL_) hipLaunchKernelGGL((k_region2<NT_, SL_>), g, b, h->lds_r2, rst, pr, h->frontier.as<int32_t>(), k, h->opt_ptr, n_opt, \
+                                                   h->status.as<uint8_t>(), out_hd, out_hi, h->fd, h->fi, out_er, ctr, kkc, kkl, \
+                                                   W, h->kept_g.as<uint8_t>(), ldk, h->done_g.as<unsigned int>(), \
+                                                   h->no_rbox ? (const double *)nullptr : h->targs.tvp + (size_t)NT_ * NT_ + NT_, rs)
+            region_out_hi = out_hi;
+            if (extra > 0) hipLaunchKernelGGL(k_init_slots, dim3((unsigned)((extra + 255) / 256)), dim3(256), 0, st, out_hi, h->fi, n_opt, extra, 0, (const int32_t *)nullptr);
+            if (rst != st) {
+                // fork; the main stream continues only when the side stream has reached the region kernel, so that the region
+                // wavefronts (the long chains) are placed first and the (x,theta) kernels fill in around them -- without this the
+                // two dispatches race and the persistent (x,theta) kernel often takes the whole GPU first
+                HIP_TRY(h, hipEventRecord(h->ev_rfork, st));
+                HIP_TRY(h, hipStreamWaitEvent(rst, h->ev_rfork, 0));
+                HIP_TRY(h, hipEventRecord(h->ev_rgo, rst));
+                HIP_TRY(h, hipStreamWaitEvent(st, h->ev_rgo, 0));
+            }
+            HIP_TRY(h, hipEventRecord(h->kev[4], rst));
+            switch (h->fast_r) {
+                case 0: MPC_LAUNCH_R2(4, 1); break;
+                case 1: MPC_LAUNCH_R2(4, 2); break;
+                case 2: MPC_LAUNCH_R2(8, 1); break;
+                case 3: MPC_LAUNCH_R2(8, 2); break;
+                case 4: MPC_LAUNCH_R2(10, 1); break;
+                default: MPC_LAUNCH_R2(10, 2); break;
+            }
+#undef MPC_LAUNCH_R2
+            HIP_TRY(h, hipEventRecord(h->kev[5], rst));
+            if (rst != st) HIP_TRY(h, hipEventRecord(h->ev_rjoin, rst));
+            kernel_timed[2] = true;
+            HIP_TRY(h, hipGetLastError());
+            h->used_region2 = true;
+            stream_ready(h);   // the caller of mpc_level_stream_info may start consuming chunks
+            return MPC_OK;
+        };
+        bool region_launched = false;
+        int32_t n_late = 0;   // optimal candidates found after an overlapped region launch (spare slots)
         int32_t n_opt_fast = -1;   // >= 0: the fast path has already built h->opt_list
         // verdict
-        const uint8_t *kkc = nullptr;
-        const double *kkl = nullptr;
         HIP_TRY(h, hipEventRecord(h->ev[0], st));
         if (h->fast && !h->force_v1) {
             const int32_t *fr = h->frontier.as<int32_t>();
@@ -1155,6 +1262,36 @@ static int level_run_impl(mpc_handle *h, int32_t gen_children, int32_t flags, mp
                 dc.stored = h->dict_stored[h->dict_cur].as<uint8_t>();
                 h->storing = true;
             }
+            // The region stage needs the theta stage's verdicts only (no later stage turns a candidate optimal, except the
+            // re-solved doubtful ones): it starts now on its own stream and runs under the (x,theta) stage -- a few thousand
+            // long wavefronts at two per SIMD whose tail the streaming kernels of the (x,theta) stage fill.
+            int32_t region_extra = 0;
+            // x_items: what the (x,theta) stage has to do.  Below ROVERLAP_MIN_ITEMS there is nothing to hide the region stage
+            // under; from ROVERLAP_LONG_ITEMS on the stage outlasts the region kernel anyway, which then runs one wavefront per
+            // candidate (splitting a candidate over four wavefronts shortens its latency but takes registers from four SIMDs).
+            const long long x_items = (long long)cntA[3] + (h->storing ? (long long)cntA[1] + cntA[2] : 0);
+            // (the grouped quick test keeps four 128-register wavefronts per SIMD busy through LDS latency: one region wavefront on
+            // a CU halves that CU's share of it -- config 3's last level loses 0.1-0.25 ms with the region stage under it)
+            const size_t lds_q = (size_t)h->dict_stride_d * sizeof(double) + (size_t)h->dict_stride_i * sizeof(int32_t);
+            const bool quick_test = cntA[3] > 0 && !(flags & MPC_LEVEL_GRAPH) && !h->storing && dc.parent_slot && !h->no_xquick;
+            const bool use_grouped = quick_test && !h->no_xqgroup && ((h->last_level_n > 0 && (long long)cntA[3] >= 10 * h->last_level_n) || h->force_xqgroup) &&
+                                     cntA[3] >= 4096 && lds_q <= 64 * 1024;
+            if (!h->no_roverlap && cntA[2] > 0 && h->fast_r >= 0 && !(flags & MPC_LEVEL_GRAPH) && x_items >= h->roverlap_min && !use_grouped) {
+                // Candidates that turn out optimal later -- re-solved doubtful ones: the n_early of the theta stage, rarely one of
+                // the (x,theta) stage -- get spare slots behind the launch's and take the LDS-engine route of the candidates
+                // k_region2 gives up on.  More than 64 late ones from the (x,theta) stage (candidates whose theta stage found no
+                // feasible parameter and whose re-solve, in other arithmetic, calls them optimal) would keep the theta stage's
+                // answer: feasible, not optimal.
+                const int32_t hold = std::min<int32_t>(std::max(h->test_late, 0), cntA[2] - 1);
+                const int32_t n_launch = cntA[2] - hold;
+                region_extra = n_early + hold + (cntA[3] > 0 ? 64 : 0);
+                HIP_TRY(h, hipMemcpyAsync(h->opt_list.p, part_list(2), (size_t)n_launch * sizeof(int32_t), hipMemcpyDeviceToDevice, st));
+                h->opt_ptr = h->opt_list.as<int32_t>();
+                h->n_opt = n_launch;
+                int rcs = region2_launch(n_launch, region_extra, h->stream3, x_items >= h->roverlap_long);
+                if (rcs) return rcs;
+                region_launched = true;
+            }
             auto launch_x = [&](const int32_t *ls, int n_items, const DictCache &d0) -> int {
                 // ctr->work_x is zero: the counters were cleared at the start of the level and this is the level's only k_x2 launch
                 DictCache d = d0;
@@ -1186,17 +1323,15 @@ static int level_run_impl(mpc_handle *h, int32_t gen_children, int32_t flags, mp
                 HIP_TRY(h, hipGetLastError());
                 n_needx = 0;
             }
-            if (n_needx > 0 && !h->storing && dc.parent_slot && !h->no_xquick) {
+            if (quick_test) {
                 // last level: decisions only -- the quick test on three vectors of the parent's dictionary first
                 DictCache dq = dc;
                 const long long grid_q = (long long)h->n_cu * 32;
                 dq.chunk = (int)std::max<long long>(1, std::min<long long>(16, n_needx / (grid_q * 4)));
                 const dim3 gg((unsigned)std::min<long long>((n_needx + dq.chunk - 1) / dq.chunk, grid_q)), bb(64);
-                const size_t lds_q = (size_t)h->dict_stride_d * sizeof(double) + (size_t)h->dict_stride_i * sizeof(int32_t);
-                // Worth it when a parent has many open children (config 3: 12.6 per parent, -0.5 ms; config 4: 7.1 per parent, where
-                // the per-candidate reads of k_xq are cheaper than one 16 KB copy per parent, +0.45 ms): threshold 10.
-                const bool many_siblings = h->last_level_n > 0 && (long long)n_needx >= 10 * h->last_level_n;
-                if (!h->no_xqgroup && (many_siblings || h->force_xqgroup) && n_needx >= 4096 && lds_q <= 64 * 1024) {
+                // Grouped by parent when a parent has many open children (config 3: 12.6 per parent, -0.5 ms; config 4: 7.1 per
+                // parent, where the per-candidate reads of k_xq are cheaper than one 16 KB copy per parent, +0.45 ms): threshold 10.
+                if (use_grouped) {
                     // grouped by parent: the record is staged in LDS once per parent (k_xq_grouped)
                     HIP_TRY(h, h->xq_groups.ensure((size_t)n_needx * sizeof(int32_t), st));
                     const int nbq = (n_needx + 255) / 256;
@@ -1239,6 +1374,7 @@ static int level_run_impl(mpc_handle *h, int32_t gen_children, int32_t flags, mp
             }
             // second partition: [0] doubtful candidates of the (x,theta) stage, [2] the optimal candidates for the region stage
             int32_t cntB[PART_CLASSES] = {0, 0, 0, 0};
+            if (region_launched) HIP_TRY(h, hipStreamWaitEvent(st, h->ev_rjoin, 0));   // the region kernel rewrites statuses
             { int rcs = partition({{ST_RETRY, 0}, {ST_OPT_PENDING, 2}}, cntB); if (rcs) return rcs; }
             n_retry = cntB[0];
             if (n_retry > 0) {
@@ -1247,8 +1383,25 @@ static int level_run_impl(mpc_handle *h, int32_t gen_children, int32_t flags, mp
                 HIP_TRY(h, hipGetLastError());
                 { int rcs = partition({{ST_OPT_PENDING, 2}}, cntB); if (rcs) return rcs; }   // they may have turned out optimal
             }
-            n_opt_fast = cntB[2];
-            h->opt_ptr = part_list(2);   // stays valid until the next level's partition (the region fetch reads it before that)
+            if (region_launched) {
+                n_late = cntB[2];
+                const int32_t *late = part_list(2);
+                if (n_late > region_extra) {
+                    hipLaunchKernelGGL(k_set_status, dim3((unsigned)((n_late - region_extra + 255) / 256)), dim3(256), 0, st, late, region_extra, n_late, ST_FEASIBLE, stp);
+                    n_late = region_extra;
+                }
+                if (n_late > 0) {
+                    const int32_t n_a = (int32_t)h->n_opt;
+                    HIP_TRY(h, hipMemcpyAsync(h->opt_list.as<int32_t>() + n_a, late, (size_t)n_late * sizeof(int32_t), hipMemcpyDeviceToDevice, st));
+                    hipLaunchKernelGGL(k_init_slots, dim3((unsigned)((n_late + 255) / 256)), dim3(256), 0, st, region_out_hi, h->fi, n_a, n_late, ST_RETRY, late);
+                    HIP_TRY(h, hipGetLastError());
+                    h->n_opt = n_a + n_late;
+                }
+                n_opt_fast = (int32_t)h->n_opt;
+            } else {
+                n_opt_fast = cntB[2];
+                h->opt_ptr = part_list(2);   // stays valid until the next level's partition (the region fetch reads it before that)
+            }
         } else {
             hipLaunchKernelGGL(k_verdict, dim3((unsigned)std::min<long long>(n, h->grid_v)), dim3(64), h->lds_v, st, h->Pv,
                                h->frontier.as<int32_t>(), n, k, h->status.as<uint8_t>(), ctr, (const int32_t *)nullptr);
@@ -1267,80 +1420,20 @@ static int level_run_impl(mpc_handle *h, int32_t gen_children, int32_t flags, mp
             n_opt = h->tot_host[0];
         }
         h->n_opt = n_opt;
-        h->used_region2 = false; h->n_rretry = 0; h->n_erows = 0;
-        h->fd = h->n_x * h->n_t + h->n_x + k * h->n_t + k;
-        h->fi = 8 + k + h->n_tc + k + 2 * (h->n_c - k);
         if (n_opt > 0 && h->fast && h->fast_r >= 0 && !h->force_v1) {
-            const int rows_t_ = h->n_c - h->n_eq + h->n_tc;
-            HIP_TRY(h, h->headd.ensure((size_t)n_opt * h->fd * sizeof(double), st));
-            HIP_TRY(h, h->headi.ensure((size_t)n_opt * h->fi * sizeof(int32_t), st));
-            HIP_TRY(h, h->epool.ensure((size_t)n_opt * rows_t_ * (h->n_t + 1) * sizeof(double), st));
-            // few optimal candidates: several wavefronts per candidate (the facet tests are split among them)
-            const int W = h->no_rsplit ? 1 : ((long long)n_opt * 4 <= h->grid_r2 ? 4 : ((long long)n_opt * 2 <= h->grid_r2 ? 2 : 1));
-            const int ldk = (rows_t_ + 1 + 63) & ~63;
-            if (W > 1) {
-                HIP_TRY(h, h->kept_g.ensure((size_t)n_opt * ldk, st));
-                HIP_TRY(h, h->done_g.ensure((size_t)n_opt * 2 * sizeof(unsigned int), st));
-                HIP_TRY(h, hipMemsetAsync(h->done_g.p, 0, (size_t)n_opt * 2 * sizeof(unsigned int), st));
-            }
-            const dim3 g((unsigned)std::min<long long>((long long)n_opt * W, h->grid_r2)), b(64);
-            const DevProblem *pr = h->pr2_dev.as<DevProblem>();
-            // where the records go: device buffers (fetched / gathered later), or -- streaming -- page-locked host blocks the
-            // kernel writes directly, in chunks the host consumes while the kernel is still running
-            double *out_hd = h->headd.as<double>(), *out_er = h->epool.as<double>();
-            int32_t *out_hi = h->headi.as<int32_t>();
-            RegionStream rs{};
-            const size_t bytes_hd = (size_t)n_opt * h->fd * sizeof(double), bytes_hi = (size_t)n_opt * h->fi * sizeof(int32_t),
-                         bytes_er = (size_t)n_opt * rows_t_ * (h->n_t + 1) * sizeof(double);
-            if ((flags & MPC_LEVEL_STREAM) && bytes_hd + bytes_hi + bytes_er <= (size_t(1) << 30)) {
-                auto &so = h->so;
-                so.shift = 8;
-                while (so.shift > 4 && ((long long)n_opt >> so.shift) < 8) --so.shift;   // at least ~8 chunks, 16..256 slots each
-                so.n_chunks = (int)(((long long)n_opt + (1ll << so.shift) - 1) >> so.shift);
-                so.n_slots = n_opt; so.cap_rows = (long long)n_opt * rows_t_;
-                HIP_TRY(h, host_pool_take(bytes_hd, &so.hd, nullptr));
-                HIP_TRY(h, host_pool_take(bytes_hi, &so.hi, nullptr));
-                HIP_TRY(h, host_pool_take(std::max<size_t>(bytes_er, 8), &so.er, nullptr));
-                HIP_TRY(h, h->st_flags.ensure((size_t)so.n_chunks * sizeof(int32_t)));
-                std::memset(h->st_flags.p, 0, (size_t)so.n_chunks * sizeof(int32_t));
-                h->cw_chunks = so.n_chunks;
-                HIP_TRY(h, h->chunk_count.ensure((size_t)so.n_chunks * sizeof(unsigned int), st));
-                HIP_TRY(h, hipMemsetAsync(h->chunk_count.p, 0, (size_t)so.n_chunks * sizeof(unsigned int), st));
-                void *d_hd = nullptr, *d_hi = nullptr, *d_er = nullptr, *d_fl = nullptr;
-                HIP_TRY(h, hipHostGetDevicePointer(&d_hd, so.hd, 0));
-                HIP_TRY(h, hipHostGetDevicePointer(&d_hi, so.hi, 0));
-                HIP_TRY(h, hipHostGetDevicePointer(&d_er, so.er, 0));
-                HIP_TRY(h, hipHostGetDevicePointer(&d_fl, h->st_flags.p, 0));
-                out_hd = static_cast<double *>(d_hd); out_hi = static_cast<int32_t *>(d_hi); out_er = static_cast<double *>(d_er);
-                rs.count = h->chunk_count.as<unsigned int>(); rs.flags = static_cast<int32_t *>(d_fl); rs.shift = so.shift; rs.n_slots = n_opt;
-                so.active = true;
-            }
-#define MPC_LAUNCH_R2(NT_, SL_) hipLaunchKernelGGL((k_region2<NT_, SL_>), g, b, h->lds_r2, st, pr, h->frontier.as<int32_t>(), k, h->opt_ptr, n_opt, \
-                                                   h->status.as<uint8_t>(), out_hd, out_hi, h->fd, h->fi, out_er, ctr, kkc, kkl, \
-                                                   W, h->kept_g.as<uint8_t>(), ldk, h->done_g.as<unsigned int>(), \
-                                                   h->no_rbox ? (const double *)nullptr : h->targs.tvp + (size_t)NT_ * NT_ + NT_, rs)
-            HIP_TRY(h, hipEventRecord(h->kev[4], st));
-            switch (h->fast_r) {
-                case 0: MPC_LAUNCH_R2(4, 1); break;
-                case 1: MPC_LAUNCH_R2(4, 2); break;
-                case 2: MPC_LAUNCH_R2(8, 1); break;
-                case 3: MPC_LAUNCH_R2(8, 2); break;
-                case 4: MPC_LAUNCH_R2(10, 1); break;
-                default: MPC_LAUNCH_R2(10, 2); break;
-            }
-#undef MPC_LAUNCH_R2
-            HIP_TRY(h, hipEventRecord(h->kev[5], st));
-            kernel_timed[2] = true;
-            HIP_TRY(h, hipGetLastError());
-            h->used_region2 = true;
-            stream_ready(h);   // the caller of mpc_level_stream_info may start consuming chunks
+            if (!region_launched) { int rcs = region2_launch(n_opt, 0, st, false); if (rcs) return rcs; }
             // candidates k_region2 gave up on (counted by the kernel; normally none): the LDS-engine kernel, fixed-stride records
             hipLaunchKernelGGL(k_publish_words, dim3(1), dim3(64), 0, st, &ctr->n_rretry, reinterpret_cast<unsigned int *>(h->tot_dev + 8), 1);
             HIP_TRY(h, hipGetLastError());
             HIP_TRY(h, hipStreamSynchronize(st));
             const unsigned int n_rr_dev = (unsigned int)h->tot_host[8];
             int32_t n_rr = 0;
-            if (n_rr_dev > 0) { int rcs = compact(ST_RETRY, ST_RETRY, &n_rr); if (rcs) return rcs; }
+            if (n_rr_dev > 0) { int rcs = compact(ST_RRETRY, ST_RRETRY, &n_rr); if (rcs) return rcs; }
+            if (n_late > 0) {   // the late optimal candidates follow, in the order of their slots
+                HIP_TRY(h, h->retry_list.ensure(nn * sizeof(int32_t), st));
+                HIP_TRY(h, hipMemcpyAsync(h->retry_list.as<int32_t>() + n_rr, h->opt_list.as<int32_t>() + (n_opt - n_late), (size_t)n_late * sizeof(int32_t), hipMemcpyDeviceToDevice, st));
+                n_rr += n_late;
+            }
             h->n_rretry = n_rr;
             if (n_rr > 0) {   // numerically doubtful regions: the LDS-engine kernel, fixed-stride records
                 int rcs = launch_region_v1(h, h->retry_list.as<int32_t>(), n_rr, k, ctr);
@@ -1393,6 +1486,8 @@ static int level_run_impl(mpc_handle *h, int32_t gen_children, int32_t flags, mp
         HIP_TRY(h, hipEventElapsedTime(&ms[1], h->ev[1], h->ev[2]));
         HIP_TRY(h, hipEventElapsedTime(&ms[2], h->ev[2], h->ev[3]));
         for (int i = 0; i < 3; ++i) if (kernel_timed[i]) HIP_TRY(h, hipEventElapsedTime(&kms[i], h->kev[2 * i], h->kev[2 * i + 1]));
+        if (kernel_timed[2] && host_ctr.r2_t1 > ~host_ctr.r2_not_t0 && h->wall_khz > 0)   // k_region2 times itself (see the kernel)
+            kms[2] = (float)((double)(host_ctr.r2_t1 - ~host_ctr.r2_not_t0) / (double)h->wall_khz);
         if (h->debug_cycles)
             std::fprintf(stderr, "[mpc] k=%d n=%lld cycles/cand: kkt %.0f theta %.0f (rows %.0f, stage2 %.0f) x %.0f region %.0f; pivots %.2f; box screen %.3f / %.3f; x quick %.3f; retries theta %u of %llu\n", k, n,
                          host_ctr.cycles[0] / (double)n, host_ctr.cycles[1] / (double)n, host_ctr.cycles[4] / (double)n, host_ctr.cycles[5] / (double)n,

@@ -42,7 +42,8 @@ def run_levels(eng, max_levels=None):
         st = eng.level_run(gen)
         cands, status = eng.frontier_get(), eng.level_status()
         rd, ri, idx = eng.level_regions()
-        assert numpy.array_equal(numpy.nonzero(status == 3)[0], idx)
+        # slot order: the candidates of the region launch in candidate order, then those found optimal by a re-solve
+        assert numpy.array_equal(numpy.nonzero(status == 3)[0], numpy.sort(idx))
         fixed = [unpack_region(rd[j], ri[j], eng.n_x, eng.n_t, eng.n_c, eng.n_tc) for j in range(len(rd))]
         # the compact form (what the driver uses) must describe the same regions as the fixed-stride records
         from ppopt_amd.region_batch import RegionBatch
@@ -217,7 +218,7 @@ def test_host_buffer_operator_equals_resident_pipeline():
     s2, rd, ri, idx, kids = eng.check_level(cands, _lib.sets_to_masks(pruned), True)
     assert numpy.array_equal(s2, status)
     assert numpy.array_equal(kids, g['L3_cands'])
-    assert len(rd) == int(st.n_regions) and numpy.array_equal(idx, numpy.nonzero(status == 3)[0])
+    assert len(rd) == int(st.n_regions) and numpy.array_equal(numpy.sort(idx), numpy.nonzero(status == 3)[0])
     eng.close()
 
 
@@ -654,6 +655,44 @@ def test_streamed_regions_equal_fetched_regions(name):
         assert r1.regular_set == r2.regular_set
         for fld in ('A', 'b', 'C', 'd', 'E', 'f'):
             assert numpy.array_equal(getattr(r1, fld), getattr(r2, fld)), fld
+
+
+@pytest.mark.parametrize('name', ['c4', 'c3', 'rand_6_3_12_s1', 'c5_control_allocation', 'quadtank_n3'])
+def test_region_stage_under_the_x_stage_returns_the_same_regions(name, monkeypatch):
+    """The region kernel of a level is launched as soon as the theta stage has named the optimal candidates and runs under the
+    level's (x,theta) stage (level_run_impl).  Candidates that turn out optimal only afterwards -- re-solved doubtful ones --
+    get spare slots and the LDS-engine kernel's record.  Three engines per program: the default, MPC_NO_ROVERLAP=1 (region
+    stage after the (x,theta) stage) and MPC_TEST_LATE=5 with MPC_ROVERLAP_MIN=0 (every level overlaps and leaves five optimal
+    candidates to the late path): identical sets of regions; the late path's records come from the other simplex engine, so
+    coefficients are compared to 1e-8, everything else exactly."""
+    import bench
+    from ppopt_amd import Solver
+    from ppopt_amd.mp_solvers import mpqp_hip_combinatorial
+    from test_host_logic import build_program
+
+    def solve():
+        with warnings.catch_warnings():
+            warnings.simplefilter('ignore')
+            if name in ('c4', 'c3'):
+                prog, ml = bench.build_program(name), bench.WORKLOADS[name][2]
+            else:
+                prog, ml = build_program(load_golden(name), Solver()), None
+        sol = mpqp_hip_combinatorial.solve(prog, max_levels=ml)
+        return {tuple(r.active_set): r for r in sol.critical_regions}, len(sol.critical_regions)
+
+    base, n_base = solve()
+    assert n_base == len(base) > 0
+    for env in ({'MPC_NO_ROVERLAP': '1'}, {'MPC_TEST_LATE': '5', 'MPC_ROVERLAP_MIN': '0'}):
+        with monkeypatch.context() as m:
+            for key, val in env.items():
+                m.setenv(key, val)
+            other, n_other = solve()
+        assert n_other == n_base and set(other) == set(base), env
+        for key, r1 in base.items():
+            r2 = other[key]
+            assert r1.omega_set == r2.omega_set and r1.lambda_set == r2.lambda_set and r1.regular_set == r2.regular_set, (env, key)
+            for fld in ('A', 'b', 'C', 'd', 'E', 'f'):
+                assert numpy.allclose(getattr(r1, fld), getattr(r2, fld), rtol=0, atol=COEF_TOL), (env, key, fld)
 
 
 def test_more_than_128_constraints(oracle):
