@@ -174,6 +174,11 @@ int mpc_level_status(mpc_handle *h, uint8_t *status_host);                      
  * feasible set and is not put on the pruned list.  Without the flag the parallel driver's rule applies (:57-59): such a set is
  * pruned together with its supersets, which can lose regions on degenerate programs. */
 #define MPC_LEVEL_KEEP_LOWDIM 16
+/* MPC_LEVEL_ONLY_BASE (mpc_level_start): the worker checks the base active set ONLY -- no level is run, the frontier is replaced by
+   the base set; result through mpc_base_result after mpc_level_wait.  For a second handle of the same program (`twin`): the
+   driver starts the check there when the solve reaches its first large level, and the check's chain of small kernels (0.45 ms
+   at config 4) runs under the large levels of the main handle instead of behind the last one. */
+#define MPC_LEVEL_ONLY_BASE 32
 #define MPC_STREAM_RETRY 7
 int mpc_level_start(mpc_handle *h, int32_t gen_children, int32_t flags);
 int mpc_level_stream_info(mpc_handle *h, double **head_d, int32_t **head_i, double **erows, int64_t *n_slots, int64_t *cap_rows,

@@ -15,7 +15,7 @@ LIB_PATH = os.environ.get('MPC_LIB_PATH') or os.path.join(_HERE, 'csrc', 'libmpc
 
 MPC_OK, MPC_ERR_INVALID, MPC_ERR_HIP, MPC_ERR_CAPACITY, MPC_ERR_STATE = range(5)
 MPC_LOCATE_OVERLAPPING, MPC_LOCATE_INCLUSIVE, MPC_LOCATE_WALK = 1, 2, 4   # flags of mpc_locator_query
-MPC_LEVEL_STREAM, MPC_LEVEL_GRAPH, MPC_LEVEL_THEN_BASE, MPC_LEVEL_KEEP_LOWDIM = 1, 4, 8, 16   # flags of mpc_level_start / mpc_level_run_ex
+MPC_LEVEL_STREAM, MPC_LEVEL_GRAPH, MPC_LEVEL_THEN_BASE, MPC_LEVEL_KEEP_LOWDIM, MPC_LEVEL_ONLY_BASE = 1, 4, 8, 16, 32   # flags of mpc_level_start / mpc_level_run_ex
 INFEASIBLE, FEASIBLE, OPTIMAL_NO_REGION, REGION, SINGULAR_KKT, LP_LIMIT = range(6)
 LP_OPTIMAL, LP_INFEASIBLE, LP_UNBOUNDED, LP_ITERLIMIT = range(4)
 MASK_WORDS = 2
@@ -233,6 +233,7 @@ class Engine:
         self.rec_d = int(L.mpc_region_doubles(self._h))
         self.rec_i = int(L.mpc_region_ints(self._h))
         self.device = int(device)
+        self._twin = None
 
     # -- plumbing ----------------------------------------------------------------------------------------------
     def _check(self, rc, what):
@@ -240,6 +241,9 @@ class Engine:
             raise MpcError(f'{what} failed ({rc}): {self._L.mpc_last_error(self._h).decode()}')
 
     def close(self):
+        if getattr(self, '_twin', None) is not None:
+            self._twin.close()
+            self._twin = None
         if self._h:
             self._L.mpc_destroy(self._h)
             self._h = ctypes.c_void_p()
@@ -316,10 +320,19 @@ class Engine:
         return st
 
     # -- the same level on the handle's worker thread, region records streamed to the host (include/mpcombi.h) ----------
-    def level_start(self, gen_children: bool, stream: bool = True, then_base: bool = False, keep_lowdim: bool = False):
+    def level_start(self, gen_children: bool, stream: bool = True, then_base: bool = False, keep_lowdim: bool = False,
+                    only_base: bool = False):
         self._check(self._L.mpc_level_start(self._h, int(bool(gen_children)),
                                             (MPC_LEVEL_STREAM if stream else 0) | (MPC_LEVEL_THEN_BASE if then_base else 0)
-                                            | (MPC_LEVEL_KEEP_LOWDIM if keep_lowdim else 0)), 'mpc_level_start')
+                                            | (MPC_LEVEL_KEEP_LOWDIM if keep_lowdim else 0)
+                                            | (MPC_LEVEL_ONLY_BASE if only_base else 0)), 'mpc_level_start')
+
+    def twin(self) -> 'Engine':
+        """A second handle of the same program on the same device (created on first use, ~0.5 ms): the solve loop runs the
+        base-set check there (``level_start(False, only_base=True)``) while this handle works on its large levels."""
+        if self._twin is None:
+            self._twin = Engine(self.A, self.b, self.F, self.c, self.H, self.Q, self.A_t, self.b_t, self.n_eq, device=self.device)
+        return self._twin
 
     def base_result(self):
         """(status, rec_d [1, rec_d] or empty, rec_i) of the base-set check the worker ran behind the last level

@@ -1548,13 +1548,14 @@ static void worker_main(mpc_handle *h) {
         }
         mpc_level_stats st;
         std::memset(&st, 0, sizeof(st));
-        const int rc = level_run_impl(h, gen, flags, &st);
+        const bool only_base = (flags & MPC_LEVEL_ONLY_BASE) != 0;
+        const int rc = only_base ? MPC_OK : level_run_impl(h, gen, flags, &st);
         h->base_valid = false;
         // only when the level's records were streamed AND the caller already owns the arrays (or the level has no region at all): a
         // level that did not stream (LDS-engine region kernel ...) is fetched by the caller after mpc_level_wait, from the very state
         // this check would replace
         const bool streamed_and_taken = h->so.active && h->so.taken;
-        if (rc == MPC_OK && (flags & MPC_LEVEL_THEN_BASE) && !gen && st.n_region_retry == 0 && (streamed_and_taken || st.n_regions == 0)) {
+        if (rc == MPC_OK && (only_base || ((flags & MPC_LEVEL_THEN_BASE) && !gen && st.n_region_retry == 0 && (streamed_and_taken || st.n_regions == 0)))) {
             // The base active set (the equality rows alone; driver :142-146) right behind the last level, while the caller
             // is still turning the streamed records into objects.  Any failure simply leaves the check to the caller.
             std::vector<int32_t> base((size_t)std::max(h->n_eq, 1));

@@ -71,6 +71,7 @@ REGION_STATUS = 3   # MPC_REGION
 # levels below this size are run synchronously and fetched afterwards: the hand-overs to the worker thread cost more than the
 # overlap gains there (sub-programs of the mixed-integer enumeration, the first levels of every solve)
 STREAM_MIN_CANDIDATES = 8192
+BASE_ON_TWIN = os.environ.get('MPC_NO_TWIN', '0') != '1'   # the base-set check on a second handle, started with the first streamed level
 
 
 def solve(program, num_cores: int = -1, device: int = 0, profile: Optional[List[Dict]] = None,
@@ -94,6 +95,7 @@ def solve(program, num_cores: int = -1, device: int = 0, profile: Optional[List[
     eng.pruned_clear()
     eng.frontier_root()
     base_behind_level = False
+    twin = None      # second handle of the program: the base-set check runs there, under this handle's large levels
     for depth in range(max_depth):
         gen_children = depth + 1 != max_depth
         t0 = time.perf_counter()
@@ -101,8 +103,14 @@ def solve(program, num_cores: int = -1, device: int = 0, profile: Optional[List[
             # The level runs on the handle's worker thread; its region kernel writes the records straight into page-locked
             # host arrays and raises a flag per chunk of slots, so the region objects of a chunk are built while the kernel
             # is still working on the later ones -- no fetch afterwards, nothing waits for Python.
-            eng.level_start(gen_children, stream=True, then_base=not gen_children, keep_lowdim=not prune_lowdim)
-            base_behind_level = not gen_children
+            if twin is None and BASE_ON_TWIN:
+                try:
+                    twin = eng.twin()
+                    twin.level_start(False, only_base=True)
+                except Exception:
+                    twin = None
+            eng.level_start(gen_children, stream=True, then_base=not gen_children and twin is None, keep_lowdim=not prune_lowdim)
+            base_behind_level = not gen_children and twin is None
             info = eng.level_stream_info()
             new_regions: List[CriticalRegion] = []
             batch = None
@@ -147,6 +155,9 @@ def solve(program, num_cores: int = -1, device: int = 0, profile: Optional[List[
     eng.sync()
     # the base active set (= the equality rows) is tested last, like the reference (driver :142-146)
     res = eng.base_result() if base_behind_level else None      # the worker may have checked it behind the last level
+    if twin is not None:
+        twin.level_wait()
+        res = twin.base_result()
     if res is None:
         base = numpy.arange(eng.n_eq, dtype=numpy.int32).reshape(1, -1)
         status, rd, ri, _, _ = eng.check_level(base, numpy.zeros((0, 2), dtype=numpy.uint64), False)
