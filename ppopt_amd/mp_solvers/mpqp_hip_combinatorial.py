@@ -70,7 +70,7 @@ def unpack_region(rec_d: numpy.ndarray, rec_i: numpy.ndarray, n_x: int, n_t: int
 REGION_STATUS = 3   # MPC_REGION
 # levels below this size are run synchronously and fetched afterwards: the hand-overs to the worker thread cost more than the
 # overlap gains there (sub-programs of the mixed-integer enumeration, the first levels of every solve)
-STREAM_MIN_CANDIDATES = 8192
+STREAM_MIN_CANDIDATES = int(os.environ.get('MPC_STREAM_MIN', '512'))
 BASE_ON_TWIN = os.environ.get('MPC_NO_TWIN', '0') != '1'   # the base-set check on a second handle, started with the first streamed level
 
 

@@ -695,6 +695,29 @@ def test_region_stage_under_the_x_stage_returns_the_same_regions(name, monkeypat
                 assert numpy.allclose(getattr(r1, fld), getattr(r2, fld), rtol=0, atol=COEF_TOL), (env, key, fld)
 
 
+def test_base_set_check_on_the_twin_handle(monkeypatch):
+    """The base active set (reference driver :142-146) is checked on a second handle of the program while the first one runs
+    its large levels (MPC_LEVEL_ONLY_BASE, Engine.twin): the same solution, the base set's region last, as with the check
+    behind the last level on the one handle."""
+    import bench
+    from ppopt_amd.mp_solvers import mpqp_hip_combinatorial
+    sols = []
+    for on in (True, False):
+        monkeypatch.setattr(mpqp_hip_combinatorial, 'BASE_ON_TWIN', on)
+        with warnings.catch_warnings():
+            warnings.simplefilter('ignore')
+            prog = bench.build_program('c4')
+        sols.append(mpqp_hip_combinatorial.solve(prog, max_levels=bench.WORKLOADS['c4'][2]))
+        assert (prog.engine()._twin is not None) == on
+    a, b_ = sols
+    assert len(a.critical_regions) == len(b_.critical_regions) == 9432
+    assert a.critical_regions[-1].active_set == b_.critical_regions[-1].active_set == []
+    for r1, r2 in zip(a.critical_regions, b_.critical_regions):
+        assert r1.active_set == r2.active_set and r1.regular_set == r2.regular_set
+        for fld in ('A', 'b', 'C', 'd', 'E', 'f'):
+            assert numpy.array_equal(getattr(r1, fld), getattr(r2, fld)), fld
+
+
 def test_more_than_128_constraints(oracle):
     """n_c = 140 (> 128): active sets and pruned sets are four-word masks (mpc_mask_words == 4) and the program runs on the
     LDS-engine kernels (more rows than the register engine holds).  140 planes tangent to a sphere, none redundant.
