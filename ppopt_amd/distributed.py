@@ -48,6 +48,7 @@ class HipLevelEngine:
         e = self.eng
         self.n_x, self.n_t, self.n_c, self.n_tc, self.n_eq = e.n_x, e.n_t, e.n_c, e.n_tc, e.n_eq
         self._stats = None
+        self._base_twin = None
 
     def clear_pruned(self):
         self.eng.pruned_clear()
@@ -129,11 +130,30 @@ class HipLevelEngine:
             return tuple(torch.from_numpy(numpy.ascontiguousarray(a)).to(self.device) for a in (h_hd, h_hi, h_er))
         return hd[:got[0]], hi[:got[0]], er[:got[1]]
 
+    def base_start(self):
+        """Starts the check of the base active set on a second handle of the program (Engine.twin, MPC_LEVEL_ONLY_BASE): its
+        chain of small kernels runs under the large levels of the main handle; check_base() collects the result."""
+        if self._base_twin is None:
+            try:
+                twin = self.eng.twin()
+                twin.level_start(False, only_base=True)
+                self._base_twin = twin
+            except Exception:
+                self._base_twin = None
+
     def check_base(self):
         """The base active set (the equality rows alone): (status histogram, region pieces or None)."""
         from .mp_solvers.mpqp_hip_combinatorial import unpack_regions
-        base = numpy.arange(self.n_eq, dtype=numpy.int32).reshape(1, -1)
-        status, rd, ri, _, _ = self.eng.check_level(base, numpy.zeros((0, 2), dtype=numpy.uint64), False)
+        res = None
+        if self._base_twin is not None:
+            twin, self._base_twin = self._base_twin, None
+            twin.level_wait()
+            res = twin.base_result()
+        if res is not None:
+            status, rd, ri = res
+        else:
+            base = numpy.arange(self.n_eq, dtype=numpy.int32).reshape(1, -1)
+            status, rd, ri, _, _ = self.eng.check_level(base, numpy.zeros((0, 2), dtype=numpy.uint64), False)
         regs = unpack_regions(rd, ri, self.n_x, self.n_t, self.n_c, self.n_tc) if len(rd) else []
         return numpy.bincount(status, minlength=6).tolist(), regs
 
@@ -241,6 +261,8 @@ def solve_distributed(engine, program=None, group=None, profile: Optional[List[D
         if not sharded and (world > 1 or force_shard) and n >= shard_min * world:   # force_shard: self-test with one rank
             engine.shard(rank, world)
             sharded = True
+            if hasattr(engine, 'base_start'):
+                engine.base_start()      # the base-set check runs beside the sharded levels (second handle)
         if pending is not None and hasattr(engine, 'run_start'):
             # the previous sharded level's regions (gathered on RCCL's stream meanwhile) come to the host and become objects
             # while this level runs on the device
