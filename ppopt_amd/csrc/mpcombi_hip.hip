@@ -1377,10 +1377,23 @@ static int level_run_impl(mpc_handle *h, int32_t gen_children, int32_t flags, mp
             if (region_launched) HIP_TRY(h, hipStreamWaitEvent(st, h->ev_rjoin, 0));   // the region kernel rewrites statuses
             { int rcs = partition({{ST_RETRY, 0}, {ST_OPT_PENDING, 2}}, cntB); if (rcs) return rcs; }
             n_retry = cntB[0];
+            if (n_retry > 0 && !region_launched && !h->no_roverlap && cntB[2] > 0 && h->fast_r >= 0 && !(flags & MPC_LEVEL_GRAPH)) {
+                // the region stage was not started under the (x,theta) stage (grouped quick test, short stage): it runs beside the
+                // re-solve of the doubtful candidates instead -- two small, latency-bound kernels; what the re-solve finds optimal
+                // takes the spare slots (config 3's last level: 235 re-solved candidates, 0.4 ms)
+                region_extra = n_retry;
+                HIP_TRY(h, hipMemcpyAsync(h->opt_list.p, part_list(2), (size_t)cntB[2] * sizeof(int32_t), hipMemcpyDeviceToDevice, st));
+                h->opt_ptr = h->opt_list.as<int32_t>();
+                h->n_opt = cntB[2];
+                int rcs = region2_launch(cntB[2], region_extra, h->stream3, false);
+                if (rcs) return rcs;
+                region_launched = true;
+            }
             if (n_retry > 0) {
                 hipLaunchKernelGGL(k_verdict, dim3((unsigned)std::min<long long>(n_retry, h->grid_v)), dim3(64), h->lds_v, st, h->Pv,
                                    h->frontier.as<int32_t>(), (long long)n_retry, k, h->status.as<uint8_t>(), ctr, part_list(0));
                 HIP_TRY(h, hipGetLastError());
+                if (region_launched) HIP_TRY(h, hipStreamWaitEvent(st, h->ev_rjoin, 0));
                 { int rcs = partition({{ST_OPT_PENDING, 2}}, cntB); if (rcs) return rcs; }   // they may have turned out optimal
             }
             if (region_launched) {
