@@ -5,7 +5,8 @@ the facets of the regions found in the previous round), solver_utils.py:204-325 
 Every region hands on its facets; for each facet the algorithm steps from the facet's Chebyshev centre across the facet
 (distance radius * 1e-6 * 2^j, j = 1, 2, ... while it stays below the radius), solves the QP at that parameter point and
 takes the optimiser's active set as the neighbour's; it needs no assumption on how neighbouring active sets differ, which is
-what makes it the robust choice for degenerate programs (the graph traversals only move by one row).
+what makes it the robust choice for degenerate programs (the graph traversals only move by one row).  For an mpLP the program at a
+parameter point is an LP (MPLP_Program.solve_theta, mplp_program.py:324-352) and the probes are a batch of the device LP plug.
 
 Here the three kinds of work of a round are three device batches:
 
@@ -68,17 +69,58 @@ def _sub_active_set(program, active: List[int]) -> List[int]:
 def solve(program, active_set: Optional[List[int]] = None, num_cores: int = -1, device: Optional[int] = None,
           profile: Optional[List[Dict]] = None, max_regions: Optional[int] = None) -> Solution:
     """mpqp_algorithm.geometric / geometric_parallel / geometric_parallel_exp.  ``profile`` receives one dict per round."""
+    from ..mplp_program import MPLP_Program
     from ..mpqp_program import MPQP_Program
-    if not isinstance(program, MPQP_Program):
-        raise NotImplementedError('the geometric algorithm is implemented for mpQPs (it needs the QP at a parameter point)')
-    ev = numpy.linalg.eigvalsh(0.5 * (program.Q + program.Q.T))
-    if not ev.min() > 1e-10 * max(ev.max(), 1.0):
-        raise NotImplementedError('the geometric algorithm needs a positive definite Q (the probes are QPs solved on the device)')
+    from .. import _lib
+    is_qp = isinstance(program, MPQP_Program)
+    if not is_qp and not isinstance(program, MPLP_Program):
+        raise NotImplementedError('the geometric algorithm needs the LP / QP of the program at a parameter point')
+    if is_qp:
+        ev = numpy.linalg.eigvalsh(0.5 * (program.Q + program.Q.T))
+        if not ev.min() > 1e-10 * max(ev.max(), 1.0):
+            raise NotImplementedError('the geometric algorithm needs a positive definite Q (the probes are QPs solved on the device)')
     eng = program.engine(device)
     dev = eng.device
     n_x, n_t, n_c, n_tc, n_eq, words = eng.n_x, eng.n_t, eng.n_c, eng.n_tc, eng.n_eq, eng.mask_words
     solution = Solution(program, [])
-    seeds = [list(active_set)] if active_set is not None else _g._seed_active_sets(program, eng)
+    eq_flags_row = numpy.zeros(n_c, dtype=numpy.uint8)
+    eq_flags_row[list(program.equality_indices)] = 1
+
+    def probe(pts: numpy.ndarray):
+        """The program at the parameter points: (solved [m] bool, active [m, n_c] bool).  mpQP: the QP as a complementarity
+        problem (mpc_qp_solve_batch); mpLP: the LP min (c + H theta)'x s.t. A x <= b + F theta as one batch of the LP plug
+        (MPLP_Program.solve_theta, mplp_program.py:324-352), active = rows tight at the optimiser."""
+        if is_qp:
+            status, _, _, act = eng.qp_solve_batch(pts)
+            return status == 0, act
+        b = program.b.reshape(1, -1) + pts @ program.F.T
+        c = program.c.reshape(1, -1) + pts @ program.H.T
+        status, x, _, _ = _lib.lp_solve_batch(program.A, b, c, numpy.tile(eq_flags_row, (len(pts), 1)), device=dev)
+        slack = b - x @ program.A.T
+        return status == _lib.LP_OPTIMAL, numpy.abs(slack) <= 1e-9 * (1.0 + numpy.abs(b))
+
+    if active_set is not None:
+        seeds = [list(active_set)]
+    elif is_qp:
+        seeds = _g._seed_active_sets(program, eng)
+    else:
+        # an mpLP has regions only at n_x active rows: the first levels of the combinatorial algorithm would be the whole
+        # enumeration.  The optimiser's active set at parameter points around the Chebyshev centre of the parameter set instead
+        # (mplp_program.py:588-618, gen_optimal_active_set).
+        seeds = []
+        ball = program.solver.solve_lp(numpy.vstack([numpy.zeros((n_t, 1)), [[-1.0]]]),
+                                       numpy.hstack([program.A_t, numpy.linalg.norm(program.A_t, axis=1, keepdims=True)]), program.b_t, []) if n_tc else None
+        th0 = ball.sol[:n_t].reshape(1, -1) if ball is not None else numpy.zeros((1, n_t))
+        r0 = min(float(ball.sol[-1]), 1.0) if ball is not None else 1.0
+        rng0 = numpy.random.default_rng(0)
+        pts0 = numpy.vstack([th0, th0 + rng0.uniform(-0.5 * r0, 0.5 * r0, (63, n_t))])
+        solved, act = probe(pts0)
+        for j in numpy.flatnonzero(solved):
+            a = numpy.flatnonzero(act[j]).tolist()
+            if len(a) > n_x:
+                a = _sub_active_set(program, a)
+            if len(a) == n_x and a not in seeds:
+                seeds.append(a)
     if not seeds:
         return solution
     book = _g._SetBook(words)
@@ -136,11 +178,11 @@ def solve(program, active_set: Optional[List[int]] = None, num_cores: int = -1, 
             if not len(facet):
                 break
             pts = centre[facet] + normal[facet] * dist[:, None]
-            status, _, _, act = eng.qp_solve_batch(pts)
+            solved, act = probe(pts)
             n_qp += len(pts)
-            # infeasible QP or a point outside A_t theta <= b_t (solve_theta returns None): looking outside the feasible space,
-            # the facet is done
-            feasible = (status == 0) & numpy.all(pts @ program.A_t.T <= program.b_t.reshape(1, -1), axis=1)
+            # infeasible program or a point outside A_t theta <= b_t (solve_theta returns None): looking outside the feasible
+            # space, the facet is done
+            feasible = solved & numpy.all(pts @ program.A_t.T <= program.b_t.reshape(1, -1), axis=1)
             facet, act = facet[feasible], act[feasible]
             if not len(facet):
                 break

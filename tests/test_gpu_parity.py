@@ -932,10 +932,11 @@ def test_qp_at_parameter_points_matches_the_explicit_solution(name):
 
 
 @pytest.mark.parametrize('name', ['transport_mpqp', 'dblint_n3', 'c2_dblint_n5', 'rand_4_2_10_s0', 'rand_5_3_8_s3', 'rand_6_3_12_s1',
-                                  'quadtank_n2', 'quadtank_n3'])
+                                  'quadtank_n2', 'quadtank_n3', 'c1_transport_mplp', 'mplp_rand_4_2_10_s0', 'mplp_rand_5_3_12_s2'])
 def test_geometric_algorithm_finds_the_same_regions(name):
     """mpqp_algorithm.geometric (reference: mpqp_geometric.py / mpqp_parallel_geometric.py; facet centres as a device LP batch,
-    probe QPs as a device batch, regions through the level kernels): the region set of the complete combinatorial golden."""
+    probe QPs -- for an mpLP, probe LPs -- as a device batch, regions through the level kernels): the region set of the complete
+    combinatorial golden."""
     from ppopt_amd import Solver
     from ppopt_amd.mp_solvers import mpqp_hip_geometric
     from ppopt_amd.mp_solvers.solve_mpqp import mpqp_algorithm, solve_mpqp
