@@ -171,6 +171,7 @@ def solve(program, active_set: Optional[List[int]] = None, num_cores: int = -1, 
         new_masks_all = []
         n_qp = 0
         step = 1
+        A_tT, b_t_row = numpy.ascontiguousarray(program.A_t.T), program.b_t.reshape(1, -1)
         while len(facet) and step <= 21:
             dist = radius[facet] * 1e-6 * (2.0 ** step)          # fathem_facet: dist starts at radius * 1e-6 and doubles before use
             alive = dist / 2.0 < radius[facet]                    # "while dist < radius" is tested before the doubling
@@ -182,36 +183,44 @@ def solve(program, active_set: Optional[List[int]] = None, num_cores: int = -1, 
             n_qp += len(pts)
             # infeasible program or a point outside A_t theta <= b_t (solve_theta returns None): looking outside the feasible
             # space, the facet is done
-            feasible = solved & numpy.all(pts @ program.A_t.T <= program.b_t.reshape(1, -1), axis=1)
-            facet, act = facet[feasible], act[feasible]
+            feasible = solved & ((pts @ A_tT - b_t_row).max(axis=1) <= 0.0) if n_tc else solved.copy()
+            # active sets as masks right away (the [probes, n_c] flag array is never indexed or copied again)
+            bits = numpy.packbits(act, axis=1, bitorder='little')
+            pad = numpy.zeros((len(bits), words * 8), dtype=numpy.uint8)
+            pad[:, :bits.shape[1]] = bits
+            pm = pad.view(numpy.uint64)[feasible]
+            facet = facet[feasible]
             if not len(facet):
                 break
-            too_many = act.sum(axis=1) > n_x
+            too_many = numpy.bitwise_count(pm).sum(axis=1) > n_x
             for j in numpy.flatnonzero(too_many):                 # overdetermined active set: a full-rank subset (rare)
-                sub = _sub_active_set(program, numpy.flatnonzero(act[j]).tolist())
-                act[j] = False
-                act[j, sub] = True
-            pm = numpy.zeros((len(facet), words), dtype=numpy.uint64)
-            bits = numpy.packbits(act, axis=1, bitorder='little')
-            pad = numpy.zeros((len(facet), words * 8), dtype=numpy.uint8)
-            pad[:, :bits.shape[1]] = bits
-            pm[:] = pad.view(numpy.uint64)
+                full = numpy.flatnonzero(numpy.unpackbits(pm[j].view(numpy.uint8), bitorder='little')[:n_c]).tolist()
+                pm[j] = _g._sets_to_masks([_sub_active_set(program, full)], words)[0]
             own = (pm == region_masks[owner[facet]]).all(axis=1)  # accidental self inclusion: step further
-            known = ~own & _g_known(book, pm)                     # a region (or set) already indexed: the facet is done
-            cand = ~own & ~known
+            # The probes of a round hit few distinct active sets (config 4: ~2e5 probes, ~2e4 sets): the book is asked, and the
+            # level kernels are run, once per distinct set.  Sets are told apart by a 64-bit key (the mask itself when one word
+            # holds it, the book's hash otherwise -- every key class is confirmed on the full masks, a collision falls back to
+            # exact structured keys).
+            one_word = words == 1 or not pm[:, 1:].any()
+            key = pm[:, 0] if one_word else book._hash(pm)
+            uk, first, inv = numpy.unique(key, return_index=True, return_inverse=True)
+            um_all = pm[first]
+            if not one_word and not (um_all[inv] == pm).all():
+                uq, inv = numpy.unique(_structured(pm, words), return_inverse=True)
+                um_all = uq.view(numpy.uint64).reshape(-1, words)
+            known_u = _g_known(book, um_all)                      # a region (or set) already indexed: the facet is done
             keep_open = own.copy()
-            if cand.any():
-                cm = pm[cand]
-                uniq, inv = numpy.unique(_structured(cm, words), return_inverse=True)
-                um = uniq.view(numpy.uint64).reshape(-1, words)
+            new_u = numpy.flatnonzero(~known_u)
+            if len(new_u):
+                um = um_all[new_u]
                 acc, nb = build_regions(um)                       # rank test + region kernel for the distinct new active sets
-                is_region = numpy.zeros(len(um), dtype=bool)
-                is_region[acc] = True
+                region_u = numpy.zeros(len(um_all), dtype=bool)
+                region_u[new_u[acc]] = True
                 if len(acc):
                     book.add(um[acc])
                     new_masks_all.extend(nb)
                 # a facet whose probe gave a set that is no full-dimensional region keeps stepping (fathem_facet :300-309)
-                keep_open[numpy.flatnonzero(cand)[~is_region[inv]]] = True
+                keep_open |= ~known_u[inv] & ~region_u[inv]
             facet = facet[keep_open]
             step += 1
         for B, slots in new_masks_all:
