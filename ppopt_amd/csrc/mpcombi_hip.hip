@@ -1266,8 +1266,8 @@ static int level_run_impl(mpc_handle *h, int32_t gen_children, int32_t flags, mp
             // re-solved doubtful ones): it starts now on its own stream and runs under the (x,theta) stage -- a few thousand
             // long wavefronts at two per SIMD whose tail the streaming kernels of the (x,theta) stage fill.
             int32_t region_extra = 0;
-            // x_items: what the (x,theta) stage has to do.  Below ROVERLAP_MIN_ITEMS there is nothing to hide the region stage
-            // under; from ROVERLAP_LONG_ITEMS on the stage outlasts the region kernel anyway, which then runs one wavefront per
+            // x_items: what the (x,theta) stage has to do.  Below roverlap_min items there is nothing to hide the region stage
+            // under; from roverlap_long items on the stage outlasts the region kernel anyway, which then runs one wavefront per
             // candidate (splitting a candidate over four wavefronts shortens its latency but takes registers from four SIMDs).
             const long long x_items = (long long)cntA[3] + (h->storing ? (long long)cntA[1] + cntA[2] : 0);
             // (the grouped quick test keeps four 128-register wavefronts per SIMD busy through LDS latency: one region wavefront on
@@ -1279,9 +1279,10 @@ static int level_run_impl(mpc_handle *h, int32_t gen_children, int32_t flags, mp
             if (!h->no_roverlap && cntA[2] > 0 && h->fast_r >= 0 && !(flags & MPC_LEVEL_GRAPH) && x_items >= h->roverlap_min && !use_grouped) {
                 // Candidates that turn out optimal later -- re-solved doubtful ones: the n_early of the theta stage, rarely one of
                 // the (x,theta) stage -- get spare slots behind the launch's and take the LDS-engine route of the candidates
-                // k_region2 gives up on.  More than 64 late ones from the (x,theta) stage (candidates whose theta stage found no
-                // feasible parameter and whose re-solve, in other arithmetic, calls them optimal) would keep the theta stage's
-                // answer: feasible, not optimal.
+                // k_region2 gives up on.  The spare slots cover every re-solved candidate of the theta stage plus 64 of the
+                // (x,theta) stage (candidates whose theta stage found no feasible parameter and whose re-solve, in other arithmetic,
+                // calls them optimal: none has been seen); late candidates beyond the spare slots -- the highest candidate indices --
+                // would keep the theta stage's answer, feasible and not optimal.
                 const int32_t hold = std::min<int32_t>(std::max(h->test_late, 0), cntA[2] - 1);
                 const int32_t n_launch = cntA[2] - hold;
                 region_extra = n_early + hold + (cntA[3] > 0 ? 64 : 0);
