@@ -33,6 +33,16 @@ def test_struct_layout_matches_header():
     assert ctypes.sizeof(_lib.LevelStats) == 8 + 4 + 4 + 6 * 8 + 4 * 8 + 4 * 4 + 8 + 8 + 4 * 8 + 8 + 8 + 4 * 4 + 6 * 8
 
 
+def test_flag_constants_match_the_header():
+    """The level flags and locator flags of the ctypes binding are the header's #defines."""
+    text = open(os.path.join(ROOT, 'include', 'mpcombi.h')).read()
+    defs = {k: int(v, 0) for k, v in re.findall(r'^#define\s+(MPC_[A-Z_0-9]+)\s+(-?(?:0x[0-9a-fA-F]+|\d+))\s*$', text, flags=re.M)}
+    for name in ('MPC_LEVEL_STREAM', 'MPC_LEVEL_GRAPH', 'MPC_LEVEL_THEN_BASE', 'MPC_LEVEL_KEEP_LOWDIM', 'MPC_LEVEL_ONLY_BASE'):
+        assert name in defs and getattr(_lib, name) == defs[name], name
+    flags = [defs[n] for n in defs if n.startswith('MPC_LEVEL_')]
+    assert len(set(flags)) == len(flags) and all(f & (f - 1) == 0 for f in flags)      # distinct single bits
+
+
 def test_no_cpu_fallback_without_gpu():
     """mpc_create and the LP plug must fail loudly when no HIP device exists (this container has none)."""
     L = _lib.load()

@@ -695,6 +695,38 @@ def test_region_stage_under_the_x_stage_returns_the_same_regions(name, monkeypat
                 assert numpy.allclose(getattr(r1, fld), getattr(r2, fld), rtol=0, atol=COEF_TOL), (env, key, fld)
 
 
+def test_region_stage_modes_agree_on_random_programs(monkeypatch):
+    """tools/overlap_fuzz.py in small: random mpQPs solved with the default region stage, with it after the (x,theta) stage, and
+    with every level overlapped and all optimal candidates but one sent through the late path (spare slots, LDS-engine record):
+    the same sets of active sets and the same laws.  (Facet lists may differ in rows that are redundant within the LP tolerance;
+    the tool classifies those, this test does not look at them.)"""
+    from ppopt_amd.problem_generator import generate_mpqp
+    from ppopt_amd.mp_solvers import mpqp_hip_combinatorial
+    rng = numpy.random.default_rng(11)
+    n_regions = 0
+    for _ in range(10):
+        nx, nt = int(rng.integers(3, 8)), int(rng.integers(2, 5))
+        m, seed = int(rng.integers(nx + 2, 3 * nx)), int(rng.integers(0, 10 ** 6))
+        sols = []
+        for env in ({}, {'MPC_NO_ROVERLAP': '1'}, {'MPC_TEST_LATE': '1000000', 'MPC_ROVERLAP_MIN': '0'}):
+            with monkeypatch.context() as mp_:
+                for key, val in env.items():
+                    mp_.setenv(key, val)
+                with warnings.catch_warnings():
+                    warnings.simplefilter('ignore')
+                    prog = generate_mpqp(nx, nt, m, seed)
+                sols.append({tuple(r.active_set): r for r in mpqp_hip_combinatorial.solve(prog).critical_regions})
+                prog.release_engine()
+        base = sols[0]
+        n_regions += len(base)
+        for other in sols[1:]:
+            assert set(other) == set(base), (nx, nt, m, seed)
+            for key, r1 in base.items():
+                for fld in ('A', 'b', 'C', 'd'):
+                    assert numpy.allclose(getattr(r1, fld), getattr(other[key], fld), rtol=0, atol=COEF_TOL), (nx, nt, m, seed, key, fld)
+    assert n_regions > 500
+
+
 def test_base_set_check_on_the_twin_handle(monkeypatch):
     """The base active set (reference driver :142-146) is checked on a second handle of the program while the first one runs
     its large levels (MPC_LEVEL_ONLY_BASE, Engine.twin): the same solution, the base set's region last, as with the check
