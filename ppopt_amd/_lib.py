@@ -310,12 +310,14 @@ class Engine:
         return out
 
     # -- one level --------------------------------------------------------------------------------------------------
-    def level_run(self, gen_children: bool, graph: bool = False, keep_lowdim: bool = False) -> LevelStats:
+    def level_run(self, gen_children: bool, graph: bool = False, keep_lowdim: bool = False, stream: bool = False) -> LevelStats:
         """One level over the resident frontier.  ``graph``: the question of the connected-graph traversal (MPC_LEVEL_GRAPH);
-        ``keep_lowdim``: the serial driver's expansion rule (MPC_LEVEL_KEEP_LOWDIM)."""
+        ``keep_lowdim``: the serial driver's expansion rule (MPC_LEVEL_KEEP_LOWDIM); ``stream``: the region records are
+        written into page-locked host arrays, complete on return, handed over by ``level_stream_info()``."""
         st = LevelStats()
         self._check(self._L.mpc_level_run_ex(self._h, int(bool(gen_children)), (MPC_LEVEL_GRAPH if graph else 0)
-                                             | (MPC_LEVEL_KEEP_LOWDIM if keep_lowdim else 0), ctypes.byref(st)), 'mpc_level_run')
+                                             | (MPC_LEVEL_KEEP_LOWDIM if keep_lowdim else 0) | (MPC_LEVEL_STREAM if stream else 0),
+                                             ctypes.byref(st)), 'mpc_level_run')
         self._last = st
         return st
 

@@ -1547,7 +1547,10 @@ int mpc_level_run_ex(mpc_handle *h, int32_t gen_children, int32_t flags, mpc_lev
     if (!h) return MPC_ERR_INVALID;
     if ((flags & MPC_LEVEL_GRAPH) && gen_children) return fail(h, MPC_ERR_INVALID, "MPC_LEVEL_GRAPH has no children");
     { std::lock_guard<std::mutex> lk(h->wm); if (h->w_busy) return fail(h, MPC_ERR_STATE, "a level started with mpc_level_start is still running"); }
-    return level_run_impl(h, gen_children, flags & ~(MPC_LEVEL_STREAM | MPC_LEVEL_THEN_BASE), stats);
+    // MPC_LEVEL_STREAM is honoured here too: the region kernel then writes its records into page-locked host memory and
+    // mpc_level_stream_info hands the (complete) arrays over after this call -- no device-to-host fetch for small levels
+    { std::lock_guard<std::mutex> lk(h->wm); h->w_stream_ready = false; }
+    return level_run_impl(h, gen_children, flags & ~(MPC_LEVEL_THEN_BASE | MPC_LEVEL_ONLY_BASE), stats);
 }
 
 // ---- the same level, driven by the handle's worker thread ---------------------------------------------------------------

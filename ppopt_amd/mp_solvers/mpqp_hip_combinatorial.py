@@ -133,12 +133,22 @@ def solve(program, num_cores: int = -1, device: int = 0, profile: Optional[List[
                 new_regions = batch.regions_of(numpy.flatnonzero(hi[:, 0] == REGION_STATUS).tolist())
             solution.critical_regions.extend(new_regions)
         else:
-            st = eng.level_run(gen_children, keep_lowdim=not prune_lowdim)
+            # small level, in this thread: the region kernel still writes its records straight into page-locked host arrays
+            # (complete when the call returns), so nothing is fetched afterwards
+            st = eng.level_run(gen_children, keep_lowdim=not prune_lowdim, stream=bool(collect_regions and stream))
             if collect_regions and st.n_regions:
-                # the integer heads are waited for (the region objects are built from them); the two large arrays keep
-                # arriving by DMA while Python builds the objects -- eng.sync() below completes them
-                hd, hi, er, kk, slots = eng.level_regions_slots(early_return=True)
-                solution.critical_regions.extend(RegionBatch(hd, hi, er, n_x, n_t, n_c, n_tc, kk, slots).regions())
+                info = eng.level_stream_info() if stream else None
+                if info is not None:
+                    hd, hi, er, _, _ = info
+                    if st.n_region_retry:
+                        eng.level_stream_fixup(hd, hi, er)
+                    batch = RegionBatch(hd, hi, er, n_x, n_t, n_c, n_tc, eng.frontier_info()[1], ())
+                    solution.critical_regions.extend(batch.regions_of(numpy.flatnonzero(hi[:, 0] == REGION_STATUS).tolist()))
+                else:
+                    # the integer heads are waited for (the region objects are built from them); the two large arrays keep
+                    # arriving by DMA while Python builds the objects -- eng.sync() below completes them
+                    hd, hi, er, kk, slots = eng.level_regions_slots(early_return=True)
+                    solution.critical_regions.extend(RegionBatch(hd, hi, er, n_x, n_t, n_c, n_tc, kk, slots).regions())
         if profile is not None:
             profile.append({'depth': depth + 1, 'k': int(st.k), 'candidates': int(st.n),
                             'status': [int(v) for v in st.n_status], 'regions': int(st.n_regions),
