@@ -363,7 +363,9 @@ def main():
         from ppopt_amd.mp_solvers import mpqp_hip_combi_graph
         mpqp_hip_combi_graph.solve_graph(prog, device=local_rank)      # warm-up (buffers, pinned result arrays)
         best, gprof, n_reg = float('inf'), [], 0
-        for _ in range(2):
+        last = None
+        for _ in range(4):
+            last = None                       # the previous solution's page-locked arrays go back to the pool before the next run
             gp = []
             tq = time.perf_counter()
             gsol = mpqp_hip_combi_graph.solve_graph(prog, device=local_rank, profile=gp)
