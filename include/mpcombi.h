@@ -180,6 +180,12 @@ int mpc_level_status(mpc_handle *h, uint8_t *status_host);                      
    at config 4) runs under the large levels of the main handle instead of behind the last one. */
 #define MPC_LEVEL_ONLY_BASE 32
 #define MPC_STREAM_RETRY 7
+/* Whether the region stage of a level may be launched under its (x,theta) stage (default 1; environment MPC_NO_ROVERLAP=1 = 0).
+ * An overlapped launch reserves spare record slots for candidates that turn out optimal only after it (re-solved doubtful ones);
+ * should a level ever find more of them than it reserved, mpc_level_run / mpc_level_wait return MPC_ERR_CAPACITY -- no
+ * candidate is demoted -- and the caller repeats the solve with on = 0, where every optimal candidate is known at launch.
+ * (Reference: full_process never loses a region, mp_solvers/mpqp_parrallel_combinatorial.py:52-61.) */
+int mpc_set_region_overlap(mpc_handle *h, int32_t on);
 int mpc_level_start(mpc_handle *h, int32_t gen_children, int32_t flags);
 int mpc_level_stream_info(mpc_handle *h, double **head_d, int32_t **head_i, double **erows, int64_t *n_slots, int64_t *cap_rows,
                           int32_t *chunk, int32_t *n_chunks);

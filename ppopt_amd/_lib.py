@@ -28,7 +28,13 @@ _u64p = ctypes.POINTER(ctypes.c_uint64)
 
 
 class MpcError(RuntimeError):
-    pass
+    code = 0
+
+
+class MpcCapacityError(MpcError):
+    """MPC_ERR_CAPACITY from a level: the overlapped region stage found more late optimal candidates than it had reserved
+    slots for (mpcombi.h, mpc_set_region_overlap).  The drivers repeat the solve with the overlap switched off."""
+    code = 3
 
 
 class MpcProblem(ctypes.Structure):
@@ -71,6 +77,7 @@ def load():
         'mpc_destroy': (ctypes.c_int, [H]),
         'mpc_last_error': (ctypes.c_char_p, [H]),
         'mpc_mask_words': (ctypes.c_int32, [H]),
+        'mpc_set_region_overlap': (ctypes.c_int, [H, ctypes.c_int32]),
         'mpc_region_doubles': (ctypes.c_int64, [H]),
         'mpc_region_ints': (ctypes.c_int64, [H]),
         'mpc_lds_bytes': (ctypes.c_int32, [H, ctypes.c_int32]),
@@ -139,7 +146,7 @@ def load():
 
 
 EXPORTED_SYMBOLS = ['mpc_device_count', 'mpc_version', 'mpc_last_global_error', 'mpc_create', 'mpc_destroy',
-                    'mpc_last_error', 'mpc_mask_words', 'mpc_region_doubles', 'mpc_region_ints', 'mpc_lds_bytes', 'mpc_stream',
+                    'mpc_last_error', 'mpc_mask_words', 'mpc_set_region_overlap', 'mpc_region_doubles', 'mpc_region_ints', 'mpc_lds_bytes', 'mpc_stream',
                     'mpc_frontier_root', 'mpc_frontier_set', 'mpc_frontier_set_device', 'mpc_frontier_info',
                     'mpc_frontier_get', 'mpc_pruned_clear', 'mpc_pruned_add', 'mpc_pruned_add_device',
                     'mpc_pruned_count', 'mpc_pruned_get', 'mpc_level_run', 'mpc_level_run_ex', 'mpc_level_status', 'mpc_level_start', 'mpc_level_stream_info', 'mpc_level_chunk_wait', 'mpc_level_wait', 'mpc_level_stream_fixup', 'mpc_base_result', 'mpc_level_regions', 'mpc_compact_strides',
@@ -238,7 +245,11 @@ class Engine:
     # -- plumbing ----------------------------------------------------------------------------------------------
     def _check(self, rc, what):
         if rc != MPC_OK:
-            raise MpcError(f'{what} failed ({rc}): {self._L.mpc_last_error(self._h).decode()}')
+            cls = MpcCapacityError if rc == 3 and what in ('mpc_level_run', 'mpc_level_wait') else MpcError
+            raise cls(f'{what} failed ({rc}): {self._L.mpc_last_error(self._h).decode()}')
+
+    def set_region_overlap(self, on: bool):
+        self._check(self._L.mpc_set_region_overlap(self._h, 1 if on else 0), 'mpc_set_region_overlap')
 
     def close(self):
         if getattr(self, '_twin', None) is not None:

@@ -110,32 +110,39 @@ struct DevBuf {
 };
 
 // pooled page-locked host memory (also behind mpc_host_alloc / mpc_host_free)
+// Two classes of blocks that are never mixed: class 0 = staging for DMA copies (default, coarse-grained mapping); class 1 =
+// blocks a RUNNING kernel writes and the host polls (streamed region records, chunk flags, the list-length counters):
+// those are allocated hipHostMallocCoherent | hipHostMallocMapped, i.e. fine-grained, so that visibility of the kernel's
+// system-scope release does not depend on HIP_HOST_COHERENT or on an undocumented L2 write-back.
 std::mutex g_pool_mutex;
-std::multimap<size_t, void *> g_pool_free;          // size -> block
-std::unordered_map<void *, size_t> g_pool_live;     // block -> size
+std::multimap<size_t, void *> g_pool_free[2];       // [class] size -> block
+std::unordered_map<void *, std::pair<size_t, int>> g_pool_live;     // block -> (size, class)
 size_t g_pool_free_bytes = 0;
 constexpr size_t POOL_MAX_FREE = size_t(2) << 30;
 
-hipError_t host_pool_take(size_t bytes, void **out, size_t *got) {
+hipError_t host_pool_take(size_t bytes, void **out, size_t *got, bool coherent = false) {
+    static const bool coarse_only = [] { const char *ev = std::getenv("MPC_HOST_COARSE"); return ev && ev[0] == '1'; }();   // A/B switch
+    if (coarse_only) coherent = false;
     const size_t gran = bytes >= (size_t(1) << 20) ? (size_t(1) << 20) : (size_t(64) << 10);
     const size_t need = std::max<size_t>((bytes + gran - 1) / gran * gran, gran);
+    const int cls = coherent ? 1 : 0;
     {
         std::lock_guard<std::mutex> lk(g_pool_mutex);
-        auto it = g_pool_free.lower_bound(need);
-        if (it != g_pool_free.end() && it->first <= need + need / 2) {
+        auto it = g_pool_free[cls].lower_bound(need);
+        if (it != g_pool_free[cls].end() && it->first <= need + need / 2) {
             *out = it->second;
             if (got) *got = it->first;
-            g_pool_live[it->second] = it->first;
+            g_pool_live[it->second] = {it->first, cls};
             g_pool_free_bytes -= it->first;
-            g_pool_free.erase(it);
+            g_pool_free[cls].erase(it);
             return hipSuccess;
         }
     }
     void *p = nullptr;
-    hipError_t e = hipHostMalloc(&p, need, hipHostMallocPortable);
+    hipError_t e = hipHostMalloc(&p, need, coherent ? (hipHostMallocPortable | hipHostMallocMapped | hipHostMallocCoherent) : hipHostMallocPortable);
     if (e != hipSuccess) return e;
     std::lock_guard<std::mutex> lk(g_pool_mutex);
-    g_pool_live[p] = need;
+    g_pool_live[p] = {need, cls};
     *out = p;
     if (got) *got = need;
     return hipSuccess;
@@ -146,10 +153,11 @@ bool host_pool_give(void *p) {
         std::lock_guard<std::mutex> lk(g_pool_mutex);
         auto it = g_pool_live.find(p);
         if (it == g_pool_live.end()) return false;
-        sz = it->second;
+        sz = it->second.first;
+        const int cls = it->second.second;
         g_pool_live.erase(it);
         if (g_pool_free_bytes + sz <= POOL_MAX_FREE) {
-            g_pool_free.emplace(sz, p);
+            g_pool_free[cls].emplace(sz, p);
             g_pool_free_bytes += sz;
             return true;
         }
@@ -162,11 +170,12 @@ bool host_pool_give(void *p) {
 struct HostBuf {
     void *p = nullptr;
     size_t cap = 0;
+    bool coherent = false;   // class 1 of the pool: written by running kernels, polled by the host
     hipError_t ensure(size_t bytes) {
         if (bytes <= cap) return hipSuccess;
         const size_t want = std::max(bytes, cap + cap / 2);
         release();
-        return host_pool_take(want, &p, &cap);
+        return host_pool_take(want, &p, &cap, coherent);
     }
     void release() { if (p) (void)host_pool_give(p); p = nullptr; cap = 0; }
     template <class T> T *as() const { return reinterpret_cast<T *>(p); }
@@ -239,13 +248,16 @@ struct mpc_handle {
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     hipStream_t stream3 = nullptr;   // region stage of a level, launched under its (x,theta) stage
     hipEvent_t ev_rfork = nullptr, ev_rjoin = nullptr, ev_rgo = nullptr;
-    bool no_roverlap = false;        // MPC_NO_ROVERLAP=1: region stage after the (x,theta) stage (no overlap)
+    bool no_roverlap = false;        // MPC_NO_ROVERLAP=1 / mpc_set_region_overlap(h, 0): region stage after the (x,theta) stage (no overlap)
+    bool r3_dirty = false;           // a region kernel launched on stream3 has not been joined by a completed level yet
+    int test_spare = 0;              // MPC_TEST_SPARE=N (tests): N fewer spare region slots than the overlapped launch would reserve
     long long roverlap_min = 2048, roverlap_long = 50000;   // MPC_ROVERLAP_MIN / MPC_ROVERLAP_LONG (items of the (x,theta) stage)
     int wall_khz = 100000;           // rate of wall_clock64() on the device
     int test_late = 0;               // MPC_TEST_LATE=N (tests): the overlapped launch leaves N optimal candidates to the late path
     bool own_stream = false;
     int n_cu = 256;
     std::string error;
+    std::mutex em;                   // fail() is called by the worker thread and by the caller's thread (mpc_level_chunk_wait)
     // problem
     int n_x = 0, n_t = 0, n_c = 0, n_eq = 0, n_tc = 0, is_qp = 0, kkt_mode = 0;
     int mw = MPC_MASK_WORDS;   // 64-bit words of an active-set mask: 2 (n_c <= 128) or 4 (n_c <= 256)
@@ -337,7 +349,7 @@ struct mpc_handle {
 namespace {
 
 int fail(mpc_handle *h, int code, const std::string &msg) {
-    if (h) h->error = msg; else g_error = msg;
+    if (h) { std::lock_guard<std::mutex> lk(h->em); h->error = msg; } else g_error = msg;
     return code;
 }
 
@@ -503,6 +515,7 @@ static int create_fill(const mpc_problem *p, int32_t device, void *stream, mpc_h
     { const char *ev = std::getenv("MPC_NO_KKT_THREAD"); h->no_kkt_thread = ev && ev[0] == '1'; }
     { const char *ev = std::getenv("MPC_NO_ROVERLAP"); h->no_roverlap = ev && ev[0] == '1'; }
     { const char *ev = std::getenv("MPC_TEST_LATE"); h->test_late = ev ? std::atoi(ev) : 0; }
+    { const char *ev = std::getenv("MPC_TEST_SPARE"); h->test_spare = ev ? std::atoi(ev) : 0; }
     { const char *ev = std::getenv("MPC_ROVERLAP_MIN"); if (ev) h->roverlap_min = std::atoll(ev); }
     { const char *ev = std::getenv("MPC_ROVERLAP_LONG"); if (ev) h->roverlap_long = std::atoll(ev); }
     { const char *ev = std::getenv("MPC_DICT_BUDGET_GB"); if (ev) h->dict_budget_gb = std::atof(ev); }
@@ -798,7 +811,7 @@ static int create_fill(const mpc_problem *p, int32_t device, void *stream, mpc_h
     HIP_TRY(nullptr, h->scratch.ensure(256, h->stream));
     {
         void *hp = nullptr, *dp = nullptr;
-        HIP_TRY(nullptr, host_pool_take(4096, &hp, nullptr));
+        HIP_TRY(nullptr, host_pool_take(4096, &hp, nullptr, true));
         HIP_TRY(nullptr, hipHostGetDevicePointer(&dp, hp, 0));
         h->tot_host = static_cast<int32_t *>(hp);
         h->tot_dev = static_cast<int32_t *>(dp);
@@ -844,6 +857,7 @@ int mpc_destroy(mpc_handle *h) {
 }
 
 int32_t mpc_mask_words(const mpc_handle *h) { return h ? h->mw : MPC_MASK_WORDS; }
+int mpc_set_region_overlap(mpc_handle *h, int32_t on) { if (!h) return MPC_ERR_INVALID; h->no_roverlap = !on; return MPC_OK; }
 int64_t mpc_region_doubles(const mpc_handle *h) { return h ? h->rec_d : 0; }
 int64_t mpc_region_ints(const mpc_handle *h) { return h ? h->rec_i : 0; }
 int32_t mpc_lds_bytes(const mpc_handle *h, int32_t which) { return !h ? 0 : (which == 0 ? h->lds_v : h->lds_r); }
@@ -1016,6 +1030,8 @@ static void stream_ready(mpc_handle *h) {
     h->wcv.notify_all();
 }
 static void stream_release(mpc_handle *h) {   // blocks of a streamed level nobody took
+    // a level that ended early (error return) after launching its region kernel on stream3 may still be writing the blocks
+    if (h->r3_dirty) { (void)hipStreamSynchronize(h->stream3); h->r3_dirty = false; }
     if (!h->so.taken) { if (h->so.hd) (void)host_pool_give(h->so.hd); if (h->so.hi) (void)host_pool_give(h->so.hi); if (h->so.er) (void)host_pool_give(h->so.er); }
     h->so = mpc_handle::StreamOut();
 }
@@ -1121,9 +1137,10 @@ static int level_run_impl(mpc_handle *h, int32_t gen_children, int32_t flags, mp
                 while (so.shift > 4 && ((long long)n_opt >> so.shift) < 8) --so.shift;   // at least ~8 chunks, 16..256 slots each
                 so.n_chunks = (int)(((long long)n_opt + (1ll << so.shift) - 1) >> so.shift);
                 so.n_slots = (long long)n_tot; so.cap_rows = (long long)n_tot * rows_t_;   // chunks cover the first n_opt slots
-                HIP_TRY(h, host_pool_take(bytes_hd, &so.hd, nullptr));
-                HIP_TRY(h, host_pool_take(bytes_hi, &so.hi, nullptr));
-                HIP_TRY(h, host_pool_take(std::max<size_t>(bytes_er, 8), &so.er, nullptr));
+                HIP_TRY(h, host_pool_take(bytes_hd, &so.hd, nullptr, true));
+                HIP_TRY(h, host_pool_take(bytes_hi, &so.hi, nullptr, true));
+                HIP_TRY(h, host_pool_take(std::max<size_t>(bytes_er, 8), &so.er, nullptr, true));
+                h->st_flags.coherent = true;
                 HIP_TRY(h, h->st_flags.ensure((size_t)so.n_chunks * sizeof(int32_t)));
                 std::memset(h->st_flags.p, 0, (size_t)so.n_chunks * sizeof(int32_t));
                 h->cw_chunks = so.n_chunks;
@@ -1164,7 +1181,7 @@ static int level_run_impl(mpc_handle *h, int32_t gen_children, int32_t flags, mp
             }
 #undef MPC_LAUNCH_R2
             HIP_TRY(h, hipEventRecord(h->kev[5], rst));
-            if (rst != st) HIP_TRY(h, hipEventRecord(h->ev_rjoin, rst));
+            if (rst != st) { h->r3_dirty = true; HIP_TRY(h, hipEventRecord(h->ev_rjoin, rst)); }
             kernel_timed[2] = true;
             HIP_TRY(h, hipGetLastError());
             h->used_region2 = true;
@@ -1279,13 +1296,14 @@ static int level_run_impl(mpc_handle *h, int32_t gen_children, int32_t flags, mp
             if (!h->no_roverlap && cntA[2] > 0 && h->fast_r >= 0 && !(flags & MPC_LEVEL_GRAPH) && x_items >= h->roverlap_min && !use_grouped) {
                 // Candidates that turn out optimal later -- re-solved doubtful ones: the n_early of the theta stage, rarely one of
                 // the (x,theta) stage -- get spare slots behind the launch's and take the LDS-engine route of the candidates
-                // k_region2 gives up on.  The spare slots cover every re-solved candidate of the theta stage plus 64 of the
+                // k_region2 gives up on.  The spare slots cover every re-solved candidate of the theta stage plus up to 1,024 of the
                 // (x,theta) stage (candidates whose theta stage found no feasible parameter and whose re-solve, in other arithmetic,
-                // calls them optimal: none has been seen); late candidates beyond the spare slots -- the highest candidate indices --
-                // would keep the theta stage's answer, feasible and not optimal.
+                // calls them optimal: none has been seen).  A candidate is never demoted for want of a slot: late candidates beyond
+                // the spare slots make the level fail with MPC_ERR_CAPACITY, and the driver repeats the solve with the region stage
+                // behind the (x,theta) stage (mpc_set_region_overlap(h, 0)), where every optimal candidate is known at launch.
                 const int32_t hold = std::min<int32_t>(std::max(h->test_late, 0), cntA[2] - 1);
                 const int32_t n_launch = cntA[2] - hold;
-                region_extra = n_early + hold + (cntA[3] > 0 ? 64 : 0);
+                region_extra = std::max(0, n_early + hold + std::min<int32_t>(cntA[3], 1024) - std::max(h->test_spare, 0));
                 HIP_TRY(h, hipMemcpyAsync(h->opt_list.p, part_list(2), (size_t)n_launch * sizeof(int32_t), hipMemcpyDeviceToDevice, st));
                 h->opt_ptr = h->opt_list.as<int32_t>();
                 h->n_opt = n_launch;
@@ -1400,10 +1418,9 @@ static int level_run_impl(mpc_handle *h, int32_t gen_children, int32_t flags, mp
             if (region_launched) {
                 n_late = cntB[2];
                 const int32_t *late = part_list(2);
-                if (n_late > region_extra) {
-                    hipLaunchKernelGGL(k_set_status, dim3((unsigned)((n_late - region_extra + 255) / 256)), dim3(256), 0, st, late, region_extra, n_late, ST_FEASIBLE, stp);
-                    n_late = region_extra;
-                }
+                if (n_late > region_extra)
+                    return fail(h, MPC_ERR_CAPACITY, "late optimal candidates (" + std::to_string(n_late) + ") exceed the spare region slots (" + std::to_string(region_extra) +
+                                                     ") of the overlapped region stage: repeat the solve after mpc_set_region_overlap(h, 0)");
                 if (n_late > 0) {
                     const int32_t n_a = (int32_t)h->n_opt;
                     HIP_TRY(h, hipMemcpyAsync(h->opt_list.as<int32_t>() + n_a, late, (size_t)n_late * sizeof(int32_t), hipMemcpyDeviceToDevice, st));
@@ -1495,6 +1512,7 @@ static int level_run_impl(mpc_handle *h, int32_t gen_children, int32_t flags, mp
                            reinterpret_cast<unsigned int *>(h->tot_dev + 16), (int)(sizeof(LevelCounters) / 4));
         HIP_TRY(h, hipGetLastError());
         HIP_TRY(h, hipStreamSynchronize(st));
+        h->r3_dirty = false;   // the main stream waited for ev_rjoin before the second partition
         std::memcpy(&host_ctr, h->tot_host + 16, sizeof(LevelCounters));
         HIP_TRY(h, hipEventElapsedTime(&ms[0], h->ev[0], h->ev[1]));
         HIP_TRY(h, hipEventElapsedTime(&ms[1], h->ev[1], h->ev[2]));

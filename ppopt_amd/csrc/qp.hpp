@@ -38,7 +38,8 @@ __global__ void __launch_bounds__(64) k_qp_batch(long long n_qp, int nc, int n_e
     int *ib = reinterpret_cast<int *>(smem + (size_t)(nc + 1) * ld);
     Lp lp;
     lp.T = T; lp.ld = ld; lp.colvar = ib; lp.rowvar = ib + ld + 1; lp.rowkind = ib + ld + 1 + nc + 2;
-    double *lamv = reinterpret_cast<double *>(lp.rowkind + nc + 2 + ((nc + 2) & 1));   // multipliers of the solved point
+    // (ld + 1) + 2 (nc + 2) ints precede it and ld is odd: the int block has an even length, lamv is 8-byte aligned as it stands
+    double *lamv = reinterpret_cast<double *>(lp.rowkind + nc + 2);   // multipliers of the solved point
     const int ID_Z0 = 2 * nc;
     for (;;) {
         unsigned int w = 0;

@@ -50,6 +50,17 @@ class HipLevelEngine:
         self._stats = None
         self._base_twin = None
 
+    @property
+    def capacity_error(self):
+        from . import _lib
+        return _lib.MpcCapacityError
+
+    def set_region_overlap(self, on: bool):
+        if self._base_twin is not None:      # a base-set check started beside the abandoned solve
+            twin, self._base_twin = self._base_twin, None
+            twin.level_wait()
+        self.eng.set_region_overlap(on)
+
     def clear_pruned(self):
         self.eng.pruned_clear()
 
@@ -226,8 +237,28 @@ def allgather_table(row: List[int], device, group=None) -> List[List[int]]:
     return torch.stack(parts).cpu().tolist()
 
 
+class _RepeatWithoutOverlap(Exception):
+    """Raised on EVERY rank of the group in the same level: some rank's level returned MPC_ERR_CAPACITY (more late optimal
+    candidates than the overlapped region stage had reserved slots for; include/mpcombi.h, mpc_set_region_overlap)."""
+
+
 def solve_distributed(engine, program=None, group=None, profile: Optional[List[Dict]] = None,
                       collect_regions: bool = True, max_levels: Optional[int] = None, shard_min: int = 128, force_shard: bool = False) -> Solution:
+    """``_solve_distributed``; when a level on some rank runs out of spare region slots, all ranks learn it from that level's
+    statistics exchange (replicated levels: every rank hits it by itself, the kernels are deterministic) and repeat the solve
+    together with the region stage behind the (x,theta) stage.  No candidate is ever demoted."""
+    try:
+        return _solve_distributed(engine, program, group, profile, collect_regions, max_levels, shard_min, force_shard)
+    except _RepeatWithoutOverlap:
+        if hasattr(engine, 'set_region_overlap'):
+            engine.set_region_overlap(False)
+        if profile is not None:
+            del profile[:]
+        return _solve_distributed(engine, program, group, profile, collect_regions, max_levels, shard_min, force_shard)
+
+
+def _solve_distributed(engine, program=None, group=None, profile: Optional[List[Dict]] = None,
+                       collect_regions: bool = True, max_levels: Optional[int] = None, shard_min: int = 128, force_shard: bool = False) -> Solution:
     """The level loop of the parallel combinatorial algorithm over the ranks of ``group`` (see the module docstring).
     Every rank returns the complete Solution.  Works without an initialised process group (world size 1)."""
     active = dist.is_available() and dist.is_initialized()
@@ -263,18 +294,24 @@ def solve_distributed(engine, program=None, group=None, profile: Optional[List[D
             sharded = True
             if hasattr(engine, 'base_start'):
                 engine.base_start()      # the base-set check runs beside the sharded levels (second handle)
-        if pending is not None and hasattr(engine, 'run_start'):
-            # the previous sharded level's regions (gathered on RCCL's stream meanwhile) come to the host and become objects
-            # while this level runs on the device
-            engine.run_start(gen_children)
-            finish(pending)
-            pending = None
-            st = engine.run_wait()
-        else:
-            if pending is not None:
+        capacity = getattr(engine, 'capacity_error', ())      # exception type(s) of "out of spare region slots", if the engine has one
+        try:
+            if pending is not None and hasattr(engine, 'run_start'):
+                # the previous sharded level's regions (gathered on RCCL's stream meanwhile) come to the host and become objects
+                # while this level runs on the device
+                engine.run_start(gen_children)
                 finish(pending)
                 pending = None
-            st = engine.run(gen_children)
+                st = engine.run_wait()
+            else:
+                if pending is not None:
+                    finish(pending)
+                    pending = None
+                st = engine.run(gen_children)
+        except capacity:
+            if not sharded:
+                raise _RepeatWithoutOverlap()      # replicated level: every rank is here
+            st = {'n': 0, 'n_children': 0, 'n_pruned_new': 0, 'n_regions': 0, 'lp_pivots': -1, 'status': [0] * 6}
         total = st
         tensors = None
         if sharded:
@@ -283,6 +320,8 @@ def solve_distributed(engine, program=None, group=None, profile: Optional[List[D
             n_slots, n_rows = (int(tensors[0].shape[0]), int(tensors[2].shape[0])) if tensors is not None else (0, 0)
             table = allgather_table([st['n'], st['n_children'], st['n_pruned_new'], st['n_regions'], st['lp_pivots'],
                                      n_slots, n_rows, *st['status']], engine.device, group)
+            if any(r[4] < 0 for r in table):
+                raise _RepeatWithoutOverlap()      # some rank's level failed for want of spare slots: all ranks repeat
             total = {'n': sum(r[0] for r in table), 'n_children': sum(r[1] for r in table),
                      'n_pruned_new': sum(r[2] for r in table), 'n_regions': sum(r[3] for r in table),
                      'lp_pivots': sum(r[4] for r in table),

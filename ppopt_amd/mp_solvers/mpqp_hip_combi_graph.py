@@ -20,9 +20,10 @@ search (csrc/graph.hpp, mpc_graph_*); ``MPC_GRAPH_HOST=1`` keeps the same bookke
 instead (cross-check).  The reference pops ``S`` in arbitrary (hash) order; the set of examined active sets and the
 resulting regions do not depend on the order.
 
-Seeds: the reference starts from ``program.sample_theta_space(1)`` -- one QP solve at a random parameter point.  This
-package has no QP solver; the traversal is seeded with the active sets of the regions the first levels of the
-combinatorial algorithm find (level by level until one has a region), which is deterministic, or with ``seeds``.
+Seeds: the reference starts from ``program.sample_theta_space(1)`` -- one QP solve at a random parameter point.  Here
+the traversal is seeded with the active sets of the regions the first levels of the combinatorial algorithm find (level
+by level until one has a region), which is deterministic, or with ``seeds`` (e.g. from ``MPQP_Program.sample_theta_space``,
+which runs on the device through ``mpc_qp_solve_batch``).
 """
 import os
 from typing import Dict, Iterable, List, Optional

@@ -77,6 +77,29 @@ BASE_ON_TWIN = os.environ.get('MPC_NO_TWIN', '0') != '1'   # the base-set check 
 def solve(program, num_cores: int = -1, device: int = 0, profile: Optional[List[Dict]] = None,
           collect_regions: bool = True, max_levels: Optional[int] = None, stream: Optional[bool] = None,
           prune_lowdim: bool = True) -> Solution:
+    """``_solve`` below; should a level report more late optimal candidates than its overlapped region stage had reserved record
+    slots for (MPC_ERR_CAPACITY, include/mpcombi.h: mpc_set_region_overlap -- never observed, forced in the tests), the solve is
+    repeated with the region stage behind the (x,theta) stage, where nothing can be late.  No candidate is ever demoted."""
+    from .._lib import MpcCapacityError, MpcError
+    try:
+        return _solve(program, num_cores, device, profile, collect_regions, max_levels, stream, prune_lowdim)
+    except MpcCapacityError:
+        eng = program.engine(device)
+        twin = getattr(eng, '_twin', None)
+        if twin is not None:
+            try:
+                twin.level_wait()      # the base-set check that was started beside the failed solve
+            except MpcError:
+                pass
+        eng.set_region_overlap(False)
+        if profile is not None:
+            del profile[:]
+        return _solve(program, num_cores, device, profile, collect_regions, max_levels, stream, prune_lowdim)
+
+
+def _solve(program, num_cores: int = -1, device: int = 0, profile: Optional[List[Dict]] = None,
+           collect_regions: bool = True, max_levels: Optional[int] = None, stream: Optional[bool] = None,
+           prune_lowdim: bool = True) -> Solution:
     """Solves the mpLP/mpQP on one GPU.  ``num_cores`` is accepted for signature compatibility with the reference
     drivers and ignored.  ``profile``: optional list that receives one dict of statistics per level.  ``stream``: region
     records are streamed to the host while the region kernel runs (default; ``MPC_NO_STREAM=1`` or False = fetch after

@@ -192,7 +192,7 @@ def solve(program, active_set: Optional[List[int]] = None, num_cores: int = -1, 
             facet = facet[feasible]
             if not len(facet):
                 break
-            too_many = numpy.bitwise_count(pm).sum(axis=1) > n_x
+            too_many = _g._popcount(pm) > n_x
             for j in numpy.flatnonzero(too_many):                 # overdetermined active set: a full-rank subset (rare)
                 full = numpy.flatnonzero(numpy.unpackbits(pm[j].view(numpy.uint8), bitorder='little')[:n_c]).tolist()
                 pm[j] = _g._sets_to_masks([_sub_active_set(program, full)], words)[0]

@@ -20,6 +20,55 @@ def pytest_configure(config):
     config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
 
 
+# ---- knife-edge exceptions: explicit, per golden, and counted ----------------------------------------------------------
+# north_star: region count and active-set indices bit-exact.  A parity test may accept a difference from the reference ONLY
+# for an active set that is listed here by name AND is knife-edge by the rule of is_knife_edge (the oracle's own verdict flips
+# when its LP tolerance moves two decades, or cond(KKT) is beyond the limit).  Every exception a run consumes is recorded and
+# written to gpurun_out/parity_exceptions.json (and printed in the terminal summary), so the record shows how many were used.
+KNIFE_EDGE_VERDICTS = {
+    # golden name: {active set: reason}
+}
+KNIFE_EDGE_REGIONS = {
+    # golden name: {active set: reason}   (region present on one side only)
+}
+KNIFE_EDGE_FACETS = {
+    # golden name: {active set: reason}   (same region, omega / lambda / regular sets differ in rows redundant within the LP tolerance)
+}
+_CONSUMED = []
+
+
+def consume_exception(kind, golden, active_set, detail=''):
+    table = {'verdict': KNIFE_EDGE_VERDICTS, 'region': KNIFE_EDGE_REGIONS, 'facets': KNIFE_EDGE_FACETS}[kind]
+    key = tuple(int(v) for v in active_set)
+    listed = key in table.get(golden, {})
+    if listed:
+        _CONSUMED.append({'kind': kind, 'golden': golden, 'active_set': list(key), 'detail': detail})
+    return listed
+
+
+def _exception_report():
+    listed = {kind: {g: len(v) for g, v in table.items()} for kind, table in
+              (('verdict', KNIFE_EDGE_VERDICTS), ('region', KNIFE_EDGE_REGIONS), ('facets', KNIFE_EDGE_FACETS))}
+    return {'listed': listed, 'consumed': _CONSUMED, 'n_consumed': len(_CONSUMED)}
+
+
+def pytest_sessionfinish(session, exitstatus):
+    import json
+    try:
+        out = os.path.join(ROOT, 'gpurun_out')
+        os.makedirs(out, exist_ok=True)
+        with open(os.path.join(out, 'parity_exceptions.json'), 'w') as fh:
+            json.dump(_exception_report(), fh, indent=1)
+    except OSError:
+        pass
+
+
+def pytest_terminal_summary(terminalreporter):
+    rep = _exception_report()
+    terminalreporter.write_line(f"parity exceptions consumed: {rep['n_consumed']} "
+                                f"(listed: {sum(sum(v.values()) for v in rep['listed'].values())}) -> gpurun_out/parity_exceptions.json")
+
+
 def load_golden(name):
     return numpy.load(os.path.join(GOLDEN, name + '.npz'))
 

@@ -11,7 +11,7 @@ import warnings
 import numpy
 import pytest
 
-from conftest import golden_regions, is_knife_edge, kkt_condition, load_golden, rel_err, rows_match
+from conftest import consume_exception, golden_regions, is_knife_edge, kkt_condition, load_golden, rel_err, rows_match
 
 pytestmark = pytest.mark.gpu
 
@@ -109,30 +109,32 @@ def test_lp_batch_shared_matrix_many_instances(oracle):
 
 @pytest.mark.parametrize('name', FULL + PARTIAL)
 def test_level_trace_and_regions_match_reference(oracle, name):
+    """Candidates, verdicts and regions of every golden level.  Bit-exact unless the active set is LISTED in
+    conftest.KNIFE_EDGE_* for this golden and is knife-edge by conftest.is_knife_edge; every exception used is recorded
+    (gpurun_out/parity_exceptions.json).  All offenders are collected before the test fails, so one run names them all."""
     g = load_golden(name)
     P = oracle.problem_from_golden(g)
     eng = engine_from_golden(g)
     nl = int(g['n_levels'])
     levels, regions = run_levels(eng, None if bool(g['complete']) else nl)
-    total = mismatches = 0
-    diverged = False
+    total = used = 0
+    offenders = []
     for i, (cands, status, st) in enumerate(levels[:nl]):
         gc, gv = g[f'L{i}_cands'], g[f'L{i}_verdict']
         ref = {tuple(r): int(v) for r, v in zip(gc.tolist(), gv.tolist())}
-        if not diverged and not numpy.array_equal(cands, gc):
-            diverged = True  # only possible after a knife-edge verdict changed the pruning upstream
+        if used == 0 and not offenders:
+            assert numpy.array_equal(cands, gc), f'{name} level {i}: candidate list differs'   # only a changed verdict upstream can change it
         for cand, v in zip(cands.tolist(), status.tolist()):
             key = tuple(cand)
             if key not in ref:
                 continue
             total += 1
             if ref[key] != v:
-                assert is_knife_edge(P, cand), f'{name} level {i}: {cand} gpu {v} reference {ref[key]} (robust candidate)'
-                mismatches += 1
+                if consume_exception('verdict', name, key, f'gpu {v} reference {ref[key]}') and is_knife_edge(P, cand):
+                    used += 1
+                else:
+                    offenders.append(('verdict', i, key, v, ref[key], is_knife_edge(P, cand)))
     assert total >= 0.98 * sum(len(g[f'L{i}_verdict']) for i in range(nl))
-    assert mismatches <= max(2, total // 500), f'{mismatches} knife-edge verdicts out of {total}'
-    if mismatches == 0:
-        assert not diverged
     # regions: bit-exact active sets and index sets, coefficients within 1e-8
     ref = golden_regions(g)
     got = {tuple(r.active_set): r for r in regions}
@@ -140,8 +142,8 @@ def test_level_trace_and_regions_match_reference(oracle, name):
     only_ref = [k for k in ref if k not in got and len(k) > len(g['proc_eq'])]
     only_gpu = [k for k in got if k not in ref and len(k) in levels_k and bool(g['complete'])]
     for key in only_ref + only_gpu:
-        assert is_knife_edge(P, list(key)), f'{name}: region set differs at robust active set {key}'
-    assert len(only_ref) + len(only_gpu) <= 2
+        if not (consume_exception('region', name, key, 'reference only' if key in ref else 'gpu only') and is_knife_edge(P, list(key))):
+            offenders.append(('region', key, 'reference only' if key in ref else 'gpu only', is_knife_edge(P, list(key))))
     for key, r in got.items():
         if key not in ref:
             continue
@@ -150,10 +152,12 @@ def test_level_trace_and_regions_match_reference(oracle, name):
             assert rel_err(getattr(r, fld), q[fld]) <= COEF_TOL, (name, key, fld)
         same_sets = (r.omega_set == q['omega_set'] and r.lambda_set == q['lambda_set'] and r.regular_set == q['regular_set'])
         if not same_sets:
-            assert is_knife_edge(P, list(key), cond_limit=1e6), f'{name}: facet sets differ at robust region {key}'
+            if not (consume_exception('facets', name, key) and is_knife_edge(P, list(key), cond_limit=1e6)):
+                offenders.append(('facets', key, is_knife_edge(P, list(key), cond_limit=1e6)))
             continue
         assert rows_match(r.E, r.f, q['E'], q['f'], COEF_TOL), (name, key)
     eng.close()
+    assert not offenders, f'{name}: differences from the reference that are not listed knife-edge exceptions: {offenders}'
 
 
 def test_solve_mpqp_region_counts_like_reference_tests():
