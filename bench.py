@@ -101,7 +101,20 @@ def cpu_baseline(prog, frontiers, gpu_status, target_candidates):
         regions += int((status == orc.REGION).sum())
         differ += int((status != gst[idx]).sum())
     dt = time.perf_counter() - t0
+    # the same port on ONE thread, on every 256th candidate of the sample (about ten seconds)
+    t1 = time.perf_counter()
+    n1 = 0
+    for s in samples:
+        sub = numpy.ascontiguousarray(s[::256])
+        if len(sub):
+            P.check_level(sub, 1, False)
+            n1 += len(sub)
+    dt1 = time.perf_counter() - t1
     return {'value': n / dt, 'unit': 'candidate active sets checked/s', 'cores': cores, 'kind': 'port',
+            'label': 'naive port: a BLAS-free C restatement that poses every LP the way the reference does (dense two-phase simplex from '
+                     'scratch per LP); per thread it is SLOWER than the Python reference with HiGHS (about 175 candidates/s/worker, '
+                     'BASELINE.md 4) -- a baseline for orientation, the GPU/CPU ratio is not a quality claim',
+            'value_one_thread': n1 / max(dt1, 1e-9), 'one_thread_sample': f'{n1} candidates, {dt1:.1f} s',
             'sample': f'{n} candidates ({100 * frac:.1f}% of every BFS level, evenly strided), {dt:.1f} s, '
                       f'{regions} regions; oracle/mpcombi_oracle.c (C port of the reference algorithm, OpenMP)',
             'regions_per_s': regions / dt,
@@ -233,22 +246,62 @@ def main():
         lambda p: p['n_x_items'] * (p['dict_read_bytes'] + p['dict_write_bytes'] + 4 + 4 * p['k'] + 1))
     R = lambda k: 8 * (nt + 1) * (nx + k + n_e) + 4 * (8 + 2 * k + prog.A_t.shape[0] + 2 * (nc - k))
     add('k_region2', 'ms_region2', 'n_opt', lambda p: p['n_opt'] * (4 * p['k'] + 8 * p['k'] * (nt + 1) + R(p['k'])))
+    #   k_kkt_thread  per candidate: active set (4k) in, KKT code + status out, the multipliers (8 k (n_t+1)) of the candidates its
+    #             box screen leaves open (= the items of k_theta2); W, UV, A A' once per launch (gathers are served from L2)
+    add('k_kkt_thread', 'ms_kkt', 'candidates',
+        lambda p: p.get('local_candidates', p['candidates']) * (4 * p['k'] + 2) + p['n_theta_items'] * 8 * p['k'] * (nt + 1)
+        + 8 * nc * (2 * nc + nt + 1))
+    #   k_xq      (last level) per candidate: list entry, parent slot, last index, status (13) + the integer part of the parent's
+    #             record (4 x ints) + its value column (8 x rows) + the new row (8 x cols); per product-form iteration one column
+    #             (8 x rows) and one row (8 x cols) of the record: "vectors touched x length"
+    def xq_bytes(p):
+        ints, rows, cols = p.get('xq_record', [0, 0, 0])
+        return p['n_xq_items'] * (13 + 4 * ints + 8 * rows + 8 * cols) + p['xq_pivots'] * 8 * (rows + cols)
+    add('k_xq', 'ms_xq', 'n_xq_items', xq_bytes)
     # The roofline object follows SURVEY.md 8(d): achieved = B_alg x candidates/s for the path (all kernels of a level), against
     # the HBM peak.  The kernel with the largest total time is described under `dominant_kernel` (its own algorithmic bytes
     # over its own HIP-event time), every heavy kernel under `kernels`.
     dominant = max(kern, key=lambda k: kern[k]['total_ms'])
     dom = kern[dominant]
+    # Counter record of the same command (tools/profile_round3.sh -> tools/pmc_round.py -> profiles/r03_pmc.json): HBM-side bytes
+    # with the FETCH_SIZE / WRITE_SIZE factors calibrated on known byte counts in each kernel's own access pattern, and the SQ
+    # instruction counters per launch.  From the latter the VALU-issue roofline of the simplex kernels: wave-level VALU instructions
+    # x 4 cycles (one 64-lane fp64 instruction occupies its 16-lane SIMD for 4 cycles; 78.6 TFLOP/s = 1024 SIMDs x 16 lanes x 2 x
+    # 2.4 GHz) / (SIMD-cycles of the launch = live HIP-event time x 2.4 GHz x 1024 SIMDs).  With the F64 instruction counters the
+    # fp64 share is priced at 4 cycles and the rest at 2 (v_fma_f32 wave64: 2 cycles, MI355X_MICROARCH.md).
     traffic = dom_traffic = None
-    tpath = os.path.join(ROOT, 'profiles', 'r02_pmc_traffic.json')
+    n_simd, clk_hz = 1024, 2.4e9
+    tpath = os.path.join(ROOT, 'profiles', 'r03_pmc.json')
     if os.path.exists(tpath):
         try:
-            tw = json.load(open(tpath)).get(args.workload)
+            rec = json.load(open(tpath))
+            tw = rec.get(args.workload)
             if tw:
                 traffic = {'bytes_per_step': tw['bytes_per_step'], 'fetch_bytes_per_step': tw['fetch_bytes_per_step'],
-                           'write_bytes_per_step': tw['write_bytes_per_step'], 'fetch_size_doubled': True,
-                           'source': 'profiles/r02_pmc_traffic.json'}
+                           'write_bytes_per_step': tw['write_bytes_per_step'], 'factors': tw.get('factors'),
+                           'calibration': 'tools/calib/pmc_calib.hip (known byte counts; profiles/r03_pmc.json -> calibration)',
+                           'source': 'profiles/r03_pmc.json'}
+                for name, kk in kern.items():
+                    pk = tw['kernels'].get(name)
+                    if not pk:
+                        continue
+                    kk['traffic_bytes_per_launch'] = pk.get('bytes_per_launch')
+                    sq = pk.get('sq_per_launch')
+                    if sq and kk['avg_launch_ms'] > 0:
+                        simd_cycles = kk['avg_launch_ms'] * 1e-3 * clk_hz * n_simd
+                        valu = sq.get('SQ_INSTS_VALU', 0.0)
+                        f64 = sum(sq.get(c, 0.0) for c in ('SQ_INSTS_VALU_ADD_F64', 'SQ_INSTS_VALU_MUL_F64', 'SQ_INSTS_VALU_FMA_F64',
+                                                           'SQ_INSTS_VALU_TRANS_F64'))
+                        kk['valu_insts_per_launch'] = valu
+                        kk['fp64_insts_per_launch'] = f64 if f64 > 0 else None
+                        kk['frac_valu_issue_4cyc'] = 4.0 * valu / simd_cycles          # every VALU instruction priced as fp64
+                        kk['frac_fp64_issue'] = (4.0 * f64 / simd_cycles) if f64 > 0 else None
+                        wc = sq.get('SQ_WAVE_CYCLES', 0.0)
+                        if wc > 0:
+                            kk['wave_cycles_share'] = {'active_inst': sq.get('SQ_ACTIVE_INST_ANY', 0.0) / wc, 'wait_inst': sq.get('SQ_WAIT_INST_ANY', 0.0) / wc,
+                                                       'wait_any': sq.get('SQ_WAIT_ANY', 0.0) / wc}
                 dom_traffic = tw['kernels'].get(dominant)
-        except (OSError, ValueError, KeyError):
+        except (OSError, ValueError, KeyError, TypeError):
             traffic = dom_traffic = None
     b_alg = bytes_path / max(local_cands, 1)
     out = {
@@ -282,12 +335,13 @@ def main():
                                          'achieved': dom['achieved_GBs'], 'frac': dom['achieved_GBs'] / HBM_PEAK_GBS,
                                          'launches': dom['launches'], 'avg_launch_ms': dom['avg_launch_ms'],
                                          'algorithmic_bytes_per_launch': dom['algorithmic_bytes'] / max(dom['launches'], 1),
+                                         'frac_fp64_issue': dom.get('frac_fp64_issue'), 'frac_valu_issue_4cyc': dom.get('frac_valu_issue_4cyc'),
                                          'traffic': dom_traffic},
                      'kernels': kern,
                      'note': 'B_alg = P + 4k + 8 + rho*R per candidate (SURVEY.md 8(d)): the shared problem block P is counted once per '
                              'candidate although it is served from L2, so `achieved` is the figure the survey defines, not measured DRAM '
-                             'traffic (that is `traffic`, from the rocprofv3 --pmc passes in profiles/, FETCH_SIZE doubled + WRITE_SIZE; '
-                             'null if not collected).  avg_launch_ms are HIP-event times taken inside the library on the stream the kernel '
+                             'traffic (that is `traffic`, from the rocprofv3 --pmc passes in profiles/, FETCH_SIZE / WRITE_SIZE with factors '
+                             'calibrated on known byte counts per access pattern; null if not collected).  avg_launch_ms are HIP-event times taken inside the library on the stream the kernel '
                              'runs on.  k_region2 and k_theta2 are fp64 simplex pivots in registers (VALU issue / dependent latency, '
                              'almost no HBM traffic); k_x2 streams one cached dictionary per candidate and is the kernel the HBM roof '
                              'applies to.'},
@@ -299,6 +353,10 @@ def main():
         if hasattr(cr, 'materialize'):
             cr.materialize()
     out['materialize_all_regions_ms'] = 1e3 * (time.perf_counter() - t_mat)
+    # regions/s both ways: `regions_per_s` counts the lazy CriticalRegion views the solve returns; the materialised figure adds the
+    # time to cut every field of every region out of the level arrays to each step
+    out['regions_per_s_lazy'] = out['regions_per_s']
+    out['regions_per_s_materialised'] = regions / (1e-3 * (out['ms_per_step'] + out['materialize_all_regions_ms']))
     if rank == 0 and not distributed and args.locate > 0 and regions:
         # consumer of the path: point location + evaluation of x*(theta) over the solution, batched on the GPU;
         # beside it the reference's loop (Solution.get_region, numpy per region) on a few points.  Not part of `value`.

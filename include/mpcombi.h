@@ -94,6 +94,11 @@ typedef struct {
     int64_t dict_write_bytes;  /* bytes of one record as k_x2 stores it for the next level (0: nothing stored)         */
     int64_t n_theta_items;     /* candidates k_theta2 processed (those the thread kernel's screen left open)             */
     int64_t n_region_rows;     /* rows [f | E] the region kernel appended to the row pool (streamed levels: rows of erows in use) */
+    /* HIP-event times of k_kkt_thread (over n candidates) and of the last level's quick test k_xq / k_xq_grouped (over n_xq_items
+     * candidates, xq_pivots product-form iterations: each reads one column and one row of the parent's record) */
+    float ms_kkt, ms_xq;
+    int64_t n_xq_items, xq_pivots;
+    int64_t xq_record_ints, xq_record_rows, xq_record_cols;   /* 2 mr + NXC + 3 ints, mr rows, n_d0c + 1 columns of a record */
 } mpc_level_stats;
 
 /* ---- library / device ------------------------------------------------------------------------------ */

@@ -65,6 +65,7 @@ struct LevelCounters {
     unsigned int work_verdict, work_region, n_opt, n_pruned_new, work_retry, work_x, e_rows, work_r2, work_q, n_retry_theta, n_rretry;
     unsigned long long r_box;       // k_region2: region rows removed by the bounding-box screen
     unsigned long long r2_not_t0, r2_t1;  // k_region2: ~(wall clock of the first wavefront's start), wall clock of the last one's end
+    unsigned long long xq_pivots;   // k_xq / k_xq_grouped: product-form iterations executed (each reads one column and one row of the parent's record)
 };
 
 struct Smem {
@@ -936,12 +937,6 @@ __global__ void k_init_slots(int32_t *__restrict__ head_i, int fi, int first, in
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j < count) { int32_t *hi = head_i + (size_t)(first + j) * fi; hi[0] = st; hi[1] = list ? list[j] : -1; }
 }
-// status[list[w]] = st for w in [from, n_list)
-__global__ void k_set_status(const int32_t *__restrict__ list, int from, int n_list, int st, uint8_t *__restrict__ status) {
-    const int w = from + blockIdx.x * blockDim.x + threadIdx.x;
-    if (w < n_list) status[list[w]] = (uint8_t)st;
-}
-
 // keeps rows start, start+stride, ... of a row-major int matrix (frontier sharding, mpc_frontier_shard)
 __global__ void k_take_rows(const int32_t *__restrict__ src, long long n_new, int width, long long start, long long stride,
                             int32_t *__restrict__ dst) {

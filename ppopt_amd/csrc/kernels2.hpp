@@ -700,7 +700,7 @@ __global__ void __launch_bounds__(64, XQ_WAVES) k_xq(const DevProblem *__restric
             }
         }
     }
-    if (lane == 0) { atomicAdd(&ctr->pivots, pivots); atomicAdd(&ctr->x_cached, n_quick); atomicAdd(&ctr->xtheta_lps, n_quick); }
+    if (lane == 0) { atomicAdd(&ctr->pivots, pivots); atomicAdd(&ctr->xq_pivots, pivots); atomicAdd(&ctr->x_cached, n_quick); atomicAdd(&ctr->xtheta_lps, n_quick); }
 }
 
 // k_xq_grouped: the same decisions with the parent's dictionary read ONCE per parent.  The candidates of a level are
@@ -765,7 +765,7 @@ __global__ void __launch_bounds__(256, XQG_WAVES) k_xq_grouped(const DevProblem 
         }
         __syncthreads();
     }
-    if (lane == 0) { atomicAdd(&ctr->pivots, pivots); atomicAdd(&ctr->x_cached, n_quick); atomicAdd(&ctr->xtheta_lps, n_quick); }
+    if (lane == 0) { atomicAdd(&ctr->pivots, pivots); atomicAdd(&ctr->xq_pivots, pivots); atomicAdd(&ctr->x_cached, n_quick); atomicAdd(&ctr->xtheta_lps, n_quick); }
 }
 
 #ifndef R2_CERT

@@ -343,7 +343,7 @@ struct mpc_handle {
     } g;
     hipEvent_t ev_hi = nullptr;   // completion of the head_i copy of an asynchronous slot fetch
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
-    hipEvent_t kev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // around k_theta2 / the main k_x2 launch / k_region2
+    hipEvent_t kev[10] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // around k_theta2 / the main k_x2 launch / k_region2 / k_kkt_thread / k_xq
 };
 
 namespace {
@@ -1047,9 +1047,9 @@ static int level_run_impl(mpc_handle *h, int32_t gen_children, int32_t flags, mp
     h->n_needx = 0;
     LevelCounters host_ctr;
     std::memset(&host_ctr, 0, sizeof(host_ctr));
-    float ms[3] = {0, 0, 0}, kms[3] = {0, 0, 0};
-    bool kernel_timed[3] = {false, false, false};
-    long long n_x_items = 0, n_theta_items = 0;
+    float ms[3] = {0, 0, 0}, kms[5] = {0, 0, 0, 0, 0};
+    bool kernel_timed[5] = {false, false, false, false, false};
+    long long n_x_items = 0, n_theta_items = 0, n_xq_items = 0;
     if (n > 0) {
         const size_t nn = (size_t)n;
         HIP_TRY(h, h->status.ensure(nn, st));
@@ -1207,11 +1207,14 @@ static int level_run_impl(mpc_handle *h, int32_t gen_children, int32_t flags, mp
                 kkc = h->kkt_code.as<uint8_t>(); kkl = h->kkt_L.as<double>();
                 const dim3 g((unsigned)blocks256), b(256);
                 const ThetaArgs ta = h->targs;
+                HIP_TRY(h, hipEventRecord(h->kev[6], st));
 #define MPC_LAUNCH_KKT(K_) case K_: if (h->fast_t >= 4) hipLaunchKernelGGL((k_kkt_thread<K_, 10>), g, b, 0, st, pf, fr, n, h->kkt_code.as<uint8_t>(), h->kkt_L.as<double>(), stp, ta, ctr); \
                                     else if (h->fast_t >= 2) hipLaunchKernelGGL((k_kkt_thread<K_, 8>), g, b, 0, st, pf, fr, n, h->kkt_code.as<uint8_t>(), h->kkt_L.as<double>(), stp, ta, ctr); \
                                     else hipLaunchKernelGGL((k_kkt_thread<K_, 4>), g, b, 0, st, pf, fr, n, h->kkt_code.as<uint8_t>(), h->kkt_L.as<double>(), stp, ta, ctr); break
                 switch (k) { MPC_LAUNCH_KKT(1); MPC_LAUNCH_KKT(2); MPC_LAUNCH_KKT(3); MPC_LAUNCH_KKT(4); MPC_LAUNCH_KKT(5); MPC_LAUNCH_KKT(6); MPC_LAUNCH_KKT(7); MPC_LAUNCH_KKT(8); }
 #undef MPC_LAUNCH_KKT
+                HIP_TRY(h, hipEventRecord(h->kev[7], st));
+                kernel_timed[3] = true;
                 HIP_TRY(h, hipGetLastError());
                 int32_t n_todo = 0;
                 { int rcs = compact(ST_TODO, ST_TODO, &n_todo); if (rcs) return rcs; }
@@ -1348,6 +1351,8 @@ static int level_run_impl(mpc_handle *h, int32_t gen_children, int32_t flags, mp
                 const long long grid_q = (long long)h->n_cu * 32;
                 dq.chunk = (int)std::max<long long>(1, std::min<long long>(16, n_needx / (grid_q * 4)));
                 const dim3 gg((unsigned)std::min<long long>((n_needx + dq.chunk - 1) / dq.chunk, grid_q)), bb(64);
+                HIP_TRY(h, hipEventRecord(h->kev[8], st));
+                n_xq_items = n_needx;
                 // Grouped by parent when a parent has many open children (config 3: 12.6 per parent, -0.5 ms; config 4: 7.1 per
                 // parent, where the per-candidate reads of k_xq are cheaper than one 16 KB copy per parent, +0.45 ms): threshold 10.
                 if (use_grouped) {
@@ -1367,6 +1372,8 @@ static int level_run_impl(mpc_handle *h, int32_t gen_children, int32_t flags, mp
                     else hipLaunchKernelGGL((k_xq_grouped<1>), gq, bq, lds_q, st, pf, fr, k, needx_list, n_needx, stp, ctr, dq, nxc, h->xq_groups.as<int32_t>(), h->scratch.as<int32_t>());
                 } else if (h->fast_x & 1) hipLaunchKernelGGL((k_xq<2>), gg, bb, 0, st, pf, fr, k, needx_list, n_needx, stp, ctr, dq, nxc);
                 else hipLaunchKernelGGL((k_xq<1>), gg, bb, 0, st, pf, fr, k, needx_list, n_needx, stp, ctr, dq, nxc);
+                HIP_TRY(h, hipEventRecord(h->kev[9], st));
+                kernel_timed[4] = true;
                 HIP_TRY(h, hipGetLastError());
                 int32_t n_left = 0;
                 { int rcs = compact(ST_NEEDX, ST_NEEDX_SING, &n_left); if (rcs) return rcs; }
@@ -1517,7 +1524,7 @@ static int level_run_impl(mpc_handle *h, int32_t gen_children, int32_t flags, mp
         HIP_TRY(h, hipEventElapsedTime(&ms[0], h->ev[0], h->ev[1]));
         HIP_TRY(h, hipEventElapsedTime(&ms[1], h->ev[1], h->ev[2]));
         HIP_TRY(h, hipEventElapsedTime(&ms[2], h->ev[2], h->ev[3]));
-        for (int i = 0; i < 3; ++i) if (kernel_timed[i]) HIP_TRY(h, hipEventElapsedTime(&kms[i], h->kev[2 * i], h->kev[2 * i + 1]));
+        for (int i = 0; i < 5; ++i) if (kernel_timed[i]) HIP_TRY(h, hipEventElapsedTime(&kms[i], h->kev[2 * i], h->kev[2 * i + 1]));
         if (kernel_timed[2] && host_ctr.r2_t1 > ~host_ctr.r2_not_t0 && h->wall_khz > 0)   // k_region2 times itself (see the kernel)
             kms[2] = (float)((double)(host_ctr.r2_t1 - ~host_ctr.r2_not_t0) / (double)h->wall_khz);
         if (h->debug_cycles)
@@ -1549,6 +1556,9 @@ static int level_run_impl(mpc_handle *h, int32_t gen_children, int32_t flags, mp
         stats->ms_theta = kms[0]; stats->ms_x = kms[1]; stats->ms_region2 = kms[2];
         stats->n_x_items = n_x_items;
         stats->n_theta_items = n_theta_items;
+        stats->ms_kkt = kms[3]; stats->ms_xq = kms[4];
+        stats->n_xq_items = n_xq_items; stats->xq_pivots = (int64_t)host_ctr.xq_pivots;
+        stats->xq_record_ints = h->dict_stride_i; stats->xq_record_rows = h->Pf.n_d0r; stats->xq_record_cols = h->Pf.n_d0c + 1;
         stats->n_region_rows = h->n_erows;
         stats->n_opt = h->n_opt;
         // bytes of one dictionary record that are actually moved: the used columns (value + D0 columns) and the integer part

@@ -85,7 +85,9 @@ class HipLevelEngine:
                 'ms_verdict': float(st.ms_verdict), 'ms_region': float(st.ms_region), 'ms_children': float(st.ms_children),
                 'ms_theta': float(st.ms_theta), 'ms_x': float(st.ms_x), 'ms_region2': float(st.ms_region2),
                 'n_x_items': int(st.n_x_items), 'n_opt': int(st.n_opt), 'n_theta_items': int(st.n_theta_items), 'dict_read_bytes': int(st.dict_read_bytes),
-                'dict_write_bytes': int(st.dict_write_bytes)}
+                'dict_write_bytes': int(st.dict_write_bytes), 'ms_kkt': float(st.ms_kkt), 'ms_xq': float(st.ms_xq),
+                'n_xq_items': int(st.n_xq_items), 'xq_pivots': int(st.xq_pivots),
+                'xq_record': [int(st.xq_record_ints), int(st.xq_record_rows), int(st.xq_record_cols)]}
 
     def _fresh(self, shape, dtype) -> torch.Tensor:
         """A tensor the ENGINE's stream may write.  torch's caching allocator only orders the reuse of a block against
@@ -355,7 +357,8 @@ def _solve_distributed(engine, program=None, group=None, profile: Optional[List[
                             'ms_verdict': st.get('ms_verdict', 0.0), 'ms_region': st.get('ms_region', 0.0),
                             'ms_children': st.get('ms_children', 0.0), 'local_candidates': st['n'], 'sharded': sharded,
                             **{key: st.get(key, 0) for key in ('ms_theta', 'ms_x', 'ms_region2', 'n_x_items', 'n_opt', 'n_theta_items',
-                                                               'dict_read_bytes', 'dict_write_bytes')}})
+                                                               'dict_read_bytes', 'dict_write_bytes', 'ms_kkt', 'ms_xq', 'n_xq_items',
+                                                               'xq_pivots', 'xq_record')}})
         if not gen_children or total['n_children'] == 0:
             break
         engine.advance()

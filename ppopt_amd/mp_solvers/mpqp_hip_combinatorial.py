@@ -181,6 +181,8 @@ def _solve(program, num_cores: int = -1, device: int = 0, profile: Optional[List
                             'ms_theta': float(st.ms_theta), 'ms_x': float(st.ms_x), 'ms_region2': float(st.ms_region2),
                             'n_x_items': int(st.n_x_items), 'n_opt': int(st.n_opt), 'n_theta_items': int(st.n_theta_items),
                             'dict_read_bytes': int(st.dict_read_bytes), 'dict_write_bytes': int(st.dict_write_bytes),
+                            'ms_kkt': float(st.ms_kkt), 'ms_xq': float(st.ms_xq), 'n_xq_items': int(st.n_xq_items), 'xq_pivots': int(st.xq_pivots),
+                            'xq_record': [int(st.xq_record_ints), int(st.xq_record_rows), int(st.xq_record_cols)],
                             'ms_wall': (time.perf_counter() - t0) * 1e3})
         if not gen_children or st.n_children == 0:
             break

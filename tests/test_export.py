@@ -161,3 +161,46 @@ def test_export_tables_share_hyperplanes_and_matlab_file(tmp_path):
     text = (tmp_path / 'ppopt_solution.m').read_text()
     assert text.startswith('function [x, region] = ppopt_solution(theta)') and 'plane_normal' in text
     assert generate_code_js(sol).count('function ') == 2
+
+
+# ---- the reference's own format (uPOP payload), against fixtures produced by the reference itself -------------------------
+@pytest.mark.parametrize('name', ['transport_mpqp', 'c1_transport_mplp', 'rand_5_3_8_s3'])
+def test_upop_payload_equals_the_reference(name):
+    """tests/golden/export_*.npz (oracle/ref_harness/gen_export_goldens.py): for a solution the reference computed, the text its
+    generate_code_cpp / generate_code_js paste into the uPOP templates, the find_unique_hyperplanes tables and the .mat
+    structure of generate_code_matlab.  ppopt_amd.upop.upop_payload must reproduce all of it exactly -- same names, same order,
+    same digits."""
+    import scipy.io as sio
+    from ppopt_amd.upop import upop_payload as up
+    g = numpy.load(os.path.join(GOLDEN, f'export_{name}.npz'))
+    n_x, n_t = int(g['n_x']), int(g['n_t'])
+
+    class Prog(_Program):
+        def num_x(self):
+            return n_x
+    packed = golden_regions(g)
+    keys = sorted(packed, key=lambda k: (len(k), list(k)))
+    regs = []
+    for j in g['solution_order'].tolist():      # the reference's solution order
+        q = packed[keys[j]]
+        regs.append(CriticalRegion(q['A'], q['b'].reshape(-1, 1), q['C'], q['d'].reshape(-1, 1), q['E'], q['f'].reshape(-1, 1), list(keys[j])))
+    prog = Prog(g['prog_c'], g['prog_H'], g['prog_Q'] if 'prog_Q' in g.files else None, g['prog_c_c'], g['prog_c_t'], g['prog_Q_t'], n_t)
+    sol = Solution(prog, regs, is_overlapping=bool(g['is_overlapping']))
+    t = up.upop_tables(sol)
+    for key in ('fundamental_c', 'original_c', 'parity_c', 'fundamental_f', 'original_f', 'parity_f'):
+        assert t[key] == g['T_' + key].tolist(), key
+    assert up.payload_cpp(sol, 'double') == str(g['payload_cpp'])
+    assert up.payload_js(sol) == str(g['payload_js'])
+    m = up.matlab_struct(sol)
+    for key in ('constraint_block', 'constraint_vector', 'function_block', 'function_vec', 'Q', 'H', 'c', 'c_c', 'c_t', 'Q_t'):
+        assert numpy.array_equal(numpy.atleast_2d(numpy.asarray(m[key], dtype=float)), numpy.atleast_2d(g['M_' + key])), key
+    assert numpy.array_equal(numpy.asarray(m['region_list']).ravel(), g['M_region_list'].ravel())
+    assert int(m['num_regions']) == int(g['M_num_regions'].ravel()[0])
+    # and the file written by save_matlab loads back to the same structure
+    import tempfile
+    with tempfile.TemporaryDirectory() as tmp:
+        path = os.path.join(tmp, 's.mat')
+        up.save_matlab(sol, path)
+        back = sio.loadmat(path)['upop_solution'][0, 0]
+        assert set(back.dtype.names) == {k[2:] for k in g.files if k.startswith('M_')}
+        assert numpy.array_equal(back['constraint_block'], g['M_constraint_block'])

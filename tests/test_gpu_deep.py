@@ -1,0 +1,239 @@
+"""The benchmarked solves themselves against the REAL reference, candidate by candidate (tests/golden/c4_deep.npz, c3_deep.npz:
+every candidate of every benchmarked level run through the reference's own check_feasibility / check_optimality /
+gen_cr_from_active_set by oracle/ref_harness/gen_deep_goldens.py), and config 5 against its golden verdicts.
+
+Bars (north_star): candidate lists, verdicts, the set of region active sets and every region's omega / lambda / regular index
+sets bit-exact; coefficients within 1e-8.  A difference is accepted only for an active set listed in conftest.KNIFE_EDGE_* and
+knife-edge by conftest.is_knife_edge; the number used is recorded.
+"""
+import os
+import warnings
+
+import numpy
+import pytest
+
+from conftest import GOLDEN, consume_exception, is_knife_edge, load_golden, rel_err, rows_match
+
+pytestmark = pytest.mark.gpu
+
+COEF_TOL = 1e-8
+
+
+def unpad(row):
+    return [int(v) for v in row if v >= 0]
+
+
+def digest(arrs):
+    return numpy.array([[a.sum(), (a * a).sum()] for a in arrs])
+
+
+def run_deep(name, base_golden, oracle):
+    from ppopt_amd.region_batch import RegionBatch
+    from test_gpu_parity import engine_from_golden
+    path = os.path.join(GOLDEN, name + '_deep.npz')
+    if not os.path.exists(path):
+        pytest.skip(f'{name}_deep.npz has not been generated')
+    d = numpy.load(path)
+    g = load_golden(base_golden)
+    P = oracle.problem_from_golden(g)
+    n_levels = sum(1 for key in d.files if key.endswith('_verdict') and key.startswith('L'))
+    eng = engine_from_golden(g)
+    eng.pruned_clear()
+    eng.frontier_root()
+    offenders = []
+    used = 0
+    regions = {}
+    n_cand = 0
+    for lev in range(n_levels):
+        gen = lev + 1 != n_levels
+        st = eng.level_run(gen)
+        cands, status = eng.frontier_get(), eng.level_status()
+        gc, gv = d[f'L{lev}_cands'].astype(numpy.int32), d[f'L{lev}_verdict']
+        if used == 0 and not offenders:
+            assert numpy.array_equal(cands, gc), f'{name} level {lev + 1}: candidate list differs from the reference run'
+            for j in numpy.flatnonzero(status != gv).tolist():
+                key = tuple(int(v) for v in cands[j])
+                if consume_exception('verdict', name + '_deep', key, f'gpu {int(status[j])} reference {int(gv[j])}') and is_knife_edge(P, list(key)):
+                    used += 1
+                else:
+                    offenders.append(('verdict', lev + 1, key, int(status[j]), int(gv[j]), float(d[f'L{lev}_cond'][j])))
+        n_cand += len(cands)
+        if st.n_regions:
+            hd, hi, er, kk, slots = eng.level_regions_slots()
+            for r in RegionBatch(hd, hi, er, eng.n_x, eng.n_t, eng.n_c, eng.n_tc, kk, slots).regions():
+                regions[tuple(r.active_set)] = r
+        if not gen or st.n_children == 0:
+            break
+        eng.frontier_advance()
+    eng.close()
+    assert n_cand == sum(len(d[f'L{i}_verdict']) for i in range(n_levels))
+    # ---- the region set: exactly the reference's active sets -----------------------------------------------------------
+    ref_keys = [tuple(int(v) for v in row[:k]) for row, k in zip(d['R_active'], d['R_k'])]
+    ref_index = {key: i for i, key in enumerate(ref_keys) if len(key) > 0}
+    for key in set(ref_index) ^ set(regions):
+        side = 'reference only' if key in ref_index else 'gpu only'
+        if not (consume_exception('region', name + '_deep', key, side) and is_knife_edge(P, list(key))):
+            offenders.append(('region', key, side))
+    # ---- every region: index sets bit-exact, coefficient digests within 1e-8 per element ---------------------------------
+    S = d['S_digest']
+    for key, r in regions.items():
+        i = ref_index.get(key)
+        if i is None:
+            continue
+        same = (r.omega_set == unpad(d['R_omega'][i]) and r.lambda_set == unpad(d['R_lambda'][i])
+                and r.regular_set == [unpad(d['R_regular_idx'][i]), unpad(d['R_regular_con'][i])] and r.E.shape[0] == int(d['R_nE'][i]))
+        if not same:
+            if not (consume_exception('facets', name + '_deep', key) and is_knife_edge(P, list(key), cond_limit=1e6)):
+                offenders.append(('facets', key))
+            continue
+        arrs = (r.A, r.b, r.C, r.d, r.E, r.f)
+        got = digest(arrs)
+        for j, a in enumerate(arrs):
+            # every element within tol (1 + |ref|)  =>  |sum - sum_ref| <= tol (n + sum|ref|) <= tol (n + sqrt(n * sumsq_ref))
+            bound = COEF_TOL * (a.size + numpy.sqrt(a.size * S[i, j, 1]))
+            assert abs(got[j, 0] - S[i, j, 0]) <= bound, (name, key, 'sum', j)
+            assert abs(got[j, 1] - S[i, j, 1]) <= 4 * COEF_TOL * (a.size + S[i, j, 1]), (name, key, 'sumsq', j)
+    # ---- the strided sample with full coefficient arrays ---------------------------------------------------------------------
+    for pos, i in enumerate(d['F_index'].tolist()):
+        key = ref_keys[i]
+        r = regions.get(key)
+        if r is None or key not in ref_index:
+            continue
+        k, ne = int(d['R_k'][i]), int(d['R_nE'][i])
+        assert rel_err(r.A, d['F_A'][pos]) <= COEF_TOL and rel_err(r.b.ravel(), d['F_b'][pos]) <= COEF_TOL, key
+        assert rel_err(r.C, d['F_C'][pos][:k]) <= COEF_TOL and rel_err(r.d.ravel(), d['F_d'][pos][:k]) <= COEF_TOL, key
+        if r.E.shape[0] == ne:
+            assert rows_match(r.E, r.f, d['F_E'][pos][:ne], d['F_f'][pos][:ne], COEF_TOL), key
+    assert not offenders, f'{name}: {len(offenders)} differences from the reference run that are not listed knife-edge exceptions: {offenders[:40]}'
+    return n_cand, len(regions)
+
+
+def test_config4_every_candidate_and_region_equals_the_reference(oracle):
+    """bench.py's workload: generate_mpqp(20,8,20,seed=0), levels 1-5 -- 1,151,349 candidates, every one with the reference's
+    verdict, and exactly the reference's regions."""
+    n_cand, n_reg = run_deep('c4', 'c4_rand_20_8_20_s0', oracle)
+    assert n_cand == 1151349
+
+
+def test_config3_every_candidate_and_region_equals_the_reference(oracle):
+    """bench.py --workload c3: quad tank N=10, levels 1-4."""
+    run_deep('c3', 'c3_quadtank_n10', oracle)
+
+
+def test_config5_verdicts_equal_the_reference_where_the_kkt_matrix_is_well_conditioned(oracle):
+    """Config 5 (control allocation, Q of rank 4 of 8): the reference decides its first level with KKT matrices of condition
+    4e16 and aborts with LinAlgError; every candidate whose KKT matrix the reference could solve at cond < 1e10 (or that it
+    rejected before the KKT solve) must carry the reference's verdict here -- the GPU mirror of
+    tests/test_oracle_goldens.py::test_control_allocation_singular_kkt."""
+    from test_gpu_parity import engine_from_golden, run_levels
+    g = load_golden('c5_control_allocation')
+    P = oracle.problem_from_golden(g)
+    eng = engine_from_golden(g)
+    levels, regions = run_levels(eng)
+    got = {}
+    for cands, status, _ in levels:
+        for cand, v in zip(cands.tolist(), status.tolist()):
+            got[tuple(cand)] = int(v)
+    checked = skipped = 0
+    offenders = []
+    for i in range(int(g['n_levels'])):
+        for cand, v, cond in zip(g[f'L{i}_cands'].tolist(), g[f'L{i}_verdict'].tolist(), g[f'L{i}_cond'].tolist()):
+            key = tuple(cand)
+            if not (numpy.isnan(cond) or cond < 1e10):
+                skipped += 1
+                continue
+            if key not in got:
+                continue      # pruned upstream by a verdict the reference took at cond >= 1e10
+            checked += 1
+            if got[key] != int(v):
+                if not (consume_exception('verdict', 'c5_control_allocation', key, f'gpu {got[key]} reference {v}') and is_knife_edge(P, cand)):
+                    offenders.append((key, got[key], int(v), cond))
+    eng.close()
+    assert checked >= 100, (checked, skipped)
+    assert not offenders, offenders[:40]
+
+
+def test_out_of_spare_region_slots_repeats_the_solve_and_loses_nothing(monkeypatch):
+    """late optimal candidates beyond the spare slots of an overlapped region launch used to be demoted to
+    'feasible'.  Now the level fails with MPC_ERR_CAPACITY and the driver repeats the solve without the overlap.  Forced here:
+    every level overlaps (MPC_ROVERLAP_MIN=0), five optimal candidates are held back for the late path (MPC_TEST_LATE=5) and the
+    launch reserves 1,030 slots fewer than it would (MPC_TEST_SPARE)."""
+    from ppopt_amd import Solver, _lib
+    from ppopt_amd.mp_solvers import mpqp_hip_combinatorial
+    from test_host_logic import build_program
+
+    def solve():
+        with warnings.catch_warnings():
+            warnings.simplefilter('ignore')
+            prog = build_program(load_golden('rand_6_3_12_s1'), Solver())
+        sol = mpqp_hip_combinatorial.solve(prog)
+        eng = prog.engine(0)
+        return {tuple(r.active_set): r for r in sol.critical_regions}, prog, eng
+
+    base, _, _ = solve()
+    with monkeypatch.context() as m:
+        m.setenv('MPC_TEST_LATE', '5')
+        m.setenv('MPC_ROVERLAP_MIN', '0')
+        m.setenv('MPC_TEST_SPARE', '1030')
+        # the level itself reports the shortage ...
+        with warnings.catch_warnings():
+            warnings.simplefilter('ignore')
+            prog = build_program(load_golden('rand_6_3_12_s1'), Solver())
+        with pytest.raises(_lib.MpcCapacityError):
+            mpqp_hip_combinatorial._solve(prog)
+        prog.release_engine()
+        # ... and the public driver repeats and returns everything
+        other, _, _ = solve()
+    assert set(other) == set(base) and len(base) > 20
+    for key, r1 in base.items():
+        r2 = other[key]
+        assert r1.omega_set == r2.omega_set and r1.lambda_set == r2.lambda_set and r1.regular_set == r2.regular_set
+        for fld in ('A', 'b', 'C', 'd', 'E', 'f'):
+            assert numpy.allclose(getattr(r1, fld), getattr(r2, fld), rtol=0, atol=COEF_TOL), (key, fld)
+
+
+@pytest.mark.parametrize('name', ['transport_mpqp', 'c1_transport_mplp', 'rand_5_3_8_s3'])
+def test_upop_payload_of_a_device_solution_describes_the_reference_solution(name):
+    """SURVEY.md 8(f)4 on the device path: the program is presolved and solved on the GPU, exported in the reference's uPOP format
+    (ppopt_amd.upop.upop_payload), and the export is compared with the fixture the reference produced for ITS solution of the
+    same program (tests/golden/export_*.npz).  The two solutions list their regions in different orders, so the comparison is
+    order-free: the same set of fundamental hyperplanes and of fundamental functions (to 1e-8, up to the sign the first
+    occurrence fixes), the same number of rows, and every region's rows rebuilt from the tables equal to its E, f."""
+    from ppopt_amd import MPLP_Program, MPQP_Program, problem_generator as pg
+    from ppopt_amd.mp_solvers.solve_mpqp import mpqp_algorithm, solve_mpqp
+    from ppopt_amd.upop import upop_payload as up
+    g = numpy.load(os.path.join(GOLDEN, f'export_{name}.npz'))
+    d = {'transport_mpqp': pg.transport_mpqp_data, 'c1_transport_mplp': pg.transport_mplp_data,
+         'rand_5_3_8_s3': lambda: pg.generate_mpqp_data(5, 3, 8, 3)}[name]()
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        if d['Q'] is None:
+            prog = MPLP_Program(d['A'], d['b'], d['c'], d['H'], d['A_t'], d['b_t'], d['F'], equality_indices=list(d['equality_indices']))
+        else:
+            prog = MPQP_Program(d['A'], d['b'], d['c'], d['H'], d['Q'], d['A_t'], d['b_t'], d['F'], equality_indices=list(d['equality_indices']))
+        sol = solve_mpqp(prog, mpqp_algorithm.combinatorial)
+    t = up.upop_tables(sol)
+    assert t['num_regions'] == len(g['R_k']) and t['num_constraints'] == int(g['M_constraint_block'].shape[0])
+    assert len(t['fundamental_c']) == len(g['T_fundamental_c']) and len(t['fundamental_f']) == len(g['T_fundamental_f'])
+
+    def canon(rows):
+        out = []
+        for r in rows:
+            nz = numpy.flatnonzero(numpy.abs(r) > 1e-9)
+            s = 1.0 if len(nz) == 0 or r[nz[0]] > 0 else -1.0
+            out.append(tuple(numpy.round(s * r, 7) + 0.0))
+        return sorted(out)
+    mine = numpy.hstack([t['E'], t['f']])[t['fundamental_c']]
+    ref = numpy.hstack([g['M_constraint_block'], g['M_constraint_vector']])[g['T_fundamental_c']]
+    assert canon(mine) == canon(ref)
+    mine_f = numpy.hstack([t['A'], t['b']])[t['fundamental_f']]
+    ref_f = numpy.hstack([g['M_function_block'], g['M_function_vec']])[g['T_fundamental_f']]
+    assert numpy.allclose(numpy.array(canon(mine_f)), numpy.array(canon(ref_f)), rtol=0, atol=1e-6)
+    # the tables reproduce every region's own rows
+    planes = numpy.hstack([t['E'], t['f']])[t['fundamental_c']]
+    for j, r in enumerate(sol.critical_regions):
+        lo, hi = t['region_boundary_index'][j], t['region_boundary_index'][j + 1]
+        rebuilt = numpy.array([t['parity_c'][i] * planes[t['original_c'][i]] for i in range(lo, hi)])
+        assert numpy.allclose(rebuilt, numpy.hstack([r.E, r.f]), rtol=0, atol=2e-9)
+    text = up.payload_cpp(sol, 'double')
+    assert text.count('\n') == str(g['payload_cpp']).count('\n') and f'const int num_regions = {len(g["R_k"])};' in text

@@ -67,3 +67,36 @@ def test_control_allocation_singular_kkt(oracle):
                 assert P.full_process(cand) == int(v)
                 checked += 1
     assert checked >= 1
+
+
+@pytest.mark.parametrize('name,base', [('c4', 'c4_rand_20_8_20_s0'), ('c3', 'c3_quadtank_n10')])
+def test_deep_goldens_sample(oracle, name, base):
+    """The benchmarked solves as the REAL reference ran them (tests/golden/c4_deep.npz, c3_deep.npz: every candidate of every
+    benchmarked level, oracle/ref_harness/gen_deep_goldens.py).  On the CPU the oracle is pinned to an evenly strided sample
+    of them -- every 150th candidate of every level (all of levels 1-2), every 25th region -- sized for a suite of a few minutes;
+    the GPU suite (tests/test_gpu_deep.py) compares all of them."""
+    import os
+    from conftest import GOLDEN
+    path = os.path.join(GOLDEN, name + '_deep.npz')
+    if not os.path.exists(path):
+        pytest.skip(f'{name}_deep.npz has not been generated')
+    d = numpy.load(path)
+    P = oracle.problem_from_golden(load_golden(base))
+    n_levels = sum(1 for key in d.files if key.startswith('L') and key.endswith('_verdict'))
+    for lev in range(n_levels):
+        cands, gv = d[f'L{lev}_cands'].astype(numpy.int32), d[f'L{lev}_verdict']
+        step = 1 if len(cands) <= 4000 else 150
+        status, _ = P.check_level(cands[::step], threads=8, want_regions=False)
+        assert numpy.array_equal(status, gv[::step]), f'{name} level {lev + 1}: {int((status != gv[::step]).sum())} sampled verdicts differ'
+    unpad = lambda a: [int(v) for v in a if v >= 0]
+    for i in range(0, len(d['R_k']), 25):
+        k = int(d['R_k'][i])
+        if k == 0:
+            continue
+        v, r = P.gen_cr_from_active_set(d['R_active'][i][:k].astype(numpy.int32))
+        assert v == 3, (name, i)
+        assert r['omega_set'] == unpad(d['R_omega'][i]) and r['lambda_set'] == unpad(d['R_lambda'][i]), (name, i)
+        assert r['regular_set'] == [unpad(d['R_regular_idx'][i]), unpad(d['R_regular_con'][i])], (name, i)
+        assert r['E'].shape[0] == int(d['R_nE'][i])
+        for j, a in enumerate((r['A'], r['b'], r['C'], r['d'], r['E'], r['f'])):
+            assert abs(a.sum() - d['S_digest'][i, j, 0]) <= 1e-8 * (a.size + numpy.sqrt(a.size * d['S_digest'][i, j, 1])), (name, i, j)
