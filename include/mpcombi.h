@@ -117,6 +117,13 @@ int64_t mpc_region_doubles(const mpc_handle *h);
 int64_t mpc_region_ints(const mpc_handle *h);
 /* dynamic LDS bytes per wavefront of the verdict / region kernels (for reports) */
 int32_t mpc_lds_bytes(const mpc_handle *h, int32_t which);
+/* The one-off dense blocks of the program as the device holds them (diagnostics, tests).  For a positive definite Q they are
+ * formed at mpc_create by the MFMA set-up kernel (csrc/setup_mfma.hip: blocked Cholesky of Q and the products below as
+ * v_mfma_f64_16x16x4_f64 tiles) and replace the per-active-set dense KKT factorisation of MPQP_Program.optimal_control_law
+ * (mpqp_program.py:182-198):  which = 0: W = A Q^-1 A' (n_c x n_c), 1: UV = [A Q^-1 c + b | A Q^-1 H + F] (n_c x (n_t+1)),
+ * 2: Gt = A Q^-1 (n_c x n_x), 3: X0H = -Q^-1 [c | H] (n_x x (n_t+1)), 4: A A' (n_c x n_c; any program).  *n = number of doubles
+ * (0 for which < 4 when Q is absent or not positive definite); MPC_ERR_CAPACITY when cap < *n. */
+int mpc_program_block(mpc_handle *h, int32_t which, double *out_host, int64_t cap, int64_t *n);
 /* the HIP stream the handle launches on (hipStream_t as void*) */
 void *mpc_stream(const mpc_handle *h);
 

@@ -168,5 +168,70 @@ def main(name, workers):
           f'({os.path.getsize(path) / 1e6:.1f} MB)', flush=True)
 
 
+def main_c5(workers):
+    """Config 5 (doc/control_allocation, Q of rank 4 of 8).  The reference's own driver cannot walk this program: its first
+    level is decided by KKT matrices of condition 4e16 (garbage regions or LinAlgError, mpqp_program.py:187), so
+    c5_control_allocation.npz holds 29 candidates.  Here the tree is walked with the rule the build uses for such sets -- a
+    candidate whose KKT matrix is singular or ill-conditioned (cond >= 1e10) is EXPANDED, never trusted and never pruned
+    (DESIGN.md 3.5, MPC_SINGULAR_KKT) -- and EVERY candidate met is put through the reference's primitives (classify;
+    LinAlgError -> verdict 4) with cond(KKT) recorded where the reference got as far as the KKT solve.  Tests pin the
+    verdicts with cond < 1e10 (or taken before any KKT solve: infeasible / not optimal) on the candidates both sides visit."""
+    import multiprocess
+    d = gg.pg.control_allocation_data()
+    program = gg.build_reference_program(d)
+    n_c = program.num_constraints()
+    max_depth = max(program.num_x(), program.num_t())
+    out = {}
+    t_all = time.time()
+    n_pinned = n_all = 0
+    regions = []
+    pruned_by_size = {}
+    to_check = [tuple(c) for c in generate_children_sets(program.equality_indices, n_c)]
+    with multiprocess.Pool(workers, initializer=_init, initargs=(program,)) as pool:
+        for lev in range(max_depth):
+            to_check = sorted(to_check)
+            res = pool.map(_work, to_check, chunksize=32)
+            verdicts = numpy.array([r[0] for r in res], dtype=numpy.uint8)
+            conds = numpy.array([r[2] for r in res], dtype=numpy.float64)
+            pinned = numpy.isnan(conds) | (conds < 1e10)
+            n_pinned += int(pinned.sum())
+            n_all += len(to_check)
+            print(f'  level {lev + 1}: {len(to_check)} candidates, reference hist {numpy.bincount(verdicts, minlength=5)}, pinned {int(pinned.sum())}', flush=True)
+            out[f'L{lev}_cands'] = numpy.array(to_check, dtype=numpy.uint8).reshape(len(to_check), lev + 1)
+            out[f'L{lev}_verdict'] = verdicts
+            out[f'L{lev}_cond'] = conds
+            regions.extend(r[1] for r, ok in zip(res, pinned) if r[0] == 3 and ok)
+            if lev + 1 == max_depth:
+                break
+            expand = [(v in (1, 3)) or not ok for v, ok in zip(verdicts.tolist(), pinned.tolist())]
+            parents = [c for c, e in zip(to_check, expand) if e]
+            kids = fast_children(parents, n_c, pruned_by_size)
+            pruned_by_size[lev + 1] = {c for c, e in zip(to_check, expand) if not e}
+            to_check = kids
+            if not to_check:
+                break
+    out['n_levels'] = numpy.array(lev + 1)
+    regions = sorted(regions, key=lambda r: (len(r.active_set), list(r.active_set)))
+    out['R_k'] = numpy.array([len(r.active_set) for r in regions], dtype=numpy.int16)
+    out['R_active'] = gg.pad_int([r.active_set for r in regions]).astype(numpy.int16)
+    out['R_nE'] = numpy.array([r.E.shape[0] for r in regions], dtype=numpy.int16)
+    out['R_omega'] = gg.pad_int([r.omega_set for r in regions]).astype(numpy.int16)
+    out['R_lambda'] = gg.pad_int([r.lambda_set for r in regions]).astype(numpy.int16)
+    out['R_regular_idx'] = gg.pad_int([r.regular_set[0] for r in regions]).astype(numpy.int16)
+    out['R_regular_con'] = gg.pad_int([r.regular_set[1] for r in regions]).astype(numpy.int16)
+    dig = numpy.zeros((len(regions), 6, 2))
+    for i, r in enumerate(regions):
+        for j, arr in enumerate((r.A, r.b, r.C, r.d, r.E, r.f)):
+            dig[i, j] = (arr.sum(), (arr * arr).sum())
+    out['S_digest'] = dig
+    out['seconds'] = numpy.array(time.time() - t_all)
+    path = os.path.join(gg.GOLDEN, 'c5_deep.npz')
+    numpy.savez_compressed(path, **out)
+    print(f'== c5: {n_all} candidates, {n_pinned} pinned, {len(regions)} pinned regions, {time.time() - t_all:.0f}s -> {path}', flush=True)
+
+
 if __name__ == '__main__':
-    main(sys.argv[1], int(sys.argv[2]) if len(sys.argv) > 2 else 6)
+    if sys.argv[1] == 'c5':
+        main_c5(int(sys.argv[2]) if len(sys.argv) > 2 else 2)
+    else:
+        main(sys.argv[1], int(sys.argv[2]) if len(sys.argv) > 2 else 6)

@@ -80,6 +80,7 @@ def load():
         'mpc_last_error': (ctypes.c_char_p, [H]),
         'mpc_mask_words': (ctypes.c_int32, [H]),
         'mpc_set_region_overlap': (ctypes.c_int, [H, ctypes.c_int32]),
+        'mpc_program_block': (ctypes.c_int, [H, ctypes.c_int32, _dp, ctypes.c_int64, _lp]),
         'mpc_region_doubles': (ctypes.c_int64, [H]),
         'mpc_region_ints': (ctypes.c_int64, [H]),
         'mpc_lds_bytes': (ctypes.c_int32, [H, ctypes.c_int32]),
@@ -148,7 +149,7 @@ def load():
 
 
 EXPORTED_SYMBOLS = ['mpc_device_count', 'mpc_version', 'mpc_last_global_error', 'mpc_create', 'mpc_destroy',
-                    'mpc_last_error', 'mpc_mask_words', 'mpc_set_region_overlap', 'mpc_region_doubles', 'mpc_region_ints', 'mpc_lds_bytes', 'mpc_stream',
+                    'mpc_last_error', 'mpc_mask_words', 'mpc_set_region_overlap', 'mpc_program_block', 'mpc_region_doubles', 'mpc_region_ints', 'mpc_lds_bytes', 'mpc_stream',
                     'mpc_frontier_root', 'mpc_frontier_set', 'mpc_frontier_set_device', 'mpc_frontier_info',
                     'mpc_frontier_get', 'mpc_pruned_clear', 'mpc_pruned_add', 'mpc_pruned_add_device',
                     'mpc_pruned_count', 'mpc_pruned_get', 'mpc_level_run', 'mpc_level_run_ex', 'mpc_level_status', 'mpc_level_start', 'mpc_level_stream_info', 'mpc_level_chunk_wait', 'mpc_level_wait', 'mpc_level_stream_fixup', 'mpc_base_result', 'mpc_level_regions', 'mpc_compact_strides',
@@ -249,6 +250,15 @@ class Engine:
         if rc != MPC_OK:
             cls = MpcCapacityError if rc == 3 and what in ('mpc_level_run', 'mpc_level_wait') else MpcError
             raise cls(f'{what} failed ({rc}): {self._L.mpc_last_error(self._h).decode()}')
+
+    def program_block(self, which: int) -> numpy.ndarray:
+        """One of the program's one-off dense blocks as the device holds it (mpc_program_block): 0 W, 1 UV, 2 Gt, 3 X0H, 4 A A'."""
+        n = ctypes.c_int64(0)
+        shape = {0: (self.n_c, self.n_c), 1: (self.n_c, self.n_t + 1), 2: (self.n_c, self.n_x), 3: (self.n_x, self.n_t + 1),
+                 4: (self.n_c, self.n_c)}[which]
+        out = numpy.zeros(shape)
+        self._check(self._L.mpc_program_block(self._h, which, out.ctypes.data_as(_dp), out.size, ctypes.byref(n)), 'mpc_program_block')
+        return out if n.value else numpy.zeros((0, 0))
 
     def set_region_overlap(self, on: bool):
         self._check(self._L.mpc_set_region_overlap(self._h, 1 if on else 0), 'mpc_set_region_overlap')

@@ -27,6 +27,7 @@
 #include "locate.hpp"
 #include "graph.hpp"
 #include "qp.hpp"
+#include "setup_mfma.hpp"
 #include <rocprim/device/device_radix_sort.hpp>
 
 using namespace mpc;
@@ -522,9 +523,12 @@ static int create_fill(const mpc_problem *p, int32_t device, void *stream, mpc_h
 
     const int nr = nt + 1;
     // ---- host-side one-off blocks ----------------------------------------------------------------------
+    // W = A Q^-1 A', UV, G', X0H and A A' are formed on the DEVICE by the MFMA set-up kernel (setup_mfma.hip) once the raw
+    // matrices are in HBM (below).  MPC_HOST_SETUP=1 keeps the scalar host computation instead (A/B comparisons, tests).
+    const bool host_setup = [] { const char *ev = std::getenv("MPC_HOST_SETUP"); return ev && ev[0] == '1'; }();
     std::vector<double> W, UV, Gt, X0H;
     int mode = 1;
-    if (p->Q) {
+    if (p->Q && host_setup) {
         std::vector<double> L(p->Q, p->Q + (size_t)nx * nx);
         for (int i = 0; i < nx; ++i) for (int j = 0; j < i; ++j) { const double s = 0.5 * (L[(size_t)i * nx + j] + L[(size_t)j * nx + i]); L[(size_t)i * nx + j] = s; L[(size_t)j * nx + i] = s; }
         if (cholesky(L, nx)) {
@@ -552,7 +556,6 @@ static int create_fill(const mpc_problem *p, int32_t device, void *stream, mpc_h
             }
         }
     }
-    h->kkt_mode = mode;
     const int cols = 1 + nx + nt, rows_x = nc + ntc;
     std::vector<double> base((size_t)rows_x * cols, 0.0);
     for (int i = 0; i < nc; ++i) {
@@ -676,14 +679,20 @@ static int create_fill(const mpc_problem *p, int32_t device, void *stream, mpc_h
     const size_t oA = put(p->A, (size_t)nc * nx), ob = put(p->b, nc), oF = put(p->F, (size_t)nc * nt), oc = put(p->c, nx), oH = put(p->H, (size_t)nx * nt);
     const size_t oQ = put(p->Q ? p->Q : zeros.data(), (size_t)nx * nx);
     const size_t oAt = put(ntc ? p->A_t : zeros.data(), (size_t)std::max(ntc * nt, 1)), obt = put(ntc ? p->b_t : zeros.data(), std::max(ntc, 1));
-    const size_t oW = put(mode == 0 ? W.data() : zeros.data(), mode == 0 ? W.size() : 1), oUV = put(mode == 0 ? UV.data() : zeros.data(), mode == 0 ? UV.size() : 1);
-    const size_t oGt = put(mode == 0 ? Gt.data() : zeros.data(), mode == 0 ? Gt.size() : 1), oX0H = put(mode == 0 ? X0H.data() : zeros.data(), mode == 0 ? X0H.size() : 1);
-    std::vector<double> AAT((size_t)nc * nc, 0.0);
-    for (int i = 0; i < nc; ++i) for (int j = 0; j <= i; ++j) {
-        double sdot = 0; for (int l = 0; l < nx; ++l) sdot += p->A[(size_t)i * nx + l] * p->A[(size_t)j * nx + l];
-        AAT[(size_t)i * nc + j] = sdot; AAT[(size_t)j * nc + i] = sdot;
+    // the blocks the set-up kernel fills are reserved at full size (zero until then); with MPC_HOST_SETUP=1 they are filled here
+    auto put_or_reserve = [&](const std::vector<double> &v, size_t cnt) { std::vector<double> z; if (v.empty()) z.assign(std::max<size_t>(cnt, 1), 0.0); return put(v.empty() ? z.data() : v.data(), std::max<size_t>(cnt, 1)); };
+    const bool dev_schur = p->Q && !host_setup;
+    const size_t oW = put_or_reserve(W, (mode == 0 || dev_schur) ? (size_t)nc * nc : 1), oUV = put_or_reserve(UV, (mode == 0 || dev_schur) ? (size_t)nc * nr : 1);
+    const size_t oGt = put_or_reserve(Gt, (mode == 0 || dev_schur) ? (size_t)nc * nx : 1), oX0H = put_or_reserve(X0H, (mode == 0 || dev_schur) ? (size_t)nx * nr : 1);
+    std::vector<double> AAT;
+    if (host_setup) {
+        AAT.assign((size_t)nc * nc, 0.0);
+        for (int i = 0; i < nc; ++i) for (int j = 0; j <= i; ++j) {
+            double sdot = 0; for (int l = 0; l < nx; ++l) sdot += p->A[(size_t)i * nx + l] * p->A[(size_t)j * nx + l];
+            AAT[(size_t)i * nc + j] = sdot; AAT[(size_t)j * nc + i] = sdot;
+        }
     }
-    const size_t oAAT = put(AAT.data(), AAT.size());
+    const size_t oAAT = put_or_reserve(AAT, (size_t)nc * nc);
     const size_t obase = put(base.data(), base.size());
     const size_t od0 = put(d0.empty() ? zeros.data() : d0.data(), d0.empty() ? 1 : d0.size());
     const size_t od0T = put(d0T.empty() ? zeros.data() : d0T.data(), d0T.empty() ? 1 : d0T.size());
@@ -692,7 +701,33 @@ static int create_fill(const mpc_problem *p, int32_t device, void *stream, mpc_h
     const size_t otvr = put(tv_rows.empty() ? zeros.data() : tv_rows.data(), tv_rows.empty() ? 1 : tv_rows.size());
     HIP_TRY(nullptr, h->blocks.ensure(host.size() * sizeof(double), h->stream));
     HIP_TRY(nullptr, hipMemcpyAsync(h->blocks.p, host.data(), host.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    if (!host_setup) {
+        // ---- the dense Hessian factor and the one-off Schur blocks on the matrix cores (setup_mfma.hip) ----------------------
+        double *db = h->blocks.as<double>();
+        SetupJob job{};
+        job.nx = nx; job.nt = nt; job.nc = nc; job.NP = setup_pad16(nx); job.MP = setup_pad16(nc); job.RP = setup_pad16(nr);
+        job.A = db + oA; job.b = db + ob; job.F = db + oF; job.c = db + oc; job.H = db + oH; job.Q = p->Q ? db + oQ : nullptr;
+        job.W = db + oW; job.UV = db + oUV; job.Gt = db + oGt; job.X0H = db + oX0H; job.AAT = db + oAAT;
+        DevBuf work, jobbuf;
+        const size_t job_bytes = (sizeof(SetupJob) + 15) & ~size_t(15);
+        hipError_t e1 = work.ensure(setup_work_doubles(nx, nt, nc) * sizeof(double), h->stream);
+        hipError_t e2 = e1 == hipSuccess ? jobbuf.ensure(job_bytes + 16, h->stream) : e1;
+        int flag = 1;
+        if (e2 == hipSuccess) {
+            job.work = work.as<double>();
+            job.flag = reinterpret_cast<int *>(jobbuf.as<char>() + job_bytes);
+            e2 = hipMemcpyAsync(jobbuf.p, &job, sizeof(SetupJob), hipMemcpyHostToDevice, h->stream);
+            if (e2 == hipSuccess) e2 = setup_launch(jobbuf.as<SetupJob>(), 1, h->stream);
+            if (e2 == hipSuccess) e2 = hipMemcpyAsync(&flag, job.flag, sizeof(int), hipMemcpyDeviceToHost, h->stream);
+            if (e2 == hipSuccess && p->Q) { UV.assign((size_t)nc * nr, 0.0); e2 = hipMemcpyAsync(UV.data(), job.UV, UV.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream); }
+            if (e2 == hipSuccess) e2 = hipStreamSynchronize(h->stream);
+        }
+        work.release(); jobbuf.release();   // the stream has been synchronised (or nothing was queued)
+        if (e2 != hipSuccess) return fail(nullptr, MPC_ERR_HIP, std::string("MFMA set-up kernel: ") + hipGetErrorString(e2));
+        mode = (p->Q && flag == 0) ? 0 : 1;
+    }
     HIP_TRY(nullptr, hipStreamSynchronize(h->stream));
+    h->kkt_mode = mode;
     const double *d = h->blocks.as<double>();
     DevProblem P{};
     P.n_x = nx; P.n_t = nt; P.n_c = nc; P.n_eq = ne; P.n_tc = ntc; P.is_qp = h->is_qp; P.kkt_mode = mode;
@@ -857,6 +892,28 @@ int mpc_destroy(mpc_handle *h) {
 }
 
 int32_t mpc_mask_words(const mpc_handle *h) { return h ? h->mw : MPC_MASK_WORDS; }
+int mpc_program_block(mpc_handle *h, int32_t which, double *out, int64_t cap, int64_t *n_out) {
+    if (!h || !n_out) return MPC_ERR_INVALID;
+    const long long nc = h->n_c, nx = h->n_x, nr = h->n_t + 1;
+    const double *src = nullptr;
+    long long n = 0;
+    switch (which) {
+        case 0: src = h->Pv.W; n = nc * nc; break;
+        case 1: src = h->Pv.UV; n = nc * nr; break;
+        case 2: src = h->Pv.Gt; n = nc * nx; break;
+        case 3: src = h->Pv.X0H; n = nx * nr; break;
+        case 4: src = h->Pv.AAT; n = nc * nc; break;
+        default: return fail(h, MPC_ERR_INVALID, "mpc_program_block: which must be 0..4");
+    }
+    if (which < 4 && h->kkt_mode != 0) n = 0;   // the Schur blocks exist only for a positive definite Q
+    *n_out = n;
+    if (n == 0) return MPC_OK;
+    if (!out || cap < n) return fail(h, MPC_ERR_CAPACITY, "mpc_program_block: buffer too small");
+    HIP_TRY(h, hipSetDevice(h->device));
+    HIP_TRY(h, hipMemcpyAsync(out, src, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    return MPC_OK;
+}
 int mpc_set_region_overlap(mpc_handle *h, int32_t on) { if (!h) return MPC_ERR_INVALID; h->no_roverlap = !on; return MPC_OK; }
 int64_t mpc_region_doubles(const mpc_handle *h) { return h ? h->rec_d : 0; }
 int64_t mpc_region_ints(const mpc_handle *h) { return h ? h->rec_i : 0; }

@@ -122,11 +122,14 @@ def test_config3_every_candidate_and_region_equals_the_reference(oracle):
 
 def test_config5_verdicts_equal_the_reference_where_the_kkt_matrix_is_well_conditioned(oracle):
     """Config 5 (control allocation, Q of rank 4 of 8): the reference decides its first level with KKT matrices of condition
-    4e16 and aborts with LinAlgError; every candidate whose KKT matrix the reference could solve at cond < 1e10 (or that it
-    rejected before the KKT solve) must carry the reference's verdict here -- the GPU mirror of
-    tests/test_oracle_goldens.py::test_control_allocation_singular_kkt."""
+    4e16 and aborts with LinAlgError, so its own trace (c5_control_allocation.npz) is 29 candidates long.  c5_deep.npz
+    (oracle/ref_harness/gen_deep_goldens.py c5) holds the reference's verdict and cond(KKT) for every candidate of the tree
+    walked with ill-conditioned sets expanded -- 5,102 candidates, 4,395 of them decided by the reference before any KKT solve
+    or with cond < 1e10.  Every such candidate the device visits must carry the reference's verdict, and every such region
+    the reference's index sets."""
     from test_gpu_parity import engine_from_golden, run_levels
     g = load_golden('c5_control_allocation')
+    d = load_golden('c5_deep')
     P = oracle.problem_from_golden(g)
     eng = engine_from_golden(g)
     levels, regions = run_levels(eng)
@@ -134,23 +137,38 @@ def test_config5_verdicts_equal_the_reference_where_the_kkt_matrix_is_well_condi
     for cands, status, _ in levels:
         for cand, v in zip(cands.tolist(), status.tolist()):
             got[tuple(cand)] = int(v)
-    checked = skipped = 0
+    checked = 0
     offenders = []
-    for i in range(int(g['n_levels'])):
-        for cand, v, cond in zip(g[f'L{i}_cands'].tolist(), g[f'L{i}_verdict'].tolist(), g[f'L{i}_cond'].tolist()):
+    for i in range(int(d['n_levels'])):
+        for cand, v, cond in zip(d[f'L{i}_cands'].tolist(), d[f'L{i}_verdict'].tolist(), d[f'L{i}_cond'].tolist()):
             key = tuple(cand)
-            if not (numpy.isnan(cond) or cond < 1e10):
-                skipped += 1
+            if not (numpy.isnan(cond) or cond < 1e10) or key not in got:
                 continue
-            if key not in got:
-                continue      # pruned upstream by a verdict the reference took at cond >= 1e10
             checked += 1
             if got[key] != int(v):
-                if not (consume_exception('verdict', 'c5_control_allocation', key, f'gpu {got[key]} reference {v}') and is_knife_edge(P, cand)):
-                    offenders.append((key, got[key], int(v), cond))
+                if not (consume_exception('verdict', 'c5_deep', key, f'gpu {got[key]} reference {v}') and is_knife_edge(P, cand)):
+                    offenders.append(('verdict', key, got[key], int(v), cond))
+    mine = {tuple(r.active_set): r for r in regions}
+    n_regions = 0
+    for i in range(len(d['R_k'])):
+        key = tuple(int(v) for v in d['R_active'][i][:int(d['R_k'][i])])
+        r = mine.get(key)
+        if r is None:
+            continue      # reported above as a verdict difference if the device visited it
+        n_regions += 1
+        same = (r.omega_set == unpad(d['R_omega'][i]) and r.lambda_set == unpad(d['R_lambda'][i])
+                and r.regular_set == [unpad(d['R_regular_idx'][i]), unpad(d['R_regular_con'][i])] and r.E.shape[0] == int(d['R_nE'][i]))
+        if not same:
+            if not (consume_exception('facets', 'c5_deep', key) and is_knife_edge(P, list(key), cond_limit=1e6)):
+                offenders.append(('facets', key))
+            continue
+        for j, a in enumerate((r.A, r.b, r.C, r.d, r.E, r.f)):
+            S = d['S_digest'][i, j]
+            # cond < 1e10: the reference's own solve carries up to cond * eps of error, so 1e-8 relative is asked of cond <= 1e6 only
+            assert abs(a.sum() - S[0]) <= 1e-6 * (a.size + numpy.sqrt(a.size * S[1])), ('c5', key, j)
     eng.close()
-    assert checked >= 100, (checked, skipped)
-    assert not offenders, offenders[:40]
+    assert checked >= 2000 and n_regions >= 300, (checked, n_regions)
+    assert not offenders, (len(offenders), offenders[:40])
 
 
 def test_out_of_spare_region_slots_repeats_the_solve_and_loses_nothing(monkeypatch):
@@ -237,3 +255,75 @@ def test_upop_payload_of_a_device_solution_describes_the_reference_solution(name
         assert numpy.allclose(rebuilt, numpy.hstack([r.E, r.f]), rtol=0, atol=2e-9)
     text = up.payload_cpp(sol, 'double')
     assert text.count('\n') == str(g['payload_cpp']).count('\n') and f'const int num_regions = {len(g["R_k"])};' in text
+
+
+# ---- the dense Hessian factor and the one-off Schur blocks on the matrix cores (csrc/setup_mfma.hip) ---------------------------
+def _random_program(rng, nx, nt, nc, psd_rank=None):
+    R = rng.standard_normal((nx if psd_rank is None else psd_rank, nx))
+    Q = R.T @ R + (numpy.eye(nx) if psd_rank is None else 0.0)
+    A = numpy.round(rng.standard_normal((nc, nx)) * 3) / 2
+    A[rng.random((nc, nx)) < 0.3] = 0.0
+    return dict(A=A, b=rng.random((nc, 1)) + 1.0, F=numpy.round(rng.standard_normal((nc, nt)) * 2) / 2, c=rng.standard_normal((nx, 1)),
+                H=rng.standard_normal((nx, nt)), Q=Q, A_t=numpy.vstack([numpy.eye(nt), -numpy.eye(nt)]), b_t=numpy.ones((2 * nt, 1)))
+
+
+@pytest.mark.parametrize('shape', [(20, 8, 47), (5, 3, 8), (16, 2, 16), (17, 4, 33), (40, 10, 100), (64, 6, 130), (33, 3, 49)])
+def test_mfma_setup_blocks_equal_numpy(shape):
+    """mpc_create forms W = A Q^-1 A', UV, Gt = A Q^-1, X0H = -Q^-1 [c | H] and A A' on the device with
+    v_mfma_f64_16x16x4_f64 tiles (blocked Cholesky, two blocked triangular solves, tile products).  Compared with numpy on
+    shapes with one to five 16-row blocks per dimension, including exact multiples of 16; tolerance 1e-11 x cond(Q) relative."""
+    from ppopt_amd import _lib
+    nx, nt, nc = shape
+    d = _random_program(numpy.random.default_rng(nx * 1000 + nc), nx, nt, nc)
+    eng = _lib.Engine(d['A'], d['b'], d['F'], d['c'], d['H'], d['Q'], d['A_t'], d['b_t'], 0)
+    Qi = numpy.linalg.inv(d['Q'])
+    cond = numpy.linalg.cond(d['Q'])
+    want = {0: d['A'] @ Qi @ d['A'].T, 1: numpy.hstack([d['A'] @ Qi @ d['c'] + d['b'], d['A'] @ Qi @ d['H'] + d['F']]),
+            2: d['A'] @ Qi, 3: -Qi @ numpy.hstack([d['c'], d['H']]), 4: d['A'] @ d['A'].T}
+    for which, ref in want.items():
+        got = eng.program_block(which)
+        assert got.shape == ref.shape, (which, got.shape)
+        err = numpy.max(numpy.abs(got - ref)) / (1.0 + numpy.max(numpy.abs(ref)))
+        assert err <= 1e-11 * max(cond, 1.0), (shape, which, err, cond)
+    W = eng.program_block(0)
+    assert numpy.array_equal(W, W.T)      # symmetric by construction (Y'Y)
+    eng.close()
+
+
+def test_mfma_setup_reports_a_semidefinite_hessian():
+    """A rank-deficient Q fails the Cholesky pivot test on the device: the program runs in dense-KKT mode (no Schur blocks)."""
+    from ppopt_amd import _lib
+    d = _random_program(numpy.random.default_rng(3), 8, 3, 14, psd_rank=4)
+    eng = _lib.Engine(d['A'], d['b'], d['F'], d['c'], d['H'], d['Q'], d['A_t'], d['b_t'], 0)
+    assert eng.program_block(0).size == 0 and eng.program_block(4).shape == (14, 14)
+    st = (eng.pruned_clear(), eng.frontier_root(), eng.level_run(True))[2]
+    assert st.kkt_mode == 1
+    eng.close()
+
+
+@pytest.mark.parametrize('name', ['rand_6_3_12_s1', 'c2_dblint_n5', 'quadtank_n3', 'c4_rand_20_8_20_s0'])
+def test_device_setup_and_host_setup_give_the_same_solve(name, monkeypatch):
+    """A/B: the blocks formed by the MFMA kernel against the scalar host computation it replaced (MPC_HOST_SETUP=1): identical
+    verdicts on every level, identical region sets and index sets, coefficients within 1e-10."""
+    from test_gpu_parity import engine_from_golden, run_levels
+    g = load_golden(name)
+    nl = None if bool(g['complete']) else int(g['n_levels']) + 1
+    runs = []
+    for env in ({}, {'MPC_HOST_SETUP': '1'}):
+        with monkeypatch.context() as m:
+            for key, val in env.items():
+                m.setenv(key, val)
+            eng = engine_from_golden(g)
+            levels, regions = run_levels(eng, nl)
+            runs.append(([(c.copy(), s.copy()) for c, s, _ in levels], {tuple(r.active_set): r for r in regions}))
+            eng.close()
+    (la, ra), (lb, rb) = runs
+    assert len(la) == len(lb)
+    for (ca, sa), (cb, sb) in zip(la, lb):
+        assert numpy.array_equal(ca, cb) and numpy.array_equal(sa, sb)
+    assert set(ra) == set(rb)
+    for key, r1 in ra.items():
+        r2 = rb[key]
+        assert r1.omega_set == r2.omega_set and r1.lambda_set == r2.lambda_set and r1.regular_set == r2.regular_set, key
+        for fld in ('A', 'b', 'C', 'd', 'E', 'f'):
+            assert numpy.allclose(getattr(r1, fld), getattr(r2, fld), rtol=0, atol=1e-10), (key, fld)

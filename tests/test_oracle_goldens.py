@@ -100,3 +100,23 @@ def test_deep_goldens_sample(oracle, name, base):
         assert r['E'].shape[0] == int(d['R_nE'][i])
         for j, a in enumerate((r['A'], r['b'], r['C'], r['d'], r['E'], r['f'])):
             assert abs(a.sum() - d['S_digest'][i, j, 0]) <= 1e-8 * (a.size + numpy.sqrt(a.size * d['S_digest'][i, j, 1])), (name, i, j)
+
+
+def test_config5_deep_golden(oracle):
+    """c5_deep.npz: the reference's verdict for every candidate of config 5's tree walked with ill-conditioned sets expanded
+    (oracle/ref_harness/gen_deep_goldens.py c5).  The oracle reproduces every verdict the reference took before a KKT solve or
+    with cond(KKT) < 1e10."""
+    g = load_golden('c5_control_allocation')
+    d = load_golden('c5_deep')
+    P = oracle.problem_from_golden(g)
+    checked = differ = 0
+    for i in range(int(d['n_levels'])):
+        cands, gv, cond = d[f'L{i}_cands'].astype(numpy.int32), d[f'L{i}_verdict'], d[f'L{i}_cond']
+        pinned = numpy.isnan(cond) | (cond < 1e10)
+        if not pinned.any():
+            continue
+        status, _ = P.check_level(cands[pinned], threads=8, want_regions=False)
+        checked += int(pinned.sum())
+        differ += int((status != gv[pinned]).sum())
+    assert checked >= 4000
+    assert differ == 0, differ
