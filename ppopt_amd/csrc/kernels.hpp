@@ -285,7 +285,9 @@ __device__ inline int xtheta_from_vertex(const DevProblem &P, int k, Smem &s, Lp
 // list != nullptr: process only the candidates list[0..n) (the retry list of k_verdict2), work counter ctr->work_region
 __global__ void __launch_bounds__(64) k_verdict(DevProblem P, const int32_t *__restrict__ cands, long long n, int k,
                                                 uint8_t *__restrict__ status, LevelCounters *__restrict__ ctr,
-                                                const int32_t *__restrict__ list) {
+                                                const int32_t *__restrict__ list, const int32_t *__restrict__ n_dev) {
+    // n_dev != nullptr: the length of `list` is read from device memory (the level runs without host round trips)
+    if (n_dev) { n = *n_dev; if ((long long)blockIdx.x >= n) return; }   // surplus block of a launch sized by a bound
     extern __shared__ __attribute__((aligned(16))) double smem[];
     Smem s = carve(P, smem);
     const int lane = lane_id(), nt = P.n_t, nx = P.n_x;

@@ -44,6 +44,7 @@ struct ThetaArgs {
     const double *W, *UVp, *tvp, *tv_rows;
     int chunk;   // candidates taken from the work queue per atomic
     int cbuf_off;   // offset (in doubles, from the start of dynamic LDS) of the row-compaction scratch of k_theta2<.,2>; 0 = none
+    const int32_t *n_dev;   // != nullptr: the number of work items is read from device memory (the level runs without host round trips)
 };
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -248,6 +249,10 @@ __global__ void __launch_bounds__(64, (NT * SLOTS >= 20 ? 3 : (SLOTS >= 2 ? TH_W
     // list != nullptr: the candidates list[0..n) that k_kkt_thread's screen left open; else all candidates 0..n
     // the program descriptor stays in memory (scalar loads on demand) instead of ~90 live SGPRs
     const DevProblem &P = *Pg;
+    // (a block beyond the number of work items has nothing to take from the queue: it leaves before touching the queue's counter --
+    //  with device-resident lengths the launch is sized by a bound, and thousands of surplus blocks would otherwise serialise on
+    //  that one address)
+    if (ta.n_dev) { n = *ta.n_dev; if ((long long)blockIdx.x * ta.chunk >= n) return; }
     extern __shared__ __attribute__((aligned(16))) double smem[];
     Smem s = carve(P, smem);
     constexpr int LS = NT + 1;
@@ -508,6 +513,8 @@ struct DictCache {
     const int32_t *pre1, *pre2;
     int n_pre1, n_pre2;
     int chunk;       // work items per queue atomic (<= 64)
+    // != nullptr: the three list lengths are read from device memory (the level runs without host round trips)
+    const int32_t *n_list_dev, *n_pre1_dev, *n_pre2_dev;
 };
 // k_xq: the last level's quick (x,theta) test.  No dictionary is stored on the last level, so a candidate only needs a
 // DECISION: up to XQ_ITERS simplex iterations from the parent's dictionary in product form (revised simplex with an eta
@@ -669,6 +676,7 @@ __global__ void __launch_bounds__(64, XQ_WAVES) k_xq(const DevProblem *__restric
                                                LevelCounters *__restrict__ ctr, DictCache dc, int NXC) {
     const DevProblem &P = *Pg;
     const int lane = lane_id(), nv = P.n_x + P.n_t, mr = P.n_d0r;
+    if (dc.n_list_dev) { n_list = *dc.n_list_dev; if ((long long)blockIdx.x * dc.chunk >= n_list) return; }
     unsigned long long pivots = 0, n_quick = 0;
     for (;;) {
         unsigned int w0 = 0;
@@ -788,7 +796,11 @@ __global__ void __launch_bounds__(64, (NXC * SLOTS >= 32 ? X2_WAVES : 3)) k_x2(c
     const int32_t *d0_rows = P.d0_rows, *d0_cols = P.d0_cols;
     const bool all_dict_only = dc.dict_only != 0;
     const bool last_only = !all_dict_only && dc.cur_d == nullptr;   // nothing is stored: only the verdict is wanted
+    if (dc.n_list_dev) n_list = *dc.n_list_dev;
+    if (dc.n_pre1_dev) dc.n_pre1 = *dc.n_pre1_dev;
+    if (dc.n_pre2_dev) dc.n_pre2 = *dc.n_pre2_dev;
     const int n_pre = dc.n_pre1 + dc.n_pre2, n_items = n_pre + n_list;
+    if (dc.n_list_dev && (long long)blockIdx.x * dc.chunk >= n_items) return;
     unsigned long long pivots = 0, n_retry = 0, n_cached = 0;
     long long cyc_x = 0;
     int sink = 0;
@@ -944,6 +956,10 @@ struct RegionStream {
     int32_t *flags;        // [n_chunks] host-mapped: 1 = every slot of the chunk is complete and visible to the host
     int shift;             // log2(chunk size)
     int n_slots;           // == n_opt
+    // != nullptr: n_opt is read from device memory, and with W == 0 the number of wavefronts per candidate is chosen in the
+    // kernel by the host's rule (4 if n_opt * 4 <= w_cap, 2 if n_opt * 2 <= w_cap, else 1)
+    const int32_t *n_opt_dev;
+    int w_cap;
 };
 
 template <int NT, int SLOTS>
@@ -965,6 +981,11 @@ __global__ void __launch_bounds__(64, (SLOTS >= 2 ? 2 : R2W)) k_region2(
     long long cyc = 0, rc_rows = 0, rc_cheb = 0, rc_facet = 0, rc_tot = 0, rc_refac = 0, rc_fpiv = 0, rc_box = 0;
     // the kernel's own duration on the constant-rate wall clock (first wavefront in, last wavefront out): the kernel may run on
     // a side stream under other kernels, where event markers are timestamped when the busy command processor reaches them
+    if (rs.n_opt_dev) {
+        n_opt = *rs.n_opt_dev;
+        if (W == 0) W = (long long)n_opt * 4 <= rs.w_cap ? 4 : ((long long)n_opt * 2 <= rs.w_cap ? 2 : 1);
+        if ((long long)blockIdx.x >= (long long)n_opt * W) return;   // surplus block of a launch sized by a bound
+    }
     if (lane == 0) atomicMax(&ctr->r2_not_t0, ~(unsigned long long)wall_clock64());
     for (;;) {
         unsigned int item = 0;

@@ -252,6 +252,11 @@ struct mpc_handle {
     bool no_roverlap = false;        // MPC_NO_ROVERLAP=1 / mpc_set_region_overlap(h, 0): region stage after the (x,theta) stage (no overlap)
     bool r3_dirty = false;           // a region kernel launched on stream3 has not been joined by a completed level yet
     int test_spare = 0;              // MPC_TEST_SPARE=N (tests): N fewer spare region slots than the overlapped launch would reserve
+    bool no_smallpath = false;       // MPC_NO_SMALLPATH=1: levels of any size take the classic path with its host round trips (A/B)
+    long long smallpath_max = 4096;  // MPC_SMALLPATH_MAX: largest level (candidates) that runs without host round trips (measured: config 4 is
+                                     // fastest with 1,024-4,096 -- a level of 15,691 candidates prefers the classic path, which streams its records)
+    long long n_smallpath = 0, n_smallpath_fallback = 0;   // levels run that way / of which repeated on the classic path
+    DevBuf dcnt;                     // device-resident list lengths of such a level
     long long roverlap_min = 2048, roverlap_long = 50000;   // MPC_ROVERLAP_MIN / MPC_ROVERLAP_LONG (items of the (x,theta) stage)
     int wall_khz = 100000;           // rate of wall_clock64() on the device
     int test_late = 0;               // MPC_TEST_LATE=N (tests): the overlapped launch leaves N optimal candidates to the late path
@@ -517,6 +522,8 @@ static int create_fill(const mpc_problem *p, int32_t device, void *stream, mpc_h
     { const char *ev = std::getenv("MPC_NO_ROVERLAP"); h->no_roverlap = ev && ev[0] == '1'; }
     { const char *ev = std::getenv("MPC_TEST_LATE"); h->test_late = ev ? std::atoi(ev) : 0; }
     { const char *ev = std::getenv("MPC_TEST_SPARE"); h->test_spare = ev ? std::atoi(ev) : 0; }
+    { const char *ev = std::getenv("MPC_NO_SMALLPATH"); h->no_smallpath = ev && ev[0] == '1'; }
+    { const char *ev = std::getenv("MPC_SMALLPATH_MAX"); if (ev) h->smallpath_max = std::atoll(ev); }
     { const char *ev = std::getenv("MPC_ROVERLAP_MIN"); if (ev) h->roverlap_min = std::atoll(ev); }
     { const char *ev = std::getenv("MPC_ROVERLAP_LONG"); if (ev) h->roverlap_long = std::atoll(ev); }
     { const char *ev = std::getenv("MPC_DICT_BUDGET_GB"); if (ev) h->dict_budget_gb = std::atof(ev); }
@@ -870,7 +877,7 @@ int mpc_destroy(mpc_handle *h) {
     if (h->stream3) (void)hipStreamSynchronize(h->stream3);
     for (DevBuf *b : {&h->blocks, &h->iblocks, &h->frontier, &h->children, &h->status, &h->pruned, &h->pruned_new, &h->flag, &h->pos, &h->opt_list,
                       &h->childmask, &h->count, &h->offset, &h->recd, &h->reci, &h->ctr, &h->scratch, &h->sums, &h->retry_list, &h->pf_dev, &h->pr2_dev, &h->headd, &h->headi, &h->epool, &h->facet_flags, &h->kkt_code, &h->kkt_L, &h->theta_blocks, &h->xq_groups, &h->theta_list, &h->vretry_list, &h->status_tmp, &h->part_counts, &h->part_lists, &h->kept_g, &h->done_g, &h->dict_d[0], &h->dict_d[1], &h->dict_i[0], &h->dict_i[1],
-                      &h->dict_stored[0], &h->dict_stored[1], &h->parent_slot, &h->parent_slot_next}) b->release();
+                      &h->dict_stored[0], &h->dict_stored[1], &h->parent_slot, &h->parent_slot_next, &h->dcnt}) b->release();
     if (h->tot_host) { (void)host_pool_give(h->tot_host); h->tot_host = h->tot_dev = nullptr; }
     for (HostBuf *b : {&h->st_list, &h->st_status, &h->st_hd, &h->st_hi, &h->st_pool, &h->st_fxd, &h->st_fxi, &h->st_rlist, &h->st_flags}) b->release();
     stream_release(h);
@@ -1093,10 +1100,293 @@ static void stream_release(mpc_handle *h) {   // blocks of a streamed level nobo
     h->so = mpc_handle::StreamOut();
 }
 
+
+// ---- a level without host round trips ---------------------------------------------------------------------------------------
+// The classic path below reads a list length back after almost every stage (to size the next launch): six synchronisations and
+// ~25 dependent launches per level, 0.3-0.45 ms whatever the level computes -- the fixed cost of the first levels of every
+// program, of all of config 2 and of the sub-programs of the mixed-integer enumeration.  Here every list length stays in device
+// memory (h->dcnt; the kernels read it there: ThetaArgs::n_dev, DictCache::n_*_dev, RegionStream::n_opt_dev, k_verdict's n_dev),
+// launches are sized by the one bound the host knows -- the number of candidates of the level --, buffers by the same bound,
+// and the host synchronises ONCE, at the end.  Same kernels, same lists (the single-block compaction / partition kernels keep
+// the candidate order), same decisions.  The rare stages whose buffers cannot be bounded cheaply -- the LDS-engine region kernel
+// for candidates k_region2 gives up on -- are not part of it: if the level turns out to need them, it is repeated on the
+// classic path (deterministic, so the repeat computes the same thing).
+// dcnt layout (int32): [0] theta list | [12] doubtful after the theta stage | [4..7] classes after their re-solve: -, feasible,
+// optimal (= the region launch), open | [8] open after the quick test | [24] doubtful after the (x,theta) stage | [17] optimal
+// candidates that missed the region launch | [20] children
+static bool small_path_ok(const mpc_handle *h, long long n, int k, int32_t flags, int32_t gen_children) {
+    if (h->no_smallpath || !h->fast || h->force_v1 || h->fast_r < 0 || n < 1 || n > h->smallpath_max) return false;
+    if (flags & MPC_LEVEL_GRAPH) return false;
+    if (h->test_late > 0 || h->debug_cycles) return false;
+    // children and their parent slots are sized by the bound n (n_c - k) candidates of k + 1 indices
+    const double child_bytes = (double)n * std::max(h->n_c - k, 1) * (k + 2) * 4.0;
+    if (gen_children && child_bytes > 512e6) return false;
+    const long long rows_t = h->n_c - h->n_eq + h->n_tc;
+    const double rec_bytes = (double)n * ((double)(h->n_x * h->n_t + h->n_x + k * h->n_t + k) * 8.0 + (double)(8 + 2 * k + h->n_tc + 2 * (h->n_c - k)) * 4.0 +
+                                          (double)rows_t * (h->n_t + 1) * 8.0);
+    return rec_bytes <= 2e9;
+}
+
+static int level_run_small(mpc_handle *h, int32_t gen_children, int32_t flags, mpc_level_stats *stats, bool *fallback) {
+    *fallback = false;
+    const long long n = h->n;
+    const int k = h->k;
+    const size_t nn = (size_t)n;
+    hipStream_t st = h->stream;
+    h->n_opt = h->n_children = h->n_pruned_new = h->n_regions = 0;
+    h->n_needx = 0;
+    HIP_TRY(h, h->status.ensure(nn, st));
+    HIP_TRY(h, h->pruned_new.ensure(nn * h->mw * sizeof(uint64_t), st));
+    HIP_TRY(h, h->retry_list.ensure(nn * sizeof(int32_t), st));
+    HIP_TRY(h, h->theta_list.ensure(nn * sizeof(int32_t), st));
+    HIP_TRY(h, h->part_lists.ensure((size_t)PART_CLASSES * nn * sizeof(int32_t), st));
+    HIP_TRY(h, h->dcnt.ensure(32 * sizeof(int32_t), st));
+    HIP_TRY(h, hipMemsetAsync(h->ctr.p, 0, sizeof(LevelCounters), st));
+    HIP_TRY(h, hipMemsetAsync(h->dcnt.p, 0, 32 * sizeof(int32_t), st));
+    LevelCounters *ctr = h->ctr.as<LevelCounters>();
+    int32_t *dcnt = h->dcnt.as<int32_t>();
+    const int32_t *fr = h->frontier.as<int32_t>();
+    uint8_t *stp = h->status.as<uint8_t>();
+    const DevProblem *pf = h->pf_dev.as<DevProblem>();
+    auto part_list = [&](int c) -> int32_t * { return h->part_lists.as<int32_t>() + (size_t)c * nn; };
+    auto spec_of = [](std::initializer_list<std::pair<int, int>> classes) {
+        unsigned long long spec = ~0ull;
+        for (const auto &sc : classes) spec = (spec & ~(15ull << (4 * sc.first))) | ((unsigned long long)sc.second << (4 * sc.first));
+        return spec;
+    };
+    const int blocks256 = (int)((n + 255) / 256);
+    h->used_region2 = false; h->n_rretry = 0; h->n_erows = 0;
+    h->fd = h->n_x * h->n_t + h->n_x + k * h->n_t + k;
+    h->fi = 8 + k + h->n_tc + k + 2 * (h->n_c - k);
+    HIP_TRY(h, hipEventRecord(h->ev[0], st));
+    // ---- KKT solves + box screen, theta stage ----------------------------------------------------------------------------------
+    const uint8_t *kkc = nullptr;
+    const double *kkl = nullptr;
+    const int32_t *theta_list = nullptr;
+    ThetaArgs ta = h->targs;
+    ta.chunk = 1;
+    if (h->kkt_mode == 0 && k >= 1 && k <= 8 && !h->no_kkt_thread) {
+        HIP_TRY(h, h->kkt_code.ensure(nn, st));
+        HIP_TRY(h, h->kkt_L.ensure(nn * (size_t)k * (h->n_t + 1) * sizeof(double), st));
+        kkc = h->kkt_code.as<uint8_t>(); kkl = h->kkt_L.as<double>();
+        const dim3 g((unsigned)blocks256), b(256);
+        const ThetaArgs tk = h->targs;
+#define MPC_LAUNCH_KKT(K_) case K_: if (h->fast_t >= 4) hipLaunchKernelGGL((k_kkt_thread<K_, 10>), g, b, 0, st, pf, fr, n, h->kkt_code.as<uint8_t>(), h->kkt_L.as<double>(), stp, tk, ctr); \
+                                    else if (h->fast_t >= 2) hipLaunchKernelGGL((k_kkt_thread<K_, 8>), g, b, 0, st, pf, fr, n, h->kkt_code.as<uint8_t>(), h->kkt_L.as<double>(), stp, tk, ctr); \
+                                    else hipLaunchKernelGGL((k_kkt_thread<K_, 4>), g, b, 0, st, pf, fr, n, h->kkt_code.as<uint8_t>(), h->kkt_L.as<double>(), stp, tk, ctr); break
+        switch (k) { MPC_LAUNCH_KKT(1); MPC_LAUNCH_KKT(2); MPC_LAUNCH_KKT(3); MPC_LAUNCH_KKT(4); MPC_LAUNCH_KKT(5); MPC_LAUNCH_KKT(6); MPC_LAUNCH_KKT(7); MPC_LAUNCH_KKT(8); }
+#undef MPC_LAUNCH_KKT
+        hipLaunchKernelGGL(k_compact_small, dim3(1), dim3(1024), 0, st, h->status.as<uint8_t>(), (int)n, ST_TODO, ST_TODO, h->theta_list.as<int32_t>(), dcnt + 0);
+        theta_list = h->theta_list.as<int32_t>();
+        ta.n_dev = dcnt + 0;
+    }
+    {
+        const dim3 g((unsigned)std::min<long long>(n, h->grid_f)), b(64);
+        switch (h->fast_t) {
+            case 0: hipLaunchKernelGGL((k_theta2<4, 1>), g, b, h->lds_f, st, pf, fr, n, k, stp, ctr, kkc, kkl, ta, theta_list); break;
+            case 1: hipLaunchKernelGGL((k_theta2<4, 2>), g, b, h->lds_f, st, pf, fr, n, k, stp, ctr, kkc, kkl, ta, theta_list); break;
+            case 2: hipLaunchKernelGGL((k_theta2<8, 1>), g, b, h->lds_f, st, pf, fr, n, k, stp, ctr, kkc, kkl, ta, theta_list); break;
+            case 3: hipLaunchKernelGGL((k_theta2<8, 2>), g, b, h->lds_f, st, pf, fr, n, k, stp, ctr, kkc, kkl, ta, theta_list); break;
+            case 4: hipLaunchKernelGGL((k_theta2<10, 1>), g, b, h->lds_f, st, pf, fr, n, k, stp, ctr, kkc, kkl, ta, theta_list); break;
+            default: hipLaunchKernelGGL((k_theta2<10, 2>), g, b, h->lds_f, st, pf, fr, n, k, stp, ctr, kkc, kkl, ta, theta_list); break;
+        }
+    }
+    // the doubtful candidates of the theta stage are re-solved in place by the LDS engine first (the classic path does this on a
+    // side stream under the (x,theta) stage), so that the partition below already knows every optimal candidate they yield
+    hipLaunchKernelGGL(k_partition_small, dim3(1), dim3(1024), 0, st, h->status.as<uint8_t>(), (int)n, spec_of({{ST_RETRY, 0}}), h->part_lists.as<int32_t>(), (long long)n, dcnt + 12);
+    hipLaunchKernelGGL(k_verdict, dim3((unsigned)std::min<long long>(n, 128)), dim3(64), h->lds_v, st, h->Pv, fr, n, k, stp, ctr, part_list(0), dcnt + 12);
+    // classes after the theta stage: [1] feasible, [2] optimal, [3] feasibility open
+    hipLaunchKernelGGL(k_partition_small, dim3(1), dim3(1024), 0, st, h->status.as<uint8_t>(), (int)n,
+                       spec_of({{ST_FEASIBLE, 1}, {ST_OPT_PENDING, 2}, {ST_NEEDX, 3}, {ST_NEEDX_SING, 3}}), h->part_lists.as<int32_t>(), (long long)n, dcnt + 4);
+    HIP_TRY(h, hipGetLastError());
+    // ---- region stage: one slot per optimal candidate, buffers sized by the bound.  It needs the theta stage's verdicts only; a
+    // candidate that turns out optimal only later -- a doubtful one of the (x,theta) stage, re-solved -- sends the level to the classic
+    // path.  (Measured: on its own stream beside the (x,theta) stage it gains nothing at this size -- the fork / join events cost what
+    // the overlap of two 50-100 us kernels saves: config 2 1.76 ms against 1.68 in line.) -----------------------------------------------
+    h->opt_ptr = part_list(2);
+    {
+        const int rows_t_ = h->n_c - h->n_eq + h->n_tc;
+        HIP_TRY(h, h->headd.ensure(nn * h->fd * sizeof(double), st));
+        HIP_TRY(h, h->headi.ensure(nn * h->fi * sizeof(int32_t), st));
+        HIP_TRY(h, h->epool.ensure(nn * rows_t_ * (h->n_t + 1) * sizeof(double), st));
+        const int ldk = (rows_t_ + 1 + 63) & ~63;
+        HIP_TRY(h, h->kept_g.ensure(nn * ldk, st));
+        HIP_TRY(h, h->done_g.ensure(nn * 2 * sizeof(unsigned int), st));
+        HIP_TRY(h, hipMemsetAsync(h->done_g.p, 0, nn * 2 * sizeof(unsigned int), st));
+        RegionStream rs{};
+        rs.n_opt_dev = dcnt + 6;
+        rs.w_cap = h->grid_r2;
+        const int W = h->no_rsplit ? 1 : 0;   // 0: chosen in the kernel from the number of optimal candidates
+        const dim3 g((unsigned)std::min<long long>(n * 4, h->grid_r2)), b(64);
+        const DevProblem *pr = h->pr2_dev.as<DevProblem>();
+#define MPC_LAUNCH_R2(NT_, SL_) hipLaunchKernelGGL((k_region2<NT_, SL_>), g, b, h->lds_r2, st, pr, h->frontier.as<int32_t>(), k, h->opt_ptr, (int)n, \
+                                                   h->status.as<uint8_t>(), h->headd.as<double>(), h->headi.as<int32_t>(), h->fd, h->fi, h->epool.as<double>(), ctr, kkc, kkl, \
+                                                   W, h->kept_g.as<uint8_t>(), ldk, h->done_g.as<unsigned int>(), \
+                                                   h->no_rbox ? (const double *)nullptr : h->targs.tvp + (size_t)NT_ * NT_ + NT_, rs)
+        switch (h->fast_r) {
+            case 0: MPC_LAUNCH_R2(4, 1); break;
+            case 1: MPC_LAUNCH_R2(4, 2); break;
+            case 2: MPC_LAUNCH_R2(8, 1); break;
+            case 3: MPC_LAUNCH_R2(8, 2); break;
+            case 4: MPC_LAUNCH_R2(10, 1); break;
+            default: MPC_LAUNCH_R2(10, 2); break;
+        }
+#undef MPC_LAUNCH_R2
+        HIP_TRY(h, hipGetLastError());
+        h->used_region2 = true;
+    }
+    HIP_TRY(h, hipMemsetAsync(&ctr->work_retry, 0, sizeof(unsigned int), st));
+    // ---- (x,theta) stage with the dictionary cache ---------------------------------------------------------------------------------
+    const int nxc = h->fast_x >= 2 ? 32 : 16;
+    h->dict_stride_d = (long long)nxc * h->Pf.n_d0r;
+    h->dict_stride_i = 2LL * h->Pf.n_d0r + nxc + 4;
+    DictCache dc{};
+    dc.stride_d = h->dict_stride_d; dc.stride_i = h->dict_stride_i;
+    if (h->have_prev_dict && h->have_parent_slot) {
+        dc.parent_slot = h->parent_slot.as<int32_t>();
+        dc.prev_d = h->dict_d[1 - h->dict_cur].as<double>();
+        dc.prev_i = h->dict_i[1 - h->dict_cur].as<int32_t>();
+    }
+    h->storing = false;
+    const double need_gb = (double)nn * (h->dict_stride_d * 8.0 + h->dict_stride_i * 4.0) / 1e9;
+    if (gen_children && need_gb <= h->dict_budget_gb) {
+        HIP_TRY(h, h->dict_d[h->dict_cur].ensure(nn * h->dict_stride_d * sizeof(double), st));
+        HIP_TRY(h, h->dict_i[h->dict_cur].ensure(nn * h->dict_stride_i * sizeof(int32_t), st));
+        HIP_TRY(h, h->dict_stored[h->dict_cur].ensure(nn, st));
+        HIP_TRY(h, hipMemsetAsync(h->dict_stored[h->dict_cur].p, 0, nn, st));
+        dc.cur_d = h->dict_d[h->dict_cur].as<double>(); dc.cur_i = h->dict_i[h->dict_cur].as<int32_t>();
+        dc.stored = h->dict_stored[h->dict_cur].as<uint8_t>();
+        h->storing = true;
+        dc.pre1 = part_list(1); dc.n_pre1_dev = dcnt + 5;
+        dc.pre2 = part_list(2); dc.n_pre2_dev = dcnt + 6;
+    }
+    dc.chunk = 1;
+    const int32_t *needx_list = part_list(3);
+    const int32_t *needx_n = dcnt + 7;
+    const bool quick_test = !h->storing && dc.parent_slot && !h->no_xquick;
+    if (quick_test) {   // last level: decisions only -- the quick test on a few vectors of the parent's dictionary first
+        DictCache dq = dc;
+        dq.n_list_dev = needx_n;
+        const dim3 gg((unsigned)std::min<long long>(n, (long long)h->n_cu * 32)), bb(64);
+        if (h->fast_x & 1) hipLaunchKernelGGL((k_xq<2>), gg, bb, 0, st, pf, fr, k, needx_list, (int)n, stp, ctr, dq, nxc);
+        else hipLaunchKernelGGL((k_xq<1>), gg, bb, 0, st, pf, fr, k, needx_list, (int)n, stp, ctr, dq, nxc);
+        hipLaunchKernelGGL(k_compact_small, dim3(1), dim3(1024), 0, st, h->status.as<uint8_t>(), (int)n, ST_NEEDX, ST_NEEDX_SING, h->retry_list.as<int32_t>(), dcnt + 8);
+        needx_list = h->retry_list.as<int32_t>();
+        needx_n = dcnt + 8;
+    }
+    {
+        DictCache d = dc;
+        d.n_list_dev = needx_n;
+        // bound of the work items: every candidate once (open, or decided and expanded for its dictionary)
+        const dim3 gg((unsigned)std::min<long long>(n, (long long)h->n_cu * 16)), bb(64);
+        switch (h->fast_x) {
+            case 0: hipLaunchKernelGGL((k_x2<16, 1>), gg, bb, 0, st, pf, fr, k, needx_list, (int)n, stp, ctr, d); break;
+            case 1: hipLaunchKernelGGL((k_x2<16, 2>), gg, bb, 0, st, pf, fr, k, needx_list, (int)n, stp, ctr, d); break;
+            case 2: hipLaunchKernelGGL((k_x2<32, 1>), gg, bb, 0, st, pf, fr, k, needx_list, (int)n, stp, ctr, d); break;
+            default: hipLaunchKernelGGL((k_x2<32, 2>), gg, bb, 0, st, pf, fr, k, needx_list, (int)n, stp, ctr, d); break;
+        }
+    }
+    HIP_TRY(h, hipGetLastError());
+    // doubtful candidates of the (x,theta) stage (rare): re-solved in place as well
+    hipLaunchKernelGGL(k_partition_small, dim3(1), dim3(1024), 0, st, h->status.as<uint8_t>(), (int)n, spec_of({{ST_RETRY, 0}}), h->part_lists.as<int32_t>(), (long long)n, dcnt + 24);
+    hipLaunchKernelGGL(k_verdict, dim3((unsigned)std::min<long long>(n, 128)), dim3(64), h->lds_v, st, h->Pv, fr, n, k, stp, ctr, part_list(0), dcnt + 24);
+    HIP_TRY(h, hipGetLastError());
+    HIP_TRY(h, hipEventRecord(h->ev[1], st));
+    // a candidate that is still "optimal, region pending" now was not in the region launch: counted in [17]
+    hipLaunchKernelGGL(k_partition_small, dim3(1), dim3(1024), 0, st, h->status.as<uint8_t>(), (int)n, spec_of({{ST_OPT_PENDING, 1}}), h->part_lists.as<int32_t>(), (long long)n, dcnt + 16);
+    HIP_TRY(h, hipGetLastError());
+    HIP_TRY(h, hipEventRecord(h->ev[2], st));
+    // ---- pruned masks of this level + children -------------------------------------------------------------------------------------
+    const int keep_lowdim = (flags & MPC_LEVEL_KEEP_LOWDIM) ? 1 : 0;
+    if (h->mw == 2) hipLaunchKernelGGL(k_pruned_append<2>, dim3(blocks256), dim3(256), 0, st, h->frontier.as<int32_t>(), n, k, h->status.as<uint8_t>(),
+                                       h->pruned_new.as<unsigned long long>(), ctr, keep_lowdim);
+    else hipLaunchKernelGGL(k_pruned_append<4>, dim3(blocks256), dim3(256), 0, st, h->frontier.as<int32_t>(), n, k, h->status.as<uint8_t>(),
+                            h->pruned_new.as<unsigned long long>(), ctr, keep_lowdim);
+    if (gen_children) {
+        HIP_TRY(h, h->childmask.ensure(nn * h->mw * sizeof(uint64_t), st));
+        HIP_TRY(h, h->count.ensure(nn * sizeof(int32_t), st));
+        HIP_TRY(h, h->offset.ensure(nn * sizeof(int32_t), st));
+        const size_t child_bound = nn * (size_t)std::max(h->n_c - k, 1);
+        HIP_TRY(h, h->children.ensure(child_bound * (k + 1) * sizeof(int32_t), st));
+        HIP_TRY(h, h->parent_slot_next.ensure(child_bound * sizeof(int32_t), st));
+        if (h->mw == 2) hipLaunchKernelGGL(k_children_count<2>, dim3((unsigned)n), dim3(64), 0, st, h->Pv, h->frontier.as<int32_t>(), n, k, h->status.as<uint8_t>(),
+                                           h->pruned.as<unsigned long long>(), (long long)h->n_pruned, h->childmask.as<unsigned long long>(), h->count.as<int32_t>(), keep_lowdim);
+        else hipLaunchKernelGGL(k_children_count<4>, dim3((unsigned)n), dim3(64), 0, st, h->Pv, h->frontier.as<int32_t>(), n, k, h->status.as<uint8_t>(),
+                                h->pruned.as<unsigned long long>(), (long long)h->n_pruned, h->childmask.as<unsigned long long>(), h->count.as<int32_t>(), keep_lowdim);
+        hipLaunchKernelGGL(k_scan_small, dim3(1), dim3(SCAN_BLOCK), 0, st, h->count.as<int32_t>(), h->offset.as<int32_t>(), (int)n, dcnt + 20);
+        hipLaunchKernelGGL(k_children_write, dim3((unsigned)n), dim3(64), 0, st, h->frontier.as<int32_t>(), n, k, h->mw,
+                           h->childmask.as<unsigned long long>(), h->offset.as<int32_t>(), h->children.as<int32_t>(),
+                           h->storing ? h->dict_stored[h->dict_cur].as<uint8_t>() : (const uint8_t *)nullptr, h->parent_slot_next.as<int32_t>());
+        HIP_TRY(h, hipGetLastError());
+    }
+    hipLaunchKernelGGL(k_histogram, dim3(std::min(blocks256, 1024)), dim3(256), 0, st, h->status.as<uint8_t>(), n, ctr);
+    HIP_TRY(h, hipEventRecord(h->ev[3], st));
+    static_assert(sizeof(LevelCounters) + 64 + 32 * 4 <= 4096, "LevelCounters + list lengths must fit the pinned block");
+    hipLaunchKernelGGL(k_publish_words, dim3(1), dim3(128), 0, st, reinterpret_cast<const unsigned int *>(ctr),
+                       reinterpret_cast<unsigned int *>(h->tot_dev + 16), (int)(sizeof(LevelCounters) / 4));
+    int32_t *cnt_host = h->tot_host + 16 + (int)(sizeof(LevelCounters) / 4);
+    hipLaunchKernelGGL(k_publish_words, dim3(1), dim3(64), 0, st, reinterpret_cast<const unsigned int *>(dcnt),
+                       reinterpret_cast<unsigned int *>(h->tot_dev + 16 + (int)(sizeof(LevelCounters) / 4)), 32);
+    HIP_TRY(h, hipGetLastError());
+    HIP_TRY(h, hipStreamSynchronize(st));   // the level's only synchronisation
+    LevelCounters host_ctr;
+    std::memcpy(&host_ctr, h->tot_host + 16, sizeof(LevelCounters));
+    h->n_smallpath++;
+    if (host_ctr.n_rretry > 0 || cnt_host[17] > 0) {
+        // a candidate k_region2 gave up on (the LDS-engine region kernel is not part of this path), or one that turned out optimal
+        // after the region launch: the level is repeated classically
+        h->n_smallpath_fallback++;
+        *fallback = true;
+        return MPC_OK;
+    }
+    float ms[3] = {0, 0, 0};
+    HIP_TRY(h, hipEventElapsedTime(&ms[0], h->ev[0], h->ev[1]));
+    HIP_TRY(h, hipEventElapsedTime(&ms[1], h->ev[1], h->ev[2]));
+    HIP_TRY(h, hipEventElapsedTime(&ms[2], h->ev[2], h->ev[3]));
+    h->n_opt = cnt_host[6];
+    h->n_children = gen_children ? cnt_host[20] : 0;
+    h->n_needx = cnt_host[7];
+    h->n_pruned_new = host_ctr.n_pruned_new;
+    h->n_erows = host_ctr.e_rows;
+    h->n_regions = (long long)host_ctr.status[ST_REGION];
+    h->level_done = true;
+    h->last_level_n = n;
+    stream_ready(h);
+    if (stats) {
+        std::memset(stats, 0, sizeof(*stats));
+        stats->n = n; stats->k = k; stats->kkt_mode = h->kkt_mode;
+        for (int i = 0; i < 6; ++i) stats->n_status[i] = (int64_t)host_ctr.status[i];
+        stats->n_regions = h->n_regions; stats->n_children = h->n_children; stats->n_pruned_new = h->n_pruned_new;
+        stats->lp_pivots = (int64_t)host_ctr.pivots;
+        stats->n_xtheta_lp = h->n_needx;
+        stats->n_xtheta_fallback = (int64_t)host_ctr.xtheta_fallbacks;
+        for (int i = 0; i < 4; ++i) stats->wave_cycles[i] = (int64_t)host_ctr.cycles[i];
+        stats->n_x_cached = (int64_t)host_ctr.x_cached;
+        stats->n_region_rows = h->n_erows;
+        stats->n_opt = h->n_opt;
+        stats->n_theta_items = kkc ? cnt_host[0] : n;
+        if (h->n_opt > 0 && host_ctr.r2_t1 > ~host_ctr.r2_not_t0 && h->wall_khz > 0)   // k_region2 times itself on the wall clock
+            stats->ms_region2 = (float)((double)(host_ctr.r2_t1 - ~host_ctr.r2_not_t0) / (double)h->wall_khz);
+        stats->n_xq_items = quick_test ? cnt_host[7] : 0; stats->xq_pivots = (int64_t)host_ctr.xq_pivots;
+        stats->n_x_items = (quick_test ? cnt_host[8] : cnt_host[7]) + (h->storing ? (long long)cnt_host[5] + cnt_host[6] : 0);
+        stats->xq_record_ints = h->dict_stride_i; stats->xq_record_rows = h->Pf.n_d0r; stats->xq_record_cols = h->Pf.n_d0c + 1;
+        const long long rec_bytes = (long long)(h->Pf.n_d0c + 1) * h->Pf.n_d0r * 8 + h->dict_stride_i * 4;
+        stats->dict_read_bytes = (h->have_prev_dict && h->have_parent_slot) ? rec_bytes : 0;
+        stats->dict_write_bytes = h->storing ? rec_bytes : 0;
+        stats->ms_verdict = ms[0]; stats->ms_region = ms[1]; stats->ms_children = ms[2]; stats->ms_total = ms[0] + ms[1] + ms[2];
+    }
+    return MPC_OK;
+}
+
 static int level_run_impl(mpc_handle *h, int32_t gen_children, int32_t flags, mpc_level_stats *stats) {
     if (!h) return MPC_ERR_INVALID;
     HIP_TRY(h, hipSetDevice(h->device));
     stream_release(h);
+    if (small_path_ok(h, h->n, h->k, flags, gen_children)) {
+        bool fallback = false;
+        const int rcs = level_run_small(h, gen_children, flags, stats, &fallback);
+        if (rcs != MPC_OK || !fallback) return rcs;
+    }
     const long long n = h->n;
     const int k = h->k;
     hipStream_t st = h->stream;
@@ -1313,7 +1603,7 @@ static int level_run_impl(mpc_handle *h, int32_t gen_children, int32_t flags, mp
                 HIP_TRY(h, hipEventRecord(h->ev_fork, st));
                 HIP_TRY(h, hipStreamWaitEvent(h->stream2, h->ev_fork, 0));
                 hipLaunchKernelGGL(k_verdict, dim3((unsigned)std::min<long long>(n_early, h->grid_v)), dim3(64), h->lds_v, h->stream2, h->Pv,
-                                   h->frontier.as<int32_t>(), (long long)n_early, k, h->status_tmp.as<uint8_t>(), ctr, h->vretry_list.as<int32_t>());
+                                   h->frontier.as<int32_t>(), (long long)n_early, k, h->status_tmp.as<uint8_t>(), ctr, h->vretry_list.as<int32_t>(), (const int32_t *)nullptr);
                 HIP_TRY(h, hipGetLastError());
                 HIP_TRY(h, hipEventRecord(h->ev_join, h->stream2));
             }
@@ -1474,7 +1764,7 @@ static int level_run_impl(mpc_handle *h, int32_t gen_children, int32_t flags, mp
             }
             if (n_retry > 0) {
                 hipLaunchKernelGGL(k_verdict, dim3((unsigned)std::min<long long>(n_retry, h->grid_v)), dim3(64), h->lds_v, st, h->Pv,
-                                   h->frontier.as<int32_t>(), (long long)n_retry, k, h->status.as<uint8_t>(), ctr, part_list(0));
+                                   h->frontier.as<int32_t>(), (long long)n_retry, k, h->status.as<uint8_t>(), ctr, part_list(0), (const int32_t *)nullptr);
                 HIP_TRY(h, hipGetLastError());
                 if (region_launched) HIP_TRY(h, hipStreamWaitEvent(st, h->ev_rjoin, 0));
                 { int rcs = partition({{ST_OPT_PENDING, 2}}, cntB); if (rcs) return rcs; }   // they may have turned out optimal
@@ -1499,7 +1789,7 @@ static int level_run_impl(mpc_handle *h, int32_t gen_children, int32_t flags, mp
             }
         } else {
             hipLaunchKernelGGL(k_verdict, dim3((unsigned)std::min<long long>(n, h->grid_v)), dim3(64), h->lds_v, st, h->Pv,
-                               h->frontier.as<int32_t>(), n, k, h->status.as<uint8_t>(), ctr, (const int32_t *)nullptr);
+                               h->frontier.as<int32_t>(), n, k, h->status.as<uint8_t>(), ctr, (const int32_t *)nullptr, (const int32_t *)nullptr);
             HIP_TRY(h, hipGetLastError());
         }
         HIP_TRY(h, hipEventRecord(h->ev[1], st));

@@ -147,8 +147,9 @@ def _solve(program, num_cores: int = -1, device: int = 0, profile: Optional[List
                     new_regions.extend(batch.regions_of((lo + numpy.flatnonzero(status_col[lo:lo + chunk] == REGION_STATUS)).tolist()))
             st = eng.level_wait()
             if st.n_regions and info is None:
-                # a level outside the streaming path (LDS-engine region kernel, very large record sets)
-                hd, hi, er, kk, slots = eng.level_regions_slots()
+                # a level outside the streaming path (run without host round trips: its records are in device buffers; LDS-engine
+                # region kernel; very large record sets): the integer heads are waited for, the large arrays arrive under the next level
+                hd, hi, er, kk, slots = eng.level_regions_slots(early_return=True)
                 new_regions = RegionBatch(hd, hi, er, n_x, n_t, n_c, n_tc, kk, slots).regions()
             elif st.n_region_retry and batch is not None:
                 # some candidates were re-solved by the LDS-engine kernel after the stream: fill their slots, list the level again

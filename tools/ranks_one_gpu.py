@@ -1,0 +1,68 @@
+"""N ranks of the multi-GPU driver on ONE GPU (gloo carries the device tensors): the sharded path end to end with world sizes
+2, 4 and 8 where only a single device is available.  For every world size: each rank's region set against the single-rank
+solve, and per level the ranks' shard sizes (candidates, regions, children) -- the imbalance of the static subtree ownership
+that follows the one split.  Times are NOT multi-GPU times (the ranks share one device).
+
+    python tools/ranks_one_gpu.py [workload=c4] [world sizes, default 2 4 8]   -> gpurun_out/r3/ranks_<workload>.json
+"""
+import json
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def worker(rank, world, port, wl, out):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    import bench
+    from ppopt_amd.distributed import HipLevelEngine, solve_distributed
+    torch.cuda.set_device(0)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        prog = bench.build_program(wl, 0)
+        eng = HipLevelEngine(prog, 0)
+        prof = []
+        sol = solve_distributed(eng, prog, profile=prof, max_levels=bench.WORKLOADS[wl][2])
+        out[rank] = (sorted(tuple(r.active_set) for r in sol.critical_regions),
+                     [{'k': p['k'], 'candidates': p['candidates'], 'local': p.get('local_candidates'), 'sharded': bool(p.get('sharded')),
+                       'regions': p['regions'], 'children': p['children'], 'ms_kernels': p.get('ms_verdict', 0) + p.get('ms_region', 0) + p.get('ms_children', 0)}
+                      for p in prof if p['depth'] > 0])
+        eng.close()
+    finally:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    wl = sys.argv[1] if len(sys.argv) > 1 else 'c4'
+    worlds = [int(v) for v in sys.argv[2:]] or [2, 4, 8]
+    import bench
+    from ppopt_amd.mp_solvers import mpqp_hip_combinatorial
+    solo = mpqp_hip_combinatorial.solve(bench.build_program(wl, 0), max_levels=bench.WORKLOADS[wl][2])
+    ref = sorted(tuple(r.active_set) for r in solo.critical_regions)
+    report = {'workload': wl, 'regions_single_rank': len(ref), 'worlds': {}}
+    ctx = mp.get_context('spawn')          # fresh children: a process that has touched the GPU is never re-executed
+    for world in worlds:
+        with ctx.Manager() as mgr:
+            out = mgr.dict()
+            ps = [ctx.Process(target=worker, args=(r, world, 29611 + world, wl, out)) for r in range(world)]
+            [p.start() for p in ps]
+            [p.join(900) for p in ps]
+            res = dict(out)
+        ok = len(res) == world and all(res[r][0] == ref for r in res)
+        levels = []
+        n_lev = len(res[0][1]) if res else 0
+        for i in range(n_lev):
+            loc = [res[r][1][i]['local'] or res[r][1][i]['candidates'] for r in sorted(res)]
+            ms = [res[r][1][i]['ms_kernels'] for r in sorted(res)]
+            levels.append({'k': res[0][1][i]['k'], 'candidates': res[0][1][i]['candidates'], 'sharded': res[0][1][i]['sharded'], 'shards': loc,
+                           'imbalance_max_over_mean': max(loc) / (sum(loc) / len(loc)) if res[0][1][i]['sharded'] else 1.0,
+                           'kernel_ms_per_rank_sharing_one_gpu': [round(v, 3) for v in ms]})
+        report['worlds'][str(world)] = {'all_ranks_equal_single_rank_solve': ok, 'exit_codes': [p.exitcode for p in ps], 'levels': levels}
+        print(f'world {world}: every rank returns the single-rank region set: {ok}; shards per level: '
+              + '; '.join(f"k={lv['k']}: {lv['shards']} (max/mean {lv['imbalance_max_over_mean']:.3f})" for lv in levels if lv['sharded']), flush=True)
+    os.makedirs('gpurun_out/r3', exist_ok=True)
+    json.dump(report, open(f'gpurun_out/r3/ranks_{wl}.json', 'w'), indent=1)
