@@ -176,7 +176,8 @@ def main():
 
     def step(profile):
         if distributed:
-            return solve_distributed(engine, prog, profile=profile, max_levels=max_levels, force_shard=args.dist_single)
+            # rank 0 holds the complete Solution (it is the one that reports); the other ranks build only their own shards' objects
+            return solve_distributed(engine, prog, profile=profile, max_levels=max_levels, force_shard=args.dist_single, full_solution='rank0')
         return mpqp_hip_combinatorial.solve(prog, device=local_rank, profile=profile, max_levels=max_levels)
 
     # warm-up solves are held together and released together, so that the allocators (the engine's device buffers, the
@@ -282,20 +283,24 @@ def main():
                            'calibration': 'tools/calib/pmc_calib.hip (known byte counts; profiles/r03_pmc.json -> calibration)',
                            'source': 'profiles/r03_pmc.json'}
                 for name, kk in kern.items():
-                    pk = tw['kernels'].get(name)
+                    pk = tw['kernels'].get(name) or (tw['kernels'].get('k_xq_grouped') if name == 'k_xq' else None)
                     if not pk:
                         continue
-                    kk['traffic_bytes_per_launch'] = pk.get('bytes_per_launch')
-                    sq = pk.get('sq_per_launch')
-                    if sq and kk['avg_launch_ms'] > 0:
-                        simd_cycles = kk['avg_launch_ms'] * 1e-3 * clk_hz * n_simd
+                    # counters are sums over every dispatch of the kernel in a solve (small levels included); times are the live
+                    # HIP-event times of this run's timed launches (the large levels: they carry the kernel's time)
+                    kk['traffic_bytes_per_step'] = pk.get('bytes_per_step')
+                    sq = pk.get('sq_per_step')
+                    ms_step = kk['total_ms'] / steps
+                    if sq and ms_step > 0:
+                        simd_cycles = ms_step * 1e-3 * clk_hz * n_simd
                         valu = sq.get('SQ_INSTS_VALU', 0.0)
                         f64 = sum(sq.get(c, 0.0) for c in ('SQ_INSTS_VALU_ADD_F64', 'SQ_INSTS_VALU_MUL_F64', 'SQ_INSTS_VALU_FMA_F64',
                                                            'SQ_INSTS_VALU_TRANS_F64'))
-                        kk['valu_insts_per_launch'] = valu
-                        kk['fp64_insts_per_launch'] = f64 if f64 > 0 else None
-                        kk['frac_valu_issue_4cyc'] = 4.0 * valu / simd_cycles          # every VALU instruction priced as fp64
+                        kk['valu_insts_per_step'] = valu
+                        kk['fp64_insts_per_step'] = f64 if f64 > 0 else None
+                        kk['frac_valu_issue_4cyc'] = 4.0 * valu / simd_cycles          # every VALU instruction priced as fp64 (upper bound)
                         kk['frac_fp64_issue'] = (4.0 * f64 / simd_cycles) if f64 > 0 else None
+                        kk['frac_valu_issue'] = ((4.0 * f64 + 2.0 * (valu - f64)) / simd_cycles) if f64 > 0 else None   # fp64 at 4 cycles, the rest at 2
                         wc = sq.get('SQ_WAVE_CYCLES', 0.0)
                         if wc > 0:
                             kk['wave_cycles_share'] = {'active_inst': sq.get('SQ_ACTIVE_INST_ANY', 0.0) / wc, 'wait_inst': sq.get('SQ_WAIT_INST_ANY', 0.0) / wc,
@@ -335,7 +340,8 @@ def main():
                                          'achieved': dom['achieved_GBs'], 'frac': dom['achieved_GBs'] / HBM_PEAK_GBS,
                                          'launches': dom['launches'], 'avg_launch_ms': dom['avg_launch_ms'],
                                          'algorithmic_bytes_per_launch': dom['algorithmic_bytes'] / max(dom['launches'], 1),
-                                         'frac_fp64_issue': dom.get('frac_fp64_issue'), 'frac_valu_issue_4cyc': dom.get('frac_valu_issue_4cyc'),
+                                         'frac_fp64_issue': dom.get('frac_fp64_issue'), 'frac_valu_issue': dom.get('frac_valu_issue'),
+                                         'frac_valu_issue_4cyc': dom.get('frac_valu_issue_4cyc'),
                                          'traffic': dom_traffic},
                      'kernels': kern,
                      'note': 'B_alg = P + 4k + 8 + rho*R per candidate (SURVEY.md 8(d)): the shared problem block P is counted once per '

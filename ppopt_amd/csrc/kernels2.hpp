@@ -957,9 +957,9 @@ struct RegionStream {
     int shift;             // log2(chunk size)
     int n_slots;           // == n_opt
     // != nullptr: n_opt is read from device memory, and with W == 0 the number of wavefronts per candidate is chosen in the
-    // kernel by the host's rule (4 if n_opt * 4 <= w_cap, 2 if n_opt * 2 <= w_cap, else 1)
+    // kernel by the host's rule (the largest power of two <= w_max with n_opt * W <= w_cap)
     const int32_t *n_opt_dev;
-    int w_cap;
+    int w_cap, w_max;
 };
 
 template <int NT, int SLOTS>
@@ -983,7 +983,7 @@ __global__ void __launch_bounds__(64, (SLOTS >= 2 ? 2 : R2W)) k_region2(
     // a side stream under other kernels, where event markers are timestamped when the busy command processor reaches them
     if (rs.n_opt_dev) {
         n_opt = *rs.n_opt_dev;
-        if (W == 0) W = (long long)n_opt * 4 <= rs.w_cap ? 4 : ((long long)n_opt * 2 <= rs.w_cap ? 2 : 1);
+        if (W == 0) { W = rs.w_max > 0 ? rs.w_max : 1; while (W > 1 && (long long)n_opt * W > rs.w_cap) W >>= 1; }
         if ((long long)blockIdx.x >= (long long)n_opt * W) return;   // surplus block of a launch sized by a bound
     }
     if (lane == 0) atomicMax(&ctr->r2_not_t0, ~(unsigned long long)wall_clock64());

@@ -252,6 +252,9 @@ struct mpc_handle {
     bool no_roverlap = false;        // MPC_NO_ROVERLAP=1 / mpc_set_region_overlap(h, 0): region stage after the (x,theta) stage (no overlap)
     bool r3_dirty = false;           // a region kernel launched on stream3 has not been joined by a completed level yet
     int test_spare = 0;              // MPC_TEST_SPARE=N (tests): N fewer spare region slots than the overlapped launch would reserve
+    int rsplit_max = 4;              // MPC_RSPLIT_MAX: most wavefronts that share one optimal candidate in k_region2 (power of two, <= 16; measured:
+                                     // 8 and 16 shorten no level of config 4 or 2 -- every wavefront repeats the row build and the Chebyshev LP, 40 % of
+                                     // a region at 4 -- and move the facet list of one sliver region)
     bool no_smallpath = false;       // MPC_NO_SMALLPATH=1: levels of any size take the classic path with its host round trips (A/B)
     long long smallpath_max = 4096;  // MPC_SMALLPATH_MAX: largest level (candidates) that runs without host round trips (measured: config 4 is
                                      // fastest with 1,024-4,096 -- a level of 15,691 candidates prefers the classic path, which streams its records)
@@ -523,6 +526,7 @@ static int create_fill(const mpc_problem *p, int32_t device, void *stream, mpc_h
     { const char *ev = std::getenv("MPC_TEST_LATE"); h->test_late = ev ? std::atoi(ev) : 0; }
     { const char *ev = std::getenv("MPC_TEST_SPARE"); h->test_spare = ev ? std::atoi(ev) : 0; }
     { const char *ev = std::getenv("MPC_NO_SMALLPATH"); h->no_smallpath = ev && ev[0] == '1'; }
+    { const char *ev = std::getenv("MPC_RSPLIT_MAX"); if (ev) { int v = std::atoi(ev); h->rsplit_max = v >= 16 ? 16 : (v >= 8 ? 8 : (v >= 4 ? 4 : (v >= 2 ? 2 : 1))); } }
     { const char *ev = std::getenv("MPC_SMALLPATH_MAX"); if (ev) h->smallpath_max = std::atoll(ev); }
     { const char *ev = std::getenv("MPC_ROVERLAP_MIN"); if (ev) h->roverlap_min = std::atoll(ev); }
     { const char *ev = std::getenv("MPC_ROVERLAP_LONG"); if (ev) h->roverlap_long = std::atoll(ev); }
@@ -1215,9 +1219,9 @@ static int level_run_small(mpc_handle *h, int32_t gen_children, int32_t flags, m
         HIP_TRY(h, hipMemsetAsync(h->done_g.p, 0, nn * 2 * sizeof(unsigned int), st));
         RegionStream rs{};
         rs.n_opt_dev = dcnt + 6;
-        rs.w_cap = h->grid_r2;
+        rs.w_cap = h->grid_r2; rs.w_max = h->rsplit_max;
         const int W = h->no_rsplit ? 1 : 0;   // 0: chosen in the kernel from the number of optimal candidates
-        const dim3 g((unsigned)std::min<long long>(n * 4, h->grid_r2)), b(64);
+        const dim3 g((unsigned)std::min<long long>(n * std::max(h->rsplit_max, 1), h->grid_r2)), b(64);
         const DevProblem *pr = h->pr2_dev.as<DevProblem>();
 #define MPC_LAUNCH_R2(NT_, SL_) hipLaunchKernelGGL((k_region2<NT_, SL_>), g, b, h->lds_r2, st, pr, h->frontier.as<int32_t>(), k, h->opt_ptr, (int)n, \
                                                    h->status.as<uint8_t>(), h->headd.as<double>(), h->headi.as<int32_t>(), h->fd, h->fi, h->epool.as<double>(), ctr, kkc, kkl, \
@@ -1462,7 +1466,8 @@ static int level_run_impl(mpc_handle *h, int32_t gen_children, int32_t flags, mp
             HIP_TRY(h, h->headi.ensure(n_tot * h->fi * sizeof(int32_t), st));
             HIP_TRY(h, h->epool.ensure(n_tot * rows_t_ * (h->n_t + 1) * sizeof(double), st));
             // few optimal candidates: several wavefronts per candidate (the facet tests are split among them)
-            const int W = (h->no_rsplit || one_wave) ? 1 : ((long long)n_opt * 4 <= h->grid_r2 ? 4 : ((long long)n_opt * 2 <= h->grid_r2 ? 2 : 1));
+            int W = (h->no_rsplit || one_wave) ? 1 : h->rsplit_max;
+            while (W > 1 && (long long)n_opt * W > h->grid_r2) W >>= 1;
             const int ldk = (rows_t_ + 1 + 63) & ~63;
             if (W > 1) {
                 HIP_TRY(h, h->kept_g.ensure((size_t)n_opt * ldk, st));

@@ -245,22 +245,31 @@ class _RepeatWithoutOverlap(Exception):
 
 
 def solve_distributed(engine, program=None, group=None, profile: Optional[List[Dict]] = None,
-                      collect_regions: bool = True, max_levels: Optional[int] = None, shard_min: int = 128, force_shard: bool = False) -> Solution:
-    """``_solve_distributed``; when a level on some rank runs out of spare region slots, all ranks learn it from that level's
+                      collect_regions: bool = True, max_levels: Optional[int] = None, shard_min: int = 128, force_shard: bool = False,
+                      full_solution: str = 'all') -> Solution:
+    """``full_solution``: 'all' -- every rank returns the complete Solution (the reference's parent process holds it,
+    mpqp_parrallel_combinatorial.py:127-131; default); 'rank0' -- only rank 0 turns the other ranks' gathered records into host
+    arrays and region objects, every other rank returns the regions of the replicated levels and of its own shards (its
+    ``Solution`` is then partial: the eight-fold repetition of the host work is what the option removes).
+
+    ``_solve_distributed``; when a level on some rank runs out of spare region slots, all ranks learn it from that level's
     statistics exchange (replicated levels: every rank hits it by itself, the kernels are deterministic) and repeat the solve
     together with the region stage behind the (x,theta) stage.  No candidate is ever demoted."""
+    if full_solution not in ('all', 'rank0'):
+        raise ValueError("full_solution must be 'all' or 'rank0'")
     try:
-        return _solve_distributed(engine, program, group, profile, collect_regions, max_levels, shard_min, force_shard)
+        return _solve_distributed(engine, program, group, profile, collect_regions, max_levels, shard_min, force_shard, full_solution)
     except _RepeatWithoutOverlap:
         if hasattr(engine, 'set_region_overlap'):
             engine.set_region_overlap(False)
         if profile is not None:
             del profile[:]
-        return _solve_distributed(engine, program, group, profile, collect_regions, max_levels, shard_min, force_shard)
+        return _solve_distributed(engine, program, group, profile, collect_regions, max_levels, shard_min, force_shard, full_solution)
 
 
 def _solve_distributed(engine, program=None, group=None, profile: Optional[List[Dict]] = None,
-                       collect_regions: bool = True, max_levels: Optional[int] = None, shard_min: int = 128, force_shard: bool = False) -> Solution:
+                       collect_regions: bool = True, max_levels: Optional[int] = None, shard_min: int = 128, force_shard: bool = False,
+                       full_solution: str = 'all') -> Solution:
     """The level loop of the parallel combinatorial algorithm over the ranks of ``group`` (see the module docstring).
     Every rank returns the complete Solution.  Works without an initialised process group (world size 1)."""
     active = dist.is_available() and dist.is_initialized()
@@ -282,7 +291,9 @@ def _solve_distributed(engine, program=None, group=None, profile: Optional[List[
         for _, work in gathers:
             if work is not None:
                 work.wait()
-        for a, b, c in zip(gathers[0][0], gathers[1][0], gathers[2][0]):
+        for src, (a, b, c) in enumerate(zip(gathers[0][0], gathers[1][0], gathers[2][0])):
+            if full_solution == 'rank0' and rank != 0 and src != rank:
+                continue      # another rank's shard: only rank 0 builds its objects
             if a.shape[0]:
                 hd, hi, er = to_host(a), to_host(b), to_host(c)
                 slots = numpy.flatnonzero(hi[:, 0] == REGION_STATUS)

@@ -110,6 +110,55 @@ class OracleLevelEngine:
         return numpy.bincount(status, minlength=6).tolist(), self._unpack(status, d, i)
 
 
+class _OutOfSlots(Exception):
+    pass
+
+
+class FlakyEngine(OracleLevelEngine):
+    """Fails ONE level on ONE rank the way the HIP engine reports 'out of spare region slots' (MpcCapacityError), until the driver
+    switches the overlapped region stage off."""
+    capacity_error = _OutOfSlots
+
+    def __init__(self, P, rank, fail_rank, fail_level):
+        super().__init__(P)
+        self.rank, self.fail_rank, self.fail_level, self.level, self.overlap, self.failed = rank, fail_rank, fail_level, 0, True, 0
+
+    def root(self):
+        self.level = 0
+        super().root()
+
+    def run(self, gen_children):
+        self.level += 1
+        if self.overlap and self.rank == self.fail_rank and self.level == self.fail_level:
+            self.failed += 1
+            raise _OutOfSlots('late optimal candidates exceed the spare region slots')
+        return super().run(gen_children)
+
+    def set_region_overlap(self, on):
+        self.overlap = on
+
+
+def _worker_opts(rank, world, port, name, shard_min, mode, out):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        from oracle import oracle as orc
+        from ppopt_amd.distributed import solve_distributed
+        P = orc.problem_from_golden(load_golden(name))
+        if mode == 'rank0':
+            sol = solve_distributed(OracleLevelEngine(P), shard_min=shard_min, full_solution='rank0')
+            out[rank] = ([tuple(r.active_set) for r in sol.critical_regions], 0)
+        else:
+            eng = FlakyEngine(P, rank, fail_rank=1, fail_level=int(mode))
+            sol = solve_distributed(eng, shard_min=shard_min)
+            out[rank] = ([tuple(r.active_set) for r in sol.critical_regions], eng.failed)
+    finally:
+        dist.destroy_process_group()
+
+
 def _worker(rank, world, port, name, shard_min, out):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, 'tests'))
@@ -166,3 +215,24 @@ def test_single_process_path_without_process_group(oracle):
     g = load_golden('transport_mpqp')
     sol = solve_distributed(OracleLevelEngine(oracle.problem_from_golden(g)))
     assert sorted(tuple(r.active_set) for r in sol.critical_regions) == sorted(golden_regions(g))
+
+
+@pytest.mark.parametrize('mode', ['rank0', '1', '3'])
+def test_two_rank_options(mode):
+    """'rank0': only rank 0 returns the complete Solution, rank 1 the regions of the replicated levels and of its own shards.
+    '1' / '3': rank 1's level 1 (replicated) / level 3 (sharded) fails with the engine's 'out of spare region slots' error --
+    BOTH ranks must learn it in that level's exchange, repeat the solve together with the region overlap switched off, and
+    return the complete region set (a rank that carried on alone would hang in the next collective)."""
+    world, name, shard_min = 2, 'rand_4_2_10_s0', 20
+    port = 31500 + (os.getpid() % 2000)
+    with mp.Manager() as mgr:
+        out = mgr.dict()
+        mp.spawn(_worker_opts, args=(world, port, name, shard_min, mode, out), nprocs=world, join=True)
+        res = dict(out)
+    ref = sorted(golden_regions(load_golden(name)))
+    assert sorted(res[0][0]) == ref
+    if mode == 'rank0':
+        assert set(res[1][0]) < set(ref) and len(res[1][0]) > 0
+    else:
+        assert sorted(res[1][0]) == ref
+        assert res[1][1] == 1 and res[0][1] == 0

@@ -101,6 +101,8 @@ def bench(wl, solves, dbs):
            'factors': {'read16': f_r16, 'read8': f_r8, 'sector8': f_rs, 'write16': f_w16, 'write8': f_w8},
            'note': 'per-step totals use the coalesced 8-byte factors for every kernel; per-kernel figures use the factor of the kernel\'s own pattern'}
     res['bytes_per_step'] = res['fetch_bytes_per_step'] + res['write_bytes_per_step']
+    for key, k in kernels.items():      # per step (= per solve): independent of how launches are counted
+        k['bytes_per_step'] = k['bytes_per_launch'] * k['launches_counted'] / solves
     for tag in ('sq', 'f64'):
         if tag in dbs and os.path.exists(dbs[tag]):
             t, _ = per_kernel(dbs[tag])
@@ -108,8 +110,10 @@ def bench(wl, solves, dbs):
                 launches = solves * (1 if key.startswith('k_xq') else LEVELS[wl])
                 k = kernels.setdefault(key, {'launches_counted': launches})
                 sq = k.setdefault('sq_per_launch', {})
+                st = k.setdefault('sq_per_step', {})
                 for c, (n, v) in ctrs.items():
                     sq[c] = v / launches
+                    st[c] = v / solves
     d[wl] = res
     save(d)
     print(json.dumps(res, indent=1)[:3000])
