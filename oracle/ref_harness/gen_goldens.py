@@ -278,6 +278,9 @@ REGISTRY = {
     'c5_control_allocation': (lambda: pg.control_allocation_data(), {}),
     'c4_rand_20_8_20_s0': (lambda: pg.generate_mpqp_data(20, 8, 20, 0), dict(max_levels=2)),
     'c3_quadtank_n10': (lambda: pg.quad_tank_data(10), dict(max_levels=2)),
+    # 82 rows after presolve (two tableau rows per lane on the device), big-M rows with right-hand sides of 1e7 left in: found by
+    # tools/fuzz_scan.py big -- the reference and the device agree on [0, 2, 4] (a region), the CPU oracle's dense simplex does not
+    'big_24_7_34_s430912': (lambda: pg.generate_mpqp_data(24, 7, 34, 430912), dict(max_levels=3)),
 }
 
 if __name__ == '__main__':

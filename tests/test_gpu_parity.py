@@ -17,7 +17,10 @@ pytestmark = pytest.mark.gpu
 
 FULL = ['c1_transport_mplp', 'mplp_rand_4_2_10_s0', 'mplp_rand_5_3_12_s2', 'transport_mpqp', 'dblint_n3', 'c2_dblint_n5', 'rand_4_2_10_s0', 'rand_5_3_8_s3',
         'rand_6_3_12_s1', 'quadtank_n2', 'quadtank_n3']
-PARTIAL = ['c4_rand_20_8_20_s0', 'c3_quadtank_n10']
+# big_24_7_34_s430912: 82 rows (two tableau rows per lane), big-M rows left in; three levels, 91,183 candidates (regions stored for
+# levels 1-2).  Found by tools/fuzz_scan.py: on [0, 2, 4] the reference and the device say "region", the CPU oracle's dense simplex
+# does not (tests/test_oracle_goldens.py lists it) -- this golden pins the device to the reference where the oracle cannot
+PARTIAL = ['c4_rand_20_8_20_s0', 'c3_quadtank_n10', 'big_24_7_34_s430912']
 COEF_TOL = 1e-8  # north_star: "within 1e-8 on region affine coefficients"
 
 

@@ -120,3 +120,27 @@ def test_config5_deep_golden(oracle):
         differ += int((status != gv[pinned]).sum())
     assert checked >= 4000
     assert differ == 0, differ
+
+
+# candidates on which the CPU oracle is known to differ from the reference (golden name -> {active set: reference verdict}): its
+# dense two-phase simplex declares the reference's 285 x 114 optimality LP infeasible -- rows with right-hand sides of 1e7 (big-M
+# rows the presolve leaves in) against an absolute 1e-7 tolerance; HiGHS scales the problem.  The DEVICE agrees with the reference
+# there (tests/test_gpu_parity.py, same golden).
+ORACLE_KNOWN_DIFFERENCES = {'big_24_7_34_s430912': {(0, 2, 4): 3}}
+
+
+def test_big_m_golden_oracle_differs_only_where_listed(oracle):
+    name = 'big_24_7_34_s430912'
+    g = load_golden(name)
+    P = oracle.problem_from_golden(g)
+    differing = {}
+    for i in range(int(g['n_levels'])):
+        cands, gv = g[f'L{i}_cands'], g[f'L{i}_verdict']
+        step = 1 if len(cands) <= 4000 else 8          # level 3: every 8th candidate, plus the listed ones
+        idx = numpy.arange(0, len(cands), step)
+        listed = [j for j, c in enumerate(cands.tolist()) if tuple(c) in ORACLE_KNOWN_DIFFERENCES[name]]
+        idx = numpy.unique(numpy.concatenate([idx, numpy.array(listed, dtype=idx.dtype)]))
+        status, _ = P.check_level(cands[idx], threads=8, want_regions=False)
+        for j in numpy.flatnonzero(status != gv[idx]).tolist():
+            differing[tuple(int(v) for v in cands[idx[j]])] = int(gv[idx[j]])
+    assert differing == ORACLE_KNOWN_DIFFERENCES[name]
