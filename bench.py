@@ -355,6 +355,7 @@ def main():
     # CriticalRegion objects returned by the solve are views into per-level arrays that are cut out on first access;
     # the time to touch every field of every region is reported separately (not part of `value`)
     t_mat = time.perf_counter()
+    sol.materialize()                     # batch-wise (Solution.materialize); then every region is touched once more, field by field
     for cr in sol.critical_regions:
         if hasattr(cr, 'materialize'):
             cr.materialize()

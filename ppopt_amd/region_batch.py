@@ -124,3 +124,35 @@ class BatchCriticalRegion(CriticalRegion):
         for name in ('A', 'b', 'C', 'd', 'E', 'f', 'active_set', 'omega_set', 'lambda_set', 'regular_set'):
             getattr(self, name)
         return self
+
+
+def materialize_regions(regions) -> None:
+    """Touches every field of many regions at once: the regions of one RegionBatch are cut out of its three arrays with a handful
+    of array-wide operations (one reshape per matrix field, one ``tolist`` per index field) instead of ten small slices per
+    region.  Regions that are ordinary ``CriticalRegion`` objects are left as they are."""
+    groups = {}
+    for r in regions:
+        if isinstance(r, BatchCriticalRegion):
+            groups.setdefault(id(r._batch), (r._batch, []))[1].append(r)
+    for B, regs in groups.values():
+        js = numpy.fromiter((r._j for r in regs), dtype=numpy.int64, count=len(regs))
+        hd, hi = B.hd[js], B.hi[js]
+        A = hd[:, B.oA:B.ob].reshape(-1, B.n_x, B.n_t)
+        b = hd[:, B.ob:B.oC].reshape(-1, B.n_x, 1)
+        C = hd[:, B.oC:B.od].reshape(-1, B.k, B.n_t)
+        d = hd[:, B.od:B.od + B.k].reshape(-1, B.k, 1)
+        hdr = hi[:, :8].tolist()
+        act = hi[:, B.iact:B.iact + B.k].tolist()
+        om = hi[:, B.iom:B.iom + B.n_tc].tolist()
+        la = hi[:, B.ila:B.ila + B.k].tolist()
+        ri = hi[:, B.iri:B.iri + (B.n_c - B.k)].tolist()
+        rc = hi[:, B.irc:B.irc + (B.n_c - B.k)].tolist()
+        er = B.er
+        for i, r in enumerate(regs):
+            h = hdr[i]
+            dd = r.__dict__
+            rows = er[h[6]:h[6] + h[2]]
+            dd.setdefault('A', A[i]); dd.setdefault('b', b[i]); dd.setdefault('C', C[i]); dd.setdefault('d', d[i])
+            dd.setdefault('E', rows[:, 1:]); dd.setdefault('f', rows[:, :1])
+            dd.setdefault('active_set', act[i]); dd.setdefault('omega_set', om[i][:h[3]]); dd.setdefault('lambda_set', la[i][:h[4]])
+            dd.setdefault('regular_set', [ri[i][:h[5]], rc[i][:h[5]]])

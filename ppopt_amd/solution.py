@@ -270,6 +270,13 @@ class Solution:
                     return False
         return True
 
+    def materialize(self) -> 'Solution':
+        """Cuts every field of every region out of the per-level arrays the device returned (the regions a solve hands back are lazy
+        views, ppopt_amd/region_batch.py) -- batch-wise, a few array operations per level.  Returns self."""
+        from .region_batch import materialize_regions
+        materialize_regions(self.critical_regions)
+        return self
+
     def is_mixed_integer_sol(self) -> bool:
         from .mpmilp_program import MPMILP_Program
         return isinstance(self.program, MPMILP_Program)

@@ -246,3 +246,46 @@ def test_geometric_sub_active_set():
     assert _sub_active_set(P(), [0, 1, 2, 3]) == [0, 2]
     P.equality_indices = [3]
     assert _sub_active_set(P(), [3, 0, 1, 2]) == [3, 0]
+
+
+def test_batch_materialisation_equals_lazy_access():
+    """Solution.materialize / region_batch.materialize_regions: the fields cut out batch-wise are the fields each region would
+    cut out lazily; fields that were assigned before are kept; plain CriticalRegion objects are left alone."""
+    from ppopt_amd.region_batch import RegionBatch
+    from ppopt_amd.solution import Solution
+    rng = numpy.random.default_rng(2)
+    n_x, n_t, n_c, n_tc, k = 4, 3, 9, 6, 3
+    fd = n_x * n_t + n_x + k * n_t + k
+    fi = 8 + k + n_tc + k + 2 * (n_c - k)
+    n = 7
+    hd = rng.random((n, fd))
+    hi = -numpy.ones((n, fi), dtype=numpy.int32)
+    er = rng.random((40, n_t + 1))
+    off = 0
+    for j in range(n):
+        nE, n_om, n_la, n_re = int(rng.integers(1, 6)), int(rng.integers(0, n_tc + 1)), int(rng.integers(0, k + 1)), int(rng.integers(0, n_c - k + 1))
+        hi[j, :8] = [3, j, nE, n_om, n_la, n_re, off, 0]
+        off += nE
+        hi[j, 8:8 + k] = sorted(rng.choice(n_c, k, replace=False).tolist())
+        hi[j, 8 + k:8 + k + n_om] = numpy.arange(n_om)
+        hi[j, 8 + k + n_tc:8 + k + n_tc + n_la] = numpy.arange(n_la)
+        hi[j, 8 + 2 * k + n_tc:8 + 2 * k + n_tc + n_re] = numpy.arange(n_re)
+        hi[j, 8 + 2 * k + n_tc + (n_c - k):8 + 2 * k + n_tc + (n_c - k) + n_re] = 10 + numpy.arange(n_re)
+    slots = numpy.array([0, 2, 3, 5, 6])
+    lazy = RegionBatch(hd, hi, er, n_x, n_t, n_c, n_tc, k, slots).regions()
+    eager = RegionBatch(hd, hi, er, n_x, n_t, n_c, n_tc, k, slots).regions()
+    marker = numpy.zeros((n_x, n_t))
+    eager[1].A = marker
+    plain = CriticalRegion(numpy.ones((n_x, n_t)), numpy.ones((n_x, 1)), numpy.ones((k, n_t)), numpy.ones((k, 1)), numpy.ones((2, n_t)),
+                           numpy.ones((2, 1)), [0, 1, 2], [], [], [[], []])
+
+    class P:
+        def num_t(self):
+            return n_t
+    sol = Solution(P(), eager + [plain])
+    assert sol.materialize() is sol
+    assert eager[1].A is marker
+    for a, b in zip(lazy, eager):
+        for fld in ('b', 'C', 'd', 'E', 'f') + (() if b is eager[1] else ('A',)):
+            assert fld in b.__dict__ and numpy.array_equal(getattr(a, fld), getattr(b, fld)), fld
+        assert a.active_set == b.active_set and a.omega_set == b.omega_set and a.lambda_set == b.lambda_set and a.regular_set == b.regular_set
