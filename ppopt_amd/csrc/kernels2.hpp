@@ -252,7 +252,13 @@ __global__ void __launch_bounds__(64, (NT * SLOTS >= 20 ? 3 : (SLOTS >= 2 ? TH_W
     // (a block beyond the number of work items has nothing to take from the queue: it leaves before touching the queue's counter --
     //  with device-resident lengths the launch is sized by a bound, and thousands of surplus blocks would otherwise serialise on
     //  that one address)
-    if (ta.n_dev) { n = *ta.n_dev; if ((long long)blockIdx.x * ta.chunk >= n) return; }
+    if (ta.n_dev) {
+        n = *ta.n_dev;
+        // chunk <= 0: the host does not know n either; the rule it would have applied (candidates per queue atomic so that every
+        // block of the persistent grid gets about eight turns, at most 16) is applied here
+        if (ta.chunk <= 0) ta.chunk = (int)max(1ll, min(16ll, n / ((long long)gridDim.x * 8)));
+        if ((long long)blockIdx.x * ta.chunk >= n) return;
+    }
     extern __shared__ __attribute__((aligned(16))) double smem[];
     Smem s = carve(P, smem);
     constexpr int LS = NT + 1;
@@ -676,7 +682,11 @@ __global__ void __launch_bounds__(64, XQ_WAVES) k_xq(const DevProblem *__restric
                                                LevelCounters *__restrict__ ctr, DictCache dc, int NXC) {
     const DevProblem &P = *Pg;
     const int lane = lane_id(), nv = P.n_x + P.n_t, mr = P.n_d0r;
-    if (dc.n_list_dev) { n_list = *dc.n_list_dev; if ((long long)blockIdx.x * dc.chunk >= n_list) return; }
+    if (dc.n_list_dev) {
+        n_list = *dc.n_list_dev;
+        if (dc.chunk <= 0) dc.chunk = (int)max(1ll, min(16ll, (long long)n_list / ((long long)gridDim.x * 4)));
+        if ((long long)blockIdx.x * dc.chunk >= n_list) return;
+    }
     unsigned long long pivots = 0, n_quick = 0;
     for (;;) {
         unsigned int w0 = 0;
@@ -800,7 +810,10 @@ __global__ void __launch_bounds__(64, (NXC * SLOTS >= 32 ? X2_WAVES : 3)) k_x2(c
     if (dc.n_pre1_dev) dc.n_pre1 = *dc.n_pre1_dev;
     if (dc.n_pre2_dev) dc.n_pre2 = *dc.n_pre2_dev;
     const int n_pre = dc.n_pre1 + dc.n_pre2, n_items = n_pre + n_list;
-    if (dc.n_list_dev && (long long)blockIdx.x * dc.chunk >= n_items) return;
+    if (dc.n_list_dev) {
+        if (dc.chunk <= 0) dc.chunk = (int)max(1ll, min(16ll, (long long)n_items / ((long long)gridDim.x * 8)));
+        if ((long long)blockIdx.x * dc.chunk >= n_items) return;
+    }
     unsigned long long pivots = 0, n_retry = 0, n_cached = 0;
     long long cyc_x = 0;
     int sink = 0;

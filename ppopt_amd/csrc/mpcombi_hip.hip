@@ -255,6 +255,8 @@ struct mpc_handle {
     int rsplit_max = 4;              // MPC_RSPLIT_MAX: most wavefronts that share one optimal candidate in k_region2 (power of two, <= 16; measured:
                                      // 8 and 16 shorten no level of config 4 or 2 -- every wavefront repeats the row build and the Chebyshev LP, 40 % of
                                      // a region at 4 -- and move the facet list of one sliver region)
+    bool no_lean = false;            // MPC_NO_LEAN=1: large levels read every list length back (round-2 behaviour); default: only the lengths the
+                                     // host needs to size the region stage are read back, the other stages take theirs from device memory
     bool no_smallpath = false;       // MPC_NO_SMALLPATH=1: levels of any size take the classic path with its host round trips (A/B)
     long long smallpath_max = 4096;  // MPC_SMALLPATH_MAX: largest level (candidates) that runs without host round trips (measured: config 4 is
                                      // fastest with 1,024-4,096 -- a level of 15,691 candidates prefers the classic path, which streams its records)
@@ -308,10 +310,11 @@ struct mpc_handle {
     // frontier / pruned
     int32_t *tot_host = nullptr, *tot_dev = nullptr;   // 16 counters in pinned host memory that the kernels write directly: list lengths need no copy
     const int32_t *opt_ptr = nullptr;                  // list of the optimal candidates of the level (a view, not a copy)
-    DevBuf frontier, children, status, pruned, pruned_new, flag, pos, opt_list, childmask, count, offset, recd, reci, ctr, scratch, sums;
+    DevBuf frontier, children, status, pruned, flag, pos, opt_list, childmask, count, offset, recd, reci, ctr, scratch, sums;
     long long n = 0;
     int k = 0;
     long long n_pruned = 0;
+    long long n_pruned_extra = 0;   // masks added from outside (other ranks') behind this level's own new ones, before mpc_frontier_advance
     // level results
     bool level_done = false;
     long long n_opt = 0, n_children = 0, n_pruned_new = 0, n_regions = 0;
@@ -333,6 +336,9 @@ struct mpc_handle {
     std::condition_variable wcv;
     int w_req = 0;              // 0 idle, 1 run a level, 2 exit
     bool w_busy = false, w_stream_ready = false;
+    // mirrors of the three flags for a short spin before the condition-variable wait: a hand-over through the condition variable
+    // alone costs 20-50 us of GPU idle time per level (tools/gpu_idle.sh), a spinning waiter sees the flag within a microsecond
+    std::atomic<int> a_req{0}, a_busy{0}, a_ready{0};
     int w_gen = 0, w_flags = 0, w_rc = 0;
     // result of the base-set check the worker ran behind the last level (MPC_LEVEL_THEN_BASE)
     bool base_valid = false;
@@ -526,6 +532,7 @@ static int create_fill(const mpc_problem *p, int32_t device, void *stream, mpc_h
     { const char *ev = std::getenv("MPC_TEST_LATE"); h->test_late = ev ? std::atoi(ev) : 0; }
     { const char *ev = std::getenv("MPC_TEST_SPARE"); h->test_spare = ev ? std::atoi(ev) : 0; }
     { const char *ev = std::getenv("MPC_NO_SMALLPATH"); h->no_smallpath = ev && ev[0] == '1'; }
+    { const char *ev = std::getenv("MPC_NO_LEAN"); h->no_lean = ev && ev[0] == '1'; }
     { const char *ev = std::getenv("MPC_RSPLIT_MAX"); if (ev) { int v = std::atoi(ev); h->rsplit_max = v >= 16 ? 16 : (v >= 8 ? 8 : (v >= 4 ? 4 : (v >= 2 ? 2 : 1))); } }
     { const char *ev = std::getenv("MPC_SMALLPATH_MAX"); if (ev) h->smallpath_max = std::atoll(ev); }
     { const char *ev = std::getenv("MPC_ROVERLAP_MIN"); if (ev) h->roverlap_min = std::atoll(ev); }
@@ -871,7 +878,7 @@ extern "C" {
 int mpc_destroy(mpc_handle *h) {
     if (!h) return MPC_OK;
     if (h->worker.joinable()) {
-        { std::unique_lock<std::mutex> lk(h->wm); h->wcv.wait(lk, [&] { return !h->w_busy; }); h->w_req = 2; }
+        { std::unique_lock<std::mutex> lk(h->wm); h->wcv.wait(lk, [&] { return !h->w_busy; }); h->w_req = 2; h->a_req.store(1, std::memory_order_release); }
         h->wcv.notify_all();
         h->worker.join();
     }
@@ -879,7 +886,7 @@ int mpc_destroy(mpc_handle *h) {
     (void)hipStreamSynchronize(h->stream);
     if (h->stream2) (void)hipStreamSynchronize(h->stream2);
     if (h->stream3) (void)hipStreamSynchronize(h->stream3);
-    for (DevBuf *b : {&h->blocks, &h->iblocks, &h->frontier, &h->children, &h->status, &h->pruned, &h->pruned_new, &h->flag, &h->pos, &h->opt_list,
+    for (DevBuf *b : {&h->blocks, &h->iblocks, &h->frontier, &h->children, &h->status, &h->pruned, &h->flag, &h->pos, &h->opt_list,
                       &h->childmask, &h->count, &h->offset, &h->recd, &h->reci, &h->ctr, &h->scratch, &h->sums, &h->retry_list, &h->pf_dev, &h->pr2_dev, &h->headd, &h->headi, &h->epool, &h->facet_flags, &h->kkt_code, &h->kkt_L, &h->theta_blocks, &h->xq_groups, &h->theta_list, &h->vretry_list, &h->status_tmp, &h->part_counts, &h->part_lists, &h->kept_g, &h->done_g, &h->dict_d[0], &h->dict_d[1], &h->dict_i[0], &h->dict_i[1],
                       &h->dict_stored[0], &h->dict_stored[1], &h->parent_slot, &h->parent_slot_next, &h->dcnt}) b->release();
     if (h->tot_host) { (void)host_pool_give(h->tot_host); h->tot_host = h->tot_dev = nullptr; }
@@ -937,7 +944,7 @@ static int frontier_reset(mpc_handle *h, long long n, int k) {
     if (n > 0x7fffffffLL / std::max(k + 1, 1)) return fail(h, MPC_ERR_INVALID, "frontier too large for 32-bit offsets");
     HIP_TRY(h, hipSetDevice(h->device));
     HIP_TRY(h, h->frontier.ensure((size_t)std::max<long long>(n, 1) * std::max(k, 1) * sizeof(int32_t), h->stream));
-    h->n = n; h->k = k; h->level_done = false;
+    h->n = n; h->k = k; h->level_done = false; h->n_pruned_extra = 0;
     h->have_prev_dict = false; h->have_parent_slot = false;   // a frontier set from outside has no cached parent dictionaries
     return MPC_OK;
 }
@@ -1020,16 +1027,19 @@ int mpc_frontier_get(mpc_handle *h, int32_t *cand, int64_t cap) {
     return MPC_OK;
 }
 
-int mpc_pruned_clear(mpc_handle *h) { if (!h) return MPC_ERR_INVALID; h->n_pruned = 0; return MPC_OK; }
+int mpc_pruned_clear(mpc_handle *h) { if (!h) return MPC_ERR_INVALID; h->n_pruned = 0; h->n_pruned_extra = 0; return MPC_OK; }
 
 static int pruned_add(mpc_handle *h, const uint64_t *masks, int64_t m, hipMemcpyKind kind) {
     if (!h || (m > 0 && !masks) || m < 0) return MPC_ERR_INVALID;
     if (m == 0) return MPC_OK;
     HIP_TRY(h, hipSetDevice(h->device));
-    HIP_TRY(h, h->pruned.ensure((size_t)(h->n_pruned + m) * h->mw * sizeof(uint64_t), h->stream, true));
-    HIP_TRY(h, hipMemcpyAsync(h->pruned.as<uint64_t>() + (size_t)h->n_pruned * h->mw, masks, (size_t)m * h->mw * sizeof(uint64_t), kind, h->stream));
-    if (masks != h->pruned_new.p) HIP_TRY(h, hipStreamSynchronize(h->stream));  // caller-owned source
-    h->n_pruned += m;
+    // A level that has run keeps its newly pruned masks right behind the list (they join it at mpc_frontier_advance): masks that
+    // arrive in between -- the other ranks' -- go behind those.
+    const long long tail = h->level_done ? h->n_pruned_new + h->n_pruned_extra : 0;
+    HIP_TRY(h, h->pruned.ensure((size_t)(h->n_pruned + tail + m) * h->mw * sizeof(uint64_t), h->stream, true));
+    HIP_TRY(h, hipMemcpyAsync(h->pruned.as<uint64_t>() + (size_t)(h->n_pruned + tail) * h->mw, masks, (size_t)m * h->mw * sizeof(uint64_t), kind, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));  // caller-owned source
+    if (h->level_done) h->n_pruned_extra += m; else h->n_pruned += m;
     return MPC_OK;
 }
 int mpc_pruned_add(mpc_handle *h, const uint64_t *masks, int64_t m) { return pruned_add(h, masks, m, hipMemcpyHostToDevice); }
@@ -1095,6 +1105,7 @@ static int launch_region_v1(mpc_handle *h, const int32_t *list, long long n_list
 static void stream_ready(mpc_handle *h) {
     std::lock_guard<std::mutex> lk(h->wm);
     h->w_stream_ready = true;
+    h->a_ready.store(1, std::memory_order_release);
     h->wcv.notify_all();
 }
 static void stream_release(mpc_handle *h) {   // blocks of a streamed level nobody took
@@ -1140,7 +1151,7 @@ static int level_run_small(mpc_handle *h, int32_t gen_children, int32_t flags, m
     h->n_opt = h->n_children = h->n_pruned_new = h->n_regions = 0;
     h->n_needx = 0;
     HIP_TRY(h, h->status.ensure(nn, st));
-    HIP_TRY(h, h->pruned_new.ensure(nn * h->mw * sizeof(uint64_t), st));
+    HIP_TRY(h, h->pruned.ensure((size_t)(h->n_pruned + n) * h->mw * sizeof(uint64_t), st, true));   // the level's newly pruned masks go behind the list
     HIP_TRY(h, h->retry_list.ensure(nn * sizeof(int32_t), st));
     HIP_TRY(h, h->theta_list.ensure(nn * sizeof(int32_t), st));
     HIP_TRY(h, h->part_lists.ensure((size_t)PART_CLASSES * nn * sizeof(int32_t), st));
@@ -1303,9 +1314,9 @@ static int level_run_small(mpc_handle *h, int32_t gen_children, int32_t flags, m
     // ---- pruned masks of this level + children -------------------------------------------------------------------------------------
     const int keep_lowdim = (flags & MPC_LEVEL_KEEP_LOWDIM) ? 1 : 0;
     if (h->mw == 2) hipLaunchKernelGGL(k_pruned_append<2>, dim3(blocks256), dim3(256), 0, st, h->frontier.as<int32_t>(), n, k, h->status.as<uint8_t>(),
-                                       h->pruned_new.as<unsigned long long>(), ctr, keep_lowdim);
+                                       h->pruned.as<unsigned long long>() + (size_t)h->n_pruned * h->mw, ctr, keep_lowdim);
     else hipLaunchKernelGGL(k_pruned_append<4>, dim3(blocks256), dim3(256), 0, st, h->frontier.as<int32_t>(), n, k, h->status.as<uint8_t>(),
-                            h->pruned_new.as<unsigned long long>(), ctr, keep_lowdim);
+                            h->pruned.as<unsigned long long>() + (size_t)h->n_pruned * h->mw, ctr, keep_lowdim);
     if (gen_children) {
         HIP_TRY(h, h->childmask.ensure(nn * h->mw * sizeof(uint64_t), st));
         HIP_TRY(h, h->count.ensure(nn * sizeof(int32_t), st));
@@ -1407,28 +1418,41 @@ static int level_run_impl(mpc_handle *h, int32_t gen_children, int32_t flags, mp
         HIP_TRY(h, h->flag.ensure(nn * sizeof(int32_t), st));
         HIP_TRY(h, h->pos.ensure(nn * sizeof(int32_t), st));
         HIP_TRY(h, h->opt_list.ensure(nn * sizeof(int32_t), st));
-        HIP_TRY(h, h->pruned_new.ensure(nn * h->mw * sizeof(uint64_t), st));
+        HIP_TRY(h, h->pruned.ensure((size_t)(h->n_pruned + n) * h->mw * sizeof(uint64_t), st, true));   // the level's newly pruned masks go behind the list
         HIP_TRY(h, hipMemsetAsync(h->ctr.p, 0, sizeof(LevelCounters), st));
         LevelCounters *ctr = h->ctr.as<LevelCounters>();
         int32_t *total = h->tot_dev;          // device alias of h->tot_host: valid on the host after the next synchronisation
         const bool small = n <= SMALL_LEVEL_N;
         const int blocks256 = (int)((n + 255) / 256);
         // compacts the candidates whose status lies in [lo, hi] into h->retry_list; returns their number
-        auto compact = [&](int lo, int hi, int32_t *count) -> int {
+        // count_dev != nullptr: the length goes to device memory only and nobody waits for it (the consumer kernel reads it there)
+        auto compact = [&](int lo, int hi, int32_t *count, int32_t *count_dev = nullptr) -> int {
             HIP_TRY(h, h->retry_list.ensure(nn * sizeof(int32_t), st));
+            int32_t *tot = count_dev ? count_dev : total;
             if (small) {
-                hipLaunchKernelGGL(k_compact_small, dim3(1), dim3(1024), 0, st, h->status.as<uint8_t>(), (int)n, lo, hi, h->retry_list.as<int32_t>(), total);
+                hipLaunchKernelGGL(k_compact_small, dim3(1), dim3(1024), 0, st, h->status.as<uint8_t>(), (int)n, lo, hi, h->retry_list.as<int32_t>(), tot);
             } else {
                 hipLaunchKernelGGL(k_flag_status, dim3(blocks256), dim3(256), 0, st, h->status.as<uint8_t>(), n, lo, hi, h->flag.as<int32_t>());
-                int rcs = launch_scan(h, h->flag.as<int32_t>(), h->pos.as<int32_t>(), n, total);
+                int rcs = launch_scan(h, h->flag.as<int32_t>(), h->pos.as<int32_t>(), n, tot);
                 if (rcs) return rcs;
                 hipLaunchKernelGGL(k_scatter_index, dim3(blocks256), dim3(256), 0, st, h->flag.as<int32_t>(), h->pos.as<int32_t>(), n, h->retry_list.as<int32_t>());
             }
             HIP_TRY(h, hipGetLastError());
+            if (count_dev) return MPC_OK;
             HIP_TRY(h, hipStreamSynchronize(st));
             *count = h->tot_host[0];
             return MPC_OK;
         };
+        // Lean form of a large level (round 3): the classic sequence read a list length back after almost every stage -- 22 idle gaps of
+        // 15-30 us per solve of config 4 (tools/gpu_idle.sh).  The host needs only the lengths that size the region stage (one
+        // read-back after the theta stage) and the final statistics; the theta LP, the (x,theta) stage after the quick test and the
+        // child generation take theirs from device memory (dcnt: [0] theta list, [8] open after the quick test, [20] children) and are
+        // launched for the bound the host does know.
+        const bool lean = !h->no_lean;
+        HIP_TRY(h, h->dcnt.ensure(32 * sizeof(int32_t), st));
+        HIP_TRY(h, hipMemsetAsync(h->dcnt.p, 0, 32 * sizeof(int32_t), st));
+        int32_t *dcnt = h->dcnt.as<int32_t>();
+        bool theta_lean = false, xq_lean = false, children_lean = false;
         // deterministic partition of the candidates into up to four lists by status (spec: status -> class nibble, 15 = none);
         // the lists are h->part_lists + c * n, their lengths come back in counts[]
         const int nb1024 = (int)((n + 1023) / 1024);
@@ -1569,8 +1593,9 @@ static int level_run_impl(mpc_handle *h, int32_t gen_children, int32_t flags, mp
                 kernel_timed[3] = true;
                 HIP_TRY(h, hipGetLastError());
                 int32_t n_todo = 0;
-                { int rcs = compact(ST_TODO, ST_TODO, &n_todo); if (rcs) return rcs; }
-                n_theta = n_todo;
+                if (lean) { int rcs = compact(ST_TODO, ST_TODO, nullptr, dcnt + 0); if (rcs) return rcs; theta_lean = true; n_todo = (int32_t)n; }
+                else { int rcs = compact(ST_TODO, ST_TODO, &n_todo); if (rcs) return rcs; }
+                n_theta = n_todo;   // lean: the bound
                 HIP_TRY(h, h->theta_list.ensure(nn * sizeof(int32_t), st));
                 std::swap(h->theta_list, h->retry_list);   // compact() filled retry_list; keep it as the theta list
                 theta_list = h->theta_list.as<int32_t>();
@@ -1578,7 +1603,8 @@ static int level_run_impl(mpc_handle *h, int32_t gen_children, int32_t flags, mp
             if (n_theta > 0) {   // two-stage theta LP
                 ThetaArgs ta = h->targs;
                 ta.chunk = (int)std::max<long long>(1, std::min<long long>(16, n_theta / ((long long)h->grid_f * 8)));
-                const dim3 g((unsigned)std::min<long long>((n_theta + ta.chunk - 1) / ta.chunk, h->grid_f)), b(64);
+                if (theta_lean) { ta.n_dev = dcnt + 0; ta.chunk = 0; }   // length and chunk rule on the device
+                const dim3 g((unsigned)std::min<long long>(theta_lean ? n_theta : (n_theta + ta.chunk - 1) / ta.chunk, h->grid_f)), b(64);
                 HIP_TRY(h, hipEventRecord(h->kev[0], st));
                 switch (h->fast_t) {
                     case 0: hipLaunchKernelGGL((k_theta2<4, 1>), g, b, h->lds_f, st, pf, fr, n_theta, k, stp, ctr, kkc, kkl, ta, theta_list); break;
@@ -1671,7 +1697,8 @@ static int level_run_impl(mpc_handle *h, int32_t gen_children, int32_t flags, mp
                 DictCache d = d0;
                 const long long grid_x = (long long)h->n_cu * 16, n_all = (long long)n_items + d.n_pre1 + d.n_pre2;
                 d.chunk = (int)std::max<long long>(1, std::min<long long>(16, n_all / (grid_x * 8)));
-                const dim3 gg((unsigned)std::min<long long>((n_all + d.chunk - 1) / d.chunk, grid_x)), bb(64);
+                if (xq_lean) { d.n_list_dev = dcnt + 8; d.chunk = 0; }   // length of `ls` and chunk rule on the device
+                const dim3 gg((unsigned)std::min<long long>(xq_lean ? n_all : (n_all + d.chunk - 1) / d.chunk, grid_x)), bb(64);
                 switch (h->fast_x) {
                     case 0: hipLaunchKernelGGL((k_x2<16, 1>), gg, bb, 0, st, pf, fr, k, ls, n_items, stp, ctr, d); break;
                     case 1: hipLaunchKernelGGL((k_x2<16, 2>), gg, bb, 0, st, pf, fr, k, ls, n_items, stp, ctr, d); break;
@@ -1728,8 +1755,9 @@ static int level_run_impl(mpc_handle *h, int32_t gen_children, int32_t flags, mp
                 kernel_timed[4] = true;
                 HIP_TRY(h, hipGetLastError());
                 int32_t n_left = 0;
-                { int rcs = compact(ST_NEEDX, ST_NEEDX_SING, &n_left); if (rcs) return rcs; }
-                n_needx = n_left;
+                if (lean) { int rcs = compact(ST_NEEDX, ST_NEEDX_SING, nullptr, dcnt + 8); if (rcs) return rcs; xq_lean = true; n_left = n_needx; }
+                else { int rcs = compact(ST_NEEDX, ST_NEEDX_SING, &n_left); if (rcs) return rcs; }
+                n_needx = n_left;   // lean: the bound (everything the quick test was given)
                 needx_list = h->retry_list.as<int32_t>();
             }
             if (n_needx + dc.n_pre1 + dc.n_pre2 > 0) {   // feasibility for the candidates left open (+ dictionary-only items)
@@ -1838,9 +1866,9 @@ static int level_run_impl(mpc_handle *h, int32_t gen_children, int32_t flags, mp
         const int keep_lowdim = (flags & MPC_LEVEL_KEEP_LOWDIM) ? 1 : 0;
         if (flags & MPC_LEVEL_GRAPH) { /* no pruning in the graph traversal */ }
         else if (h->mw == 2) hipLaunchKernelGGL(k_pruned_append<2>, dim3(blocks256), dim3(256), 0, st, h->frontier.as<int32_t>(), n, k, h->status.as<uint8_t>(),
-                                           h->pruned_new.as<unsigned long long>(), ctr, keep_lowdim);
+                                           h->pruned.as<unsigned long long>() + (size_t)h->n_pruned * h->mw, ctr, keep_lowdim);
         else hipLaunchKernelGGL(k_pruned_append<4>, dim3(blocks256), dim3(256), 0, st, h->frontier.as<int32_t>(), n, k, h->status.as<uint8_t>(),
-                                h->pruned_new.as<unsigned long long>(), ctr, keep_lowdim);
+                                h->pruned.as<unsigned long long>() + (size_t)h->n_pruned * h->mw, ctr, keep_lowdim);
         if (gen_children) {
             HIP_TRY(h, h->childmask.ensure(nn * h->mw * sizeof(uint64_t), st));
             HIP_TRY(h, h->count.ensure(nn * sizeof(int32_t), st));
@@ -1849,11 +1877,15 @@ static int level_run_impl(mpc_handle *h, int32_t gen_children, int32_t flags, mp
                                                h->pruned.as<unsigned long long>(), (long long)h->n_pruned, h->childmask.as<unsigned long long>(), h->count.as<int32_t>(), keep_lowdim);
             else hipLaunchKernelGGL(k_children_count<4>, dim3((unsigned)n), dim3(64), 0, st, h->Pv, h->frontier.as<int32_t>(), n, k, h->status.as<uint8_t>(),
                                     h->pruned.as<unsigned long long>(), (long long)h->n_pruned, h->childmask.as<unsigned long long>(), h->count.as<int32_t>(), keep_lowdim);
-            { int rcs = launch_scan(h, h->count.as<int32_t>(), h->offset.as<int32_t>(), n, total); if (rcs) return rcs; }
+            // lean: children and their parent slots are sized by the bound n (n_c - k) and written without waiting for the count
+            const double child_bound_bytes = (double)nn * std::max(h->n_c - k, 1) * (k + 2) * 4.0;
+            children_lean = lean && child_bound_bytes <= 1.5e9;
+            { int rcs = launch_scan(h, h->count.as<int32_t>(), h->offset.as<int32_t>(), n, children_lean ? dcnt + 20 : total); if (rcs) return rcs; }
             HIP_TRY(h, hipGetLastError());
-            HIP_TRY(h, hipStreamSynchronize(st));
-            const int32_t n_children = h->tot_host[0];
-            h->n_children = n_children;
+            int32_t n_children = 0;
+            if (children_lean) n_children = (int32_t)std::min<double>((double)nn * std::max(h->n_c - k, 1), 2147483647.0 / (k + 2));   // the bound, for the allocation only
+            else { HIP_TRY(h, hipStreamSynchronize(st)); n_children = h->tot_host[0]; }
+            h->n_children = children_lean ? 0 : n_children;
             if (n_children > 0) {
                 HIP_TRY(h, h->children.ensure((size_t)n_children * (k + 1) * sizeof(int32_t), st));
                 HIP_TRY(h, h->parent_slot_next.ensure((size_t)n_children * sizeof(int32_t), st));
@@ -1869,10 +1901,18 @@ static int level_run_impl(mpc_handle *h, int32_t gen_children, int32_t flags, mp
         static_assert(sizeof(LevelCounters) % 4 == 0 && sizeof(LevelCounters) + 64 <= 4096, "LevelCounters must fit the pinned block");
         hipLaunchKernelGGL(k_publish_words, dim3(1), dim3(128), 0, st, reinterpret_cast<const unsigned int *>(ctr),
                            reinterpret_cast<unsigned int *>(h->tot_dev + 16), (int)(sizeof(LevelCounters) / 4));
+        hipLaunchKernelGGL(k_publish_words, dim3(1), dim3(64), 0, st, reinterpret_cast<const unsigned int *>(dcnt),
+                           reinterpret_cast<unsigned int *>(h->tot_dev + 16 + (int)(sizeof(LevelCounters) / 4)), 32);
         HIP_TRY(h, hipGetLastError());
         HIP_TRY(h, hipStreamSynchronize(st));
         h->r3_dirty = false;   // the main stream waited for ev_rjoin before the second partition
         std::memcpy(&host_ctr, h->tot_host + 16, sizeof(LevelCounters));
+        {
+            const int32_t *cnt_host = h->tot_host + 16 + (int)(sizeof(LevelCounters) / 4);
+            if (children_lean) h->n_children = cnt_host[20];
+            if (theta_lean) n_theta_items = cnt_host[0];
+            if (xq_lean) n_x_items = (long long)cnt_host[8] + (n_x_items - n_xq_items);   // what the quick test left + the dictionary-only items
+        }
         HIP_TRY(h, hipEventElapsedTime(&ms[0], h->ev[0], h->ev[1]));
         HIP_TRY(h, hipEventElapsedTime(&ms[1], h->ev[1], h->ev[2]));
         HIP_TRY(h, hipEventElapsedTime(&ms[2], h->ev[2], h->ev[3]));
@@ -1929,7 +1969,7 @@ int mpc_level_run_ex(mpc_handle *h, int32_t gen_children, int32_t flags, mpc_lev
     { std::lock_guard<std::mutex> lk(h->wm); if (h->w_busy) return fail(h, MPC_ERR_STATE, "a level started with mpc_level_start is still running"); }
     // MPC_LEVEL_STREAM is honoured here too: the region kernel then writes its records into page-locked host memory and
     // mpc_level_stream_info hands the (complete) arrays over after this call -- no device-to-host fetch for small levels
-    { std::lock_guard<std::mutex> lk(h->wm); h->w_stream_ready = false; }
+    { std::lock_guard<std::mutex> lk(h->wm); h->w_stream_ready = false; h->a_ready.store(0, std::memory_order_release); }
     return level_run_impl(h, gen_children, flags & ~(MPC_LEVEL_THEN_BASE | MPC_LEVEL_ONLY_BASE), stats);
 }
 
@@ -1938,10 +1978,11 @@ static void worker_main(mpc_handle *h) {
     for (;;) {
         int gen = 0, flags = 0;
         {
+            for (int spin = 0; spin < 20000 && !h->a_req.load(std::memory_order_acquire); ++spin) __builtin_ia32_pause();
             std::unique_lock<std::mutex> lk(h->wm);
             h->wcv.wait(lk, [&] { return h->w_req != 0; });
             if (h->w_req == 2) return;
-            gen = h->w_gen; flags = h->w_flags; h->w_req = 0;
+            gen = h->w_gen; flags = h->w_flags; h->w_req = 0; h->a_req.store(0, std::memory_order_release);
         }
         mpc_level_stats st;
         std::memset(&st, 0, sizeof(st));
@@ -1971,6 +2012,7 @@ static void worker_main(mpc_handle *h) {
         {
             std::lock_guard<std::mutex> lk(h->wm);
             h->w_rc = rc; h->w_stats = st; h->w_busy = false; h->w_stream_ready = true;
+            h->a_ready.store(1, std::memory_order_release); h->a_busy.store(0, std::memory_order_release);
         }
         h->wcv.notify_all();
     }
@@ -1982,6 +2024,7 @@ int mpc_level_start(mpc_handle *h, int32_t gen_children, int32_t flags) {
     if (h->w_busy) return fail(h, MPC_ERR_STATE, "mpc_level_start: the previous level has not been waited for");
     if (!h->worker.joinable()) h->worker = std::thread(worker_main, h);
     h->w_gen = gen_children; h->w_flags = flags; h->w_busy = true; h->w_stream_ready = false; h->w_req = 1;
+    h->a_busy.store(1, std::memory_order_release); h->a_ready.store(0, std::memory_order_release); h->a_req.store(1, std::memory_order_release);
     lk.unlock();
     h->wcv.notify_all();
     return MPC_OK;
@@ -1992,6 +2035,11 @@ int mpc_level_stream_info(mpc_handle *h, double **head_d, int32_t **head_i, doub
     if (!h) return MPC_ERR_INVALID;
     std::unique_lock<std::mutex> lk(h->wm);
     if (!h->w_busy && !h->w_stream_ready) return fail(h, MPC_ERR_STATE, "mpc_level_stream_info without a level started by mpc_level_start");
+    if (!h->w_stream_ready) {
+        lk.unlock();
+        for (int spin = 0; spin < 200000 && !h->a_ready.load(std::memory_order_acquire); ++spin) __builtin_ia32_pause();
+        lk.lock();
+    }
     h->wcv.wait(lk, [&] { return h->w_stream_ready; });
     auto &so = h->so;
     const bool on = so.active && !so.taken;
@@ -2025,6 +2073,11 @@ int mpc_level_wait(mpc_handle *h, mpc_level_stats *stats) {
     if (!h) return MPC_ERR_INVALID;
     std::unique_lock<std::mutex> lk(h->wm);
     if (!h->worker.joinable()) return fail(h, MPC_ERR_STATE, "mpc_level_wait without mpc_level_start");
+    if (h->w_busy) {
+        lk.unlock();
+        for (int spin = 0; spin < 200000 && h->a_busy.load(std::memory_order_acquire); ++spin) __builtin_ia32_pause();
+        lk.lock();
+    }
     h->wcv.wait(lk, [&] { return !h->w_busy; });
     if (stats) *stats = h->w_stats;
     return h->w_rc;
@@ -2378,7 +2431,7 @@ int mpc_level_pruned_new(mpc_handle *h, uint64_t *out, int64_t cap) {
     if (!h || (!out && cap > 0)) return MPC_ERR_INVALID;
     if (!h->level_done) return fail(h, MPC_ERR_STATE, "mpc_level_run has not been called for this frontier");
     if (cap < h->n_pruned_new) return fail(h, MPC_ERR_CAPACITY, "pruned buffer too small");
-    return copy_out(h, out, h->pruned_new.p, (size_t)h->n_pruned_new * h->mw * sizeof(uint64_t), hipMemcpyDeviceToHost);
+    return copy_out(h, out, h->pruned.as<uint64_t>() + (size_t)h->n_pruned * h->mw, (size_t)h->n_pruned_new * h->mw * sizeof(uint64_t), hipMemcpyDeviceToHost);
 }
 int mpc_level_regions_device(mpc_handle *h, double *head_d_dev, int32_t *head_i_dev, double *erows_dev, int64_t cap_slots,
                              int64_t cap_rows, int64_t *n_slots, int64_t *n_rows) {
@@ -2407,16 +2460,14 @@ int mpc_level_pruned_new_device(mpc_handle *h, uint64_t *out, int64_t cap) {
     if (!h || (!out && cap > 0)) return MPC_ERR_INVALID;
     if (!h->level_done) return fail(h, MPC_ERR_STATE, "mpc_level_run has not been called for this frontier");
     if (cap < h->n_pruned_new) return fail(h, MPC_ERR_CAPACITY, "pruned buffer too small");
-    return copy_out(h, out, h->pruned_new.p, (size_t)h->n_pruned_new * h->mw * sizeof(uint64_t), hipMemcpyDeviceToDevice);
+    return copy_out(h, out, h->pruned.as<uint64_t>() + (size_t)h->n_pruned * h->mw, (size_t)h->n_pruned_new * h->mw * sizeof(uint64_t), hipMemcpyDeviceToDevice);
 }
 
 int mpc_frontier_advance(mpc_handle *h) {
     if (!h) return MPC_ERR_INVALID;
     if (!h->level_done) return fail(h, MPC_ERR_STATE, "mpc_level_run has not been called for this frontier");
-    if (h->n_pruned_new > 0) {
-        int rc = pruned_add(h, h->pruned_new.as<uint64_t>(), h->n_pruned_new, hipMemcpyDeviceToDevice);
-        if (rc) return rc;
-    }
+    h->n_pruned += h->n_pruned_new + h->n_pruned_extra;   // already in place behind the list (no copy)
+    h->n_pruned_extra = 0;
     std::swap(h->frontier, h->children);
     std::swap(h->parent_slot, h->parent_slot_next);
     h->have_parent_slot = true;

@@ -29,8 +29,25 @@ def test_library_exports_every_declared_symbol():
 
 
 def test_struct_layout_matches_header():
+    """The ctypes mirrors against the C compiler's view of include/mpcombi.h: sizes of both structures and the offset of every
+    field of mpc_level_stats (a tiny C program prints them)."""
+    import subprocess
+    import tempfile
     assert ctypes.sizeof(_lib.MpcProblem) == 5 * 4 + 4 + 8 * 8  # five int32 (+pad) and eight pointers
-    assert ctypes.sizeof(_lib.LevelStats) == 8 + 4 + 4 + 6 * 8 + 4 * 8 + 4 * 4 + 8 + 8 + 4 * 8 + 8 + 8 + 4 * 4 + 6 * 8
+    fields = [name for name, *_ in _lib.LevelStats._fields_]
+    prog = '#include <stdio.h>\n#include <stddef.h>\n#include "mpcombi.h"\nint main(void) {\n' \
+           '  printf("%zu %zu\\n", sizeof(mpc_problem), sizeof(mpc_level_stats));\n' + \
+           ''.join(f'  printf("{f} %zu\\n", offsetof(mpc_level_stats, {f}));\n' for f in fields) + '  return 0;\n}\n'
+    with tempfile.TemporaryDirectory() as tmp:
+        src, exe = os.path.join(tmp, 'l.c'), os.path.join(tmp, 'l')
+        open(src, 'w').write(prog)
+        subprocess.check_call(['gcc', '-I', os.path.join(ROOT, 'include'), src, '-o', exe])
+        out = subprocess.check_output([exe]).decode().split('\n')
+    size_p, size_s = (int(v) for v in out[0].split())
+    assert size_p == ctypes.sizeof(_lib.MpcProblem) and size_s == ctypes.sizeof(_lib.LevelStats)
+    offsets = dict((line.split()[0], int(line.split()[1])) for line in out[1:] if line.strip())
+    for f in fields:
+        assert offsets[f] == getattr(_lib.LevelStats, f).offset, f
 
 
 def test_flag_constants_match_the_header():
