@@ -257,6 +257,7 @@ struct mpc_handle {
                                      // a region at 4 -- and move the facet list of one sliver region)
     bool no_lean = false;            // MPC_NO_LEAN=1: large levels read every list length back (round-2 behaviour); default: only the lengths the
                                      // host needs to size the region stage are read back, the other stages take theirs from device memory
+    bool test_small_fallback = false; // MPC_TEST_SMALL_FALLBACK=1 (tests): every level run without host round trips reports "repeat on the classic path"
     bool no_smallpath = false;       // MPC_NO_SMALLPATH=1: levels of any size take the classic path with its host round trips (A/B)
     long long smallpath_max = 4096;  // MPC_SMALLPATH_MAX: largest level (candidates) that runs without host round trips (measured: config 4 is
                                      // fastest with 1,024-4,096 -- a level of 15,691 candidates prefers the classic path, which streams its records)
@@ -533,6 +534,7 @@ static int create_fill(const mpc_problem *p, int32_t device, void *stream, mpc_h
     { const char *ev = std::getenv("MPC_TEST_SPARE"); h->test_spare = ev ? std::atoi(ev) : 0; }
     { const char *ev = std::getenv("MPC_NO_SMALLPATH"); h->no_smallpath = ev && ev[0] == '1'; }
     { const char *ev = std::getenv("MPC_NO_LEAN"); h->no_lean = ev && ev[0] == '1'; }
+    { const char *ev = std::getenv("MPC_TEST_SMALL_FALLBACK"); h->test_small_fallback = ev && ev[0] == '1'; }
     { const char *ev = std::getenv("MPC_RSPLIT_MAX"); if (ev) { int v = std::atoi(ev); h->rsplit_max = v >= 16 ? 16 : (v >= 8 ? 8 : (v >= 4 ? 4 : (v >= 2 ? 2 : 1))); } }
     { const char *ev = std::getenv("MPC_SMALLPATH_MAX"); if (ev) h->smallpath_max = std::atoll(ev); }
     { const char *ev = std::getenv("MPC_ROVERLAP_MIN"); if (ev) h->roverlap_min = std::atoll(ev); }
@@ -1347,7 +1349,7 @@ static int level_run_small(mpc_handle *h, int32_t gen_children, int32_t flags, m
     LevelCounters host_ctr;
     std::memcpy(&host_ctr, h->tot_host + 16, sizeof(LevelCounters));
     h->n_smallpath++;
-    if (host_ctr.n_rretry > 0 || cnt_host[17] > 0) {
+    if (host_ctr.n_rretry > 0 || cnt_host[17] > 0 || h->test_small_fallback) {
         // a candidate k_region2 gave up on (the LDS-engine region kernel is not part of this path), or one that turned out optimal
         // after the region launch: the level is repeated classically
         h->n_smallpath_fallback++;

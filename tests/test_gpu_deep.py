@@ -338,3 +338,52 @@ def test_device_setup_and_host_setup_give_the_same_solve(name, monkeypatch):
         assert r1.omega_set == r2.omega_set and r1.lambda_set == r2.lambda_set and r1.regular_set == r2.regular_set, key
         for fld in ('A', 'b', 'C', 'd', 'E', 'f'):
             assert rel_err(getattr(r1, fld), getattr(r2, fld)) <= COEF_TOL, (key, fld, rel_err(getattr(r1, fld), getattr(r2, fld)))
+
+
+# ---- levels without host round trips (level_run_small) and lean large levels -------------------------------------------------
+@pytest.mark.parametrize('name', ['rand_6_3_12_s1', 'c2_dblint_n5', 'quadtank_n3', 'c4_rand_20_8_20_s0', 'mplp_rand_5_3_12_s2'])
+def test_levels_without_host_round_trips_equal_the_classic_path(name, monkeypatch):
+    """Four ways through the same levels: default (small levels keep every list length on the device, large ones most of them),
+    MPC_NO_SMALLPATH=1 + MPC_NO_LEAN=1 (round-2 behaviour: a read-back after every stage), MPC_SMALLPATH_MAX=10^9 (every level on
+    the no-round-trip path), MPC_TEST_SMALL_FALLBACK=1 (every small level runs that way, reports 'repeat', and is repeated on the
+    classic path).  Same kernels, same lists: candidates, verdicts and region records must be IDENTICAL, bit for bit."""
+    from test_gpu_parity import engine_from_golden, run_levels
+    g = load_golden(name)
+    nl = None if bool(g['complete']) else int(g['n_levels']) + 1
+    runs = []
+    for env in ({}, {'MPC_NO_SMALLPATH': '1', 'MPC_NO_LEAN': '1'}, {'MPC_SMALLPATH_MAX': '1000000000'}, {'MPC_TEST_SMALL_FALLBACK': '1'}):
+        with monkeypatch.context() as m:
+            for key, val in env.items():
+                m.setenv(key, val)
+            eng = engine_from_golden(g)
+            levels, regions = run_levels(eng, nl)
+            runs.append(([(c.copy(), s.copy(), int(st.n_children)) for c, s, st in levels], {tuple(r.active_set): r for r in regions}))
+            eng.close()
+    la, ra = runs[0]
+    for lb, rb in runs[1:]:
+        assert len(la) == len(lb)
+        for (ca, sa, na), (cb, sb, nb) in zip(la, lb):
+            assert numpy.array_equal(ca, cb) and numpy.array_equal(sa, sb) and na == nb
+        assert set(ra) == set(rb)
+        for key, r1 in ra.items():
+            r2 = rb[key]
+            assert r1.omega_set == r2.omega_set and r1.lambda_set == r2.lambda_set and r1.regular_set == r2.regular_set, key
+            for fld in ('A', 'b', 'C', 'd', 'E', 'f'):
+                assert numpy.array_equal(getattr(r1, fld), getattr(r2, fld)), (key, fld)
+
+
+def test_streamed_records_with_non_coherent_default(tmp_path):
+    """the blocks a running kernel writes and the host polls (streamed region records, chunk flags, list lengths) are
+    allocated hipHostMallocCoherent, so they do not depend on the runtime's default.  A fresh process with HIP_HOST_COHERENT=0
+    solves config 4 with streaming and must return all 9,432 regions."""
+    import subprocess
+    import sys
+    code = "\n".join(["import sys; sys.path.insert(0, '.'); import bench",
+                      "from ppopt_amd.mp_solvers import mpqp_hip_combinatorial",
+                      "sol = mpqp_hip_combinatorial.solve(bench.build_program('c4', 0), max_levels=5, stream=True)",
+                      "print('REGIONS', len(sol.critical_regions))"])
+    env = dict(os.environ, HIP_HOST_COHERENT='0')
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, '-c', code], cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert 'REGIONS 9432' in out.stdout, out.stdout[-500:]
