@@ -44,6 +44,8 @@ for rep in range(2):
             if p['depth'] > 0:
                 lev_n[p['depth']] += p['candidates']; lev_ms[p['depth']] += p.get('ms_wall', 0.0); lev_cnt[p['depth']] += 1
                 tot['kernel ms (events)'] += 1e-3 * (p.get('ms_verdict', 0) + p.get('ms_region', 0) + p.get('ms_children', 0))
+                tot['(x,theta) runs flagged doubtful (count/1000)'] += 1e-3 * p.get('xtheta_fallbacks', 0) * 1e-3
+                tot['candidates (count/1000)'] += 1e-3 * p['candidates'] * 1e-3
     wall = time.perf_counter() - t_all
     print(f'rep {rep}: {len(combos)} sub-programs, {n_reg} regions, {1e3 * wall:.1f} ms sequential; per stage (ms): '
           + ', '.join(f'{k} {1e3 * v:.1f}' for k, v in tot.items()))
