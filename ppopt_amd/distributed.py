@@ -217,13 +217,14 @@ def _region_tensors(engine):
 REGION_STATUS = 3
 
 
-def to_host(t: torch.Tensor) -> numpy.ndarray:
-    """Device tensor -> numpy array in pooled page-locked memory (DMA copy); CPU tensors are returned as they are."""
+def to_host(t: torch.Tensor, non_blocking: bool = False) -> numpy.ndarray:
+    """Device tensor -> numpy array in pooled page-locked memory (DMA copy); CPU tensors are returned as they are.  With
+    ``non_blocking`` the copy is only queued on torch's current stream: the caller waits for an event recorded behind it."""
     if not t.is_cuda:
         return t.numpy()
     from . import _lib
     arr = _lib.pinned_empty(tuple(t.shape), _NP_DTYPE[t.dtype])
-    torch.from_numpy(arr).copy_(t)
+    torch.from_numpy(arr).copy_(t, non_blocking=non_blocking)
     return arr
 
 
@@ -291,14 +292,23 @@ def _solve_distributed(engine, program=None, group=None, profile: Optional[List[
         for _, work in gathers:
             if work is not None:
                 work.wait()
+        # every piece's copy to the host is queued first; the objects of piece i are built while pieces i+1.. are still arriving
+        queued = []
         for src, (a, b, c) in enumerate(zip(gathers[0][0], gathers[1][0], gathers[2][0])):
             if full_solution == 'rank0' and rank != 0 and src != rank:
                 continue      # another rank's shard: only rank 0 builds its objects
             if a.shape[0]:
-                hd, hi, er = to_host(a), to_host(b), to_host(c)
-                slots = numpy.flatnonzero(hi[:, 0] == REGION_STATUS)
-                solution.critical_regions.extend(RegionBatch(hd, hi, er, engine.n_x, engine.n_t, engine.n_c, engine.n_tc, kk,
-                                                             slots).regions())
+                arrays = (to_host(a, True), to_host(b, True), to_host(c, True))
+                ev = None
+                if a.is_cuda:
+                    ev = torch.cuda.Event()
+                    ev.record()
+                queued.append((arrays, ev))
+        for (hd, hi, er), ev in queued:
+            if ev is not None:
+                ev.synchronize()
+            slots = numpy.flatnonzero(hi[:, 0] == REGION_STATUS)
+            solution.critical_regions.extend(RegionBatch(hd, hi, er, engine.n_x, engine.n_t, engine.n_c, engine.n_tc, kk, slots).regions())
     for depth in range(max_depth):
         gen_children = depth + 1 != max_depth
         n, k = engine.frontier_size()
