@@ -285,26 +285,37 @@ def _solve_distributed(engine, program=None, group=None, profile: Optional[List[
     engine.root()
     sharded = False
     pending = None    # (k, three all-gathers in flight) of the most recent sharded level with regions
+    tail_events = []  # completion of the large arrays' host copies (waited for once, before the solve returns)
 
     def finish(entry):
         """Waits for a level's gathers, copies every rank's piece to pinned host memory and lists its regions (rank order)."""
         kk, gathers = entry
-        for _, work in gathers:
-            if work is not None:
-                work.wait()
-        # every piece's copy to the host is queued first; the objects of piece i are built while pieces i+1.. are still arriving
+        if gathers[1][1] is not None:
+            gathers[1][1].wait()      # the integer heads' gather (the current stream waits for it, not the host)
+        # Host copies are queued in the order the host needs them: the integer heads of every piece first (a region object is a lazy
+        # view: building it needs the heads only), then the two large arrays.  The objects of a level are built while its large
+        # arrays are still on their way; the solve waits for them once, before it returns.
         queued = []
         for src, (a, b, c) in enumerate(zip(gathers[0][0], gathers[1][0], gathers[2][0])):
             if full_solution == 'rank0' and rank != 0 and src != rank:
                 continue      # another rank's shard: only rank 0 builds its objects
             if a.shape[0]:
-                arrays = (to_host(a, True), to_host(b, True), to_host(c, True))
+                hi = to_host(b, True)
                 ev = None
-                if a.is_cuda:
+                if b.is_cuda:
                     ev = torch.cuda.Event()
                     ev.record()
-                queued.append((arrays, ev))
-        for (hd, hi, er), ev in queued:
+                queued.append([a, c, hi, ev])
+        for j in (0, 2):
+            if gathers[j][1] is not None:
+                gathers[j][1].wait()
+        for q in queued:
+            q[0], q[1] = to_host(q[0], True), to_host(q[1], True)
+        if queued and queued[0][3] is not None:
+            done = torch.cuda.Event()
+            done.record()
+            tail_events.append(done)
+        for hd, er, hi, ev in queued:
             if ev is not None:
                 ev.synchronize()
             slots = numpy.flatnonzero(hi[:, 0] == REGION_STATUS)
@@ -391,4 +402,6 @@ def _solve_distributed(engine, program=None, group=None, profile: Optional[List[
         profile.append({'depth': 0, 'k': e, 'candidates': 1, 'status': hist, 'regions': len(regs)})
     if collect_regions:
         solution.critical_regions.extend(regs)
+    for ev in tail_events:
+        ev.synchronize()
     return solution
