@@ -37,6 +37,9 @@ WORKLOADS = {
            'BFS levels 1-4 (1,076,342 candidates)', lambda pg: pg.quad_tank_data(10), 4),
     'c2': ('double-integrator explicit-MPC mpQP, N=5 (n_x=15, n_theta=2, 32 rows, 10 equalities); full tree '
            '(4,795 candidates, 9 regions)', lambda pg: pg.double_integrator_data(5), None),
+    # BASELINE.json quotes config 2 with "~50 regions": the doc formulation's state box |x| <= 4 gives 9 regions, |x| <= 20 gives 51
+    'c2x20': ('double-integrator explicit-MPC mpQP, N=5, state box |x| <= 20 (n_x=15, n_theta=2, 10 equalities); full tree '
+              '(4,381 candidates, 51 regions)', lambda pg: pg.double_integrator_data(5, x_bound=20.0), None),
 }
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
@@ -422,7 +425,7 @@ def main():
         out['mi_enumeration'] = {'workload': 'generate_mpmiqp_data(8,4,16,n_bin=6,seed=1)', 'fixations': n_fix,
                                  'regions': n_reg, 'ms': 1e3 * best, 'sub_programs_per_s': n_fix / best,
                                  'regions_per_s': n_reg / best}
-    if rank == 0 and not distributed and args.complete > 0 and args.workload in ('c4', 'c3', 'c2'):
+    if rank == 0 and not distributed and args.complete > 0 and args.workload in ('c4', 'c3', 'c2', 'c2x20'):
         # The COMPLETE explicit solution of the same program by the connected-graph traversal (mpqp_algorithm.graph, reference
         # mp_solvers/mpqp_graph.py) on the same kernels, wave / visited set / neighbours resident on the device.  Not part of `value`.
         from ppopt_amd.mp_solvers import mpqp_hip_combi_graph

@@ -267,6 +267,8 @@ REGISTRY = {
     'transport_mpqp': (lambda: pg.transport_mpqp_data(), dict(check_full_process=True)),
     'dblint_n3': (lambda: pg.double_integrator_data(3), dict(check_full_process=True)),
     'c2_dblint_n5': (lambda: pg.double_integrator_data(5), {}),
+    # BASELINE.json quotes config 2 with "~50 regions": the doc formulation's state box |x| <= 4 gives 9; with |x| <= 20 it is 52
+    'c2_dblint_n5_x20': (lambda: pg.double_integrator_data(5, x_bound=20.0), {}),
     'rand_4_2_10_s0': (lambda: pg.generate_mpqp_data(4, 2, 10, 0), dict(check_full_process=True)),
     'rand_5_3_8_s3': (lambda: pg.generate_mpqp_data(5, 3, 8, 3), {}),
     'rand_6_3_12_s1': (lambda: pg.generate_mpqp_data(6, 3, 12, 1), {}),

@@ -15,7 +15,7 @@ from conftest import consume_exception, golden_regions, is_knife_edge, kkt_condi
 
 pytestmark = pytest.mark.gpu
 
-FULL = ['c1_transport_mplp', 'mplp_rand_4_2_10_s0', 'mplp_rand_5_3_12_s2', 'transport_mpqp', 'dblint_n3', 'c2_dblint_n5', 'rand_4_2_10_s0', 'rand_5_3_8_s3',
+FULL = ['c1_transport_mplp', 'mplp_rand_4_2_10_s0', 'mplp_rand_5_3_12_s2', 'transport_mpqp', 'dblint_n3', 'c2_dblint_n5', 'c2_dblint_n5_x20', 'rand_4_2_10_s0', 'rand_5_3_8_s3',
         'rand_6_3_12_s1', 'quadtank_n2', 'quadtank_n3']
 # big_24_7_34_s430912: 82 rows (two tableau rows per lane), big-M rows left in; three levels, 91,183 candidates (regions stored for
 # levels 1-2).  Found by tools/fuzz_scan.py: on [0, 2, 4] the reference and the device say "region", the CPU oracle's dense simplex

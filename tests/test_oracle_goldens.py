@@ -8,7 +8,7 @@ import pytest
 
 from conftest import golden_regions, load_golden, rel_err, rows_match
 
-FULL = ['c1_transport_mplp', 'mplp_rand_4_2_10_s0', 'mplp_rand_5_3_12_s2', 'transport_mpqp', 'dblint_n3', 'c2_dblint_n5', 'rand_4_2_10_s0', 'rand_5_3_8_s3',
+FULL = ['c1_transport_mplp', 'mplp_rand_4_2_10_s0', 'mplp_rand_5_3_12_s2', 'transport_mpqp', 'dblint_n3', 'c2_dblint_n5', 'c2_dblint_n5_x20', 'rand_4_2_10_s0', 'rand_5_3_8_s3',
         'rand_6_3_12_s1', 'quadtank_n2', 'quadtank_n3']
 PARTIAL = ['c4_rand_20_8_20_s0', 'c3_quadtank_n10']
 # facets whose redundancy LP sits on the 1e-7 tolerance in the reference run (min slack 3e-8 .. 1e-7, sliver
