@@ -122,7 +122,11 @@ int32_t mpc_lds_bytes(const mpc_handle *h, int32_t which);
  * v_mfma_f64_16x16x4_f64 tiles) and replace the per-active-set dense KKT factorisation of MPQP_Program.optimal_control_law
  * (mpqp_program.py:182-198):  which = 0: W = A Q^-1 A' (n_c x n_c), 1: UV = [A Q^-1 c + b | A Q^-1 H + F] (n_c x (n_t+1)),
  * 2: Gt = A Q^-1 (n_c x n_x), 3: X0H = -Q^-1 [c | H] (n_x x (n_t+1)), 4: A A' (n_c x n_c; any program).  *n = number of doubles
- * (0 for which < 4 when Q is absent or not positive definite); MPC_ERR_CAPACITY when cap < *n. */
+ * (0 for which < 4 when Q is absent or not positive definite); MPC_ERR_CAPACITY when cap < *n.
+ * which = 5..10: the blocks with the program's n_eq equality rows E (members of every active set) eliminated, so that the Schur
+ * system of an active set E + a is the one of `a` alone:  5: Wr = W - W[:,E] W_EE^-1 W[E,:], 6: UVr = UV - W[:,E] W_EE^-1 UV[E,:],
+ * 7: (A A')r likewise, 8: Me = W_EE^-1 UV[E,:] (n_eq x (n_t+1)), 9: Ne = W_EE^-1 W[E,:] (n_eq x n_c), 10: the n_eq pivots of the
+ * Gram elimination of E, then the n_eq diagonal entries of A_E A_E'.  *n = 0 when n_eq = 0 or the elimination is not in use. */
 int mpc_program_block(mpc_handle *h, int32_t which, double *out_host, int64_t cap, int64_t *n);
 /* the HIP stream the handle launches on (hipStream_t as void*) */
 void *mpc_stream(const mpc_handle *h);

@@ -254,10 +254,13 @@ class Engine:
             raise cls(f'{what} failed ({rc}): {self._L.mpc_last_error(self._h).decode()}')
 
     def program_block(self, which: int) -> numpy.ndarray:
-        """One of the program's one-off dense blocks as the device holds it (mpc_program_block): 0 W, 1 UV, 2 Gt, 3 X0H, 4 A A'."""
+        """One of the program's one-off dense blocks as the device holds it (mpc_program_block): 0 W, 1 UV, 2 Gt, 3 X0H, 4 A A';
+        5..10: the blocks with the equality rows eliminated (Wr, UVr, (A A')r, Me, Ne, gE; empty when not in use)."""
         n = ctypes.c_int64(0)
+        ne = self.n_eq
         shape = {0: (self.n_c, self.n_c), 1: (self.n_c, self.n_t + 1), 2: (self.n_c, self.n_x), 3: (self.n_x, self.n_t + 1),
-                 4: (self.n_c, self.n_c)}[which]
+                 4: (self.n_c, self.n_c), 5: (self.n_c, self.n_c), 6: (self.n_c, self.n_t + 1), 7: (self.n_c, self.n_c),
+                 8: (ne, self.n_t + 1), 9: (ne, self.n_c), 10: (2, ne)}[which]
         out = numpy.zeros(shape)
         self._check(self._L.mpc_program_block(self._h, which, out.ctypes.data_as(_dp), out.size, ctypes.byref(n)), 'mpc_program_block')
         return out if n.value else numpy.zeros((0, 0))

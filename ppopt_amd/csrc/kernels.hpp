@@ -22,6 +22,15 @@
 
 #include "kkt.hpp"
 
+// Every kernel of kernels.hpp / kernels2.hpp is declared MPC_GLOBAL void MPC_LB(bounds) name(...).  In the library's main
+// translation unit these are ordinary kernels.  batch_level.hip defines MPC_GLOBAL as an inlined device function before it
+// includes the headers: there the bodies are called from kernels that take one argument table per MEMBER PROGRAM of a batch
+// (blockIdx.y = member), so one launch runs a stage of a level for many programs -- the same code, statement for statement.
+#ifndef MPC_GLOBAL
+#define MPC_GLOBAL __global__
+#define MPC_LB(...) __launch_bounds__(__VA_ARGS__)
+#endif
+
 namespace mpc {
 
 constexpr int ST_INFEASIBLE = 0, ST_FEASIBLE = 1, ST_OPT_NO_REGION = 2, ST_REGION = 3, ST_SINGULAR = 4, ST_LP_LIMIT = 5;
@@ -283,7 +292,7 @@ __device__ inline int xtheta_from_vertex(const DevProblem &P, int k, Smem &s, Lp
 // k_verdict: status per candidate: INFEASIBLE / FEASIBLE / SINGULAR / LP_LIMIT / OPT_PENDING
 // ------------------------------------------------------------------------------------------------------------
 // list != nullptr: process only the candidates list[0..n) (the retry list of k_verdict2), work counter ctr->work_region
-__global__ void __launch_bounds__(64) k_verdict(DevProblem P, const int32_t *__restrict__ cands, long long n, int k,
+MPC_GLOBAL void MPC_LB(64) k_verdict(DevProblem P, const int32_t *__restrict__ cands, long long n, int k,
                                                 uint8_t *__restrict__ status, LevelCounters *__restrict__ ctr,
                                                 const int32_t *__restrict__ list, const int32_t *__restrict__ n_dev) {
     // n_dev != nullptr: the length of `list` is read from device memory (the level runs without host round trips)
@@ -392,7 +401,7 @@ __global__ void __launch_bounds__(64) k_verdict(DevProblem P, const int32_t *__r
 // MODE 2 (RG_ASSEMBLE)  one wavefront per candidate: rows + Chebyshev LP, facet decisions read from facet_flags (step 2)
 constexpr int RG_FULL = 0, RG_FACET = 1, RG_ASSEMBLE = 2;
 template <int MODE>
-__global__ void __launch_bounds__(64) k_region(DevProblem P, const int32_t *__restrict__ cands, int k,
+MPC_GLOBAL void MPC_LB(64) k_region(DevProblem P, const int32_t *__restrict__ cands, int k,
                                                const int32_t *__restrict__ opt_list, int n_opt,
                                                uint8_t *__restrict__ status, double *__restrict__ rec_d,
                                                int32_t *__restrict__ rec_i, long long sd, long long si,
@@ -594,7 +603,7 @@ __global__ void __launch_bounds__(64) k_region(DevProblem P, const int32_t *__re
 // ------------------------------------------------------------------------------------------------------------
 // small utility kernels: flags, scan, compaction, children, pruned masks
 // ------------------------------------------------------------------------------------------------------------
-__global__ void k_histogram(const uint8_t *__restrict__ status, long long n, LevelCounters *ctr) {
+MPC_GLOBAL void k_histogram(const uint8_t *__restrict__ status, long long n, LevelCounters *ctr) {
     __shared__ unsigned int h[8];
     if (threadIdx.x < 8) h[threadIdx.x] = 0;
     __syncthreads();
@@ -625,7 +634,7 @@ __device__ __forceinline__ int block_exclusive_scan_1024(int v, int *total_out) 
     __syncthreads();
     return incl - v + wsum[w];
 }
-__global__ void __launch_bounds__(1024) k_scan_block_sums(const int32_t *__restrict__ in, long long n, int32_t *__restrict__ sums) {
+MPC_GLOBAL void MPC_LB(1024) k_scan_block_sums(const int32_t *__restrict__ in, long long n, int32_t *__restrict__ sums) {
     __shared__ int tot;
     const long long i = blockIdx.x * (long long)SCAN_BLOCK + threadIdx.x;
     (void)block_exclusive_scan_1024(i < n ? in[i] : 0, &tot);
@@ -633,7 +642,7 @@ __global__ void __launch_bounds__(1024) k_scan_block_sums(const int32_t *__restr
     if (threadIdx.x == 0) sums[blockIdx.x] = tot;
 }
 // one block: exclusive scan of up to nb block sums in place (chunked), total -> *total
-__global__ void __launch_bounds__(1024) k_scan_sums(int32_t *__restrict__ sums, int nb, int32_t *__restrict__ total) {
+MPC_GLOBAL void MPC_LB(1024) k_scan_sums(int32_t *__restrict__ sums, int nb, int32_t *__restrict__ total) {
     __shared__ int tot;
     int carry = 0;
     for (int base = 0; base < nb; base += SCAN_BLOCK) {
@@ -647,7 +656,7 @@ __global__ void __launch_bounds__(1024) k_scan_sums(int32_t *__restrict__ sums, 
     }
     if (threadIdx.x == 0) *total = carry;
 }
-__global__ void __launch_bounds__(1024) k_scan_apply(const int32_t *__restrict__ in, int32_t *__restrict__ out, long long n,
+MPC_GLOBAL void MPC_LB(1024) k_scan_apply(const int32_t *__restrict__ in, int32_t *__restrict__ out, long long n,
                                                     const int32_t *__restrict__ sums) {
     const long long i = blockIdx.x * (long long)SCAN_BLOCK + threadIdx.x;
     const int ex = block_exclusive_scan_1024(i < n ? in[i] : 0, nullptr);
@@ -659,7 +668,7 @@ __global__ void __launch_bounds__(1024) k_scan_apply(const int32_t *__restrict__
 // frontier order (lists + c*n) and their lengths, instead of one flag/scan/scatter round per class.
 constexpr int PART_CLASSES = 4;
 __device__ __forceinline__ int part_class(unsigned long long spec, int st) { return (int)((spec >> (4 * (st & 15))) & 15ull); }
-__global__ void __launch_bounds__(1024) k_part_count(const uint8_t *__restrict__ status, long long n, unsigned long long spec,
+MPC_GLOBAL void MPC_LB(1024) k_part_count(const uint8_t *__restrict__ status, long long n, unsigned long long spec,
                                                      int32_t *__restrict__ blockcounts, int nb) {
     __shared__ int wc[16][PART_CLASSES];
     const long long i = blockIdx.x * 1024LL + threadIdx.x;
@@ -678,7 +687,7 @@ __global__ void __launch_bounds__(1024) k_part_count(const uint8_t *__restrict__
     }
 }
 // grid = PART_CLASSES blocks: exclusive scan of each class's block counts in place, totals[c] = list length
-__global__ void __launch_bounds__(1024) k_part_sums(int32_t *__restrict__ blockcounts, int nb, int32_t *__restrict__ totals) {
+MPC_GLOBAL void MPC_LB(1024) k_part_sums(int32_t *__restrict__ blockcounts, int nb, int32_t *__restrict__ totals) {
     __shared__ int tot;
     int32_t *sums = blockcounts + (size_t)blockIdx.x * nb;
     int carry = 0;
@@ -693,7 +702,7 @@ __global__ void __launch_bounds__(1024) k_part_sums(int32_t *__restrict__ blockc
     }
     if (threadIdx.x == 0) totals[blockIdx.x] = carry;
 }
-__global__ void __launch_bounds__(1024) k_part_scatter(const uint8_t *__restrict__ status, long long n, unsigned long long spec,
+MPC_GLOBAL void MPC_LB(1024) k_part_scatter(const uint8_t *__restrict__ status, long long n, unsigned long long spec,
                                                        const int32_t *__restrict__ blockbase, int nb, int32_t *__restrict__ lists) {
     __shared__ int wc[16][PART_CLASSES];
     const long long i = blockIdx.x * 1024LL + threadIdx.x;
@@ -714,11 +723,11 @@ __global__ void __launch_bounds__(1024) k_part_scatter(const uint8_t *__restrict
     }
 }
 
-__global__ void k_flag_status(const uint8_t *__restrict__ status, long long n, int lo, int hi, int32_t *__restrict__ flag) {
+MPC_GLOBAL void k_flag_status(const uint8_t *__restrict__ status, long long n, int lo, int hi, int32_t *__restrict__ flag) {
     const long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
     if (i < n) flag[i] = status[i] >= lo && status[i] <= hi;
 }
-__global__ void k_scatter_index(const int32_t *__restrict__ flag, const int32_t *__restrict__ pos, long long n,
+MPC_GLOBAL void k_scatter_index(const int32_t *__restrict__ flag, const int32_t *__restrict__ pos, long long n,
                                 int32_t *__restrict__ list) {
     const long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
     if (i < n && flag[i]) list[pos[i]] = (int32_t)i;
@@ -726,7 +735,7 @@ __global__ void k_scatter_index(const int32_t *__restrict__ flag, const int32_t 
 
 // copies a few words of device memory into pinned host memory (a read-back without a copy command: on this runtime a
 // hipMemcpyAsync costs the host ~16 us, a launch ~3 us)
-__global__ void k_publish_words(const unsigned int *__restrict__ src, unsigned int *__restrict__ dst, int n) {
+MPC_GLOBAL void k_publish_words(const unsigned int *__restrict__ src, unsigned int *__restrict__ dst, int n) {
     for (int i = threadIdx.x; i < n; i += blockDim.x) dst[i] = src[i];
 }
 
@@ -735,7 +744,7 @@ __global__ void k_publish_words(const unsigned int *__restrict__ src, unsigned i
 // below SMALL_LEVEL_N candidates compaction, partition and scan run as one block of 1024 threads that walks the array
 // in chunks of 1024 (order preserved, so the lists are identical to the multi-block versions).
 constexpr int SMALL_LEVEL_N = 16384;
-__global__ void __launch_bounds__(1024) k_compact_small(const uint8_t *__restrict__ status, int n, int lo, int hi,
+MPC_GLOBAL void MPC_LB(1024) k_compact_small(const uint8_t *__restrict__ status, int n, int lo, int hi,
                                                         int32_t *__restrict__ list, int32_t *__restrict__ total) {
     __shared__ int wc[16];
     __shared__ int base;
@@ -757,7 +766,7 @@ __global__ void __launch_bounds__(1024) k_compact_small(const uint8_t *__restric
     }
     if (threadIdx.x == 0) *total = base;
 }
-__global__ void __launch_bounds__(1024) k_partition_small(const uint8_t *__restrict__ status, int n, unsigned long long spec,
+MPC_GLOBAL void MPC_LB(1024) k_partition_small(const uint8_t *__restrict__ status, int n, unsigned long long spec,
                                                           int32_t *__restrict__ lists, long long stride, int32_t *__restrict__ totals) {
     __shared__ int wc[16][PART_CLASSES];
     __shared__ int base[PART_CLASSES];
@@ -786,7 +795,7 @@ __global__ void __launch_bounds__(1024) k_partition_small(const uint8_t *__restr
     }
     if (threadIdx.x < PART_CLASSES) totals[threadIdx.x] = base[threadIdx.x];
 }
-__global__ void __launch_bounds__(1024) k_scan_small(const int32_t *__restrict__ in, int32_t *__restrict__ out, int n,
+MPC_GLOBAL void MPC_LB(1024) k_scan_small(const int32_t *__restrict__ in, int32_t *__restrict__ out, int n,
                                                      int32_t *__restrict__ total) {
     __shared__ int tot;
     int carry = 0;
@@ -826,7 +835,7 @@ __device__ __forceinline__ void set_mask(const int32_t *as, int k, unsigned long
 // child contains p: all culled) or a single bit i > last(parent) (exactly child i contains p) or irrelevant.  Lanes
 // stride over the pruned list, each accumulating the bit set of culled children, then the wave ORs them together.
 template <int MW>
-__global__ void __launch_bounds__(64) k_children_count(DevProblem P, const int32_t *__restrict__ cands, long long n, int k,
+MPC_GLOBAL void MPC_LB(64) k_children_count(DevProblem P, const int32_t *__restrict__ cands, long long n, int k,
                                                        const uint8_t *__restrict__ status,
                                                        const unsigned long long *__restrict__ pruned, long long n_pruned,
                                                        unsigned long long *__restrict__ childmask, int32_t *__restrict__ count, int keep_lowdim) {
@@ -880,7 +889,7 @@ __global__ void __launch_bounds__(64) k_children_count(DevProblem P, const int32
 
 // stored / parent_slot (both optional): child -> index of its parent when the parent left its (x,theta) dictionary in the
 // dictionary cache (k_x2), else -1
-__global__ void __launch_bounds__(64) k_children_write(const int32_t *__restrict__ cands, long long n, int k, int mw,
+MPC_GLOBAL void MPC_LB(64) k_children_write(const int32_t *__restrict__ cands, long long n, int k, int mw,
                                                        const unsigned long long *__restrict__ childmask,
                                                        const int32_t *__restrict__ offset, int32_t *__restrict__ out,
                                                        const uint8_t *__restrict__ stored, int32_t *__restrict__ parent_slot) {
@@ -907,7 +916,7 @@ __global__ void __launch_bounds__(64) k_children_write(const int32_t *__restrict
 
 // masks of the candidates pruned by this level (INFEASIBLE, OPT_NO_REGION), appended at pruned[n_pruned_old + ...]
 template <int MW>
-__global__ void k_pruned_append(const int32_t *__restrict__ cands, long long n, int k, const uint8_t *__restrict__ status,
+MPC_GLOBAL void k_pruned_append(const int32_t *__restrict__ cands, long long n, int k, const uint8_t *__restrict__ status,
                                 unsigned long long *__restrict__ out, LevelCounters *ctr, int keep_lowdim) {
     const long long c = blockIdx.x * (long long)blockDim.x + threadIdx.x;
     if (c >= n) return;
@@ -921,13 +930,13 @@ __global__ void k_pruned_append(const int32_t *__restrict__ cands, long long n, 
 }
 
 // graph mode (MPC_LEVEL_GRAPH): the (x,theta) feasibility question is not posed -- "feasibility open" becomes "no region"
-__global__ void k_close_open(const int32_t *__restrict__ list, int n_list, uint8_t *__restrict__ status) {
+MPC_GLOBAL void k_close_open(const int32_t *__restrict__ list, int n_list, uint8_t *__restrict__ status) {
     const int w = blockIdx.x * blockDim.x + threadIdx.x;
     if (w < n_list) { const int c = list[w]; status[c] = (uint8_t)(status[c] == 9 ? ST_SINGULAR : ST_FEASIBLE); }   // 9 = ST_NEEDX_SING
 }
 
 // status[list[w]] = tmp[list[w]]  (results of a retry kernel that ran on a side stream)
-__global__ void k_apply_status(const int32_t *__restrict__ list, int n_list, const uint8_t *__restrict__ tmp, uint8_t *__restrict__ status) {
+MPC_GLOBAL void k_apply_status(const int32_t *__restrict__ list, int n_list, const uint8_t *__restrict__ tmp, uint8_t *__restrict__ status) {
     const int w = blockIdx.x * blockDim.x + threadIdx.x;
     if (w < n_list) { const int c = list[w]; status[c] = tmp[c]; }
 }
@@ -935,12 +944,12 @@ __global__ void k_apply_status(const int32_t *__restrict__ list, int n_list, con
 // Spare region slots behind the slots of the overlapped region launch (level_run_impl): slot first + j gets status word `st`
 // and candidate list[j] (or -1).  st = 0: unused slot; st = 7 (ST_RETRY): a candidate that turned out optimal after the launch,
 // its record comes from the LDS-engine kernel like that of a candidate k_region2 gave up on.
-__global__ void k_init_slots(int32_t *__restrict__ head_i, int fi, int first, int count, int st, const int32_t *__restrict__ list) {
+MPC_GLOBAL void k_init_slots(int32_t *__restrict__ head_i, int fi, int first, int count, int st, const int32_t *__restrict__ list) {
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j < count) { int32_t *hi = head_i + (size_t)(first + j) * fi; hi[0] = st; hi[1] = list ? list[j] : -1; }
 }
 // keeps rows start, start+stride, ... of a row-major int matrix (frontier sharding, mpc_frontier_shard)
-__global__ void k_take_rows(const int32_t *__restrict__ src, long long n_new, int width, long long start, long long stride,
+MPC_GLOBAL void k_take_rows(const int32_t *__restrict__ src, long long n_new, int width, long long start, long long stride,
                             int32_t *__restrict__ dst) {
     const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= n_new * width) return;
@@ -948,7 +957,7 @@ __global__ void k_take_rows(const int32_t *__restrict__ src, long long n_new, in
     dst[idx] = src[(start + r * stride) * width + (idx - r * width)];
 }
 
-__global__ void k_root_frontier(int n_eq, int n_c, int32_t *out) {
+MPC_GLOBAL void k_root_frontier(int n_eq, int n_c, int32_t *out) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     const int cnt = n_c - n_eq;
     if (i >= cnt) return;
@@ -960,7 +969,7 @@ __global__ void k_root_frontier(int n_eq, int n_c, int32_t *out) {
 // ------------------------------------------------------------------------------------------------------------
 // k_lp_batch: generic LPs, one wavefront each (deterministic-solver plug)
 // ------------------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(64) k_lp_batch(long long n_lp, int m, int n, int ld, const double *__restrict__ A, int shared_A,
+MPC_GLOBAL void MPC_LB(64) k_lp_batch(long long n_lp, int m, int n, int ld, const double *__restrict__ A, int shared_A,
                                                  const double *__restrict__ b, int shared_b, const double *__restrict__ c,
                                                  int shared_c, const uint8_t *__restrict__ eq, int32_t *__restrict__ status,
                                                  double *__restrict__ x, double *__restrict__ obj, int32_t *__restrict__ iters,
@@ -1024,7 +1033,7 @@ __global__ void __launch_bounds__(64) k_lp_batch(long long n_lp, int m, int n, i
 // LP over (theta, r):  max r  s.t.  E_j theta + ||E_j|| r <= f_j (j != i),  E_i theta = f_i,  -r <= 0.
 // The tableau is filled in LDS straight from the region's rows: nothing but the rows themselves crosses PCIe.
 // ------------------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(64) k_facet_centres(long long n_facets, int nt, int m_max, int ld, const double *__restrict__ ef,
+MPC_GLOBAL void MPC_LB(64) k_facet_centres(long long n_facets, int nt, int m_max, int ld, const double *__restrict__ ef,
                                                       const long long *__restrict__ row_off, const int32_t *__restrict__ region_of_row,
                                                       double *__restrict__ centre, double *__restrict__ radius, int32_t *__restrict__ status,
                                                       unsigned int *work) {

@@ -45,6 +45,11 @@ struct ThetaArgs {
     int chunk;   // candidates taken from the work queue per atomic
     int cbuf_off;   // offset (in doubles, from the start of dynamic LDS) of the row-compaction scratch of k_theta2<.,2>; 0 = none
     const int32_t *n_dev;   // != nullptr: the number of work items is read from device memory (the level runs without host round trips)
+    // k_kkt_thread works on the blocks with the program's ne equality rows eliminated (setup_mfma.hpp): Wr, UVrp (padded like UVp),
+    // AATr; Me (ne x (n_t+1)), Ne (ne x n_c) give the equality rows' multipliers back; gE: ne Gram pivots of the equality rows, then
+    // their ne diagonal entries.  Programs without equality rows: Wr == W, UVrp == UVp, AATr == the Gram matrix, ne == 0.
+    const double *Wr, *UVrp, *AATr, *Me, *Ne, *gE;
+    int ne;
 };
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -72,31 +77,36 @@ constexpr int KK_ILL = 64;        // solved, but the Schur system is ill-conditi
 constexpr int ST_TODO = 10;       // internal: waiting for k_theta2
 constexpr int ST_RRETRY = 11;     // status[] of a candidate k_region2 gave up on (its slot carries ST_RETRY): re-solved by k_region
 template <int K, int NT>
-__global__ void __launch_bounds__(256) k_kkt_thread(const DevProblem *__restrict__ Pg, const int32_t *__restrict__ cands, long long n,
+MPC_GLOBAL void MPC_LB(256) k_kkt_thread(const DevProblem *__restrict__ Pg, const int32_t *__restrict__ cands, long long n,
                                                      uint8_t *__restrict__ code, double *__restrict__ Lout, uint8_t *__restrict__ status,
                                                      ThetaArgs ta, LevelCounters *__restrict__ ctr) {
+    // K = the INEQUALITY rows of the active set; the program's ne equality rows lead every candidate (cardinality ne + K) and are
+    // eliminated from the systems below (ThetaArgs: Wr, UVrp, AATr) -- with ne == 0 these are the original blocks.
     const DevProblem &P = *Pg;
     const long long c = (long long)blockIdx.x * 256 + threadIdx.x;
     if (c >= n) return;
     constexpr int LS = NT + 1;
-    const int nc = P.n_c, nt = P.n_t, nr = nt + 1;
+    const int nc = P.n_c, nt = P.n_t, nr = nt + 1, ne = ta.ne, kf = ne + K;
     int as[K];
 #pragma unroll
-    for (int i = 0; i < K; ++i) as[i] = cands[c * K + i];
+    for (int i = 0; i < K; ++i) as[i] = cands[c * kf + ne + i];
     double S[K][K];
     // ---- Gram test ----------------------------------------------------------------------------------------------
     {
         double gmax = 0.0, g0[K];
+        bool clear = true;
+        for (int j = 0; j < ne; ++j) { gmax = fmax(gmax, ta.gE[ne + j]); clear = clear && (ta.gE[j] > 1e-8 * ta.gE[ne + j]); }
 #pragma unroll
         for (int i = 0; i < K; ++i) {
 #pragma unroll
-            for (int j = 0; j <= i; ++j) S[i][j] = P.AAT[as[i] * nc + as[j]];
-            g0[i] = S[i][i];
+            for (int j = 0; j <= i; ++j) S[i][j] = ta.AATr[as[i] * nc + as[j]];
+            g0[i] = P.AAT[as[i] * nc + as[i]];
             gmax = fmax(gmax, g0[i]);
         }
-        bool clear = gmax > 0.0;
+        clear = clear && gmax > 0.0;
         double vol = 1.0;
         const double ginv = 1.0 / gmax;
+        for (int j = 0; j < ne; ++j) vol *= ta.gE[j] * ginv;
 #pragma unroll
         for (int j = 0; j < K; ++j) {
             const double d = S[j][j];
@@ -113,13 +123,13 @@ __global__ void __launch_bounds__(256) k_kkt_thread(const DevProblem *__restrict
         clear = clear && (vol > 1e-10);
         if (!clear) { code[c] = (uint8_t)KK_UNDECIDED; status[c] = (uint8_t)ST_TODO; return; }
     }
-    // ---- S = W[as,as] = L L'  (chol_solve arithmetic) ---------------------------------------------------------------
+    // ---- S = Wr[as,as] = L L'  (chol_solve arithmetic; the pivots are those of the full Schur matrix behind its equality block) ----
     double diag0[K], invd[K];
 #pragma unroll
     for (int i = 0; i < K; ++i) {
 #pragma unroll
-        for (int j = 0; j <= i; ++j) S[i][j] = ta.W[as[i] * nc + as[j]];
-        diag0[i] = S[i][i];
+        for (int j = 0; j <= i; ++j) S[i][j] = ta.Wr[as[i] * nc + as[j]];
+        diag0[i] = ta.W[as[i] * nc + as[i]];
     }
     bool ok = true, ill = false;
 #pragma unroll
@@ -139,13 +149,13 @@ __global__ void __launch_bounds__(256) k_kkt_thread(const DevProblem *__restrict
         }
     }
     if (!ok) { code[c] = 2; status[c] = (uint8_t)ST_TODO; return; }
-    // ---- multipliers, all n_t + 1 right-hand sides (zero beyond n_t) ------------------------------------------------------
+    // ---- multipliers of the inequality rows, all n_t + 1 right-hand sides (zero beyond n_t) -----------------------------------------
     double Lr[K][LS];
 #pragma unroll
     for (int t = 0; t < LS; ++t) {
         double R[K];
 #pragma unroll
-        for (int i = 0; i < K; ++i) R[i] = -ta.UVp[as[i] * LS + t];
+        for (int i = 0; i < K; ++i) R[i] = -ta.UVrp[as[i] * LS + t];
 #pragma unroll
         for (int j = 0; j < K; ++j) {
             R[j] = R[j] * invd[j];
@@ -161,17 +171,17 @@ __global__ void __launch_bounds__(256) k_kkt_thread(const DevProblem *__restrict
 #pragma unroll
         for (int i = 0; i < K; ++i) Lr[i][t] = R[i];
     }
-    // ---- box screen over the inactive rows (k_theta2's test, same arithmetic) -------------------------------------------
+    // ---- box screen over the inactive rows (k_theta2's test, same arithmetic; the equality rows are never inactive) ---------------
     const double *blo = ta.tvp + NT * NT + NT, *bhi = blo + NT;
     bool fired = false;
-    for (int ci = 0; ci < nc; ++ci) {
+    for (int ci = ne; ci < nc; ++ci) {
         bool active = false;
 #pragma unroll
         for (int a = 0; a < K; ++a) active = active || (as[a] == ci);
         double acc[LS];
 #pragma unroll
-        for (int t = 0; t < LS; ++t) acc[t] = ta.UVp[ci * LS + t];
-        const double *Wrow = ta.W + (size_t)ci * nc;
+        for (int t = 0; t < LS; ++t) acc[t] = ta.UVrp[ci * LS + t];
+        const double *Wrow = ta.Wr + (size_t)ci * nc;
 #pragma unroll
         for (int a = 0; a < K; ++a) {
             const double w = Wrow[as[a]];
@@ -202,18 +212,32 @@ __global__ void __launch_bounds__(256) k_kkt_thread(const DevProblem *__restrict
             smax -= term;
         }
         if (!active && smax < -10 * TOL_FEAS * sc) fired = true;   // the margin is meant in the row's own units
-        if ((ci & 3) == 3 && __all(fired)) break;
+        if (((ci - ne) & 3) == 3 && __all(fired)) break;
     }
     if (fired) {
         code[c] = ill ? KK_ILL : 0;
         status[c] = (uint8_t)ST_NEEDX;
         return;
     }
-    double *out = Lout + (size_t)c * K * nr;
+    double *out = Lout + (size_t)c * kf * nr;
+    // multipliers of the equality rows:  lambda_E = -(Me + Ne[:, as] lambda_a)
+    for (int i = 0; i < ne; ++i) {
+        double v[LS];
+#pragma unroll
+        for (int t = 0; t < LS; ++t) v[t] = t < nr ? ta.Me[i * nr + t] : 0.0;
+#pragma unroll
+        for (int a = 0; a < K; ++a) {
+            const double w = ta.Ne[(size_t)i * nc + as[a]];
+#pragma unroll
+            for (int t = 0; t < LS; ++t) v[t] = fma(w, Lr[a][t], v[t]);
+        }
+#pragma unroll
+        for (int t = 0; t < LS; ++t) if (t < nr) out[i * nr + t] = -v[t];
+    }
 #pragma unroll
     for (int i = 0; i < K; ++i) {
 #pragma unroll
-        for (int t = 0; t < LS; ++t) if (t < nr) out[i * nr + t] = Lr[i][t];
+        for (int t = 0; t < LS; ++t) if (t < nr) out[(ne + i) * nr + t] = Lr[i][t];
     }
     code[c] = ill ? KK_ILL : 0;
     status[c] = (uint8_t)ST_TODO;
@@ -242,7 +266,7 @@ __device__ inline int kkt_fetch_or_solve(const DevProblem &P, int k, Smem &s, co
 #define TH_WAVES_S2 4
 #endif
 template <int NT, int SLOTS>
-__global__ void __launch_bounds__(64, (NT * SLOTS >= 20 ? 3 : (SLOTS >= 2 ? TH_WAVES_S2 : 4))) k_theta2(const DevProblem *__restrict__ Pg, const int32_t *__restrict__ cands, long long n, int k,
+MPC_GLOBAL void MPC_LB(64, (NT * SLOTS >= 20 ? 3 : (SLOTS >= 2 ? TH_WAVES_S2 : 4))) k_theta2(const DevProblem *__restrict__ Pg, const int32_t *__restrict__ cands, long long n, int k,
                                                     uint8_t *__restrict__ status, LevelCounters *__restrict__ ctr,
                                                     const uint8_t *__restrict__ kkcode, const double *__restrict__ Lin, ThetaArgs ta,
                                                     const int32_t *__restrict__ list) {
@@ -677,7 +701,7 @@ __device__ __forceinline__ int xq_decide(PD pd, PI pi, int mr, int NXC, int ncol
 }
 
 template <int SLOTS>
-__global__ void __launch_bounds__(64, XQ_WAVES) k_xq(const DevProblem *__restrict__ Pg, const int32_t *__restrict__ cands, int k,
+MPC_GLOBAL void MPC_LB(64, XQ_WAVES) k_xq(const DevProblem *__restrict__ Pg, const int32_t *__restrict__ cands, int k,
                                                const int32_t *__restrict__ list, int n_list, uint8_t *__restrict__ status,
                                                LevelCounters *__restrict__ ctr, DictCache dc, int NXC) {
     const DevProblem &P = *Pg;
@@ -728,13 +752,13 @@ __global__ void __launch_bounds__(64, XQ_WAVES) k_xq(const DevProblem *__restric
 // xq_decide against LDS -- the dependent round trips of the product-form iterations cost an LDS access instead of an HBM
 // access, and HBM sees one streaming read per parent instead of scattered 64-byte sectors per candidate and iteration.
 // gstart[g] = position in `list` of the first candidate of group g (k_group_flags + scan + scatter), *n_groups_p groups.
-__global__ void k_group_flags(const int32_t *__restrict__ list, int n_list, const int32_t *__restrict__ parent_slot,
+MPC_GLOBAL void k_group_flags(const int32_t *__restrict__ list, int n_list, const int32_t *__restrict__ parent_slot,
                               int32_t *__restrict__ flag) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n_list) flag[i] = (i == 0 || parent_slot[list[i]] != parent_slot[list[i - 1]]) ? 1 : 0;
 }
 template <int SLOTS>
-__global__ void __launch_bounds__(256, XQG_WAVES) k_xq_grouped(const DevProblem *__restrict__ Pg, const int32_t *__restrict__ cands, int k,
+MPC_GLOBAL void MPC_LB(256, XQG_WAVES) k_xq_grouped(const DevProblem *__restrict__ Pg, const int32_t *__restrict__ cands, int k,
                                                           const int32_t *__restrict__ list, int n_list, uint8_t *__restrict__ status,
                                                           LevelCounters *__restrict__ ctr, DictCache dc, int NXC,
                                                           const int32_t *__restrict__ gstart, const int32_t *__restrict__ n_groups_p) {
@@ -796,7 +820,7 @@ __global__ void __launch_bounds__(256, XQG_WAVES) k_xq_grouped(const DevProblem 
 #define X2_WAVES 3
 #endif
 template <int NXC, int SLOTS>
-__global__ void __launch_bounds__(64, (NXC * SLOTS >= 32 ? X2_WAVES : 3)) k_x2(const DevProblem *__restrict__ Pg, const int32_t *__restrict__ cands, int k,
+MPC_GLOBAL void MPC_LB(64, (NXC * SLOTS >= 32 ? X2_WAVES : 3)) k_x2(const DevProblem *__restrict__ Pg, const int32_t *__restrict__ cands, int k,
                                               const int32_t *__restrict__ list, int n_list, uint8_t *__restrict__ status,
                                               LevelCounters *__restrict__ ctr, DictCache dc) {
     const DevProblem &P = *Pg;
@@ -976,7 +1000,7 @@ struct RegionStream {
 };
 
 template <int NT, int SLOTS>
-__global__ void __launch_bounds__(64, (SLOTS >= 2 ? 2 : R2W)) k_region2(
+MPC_GLOBAL void MPC_LB(64, (SLOTS >= 2 ? 2 : R2W)) k_region2(
     const DevProblem *__restrict__ Pg, const int32_t *__restrict__ cands, int k, const int32_t *__restrict__ opt_list, int n_opt,
     uint8_t *__restrict__ status, double *__restrict__ head_d, int32_t *__restrict__ head_i, int fd, int fi,
     double *__restrict__ epool, LevelCounters *__restrict__ ctr, const uint8_t *__restrict__ kkcode, const double *__restrict__ Lin,

@@ -284,6 +284,8 @@ struct mpc_handle {
     int no_rbox = 0;          // MPC_NO_RBOX=1: no bounding-box screen of the region rows in k_region2 (A/B)
     int no_rsplit = 0;        // MPC_NO_RSPLIT=1: one wavefront per candidate in k_region2 whatever the load (A/B)
     int no_xquick = 0;        // MPC_NO_XQUICK=1: no quick (x,theta) test on the last level (A/B)
+    size_t o_elim[6] = {0, 0, 0, 0, 0, 0};   // offsets of Wr, UVr, AATr, Me, Ne, gE in `blocks` (mpc_program_block)
+    bool elim_ok = false;     // the blocks with the equality rows eliminated are valid
     int no_kkt_thread = 0;    // MPC_NO_KKT_THREAD=1: KKT solves stay inside the wave kernels (A/B)
     int force_v1 = 0;         // MPC_FORCE_V1=1 in the environment: never use k_verdict2 (A/B comparisons, tests)
     int fast = 0;             // 1: register-engine kernels (k_theta2 / k_x2) with k_verdict as the retry path
@@ -713,6 +715,14 @@ static int create_fill(const mpc_problem *p, int32_t device, void *stream, mpc_h
         }
     }
     const size_t oAAT = put_or_reserve(AAT, (size_t)nc * nc);
+    // equality rows eliminated from the Schur blocks (setup_mfma.hpp): lets k_kkt_thread take active sets of ne + (1..8) rows
+    const bool want_elim = ne > 0 && dev_schur && ![] { const char *ev = std::getenv("MPC_NO_EQ_ELIM"); return ev && ev[0] == '1'; }();
+    const std::vector<double> none;
+    const size_t oWr = put_or_reserve(none, want_elim ? (size_t)nc * nc : 1), oUVr = put_or_reserve(none, want_elim ? (size_t)nc * nr : 1);
+    const size_t oAATr = put_or_reserve(none, want_elim ? (size_t)nc * nc : 1), oMe = put_or_reserve(none, want_elim ? (size_t)ne * nr : 1);
+    const size_t oNe = put_or_reserve(none, want_elim ? (size_t)ne * nc : 1), ogE = put_or_reserve(none, want_elim ? (size_t)2 * ne : 1);
+    std::vector<double> UVr;
+    bool elim_ok = false;
     const size_t obase = put(base.data(), base.size());
     const size_t od0 = put(d0.empty() ? zeros.data() : d0.data(), d0.empty() ? 1 : d0.size());
     const size_t od0T = put(d0T.empty() ? zeros.data() : d0T.data(), d0T.empty() ? 1 : d0T.size());
@@ -732,19 +742,31 @@ static int create_fill(const mpc_problem *p, int32_t device, void *stream, mpc_h
         const size_t job_bytes = (sizeof(SetupJob) + 15) & ~size_t(15);
         hipError_t e1 = work.ensure(setup_work_doubles(nx, nt, nc) * sizeof(double), h->stream);
         hipError_t e2 = e1 == hipSuccess ? jobbuf.ensure(job_bytes + 16, h->stream) : e1;
-        int flag = 1;
+        int flag = 1, flag_e = 1;
         if (e2 == hipSuccess) {
             job.work = work.as<double>();
             job.flag = reinterpret_cast<int *>(jobbuf.as<char>() + job_bytes);
+            if (want_elim) {
+                job.ne = ne; job.Wr = db + oWr; job.UVr = db + oUVr; job.AATr = db + oAATr; job.Me = db + oMe; job.Ne = db + oNe; job.gE = db + ogE;
+                job.flag_e = job.flag + 1;
+            }
             e2 = hipMemcpyAsync(jobbuf.p, &job, sizeof(SetupJob), hipMemcpyHostToDevice, h->stream);
             if (e2 == hipSuccess) e2 = setup_launch(jobbuf.as<SetupJob>(), 1, h->stream);
             if (e2 == hipSuccess) e2 = hipMemcpyAsync(&flag, job.flag, sizeof(int), hipMemcpyDeviceToHost, h->stream);
             if (e2 == hipSuccess && p->Q) { UV.assign((size_t)nc * nr, 0.0); e2 = hipMemcpyAsync(UV.data(), job.UV, UV.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream); }
+            if (e2 == hipSuccess && want_elim) {
+                UVr.assign((size_t)nc * nr, 0.0);
+                e2 = hipMemcpyAsync(UVr.data(), job.UVr, UVr.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream);
+                if (e2 == hipSuccess) e2 = hipMemcpyAsync(&flag_e, job.flag_e, sizeof(int), hipMemcpyDeviceToHost, h->stream);
+            }
             if (e2 == hipSuccess) e2 = hipStreamSynchronize(h->stream);
         }
         work.release(); jobbuf.release();   // the stream has been synchronised (or nothing was queued)
         if (e2 != hipSuccess) return fail(nullptr, MPC_ERR_HIP, std::string("MFMA set-up kernel: ") + hipGetErrorString(e2));
         mode = (p->Q && flag == 0) ? 0 : 1;
+        elim_ok = want_elim && mode == 0 && flag_e == 0;
+        h->elim_ok = elim_ok;
+        h->o_elim[0] = oWr; h->o_elim[1] = oUVr; h->o_elim[2] = oAATr; h->o_elim[3] = oMe; h->o_elim[4] = oNe; h->o_elim[5] = ogE;
     }
     HIP_TRY(nullptr, hipStreamSynchronize(h->stream));
     h->kkt_mode = mode;
@@ -806,6 +828,11 @@ static int create_fill(const mpc_problem *p, int32_t device, void *stream, mpc_h
                 std::vector<double> tb;
                 const size_t oUVp = tb.size(); tb.resize(tb.size() + (size_t)nc * LS, 0.0);
                 if (mode == 0) for (int i = 0; i < nc; ++i) for (int t = 0; t < nr; ++t) tb[oUVp + (size_t)i * LS + t] = UV[(size_t)i * nr + t];
+                const size_t oUVrp = tb.size();
+                if (elim_ok) {
+                    tb.resize(tb.size() + (size_t)nc * LS, 0.0);
+                    for (int i = 0; i < nc; ++i) for (int t = 0; t < nr; ++t) tb[oUVrp + (size_t)i * LS + t] = UVr[(size_t)i * nr + t];
+                }
                 const size_t otvp = tb.size(); tb.resize(tb.size() + (size_t)NTP * NTP + 3 * NTP, 0.0);
                 for (int t = 0; t < nt; ++t) for (int j = 0; j < nt; ++j) tb[otvp + (size_t)t * NTP + j] = tv_minv[(size_t)t * nt + j];
                 for (int t = 0; t < nt; ++t) tb[otvp + (size_t)NTP * NTP + t] = tv_theta[t];
@@ -833,6 +860,9 @@ static int create_fill(const mpc_problem *p, int32_t device, void *stream, mpc_h
                 HIP_TRY(nullptr, hipStreamSynchronize(h->stream));
                 const double *tbd = h->theta_blocks.as<double>();
                 h->targs.W = P.W; h->targs.UVp = tbd + oUVp; h->targs.tvp = tbd + otvp; h->targs.tv_rows = tbd + otvr; h->targs.chunk = 1;
+                h->targs.ne = elim_ok ? ne : 0;
+                h->targs.Wr = elim_ok ? d + oWr : P.W; h->targs.UVrp = elim_ok ? tbd + oUVrp : h->targs.UVp; h->targs.AATr = elim_ok ? d + oAATr : P.AAT;
+                h->targs.Me = d + oMe; h->targs.Ne = d + oNe; h->targs.gE = d + ogE;
             }
             const Layout lf = make_layout(NTP * NTP + 3 * NTP + kmax * LS, size_K, size_L, 0, mode == 1 ? size_X : 0, kmax, nc, 2, 2, 2);
             h->Pf = P; apply_layout(h->Pf, lf); h->lds_f = lf.bytes;
@@ -923,9 +953,17 @@ int mpc_program_block(mpc_handle *h, int32_t which, double *out, int64_t cap, in
         case 2: src = h->Pv.Gt; n = nc * nx; break;
         case 3: src = h->Pv.X0H; n = nx * nr; break;
         case 4: src = h->Pv.AAT; n = nc * nc; break;
-        default: return fail(h, MPC_ERR_INVALID, "mpc_program_block: which must be 0..4");
+        // blocks with the equality rows eliminated (setup_mfma.hpp); empty when the program has none or the elimination is off
+        case 5: src = h->blocks.as<double>() + h->o_elim[0]; n = nc * nc; break;
+        case 6: src = h->blocks.as<double>() + h->o_elim[1]; n = nc * nr; break;
+        case 7: src = h->blocks.as<double>() + h->o_elim[2]; n = nc * nc; break;
+        case 8: src = h->blocks.as<double>() + h->o_elim[3]; n = (long long)h->n_eq * nr; break;
+        case 9: src = h->blocks.as<double>() + h->o_elim[4]; n = (long long)h->n_eq * nc; break;
+        case 10: src = h->blocks.as<double>() + h->o_elim[5]; n = 2LL * h->n_eq; break;
+        default: return fail(h, MPC_ERR_INVALID, "mpc_program_block: which must be 0..10");
     }
     if (which < 4 && h->kkt_mode != 0) n = 0;   // the Schur blocks exist only for a positive definite Q
+    if (which >= 5 && !h->elim_ok) n = 0;
     *n_out = n;
     if (n == 0) return MPC_OK;
     if (!out || cap < n) return fail(h, MPC_ERR_CAPACITY, "mpc_program_block: buffer too small");
@@ -1182,7 +1220,8 @@ static int level_run_small(mpc_handle *h, int32_t gen_children, int32_t flags, m
     const int32_t *theta_list = nullptr;
     ThetaArgs ta = h->targs;
     ta.chunk = 1;
-    if (h->kkt_mode == 0 && k >= 1 && k <= 8 && !h->no_kkt_thread) {
+    const int kd = k - h->targs.ne;   // rows the one-thread KKT kernel solves for (the equality rows are eliminated)
+    if (h->kkt_mode == 0 && kd >= 1 && kd <= 8 && !h->no_kkt_thread) {
         HIP_TRY(h, h->kkt_code.ensure(nn, st));
         HIP_TRY(h, h->kkt_L.ensure(nn * (size_t)k * (h->n_t + 1) * sizeof(double), st));
         kkc = h->kkt_code.as<uint8_t>(); kkl = h->kkt_L.as<double>();
@@ -1191,7 +1230,7 @@ static int level_run_small(mpc_handle *h, int32_t gen_children, int32_t flags, m
 #define MPC_LAUNCH_KKT(K_) case K_: if (h->fast_t >= 4) hipLaunchKernelGGL((k_kkt_thread<K_, 10>), g, b, 0, st, pf, fr, n, h->kkt_code.as<uint8_t>(), h->kkt_L.as<double>(), stp, tk, ctr); \
                                     else if (h->fast_t >= 2) hipLaunchKernelGGL((k_kkt_thread<K_, 8>), g, b, 0, st, pf, fr, n, h->kkt_code.as<uint8_t>(), h->kkt_L.as<double>(), stp, tk, ctr); \
                                     else hipLaunchKernelGGL((k_kkt_thread<K_, 4>), g, b, 0, st, pf, fr, n, h->kkt_code.as<uint8_t>(), h->kkt_L.as<double>(), stp, tk, ctr); break
-        switch (k) { MPC_LAUNCH_KKT(1); MPC_LAUNCH_KKT(2); MPC_LAUNCH_KKT(3); MPC_LAUNCH_KKT(4); MPC_LAUNCH_KKT(5); MPC_LAUNCH_KKT(6); MPC_LAUNCH_KKT(7); MPC_LAUNCH_KKT(8); }
+        switch (kd) { MPC_LAUNCH_KKT(1); MPC_LAUNCH_KKT(2); MPC_LAUNCH_KKT(3); MPC_LAUNCH_KKT(4); MPC_LAUNCH_KKT(5); MPC_LAUNCH_KKT(6); MPC_LAUNCH_KKT(7); MPC_LAUNCH_KKT(8); }
 #undef MPC_LAUNCH_KKT
         hipLaunchKernelGGL(k_compact_small, dim3(1), dim3(1024), 0, st, h->status.as<uint8_t>(), (int)n, ST_TODO, ST_TODO, h->theta_list.as<int32_t>(), dcnt + 0);
         theta_list = h->theta_list.as<int32_t>();
@@ -1579,7 +1618,8 @@ static int level_run_impl(mpc_handle *h, int32_t gen_children, int32_t flags, mp
             // fetch the multipliers of the candidates the screen left open
             long long n_theta = n;
             const int32_t *theta_list = nullptr;
-            if (h->kkt_mode == 0 && k >= 1 && k <= 8 && !h->no_kkt_thread) {
+            const int kd = k - h->targs.ne;   // rows the one-thread KKT kernel solves for (the equality rows are eliminated)
+            if (h->kkt_mode == 0 && kd >= 1 && kd <= 8 && !h->no_kkt_thread) {
                 HIP_TRY(h, h->kkt_code.ensure(nn, st));
                 HIP_TRY(h, h->kkt_L.ensure(nn * (size_t)k * (h->n_t + 1) * sizeof(double), st));
                 kkc = h->kkt_code.as<uint8_t>(); kkl = h->kkt_L.as<double>();
@@ -1589,7 +1629,7 @@ static int level_run_impl(mpc_handle *h, int32_t gen_children, int32_t flags, mp
 #define MPC_LAUNCH_KKT(K_) case K_: if (h->fast_t >= 4) hipLaunchKernelGGL((k_kkt_thread<K_, 10>), g, b, 0, st, pf, fr, n, h->kkt_code.as<uint8_t>(), h->kkt_L.as<double>(), stp, ta, ctr); \
                                     else if (h->fast_t >= 2) hipLaunchKernelGGL((k_kkt_thread<K_, 8>), g, b, 0, st, pf, fr, n, h->kkt_code.as<uint8_t>(), h->kkt_L.as<double>(), stp, ta, ctr); \
                                     else hipLaunchKernelGGL((k_kkt_thread<K_, 4>), g, b, 0, st, pf, fr, n, h->kkt_code.as<uint8_t>(), h->kkt_L.as<double>(), stp, ta, ctr); break
-                switch (k) { MPC_LAUNCH_KKT(1); MPC_LAUNCH_KKT(2); MPC_LAUNCH_KKT(3); MPC_LAUNCH_KKT(4); MPC_LAUNCH_KKT(5); MPC_LAUNCH_KKT(6); MPC_LAUNCH_KKT(7); MPC_LAUNCH_KKT(8); }
+                switch (kd) { MPC_LAUNCH_KKT(1); MPC_LAUNCH_KKT(2); MPC_LAUNCH_KKT(3); MPC_LAUNCH_KKT(4); MPC_LAUNCH_KKT(5); MPC_LAUNCH_KKT(6); MPC_LAUNCH_KKT(7); MPC_LAUNCH_KKT(8); }
 #undef MPC_LAUNCH_KKT
                 HIP_TRY(h, hipEventRecord(h->kev[7], st));
                 kernel_timed[3] = true;

@@ -301,6 +301,67 @@ def test_mfma_setup_blocks_equal_numpy(shape):
     eng.close()
 
 
+@pytest.mark.parametrize('shape', [(20, 4, 40, 1), (15, 2, 32, 10), (24, 3, 49, 16), (30, 8, 60, 17), (40, 10, 90, 33)])
+def test_mfma_equality_elimination_equals_numpy(shape):
+    """The blocks with the n_eq equality rows eliminated (set-up kernel, second phase): Wr, UVr, (A A')r, Me, Ne and the Gram
+    pivots against numpy; one to three 16-row blocks of equality rows.  The eliminated rows / columns of the reduced blocks are
+    zero up to rounding and are never read."""
+    from ppopt_amd import _lib
+    nx, nt, nc, ne = shape
+    d = _random_program(numpy.random.default_rng(nx * 1000 + nc + ne), nx, nt, nc)
+    d['A'][:ne] = numpy.random.default_rng(ne).standard_normal((ne, nx))      # independent equality rows
+    eng = _lib.Engine(d['A'], d['b'], d['F'], d['c'], d['H'], d['Q'], d['A_t'], d['b_t'], ne)
+    Qi = numpy.linalg.inv(d['Q'])
+    W = d['A'] @ Qi @ d['A'].T
+    UV = numpy.hstack([d['A'] @ Qi @ d['c'] + d['b'], d['A'] @ Qi @ d['H'] + d['F']])
+    G = d['A'] @ d['A'].T
+    E, I = numpy.arange(ne), numpy.arange(ne, nc)
+    WEi, GEi = numpy.linalg.inv(W[numpy.ix_(E, E)]), numpy.linalg.inv(G[numpy.ix_(E, E)])
+    cond = max(numpy.linalg.cond(d['Q']), numpy.linalg.cond(W[numpy.ix_(E, E)]), numpy.linalg.cond(G[numpy.ix_(E, E)]))
+    want = {5: (W - W[:, E] @ WEi @ W[E, :])[numpy.ix_(I, I)], 6: (UV - W[:, E] @ WEi @ UV[E, :])[I],
+            7: (G - G[:, E] @ GEi @ G[E, :])[numpy.ix_(I, I)], 8: WEi @ UV[E, :], 9: (WEi @ W[E, :])[:, I]}
+    for which, ref in want.items():
+        got = eng.program_block(which)
+        assert got.size, which
+        got = got[numpy.ix_(I, I)] if which in (5, 7) else (got[I] if which == 6 else (got[:, I] if which == 9 else got))
+        err = numpy.max(numpy.abs(got - ref)) / (1.0 + numpy.max(numpy.abs(ref)))
+        assert err <= 1e-11 * max(cond, 1.0), (shape, which, err, cond)
+    gE = eng.program_block(10)
+    L = numpy.linalg.cholesky(G[numpy.ix_(E, E)])
+    assert numpy.allclose(gE[0], numpy.diag(L) ** 2, rtol=1e-9 * cond, atol=0) and numpy.allclose(gE[1], numpy.diag(G)[:ne], rtol=1e-13)
+    eng.close()
+
+
+@pytest.mark.parametrize('name', ['c2_dblint_n5', 'c2_dblint_n5_x20', 'dblint_n3'])
+def test_equality_elimination_gives_the_same_solve(name, monkeypatch):
+    """A/B: active sets of n_eq + (1..8) rows solved one thread per candidate on the reduced blocks (default) against the
+    full (n_eq + k)-row Schur systems solved inside the theta kernel's wavefronts (MPC_NO_EQ_ELIM=1): identical verdicts on every
+    level, identical region sets and index sets, coefficients within 1e-8 relative."""
+    from test_gpu_parity import engine_from_golden, run_levels
+    g = load_golden(name)
+    nl = None if bool(g['complete']) else int(g['n_levels']) + 1
+    runs = []
+    for env in ({}, {'MPC_NO_EQ_ELIM': '1'}):
+        with monkeypatch.context() as m:
+            for key, val in env.items():
+                m.setenv(key, val)
+            eng = engine_from_golden(g)
+            assert (eng.program_block(5).size > 0) == (not env and 'raw_Q' in g.files)
+            levels, regions = run_levels(eng, nl)
+            runs.append(([(c.copy(), s.copy()) for c, s, _ in levels], {tuple(r.active_set): r for r in regions}))
+            eng.close()
+    (la, ra), (lb, rb) = runs
+    assert len(la) == len(lb)
+    for (ca, sa), (cb, sb) in zip(la, lb):
+        assert numpy.array_equal(ca, cb) and numpy.array_equal(sa, sb)
+    assert set(ra) == set(rb)
+    for key, r1 in ra.items():
+        r2 = rb[key]
+        assert r1.omega_set == r2.omega_set and r1.lambda_set == r2.lambda_set and r1.regular_set == r2.regular_set, key
+        for fld in ('A', 'b', 'C', 'd', 'E', 'f'):
+            assert rel_err(getattr(r1, fld), getattr(r2, fld)) <= COEF_TOL, (key, fld, rel_err(getattr(r1, fld), getattr(r2, fld)))
+
+
 def test_mfma_setup_reports_a_semidefinite_hessian():
     """A rank-deficient Q fails the Cholesky pivot test on the device: the program runs in dense-KKT mode (no Schur blocks)."""
     from ppopt_amd import _lib
