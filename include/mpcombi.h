@@ -155,6 +155,22 @@ int mpc_pruned_get(mpc_handle *h, uint64_t *masks_host, int64_t cap);
 int mpc_level_run(mpc_handle *h, int32_t gen_children, mpc_level_stats *stats);
 int mpc_level_run_ex(mpc_handle *h, int32_t gen_children, int32_t flags, mpc_level_stats *stats);   /* flags: MPC_LEVEL_GRAPH, MPC_LEVEL_KEEP_LOWDIM */
 int mpc_level_status(mpc_handle *h, uint8_t *status_host);                       /* n bytes, frontier order */
+/* One level of SEVERAL programs per launch (reference: mp_solvers/mpmiqp_enumeration.py:41-50 maps solve_mpqp over the
+ * binary fixations one sub-program at a time).  handles[0..n_handles) are distinct programs on one device, each with its own
+ * resident frontier; gen_children[i] as in mpc_level_run; flags: MPC_LEVEL_KEEP_LOWDIM.  Every stage of the level is ONE launch for
+ * all members (blockIdx.y = member, arguments from a table in device memory), the host synchronises once, and each member is left
+ * exactly in the state mpc_level_run would have left it -- same kernels' bodies, same lists, bit-identical statuses, records,
+ * children and pruned masks; afterwards every handle is used on its own as usual (mpc_level_regions_slots, mpc_frontier_advance,
+ * ...).  Members the batch form does not cover (no register-resident LP instantiation, MPC_NO_SMALLPATH=1, a level that needs the
+ * LDS-engine region kernel or has a late optimal candidate) are run by mpc_level_run's own paths inside this call; *n_batched
+ * (optional) = members that went through the shared launches.  stats (optional): n_handles entries. */
+int mpc_level_run_batch(mpc_handle **handles, int32_t n_handles, const int32_t *gen_children, int32_t flags, mpc_level_stats *stats,
+                        int32_t *n_batched);
+/* The two halves of mpc_level_run_batch: _start queues the shared launches and returns (*token owns the state; the handles must not
+ * be used until _wait), _wait synchronises, completes every member and runs the members outside the shared launches.  A token is
+ * consumed by exactly one _wait. */
+int mpc_level_batch_start(mpc_handle **handles, int32_t n_handles, const int32_t *gen_children, int32_t flags, void **token);
+int mpc_level_batch_wait(void *token, mpc_level_stats *stats, int32_t *n_batched);
 /* The same level driven by the handle's worker thread: mpc_level_start returns at once, mpc_level_wait joins it and returns
  * what mpc_level_run would have returned.  Between the two only mpc_level_stream_info / mpc_level_chunk_wait may be called
  * on the handle.  (Reference: the parent process is free while pool.map runs, driver :116, and merges results as they come.)
@@ -240,6 +256,11 @@ int mpc_level_regions_slots(mpc_handle *h, double *head_d, int32_t *head_i, int6
  * then.  When some record needs host-side repacking the call behaves like mpc_level_regions_slots. */
 int mpc_level_regions_slots_async(mpc_handle *h, double *head_d, int32_t *head_i, int64_t cap_slots, double *erows,
                                   int64_t cap_rows, int64_t *n_slots, int64_t *n_rows);
+/* The same, not even waiting for head_i: all three arrays are complete after mpc_sync or the next level of the handle
+ * (mpc_level_run, mpc_level_batch_start) -- the driver of a batch queues the fetches of every member, starts the next level for all of
+ * them and builds the region objects of the finished level while the device works. */
+int mpc_level_regions_slots_nowait(mpc_handle *h, double *head_d, int32_t *head_i, int64_t cap_slots, double *erows,
+                                   int64_t cap_rows, int64_t *n_slots, int64_t *n_rows);
 int mpc_sync(mpc_handle *h);   /* waits for everything queued on the handle's stream */
 /* Page-locked host memory from a recycling pool (blocks return to the pool on mpc_host_free and are handed out again
  * without re-pinning).  For result arrays that are filled by mpc_level_regions_slots. */

@@ -97,6 +97,7 @@ def load():
         'mpc_pruned_get': (ctypes.c_int, [H, _u64p, ctypes.c_int64]),
         'mpc_level_run': (ctypes.c_int, [H, ctypes.c_int32, ctypes.POINTER(LevelStats)]),
         'mpc_level_run_ex': (ctypes.c_int, [H, ctypes.c_int32, ctypes.c_int32, ctypes.POINTER(LevelStats)]),
+        'mpc_level_run_batch': (ctypes.c_int, [ctypes.POINTER(H), ctypes.c_int32, ctypes.POINTER(ctypes.c_int32), ctypes.c_int32, ctypes.POINTER(LevelStats), ctypes.POINTER(ctypes.c_int32)]),
         'mpc_level_status': (ctypes.c_int, [H, _u8p]),
         'mpc_level_start': (ctypes.c_int, [H, ctypes.c_int32, ctypes.c_int32]),
         'mpc_level_stream_info': (ctypes.c_int, [H, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_void_p),
@@ -112,6 +113,7 @@ def load():
         'mpc_level_slots': (ctypes.c_int64, [H]),
         'mpc_level_regions_slots': (ctypes.c_int, [H, _dp, _ip, ctypes.c_int64, _dp, ctypes.c_int64, _lp, _lp]),
         'mpc_level_regions_slots_async': (ctypes.c_int, [H, _dp, _ip, ctypes.c_int64, _dp, ctypes.c_int64, _lp, _lp]),
+        'mpc_level_regions_slots_nowait': (ctypes.c_int, [H, _dp, _ip, ctypes.c_int64, _dp, ctypes.c_int64, _lp, _lp]),
         'mpc_sync': (ctypes.c_int, [H]),
         'mpc_locator_create': (ctypes.c_int, [ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int64, _lp, _dp, _dp, _dp, _dp, _dp,
                                                ctypes.POINTER(ctypes.c_void_p)]),
@@ -154,7 +156,7 @@ EXPORTED_SYMBOLS = ['mpc_device_count', 'mpc_version', 'mpc_last_global_error', 
                     'mpc_last_error', 'mpc_mask_words', 'mpc_set_region_overlap', 'mpc_program_block', 'mpc_region_doubles', 'mpc_region_ints', 'mpc_lds_bytes', 'mpc_stream',
                     'mpc_frontier_root', 'mpc_frontier_set', 'mpc_frontier_set_device', 'mpc_frontier_info',
                     'mpc_frontier_get', 'mpc_pruned_clear', 'mpc_pruned_add', 'mpc_pruned_add_device',
-                    'mpc_pruned_count', 'mpc_pruned_get', 'mpc_level_run', 'mpc_level_run_ex', 'mpc_level_status', 'mpc_level_start', 'mpc_level_stream_info', 'mpc_level_chunk_wait', 'mpc_level_wait', 'mpc_level_stream_fixup', 'mpc_base_result', 'mpc_level_regions', 'mpc_compact_strides',
+                    'mpc_pruned_count', 'mpc_pruned_get', 'mpc_level_run', 'mpc_level_run_ex', 'mpc_level_run_batch', 'mpc_level_batch_start', 'mpc_level_batch_wait', 'mpc_level_regions_slots_nowait', 'mpc_level_status', 'mpc_level_start', 'mpc_level_stream_info', 'mpc_level_chunk_wait', 'mpc_level_wait', 'mpc_level_stream_fixup', 'mpc_base_result', 'mpc_level_regions', 'mpc_compact_strides',
                     'mpc_level_regions_compact', 'mpc_frontier_shard', 'mpc_level_slots', 'mpc_level_regions_slots', 'mpc_level_regions_slots_async', 'mpc_sync', 'mpc_host_alloc', 'mpc_host_free', 'mpc_locator_create', 'mpc_locator_query', 'mpc_locator_destroy', 'mpc_locator_set_adjacency', 'mpc_level_children', 'mpc_level_children_device', 'mpc_level_pruned_new',
                     'mpc_level_pruned_new_device', 'mpc_level_regions_device', 'mpc_frontier_advance', 'mpc_qp_solve_batch', 'mpc_facet_centres', 'mpc_graph_begin', 'mpc_graph_wave', 'mpc_graph_group_run', 'mpc_graph_wave_close', 'mpc_check_level', 'mpc_lp_solve_batch']
 
@@ -250,7 +252,7 @@ class Engine:
     # -- plumbing ----------------------------------------------------------------------------------------------
     def _check(self, rc, what):
         if rc != MPC_OK:
-            cls = MpcCapacityError if rc == 3 and what in ('mpc_level_run', 'mpc_level_wait') else MpcError
+            cls = MpcCapacityError if rc == 3 and what in ('mpc_level_run', 'mpc_level_wait', 'mpc_level_run_batch') else MpcError
             raise cls(f'{what} failed ({rc}): {self._L.mpc_last_error(self._h).decode()}')
 
     def program_block(self, which: int) -> numpy.ndarray:
@@ -348,6 +350,52 @@ class Engine:
                                              ctypes.byref(st)), 'mpc_level_run')
         self._last = st
         return st
+
+    @staticmethod
+    def level_batch_start(engines, gen_children, keep_lowdim: bool = False):
+        """First half of ``level_run_batch`` (mpc_level_batch_start): queues the shared launches of one level for all engines and
+        returns a token for ``level_batch_wait``; the engines must not be touched in between."""
+        B = len(engines)
+        L = engines[0]._L
+        hs = (ctypes.c_void_p * B)(*[e._h for e in engines])
+        gc = (ctypes.c_int32 * B)(*[int(bool(g)) for g in gen_children])
+        tok = ctypes.c_void_p()
+        rc = L.mpc_level_batch_start(hs, B, gc, MPC_LEVEL_KEEP_LOWDIM if keep_lowdim else 0, ctypes.byref(tok))
+        if rc != 0:
+            Engine._raise_for(engines, rc)
+        return (tok, list(engines))
+
+    @staticmethod
+    def level_batch_wait(token):
+        """Second half: ([LevelStats per engine], members that went through the shared launches)."""
+        tok, engines = token
+        B = len(engines)
+        stats = (LevelStats * B)()
+        nb = ctypes.c_int32(0)
+        rc = engines[0]._L.mpc_level_batch_wait(tok, stats, ctypes.byref(nb))
+        if rc != 0:
+            Engine._raise_for(engines, rc)
+        out = []
+        for e, st in zip(engines, stats):
+            c = LevelStats()
+            ctypes.memmove(ctypes.byref(c), ctypes.byref(st), ctypes.sizeof(LevelStats))
+            e._last = c
+            out.append(c)
+        return out, int(nb.value)
+
+    @staticmethod
+    def _raise_for(engines, rc):
+        for e in engines:      # the failing member carries the message
+            if e._L.mpc_last_error(e._h):
+                e._check(rc, 'mpc_level_run_batch')
+        engines[0]._check(rc, 'mpc_level_run_batch')
+
+    @staticmethod
+    def level_run_batch(engines, gen_children, keep_lowdim: bool = False):
+        """One level of several programs per launch (mpc_level_run_batch): ``engines`` are distinct Engines on one device, each
+        with its frontier; ``gen_children`` one flag per engine.  Returns ([LevelStats per engine], members that went through the
+        shared launches).  Afterwards every engine is in the state ``level_run`` would have left it in."""
+        return Engine.level_batch_wait(Engine.level_batch_start(engines, gen_children, keep_lowdim))
 
     # -- the same level on the handle's worker thread, region records streamed to the host (include/mpcombi.h) ----------
     def level_start(self, gen_children: bool, stream: bool = True, then_base: bool = False, keep_lowdim: bool = False,
@@ -486,6 +534,23 @@ class Engine:
     def sync(self):
         """Waits for everything queued on the handle's stream (completes an asynchronous slot fetch)."""
         self._check(self._L.mpc_sync(self._h), 'mpc_sync')
+
+    def level_regions_slots_nowait(self):
+        """``level_regions_slots`` that only QUEUES the copies: (head_d, head_i, erows, k) -- all three complete after ``sync()`` or
+        the next level of this engine; then ``numpy.flatnonzero(head_i[:, 0] == REGION)`` are the region slots."""
+        nr = int(self._last.n_regions)
+        fd, fi, mr = ctypes.c_int64(0), ctypes.c_int64(0), ctypes.c_int64(0)
+        self._check(self._L.mpc_compact_strides(self._h, ctypes.byref(fd), ctypes.byref(fi), ctypes.byref(mr)), 'mpc_compact_strides')
+        ns = int(self._L.mpc_level_slots(self._h)) if nr else 0
+        rows_cap = int(mr.value) if nr else 0
+        hd = pinned_empty((ns, fd.value), numpy.float64)
+        hi = pinned_empty((ns, fi.value), numpy.int32)
+        er = pinned_empty((max(rows_cap, 1), self.n_t + 1), numpy.float64)
+        n1, n2 = ctypes.c_int64(0), ctypes.c_int64(0)
+        if nr:
+            self._check(self._L.mpc_level_regions_slots_nowait(self._h, hd.ctypes.data_as(_dp), hi.ctypes.data_as(_ip), ns, er.ctypes.data_as(_dp),
+                                                               rows_cap, ctypes.byref(n1), ctypes.byref(n2)), 'mpc_level_regions_slots')
+        return hd[:n1.value], hi[:n1.value], er[:n2.value], int(self._last.k)
 
     def level_regions_slots(self, early_return: bool = False):
         """All slots the region kernel wrote for this level, copied by DMA into pooled page-locked arrays:

@@ -1,0 +1,291 @@
+// batch_level.hip -- the launches of one level for many member programs (batch_level.hpp).
+//
+// MPC_GLOBAL turns every kernel of kernels.hpp / kernels2.hpp into an inlined device function in this translation unit; the
+// kernels below fetch their member's argument block (blockIdx.y) and call those bodies with exactly the arguments
+// level_run_small (mpcombi_hip.hip) passes for a single program.  blockIdx.x / gridDim.x keep their meaning inside the bodies:
+// the x-extent of a launch is the largest any member of the group needs, a member's surplus blocks leave at once (every body
+// tests its index or its work queue against the member's own counts).
+#define MPC_GLOBAL __device__ __forceinline__
+#define MPC_LB(...)
+#include "batch_level.hpp"
+
+#include <algorithm>
+#include <cstring>
+#include <mutex>
+#include <tuple>
+#include <vector>
+
+namespace mpc {
+namespace {
+
+#define MEMBER const BatchMember &m = tab[blockIdx.y]
+__device__ __forceinline__ int32_t *part_list_of(const BatchMember &m, int c) { return m.part_lists + (size_t)c * (size_t)m.n; }
+
+// ---- clears -------------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) m_zero(const BatchMember *__restrict__ tab) {
+    MEMBER;
+    for (int z = 0; z < m.n_zero; ++z) {
+        const unsigned long long bytes = m.zero[z].bytes;
+        if ((reinterpret_cast<unsigned long long>(m.zero[z].p) & 7ull) == 0 && (bytes & 7ull) == 0) {
+            unsigned long long *p = reinterpret_cast<unsigned long long *>(m.zero[z].p);
+            for (unsigned long long i = blockIdx.x * 256ull + threadIdx.x; i < bytes / 8; i += (unsigned long long)gridDim.x * 256ull) p[i] = 0ull;
+        } else {
+            unsigned char *p = reinterpret_cast<unsigned char *>(m.zero[z].p);
+            for (unsigned long long i = blockIdx.x * 256ull + threadIdx.x; i < bytes; i += (unsigned long long)gridDim.x * 256ull) p[i] = 0;
+        }
+    }
+}
+__global__ void m_zero_counter(const BatchMember *__restrict__ tab, int which) {   // 0: work_retry, 1: work_region
+    MEMBER;
+    if (threadIdx.x == 0) { if (which == 0) m.ctr->work_retry = 0u; else m.ctr->work_region = 0u; }
+}
+
+// ---- theta stage --------------------------------------------------------------------------------------------------------------
+template <int K, int NT>
+__global__ void __launch_bounds__(256) m_kkt_thread(const BatchMember *__restrict__ tab) {
+    MEMBER;
+    k_kkt_thread<K, NT>(m.pf, m.fr, m.n, m.kkt_code, m.kkt_L, m.status, m.targs, m.ctr);
+}
+__global__ void __launch_bounds__(1024) m_compact_small(const BatchMember *__restrict__ tab, int lo, int hi, int into_retry, int slot) {
+    MEMBER;
+    k_compact_small(m.status, (int)m.n, lo, hi, into_retry ? m.retry_list : m.theta_list, m.dcnt + slot);
+}
+template <int NT, int SLOTS>
+__global__ void __launch_bounds__(64, (NT * SLOTS >= 20 ? 3 : (SLOTS >= 2 ? TH_WAVES_S2 : 4))) m_theta2(const BatchMember *__restrict__ tab) {
+    MEMBER;
+    ThetaArgs ta = m.targs;
+    ta.chunk = 1;
+    const uint8_t *kkc = nullptr;
+    const double *kkl = nullptr;
+    const int32_t *list = nullptr;
+    if (m.use_kkt) { kkc = m.kkt_code; kkl = m.kkt_L; list = m.theta_list; ta.n_dev = m.dcnt + 0; }
+    k_theta2<NT, SLOTS>(m.pf, m.fr, m.n, m.k, m.status, m.ctr, kkc, kkl, ta, list);
+}
+__global__ void __launch_bounds__(1024) m_partition_small(const BatchMember *__restrict__ tab, unsigned long long spec, int slot) {
+    MEMBER;
+    k_partition_small(m.status, (int)m.n, spec, m.part_lists, m.n, m.dcnt + slot);
+}
+__global__ void __launch_bounds__(64) m_verdict(const BatchMember *__restrict__ tab, int slot) {
+    MEMBER;
+    k_verdict(m.Pv, m.fr, m.n, m.k, m.status, m.ctr, part_list_of(m, 0), m.dcnt + slot);
+}
+
+// ---- region stage -------------------------------------------------------------------------------------------------------------
+template <int NT, int SLOTS>
+__global__ void __launch_bounds__(64, (SLOTS >= 2 ? 2 : R2W)) m_region2(const BatchMember *__restrict__ tab) {
+    MEMBER;
+    const uint8_t *kkc = m.use_kkt ? m.kkt_code : nullptr;
+    const double *kkl = m.use_kkt ? m.kkt_L : nullptr;
+    k_region2<NT, SLOTS>(m.pr, m.fr, m.k, part_list_of(m, 2), (int)m.n, m.status, m.headd, m.headi, m.fd, m.fi, m.epool, m.ctr, kkc, kkl, m.W,
+                         m.kept_g, m.ldk, m.done_g, m.no_rbox ? (const double *)nullptr : m.targs.tvp + (size_t)NT * NT + NT, m.rs);
+}
+
+// the candidates k_region2 gave up on (status RRETRY, compacted into retry_list, length at dcnt[28]): the LDS-engine kernel in its
+// latency form, as launch_region_v1 runs it for a short list -- one wavefront per (candidate, region row), then the assembly pass
+template <int MODE>
+__global__ void __launch_bounds__(64) m_region_v1(const BatchMember *__restrict__ tab) {
+    MEMBER;
+    const int n_list = m.dcnt[28];
+    if (n_list <= 0 || n_list > m.rcap) return;      // none (the usual case) / more than the reserved slots: the member repeats the level alone
+    k_region<MODE>(m.Pr, m.fr, m.k, m.retry_list, n_list, m.status, m.recd, m.reci, m.rec_d, m.rec_i, m.ctr, m.facet_flags);
+}
+
+// ---- (x,theta) stage ------------------------------------------------------------------------------------------------------------
+template <int SLOTS>
+__global__ void __launch_bounds__(64, XQ_WAVES) m_xq(const BatchMember *__restrict__ tab) {
+    MEMBER;
+    DictCache dq = m.dc;
+    dq.n_list_dev = m.dcnt + 7;
+    k_xq<SLOTS>(m.pf, m.fr, m.k, part_list_of(m, 3), (int)m.n, m.status, m.ctr, dq, m.nxc);
+}
+template <int NXC, int SLOTS>
+__global__ void __launch_bounds__(64, (NXC * SLOTS >= 32 ? X2_WAVES : 3)) m_x2(const BatchMember *__restrict__ tab) {
+    MEMBER;
+    DictCache d = m.dc;
+    d.n_list_dev = m.dcnt + (m.quick_test ? 8 : 7);
+    k_x2<NXC, SLOTS>(m.pf, m.fr, m.k, m.quick_test ? m.retry_list : part_list_of(m, 3), (int)m.n, m.status, m.ctr, d);
+}
+
+// ---- pruned masks, children, counters -----------------------------------------------------------------------------------------
+template <int MW>
+__global__ void m_pruned_append(const BatchMember *__restrict__ tab) {
+    MEMBER;
+    k_pruned_append<MW>(m.fr, m.n, m.k, m.status, m.pruned + (size_t)m.n_pruned * MW, m.ctr, m.keep_lowdim);
+}
+template <int MW>
+__global__ void __launch_bounds__(64) m_children_count(const BatchMember *__restrict__ tab) {
+    MEMBER;
+    k_children_count<MW>(m.Pv, m.fr, m.n, m.k, m.status, m.pruned, m.n_pruned, m.childmask, m.count, m.keep_lowdim);
+}
+__global__ void __launch_bounds__(1024) m_scan_small(const BatchMember *__restrict__ tab) {
+    MEMBER;
+    k_scan_small(m.count, m.offset, (int)m.n, m.dcnt + 20);
+}
+__global__ void __launch_bounds__(64) m_children_write(const BatchMember *__restrict__ tab) {
+    MEMBER;
+    k_children_write(m.fr, m.n, m.k, m.mw, m.childmask, m.offset, m.children, m.storing ? m.dict_stored_cur : (const uint8_t *)nullptr, m.parent_slot_next);
+}
+__global__ void m_histogram(const BatchMember *__restrict__ tab) {
+    MEMBER;
+    k_histogram(m.status, m.n, m.ctr);
+}
+__global__ void m_publish(const BatchMember *__restrict__ tab) {
+    MEMBER;
+    k_publish_words(reinterpret_cast<const unsigned int *>(m.ctr), m.pub_ctr, (int)(sizeof(LevelCounters) / 4));
+    k_publish_words(reinterpret_cast<const unsigned int *>(m.dcnt), m.pub_cnt, 32);
+}
+
+unsigned long long spec_of(std::initializer_list<std::pair<int, int>> classes) {
+    unsigned long long spec = ~0ull;
+    for (const auto &sc : classes) spec = (spec & ~(15ull << (4 * sc.first))) | ((unsigned long long)sc.second << (4 * sc.first));
+    return spec;
+}
+
+// the argument table: pinned staging + device copy, grown on demand, one per process (batch launches are serialised)
+std::mutex g_batch_mutex;
+BatchMember *g_tab_host = nullptr, *g_tab_dev = nullptr;
+int g_tab_cap = 0;
+
+auto group_key(const BatchMember &m) { return std::make_tuple(m.k, m.kd, m.fast_t, m.fast_x, m.fast_r, m.mw, m.use_kkt, m.quick_test, m.gen_children); }
+
+template <class F>
+hipError_t raise_lds(F *fn, int bytes) {
+    if (bytes <= 48 * 1024) return hipSuccess;
+    return hipFuncSetAttribute(reinterpret_cast<const void *>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+}
+
+}  // namespace
+
+#define TRY(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) return e_; } while (0)
+
+hipError_t batch_level_launch(BatchMember *members, int B, hipStream_t st) {
+    if (B <= 0) return hipSuccess;
+    std::lock_guard<std::mutex> lk(g_batch_mutex);
+    std::stable_sort(members, members + B, [](const BatchMember &a, const BatchMember &b) { return group_key(a) < group_key(b); });
+    if (B > g_tab_cap) {
+        if (g_tab_host) { (void)hipHostFree(g_tab_host); g_tab_host = nullptr; }
+        if (g_tab_dev) { (void)hipFree(g_tab_dev); g_tab_dev = nullptr; }
+        g_tab_cap = 0;
+        const int cap = std::max(64, B + B / 2);
+        TRY(hipHostMalloc(reinterpret_cast<void **>(&g_tab_host), (size_t)cap * sizeof(BatchMember), hipHostMallocPortable));
+        TRY(hipMalloc(reinterpret_cast<void **>(&g_tab_dev), (size_t)cap * sizeof(BatchMember)));
+        g_tab_cap = cap;
+    }
+    std::memcpy(g_tab_host, members, (size_t)B * sizeof(BatchMember));
+    TRY(hipMemcpyAsync(g_tab_dev, g_tab_host, (size_t)B * sizeof(BatchMember), hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(m_zero, dim3(64, (unsigned)B), dim3(256), 0, st, g_tab_dev);
+    TRY(hipGetLastError());
+    // ---- one launch sequence per group ----------------------------------------------------------------------------------------
+    for (int g0 = 0; g0 < B;) {
+        int g1 = g0 + 1;
+        while (g1 < B && group_key(members[g1]) == group_key(members[g0])) ++g1;
+        const BatchMember &r = members[g0];           // the group's representative
+        const BatchMember *tab = g_tab_dev + g0;
+        const unsigned G = (unsigned)(g1 - g0);
+        long long n_max = 0;
+        int grid_f = 1, grid_r2 = 1, lds_f = 0, lds_v = 0, lds_r2 = 0, rsplit = 1;
+        for (int i = g0; i < g1; ++i) {
+            n_max = std::max(n_max, members[i].n);
+            grid_f = std::max(grid_f, members[i].grid_f); grid_r2 = std::max(grid_r2, members[i].grid_r2);
+            lds_f = std::max(lds_f, members[i].lds_f); lds_v = std::max(lds_v, members[i].lds_v); lds_r2 = std::max(lds_r2, members[i].lds_r2);
+            rsplit = std::max(rsplit, members[i].rsplit_max);
+        }
+        const unsigned blocks256 = (unsigned)((n_max + 255) / 256);
+        // KKT solves + box screen, theta stage
+        if (r.use_kkt) {
+            const dim3 g(blocks256, G), b(256);
+#define MPC_LAUNCH_KKT(K_) case K_: if (r.fast_t >= 4) hipLaunchKernelGGL((m_kkt_thread<K_, 10>), g, b, 0, st, tab); \
+                                    else if (r.fast_t >= 2) hipLaunchKernelGGL((m_kkt_thread<K_, 8>), g, b, 0, st, tab); \
+                                    else hipLaunchKernelGGL((m_kkt_thread<K_, 4>), g, b, 0, st, tab); break
+            switch (r.kd) { MPC_LAUNCH_KKT(1); MPC_LAUNCH_KKT(2); MPC_LAUNCH_KKT(3); MPC_LAUNCH_KKT(4); MPC_LAUNCH_KKT(5); MPC_LAUNCH_KKT(6); MPC_LAUNCH_KKT(7); MPC_LAUNCH_KKT(8); }
+#undef MPC_LAUNCH_KKT
+            hipLaunchKernelGGL(m_compact_small, dim3(1, G), dim3(1024), 0, st, tab, ST_TODO, ST_TODO, 0, 0);
+        }
+        {
+            const dim3 g((unsigned)std::min<long long>(n_max, grid_f), G), b(64);
+#define MPC_LAUNCH_TH(NT_, SL_) do { TRY(raise_lds(m_theta2<NT_, SL_>, lds_f)); hipLaunchKernelGGL((m_theta2<NT_, SL_>), g, b, lds_f, st, tab); } while (0)
+            switch (r.fast_t) {
+                case 0: MPC_LAUNCH_TH(4, 1); break;
+                case 1: MPC_LAUNCH_TH(4, 2); break;
+                case 2: MPC_LAUNCH_TH(8, 1); break;
+                case 3: MPC_LAUNCH_TH(8, 2); break;
+                case 4: MPC_LAUNCH_TH(10, 1); break;
+                default: MPC_LAUNCH_TH(10, 2); break;
+            }
+#undef MPC_LAUNCH_TH
+        }
+        TRY(raise_lds(m_verdict, lds_v));
+        hipLaunchKernelGGL(m_partition_small, dim3(1, G), dim3(1024), 0, st, tab, spec_of({{ST_RETRY, 0}}), 12);
+        hipLaunchKernelGGL(m_verdict, dim3((unsigned)std::min<long long>(n_max, 128), G), dim3(64), lds_v, st, tab, 12);
+        hipLaunchKernelGGL(m_partition_small, dim3(1, G), dim3(1024), 0, st, tab,
+                           spec_of({{ST_FEASIBLE, 1}, {ST_OPT_PENDING, 2}, {ST_NEEDX, 3}, {ST_NEEDX_SING, 3}}), 4);
+        TRY(hipGetLastError());
+        hipLaunchKernelGGL(m_zero_counter, dim3(1, G), dim3(64), 0, st, tab, 0);
+        // (x,theta) stage
+        if (r.quick_test) {
+            const dim3 gg((unsigned)std::min<long long>(n_max, (long long)r.n_cu * 32), G), bb(64);
+            if (r.fast_x & 1) hipLaunchKernelGGL((m_xq<2>), gg, bb, 0, st, tab);
+            else hipLaunchKernelGGL((m_xq<1>), gg, bb, 0, st, tab);
+            hipLaunchKernelGGL(m_compact_small, dim3(1, G), dim3(1024), 0, st, tab, ST_NEEDX, ST_NEEDX_SING, 1, 8);
+        }
+        {
+            const dim3 gg((unsigned)std::min<long long>(n_max, (long long)r.n_cu * 16), G), bb(64);
+            switch (r.fast_x) {
+                case 0: hipLaunchKernelGGL((m_x2<16, 1>), gg, bb, 0, st, tab); break;
+                case 1: hipLaunchKernelGGL((m_x2<16, 2>), gg, bb, 0, st, tab); break;
+                case 2: hipLaunchKernelGGL((m_x2<32, 1>), gg, bb, 0, st, tab); break;
+                default: hipLaunchKernelGGL((m_x2<32, 2>), gg, bb, 0, st, tab); break;
+            }
+        }
+        TRY(hipGetLastError());
+        hipLaunchKernelGGL(m_partition_small, dim3(1, G), dim3(1024), 0, st, tab, spec_of({{ST_RETRY, 0}}), 24);
+        hipLaunchKernelGGL(m_verdict, dim3((unsigned)std::min<long long>(n_max, 128), G), dim3(64), lds_v, st, tab, 24);
+        // region stage, behind the (x,theta) stage: every optimal candidate of the level is known -- those of the theta stage and those a
+        // re-solve of a doubtful (x,theta) run has just found -- so one launch covers them all (class 2 of the partition at [16..19];
+        // a single program overlaps its region stage with the (x,theta) stage instead and handles late candidates separately: with
+        // other members filling the device there is nothing to gain from that here)
+        hipLaunchKernelGGL(m_partition_small, dim3(1, G), dim3(1024), 0, st, tab, spec_of({{ST_OPT_PENDING, 2}}), 16);
+        TRY(hipGetLastError());
+        {
+            const dim3 g((unsigned)std::min<long long>(n_max * std::max(rsplit, 1), grid_r2), G), b(64);
+#define MPC_LAUNCH_R2(NT_, SL_) do { TRY(raise_lds(m_region2<NT_, SL_>, lds_r2)); hipLaunchKernelGGL((m_region2<NT_, SL_>), g, b, lds_r2, st, tab); } while (0)
+            switch (r.fast_r) {
+                case 0: MPC_LAUNCH_R2(4, 1); break;
+                case 1: MPC_LAUNCH_R2(4, 2); break;
+                case 2: MPC_LAUNCH_R2(8, 1); break;
+                case 3: MPC_LAUNCH_R2(8, 2); break;
+                case 4: MPC_LAUNCH_R2(10, 1); break;
+                default: MPC_LAUNCH_R2(10, 2); break;
+            }
+#undef MPC_LAUNCH_R2
+            TRY(hipGetLastError());
+            // what k_region2 gave up on (rare): LDS-engine kernel, fixed-layout records in the member's retry slots
+            int lds_r = 0, rcap = 1;
+            for (int i = g0; i < g1; ++i) { lds_r = std::max(lds_r, members[i].lds_r); rcap = std::max(rcap, members[i].rcap); }
+            TRY(raise_lds(m_region_v1<RG_FACET>, lds_r));
+            TRY(raise_lds(m_region_v1<RG_ASSEMBLE>, lds_r));
+            hipLaunchKernelGGL(m_compact_small, dim3(1, G), dim3(1024), 0, st, tab, ST_RRETRY, ST_RRETRY, 1, 28);
+            hipLaunchKernelGGL(m_zero_counter, dim3(1, G), dim3(64), 0, st, tab, 1);
+            hipLaunchKernelGGL(m_region_v1<RG_FACET>, dim3((unsigned)std::min(rcap * 8, 512), G), dim3(64), lds_r, st, tab);
+            hipLaunchKernelGGL(m_zero_counter, dim3(1, G), dim3(64), 0, st, tab, 1);
+            hipLaunchKernelGGL(m_region_v1<RG_ASSEMBLE>, dim3((unsigned)std::min(rcap, 128), G), dim3(64), lds_r, st, tab);
+            TRY(hipGetLastError());
+        }
+        // pruned masks of this level + children
+        if (r.mw == 2) hipLaunchKernelGGL(m_pruned_append<2>, dim3(blocks256, G), dim3(256), 0, st, tab);
+        else hipLaunchKernelGGL(m_pruned_append<4>, dim3(blocks256, G), dim3(256), 0, st, tab);
+        if (r.gen_children) {
+            if (r.mw == 2) hipLaunchKernelGGL(m_children_count<2>, dim3((unsigned)n_max, G), dim3(64), 0, st, tab);
+            else hipLaunchKernelGGL(m_children_count<4>, dim3((unsigned)n_max, G), dim3(64), 0, st, tab);
+            hipLaunchKernelGGL(m_scan_small, dim3(1, G), dim3(SCAN_BLOCK), 0, st, tab);
+            hipLaunchKernelGGL(m_children_write, dim3((unsigned)n_max, G), dim3(64), 0, st, tab);
+        }
+        hipLaunchKernelGGL(m_histogram, dim3(std::min(blocks256, 1024u), G), dim3(256), 0, st, tab);
+        hipLaunchKernelGGL(m_publish, dim3(1, G), dim3(128), 0, st, tab);
+        TRY(hipGetLastError());
+        g0 = g1;
+    }
+    return hipSuccess;
+}
+
+}  // namespace mpc

@@ -1,0 +1,67 @@
+// batch_level.hpp -- one level of MANY programs per launch ("batch several programs per launch").
+//
+// Reference counterpart: mp_solvers/mpmiqp_enumeration.py:41-50 maps solve_mpqp over the feasible binary fixations, one
+// sub-program after the other (or one per pool worker).  Here the sub-programs advance level by level TOGETHER: every stage of the
+// level -- KKT solves, theta LPs, partitions, (x,theta) LPs, region construction, pruned masks, children -- is ONE launch whose
+// blockIdx.y selects the member program and whose arguments come from a table in device memory (one BatchMember per program),
+// instead of one launch per stage and program.  The kernels' bodies are the single-program kernels of kernels.hpp / kernels2.hpp,
+// statement for statement (MPC_GLOBAL, kernels.hpp): a member's level computes bit for bit what mpc_level_run computes for it.
+//
+// The level is the no-round-trip form of mpcombi_hip.hip (level_run_small): list lengths live in device memory, launches are sized
+// by the members' candidate counts, the host synchronises once per level for ALL members.  Members whose kernels are different
+// template instantiations (n_theta class, rows per lane, mask words, cardinality) form separate groups of the same launch sequence.
+#pragma once
+#include <string>
+
+#include "kernels2.hpp"
+
+namespace mpc {
+
+struct BatchZero { void *p; unsigned long long bytes; };
+
+struct BatchMember {
+    int id;                  // position in the caller's array (batch_level_launch reorders the members into groups)
+    // ---- what selects the kernels (members of one group agree on all of these) ------------------------------------------------
+    int k, kd, fast_t, fast_x, fast_r, mw, use_kkt, quick_test, gen_children;
+    // ---- sizes ------------------------------------------------------------------------------------------------------------------
+    long long n;             // candidates of the level
+    int grid_f, grid_r2, n_cu, lds_f, lds_v, lds_r2, rsplit_max;
+    int W, ldk, fd, fi, no_rbox, nxc, storing, keep_lowdim;
+    int lds_r, rcap;         // LDS-engine region kernel (candidates k_region2 gives up on): dynamic LDS, record slots reserved
+    long long rec_d, rec_i;  // strides of its fixed-layout records
+    // ---- the arguments of level_run_small's launches ---------------------------------------------------------------------------
+    const DevProblem *pf, *pr;
+    DevProblem Pv, Pr;
+    const int32_t *fr;
+    uint8_t *status;
+    LevelCounters *ctr;
+    int32_t *dcnt;
+    uint8_t *kkt_code;
+    double *kkt_L;
+    int32_t *theta_list, *retry_list, *part_lists;
+    double *headd;
+    int32_t *headi;
+    double *epool;
+    uint8_t *kept_g;
+    unsigned int *done_g;
+    double *recd;
+    int32_t *reci;
+    uint8_t *facet_flags;
+    ThetaArgs targs;
+    RegionStream rs;
+    DictCache dc;
+    unsigned long long *pruned;
+    long long n_pruned;
+    unsigned long long *childmask;
+    int32_t *count, *offset, *children, *parent_slot_next;
+    const uint8_t *dict_stored_cur;
+    unsigned int *pub_ctr, *pub_cnt;     // device aliases of the member's pinned counters block
+    BatchZero zero[6];                   // cleared before the first launch
+    int n_zero;
+};
+
+// Queues the launches of one level for the B members on `st` (no synchronisation).  The members are reordered into groups.
+// Returns hipSuccess or the first error.
+hipError_t batch_level_launch(BatchMember *members, int B, hipStream_t st);
+
+}  // namespace mpc

@@ -27,6 +27,9 @@
 #include "locate.hpp"
 #include "graph.hpp"
 #include "qp.hpp"
+#include <memory>
+
+#include "batch_level.hpp"
 #include "setup_mfma.hpp"
 #include <rocprim/device/device_radix_sort.hpp>
 
@@ -45,12 +48,20 @@ thread_local std::string g_error;
 std::mutex g_dev_pool_mutex;
 std::multimap<std::pair<int, size_t>, void *> g_dev_pool_free;   // (device, size) -> block
 size_t g_dev_pool_bytes = 0;
-constexpr size_t DEV_POOL_MAX_BYTES = size_t(4) << 30, DEV_POOL_MAX_BLOCK = size_t(512) << 20;
+// Free blocks kept: MPC_DEV_POOL_GB (default 48 -- a sixth of the 288 GB of an MI355X; a batch of 64 sub-programs of the
+// mixed-integer enumeration holds ~20 GB of level buffers at once, and the next enumeration takes them over as they are).
+const size_t DEV_POOL_MAX_BYTES = [] { const char *ev = std::getenv("MPC_DEV_POOL_GB"); const double gb = ev ? std::atof(ev) : 48.0; return (size_t)(std::max(gb, 0.0) * 1073741824.0); }();
+constexpr size_t DEV_POOL_MAX_BLOCK = size_t(8) << 30;
 
+// size classes: powers of two up to 1 MiB, above that four steps per octave (1, 1.25, 1.5, 1.75 x 2^k: at most 25 % slack, and
+// buffers that grow with the level -- a different size at every level of every program -- meet blocks of earlier handles)
 size_t dev_size_class(size_t bytes) {
     if (bytes <= 256) return 256;
     if (bytes <= (size_t(1) << 20)) { size_t c = 256; while (c < bytes) c <<= 1; return c; }
-    return (bytes + (size_t(1) << 20) - 1) & ~((size_t(1) << 20) - 1);
+    size_t p = size_t(1) << 20;
+    while ((p << 1) <= bytes) p <<= 1;
+    const size_t step = p >> 2;
+    return (bytes + step - 1) / step * step;
 }
 hipError_t dev_pool_take(size_t cls, void **out) {
     int dev = 0;
@@ -119,7 +130,7 @@ std::mutex g_pool_mutex;
 std::multimap<size_t, void *> g_pool_free[2];       // [class] size -> block
 std::unordered_map<void *, std::pair<size_t, int>> g_pool_live;     // block -> (size, class)
 size_t g_pool_free_bytes = 0;
-constexpr size_t POOL_MAX_FREE = size_t(2) << 30;
+constexpr size_t POOL_MAX_FREE = size_t(16) << 30;
 
 hipError_t host_pool_take(size_t bytes, void **out, size_t *got, bool coherent = false) {
     static const bool coarse_only = [] { const char *ev = std::getenv("MPC_HOST_COARSE"); return ev && ev[0] == '1'; }();   // A/B switch
@@ -204,7 +215,7 @@ void return_stream(hipStream_t s) {   // synchronised by the caller
     (void)hipGetDevice(&dev);
     std::lock_guard<std::mutex> lk(g_sync_pool_mutex);
     auto &v = g_stream_pool[dev];
-    if (v.size() < 64) v.push_back(s); else (void)hipStreamDestroy(s);
+    if (v.size() < 1024) v.push_back(s); else (void)hipStreamDestroy(s);   // a stream costs ~3 ms to create and ~2 ms to destroy; a batch of 64 programs holds 200
 }
 hipError_t pooled_event(hipEvent_t *out, bool timing) {
     int dev = 0;
@@ -222,7 +233,14 @@ void return_event(hipEvent_t e, bool timing) {
     (void)hipGetDevice(&dev);
     std::lock_guard<std::mutex> lk(g_sync_pool_mutex);
     auto &v = g_event_pool[{dev, timing ? 1 : 0}];
-    if (v.size() < 512) v.push_back(e); else (void)hipEventDestroy(e);
+    if (v.size() < 8192) v.push_back(e); else (void)hipEventDestroy(e);
+}
+// hipGetDeviceCount costs ~80 us per call on this runtime (it is asked at every mpc_create and every LP batch)
+int device_count_cached() {
+    static const int n = [] { int v = 0; return hipGetDeviceCount(&v) == hipSuccess ? v : 0; }();
+    if (n > 0) return n;
+    int v = 0;      // none seen yet: ask again (a device may have been made visible since)
+    return hipGetDeviceCount(&v) == hipSuccess ? v : 0;
 }
 int cu_count(int device) {
     {
@@ -284,6 +302,8 @@ struct mpc_handle {
     int no_rbox = 0;          // MPC_NO_RBOX=1: no bounding-box screen of the region rows in k_region2 (A/B)
     int no_rsplit = 0;        // MPC_NO_RSPLIT=1: one wavefront per candidate in k_region2 whatever the load (A/B)
     int no_xquick = 0;        // MPC_NO_XQUICK=1: no quick (x,theta) test on the last level (A/B)
+    bool fetch_nowait = false; // mpc_level_regions_slots_nowait: even the integer heads are only queued
+    bool skip_small = false;  // mpc_level_run_batch: this level already went through the no-round-trip launches and has to be repeated classically
     size_t o_elim[6] = {0, 0, 0, 0, 0, 0};   // offsets of Wr, UVr, AATr, Me, Ne, gE in `blocks` (mpc_program_block)
     bool elim_ok = false;     // the blocks with the equality rows eliminated are valid
     int no_kkt_thread = 0;    // MPC_NO_KKT_THREAD=1: KKT solves stay inside the wave kernels (A/B)
@@ -469,11 +489,7 @@ static int lp_batch_impl(int32_t device, int64_t n_lp, int32_t m, int32_t n, con
 
 extern "C" {
 
-int mpc_device_count(void) {
-    int n = 0;
-    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
-    return n;
-}
+int mpc_device_count(void) { return device_count_cached(); }
 
 const char *mpc_version(void) { return "mpcombi-hip 0.1 (gfx950)"; }
 const char *mpc_last_global_error(void) { return g_error.c_str(); }
@@ -489,7 +505,7 @@ int mpc_create(const mpc_problem *p, int32_t device, void *stream, mpc_handle **
     if (nt > 64 || nx > 256) return fail(nullptr, MPC_ERR_INVALID, "n_t > 64 or n_x > 256 is not supported");
     if (!p->A || !p->b || !p->F || !p->c || !p->H || (ntc > 0 && (!p->A_t || !p->b_t))) return fail(nullptr, MPC_ERR_INVALID, "null matrix");
     int ndev = 0;
-    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return fail(nullptr, MPC_ERR_HIP, "no HIP device available (libmpcombi_hip has no CPU fallback)");
+    if ((ndev = device_count_cached()) < 1) return fail(nullptr, MPC_ERR_HIP, "no HIP device available (libmpcombi_hip has no CPU fallback)");
     if (device < 0 || device >= ndev) return fail(nullptr, MPC_ERR_INVALID, "device index out of range");
     // every failure from here on goes through one cleanup path: mpc_destroy returns the handle's streams, events, device
     // blocks and pinned block to the pools (a caller that creates one handle per binary fixation must not leak on OOM)
@@ -1434,11 +1450,275 @@ static int level_run_small(mpc_handle *h, int32_t gen_children, int32_t flags, m
     return MPC_OK;
 }
 
+// ---- the same level for many programs at once (batch_level.hpp) -----------------------------------------------------------------
+// batch_prepare = level_run_small up to its first launch (buffers, arguments), batch_finish = level_run_small after its one
+// synchronisation; the launches in between are batch_level_launch's, one per stage for all members.
+static int batch_prepare(mpc_handle *h, int32_t gen_children, int32_t flags, BatchMember &m) {
+    const long long n = h->n;
+    const int k = h->k;
+    const size_t nn = (size_t)n;
+    hipStream_t st = h->stream;
+    std::memset(&m, 0, sizeof(m));
+    h->n_opt = h->n_children = h->n_pruned_new = h->n_regions = 0;
+    h->n_needx = 0;
+    HIP_TRY(h, h->status.ensure(nn, st));
+    HIP_TRY(h, h->pruned.ensure((size_t)(h->n_pruned + n) * h->mw * sizeof(uint64_t), st, true));
+    HIP_TRY(h, h->retry_list.ensure(nn * sizeof(int32_t), st));
+    HIP_TRY(h, h->theta_list.ensure(nn * sizeof(int32_t), st));
+    HIP_TRY(h, h->part_lists.ensure((size_t)PART_CLASSES * nn * sizeof(int32_t), st));
+    HIP_TRY(h, h->dcnt.ensure(32 * sizeof(int32_t), st));
+    h->used_region2 = false; h->n_rretry = 0; h->n_erows = 0;
+    h->fd = h->n_x * h->n_t + h->n_x + k * h->n_t + k;
+    h->fi = 8 + k + h->n_tc + k + 2 * (h->n_c - k);
+    m.k = k; m.kd = k - h->targs.ne; m.fast_t = h->fast_t; m.fast_x = h->fast_x; m.fast_r = h->fast_r; m.mw = h->mw;
+    m.gen_children = gen_children ? 1 : 0;
+    m.n = n; m.grid_f = h->grid_f; m.grid_r2 = h->grid_r2; m.n_cu = h->n_cu; m.lds_f = h->lds_f; m.lds_v = h->lds_v; m.lds_r2 = h->lds_r2;
+    m.rsplit_max = h->rsplit_max;
+    m.pf = h->pf_dev.as<DevProblem>(); m.pr = h->pr2_dev.as<DevProblem>(); m.Pv = h->Pv;
+    m.fr = h->frontier.as<int32_t>(); m.status = h->status.as<uint8_t>(); m.ctr = h->ctr.as<LevelCounters>(); m.dcnt = h->dcnt.as<int32_t>();
+    m.theta_list = h->theta_list.as<int32_t>(); m.retry_list = h->retry_list.as<int32_t>(); m.part_lists = h->part_lists.as<int32_t>();
+    m.targs = h->targs;
+    m.zero[m.n_zero++] = {h->ctr.p, sizeof(LevelCounters)};
+    m.zero[m.n_zero++] = {h->dcnt.p, 32 * sizeof(int32_t)};
+    m.use_kkt = (h->kkt_mode == 0 && m.kd >= 1 && m.kd <= 8 && !h->no_kkt_thread) ? 1 : 0;
+    if (m.use_kkt) {
+        HIP_TRY(h, h->kkt_code.ensure(nn, st));
+        HIP_TRY(h, h->kkt_L.ensure(nn * (size_t)k * (h->n_t + 1) * sizeof(double), st));
+        m.kkt_code = h->kkt_code.as<uint8_t>(); m.kkt_L = h->kkt_L.as<double>();
+    }
+    // region stage: one slot per optimal candidate, buffers sized by the bound
+    auto part_list = [&](int c) -> int32_t * { return h->part_lists.as<int32_t>() + (size_t)c * nn; };
+    h->opt_ptr = part_list(2);
+    {
+        const int rows_t_ = h->n_c - h->n_eq + h->n_tc;
+        HIP_TRY(h, h->headd.ensure(nn * h->fd * sizeof(double), st));
+        HIP_TRY(h, h->headi.ensure(nn * h->fi * sizeof(int32_t), st));
+        HIP_TRY(h, h->epool.ensure(nn * rows_t_ * (h->n_t + 1) * sizeof(double), st));
+        const int ldk = (rows_t_ + 1 + 63) & ~63;
+        HIP_TRY(h, h->kept_g.ensure(nn * ldk, st));
+        HIP_TRY(h, h->done_g.ensure(nn * 2 * sizeof(unsigned int), st));
+        m.zero[m.n_zero++] = {h->done_g.p, nn * 2 * sizeof(unsigned int)};
+        m.rs.n_opt_dev = m.dcnt + 18;   // the region launch comes last in the batch form: all optimal candidates, class 2 of the partition at [16..19]
+        m.rs.w_cap = h->grid_r2; m.rs.w_max = h->rsplit_max;
+        m.W = h->no_rsplit ? 1 : 0;
+        m.ldk = ldk; m.fd = h->fd; m.fi = h->fi; m.no_rbox = h->no_rbox ? 1 : 0;
+        m.headd = h->headd.as<double>(); m.headi = h->headi.as<int32_t>(); m.epool = h->epool.as<double>();
+        m.kept_g = h->kept_g.as<uint8_t>(); m.done_g = h->done_g.as<unsigned int>();
+        h->used_region2 = true;
+        // retry slots of the LDS-engine region kernel (launch_region_v1's buffers)
+        m.rcap = (int)std::min<long long>(n, 256);
+        HIP_TRY(h, h->recd.ensure((size_t)m.rcap * h->rec_d * sizeof(double), st));
+        HIP_TRY(h, h->reci.ensure((size_t)m.rcap * h->rec_i * sizeof(int32_t), st));
+        HIP_TRY(h, h->facet_flags.ensure((size_t)m.rcap * rows_t_, st));
+        m.recd = h->recd.as<double>(); m.reci = h->reci.as<int32_t>(); m.facet_flags = h->facet_flags.as<uint8_t>();
+        m.rec_d = h->rec_d; m.rec_i = h->rec_i; m.Pr = h->Pr; m.lds_r = h->lds_r;
+    }
+    // (x,theta) stage with the dictionary cache
+    const int nxc = h->fast_x >= 2 ? 32 : 16;
+    m.nxc = nxc;
+    h->dict_stride_d = (long long)nxc * h->Pf.n_d0r;
+    h->dict_stride_i = 2LL * h->Pf.n_d0r + nxc + 4;
+    DictCache dc{};
+    dc.stride_d = h->dict_stride_d; dc.stride_i = h->dict_stride_i;
+    if (h->have_prev_dict && h->have_parent_slot) {
+        dc.parent_slot = h->parent_slot.as<int32_t>();
+        dc.prev_d = h->dict_d[1 - h->dict_cur].as<double>();
+        dc.prev_i = h->dict_i[1 - h->dict_cur].as<int32_t>();
+    }
+    h->storing = false;
+    const double need_gb = (double)nn * (h->dict_stride_d * 8.0 + h->dict_stride_i * 4.0) / 1e9;
+    if (gen_children && need_gb <= h->dict_budget_gb) {
+        HIP_TRY(h, h->dict_d[h->dict_cur].ensure(nn * h->dict_stride_d * sizeof(double), st));
+        HIP_TRY(h, h->dict_i[h->dict_cur].ensure(nn * h->dict_stride_i * sizeof(int32_t), st));
+        HIP_TRY(h, h->dict_stored[h->dict_cur].ensure(nn, st));
+        m.zero[m.n_zero++] = {h->dict_stored[h->dict_cur].p, nn};
+        dc.cur_d = h->dict_d[h->dict_cur].as<double>(); dc.cur_i = h->dict_i[h->dict_cur].as<int32_t>();
+        dc.stored = h->dict_stored[h->dict_cur].as<uint8_t>();
+        h->storing = true;
+        dc.pre1 = part_list(1); dc.n_pre1_dev = m.dcnt + 5;
+        dc.pre2 = part_list(2); dc.n_pre2_dev = m.dcnt + 6;
+    }
+    dc.chunk = 1;
+    m.dc = dc;
+    m.storing = h->storing ? 1 : 0;
+    m.dict_stored_cur = h->storing ? h->dict_stored[h->dict_cur].as<uint8_t>() : nullptr;
+    m.quick_test = (!h->storing && dc.parent_slot && !h->no_xquick) ? 1 : 0;
+    // pruned masks + children
+    m.keep_lowdim = (flags & MPC_LEVEL_KEEP_LOWDIM) ? 1 : 0;
+    m.pruned = h->pruned.as<unsigned long long>(); m.n_pruned = h->n_pruned;
+    if (gen_children) {
+        HIP_TRY(h, h->childmask.ensure(nn * h->mw * sizeof(uint64_t), st));
+        HIP_TRY(h, h->count.ensure(nn * sizeof(int32_t), st));
+        HIP_TRY(h, h->offset.ensure(nn * sizeof(int32_t), st));
+        const size_t child_bound = nn * (size_t)std::max(h->n_c - k, 1);
+        HIP_TRY(h, h->children.ensure(child_bound * (k + 1) * sizeof(int32_t), st));
+        HIP_TRY(h, h->parent_slot_next.ensure(child_bound * sizeof(int32_t), st));
+        m.childmask = h->childmask.as<unsigned long long>(); m.count = h->count.as<int32_t>(); m.offset = h->offset.as<int32_t>();
+        m.children = h->children.as<int32_t>(); m.parent_slot_next = h->parent_slot_next.as<int32_t>();
+    }
+    m.pub_ctr = reinterpret_cast<unsigned int *>(h->tot_dev + 16);
+    m.pub_cnt = reinterpret_cast<unsigned int *>(h->tot_dev + 16 + (int)(sizeof(LevelCounters) / 4));
+    // pruned.ensure(..., keep) may have moved the list: the frontier and everything else above is read after this point only
+    HIP_TRY(h, hipStreamSynchronize(st));   // whatever the member's own stream still had queued (frontier kernels, copies of a grown buffer)
+    return MPC_OK;
+}
+
+static int batch_finish(mpc_handle *h, int32_t gen_children, const BatchMember &m, float ms_total, mpc_level_stats *stats, bool *fallback) {
+    *fallback = false;
+    const long long n = h->n;
+    LevelCounters host_ctr;
+    std::memcpy(&host_ctr, h->tot_host + 16, sizeof(LevelCounters));
+    const int32_t *cnt_host = h->tot_host + 16 + (int)(sizeof(LevelCounters) / 4);
+    h->n_smallpath++;
+    if (cnt_host[28] > m.rcap || h->test_small_fallback) {
+        // more candidates k_region2 gave up on than retry slots were reserved (never observed): the member repeats the level alone
+        h->n_smallpath_fallback++;
+        *fallback = true;
+        return MPC_OK;
+    }
+    h->n_opt = cnt_host[18];
+    h->n_rretry = cnt_host[28];      // their records are in the fixed layout (recd / reci), listed in retry_list
+    h->n_children = gen_children ? cnt_host[20] : 0;
+    h->n_needx = cnt_host[7];
+    h->n_pruned_new = host_ctr.n_pruned_new;
+    h->n_erows = host_ctr.e_rows;
+    h->n_regions = (long long)host_ctr.status[ST_REGION];
+    h->level_done = true;
+    h->last_level_n = n;
+    stream_ready(h);
+    if (stats) {
+        std::memset(stats, 0, sizeof(*stats));
+        stats->n = n; stats->k = h->k; stats->kkt_mode = h->kkt_mode;
+        for (int i = 0; i < 6; ++i) stats->n_status[i] = (int64_t)host_ctr.status[i];
+        stats->n_regions = h->n_regions; stats->n_children = h->n_children; stats->n_pruned_new = h->n_pruned_new;
+        stats->lp_pivots = (int64_t)host_ctr.pivots;
+        stats->n_xtheta_lp = h->n_needx;
+        stats->n_xtheta_fallback = (int64_t)host_ctr.xtheta_fallbacks;
+        for (int i = 0; i < 4; ++i) stats->wave_cycles[i] = (int64_t)host_ctr.cycles[i];
+        stats->n_x_cached = (int64_t)host_ctr.x_cached;
+        stats->n_region_rows = h->n_erows;
+        stats->n_opt = h->n_opt;
+        stats->n_theta_items = m.use_kkt ? cnt_host[0] : n;
+        stats->n_region_retry = h->n_rretry;
+        if (h->n_opt > 0 && host_ctr.r2_t1 > ~host_ctr.r2_not_t0 && h->wall_khz > 0)
+            stats->ms_region2 = (float)((double)(host_ctr.r2_t1 - ~host_ctr.r2_not_t0) / (double)h->wall_khz);
+        stats->n_xq_items = m.quick_test ? cnt_host[7] : 0; stats->xq_pivots = (int64_t)host_ctr.xq_pivots;
+        stats->n_x_items = (m.quick_test ? cnt_host[8] : cnt_host[7]) + (h->storing ? (long long)cnt_host[5] + cnt_host[6] : 0);
+        stats->xq_record_ints = h->dict_stride_i; stats->xq_record_rows = h->Pf.n_d0r; stats->xq_record_cols = h->Pf.n_d0c + 1;
+        const long long rec_bytes = (long long)(h->Pf.n_d0c + 1) * h->Pf.n_d0r * 8 + h->dict_stride_i * 4;
+        stats->dict_read_bytes = (h->have_prev_dict && h->have_parent_slot) ? rec_bytes : 0;
+        stats->dict_write_bytes = h->storing ? rec_bytes : 0;
+        stats->ms_total = ms_total;   // the batch's launches, first to last (shared by all members)
+    }
+    return MPC_OK;
+}
+
+static int level_run_impl(mpc_handle *h, int32_t gen_children, int32_t flags, mpc_level_stats *stats);
+
+struct BatchToken {
+    std::vector<mpc_handle *> hs;
+    std::vector<int32_t> gen;
+    int32_t flags = 0;
+    std::vector<BatchMember> members;
+    std::vector<int> alone;      // members outside the shared launches: run one after the other by mpc_level_run's own paths
+    hipStream_t st = nullptr;
+};
+
+int mpc_level_batch_start(mpc_handle **hs, int32_t n_handles, const int32_t *gen_children, int32_t flags, void **token) {
+    if (!hs || n_handles <= 0 || !gen_children || !token) return MPC_ERR_INVALID;
+    *token = nullptr;
+    mpc_handle *h0 = hs[0];
+    if (!h0) return MPC_ERR_INVALID;
+    for (int i = 0; i < n_handles; ++i) {
+        mpc_handle *h = hs[i];
+        if (!h) return MPC_ERR_INVALID;
+        if (h->device != h0->device) return fail(h, MPC_ERR_INVALID, "mpc_level_run_batch: the members must live on one device");
+        if (flags & MPC_LEVEL_GRAPH) return fail(h, MPC_ERR_INVALID, "mpc_level_run_batch: MPC_LEVEL_GRAPH is not a batch level");
+        { std::lock_guard<std::mutex> lk(h->wm); if (h->w_busy) return fail(h, MPC_ERR_STATE, "a level started with mpc_level_start is still running"); }
+        { std::lock_guard<std::mutex> lk(h->wm); h->w_stream_ready = false; h->a_ready.store(0, std::memory_order_release); }
+    }
+    {
+        std::vector<mpc_handle *> sorted(hs, hs + n_handles);
+        std::sort(sorted.begin(), sorted.end());
+        if (std::adjacent_find(sorted.begin(), sorted.end()) != sorted.end()) return fail(h0, MPC_ERR_INVALID, "mpc_level_run_batch: a handle appears twice");
+    }
+    HIP_TRY(h0, hipSetDevice(h0->device));
+    std::unique_ptr<BatchToken> t(new BatchToken());
+    t->hs.assign(hs, hs + n_handles);
+    t->gen.assign(gen_children, gen_children + n_handles);
+    t->flags = flags & ~(MPC_LEVEL_THEN_BASE | MPC_LEVEL_ONLY_BASE | MPC_LEVEL_STREAM);
+    t->members.reserve(n_handles);
+    for (int i = 0; i < n_handles; ++i) {
+        mpc_handle *h = hs[i];
+        stream_release(h);
+        // MPC_SMALLPATH_MAX bounds the single-program path only (above it the overlapped classic path is faster for ONE program)
+        const long long keep_max = h->smallpath_max;
+        h->smallpath_max = std::max<long long>(keep_max, 1LL << 40);
+        const bool ok = small_path_ok(h, h->n, h->k, t->flags, gen_children[i]);
+        h->smallpath_max = keep_max;
+        if (!ok) { t->alone.push_back(i); HIP_TRY(h, hipStreamSynchronize(h->stream)); continue; }   // (copies of the last level's records: complete when this call returns, as for the members)
+        BatchMember m;
+        const int rc = batch_prepare(h, gen_children[i], t->flags, m);
+        if (rc != MPC_OK) return rc;
+        m.id = i;
+        t->members.push_back(m);
+    }
+    if (!t->members.empty()) {
+        mpc_handle *hl = hs[t->members[0].id];     // ids are the caller's positions (batch_level_launch reorders the members)
+        t->st = hl->stream;
+        const int lead = t->members[0].id;
+        HIP_TRY(hl, hipEventRecord(hl->ev[0], t->st));
+        hipError_t e = batch_level_launch(t->members.data(), (int)t->members.size(), t->st);
+        if (e != hipSuccess) return fail(hl, MPC_ERR_HIP, std::string("batch level launch: ") + hipGetErrorString(e));
+        HIP_TRY(hl, hipEventRecord(hl->ev[3], t->st));
+        t->alone.insert(t->alone.begin(), -1 - lead);      // first entry < 0: the member whose events bracket the launches
+    }
+    *token = t.release();
+    return MPC_OK;
+}
+
+int mpc_level_batch_wait(void *token, mpc_level_stats *stats, int32_t *n_batched) {
+    if (!token) return MPC_ERR_INVALID;
+    std::unique_ptr<BatchToken> t(static_cast<BatchToken *>(token));
+    if (n_batched) *n_batched = 0;
+    if (!t->members.empty()) {
+        const int lead = -1 - t->alone.front();
+        t->alone.erase(t->alone.begin());
+        mpc_handle *hl = t->hs[lead];
+        HIP_TRY(hl, hipSetDevice(hl->device));
+        HIP_TRY(hl, hipStreamSynchronize(t->st));   // the level's only synchronisation, for all members
+        float ms = 0;
+        HIP_TRY(hl, hipEventElapsedTime(&ms, hl->ev[0], hl->ev[3]));
+        for (const BatchMember &m : t->members) {
+            bool fallback = false;
+            const int rc = batch_finish(t->hs[m.id], t->gen[m.id], m, ms, stats ? stats + m.id : nullptr, &fallback);
+            if (rc != MPC_OK) return rc;
+            if (fallback) t->alone.push_back(m.id);
+            else if (n_batched) ++*n_batched;
+        }
+    }
+    for (int i : t->alone) {
+        mpc_handle *h = t->hs[i];
+        h->skip_small = true;
+        const int rc = level_run_impl(h, t->gen[i], t->flags, stats ? stats + i : nullptr);
+        h->skip_small = false;
+        if (rc != MPC_OK) return rc;
+    }
+    return MPC_OK;
+}
+
+int mpc_level_run_batch(mpc_handle **hs, int32_t n_handles, const int32_t *gen_children, int32_t flags, mpc_level_stats *stats, int32_t *n_batched) {
+    void *token = nullptr;
+    const int rc = mpc_level_batch_start(hs, n_handles, gen_children, flags, &token);
+    if (rc != MPC_OK) return rc;
+    return mpc_level_batch_wait(token, stats, n_batched);
+}
+
 static int level_run_impl(mpc_handle *h, int32_t gen_children, int32_t flags, mpc_level_stats *stats) {
     if (!h) return MPC_ERR_INVALID;
     HIP_TRY(h, hipSetDevice(h->device));
     stream_release(h);
-    if (small_path_ok(h, h->n, h->k, flags, gen_children)) {
+    if (!h->skip_small && small_path_ok(h, h->n, h->k, flags, gen_children)) {
         bool fallback = false;
         const int rcs = level_run_small(h, gen_children, flags, stats, &fallback);
         if (rcs != MPC_OK || !fallback) return rcs;
@@ -2299,7 +2579,7 @@ static int level_regions_slots_impl(mpc_handle *h, double *head_d, int32_t *head
         HIP_TRY(h, hipEventRecord(h->ev_hi, s));
         HIP_TRY(h, hipMemcpyAsync(head_d, h->headd.p, (size_t)n_opt * fd * sizeof(double), hipMemcpyDeviceToHost, s));
         if (h->n_erows > 0) HIP_TRY(h, hipMemcpyAsync(erows, h->epool.p, (size_t)h->n_erows * nr * sizeof(double), hipMemcpyDeviceToHost, s));
-        HIP_TRY(h, hipEventSynchronize(h->ev_hi));
+        if (!h->fetch_nowait) HIP_TRY(h, hipEventSynchronize(h->ev_hi));
         if (n_slots) *n_slots = n_opt;
         if (n_rows) *n_rows = h->n_erows;
         return MPC_OK;
@@ -2378,6 +2658,14 @@ int mpc_level_regions_slots(mpc_handle *h, double *head_d, int32_t *head_i, int6
 int mpc_level_regions_slots_async(mpc_handle *h, double *head_d, int32_t *head_i, int64_t cap_slots, double *erows, int64_t cap_rows,
                                   int64_t *n_slots, int64_t *n_rows) {
     return level_regions_slots_impl(h, head_d, head_i, cap_slots, erows, cap_rows, n_slots, n_rows, true);
+}
+int mpc_level_regions_slots_nowait(mpc_handle *h, double *head_d, int32_t *head_i, int64_t cap_slots, double *erows, int64_t cap_rows,
+                                   int64_t *n_slots, int64_t *n_rows) {
+    if (!h) return MPC_ERR_INVALID;
+    h->fetch_nowait = true;
+    const int rc = level_regions_slots_impl(h, head_d, head_i, cap_slots, erows, cap_rows, n_slots, n_rows, true);
+    h->fetch_nowait = false;
+    return rc;
 }
 int mpc_level_stream_fixup(mpc_handle *h, double *head_d, int32_t *head_i, double *erows, int64_t *n_rows) {
     if (!h || !head_d || !head_i || !erows) return MPC_ERR_INVALID;
@@ -2765,7 +3053,7 @@ extern "C" int mpc_facet_centres(int32_t device, int32_t n_t, int64_t n_regions,
     if (rows == 0) return MPC_OK;
     if (!ef_rows) return fail(nullptr, MPC_ERR_INVALID, "bad argument");
     int ndev = 0;
-    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return fail(nullptr, MPC_ERR_HIP, "no HIP device available (libmpcombi_hip has no CPU fallback)");
+    if ((ndev = device_count_cached()) < 1) return fail(nullptr, MPC_ERR_HIP, "no HIP device available (libmpcombi_hip has no CPU fallback)");
     if (device < 0 || device >= ndev) return fail(nullptr, MPC_ERR_INVALID, "device index out of range");
     HIP_TRY(nullptr, hipSetDevice(device));
     int m_max = 0;
@@ -2812,7 +3100,7 @@ static int lp_batch_impl(int32_t device, int64_t n_lp, int32_t m, int32_t n, con
     if (n_lp < 0 || m < 1 || n < 1 || !A || !b || !eq || !status) return fail(nullptr, MPC_ERR_INVALID, "bad argument");
     if (n_lp == 0) return MPC_OK;
     int ndev = 0;
-    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return fail(nullptr, MPC_ERR_HIP, "no HIP device available (libmpcombi_hip has no CPU fallback)");
+    if ((ndev = device_count_cached()) < 1) return fail(nullptr, MPC_ERR_HIP, "no HIP device available (libmpcombi_hip has no CPU fallback)");
     if (device < 0 || device >= ndev) return fail(nullptr, MPC_ERR_INVALID, "device index out of range");
     HIP_TRY(nullptr, hipSetDevice(device));
     const int ld = odd_at_least(n + 3);

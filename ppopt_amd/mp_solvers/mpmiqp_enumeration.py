@@ -6,18 +6,26 @@
      by the MI355X combinatorial path (`solve_mpqp`);
   3. regions tagged with their fixation and concatenated, in fixation order.
 
+With a combinatorial ``cont_algorithm`` (the default) the sub-programs are solved TOGETHER, level by level, every stage of a
+level being one launch for all of them (``mpqp_hip_combinatorial.solve_many`` -> mpc_level_run_batch, "several programs per
+launch"); the regions are those of the one-by-one solves, bit for bit.  ``MPC_NO_BATCH=1`` keeps the one-by-one form below.
+
 ``num_cores`` keeps its meaning of "sub-problems in flight": the reference maps them over a process pool
 (mpmiqp_enumeration.py:46-50); here each in-flight sub-problem is a host thread driving its own device handle and
 HIP streams (the C ABI releases the GIL, handles are independent, pools are locked), so the small kernels of
 different sub-problems overlap on the GPU and one sub-problem's host bookkeeping hides behind another's kernels.
 ``num_cores=1`` runs them one after the other; -1 picks min(8, host cores).
 """
+import os
 import warnings
 from concurrent.futures import ThreadPoolExecutor
 
 from ..solution import Solution
 from ..utils.general_utils import num_cpu_cores
-from .solve_mpqp import mpqp_algorithm, solve_mpqp
+from . import mpqp_hip_combinatorial
+from .solve_mpqp import _COMBINATORIAL, mpqp_algorithm, solve_mpqp
+
+BATCH_CHUNKS = int(os.environ.get('MPC_BATCH_CHUNKS', '4'))   # chunks of fixations solved together (see below)
 
 
 def solve_mpmiqp_enumeration(program, num_cores: int = -1,
@@ -35,7 +43,41 @@ def solve_mpmiqp_enumeration(program, num_cores: int = -1,
             finally:
                 sub.release_engine()       # the handle's device blocks go straight to the next sub-problem
 
-    if num_cores <= 1 or len(feasible_combinations) <= 1:
+    batched = cont_algorithm in _COMBINATORIAL and len(feasible_combinations) > 1 and os.environ.get('MPC_NO_BATCH', '0') != '1'
+    if batched:
+        device = int(getattr(getattr(program, 'solver', None), 'device', 0) or 0)
+        prune_lowdim = cont_algorithm is mpqp_algorithm.combinatorial_parallel
+
+        def substitute(fixes):
+            out = []
+            with warnings.catch_warnings():
+                warnings.simplefilter('ignore')
+                for fix in fixes:
+                    sub = program.generate_substituted_problem(fix)
+                    sub.engine(device)         # presolve (device LP batches) and set-up (MFMA set-up kernel) of the sub-program
+                    out.append(sub)
+            return out
+
+        # The fixations are solved in a few chunks: while the device works on the levels of one chunk (the host waits inside the C ABI,
+        # GIL released) a second thread substitutes, presolves and sets up the sub-programs of the next one.
+        n_fix = len(feasible_combinations)
+        chunk = n_fix if num_cores <= 1 else max(8, -(-n_fix // BATCH_CHUNKS))
+        chunks = [feasible_combinations[i:i + chunk] for i in range(0, n_fix, chunk)]
+        sols = []
+        with ThreadPoolExecutor(max_workers=1) as pool:
+            pending = pool.submit(substitute, chunks[0])
+            for j in range(len(chunks)):
+                subs = pending.result()
+                if j + 1 < len(chunks):
+                    pending = pool.submit(substitute, chunks[j + 1])
+                try:
+                    sols.extend(mpqp_hip_combinatorial.solve_many(subs, device=device, prune_lowdim=prune_lowdim))
+                finally:
+                    for sub in subs:
+                        sub.release_engine()
+        for sol in sols:                       # what solve_mpqp sets for one program (solve_mpqp.py: every MPLP_Program instance)
+            sol.is_overlapping = True
+    elif num_cores <= 1 or len(feasible_combinations) <= 1:
         sols = [solve_fixation(fix) for fix in feasible_combinations]
     else:
         with ThreadPoolExecutor(max_workers=num_cores) as pool:
@@ -43,7 +85,11 @@ def solve_mpmiqp_enumeration(program, num_cores: int = -1,
 
     collected = []
     for fix, sol in zip(feasible_combinations, sols):
-        for region in sol.critical_regions:
+        batches = getattr(sol, 'region_batches', None)
+        if batches is not None:                # lazy regions: the three fields are read from their batch (region_batch.py)
+            for batch in batches:
+                batch.y_fixation, batch.y_indices, batch.x_indices = fix, program.binary_indices, program.cont_indices
+        for region in (sol.critical_regions if batches is None else sol.loose_regions):
             region.y_fixation = fix
             region.y_indices = program.binary_indices
             region.x_indices = program.cont_indices

@@ -206,3 +206,85 @@ def _solve(program, num_cores: int = -1, device: int = 0, profile: Optional[List
         solution.add_region(unpack_region(rd[0], ri[0], n_x, n_t, n_c, n_tc))
     solution.is_complete = collect_regions and max_levels is None      # every cardinality up to max(n_x, n_theta) was enumerated
     return solution
+
+
+def solve_many(programs, device: int = 0, max_levels: Optional[int] = None, prune_lowdim: bool = True,
+               profile: Optional[List[Dict]] = None) -> List[Solution]:
+    """Solves SEVERAL programs together, level by level: every stage of a level is one launch for all programs that still have a
+    frontier (``Engine.level_run_batch`` -> mpc_level_run_batch, include/mpcombi.h; SURVEY.md 8(f)2, reference caller
+    mp_solvers/mpmiqp_enumeration.py:41-50, which maps solve_mpqp over the sub-programs).  Each program's result is the one
+    ``solve`` gives for it alone -- the same kernels' bodies on the same lists: the same regions in the same order, bit for bit.
+    ``profile``: receives one dict per level (members, members that shared the launches, candidates, regions, wall time)."""
+    from .._lib import Engine, MpcCapacityError
+    programs = list(programs)
+    if not programs:
+        return []
+    engs = [p.engine(device) for p in programs]
+    if len(set(id(e) for e in engs)) != len(engs):
+        raise ValueError('solve_many: the programs must be distinct objects (one device handle each)')
+    sols = [Solution(p, []) for p in programs]
+    for sol in sols:
+        sol.region_batches, sol.loose_regions = [], []      # the RegionBatch objects behind the lazy regions / regions that are plain objects
+    depth_max = []
+    for e in engs:
+        d = max(e.n_x, e.n_t) - e.n_eq
+        depth_max.append(d if max_levels is None else min(d, max_levels))
+        e.pruned_clear()
+        e.frontier_root()
+    try:
+        active = [i for i in range(len(engs)) if depth_max[i] > 0]
+        depth = 0
+        gens = [depth + 1 != depth_max[i] for i in active]
+        token = Engine.level_batch_start([engs[i] for i in active], gens, keep_lowdim=not prune_lowdim) if active else None
+        while active:
+            t0 = time.perf_counter()
+            stats, n_shared = Engine.level_batch_wait(token)
+            t_wait = time.perf_counter() - t0
+            # the region records of this level: copies queued on each member's stream, nobody waits ...
+            fetched = [(i, engs[i].level_regions_slots_nowait()) for i, st in zip(active, stats) if st.n_regions]
+            nxt = [i for i, st, gen in zip(active, stats, gens) if gen and st.n_children]
+            for i in nxt:
+                engs[i].frontier_advance()
+            # ... the next level is started for all members that still have a frontier (its preparation completes the copies) ...
+            gens_next = [depth + 2 != depth_max[i] for i in nxt]
+            if nxt:
+                token = Engine.level_batch_start([engs[i] for i in nxt], gens_next, keep_lowdim=not prune_lowdim)
+            still = set(nxt)
+            for i, _ in fetched:
+                if i not in still:
+                    engs[i].sync()      # a member that has just finished: nothing else completes its copies
+            # ... and the region objects of the finished level are built while the device works on it
+            for i, (hd, hi, er, kk) in fetched:
+                eng = engs[i]
+                slots = numpy.flatnonzero(hi[:, 0] == REGION_STATUS)
+                batch = RegionBatch(hd, hi, er, eng.n_x, eng.n_t, eng.n_c, eng.n_tc, kk, slots)
+                sols[i].region_batches.append(batch)
+                sols[i].critical_regions.extend(batch.regions())
+            if profile is not None:
+                profile.append({'depth': depth + 1, 'members': len(active), 'shared_launches': n_shared,
+                                'candidates': int(sum(int(st.n) for st in stats)), 'regions': int(sum(int(st.n_regions) for st in stats)),
+                                'ms_launches': float(stats[0].ms_total) if stats else 0.0, 'ms_wait': t_wait * 1e3, 'ms_wall': (time.perf_counter() - t0) * 1e3})
+            active, gens = nxt, gens_next
+            depth += 1
+        for e in engs:
+            e.sync()
+        # the base active set of every program (driver :142-146), as one more shared level of one candidate each
+        t0 = time.perf_counter()
+        for e in engs:
+            e.frontier_set(numpy.arange(e.n_eq, dtype=numpy.int32).reshape(1, -1))
+            e.pruned_clear()
+        stats, n_shared = Engine.level_run_batch(engs, [False] * len(engs), keep_lowdim=not prune_lowdim)
+        for i, (e, st) in enumerate(zip(engs, stats)):
+            if st.n_regions:
+                rd, ri, _ = e.level_regions()
+                sols[i].add_region(unpack_region(rd[0], ri[0], e.n_x, e.n_t, e.n_c, e.n_tc))
+                sols[i].loose_regions.append(sols[i].critical_regions[-1])
+        if profile is not None:
+            profile.append({'depth': 0, 'members': len(engs), 'shared_launches': n_shared, 'candidates': len(engs),
+                            'regions': int(sum(int(st.n_regions) for st in stats)), 'ms_wall': (time.perf_counter() - t0) * 1e3})
+    except MpcCapacityError:
+        # a member that fell back to the overlapped single-program path ran out of reserved record slots (never observed): one by one
+        return [solve(p, device=device, max_levels=max_levels, prune_lowdim=prune_lowdim) for p in programs]
+    for sol in sols:
+        sol.is_complete = max_levels is None
+    return sols

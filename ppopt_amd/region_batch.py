@@ -27,6 +27,8 @@ class RegionBatch:
         self.ila = self.iom + n_tc
         self.iri = self.ila + k
         self.irc = self.iri + (n_c - k)
+        # set by the mixed-integer enumeration for all regions of the batch at once (CriticalRegion.y_fixation / y_indices / x_indices)
+        self.y_fixation = self.y_indices = self.x_indices = None
 
     def __len__(self):
         return len(self.slots)
@@ -118,6 +120,18 @@ class BatchCriticalRegion(CriticalRegion):
     def regular_set(self):
         B, h = self._batch, self._hdr()
         return [B.hi[self._j, B.iri:B.iri + h[5]].tolist(), B.hi[self._j, B.irc:B.irc + h[5]].tolist()]
+
+    @_Lazy
+    def y_fixation(self):
+        return self._batch.y_fixation
+
+    @_Lazy
+    def y_indices(self):
+        return self._batch.y_indices
+
+    @_Lazy
+    def x_indices(self):
+        return self._batch.x_indices
 
     def materialize(self) -> 'BatchCriticalRegion':
         """Touches every field (so that nothing refers to the batch lazily any more)."""
