@@ -414,17 +414,41 @@ def main():
             warnings.simplefilter('ignore')
             pmi = MPMIQP_Program(dmi['A'], dmi['b'], dmi['c'], dmi['H'], dmi['Q'], dmi['A_t'], dmi['b_t'], dmi['F'],
                                  dmi['binary_indices'])
-            solve_mpmiqp(pmi)
-            best, n_reg = float('inf'), 0
-            for _ in range(3):
-                tq = time.perf_counter()
-                smi = solve_mpmiqp(pmi)
-                best = min(best, time.perf_counter() - tq)
-                n_reg = len(smi)
+            from ppopt_amd.mp_solvers import mpqp_hip_combinatorial
+
+            def timed(n_rep):
+                solve_mpmiqp(pmi)
+                best_, n_ = float('inf'), 0
+                for _ in range(n_rep):
+                    tq = time.perf_counter()
+                    smi = solve_mpmiqp(pmi)
+                    best_ = min(best_, time.perf_counter() - tq)
+                    n_ = len(smi)
+                return best_, n_
+            best, n_reg = timed(3)          # default: the sub-programs share every launch of a level (mpc_level_run_batch)
+            os.environ['MPC_NO_BATCH'] = '1'
+            try:
+                best_1, n_reg_1 = timed(2)  # one handle per fixation, eight host threads (round 2's form)
+            finally:
+                del os.environ['MPC_NO_BATCH']
+            # the device's share of the batched form: the launches of each shared level, first to last (events)
+            subs = [pmi.generate_substituted_problem(f) for f in pmi.feasible_combinations()]
+            prof_mi = []
+            mpqp_hip_combinatorial.solve_many(subs, device=local_rank, profile=prof_mi)
+            for sub in subs:
+                sub.release_engine()
         n_fix = len(pmi.feasible_combinations())
         out['mi_enumeration'] = {'workload': 'generate_mpmiqp_data(8,4,16,n_bin=6,seed=1)', 'fixations': n_fix,
                                  'regions': n_reg, 'ms': 1e3 * best, 'sub_programs_per_s': n_fix / best,
-                                 'regions_per_s': n_reg / best}
+                                 'regions_per_s': n_reg / best,
+                                 'form': 'several programs per launch (mpc_level_run_batch): every stage of a level is one launch for all sub-programs',
+                                 'candidates': int(sum(p['candidates'] for p in prof_mi)),
+                                 'device_ms_shared_levels': float(sum(p.get('ms_launches', 0.0) for p in prof_mi)),
+                                 'shared_levels': [{'depth': p['depth'], 'members': p['members'], 'members_in_shared_launches': p['shared_launches'],
+                                                    'candidates': p['candidates'], 'regions': p['regions'], 'ms_launches': p.get('ms_launches', 0.0)}
+                                                   for p in prof_mi],
+                                 'one_by_one': {'form': 'MPC_NO_BATCH=1: one handle per fixation, eight host threads', 'ms': 1e3 * best_1,
+                                                'regions': n_reg_1, 'sub_programs_per_s': n_fix / best_1}}
     if rank == 0 and not distributed and args.complete > 0 and args.workload in ('c4', 'c3', 'c2', 'c2x20'):
         # The COMPLETE explicit solution of the same program by the connected-graph traversal (mpqp_algorithm.graph, reference
         # mp_solvers/mpqp_graph.py) on the same kernels, wave / visited set / neighbours resident on the device.  Not part of `value`.

@@ -61,6 +61,26 @@ class LevelStats(ctypes.Structure):
 _lib = None
 
 
+def _share_the_hip_runtime_with_torch():
+    """PyTorch-ROCm wheels carry their own libamdhip64.so.  Two HIP runtimes in one process cannot both open the GPU: when this
+    library (linked against /opt/rocm's runtime) is loaded BEFORE torch, a later ``torch.cuda`` call fails with "No HIP GPUs are
+    available".  If torch is installed but not imported yet, its runtime is loaded here first, globally, so that this library and
+    torch bind to the same one -- the state a process is in anyway when torch was imported first.  ``MPC_NO_TORCH_HIP=1`` skips it."""
+    import sys
+    if 'torch' in sys.modules or os.environ.get('MPC_NO_TORCH_HIP', '0') == '1':
+        return
+    try:
+        import importlib.util
+        spec = importlib.util.find_spec('torch')
+        if spec is None or not spec.origin:
+            return
+        path = os.path.join(os.path.dirname(spec.origin), 'lib', 'libamdhip64.so')
+        if os.path.exists(path):
+            ctypes.CDLL(path, mode=ctypes.RTLD_GLOBAL)
+    except Exception:       # no torch, or an unusual layout: the library's own runtime is used
+        pass
+
+
 def load():
     """Loads the HIP library; raises MpcError (never falls back) when it is absent."""
     global _lib
@@ -69,6 +89,7 @@ def load():
     if not os.path.exists(LIB_PATH):
         raise MpcError(f'{LIB_PATH} is missing: build it with `python -c "import __graft_entry__ as g; g.build()"` '
                        f'(hipcc --offload-arch=gfx950). ppopt_amd has no CPU fallback.')
+    _share_the_hip_runtime_with_torch()
     L = ctypes.CDLL(LIB_PATH)
     H = ctypes.c_void_p
     sig = {

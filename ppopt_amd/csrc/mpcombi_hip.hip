@@ -1615,6 +1615,19 @@ static int batch_finish(mpc_handle *h, int32_t gen_children, const BatchMember &
 
 static int level_run_impl(mpc_handle *h, int32_t gen_children, int32_t flags, mpc_level_stats *stats);
 
+// device memory one member's level holds on the no-round-trip path (the buffers are sized by the bound n): region records, children,
+// two generations of the dictionary cache
+static double batch_level_gb(const mpc_handle *h, int32_t gen_children) {
+    const double n = (double)h->n;
+    const int k = h->k;
+    const double rows_t = h->n_c - h->n_eq + h->n_tc;
+    double bytes = n * ((double)(h->n_x * h->n_t + h->n_x + k * h->n_t + k) * 8.0 + (double)(8 + 2 * k + h->n_tc + 2 * (h->n_c - k)) * 4.0 + rows_t * (h->n_t + 1) * 8.0);
+    if (gen_children) bytes += n * std::max(h->n_c - k, 1) * (k + 2) * 4.0;
+    const double nxc = h->fast_x >= 2 ? 32 : 16;
+    bytes += 2.0 * n * (nxc * h->Pf.n_d0r * 8.0 + (2.0 * h->Pf.n_d0r + nxc + 4) * 4.0);
+    return bytes / 1e9;
+}
+
 struct BatchToken {
     std::vector<mpc_handle *> hs;
     std::vector<int32_t> gen;
@@ -1648,6 +1661,8 @@ int mpc_level_batch_start(mpc_handle **hs, int32_t n_handles, const int32_t *gen
     t->gen.assign(gen_children, gen_children + n_handles);
     t->flags = flags & ~(MPC_LEVEL_THEN_BASE | MPC_LEVEL_ONLY_BASE | MPC_LEVEL_STREAM);
     t->members.reserve(n_handles);
+    const double budget_gb = [] { const char *ev = std::getenv("MPC_BATCH_BUDGET_GB"); return ev ? std::atof(ev) : 160.0; }();
+    double used_gb = 0.0;
     for (int i = 0; i < n_handles; ++i) {
         mpc_handle *h = hs[i];
         stream_release(h);
@@ -1656,7 +1671,13 @@ int mpc_level_batch_start(mpc_handle **hs, int32_t n_handles, const int32_t *gen
         h->smallpath_max = std::max<long long>(keep_max, 1LL << 40);
         const bool ok = small_path_ok(h, h->n, h->k, t->flags, gen_children[i]);
         h->smallpath_max = keep_max;
-        if (!ok) { t->alone.push_back(i); HIP_TRY(h, hipStreamSynchronize(h->stream)); continue; }   // (copies of the last level's records: complete when this call returns, as for the members)
+        bool ok_i = ok;
+        if (ok_i) {
+            // MPC_BATCH_BUDGET_GB (default 160 of the 288 GB): members beyond it take their turn after the shared launches, one at a time
+            const double gb = batch_level_gb(h, gen_children[i]);
+            if (used_gb + gb > budget_gb && !t->members.empty()) ok_i = false; else used_gb += gb;
+        }
+        if (!ok_i) { t->alone.push_back(i); HIP_TRY(h, hipStreamSynchronize(h->stream)); continue; }   // (copies of the last level's records: complete when this call returns, as for the members)
         BatchMember m;
         const int rc = batch_prepare(h, gen_children[i], t->flags, m);
         if (rc != MPC_OK) return rc;

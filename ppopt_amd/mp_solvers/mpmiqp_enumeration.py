@@ -25,7 +25,7 @@ from ..utils.general_utils import num_cpu_cores
 from . import mpqp_hip_combinatorial
 from .solve_mpqp import _COMBINATORIAL, mpqp_algorithm, solve_mpqp
 
-BATCH_CHUNKS = int(os.environ.get('MPC_BATCH_CHUNKS', '4'))   # chunks of fixations solved together (see below)
+BATCH_CHUNKS = int(os.environ.get('MPC_BATCH_CHUNKS', '1'))   # chunks of fixations solved together (see below)
 
 
 def solve_mpmiqp_enumeration(program, num_cores: int = -1,
@@ -58,8 +58,10 @@ def solve_mpmiqp_enumeration(program, num_cores: int = -1,
                     out.append(sub)
             return out
 
-        # The fixations are solved in a few chunks: while the device works on the levels of one chunk (the host waits inside the C ABI,
-        # GIL released) a second thread substitutes, presolves and sets up the sub-programs of the next one.
+        # MPC_BATCH_CHUNKS > 1: the fixations are solved in chunks -- while the device works on the levels of one chunk (the host waits
+        # inside the C ABI, GIL released) a second thread substitutes, presolves and sets up the sub-programs of the next one.  Measured
+        # on the bench workload (64 fixations): 1 chunk 345 ms, 2 chunks 368, 4 chunks 350-435, 8 chunks 425-450 -- the host work of
+        # the two threads shares one interpreter lock and smaller batches fill the device less; default 1.
         n_fix = len(feasible_combinations)
         chunk = n_fix if num_cores <= 1 else max(8, -(-n_fix // BATCH_CHUNKS))
         chunks = [feasible_combinations[i:i + chunk] for i in range(0, n_fix, chunk)]

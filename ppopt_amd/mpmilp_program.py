@@ -110,17 +110,24 @@ class MPMILP_Program(MPLP_Program):
 
     # ---- substituted / relaxed continuous programs (mpmilp_program.py:145-185, 239-269) ---------------------------------------
     def _substituted_rows(self, fixed_combination):
-        A_cont = self.A[:, self.cont_indices]
-        A_bin = self.A[:, self.binary_indices]
         y = numpy.array(fixed_combination).reshape(-1, 1)
+        # which rows carry continuous or parametric content does not depend on the fixation: found once per program (the
+        # enumeration substitutes every feasible fixation), dropped whenever the rows change
+        key = (id(self.A), id(self.F), self.A.shape, tuple(self.equality_indices))
+        cache = getattr(self, '_subst_rows', None)
+        if cache is None or cache[0] != key:
+            A_cont = self.A[:, self.cont_indices]
 
-        def carries_continuous(i: int) -> bool:
-            return not (numpy.allclose(A_cont[i], 0 * A_cont[i]) and numpy.allclose(self.F[i], 0 * self.F[i]))
+            def carries_continuous(i: int) -> bool:
+                return not (numpy.allclose(A_cont[i], 0 * A_cont[i]) and numpy.allclose(self.F[i], 0 * self.F[i]))
 
-        eq = [i for i in self.equality_indices if carries_continuous(i)]
-        ineq = [i for i in range(self.num_constraints()) if i not in self.equality_indices and carries_continuous(i)]
-        kept = [*eq, *ineq]
-        return A_cont[kept], self.b[kept] - A_bin[kept] @ y, self.F[kept], list(range(len(eq))), y
+            eq = [i for i in self.equality_indices if carries_continuous(i)]
+            ineq = [i for i in range(self.num_constraints()) if i not in self.equality_indices and carries_continuous(i)]
+            kept = [*eq, *ineq]
+            cache = (key, A_cont[kept], self.A[:, self.binary_indices][kept], self.b[kept], self.F[kept], len(eq), (self.A, self.F))
+            self._subst_rows = cache
+        _, A_cont_k, A_bin_k, b_k, F_k, n_eq, _ = cache
+        return A_cont_k.copy(), b_k - A_bin_k @ y, F_k.copy(), list(range(n_eq)), y
 
     def generate_substituted_problem(self, fixed_combination: List[int]):
         """The continuous mpLP with the binaries fixed; rows without continuous or parametric content are dropped."""

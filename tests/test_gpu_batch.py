@@ -113,6 +113,25 @@ def test_batch_members_that_fall_back_are_run_alone(monkeypatch):
         e.close()
 
 
+def test_batch_memory_budget_runs_the_overflow_alone(monkeypatch):
+    """MPC_BATCH_BUDGET_GB: members whose level buffers would not fit the budget next to the others are run after the shared
+    launches, one at a time -- same results."""
+    from ppopt_amd import _lib
+    from test_gpu_parity import engine_from_golden
+    names = ['rand_6_3_12_s1', 'quadtank_n3', 'c2_dblint_n5', 'rand_5_3_8_s3']
+    goldens = [load_golden(n) for n in names]
+    alone = [_levels_alone(g, 2) for g in goldens]
+    monkeypatch.setenv('MPC_BATCH_BUDGET_GB', '1e-9')
+    engs = [engine_from_golden(g) for g in goldens]
+    for e in engs:
+        e.pruned_clear(); e.frontier_root()
+    stats, n_shared = _lib.Engine.level_run_batch(engs, [True] * len(engs))
+    assert n_shared == 1
+    for i, (e, st) in enumerate(zip(engs, stats)):
+        _same(_snapshot(e, st, True), alone[i][0], names[i])
+        e.close()
+
+
 def _programs():
     import warnings
     from ppopt_amd import MPLP_Program, MPQP_Program, problem_generator as pg

@@ -35,11 +35,14 @@ for rep in range(3):
           f'solve_many {1e3*(t3-t2):.1f}, release {1e3*(t4-t3):.1f}')
     print('   levels: ' + ', '.join(f"L{p['depth']}: {p['members']}/{p['shared_launches']} members, {p['candidates']} cand, {p['regions']} reg, "
                                     f"launches {p.get('ms_launches', 0):.2f} ms, wait {p.get('ms_wait', 0):.2f}, wall {p['ms_wall']:.2f} ms" for p in prof))
-for env in (() if os.environ.get('MI_BATCH_ONLY') else ('0', '1', '0', '1')):
+from ppopt_amd.mp_solvers import mpmiqp_enumeration  # noqa: E402
+for env in (() if os.environ.get('MI_BATCH_ONLY') else ('0', '1', 'c1', 'c2', 'c4', 'c8', '0', '1')):
+    if env[0] == 'c':
+        mpmiqp_enumeration.BATCH_CHUNKS = int(env[1:]); env = '0'
     os.environ['MPC_NO_BATCH'] = env
     best = 1e9
     for _ in range(3):
         t0 = time.perf_counter()
         sol = solve_mpmiqp(prog)
         best = min(best, time.perf_counter() - t0)
-    print(f'solve_mpmiqp MPC_NO_BATCH={env}: {1e3*best:.1f} ms, {len(sol)} regions, {len(combos)/best:.0f} sub-programs/s')
+    print(f'solve_mpmiqp MPC_NO_BATCH={env} chunks={mpmiqp_enumeration.BATCH_CHUNKS}: {1e3*best:.1f} ms, {len(sol)} regions, {len(combos)/best:.0f} sub-programs/s')
