@@ -48,15 +48,18 @@ def solve_mpmiqp_enumeration(program, num_cores: int = -1,
         device = int(getattr(getattr(program, 'solver', None), 'device', 0) or 0)
         prune_lowdim = cont_algorithm is mpqp_algorithm.combinatorial_parallel
 
+        def substitute_one(fix):
+            sub = program.generate_substituted_problem(fix)
+            sub.engine(device)                 # presolve (device LP batches) and set-up (MFMA set-up kernel) of the sub-program
+            return sub
+
         def substitute(fixes):
-            out = []
-            with warnings.catch_warnings():
+            with warnings.catch_warnings():    # the substituted programs repeat the parent's construction warnings
                 warnings.simplefilter('ignore')
-                for fix in fixes:
-                    sub = program.generate_substituted_problem(fix)
-                    sub.engine(device)         # presolve (device LP batches) and set-up (MFMA set-up kernel) of the sub-program
-                    out.append(sub)
-            return out
+                if num_cores <= 1:
+                    return [substitute_one(fix) for fix in fixes]
+                with ThreadPoolExecutor(max_workers=num_cores) as inner:      # the LP batches and mpc_create release the interpreter lock
+                    return list(inner.map(substitute_one, fixes))
 
         # MPC_BATCH_CHUNKS > 1: the fixations are solved in chunks -- while the device works on the levels of one chunk (the host waits
         # inside the C ABI, GIL released) a second thread substitutes, presolves and sets up the sub-programs of the next one.  Measured
