@@ -182,3 +182,51 @@ def test_enumeration_batched_equals_one_by_one(monkeypatch):
         assert list(r1.y_fixation) == list(r2.y_fixation) and list(r1.active_set) == list(r2.active_set)
         for fld in ('A', 'b', 'C', 'd', 'E', 'f'):
             assert numpy.asarray(getattr(r1, fld)).tobytes() == numpy.asarray(getattr(r2, fld)).tobytes(), fld
+
+
+def test_solve_many_on_random_programs_of_many_shapes():
+    """Forty random mpQPs / mpLPs of different sizes in ONE batch -- one to ten parameters (n_theta = 1 has no register-resident
+    region kernel: such members run alone inside the call), 3 to 14 variables, with and without equality rows, some infeasible
+    from the first level on -- against forty separate solves: the same regions in the same order with the same numbers."""
+    import warnings
+    from ppopt_amd import MPLP_Program, MPQP_Program, problem_generator as pg
+    from ppopt_amd.mp_solvers import mpqp_hip_combinatorial
+    rng = numpy.random.default_rng(77)
+
+    def make():
+        out = []
+        with warnings.catch_warnings():
+            warnings.simplefilter('ignore')
+            for j in range(40):
+                nx, nt, m = int(rng.integers(3, 15)), int(rng.integers(1, 11)), int(rng.integers(6, 22))
+                d = pg.generate_mpqp_data(nx, nt, m, 1000 + j)
+                if j % 5 == 4:      # an equality row
+                    d['equality_indices'] = [0]
+                try:
+                    if j % 7 == 6:
+                        out.append(MPLP_Program(d['A'], d['b'], d['c'], d['H'], d['A_t'], d['b_t'], d['F'], equality_indices=d['equality_indices']))
+                    else:
+                        out.append(MPQP_Program(d['A'], d['b'], d['c'], d['H'], d['Q'], d['A_t'], d['b_t'], d['F'], equality_indices=d['equality_indices']))
+                except Exception:
+                    continue
+        return out
+    rng = numpy.random.default_rng(77)
+    one = [mpqp_hip_combinatorial.solve(p, max_levels=4) for p in make()]
+    rng = numpy.random.default_rng(77)
+    progs = make()
+    prof = []
+    many = mpqp_hip_combinatorial.solve_many(progs, max_levels=4, profile=prof)
+    assert len(one) == len(many) >= 30
+    assert sum(p['shared_launches'] for p in prof) > sum(p['members'] for p in prof) // 2
+    n_regions = 0
+    for n, (a, b) in enumerate(zip(one, many)):
+        assert len(a.critical_regions) == len(b.critical_regions), n
+        key = lambda r: tuple(r.active_set)
+        ra, rb = sorted(a.critical_regions, key=key), sorted(b.critical_regions, key=key)      # a level with a late optimal candidate lists it last when solved alone
+        for r1, r2 in zip(ra, rb):
+            assert list(r1.active_set) == list(r2.active_set), n
+            assert r1.omega_set == r2.omega_set and r1.lambda_set == r2.lambda_set and r1.regular_set == r2.regular_set, n
+            for fld in ('A', 'b', 'C', 'd', 'E', 'f'):
+                assert numpy.asarray(getattr(r1, fld)).tobytes() == numpy.asarray(getattr(r2, fld)).tobytes(), (n, fld)
+        n_regions += len(ra)
+    assert n_regions > 500
