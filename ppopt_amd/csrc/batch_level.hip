@@ -141,11 +141,6 @@ unsigned long long spec_of(std::initializer_list<std::pair<int, int>> classes) {
     return spec;
 }
 
-// the argument table: pinned staging + device copy, grown on demand, one per process (batch launches are serialised)
-std::mutex g_batch_mutex;
-BatchMember *g_tab_host = nullptr, *g_tab_dev = nullptr;
-int g_tab_cap = 0;
-
 auto group_key(const BatchMember &m) { return std::make_tuple(m.k, m.kd, m.fast_t, m.fast_x, m.fast_r, m.mw, m.use_kkt, m.quick_test, m.gen_children); }
 
 template <class F>
@@ -158,19 +153,10 @@ hipError_t raise_lds(F *fn, int bytes) {
 
 #define TRY(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) return e_; } while (0)
 
-hipError_t batch_level_launch(BatchMember *members, int B, hipStream_t st) {
+hipError_t batch_level_launch(BatchMember *members, int B, hipStream_t st, BatchMember *g_tab_host, BatchMember *g_tab_dev) {
     if (B <= 0) return hipSuccess;
-    std::lock_guard<std::mutex> lk(g_batch_mutex);
+    if (!g_tab_host || !g_tab_dev) return hipErrorInvalidValue;
     std::stable_sort(members, members + B, [](const BatchMember &a, const BatchMember &b) { return group_key(a) < group_key(b); });
-    if (B > g_tab_cap) {
-        if (g_tab_host) { (void)hipHostFree(g_tab_host); g_tab_host = nullptr; }
-        if (g_tab_dev) { (void)hipFree(g_tab_dev); g_tab_dev = nullptr; }
-        g_tab_cap = 0;
-        const int cap = std::max(64, B + B / 2);
-        TRY(hipHostMalloc(reinterpret_cast<void **>(&g_tab_host), (size_t)cap * sizeof(BatchMember), hipHostMallocPortable));
-        TRY(hipMalloc(reinterpret_cast<void **>(&g_tab_dev), (size_t)cap * sizeof(BatchMember)));
-        g_tab_cap = cap;
-    }
     std::memcpy(g_tab_host, members, (size_t)B * sizeof(BatchMember));
     TRY(hipMemcpyAsync(g_tab_dev, g_tab_host, (size_t)B * sizeof(BatchMember), hipMemcpyHostToDevice, st));
     hipLaunchKernelGGL(m_zero, dim3(64, (unsigned)B), dim3(256), 0, st, g_tab_dev);

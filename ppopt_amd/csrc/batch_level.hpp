@@ -61,7 +61,8 @@ struct BatchMember {
 };
 
 // Queues the launches of one level for the B members on `st` (no synchronisation).  The members are reordered into groups.
-// Returns hipSuccess or the first error.
-hipError_t batch_level_launch(BatchMember *members, int B, hipStream_t st);
+// tab_host (page-locked) / tab_dev: room for B BatchMember each, owned by the caller until the launches have completed (the kernels
+// read their arguments from tab_dev).  Returns hipSuccess or the first error.
+hipError_t batch_level_launch(BatchMember *members, int B, hipStream_t st, BatchMember *tab_host, BatchMember *tab_dev);
 
 }  // namespace mpc

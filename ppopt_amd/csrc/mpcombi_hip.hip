@@ -1635,6 +1635,9 @@ struct BatchToken {
     std::vector<BatchMember> members;
     std::vector<int> alone;      // members outside the shared launches: run one after the other by mpc_level_run's own paths
     hipStream_t st = nullptr;
+    DevBuf tab_dev;              // the members' argument table the launches read (one per batch call: concurrent batches do not share it)
+    HostBuf tab_host;
+    ~BatchToken() { tab_dev.release(); tab_host.release(); }   // only after the launches have completed (wait) or were never queued
 };
 
 int mpc_level_batch_start(mpc_handle **hs, int32_t n_handles, const int32_t *gen_children, int32_t flags, void **token) {
@@ -1689,8 +1692,11 @@ int mpc_level_batch_start(mpc_handle **hs, int32_t n_handles, const int32_t *gen
         t->st = hl->stream;
         const int lead = t->members[0].id;
         HIP_TRY(hl, hipEventRecord(hl->ev[0], t->st));
-        hipError_t e = batch_level_launch(t->members.data(), (int)t->members.size(), t->st);
-        if (e != hipSuccess) return fail(hl, MPC_ERR_HIP, std::string("batch level launch: ") + hipGetErrorString(e));
+        const size_t tab_bytes = t->members.size() * sizeof(BatchMember);
+        HIP_TRY(hl, t->tab_dev.ensure(tab_bytes, t->st));
+        HIP_TRY(hl, t->tab_host.ensure(tab_bytes));
+        hipError_t e = batch_level_launch(t->members.data(), (int)t->members.size(), t->st, t->tab_host.as<BatchMember>(), t->tab_dev.as<BatchMember>());
+        if (e != hipSuccess) { (void)hipStreamSynchronize(t->st); return fail(hl, MPC_ERR_HIP, std::string("batch level launch: ") + hipGetErrorString(e)); }   // (what was queued still reads the table)
         HIP_TRY(hl, hipEventRecord(hl->ev[3], t->st));
         t->alone.insert(t->alone.begin(), -1 - lead);      // first entry < 0: the member whose events bracket the launches
     }

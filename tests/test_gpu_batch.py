@@ -230,3 +230,21 @@ def test_solve_many_on_random_programs_of_many_shapes():
                 assert numpy.asarray(getattr(r1, fld)).tobytes() == numpy.asarray(getattr(r2, fld)).tobytes(), (n, fld)
         n_regions += len(ra)
     assert n_regions > 500
+
+
+def test_two_batches_at_once_from_two_threads():
+    """Two threads, each driving its own batch of programs through shared launches at the same time (two mixed-integer problems
+    solved side by side): every call owns its argument table, the results are those of the separate solves."""
+    from concurrent.futures import ThreadPoolExecutor
+    from ppopt_amd.mp_solvers import mpqp_hip_combinatorial
+    one = [mpqp_hip_combinatorial.solve(p) for p in _programs()]
+    sets = [_programs() for _ in range(4)]
+    with ThreadPoolExecutor(max_workers=4) as pool:
+        results = list(pool.map(lambda ps: mpqp_hip_combinatorial.solve_many(ps), sets))
+    for many in results:
+        for n, (a, b) in enumerate(zip(one, many)):
+            assert len(a.critical_regions) == len(b.critical_regions) > 0, n
+            for r1, r2 in zip(a.critical_regions, b.critical_regions):
+                assert list(r1.active_set) == list(r2.active_set), n
+                for fld in ('A', 'b', 'C', 'd', 'E', 'f'):
+                    assert numpy.asarray(getattr(r1, fld)).tobytes() == numpy.asarray(getattr(r2, fld)).tobytes(), (n, fld)
