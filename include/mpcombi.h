@@ -261,6 +261,10 @@ int mpc_level_regions_slots_async(mpc_handle *h, double *head_d, int32_t *head_i
  * them and builds the region objects of the finished level while the device works. */
 int mpc_level_regions_slots_nowait(mpc_handle *h, double *head_d, int32_t *head_i, int64_t cap_slots, double *erows,
                                    int64_t cap_rows, int64_t *n_slots, int64_t *n_rows);
+/* mpc_level_regions_slots_nowait for every handle of a list in one call (the driver of a batch: one call per level instead of one
+ * per member).  Arrays of n_handles entries; a member without regions gets n_slots = n_rows = 0 and may pass null buffers. */
+int mpc_level_batch_fetch(mpc_handle **handles, int32_t n_handles, double *const *head_d, int32_t *const *head_i, const int64_t *cap_slots,
+                          double *const *erows, const int64_t *cap_rows, int64_t *n_slots, int64_t *n_rows);
 int mpc_sync(mpc_handle *h);   /* waits for everything queued on the handle's stream */
 /* Page-locked host memory from a recycling pool (blocks return to the pool on mpc_host_free and are handed out again
  * without re-pinning).  For result arrays that are filled by mpc_level_regions_slots. */

@@ -135,6 +135,7 @@ def load():
         'mpc_level_regions_slots': (ctypes.c_int, [H, _dp, _ip, ctypes.c_int64, _dp, ctypes.c_int64, _lp, _lp]),
         'mpc_level_regions_slots_async': (ctypes.c_int, [H, _dp, _ip, ctypes.c_int64, _dp, ctypes.c_int64, _lp, _lp]),
         'mpc_level_regions_slots_nowait': (ctypes.c_int, [H, _dp, _ip, ctypes.c_int64, _dp, ctypes.c_int64, _lp, _lp]),
+        'mpc_level_batch_fetch': (ctypes.c_int, [ctypes.POINTER(H), ctypes.c_int32, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_void_p), _lp, ctypes.POINTER(ctypes.c_void_p), _lp, _lp, _lp]),
         'mpc_sync': (ctypes.c_int, [H]),
         'mpc_locator_create': (ctypes.c_int, [ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int64, _lp, _dp, _dp, _dp, _dp, _dp,
                                                ctypes.POINTER(ctypes.c_void_p)]),
@@ -177,7 +178,7 @@ EXPORTED_SYMBOLS = ['mpc_device_count', 'mpc_version', 'mpc_last_global_error', 
                     'mpc_last_error', 'mpc_mask_words', 'mpc_set_region_overlap', 'mpc_program_block', 'mpc_region_doubles', 'mpc_region_ints', 'mpc_lds_bytes', 'mpc_stream',
                     'mpc_frontier_root', 'mpc_frontier_set', 'mpc_frontier_set_device', 'mpc_frontier_info',
                     'mpc_frontier_get', 'mpc_pruned_clear', 'mpc_pruned_add', 'mpc_pruned_add_device',
-                    'mpc_pruned_count', 'mpc_pruned_get', 'mpc_level_run', 'mpc_level_run_ex', 'mpc_level_run_batch', 'mpc_level_batch_start', 'mpc_level_batch_wait', 'mpc_level_regions_slots_nowait', 'mpc_level_status', 'mpc_level_start', 'mpc_level_stream_info', 'mpc_level_chunk_wait', 'mpc_level_wait', 'mpc_level_stream_fixup', 'mpc_base_result', 'mpc_level_regions', 'mpc_compact_strides',
+                    'mpc_pruned_count', 'mpc_pruned_get', 'mpc_level_run', 'mpc_level_run_ex', 'mpc_level_run_batch', 'mpc_level_batch_start', 'mpc_level_batch_wait', 'mpc_level_regions_slots_nowait', 'mpc_level_batch_fetch', 'mpc_level_status', 'mpc_level_start', 'mpc_level_stream_info', 'mpc_level_chunk_wait', 'mpc_level_wait', 'mpc_level_stream_fixup', 'mpc_base_result', 'mpc_level_regions', 'mpc_compact_strides',
                     'mpc_level_regions_compact', 'mpc_frontier_shard', 'mpc_level_slots', 'mpc_level_regions_slots', 'mpc_level_regions_slots_async', 'mpc_sync', 'mpc_host_alloc', 'mpc_host_free', 'mpc_locator_create', 'mpc_locator_query', 'mpc_locator_destroy', 'mpc_locator_set_adjacency', 'mpc_level_children', 'mpc_level_children_device', 'mpc_level_pruned_new',
                     'mpc_level_pruned_new_device', 'mpc_level_regions_device', 'mpc_frontier_advance', 'mpc_qp_solve_batch', 'mpc_facet_centres', 'mpc_graph_begin', 'mpc_graph_wave', 'mpc_graph_group_run', 'mpc_graph_wave_close', 'mpc_check_level', 'mpc_lp_solve_batch']
 
@@ -403,6 +404,50 @@ class Engine:
             e._last = c
             out.append(c)
         return out, int(nb.value)
+
+    @staticmethod
+    def level_batch_fetch(engines):
+        """``level_regions_slots_nowait`` for many engines with ONE call into the library and THREE page-locked blocks for all of
+        them (the members' arrays are views into those): [(head_d, head_i, erows, k) per engine], copies queued only.  Sizes come from
+        each engine's LevelStats of the level just run."""
+        B = len(engines)
+        if B == 0:
+            return []
+        fds, fis, nss, nrs = [], [], [], []
+        for e in engines:
+            st = e._last
+            k = int(st.k)
+            nr = int(st.n_regions)
+            fds.append(e.n_x * e.n_t + e.n_x + k * e.n_t + k)
+            fis.append(8 + k + e.n_tc + k + 2 * (e.n_c - k))
+            nss.append(int(st.n_opt) if nr else 0)
+            rows_t = e.n_c - e.n_eq + e.n_tc
+            # mpc_compact_strides' max_rows: pooled rows + a full row block per candidate the LDS-engine kernel re-solved; a level
+            # built by that kernel alone (no register-resident instantiation: one parameter) reports no pooled rows
+            nrs.append(0 if not nr else (int(st.n_region_rows) + int(st.n_region_retry) * rows_t if st.n_region_rows else nr * rows_t))
+        od = numpy.concatenate([[0], numpy.cumsum([n * f for n, f in zip(nss, fds)])]).astype(numpy.int64)
+        oi = numpy.concatenate([[0], numpy.cumsum([n * f for n, f in zip(nss, fis)])]).astype(numpy.int64)
+        oe = numpy.concatenate([[0], numpy.cumsum([n * (e.n_t + 1) for n, e in zip(nrs, engines)])]).astype(numpy.int64)
+        big_d = pinned_empty((max(int(od[-1]), 1),), numpy.float64)
+        big_i = pinned_empty((max(int(oi[-1]), 1),), numpy.int32)
+        big_e = pinned_empty((max(int(oe[-1]), 1),), numpy.float64)
+        pd = (ctypes.c_void_p * B)(*(big_d.ctypes.data + 8 * od[:-1]).tolist())
+        pi = (ctypes.c_void_p * B)(*(big_i.ctypes.data + 4 * oi[:-1]).tolist())
+        pe = (ctypes.c_void_p * B)(*(big_e.ctypes.data + 8 * oe[:-1]).tolist())
+        caps = (ctypes.c_int64 * B)(*nss)
+        capr = (ctypes.c_int64 * B)(*nrs)
+        n1 = (ctypes.c_int64 * B)()
+        n2 = (ctypes.c_int64 * B)()
+        hs = (ctypes.c_void_p * B)(*[e._h for e in engines])
+        rc = engines[0]._L.mpc_level_batch_fetch(hs, B, pd, pi, caps, pe, capr, n1, n2)
+        if rc != 0:
+            Engine._raise_for(engines, rc)
+        out = []
+        for j, e in enumerate(engines):
+            ns, nr = int(n1[j]), int(n2[j])
+            out.append((big_d[od[j]:od[j] + ns * fds[j]].reshape(ns, fds[j]), big_i[oi[j]:oi[j] + ns * fis[j]].reshape(ns, fis[j]),
+                        big_e[oe[j]:oe[j] + nr * (e.n_t + 1)].reshape(nr, e.n_t + 1), int(e._last.k)))
+        return out
 
     @staticmethod
     def _raise_for(engines, rc):

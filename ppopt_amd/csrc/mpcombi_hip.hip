@@ -2694,6 +2694,15 @@ int mpc_level_regions_slots_nowait(mpc_handle *h, double *head_d, int32_t *head_
     h->fetch_nowait = false;
     return rc;
 }
+int mpc_level_batch_fetch(mpc_handle **hs, int32_t n_handles, double *const *head_d, int32_t *const *head_i, const int64_t *cap_slots,
+                          double *const *erows, const int64_t *cap_rows, int64_t *n_slots, int64_t *n_rows) {
+    if (!hs || n_handles < 0 || !head_d || !head_i || !cap_slots || !erows || !cap_rows || !n_slots || !n_rows) return MPC_ERR_INVALID;
+    for (int i = 0; i < n_handles; ++i) {
+        const int rc = mpc_level_regions_slots_nowait(hs[i], head_d[i], head_i[i], cap_slots[i], erows[i], cap_rows[i], n_slots + i, n_rows + i);
+        if (rc != MPC_OK) return rc;
+    }
+    return MPC_OK;
+}
 int mpc_level_stream_fixup(mpc_handle *h, double *head_d, int32_t *head_i, double *erows, int64_t *n_rows) {
     if (!h || !head_d || !head_i || !erows) return MPC_ERR_INVALID;
     if (!h->so.active) return fail(h, MPC_ERR_STATE, "mpc_level_stream_fixup: this level was not streamed");

@@ -48,18 +48,34 @@ def solve_mpmiqp_enumeration(program, num_cores: int = -1,
         device = int(getattr(getattr(program, 'solver', None), 'device', 0) or 0)
         prune_lowdim = cont_algorithm is mpqp_algorithm.combinatorial_parallel
 
-        def substitute_one(fix):
-            sub = program.generate_substituted_problem(fix)
-            sub.engine(device)                 # presolve (device LP batches) and set-up (MFMA set-up kernel) of the sub-program
-            return sub
-
         def substitute(fixes):
-            with warnings.catch_warnings():    # the substituted programs repeat the parent's construction warnings
+            """The sub-programs of ``fixes``, presolved and set up.  One thread per fixation: the presolve LPs of all of them (three
+            small device batches per construction) are posed together, one batch per presolve stage (solver.LPCoalescer)."""
+            import copy
+            from ..solver import LPCoalescer
+            if len(fixes) <= 1 or num_cores == 1 or os.environ.get('MPC_NO_LP_COALESCE', '0') == '1':
+                with warnings.catch_warnings():    # the substituted programs repeat the parent's construction warnings
+                    warnings.simplefilter('ignore')
+                    subs = [program.generate_substituted_problem(fix) for fix in fixes]
+                    for sub in subs:
+                        sub.engine(device)     # set-up of the sub-program (MFMA set-up kernel)
+                    return subs
+            co = LPCoalescer(program.solver, len(fixes))
+            parked = copy.copy(program)
+            parked.solver = co.solver()
+
+            def one(fix):
+                try:
+                    sub = parked.generate_substituted_problem(fix)
+                finally:
+                    co.worker_done()
+                sub.solver = program.solver
+                sub.engine(device)
+                return sub
+            with warnings.catch_warnings():        # one filter around all threads (catch_warnings is not thread-safe)
                 warnings.simplefilter('ignore')
-                if num_cores <= 1:
-                    return [substitute_one(fix) for fix in fixes]
-                with ThreadPoolExecutor(max_workers=num_cores) as inner:      # the LP batches and mpc_create release the interpreter lock
-                    return list(inner.map(substitute_one, fixes))
+                with ThreadPoolExecutor(max_workers=len(fixes)) as inner:
+                    return list(inner.map(one, fixes))
 
         # MPC_BATCH_CHUNKS > 1: the fixations are solved in chunks -- while the device works on the levels of one chunk (the host waits
         # inside the C ABI, GIL released) a second thread substitutes, presolves and sets up the sub-programs of the next one.  Measured

@@ -241,7 +241,8 @@ def solve_many(programs, device: int = 0, max_levels: Optional[int] = None, prun
             stats, n_shared = Engine.level_batch_wait(token)
             t_wait = time.perf_counter() - t0
             # the region records of this level: copies queued on each member's stream, nobody waits ...
-            fetched = [(i, engs[i].level_regions_slots_nowait()) for i, st in zip(active, stats) if st.n_regions]
+            with_regions = [i for i, st in zip(active, stats) if st.n_regions]
+            fetched = list(zip(with_regions, Engine.level_batch_fetch([engs[i] for i in with_regions])))
             nxt = [i for i, st, gen in zip(active, stats, gens) if gen and st.n_children]
             for i in nxt:
                 engs[i].frontier_advance()

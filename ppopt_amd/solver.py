@@ -244,3 +244,95 @@ class Solver:
         bb = numpy.asarray(b, dtype=numpy.float64).reshape(-1)
         slack = bb - numpy.asarray(A, dtype=numpy.float64) @ sol
         return SolverOutput(float(obj[best]), sol, slack, numpy.nonzero(numpy.abs(slack) <= 1e-10)[0], None)
+
+
+class LPCoalescer:
+    """Turns the LP calls of several host threads into shared device batches.
+
+    The mixed-integer enumeration builds one continuous sub-program per binary fixation; each construction presolves (a Chebyshev
+    LP, a feasibility LP, one redundancy LP per row -- mplp_program.py) through ``Solver.solve_lp_batch``, three small device
+    batches per sub-program, each paying the fixed cost of a launch and a synchronisation.  With the constructions running in
+    ``n_workers`` threads against ``solver()``, a call parks its LPs here; when every live worker is parked the last one to arrive
+    poses ALL parked LPs as one batch per shape (per-instance matrices, mpc_lp_solve_batch) and hands the results back.  The kernel
+    and its arithmetic are those of the separate calls, instance for instance."""
+
+    def __init__(self, base: Solver, n_workers: int):
+        import threading
+        self.base, self.live = base, n_workers
+        self.cv = threading.Condition()
+        self.queue: List[dict] = []
+        self.n_flushes = self.n_calls = 0
+
+    def solver(self) -> 'Solver':
+        outer = self
+
+        class _Parked(Solver):
+            def solve_lp_batch(self, c, A, b, equality_sets):      # solve_lp goes through here too
+                return outer.submit(c, A, b, equality_sets)
+        return _Parked(solvers=dict(self.base.solvers), device=self.base.device)
+
+    def worker_done(self):
+        with self.cv:
+            self.live -= 1
+            if self.queue and len(self.queue) >= self.live:
+                self._flush()
+
+    def submit(self, c, A, b, equality_sets):
+        A = numpy.ascontiguousarray(A, dtype=numpy.float64)
+        item = {'c': None if c is None else numpy.ascontiguousarray(c, dtype=numpy.float64).reshape(-1), 'A': A,
+                'b': numpy.ascontiguousarray(b, dtype=numpy.float64).reshape(-1), 'eq': [list(e) for e in equality_sets], 'res': None, 'err': None}
+        with self.cv:
+            self.n_calls += 1
+            self.queue.append(item)
+            if len(self.queue) >= self.live:
+                self._flush()
+            while item['res'] is None and item['err'] is None:
+                self.cv.wait()
+        if item['err'] is not None:
+            raise item['err']
+        return item['res']
+
+    def _flush(self):       # the lock is held; every other live worker is waiting
+        items, self.queue = self.queue, []
+        self.n_flushes += 1
+        try:
+            groups: Dict[tuple, List[dict]] = {}
+            for it in items:
+                groups.setdefault((it['A'].shape, it['c'] is None), []).append(it)
+            for (shape, no_c), grp in groups.items():
+                m, n = shape
+                counts = [len(it['eq']) for it in grp]
+                total = sum(counts)
+                if total == 0:
+                    for it in grp:
+                        it['res'] = []
+                    continue
+                A = numpy.empty((total, m, n))
+                bb = numpy.empty((total, m))
+                cc = None if no_c else numpy.empty((total, n))
+                flags = numpy.zeros((total, m), dtype=numpy.uint8)
+                pos = 0
+                for it, cnt in zip(grp, counts):
+                    A[pos:pos + cnt], bb[pos:pos + cnt] = it['A'], it['b']
+                    if cc is not None:
+                        cc[pos:pos + cnt] = it['c']
+                    for j, eq in enumerate(it['eq']):
+                        flags[pos + j, eq] = 1
+                    pos += cnt
+                status, x, obj, _ = _lib.lp_solve_batch(A, bb, cc, flags, device=self.base.device)
+                pos = 0
+                for it, cnt in zip(grp, counts):
+                    res: List[Optional[SolverOutput]] = []
+                    for i in range(pos, pos + cnt):
+                        if status[i] != _lib.LP_OPTIMAL:
+                            res.append(None)
+                            continue
+                        slack = it['b'] - it['A'] @ x[i]
+                        res.append(SolverOutput(float(obj[i]), x[i].copy(), slack, numpy.nonzero(numpy.abs(slack) <= 1e-10)[0], None))
+                    it['res'] = res
+                    pos += cnt
+        except Exception as ex:      # every parked caller sees the failure
+            for it in items:
+                if it['res'] is None:
+                    it['err'] = ex
+        self.cv.notify_all()

@@ -36,7 +36,9 @@ for rep in range(3):
     print('   levels: ' + ', '.join(f"L{p['depth']}: {p['members']}/{p['shared_launches']} members, {p['candidates']} cand, {p['regions']} reg, "
                                     f"launches {p.get('ms_launches', 0):.2f} ms, wait {p.get('ms_wait', 0):.2f}, wall {p['ms_wall']:.2f} ms" for p in prof))
 from ppopt_amd.mp_solvers import mpmiqp_enumeration  # noqa: E402
-for env in (() if os.environ.get('MI_BATCH_ONLY') else ('0', '1', 'c1', 'c2', 'c4', 'c8', '0', '1')):
+for env in (() if os.environ.get('MI_BATCH_ONLY') else ('0', '1', 'L', '0', 'L', '0', '1')):
+    os.environ['MPC_NO_LP_COALESCE'] = '1' if env == 'L' else '0'
+    env = '0' if env == 'L' else env
     if env[0] == 'c':
         mpmiqp_enumeration.BATCH_CHUNKS = int(env[1:]); env = '0'
     os.environ['MPC_NO_BATCH'] = env
@@ -45,4 +47,4 @@ for env in (() if os.environ.get('MI_BATCH_ONLY') else ('0', '1', 'c1', 'c2', 'c
         t0 = time.perf_counter()
         sol = solve_mpmiqp(prog)
         best = min(best, time.perf_counter() - t0)
-    print(f'solve_mpmiqp MPC_NO_BATCH={env} chunks={mpmiqp_enumeration.BATCH_CHUNKS}: {1e3*best:.1f} ms, {len(sol)} regions, {len(combos)/best:.0f} sub-programs/s')
+    print(f'solve_mpmiqp MPC_NO_BATCH={env} MPC_NO_LP_COALESCE={os.environ["MPC_NO_LP_COALESCE"]}: {1e3*best:.1f} ms, {len(sol)} regions, {len(combos)/best:.0f} sub-programs/s')
