@@ -733,10 +733,31 @@ MPC_GLOBAL void k_scatter_index(const int32_t *__restrict__ flag, const int32_t 
     if (i < n && flag[i]) list[pos[i]] = (int32_t)i;
 }
 
+// clears up to four buffers in ONE launch (a level's counters, list lengths and flags: a hipMemsetAsync each costs the small levels
+// a ~4 us dispatch of its own).  Sizes in bytes, multiples of 8 with 8-byte-aligned pointers take the word path.
+struct ZeroBufs { void *p[4]; unsigned long long bytes[4]; };
+MPC_GLOBAL void MPC_LB(256) k_zero_bufs(ZeroBufs z) {
+    for (int j = 0; j < 4; ++j) {
+        const unsigned long long bytes = z.bytes[j];
+        if (!z.p[j] || bytes == 0) continue;
+        if ((reinterpret_cast<unsigned long long>(z.p[j]) & 7ull) == 0 && (bytes & 7ull) == 0) {
+            unsigned long long *p = reinterpret_cast<unsigned long long *>(z.p[j]);
+            for (unsigned long long i = blockIdx.x * 256ull + threadIdx.x; i < bytes / 8; i += (unsigned long long)gridDim.x * 256ull) p[i] = 0ull;
+        } else {
+            unsigned char *p = reinterpret_cast<unsigned char *>(z.p[j]);
+            for (unsigned long long i = blockIdx.x * 256ull + threadIdx.x; i < bytes; i += (unsigned long long)gridDim.x * 256ull) p[i] = 0;
+        }
+    }
+}
+
 // copies a few words of device memory into pinned host memory (a read-back without a copy command: on this runtime a
 // hipMemcpyAsync costs the host ~16 us, a launch ~3 us)
 MPC_GLOBAL void k_publish_words(const unsigned int *__restrict__ src, unsigned int *__restrict__ dst, int n) {
     for (int i = threadIdx.x; i < n; i += blockDim.x) dst[i] = src[i];
+}
+// two sources, one after the other in dst (a level's counters and its list lengths: one launch)
+MPC_GLOBAL void k_publish_words2(const unsigned int *__restrict__ src1, int n1, const unsigned int *__restrict__ src2, int n2, unsigned int *__restrict__ dst) {
+    for (int i = threadIdx.x; i < n1 + n2; i += blockDim.x) dst[i] = i < n1 ? src1[i] : src2[i - n1];
 }
 
 // ---- small levels: the same bookkeeping in ONE single-block launch each -------------------------------------------------------

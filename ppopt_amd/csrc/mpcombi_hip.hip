@@ -650,6 +650,9 @@ static int create_fill(const mpc_problem *p, int32_t device, void *stream, mpc_h
             }
         }
         if (!ok) { d0.clear(); d0_rows.clear(); d0_cols.clear(); }
+        if (std::getenv("MPC_DEBUG_CREATE"))
+            std::fprintf(stderr, "[mpc] create: base vertex rc %d status %d, %d tight rows of n_x + n_t = %d -> pre-crashed dictionary %s\n", rc0, (int)lp_status,
+                         (int)B.size(), nv, ok ? "built" : "NOT built (no register-resident fast path for this program)");
     }
     // ---- vertex of the parameter polytope {A_t theta <= b_t} (kernels2.hpp) ----------------------------------------
     std::vector<double> tv_theta, tv_minv, tv_rows, d0T;
@@ -834,6 +837,10 @@ static int create_fill(const mpc_problem *p, int32_t device, void *stream, mpc_h
         const int slots_t = rows_th <= 64 ? 1 : (rows_th <= 128 ? 2 : 0), slots_x = rows_x <= 64 ? 1 : (rows_x <= 128 ? 2 : 0);
         const int tsel = nt <= 4 ? 0 : (nt <= 8 ? 1 : (nt <= 10 ? 2 : -1));   // kernels are instantiated for n_theta <= 4, 8, 10
         const int xsel = P.n_d0c <= 14 ? 0 : (P.n_d0c <= 30 ? 1 : -1);
+        if (std::getenv("MPC_DEBUG_CREATE"))
+            std::fprintf(stderr, "[mpc] create: vertex of the parameter set %d, dictionary %d (rows %d, columns %d), theta rows %d -> slots %d / %d, n_theta class %d, column class %d: register-resident kernels %s\n",
+                         (int)P.has_tv, (int)P.has_d0, rows_x, (int)P.n_d0c, rows_th, slots_t, slots_x, tsel, xsel,
+                         (P.has_tv && P.has_d0 && slots_t && slots_x && tsel >= 0 && xsel >= 0) ? "ON" : "OFF (LDS-engine kernels)");
         if (P.has_tv && P.has_d0 && slots_t && slots_x && tsel >= 0 && xsel >= 0) {
             h->fast = 1;
             h->fast_t = tsel * 2 + (slots_t - 1);
@@ -1212,8 +1219,20 @@ static int level_run_small(mpc_handle *h, int32_t gen_children, int32_t flags, m
     HIP_TRY(h, h->theta_list.ensure(nn * sizeof(int32_t), st));
     HIP_TRY(h, h->part_lists.ensure((size_t)PART_CLASSES * nn * sizeof(int32_t), st));
     HIP_TRY(h, h->dcnt.ensure(32 * sizeof(int32_t), st));
-    HIP_TRY(h, hipMemsetAsync(h->ctr.p, 0, sizeof(LevelCounters), st));
-    HIP_TRY(h, hipMemsetAsync(h->dcnt.p, 0, 32 * sizeof(int32_t), st));
+    {
+        // counters, list lengths, the region kernel's completion flags and the "dictionary stored" flags: cleared by one launch
+        const int nxc_ = h->fast_x >= 2 ? 32 : 16;
+        const double need_gb_ = (double)nn * ((double)nxc_ * h->Pf.n_d0r * 8.0 + (2.0 * h->Pf.n_d0r + nxc_ + 4) * 4.0) / 1e9;
+        const bool will_store = gen_children && need_gb_ <= h->dict_budget_gb;
+        HIP_TRY(h, h->done_g.ensure(nn * 2 * sizeof(unsigned int), st));
+        if (will_store) HIP_TRY(h, h->dict_stored[h->dict_cur].ensure(nn, st));
+        ZeroBufs z{};
+        z.p[0] = h->ctr.p; z.bytes[0] = sizeof(LevelCounters);
+        z.p[1] = h->dcnt.p; z.bytes[1] = 32 * sizeof(int32_t);
+        z.p[2] = h->done_g.p; z.bytes[2] = nn * 2 * sizeof(unsigned int);
+        if (will_store) { z.p[3] = h->dict_stored[h->dict_cur].p; z.bytes[3] = nn; }
+        hipLaunchKernelGGL(k_zero_bufs, dim3((unsigned)std::min<size_t>(64, (nn * 8 + 2047) / 2048 + 1)), dim3(256), 0, st, z);
+    }
     LevelCounters *ctr = h->ctr.as<LevelCounters>();
     int32_t *dcnt = h->dcnt.as<int32_t>();
     const int32_t *fr = h->frontier.as<int32_t>();
@@ -1284,7 +1303,6 @@ static int level_run_small(mpc_handle *h, int32_t gen_children, int32_t flags, m
         const int ldk = (rows_t_ + 1 + 63) & ~63;
         HIP_TRY(h, h->kept_g.ensure(nn * ldk, st));
         HIP_TRY(h, h->done_g.ensure(nn * 2 * sizeof(unsigned int), st));
-        HIP_TRY(h, hipMemsetAsync(h->done_g.p, 0, nn * 2 * sizeof(unsigned int), st));
         RegionStream rs{};
         rs.n_opt_dev = dcnt + 6;
         rs.w_cap = h->grid_r2; rs.w_max = h->rsplit_max;
@@ -1325,7 +1343,6 @@ static int level_run_small(mpc_handle *h, int32_t gen_children, int32_t flags, m
         HIP_TRY(h, h->dict_d[h->dict_cur].ensure(nn * h->dict_stride_d * sizeof(double), st));
         HIP_TRY(h, h->dict_i[h->dict_cur].ensure(nn * h->dict_stride_i * sizeof(int32_t), st));
         HIP_TRY(h, h->dict_stored[h->dict_cur].ensure(nn, st));
-        HIP_TRY(h, hipMemsetAsync(h->dict_stored[h->dict_cur].p, 0, nn, st));
         dc.cur_d = h->dict_d[h->dict_cur].as<double>(); dc.cur_i = h->dict_i[h->dict_cur].as<int32_t>();
         dc.stored = h->dict_stored[h->dict_cur].as<uint8_t>();
         h->storing = true;
@@ -1394,11 +1411,9 @@ static int level_run_small(mpc_handle *h, int32_t gen_children, int32_t flags, m
     hipLaunchKernelGGL(k_histogram, dim3(std::min(blocks256, 1024)), dim3(256), 0, st, h->status.as<uint8_t>(), n, ctr);
     HIP_TRY(h, hipEventRecord(h->ev[3], st));
     static_assert(sizeof(LevelCounters) + 64 + 32 * 4 <= 4096, "LevelCounters + list lengths must fit the pinned block");
-    hipLaunchKernelGGL(k_publish_words, dim3(1), dim3(128), 0, st, reinterpret_cast<const unsigned int *>(ctr),
-                       reinterpret_cast<unsigned int *>(h->tot_dev + 16), (int)(sizeof(LevelCounters) / 4));
     int32_t *cnt_host = h->tot_host + 16 + (int)(sizeof(LevelCounters) / 4);
-    hipLaunchKernelGGL(k_publish_words, dim3(1), dim3(64), 0, st, reinterpret_cast<const unsigned int *>(dcnt),
-                       reinterpret_cast<unsigned int *>(h->tot_dev + 16 + (int)(sizeof(LevelCounters) / 4)), 32);
+    hipLaunchKernelGGL(k_publish_words2, dim3(1), dim3(128), 0, st, reinterpret_cast<const unsigned int *>(ctr), (int)(sizeof(LevelCounters) / 4),
+                       reinterpret_cast<const unsigned int *>(dcnt), 32, reinterpret_cast<unsigned int *>(h->tot_dev + 16));
     HIP_TRY(h, hipGetLastError());
     HIP_TRY(h, hipStreamSynchronize(st));   // the level's only synchronisation
     LevelCounters host_ctr;
