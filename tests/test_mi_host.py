@@ -114,16 +114,20 @@ def _scipy_lp_batch(counter):
 
     def lp_solve_batch(A, b, c, eq_flags, device=0, want_x=True):
         n_lp, m = eq_flags.shape
-        n = A.shape[1]
+        n = A.shape[-1]
         counter['lps'] += n_lp
+        counter['calls'] = counter.get('calls', 0) + 1
         counter['max_flag_bytes'] = max(counter['max_flag_bytes'], eq_flags.nbytes)
         status = numpy.zeros(n_lp, dtype=numpy.int32)
         x = numpy.zeros((n_lp, n)) if want_x else None
         obj = numpy.zeros(n_lp)
         for i in range(n_lp):
             eq = eq_flags[i].astype(bool)
-            res = linprog(numpy.zeros(n) if c is None else c, A_ub=A[~eq], b_ub=b[~eq], A_eq=A[eq] if eq.any() else None,
-                          b_eq=b[eq] if eq.any() else None, bounds=(None, None), method='highs-ds')
+            Ai = A[i] if A.ndim == 3 else A                      # per-instance or shared data, as mpc_lp_solve_batch takes it
+            bi = b[i] if numpy.ndim(b) == 2 else b
+            ci = None if c is None else (c[i] if numpy.ndim(c) == 2 else c)
+            res = linprog(numpy.zeros(n) if ci is None else ci, A_ub=Ai[~eq], b_ub=bi[~eq], A_eq=Ai[eq] if eq.any() else None,
+                          b_eq=bi[eq] if eq.any() else None, bounds=(None, None), method='highs-ds')
             status[i] = 0 if res.status == 0 else (2 if res.status == 3 else 1)
             if res.status == 0:
                 obj[i] = res.fun
@@ -197,3 +201,100 @@ def test_milp_any_feasible_and_solve_milp_with_bounded_batches(monkeypatch):
     S.MILP_BATCH_BYTES = 16
     with pytest.raises(MemoryError):
         S.solve_milp_batch(None, A, b, [[]] * 64, bins)
+
+
+# ---- LP calls of several threads posed as shared device batches (solver.LPCoalescer; the presolve of the enumeration's sub-programs) ----
+def test_lp_coalescer_poses_the_calls_of_all_threads_together(monkeypatch):
+    from concurrent.futures import ThreadPoolExecutor
+    from ppopt_amd import solver as solver_mod
+    from ppopt_amd.solver import LPCoalescer
+    counter = {'lps': 0, 'max_flag_bytes': 0}
+    monkeypatch.setattr(solver_mod._lib, 'lp_solve_batch', _scipy_lp_batch(counter))
+    rng = numpy.random.default_rng(5)
+
+    def box_lp(n, shift):      # a box around `shift`, two extra cuts; feasible, bounded
+        A = numpy.vstack([numpy.eye(n), -numpy.eye(n), rng.standard_normal((2, n))])
+        b = numpy.concatenate([shift + 1.0, 1.0 - shift, [5.0, 5.0]])
+        return A, b, rng.standard_normal(n)
+    jobs = [box_lp(3 if j % 2 else 4, rng.standard_normal(3 if j % 2 else 4) * 0.1) for j in range(10)]
+
+    def work(solver, job, extra_round):
+        A, b, c = job
+        out = [solver.solve_lp(c, A, b, [])]                                           # stage 1: one LP
+        out.append(solver.solve_lp_batch(None, A, b, [[i] for i in range(A.shape[0])]))    # stage 2: one LP per row
+        if extra_round:
+            out.append(solver.solve_lp(-c, A, b, [0]))                                 # some workers make a third call
+        return out
+    plain = Solver()
+    want = [work(plain, job, j % 3 == 0) for j, job in enumerate(jobs)]
+    calls_plain = counter['calls']
+    counter['calls'] = 0
+    co = LPCoalescer(plain, len(jobs))
+    parked = co.solver()
+
+    def worker(args):
+        j, job = args
+        try:
+            return work(parked, job, j % 3 == 0)
+        finally:
+            co.worker_done()
+    with ThreadPoolExecutor(max_workers=len(jobs)) as pool:
+        got = list(pool.map(worker, enumerate(jobs)))
+    assert counter['calls'] <= 6 < calls_plain            # three stages x two shapes at most, against 24 separate calls
+    assert co.n_calls == calls_plain
+
+    def same(a, b):
+        if a is None or b is None:
+            return a is None and b is None
+        return a.obj == b.obj and numpy.array_equal(a.sol, b.sol) and numpy.array_equal(a.active_set, b.active_set)
+    for w, g in zip(want, got):
+        assert same(w[0], g[0]) and len(w[1]) == len(g[1]) and all(same(x, y) for x, y in zip(w[1], g[1]))
+        assert len(w) == len(g) and (len(w) == 2 or same(w[2], g[2]))
+
+
+def test_lp_coalescer_hands_a_failure_to_every_parked_caller(monkeypatch):
+    from concurrent.futures import ThreadPoolExecutor
+    from ppopt_amd import solver as solver_mod
+    from ppopt_amd.solver import LPCoalescer
+
+    def broken(*a, **k):
+        raise RuntimeError('device lost')
+    monkeypatch.setattr(solver_mod._lib, 'lp_solve_batch', broken)
+    co = LPCoalescer(Solver(), 4)
+    parked = co.solver()
+    A, b = numpy.vstack([numpy.eye(2), -numpy.eye(2)]), numpy.ones(4)
+
+    def worker(_):
+        try:
+            parked.solve_lp(None, A, b, [])
+            return 'no error'
+        except RuntimeError as ex:
+            return str(ex)
+        finally:
+            co.worker_done()
+    with ThreadPoolExecutor(max_workers=4) as pool:
+        assert list(pool.map(worker, range(4))) == ['device lost'] * 4
+
+
+def test_substituted_rows_are_cached_per_program_and_follow_row_changes():
+    """MPMILP_Program._substituted_rows finds the rows with continuous / parametric content once per program; a program whose rows
+    are replaced afterwards must not reuse the old selection."""
+    import warnings
+    from ppopt_amd import MPMILP_Program
+    A = numpy.array([[1.0, 0.0, 1.0], [0.0, 0.0, 1.0], [-1.0, 0.0, 0.0], [0.0, 1.0, 0.0], [0.0, -1.0, 0.0]])
+    b = numpy.array([[2.0], [1.0], [0.0], [1.0], [0.0]])
+    F = numpy.array([[1.0], [0.0], [0.0], [0.0], [0.0]])
+
+    class NoLP(Solver):         # the constructor's presolve is not what is tested here
+        def solve_lp_batch(self, c, A, b, equality_sets):
+            return [object()] * len(equality_sets)
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        prog = MPMILP_Program(A, b, numpy.zeros((3, 1)), numpy.zeros((3, 1)), numpy.array([[1.0], [-1.0]]), numpy.array([[1.0], [1.0]]), F,
+                              binary_indices=[2], solver=NoLP(), post_process=False)
+    r0 = prog._substituted_rows([0])
+    r1 = prog._substituted_rows([1])
+    assert numpy.array_equal(r0[0], r1[0]) and not numpy.array_equal(r0[1], r1[1])      # same rows, right-hand side moved by A_bin y
+    kept_before = r0[0].shape[0]
+    prog.A = prog.A[:-1].copy(); prog.b = prog.b[:-1].copy(); prog.F = prog.F[:-1].copy()
+    assert prog._substituted_rows([0])[0].shape[0] == kept_before - 1
