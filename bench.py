@@ -345,7 +345,10 @@ def main():
                                          'algorithmic_bytes_per_launch': dom['algorithmic_bytes'] / max(dom['launches'], 1),
                                          'frac_fp64_issue': dom.get('frac_fp64_issue'), 'frac_valu_issue': dom.get('frac_valu_issue'),
                                          'frac_valu_issue_4cyc': dom.get('frac_valu_issue_4cyc'),
-                                         'traffic': dom_traffic},
+                                         'traffic': dom_traffic,
+                                         **({'note': 'this program has no register-resident kernels (its parameter set has no vertex after the presolve, DESIGN.md 6c; '
+                                                     'MPC_DEBUG_CREATE=1 prints the decision): every stage runs on the LDS-engine kernels k_verdict / k_region, '
+                                                     'whose time is kernel_ms_per_step'} if dom['total_ms'] <= 0 else {})},
                      'kernels': kern,
                      'note': 'B_alg = P + 4k + 8 + rho*R per candidate (SURVEY.md 8(d)): the shared problem block P is counted once per '
                              'candidate although it is served from L2, so `achieved` is the figure the survey defines, not measured DRAM '

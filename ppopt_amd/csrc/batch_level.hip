@@ -99,7 +99,7 @@ __global__ void __launch_bounds__(64, XQ_WAVES) m_xq(const BatchMember *__restri
     k_xq<SLOTS>(m.pf, m.fr, m.k, part_list_of(m, 3), (int)m.n, m.status, m.ctr, dq, m.nxc);
 }
 template <int NXC, int SLOTS>
-__global__ void __launch_bounds__(64, (NXC * SLOTS >= 32 ? X2_WAVES : 3)) m_x2(const BatchMember *__restrict__ tab) {
+__global__ void __launch_bounds__(64, (NXC * SLOTS >= 32 ? X2_WAVES : X2_WAVES_16)) m_x2(const BatchMember *__restrict__ tab) {
     MEMBER;
     DictCache d = m.dc;
     d.n_list_dev = m.dcnt + (m.quick_test ? 8 : 7);

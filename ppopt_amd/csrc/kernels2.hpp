@@ -819,8 +819,11 @@ MPC_GLOBAL void MPC_LB(256, XQG_WAVES) k_xq_grouped(const DevProblem *__restrict
 #ifndef X2_WAVES
 #define X2_WAVES 3
 #endif
+#ifndef X2_WAVES_16
+#define X2_WAVES_16 3   // the 16-column instantiations (168 registers, no scratch at 3 waves per SIMD; 4 waves: 64 sub-programs per launch 175.0 -> 173.4 ms on the device, config 2 unchanged -- not worth the spills)
+#endif
 template <int NXC, int SLOTS>
-MPC_GLOBAL void MPC_LB(64, (NXC * SLOTS >= 32 ? X2_WAVES : 3)) k_x2(const DevProblem *__restrict__ Pg, const int32_t *__restrict__ cands, int k,
+MPC_GLOBAL void MPC_LB(64, (NXC * SLOTS >= 32 ? X2_WAVES : X2_WAVES_16)) k_x2(const DevProblem *__restrict__ Pg, const int32_t *__restrict__ cands, int k,
                                               const int32_t *__restrict__ list, int n_list, uint8_t *__restrict__ status,
                                               LevelCounters *__restrict__ ctr, DictCache dc) {
     const DevProblem &P = *Pg;

@@ -33,6 +33,7 @@ for rep in range(3):
     t4 = time.perf_counter()
     print(f'rep {rep}: {len(subs)} sub-programs, {sum(len(s) for s in sols)} regions; substitute+presolve {1e3*(t1-t0):.1f} ms, set-up {1e3*(t2-t1):.1f}, '
           f'solve_many {1e3*(t3-t2):.1f}, release {1e3*(t4-t3):.1f}')
+    print(f'   device, shared levels: {sum(p.get("ms_launches", 0) for p in prof):.1f} ms')
     print('   levels: ' + ', '.join(f"L{p['depth']}: {p['members']}/{p['shared_launches']} members, {p['candidates']} cand, {p['regions']} reg, "
                                     f"launches {p.get('ms_launches', 0):.2f} ms, wait {p.get('ms_wait', 0):.2f}, wall {p['ms_wall']:.2f} ms" for p in prof))
 from ppopt_amd.mp_solvers import mpmiqp_enumeration  # noqa: E402
