@@ -452,6 +452,37 @@ def main():
                                                    for p in prof_mi],
                                  'one_by_one': {'form': 'MPC_NO_BATCH=1: one handle per fixation, eight host threads', 'ms': 1e3 * best_1,
                                                 'regions': n_reg_1, 'sub_programs_per_s': n_fix / best_1}}
+    if rank == 0 and not distributed and args.mi > 0:
+        # Many small programs at once (tools/many_programs.py): 128 random mpQPs generate_mpqp_data(6, 3, 12, seed) -- each a latency-bound
+        # chain of small levels on its own -- one after the other (solve) and together (solve_many: one launch per stage and level for
+        # all of them, mpc_level_run_batch).  Same regions either way (tests/test_gpu_batch.py).  Not part of `value`.
+        from ppopt_amd import MPQP_Program, problem_generator as pgm
+        from ppopt_amd.mp_solvers import mpqp_hip_combinatorial as mhc
+        with warnings.catch_warnings():
+            warnings.simplefilter('ignore')
+            small = []
+            for seed in range(128):
+                dd = pgm.generate_mpqp_data(6, 3, 12, 5000 + seed)
+                small.append(MPQP_Program(dd['A'], dd['b'], dd['c'], dd['H'], dd['Q'], dd['A_t'], dd['b_t'], dd['F']))
+            for ps in small:
+                ps.engine(local_rank)
+            t_one = t_many = float('inf')
+            for _ in range(3):
+                tq = time.perf_counter()
+                sols_one = [mhc.solve(ps, device=local_rank) for ps in small]
+                t_one = min(t_one, time.perf_counter() - tq)
+                prof_sm = []
+                tq = time.perf_counter()
+                sols_many = mhc.solve_many(small, device=local_rank, profile=prof_sm)
+                t_many = min(t_many, time.perf_counter() - tq)
+            for ps in small:
+                ps.release_engine()
+        out['many_programs'] = {'workload': '128 x generate_mpqp_data(6,3,12,seed=5000..5127), complete solves', 'programs': len(small),
+                                'regions': int(sum(len(sv) for sv in sols_many)), 'candidates': int(sum(pp['candidates'] for pp in prof_sm)),
+                                'same_region_counts': bool(all(len(a) == len(b) for a, b in zip(sols_one, sols_many))),
+                                'one_by_one_ms': 1e3 * t_one, 'together_ms': 1e3 * t_many, 'speedup': t_one / t_many,
+                                'device_ms_shared_levels': float(sum(pp.get('ms_launches', 0.0) for pp in prof_sm)),
+                                'programs_per_s_together': len(small) / t_many}
     if rank == 0 and not distributed and args.complete > 0 and args.workload in ('c4', 'c3', 'c2', 'c2x20'):
         # The COMPLETE explicit solution of the same program by the connected-graph traversal (mpqp_algorithm.graph, reference
         # mp_solvers/mpqp_graph.py) on the same kernels, wave / visited set / neighbours resident on the device.  Not part of `value`.

@@ -166,6 +166,11 @@ int mpc_level_status(mpc_handle *h, uint8_t *status_host);                      
  * (optional) = members that went through the shared launches.  stats (optional): n_handles entries. */
 int mpc_level_run_batch(mpc_handle **handles, int32_t n_handles, const int32_t *gen_children, int32_t flags, mpc_level_stats *stats,
                         int32_t *n_batched);
+/* For drivers that hold many handles: the device memory (GB) the next level of h's frontier will hold in a batch (what is charged
+ * against MPC_BATCH_BUDGET_GB), and mpc_trim: an idle handle gives its level buffers (frontier, lists, region records, dictionary
+ * cache, pruned list) back to the library's pool -- the program stays, a later solve allocates again. */
+double mpc_level_memory_gb(const mpc_handle *h, int32_t gen_children);
+int mpc_trim(mpc_handle *h);
 /* The two halves of mpc_level_run_batch: _start queues the shared launches and returns (*token owns the state; the handles must not
  * be used until _wait), _wait synchronises, completes every member and runs the members outside the shared launches.  A token is
  * consumed by exactly one _wait. */

@@ -119,6 +119,10 @@ def load():
         'mpc_level_run': (ctypes.c_int, [H, ctypes.c_int32, ctypes.POINTER(LevelStats)]),
         'mpc_level_run_ex': (ctypes.c_int, [H, ctypes.c_int32, ctypes.c_int32, ctypes.POINTER(LevelStats)]),
         'mpc_level_run_batch': (ctypes.c_int, [ctypes.POINTER(H), ctypes.c_int32, ctypes.POINTER(ctypes.c_int32), ctypes.c_int32, ctypes.POINTER(LevelStats), ctypes.POINTER(ctypes.c_int32)]),
+        'mpc_level_batch_start': (ctypes.c_int, [ctypes.POINTER(H), ctypes.c_int32, ctypes.POINTER(ctypes.c_int32), ctypes.c_int32, ctypes.POINTER(ctypes.c_void_p)]),
+        'mpc_level_batch_wait': (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(LevelStats), ctypes.POINTER(ctypes.c_int32)]),
+        'mpc_level_memory_gb': (ctypes.c_double, [H, ctypes.c_int32]),
+        'mpc_trim': (ctypes.c_int, [H]),
         'mpc_level_status': (ctypes.c_int, [H, _u8p]),
         'mpc_level_start': (ctypes.c_int, [H, ctypes.c_int32, ctypes.c_int32]),
         'mpc_level_stream_info': (ctypes.c_int, [H, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_void_p),
@@ -178,7 +182,7 @@ EXPORTED_SYMBOLS = ['mpc_device_count', 'mpc_version', 'mpc_last_global_error', 
                     'mpc_last_error', 'mpc_mask_words', 'mpc_set_region_overlap', 'mpc_program_block', 'mpc_region_doubles', 'mpc_region_ints', 'mpc_lds_bytes', 'mpc_stream',
                     'mpc_frontier_root', 'mpc_frontier_set', 'mpc_frontier_set_device', 'mpc_frontier_info',
                     'mpc_frontier_get', 'mpc_pruned_clear', 'mpc_pruned_add', 'mpc_pruned_add_device',
-                    'mpc_pruned_count', 'mpc_pruned_get', 'mpc_level_run', 'mpc_level_run_ex', 'mpc_level_run_batch', 'mpc_level_batch_start', 'mpc_level_batch_wait', 'mpc_level_regions_slots_nowait', 'mpc_level_batch_fetch', 'mpc_level_status', 'mpc_level_start', 'mpc_level_stream_info', 'mpc_level_chunk_wait', 'mpc_level_wait', 'mpc_level_stream_fixup', 'mpc_base_result', 'mpc_level_regions', 'mpc_compact_strides',
+                    'mpc_pruned_count', 'mpc_pruned_get', 'mpc_level_run', 'mpc_level_run_ex', 'mpc_level_run_batch', 'mpc_level_memory_gb', 'mpc_trim', 'mpc_level_batch_start', 'mpc_level_batch_wait', 'mpc_level_regions_slots_nowait', 'mpc_level_batch_fetch', 'mpc_level_status', 'mpc_level_start', 'mpc_level_stream_info', 'mpc_level_chunk_wait', 'mpc_level_wait', 'mpc_level_stream_fixup', 'mpc_base_result', 'mpc_level_regions', 'mpc_compact_strides',
                     'mpc_level_regions_compact', 'mpc_frontier_shard', 'mpc_level_slots', 'mpc_level_regions_slots', 'mpc_level_regions_slots_async', 'mpc_sync', 'mpc_host_alloc', 'mpc_host_free', 'mpc_locator_create', 'mpc_locator_query', 'mpc_locator_destroy', 'mpc_locator_set_adjacency', 'mpc_level_children', 'mpc_level_children_device', 'mpc_level_pruned_new',
                     'mpc_level_pruned_new_device', 'mpc_level_regions_device', 'mpc_frontier_advance', 'mpc_qp_solve_batch', 'mpc_facet_centres', 'mpc_graph_begin', 'mpc_graph_wave', 'mpc_graph_group_run', 'mpc_graph_wave_close', 'mpc_check_level', 'mpc_lp_solve_batch']
 
@@ -372,6 +376,14 @@ class Engine:
                                              ctypes.byref(st)), 'mpc_level_run')
         self._last = st
         return st
+
+    def level_memory_gb(self, gen_children: bool) -> float:
+        """Device memory (GB) the next level of this engine's frontier holds in a batch (mpc_level_memory_gb)."""
+        return float(self._L.mpc_level_memory_gb(self._h, int(bool(gen_children))))
+
+    def trim(self):
+        """Gives the level buffers back to the pool (mpc_trim); the program stays usable."""
+        self._check(self._L.mpc_trim(self._h), 'mpc_trim')
 
     @staticmethod
     def level_batch_start(engines, gen_children, keep_lowdim: bool = False):

@@ -483,6 +483,7 @@ void lu_solve_host(const std::vector<double> &LU, const std::vector<int> &perm, 
 
 static int create_fill(const mpc_problem *p, int32_t device, void *stream, mpc_handle *h);
 static void stream_release(mpc_handle *h);
+static double batch_level_gb(const mpc_handle *h, int32_t gen_children);
 static int lp_batch_impl(int32_t device, int64_t n_lp, int32_t m, int32_t n, const double *A, int32_t shared_A, const double *b,
                          int32_t shared_b, const double *c, int32_t shared_c, const uint8_t *eq, int32_t *status, double *x,
                          double *obj, int32_t *iters, int32_t *tight);
@@ -963,6 +964,31 @@ int mpc_destroy(mpc_handle *h) {
     delete h;
     return MPC_OK;
 }
+
+// Gives the level buffers of an idle handle (frontier, children, statuses, lists, region records, both generations of the dictionary
+// cache, the pruned list ...) back to the pool: the program's own blocks stay, a later level allocates again.  For a driver that holds
+// many handles at once (mpc_level_run_batch) and wants the memory of those that are finished for the ones that are not.
+int mpc_trim(mpc_handle *h) {
+    if (!h) return MPC_ERR_INVALID;
+    { std::lock_guard<std::mutex> lk(h->wm); if (h->w_busy) return fail(h, MPC_ERR_STATE, "a level started with mpc_level_start is still running"); }
+    HIP_TRY(h, hipSetDevice(h->device));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    if (h->stream2) HIP_TRY(h, hipStreamSynchronize(h->stream2));
+    if (h->stream3) HIP_TRY(h, hipStreamSynchronize(h->stream3));
+    stream_release(h);
+    for (DevBuf *b : {&h->frontier, &h->children, &h->status, &h->pruned, &h->flag, &h->pos, &h->opt_list, &h->childmask, &h->count, &h->offset, &h->recd, &h->reci,
+                      &h->sums, &h->retry_list, &h->headd, &h->headi, &h->epool, &h->facet_flags, &h->kkt_code, &h->kkt_L, &h->xq_groups, &h->theta_list, &h->vretry_list,
+                      &h->status_tmp, &h->part_counts, &h->part_lists, &h->kept_g, &h->done_g, &h->dict_d[0], &h->dict_d[1], &h->dict_i[0], &h->dict_i[1],
+                      &h->dict_stored[0], &h->dict_stored[1], &h->parent_slot, &h->parent_slot_next}) b->release();
+    for (HostBuf *b : {&h->st_list, &h->st_status, &h->st_hd, &h->st_hi, &h->st_pool, &h->st_fxd, &h->st_fxi, &h->st_rlist, &h->st_flags}) b->release();
+    h->n = 0; h->k = 0; h->n_pruned = 0; h->n_pruned_extra = 0; h->level_done = false;
+    h->have_prev_dict = false; h->have_parent_slot = false;
+    return MPC_OK;
+}
+// Device memory (GB) the next level of the handle's frontier will hold on the no-round-trip path (buffers sized by the number of
+// candidates: region records, children, two generations of the dictionary cache): what mpc_level_batch_start charges against
+// MPC_BATCH_BUDGET_GB.
+double mpc_level_memory_gb(const mpc_handle *h, int32_t gen_children) { return h ? batch_level_gb(h, gen_children) : 0.0; }
 
 int32_t mpc_mask_words(const mpc_handle *h) { return h ? h->mw : MPC_MASK_WORDS; }
 int mpc_program_block(mpc_handle *h, int32_t which, double *out, int64_t cap, int64_t *n_out) {

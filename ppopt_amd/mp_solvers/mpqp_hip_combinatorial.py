@@ -231,11 +231,32 @@ def solve_many(programs, device: int = 0, max_levels: Optional[int] = None, prun
         depth_max.append(d if max_levels is None else min(d, max_levels))
         e.pruned_clear()
         e.frontier_root()
+    # Device memory: a member's level holds buffers sized by its number of candidates (region records, children, two generations of
+    # the dictionary cache: Engine.level_memory_gb).  Members whose next level does not fit the budget next to the others are PARKED
+    # at their current level and resumed when the running ones have finished (and given their level buffers back: Engine.trim).
+    budget_gb = 0.6 * float(os.environ.get('MPC_BATCH_BUDGET_GB', '160'))      # headroom: size classes round up, the pool keeps free blocks
+    depth_of = [0] * len(engs)
+    parked: List[int] = []
+
+    def gen_of(i):
+        return depth_of[i] + 1 != depth_max[i]
+
+    def admit(candidates):
+        """The members of ``candidates`` that run their next level together (in index order); the others go to ``parked``."""
+        need = {i: engs[i].level_memory_gb(gen_of(i)) for i in candidates}
+        take, used = [], 0.0
+        for i in sorted(candidates, key=lambda j: (need[j], j)):
+            if take and used + need[i] > budget_gb:
+                parked.append(i)
+            else:
+                take.append(i)
+                used += need[i]
+        return sorted(take)
     try:
-        active = [i for i in range(len(engs)) if depth_max[i] > 0]
-        depth = 0
-        gens = [depth + 1 != depth_max[i] for i in active]
+        active = admit([i for i in range(len(engs)) if depth_max[i] > 0])
+        gens = [gen_of(i) for i in active]
         token = Engine.level_batch_start([engs[i] for i in active], gens, keep_lowdim=not prune_lowdim) if active else None
+        level_no = 0
         while active:
             t0 = time.perf_counter()
             stats, n_shared = Engine.level_batch_wait(token)
@@ -244,16 +265,24 @@ def solve_many(programs, device: int = 0, max_levels: Optional[int] = None, prun
             with_regions = [i for i, st in zip(active, stats) if st.n_regions]
             fetched = list(zip(with_regions, Engine.level_batch_fetch([engs[i] for i in with_regions])))
             nxt = [i for i, st, gen in zip(active, stats, gens) if gen and st.n_children]
+            done = [i for i in active if i not in set(nxt)]
             for i in nxt:
                 engs[i].frontier_advance()
-            # ... the next level is started for all members that still have a frontier (its preparation completes the copies) ...
-            gens_next = [depth + 2 != depth_max[i] for i in nxt]
+                depth_of[i] += 1
+            candidates, parked[:] = nxt + parked, []
+            nxt = admit(candidates)     # by the size of everybody's NEXT level
+            pressure = bool(parked)
+            if pressure:
+                for i in done:
+                    engs[i].trim()      # (synchronises the member: its copies are complete) its level buffers serve the waiting members
+            # ... the next level is started for all members that have a frontier and fit (its preparation completes the copies) ...
+            gens_next = [gen_of(i) for i in nxt]
             if nxt:
                 token = Engine.level_batch_start([engs[i] for i in nxt], gens_next, keep_lowdim=not prune_lowdim)
-            still = set(nxt)
-            for i, _ in fetched:
-                if i not in still:
-                    engs[i].sync()      # a member that has just finished: nothing else completes its copies
+            if not pressure:
+                for i in done:
+                    if any(i == j for j, _ in fetched):
+                        engs[i].sync()  # a member that has just finished: nothing else completes its copies
             # ... and the region objects of the finished level are built while the device works on it
             for i, (hd, hi, er, kk) in fetched:
                 eng = engs[i]
@@ -261,12 +290,12 @@ def solve_many(programs, device: int = 0, max_levels: Optional[int] = None, prun
                 batch = RegionBatch(hd, hi, er, eng.n_x, eng.n_t, eng.n_c, eng.n_tc, kk, slots)
                 sols[i].region_batches.append(batch)
                 sols[i].critical_regions.extend(batch.regions())
+            level_no += 1
             if profile is not None:
-                profile.append({'depth': depth + 1, 'members': len(active), 'shared_launches': n_shared,
+                profile.append({'depth': level_no, 'members': len(active), 'shared_launches': n_shared, 'parked': len(parked),
                                 'candidates': int(sum(int(st.n) for st in stats)), 'regions': int(sum(int(st.n_regions) for st in stats)),
                                 'ms_launches': float(stats[0].ms_total) if stats else 0.0, 'ms_wait': t_wait * 1e3, 'ms_wall': (time.perf_counter() - t0) * 1e3})
             active, gens = nxt, gens_next
-            depth += 1
         for e in engs:
             e.sync()
         # the base active set of every program (driver :142-146), as one more shared level of one candidate each

@@ -248,3 +248,20 @@ def test_two_batches_at_once_from_two_threads():
                 assert list(r1.active_set) == list(r2.active_set), n
                 for fld in ('A', 'b', 'C', 'd', 'E', 'f'):
                     assert numpy.asarray(getattr(r1, fld)).tobytes() == numpy.asarray(getattr(r2, fld)).tobytes(), (n, fld)
+
+
+def test_solve_many_parks_members_beyond_the_memory_budget(monkeypatch):
+    """With a budget that holds one or two members' levels at a time, the others wait at their current level and are resumed when the
+    running ones have finished and given their buffers back: same Solutions as the separate solves."""
+    from ppopt_amd.mp_solvers import mpqp_hip_combinatorial
+    one = [mpqp_hip_combinatorial.solve(p) for p in _programs()]
+    monkeypatch.setenv('MPC_BATCH_BUDGET_GB', '0.002')
+    prof = []
+    many = mpqp_hip_combinatorial.solve_many(_programs(), profile=prof)
+    assert max(p.get('parked', 0) for p in prof) > 0
+    for n, (a, b) in enumerate(zip(one, many)):
+        assert len(a.critical_regions) == len(b.critical_regions) > 0, n
+        for r1, r2 in zip(a.critical_regions, b.critical_regions):
+            assert list(r1.active_set) == list(r2.active_set), n
+            for fld in ('A', 'b', 'C', 'd', 'E', 'f'):
+                assert numpy.asarray(getattr(r1, fld)).tobytes() == numpy.asarray(getattr(r2, fld)).tobytes(), (n, fld)
