@@ -169,6 +169,7 @@ int mpc_level_run_batch(mpc_handle **handles, int32_t n_handles, const int32_t *
 /* For drivers that hold many handles: the device memory (GB) the next level of h's frontier will hold in a batch (what is charged
  * against MPC_BATCH_BUDGET_GB), and mpc_trim: an idle handle gives its level buffers (frontier, lists, region records, dictionary
  * cache, pruned list) back to the library's pool -- the program stays, a later solve allocates again. */
+int mpc_frontier_advance_batch(mpc_handle **handles, int32_t n_handles);   /* mpc_frontier_advance for every handle of a list */
 double mpc_level_memory_gb(const mpc_handle *h, int32_t gen_children);
 int mpc_trim(mpc_handle *h);
 /* The two halves of mpc_level_run_batch: _start queues the shared launches and returns (*token owns the state; the handles must not

@@ -122,6 +122,7 @@ def load():
         'mpc_level_batch_start': (ctypes.c_int, [ctypes.POINTER(H), ctypes.c_int32, ctypes.POINTER(ctypes.c_int32), ctypes.c_int32, ctypes.POINTER(ctypes.c_void_p)]),
         'mpc_level_batch_wait': (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(LevelStats), ctypes.POINTER(ctypes.c_int32)]),
         'mpc_level_memory_gb': (ctypes.c_double, [H, ctypes.c_int32]),
+        'mpc_frontier_advance_batch': (ctypes.c_int, [ctypes.POINTER(H), ctypes.c_int32]),
         'mpc_trim': (ctypes.c_int, [H]),
         'mpc_level_status': (ctypes.c_int, [H, _u8p]),
         'mpc_level_start': (ctypes.c_int, [H, ctypes.c_int32, ctypes.c_int32]),
@@ -182,7 +183,7 @@ EXPORTED_SYMBOLS = ['mpc_device_count', 'mpc_version', 'mpc_last_global_error', 
                     'mpc_last_error', 'mpc_mask_words', 'mpc_set_region_overlap', 'mpc_program_block', 'mpc_region_doubles', 'mpc_region_ints', 'mpc_lds_bytes', 'mpc_stream',
                     'mpc_frontier_root', 'mpc_frontier_set', 'mpc_frontier_set_device', 'mpc_frontier_info',
                     'mpc_frontier_get', 'mpc_pruned_clear', 'mpc_pruned_add', 'mpc_pruned_add_device',
-                    'mpc_pruned_count', 'mpc_pruned_get', 'mpc_level_run', 'mpc_level_run_ex', 'mpc_level_run_batch', 'mpc_level_memory_gb', 'mpc_trim', 'mpc_level_batch_start', 'mpc_level_batch_wait', 'mpc_level_regions_slots_nowait', 'mpc_level_batch_fetch', 'mpc_level_status', 'mpc_level_start', 'mpc_level_stream_info', 'mpc_level_chunk_wait', 'mpc_level_wait', 'mpc_level_stream_fixup', 'mpc_base_result', 'mpc_level_regions', 'mpc_compact_strides',
+                    'mpc_pruned_count', 'mpc_pruned_get', 'mpc_level_run', 'mpc_level_run_ex', 'mpc_level_run_batch', 'mpc_frontier_advance_batch', 'mpc_level_memory_gb', 'mpc_trim', 'mpc_level_batch_start', 'mpc_level_batch_wait', 'mpc_level_regions_slots_nowait', 'mpc_level_batch_fetch', 'mpc_level_status', 'mpc_level_start', 'mpc_level_stream_info', 'mpc_level_chunk_wait', 'mpc_level_wait', 'mpc_level_stream_fixup', 'mpc_base_result', 'mpc_level_regions', 'mpc_compact_strides',
                     'mpc_level_regions_compact', 'mpc_frontier_shard', 'mpc_level_slots', 'mpc_level_regions_slots', 'mpc_level_regions_slots_async', 'mpc_sync', 'mpc_host_alloc', 'mpc_host_free', 'mpc_locator_create', 'mpc_locator_query', 'mpc_locator_destroy', 'mpc_locator_set_adjacency', 'mpc_level_children', 'mpc_level_children_device', 'mpc_level_pruned_new',
                     'mpc_level_pruned_new_device', 'mpc_level_regions_device', 'mpc_frontier_advance', 'mpc_qp_solve_batch', 'mpc_facet_centres', 'mpc_graph_begin', 'mpc_graph_wave', 'mpc_graph_group_run', 'mpc_graph_wave_close', 'mpc_check_level', 'mpc_lp_solve_batch']
 
@@ -377,6 +378,16 @@ class Engine:
         self._last = st
         return st
 
+    @staticmethod
+    def frontier_advance_batch(engines):
+        """``frontier_advance`` for many engines with one call into the library (mpc_frontier_advance_batch)."""
+        B = len(engines)
+        if B:
+            hs = (ctypes.c_void_p * B)(*[e._h for e in engines])
+            rc = engines[0]._L.mpc_frontier_advance_batch(hs, B)
+            if rc != 0:
+                Engine._raise_for(engines, rc)
+
     def level_memory_gb(self, gen_children: bool) -> float:
         """Device memory (GB) the next level of this engine's frontier holds in a batch (mpc_level_memory_gb)."""
         return float(self._L.mpc_level_memory_gb(self._h, int(bool(gen_children))))
@@ -409,12 +420,9 @@ class Engine:
         rc = engines[0]._L.mpc_level_batch_wait(tok, stats, ctypes.byref(nb))
         if rc != 0:
             Engine._raise_for(engines, rc)
-        out = []
-        for e, st in zip(engines, stats):
-            c = LevelStats()
-            ctypes.memmove(ctypes.byref(c), ctypes.byref(st), ctypes.sizeof(LevelStats))
-            e._last = c
-            out.append(c)
+        out = list(stats)               # elements are views that keep the array alive
+        for e, st in zip(engines, out):
+            e._last = st
         return out, int(nb.value)
 
     @staticmethod

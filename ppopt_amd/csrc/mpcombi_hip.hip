@@ -2887,6 +2887,11 @@ int mpc_frontier_advance(mpc_handle *h) {
     h->n_children = 0; h->n_pruned_new = 0; h->n_regions = 0; h->n_opt = 0;
     return MPC_OK;
 }
+int mpc_frontier_advance_batch(mpc_handle **hs, int32_t n_handles) {
+    if (!hs || n_handles < 0) return MPC_ERR_INVALID;
+    for (int i = 0; i < n_handles; ++i) { const int rc = mpc_frontier_advance(hs[i]); if (rc != MPC_OK) return rc; }
+    return MPC_OK;
+}
 
 }  // extern "C"
 

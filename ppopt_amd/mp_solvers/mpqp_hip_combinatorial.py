@@ -266,11 +266,14 @@ def solve_many(programs, device: int = 0, max_levels: Optional[int] = None, prun
             fetched = list(zip(with_regions, Engine.level_batch_fetch([engs[i] for i in with_regions])))
             nxt = [i for i, st, gen in zip(active, stats, gens) if gen and st.n_children]
             done = [i for i in active if i not in set(nxt)]
+            Engine.frontier_advance_batch([engs[i] for i in nxt])
             for i in nxt:
-                engs[i].frontier_advance()
                 depth_of[i] += 1
-            candidates, parked[:] = nxt + parked, []
-            nxt = admit(candidates)     # by the size of everybody's NEXT level
+            # admission by the size of everybody's NEXT level; skipped while the frontiers are far from the budget (128 KB per candidate
+            # is more than a level of the register-resident kernels can hold per candidate: two dictionary records of 32 x 128 doubles)
+            if parked or 128e-6 * sum(int(st.n_children) for st in stats) > 0.25 * budget_gb:
+                candidates, parked[:] = nxt + parked, []
+                nxt = admit(candidates)
             pressure = bool(parked)
             if pressure:
                 for i in done:

@@ -18,6 +18,18 @@ GOLDEN = os.path.join(ROOT, 'tests', 'golden')
 
 def pytest_configure(config):
     config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
+    # A test that hangs (a kernel that never ends, a lost wake-up) must FAIL with the stacks of all threads instead of stalling the
+    # run: pytest-timeout, when it is installed and the command line does not set its own limit.  The longest tests take ~20 s
+    # on the GPU box and ~2 min in the build container (the C-ABI layout test compiles).
+    # (applied per item below, through the plugin's own marker)
+
+
+def pytest_collection_modifyitems(config, items):
+    if not config.pluginmanager.hasplugin('timeout') or getattr(config.option, 'timeout', None):
+        return
+    for item in items:
+        if item.get_closest_marker('timeout') is None:
+            item.add_marker(pytest.mark.timeout(900, method='thread'))
 
 
 # ---- knife-edge exceptions: explicit, per golden, and counted ----------------------------------------------------------
