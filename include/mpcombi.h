@@ -159,8 +159,10 @@ int mpc_level_status(mpc_handle *h, uint8_t *status_host);                      
  * binary fixations one sub-program at a time).  handles[0..n_handles) are distinct programs on one device, each with its own
  * resident frontier; gen_children[i] as in mpc_level_run; flags: MPC_LEVEL_KEEP_LOWDIM.  Every stage of the level is ONE launch for
  * all members (blockIdx.y = member, arguments from a table in device memory), the host synchronises once, and each member is left
- * exactly in the state mpc_level_run would have left it -- same kernels' bodies, same lists, bit-identical statuses, records,
- * children and pruned masks; afterwards every handle is used on its own as usual (mpc_level_regions_slots, mpc_frontier_advance,
+ * in the state mpc_level_run would have left it -- same kernels' bodies, same lists: identical statuses, children and pruned masks,
+ * and bit-identical region records except for the rare candidates that turn out optimal only after the theta stage (built here by
+ * the register-resident region kernel with all others, by the LDS-engine kernel in the single-program form: same regions, coefficients
+ * equal to ~1e-10, see csrc/batch_level.hpp); afterwards every handle is used on its own as usual (mpc_level_regions_slots, mpc_frontier_advance,
  * ...).  Members the batch form does not cover (no register-resident LP instantiation, MPC_NO_SMALLPATH=1, a level that needs the
  * LDS-engine region kernel or has a late optimal candidate) are run by mpc_level_run's own paths inside this call; *n_batched
  * (optional) = members that went through the shared launches.  stats (optional): n_handles entries. */

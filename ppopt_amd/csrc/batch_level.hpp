@@ -5,7 +5,13 @@
 // level -- KKT solves, theta LPs, partitions, (x,theta) LPs, region construction, pruned masks, children -- is ONE launch whose
 // blockIdx.y selects the member program and whose arguments come from a table in device memory (one BatchMember per program),
 // instead of one launch per stage and program.  The kernels' bodies are the single-program kernels of kernels.hpp / kernels2.hpp,
-// statement for statement (MPC_GLOBAL, kernels.hpp): a member's level computes bit for bit what mpc_level_run computes for it.
+// statement for statement (MPC_GLOBAL, kernels.hpp).  A member's level computes what mpc_level_run computes for it: bit for bit the same
+// statuses, children, pruned masks and region records, with ONE qualification.  A single program launches its region stage on the
+// candidates the theta stage found optimal and hands the few that turn out optimal later (a re-solved doubtful (x,theta) run) to the
+// LDS-engine region kernel; here the region stage comes last and builds all of them with k_region2, and the number of wavefronts
+// sharing a candidate follows the larger count.  Those regions are the same sets with coefficients equal to ~1e-10; a sliver facet
+// may be kept by one form and dropped by the other (tools/fuzz_batch.py: 599 random programs, 1,217,481 regions -- 2 regions with a
+// different facet list, 3 with coefficients differing by at most 6.5e-11, all others bit-identical).
 //
 // The level is the no-round-trip form of mpcombi_hip.hip (level_run_small): list lengths live in device memory, launches are sized
 // by the members' candidate counts, the host synchronises once per level for ALL members.  Members whose kernels are different

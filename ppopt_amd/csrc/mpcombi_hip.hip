@@ -1168,11 +1168,11 @@ static int launch_region_v1(mpc_handle *h, const int32_t *list, long long n_list
     HIP_TRY(h, h->recd.ensure((size_t)n_list * h->rec_d * sizeof(double), st));
     HIP_TRY(h, h->reci.ensure((size_t)n_list * h->rec_i * sizeof(int32_t), st));
     const long long rows_t = h->n_c - h->n_eq + h->n_tc;
-    const bool split = h->n_t > 1 && n_list <= 2LL * h->grid_r;
+    const bool split = h->n_t > 1 && rows_t > 0 && n_list <= 2LL * h->grid_r;
     HIP_TRY(h, hipMemsetAsync(&ctr->work_region, 0, sizeof(unsigned int), st));
     if (split) {
         HIP_TRY(h, h->facet_flags.ensure((size_t)n_list * rows_t, st));
-        hipLaunchKernelGGL((k_region<RG_FACET>), dim3((unsigned)std::min<long long>(n_list * rows_t, 4LL * h->grid_r)), dim3(64), h->lds_r, st, h->Pr,
+        hipLaunchKernelGGL((k_region<RG_FACET>), dim3((unsigned)std::max<long long>(1, std::min<long long>(n_list * rows_t, 4LL * h->grid_r))), dim3(64), h->lds_r, st, h->Pr,   // (a program without inactive rows: rows_t = 0)
                            h->frontier.as<int32_t>(), k, list, (int)n_list, h->status.as<uint8_t>(), h->recd.as<double>(), h->reci.as<int32_t>(),
                            h->rec_d, h->rec_i, ctr, h->facet_flags.as<uint8_t>());
         HIP_TRY(h, hipMemsetAsync(&ctr->work_region, 0, sizeof(unsigned int), st));

@@ -8,7 +8,7 @@
 
 With a combinatorial ``cont_algorithm`` (the default) the sub-programs are solved TOGETHER, level by level, every stage of a
 level being one launch for all of them (``mpqp_hip_combinatorial.solve_many`` -> mpc_level_run_batch, "several programs per
-launch"); the regions are those of the one-by-one solves, bit for bit.  ``MPC_NO_BATCH=1`` keeps the one-by-one form below.
+launch"); the regions are those of the one-by-one solves (bit for bit up to the qualification in csrc/batch_level.hpp).  ``MPC_NO_BATCH=1`` keeps the one-by-one form below.
 
 ``num_cores`` keeps its meaning of "sub-problems in flight": the reference maps them over a process pool
 (mpmiqp_enumeration.py:46-50); here each in-flight sub-problem is a host thread driving its own device handle and

@@ -213,7 +213,8 @@ def solve_many(programs, device: int = 0, max_levels: Optional[int] = None, prun
     """Solves SEVERAL programs together, level by level: every stage of a level is one launch for all programs that still have a
     frontier (``Engine.level_run_batch`` -> mpc_level_run_batch, include/mpcombi.h; SURVEY.md 8(f)2, reference caller
     mp_solvers/mpmiqp_enumeration.py:41-50, which maps solve_mpqp over the sub-programs).  Each program's result is the one
-    ``solve`` gives for it alone -- the same kernels' bodies on the same lists: the same regions in the same order, bit for bit.
+    ``solve`` gives for it alone -- the same kernels' bodies on the same lists: the same regions, bit for bit except for the rare candidates
+    that turn out optimal only after the theta stage (csrc/batch_level.hpp: built by another region kernel there, coefficients equal to ~1e-10).
     ``profile``: receives one dict per level (members, members that shared the launches, candidates, regions, wall time)."""
     from .._lib import Engine, MpcCapacityError
     programs = list(programs)

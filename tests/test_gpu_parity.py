@@ -1065,3 +1065,19 @@ def test_all_drivers_and_consumers_agree_on_random_programs():
     finally:
         Solution.WALK_MIN_REGIONS = old_min
     assert n_walk >= 6
+
+
+def test_program_of_one_equality_row_and_no_parameter_rows():
+    """Edge of the input space (found by tools/fuzz_batch.py): a single row, an equality, and an EMPTY parameter set description
+    (A_t with zero rows).  No row can be inactive, a region has no boundary rows: the solve must come back (the base
+    active set is optimal everywhere; the Chebyshev LP of a region without rows is unbounded, which the reference's
+    is_full_dimensional reports as "no region") instead of failing on an empty launch."""
+    from ppopt_amd import _lib
+    rng = numpy.random.default_rng(4)
+    nx, nt = 4, 5
+    R = rng.standard_normal((nx, nx))
+    eng = _lib.Engine(rng.standard_normal((1, nx)), numpy.ones((1, 1)), rng.standard_normal((1, nt)), rng.standard_normal((nx, 1)),
+                      rng.standard_normal((nx, nt)), R.T @ R + numpy.eye(nx), numpy.zeros((0, nt)), numpy.zeros((0, 1)), 1)
+    status, rd, ri, _, _ = eng.check_level(numpy.zeros((1, 1), dtype=numpy.int32), numpy.zeros((0, 2), dtype=numpy.uint64), False)
+    assert status.tolist() == [2] and len(rd) == 0      # optimal, no (bounded) region
+    eng.close()
