@@ -26,6 +26,7 @@ from . import mpqp_hip_combinatorial
 from .solve_mpqp import _COMBINATORIAL, mpqp_algorithm, solve_mpqp
 
 BATCH_CHUNKS = int(os.environ.get('MPC_BATCH_CHUNKS', '1'))   # chunks of fixations solved together (see below)
+MAX_BATCH = int(os.environ.get('MPC_MAX_BATCH', '256'))       # most sub-programs alive at once (one host thread each while they are constructed)
 
 
 def solve_mpmiqp_enumeration(program, num_cores: int = -1,
@@ -72,17 +73,36 @@ def solve_mpmiqp_enumeration(program, num_cores: int = -1,
                 sub.solver = program.solver
                 sub.engine(device)
                 return sub
+            # exactly one thread per fixation, all alive until every construction is through: the coalescer counts on each of them
+            # reaching its next LP call (an executor may run two constructions on one thread, one after the other)
+            import threading
+            results, errors = [None] * len(fixes), []
+
+            def run(j):
+                try:
+                    results[j] = one(fixes[j])
+                except BaseException as ex:        # re-raised below, in the caller's thread
+                    errors.append(ex)
             with warnings.catch_warnings():        # one filter around all threads (catch_warnings is not thread-safe)
                 warnings.simplefilter('ignore')
-                with ThreadPoolExecutor(max_workers=len(fixes)) as inner:
-                    return list(inner.map(one, fixes))
+                threads = [threading.Thread(target=run, args=(j,)) for j in range(len(fixes))]
+                for th in threads:
+                    th.start()
+                for th in threads:
+                    th.join()
+            if errors:
+                for sub in results:
+                    if sub is not None:
+                        sub.release_engine()
+                raise errors[0]
+            return results
 
         # MPC_BATCH_CHUNKS > 1: the fixations are solved in chunks -- while the device works on the levels of one chunk (the host waits
         # inside the C ABI, GIL released) a second thread substitutes, presolves and sets up the sub-programs of the next one.  Measured
         # on the bench workload (64 fixations): 1 chunk 345 ms, 2 chunks 368, 4 chunks 350-435, 8 chunks 425-450 -- the host work of
         # the two threads shares one interpreter lock and smaller batches fill the device less; default 1.
         n_fix = len(feasible_combinations)
-        chunk = n_fix if num_cores <= 1 else max(8, -(-n_fix // BATCH_CHUNKS))
+        chunk = min(MAX_BATCH, n_fix if num_cores <= 1 else max(8, -(-n_fix // BATCH_CHUNKS)))
         chunks = [feasible_combinations[i:i + chunk] for i in range(0, n_fix, chunk)]
         sols = []
         with ThreadPoolExecutor(max_workers=1) as pool:

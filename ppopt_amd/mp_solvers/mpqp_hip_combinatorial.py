@@ -235,6 +235,7 @@ def solve_many(programs, device: int = 0, max_levels: Optional[int] = None, prun
     # Device memory: a member's level holds buffers sized by its number of candidates (region records, children, two generations of
     # the dictionary cache: Engine.level_memory_gb).  Members whose next level does not fit the budget next to the others are PARKED
     # at their current level and resumed when the running ones have finished (and given their level buffers back: Engine.trim).
+    in_flight = [None]      # the token of a level that has been started and not yet waited for
     budget_gb = 0.6 * float(os.environ.get('MPC_BATCH_BUDGET_GB', '160'))      # headroom: size classes round up, the pool keeps free blocks
     depth_of = [0] * len(engs)
     parked: List[int] = []
@@ -257,9 +258,11 @@ def solve_many(programs, device: int = 0, max_levels: Optional[int] = None, prun
         active = admit([i for i in range(len(engs)) if depth_max[i] > 0])
         gens = [gen_of(i) for i in active]
         token = Engine.level_batch_start([engs[i] for i in active], gens, keep_lowdim=not prune_lowdim) if active else None
+        in_flight[0] = token
         level_no = 0
         while active:
             t0 = time.perf_counter()
+            in_flight[0] = None             # the wait consumes the token, whatever it returns
             stats, n_shared = Engine.level_batch_wait(token)
             t_wait = time.perf_counter() - t0
             # the region records of this level: copies queued on each member's stream, nobody waits ...
@@ -283,6 +286,7 @@ def solve_many(programs, device: int = 0, max_levels: Optional[int] = None, prun
             gens_next = [gen_of(i) for i in nxt]
             if nxt:
                 token = Engine.level_batch_start([engs[i] for i in nxt], gens_next, keep_lowdim=not prune_lowdim)
+                in_flight[0] = token
             if not pressure:
                 for i in done:
                     if any(i == j for j, _ in fetched):
@@ -319,6 +323,14 @@ def solve_many(programs, device: int = 0, max_levels: Optional[int] = None, prun
     except MpcCapacityError:
         # a member that fell back to the overlapped single-program path ran out of reserved record slots (never observed): one by one
         return [solve(p, device=device, max_levels=max_levels, prune_lowdim=prune_lowdim) for p in programs]
+    except BaseException:
+        # a level may have been started and not waited for: let it finish (the handles must be idle before anybody touches them again)
+        if in_flight[0] is not None:
+            try:
+                Engine.level_batch_wait(in_flight[0])
+            except Exception:
+                pass
+        raise
     for sol in sols:
         sol.is_complete = max_levels is None
     return sols
