@@ -59,7 +59,7 @@ def solve_mpmiqp_enumeration(program, num_cores: int = -1,
                     warnings.simplefilter('ignore')
                     subs = [program.generate_substituted_problem(fix) for fix in fixes]
                     for sub in subs:
-                        sub.engine(device)     # set-up of the sub-program (MFMA set-up kernel)
+                        sub.engine(device, closed=True)     # set-up of the sub-program (MFMA set-up kernel)
                     return subs
             co = LPCoalescer(program.solver, len(fixes))
             parked = copy.copy(program)
@@ -71,7 +71,7 @@ def solve_mpmiqp_enumeration(program, num_cores: int = -1,
                 finally:
                     co.worker_done()
                 sub.solver = program.solver
-                sub.engine(device)
+                sub.engine(device, closed=True)
                 return sub
             # exactly one thread per fixation, all alive until every construction is through: the coalescer counts on each of them
             # reaching its next LP call (an executor may run two constructions on one thread, one after the other)

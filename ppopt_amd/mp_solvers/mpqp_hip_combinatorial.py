@@ -74,6 +74,15 @@ STREAM_MIN_CANDIDATES = int(os.environ.get('MPC_STREAM_MIN', '512'))
 BASE_ON_TWIN = os.environ.get('MPC_NO_TWIN', '0') != '1'   # the base-set check on a second handle, started with the first streamed level
 
 
+def _closing_rows_unused(eng, solution) -> bool:
+    """True unless some region lists one of the closing rows MPLP_Program._engine_parameter_rows appended to a parameter set without
+    a vertex (they are strictly redundant: this is a guard, not an expected outcome)."""
+    n_own = getattr(eng, 'n_tc_program', eng.n_tc)
+    if n_own >= eng.n_tc:
+        return True
+    return all(max(cr.omega_set, default=-1) < n_own for cr in solution.critical_regions)
+
+
 def solve(program, num_cores: int = -1, device: int = 0, profile: Optional[List[Dict]] = None,
           collect_regions: bool = True, max_levels: Optional[int] = None, stream: Optional[bool] = None,
           prune_lowdim: bool = True) -> Solution:
@@ -82,9 +91,21 @@ def solve(program, num_cores: int = -1, device: int = 0, profile: Optional[List[
     repeated with the region stage behind the (x,theta) stage, where nothing can be late.  No candidate is ever demoted."""
     from .._lib import MpcCapacityError, MpcError
     try:
-        return _solve(program, num_cores, device, profile, collect_regions, max_levels, stream, prune_lowdim)
+        sol = _solve(program, num_cores, device, profile, collect_regions, max_levels, stream, prune_lowdim)
+        if not _closing_rows_unused(program.engine(device, closed=True), sol):
+            # never observed: a closing row of the parameter set in a region -- the program is solved again on its own rows only
+            program.release_engine()
+            os.environ['MPC_NO_THETA_CLOSE'] = '1'
+            try:
+                if profile is not None:
+                    del profile[:]
+                sol = _solve(program, num_cores, device, profile, collect_regions, max_levels, stream, prune_lowdim)
+            finally:
+                del os.environ['MPC_NO_THETA_CLOSE']
+                program.release_engine()
+        return sol
     except MpcCapacityError:
-        eng = program.engine(device)
+        eng = program.engine(device, closed=True)
         twin = getattr(eng, '_twin', None)
         if twin is not None:
             try:
@@ -109,7 +130,7 @@ def _solve(program, num_cores: int = -1, device: int = 0, profile: Optional[List
     degenerate programs more regions."""
     if stream is None:
         stream = os.environ.get('MPC_NO_STREAM', '0') != '1'
-    eng = program.engine(device)
+    eng = program.engine(device, closed=True)
     n_x, n_t, n_c, n_tc = eng.n_x, eng.n_t, eng.n_c, eng.n_tc
     solution = Solution(program, [])
     max_depth = max(n_x, n_t) - eng.n_eq
@@ -220,7 +241,7 @@ def solve_many(programs, device: int = 0, max_levels: Optional[int] = None, prun
     programs = list(programs)
     if not programs:
         return []
-    engs = [p.engine(device) for p in programs]
+    engs = [p.engine(device, closed=True) for p in programs]
     if len(set(id(e) for e in engs)) != len(engs):
         raise ValueError('solve_many: the programs must be distinct objects (one device handle each)')
     sols = [Solution(p, []) for p in programs]
@@ -331,6 +352,8 @@ def solve_many(programs, device: int = 0, max_levels: Optional[int] = None, prun
             except Exception:
                 pass
         raise
-    for sol in sols:
+    for i, sol in enumerate(sols):
         sol.is_complete = max_levels is None
+        if not _closing_rows_unused(engs[i], sol):      # (see solve: never observed) this program again, alone, on its own rows
+            sols[i] = solve(programs[i], device=device, max_levels=max_levels, prune_lowdim=prune_lowdim)
     return sols

@@ -227,23 +227,77 @@ class MPLP_Program:
         Pb = ppopt_block([[self.b], [self.b_t]])
         return self.solver.solve_lp(numpy.zeros((self.num_x() + self.num_t(), 1)), PA, Pb, list(active_set)) is not None
 
-    def engine(self, device: Optional[int] = None):
+    def engine(self, device: Optional[int] = None, closed: bool = False):
         """The device-resident twin of this program (created on first use; dropped when the rows change).  Default
         device: the one the program's solver runs its presolve LPs on (``Solver(device=...)``)."""
         from . import _lib
         if device is None:
             device = int(getattr(self.solver, 'device', 0) or 0)
+        if closed:
+            # the combinatorial drivers: a parameter set without a vertex is closed for the device (_engine_parameter_rows); the handle
+            # is a second one, the other drivers (graph, geometric, point location) keep the program's own rows
+            eng_c = getattr(self, '_engine_closed', None)
+            if eng_c is not None and eng_c.device == device:
+                return eng_c
+            A_t, b_t = self._engine_parameter_rows()
+            if A_t.shape[0] != self.A_t.shape[0]:
+                if eng_c is not None:
+                    eng_c.close()
+                self._engine_closed = _lib.Engine(self.A, self.b, self.F, self.c, self.H, getattr(self, 'Q', None), A_t, b_t,
+                                                  len(self.equality_indices), device=device)
+                self._engine_closed.n_tc_program = int(self.A_t.shape[0])   # rows beyond it are the closing rows
+                return self._engine_closed
         if self._engine is None or self._engine.device != device:
             Q = getattr(self, 'Q', None)
             self._engine = _lib.Engine(self.A, self.b, self.F, self.c, self.H, Q, self.A_t, self.b_t,
                                        len(self.equality_indices), device=device)
         return self._engine
 
+    CLOSING_BOX_LIMIT = 1e3     # largest |theta| of the program's parameter box for which closing rows are used (see below)
+
+    def _engine_parameter_rows(self):
+        """(A_t, b_t) as the device handle gets them.  The register-resident kernels start their theta-space LPs at a VERTEX of the
+        parameter set {A_t theta <= b_t}.  The presolve may leave a set without one (fewer than n_theta independent rows: the others
+        were implied by rows in x -- the 51-region variant of the double-integrator MPC keeps two parallel rows); such a program
+        would run on the slower LDS-engine kernels.  Then the box of theta over the whole program {A x <= b + F theta, A_t theta
+        <= b_t} (2 n_theta LPs through the solver), widened by half its size, is appended as closing rows.  Every parameter any
+        active set can be feasible at lies strictly inside that box, so the rows are strictly redundant in every LP the path poses
+        (optimality, full dimension, facets): verdicts and regions do not change, and no region can list one of them -- the solve
+        checks that (mpqp_hip_combinatorial._closing_rows_unused) and repeats without them otherwise.  Only for boxes of moderate
+        size (CLOSING_BOX_LIMIT): a program that keeps big-M rows has a box of 1e8, and rows that far out ruin the absolute
+        tolerances of the LPs they take part in (measured: facet lists of regions change).  MPC_NO_THETA_CLOSE=1: off."""
+        import os
+        A_t, b_t = self.A_t, self.b_t
+        nt = self.num_t()
+        if os.environ.get('MPC_NO_THETA_CLOSE', '0') == '1' or (A_t.shape[0] >= nt and numpy.linalg.matrix_rank(A_t) >= nt):
+            return A_t, b_t
+        nx = self.num_x()
+        PA = ppopt_block([[self.A, -self.F], [numpy.zeros((A_t.shape[0], nx)), A_t]])
+        Pb = ppopt_block([[self.b], [b_t]])
+        lo, hi = numpy.zeros(nt), numpy.zeros(nt)
+        for j in range(nt):
+            for sign, out in ((1.0, lo), (-1.0, hi)):
+                c = numpy.zeros((nx + nt, 1))
+                c[nx + j, 0] = sign
+                res = self.solver.solve_lp(c, PA, Pb, list(self.equality_indices))
+                if res is None:
+                    return A_t, b_t        # unbounded (or infeasible) in this direction: no closing rows, the program keeps the slower kernels
+                out[j] = sign * res.obj
+        if max(float(numpy.max(numpy.abs(lo))), float(numpy.max(numpy.abs(hi)))) > self.CLOSING_BOX_LIMIT:
+            return A_t, b_t
+        pad = 0.5 * (hi - lo) + 1.0
+        rows = numpy.vstack([numpy.eye(nt), -numpy.eye(nt)])
+        rhs = numpy.concatenate([hi + pad, -(lo - pad)]).reshape(-1, 1)
+        return numpy.vstack([A_t, rows]), numpy.vstack([b_t.reshape(-1, 1), rhs])
+
     def release_engine(self) -> None:
         """Gives the device handle back (its blocks return to the library's pool); a later call re-creates it."""
         if self._engine is not None:
             self._engine.close()
             self._engine = None
+        if getattr(self, '_engine_closed', None) is not None:
+            self._engine_closed.close()
+            self._engine_closed = None
 
     def _device_status(self, active_set) -> int:
         eng = self.engine()

@@ -448,3 +448,60 @@ def test_streamed_records_with_non_coherent_default(tmp_path):
     out = subprocess.run([sys.executable, '-c', code], cwd=root, env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     assert 'REGIONS 9432' in out.stdout, out.stdout[-500:]
+
+
+def test_parameter_set_without_a_vertex_is_closed_by_redundant_rows(monkeypatch):
+    """The 51-region variant of config 2 (state box |x| <= 20): the presolve leaves two parallel rows of A_t, a slab without a
+    vertex, and the register-resident kernels need a vertex to start their theta-space LPs from.  MPLP_Program.engine() closes the
+    set with the (widened) box of theta over the whole program -- strictly redundant rows.  The solve must return exactly the
+    reference's 51 regions (golden c2_dblint_n5_x20), no region may list a closing row, and it must be the solution the program gets
+    without the closing rows (MPC_NO_THETA_CLOSE=1, LDS-engine kernels): same index sets, coefficients within 1e-8."""
+    import warnings
+    from ppopt_amd import MPQP_Program, problem_generator as pg
+    from ppopt_amd.mp_solvers import mpqp_hip_combinatorial
+    g = load_golden('c2_dblint_n5_x20')
+    d = pg.double_integrator_data(5, 20.0)
+
+    def build():
+        with warnings.catch_warnings():
+            warnings.simplefilter('ignore')
+            return MPQP_Program(d['A'], d['b'], d['c'], d['H'], d['Q'], d['A_t'], d['b_t'], d['F'], equality_indices=d['equality_indices'])
+    prog = build()
+    assert numpy.linalg.matrix_rank(prog.A_t) < prog.num_t()          # no vertex
+    eng = prog.engine(0, closed=True)
+    assert eng.n_tc > eng.n_tc_program == prog.A_t.shape[0]          # closing rows were appended for the device
+    assert prog.engine(0).n_tc == prog.A_t.shape[0]                  # the other drivers' handle keeps the program's own rows
+    prof = []
+    sol = mpqp_hip_combinatorial.solve(prog, profile=prof)
+    assert sum(p.get('ms_region2', 0.0) for p in prof) > 0           # the register-resident region kernel ran
+    monkeypatch.setenv('MPC_NO_THETA_CLOSE', '1')
+    plain = build()
+    assert plain.engine(0, closed=True).n_tc == plain.A_t.shape[0]
+    ref = mpqp_hip_combinatorial.solve(plain)
+    want = {tuple(int(v) for v in row[:int(kk)]) for row, kk in zip(g['R_active'], g['R_k'])}      # the reference's region active sets
+    ka = {tuple(r.active_set): r for r in sol.critical_regions}
+    kb = {tuple(r.active_set): r for r in ref.critical_regions}
+    assert len(ka) == len(kb) == 51 and ka.keys() == kb.keys() and want == set(ka)
+    for key, r1 in ka.items():
+        r2 = kb[key]
+        assert max(r1.omega_set, default=-1) < prog.A_t.shape[0]
+        assert r1.omega_set == r2.omega_set and r1.lambda_set == r2.lambda_set and r1.regular_set == r2.regular_set, key
+        for fld in ('A', 'b', 'C', 'd', 'E', 'f'):
+            assert rel_err(getattr(r1, fld), getattr(r2, fld)) <= COEF_TOL, (key, fld)
+
+
+def test_closing_rows_are_not_used_for_a_box_of_big_m_size():
+    """A program that keeps big-M rows (right-hand sides of 1e7) has a parameter box of 1e8: closing rows that far out would ruin the
+    absolute tolerances of the LPs they take part in (tools/fuzz_close.py: facet lists changed), so the handle gets the program's own rows."""
+    import warnings
+    from ppopt_amd import MPQP_Program, problem_generator as pg
+    rng = numpy.random.default_rng(7 * 1000003 + 47)
+    nx, nt, m = int(rng.integers(3, 13)), int(rng.integers(2, 7)), int(rng.integers(6, 20))
+    d = pg.generate_mpqp_data(nx, nt, m, 7 * 7919 + 47)
+    keep = rng.random(d['A_t'].shape[0]) < 0.5
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        prog = MPQP_Program(d['A'], d['b'], d['c'], d['H'], d['Q'], d['A_t'][keep], d['b_t'][keep], d['F'])
+    assert numpy.linalg.matrix_rank(prog.A_t) < prog.num_t()
+    assert prog.engine(0, closed=True).n_tc == prog.A_t.shape[0]
+    prog.release_engine()
