@@ -269,7 +269,18 @@ class MPLP_Program:
         import os
         A_t, b_t = self.A_t, self.b_t
         nt = self.num_t()
-        if os.environ.get('MPC_NO_THETA_CLOSE', '0') == '1' or (A_t.shape[0] >= nt and numpy.linalg.matrix_rank(A_t) >= nt):
+        if os.environ.get('MPC_NO_THETA_CLOSE', '0') == '1':
+            return A_t, b_t
+        key = (id(self.A), id(self.b), id(self.F), id(A_t), id(b_t), self.A.shape, A_t.shape)
+        cached = getattr(self, '_closing_rows', None)      # the decision is made once per set of rows (2 n_theta LPs when a set has no vertex)
+        if cached is not None and cached[0] == key:
+            return cached[1], cached[2]
+        out = self._closing_rows_compute(A_t, b_t, nt)
+        self._closing_rows = (key, out[0], out[1], (self.A, self.b, self.F, A_t, b_t))      # (the arrays are held: their ids stay theirs)
+        return out
+
+    def _closing_rows_compute(self, A_t, b_t, nt):
+        if A_t.shape[0] >= nt and numpy.linalg.matrix_rank(A_t) >= nt:
             return A_t, b_t
         nx = self.num_x()
         PA = ppopt_block([[self.A, -self.F], [numpy.zeros((A_t.shape[0], nx)), A_t]])
