@@ -298,3 +298,40 @@ def test_substituted_rows_are_cached_per_program_and_follow_row_changes():
     kept_before = r0[0].shape[0]
     prog.A = prog.A[:-1].copy(); prog.b = prog.b[:-1].copy(); prog.F = prog.F[:-1].copy()
     assert prog._substituted_rows([0])[0].shape[0] == kept_before - 1
+
+
+def test_closing_rows_of_a_parameter_set_without_a_vertex(monkeypatch):
+    """MPLP_Program._engine_parameter_rows (host logic, LPs through the stand-in): a parameter set with a vertex is handed over as it
+    is; a slab gets the widened box of theta over the whole program appended (2 n_theta rows, none of them reachable); a box of big-M size or an
+    unbounded direction leaves the rows alone."""
+    import warnings
+    from ppopt_amd import MPQP_Program, solver as solver_mod
+    counter = {'lps': 0, 'max_flag_bytes': 0}
+    monkeypatch.setattr(solver_mod._lib, 'lp_solve_batch', _scipy_lp_batch(counter))
+
+    def program(x_box, theta_rows):
+        # x in R^2, theta in R^2:  |x_i| <= x_box,  x_1 - theta_1 = 0 as two inequalities (theta_1 bounded through x),  theta_2 rows given
+        A = numpy.array([[1.0, 0], [-1, 0], [0, 1], [0, -1], [1, 0], [-1, 0]])
+        b = numpy.array([[x_box], [x_box], [x_box], [x_box], [0.0], [0.0]])
+        F = numpy.array([[0.0, 0], [0, 0], [0, 0], [0, 0], [1, 0], [-1, 0]])
+        A_t = numpy.array(theta_rows, dtype=float).reshape(-1, 2)
+        b_t = numpy.ones((A_t.shape[0], 1)) * 3.0
+        with warnings.catch_warnings():
+            warnings.simplefilter('ignore')
+            return MPQP_Program(A, b, numpy.zeros((2, 1)), numpy.zeros((2, 2)), numpy.eye(2), A_t, b_t, F, post_process=False)
+    with_vertex = program(2.0, [[1, 0], [-1, 0], [0, 1], [0, -1]])
+    A_t, b_t = with_vertex._engine_parameter_rows()
+    assert A_t is with_vertex.A_t and b_t is with_vertex.b_t
+    slab = program(2.0, [[0, 1], [0, -1]])          # theta_1 is bounded only through x_1 = theta_1, |x_1| <= 2
+    A_t, b_t = slab._engine_parameter_rows()
+    assert A_t.shape == (2 + 4, 2) and numpy.array_equal(A_t[:2], slab.A_t)
+    lo, hi = -(b_t[4:, 0]), b_t[2:4, 0]             # closing rows: theta <= hi + pad, -theta <= -(lo - pad)
+    scale = numpy.linalg.norm([1.0, 1.0])           # the constructor scales [A | -F] rows to unit norm: x_1 - theta_1 = 0 keeps theta_1 = x_1
+    assert numpy.all(hi > numpy.array([2.0, 3.0]) + 0.9) and numpy.all(lo < -numpy.array([2.0, 3.0]) - 0.9), (lo, hi, scale)
+    assert slab._engine_parameter_rows()[0] is A_t  # decided once per set of rows
+    big = program(1e7, [[0, 1], [0, -1]])
+    assert big._engine_parameter_rows()[0] is big.A_t
+    open_set = program(2.0, [[0, 1]])               # theta_2 unbounded below
+    assert open_set._engine_parameter_rows()[0] is open_set.A_t
+    monkeypatch.setenv('MPC_NO_THETA_CLOSE', '1')
+    assert slab._engine_parameter_rows()[0] is slab.A_t
