@@ -233,6 +233,42 @@ int mpc_level_chunk_wait(mpc_handle *h, int32_t j);
 int mpc_level_wait(mpc_handle *h, mpc_level_stats *stats);
 int mpc_level_stream_fixup(mpc_handle *h, double *head_d, int32_t *head_i, double *erows, int64_t *n_rows);
 int mpc_base_result(mpc_handle *h, uint8_t *status, int64_t *n_regions, double *rec_d, int32_t *rec_i);
+/* The WHOLE level loop of the reference's driver behind one call (mp_solvers/mpqp_parrallel_combinatorial.py:98-139: root frontier =
+ * children of the equality set, then per level pool.map(full_process) -> merge pruned / children / regions -> next level), run by
+ * the handle's worker thread: no level is handed back to the caller, so the device never waits for the host between levels
+ * (round 3: 0.38 ms of a 6.7 ms solve of config 4 sat in those hand-overs, tools/gpu_idle.sh).  The caller only CONSUMES: per level
+ * it receives the region records while later levels already run.
+ *   mpc_solve_start(h, max_levels, flags)  clears the pruned list, roots the frontier and starts the loop for at most max_levels
+ *          levels (the last one without children, driver :108).  flags: MPC_LEVEL_STREAM (large levels stream their records),
+ *          MPC_LEVEL_KEEP_LOWDIM, MPC_SOLVE_FETCH (records of levels that do not stream are copied to page-locked host arrays by the
+ *          loop), MPC_LEVEL_THEN_BASE (the base active set is checked behind the last level: mpc_base_result).
+ *   mpc_solve_level(h, level, &info)       blocks until level `level` (0-based) has records to hand over or has finished.
+ *          info.mode: 1 = streamed (arrays are being written; chunk j readable after mpc_solve_chunk_wait(h, level, j); layout of
+ *          mpc_level_stream_info), 2 = complete arrays (n_slots slots, n_rows rows in use), 0 = the level has no records,
+ *          -1 = the loop ended before this level (return code = the loop's).  Arrays are the caller's from then on (mpc_host_free).
+ *   mpc_solve_level_wait(h, level, &stats, &ms_wall)  blocks until the level has finished: its statistics; when
+ *          stats.n_region_retry > 0 the slots of the re-solved candidates of a streamed level have been filled in place (list the
+ *          level's slots again: head_i[slot][0] == MPC_REGION).
+ *   mpc_solve_wait(h, &n_levels)           joins the loop: its return code (MPC_ERR_CAPACITY as for mpc_level_wait) and the number
+ *          of levels completed.  The handle is then in the state after the last level (mpc_frontier_info, mpc_level_* fetches). */
+#define MPC_SOLVE_FETCH 64
+typedef struct {
+    int32_t level, k;          /* 0-based level, cardinality of its candidates                                   */
+    int32_t mode;              /* see above                                                                      */
+    int32_t chunk, n_chunks;   /* mode 1: slots per chunk, number of chunks                                      */
+    int32_t pad_;
+    int64_t n;                 /* candidates of the level                                                        */
+    int64_t n_slots;           /* rows of head_d / head_i                                                        */
+    int64_t n_rows;            /* mode 1: row capacity of erows; mode 2: rows in use                             */
+    double *head_d;            /* [n_slots][fd]     fd = n_x n_t + n_x + k n_t + k                               */
+    int32_t *head_i;           /* [n_slots][fi]     fi = 8 + k + n_tc + k + 2 (n_c - k)                          */
+    double *erows;             /* [n_rows][n_t + 1] */
+} mpc_solve_level_info;
+int mpc_solve_start(mpc_handle *h, int32_t max_levels, int32_t flags);
+int mpc_solve_level(mpc_handle *h, int32_t level, mpc_solve_level_info *info);
+int mpc_solve_chunk_wait(mpc_handle *h, int32_t level, int32_t j);
+int mpc_solve_level_wait(mpc_handle *h, int32_t level, mpc_level_stats *stats, double *ms_wall);
+int mpc_solve_wait(mpc_handle *h, int32_t *n_levels);
 /* Region records of this level in frontier order.  cand_index[i] = position of region i's candidate.
  *   rec_d (mpc_region_doubles each): A_x[n_x*n_t] b_x[n_x] A_l[n_c*n_t] b_l[n_c] E[(n_c+n_tc)*n_t] f[n_c+n_tc]
  *   rec_i (mpc_region_ints each):    k n_E n_omega n_lambda n_regular | active[n_c] | omega[n_tc] | lambda[n_c]

@@ -16,6 +16,7 @@ LIB_PATH = os.environ.get('MPC_LIB_PATH') or os.path.join(_HERE, 'csrc', 'libmpc
 MPC_OK, MPC_ERR_INVALID, MPC_ERR_HIP, MPC_ERR_CAPACITY, MPC_ERR_STATE = range(5)
 MPC_LOCATE_OVERLAPPING, MPC_LOCATE_INCLUSIVE, MPC_LOCATE_WALK = 1, 2, 4   # flags of mpc_locator_query
 MPC_LEVEL_STREAM, MPC_LEVEL_GRAPH, MPC_LEVEL_THEN_BASE, MPC_LEVEL_KEEP_LOWDIM, MPC_LEVEL_ONLY_BASE = 1, 4, 8, 16, 32   # flags of mpc_level_start / mpc_level_run_ex
+MPC_SOLVE_FETCH = 64   # flag of mpc_solve_start
 INFEASIBLE, FEASIBLE, OPTIMAL_NO_REGION, REGION, SINGULAR_KKT, LP_LIMIT = range(6)
 LP_OPTIMAL, LP_INFEASIBLE, LP_UNBOUNDED, LP_ITERLIMIT = range(4)
 MASK_WORDS = 2
@@ -56,6 +57,13 @@ class LevelStats(ctypes.Structure):
                 ('n_theta_items', ctypes.c_int64), ('n_region_rows', ctypes.c_int64),
                 ('ms_kkt', ctypes.c_float), ('ms_xq', ctypes.c_float), ('n_xq_items', ctypes.c_int64), ('xq_pivots', ctypes.c_int64),
                 ('xq_record_ints', ctypes.c_int64), ('xq_record_rows', ctypes.c_int64), ('xq_record_cols', ctypes.c_int64)]
+
+
+class SolveLevelInfo(ctypes.Structure):
+    """mpc_solve_level_info (include/mpcombi.h)."""
+    _fields_ = [('level', ctypes.c_int32), ('k', ctypes.c_int32), ('mode', ctypes.c_int32), ('chunk', ctypes.c_int32),
+                ('n_chunks', ctypes.c_int32), ('pad_', ctypes.c_int32), ('n', ctypes.c_int64), ('n_slots', ctypes.c_int64),
+                ('n_rows', ctypes.c_int64), ('head_d', ctypes.c_void_p), ('head_i', ctypes.c_void_p), ('erows', ctypes.c_void_p)]
 
 
 _lib = None
@@ -132,6 +140,11 @@ def load():
         'mpc_level_wait': (ctypes.c_int, [H, ctypes.POINTER(LevelStats)]),
         'mpc_level_stream_fixup': (ctypes.c_int, [H, _dp, _ip, _dp, _lp]),
         'mpc_base_result': (ctypes.c_int, [H, _u8p, _lp, _dp, _ip]),
+        'mpc_solve_start': (ctypes.c_int, [H, ctypes.c_int32, ctypes.c_int32]),
+        'mpc_solve_level': (ctypes.c_int, [H, ctypes.c_int32, ctypes.POINTER(SolveLevelInfo)]),
+        'mpc_solve_chunk_wait': (ctypes.c_int, [H, ctypes.c_int32, ctypes.c_int32]),
+        'mpc_solve_level_wait': (ctypes.c_int, [H, ctypes.c_int32, ctypes.POINTER(LevelStats), ctypes.POINTER(ctypes.c_double)]),
+        'mpc_solve_wait': (ctypes.c_int, [H, ctypes.POINTER(ctypes.c_int32)]),
         'mpc_level_regions': (ctypes.c_int, [H, _dp, _ip, _lp, ctypes.c_int64]),
         'mpc_compact_strides': (ctypes.c_int, [H, _lp, _lp, _lp]),
         'mpc_level_regions_compact': (ctypes.c_int, [H, _dp, _ip, ctypes.c_int64, _dp, ctypes.c_int64, _lp, _lp]),
@@ -183,7 +196,7 @@ EXPORTED_SYMBOLS = ['mpc_device_count', 'mpc_version', 'mpc_last_global_error', 
                     'mpc_last_error', 'mpc_mask_words', 'mpc_set_region_overlap', 'mpc_program_block', 'mpc_region_doubles', 'mpc_region_ints', 'mpc_lds_bytes', 'mpc_stream',
                     'mpc_frontier_root', 'mpc_frontier_set', 'mpc_frontier_set_device', 'mpc_frontier_info',
                     'mpc_frontier_get', 'mpc_pruned_clear', 'mpc_pruned_add', 'mpc_pruned_add_device',
-                    'mpc_pruned_count', 'mpc_pruned_get', 'mpc_level_run', 'mpc_level_run_ex', 'mpc_level_run_batch', 'mpc_frontier_advance_batch', 'mpc_level_memory_gb', 'mpc_trim', 'mpc_level_batch_start', 'mpc_level_batch_wait', 'mpc_level_regions_slots_nowait', 'mpc_level_batch_fetch', 'mpc_level_status', 'mpc_level_start', 'mpc_level_stream_info', 'mpc_level_chunk_wait', 'mpc_level_wait', 'mpc_level_stream_fixup', 'mpc_base_result', 'mpc_level_regions', 'mpc_compact_strides',
+                    'mpc_pruned_count', 'mpc_pruned_get', 'mpc_level_run', 'mpc_level_run_ex', 'mpc_level_run_batch', 'mpc_frontier_advance_batch', 'mpc_level_memory_gb', 'mpc_trim', 'mpc_level_batch_start', 'mpc_level_batch_wait', 'mpc_level_regions_slots_nowait', 'mpc_level_batch_fetch', 'mpc_level_status', 'mpc_level_start', 'mpc_level_stream_info', 'mpc_level_chunk_wait', 'mpc_level_wait', 'mpc_level_stream_fixup', 'mpc_base_result', 'mpc_solve_start', 'mpc_solve_level', 'mpc_solve_chunk_wait', 'mpc_solve_level_wait', 'mpc_solve_wait', 'mpc_level_regions', 'mpc_compact_strides',
                     'mpc_level_regions_compact', 'mpc_frontier_shard', 'mpc_level_slots', 'mpc_level_regions_slots', 'mpc_level_regions_slots_async', 'mpc_sync', 'mpc_host_alloc', 'mpc_host_free', 'mpc_locator_create', 'mpc_locator_query', 'mpc_locator_destroy', 'mpc_locator_set_adjacency', 'mpc_level_children', 'mpc_level_children_device', 'mpc_level_pruned_new',
                     'mpc_level_pruned_new_device', 'mpc_level_regions_device', 'mpc_frontier_advance', 'mpc_qp_solve_batch', 'mpc_facet_centres', 'mpc_graph_begin', 'mpc_graph_wave', 'mpc_graph_group_run', 'mpc_graph_wave_close', 'mpc_check_level', 'mpc_lp_solve_batch']
 
@@ -279,7 +292,7 @@ class Engine:
     # -- plumbing ----------------------------------------------------------------------------------------------
     def _check(self, rc, what):
         if rc != MPC_OK:
-            cls = MpcCapacityError if rc == 3 and what in ('mpc_level_run', 'mpc_level_wait', 'mpc_level_run_batch') else MpcError
+            cls = MpcCapacityError if rc == 3 and what in ('mpc_level_run', 'mpc_level_wait', 'mpc_level_run_batch', 'mpc_solve_wait') else MpcError
             raise cls(f'{what} failed ({rc}): {self._L.mpc_last_error(self._h).decode()}')
 
     def program_block(self, which: int) -> numpy.ndarray:
@@ -541,6 +554,46 @@ class Engine:
         self._check(self._L.mpc_level_stream_fixup(self._h, hd.ctypes.data_as(_dp), hi.ctypes.data_as(_ip), er.ctypes.data_as(_dp),
                                                    ctypes.byref(nrows)), 'mpc_level_stream_fixup')
         return int(nrows.value)
+
+    # -- the whole level loop on the handle's worker thread (include/mpcombi.h, mpc_solve_*) ---------------------------------
+    def solve_start(self, max_levels: int, stream: bool = True, fetch: bool = True, then_base: bool = False, keep_lowdim: bool = False):
+        self._check(self._L.mpc_solve_start(self._h, int(max_levels), (MPC_LEVEL_STREAM if stream else 0) | (MPC_SOLVE_FETCH if fetch else 0)
+                                            | (MPC_LEVEL_THEN_BASE if then_base else 0) | (MPC_LEVEL_KEEP_LOWDIM if keep_lowdim else 0)), 'mpc_solve_start')
+
+    def solve_level(self, level: int):
+        """Blocks until level ``level`` of the running solve has records to hand over or has finished.  None: the loop ended before
+        this level.  Else (mode, k, n, head_d, head_i, erows, chunk, n_chunks): mode 1 = arrays the region kernel is still writing
+        (chunk j readable after ``solve_chunk_wait(level, j)``), 2 = complete arrays, 0 = no records (arrays None)."""
+        info = SolveLevelInfo()
+        rc = self._L.mpc_solve_level(self._h, int(level), ctypes.byref(info))
+        if info.mode < 0:
+            return None
+        self._check(rc, 'mpc_solve_level')
+        if info.mode == 0:
+            return 0, int(info.k), int(info.n), None, None, None, 0, 0
+        k = int(info.k)
+        fd = self.n_x * self.n_t + self.n_x + k * self.n_t + k
+        fi = 8 + k + self.n_tc + k + 2 * (self.n_c - k)
+        ns = int(info.n_slots)
+        return (int(info.mode), k, int(info.n), pinned_adopt(info.head_d, (ns, fd), numpy.float64), pinned_adopt(info.head_i, (ns, fi), numpy.int32),
+                pinned_adopt(info.erows, (max(int(info.n_rows), 1), self.n_t + 1), numpy.float64), int(info.chunk), int(info.n_chunks))
+
+    def solve_chunk_wait(self, level: int, j: int):
+        self._check(self._L.mpc_solve_chunk_wait(self._h, int(level), int(j)), 'mpc_solve_chunk_wait')
+
+    def solve_level_wait(self, level: int):
+        """(LevelStats, wall milliseconds) of a finished level of the running solve."""
+        st = LevelStats()
+        ms = ctypes.c_double(0.0)
+        self._check(self._L.mpc_solve_level_wait(self._h, int(level), ctypes.byref(st), ctypes.byref(ms)), 'mpc_solve_level_wait')
+        self._last = st
+        return st, float(ms.value)
+
+    def solve_wait(self) -> int:
+        """Joins the solve loop; raises what the loop failed with (MpcCapacityError as for ``level_wait``); levels completed."""
+        nl = ctypes.c_int32(0)
+        self._check(self._L.mpc_solve_wait(self._h, ctypes.byref(nl)), 'mpc_solve_wait')
+        return int(nl.value)
 
     def qp_solve_batch(self, thetas: numpy.ndarray):
         """The program's QP at every row of ``thetas`` [m, n_t] (positive definite Q), one wavefront per point:

@@ -15,6 +15,8 @@
 #include <mutex>
 #include <condition_variable>
 #include <thread>
+#include <functional>
+#include <chrono>
 #include <atomic>
 #include <cstring>
 #include <cstdlib>
@@ -370,6 +372,21 @@ struct mpc_handle {
     std::vector<double> base_rec_d;
     std::vector<int32_t> base_rec_i;
     mpc_level_stats w_stats{};
+    // ---- the whole level loop on the worker thread (mpc_solve_start / _level / _chunk_wait / _level_wait / _wait) -----------------
+    struct SolveLevel {
+        int32_t k = 0, mode = 0, chunk = 0, n_chunks = 0;   // mode: 0 nothing to read, 1 streamed in chunks, 2 complete arrays
+        int64_t n = 0, n_slots = 0, n_rows = 0;
+        void *hd = nullptr, *hi = nullptr, *er = nullptr;   // page-locked blocks; the caller's once mpc_solve_level has handed them over
+        bool handed = false;
+        const int32_t *flags = nullptr;                     // chunk flags (valid while the level runs)
+        mpc_level_stats stats{};
+        double ms_wall = 0.0;
+        std::atomic<int> ready{0}, done{0};
+    };
+    std::unique_ptr<SolveLevel[]> sv_levels;                // MPC_MAX_NC + 2 entries, allocated by the first mpc_solve_start
+    int sv_max_levels = 0, sv_flags = 0, sv_rc = 0;
+    int sv_cur = -1;                                        // level the worker is running (-1: not inside a solve loop)
+    std::atomic<int> sv_n{0}, sv_finished{1};               // levels begun so far; the loop has ended
     // ---- connected-graph traversal: wave, visited set and pending neighbours resident on the device (graph.hpp) ----------
     struct GraphState {
         bool active = false;
@@ -483,6 +500,7 @@ void lu_solve_host(const std::vector<double> &LU, const std::vector<int> &perm, 
 
 static int create_fill(const mpc_problem *p, int32_t device, void *stream, mpc_handle *h);
 static void stream_release(mpc_handle *h);
+static void solve_release(mpc_handle *h);
 static double batch_level_gb(const mpc_handle *h, int32_t gen_children);
 static int lp_batch_impl(int32_t device, int64_t n_lp, int32_t m, int32_t n, const double *A, int32_t shared_A, const double *b,
                          int32_t shared_b, const double *c, int32_t shared_c, const uint8_t *eq, int32_t *status, double *x,
@@ -948,6 +966,7 @@ int mpc_destroy(mpc_handle *h) {
     if (h->tot_host) { (void)host_pool_give(h->tot_host); h->tot_host = h->tot_dev = nullptr; }
     for (HostBuf *b : {&h->st_list, &h->st_status, &h->st_hd, &h->st_hi, &h->st_pool, &h->st_fxd, &h->st_fxi, &h->st_rlist, &h->st_flags}) b->release();
     stream_release(h);
+    solve_release(h);
     h->chunk_count.release();
     for (DevBuf *b : {&h->g.wave, &h->g.visited, &h->g.pending, &h->g.tmp_a, &h->g.tmp_b, &h->g.sort_tmp, &h->g.card, &h->g.idx, &h->g.card2, &h->g.idx2, &h->g.facet, &h->g.cnt, &h->g.off, &h->g.hist}) b->release();
     for (auto &e : h->ev) return_event(e, true);
@@ -1192,6 +1211,21 @@ static int launch_region_v1(mpc_handle *h, const int32_t *list, long long n_list
 // tells a caller blocked in mpc_level_stream_info that the region stage of the running level has been launched (or that
 // this level does not stream)
 static void stream_ready(mpc_handle *h) {
+    if (h->sv_cur >= 0) {
+        // inside mpc_solve_start's loop: the region stage of level sv_cur has been launched -- its page-locked arrays are handed to
+        // the caller of mpc_solve_level right away (a level that does not stream is published by the loop itself, after its fetch)
+        auto &lv = h->sv_levels[h->sv_cur];
+        if (h->so.active && !h->so.taken && !lv.ready.load(std::memory_order_relaxed)) {
+            lv.mode = 1; lv.hd = h->so.hd; lv.hi = h->so.hi; lv.er = h->so.er;
+            lv.n_slots = h->so.n_slots; lv.n_rows = h->so.cap_rows; lv.chunk = 1 << h->so.shift; lv.n_chunks = h->so.n_chunks;
+            lv.flags = h->st_flags.as<int32_t>();
+            h->so.taken = true;
+            lv.ready.store(1, std::memory_order_release);
+            { std::lock_guard<std::mutex> lk(h->wm); }
+            h->wcv.notify_all();
+        }
+        return;
+    }
     std::lock_guard<std::mutex> lk(h->wm);
     h->w_stream_ready = true;
     h->a_ready.store(1, std::memory_order_release);
@@ -2364,18 +2398,111 @@ int mpc_level_run_ex(mpc_handle *h, int32_t gen_children, int32_t flags, mpc_lev
 }
 
 // ---- the same level, driven by the handle's worker thread ---------------------------------------------------------------
+static int level_regions_slots_impl(mpc_handle *h, double *head_d, int32_t *head_i, int64_t cap_slots, double *erows, int64_t cap_rows,
+                                    int64_t *n_slots, int64_t *n_rows, bool may_return_early, bool in_place);
+// The base active set (the equality rows alone; driver :142-146) on the worker thread.  Any failure simply leaves the check to the caller.
+static void worker_base_check(mpc_handle *h) {
+    std::vector<int32_t> base((size_t)std::max(h->n_eq, 1));
+    for (int i = 0; i < h->n_eq; ++i) base[(size_t)i] = i;
+    mpc_level_stats bs;
+    std::memset(&bs, 0, sizeof(bs));
+    h->base_rec_d.assign((size_t)h->rec_d, 0.0);
+    h->base_rec_i.assign((size_t)h->rec_i, -1);
+    int64_t cand = 0;
+    int rb = mpc_frontier_set(h, base.data(), 1, h->n_eq);
+    if (rb == MPC_OK) { h->n_pruned = 0; rb = level_run_impl(h, 0, 0, &bs); }
+    if (rb == MPC_OK) rb = mpc_level_status(h, &h->base_status);
+    if (rb == MPC_OK && bs.n_regions > 0) rb = mpc_level_regions(h, h->base_rec_d.data(), h->base_rec_i.data(), &cand, 1);
+    if (rb == MPC_OK) { h->base_regions = bs.n_regions; h->base_valid = true; }
+}
+
+// blocks of levels of the previous solve loop that nobody took
+static void solve_release(mpc_handle *h) {
+    if (!h->sv_levels) return;
+    const int nl = h->sv_n.load(std::memory_order_acquire);
+    for (int i = 0; i < nl; ++i) {
+        auto &lv = h->sv_levels[i];
+        if (!lv.handed) { if (lv.hd) (void)host_pool_give(lv.hd); if (lv.hi) (void)host_pool_give(lv.hi); if (lv.er) (void)host_pool_give(lv.er); }
+        lv.hd = lv.hi = lv.er = nullptr; lv.handed = false; lv.flags = nullptr; lv.mode = 0;
+        lv.ready.store(0, std::memory_order_relaxed); lv.done.store(0, std::memory_order_relaxed);
+    }
+    h->sv_n.store(0, std::memory_order_release);
+}
+
+// The level loop of the reference's driver (mp_solvers/mpqp_parrallel_combinatorial.py:98-139) on the worker thread: root frontier,
+// then level after level -- run, publish the level's records, advance the frontier -- without a hand-over to the caller in between.
+static int worker_solve(mpc_handle *h) {
+    const int flags = h->sv_flags;
+    int rc = mpc_pruned_clear(h);
+    if (rc == MPC_OK) rc = mpc_frontier_root(h);
+    const int level_flags = flags & (MPC_LEVEL_STREAM | MPC_LEVEL_KEEP_LOWDIM);
+    for (int depth = 0; rc == MPC_OK && depth < h->sv_max_levels; ++depth) {
+        const int gen = depth + 1 != h->sv_max_levels;
+        auto &lv = h->sv_levels[depth];
+        lv.k = h->k; lv.n = h->n;
+        const auto t0 = std::chrono::steady_clock::now();
+        h->sv_cur = depth;
+        h->sv_n.store(depth + 1, std::memory_order_release);
+        rc = level_run_impl(h, gen, level_flags, &lv.stats);
+        if (rc == MPC_OK && !lv.ready.load(std::memory_order_relaxed)) {
+            // the level did not stream (no optimal candidate; run without host round trips, its records in device buffers; LDS-engine
+            // region kernel; > 1 GiB of records): fetched here, complete when published
+            if ((flags & MPC_SOLVE_FETCH) && lv.stats.n_regions > 0 && h->n_opt > 0 && !h->so.active) {
+                int64_t rows_cap = 0, ns = 0, nr = 0;
+                mpc_compact_strides(h, nullptr, nullptr, &rows_cap);
+                const size_t b_hd = (size_t)h->n_opt * h->fd * sizeof(double), b_hi = (size_t)h->n_opt * h->fi * sizeof(int32_t),
+                             b_er = (size_t)std::max<int64_t>(rows_cap, 1) * (h->n_t + 1) * sizeof(double);
+                if (host_pool_take(b_hd, &lv.hd, nullptr) != hipSuccess || host_pool_take(b_hi, &lv.hi, nullptr) != hipSuccess ||
+                    host_pool_take(b_er, &lv.er, nullptr) != hipSuccess) rc = fail(h, MPC_ERR_HIP, "mpc_solve: page-locked memory for a level's region records");
+                if (rc == MPC_OK) rc = level_regions_slots_impl(h, static_cast<double *>(lv.hd), static_cast<int32_t *>(lv.hi), h->n_opt, static_cast<double *>(lv.er),
+                                                                rows_cap, &ns, &nr, false, false);
+                lv.mode = 2; lv.n_slots = ns; lv.n_rows = nr; lv.chunk = 0; lv.n_chunks = 0;
+            } else lv.mode = 0;
+        } else if (rc == MPC_OK && lv.stats.n_region_retry > 0) {
+            // candidates the LDS-engine kernel re-solved after the stream: their slots are filled in place (the caller lists the level
+            // again after mpc_solve_level_wait)
+            int64_t ns = 0, nr = 0;
+            rc = level_regions_slots_impl(h, static_cast<double *>(lv.hd), static_cast<int32_t *>(lv.hi), lv.n_slots, static_cast<double *>(lv.er), lv.n_rows, &ns, &nr, false, true);
+        }
+        lv.ms_wall = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        h->sv_cur = -1;
+        if (rc != MPC_OK) break;
+        lv.ready.store(1, std::memory_order_release);
+        lv.done.store(1, std::memory_order_release);
+        { std::lock_guard<std::mutex> lk(h->wm); }
+        h->wcv.notify_all();
+        if (!gen || lv.stats.n_children == 0) break;
+        rc = mpc_frontier_advance(h);
+    }
+    h->sv_cur = -1;
+    h->base_valid = false;
+    if (rc == MPC_OK && (flags & MPC_LEVEL_THEN_BASE)) worker_base_check(h);
+    return rc;
+}
+
 static void worker_main(mpc_handle *h) {
     for (;;) {
-        int gen = 0, flags = 0;
+        int gen = 0, flags = 0, req = 0;
         {
             for (int spin = 0; spin < 20000 && !h->a_req.load(std::memory_order_acquire); ++spin) __builtin_ia32_pause();
             std::unique_lock<std::mutex> lk(h->wm);
             h->wcv.wait(lk, [&] { return h->w_req != 0; });
             if (h->w_req == 2) return;
-            gen = h->w_gen; flags = h->w_flags; h->w_req = 0; h->a_req.store(0, std::memory_order_release);
+            req = h->w_req; gen = h->w_gen; flags = h->w_flags; h->w_req = 0; h->a_req.store(0, std::memory_order_release);
         }
         mpc_level_stats st;
         std::memset(&st, 0, sizeof(st));
+        if (req == 3) {
+            const int rcs = worker_solve(h);
+            {
+                std::lock_guard<std::mutex> lk(h->wm);
+                h->sv_rc = rcs; h->w_rc = rcs; h->w_stats = st; h->w_busy = false; h->w_stream_ready = true;
+                h->sv_finished.store(1, std::memory_order_release);
+                h->a_ready.store(1, std::memory_order_release); h->a_busy.store(0, std::memory_order_release);
+            }
+            h->wcv.notify_all();
+            continue;
+        }
         const bool only_base = (flags & MPC_LEVEL_ONLY_BASE) != 0;
         const int rc = only_base ? MPC_OK : level_run_impl(h, gen, flags, &st);
         h->base_valid = false;
@@ -2383,22 +2510,8 @@ static void worker_main(mpc_handle *h) {
         // level that did not stream (LDS-engine region kernel ...) is fetched by the caller after mpc_level_wait, from the very state
         // this check would replace
         const bool streamed_and_taken = h->so.active && h->so.taken;
-        if (rc == MPC_OK && (only_base || ((flags & MPC_LEVEL_THEN_BASE) && !gen && st.n_region_retry == 0 && (streamed_and_taken || st.n_regions == 0)))) {
-            // The base active set (the equality rows alone; driver :142-146) right behind the last level, while the caller
-            // is still turning the streamed records into objects.  Any failure simply leaves the check to the caller.
-            std::vector<int32_t> base((size_t)std::max(h->n_eq, 1));
-            for (int i = 0; i < h->n_eq; ++i) base[(size_t)i] = i;
-            mpc_level_stats bs;
-            std::memset(&bs, 0, sizeof(bs));
-            h->base_rec_d.assign((size_t)h->rec_d, 0.0);
-            h->base_rec_i.assign((size_t)h->rec_i, -1);
-            int64_t cand = 0;
-            int rb = mpc_frontier_set(h, base.data(), 1, h->n_eq);
-            if (rb == MPC_OK) { h->n_pruned = 0; rb = level_run_impl(h, 0, 0, &bs); }
-            if (rb == MPC_OK) rb = mpc_level_status(h, &h->base_status);
-            if (rb == MPC_OK && bs.n_regions > 0) rb = mpc_level_regions(h, h->base_rec_d.data(), h->base_rec_i.data(), &cand, 1);
-            if (rb == MPC_OK) { h->base_regions = bs.n_regions; h->base_valid = true; }
-        }
+        if (rc == MPC_OK && (only_base || ((flags & MPC_LEVEL_THEN_BASE) && !gen && st.n_region_retry == 0 && (streamed_and_taken || st.n_regions == 0))))
+            worker_base_check(h);   // right behind the last level, while the caller is still turning the streamed records into objects
         {
             std::lock_guard<std::mutex> lk(h->wm);
             h->w_rc = rc; h->w_stats = st; h->w_busy = false; h->w_stream_ready = true;
@@ -2471,6 +2584,90 @@ int mpc_level_wait(mpc_handle *h, mpc_level_stats *stats) {
     h->wcv.wait(lk, [&] { return !h->w_busy; });
     if (stats) *stats = h->w_stats;
     return h->w_rc;
+}
+
+// ---- the whole level loop behind one call ---------------------------------------------------------------------------------------
+int mpc_solve_start(mpc_handle *h, int32_t max_levels, int32_t flags) {
+    if (!h || max_levels < 0) return MPC_ERR_INVALID;
+    std::unique_lock<std::mutex> lk(h->wm);
+    if (h->w_busy) return fail(h, MPC_ERR_STATE, "mpc_solve_start: the previous level / solve has not been waited for");
+    if (!h->sv_levels) h->sv_levels.reset(new mpc_handle::SolveLevel[MPC_MAX_NC + 2]);
+    solve_release(h);
+    h->sv_max_levels = std::min<int>(max_levels, MPC_MAX_NC + 1); h->sv_flags = flags; h->sv_rc = MPC_OK;
+    h->sv_finished.store(0, std::memory_order_release);
+    if (!h->worker.joinable()) h->worker = std::thread(worker_main, h);
+    h->w_gen = 0; h->w_flags = flags; h->w_busy = true; h->w_stream_ready = false; h->w_req = 3;
+    h->a_busy.store(1, std::memory_order_release); h->a_ready.store(0, std::memory_order_release); h->a_req.store(1, std::memory_order_release);
+    lk.unlock();
+    h->wcv.notify_all();
+    return MPC_OK;
+}
+
+// waits (short spin, then the condition variable) until pred() holds
+static void solve_wait_for(mpc_handle *h, const std::function<bool()> &pred) {
+    for (int spin = 0; spin < 400000; ++spin) { if (pred()) return; __builtin_ia32_pause(); }
+    std::unique_lock<std::mutex> lk(h->wm);
+    h->wcv.wait(lk, pred);
+}
+
+int mpc_solve_level(mpc_handle *h, int32_t level, mpc_solve_level_info *info) {
+    if (!h || !info || level < 0 || !h->sv_levels || level > MPC_MAX_NC) return MPC_ERR_INVALID;
+    auto &lv = h->sv_levels[level];
+    solve_wait_for(h, [&] { return lv.ready.load(std::memory_order_acquire) != 0 || h->sv_finished.load(std::memory_order_acquire) != 0; });
+    std::memset(info, 0, sizeof(*info));
+    info->level = level;
+    if (!lv.ready.load(std::memory_order_acquire)) { info->mode = -1; return h->sv_rc; }   // the loop ended before (or inside) this level
+    info->k = lv.k; info->n = lv.n; info->mode = lv.mode; info->chunk = lv.chunk; info->n_chunks = lv.n_chunks;
+    info->n_slots = lv.n_slots; info->n_rows = lv.n_rows;
+    if (lv.mode != 0 && !lv.handed) {
+        info->head_d = static_cast<double *>(lv.hd); info->head_i = static_cast<int32_t *>(lv.hi); info->erows = static_cast<double *>(lv.er);
+        lv.handed = true;   // the three blocks now belong to the caller (mpc_host_free)
+    } else if (lv.mode != 0) return fail(h, MPC_ERR_STATE, "mpc_solve_level: the arrays of this level have been handed over already");
+    return MPC_OK;
+}
+
+int mpc_solve_chunk_wait(mpc_handle *h, int32_t level, int32_t j) {
+    if (!h || level < 0 || !h->sv_levels || level > MPC_MAX_NC) return MPC_ERR_INVALID;
+    auto &lv = h->sv_levels[level];
+    if (lv.mode != 1 || j < 0 || j >= lv.n_chunks) return MPC_ERR_INVALID;
+    for (unsigned spin = 0;; ++spin) {
+        // a finished level has every chunk complete (and its flag words may already belong to the next level)
+        if (lv.done.load(std::memory_order_acquire)) return MPC_OK;
+        if (__atomic_load_n(lv.flags + j, __ATOMIC_ACQUIRE)) return MPC_OK;
+        if ((spin & 1023u) == 1023u && h->sv_finished.load(std::memory_order_acquire))
+            return lv.done.load(std::memory_order_acquire) ? MPC_OK : fail(h, MPC_ERR_STATE, "mpc_solve_chunk_wait: the solve ended without completing this chunk");
+        __builtin_ia32_pause();
+    }
+}
+
+int mpc_solve_level_wait(mpc_handle *h, int32_t level, mpc_level_stats *stats, double *ms_wall) {
+    if (!h || level < 0 || !h->sv_levels || level > MPC_MAX_NC) return MPC_ERR_INVALID;
+    auto &lv = h->sv_levels[level];
+    solve_wait_for(h, [&] { return lv.done.load(std::memory_order_acquire) != 0 || h->sv_finished.load(std::memory_order_acquire) != 0; });
+    if (!lv.done.load(std::memory_order_acquire)) return h->sv_rc != MPC_OK ? h->sv_rc : fail(h, MPC_ERR_STATE, "mpc_solve_level_wait: the solve ended before this level");
+    if (stats) *stats = lv.stats;
+    if (ms_wall) *ms_wall = lv.ms_wall;
+    return MPC_OK;
+}
+
+int mpc_solve_wait(mpc_handle *h, int32_t *n_levels) {
+    if (!h) return MPC_ERR_INVALID;
+    if (!h->worker.joinable() || !h->sv_levels) return fail(h, MPC_ERR_STATE, "mpc_solve_wait without mpc_solve_start");
+    {
+        std::unique_lock<std::mutex> lk(h->wm);
+        if (h->w_busy) {
+            lk.unlock();
+            for (int spin = 0; spin < 200000 && h->a_busy.load(std::memory_order_acquire); ++spin) __builtin_ia32_pause();
+            lk.lock();
+        }
+        h->wcv.wait(lk, [&] { return !h->w_busy; });
+    }
+    if (n_levels) {
+        int nl = 0;
+        while (nl < h->sv_n.load(std::memory_order_acquire) && h->sv_levels[nl].done.load(std::memory_order_acquire)) ++nl;
+        *n_levels = nl;
+    }
+    return h->sv_rc;
 }
 
 int mpc_base_result(mpc_handle *h, uint8_t *status, int64_t *n_regions, double *rec_d, int32_t *rec_i) {
@@ -2613,7 +2810,7 @@ int64_t mpc_level_slots(const mpc_handle *h) { return h ? h->n_opt : 0; }
 // in_place: the level's records were streamed into head_d / head_i / erows (host memory) by the region kernel itself; only
 // the slots of candidates re-solved by the LDS-engine kernel still have to be filled in
 static int level_regions_slots_impl(mpc_handle *h, double *head_d, int32_t *head_i, int64_t cap_slots, double *erows, int64_t cap_rows,
-                                    int64_t *n_slots, int64_t *n_rows, bool may_return_early, bool in_place = false) {
+                                    int64_t *n_slots, int64_t *n_rows, bool may_return_early, bool in_place) {
     if (!h) return MPC_ERR_INVALID;
     if (!h->level_done) return fail(h, MPC_ERR_STATE, "mpc_level_run has not been called for this frontier");
     if (h->so.active && !in_place) return fail(h, MPC_ERR_STATE, "the records of this level were streamed to the host (mpc_level_stream_info)");
@@ -2721,17 +2918,17 @@ static int level_regions_slots_impl(mpc_handle *h, double *head_d, int32_t *head
 
 int mpc_level_regions_slots(mpc_handle *h, double *head_d, int32_t *head_i, int64_t cap_slots, double *erows, int64_t cap_rows,
                             int64_t *n_slots, int64_t *n_rows) {
-    return level_regions_slots_impl(h, head_d, head_i, cap_slots, erows, cap_rows, n_slots, n_rows, false);
+    return level_regions_slots_impl(h, head_d, head_i, cap_slots, erows, cap_rows, n_slots, n_rows, false, false);
 }
 int mpc_level_regions_slots_async(mpc_handle *h, double *head_d, int32_t *head_i, int64_t cap_slots, double *erows, int64_t cap_rows,
                                   int64_t *n_slots, int64_t *n_rows) {
-    return level_regions_slots_impl(h, head_d, head_i, cap_slots, erows, cap_rows, n_slots, n_rows, true);
+    return level_regions_slots_impl(h, head_d, head_i, cap_slots, erows, cap_rows, n_slots, n_rows, true, false);
 }
 int mpc_level_regions_slots_nowait(mpc_handle *h, double *head_d, int32_t *head_i, int64_t cap_slots, double *erows, int64_t cap_rows,
                                    int64_t *n_slots, int64_t *n_rows) {
     if (!h) return MPC_ERR_INVALID;
     h->fetch_nowait = true;
-    const int rc = level_regions_slots_impl(h, head_d, head_i, cap_slots, erows, cap_rows, n_slots, n_rows, true);
+    const int rc = level_regions_slots_impl(h, head_d, head_i, cap_slots, erows, cap_rows, n_slots, n_rows, true, false);
     h->fetch_nowait = false;
     return rc;
 }

@@ -72,6 +72,7 @@ REGION_STATUS = 3   # MPC_REGION
 # overlap gains there (sub-programs of the mixed-integer enumeration, the first levels of every solve)
 STREAM_MIN_CANDIDATES = int(os.environ.get('MPC_STREAM_MIN', '512'))
 BASE_ON_TWIN = os.environ.get('MPC_NO_TWIN', '0') != '1'   # the base-set check on a second handle, started with the first streamed level
+SOLVE_LOOP = os.environ.get('MPC_NO_SOLVE_LOOP', '0') != '1'   # the level loop inside the library (mpc_solve_start); '1' = level by level from here (A/B)
 
 
 def _closing_rows_unused(eng, solution) -> bool:
@@ -136,6 +137,8 @@ def _solve(program, num_cores: int = -1, device: int = 0, profile: Optional[List
     max_depth = max(n_x, n_t) - eng.n_eq
     if max_levels is not None:
         max_depth = min(max_depth, max_levels)
+    if collect_regions and stream and SOLVE_LOOP and max_depth > 0:
+        return _solve_in_library(program, eng, solution, max_depth, profile, prune_lowdim, max_levels)
     eng.pruned_clear()
     eng.frontier_root()
     base_behind_level = False
@@ -226,6 +229,87 @@ def _solve(program, num_cores: int = -1, device: int = 0, profile: Optional[List
     if collect_regions and len(rd):
         solution.add_region(unpack_region(rd[0], ri[0], n_x, n_t, n_c, n_tc))
     solution.is_complete = collect_regions and max_levels is None      # every cardinality up to max(n_x, n_theta) was enumerated
+    return solution
+
+
+def _level_profile(depth, st, ms_wall):
+    return {'depth': depth, 'k': int(st.k), 'candidates': int(st.n),
+            'status': [int(v) for v in st.n_status], 'regions': int(st.n_regions),
+            'children': int(st.n_children), 'pruned_new': int(st.n_pruned_new),
+            'lp_pivots': int(st.lp_pivots), 'xtheta_lps': int(st.n_xtheta_lp), 'xtheta_fallbacks': int(st.n_xtheta_fallback), 'ms_verdict': float(st.ms_verdict),
+            'ms_region': float(st.ms_region), 'ms_children': float(st.ms_children),
+            'ms_theta': float(st.ms_theta), 'ms_x': float(st.ms_x), 'ms_region2': float(st.ms_region2),
+            'n_x_items': int(st.n_x_items), 'n_opt': int(st.n_opt), 'n_theta_items': int(st.n_theta_items),
+            'dict_read_bytes': int(st.dict_read_bytes), 'dict_write_bytes': int(st.dict_write_bytes),
+            'ms_kkt': float(st.ms_kkt), 'ms_xq': float(st.ms_xq), 'n_xq_items': int(st.n_xq_items), 'xq_pivots': int(st.xq_pivots),
+            'xq_record': [int(st.xq_record_ints), int(st.xq_record_rows), int(st.xq_record_cols)],
+            'ms_wall': ms_wall}
+
+
+def _solve_in_library(program, eng, solution, max_depth, profile, prune_lowdim, max_levels) -> Solution:
+    """The level loop of the reference's driver (mpqp_parrallel_combinatorial.py:102-139) runs INSIDE the library, on the handle's
+    worker thread (``Engine.solve_start`` -> mpc_solve_start): root frontier, level, frontier hand-over, next level -- the device never
+    waits for this interpreter between levels.  This thread only consumes: per level it is handed the region records (large levels:
+    page-locked arrays the region kernel is still writing, chunk by chunk; small ones: complete arrays) and builds the region objects
+    while later levels already run.  The base active set (driver :142-146) is checked on the program's second handle beside the levels.
+    ``MPC_NO_SOLVE_LOOP=1`` keeps the level-by-level loop in ``_solve``."""
+    from .._lib import MpcError
+    n_x, n_t, n_c, n_tc = eng.n_x, eng.n_t, eng.n_c, eng.n_tc
+    twin = None
+    if BASE_ON_TWIN:
+        try:
+            twin = eng.twin()
+            twin.level_start(False, only_base=True)
+        except Exception:
+            twin = None
+    eng.solve_start(max_depth, stream=True, fetch=True, then_base=twin is None, keep_lowdim=not prune_lowdim)
+    regions = solution.critical_regions
+    level = 0
+    try:
+        while True:
+            info = eng.solve_level(level)
+            if info is None:
+                break
+            mode, k, _, hd, hi, er, chunk, n_chunks = info
+            first = len(regions)
+            if mode == 1:
+                batch = RegionBatch(hd, hi, er, n_x, n_t, n_c, n_tc, k, ())
+                status_col = hi[:, 0]
+                for j in range(n_chunks):
+                    eng.solve_chunk_wait(level, j)
+                    lo = j * chunk
+                    regions.extend(batch.regions_of((lo + numpy.flatnonzero(status_col[lo:lo + chunk] == REGION_STATUS)).tolist()))
+            elif mode == 2:
+                regions.extend(RegionBatch(hd, hi, er, n_x, n_t, n_c, n_tc, k, numpy.flatnonzero(hi[:, 0] == REGION_STATUS)).regions())
+            st, ms_wall = eng.solve_level_wait(level)
+            if mode == 1 and st.n_region_retry:
+                # some candidates were re-solved by the LDS-engine kernel after the stream (their slots are filled now): list the level again
+                del regions[first:]
+                regions.extend(batch.regions_of(numpy.flatnonzero(hi[:, 0] == REGION_STATUS).tolist()))
+            if profile is not None:
+                profile.append(_level_profile(level + 1, st, ms_wall))
+            level += 1
+    except MpcError:
+        eng.solve_wait()      # raises what the loop itself failed with (MpcCapacityError: the solve is repeated without the overlap)
+        raise
+    eng.solve_wait()
+    # the base active set (= the equality rows) is tested last, like the reference (driver :142-146)
+    if twin is not None:
+        twin.level_wait()
+        res = twin.base_result()
+    else:
+        res = eng.base_result()
+    if res is None:
+        base = numpy.arange(eng.n_eq, dtype=numpy.int32).reshape(1, -1)
+        status, rd, ri, _, _ = eng.check_level(base, numpy.zeros((0, 2), dtype=numpy.uint64), False)
+    else:
+        status, rd, ri = res
+    if profile is not None:
+        profile.append({'depth': 0, 'k': eng.n_eq, 'candidates': 1, 'status': numpy.bincount(status, minlength=6).tolist(),
+                        'regions': len(rd)})
+    if len(rd):
+        solution.add_region(unpack_region(rd[0], ri[0], n_x, n_t, n_c, n_tc))
+    solution.is_complete = max_levels is None
     return solution
 
 
