@@ -750,6 +750,49 @@ MPC_GLOBAL void MPC_LB(256) k_zero_bufs(ZeroBufs z) {
     }
 }
 
+// Everything a region launch needs cleared / copied / initialised, as ONE launch (each hipMemsetAsync / hipMemcpyAsync costs the host
+// ~16 us and the device a dependent 5-10 us step: five of them sat between the theta stage and the region kernel of every large level):
+// up to four buffers zeroed, one int32 list copied (the optimal candidates, out of the partition buffer the next partition reuses),
+// the spare record slots marked empty (what k_init_slots does).
+struct RegionPrep { ZeroBufs z; const int32_t *copy_src; int32_t *copy_dst; long long copy_n; int32_t *head_i; int fi, first, extra; };
+MPC_GLOBAL void MPC_LB(256) k_region_prep(RegionPrep a) {
+    for (int j = 0; j < 4; ++j) {
+        const unsigned long long bytes = a.z.bytes[j];
+        if (!a.z.p[j] || bytes == 0) continue;
+        if ((reinterpret_cast<unsigned long long>(a.z.p[j]) & 7ull) == 0 && (bytes & 7ull) == 0) {
+            unsigned long long *p = reinterpret_cast<unsigned long long *>(a.z.p[j]);
+            for (unsigned long long i = blockIdx.x * 256ull + threadIdx.x; i < bytes / 8; i += (unsigned long long)gridDim.x * 256ull) p[i] = 0ull;
+        } else {
+            unsigned char *p = reinterpret_cast<unsigned char *>(a.z.p[j]);
+            for (unsigned long long i = blockIdx.x * 256ull + threadIdx.x; i < bytes; i += (unsigned long long)gridDim.x * 256ull) p[i] = 0;
+        }
+    }
+    for (long long i = blockIdx.x * 256ll + threadIdx.x; i < a.copy_n; i += (long long)gridDim.x * 256ll) a.copy_dst[i] = a.copy_src[i];
+    for (int j = blockIdx.x * 256 + threadIdx.x; j < a.extra; j += gridDim.x * 256) { int32_t *hi = a.head_i + (size_t)(a.first + j) * a.fi; hi[0] = 0; hi[1] = -1; }
+}
+
+// The slot arrays of a level that did not stream (head_d, head_i, rows) from their device buffers into page-locked host blocks, by
+// stores of this kernel instead of three copy commands (each ~16 us of host time) and a synchronisation: the workgroup that finishes
+// last raises `flag` (host memory, system-scope release), which is all the consumer waits for -- the level loop goes on at once.
+struct FetchCopy { const void *src[3]; void *dst[3]; unsigned long long bytes[3]; unsigned int *counter; int32_t *flag; };
+MPC_GLOBAL void MPC_LB(256) k_fetch_slots(FetchCopy a) {
+    for (int j = 0; j < 3; ++j) {
+        const unsigned long long words = a.bytes[j] / 4;      // every array is a whole number of 4-byte words
+        const unsigned int *src = static_cast<const unsigned int *>(a.src[j]);
+        unsigned int *dst = static_cast<unsigned int *>(a.dst[j]);
+        for (unsigned long long i = blockIdx.x * 256ull + threadIdx.x; i < words; i += (unsigned long long)gridDim.x * 256ull) dst[i] = src[i];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        if (atomicAdd(a.counter, 1u) + 1u == gridDim.x) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "");
+            atomicExch(a.counter, 0u);
+            __hip_atomic_store(a.flag, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
+}
+
 // copies a few words of device memory into pinned host memory (a read-back without a copy command: on this runtime a
 // hipMemcpyAsync costs the host ~16 us, a launch ~3 us)
 MPC_GLOBAL void k_publish_words(const unsigned int *__restrict__ src, unsigned int *__restrict__ dst, int n) {

@@ -174,17 +174,31 @@ MPC_GLOBAL void MPC_LB(256) k_kkt_thread(const DevProblem *__restrict__ Pg, cons
     // ---- box screen over the inactive rows (k_theta2's test, same arithmetic; the equality rows are never inactive) ---------------
     const double *blo = ta.tvp + NT * NT + NT, *bhi = blo + NT;
     bool fired = false;
-    for (int ci = ne; ci < nc; ++ci) {
+    // Rows are taken RU at a time with all their W gathers issued before the first is used: one row per trip made the loop a chain of
+    // n_c dependent L2 round trips -- 55 us for ONE candidate, the floor of this kernel on every level however small (round 4,
+    // tools/timeline.sh).  Same rows, same order, same arithmetic per row.
+    constexpr int RU = K <= 4 ? 8 : (K <= 6 ? 4 : 2);
+    for (int c0 = ne; c0 < nc; c0 += RU) {
+      double wpre[RU][K];
+#pragma unroll
+      for (int u = 0; u < RU; ++u) {
+        const double *Wrow = ta.Wr + (size_t)min(c0 + u, nc - 1) * nc;
+#pragma unroll
+        for (int a = 0; a < K; ++a) wpre[u][a] = Wrow[as[a]];
+      }
+#pragma unroll
+      for (int u = 0; u < RU; ++u) {
+        const int ci = c0 + u;
+        if (ci >= nc) break;
         bool active = false;
 #pragma unroll
         for (int a = 0; a < K; ++a) active = active || (as[a] == ci);
         double acc[LS];
 #pragma unroll
         for (int t = 0; t < LS; ++t) acc[t] = ta.UVrp[ci * LS + t];
-        const double *Wrow = ta.Wr + (size_t)ci * nc;
 #pragma unroll
         for (int a = 0; a < K; ++a) {
-            const double w = Wrow[as[a]];
+            const double w = wpre[u][a];
 #pragma unroll
             for (int t = 0; t < LS; ++t) acc[t] = fma(w, Lr[a][t], acc[t]);
         }
@@ -212,7 +226,8 @@ MPC_GLOBAL void MPC_LB(256) k_kkt_thread(const DevProblem *__restrict__ Pg, cons
             smax -= term;
         }
         if (!active && smax < -10 * TOL_FEAS * sc) fired = true;   // the margin is meant in the row's own units
-        if (((ci - ne) & 3) == 3 && __all(fired)) break;
+      }
+      if (__all(fired)) break;
     }
     if (fired) {
         code[c] = ill ? KK_ILL : 0;

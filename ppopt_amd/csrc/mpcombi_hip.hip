@@ -277,6 +277,10 @@ struct mpc_handle {
                                      // a region at 4 -- and move the facet list of one sliver region)
     bool no_lean = false;            // MPC_NO_LEAN=1: large levels read every list length back (round-2 behaviour); default: only the lengths the
                                      // host needs to size the region stage are read back, the other stages take theirs from device memory
+    int r2_cap_pct = 100;            // MPC_R2_CAP: share (per cent) of k_region2's wave slots an overlapped one-wave-per-candidate launch may take
+    bool no_fetch_kernel = false;    // MPC_NO_FETCH_KERNEL=1: the solve loop fetches the records of a level that did not stream with copy commands and waits (A/B)
+    bool no_spec_tail = false;       // MPC_NO_SPEC_TAIL=1: a large level waits for the second partition and for the region kernel's give-up count before
+                                     // it queues its end (round-3 behaviour); default: the end is queued behind the partition, one synchronisation
     bool test_small_fallback = false; // MPC_TEST_SMALL_FALLBACK=1 (tests): every level run without host round trips reports "repeat on the classic path"
     bool no_smallpath = false;       // MPC_NO_SMALLPATH=1: levels of any size take the classic path with its host round trips (A/B)
     long long smallpath_max = 4096;  // MPC_SMALLPATH_MAX: largest level (candidates) that runs without host round trips (measured: config 4 is
@@ -379,6 +383,7 @@ struct mpc_handle {
         void *hd = nullptr, *hi = nullptr, *er = nullptr;   // page-locked blocks; the caller's once mpc_solve_level has handed them over
         bool handed = false;
         const int32_t *flags = nullptr;                     // chunk flags (valid while the level runs)
+        const int32_t *ready_flag = nullptr;                // mode 2, copied by k_fetch_slots: raised (behind head_i, in its block) when the arrays are complete
         mpc_level_stats stats{};
         double ms_wall = 0.0;
         std::atomic<int> ready{0}, done{0};
@@ -571,6 +576,9 @@ static int create_fill(const mpc_problem *p, int32_t device, void *stream, mpc_h
     { const char *ev = std::getenv("MPC_TEST_SPARE"); h->test_spare = ev ? std::atoi(ev) : 0; }
     { const char *ev = std::getenv("MPC_NO_SMALLPATH"); h->no_smallpath = ev && ev[0] == '1'; }
     { const char *ev = std::getenv("MPC_NO_LEAN"); h->no_lean = ev && ev[0] == '1'; }
+    { const char *ev = std::getenv("MPC_NO_SPEC_TAIL"); h->no_spec_tail = ev && ev[0] == '1'; }
+    { const char *ev = std::getenv("MPC_NO_FETCH_KERNEL"); h->no_fetch_kernel = ev && ev[0] == '1'; }
+    { const char *ev = std::getenv("MPC_R2_CAP"); if (ev && std::atoi(ev) > 0) h->r2_cap_pct = std::min(100, std::atoi(ev)); }
     { const char *ev = std::getenv("MPC_TEST_SMALL_FALLBACK"); h->test_small_fallback = ev && ev[0] == '1'; }
     { const char *ev = std::getenv("MPC_RSPLIT_MAX"); if (ev) { int v = std::atoi(ev); h->rsplit_max = v >= 16 ? 16 : (v >= 8 ? 8 : (v >= 4 ? 4 : (v >= 2 ? 2 : 1))); } }
     { const char *ev = std::getenv("MPC_SMALLPATH_MAX"); if (ev) h->smallpath_max = std::atoll(ev); }
@@ -1842,7 +1850,6 @@ static int level_run_impl(mpc_handle *h, int32_t gen_children, int32_t flags, mp
         HIP_TRY(h, h->pos.ensure(nn * sizeof(int32_t), st));
         HIP_TRY(h, h->opt_list.ensure(nn * sizeof(int32_t), st));
         HIP_TRY(h, h->pruned.ensure((size_t)(h->n_pruned + n) * h->mw * sizeof(uint64_t), st, true));   // the level's newly pruned masks go behind the list
-        HIP_TRY(h, hipMemsetAsync(h->ctr.p, 0, sizeof(LevelCounters), st));
         LevelCounters *ctr = h->ctr.as<LevelCounters>();
         int32_t *total = h->tot_dev;          // device alias of h->tot_host: valid on the host after the next synchronisation
         const bool small = n <= SMALL_LEVEL_N;
@@ -1873,28 +1880,63 @@ static int level_run_impl(mpc_handle *h, int32_t gen_children, int32_t flags, mp
         // launched for the bound the host does know.
         const bool lean = !h->no_lean;
         HIP_TRY(h, h->dcnt.ensure(32 * sizeof(int32_t), st));
-        HIP_TRY(h, hipMemsetAsync(h->dcnt.p, 0, 32 * sizeof(int32_t), st));
+        {   // counters and list lengths cleared by one launch (a hipMemsetAsync costs the host ~16 us, a launch ~3 us)
+            ZeroBufs z{};
+            z.p[0] = h->ctr.p; z.bytes[0] = sizeof(LevelCounters);
+            z.p[1] = h->dcnt.p; z.bytes[1] = 32 * sizeof(int32_t);
+            hipLaunchKernelGGL(k_zero_bufs, dim3(1), dim3(256), 0, st, z);
+            HIP_TRY(h, hipGetLastError());
+        }
         int32_t *dcnt = h->dcnt.as<int32_t>();
         bool theta_lean = false, xq_lean = false, children_lean = false;
         // deterministic partition of the candidates into up to four lists by status (spec: status -> class nibble, 15 = none);
         // the lists are h->part_lists + c * n, their lengths come back in counts[]
         const int nb1024 = (int)((n + 1023) / 1024);
-        auto partition = [&](std::initializer_list<std::pair<int, int>> classes, int32_t counts[PART_CLASSES]) -> int {
+        // deferred: the counts go to the pinned words [12..15] and nobody waits here (the caller reads them after a later synchronisation)
+        auto partition = [&](std::initializer_list<std::pair<int, int>> classes, int32_t counts[PART_CLASSES], bool deferred = false) -> int {
             unsigned long long spec = ~0ull;
             for (const auto &sc : classes) spec = (spec & ~(15ull << (4 * sc.first))) | ((unsigned long long)sc.second << (4 * sc.first));
             HIP_TRY(h, h->part_counts.ensure((size_t)PART_CLASSES * nb1024 * sizeof(int32_t), st));
             HIP_TRY(h, h->part_lists.ensure((size_t)PART_CLASSES * nn * sizeof(int32_t), st));
+            int32_t *tot = deferred ? total + 12 : total;
             if (small) {
-                hipLaunchKernelGGL(k_partition_small, dim3(1), dim3(1024), 0, st, h->status.as<uint8_t>(), (int)n, spec, h->part_lists.as<int32_t>(), (long long)n, total);
+                hipLaunchKernelGGL(k_partition_small, dim3(1), dim3(1024), 0, st, h->status.as<uint8_t>(), (int)n, spec, h->part_lists.as<int32_t>(), (long long)n, tot);
             } else {
                 hipLaunchKernelGGL(k_part_count, dim3(nb1024), dim3(1024), 0, st, h->status.as<uint8_t>(), n, spec, h->part_counts.as<int32_t>(), nb1024);
-                hipLaunchKernelGGL(k_part_sums, dim3(PART_CLASSES), dim3(1024), 0, st, h->part_counts.as<int32_t>(), nb1024, total);
+                hipLaunchKernelGGL(k_part_sums, dim3(PART_CLASSES), dim3(1024), 0, st, h->part_counts.as<int32_t>(), nb1024, tot);
                 hipLaunchKernelGGL(k_part_scatter, dim3(nb1024), dim3(1024), 0, st, h->status.as<uint8_t>(), n, spec, h->part_counts.as<int32_t>(), nb1024,
                                    h->part_lists.as<int32_t>());
             }
             HIP_TRY(h, hipGetLastError());
+            if (deferred) return MPC_OK;
             HIP_TRY(h, hipStreamSynchronize(st));
             for (int c = 0; c < PART_CLASSES; ++c) counts[c] = h->tot_host[c];
+            return MPC_OK;
+        };
+        // clears / copies / slot marks that a region launch and the (x,theta) stage need, collected and issued as ONE launch (k_region_prep)
+        RegionPrep prep{};
+        bool prep_any = false;
+        auto prep_flush = [&]() -> int {
+            if (!prep_any) return MPC_OK;
+            unsigned long long work = (unsigned long long)std::max<long long>(prep.copy_n, prep.extra);
+            for (int j = 0; j < 4; ++j) work = std::max(work, prep.z.bytes[j] / 8);
+            hipLaunchKernelGGL(k_region_prep, dim3((unsigned)std::min<unsigned long long>(256, work / 1024 + 1)), dim3(256), 0, st, prep);
+            HIP_TRY(h, hipGetLastError());
+            prep = RegionPrep{}; prep_any = false;
+            return MPC_OK;
+        };
+        auto prep_zero = [&](void *ptr, size_t bytes) -> int {
+            if (!ptr || bytes == 0) return MPC_OK;
+            int j = 0;
+            while (j < 4 && prep.z.p[j]) ++j;
+            if (j == 4) { int rcs = prep_flush(); if (rcs) return rcs; j = 0; }
+            prep.z.p[j] = ptr; prep.z.bytes[j] = bytes; prep_any = true;
+            return MPC_OK;
+        };
+        auto prep_copy = [&](int32_t *dst, const int32_t *src, long long cnt) -> int {
+            if (cnt <= 0) return MPC_OK;
+            if (prep.copy_n > 0) { int rcs = prep_flush(); if (rcs) return rcs; }
+            prep.copy_dst = dst; prep.copy_src = src; prep.copy_n = cnt; prep_any = true;
             return MPC_OK;
         };
         auto part_list = [&](int c) -> int32_t * { return h->part_lists.as<int32_t>() + (size_t)c * nn; };
@@ -1919,9 +1961,12 @@ static int level_run_impl(mpc_handle *h, int32_t gen_children, int32_t flags, mp
             if (W > 1) {
                 HIP_TRY(h, h->kept_g.ensure((size_t)n_opt * ldk, st));
                 HIP_TRY(h, h->done_g.ensure((size_t)n_opt * 2 * sizeof(unsigned int), st));
-                HIP_TRY(h, hipMemsetAsync(h->done_g.p, 0, (size_t)n_opt * 2 * sizeof(unsigned int), st));
+                { int rcs = prep_zero(h->done_g.p, (size_t)n_opt * 2 * sizeof(unsigned int)); if (rcs) return rcs; }
             }
-            const dim3 g((unsigned)std::min<long long>((long long)n_opt * W, h->grid_r2)), b(64);
+            // an overlapped launch may take only a share of the wave slots (r2_cap_pct): its 256-register wavefronts otherwise fill the
+            // register file of every SIMD they sit on and the (x,theta) kernel beside them gets no slot there until they leave
+            const long long grid_cap = (rst != st && one_wave) ? std::max<long long>(h->n_cu, (long long)h->grid_r2 * h->r2_cap_pct / 100) : h->grid_r2;
+            const dim3 g((unsigned)std::min<long long>((long long)n_opt * W, grid_cap)), b(64);
             const DevProblem *pr = h->pr2_dev.as<DevProblem>();
             // where the records go: device buffers (fetched / gathered later), or -- streaming -- page-locked host blocks the
             // kernel writes directly, in chunks the host consumes while the kernel is still running
@@ -1944,7 +1989,7 @@ static int level_run_impl(mpc_handle *h, int32_t gen_children, int32_t flags, mp
                 std::memset(h->st_flags.p, 0, (size_t)so.n_chunks * sizeof(int32_t));
                 h->cw_chunks = so.n_chunks;
                 HIP_TRY(h, h->chunk_count.ensure((size_t)so.n_chunks * sizeof(unsigned int), st));
-                HIP_TRY(h, hipMemsetAsync(h->chunk_count.p, 0, (size_t)so.n_chunks * sizeof(unsigned int), st));
+                { int rcs = prep_zero(h->chunk_count.p, (size_t)so.n_chunks * sizeof(unsigned int)); if (rcs) return rcs; }
                 void *d_hd = nullptr, *d_hi = nullptr, *d_er = nullptr, *d_fl = nullptr;
                 HIP_TRY(h, hipHostGetDevicePointer(&d_hd, so.hd, 0));
                 HIP_TRY(h, hipHostGetDevicePointer(&d_hi, so.hi, 0));
@@ -1959,7 +2004,8 @@ static int level_run_impl(mpc_handle *h, int32_t gen_children, int32_t flags, mp
                                                    W, h->kept_g.as<uint8_t>(), ldk, h->done_g.as<unsigned int>(), \
                                                    h->no_rbox ? (const double *)nullptr : h->targs.tvp + (size_t)NT_ * NT_ + NT_, rs)
             region_out_hi = out_hi;
-            if (extra > 0) hipLaunchKernelGGL(k_init_slots, dim3((unsigned)((extra + 255) / 256)), dim3(256), 0, st, out_hi, h->fi, n_opt, extra, 0, (const int32_t *)nullptr);
+            if (extra > 0) { prep.head_i = out_hi; prep.fi = h->fi; prep.first = n_opt; prep.extra = extra; prep_any = true; }
+            { int rcs = prep_flush(); if (rcs) return rcs; }
             if (rst != st) {
                 // fork; the main stream continues only when the side stream has reached the region kernel, so that the region
                 // wavefronts (the long chains) are placed first and the (x,theta) kernels fill in around them -- without this the
@@ -1990,6 +2036,50 @@ static int level_run_impl(mpc_handle *h, int32_t gen_children, int32_t flags, mp
         bool region_launched = false;
         int32_t n_late = 0;   // optimal candidates found after an overlapped region launch (spare slots)
         int32_t n_opt_fast = -1;   // >= 0: the fast path has already built h->opt_list
+        // The end of a level -- pruned masks, children, histogram, counters published -- as launches only (the caller synchronises).
+        bool tail_done = false;
+        auto queue_tail = [&]() -> int {
+            const int keep_lowdim = (flags & MPC_LEVEL_KEEP_LOWDIM) ? 1 : 0;
+            if (flags & MPC_LEVEL_GRAPH) { /* no pruning in the graph traversal */ }
+            else if (h->mw == 2) hipLaunchKernelGGL(k_pruned_append<2>, dim3(blocks256), dim3(256), 0, st, h->frontier.as<int32_t>(), n, k, h->status.as<uint8_t>(),
+                                               h->pruned.as<unsigned long long>() + (size_t)h->n_pruned * h->mw, ctr, keep_lowdim);
+            else hipLaunchKernelGGL(k_pruned_append<4>, dim3(blocks256), dim3(256), 0, st, h->frontier.as<int32_t>(), n, k, h->status.as<uint8_t>(),
+                                    h->pruned.as<unsigned long long>() + (size_t)h->n_pruned * h->mw, ctr, keep_lowdim);
+            if (gen_children) {
+                HIP_TRY(h, h->childmask.ensure(nn * h->mw * sizeof(uint64_t), st));
+                HIP_TRY(h, h->count.ensure(nn * sizeof(int32_t), st));
+                HIP_TRY(h, h->offset.ensure(nn * sizeof(int32_t), st));
+                if (h->mw == 2) hipLaunchKernelGGL(k_children_count<2>, dim3((unsigned)n), dim3(64), 0, st, h->Pv, h->frontier.as<int32_t>(), n, k, h->status.as<uint8_t>(),
+                                                   h->pruned.as<unsigned long long>(), (long long)h->n_pruned, h->childmask.as<unsigned long long>(), h->count.as<int32_t>(), keep_lowdim);
+                else hipLaunchKernelGGL(k_children_count<4>, dim3((unsigned)n), dim3(64), 0, st, h->Pv, h->frontier.as<int32_t>(), n, k, h->status.as<uint8_t>(),
+                                        h->pruned.as<unsigned long long>(), (long long)h->n_pruned, h->childmask.as<unsigned long long>(), h->count.as<int32_t>(), keep_lowdim);
+                // lean: children and their parent slots are sized by the bound n (n_c - k) and written without waiting for the count
+                const double child_bound_bytes = (double)nn * std::max(h->n_c - k, 1) * (k + 2) * 4.0;
+                children_lean = lean && child_bound_bytes <= 1.5e9;
+                { int rcs = launch_scan(h, h->count.as<int32_t>(), h->offset.as<int32_t>(), n, children_lean ? dcnt + 20 : total); if (rcs) return rcs; }
+                HIP_TRY(h, hipGetLastError());
+                int32_t n_children = 0;
+                if (children_lean) n_children = (int32_t)std::min<double>((double)nn * std::max(h->n_c - k, 1), 2147483647.0 / (k + 2));   // the bound, for the allocation only
+                else { HIP_TRY(h, hipStreamSynchronize(st)); n_children = h->tot_host[0]; }
+                h->n_children = children_lean ? 0 : n_children;
+                if (n_children > 0) {
+                    HIP_TRY(h, h->children.ensure((size_t)n_children * (k + 1) * sizeof(int32_t), st));
+                    HIP_TRY(h, h->parent_slot_next.ensure((size_t)n_children * sizeof(int32_t), st));
+                    hipLaunchKernelGGL(k_children_write, dim3((unsigned)n), dim3(64), 0, st, h->frontier.as<int32_t>(), n, k, h->mw,
+                                       h->childmask.as<unsigned long long>(), h->offset.as<int32_t>(), h->children.as<int32_t>(),
+                                       h->storing ? h->dict_stored[h->dict_cur].as<uint8_t>() : (const uint8_t *)nullptr, h->parent_slot_next.as<int32_t>());
+                    HIP_TRY(h, hipGetLastError());
+                }
+            }
+            hipLaunchKernelGGL(k_histogram, dim3(std::min(blocks256, 1024)), dim3(256), 0, st, h->status.as<uint8_t>(), n, ctr);
+            HIP_TRY(h, hipGetLastError());
+            HIP_TRY(h, hipEventRecord(h->ev[3], st));
+            static_assert(sizeof(LevelCounters) % 4 == 0 && sizeof(LevelCounters) + 64 + 32 * 4 <= 4096, "LevelCounters + list lengths must fit the pinned block");
+            hipLaunchKernelGGL(k_publish_words2, dim3(1), dim3(128), 0, st, reinterpret_cast<const unsigned int *>(ctr), (int)(sizeof(LevelCounters) / 4),
+                               reinterpret_cast<const unsigned int *>(dcnt), 32, reinterpret_cast<unsigned int *>(h->tot_dev + 16));
+            HIP_TRY(h, hipGetLastError());
+            return MPC_OK;
+        };
         // verdict
         HIP_TRY(h, hipEventRecord(h->ev[0], st));
         if (h->fast && !h->force_v1) {
@@ -2079,7 +2169,7 @@ static int level_run_impl(mpc_handle *h, int32_t gen_children, int32_t flags, mp
                 HIP_TRY(h, h->dict_d[h->dict_cur].ensure(nn * h->dict_stride_d * sizeof(double), st));
                 HIP_TRY(h, h->dict_i[h->dict_cur].ensure(nn * h->dict_stride_i * sizeof(int32_t), st));
                 HIP_TRY(h, h->dict_stored[h->dict_cur].ensure(nn, st));
-                HIP_TRY(h, hipMemsetAsync(h->dict_stored[h->dict_cur].p, 0, nn, st));
+                { int rcs = prep_zero(h->dict_stored[h->dict_cur].p, nn); if (rcs) return rcs; }
                 dc.cur_d = h->dict_d[h->dict_cur].as<double>(); dc.cur_i = h->dict_i[h->dict_cur].as<int32_t>();
                 dc.stored = h->dict_stored[h->dict_cur].as<uint8_t>();
                 h->storing = true;
@@ -2109,7 +2199,7 @@ static int level_run_impl(mpc_handle *h, int32_t gen_children, int32_t flags, mp
                 const int32_t hold = std::min<int32_t>(std::max(h->test_late, 0), cntA[2] - 1);
                 const int32_t n_launch = cntA[2] - hold;
                 region_extra = std::max(0, n_early + hold + std::min<int32_t>(cntA[3], 1024) - std::max(h->test_spare, 0));
-                HIP_TRY(h, hipMemcpyAsync(h->opt_list.p, part_list(2), (size_t)n_launch * sizeof(int32_t), hipMemcpyDeviceToDevice, st));
+                { int rcs = prep_copy(h->opt_list.as<int32_t>(), part_list(2), n_launch); if (rcs) return rcs; }
                 h->opt_ptr = h->opt_list.as<int32_t>();
                 h->n_opt = n_launch;
                 int rcs = region2_launch(n_launch, region_extra, h->stream3, x_items >= h->roverlap_long);
@@ -2118,6 +2208,7 @@ static int level_run_impl(mpc_handle *h, int32_t gen_children, int32_t flags, mp
             }
             auto launch_x = [&](const int32_t *ls, int n_items, const DictCache &d0) -> int {
                 // ctr->work_x is zero: the counters were cleared at the start of the level and this is the level's only k_x2 launch
+                { int rcs = prep_flush(); if (rcs) return rcs; }
                 DictCache d = d0;
                 const long long grid_x = (long long)h->n_cu * 16, n_all = (long long)n_items + d.n_pre1 + d.n_pre2;
                 d.chunk = (int)std::max<long long>(1, std::min<long long>(16, n_all / (grid_x * 8)));
@@ -2205,7 +2296,30 @@ static int level_run_impl(mpc_handle *h, int32_t gen_children, int32_t flags, mp
             // second partition: [0] doubtful candidates of the (x,theta) stage, [2] the optimal candidates for the region stage
             int32_t cntB[PART_CLASSES] = {0, 0, 0, 0};
             if (region_launched) HIP_TRY(h, hipStreamWaitEvent(st, h->ev_rjoin, 0));   // the region kernel rewrites statuses
-            { int rcs = partition({{ST_RETRY, 0}, {ST_OPT_PENDING, 2}}, cntB); if (rcs) return rcs; }
+            bool have_cntB = false;
+            if (region_launched && lean && !h->no_spec_tail) {
+                // The overlapped region stage has finished (the stream waits for it above), so in the usual case nothing is left to do but
+                // the end of the level: no doubtful candidate of the (x,theta) stage, no late optimal one, none that k_region2 gave up on.
+                // The three counts that say so used to cost three host round trips (this partition, the n_rretry read-back, the final one:
+                // 45-70 us of idle device per large level, tools/timeline.sh); now the end of the level is queued right behind the
+                // partition, ONE synchronisation reads everything, and only when a count is not zero the classic sequence below runs and
+                // the end of the level is repeated (its two accumulating counters are cleared; everything else it wrote is overwritten).
+                { int rcs = partition({{ST_RETRY, 0}, {ST_OPT_PENDING, 2}}, cntB, true); if (rcs) return rcs; }
+                hipLaunchKernelGGL(k_publish_words, dim3(1), dim3(64), 0, st, &ctr->n_rretry, reinterpret_cast<unsigned int *>(h->tot_dev + 8), 1);
+                HIP_TRY(h, hipEventRecord(h->ev[1], st));
+                HIP_TRY(h, hipEventRecord(h->ev[2], st));
+                { int rcs = queue_tail(); if (rcs) return rcs; }
+                HIP_TRY(h, hipStreamSynchronize(st));
+                for (int c = 0; c < PART_CLASSES; ++c) cntB[c] = h->tot_host[12 + c];
+                have_cntB = true;
+                if (cntB[0] == 0 && cntB[2] == 0 && h->tot_host[8] == 0) tail_done = true;
+                else {
+                    HIP_TRY(h, hipMemsetAsync(&ctr->n_pruned_new, 0, sizeof(unsigned int), st));
+                    HIP_TRY(h, hipMemsetAsync(ctr->status, 0, sizeof(ctr->status), st));
+                    h->n_children = 0;
+                }
+            }
+            if (!have_cntB) { int rcs = partition({{ST_RETRY, 0}, {ST_OPT_PENDING, 2}}, cntB); if (rcs) return rcs; }
             n_retry = cntB[0];
             if (n_retry > 0 && !region_launched && !h->no_roverlap && cntB[2] > 0 && h->fast_r >= 0 && !(flags & MPC_LEVEL_GRAPH)) {
                 // the region stage was not started under the (x,theta) stage (grouped quick test, short stage): it runs beside the
@@ -2249,7 +2363,7 @@ static int level_run_impl(mpc_handle *h, int32_t gen_children, int32_t flags, mp
                                h->frontier.as<int32_t>(), n, k, h->status.as<uint8_t>(), ctr, (const int32_t *)nullptr, (const int32_t *)nullptr);
             HIP_TRY(h, hipGetLastError());
         }
-        HIP_TRY(h, hipEventRecord(h->ev[1], st));
+        if (!tail_done) HIP_TRY(h, hipEventRecord(h->ev[1], st));
         // optimal candidates -> region kernel
         int32_t n_opt = n_opt_fast;
         if (n_opt < 0) {
@@ -2262,7 +2376,8 @@ static int level_run_impl(mpc_handle *h, int32_t gen_children, int32_t flags, mp
             n_opt = h->tot_host[0];
         }
         h->n_opt = n_opt;
-        if (n_opt > 0 && h->fast && h->fast_r >= 0 && !h->force_v1) {
+        if (tail_done) { /* the overlapped region stage left nothing to do: see the speculative end of the level above */ }
+        else if (n_opt > 0 && h->fast && h->fast_r >= 0 && !h->force_v1) {
             if (!region_launched) { int rcs = region2_launch(n_opt, 0, st, false); if (rcs) return rcs; }
             // candidates k_region2 gave up on (counted by the kernel; normally none): the LDS-engine kernel, fixed-stride records
             hipLaunchKernelGGL(k_publish_words, dim3(1), dim3(64), 0, st, &ctr->n_rretry, reinterpret_cast<unsigned int *>(h->tot_dev + 8), 1);
@@ -2285,50 +2400,12 @@ static int level_run_impl(mpc_handle *h, int32_t gen_children, int32_t flags, mp
             int rcs = launch_region_v1(h, h->opt_ptr, n_opt, k, ctr);
             if (rcs) return rcs;
         }
-        HIP_TRY(h, hipEventRecord(h->ev[2], st));
-        // pruned masks of this level + children
-        const int keep_lowdim = (flags & MPC_LEVEL_KEEP_LOWDIM) ? 1 : 0;
-        if (flags & MPC_LEVEL_GRAPH) { /* no pruning in the graph traversal */ }
-        else if (h->mw == 2) hipLaunchKernelGGL(k_pruned_append<2>, dim3(blocks256), dim3(256), 0, st, h->frontier.as<int32_t>(), n, k, h->status.as<uint8_t>(),
-                                           h->pruned.as<unsigned long long>() + (size_t)h->n_pruned * h->mw, ctr, keep_lowdim);
-        else hipLaunchKernelGGL(k_pruned_append<4>, dim3(blocks256), dim3(256), 0, st, h->frontier.as<int32_t>(), n, k, h->status.as<uint8_t>(),
-                                h->pruned.as<unsigned long long>() + (size_t)h->n_pruned * h->mw, ctr, keep_lowdim);
-        if (gen_children) {
-            HIP_TRY(h, h->childmask.ensure(nn * h->mw * sizeof(uint64_t), st));
-            HIP_TRY(h, h->count.ensure(nn * sizeof(int32_t), st));
-            HIP_TRY(h, h->offset.ensure(nn * sizeof(int32_t), st));
-            if (h->mw == 2) hipLaunchKernelGGL(k_children_count<2>, dim3((unsigned)n), dim3(64), 0, st, h->Pv, h->frontier.as<int32_t>(), n, k, h->status.as<uint8_t>(),
-                                               h->pruned.as<unsigned long long>(), (long long)h->n_pruned, h->childmask.as<unsigned long long>(), h->count.as<int32_t>(), keep_lowdim);
-            else hipLaunchKernelGGL(k_children_count<4>, dim3((unsigned)n), dim3(64), 0, st, h->Pv, h->frontier.as<int32_t>(), n, k, h->status.as<uint8_t>(),
-                                    h->pruned.as<unsigned long long>(), (long long)h->n_pruned, h->childmask.as<unsigned long long>(), h->count.as<int32_t>(), keep_lowdim);
-            // lean: children and their parent slots are sized by the bound n (n_c - k) and written without waiting for the count
-            const double child_bound_bytes = (double)nn * std::max(h->n_c - k, 1) * (k + 2) * 4.0;
-            children_lean = lean && child_bound_bytes <= 1.5e9;
-            { int rcs = launch_scan(h, h->count.as<int32_t>(), h->offset.as<int32_t>(), n, children_lean ? dcnt + 20 : total); if (rcs) return rcs; }
-            HIP_TRY(h, hipGetLastError());
-            int32_t n_children = 0;
-            if (children_lean) n_children = (int32_t)std::min<double>((double)nn * std::max(h->n_c - k, 1), 2147483647.0 / (k + 2));   // the bound, for the allocation only
-            else { HIP_TRY(h, hipStreamSynchronize(st)); n_children = h->tot_host[0]; }
-            h->n_children = children_lean ? 0 : n_children;
-            if (n_children > 0) {
-                HIP_TRY(h, h->children.ensure((size_t)n_children * (k + 1) * sizeof(int32_t), st));
-                HIP_TRY(h, h->parent_slot_next.ensure((size_t)n_children * sizeof(int32_t), st));
-                hipLaunchKernelGGL(k_children_write, dim3((unsigned)n), dim3(64), 0, st, h->frontier.as<int32_t>(), n, k, h->mw,
-                                   h->childmask.as<unsigned long long>(), h->offset.as<int32_t>(), h->children.as<int32_t>(),
-                                   h->storing ? h->dict_stored[h->dict_cur].as<uint8_t>() : (const uint8_t *)nullptr, h->parent_slot_next.as<int32_t>());
-                HIP_TRY(h, hipGetLastError());
-            }
+        if (!tail_done) {
+            HIP_TRY(h, hipEventRecord(h->ev[2], st));
+            // pruned masks of this level + children, histogram, counters
+            { int rcs = queue_tail(); if (rcs) return rcs; }
+            HIP_TRY(h, hipStreamSynchronize(st));
         }
-        hipLaunchKernelGGL(k_histogram, dim3(std::min(blocks256, 1024)), dim3(256), 0, st, h->status.as<uint8_t>(), n, ctr);
-        HIP_TRY(h, hipGetLastError());
-        HIP_TRY(h, hipEventRecord(h->ev[3], st));
-        static_assert(sizeof(LevelCounters) % 4 == 0 && sizeof(LevelCounters) + 64 <= 4096, "LevelCounters must fit the pinned block");
-        hipLaunchKernelGGL(k_publish_words, dim3(1), dim3(128), 0, st, reinterpret_cast<const unsigned int *>(ctr),
-                           reinterpret_cast<unsigned int *>(h->tot_dev + 16), (int)(sizeof(LevelCounters) / 4));
-        hipLaunchKernelGGL(k_publish_words, dim3(1), dim3(64), 0, st, reinterpret_cast<const unsigned int *>(dcnt),
-                           reinterpret_cast<unsigned int *>(h->tot_dev + 16 + (int)(sizeof(LevelCounters) / 4)), 32);
-        HIP_TRY(h, hipGetLastError());
-        HIP_TRY(h, hipStreamSynchronize(st));
         h->r3_dirty = false;   // the main stream waited for ev_rjoin before the second partition
         std::memcpy(&host_ctr, h->tot_host + 16, sizeof(LevelCounters));
         {
@@ -2423,7 +2500,7 @@ static void solve_release(mpc_handle *h) {
     for (int i = 0; i < nl; ++i) {
         auto &lv = h->sv_levels[i];
         if (!lv.handed) { if (lv.hd) (void)host_pool_give(lv.hd); if (lv.hi) (void)host_pool_give(lv.hi); if (lv.er) (void)host_pool_give(lv.er); }
-        lv.hd = lv.hi = lv.er = nullptr; lv.handed = false; lv.flags = nullptr; lv.mode = 0;
+        lv.hd = lv.hi = lv.er = nullptr; lv.handed = false; lv.flags = nullptr; lv.ready_flag = nullptr; lv.mode = 0;
         lv.ready.store(0, std::memory_order_relaxed); lv.done.store(0, std::memory_order_relaxed);
     }
     h->sv_n.store(0, std::memory_order_release);
@@ -2452,10 +2529,31 @@ static int worker_solve(mpc_handle *h) {
                 mpc_compact_strides(h, nullptr, nullptr, &rows_cap);
                 const size_t b_hd = (size_t)h->n_opt * h->fd * sizeof(double), b_hi = (size_t)h->n_opt * h->fi * sizeof(int32_t),
                              b_er = (size_t)std::max<int64_t>(rows_cap, 1) * (h->n_t + 1) * sizeof(double);
-                if (host_pool_take(b_hd, &lv.hd, nullptr) != hipSuccess || host_pool_take(b_hi, &lv.hi, nullptr) != hipSuccess ||
-                    host_pool_take(b_er, &lv.er, nullptr) != hipSuccess) rc = fail(h, MPC_ERR_HIP, "mpc_solve: page-locked memory for a level's region records");
-                if (rc == MPC_OK) rc = level_regions_slots_impl(h, static_cast<double *>(lv.hd), static_cast<int32_t *>(lv.hi), h->n_opt, static_cast<double *>(lv.er),
-                                                                rows_cap, &ns, &nr, false, false);
+                const bool all_slots = h->used_region2 && h->n_rretry == 0 && !h->no_fetch_kernel;   // every record is in slot form on the device
+                if (host_pool_take(b_hd, &lv.hd, nullptr, all_slots) != hipSuccess || host_pool_take(b_hi + 64, &lv.hi, nullptr, all_slots) != hipSuccess ||
+                    host_pool_take(b_er, &lv.er, nullptr, all_slots) != hipSuccess) rc = fail(h, MPC_ERR_HIP, "mpc_solve: page-locked memory for a level's region records");
+                if (rc == MPC_OK && all_slots) {
+                    // one launch writes the three arrays into the host blocks and raises the flag behind head_i; nobody waits here
+                    FetchCopy fc{};
+                    int32_t *flag = reinterpret_cast<int32_t *>(static_cast<char *>(lv.hi) + ((b_hi + 7) & ~size_t(7)));
+                    *flag = 0;
+                    void *d_hd = nullptr, *d_hi = nullptr, *d_er = nullptr;
+                    if (hipHostGetDevicePointer(&d_hd, lv.hd, 0) != hipSuccess || hipHostGetDevicePointer(&d_hi, lv.hi, 0) != hipSuccess ||
+                        hipHostGetDevicePointer(&d_er, lv.er, 0) != hipSuccess) rc = fail(h, MPC_ERR_HIP, "hipHostGetDevicePointer (level records)");
+                    if (rc == MPC_OK) {
+                        fc.src[0] = h->headi.p; fc.dst[0] = d_hi; fc.bytes[0] = b_hi;
+                        fc.src[1] = h->headd.p; fc.dst[1] = d_hd; fc.bytes[1] = b_hd;
+                        fc.src[2] = h->epool.p; fc.dst[2] = d_er; fc.bytes[2] = (size_t)h->n_erows * (h->n_t + 1) * sizeof(double);
+                        fc.counter = reinterpret_cast<unsigned int *>(h->dcnt.as<int32_t>() + 30);   // zero: cleared with the list lengths at the start of every level
+                        fc.flag = reinterpret_cast<int32_t *>(static_cast<char *>(d_hi) + ((b_hi + 7) & ~size_t(7)));
+                        const unsigned long long words = (b_hi + b_hd + fc.bytes[2]) / 4;
+                        hipLaunchKernelGGL(k_fetch_slots, dim3((unsigned)std::min<unsigned long long>(256, words / 2048 + 1)), dim3(256), 0, h->stream, fc);
+                        if (hipGetLastError() != hipSuccess) rc = fail(h, MPC_ERR_HIP, "k_fetch_slots launch");
+                        lv.ready_flag = flag; ns = h->n_opt; nr = h->n_erows;
+                    }
+                } else if (rc == MPC_OK)
+                    rc = level_regions_slots_impl(h, static_cast<double *>(lv.hd), static_cast<int32_t *>(lv.hi), h->n_opt, static_cast<double *>(lv.er),
+                                                  rows_cap, &ns, &nr, false, false);
                 lv.mode = 2; lv.n_slots = ns; lv.n_rows = nr; lv.chunk = 0; lv.n_chunks = 0;
             } else lv.mode = 0;
         } else if (rc == MPC_OK && lv.stats.n_region_retry > 0) {
@@ -2617,6 +2715,13 @@ int mpc_solve_level(mpc_handle *h, int32_t level, mpc_solve_level_info *info) {
     std::memset(info, 0, sizeof(*info));
     info->level = level;
     if (!lv.ready.load(std::memory_order_acquire)) { info->mode = -1; return h->sv_rc; }   // the loop ended before (or inside) this level
+    if (lv.mode == 2 && lv.ready_flag) {
+        // the arrays are being written by k_fetch_slots on the handle's stream: its last workgroup raises the flag
+        for (unsigned spin = 0; !__atomic_load_n(lv.ready_flag, __ATOMIC_ACQUIRE); ++spin) {
+            if ((spin & 4095u) == 4095u && h->sv_finished.load(std::memory_order_acquire) && h->sv_rc != MPC_OK) { info->mode = -1; return h->sv_rc; }
+            __builtin_ia32_pause();
+        }
+    }
     info->k = lv.k; info->n = lv.n; info->mode = lv.mode; info->chunk = lv.chunk; info->n_chunks = lv.n_chunks;
     info->n_slots = lv.n_slots; info->n_rows = lv.n_rows;
     if (lv.mode != 0 && !lv.handed) {
