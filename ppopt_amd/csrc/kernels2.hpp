@@ -177,7 +177,9 @@ MPC_GLOBAL void MPC_LB(256) k_kkt_thread(const DevProblem *__restrict__ Pg, cons
     // Rows are taken RU at a time with all their W gathers issued before the first is used: one row per trip made the loop a chain of
     // n_c dependent L2 round trips -- 55 us for ONE candidate, the floor of this kernel on every level however small (round 4,
     // tools/timeline.sh).  Same rows, same order, same arithmetic per row.
-    constexpr int RU = K <= 4 ? 8 : (K <= 6 ? 4 : 2);
+    // (no early exit inside a group of rows: a group is ONE basic block, so the scheduler can issue all its loads first; from five rows of
+    // active set on the kernel is bound by registers and throughput -- config 4's level of 10^6 candidates -- and keeps one row per trip)
+    constexpr int RU = K <= 2 ? 8 : (K <= 4 ? 4 : 1);
     for (int c0 = ne; c0 < nc; c0 += RU) {
       double wpre[RU][K];
 #pragma unroll
@@ -188,9 +190,8 @@ MPC_GLOBAL void MPC_LB(256) k_kkt_thread(const DevProblem *__restrict__ Pg, cons
       }
 #pragma unroll
       for (int u = 0; u < RU; ++u) {
-        const int ci = c0 + u;
-        if (ci >= nc) break;
-        bool active = false;
+        const int ci = min(c0 + u, nc - 1);
+        bool active = c0 + u >= nc;      // rows beyond the last one repeat it and never fire
 #pragma unroll
         for (int a = 0; a < K; ++a) active = active || (as[a] == ci);
         double acc[LS];

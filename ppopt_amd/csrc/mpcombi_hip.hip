@@ -277,6 +277,7 @@ struct mpc_handle {
                                      // a region at 4 -- and move the facet list of one sliver region)
     bool no_lean = false;            // MPC_NO_LEAN=1: large levels read every list length back (round-2 behaviour); default: only the lengths the
                                      // host needs to size the region stage are read back, the other stages take theirs from device memory
+    bool r3_fork_event = false;      // MPC_R3_FORK=1: the region stream starts behind an event of the main stream (round-3 form; A/B)
     int r2_cap_pct = 100;            // MPC_R2_CAP: share (per cent) of k_region2's wave slots an overlapped one-wave-per-candidate launch may take
     bool no_fetch_kernel = false;    // MPC_NO_FETCH_KERNEL=1: the solve loop fetches the records of a level that did not stream with copy commands and waits (A/B)
     bool no_spec_tail = false;       // MPC_NO_SPEC_TAIL=1: a large level waits for the second partition and for the region kernel's give-up count before
@@ -578,6 +579,7 @@ static int create_fill(const mpc_problem *p, int32_t device, void *stream, mpc_h
     { const char *ev = std::getenv("MPC_NO_LEAN"); h->no_lean = ev && ev[0] == '1'; }
     { const char *ev = std::getenv("MPC_NO_SPEC_TAIL"); h->no_spec_tail = ev && ev[0] == '1'; }
     { const char *ev = std::getenv("MPC_NO_FETCH_KERNEL"); h->no_fetch_kernel = ev && ev[0] == '1'; }
+    { const char *ev = std::getenv("MPC_R3_FORK"); h->r3_fork_event = ev && ev[0] == '1'; }
     { const char *ev = std::getenv("MPC_R2_CAP"); if (ev && std::atoi(ev) > 0) h->r2_cap_pct = std::min(100, std::atoi(ev)); }
     { const char *ev = std::getenv("MPC_TEST_SMALL_FALLBACK"); h->test_small_fallback = ev && ev[0] == '1'; }
     { const char *ev = std::getenv("MPC_RSPLIT_MAX"); if (ev) { int v = std::atoi(ev); h->rsplit_max = v >= 16 ? 16 : (v >= 8 ? 8 : (v >= 4 ? 4 : (v >= 2 ? 2 : 1))); } }
@@ -1913,32 +1915,29 @@ static int level_run_impl(mpc_handle *h, int32_t gen_children, int32_t flags, mp
             for (int c = 0; c < PART_CLASSES; ++c) counts[c] = h->tot_host[c];
             return MPC_OK;
         };
-        // clears / copies / slot marks that a region launch and the (x,theta) stage need, collected and issued as ONE launch (k_region_prep)
-        RegionPrep prep{};
-        bool prep_any = false;
-        auto prep_flush = [&]() -> int {
-            if (!prep_any) return MPC_OK;
-            unsigned long long work = (unsigned long long)std::max<long long>(prep.copy_n, prep.extra);
-            for (int j = 0; j < 4; ++j) work = std::max(work, prep.z.bytes[j] / 8);
-            hipLaunchKernelGGL(k_region_prep, dim3((unsigned)std::min<unsigned long long>(256, work / 1024 + 1)), dim3(256), 0, st, prep);
+        // clears / copies / slot marks that a region launch and the (x,theta) stage need, collected and issued as ONE launch each
+        // (k_region_prep): `prep` for the main stream, `rprep` for what only the region kernel reads (issued on ITS stream)
+        RegionPrep prep{}, rprep{};
+        bool prep_any = false, rprep_any = false;
+        auto prep_flush_on = [&](RegionPrep &pp, bool &any, hipStream_t ps) -> int {
+            if (!any) return MPC_OK;
+            unsigned long long work = (unsigned long long)std::max<long long>(pp.copy_n, pp.extra);
+            for (int j = 0; j < 4; ++j) work = std::max(work, pp.z.bytes[j] / 8);
+            hipLaunchKernelGGL(k_region_prep, dim3((unsigned)std::min<unsigned long long>(256, work / 1024 + 1)), dim3(256), 0, ps, pp);
             HIP_TRY(h, hipGetLastError());
-            prep = RegionPrep{}; prep_any = false;
+            pp = RegionPrep{}; any = false;
             return MPC_OK;
         };
-        auto prep_zero = [&](void *ptr, size_t bytes) -> int {
+        auto prep_flush = [&]() -> int { return prep_flush_on(prep, prep_any, st); };
+        auto prep_zero_in = [&](RegionPrep &pp, bool &any, hipStream_t ps, void *ptr, size_t bytes) -> int {
             if (!ptr || bytes == 0) return MPC_OK;
             int j = 0;
-            while (j < 4 && prep.z.p[j]) ++j;
-            if (j == 4) { int rcs = prep_flush(); if (rcs) return rcs; j = 0; }
-            prep.z.p[j] = ptr; prep.z.bytes[j] = bytes; prep_any = true;
+            while (j < 4 && pp.z.p[j]) ++j;
+            if (j == 4) { int rcs = prep_flush_on(pp, any, ps); if (rcs) return rcs; j = 0; }
+            pp.z.p[j] = ptr; pp.z.bytes[j] = bytes; any = true;
             return MPC_OK;
         };
-        auto prep_copy = [&](int32_t *dst, const int32_t *src, long long cnt) -> int {
-            if (cnt <= 0) return MPC_OK;
-            if (prep.copy_n > 0) { int rcs = prep_flush(); if (rcs) return rcs; }
-            prep.copy_dst = dst; prep.copy_src = src; prep.copy_n = cnt; prep_any = true;
-            return MPC_OK;
-        };
+        auto prep_zero = [&](void *ptr, size_t bytes) -> int { return prep_zero_in(prep, prep_any, st, ptr, bytes); };
         auto part_list = [&](int c) -> int32_t * { return h->part_lists.as<int32_t>() + (size_t)c * nn; };
         const uint8_t *kkc = nullptr;   // KKT codes and multipliers of k_kkt_thread (read by k_theta2 / k_region2)
         const double *kkl = nullptr;
@@ -1961,7 +1960,7 @@ static int level_run_impl(mpc_handle *h, int32_t gen_children, int32_t flags, mp
             if (W > 1) {
                 HIP_TRY(h, h->kept_g.ensure((size_t)n_opt * ldk, st));
                 HIP_TRY(h, h->done_g.ensure((size_t)n_opt * 2 * sizeof(unsigned int), st));
-                { int rcs = prep_zero(h->done_g.p, (size_t)n_opt * 2 * sizeof(unsigned int)); if (rcs) return rcs; }
+                { int rcs = prep_zero_in(rprep, rprep_any, rst, h->done_g.p, (size_t)n_opt * 2 * sizeof(unsigned int)); if (rcs) return rcs; }
             }
             // an overlapped launch may take only a share of the wave slots (r2_cap_pct): its 256-register wavefronts otherwise fill the
             // register file of every SIMD they sit on and the (x,theta) kernel beside them gets no slot there until they leave
@@ -1989,7 +1988,7 @@ static int level_run_impl(mpc_handle *h, int32_t gen_children, int32_t flags, mp
                 std::memset(h->st_flags.p, 0, (size_t)so.n_chunks * sizeof(int32_t));
                 h->cw_chunks = so.n_chunks;
                 HIP_TRY(h, h->chunk_count.ensure((size_t)so.n_chunks * sizeof(unsigned int), st));
-                { int rcs = prep_zero(h->chunk_count.p, (size_t)so.n_chunks * sizeof(unsigned int)); if (rcs) return rcs; }
+                { int rcs = prep_zero_in(rprep, rprep_any, rst, h->chunk_count.p, (size_t)so.n_chunks * sizeof(unsigned int)); if (rcs) return rcs; }
                 void *d_hd = nullptr, *d_hi = nullptr, *d_er = nullptr, *d_fl = nullptr;
                 HIP_TRY(h, hipHostGetDevicePointer(&d_hd, so.hd, 0));
                 HIP_TRY(h, hipHostGetDevicePointer(&d_hi, so.hi, 0));
@@ -2004,16 +2003,24 @@ static int level_run_impl(mpc_handle *h, int32_t gen_children, int32_t flags, mp
                                                    W, h->kept_g.as<uint8_t>(), ldk, h->done_g.as<unsigned int>(), \
                                                    h->no_rbox ? (const double *)nullptr : h->targs.tvp + (size_t)NT_ * NT_ + NT_, rs)
             region_out_hi = out_hi;
-            if (extra > 0) { prep.head_i = out_hi; prep.fi = h->fi; prep.first = n_opt; prep.extra = extra; prep_any = true; }
-            { int rcs = prep_flush(); if (rcs) return rcs; }
+            if (extra > 0) { rprep.head_i = out_hi; rprep.fi = h->fi; rprep.first = n_opt; rprep.extra = extra; rprep_any = true; }
             if (rst != st) {
-                // fork; the main stream continues only when the side stream has reached the region kernel, so that the region
-                // wavefronts (the long chains) are placed first and the (x,theta) kernels fill in around them -- without this the
-                // two dispatches race and the persistent (x,theta) kernel often takes the whole GPU first
-                HIP_TRY(h, hipEventRecord(h->ev_rfork, st));
-                HIP_TRY(h, hipStreamWaitEvent(rst, h->ev_rfork, 0));
+                // The side stream does NOT wait for the main stream: every caller has synchronised the main stream (the partition whose
+                // counts sized this launch) and has queued nothing since that the region kernel reads, so the region stage's own
+                // preparation and the kernel go straight to the side stream -- one cross-stream hop (~25 us) less per large level than the
+                // fork through an event.  The main stream continues only when the side stream has reached the region kernel, so that
+                // the region wavefronts (the long chains) are placed first and the (x,theta) kernels fill in around them -- without this
+                // the two dispatches race and the persistent (x,theta) kernel often takes the whole GPU first.
+                if (h->r3_fork_event) {   // MPC_R3_FORK=1: round-3 form, the side stream starts behind an event of the main stream
+                    HIP_TRY(h, hipEventRecord(h->ev_rfork, st));
+                    HIP_TRY(h, hipStreamWaitEvent(rst, h->ev_rfork, 0));
+                }
+                { int rcs = prep_flush_on(rprep, rprep_any, rst); if (rcs) return rcs; }
                 HIP_TRY(h, hipEventRecord(h->ev_rgo, rst));
                 HIP_TRY(h, hipStreamWaitEvent(st, h->ev_rgo, 0));
+            } else {
+                { int rcs = prep_flush(); if (rcs) return rcs; }
+                { int rcs = prep_flush_on(rprep, rprep_any, st); if (rcs) return rcs; }
             }
             HIP_TRY(h, hipEventRecord(h->kev[4], rst));
             switch (h->fast_r) {
@@ -2199,7 +2206,7 @@ static int level_run_impl(mpc_handle *h, int32_t gen_children, int32_t flags, mp
                 const int32_t hold = std::min<int32_t>(std::max(h->test_late, 0), cntA[2] - 1);
                 const int32_t n_launch = cntA[2] - hold;
                 region_extra = std::max(0, n_early + hold + std::min<int32_t>(cntA[3], 1024) - std::max(h->test_spare, 0));
-                { int rcs = prep_copy(h->opt_list.as<int32_t>(), part_list(2), n_launch); if (rcs) return rcs; }
+                rprep.copy_dst = h->opt_list.as<int32_t>(); rprep.copy_src = part_list(2); rprep.copy_n = n_launch; rprep_any = true;
                 h->opt_ptr = h->opt_list.as<int32_t>();
                 h->n_opt = n_launch;
                 int rcs = region2_launch(n_launch, region_extra, h->stream3, x_items >= h->roverlap_long);
@@ -2326,7 +2333,7 @@ static int level_run_impl(mpc_handle *h, int32_t gen_children, int32_t flags, mp
                 // re-solve of the doubtful candidates instead -- two small, latency-bound kernels; what the re-solve finds optimal
                 // takes the spare slots (config 3's last level: 235 re-solved candidates, 0.4 ms)
                 region_extra = n_retry;
-                HIP_TRY(h, hipMemcpyAsync(h->opt_list.p, part_list(2), (size_t)cntB[2] * sizeof(int32_t), hipMemcpyDeviceToDevice, st));
+                rprep.copy_dst = h->opt_list.as<int32_t>(); rprep.copy_src = part_list(2); rprep.copy_n = cntB[2]; rprep_any = true;   // (on the region kernel's stream)
                 h->opt_ptr = h->opt_list.as<int32_t>();
                 h->n_opt = cntB[2];
                 int rcs = region2_launch(cntB[2], region_extra, h->stream3, false);

@@ -63,6 +63,9 @@ class _Lazy:
 
 class BatchCriticalRegion(CriticalRegion):
     """A CriticalRegion backed by row ``j`` of a RegionBatch (same fields, same index conventions)."""
+    # the two references live in slots: the instance dictionary (inherited from the dataclass) is only created when a field is
+    # first read -- a solve creates 10^4 of these per step and the next step frees them
+    __slots__ = ('_batch', '_j')
 
     def __init__(self, batch: RegionBatch, j: int):  # no dataclass __init__: fields come from the batch
         self._batch = batch
