@@ -289,6 +289,48 @@ __device__ inline int xtheta_from_vertex(const DevProblem &P, int k, Smem &s, Lp
 }
 
 // ------------------------------------------------------------------------------------------------------------
+// k_recession: "max t unbounded  =>  not optimal" for programs whose parameter set is open in some direction.
+// ------------------------------------------------------------------------------------------------------------
+// The reference's optimality LP MAXIMISES t subject to t <= lambda_i(theta) (activated rows), t <= slack_j(theta) (inactive rows),
+// A_t theta <= b_t (mpqp_program.py:203-322, mplp_program.py:446-569) and its solver adapter returns None for every status but
+// 'optimal' (solver_interface/cvxopt_interface.py:19-23): when the parameter set lets every one of those rows grow without bound the
+// LP is unbounded and the active set counts as NOT optimal although its critical region is non-empty.  The verdict kernels decide
+// "optimal" as "the rows' theta set is non-empty"; for the candidates they call optimal this kernel poses the recession question
+//        exists d :   g_i' d >= 1  (every multiplier / slack row  h_i + g_i' theta),    A_t d <= 0
+// -- the same coefficient rows as the theta LP, constants replaced by -1 / 0 -- and turns ST_OPT_PENDING into ST_FEASIBLE when it has a
+// solution (also when there is no multiplier / slack row at all: t is then bounded by nothing).  A bounded parameter set has no such
+// d, so the kernel is launched only for handles with mpc_handle::theta_open (config 1-5 never run it).
+MPC_GLOBAL void MPC_LB(64) k_recession(DevProblem P, const int32_t *__restrict__ cands, long long n, int k, uint8_t *__restrict__ status) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    Smem s = carve(P, smem);
+    const int lane = lane_id(), nt = P.n_t;
+    for (long long c = blockIdx.x; c < n; c += gridDim.x) {
+        if (status[c] != ST_OPT_PENDING) continue;      // (wave-uniform)
+        const int nin = load_active_set(P, cands + (size_t)c * k, k, s);
+        if (kkt_solve(P, k, s) != 0) continue;           // cannot happen: the verdict stage solved the same system
+        Lp lp;
+        lp.T = s.T; lp.ld = P.ld_t; lp.colvar = s.colvar; lp.rowvar = s.rowvar; lp.rowkind = s.rowkind;
+        const int nlam = k - P.n_eq;
+        lp.n = nt; lp.m = nlam + nin + P.n_tc; lp.iters = 0;
+        const int m = lp.m;
+        const int r = lp_solve(lp, false, s.pri, [&](const int *pri) {
+            build_theta_rows(P, k, nin, s, s.T, P.ld_t, P.kkt_mode == 1);
+            for (int i = lane; i <= m; i += 64) {
+                double *Ti = s.T + i * P.ld_t;
+                if (i == m) { for (int j = 0; j <= nt + 1; ++j) Ti[j] = 0.0; continue; }
+                double mx = 0.0;
+                for (int j = 1; j <= nt; ++j) mx = fmax(mx, fabs(Ti[j]));
+                if (!(mx > ZERO_ROW_ATOL)) for (int j = 1; j <= nt; ++j) Ti[j] = 0.0;   // the theta LP's zero-row rule
+                Ti[0] = i < nlam + nin ? -1.0 : 0.0;
+                s.rowkind[i] = (pri && pri[i]) ? RK_PRI : RK_INEQ;
+            }
+        });
+        if (r == LP_OPTIMAL && lane == 0) status[c] = (uint8_t)ST_FEASIBLE;
+        wave_sync();
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
 // k_verdict: status per candidate: INFEASIBLE / FEASIBLE / SINGULAR / LP_LIMIT / OPT_PENDING
 // ------------------------------------------------------------------------------------------------------------
 // list != nullptr: process only the candidates list[0..n) (the retry list of k_verdict2), work counter ctr->work_region

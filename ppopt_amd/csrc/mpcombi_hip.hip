@@ -277,6 +277,9 @@ struct mpc_handle {
                                      // a region at 4 -- and move the facet list of one sliver region)
     bool no_lean = false;            // MPC_NO_LEAN=1: large levels read every list length back (round-2 behaviour); default: only the lengths the
                                      // host needs to size the region stage are read back, the other stages take theirs from device memory
+    bool theta_open = false;         // the parameter set is open in some direction (or the program has equality rows only): the reference's
+                                     // optimality LP can be unbounded -> k_recession behind every verdict stage, no overlapped region launch,
+                                     // no level without host round trips, no shared launches (MPC_NO_RECESSION=1: round-3 behaviour, A/B)
     bool r3_fork_event = false;      // MPC_R3_FORK=1: the region stream starts behind an event of the main stream (round-3 form; A/B)
     int r2_cap_pct = 100;            // MPC_R2_CAP: share (per cent) of k_region2's wave slots an overlapped one-wave-per-candidate launch may take
     bool no_fetch_kernel = false;    // MPC_NO_FETCH_KERNEL=1: the solve loop fetches the records of a level that did not stream with copy commands and waits (A/B)
@@ -861,6 +864,7 @@ static int create_fill(const mpc_problem *p, int32_t device, void *stream, mpc_h
     }
     h->grid_v = h->n_cu * waves_per_cu(h->lds_v);
     // fast path (k_verdict2): needs the theta vertex, the pre-crashed dictionary and sizes inside the instantiations
+    bool box_done = false, box_open = false;   // the bounding box of the parameter set has been computed / has an infinite side
     {
         const int rows_th = rows_t - nt, rows_x = P.n_d0r;
         const int slots_t = rows_th <= 64 ? 1 : (rows_th <= 128 ? 2 : 0), slots_x = rows_x <= 64 ? 1 : (rows_x <= 128 ? 2 : 0);
@@ -899,6 +903,7 @@ static int create_fill(const mpc_problem *p, int32_t device, void *stream, mpc_h
                         const bool ok_lo = rcb == MPC_OK && stt[2 * t] == LP_OPTIMAL, ok_hi = rcb == MPC_OK && stt[2 * t + 1] == LP_OPTIMAL;
                         // the LP optimum carries the simplex tolerance: widen the box a little (the screen only needs an outer box)
                         const double lo = ok_lo ? obj[2 * t] : -INFINITY, hi = ok_hi ? -obj[2 * t + 1] : INFINITY;
+                        box_done = true; box_open = box_open || !ok_lo || !ok_hi;
                         const double pad = 1e-6 * (1.0 + std::max(std::fabs(ok_lo ? lo : 0.0), std::fabs(ok_hi ? hi : 0.0)));
                         tb[otvp + (size_t)NTP * NTP + NTP + t] = lo - pad;
                         tb[otvp + (size_t)NTP * NTP + 2 * NTP + t] = hi + pad;
@@ -940,6 +945,29 @@ static int create_fill(const mpc_problem *p, int32_t device, void *stream, mpc_h
                 HIP_TRY(nullptr, hipStreamSynchronize(h->stream));
             }
         }
+    }
+    // ---- is the parameter set open in some direction?  (then the reference's optimality LP can be unbounded: k_recession) -------------
+    {
+        const char *ev = std::getenv("MPC_NO_RECESSION");
+        bool open = false;
+        if (!(ev && ev[0] == '1')) {
+            if (nc == ne) open = true;                                     // no multiplier / slack row at all bounds t (the base set)
+            else if (nt > 0 && (ntc == 0 || tv_theta.empty())) open = true;   // no row, or no vertex: the set contains a line (or the search failed: the test is always safe)
+            else if (nt > 0) {
+                if (!box_done) {   // a vertex, but maybe an open cone: the bounding box (2 n_t LPs on the device, as for the register-resident kernels)
+                    std::vector<double> cc((size_t)2 * nt * nt, 0.0), obj(2 * nt, 0.0);
+                    for (int t = 0; t < nt; ++t) { cc[(size_t)(2 * t) * nt + t] = 1.0; cc[(size_t)(2 * t + 1) * nt + t] = -1.0; }
+                    std::vector<uint8_t> eqz((size_t)2 * nt * ntc, 0);
+                    std::vector<int32_t> stt(2 * nt, -1);
+                    const int rcb = lp_batch_impl(device, 2 * nt, ntc, nt, p->A_t, 1, p->b_t, 1, cc.data(), 0, eqz.data(), stt.data(), nullptr, obj.data(), nullptr, nullptr);
+                    HIP_TRY(nullptr, hipSetDevice(device));
+                    for (int t = 0; t < 2 * nt; ++t) box_open = box_open || rcb != MPC_OK || stt[t] != LP_OPTIMAL;
+                }
+                open = box_open;
+            }
+        }
+        h->theta_open = open;
+        if (std::getenv("MPC_DEBUG_CREATE")) std::fprintf(stderr, "[mpc] create: parameter set %s\n", open ? "OPEN in some direction (k_recession behind the verdict stages)" : "bounded");
     }
     h->grid_r = h->n_cu * waves_per_cu(h->lds_r);
     h->rec_d = (long long)nx * nt + nx + (long long)nc * nt + nc + (long long)(nc + ntc) * nt + (nc + ntc);
@@ -1263,7 +1291,7 @@ static void stream_release(mpc_handle *h) {   // blocks of a streamed level nobo
 // optimal (= the region launch), open | [8] open after the quick test | [24] doubtful after the (x,theta) stage | [17] optimal
 // candidates that missed the region launch | [20] children
 static bool small_path_ok(const mpc_handle *h, long long n, int k, int32_t flags, int32_t gen_children) {
-    if (h->no_smallpath || !h->fast || h->force_v1 || h->fast_r < 0 || n < 1 || n > h->smallpath_max) return false;
+    if (h->no_smallpath || !h->fast || h->force_v1 || h->fast_r < 0 || n < 1 || n > h->smallpath_max || h->theta_open) return false;
     if (flags & MPC_LEVEL_GRAPH) return false;
     if (h->test_late > 0 || h->debug_cycles) return false;
     // children and their parent slots are sized by the bound n (n_c - k) candidates of k + 1 indices
@@ -1756,7 +1784,9 @@ int mpc_level_batch_start(mpc_handle **hs, int32_t n_handles, const int32_t *gen
         stream_release(h);
         // MPC_SMALLPATH_MAX bounds the single-program path only (above it the overlapped classic path is faster for ONE program)
         const long long keep_max = h->smallpath_max;
-        h->smallpath_max = std::max<long long>(keep_max, 1LL << 40);
+        // (bounded: the shared launches compact / partition / scan a member with single 1024-thread blocks -- beyond 2^18 candidates a
+        // member takes its turn alone, on the multi-block kernels of the classic path)
+        h->smallpath_max = std::max<long long>(keep_max, 1LL << 18);
         const bool ok = small_path_ok(h, h->n, h->k, t->flags, gen_children[i]);
         h->smallpath_max = keep_max;
         bool ok_i = ok;
@@ -2087,6 +2117,13 @@ static int level_run_impl(mpc_handle *h, int32_t gen_children, int32_t flags, mp
             HIP_TRY(h, hipGetLastError());
             return MPC_OK;
         };
+        // open parameter set: the candidates the verdict stage calls optimal are asked whether the reference's max-t LP is bounded (k_recession)
+        auto recession = [&]() -> int {
+            if (!h->theta_open || (flags & MPC_LEVEL_GRAPH)) return MPC_OK;
+            hipLaunchKernelGGL(k_recession, dim3((unsigned)std::min<long long>(n, h->grid_v)), dim3(64), h->lds_v, st, h->Pv, h->frontier.as<int32_t>(), n, k, h->status.as<uint8_t>());
+            HIP_TRY(h, hipGetLastError());
+            return MPC_OK;
+        };
         // verdict
         HIP_TRY(h, hipEventRecord(h->ev[0], st));
         if (h->fast && !h->force_v1) {
@@ -2195,7 +2232,7 @@ static int level_run_impl(mpc_handle *h, int32_t gen_children, int32_t flags, mp
             const bool quick_test = cntA[3] > 0 && !(flags & MPC_LEVEL_GRAPH) && !h->storing && dc.parent_slot && !h->no_xquick;
             const bool use_grouped = quick_test && !h->no_xqgroup && ((h->last_level_n > 0 && (long long)cntA[3] >= 10 * h->last_level_n) || h->force_xqgroup) &&
                                      cntA[3] >= 4096 && lds_q <= 64 * 1024;
-            if (!h->no_roverlap && cntA[2] > 0 && h->fast_r >= 0 && !(flags & MPC_LEVEL_GRAPH) && x_items >= h->roverlap_min && !use_grouped) {
+            if (!h->no_roverlap && !h->theta_open && cntA[2] > 0 && h->fast_r >= 0 && !(flags & MPC_LEVEL_GRAPH) && x_items >= h->roverlap_min && !use_grouped) {
                 // Candidates that turn out optimal later -- re-solved doubtful ones: the n_early of the theta stage, rarely one of
                 // the (x,theta) stage -- get spare slots behind the launch's and take the LDS-engine route of the candidates
                 // k_region2 gives up on.  The spare slots cover every re-solved candidate of the theta stage plus up to 1,024 of the
@@ -2326,9 +2363,10 @@ static int level_run_impl(mpc_handle *h, int32_t gen_children, int32_t flags, mp
                     h->n_children = 0;
                 }
             }
+            { int rcs = recession(); if (rcs) return rcs; }
             if (!have_cntB) { int rcs = partition({{ST_RETRY, 0}, {ST_OPT_PENDING, 2}}, cntB); if (rcs) return rcs; }
             n_retry = cntB[0];
-            if (n_retry > 0 && !region_launched && !h->no_roverlap && cntB[2] > 0 && h->fast_r >= 0 && !(flags & MPC_LEVEL_GRAPH)) {
+            if (n_retry > 0 && !region_launched && !h->no_roverlap && !h->theta_open && cntB[2] > 0 && h->fast_r >= 0 && !(flags & MPC_LEVEL_GRAPH)) {
                 // the region stage was not started under the (x,theta) stage (grouped quick test, short stage): it runs beside the
                 // re-solve of the doubtful candidates instead -- two small, latency-bound kernels; what the re-solve finds optimal
                 // takes the spare slots (config 3's last level: 235 re-solved candidates, 0.4 ms)
@@ -2345,6 +2383,7 @@ static int level_run_impl(mpc_handle *h, int32_t gen_children, int32_t flags, mp
                                    h->frontier.as<int32_t>(), (long long)n_retry, k, h->status.as<uint8_t>(), ctr, part_list(0), (const int32_t *)nullptr);
                 HIP_TRY(h, hipGetLastError());
                 if (region_launched) HIP_TRY(h, hipStreamWaitEvent(st, h->ev_rjoin, 0));
+                { int rcs = recession(); if (rcs) return rcs; }
                 { int rcs = partition({{ST_OPT_PENDING, 2}}, cntB); if (rcs) return rcs; }   // they may have turned out optimal
             }
             if (region_launched) {
@@ -2369,6 +2408,7 @@ static int level_run_impl(mpc_handle *h, int32_t gen_children, int32_t flags, mp
             hipLaunchKernelGGL(k_verdict, dim3((unsigned)std::min<long long>(n, h->grid_v)), dim3(64), h->lds_v, st, h->Pv,
                                h->frontier.as<int32_t>(), n, k, h->status.as<uint8_t>(), ctr, (const int32_t *)nullptr, (const int32_t *)nullptr);
             HIP_TRY(h, hipGetLastError());
+            { int rcs = recession(); if (rcs) return rcs; }
         }
         if (!tail_done) HIP_TRY(h, hipEventRecord(h->ev[1], st));
         // optimal candidates -> region kernel

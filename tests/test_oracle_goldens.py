@@ -11,6 +11,11 @@ from conftest import golden_regions, load_golden, rel_err, rows_match
 FULL = ['c1_transport_mplp', 'mplp_rand_4_2_10_s0', 'mplp_rand_5_3_12_s2', 'transport_mpqp', 'dblint_n3', 'c2_dblint_n5', 'c2_dblint_n5_x20', 'rand_4_2_10_s0', 'rand_5_3_8_s3',
         'rand_6_3_12_s1', 'quadtank_n2', 'quadtank_n3']
 PARTIAL = ['c4_rand_20_8_20_s0', 'c3_quadtank_n10']
+# programs whose parameter set is open in some direction (oracle/ref_harness/gen_open_theta_goldens.py): the reference's optimality LP
+# maximises t, is UNBOUNDED on some non-empty regions there and its adapter then says "not optimal" (mpqp_program.py:203-322,
+# cvxopt_interface.py:19-23) -- L{i}_unbounded_t flags the candidates where that branch fired
+OPEN = ['open_hand_2_2', 'open_rand_4_2_10_s0_lower', 'open_rand_4_2_10_s0_slab', 'open_rand_4_2_10_s0_lower_boxed',
+        'open_rand_5_3_10_s4_lower', 'open_rand_5_3_10_s4_slab', 'open_rand_5_3_10_s4_lower_boxed']
 # facets whose redundancy LP sits on the 1e-7 tolerance in the reference run (min slack 3e-8 .. 1e-7, sliver
 # regions of rand_6_3_12_s1): the decision differs between LP solvers, documented in DESIGN.md
 KNIFE_EDGE_REGIONS = {('rand_6_3_12_s1', (0, 1, 3, 4, 5, 6))}
@@ -29,7 +34,7 @@ def test_lp_known_answers(oracle):
             assert numpy.all(A @ x - b <= 1e-6 * (1 + numpy.abs(b)))
 
 
-@pytest.mark.parametrize('name', FULL + PARTIAL)
+@pytest.mark.parametrize('name', FULL + PARTIAL + OPEN)
 def test_trace_matches_reference(oracle, name):
     g = load_golden(name)
     P = oracle.problem_from_golden(g)
@@ -52,6 +57,19 @@ def test_trace_matches_reference(oracle, name):
         assert r['omega_set'] == q['omega_set'] and r['lambda_set'] == q['lambda_set'], key
         assert r['regular_set'] == q['regular_set'], key
         assert rows_match(r['E'], r['f'], q['E'], q['f']), key
+
+
+def test_open_goldens_exercise_the_unbounded_branch():
+    """The fixtures do contain candidates (and a base set) on which the reference's max-t LP was unbounded."""
+    fired = base = 0
+    for name in OPEN:
+        g = load_golden(name)
+        for i in range(int(g['n_levels'])):
+            flag = g[f'L{i}_unbounded_t']
+            assert numpy.all(g[f'L{i}_verdict'][flag == 1] == 1)      # "feasible, not optimal" although the region's rows are non-empty
+            fired += int(flag.sum())
+        base += int(g['base_unbounded_t'])
+    assert fired >= 30 and base >= 1
 
 
 def test_control_allocation_singular_kkt(oracle):
