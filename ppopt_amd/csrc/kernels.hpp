@@ -144,9 +144,7 @@ __device__ inline int kkt_solve(const DevProblem &P, int k, Smem &s, bool *ill =
         {
             // is_full_rank(A, as) on the rows themselves (exact structural dependencies show up as ~1e-16 pivots)
             double *M = s.K;
-            for (int idx = lane; idx < k * nx; idx += 64) M[idx] = P.A[s.as[idx / nx] * nx + idx % nx];
-            wave_sync();
-            if (!full_row_rank(M, k, nx)) return 1;
+            if (!full_row_rank(M, k, nx, [&] { for (int idx = lane; idx < k * nx; idx += 64) M[idx] = P.A[s.as[idx / nx] * nx + idx % nx]; })) return 1;
             wave_sync();
         }
         double *S = s.K, *diag = s.K + k * k;
@@ -165,9 +163,7 @@ __device__ inline int kkt_solve(const DevProblem &P, int k, Smem &s, bool *ill =
     // mode 1: rank test on A_as, then the dense KKT system
     {
         double *M = s.K;
-        for (int idx = lane; idx < k * nx; idx += 64) M[idx] = P.A[s.as[idx / nx] * nx + idx % nx];
-        wave_sync();
-        if (!full_row_rank(M, k, nx)) return 1;
+        if (!full_row_rank(M, k, nx, [&] { for (int idx = lane; idx < k * nx; idx += 64) M[idx] = P.A[s.as[idx / nx] * nx + idx % nx]; })) return 1;
     }
     if (!P.is_qp && k != nx) return 3;  // mpLP: only a vertex (n_x active rows) can be optimal (mplp_program.py:472-473)
     const int n = nx + k;

@@ -14,7 +14,6 @@
 namespace mpc {
 
 constexpr double RANK_TOL_CHOL = 1e-13;  // pivot / original diagonal (= sin^2 of the angle to the span)
-constexpr double RANK_TOL_GE = 1e-11;    // complete-pivoting elimination, relative to the largest entry
 constexpr double KKT_SING_TOL = 1e-12;   // LU pivot relative to the largest entry of the KKT matrix
 
 // In-place lower Cholesky of the k x k LDS matrix S (row stride k) and solution of S X = R for the k x nr LDS
@@ -122,14 +121,24 @@ __device__ inline bool lu_solve(double *M, int n, double *B, int nr, double sing
     return true;
 }
 
-// rank(M) == k for the k x n LDS matrix M (row stride n, destroyed): Gaussian elimination with complete pivoting.
-__device__ inline bool full_row_rank(double *M, int k, int n) {
+// ---- is_full_rank(A, as)  (utils/constraint_utilities.py:222-236: numpy.linalg.matrix_rank(A[as]) == len(as)) ----------------------
+// numpy's rule: singular values by SVD, rank = #{sigma > sigma_max * max(k, n) * eps}.  Two steps here:
+//   screen   Gaussian elimination with complete pivoting on the k x n LDS matrix M (row stride n, destroyed).  Every pivot above
+//            RANK_SCREEN_FULL of the largest entry: the rows are independent by a margin of seven decades over numpy's threshold
+//            (complete pivoting keeps the growth small) -> full rank, no SVD.  Anything else is AMBIGUOUS;
+//   exact    the singular values themselves by one-sided Jacobi on the (re-loaded) rows -- the oracle's algorithm,
+//            oracle/mpcombi_oracle.c: jacobi_orthogonalise -- and numpy's rule word for word.  (Round 3 stopped at the elimination with
+//            a relative threshold of 1e-11: sets whose smallest singular value lies between 4e-15 and 1e-11 of the largest were
+//            called rank deficient where the reference goes on.)
+constexpr double RANK_SCREEN_FULL = 1e-8;
+// 1 full rank, 0 certainly deficient (k > n or a zero matrix), 2 ambiguous (M destroyed: reload it and ask svd_full_row_rank)
+__device__ inline int rank_screen(double *M, int k, int n) {
     const int lane = lane_id();
-    if (k > n) return false;
+    if (k > n) return 0;
     double scale = 0.0;
     for (int idx = lane; idx < k * n; idx += 64) scale = fmax(scale, fabs(M[idx]));
     for (int off = 32; off > 0; off >>= 1) scale = fmax(scale, __shfl_xor(scale, off));
-    if (!(scale > 0.0)) return k == 0;
+    if (!(scale > 0.0)) return k == 0 ? 1 : 0;
     for (int s = 0; s < k; ++s) {
         double best = -1.0;
         int pos = -1;
@@ -140,7 +149,7 @@ __device__ inline bool full_row_rank(double *M, int k, int n) {
             if (a > best) { best = a; pos = i * n + j; }
         }
         reduce_max_first(best, pos);
-        if (!(best > RANK_TOL_GE * scale)) return false;
+        if (!(best > RANK_SCREEN_FULL * scale)) return 2;
         const int pi = pos / n, pj = pos % n;
         wave_sync();
         if (pi != s) {
@@ -158,7 +167,69 @@ __device__ inline bool full_row_rank(double *M, int k, int n) {
         }
         wave_sync();
     }
-    return true;
+    return 1;
+}
+
+__device__ __forceinline__ double wave_sum(double v) {
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+    return v;
+}
+
+// numpy.linalg.matrix_rank(M) == k for the k x n LDS matrix M (row stride n, k <= n, destroyed): the rows are orthogonalised by
+// plane rotations (Hestenes); their norms are then the singular values.
+__device__ inline bool svd_full_row_rank(double *M, int k, int n) {
+    const int lane = lane_id();
+    if (k > n) return false;
+    if (k == 0) return true;
+    for (int sweep = 0; sweep < 60; ++sweep) {
+        bool rotated = false;
+        for (int p = 0; p < k - 1; ++p)
+            for (int q = p + 1; q < k; ++q) {
+                double app = 0.0, aqq = 0.0, apq = 0.0;
+                for (int j = lane; j < n; j += 64) { const double a = M[p * n + j], b = M[q * n + j]; app = fma(a, a, app); aqq = fma(b, b, aqq); apq = fma(a, b, apq); }
+                app = wave_sum(app); aqq = wave_sum(aqq); apq = wave_sum(apq);      // (identical in every lane)
+                if (apq == 0.0 || fabs(apq) <= 1e-15 * sqrt(app * aqq)) continue;
+                rotated = true;
+                const double zeta = (aqq - app) / (2.0 * apq);
+                const double t = (zeta >= 0.0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+                const double cs = 1.0 / sqrt(1.0 + t * t), sn = cs * t;
+                for (int j = lane; j < n; j += 64) {
+                    const double a = M[p * n + j], b = M[q * n + j];
+                    M[p * n + j] = cs * a - sn * b; M[q * n + j] = sn * a + cs * b;
+                }
+                wave_sync();
+            }
+        if (!rotated) break;
+    }
+    double smax = 0.0;
+    for (int i = 0; i < k; ++i) {
+        double s2 = 0.0;
+        for (int j = lane; j < n; j += 64) s2 = fma(M[i * n + j], M[i * n + j], s2);
+        smax = fmax(smax, sqrt(wave_sum(s2)));
+    }
+    const double tol = smax * (double)(k > n ? k : n) * 2.220446049250313e-16;
+    int rank = 0;
+    for (int i = 0; i < k; ++i) {
+        double s2 = 0.0;
+        for (int j = lane; j < n; j += 64) s2 = fma(M[i * n + j], M[i * n + j], s2);
+        if (sqrt(wave_sum(s2)) > tol) ++rank;
+    }
+    return rank == k;
+}
+
+// is_full_rank on the k x n block `load` writes into M (called again when the screen was not conclusive)
+template <class Load>
+__device__ inline bool full_row_rank(double *M, int k, int n, Load load) {
+    load();
+    wave_sync();
+    const int r = rank_screen(M, k, n);
+    wave_sync();
+    if (r != 2) return r == 1;
+    load();
+    wave_sync();
+    const bool full = svd_full_row_rank(M, k, n);
+    wave_sync();
+    return full;
 }
 
 }  // namespace mpc

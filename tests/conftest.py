@@ -48,6 +48,11 @@ KNIFE_EDGE_FACETS = {
     'rand_6_3_12_s1': {(0, 1, 3, 4, 5, 6): 'sliver region, cond(KKT) 1e9: its facet LPs sit on the 1e-7 tolerance in the reference run (min slack '
                                            '3e-8 .. 1e-7); the same region is excepted in tests/test_oracle_goldens.py (the CPU oracle differs there too)'},
 }
+KNIFE_EDGE_RANK = {
+    # case of tests/golden/rank_cases.npz: reason   (device verdict "rank deficient / infeasible" differs from the reference's check_feasibility)
+    'near_n5_eps1e-10': 'full rank by the SVD rule on both sides; the reference\'s feasibility LP (HiGHS) then calls the nearly dependent equality '
+                        'system infeasible (rows 5e-11 apart, right-hand sides equal to 1e-16): the device\'s LP finds the point',
+}
 _CONSUMED = []
 
 

@@ -31,6 +31,24 @@ def test_is_full_rank_cases(oracle):
         assert got == expect
 
 
+def test_rank_goldens_of_the_reference(oracle):
+    """tests/golden/rank_cases.npz (oracle/ref_harness/gen_rank_goldens.py): the reference's is_full_rank on its own six unit cases and
+    on duplicate / near-parallel / nearly dependent rows down to the SVD threshold -- the oracle's Jacobi SVD gives numpy's answer on every
+    case that is not within a factor of two of the threshold sigma_max * max(k, n) * eps."""
+    from conftest import load_golden
+    g = load_golden('rank_cases')
+    near = 0
+    for name in g['names'].tolist():
+        A, idx = numpy.ascontiguousarray(g[name + '__A']), g[name + '__idx'].astype(numpy.int32)
+        got = oracle.lib().orc_is_full_rank(A.ctypes.data_as(oracle._c_double_p), A.shape[1], idx.ctypes.data_as(oracle._c_int32_p), len(idx)) == 1
+        thr = max(len(idx), A.shape[1]) * 2.220446049250313e-16
+        if 0.5 * thr < float(g[name + '__sv_ratio']) < 2.0 * thr:
+            near += 1
+            continue
+        assert got == bool(g[name + '__full_rank']), name
+    assert near <= 10
+
+
 def test_singular_values_match_lapack(oracle):
     rng = numpy.random.default_rng(0)
     for m, n in ((3, 5), (6, 6), (9, 4), (20, 20)):
