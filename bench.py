@@ -104,21 +104,30 @@ def cpu_baseline(prog, frontiers, gpu_status, target_candidates):
         regions += int((status == orc.REGION).sum())
         differ += int((status != gst[idx]).sum())
     dt = time.perf_counter() - t0
-    # the same port on ONE thread, on every 256th candidate of the sample (about ten seconds)
-    t1 = time.perf_counter()
-    n1 = 0
-    for s in samples:
-        sub = numpy.ascontiguousarray(s[::256])
-        if len(sub):
-            P.check_level(sub, 1, False)
-            n1 += len(sub)
-    dt1 = time.perf_counter() - t1
+    # Thread scaling of the same port on ONE sub-sample -- every 32nd candidate of the sample above, level by level, the same candidates
+    # for every thread count (1, 8, 64, all): a coherent row, bounded at about ten seconds in all.  `value_one_thread` is its first entry.
+    subs = [numpy.ascontiguousarray(s[::32]) for s in samples]
+    n_sub = sum(len(x) for x in subs)
+    scaling = []
+    for th in sorted({1, 8, 64, cores} & set(range(1, cores + 1))):
+        P.check_level(subs[0][:min(8, len(subs[0]))], th, False)
+        t1 = time.perf_counter()
+        for sub in subs:
+            if len(sub):
+                P.check_level(sub, th, False)
+        dts = time.perf_counter() - t1
+        scaling.append({'threads': th, 'candidates_per_s': n_sub / max(dts, 1e-9), 'seconds': dts})
+    one = scaling[0]['candidates_per_s']
+    for row in scaling:
+        row['speedup_over_one_thread'] = row['candidates_per_s'] / one
     return {'value': n / dt, 'unit': 'candidate active sets checked/s', 'cores': cores, 'kind': 'port',
-            'label': 'naive port: a BLAS-free C restatement that poses every LP the way the reference does (dense two-phase simplex from '
-                     'scratch per LP); per thread it is SLOWER than the Python reference with HiGHS (about 175 candidates/s/worker, '
-                     'BASELINE.md 4) -- a baseline for orientation, the GPU/CPU ratio is not a quality claim',
-            'value_one_thread': n1 / max(dt1, 1e-9), 'one_thread_sample': f'{n1} candidates, {dt1:.1f} s',
-            'sample': f'{n} candidates ({100 * frac:.1f}% of every BFS level, evenly strided), {dt:.1f} s, '
+            'label': 'CPU port of the reference algorithm (oracle/mpcombi_oracle.c: BLAS-free C, every LP posed the way the reference poses it and solved '
+                     'by a dense two-phase simplex from scratch), OpenMP over the candidates with per-thread scratch.  Per thread it is about ten times '
+                     'the Python reference with HiGHS (about 175 candidates/s per worker process, BASELINE.md 4).  A baseline for orientation: the '
+                     'GPU/CPU ratio is not a quality claim',
+            'value_one_thread': one, 'thread_scaling': scaling,
+            'thread_scaling_sample': f'{n_sub} candidates: every 32nd of the sample below, the same for every thread count',
+            'sample': f'{n} candidates ({100 * frac:.1f}% of every BFS level, evenly strided), {dt:.1f} s on {cores} threads, '
                       f'{regions} regions; oracle/mpcombi_oracle.c (C port of the reference algorithm, OpenMP)',
             'regions_per_s': regions / dt,
             'verdicts_differing_from_gpu': differ,

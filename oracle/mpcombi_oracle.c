@@ -16,6 +16,37 @@
 #endif
 
 /* ------------------------------------------------------------------------------------------------
+ * Per-thread scratch for orc_check_level.  Every candidate allocates its LP matrices afresh (the reference builds its
+ * numpy blocks per call); those of the optimality LP are 150-500 KB, above glibc's mmap threshold, so with 256 threads
+ * every candidate paid mmap / munmap system calls under one process-wide lock -- the OpenMP loop scaled 9.8x on 256 threads
+ * (round 3).  Inside the loop malloc / calloc / free below are served from a thread-local block that is rewound per
+ * candidate; anywhere else they are the C library's.
+ * ---------------------------------------------------------------------------------------------- */
+static __thread char *t_arena = NULL;
+static __thread size_t t_top = 0, t_cap = 0;
+static __thread int t_arena_on = 0;
+static void *orc_malloc(size_t n) {
+    if (t_arena_on) {
+        const size_t need = (n + 63) & ~(size_t)63;
+        if (t_top + need <= t_cap) { void *p = t_arena + t_top; t_top += need; return p; }
+    }
+    return (malloc)(n);
+}
+static void *orc_calloc(size_t a, size_t b) {
+    void *p = orc_malloc(a * b);
+    if (p) memset(p, 0, a * b);
+    return p;
+}
+static void orc_free(void *p) {
+    if (p && t_arena && (char *)p >= t_arena && (char *)p < t_arena + t_cap) return;   /* rewound with the candidate */
+    (free)(p);
+}
+#define malloc(n) orc_malloc(n)
+#define calloc(a, b) orc_calloc(a, b)
+#define free(p) orc_free(p)
+#define ORC_ARENA_BYTES ((size_t)24 << 20)
+
+/* ------------------------------------------------------------------------------------------------
  * Dense two-phase simplex (stands in for GLPK behind solver_interface/cvxopt_interface.py:153-208).
  *
  * Dictionary form.  Row i:  basic_i = T[i][0] - sum_j T[i][j] * nonbasic_j   (j = 1..na)
@@ -671,9 +702,17 @@ int orc_check_level(const orc_problem *p, const int32_t *cands, int64_t n, int k
 #ifdef _OPENMP
     if (threads > 0) omp_set_num_threads(threads);
 #endif
-#pragma omp parallel for schedule(dynamic, 4)
-    for (int64_t i = 0; i < n; ++i)
-        status[i] = (uint8_t)orc_full_process(p, cands + i * k, k, rec_d ? rec_d + i * sd : NULL, rec_i ? rec_i + i * si : NULL);
+#pragma omp parallel
+    {
+        if (!t_arena) { t_arena = (char *)(malloc)(ORC_ARENA_BYTES); t_cap = t_arena ? ORC_ARENA_BYTES : 0; }   /* kept for the life of the thread */
+        t_arena_on = 1;
+#pragma omp for schedule(dynamic, 4)
+        for (int64_t i = 0; i < n; ++i) {
+            t_top = 0;
+            status[i] = (uint8_t)orc_full_process(p, cands + i * k, k, rec_d ? rec_d + i * sd : NULL, rec_i ? rec_i + i * si : NULL);
+        }
+        t_arena_on = 0;
+    }
     return 0;
 }
 

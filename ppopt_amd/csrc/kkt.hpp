@@ -126,8 +126,8 @@ __device__ inline bool lu_solve(double *M, int n, double *B, int nr, double sing
 //   screen   Gaussian elimination with complete pivoting on the k x n LDS matrix M (row stride n, destroyed).  Every pivot above
 //            RANK_SCREEN_FULL of the largest entry: the rows are independent by a margin of seven decades over numpy's threshold
 //            (complete pivoting keeps the growth small) -> full rank, no SVD.  Anything else is AMBIGUOUS;
-//   exact    the singular values themselves by one-sided Jacobi on the (re-loaded) rows -- the oracle's algorithm,
-//            oracle/mpcombi_oracle.c: jacobi_orthogonalise -- and numpy's rule word for word.  (Round 3 stopped at the elimination with
+//   exact    the singular values themselves by one-sided Jacobi (Hestenes) on the (re-loaded) rows, high relative accuracy also for
+//            the small ones, and numpy's rule word for word.  (Round 3 stopped at the elimination with
 //            a relative threshold of 1e-11: sets whose smallest singular value lies between 4e-15 and 1e-11 of the largest were
 //            called rank deficient where the reference goes on.)
 constexpr double RANK_SCREEN_FULL = 1e-8;

@@ -261,11 +261,20 @@ def solve_distributed(engine, program=None, group=None, profile: Optional[List[D
     try:
         return _solve_distributed(engine, program, group, profile, collect_regions, max_levels, shard_min, force_shard, full_solution)
     except _RepeatWithoutOverlap:
+        # the abandoned solve left work in flight: host copies into pooled page-locked arrays, all-gathers on RCCL's stream.  Everything
+        # is waited for before its buffers can be handed out again, the repeat runs with the region stage behind the (x,theta) stage, and
+        # the faster form is restored afterwards
+        if torch.cuda.is_available() and getattr(engine, 'device', None) is not None:
+            torch.cuda.synchronize(engine.device)
         if hasattr(engine, 'set_region_overlap'):
             engine.set_region_overlap(False)
         if profile is not None:
             del profile[:]
-        return _solve_distributed(engine, program, group, profile, collect_regions, max_levels, shard_min, force_shard, full_solution)
+        try:
+            return _solve_distributed(engine, program, group, profile, collect_regions, max_levels, shard_min, force_shard, full_solution)
+        finally:
+            if hasattr(engine, 'set_region_overlap'):
+                engine.set_region_overlap(True)
 
 
 def _solve_distributed(engine, program=None, group=None, profile: Optional[List[Dict]] = None,

@@ -91,22 +91,19 @@ def solve(program, num_cores: int = -1, device: int = 0, profile: Optional[List[
     slots for (MPC_ERR_CAPACITY, include/mpcombi.h: mpc_set_region_overlap -- never observed, forced in the tests), the solve is
     repeated with the region stage behind the (x,theta) stage, where nothing can be late.  No candidate is ever demoted."""
     from .._lib import MpcCapacityError, MpcError
+    closed = True
     try:
         sol = _solve(program, num_cores, device, profile, collect_regions, max_levels, stream, prune_lowdim)
         if not _closing_rows_unused(program.engine(device, closed=True), sol):
             # never observed: a closing row of the parameter set in a region -- the program is solved again on its own rows only
-            program.release_engine()
-            os.environ['MPC_NO_THETA_CLOSE'] = '1'
-            try:
-                if profile is not None:
-                    del profile[:]
-                sol = _solve(program, num_cores, device, profile, collect_regions, max_levels, stream, prune_lowdim)
-            finally:
-                del os.environ['MPC_NO_THETA_CLOSE']
-                program.release_engine()
+            # (an argument, not an environment variable: other threads of a mixed-integer enumeration keep their closed handles)
+            closed = False
+            if profile is not None:
+                del profile[:]
+            sol = _solve(program, num_cores, device, profile, collect_regions, max_levels, stream, prune_lowdim, closed=False)
         return sol
     except MpcCapacityError:
-        eng = program.engine(device, closed=True)
+        eng = program.engine(device, closed=closed)
         twin = getattr(eng, '_twin', None)
         if twin is not None:
             try:
@@ -116,12 +113,15 @@ def solve(program, num_cores: int = -1, device: int = 0, profile: Optional[List[
         eng.set_region_overlap(False)
         if profile is not None:
             del profile[:]
-        return _solve(program, num_cores, device, profile, collect_regions, max_levels, stream, prune_lowdim)
+        try:
+            return _solve(program, num_cores, device, profile, collect_regions, max_levels, stream, prune_lowdim, closed=closed)
+        finally:
+            eng.set_region_overlap(True)      # the slower form was for this solve only
 
 
 def _solve(program, num_cores: int = -1, device: int = 0, profile: Optional[List[Dict]] = None,
            collect_regions: bool = True, max_levels: Optional[int] = None, stream: Optional[bool] = None,
-           prune_lowdim: bool = True) -> Solution:
+           prune_lowdim: bool = True, closed: bool = True) -> Solution:
     """Solves the mpLP/mpQP on one GPU.  ``num_cores`` is accepted for signature compatibility with the reference
     drivers and ignored.  ``profile``: optional list that receives one dict of statistics per level.  ``stream``: region
     records are streamed to the host while the region kernel runs (default; ``MPC_NO_STREAM=1`` or False = fetch after
@@ -131,7 +131,7 @@ def _solve(program, num_cores: int = -1, device: int = 0, profile: Optional[List
     degenerate programs more regions."""
     if stream is None:
         stream = os.environ.get('MPC_NO_STREAM', '0') != '1'
-    eng = program.engine(device, closed=True)
+    eng = program.engine(device, closed=closed)
     n_x, n_t, n_c, n_tc = eng.n_x, eng.n_t, eng.n_c, eng.n_tc
     solution = Solution(program, [])
     max_depth = max(n_x, n_t) - eng.n_eq
@@ -396,6 +396,13 @@ def solve_many(programs, device: int = 0, max_levels: Optional[int] = None, prun
                 for i in done:
                     if any(i == j for j, _ in fetched):
                         engs[i].sync()  # a member that has just finished: nothing else completes its copies
+            # a member that produced regions, has children and was PARKED by the admission above is in neither list: its copies were only
+            # queued (mpc_level_regions_slots_nowait) and nothing of the next level completes them -- wait for them here, before the
+            # integer heads are read (regions were silently lost when a parked member's records were large)
+            started, finished = set(nxt), set(done)
+            for i, _ in fetched:
+                if i not in started and i not in finished:
+                    engs[i].sync()
             # ... and the region objects of the finished level are built while the device works on it
             for i, (hd, hi, er, kk) in fetched:
                 eng = engs[i]

@@ -31,12 +31,25 @@ class MPLP_Program:
         self.equality_indices = list(equality_indices) if equality_indices is not None and len(equality_indices) else []
         self.solver = Solver() if solver is None else solver
         self._engine = None
+        self._engine_closed = None
+        self._closing_rows = None
 
         self.base_constraint_processing()
         for msg in self.warnings():
             warnings.warn(msg, UserWarning)
         if post_process:
             self.post_process()
+
+    def _rows_changed(self) -> None:
+        """The rows have changed: both device handles (the program's own and the one with the closed parameter set) describe the old
+        rows and are given back; the next ``engine()`` call builds them again."""
+        if getattr(self, '_engine', None) is not None:
+            self._engine.close()
+        self._engine = None
+        if getattr(self, '_engine_closed', None) is not None:
+            self._engine_closed.close()
+        self._engine_closed = None
+        self._closing_rows = None
 
     # ---- presolve (mplp_program.py:110-134, 276-322) -------------------------------------------------------
     def base_constraint_processing(self):
@@ -54,7 +67,7 @@ class MPLP_Program:
                                                                                  self.equality_indices)
         self.A, self.b, self.F, self.equality_indices = generate_reduced_equality_constraints(
             self.A, self.b, self.F, self.equality_indices)
-        self._engine = None
+        self._rows_changed()
 
     def post_process(self):
         self.process_constraints()
@@ -67,7 +80,7 @@ class MPLP_Program:
         """Rows of [A | -F] (and b) to unit L2 norm."""
         norm = constraint_norm(numpy.hstack([self.A, -self.F]))
         self.A, self.b, self.F = self.A / norm, self.b / norm, self.F / norm
-        self._engine = None
+        self._rows_changed()
 
     def process_constraints(self) -> None:
         """Removes rows that cannot be active: one LP per non-equality row of [[A, -F], [0, A_t]]."""
@@ -79,7 +92,7 @@ class MPLP_Program:
         lower = [i - n_c for i in saved if i >= n_c]
         self.A, self.F, self.b = self.A[upper], self.F[upper], self.b[upper]
         self.A_t, self.b_t = self.A_t[lower], self.b_t[lower]
-        self._engine = None
+        self._rows_changed()
 
     # ---- sizes ------------------------------------------------------------------------------------------------
     def num_x(self) -> int:
@@ -235,7 +248,8 @@ class MPLP_Program:
             device = int(getattr(self.solver, 'device', 0) or 0)
         if closed:
             # the combinatorial drivers: a parameter set without a vertex is closed for the device (_engine_parameter_rows); the handle
-            # is a second one, the other drivers (graph, geometric, point location) keep the program's own rows
+            # is a second one, the other drivers (graph, geometric, point location) keep the program's own rows.  (Both handles are
+            # dropped whenever the rows change: _rows_changed.)
             eng_c = getattr(self, '_engine_closed', None)
             if eng_c is not None and eng_c.device == device:
                 return eng_c

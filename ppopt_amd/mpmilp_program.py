@@ -74,7 +74,7 @@ class MPMILP_Program(MPLP_Program):
             saved = [r for r, ok in zip(rows, feasible) if ok]
         upper = [*self.equality_indices, *[i for i in saved if i < self.A.shape[0]]]
         self.A, self.F, self.b = self.A[upper], self.F[upper], self.b[upper]
-        self._engine = None
+        self._rows_changed()
         self._leaf_table = None
 
     # ---- binary fixations ------------------------------------------------------------------------------------------------

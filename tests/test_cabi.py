@@ -48,6 +48,19 @@ def test_struct_layout_matches_header():
     offsets = dict((line.split()[0], int(line.split()[1])) for line in out[1:] if line.strip())
     for f in fields:
         assert offsets[f] == getattr(_lib.LevelStats, f).offset, f
+    # mpc_solve_level_info (the level loop behind one call): size and every field offset
+    fields2 = [name for name, *_ in _lib.SolveLevelInfo._fields_]
+    prog2 = '#include <stdio.h>\n#include <stddef.h>\n#include "mpcombi.h"\nint main(void) {\n  printf("%zu\\n", sizeof(mpc_solve_level_info));\n' + \
+            ''.join(f'  printf("{f} %zu\\n", offsetof(mpc_solve_level_info, {f}));\n' for f in fields2) + '  return 0;\n}\n'
+    with tempfile.TemporaryDirectory() as tmp:
+        src, exe = os.path.join(tmp, 'l.c'), os.path.join(tmp, 'l')
+        open(src, 'w').write(prog2)
+        subprocess.check_call(['gcc', '-I', os.path.join(ROOT, 'include'), src, '-o', exe])
+        out2 = subprocess.check_output([exe]).decode().split('\n')
+    assert int(out2[0]) == ctypes.sizeof(_lib.SolveLevelInfo)
+    for line in out2[1:]:
+        if line.strip():
+            assert int(line.split()[1]) == getattr(_lib.SolveLevelInfo, line.split()[0]).offset, line
 
 
 def test_flag_constants_match_the_header():
@@ -56,7 +69,8 @@ def test_flag_constants_match_the_header():
     defs = {k: int(v, 0) for k, v in re.findall(r'^#define\s+(MPC_[A-Z_0-9]+)\s+(-?(?:0x[0-9a-fA-F]+|\d+))\s*$', text, flags=re.M)}
     for name in ('MPC_LEVEL_STREAM', 'MPC_LEVEL_GRAPH', 'MPC_LEVEL_THEN_BASE', 'MPC_LEVEL_KEEP_LOWDIM', 'MPC_LEVEL_ONLY_BASE'):
         assert name in defs and getattr(_lib, name) == defs[name], name
-    flags = [defs[n] for n in defs if n.startswith('MPC_LEVEL_')]
+    assert _lib.MPC_SOLVE_FETCH == defs['MPC_SOLVE_FETCH']
+    flags = [defs[n] for n in defs if n.startswith('MPC_LEVEL_')] + [defs['MPC_SOLVE_FETCH']]      # mpc_solve_start takes them together
     assert len(set(flags)) == len(flags) and all(f & (f - 1) == 0 for f in flags)      # distinct single bits
 
 

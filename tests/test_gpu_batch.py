@@ -265,3 +265,34 @@ def test_solve_many_parks_members_beyond_the_memory_budget(monkeypatch):
             assert list(r1.active_set) == list(r2.active_set), n
             for fld in ('A', 'b', 'C', 'd', 'E', 'f'):
                 assert numpy.asarray(getattr(r1, fld)).tobytes() == numpy.asarray(getattr(r2, fld)).tobytes(), (n, fld)
+
+
+def test_parked_member_with_large_records_loses_no_region(monkeypatch):
+    """a member that produced regions in a level, has children and is then PARKED by the memory admission had its record
+    copies only queued -- nothing completed them before its integer heads were read.  Programs with thousands of regions per level
+    (copies of several MB, not microseconds) and a budget that parks most members at every level: every Solution must equal the
+    separate solve, region for region and byte for byte."""
+    import warnings
+    from ppopt_amd import MPQP_Program, problem_generator as pg
+    from ppopt_amd.mp_solvers import mpqp_hip_combinatorial
+
+    def programs():
+        out = []
+        with warnings.catch_warnings():
+            warnings.simplefilter('ignore')
+            for seed in (11, 12, 13, 14, 15, 16):
+                d = pg.generate_mpqp_data(9, 4, 18, seed)
+                out.append(MPQP_Program(d['A'], d['b'], d['c'], d['H'], d['Q'], d['A_t'], d['b_t'], d['F']))
+        return out
+    one = [mpqp_hip_combinatorial.solve(p) for p in programs()]
+    assert max(len(s.critical_regions) for s in one) > 1000
+    monkeypatch.setenv('MPC_BATCH_BUDGET_GB', '0.05')
+    for _ in range(3):      # (the race needed the copy to lose against the host: a few repetitions)
+        prof = []
+        many = mpqp_hip_combinatorial.solve_many(programs(), profile=prof)
+        assert max(p.get('parked', 0) for p in prof) > 0
+        for n, (a, b) in enumerate(zip(one, many)):
+            assert len(a.critical_regions) == len(b.critical_regions), n
+            ka = sorted((tuple(r.active_set), numpy.asarray(r.A).tobytes(), numpy.asarray(r.E).tobytes()) for r in a.critical_regions)
+            kb = sorted((tuple(r.active_set), numpy.asarray(r.A).tobytes(), numpy.asarray(r.E).tobytes()) for r in b.critical_regions)
+            assert ka == kb, n
