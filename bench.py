@@ -146,6 +146,7 @@ def main():
     ap.add_argument('--mi', type=int, default=1, help='mixed-integer enumeration extra on a synthetic mpMIQP (0 = skip)')
     ap.add_argument('--complete', type=int, default=1, help='complete solution of the workload by the connected-graph traversal, as an extra (0 = skip)')
     ap.add_argument('--dist-single', action='store_true', help='run the multi-GPU driver with a process group of one rank (self-test)')
+    ap.add_argument('--deep', type=int, default=0, help='also time the six-level variant of c4 on one GPU (the scaling workload the multi-GPU runs report under extra)')
     args = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -547,6 +548,36 @@ def main():
         out['cpu_baseline'] = cpu_baseline(prog, frontiers, gpu_status, args.cpu_sample)
     else:
         out['cpu_baseline'] = None
+    if args.workload == 'c4' and (distributed or args.deep):
+        # The scaling workload beside the BASELINE headline: the SAME program one level deeper (levels 1-6, 6.7 M candidates) -- five
+        # levels are 6 ms of work, of which the replicated first levels and the fixed cost per level do not shrink with the number of
+        # GPUs; the sixth level alone is 16 ms.  Same timing protocol (barrier + synchronise, max over ranks), fewer
+        # steps.  Not part of `value`.
+        def deep_step(profile):
+            if distributed:
+                return solve_distributed(engine, prog, profile=profile, max_levels=6, force_shard=args.dist_single, full_solution='rank0')
+            return mpqp_hip_combinatorial.solve(prog, device=local_rank, profile=profile, max_levels=6)
+        for _ in range(2):
+            deep_step([])
+        fence()
+        td = time.perf_counter()
+        n_deep = 3
+        for _ in range(n_deep):
+            dprof = []
+            dsol = deep_step(dprof)
+        fence()
+        deep_elapsed = time.perf_counter() - td
+        if distributed:
+            t = torch.tensor([deep_elapsed], dtype=torch.float64, device='cuda')
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            deep_elapsed = float(t.item())
+        deep_cands = sum(p['candidates'] for p in dprof)
+        out['extra'] = {'scaling_workload': {
+            'workload': 'c4, BFS levels 1-6 (the benchmark program one level deeper)', 'candidates_per_step': deep_cands,
+            'regions_per_step': len(dsol.critical_regions), 'steps': n_deep, 'ms_per_step': 1e3 * deep_elapsed / n_deep,
+            'candidates_per_s': deep_cands * n_deep / deep_elapsed, 'n_gpus': world,
+            'levels': [{'k': p['k'], 'candidates': p['candidates'], 'regions': p['regions']} for p in dprof if p['depth'] > 0]}}
+        del dsol
     if distributed:
         dist.destroy_process_group()
     # The JSON line is the LAST thing on stdout: RCCL writes its version banner through C stdio, which is block-buffered

@@ -99,10 +99,44 @@ class HipLevelEngine:
         torch.cuda.current_stream(self.device).synchronize()
         return t
 
-    def run_start(self, gen_children: bool):
+    def run_start(self, gen_children: bool, stream: bool = False):
         """``run`` on the engine's worker thread (mpc_level_start): returns at once, ``run_wait`` joins.  solve_distributed uses
-        the time in between to bring the previous level's gathered regions to the host and build their objects."""
-        self.eng.level_start(gen_children, stream=False)
+        the time in between to bring the previous level's gathered regions to the host and build their objects.  ``stream``: this
+        rank's own records are written by the region kernel straight into page-locked host arrays (MPC_LEVEL_STREAM), as in the
+        single-GPU loop -- ``own_regions`` consumes them."""
+        self.eng.level_start(gen_children, stream=stream)
+
+    streams_own_records = True
+
+    def own_regions(self):
+        """Between ``run_start(..., stream=True)`` and ``run_wait``: this rank's region objects of the running level, built chunk by
+        chunk while the region kernel writes them, and the host arrays behind them -- (regions, (head_d, head_i, erows, k)) or
+        (None, None) when the level does not stream (then ``regions()`` after ``run_wait``)."""
+        info = self.eng.level_stream_info()
+        if info is None:
+            return None, None
+        hd, hi, er, chunk, n_chunks = info
+        k = self.eng.frontier_info()[1]
+        batch = RegionBatch(hd, hi, er, self.n_x, self.n_t, self.n_c, self.n_tc, k, ())
+        status_col = hi[:, 0]
+        out = []
+        for j in range(n_chunks):
+            self.eng.level_chunk_wait(j)
+            lo = j * chunk
+            out.extend(batch.regions_of((lo + numpy.flatnonzero(status_col[lo:lo + chunk] == REGION_STATUS)).tolist()))
+        self._own_batch = batch
+        return out, (hd, hi, er, k)
+
+    def own_regions_after(self, regions, arrays):
+        """After ``run_wait`` of a streamed level: (regions, rows of erows in use) -- candidates the LDS-engine kernel re-solved after
+        the stream get their slots filled and the level is listed again."""
+        st = self._stats
+        rows = int(st.n_region_rows)
+        if st.n_region_retry:
+            hd, hi, er, _ = arrays
+            rows = self.eng.level_stream_fixup(hd, hi, er)
+            regions = self._own_batch.regions_of(numpy.flatnonzero(hi[:, 0] == REGION_STATUS).tolist())
+        return regions, rows
 
     def run_wait(self) -> Dict:
         st = self.eng.level_wait()
@@ -233,6 +267,8 @@ _NP_DTYPE = {torch.float64: numpy.float64, torch.int32: numpy.int32, torch.int64
 
 def allgather_table(row: List[int], device, group=None) -> List[List[int]]:
     """One small integer row per rank -> the table of all rows (rank order)."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return [list(row)]      # one rank: nothing to exchange (no device tensor, no read-back)
     mine = torch.tensor(row, dtype=torch.int64, device=device)
     world = dist.get_world_size(group)
     parts = [torch.empty_like(mine) for _ in range(world)]
@@ -297,8 +333,12 @@ def _solve_distributed(engine, program=None, group=None, profile: Optional[List[
     tail_events = []  # completion of the large arrays' host copies (waited for once, before the solve returns)
 
     def finish(entry):
-        """Waits for a level's gathers, copies every rank's piece to pinned host memory and lists its regions (rank order)."""
-        kk, gathers = entry
+        """Waits for a level's gathers, copies every rank's piece to pinned host memory and lists its regions (rank order).  The
+        rank's OWN shard is not copied back: its objects were built from the streamed records while the level ran."""
+        kk, gathers, own = entry
+        if gathers is None:      # one rank: nothing was gathered
+            solution.critical_regions.extend(own or [])
+            return
         if gathers[1][1] is not None:
             gathers[1][1].wait()      # the integer heads' gather (the current stream waits for it, not the host)
         # Host copies are queued in the order the host needs them: the integer heads of every piece first (a region object is a lazy
@@ -306,6 +346,9 @@ def _solve_distributed(engine, program=None, group=None, profile: Optional[List[
         # arrays are still on their way; the solve waits for them once, before it returns.
         queued = []
         for src, (a, b, c) in enumerate(zip(gathers[0][0], gathers[1][0], gathers[2][0])):
+            if src == rank and own is not None:
+                queued.append(own)      # (kept in rank order: every rank returns the regions in the same order)
+                continue
             if full_solution == 'rank0' and rank != 0 and src != rank:
                 continue      # another rank's shard: only rank 0 builds its objects
             if a.shape[0]:
@@ -318,13 +361,18 @@ def _solve_distributed(engine, program=None, group=None, profile: Optional[List[
         for j in (0, 2):
             if gathers[j][1] is not None:
                 gathers[j][1].wait()
-        for q in queued:
+        copied = [q for q in queued if q is not own]
+        for q in copied:
             q[0], q[1] = to_host(q[0], True), to_host(q[1], True)
-        if queued and queued[0][3] is not None:
+        if copied and copied[0][3] is not None:
             done = torch.cuda.Event()
             done.record()
             tail_events.append(done)
-        for hd, er, hi, ev in queued:
+        for q in queued:
+            if q is own:
+                solution.critical_regions.extend(own)
+                continue
+            hd, er, hi, ev = q
             if ev is not None:
                 ev.synchronize()
             slots = numpy.flatnonzero(hi[:, 0] == REGION_STATUS)
@@ -338,8 +386,21 @@ def _solve_distributed(engine, program=None, group=None, profile: Optional[List[
             if hasattr(engine, 'base_start'):
                 engine.base_start()      # the base-set check runs beside the sharded levels (second handle)
         capacity = getattr(engine, 'capacity_error', ())      # exception type(s) of "out of spare region slots", if the engine has one
+        own_regs = own_arrays = None
+        own_rows = 0
         try:
-            if pending is not None and hasattr(engine, 'run_start'):
+            if sharded and collect_regions and getattr(engine, 'streams_own_records', False):
+                # this rank's records are streamed to the host while the region kernel runs and become objects chunk by chunk (the
+                # single-GPU loop's form); the previous level's pieces of the OTHER ranks are copied and listed first
+                engine.run_start(gen_children, stream=True)
+                if pending is not None:
+                    finish(pending)
+                    pending = None
+                own_regs, own_arrays = engine.own_regions()
+                st = engine.run_wait()
+                if own_regs is not None:
+                    own_regs, own_rows = engine.own_regions_after(own_regs, own_arrays)
+            elif pending is not None and hasattr(engine, 'run_start'):
                 # the previous sharded level's regions (gathered on RCCL's stream meanwhile) come to the host and become objects
                 # while this level runs on the device
                 engine.run_start(gen_children)
@@ -359,7 +420,17 @@ def _solve_distributed(engine, program=None, group=None, profile: Optional[List[
         tensors = None
         if sharded:
             if collect_regions and st['n_regions']:
-                tensors = _region_tensors(engine)
+                if own_regs is not None:
+                    # streamed: the records are in host arrays; the other ranks get them from a device copy (queued on torch's stream,
+                    # under the next level).  With one rank nothing is gathered and nothing is copied.
+                    if world > 1:
+                        hd_o, hi_o, er_o, _ = own_arrays
+                        tensors = tuple(torch.from_numpy(a).to(engine.device, non_blocking=True) for a in (hd_o, hi_o, er_o[:max(own_rows, 0)]))
+                else:
+                    tensors = _region_tensors(engine)
+                    if getattr(engine, 'streams_own_records', False):      # the level did not stream: this rank's objects from the fetched arrays
+                        hd_o, hi_o, er_o, kk_o, slots_o = engine.regions()
+                        own_regs = RegionBatch(hd_o, hi_o, er_o, engine.n_x, engine.n_t, engine.n_c, engine.n_tc, kk_o, slots_o).regions()
             n_slots, n_rows = (int(tensors[0].shape[0]), int(tensors[2].shape[0])) if tensors is not None else (0, 0)
             table = allgather_table([st['n'], st['n_children'], st['n_pruned_new'], st['n_regions'], st['lp_pivots'],
                                      n_slots, n_rows, *st['status']], engine.device, group)
@@ -369,7 +440,7 @@ def _solve_distributed(engine, program=None, group=None, profile: Optional[List[
                      'n_pruned_new': sum(r[2] for r in table), 'n_regions': sum(r[3] for r in table),
                      'lp_pivots': sum(r[4] for r in table),
                      'status': [sum(r[7 + j] for r in table) for j in range(len(st['status']))]}
-            if gen_children and total['n_pruned_new']:
+            if gen_children and total['n_pruned_new'] and world > 1:
                 # the other ranks' newly pruned sets join this rank's list (its own are added by advance())
                 parts = allgather_rows(engine.pruned_new(), [r[2] for r in table], group)
                 others = [p for r, p in enumerate(parts) if r != rank and p.shape[0]]
@@ -381,13 +452,16 @@ def _solve_distributed(engine, program=None, group=None, profile: Optional[List[
                 kk = int(k)
                 fd = engine.n_x * engine.n_t + engine.n_x + kk * engine.n_t + kk
                 fi = 8 + kk + engine.n_tc + kk + 2 * (engine.n_c - kk)
-                if tensors is None:
-                    dev = engine.device
-                    tensors = (torch.zeros((0, fd), dtype=torch.float64, device=dev), torch.zeros((0, fi), dtype=torch.int32, device=dev),
-                               torch.zeros((0, engine.n_t + 1), dtype=torch.float64, device=dev))
-                pending = (kk, [allgather_rows_start(tensors[0], [r[5] for r in table], group),
-                                allgather_rows_start(tensors[1], [r[5] for r in table], group),
-                                allgather_rows_start(tensors[2], [r[6] for r in table], group)])
+                if world == 1 and own_regs is not None:
+                    pending = (kk, None, own_regs)
+                else:
+                    if tensors is None:
+                        dev = engine.device
+                        tensors = (torch.zeros((0, fd), dtype=torch.float64, device=dev), torch.zeros((0, fi), dtype=torch.int32, device=dev),
+                                   torch.zeros((0, engine.n_t + 1), dtype=torch.float64, device=dev))
+                    pending = (kk, [allgather_rows_start(tensors[0], [r[5] for r in table], group),
+                                    allgather_rows_start(tensors[1], [r[5] for r in table], group),
+                                    allgather_rows_start(tensors[2], [r[6] for r in table], group)], own_regs)
         elif collect_regions and st['n_regions']:
             hd, hi, er, kk, slots = engine.regions()
             solution.critical_regions.extend(RegionBatch(hd, hi, er, engine.n_x, engine.n_t, engine.n_c, engine.n_tc, kk, slots).regions())
