@@ -70,6 +70,13 @@ __global__ void __launch_bounds__(64) m_verdict(const BatchMember *__restrict__ 
     k_verdict(m.Pv, m.fr, m.n, m.k, m.status, m.ctr, part_list_of(m, 0), m.dcnt + slot);
 }
 
+// members whose parameter set is open: the candidates called optimal are asked whether the reference's max-t LP is bounded (kernels.hpp)
+__global__ void __launch_bounds__(64) m_recession(const BatchMember *__restrict__ tab) {
+    MEMBER;
+    if (!m.theta_open) return;
+    k_recession(m.Pv, m.fr, m.n, m.k, m.status);
+}
+
 // ---- region stage -------------------------------------------------------------------------------------------------------------
 template <int NT, int SLOTS>
 __global__ void __launch_bounds__(64, (SLOTS >= 2 ? 2 : R2W)) m_region2(const BatchMember *__restrict__ tab) {
@@ -230,6 +237,14 @@ hipError_t batch_level_launch(BatchMember *members, int B, hipStream_t st, Batch
         // re-solve of a doubtful (x,theta) run has just found -- so one launch covers them all (class 2 of the partition at [16..19];
         // a single program overlaps its region stage with the (x,theta) stage instead and handles late candidates separately: with
         // other members filling the device there is nothing to gain from that here)
+        {
+            bool any_open = false;
+            for (int i = g0; i < g1; ++i) any_open = any_open || members[i].theta_open;
+            if (any_open) {
+                TRY(raise_lds(m_recession, lds_v));
+                hipLaunchKernelGGL(m_recession, dim3((unsigned)std::min<long long>(n_max, 256), G), dim3(64), lds_v, st, tab);
+            }
+        }
         hipLaunchKernelGGL(m_partition_small, dim3(1, G), dim3(1024), 0, st, tab, spec_of({{ST_OPT_PENDING, 2}}), 16);
         TRY(hipGetLastError());
         {

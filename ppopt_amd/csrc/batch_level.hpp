@@ -35,6 +35,7 @@ struct BatchMember {
     long long n;             // candidates of the level
     int grid_f, grid_r2, n_cu, lds_f, lds_v, lds_r2, rsplit_max;
     int W, ldk, fd, fi, no_rbox, nxc, storing, keep_lowdim;
+    int theta_open;          // the member's parameter set is open in some direction: k_recession behind the verdict stages (mpcombi_hip.hip)
     int lds_r, rcap;         // LDS-engine region kernel (candidates k_region2 gives up on): dynamic LDS, record slots reserved
     long long rec_d, rec_i;  // strides of its fixed-layout records
     // ---- the arguments of level_run_small's launches ---------------------------------------------------------------------------

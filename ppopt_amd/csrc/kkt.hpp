@@ -131,7 +131,8 @@ __device__ inline bool lu_solve(double *M, int n, double *B, int nr, double sing
 //            a relative threshold of 1e-11: sets whose smallest singular value lies between 4e-15 and 1e-11 of the largest were
 //            called rank deficient where the reference goes on.)
 constexpr double RANK_SCREEN_FULL = 1e-8;
-// 1 full rank, 0 certainly deficient (k > n or a zero matrix), 2 ambiguous (M destroyed: reload it and ask svd_full_row_rank)
+constexpr double RANK_SCREEN_ZERO = 2.220446049250313e-16;
+// 1 full rank, 0 certainly deficient (k > n, a zero matrix, an exact dependency), 2 ambiguous (M destroyed: reload it and ask svd_full_row_rank)
 __device__ inline int rank_screen(double *M, int k, int n) {
     const int lane = lane_id();
     if (k > n) return 0;
@@ -149,6 +150,10 @@ __device__ inline int rank_screen(double *M, int k, int n) {
             if (a > best) { best = a; pos = i * n + j; }
         }
         reduce_max_first(best, pos);
+        // what is left is below one unit in the last place of the largest entry: an exact dependency (both bounds of a variable active, a
+        // repeated row: half of the candidates of a deep level) -- rank deficient by numpy's rule too (sigma_min <~ k * pivot, threshold
+        // sigma_max * max(k, n) * eps), without paying for the singular values
+        if (!(best > RANK_SCREEN_ZERO * scale)) return 0;
         if (!(best > RANK_SCREEN_FULL * scale)) return 2;
         const int pi = pos / n, pj = pos % n;
         wave_sync();

@@ -1291,7 +1291,7 @@ static void stream_release(mpc_handle *h) {   // blocks of a streamed level nobo
 // optimal (= the region launch), open | [8] open after the quick test | [24] doubtful after the (x,theta) stage | [17] optimal
 // candidates that missed the region launch | [20] children
 static bool small_path_ok(const mpc_handle *h, long long n, int k, int32_t flags, int32_t gen_children) {
-    if (h->no_smallpath || !h->fast || h->force_v1 || h->fast_r < 0 || n < 1 || n > h->smallpath_max || h->theta_open) return false;
+    if (h->no_smallpath || !h->fast || h->force_v1 || h->fast_r < 0 || n < 1 || n > h->smallpath_max) return false;
     if (flags & MPC_LEVEL_GRAPH) return false;
     if (h->test_late > 0 || h->debug_cycles) return false;
     // children and their parent slots are sized by the bound n (n_c - k) candidates of k + 1 indices
@@ -1384,6 +1384,8 @@ static int level_run_small(mpc_handle *h, int32_t gen_children, int32_t flags, m
     // side stream under the (x,theta) stage), so that the partition below already knows every optimal candidate they yield
     hipLaunchKernelGGL(k_partition_small, dim3(1), dim3(1024), 0, st, h->status.as<uint8_t>(), (int)n, spec_of({{ST_RETRY, 0}}), h->part_lists.as<int32_t>(), (long long)n, dcnt + 12);
     hipLaunchKernelGGL(k_verdict, dim3((unsigned)std::min<long long>(n, 128)), dim3(64), h->lds_v, st, h->Pv, fr, n, k, stp, ctr, part_list(0), dcnt + 12);
+    // open parameter set: "optimal" only if the reference's max-t LP is bounded (k_recession), decided before the region launch below
+    if (h->theta_open) hipLaunchKernelGGL(k_recession, dim3((unsigned)std::min<long long>(n, 256)), dim3(64), h->lds_v, st, h->Pv, fr, n, k, stp);
     // classes after the theta stage: [1] feasible, [2] optimal, [3] feasibility open
     hipLaunchKernelGGL(k_partition_small, dim3(1), dim3(1024), 0, st, h->status.as<uint8_t>(), (int)n,
                        spec_of({{ST_FEASIBLE, 1}, {ST_OPT_PENDING, 2}, {ST_NEEDX, 3}, {ST_NEEDX_SING, 3}}), h->part_lists.as<int32_t>(), (long long)n, dcnt + 4);
@@ -1658,6 +1660,7 @@ static int batch_prepare(mpc_handle *h, int32_t gen_children, int32_t flags, Bat
     m.quick_test = (!h->storing && dc.parent_slot && !h->no_xquick) ? 1 : 0;
     // pruned masks + children
     m.keep_lowdim = (flags & MPC_LEVEL_KEEP_LOWDIM) ? 1 : 0;
+    m.theta_open = h->theta_open ? 1 : 0;
     m.pruned = h->pruned.as<unsigned long long>(); m.n_pruned = h->n_pruned;
     if (gen_children) {
         HIP_TRY(h, h->childmask.ensure(nn * h->mw * sizeof(uint64_t), st));

@@ -12,7 +12,10 @@ from conftest import load_golden
 pytestmark = pytest.mark.gpu
 
 MIXED = ['rand_6_3_12_s1', 'c2_dblint_n5', 'quadtank_n3', 'c4_rand_20_8_20_s0', 'rand_4_2_10_s0', 'dblint_n3', 'rand_5_3_8_s3', 'quadtank_n2',
-         'transport_mpqp', 'c2_dblint_n5_x20']
+         'transport_mpqp', 'c2_dblint_n5_x20',
+         # open parameter sets (k_recession behind the verdict stages, also inside the shared launches): a pointed cone and one with the
+         # main rows' big-M box
+         'open_rand_5_3_10_s4_lower', 'open_rand_5_3_10_s4_lower_boxed']
 
 
 def _levels_alone(g, n_levels, keep_lowdim=False):
