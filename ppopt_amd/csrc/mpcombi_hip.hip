@@ -519,7 +519,12 @@ extern "C" {
 
 int mpc_device_count(void) { return device_count_cached(); }
 
-const char *mpc_version(void) { return "mpcombi-hip 0.1 (gfx950)"; }
+// the build stamp says which binary a record was made with: the compiler's date / time of THIS translation unit and the hipcc version
+#define MPC_STR2(x) #x
+#define MPC_STR(x) MPC_STR2(x)
+const char *mpc_version(void) {
+    return "mpcombi-hip 0.4 (gfx950; built " __DATE__ " " __TIME__ ", hip " MPC_STR(HIP_VERSION_MAJOR) "." MPC_STR(HIP_VERSION_MINOR) "." MPC_STR(HIP_VERSION_PATCH) ")";
+}
 const char *mpc_last_global_error(void) { return g_error.c_str(); }
 const char *mpc_last_error(const mpc_handle *h) { return h ? h->error.c_str() : g_error.c_str(); }
 

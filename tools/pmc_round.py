@@ -1,5 +1,5 @@
-"""Round-3 counter record: turns the rocprofv3 --pmc passes of one bench command (and of the calibration micro-kernels) into
-profiles/r03_pmc.json, which bench.py reads for roofline.traffic and for the VALU-issue figures of the simplex kernels.
+"""Counter record of a round: turns the rocprofv3 --pmc passes of one bench command (and of the calibration micro-kernels) into
+profiles/<tag>_pmc.json (tag: environment PMC_TAG, default r04), which bench.py reads for roofline.traffic and for the VALU-issue figures of the simplex kernels.
 
     python tools/pmc_round.py calib <fetch.db> <write.db>
     python tools/pmc_round.py bench <workload> <solves> fetch=<db> write=<db> [sq=<db>] [f64=<db>]
@@ -18,7 +18,7 @@ import sqlite3
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-OUT = os.path.join(ROOT, 'profiles', 'r03_pmc.json')
+OUT = os.path.join(ROOT, 'profiles', os.environ.get('PMC_TAG', 'r04') + '_pmc.json')
 LEVELS = {'c4': 5, 'c3': 4, 'c2': 5}
 HEAVY = ('k_theta2', 'k_x2', 'k_region2', 'k_xq_grouped', 'k_xq', 'k_kkt_thread', 'k_level_small')
 
