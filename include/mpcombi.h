@@ -38,8 +38,10 @@ extern "C" {
 #define MPC_ERR_STATE 4        /* call sequence error (e.g. level results requested before run) */
 
 /* per-candidate status == verdict of full_process (driver lines 17-64) */
-#define MPC_INFEASIBLE 0        /* rank deficient or (x,theta) LP infeasible -> pruned                     */
-#define MPC_FEASIBLE 1          /* feasible, not optimal -> children                                       */
+#define MPC_INFEASIBLE 0        /* rank deficient (numpy's SVD rule, constraint_utilities.py:222-236) or (x,theta) LP infeasible -> pruned */
+#define MPC_FEASIBLE 1          /* feasible, not optimal -> children.  "Not optimal" is the reference's: its optimality LP maximises t
+                                   (mpqp_program.py:203-322) and anything but an optimal status is None -- also an UNBOUNDED t on a
+                                   parameter set that is open in some direction (k_recession poses that question for such programs) */
 #define MPC_OPTIMAL_NO_REGION 2 /* optimal, region lower dimensional (gen_cr returned None) -> pruned      */
 #define MPC_REGION 3            /* critical region -> children                                             */
 #define MPC_SINGULAR_KKT 4      /* feasible, KKT matrix numerically singular: no region, children expanded */
