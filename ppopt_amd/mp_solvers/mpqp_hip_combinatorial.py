@@ -253,7 +253,6 @@ def _solve_in_library(program, eng, solution, max_depth, profile, prune_lowdim, 
     page-locked arrays the region kernel is still writing, chunk by chunk; small ones: complete arrays) and builds the region objects
     while later levels already run.  The base active set (driver :142-146) is checked on the program's second handle beside the levels.
     ``MPC_NO_SOLVE_LOOP=1`` keeps the level-by-level loop in ``_solve``."""
-    from .._lib import MpcError
     n_x, n_t, n_c, n_tc = eng.n_x, eng.n_t, eng.n_c, eng.n_tc
     twin = None
     if BASE_ON_TWIN:
@@ -265,6 +264,7 @@ def _solve_in_library(program, eng, solution, max_depth, profile, prune_lowdim, 
     eng.solve_start(max_depth, stream=True, fetch=True, then_base=twin is None, keep_lowdim=not prune_lowdim)
     regions = solution.critical_regions
     level = 0
+    consumed = False
     try:
         while True:
             info = eng.solve_level(level)
@@ -289,9 +289,13 @@ def _solve_in_library(program, eng, solution, max_depth, profile, prune_lowdim, 
             if profile is not None:
                 profile.append(_level_profile(level + 1, st, ms_wall))
             level += 1
-    except MpcError:
-        eng.solve_wait()      # raises what the loop itself failed with (MpcCapacityError: the solve is repeated without the overlap)
-        raise
+        consumed = True
+    finally:
+        if not consumed:
+            # whatever stopped this thread (an error of the loop seen through a wait, an interrupt): the loop is joined before the handle
+            # is touched again, and what the loop itself failed with (MpcCapacityError: the solve is repeated without the overlap)
+            # takes precedence
+            eng.solve_wait()
     eng.solve_wait()
     # the base active set (= the equality rows) is tested last, like the reference (driver :142-146)
     if twin is not None:
