@@ -588,13 +588,15 @@ template <int SLOTS, class PD, class PI>
 __device__ __forceinline__ int xq_decide(PD pd, PI pi, int mr, int NXC, int ncol, int v, int lane, int &piv_local) {
     // NXC: column slots of the record layout; ncol <= NXC: the slots that are ever used (value column + D0 columns) -- only those
     // are stored and read
-    int qvar[SLOTS], qkind[SLOTS];
+    int qvar[SLOTS], qkind[SLOTS], qhint[SLOTS];
     double qb[SLOTS];
 #pragma unroll
     for (int sl = 0; sl < SLOTS; ++sl) {
         const int i = lane + 64 * sl;
         qvar[sl] = i < mr ? pi[i] : -1;
-        qkind[sl] = i < mr ? pi[mr + i] : RK_DEAD;
+        const int kraw = i < mr ? pi[mr + i] : RK_DEAD;
+        qkind[sl] = kraw & 0xff;
+        qhint[sl] = kraw >> 8;      // the row's entering column at the parent's final dictionary (k_x2's store), 0 = none improves
         qb[sl] = i < mr ? pd[i] : 0.0;
     }
     const int qcv = lane < NXC + 3 ? pi[2 * mr + lane] : -1;
@@ -625,14 +627,23 @@ __device__ __forceinline__ int xq_decide(PD pd, PI pi, int mr, int NXC, int ncol
             int rp[XQ_ITERS], qp[XQ_ITERS];
             double invp[XQ_ITERS];
             double xrow = (lane < ncol) ? pd[(size_t)lane * mr + row] : 0.0;   // the new row, entry j in lane j
+            // first iteration: the column comes from the hint stored with the parent's record -- exactly the column the pricing of
+            // `xrow` below would choose (same rule, same numbers) -- so the column is asked for together with the row, not after it
+            const int q0 = __builtin_amdgcn_readlane((SLOTS == 1 || row < 64) ? qhint[0] : qhint[SLOTS - 1], row & 63);
             double growth = growth0;
 #pragma unroll
             for (int it = 0; it < XQ_ITERS; ++it) {
                 if (at(qb, row) <= TOL_FEAS) { feas = 1; break; }
-                const double g = (lane >= 1 && lane < ncol) ? xrow : 0.0;
-                const double gm = dpp_wave_max(g > TOL_COST ? g : 0.0);
-                if (!(gm > TOL_COST)) { feas = 0; break; }
-                const int q = uni(__ffsll((long long)__ballot(g == gm && lane >= 1 && lane < ncol)) - 1);
+                int q;
+                if (it == 0) {
+                    if (q0 <= 0) { feas = 0; break; }
+                    q = q0;
+                } else {
+                    const double g = (lane >= 1 && lane < ncol) ? xrow : 0.0;
+                    const double gm = dpp_wave_max(g > TOL_COST ? g : 0.0);
+                    if (!(gm > TOL_COST)) { feas = 0; break; }
+                    q = uni(__ffsll((long long)__ballot(g == gm && lane >= 1 && lane < ncol)) - 1);
+                }
                 // entering column at the current time
                 double a[SLOTS], ratio[SLOTS];
 #pragma unroll
@@ -921,7 +932,7 @@ MPC_GLOBAL void MPC_LB(64, (NXC * SLOTS >= 32 ? X2_WAVES : X2_WAVES_16)) k_x2(co
             for (int sl = 0; sl < SLOTS; ++sl) {
                 const int i = lane + 64 * sl;
                 lx.var[sl] = i < mr ? voff + src_i[i] : -1;
-                lx.kind[sl] = i < mr ? (cached ? src_i[mr + i] : RK_INEQ) : RK_DEAD;
+                lx.kind[sl] = i < mr ? (cached ? (src_i[mr + i] & 0xff) : RK_INEQ) : RK_DEAD;   // (bits 8.. of a stored kind: the row's entering-column hint, below)
 #pragma unroll
                 for (int j = 0; j < NXC; ++j) lx.t[sl][j] = (i < mr && j <= jmax) ? src_d[(size_t)j * mr + i] : 0.0;
             }
@@ -950,8 +961,16 @@ MPC_GLOBAL void MPC_LB(64, (NXC * SLOTS >= 32 ? X2_WAVES : X2_WAVES_16)) k_x2(co
                 for (int sl = 0; sl < SLOTS; ++sl) {
                     const int i = lane + 64 * sl;
                     if (i < mr) {
+                        // Entering-column hint for the children's quick test (k_xq, round 4): the first iteration of a child whose new row
+                        // is THIS row prices this row -- largest coefficient above the cost tolerance, lowest column among equals.  Every
+                        // lane knows that of its own row now, for nothing (the row is in registers); stored in bits 8.. of the kind word,
+                        // it saves the child one dependent read of the record (the row itself) before its first column can be asked for.
+                        int qhint = 0;
+                        double gbest = TOL_COST;
+#pragma unroll
+                        for (int j = 1; j < NXC; ++j) { const double v = lx.t[sl][j]; if (j <= nc0 && v > gbest) { gbest = v; qhint = j; } }
                         oi[i] = lx.var[sl];
-                        oi[mr + i] = lx.kind[sl];
+                        oi[mr + i] = lx.kind[sl] | (qhint << 8);
 #pragma unroll
                         for (int j = 0; j < NXC; ++j) if (j <= nc0) od[(size_t)j * mr + i] = lx.t[sl][j];
                     }
