@@ -50,10 +50,30 @@ def solve_mpmiqp_enumeration(program, num_cores: int = -1,
         prune_lowdim = cont_algorithm is mpqp_algorithm.combinatorial_parallel
 
         def substitute(fixes):
-            """The sub-programs of ``fixes``, presolved and set up.  One thread per fixation: the presolve LPs of all of them (three
-            small device batches per construction) are posed together, one batch per presolve stage (solver.LPCoalescer)."""
+            """The sub-programs of ``fixes``, presolved and set up, WITHOUT a thread per construction (round 4): every fixation is
+            substituted and brought through the LP-free part of the constructor in this thread (the rows that carry continuous content
+            are shared by all fixations: only the right-hand side differs), the redundancy LPs of ALL sub-programs are posed as one device
+            batch per shape (Solver.lp_feasible_many; statuses only), their results applied, and the set-ups (mpc_create: C, no interpreter
+            lock) run on a few threads.  The two diagnostic LPs of the constructor, whose only outcome is a warning that this function
+            discards, are not posed.  (Round 3: one thread per fixation with the LP calls of all threads coalesced -- 65 ms for 64
+            sub-programs, of which half was interpreter-lock hand-over; MPC_MI_THREADS=1 keeps that form.)"""
             import copy
             from ..solver import LPCoalescer
+            if os.environ.get('MPC_MI_THREADS', '0') != '1' and hasattr(program.solver, 'lp_feasible_many'):
+                with warnings.catch_warnings():
+                    warnings.simplefilter('ignore')
+                    subs = [program.generate_substituted_problem(fix, deferred=True) for fix in fixes]
+                    requests = [sub._redundancy_request() for sub in subs]
+                    answers = program.solver.lp_feasible_many([(PA, Pb, [[*eq, i] for i in todo]) for PA, Pb, eq, todo in requests])
+                    for sub, req, ok in zip(subs, requests, answers):
+                        sub._redundancy_apply(req, ok.tolist())
+                    if len(subs) > 2 and num_cores != 1:
+                        with ThreadPoolExecutor(max_workers=min(8, len(subs))) as setup_pool:
+                            list(setup_pool.map(lambda sub: sub.engine(device, closed=True), subs))
+                    else:
+                        for sub in subs:
+                            sub.engine(device, closed=True)
+                return subs
             if len(fixes) <= 1 or num_cores == 1 or os.environ.get('MPC_NO_LP_COALESCE', '0') == '1':
                 with warnings.catch_warnings():    # the substituted programs repeat the parent's construction warnings
                     warnings.simplefilter('ignore')

@@ -22,7 +22,9 @@ from .utils.general_utils import make_column, ppopt_block, select_not_in_list
 
 class MPLP_Program:
     def __init__(self, A, b, c, H, A_t, b_t, F, c_c=None, c_t=None, Q_t=None, equality_indices=None, solver=None,
-                 post_process=True):
+                 post_process=True, _diagnostics=True):
+        # _diagnostics=False (private; the mixed-integer enumeration's batch construction): the two LPs behind ``warnings()`` -- whose only
+        # outcome is a UserWarning, which the enumeration discards -- are not posed
         self.A, self.b, self.c, self.H = A, b, c, H
         self.A_t, self.b_t, self.F = A_t, b_t, F
         self.c_c = numpy.array([[0.0]]) if c_c is None else c_c
@@ -35,8 +37,9 @@ class MPLP_Program:
         self._closing_rows = None
 
         self.base_constraint_processing()
-        for msg in self.warnings():
-            warnings.warn(msg, UserWarning)
+        if _diagnostics:
+            for msg in self.warnings():
+                warnings.warn(msg, UserWarning)
         if post_process:
             self.post_process()
 
@@ -82,11 +85,28 @@ class MPLP_Program:
         self.A, self.b, self.F = self.A / norm, self.b / norm, self.F / norm
         self._rows_changed()
 
+    def _redundancy_request(self):
+        """(PA, Pb, equality sets) of ``process_constraints``' LPs -- one per non-equality row of [[A, -F], [0, A_t]], that row and the
+        program's equalities as equalities -- without solving them (the enumeration poses those of all sub-programs together)."""
+        PA = ppopt_block([[self.A, -self.F], [numpy.zeros((self.A_t.shape[0], self.A.shape[1])), self.A_t]])
+        Pb = ppopt_block([[self.b], [self.b_t]])
+        eq = list(self.equality_indices)
+        todo = [i for i in range(PA.shape[0]) if i not in eq]
+        return PA, Pb, eq, todo
+
+    def _redundancy_apply(self, request, feasible) -> None:
+        """Second half of ``process_constraints``: ``feasible[j]`` says whether row ``todo[j]`` of the request can be active."""
+        PA, _, _, todo = request
+        dead = {i for i, ok in zip(todo, feasible) if not ok}
+        self._keep_rows([i for i in range(PA.shape[0]) if i not in dead])
+
     def process_constraints(self) -> None:
         """Removes rows that cannot be active: one LP per non-equality row of [[A, -F], [0, A_t]]."""
         PA = ppopt_block([[self.A, -self.F], [numpy.zeros((self.A_t.shape[0], self.A.shape[1])), self.A_t]])
         Pb = ppopt_block([[self.b], [self.b_t]])
-        saved = find_redundant_constraints(PA, Pb, self.equality_indices, solver=self.solver)
+        self._keep_rows(find_redundant_constraints(PA, Pb, self.equality_indices, solver=self.solver))
+
+    def _keep_rows(self, saved) -> None:
         n_c = self.num_constraints()
         upper = [i for i in saved if i < n_c]
         lower = [i - n_c for i in saved if i >= n_c]

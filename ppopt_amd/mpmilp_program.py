@@ -129,15 +129,17 @@ class MPMILP_Program(MPLP_Program):
         _, A_cont_k, A_bin_k, b_k, F_k, n_eq, _ = cache
         return A_cont_k.copy(), b_k - A_bin_k @ y, F_k.copy(), list(range(n_eq)), y
 
-    def generate_substituted_problem(self, fixed_combination: List[int]):
-        """The continuous mpLP with the binaries fixed; rows without continuous or parametric content are dropped."""
+    def generate_substituted_problem(self, fixed_combination: List[int], deferred: bool = False):
+        """The continuous mpLP with the binaries fixed; rows without continuous or parametric content are dropped.  ``deferred``: see
+        MPMIQP_Program.generate_substituted_problem."""
         A_cont, b, F, eq, y = self._substituted_rows(fixed_combination)
         c = self.c[self.cont_indices]
         c_c = self.c_c + self.c[self.binary_indices].T @ y
         H_c = self.H[self.cont_indices]
         H_d = self.H[self.binary_indices]
         c_t = self.c_t + (y.T @ H_d).T
-        return MPLP_Program(A_cont, b, c, H_c, self.A_t, self.b_t, F, c_c, c_t, self.Q_t, eq, self.solver)
+        return MPLP_Program(A_cont, b, c, H_c, self.A_t, self.b_t, F, c_c, c_t, self.Q_t, eq, self.solver,
+                            post_process=not deferred, _diagnostics=not deferred)
 
     def _relaxation_rows(self):
         nb = len(self.binary_indices)

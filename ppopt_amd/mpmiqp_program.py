@@ -28,9 +28,10 @@ class MPMIQP_Program(MPMILP_Program):
             + self.c_t.T @ theta_point + 0.5 * theta_point.T @ self.Q_t @ theta_point
         return float(v[0, 0])
 
-    def generate_substituted_problem(self, fixed_combination: Union[numpy.ndarray, List[int]]):
+    def generate_substituted_problem(self, fixed_combination: Union[numpy.ndarray, List[int]], deferred: bool = False):
         """The continuous mpQP with the binaries fixed (mpmiqp_program.py:70-115): the binary block of Q moves into
-        the constant, the mixed block into the linear term."""
+        the constant, the mixed block into the linear term.  ``deferred`` (the enumeration's batch construction): the presolve's
+        redundancy LPs are left to the caller (``_redundancy_request`` / ``_redundancy_apply``) and the diagnostic LPs are not posed."""
         A_cont, b, F, eq, y = self._substituted_rows(fixed_combination)
         ci, bi = self.cont_indices, self.binary_indices
         Q_c = self.Q[:, ci][ci]
@@ -41,7 +42,8 @@ class MPMIQP_Program(MPMILP_Program):
         H_c = self.H[ci]
         H_d = self.H[bi]
         c_t = self.c_t + (y.T @ H_d).T
-        return MPQP_Program(A_cont, b, c, H_c, Q_c, self.A_t, self.b_t, F, c_c, c_t, self.Q_t, eq, self.solver)
+        return MPQP_Program(A_cont, b, c, H_c, Q_c, self.A_t, self.b_t, F, c_c, c_t, self.Q_t, eq, self.solver,
+                            post_process=not deferred, _diagnostics=not deferred)
 
     def generate_relaxed_problem(self, process: bool = True) -> MPQP_Program:
         A, b, F = self._relaxation_rows()

@@ -13,9 +13,9 @@ from .solver import SolverOutput
 class MPQP_Program(MPLP_Program):
     def __init__(self, A, b, c, H, Q, A_t, b_t, F, c_c: Optional[numpy.ndarray] = None,
                  c_t: Optional[numpy.ndarray] = None, Q_t: Optional[numpy.ndarray] = None, equality_indices=None,
-                 solver=None, post_process=True):
+                 solver=None, post_process=True, _diagnostics=True):
         self.Q = numpy.asarray(Q).astype('float64')
-        super().__init__(A, b, c, H, A_t, b_t, F, c_c, c_t, Q_t, equality_indices, solver, post_process=False)
+        super().__init__(A, b, c, H, A_t, b_t, F, c_c, c_t, Q_t, equality_indices, solver, post_process=False, _diagnostics=_diagnostics)
         if post_process:
             self.post_process()
 

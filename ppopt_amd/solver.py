@@ -78,6 +78,39 @@ class Solver:
             res.append(SolverOutput(float(obj[i]), x[i].copy(), slack, active, None))
         return res
 
+    def lp_feasible_many(self, requests) -> List[numpy.ndarray]:
+        """Feasibility of MANY families of LPs in as few device batches as there are shapes.  ``requests``: a list of
+        (A [m, n], b [m], equality sets) -- per family one matrix, one right-hand side and several equality sets (what the presolve's
+        redundancy test poses per program, constraint_utilities.py:186-200).  Returns one bool array per request (entry j: the LP with
+        equality set j has a solution).  Only the status comes back from the device (no solution vectors)."""
+        out: List[Optional[numpy.ndarray]] = [None] * len(requests)
+        groups: Dict[tuple, List[int]] = {}
+        for r, (A, b, eqs) in enumerate(requests):
+            if len(eqs) == 0:
+                out[r] = numpy.zeros(0, dtype=bool)
+            else:
+                groups.setdefault(tuple(numpy.shape(A)), []).append(r)
+        for (m, n), members in groups.items():
+            counts = [len(requests[r][2]) for r in members]
+            total = sum(counts)
+            A3 = numpy.empty((total, m, n))
+            b2 = numpy.empty((total, m))
+            flags = numpy.zeros((total, m), dtype=numpy.uint8)
+            pos = 0
+            for r, cnt in zip(members, counts):
+                A, b, eqs = requests[r]
+                A3[pos:pos + cnt] = A
+                b2[pos:pos + cnt] = numpy.asarray(b, dtype=numpy.float64).reshape(-1)
+                for j, eq in enumerate(eqs):
+                    flags[pos + j, list(eq)] = 1
+                pos += cnt
+            status, _, _, _ = _lib.lp_solve_batch(A3, b2, None, flags, device=self.device, want_x=False)
+            pos = 0
+            for r, cnt in zip(members, counts):
+                out[r] = status[pos:pos + cnt] == _lib.LP_OPTIMAL
+                pos += cnt
+        return out
+
     # ---- binary MILPs as LP batches (solver.py:248-282; the reference hands these to Gurobi) -------------------------
     MAX_BINARIES = 20
     # host bytes one device batch of fixation LPs may take (equality flags + the solution block when it is asked for)
