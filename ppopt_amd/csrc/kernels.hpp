@@ -378,11 +378,14 @@ MPC_GLOBAL void MPC_LB(64) k_verdict(DevProblem P, const int32_t *__restrict__ c
                     s.rowkind[i] = (pri && pri[i]) ? RK_PRI : (i < nlam ? lam_kind : RK_INEQ);
                 }
             };
+            // (Stage A of the engine may have to pivot a free theta_j into the basis on a PASSIVE multiplier row -- when the enforced rows do
+            // not span every parameter direction: open parameter sets with few inactive rows; lp_engine.hpp, lp_run -- so only rows that
+            // are still passive are switched on below.)
             const int r1 = lp_solve(lp, false, s.pri, [&](const int *pri) { load(pri, RK_PASSIVE); });
             if (r1 == LP_ITERLIMIT) st = ST_LP_LIMIT;
             else if (r1 == LP_OPTIMAL) {
                 wave_sync();
-                for (int i = lane; i < nlam; i += 64) s.rowkind[i] = RK_INEQ;
+                for (int i = lane; i < nlam; i += 64) if (s.rowkind[i] == RK_PASSIVE) s.rowkind[i] = RK_INEQ;
                 wave_sync();
                 lp.growth = 0.0;
                 int r2 = lp_phase1(lp);

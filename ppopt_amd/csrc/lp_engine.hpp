@@ -309,6 +309,12 @@ __device__ inline int lp_run(Lp &lp, bool has_cost) {
         const bool was_eq = r >= 0;
         if (r < 0) r = lp_best_row(lp, q, RK_PRI);
         if (r < 0) r = lp_best_row(lp, q, RK_INEQ);
+        // Two-stage LPs (k_verdict): when no ENFORCED row contains the free variable -- the enforced rows do not span every direction,
+        // e.g. a parameter set open in some direction with few inactive rows -- it enters the basis on a PASSIVE row instead of being
+        // dropped (= fixed at zero for the second stage, which made five non-empty regions of generate_mpqp(6,5,9,215194) over a slab
+        // "not optimal"; found by the round-4 fuzz on open parameter sets).  The passive row's slack becomes an ordinary nonbasic
+        // variable (>= 0): stage 1 then runs on a subset that still contains everything stage 2 can accept.
+        if (r < 0) r = lp_best_row(lp, q, RK_PASSIVE);
         if (r < 0) {
             if (has_cost && fabs(T[m * ld + q]) > TOL_COST) unbounded_if_feasible = true;
             lp_drop_col(lp, q);

@@ -15,7 +15,7 @@ PARTIAL = ['c4_rand_20_8_20_s0', 'c3_quadtank_n10']
 # maximises t, is UNBOUNDED on some non-empty regions there and its adapter then says "not optimal" (mpqp_program.py:203-322,
 # cvxopt_interface.py:19-23) -- L{i}_unbounded_t flags the candidates where that branch fired
 OPEN = ['open_hand_2_2', 'open_rand_4_2_10_s0_lower', 'open_rand_4_2_10_s0_slab', 'open_rand_4_2_10_s0_lower_boxed',
-        'open_rand_5_3_10_s4_lower', 'open_rand_5_3_10_s4_slab', 'open_rand_5_3_10_s4_lower_boxed']
+        'open_rand_5_3_10_s4_lower', 'open_rand_5_3_10_s4_slab', 'open_rand_5_3_10_s4_lower_boxed', 'open_rand_6_5_9_s215194_slab']
 # facets whose redundancy LP sits on the 1e-7 tolerance in the reference run (min slack 3e-8 .. 1e-7, sliver
 # regions of rand_6_3_12_s1): the decision differs between LP solvers, documented in DESIGN.md
 KNIFE_EDGE_REGIONS = {('rand_6_3_12_s1', (0, 1, 3, 4, 5, 6))}

@@ -1,6 +1,6 @@
 """Counts verdict / region differences between the GPU path and the CPU oracle over many small programs (GPU box).
 
-    python tools/fuzz_scan.py <n_programs> [mpqp|mplp|mpc] [rng seed]
+    python tools/fuzz_scan.py <n_programs> [mpqp|mpqp_eq|mplp|mpc|big|open] [rng seed]
 """
 import sys, warnings
 sys.path.insert(0, '.'); sys.path.insert(0, 'tests')
@@ -34,6 +34,17 @@ for it in range(n_prob):
         seed = int(rng.integers(0, 10 ** 6))
         d = pg.generate_mpqp_data(nx, nt, m, seed)
         tag = (nx, nt, m, seed)
+        if kind == 'open':      # parameter sets open in some direction (round 4, k_recession): the big-M box of x dropped (half of the
+            # programs), of the rows of A_t only the lower bounds / one lower and one upper bound / a random subset kept
+            if rng.random() < 0.5:
+                keep = numpy.abs(d['b']).ravel() < 1e6
+                d['A'], d['b'], d['F'] = d['A'][keep], d['b'][keep], d['F'][keep]
+            lo = [i for i in range(d['A_t'].shape[0]) if d['A_t'][i].min() < 0]
+            hi = [i for i in range(d['A_t'].shape[0]) if d['A_t'][i].max() > 0]
+            mode = int(rng.integers(0, 3))
+            rows = lo if mode == 0 else (lo[:1] + hi[:1] if mode == 1 else sorted(rng.choice(d['A_t'].shape[0], size=max(1, d['A_t'].shape[0] // 2), replace=False).tolist()))
+            d['A_t'], d['b_t'] = d['A_t'][rows], d['b_t'][rows]
+            tag = tag + ('open', mode)
         if kind == 'mpqp_eq':   # the first one or two rows become equalities
             d['equality_indices'] = list(range(int(rng.integers(1, 3))))
             tag = tag + (len(d['equality_indices']),)
