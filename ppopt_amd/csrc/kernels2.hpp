@@ -50,6 +50,10 @@ struct ThetaArgs {
     // their ne diagonal entries.  Programs without equality rows: Wr == W, UVrp == UVp, AATr == the Gram matrix, ne == 0.
     const double *Wr, *UVrp, *AATr, *Me, *Ne, *gE;
     int ne;
+    // k_theta2: at most wave_max wavefronts take work, and no more than one per wave_div work items (0: no limit).  The kernel is a
+    // tail of few long LPs: measured on config 4 (round 4, MPC_TH_CAP) an item takes 29 us with one wavefront per SIMD, 48 us with two
+    // and 130 us with four -- the launch was fastest with HALF (level 5: 15 k items) or a QUARTER (level 4: 5 k items) of its wave slots.
+    int wave_div, wave_max;
 };
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -296,8 +300,11 @@ MPC_GLOBAL void MPC_LB(64, (NT * SLOTS >= 20 ? 3 : (SLOTS >= 2 ? TH_WAVES_S2 : 4
         n = *ta.n_dev;
         // chunk <= 0: the host does not know n either; the rule it would have applied (candidates per queue atomic so that every
         // block of the persistent grid gets about eight turns, at most 16) is applied here
-        if (ta.chunk <= 0) ta.chunk = (int)max(1ll, min(16ll, n / ((long long)gridDim.x * 8)));
-        if ((long long)blockIdx.x * ta.chunk >= n) return;
+        long long active = gridDim.x;
+        if (ta.wave_max > 0) active = min(active, (long long)ta.wave_max);
+        if (ta.wave_div > 0) active = min(active, max(256ll, n / ta.wave_div));
+        if (ta.chunk <= 0) ta.chunk = (int)max(1ll, min(16ll, n / (active * 8)));
+        if ((long long)blockIdx.x >= active || (long long)blockIdx.x * ta.chunk >= n) return;
     }
     extern __shared__ __attribute__((aligned(16))) double smem[];
     Smem s = carve(P, smem);

@@ -280,6 +280,8 @@ struct mpc_handle {
     bool theta_open = false;         // the parameter set is open in some direction (or the program has equality rows only): the reference's
                                      // optimality LP can be unbounded -> k_recession behind every verdict stage, no overlapped region launch,
                                      // no level without host round trips, no shared launches (MPC_NO_RECESSION=1: round-3 behaviour, A/B)
+    int x2_wpc = 12, x2_div = 16, xq_wpc = 20;    // MPC_X2_WPC (most) / MPC_X2_DIV (items per wavefront) / MPC_XQ_WPC: wavefronts per CU of the persistent
+                                     // k_x2 / k_xq launches (round 3: 16 and 32 whatever the size of the level)
     bool r3_fork_event = false;      // MPC_R3_FORK=1: the region stream starts behind an event of the main stream (round-3 form; A/B)
     int r2_cap_pct = 100;            // MPC_R2_CAP: share (per cent) of k_region2's wave slots an overlapped one-wave-per-candidate launch may take
     bool no_fetch_kernel = false;    // MPC_NO_FETCH_KERNEL=1: the solve loop fetches the records of a level that did not stream with copy commands and waits (A/B)
@@ -587,6 +589,9 @@ static int create_fill(const mpc_problem *p, int32_t device, void *stream, mpc_h
     { const char *ev = std::getenv("MPC_NO_LEAN"); h->no_lean = ev && ev[0] == '1'; }
     { const char *ev = std::getenv("MPC_NO_SPEC_TAIL"); h->no_spec_tail = ev && ev[0] == '1'; }
     { const char *ev = std::getenv("MPC_NO_FETCH_KERNEL"); h->no_fetch_kernel = ev && ev[0] == '1'; }
+    { const char *ev = std::getenv("MPC_X2_WPC"); if (ev && std::atoi(ev) > 0) h->x2_wpc = std::atoi(ev); }
+    { const char *ev = std::getenv("MPC_XQ_WPC"); if (ev && std::atoi(ev) > 0) h->xq_wpc = std::atoi(ev); }
+    { const char *ev = std::getenv("MPC_X2_DIV"); if (ev && std::atoi(ev) > 0) h->x2_div = std::atoi(ev); }
     { const char *ev = std::getenv("MPC_R3_FORK"); h->r3_fork_event = ev && ev[0] == '1'; }
     { const char *ev = std::getenv("MPC_R2_CAP"); if (ev && std::atoi(ev) > 0) h->r2_cap_pct = std::min(100, std::atoi(ev)); }
     { const char *ev = std::getenv("MPC_TEST_SMALL_FALLBACK"); h->test_small_fallback = ev && ev[0] == '1'; }
@@ -923,6 +928,12 @@ static int create_fill(const mpc_problem *p, int32_t device, void *stream, mpc_h
                 const double *tbd = h->theta_blocks.as<double>();
                 h->targs.W = P.W; h->targs.UVp = tbd + oUVp; h->targs.tvp = tbd + otvp; h->targs.tv_rows = tbd + otvr; h->targs.chunk = 1;
                 h->targs.ne = elim_ok ? ne : 0;
+                {   // MPC_TH_DIV (work items per wavefront of k_theta2, default 4; 0 = round-3 behaviour) / MPC_TH_MAXW (waves per SIMD, default 2)
+                    const char *e1 = std::getenv("MPC_TH_DIV"), *e2 = std::getenv("MPC_TH_MAXW");
+                    h->targs.wave_div = e1 ? std::atoi(e1) : 4;
+                    h->targs.wave_max = (e2 ? std::atoi(e2) : 2) * 4 * h->n_cu;
+                    if (h->targs.wave_div <= 0) { h->targs.wave_div = 0; h->targs.wave_max = 0; }
+                }
                 h->targs.Wr = elim_ok ? d + oWr : P.W; h->targs.UVrp = elim_ok ? tbd + oUVrp : h->targs.UVp; h->targs.AATr = elim_ok ? d + oAATr : P.AAT;
                 h->targs.Me = d + oMe; h->targs.Ne = d + oNe; h->targs.gE = d + ogE;
             }
@@ -2170,7 +2181,13 @@ static int level_run_impl(mpc_handle *h, int32_t gen_children, int32_t flags, mp
                 ThetaArgs ta = h->targs;
                 ta.chunk = (int)std::max<long long>(1, std::min<long long>(16, n_theta / ((long long)h->grid_f * 8)));
                 if (theta_lean) { ta.n_dev = dcnt + 0; ta.chunk = 0; }   // length and chunk rule on the device
-                const dim3 g((unsigned)std::min<long long>(theta_lean ? n_theta : (n_theta + ta.chunk - 1) / ta.chunk, h->grid_f)), b(64);
+                // wave slots the theta kernel takes (ThetaArgs::wave_div / wave_max): with the length on the device the kernel applies the
+                // rule itself, here the host does
+                long long grid_th = h->grid_f;
+                if (ta.wave_max > 0) grid_th = std::min<long long>(grid_th, ta.wave_max);
+                if (!theta_lean && ta.wave_div > 0) grid_th = std::min<long long>(grid_th, std::max<long long>(256, n_theta / ta.wave_div));
+                if (!theta_lean) ta.chunk = (int)std::max<long long>(1, std::min<long long>(16, n_theta / (grid_th * 8)));
+                const dim3 g((unsigned)std::min<long long>(theta_lean ? n_theta : (n_theta + ta.chunk - 1) / ta.chunk, grid_th)), b(64);
                 HIP_TRY(h, hipEventRecord(h->kev[0], st));
                 switch (h->fast_t) {
                     case 0: hipLaunchKernelGGL((k_theta2<4, 1>), g, b, h->lds_f, st, pf, fr, n_theta, k, stp, ctr, kkc, kkl, ta, theta_list); break;
@@ -2262,7 +2279,11 @@ static int level_run_impl(mpc_handle *h, int32_t gen_children, int32_t flags, mp
                 // ctr->work_x is zero: the counters were cleared at the start of the level and this is the level's only k_x2 launch
                 { int rcs = prep_flush(); if (rcs) return rcs; }
                 DictCache d = d0;
-                const long long grid_x = (long long)h->n_cu * 16, n_all = (long long)n_items + d.n_pre1 + d.n_pre2;
+                // wavefronts per CU of the persistent launch: fewer for fewer items (an item is faster the fewer wavefronts share its SIMD; round 4,
+                // config 4: level 3, 15.7 k items, 0.445 ms with 16 per CU, 0.33 with 4; level 4, 138 k items, 1.134 / 1.083 / 1.161 ms with 16 / 12 / 8)
+                const long long n_all = (long long)n_items + d.n_pre1 + d.n_pre2;
+                const long long wpc = std::max<long long>(std::min<long long>(4, h->x2_wpc), std::min<long long>(h->x2_wpc, n_all / ((long long)h->x2_div * h->n_cu)));
+                const long long grid_x = (long long)h->n_cu * wpc;
                 d.chunk = (int)std::max<long long>(1, std::min<long long>(16, n_all / (grid_x * 8)));
                 if (xq_lean) { d.n_list_dev = dcnt + 8; d.chunk = 0; }   // length of `ls` and chunk rule on the device
                 const dim3 gg((unsigned)std::min<long long>(xq_lean ? n_all : (n_all + d.chunk - 1) / d.chunk, grid_x)), bb(64);
@@ -2294,7 +2315,7 @@ static int level_run_impl(mpc_handle *h, int32_t gen_children, int32_t flags, mp
             if (quick_test) {
                 // last level: decisions only -- the quick test on three vectors of the parent's dictionary first
                 DictCache dq = dc;
-                const long long grid_q = (long long)h->n_cu * 32;
+                const long long grid_q = (long long)h->n_cu * h->xq_wpc;
                 dq.chunk = (int)std::max<long long>(1, std::min<long long>(16, n_needx / (grid_q * 4)));
                 const dim3 gg((unsigned)std::min<long long>((n_needx + dq.chunk - 1) / dq.chunk, grid_q)), bb(64);
                 HIP_TRY(h, hipEventRecord(h->kev[8], st));
