@@ -10,6 +10,8 @@
 #include "batch_level.hpp"
 
 #include <algorithm>
+#include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <tuple>
@@ -55,6 +57,7 @@ __global__ void __launch_bounds__(64, (NT * SLOTS >= 20 ? 3 : (SLOTS >= 2 ? TH_W
     MEMBER;
     ThetaArgs ta = m.targs;
     ta.chunk = 1;
+    if (m.th_blocks > 0) { ta.wave_max = m.th_blocks; ta.wave_div = 0; }
     const uint8_t *kkc = nullptr;
     const double *kkl = nullptr;
     const int32_t *list = nullptr;
@@ -83,8 +86,14 @@ __global__ void __launch_bounds__(64, (SLOTS >= 2 ? 2 : R2W)) m_region2(const Ba
     MEMBER;
     const uint8_t *kkc = m.use_kkt ? m.kkt_code : nullptr;
     const double *kkl = m.use_kkt ? m.kkt_L : nullptr;
+    RegionStream rs = m.rs;
+    // the member's share also bounds the wavefronts that may SHARE one candidate (W: each of them repeats the Chebyshev LP, which pays
+    // on an idle device only).  A different W walks the facets in a different order: the records are bit for bit the single program's
+    // where W agrees (MPC_NO_RSPLIT=1 on both sides: always), else except for facets on the LP tolerance (tests/test_gpu_batch.py)
+    rs.max_blocks = m.r2_blocks;
+    if (m.r2_wcap > 0) rs.w_cap = m.r2_wcap;
     k_region2<NT, SLOTS>(m.pr, m.fr, m.k, part_list_of(m, 2), (int)m.n, m.status, m.headd, m.headi, m.fd, m.fi, m.epool, m.ctr, kkc, kkl, m.W,
-                         m.kept_g, m.ldk, m.done_g, m.no_rbox ? (const double *)nullptr : m.targs.tvp + (size_t)NT * NT + NT, m.rs);
+                         m.kept_g, m.ldk, m.done_g, m.no_rbox ? (const double *)nullptr : m.targs.tvp + (size_t)NT * NT + NT, rs);
 }
 
 // the candidates k_region2 gave up on (status RRETRY, compacted into retry_list, length at dcnt[28]): the LDS-engine kernel in its
@@ -103,6 +112,7 @@ __global__ void __launch_bounds__(64, XQ_WAVES) m_xq(const BatchMember *__restri
     MEMBER;
     DictCache dq = m.dc;
     dq.n_list_dev = m.dcnt + 7;
+    dq.max_blocks = m.xq_blocks;
     k_xq<SLOTS>(m.pf, m.fr, m.k, part_list_of(m, 3), (int)m.n, m.status, m.ctr, dq, m.nxc);
 }
 template <int NXC, int SLOTS>
@@ -110,6 +120,7 @@ __global__ void __launch_bounds__(64, (NXC * SLOTS >= 32 ? X2_WAVES : X2_WAVES_1
     MEMBER;
     DictCache d = m.dc;
     d.n_list_dev = m.dcnt + (m.quick_test ? 8 : 7);
+    d.max_blocks = m.x2_blocks;
     k_x2<NXC, SLOTS>(m.pf, m.fr, m.k, m.quick_test ? m.retry_list : part_list_of(m, 3), (int)m.n, m.status, m.ctr, d);
 }
 
@@ -150,6 +161,8 @@ unsigned long long spec_of(std::initializer_list<std::pair<int, int>> classes) {
 
 auto group_key(const BatchMember &m) { return std::make_tuple(m.k, m.kd, m.fast_t, m.fast_x, m.fast_r, m.mw, m.use_kkt, m.quick_test, m.gen_children); }
 
+int env_int(const char *name, int dflt) { const char *v = std::getenv(name); return v && *v ? std::atoi(v) : dflt; }
+
 template <class F>
 hipError_t raise_lds(F *fn, int bytes) {
     if (bytes <= 48 * 1024) return hipSuccess;
@@ -164,6 +177,26 @@ hipError_t batch_level_launch(BatchMember *members, int B, hipStream_t st, Batch
     if (B <= 0) return hipSuccess;
     if (!g_tab_host || !g_tab_dev) return hipErrorInvalidValue;
     std::stable_sort(members, members + B, [](const BatchMember &a, const BatchMember &b) { return group_key(a) < group_key(b); });
+    // Wavefront shares.  The persistent kernels of a stage run fastest with few wavefronts per SIMD (mpcombi_hip.hip: k_theta2 two, k_x2
+    // three, k_xq five, k_region2 two) -- for the whole launch, not per member: each member gets its share of that budget in proportion
+    // to its candidates, so that all members of a group run side by side and finish together.  (Round 3 gave every member the width
+    // of a single program's launch: 64 members x 4,096 blocks, the members one after the other, each with its own tail.)
+    static const int wpc_th = env_int("MPC_BATCH_WPC_TH", 8), wpc_xq = env_int("MPC_BATCH_WPC_XQ", 20), wpc_x2 = env_int("MPC_BATCH_WPC_X2", 12),
+                     wpc_r2 = env_int("MPC_BATCH_WPC_R2", 8), use_shares = env_int("MPC_BATCH_SHARES", 1), w_share = env_int("MPC_BATCH_WSHARE", 1);
+    for (int g0 = 0; g0 < B && use_shares;) {
+        int g1 = g0 + 1;
+        while (g1 < B && group_key(members[g1]) == group_key(members[g0])) ++g1;
+        double n_sum = 0.0;
+        for (int i = g0; i < g1; ++i) n_sum += (double)members[i].n;
+        for (int i = g0; i < g1; ++i) {
+            BatchMember &m = members[i];
+            const double f = n_sum > 0.0 ? (double)m.n / n_sum : 1.0;
+            auto share = [&](int wpc) { return (int)std::max(4.0, std::ceil(f * wpc * m.n_cu)); };
+            m.r2_wcap = w_share ? share(wpc_r2) : 0;
+            m.th_blocks = share(wpc_th); m.xq_blocks = share(wpc_xq); m.x2_blocks = share(wpc_x2); m.r2_blocks = share(wpc_r2);
+        }
+        g0 = g1;
+    }
     std::memcpy(g_tab_host, members, (size_t)B * sizeof(BatchMember));
     TRY(hipMemcpyAsync(g_tab_dev, g_tab_host, (size_t)B * sizeof(BatchMember), hipMemcpyHostToDevice, st));
     hipLaunchKernelGGL(m_zero, dim3(64, (unsigned)B), dim3(256), 0, st, g_tab_dev);
@@ -177,7 +210,10 @@ hipError_t batch_level_launch(BatchMember *members, int B, hipStream_t st, Batch
         const unsigned G = (unsigned)(g1 - g0);
         long long n_max = 0;
         int grid_f = 1, grid_r2 = 1, lds_f = 0, lds_v = 0, lds_r2 = 0, rsplit = 1;
+        int th_max = 0, xq_max = 0, x2_max = 0, r2_max = 0;     // largest share of the group (0: no shares, the single program's widths)
         for (int i = g0; i < g1; ++i) {
+            th_max = std::max(th_max, members[i].th_blocks); xq_max = std::max(xq_max, members[i].xq_blocks);
+            x2_max = std::max(x2_max, members[i].x2_blocks); r2_max = std::max(r2_max, members[i].r2_blocks);
             n_max = std::max(n_max, members[i].n);
             grid_f = std::max(grid_f, members[i].grid_f); grid_r2 = std::max(grid_r2, members[i].grid_r2);
             lds_f = std::max(lds_f, members[i].lds_f); lds_v = std::max(lds_v, members[i].lds_v); lds_r2 = std::max(lds_r2, members[i].lds_r2);
@@ -195,7 +231,7 @@ hipError_t batch_level_launch(BatchMember *members, int B, hipStream_t st, Batch
             hipLaunchKernelGGL(m_compact_small, dim3(1, G), dim3(1024), 0, st, tab, ST_TODO, ST_TODO, 0, 0);
         }
         {
-            const dim3 g((unsigned)std::min<long long>(n_max, grid_f), G), b(64);
+            const dim3 g((unsigned)std::min<long long>(n_max, th_max > 0 ? th_max : grid_f), G), b(64);
 #define MPC_LAUNCH_TH(NT_, SL_) do { TRY(raise_lds(m_theta2<NT_, SL_>, lds_f)); hipLaunchKernelGGL((m_theta2<NT_, SL_>), g, b, lds_f, st, tab); } while (0)
             switch (r.fast_t) {
                 case 0: MPC_LAUNCH_TH(4, 1); break;
@@ -216,13 +252,13 @@ hipError_t batch_level_launch(BatchMember *members, int B, hipStream_t st, Batch
         hipLaunchKernelGGL(m_zero_counter, dim3(1, G), dim3(64), 0, st, tab, 0);
         // (x,theta) stage
         if (r.quick_test) {
-            const dim3 gg((unsigned)std::min<long long>(n_max, (long long)r.n_cu * 32), G), bb(64);
+            const dim3 gg((unsigned)std::min<long long>(n_max, xq_max > 0 ? xq_max : (long long)r.n_cu * 32), G), bb(64);
             if (r.fast_x & 1) hipLaunchKernelGGL((m_xq<2>), gg, bb, 0, st, tab);
             else hipLaunchKernelGGL((m_xq<1>), gg, bb, 0, st, tab);
             hipLaunchKernelGGL(m_compact_small, dim3(1, G), dim3(1024), 0, st, tab, ST_NEEDX, ST_NEEDX_SING, 1, 8);
         }
         {
-            const dim3 gg((unsigned)std::min<long long>(n_max, (long long)r.n_cu * 16), G), bb(64);
+            const dim3 gg((unsigned)std::min<long long>(n_max, x2_max > 0 ? x2_max : (long long)r.n_cu * 16), G), bb(64);
             switch (r.fast_x) {
                 case 0: hipLaunchKernelGGL((m_x2<16, 1>), gg, bb, 0, st, tab); break;
                 case 1: hipLaunchKernelGGL((m_x2<16, 2>), gg, bb, 0, st, tab); break;
@@ -248,7 +284,7 @@ hipError_t batch_level_launch(BatchMember *members, int B, hipStream_t st, Batch
         hipLaunchKernelGGL(m_partition_small, dim3(1, G), dim3(1024), 0, st, tab, spec_of({{ST_OPT_PENDING, 2}}), 16);
         TRY(hipGetLastError());
         {
-            const dim3 g((unsigned)std::min<long long>(n_max * std::max(rsplit, 1), grid_r2), G), b(64);
+            const dim3 g((unsigned)std::min<long long>(n_max * std::max(rsplit, 1), r2_max > 0 ? r2_max : grid_r2), G), b(64);
 #define MPC_LAUNCH_R2(NT_, SL_) do { TRY(raise_lds(m_region2<NT_, SL_>, lds_r2)); hipLaunchKernelGGL((m_region2<NT_, SL_>), g, b, lds_r2, st, tab); } while (0)
             switch (r.fast_r) {
                 case 0: MPC_LAUNCH_R2(4, 1); break;

@@ -15,6 +15,21 @@
 // form with the region stage behind the (x,theta) stage (MPC_NO_ROVERLAP=1, which builds every optimal candidate with k_region2 as
 // well) the same fuzz finds NO difference: all 1,217,481 regions bit for bit.
 //
+// Round 4: the number of wavefronts sharing a candidate in k_region2 follows the member's SHARE of the launch (below), one when the
+// device is full, where a single program's follows its own width (up to eight on an idle device).  Each of them repeats the Chebyshev
+// LP, which pays on idle CUs only: 64 sub-programs of the bench enumeration 83 -> 67 ms of device time.  A different split walks the
+// facets in another order; with the same split (MPC_NO_RSPLIT=1 on both sides) every record is bit for bit the single program's, with
+// each side's own the x-law, multipliers, statuses, children and pruned masks still are, and a facet list may differ where it sits on
+// the LP tolerance (tests/test_gpu_batch.py `_own_split`; tools/fuzz_batch.py: 582,465 regions of 300 random programs, 1 other facet
+// list, 4 regions with coefficients differing by <= 6e-12; tools/batch_w_debug2.py: 14 of 12,871 regions, in each of them the CPU
+// oracle's own list changes when its 1e-7 tolerance moves two decades).
+//
+// Wavefront shares.  The persistent kernels run fastest with FEW wavefronts per SIMD (k_theta2 two, k_x2 three, k_xq five, k_region2
+// two; mpcombi_hip.hip) -- for the launch as a whole.  batch_level_launch gives every member a share of that budget in proportion to
+// its candidates (BatchMember::*_blocks; a member's surplus blocks leave at once), so the members of a group run side by side and end
+// together.  Round 3 gave each member the width of a single program's launch -- 64 members x 4,096 blocks, one member's tail after the
+// other: the bench enumeration's shared levels took 143 ms of device time, with shares 83 ms (MPC_BATCH_SHARES=0 A/B), 67 with the split above.
+//
 // The level is the no-round-trip form of mpcombi_hip.hip (level_run_small): list lengths live in device memory, launches are sized
 // by the members' candidate counts, the host synchronises once per level for ALL members.  Members whose kernels are different
 // template instantiations (n_theta class, rows per lane, mask words, cardinality) form separate groups of the same launch sequence.
@@ -35,6 +50,8 @@ struct BatchMember {
     long long n;             // candidates of the level
     int grid_f, grid_r2, n_cu, lds_f, lds_v, lds_r2, rsplit_max;
     int W, ldk, fd, fi, no_rbox, nxc, storing, keep_lowdim;
+    // the member's share of the group's launches (batch_level_launch: wavefronts in proportion to the candidates; 0 = no bound)
+    int th_blocks, xq_blocks, x2_blocks, r2_blocks, r2_wcap;
     int theta_open;          // the member's parameter set is open in some direction: k_recession behind the verdict stages (mpcombi_hip.hip)
     int lds_r, rcap;         // LDS-engine region kernel (candidates k_region2 gives up on): dynamic LDS, record slots reserved
     long long rec_d, rec_i;  // strides of its fixed-layout records

@@ -568,6 +568,7 @@ struct DictCache {
     int chunk;       // work items per queue atomic (<= 64)
     // != nullptr: the three list lengths are read from device memory (the level runs without host round trips)
     const int32_t *n_list_dev, *n_pre1_dev, *n_pre2_dev;
+    int max_blocks;  // > 0 (with device-resident lengths): only that many blocks of the launch work, the others leave (a member's share of a shared launch)
 };
 // k_xq: the last level's quick (x,theta) test.  No dictionary is stored on the last level, so a candidate only needs a
 // DECISION: up to XQ_ITERS simplex iterations from the parent's dictionary in product form (revised simplex with an eta
@@ -742,8 +743,9 @@ MPC_GLOBAL void MPC_LB(64, XQ_WAVES) k_xq(const DevProblem *__restrict__ Pg, con
     const int lane = lane_id(), nv = P.n_x + P.n_t, mr = P.n_d0r;
     if (dc.n_list_dev) {
         n_list = *dc.n_list_dev;
-        if (dc.chunk <= 0) dc.chunk = (int)max(1ll, min(16ll, (long long)n_list / ((long long)gridDim.x * 4)));
-        if ((long long)blockIdx.x * dc.chunk >= n_list) return;
+        const long long active = dc.max_blocks > 0 ? min((long long)gridDim.x, (long long)dc.max_blocks) : (long long)gridDim.x;
+        if (dc.chunk <= 0) dc.chunk = (int)max(1ll, min(16ll, (long long)n_list / (active * 4)));
+        if ((long long)blockIdx.x >= active || (long long)blockIdx.x * dc.chunk >= n_list) return;
     }
     unsigned long long pivots = 0, n_quick = 0;
     for (;;) {
@@ -872,8 +874,9 @@ MPC_GLOBAL void MPC_LB(64, (NXC * SLOTS >= 32 ? X2_WAVES : X2_WAVES_16)) k_x2(co
     if (dc.n_pre2_dev) dc.n_pre2 = *dc.n_pre2_dev;
     const int n_pre = dc.n_pre1 + dc.n_pre2, n_items = n_pre + n_list;
     if (dc.n_list_dev) {
-        if (dc.chunk <= 0) dc.chunk = (int)max(1ll, min(16ll, (long long)n_items / ((long long)gridDim.x * 8)));
-        if ((long long)blockIdx.x * dc.chunk >= n_items) return;
+        const long long active = dc.max_blocks > 0 ? min((long long)gridDim.x, (long long)dc.max_blocks) : (long long)gridDim.x;
+        if (dc.chunk <= 0) dc.chunk = (int)max(1ll, min(16ll, (long long)n_items / (active * 8)));
+        if ((long long)blockIdx.x >= active || (long long)blockIdx.x * dc.chunk >= n_items) return;
     }
     unsigned long long pivots = 0, n_retry = 0, n_cached = 0;
     long long cyc_x = 0;
@@ -1042,6 +1045,7 @@ struct RegionStream {
     // kernel by the host's rule (the largest power of two <= w_max with n_opt * W <= w_cap)
     const int32_t *n_opt_dev;
     int w_cap, w_max;
+    int max_blocks;        // > 0 (with n_opt_dev): only that many blocks of the launch work (a member's share of a shared launch)
 };
 
 template <int NT, int SLOTS>
@@ -1066,7 +1070,7 @@ MPC_GLOBAL void MPC_LB(64, (SLOTS >= 2 ? 2 : R2W)) k_region2(
     if (rs.n_opt_dev) {
         n_opt = *rs.n_opt_dev;
         if (W == 0) { W = rs.w_max > 0 ? rs.w_max : 1; while (W > 1 && (long long)n_opt * W > rs.w_cap) W >>= 1; }
-        if ((long long)blockIdx.x >= (long long)n_opt * W) return;   // surplus block of a launch sized by a bound
+        if ((long long)blockIdx.x >= (long long)n_opt * W || (rs.max_blocks > 0 && (int)blockIdx.x >= rs.max_blocks)) return;   // surplus block of a launch sized by a bound
     }
     if (lane == 0) atomicMax(&ctr->r2_not_t0, ~(unsigned long long)wall_clock64());
     for (;;) {

@@ -581,7 +581,7 @@ static int create_fill(const mpc_problem *p, int32_t device, void *stream, mpc_h
     { const char *ev = std::getenv("MPC_NO_XQGROUP"); h->no_xqgroup = ev && ev[0] == '1'; }
     { const char *ev = std::getenv("MPC_FORCE_XQGROUP"); h->force_xqgroup = ev && ev[0] == '1'; }
     { const char *ev = std::getenv("MPC_NO_XQUICK"); h->no_xquick = ev && ev[0] == '1'; }
-    { const char *ev = std::getenv("MPC_NO_KKT_THREAD"); h->no_kkt_thread = ev && ev[0] == '1'; }
+    { const char *ev = std::getenv("MPC_NO_KKT_THREAD"); h->no_kkt_thread = ev ? std::atoi(ev) : 0; }   // 2: only the small-level path
     { const char *ev = std::getenv("MPC_NO_ROVERLAP"); h->no_roverlap = ev && ev[0] == '1'; }
     { const char *ev = std::getenv("MPC_TEST_LATE"); h->test_late = ev ? std::atoi(ev) : 0; }
     { const char *ev = std::getenv("MPC_TEST_SPARE"); h->test_spare = ev ? std::atoi(ev) : 0; }
@@ -1409,7 +1409,8 @@ static int level_run_small(mpc_handle *h, int32_t gen_children, int32_t flags, m
     // ---- region stage: one slot per optimal candidate, buffers sized by the bound.  It needs the theta stage's verdicts only; a
     // candidate that turns out optimal only later -- a doubtful one of the (x,theta) stage, re-solved -- sends the level to the classic
     // path.  (Measured: on its own stream beside the (x,theta) stage it gains nothing at this size -- the fork / join events cost what
-    // the overlap of two 50-100 us kernels saves: config 2 1.76 ms against 1.68 in line.) -----------------------------------------------
+    // the overlap of two 50-100 us kernels saves: config 2 1.76 ms against 1.68 in line; round 4, config 4, whose regions take 150 us:
+    // 5.47 / 5.61 ms forked against 5.48 / 5.54 in line -- the region kernel itself is 0.185 instead of 0.158 ms beside k_x2.) -----------------------------------------------
     h->opt_ptr = part_list(2);
     {
         const int rows_t_ = h->n_c - h->n_eq + h->n_tc;
@@ -1611,7 +1612,7 @@ static int batch_prepare(mpc_handle *h, int32_t gen_children, int32_t flags, Bat
     m.targs = h->targs;
     m.zero[m.n_zero++] = {h->ctr.p, sizeof(LevelCounters)};
     m.zero[m.n_zero++] = {h->dcnt.p, 32 * sizeof(int32_t)};
-    m.use_kkt = (h->kkt_mode == 0 && m.kd >= 1 && m.kd <= 8 && !h->no_kkt_thread) ? 1 : 0;
+    m.use_kkt = (h->kkt_mode == 0 && m.kd >= 1 && m.kd <= 8 && h->no_kkt_thread != 1) ? 1 : 0;
     if (m.use_kkt) {
         HIP_TRY(h, h->kkt_code.ensure(nn, st));
         HIP_TRY(h, h->kkt_L.ensure(nn * (size_t)k * (h->n_t + 1) * sizeof(double), st));
@@ -2154,7 +2155,7 @@ static int level_run_impl(mpc_handle *h, int32_t gen_children, int32_t flags, mp
             long long n_theta = n;
             const int32_t *theta_list = nullptr;
             const int kd = k - h->targs.ne;   // rows the one-thread KKT kernel solves for (the equality rows are eliminated)
-            if (h->kkt_mode == 0 && kd >= 1 && kd <= 8 && !h->no_kkt_thread) {
+            if (h->kkt_mode == 0 && kd >= 1 && kd <= 8 && h->no_kkt_thread != 1) {
                 HIP_TRY(h, h->kkt_code.ensure(nn, st));
                 HIP_TRY(h, h->kkt_L.ensure(nn * (size_t)k * (h->n_t + 1) * sizeof(double), st));
                 kkc = h->kkt_code.as<uint8_t>(); kkl = h->kkt_L.as<double>();

@@ -1,13 +1,22 @@
 """Several programs per launch (mpc_level_run_batch): a member's level must be what mpc_level_run computes for
 that program alone -- candidates, statuses, region records, children and pruned masks IDENTICAL, bit for bit -- whatever else
 shares the launches; and the mixed-integer enumeration built on it must give the reference's regions (tests/test_gpu_mi.py runs
-through it by default)."""
+through it by default).
+
+One qualification (round 4).  The region kernel lets several wavefronts share a candidate when the device would otherwise idle; in a
+shared launch that number follows the member's SHARE of the launch, not the single program's width, and a different split walks the
+facets of a region in a different order.  With the same split on both sides (MPC_NO_RSPLIT=1: one wavefront per candidate) every
+record is bit for bit the single program's -- the tests below that say "bit for bit" run that way.  With each side's own split the
+x-law, the multipliers, the statuses, the children and the pruned masks are still identical bit for bit; a region's facet list may
+differ only where it sits on the LP tolerance -- the CPU oracle's own list for that region changes when its 1e-7 tolerance moves two
+decades (conftest.KNIFE_EDGE_FACETS names the one such region of the goldens) -- which the `_own_split` tests check region by region
+(tools/batch_w_debug2.py: 14 of 12,871 regions of eight random programs, all of that kind)."""
 import os
 
 import numpy
 import pytest
 
-from conftest import load_golden
+from conftest import consume_exception, load_golden
 
 pytestmark = pytest.mark.gpu
 
@@ -16,6 +25,52 @@ MIXED = ['rand_6_3_12_s1', 'c2_dblint_n5', 'quadtank_n3', 'c4_rand_20_8_20_s0', 
          # open parameter sets (k_recession behind the verdict stages, also inside the shared launches): a pointed cone and one with the
          # main rows' big-M box
          'open_rand_5_3_10_s4_lower', 'open_rand_5_3_10_s4_lower_boxed']
+
+
+@pytest.fixture(autouse=True)
+def _same_wavefront_split_on_both_sides(request, monkeypatch):
+    """One wavefront per candidate in the region kernel (MPC_NO_RSPLIT=1, read when a handle is created) for every test that
+    compares a shared launch with a single-program run bit for bit; the `own_split` tests keep each form's own choice."""
+    own = request.node.name.endswith('_own_split') or bool(getattr(getattr(request.node, 'callspec', None), 'params', {}).get('own_split'))
+    if not own:
+        monkeypatch.setenv('MPC_NO_RSPLIT', '1')
+
+
+def _facets_on_the_tolerance(prog, active_set):
+    """The facet list of this region is a matter of the LP tolerance: the CPU oracle's own list (the reference's one LP per row,
+    utils/mpqp_utils.py:143-178) changes when its 1e-7 feasibility tolerance moves two decades either way (the rule of
+    conftest.is_knife_edge, applied to the region's index sets)."""
+    from oracle import oracle as orc
+    P = orc.OracleProblem(prog.A, prog.b, prog.F, prog.c, prog.H, getattr(prog, 'Q', None), prog.A_t, prog.b_t, len(prog.equality_indices))
+    lists = set()
+    try:
+        for tol in (1e-9, 1e-7, 1e-5):
+            orc.set_feas_tol(tol)
+            v, reg = P.gen_cr_from_active_set(list(active_set))
+            lists.add(None if reg is None else (tuple(reg['omega_set']), tuple(reg['lambda_set']), tuple(map(tuple, reg['regular_set']))))
+    finally:
+        orc.set_feas_tol(1e-7)
+    return len(lists) > 1
+
+
+def _same_regions_up_to_knife_edge_facets(one, many, prog_of, tag):
+    """Regions of two Solutions: same active sets; A, b, C, d bit for bit; index sets and E, f bit for bit unless the region's
+    facet list sits on the LP tolerance (_facets_on_the_tolerance).  Returns (regions, regions whose facet lists differ)."""
+    def key(r):
+        fix = getattr(r, 'y_fixation', None)
+        return (() if fix is None else tuple(int(v) for v in fix), tuple(r.active_set))
+    ra, rb = sorted(one.critical_regions, key=key), sorted(many.critical_regions, key=key)
+    assert [key(r) for r in ra] == [key(r) for r in rb], tag
+    n_diff = 0
+    for r1, r2 in zip(ra, rb):
+        for fld in ('A', 'b', 'C', 'd'):
+            assert numpy.asarray(getattr(r1, fld)).tobytes() == numpy.asarray(getattr(r2, fld)).tobytes(), (tag, fld, key(r1))
+        same = r1.omega_set == r2.omega_set and r1.lambda_set == r2.lambda_set and r1.regular_set == r2.regular_set and all(
+            numpy.asarray(getattr(r1, fld)).tobytes() == numpy.asarray(getattr(r2, fld)).tobytes() for fld in ('E', 'f'))
+        if not same:
+            n_diff += 1
+            assert _facets_on_the_tolerance(prog_of(r1), r1.active_set), (tag, key(r1))
+    return len(ra), n_diff
 
 
 def _levels_alone(g, n_levels, keep_lowdim=False):
@@ -51,23 +106,31 @@ def _snapshot(eng, st, gen):
                 counts=[int(v) for v in st.n_status], n_children=int(st.n_children))
 
 
-def _same(a, b, tag):
+def _same(a, b, tag, facet_exceptions=None):
+    """facet_exceptions = golden name: a region whose facet list differs is accepted if conftest.KNIFE_EDGE_FACETS lists it for
+    that golden (x-law and multipliers still bit for bit); None: no exception at all."""
     assert numpy.array_equal(a['cands'], b['cands']), tag
     assert numpy.array_equal(a['status'], b['status']), tag
     assert a['counts'] == b['counts'] and a['n_children'] == b['n_children'], tag
     assert a['regs'].keys() == b['regs'].keys(), tag
     for c in a['regs']:
+        if a['regs'][c] != b['regs'][c] and facet_exceptions is not None:
+            assert a['regs'][c][1] == b['regs'][c][1], (tag, c)      # coefficient head: x-law and multipliers
+            active = a['cands'][c].tolist()
+            assert consume_exception('facets', facet_exceptions, active, 'shared launch against single program, different wavefront split'), (tag, c, active)
+            continue
         assert a['regs'][c] == b['regs'][c], (tag, c)      # integer head, coefficient head, region rows: bit for bit
     assert sorted(map(tuple, a['pruned'].tolist())) == sorted(map(tuple, b['pruned'].tolist())), tag     # appended through an atomic counter: a set
     if a['children'] is not None:
         assert numpy.array_equal(a['children'], b['children']), tag
 
 
-@pytest.mark.parametrize('keep_lowdim', [False, True])
-def test_batch_levels_equal_the_single_program_levels(keep_lowdim):
+@pytest.mark.parametrize('keep_lowdim,own_split', [(False, False), (True, False), (False, True)])
+def test_batch_levels_equal_the_single_program_levels(keep_lowdim, own_split):
     """Ten programs of different shapes (mpQPs with and without equality rows, 4/8-parameter instantiations, one and two tableau
     rows per lane, different depths) advance through shared launches; every member's every level equals its own single-program run.
-    Members leave the batch as their frontiers run out."""
+    Members leave the batch as their frontiers run out.  own_split: the region kernel's wavefronts per candidate as each form
+    chooses them (the default) instead of one on both sides -- facet lists may then differ on the listed knife-edge regions only."""
     from ppopt_amd import _lib
     from test_gpu_parity import engine_from_golden
     goldens = [load_golden(n) for n in MIXED]
@@ -85,7 +148,7 @@ def test_batch_levels_equal_the_single_program_levels(keep_lowdim):
         shared_total += n_shared
         nxt = []
         for i, st, gen in zip(active, stats, gens):
-            _same(_snapshot(engs[i], st, gen), alone[i][depth], (MIXED[i], depth))
+            _same(_snapshot(engs[i], st, gen), alone[i][depth], (MIXED[i], depth), MIXED[i] if own_split else None)
             if gen and st.n_children:
                 engs[i].frontier_advance()
                 nxt.append(i)
@@ -299,3 +362,53 @@ def test_parked_member_with_large_records_loses_no_region(monkeypatch):
             ka = sorted((tuple(r.active_set), numpy.asarray(r.A).tobytes(), numpy.asarray(r.E).tobytes()) for r in a.critical_regions)
             kb = sorted((tuple(r.active_set), numpy.asarray(r.A).tobytes(), numpy.asarray(r.E).tobytes()) for r in b.critical_regions)
             assert ka == kb, n
+
+
+def test_solve_many_equals_solve_up_to_knife_edge_facets_own_split():
+    """The default: the region kernel's wavefronts per candidate follow the member's share of the shared launch (one, when the device
+    is full) and the single program's own width (up to eight).  Same regions; x-law and multipliers bit for bit; facet lists bit for
+    bit except on regions whose list sits on the LP tolerance, which are few."""
+    import warnings
+    from ppopt_amd import MPQP_Program, problem_generator as pg
+    from ppopt_amd.mp_solvers import mpqp_hip_combinatorial
+
+    def programs():
+        out = _programs()[:5]
+        with warnings.catch_warnings():
+            warnings.simplefilter('ignore')
+            for seed in (21, 22, 23, 24, 25, 26, 27, 28):
+                d = pg.generate_mpqp_data(8, 4, 16, seed)
+                out.append(MPQP_Program(d['A'], d['b'], d['c'], d['H'], d['Q'], d['A_t'], d['b_t'], d['F']))
+        return out
+    one = [mpqp_hip_combinatorial.solve(p) for p in programs()]
+    progs = programs()
+    many = mpqp_hip_combinatorial.solve_many(progs)
+    n_regions = n_diff = 0
+    for n, (a, b, p) in enumerate(zip(one, many, progs)):
+        nr, nd = _same_regions_up_to_knife_edge_facets(a, b, lambda r: p, n)
+        n_regions += nr; n_diff += nd
+    assert n_regions > 10000 and n_diff <= n_regions // 200, (n_regions, n_diff)
+
+
+def test_enumeration_batched_equals_one_by_one_up_to_knife_edge_facets_own_split(monkeypatch):
+    """The mixed-integer enumeration, sub-programs together against MPC_NO_BATCH=1, each form with its own wavefront split."""
+    import warnings
+    from ppopt_amd import MPMIQP_Program
+    from ppopt_amd.mp_solvers.solve_mpmiqp import solve_mpmiqp
+    from ppopt_amd.problem_generator import generate_mpmiqp_data
+    d = generate_mpmiqp_data(6, 3, 12, 4, 1)
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        prog = MPMIQP_Program(d['A'], d['b'], d['c'], d['H'], d['Q'], d['A_t'], d['b_t'], d['F'], d['binary_indices'])
+        sol_b = solve_mpmiqp(prog)
+        monkeypatch.setenv('MPC_NO_BATCH', '1')
+        sol_1 = solve_mpmiqp(prog)
+        subs = {}
+
+        def sub_of(r):
+            fix = tuple(r.y_fixation)
+            if fix not in subs:
+                subs[fix] = prog.generate_substituted_problem(list(fix))
+            return subs[fix]
+        nr, nd = _same_regions_up_to_knife_edge_facets(sol_1, sol_b, sub_of, 'mi')
+    assert nr > 0 and nd <= max(1, nr // 100), (nr, nd)
