@@ -277,9 +277,14 @@ def main():
         return p['n_xq_items'] * (13 + 4 * ints + 8 * rows + 8 * cols) + p['xq_pivots'] * 8 * (rows + cols)
     add('k_xq', 'ms_xq', 'n_xq_items', xq_bytes)
     # The roofline object follows SURVEY.md 8(d): achieved = B_alg x candidates/s for the path (all kernels of a level), against
-    # the HBM peak.  The kernel with the largest total time is described under `dominant_kernel` (its own algorithmic bytes
-    # over its own HIP-event time), every heavy kernel under `kernels`.
-    dominant = max(kern, key=lambda k: kern[k]['total_ms'])
+    # the HBM peak.  `dominant_kernel` describes the kernel with the most time ON THE STEP'S CRITICAL PATH (its own algorithmic
+    # bytes over its own HIP-event time), every heavy kernel stands under `kernels`.  Critical path: k_region2 runs on the handle's
+    # side stream UNDER the (x,theta) stage on the large levels (mpc_level_stats.region_side_stream); there only what it takes beyond
+    # that stage's kernels counts.  (Rounds 1-3 named the kernel with the largest total time, k_region2, most of which is hidden.)
+    hidden = sum(min(p.get('ms_region2', 0.0), p.get('ms_x', 0.0) + p.get('ms_xq', 0.0)) for p in all_levels if p.get('region_side_stream'))
+    for name, kk in kern.items():
+        kk['on_path_ms'] = kk['total_ms'] - (hidden if name == 'k_region2' else 0.0)
+    dominant = max(kern, key=lambda k: kern[k]['on_path_ms'])
     dom = kern[dominant]
     # Counter record of the same command (tools/profile_round3.sh -> tools/pmc_round.py -> profiles/r03_pmc.json): HBM-side bytes
     # with the FETCH_SIZE / WRITE_SIZE factors calibrated on known byte counts in each kernel's own access pattern, and the SQ
@@ -353,7 +358,9 @@ def main():
                      'frac': b_alg * (candidates * steps / elapsed) / 1e9 / HBM_PEAK_GBS, 'traffic': traffic,
                      'algorithmic_bytes_per_candidate': b_alg,
                      'achieved_over_kernel_time': bytes_path / max(ms_path, 1e-9) / 1e6,
-                     'dominant_kernel': {'kernel': dominant, 'bound': 'fp64 VALU issue / dependent latency' if dominant != 'k_x2' else 'hbm',
+                     'dominant_kernel': {'kernel': dominant, 'chosen_by': 'time on the critical path of the step (k_region2 under the (x,theta) stage is not)',
+                                         'on_path_ms_per_step': {name: kk['on_path_ms'] / steps for name, kk in kern.items()},
+                                         'bound': 'hbm (dependent reads of the cached dictionaries)' if dominant in ('k_x2', 'k_xq') else 'fp64 VALU issue / dependent latency',
                                          'achieved': dom['achieved_GBs'], 'frac': dom['achieved_GBs'] / HBM_PEAK_GBS,
                                          'launches': dom['launches'], 'avg_launch_ms': dom['avg_launch_ms'],
                                          'algorithmic_bytes_per_launch': dom['algorithmic_bytes'] / max(dom['launches'], 1),
@@ -369,8 +376,8 @@ def main():
                              'traffic (that is `traffic`, from the rocprofv3 --pmc passes in profiles/, FETCH_SIZE / WRITE_SIZE with factors '
                              'calibrated on known byte counts per access pattern; null if not collected).  avg_launch_ms are HIP-event times taken inside the library on the stream the kernel '
                              'runs on.  k_region2 and k_theta2 are fp64 simplex pivots in registers (VALU issue / dependent latency, '
-                             'almost no HBM traffic); k_x2 streams one cached dictionary per candidate and is the kernel the HBM roof '
-                             'applies to.'},
+                             'almost no HBM traffic); k_x2 streams one cached dictionary per candidate and k_xq reads the vectors of the '
+                             'parent\'s dictionary its product-form iterations touch: the two kernels the HBM roof applies to.'},
     }
     # CriticalRegion objects returned by the solve are views into per-level arrays that are cut out on first access;
     # the time to touch every field of every region is reported separately (not part of `value`)

@@ -89,8 +89,9 @@ typedef struct {
     int64_t n_region_retry;    /* optimal candidates re-solved by the LDS-engine region kernel */
     int64_t n_x_cached;        /* (x,theta) solves that started from the parent's dictionary cached in HBM */
     /* HIP-event time of single launches of this level (0 when the kernel did not run): k_theta2, the main k_x2 launch
-     * (over n_x_items candidates), k_region2 (over n_opt candidates) */
-    float ms_theta, ms_x, ms_region2, pad_;
+     * (over n_x_items candidates), k_region2 (over n_opt candidates); region_side_stream = 1: that k_region2 launch ran on the
+     * handle's side stream UNDER the (x,theta) stage (its time is not on the level's critical path), 0: in line */
+    float ms_theta, ms_x, ms_region2, region_side_stream;
     int64_t n_x_items, n_opt;
     int64_t dict_read_bytes;   /* bytes of one cached dictionary record as k_x2 reads it (0: no cache on this level)   */
     int64_t dict_write_bytes;  /* bytes of one record as k_x2 stores it for the next level (0: nothing stored)         */

@@ -52,7 +52,7 @@ class LevelStats(ctypes.Structure):
                 ('n_xtheta_lp', ctypes.c_int64), ('n_xtheta_fallback', ctypes.c_int64),
                 ('wave_cycles', ctypes.c_int64 * 4), ('n_region_retry', ctypes.c_int64),
                 ('n_x_cached', ctypes.c_int64), ('ms_theta', ctypes.c_float), ('ms_x', ctypes.c_float),
-                ('ms_region2', ctypes.c_float), ('pad_', ctypes.c_float), ('n_x_items', ctypes.c_int64),
+                ('ms_region2', ctypes.c_float), ('region_side_stream', ctypes.c_float), ('n_x_items', ctypes.c_int64),
                 ('n_opt', ctypes.c_int64), ('dict_read_bytes', ctypes.c_int64), ('dict_write_bytes', ctypes.c_int64),
                 ('n_theta_items', ctypes.c_int64), ('n_region_rows', ctypes.c_int64),
                 ('ms_kkt', ctypes.c_float), ('ms_xq', ctypes.c_float), ('n_xq_items', ctypes.c_int64), ('xq_pivots', ctypes.c_int64),

@@ -282,6 +282,7 @@ struct mpc_handle {
                                      // no level without host round trips, no shared launches (MPC_NO_RECESSION=1: round-3 behaviour, A/B)
     int x2_wpc = 12, x2_div = 16, xq_wpc = 20;    // MPC_X2_WPC (most) / MPC_X2_DIV (items per wavefront) / MPC_XQ_WPC: wavefronts per CU of the persistent
                                      // k_x2 / k_xq launches (round 3: 16 and 32 whatever the size of the level)
+    bool region_side_stream = false; // this level's k_region2 launch ran on the side stream, under the (x,theta) stage (mpc_level_stats)
     bool r3_fork_event = false;      // MPC_R3_FORK=1: the region stream starts behind an event of the main stream (round-3 form; A/B)
     int r2_cap_pct = 100;            // MPC_R2_CAP: share (per cent) of k_region2's wave slots an overlapped one-wave-per-candidate launch may take
     bool no_fetch_kernel = false;    // MPC_NO_FETCH_KERNEL=1: the solve loop fetches the records of a level that did not stream with copy commands and waits (A/B)
@@ -1888,6 +1889,7 @@ static int level_run_impl(mpc_handle *h, int32_t gen_children, int32_t flags, mp
     const long long n = h->n;
     const int k = h->k;
     hipStream_t st = h->stream;
+    h->region_side_stream = false;
     h->n_opt = h->n_children = h->n_pruned_new = h->n_regions = 0;
     h->n_needx = 0;
     LevelCounters host_ctr;
@@ -2083,7 +2085,7 @@ static int level_run_impl(mpc_handle *h, int32_t gen_children, int32_t flags, mp
             }
 #undef MPC_LAUNCH_R2
             HIP_TRY(h, hipEventRecord(h->kev[5], rst));
-            if (rst != st) { h->r3_dirty = true; HIP_TRY(h, hipEventRecord(h->ev_rjoin, rst)); }
+            if (rst != st) { h->r3_dirty = true; h->region_side_stream = true; HIP_TRY(h, hipEventRecord(h->ev_rjoin, rst)); }
             kernel_timed[2] = true;
             HIP_TRY(h, hipGetLastError());
             h->used_region2 = true;
@@ -2524,6 +2526,7 @@ static int level_run_impl(mpc_handle *h, int32_t gen_children, int32_t flags, mp
         stats->n_region_retry = h->n_rretry;
         stats->n_x_cached = (int64_t)host_ctr.x_cached;
         stats->ms_theta = kms[0]; stats->ms_x = kms[1]; stats->ms_region2 = kms[2];
+        stats->region_side_stream = h->region_side_stream ? 1.0f : 0.0f;
         stats->n_x_items = n_x_items;
         stats->n_theta_items = n_theta_items;
         stats->ms_kkt = kms[3]; stats->ms_xq = kms[4];

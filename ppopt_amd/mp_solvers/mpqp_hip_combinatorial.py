@@ -203,7 +203,7 @@ def _solve(program, num_cores: int = -1, device: int = 0, profile: Optional[List
                             'children': int(st.n_children), 'pruned_new': int(st.n_pruned_new),
                             'lp_pivots': int(st.lp_pivots), 'xtheta_lps': int(st.n_xtheta_lp), 'xtheta_fallbacks': int(st.n_xtheta_fallback), 'ms_verdict': float(st.ms_verdict),
                             'ms_region': float(st.ms_region), 'ms_children': float(st.ms_children),
-                            'ms_theta': float(st.ms_theta), 'ms_x': float(st.ms_x), 'ms_region2': float(st.ms_region2),
+                            'ms_theta': float(st.ms_theta), 'ms_x': float(st.ms_x), 'ms_region2': float(st.ms_region2), 'region_side_stream': bool(st.region_side_stream),
                             'n_x_items': int(st.n_x_items), 'n_opt': int(st.n_opt), 'n_theta_items': int(st.n_theta_items),
                             'dict_read_bytes': int(st.dict_read_bytes), 'dict_write_bytes': int(st.dict_write_bytes),
                             'ms_kkt': float(st.ms_kkt), 'ms_xq': float(st.ms_xq), 'n_xq_items': int(st.n_xq_items), 'xq_pivots': int(st.xq_pivots),
