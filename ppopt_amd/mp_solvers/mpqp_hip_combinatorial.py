@@ -198,17 +198,7 @@ def _solve(program, num_cores: int = -1, device: int = 0, profile: Optional[List
                     hd, hi, er, kk, slots = eng.level_regions_slots(early_return=True)
                     solution.critical_regions.extend(RegionBatch(hd, hi, er, n_x, n_t, n_c, n_tc, kk, slots).regions())
         if profile is not None:
-            profile.append({'depth': depth + 1, 'k': int(st.k), 'candidates': int(st.n),
-                            'status': [int(v) for v in st.n_status], 'regions': int(st.n_regions),
-                            'children': int(st.n_children), 'pruned_new': int(st.n_pruned_new),
-                            'lp_pivots': int(st.lp_pivots), 'xtheta_lps': int(st.n_xtheta_lp), 'xtheta_fallbacks': int(st.n_xtheta_fallback), 'ms_verdict': float(st.ms_verdict),
-                            'ms_region': float(st.ms_region), 'ms_children': float(st.ms_children),
-                            'ms_theta': float(st.ms_theta), 'ms_x': float(st.ms_x), 'ms_region2': float(st.ms_region2), 'region_side_stream': bool(st.region_side_stream),
-                            'n_x_items': int(st.n_x_items), 'n_opt': int(st.n_opt), 'n_theta_items': int(st.n_theta_items),
-                            'dict_read_bytes': int(st.dict_read_bytes), 'dict_write_bytes': int(st.dict_write_bytes),
-                            'ms_kkt': float(st.ms_kkt), 'ms_xq': float(st.ms_xq), 'n_xq_items': int(st.n_xq_items), 'xq_pivots': int(st.xq_pivots),
-                            'xq_record': [int(st.xq_record_ints), int(st.xq_record_rows), int(st.xq_record_cols)],
-                            'ms_wall': (time.perf_counter() - t0) * 1e3})
+            profile.append(_level_profile(depth + 1, st, (time.perf_counter() - t0) * 1e3))
         if not gen_children or st.n_children == 0:
             break
         eng.frontier_advance()
@@ -238,7 +228,7 @@ def _level_profile(depth, st, ms_wall):
             'children': int(st.n_children), 'pruned_new': int(st.n_pruned_new),
             'lp_pivots': int(st.lp_pivots), 'xtheta_lps': int(st.n_xtheta_lp), 'xtheta_fallbacks': int(st.n_xtheta_fallback), 'ms_verdict': float(st.ms_verdict),
             'ms_region': float(st.ms_region), 'ms_children': float(st.ms_children),
-            'ms_theta': float(st.ms_theta), 'ms_x': float(st.ms_x), 'ms_region2': float(st.ms_region2),
+            'ms_theta': float(st.ms_theta), 'ms_x': float(st.ms_x), 'ms_region2': float(st.ms_region2), 'region_side_stream': bool(st.region_side_stream),
             'n_x_items': int(st.n_x_items), 'n_opt': int(st.n_opt), 'n_theta_items': int(st.n_theta_items),
             'dict_read_bytes': int(st.dict_read_bytes), 'dict_write_bytes': int(st.dict_write_bytes),
             'ms_kkt': float(st.ms_kkt), 'ms_xq': float(st.ms_xq), 'n_xq_items': int(st.n_xq_items), 'xq_pivots': int(st.xq_pivots),
