@@ -170,7 +170,13 @@ def main():
         local_rank = 0   # self-test: every rank on device 0
     torch.cuda.set_device(local_rank)
     import torch.distributed as dist
+    real_stdout = None
     if distributed:
+        # stdout carries the ONE JSON line and nothing else: RCCL writes a version banner to fd 1 through C stdio when the first
+        # communicator is created -- everything written to fd 1 during the run goes to stderr, the line at the end to the real stdout
+        sys.stdout.flush()
+        real_stdout = os.dup(1)
+        os.dup2(2, 1)
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29533')
         backend = os.environ.get('PPOPT_BENCH_BACKEND', 'nccl')   # 'gloo': several ranks on ONE GPU (self-test of this script)
@@ -327,7 +333,7 @@ def main():
                         if wc > 0:
                             kk['wave_cycles_share'] = {'active_inst': sq.get('SQ_ACTIVE_INST_ANY', 0.0) / wc, 'wait_inst': sq.get('SQ_WAIT_INST_ANY', 0.0) / wc,
                                                        'wait_any': sq.get('SQ_WAIT_ANY', 0.0) / wc}
-                dom_traffic = tw['kernels'].get(dominant)
+                dom_traffic = tw['kernels'].get(dominant) or (tw['kernels'].get('k_xq_grouped') if dominant == 'k_xq' else None)
         except (OSError, ValueError, KeyError, TypeError):
             traffic = dom_traffic = None
     b_alg = bytes_path / max(local_cands, 1)
@@ -591,14 +597,15 @@ def main():
         del dsol
     if distributed:
         dist.destroy_process_group()
-    # The JSON line is the LAST thing on stdout: RCCL writes its version banner through C stdio, which is block-buffered
-    # when stdout is a pipe and would otherwise be flushed at exit, after the line.
     sys.stdout.flush()
     try:
         import ctypes
-        ctypes.CDLL(None).fflush(None)
+        ctypes.CDLL(None).fflush(None)     # C stdio buffers (the RCCL banner) leave before fd 1 is restored
     except OSError:
         pass
+    if real_stdout is not None:
+        os.dup2(real_stdout, 1)
+        os.close(real_stdout)
     if rank == 0:
         print(json.dumps(out), flush=True)
 

@@ -280,6 +280,7 @@ struct mpc_handle {
     bool theta_open = false;         // the parameter set is open in some direction (or the program has equality rows only): the reference's
                                      // optimality LP can be unbounded -> k_recession behind every verdict stage, no overlapped region launch,
                                      // no level without host round trips, no shared launches (MPC_NO_RECESSION=1: round-3 behaviour, A/B)
+    int xqg_per_cu = XQG_WAVES;      // MPC_XQG_PER_CU: workgroups (of four wavefronts) per CU of the persistent k_xq_grouped launch
     int x2_wpc = 12, x2_div = 16, xq_wpc = 20;    // MPC_X2_WPC (most) / MPC_X2_DIV (items per wavefront) / MPC_XQ_WPC: wavefronts per CU of the persistent
                                      // k_x2 / k_xq launches (round 3: 16 and 32 whatever the size of the level)
     bool region_side_stream = false; // this level's k_region2 launch ran on the side stream, under the (x,theta) stage (mpc_level_stats)
@@ -592,6 +593,7 @@ static int create_fill(const mpc_problem *p, int32_t device, void *stream, mpc_h
     { const char *ev = std::getenv("MPC_NO_FETCH_KERNEL"); h->no_fetch_kernel = ev && ev[0] == '1'; }
     { const char *ev = std::getenv("MPC_X2_WPC"); if (ev && std::atoi(ev) > 0) h->x2_wpc = std::atoi(ev); }
     { const char *ev = std::getenv("MPC_XQ_WPC"); if (ev && std::atoi(ev) > 0) h->xq_wpc = std::atoi(ev); }
+    { const char *ev = std::getenv("MPC_XQG_PER_CU"); if (ev && std::atoi(ev) > 0) h->xqg_per_cu = std::atoi(ev); }
     { const char *ev = std::getenv("MPC_X2_DIV"); if (ev && std::atoi(ev) > 0) h->x2_div = std::atoi(ev); }
     { const char *ev = std::getenv("MPC_R3_FORK"); h->r3_fork_event = ev && ev[0] == '1'; }
     { const char *ev = std::getenv("MPC_R2_CAP"); if (ev && std::atoi(ev) > 0) h->r2_cap_pct = std::min(100, std::atoi(ev)); }
@@ -2332,7 +2334,7 @@ static int level_run_impl(mpc_handle *h, int32_t gen_children, int32_t flags, mp
                     hipLaunchKernelGGL(k_group_flags, dim3(nbq), dim3(256), 0, st, needx_list, n_needx, dq.parent_slot, h->flag.as<int32_t>());
                     { int rcs = launch_scan(h, h->flag.as<int32_t>(), h->pos.as<int32_t>(), n_needx, h->scratch.as<int32_t>()); if (rcs) return rcs; }
                     hipLaunchKernelGGL(k_scatter_index, dim3(nbq), dim3(256), 0, st, h->flag.as<int32_t>(), h->pos.as<int32_t>(), (long long)n_needx, h->xq_groups.as<int32_t>());
-                    const int per_cu = std::max(1, std::min(XQG_WAVES, (int)((160 * 1024) / (lds_q + 64))));
+                    const int per_cu = std::max(1, std::min(h->xqg_per_cu, (int)((160 * 1024) / (lds_q + 64))));
                     const dim3 gq((unsigned)std::min<long long>(n_needx, (long long)h->n_cu * per_cu)), bq(256);
                     if (lds_q > 48 * 1024) {
                         HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void *>(k_xq_grouped<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_q));
