@@ -1322,6 +1322,20 @@ static bool small_path_ok(const mpc_handle *h, long long n, int k, int32_t flags
     return rec_bytes <= 2e9;
 }
 
+// MPC_DEBUG_SMALL=1: at exit, how many no-round-trip levels had doubtful candidates (re-solved in place by the LDS engine) in their two verdict stages
+static std::atomic<long long> g_small_levels{0}, g_small_retry_theta{0}, g_small_retry_x{0}, g_small_retry_cands{0};
+static void small_debug_note(const int32_t *cnt_host) {
+    static const bool on = [] {
+        const char *ev = std::getenv("MPC_DEBUG_SMALL");
+        if (!(ev && ev[0] == '1')) return false;
+        std::atexit([] { std::fprintf(stderr, "[mpc] small levels %lld: with doubtful candidates after the theta stage %lld, after the (x,theta) stage %lld (candidates %lld)\n",
+                                      g_small_levels.load(), g_small_retry_theta.load(), g_small_retry_x.load(), g_small_retry_cands.load()); });
+        return true;
+    }();
+    if (!on) return;
+    g_small_levels++; g_small_retry_theta += cnt_host[12] > 0; g_small_retry_x += cnt_host[24] > 0; g_small_retry_cands += cnt_host[12] + cnt_host[24];
+}
+
 static int level_run_small(mpc_handle *h, int32_t gen_children, int32_t flags, mpc_level_stats *stats, bool *fallback) {
     *fallback = false;
     const long long n = h->n;
@@ -1539,6 +1553,7 @@ static int level_run_small(mpc_handle *h, int32_t gen_children, int32_t flags, m
     LevelCounters host_ctr;
     std::memcpy(&host_ctr, h->tot_host + 16, sizeof(LevelCounters));
     h->n_smallpath++;
+    small_debug_note(cnt_host);
     if (host_ctr.n_rretry > 0 || cnt_host[17] > 0 || h->test_small_fallback) {
         // a candidate k_region2 gave up on (the LDS-engine region kernel is not part of this path), or one that turned out optimal
         // after the region launch: the level is repeated classically
@@ -1706,6 +1721,7 @@ static int batch_finish(mpc_handle *h, int32_t gen_children, const BatchMember &
     std::memcpy(&host_ctr, h->tot_host + 16, sizeof(LevelCounters));
     const int32_t *cnt_host = h->tot_host + 16 + (int)(sizeof(LevelCounters) / 4);
     h->n_smallpath++;
+    small_debug_note(cnt_host);
     if (cnt_host[28] > m.rcap || h->test_small_fallback) {
         // more candidates k_region2 gave up on than retry slots were reserved (never observed): the member repeats the level alone
         h->n_smallpath_fallback++;
