@@ -6,12 +6,46 @@ views / lists cut out of those arrays the first time they are read (and cached, 
 attributes).  A Solution with 10^4 regions is therefore 10^4 small Python objects and three arrays, not 6*10^4 arrays
 built eagerly inside the solve.
 """
+import contextlib
+import gc
 import itertools
+import threading
 from typing import List
 
 import numpy
 
 from .critical_region import CriticalRegion
+
+
+_gc_lock = threading.Lock()
+_gc_pauses = 0
+_gc_was_enabled = False
+
+
+@contextlib.contextmanager
+def gc_paused():
+    """The cycle collector is held while ``solve_many`` creates its region objects (re-entrant, any thread).  Such a call allocates 10^5
+    small container objects that are not garbage and form no cycles; every 700 of them start a collection of the young generation,
+    every tenth of those one of the next, and the full collections walk everything alive.  Reference counting frees objects as
+    before; the collector runs again as soon as the outermost call returns.  ``MPC_KEEP_GC=1`` leaves it alone.  (tools/step_overhead.py
+    for the single solve, where holding the collector does not pay.)"""
+    global _gc_pauses, _gc_was_enabled
+    import os
+    if os.environ.get('MPC_KEEP_GC', '0') == '1':
+        yield
+        return
+    with _gc_lock:
+        if _gc_pauses == 0:
+            _gc_was_enabled = gc.isenabled()
+            gc.disable()
+        _gc_pauses += 1
+    try:
+        yield
+    finally:
+        with _gc_lock:
+            _gc_pauses -= 1
+            if _gc_pauses == 0 and _gc_was_enabled:
+                gc.enable()
 
 
 class RegionBatch:

@@ -289,3 +289,42 @@ def test_batch_materialisation_equals_lazy_access():
         for fld in ('b', 'C', 'd', 'E', 'f') + (() if b is eager[1] else ('A',)):
             assert fld in b.__dict__ and numpy.array_equal(getattr(a, fld), getattr(b, fld)), fld
         assert a.active_set == b.active_set and a.omega_set == b.omega_set and a.lambda_set == b.lambda_set and a.regular_set == b.regular_set
+
+
+def test_gc_paused_is_reentrant_and_restores_the_collector(monkeypatch):
+    """region_batch.gc_paused (used by solve_many): the cycle collector is held while the region objects are created -- nested solves and solves on other
+    threads share one pause, the collector's previous state comes back with the outermost exit (also after an exception, also when it
+    was disabled to begin with), and MPC_KEEP_GC=1 leaves it alone."""
+    import gc
+    import threading
+    from ppopt_amd.region_batch import gc_paused
+    assert gc.isenabled()
+    with gc_paused():
+        assert not gc.isenabled()
+        with gc_paused():
+            assert not gc.isenabled()
+        assert not gc.isenabled()
+        seen = []
+
+        def other():
+            with gc_paused():
+                seen.append(gc.isenabled())
+        t = threading.Thread(target=other); t.start(); t.join()
+        assert seen == [False] and not gc.isenabled()
+    assert gc.isenabled()
+    try:
+        with gc_paused():
+            raise RuntimeError('x')
+    except RuntimeError:
+        pass
+    assert gc.isenabled()
+    gc.disable()
+    try:
+        with gc_paused():
+            assert not gc.isenabled()
+        assert not gc.isenabled()      # it was off before: it stays off
+    finally:
+        gc.enable()
+    monkeypatch.setenv('MPC_KEEP_GC', '1')
+    with gc_paused():
+        assert gc.isenabled()
