@@ -412,3 +412,39 @@ def test_enumeration_batched_equals_one_by_one_up_to_knife_edge_facets_own_split
             return subs[fix]
         nr, nd = _same_regions_up_to_knife_edge_facets(sol_1, sol_b, sub_of, 'mi')
     assert nr > 0 and nd <= max(1, nr // 100), (nr, nd)
+
+
+def test_wavefront_shares_do_not_change_the_records():
+    """The shares (MPC_BATCH_SHARES / MPC_BATCH_WPC_*, read once per process: hence child processes) decide how many wavefronts of a shared
+    launch work for a member, not what they compute: with one wavefront per candidate in the region kernel the digest of every region
+    of a shared solve is the same without shares, with the default shares and with very narrow ones."""
+    import subprocess
+    import sys
+    code = (
+        "import hashlib, sys, warnings\n"
+        "sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+        "warnings.simplefilter('ignore')\n"
+        "import numpy\n"
+        "from ppopt_amd import MPQP_Program, problem_generator as pg\n"
+        "from ppopt_amd.mp_solvers import mpqp_hip_combinatorial as m\n"
+        "progs = []\n"
+        "for seed in (31, 32, 33, 34, 35, 36):\n"
+        "    d = pg.generate_mpqp_data(7, 4, 14, seed)\n"
+        "    progs.append(MPQP_Program(d['A'], d['b'], d['c'], d['H'], d['Q'], d['A_t'], d['b_t'], d['F']))\n"
+        "h = hashlib.sha256(); n = 0\n"
+        "for sol in m.solve_many(progs):\n"
+        "    for r in sorted(sol.critical_regions, key=lambda r: tuple(r.active_set)):\n"
+        "        n += 1\n"
+        "        h.update(repr((tuple(r.active_set), tuple(r.omega_set), tuple(r.lambda_set))).encode())\n"
+        "        for fld in ('A', 'b', 'C', 'd', 'E', 'f'):\n"
+        "            h.update(numpy.asarray(getattr(r, fld)).tobytes())\n"
+        "print('DIGEST', n, h.hexdigest())\n") % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.dirname(os.path.abspath(__file__)))
+    digests = []
+    for extra in ({'MPC_BATCH_SHARES': '0'}, {}, {'MPC_BATCH_WPC_TH': '1', 'MPC_BATCH_WPC_X2': '1', 'MPC_BATCH_WPC_XQ': '2', 'MPC_BATCH_WPC_R2': '1'}):
+        env = dict(os.environ, MPC_NO_RSPLIT='1', **extra)
+        out = subprocess.run([sys.executable, '-c', code], env=env, capture_output=True, text=True, timeout=600)
+        line = [l for l in out.stdout.splitlines() if l.startswith('DIGEST')]
+        assert out.returncode == 0 and line, out.stderr[-2000:]
+        digests.append(line[0])
+    assert int(digests[0].split()[1]) > 1000
+    assert digests[0] == digests[1] == digests[2], digests
