@@ -1438,15 +1438,40 @@ MPC_GLOBAL void MPC_LB(64, (SLOTS >= 2 ? 2 : R2W)) k_region2(
                 bool dup[SLOTS], kp[SLOTS];
 #pragma unroll
                 for (int sl = 0; sl < SLOTS; ++sl) { const int i = lane + 64 * sl; kp[sl] = i < m && s.kept[i] == 1; dup[sl] = false; }
-                for (int j = 0; j < m; ++j) {
-                    if (s.kept[j] != 1) continue;
+                // (round 4: every lane fingerprints its own row once -- zeros of either sign alike, as == sees them -- and the kept rows are
+                //  walked through their ballot mask: a fingerprint comes from its lane by v_readlane and only equal fingerprints are compared
+                //  entry by entry.  The loop over all m rows with its LDS reads took 35 k cycles of the ~470 k a region costs, on the wavefront
+                //  that arrives last.  Same rows dropped: the comparison that decides is the old one.)
+                unsigned long long fp[SLOTS];
 #pragma unroll
-                    for (int sl = 0; sl < SLOTS; ++sl) {
-                        const int i = lane + 64 * sl;
-                        if (kp[sl] && i > j) {
-                            bool same = true;
-                            for (int t = 0; t <= nt; ++t) same = same && (s.E[i * ldE + t] == s.E[j * ldE + t]);
-                            dup[sl] = dup[sl] || same;
+                for (int sl = 0; sl < SLOTS; ++sl) {
+                    const int i = lane + 64 * sl;
+                    fp[sl] = 0ull;
+                    if (kp[sl])
+                        for (int t = 0; t <= nt; ++t) {
+                            const double x = s.E[i * ldE + t];
+                            const unsigned long long bits = x == 0.0 ? 0ull : (unsigned long long)__double_as_longlong(x);
+                            fp[sl] = (fp[sl] ^ bits) * 0x9E3779B97F4A7C15ull;
+                            fp[sl] ^= fp[sl] >> 29;
+                        }
+                }
+#pragma unroll
+                for (int sj = 0; sj < SLOTS; ++sj) {
+                    unsigned long long km = __ballot(kp[sj]);
+                    while (km) {
+                        const int jl = __ffsll((long long)km) - 1;
+                        km &= km - 1ull;
+                        const int j = jl + 64 * sj;
+                        const unsigned long long fj = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(unsigned)(fp[sj] >> 32), jl) << 32) |
+                                                      (unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(unsigned)fp[sj], jl);
+#pragma unroll
+                        for (int sl = 0; sl < SLOTS; ++sl) {
+                            const int i = lane + 64 * sl;
+                            if (kp[sl] && i > j && fp[sl] == fj) {
+                                bool same = true;
+                                for (int t = 0; t <= nt; ++t) same = same && (s.E[i * ldE + t] == s.E[j * ldE + t]);
+                                dup[sl] = dup[sl] || same;
+                            }
                         }
                     }
                 }
