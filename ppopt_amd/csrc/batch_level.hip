@@ -177,12 +177,14 @@ hipError_t batch_level_launch(BatchMember *members, int B, hipStream_t st, Batch
     if (B <= 0) return hipSuccess;
     if (!g_tab_host || !g_tab_dev) return hipErrorInvalidValue;
     std::stable_sort(members, members + B, [](const BatchMember &a, const BatchMember &b) { return group_key(a) < group_key(b); });
-    // Wavefront shares.  The persistent kernels of a stage run fastest with few wavefronts per SIMD (mpcombi_hip.hip: k_theta2 two, k_x2
-    // three, k_xq five, k_region2 two) -- for the whole launch, not per member: each member gets its share of that budget in proportion
+    // Wavefront shares.  The persistent kernels of a stage run fastest with few wavefronts per SIMD (mpcombi_hip.hip: a single program's
+    // k_theta2 two, k_x2 three, k_xq five, k_region2 two) -- for the whole launch, not per member: each member gets its share of that budget in proportion
     // to its candidates, so that all members of a group run side by side and finish together.  (Round 3 gave every member the width
     // of a single program's launch: 64 members x 4,096 blocks, the members one after the other, each with its own tail.)
-    static const int wpc_th = env_int("MPC_BATCH_WPC_TH", 8), wpc_xq = env_int("MPC_BATCH_WPC_XQ", 20), wpc_x2 = env_int("MPC_BATCH_WPC_X2", 12),
-                     wpc_r2 = env_int("MPC_BATCH_WPC_R2", 8), use_shares = env_int("MPC_BATCH_SHARES", 1), w_share = env_int("MPC_BATCH_WSHARE", 1);
+    // (budgets in wavefronts per CU, swept on the bench enumeration -- four-parameter sub-programs, the NT = 4 instantiations: the theta
+    //  kernel 8 / 16 / 32 -> 67.5 / 60.3 / 58.3 ms of shared levels, the region kernel 8 / 16 -> 67.5 / 66.4, k_x2 8 / 12 / 16 -> 63.0 / 60.3 / 62.4)
+    static const int wpc_th = env_int("MPC_BATCH_WPC_TH", 32), wpc_xq = env_int("MPC_BATCH_WPC_XQ", 20), wpc_x2 = env_int("MPC_BATCH_WPC_X2", 12),
+                     wpc_r2 = env_int("MPC_BATCH_WPC_R2", 16), use_shares = env_int("MPC_BATCH_SHARES", 1), w_share = env_int("MPC_BATCH_WSHARE", 1);
     for (int g0 = 0; g0 < B && use_shares;) {
         int g1 = g0 + 1;
         while (g1 < B && group_key(members[g1]) == group_key(members[g0])) ++g1;
