@@ -98,6 +98,10 @@ void dev_pool_give(void *p, size_t cls) {
 struct DevBuf {
     void *p = nullptr;
     size_t cap = 0;
+    // != nullptr: a block this buffer has outgrown is parked there instead of being waited for -- the owner (a handle) gives the parked
+    // blocks back to the pool behind its next synchronisation of all its streams (graveyard_flush).  A handle's first solve grows some
+    // twenty buffers on every level: one stream synchronisation each (round 4: 170 growths per first solve of config 4).
+    std::vector<std::pair<void *, size_t>> *parked = nullptr;
     hipError_t ensure(size_t bytes, hipStream_t st, bool keep = false) {
         if (bytes <= cap) return hipSuccess;
         const size_t want = dev_size_class(std::max(bytes, cap + cap / 2));
@@ -110,9 +114,12 @@ struct DevBuf {
                 if (e != hipSuccess) return e;
             }
             // the old block may still be read by work queued on this stream: it goes back to the pool only afterwards
-            e = st ? hipStreamSynchronize(st) : hipDeviceSynchronize();
-            if (e != hipSuccess) return e;
-            dev_pool_give(p, cap);
+            if (parked) parked->emplace_back(p, cap);
+            else {
+                e = st ? hipStreamSynchronize(st) : hipDeviceSynchronize();
+                if (e != hipSuccess) return e;
+                dev_pool_give(p, cap);
+            }
         }
         p = q;
         cap = want;
@@ -283,6 +290,7 @@ struct mpc_handle {
     int xqg_per_cu = XQG_WAVES;      // MPC_XQG_PER_CU: workgroups (of four wavefronts) per CU of the persistent k_xq_grouped launch
     int x2_wpc = 12, x2_div = 16, xq_wpc = 20;    // MPC_X2_WPC (most) / MPC_X2_DIV (items per wavefront) / MPC_XQ_WPC: wavefronts per CU of the persistent
                                      // k_x2 / k_xq launches (round 3: 16 and 32 whatever the size of the level)
+    std::vector<std::pair<void *, size_t>> parked_blocks;   // device blocks the level buffers have outgrown (DevBuf::parked), given back by graveyard_flush
     bool region_side_stream = false; // this level's k_region2 launch ran on the side stream, under the (x,theta) stage (mpc_level_stats)
     bool r3_fork_event = false;      // MPC_R3_FORK=1: the region stream starts behind an event of the main stream (round-3 form; A/B)
     int r2_cap_pct = 100;            // MPC_R2_CAP: share (per cent) of k_region2's wave slots an overlapped one-wave-per-candidate launch may take
@@ -511,6 +519,18 @@ void lu_solve_host(const std::vector<double> &LU, const std::vector<int> &perm, 
 
 }  // namespace
 
+// the buffers a level (re)sizes by its number of candidates: what they outgrow is parked (DevBuf::parked) and given back to the pool by
+// graveyard_flush, which the level paths call behind their closing synchronisation (all streams of the handle have been joined by then)
+static std::vector<DevBuf *> level_buffers(mpc_handle *h) {
+    return {&h->frontier, &h->children, &h->status, &h->pruned, &h->flag, &h->pos, &h->opt_list, &h->childmask, &h->count, &h->offset, &h->recd, &h->reci,
+            &h->sums, &h->retry_list, &h->headd, &h->headi, &h->epool, &h->facet_flags, &h->kkt_code, &h->kkt_L, &h->xq_groups, &h->theta_list, &h->vretry_list,
+            &h->status_tmp, &h->part_counts, &h->part_lists, &h->kept_g, &h->done_g, &h->dict_d[0], &h->dict_d[1], &h->dict_i[0], &h->dict_i[1],
+            &h->dict_stored[0], &h->dict_stored[1], &h->parent_slot, &h->parent_slot_next};
+}
+static void graveyard_flush(mpc_handle *h) {
+    for (auto &b : h->parked_blocks) dev_pool_give(b.first, b.second);
+    h->parked_blocks.clear();
+}
 static int create_fill(const mpc_problem *p, int32_t device, void *stream, mpc_handle *h);
 static void stream_release(mpc_handle *h);
 static void solve_release(mpc_handle *h);
@@ -547,6 +567,7 @@ int mpc_create(const mpc_problem *p, int32_t device, void *stream, mpc_handle **
     // every failure from here on goes through one cleanup path: mpc_destroy returns the handle's streams, events, device
     // blocks and pinned block to the pools (a caller that creates one handle per binary fixation must not leak on OOM)
     mpc_handle *h = new mpc_handle();
+    for (DevBuf *b : level_buffers(h)) b->parked = &h->parked_blocks;
     const int rc_fill = create_fill(p, device, stream, h);
     if (rc_fill != MPC_OK) { (void)mpc_destroy(h); return rc_fill; }
     *out = h;
@@ -1017,6 +1038,7 @@ int mpc_destroy(mpc_handle *h) {
     (void)hipStreamSynchronize(h->stream);
     if (h->stream2) (void)hipStreamSynchronize(h->stream2);
     if (h->stream3) (void)hipStreamSynchronize(h->stream3);
+    graveyard_flush(h);
     for (DevBuf *b : {&h->blocks, &h->iblocks, &h->frontier, &h->children, &h->status, &h->pruned, &h->flag, &h->pos, &h->opt_list,
                       &h->childmask, &h->count, &h->offset, &h->recd, &h->reci, &h->ctr, &h->scratch, &h->sums, &h->retry_list, &h->pf_dev, &h->pr2_dev, &h->headd, &h->headi, &h->epool, &h->facet_flags, &h->kkt_code, &h->kkt_L, &h->theta_blocks, &h->xq_groups, &h->theta_list, &h->vretry_list, &h->status_tmp, &h->part_counts, &h->part_lists, &h->kept_g, &h->done_g, &h->dict_d[0], &h->dict_d[1], &h->dict_i[0], &h->dict_i[1],
                       &h->dict_stored[0], &h->dict_stored[1], &h->parent_slot, &h->parent_slot_next, &h->dcnt}) b->release();
@@ -1051,6 +1073,7 @@ int mpc_trim(mpc_handle *h) {
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     if (h->stream2) HIP_TRY(h, hipStreamSynchronize(h->stream2));
     if (h->stream3) HIP_TRY(h, hipStreamSynchronize(h->stream3));
+    graveyard_flush(h);
     stream_release(h);
     for (DevBuf *b : {&h->frontier, &h->children, &h->status, &h->pruned, &h->flag, &h->pos, &h->opt_list, &h->childmask, &h->count, &h->offset, &h->recd, &h->reci,
                       &h->sums, &h->retry_list, &h->headd, &h->headi, &h->epool, &h->facet_flags, &h->kkt_code, &h->kkt_L, &h->xq_groups, &h->theta_list, &h->vretry_list,
@@ -1571,6 +1594,7 @@ static int level_run_small(mpc_handle *h, int32_t gen_children, int32_t flags, m
     h->n_pruned_new = host_ctr.n_pruned_new;
     h->n_erows = host_ctr.e_rows;
     h->n_regions = (long long)host_ctr.status[ST_REGION];
+    graveyard_flush(h);   // (behind the level's closing synchronisation)
     h->level_done = true;
     h->last_level_n = n;
     stream_ready(h);
@@ -1735,6 +1759,7 @@ static int batch_finish(mpc_handle *h, int32_t gen_children, const BatchMember &
     h->n_pruned_new = host_ctr.n_pruned_new;
     h->n_erows = host_ctr.e_rows;
     h->n_regions = (long long)host_ctr.status[ST_REGION];
+    graveyard_flush(h);   // (behind the level's closing synchronisation)
     h->level_done = true;
     h->last_level_n = n;
     stream_ready(h);
@@ -2529,6 +2554,7 @@ static int level_run_impl(mpc_handle *h, int32_t gen_children, int32_t flags, mp
         h->n_erows = host_ctr.e_rows;
         h->n_regions = (long long)host_ctr.status[ST_REGION];
     }
+    graveyard_flush(h);   // (behind the level's closing synchronisation)
     h->level_done = true;
     h->last_level_n = n;
     stream_ready(h);

@@ -245,12 +245,16 @@ def _solve_in_library(program, eng, solution, max_depth, profile, prune_lowdim, 
     ``MPC_NO_SOLVE_LOOP=1`` keeps the level-by-level loop in ``_solve``."""
     n_x, n_t, n_c, n_tc = eng.n_x, eng.n_t, eng.n_c, eng.n_tc
     twin = None
-    if BASE_ON_TWIN:
+    # The second handle costs a set-up (~0.5 ms) and saves the base-set check at the end of a solve (~0.1 ms): a program's FIRST solve
+    # checks the base set on its own handle behind the last level, the second handle is made when the program is solved again
+    # (tools/first_solve.py: config 2's first solve 1.85 ms with the second handle against 1.1 ms in the steady state).
+    if BASE_ON_TWIN and (getattr(eng, '_solved_before', False) or getattr(eng, '_twin', None) is not None):
         try:
             twin = eng.twin()
             twin.level_start(False, only_base=True)
         except Exception:
             twin = None
+    eng._solved_before = True
     eng.solve_start(max_depth, stream=True, fetch=True, then_base=twin is None, keep_lowdim=not prune_lowdim)
     regions = solution.critical_regions
     level = 0
