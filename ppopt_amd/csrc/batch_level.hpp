@@ -20,8 +20,8 @@
 // LP, which pays on idle CUs only: 64 sub-programs of the bench enumeration 83 -> 67 ms of device time.  A different split walks the
 // facets in another order; with the same split (MPC_NO_RSPLIT=1 on both sides) every record is bit for bit the single program's, with
 // each side's own the x-law, multipliers, statuses, children and pruned masks still are, and a facet list may differ where it sits on
-// the LP tolerance (tests/test_gpu_batch.py `_own_split`; tools/fuzz_batch.py: 582,465 regions of 300 random programs, 1 other facet
-// list, 4 regions with coefficients differing by <= 6e-12; tools/batch_w_debug2.py: 14 of 12,871 regions, in each of them the CPU
+// the LP tolerance (tests/test_gpu_batch.py `_own_split`; tools/fuzz_batch.py: 999,231 regions of 600 random programs, 2 other facet
+// lists, 18 regions with coefficients differing by <= 3.4e-11; tools/batch_w_debug2.py: 14 of 12,871 regions, in each of them the CPU
 // oracle's own list changes when its 1e-7 tolerance moves two decades).
 //
 // Wavefront shares.  The persistent kernels run fastest with FEW wavefronts per SIMD (k_theta2 two, k_x2 three, k_xq five, k_region2
