@@ -526,3 +526,52 @@ def test_closing_rows_are_not_used_for_a_box_of_big_m_size():
     assert numpy.linalg.matrix_rank(prog.A_t) < prog.num_t()
     assert prog.engine(0, closed=True).n_tc == prog.A_t.shape[0]
     prog.release_engine()
+
+
+def test_config4_one_level_beyond_the_goldens_equals_the_oracle_on_a_sample(oracle):
+    """Config 4 one level deeper than the benchmark and than any reference-generated golden (level 6: 5,575,526 candidates, the scaling
+    workload of bench.py --gpus N): every 64th candidate's verdict and every sampled region against the CPU oracle.  The frontier of
+    that level is itself a product of five levels of verdicts and prunings on the device."""
+    from conftest import rel_err, rows_match
+    from ppopt_amd.region_batch import RegionBatch
+    from test_gpu_parity import engine_from_golden
+    g = load_golden('c4_rand_20_8_20_s0')
+    eng = engine_from_golden(g)
+    P = oracle.problem_from_golden(g)
+    eng.pruned_clear(); eng.frontier_root()
+    for depth in range(6):
+        st = eng.level_run(depth != 5)
+        if depth != 5:
+            eng.frontier_advance()
+    assert int(st.n) == 5575526 and int(st.k) == 6
+    cands, status = eng.frontier_get(), eng.level_status()
+    hd, hi, er, kk, slots = eng.level_regions_slots()
+    regs = {int(hi[j, 1]): r for j, r in zip(slots.tolist(), RegionBatch(hd, hi, er, eng.n_x, eng.n_t, eng.n_c, eng.n_tc, kk, slots).regions())}
+    pick = numpy.arange(0, len(cands), 64)
+    want, want_regs = P.check_level(numpy.ascontiguousarray(cands[pick]), threads=0, want_regions=True)
+    got = status[pick]
+    differ = numpy.nonzero(want != got)[0]
+    # a differing verdict has to be knife-edge (conftest.is_knife_edge): none is expected on this program (none on levels 1-5)
+    from conftest import is_knife_edge
+    for j in differ.tolist():
+        assert is_knife_edge(P, cands[pick[j]].tolist()), (cands[pick[j]].tolist(), int(want[j]), int(got[j]))
+    assert len(differ) <= 2
+    n_reg = 0
+    for j, wr in want_regs.items():
+        if int(got[j]) != 3:
+            continue
+        r = regs[int(pick[j])]
+        n_reg += 1
+        assert r.active_set == wr['active_set']
+        assert rel_err(r.A, wr['A']) < 1e-7 and rel_err(r.b, wr['b']) < 1e-7 and rel_err(r.C, wr['C']) < 1e-7 and rel_err(r.d, wr['d']) < 1e-7
+        if (r.omega_set, r.lambda_set, r.regular_set) != (wr['omega_set'], wr['lambda_set'], wr['regular_set']):
+            assert is_knife_edge(P, r.active_set) or kkt_cond_large(P, r.active_set), r.active_set
+        else:
+            assert rows_match(r.E, r.f, wr['E'], wr['f'])
+    assert n_reg > 100
+    eng.close()
+
+
+def kkt_cond_large(P, active_set):
+    from conftest import kkt_condition
+    return kkt_condition(P, active_set) > 1e6
