@@ -53,7 +53,7 @@ __global__ void __launch_bounds__(1024) m_compact_small(const BatchMember *__res
     k_compact_small(m.status, (int)m.n, lo, hi, into_retry ? m.retry_list : m.theta_list, m.dcnt + slot);
 }
 template <int NT, int SLOTS>
-__global__ void __launch_bounds__(64, (NT * SLOTS >= 20 ? 3 : (SLOTS >= 2 ? TH_WAVES_S2 : 4))) m_theta2(const BatchMember *__restrict__ tab) {
+__global__ void __launch_bounds__(64, (SLOTS >= 2 ? (NT <= 4 ? TH_WAVES_S2 : 2) : (NT * SLOTS >= 20 ? 3 : 4))) m_theta2(const BatchMember *__restrict__ tab) {
     MEMBER;
     ThetaArgs ta = m.targs;
     ta.chunk = 1;
@@ -116,7 +116,7 @@ __global__ void __launch_bounds__(64, XQ_WAVES) m_xq(const BatchMember *__restri
     k_xq<SLOTS>(m.pf, m.fr, m.k, part_list_of(m, 3), (int)m.n, m.status, m.ctr, dq, m.nxc);
 }
 template <int NXC, int SLOTS>
-__global__ void __launch_bounds__(64, (NXC * SLOTS >= 32 ? X2_WAVES : X2_WAVES_16)) m_x2(const BatchMember *__restrict__ tab) {
+__global__ void __launch_bounds__(64, (NXC * SLOTS >= 64 ? 2 : (NXC * SLOTS >= 32 ? X2_WAVES : X2_WAVES_16))) m_x2(const BatchMember *__restrict__ tab) {
     MEMBER;
     DictCache d = m.dc;
     d.n_list_dev = m.dcnt + (m.quick_test ? 8 : 7);

@@ -283,10 +283,10 @@ __device__ inline int kkt_fetch_or_solve(const DevProblem &P, int k, Smem &s, co
 }
 
 #ifndef TH_WAVES_S2
-#define TH_WAVES_S2 4
+#define TH_WAVES_S2 3   // two rows per lane, n_theta <= 4: 168 registers, no scratch (four wavefronts: 128 registers and 164 bytes); n_theta >= 8: two wavefronts, 231 registers
 #endif
 template <int NT, int SLOTS>
-MPC_GLOBAL void MPC_LB(64, (NT * SLOTS >= 20 ? 3 : (SLOTS >= 2 ? TH_WAVES_S2 : 4))) k_theta2(const DevProblem *__restrict__ Pg, const int32_t *__restrict__ cands, long long n, int k,
+MPC_GLOBAL void MPC_LB(64, (SLOTS >= 2 ? (NT <= 4 ? TH_WAVES_S2 : 2) : (NT * SLOTS >= 20 ? 3 : 4))) k_theta2(const DevProblem *__restrict__ Pg, const int32_t *__restrict__ cands, long long n, int k,
                                                     uint8_t *__restrict__ status, LevelCounters *__restrict__ ctr,
                                                     const uint8_t *__restrict__ kkcode, const double *__restrict__ Lin, ThetaArgs ta,
                                                     const int32_t *__restrict__ list) {
@@ -859,7 +859,7 @@ MPC_GLOBAL void MPC_LB(256, XQG_WAVES) k_xq_grouped(const DevProblem *__restrict
 #define X2_WAVES_16 3   // the 16-column instantiations (168 registers, no scratch at 3 waves per SIMD; 4 waves: 64 sub-programs per launch 175.0 -> 173.4 ms on the device, config 2 unchanged -- not worth the spills)
 #endif
 template <int NXC, int SLOTS>
-MPC_GLOBAL void MPC_LB(64, (NXC * SLOTS >= 32 ? X2_WAVES : X2_WAVES_16)) k_x2(const DevProblem *__restrict__ Pg, const int32_t *__restrict__ cands, int k,
+MPC_GLOBAL void MPC_LB(64, (NXC * SLOTS >= 64 ? 2 : (NXC * SLOTS >= 32 ? X2_WAVES : X2_WAVES_16))) k_x2(const DevProblem *__restrict__ Pg, const int32_t *__restrict__ cands, int k,
                                               const int32_t *__restrict__ list, int n_list, uint8_t *__restrict__ status,
                                               LevelCounters *__restrict__ ctr, DictCache dc) {
     const DevProblem &P = *Pg;

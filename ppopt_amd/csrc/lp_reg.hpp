@@ -93,13 +93,19 @@ __device__ __forceinline__ int dpp_wave_min_i32(int v) {
     return min(min(__builtin_amdgcn_readlane(v, 15), __builtin_amdgcn_readlane(v, 31)), min(__builtin_amdgcn_readlane(v, 47), __builtin_amdgcn_readlane(v, 63)));
 }
 
+// A value forced through a register (empty asm).  With two rows per lane the choice "slot 0 or slot 1" by a wave-uniform run-time row is
+// written as a select of two values; without this the optimiser turns the select (or two branches with the same code) into ONE access at a
+// run-time index of the array of slots, and an array indexed at run time lives in scratch -- the whole tableau did (round 4).
+__device__ __forceinline__ double opaque(double e) { asm volatile("" : "+v"(e)); return e; }
+__device__ __forceinline__ int opaque(int e) { asm volatile("" : "+v"(e)); return e; }
+
 template <int W> struct RowVec;
 template <> struct RowVec<8> { typedef double type __attribute__((ext_vector_type(8))); };
 template <> struct RowVec<16> { typedef double type __attribute__((ext_vector_type(16))); };
 
 // One tableau row in VGPRs.  operator[] with a compile-time index (unrolled loops) is a plain register; getq / setq take
 // a WAVE-UNIFORM run-time index.
-template <int NC>
+template <int NC, bool SELECT = false>
 struct RegRow {
     static constexpr int W = NC <= 8 ? 8 : 16;
     static constexpr int H = (NC + W - 1) / W;
@@ -125,12 +131,43 @@ struct RegRow {
     __device__ __forceinline__ double operator[](int j) const { return get(j); }
 };
 
+// Two rows per lane (SLOTS == 2): with two run-time-indexed 16-double vectors per lane the compiler keeps the tableau rows in a stack object
+// (round 4: 320-896 bytes of scratch in every <.,2> instantiation, 47 k cycles per pivot in k_region2<8,2> against 3.6 k in <8,1>).  Here a
+// row is NC named registers; the two accesses with a wave-uniform run-time column per pivot (read the entering column, write e_r) are
+// select chains over the compile-time columns -- 2 NC v_cndmask per pivot instead of scratch traffic on every entry.
+template <int NC>
+struct RegRow<NC, true> {
+    double v[NC];
+    __device__ __forceinline__ double get(int j) const { return v[j]; }
+    __device__ __forceinline__ void set(int j, double x) { v[j] = x; }
+    // (the element goes through an empty asm: otherwise the optimiser folds the chain back into ONE load / store at a run-time index,
+    //  which puts the row -- and a mirror store for every update of every entry -- into scratch)
+    static __device__ __forceinline__ double in_register(double e) { return opaque(e); }
+    __device__ __forceinline__ double getq(int q) const {
+        double r = in_register(v[0]);
+#pragma unroll
+        for (int j = 1; j < NC; ++j) r = (j == q) ? in_register(v[j]) : r;
+        return r;
+    }
+    __device__ __forceinline__ void setq(int q, double x) {
+#pragma unroll
+        for (int j = 0; j < NC; ++j) v[j] = (j == q) ? x : in_register(v[j]);
+    }
+    struct Ref {
+        RegRow &row; int j;
+        __device__ __forceinline__ operator double() const { return row.get(j); }
+        __device__ __forceinline__ Ref &operator=(double x) { row.set(j, x); return *this; }
+    };
+    __device__ __forceinline__ Ref operator[](int j) { return Ref{*this, j}; }
+    __device__ __forceinline__ double operator[](int j) const { return get(j); }
+};
+
 // WEIGHTED: row i carries a power-of-two scale w (its entries are w times the constraint as posed).  Phase 1 then measures
 // infeasibility in the constraint's own units: x0 enters row i with coefficient -w, so "x0 <= 1e-7" means every constraint
 // holds within 1e-7 as posed, however much the row was scaled for the pivoting.
 template <int NC, int SLOTS, bool WEIGHTED = false>
 struct RegLp {
-    RegRow<NC> t[SLOTS];
+    RegRow<NC, (SLOTS >= 2)> t[SLOTS];
     double w[SLOTS], winv[SLOTS];   // only read when WEIGHTED
     int kind[SLOTS];
     int var[SLOTS];
@@ -143,12 +180,12 @@ struct RegLp {
     __device__ __forceinline__ double row_entry(int r, const double (&c)[SLOTS]) const {
         const int rl = r & 63;
         if (SLOTS == 1) return readlane_f64(c[0], rl);
-        return readlane_f64((r >> 6) ? c[SLOTS - 1] : c[0], rl);
+        return readlane_f64((r >> 6) ? opaque(c[SLOTS - 1]) : opaque(c[0]), rl);
     }
     __device__ __forceinline__ int row_entry_i(int r, const int (&c)[SLOTS]) const {
         const int rl = r & 63;
         if (SLOTS == 1) return __builtin_amdgcn_readlane(c[0], rl);
-        return __builtin_amdgcn_readlane((r >> 6) ? c[SLOTS - 1] : c[0], rl);
+        return __builtin_amdgcn_readlane((r >> 6) ? opaque(c[SLOTS - 1]) : opaque(c[0]), rl);
     }
 
     // Pivot on (r, q): f = column q before the pivot, inv = 1 / f[r].
@@ -165,7 +202,7 @@ struct RegLp {
                 for (int j = 0; j < NC; ++j) t[s].set(j, t[s].get(j) * inv);
             }
         }
-        if (SLOTS == 1 || (r >> 6) == 0) {
+        if (SLOTS == 1) {
 #pragma unroll
             for (int j = 0; j < NC; ++j) {
                 const double trj = readlane_f64(t[0].get(j), r & 63);
@@ -173,9 +210,10 @@ struct RegLp {
                 for (int s = 0; s < SLOTS; ++s) t[s].set(j, fma(-fz[s], trj, t[s].get(j)));
             }
         } else {
+            const bool upper = (r >> 6) != 0;
 #pragma unroll
             for (int j = 0; j < NC; ++j) {
-                const double trj = readlane_f64(t[SLOTS - 1].get(j), r & 63);
+                const double trj = readlane_f64(upper ? opaque(t[SLOTS - 1].get(j)) : opaque(t[0].get(j)), r & 63);
 #pragma unroll
                 for (int s = 0; s < SLOTS; ++s) t[s].set(j, fma(-fz[s], trj, t[s].get(j)));
             }
