@@ -625,7 +625,8 @@ __device__ __forceinline__ int xq_decide(PD pd, PI pi, int mr, int NXC, int ncol
             row = uni(row);
             // value of entry `r` of a vector whose element i lives in lane i & 63, slot i >> 6
             auto at = [&](const double (&vec)[SLOTS], int r) -> double {
-                return readlane_f64((SLOTS == 1 || r < 64) ? vec[0] : vec[SLOTS - 1], r & 63);
+                if (SLOTS == 1) return readlane_f64(vec[0], r & 63);
+                return readlane_f64(r < 64 ? opaque(vec[0]) : opaque(vec[SLOTS - 1]), r & 63);   // (opaque: lp_reg.hpp -- the select must not become an indexed load)
             };
             // Up to XQ_ITERS simplex iterations in product form: the tableau is never formed.  Per pivot p the entering
             // column as it was (E[p], one entry per row) and the scaled pivot row (R[p], one entry per column) are kept;
@@ -637,7 +638,7 @@ __device__ __forceinline__ int xq_decide(PD pd, PI pi, int mr, int NXC, int ncol
             double xrow = (lane < ncol) ? pd[(size_t)lane * mr + row] : 0.0;   // the new row, entry j in lane j
             // first iteration: the column comes from the hint stored with the parent's record -- exactly the column the pricing of
             // `xrow` below would choose (same rule, same numbers) -- so the column is asked for together with the row, not after it
-            const int q0 = __builtin_amdgcn_readlane((SLOTS == 1 || row < 64) ? qhint[0] : qhint[SLOTS - 1], row & 63);
+            const int q0 = SLOTS == 1 ? __builtin_amdgcn_readlane(qhint[0], row & 63) : __builtin_amdgcn_readlane(row < 64 ? opaque(qhint[0]) : opaque(qhint[SLOTS - 1]), row & 63);
             double growth = growth0;
 #pragma unroll
             for (int it = 0; it < XQ_ITERS; ++it) {
