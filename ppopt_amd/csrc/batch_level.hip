@@ -53,7 +53,7 @@ __global__ void __launch_bounds__(1024) m_compact_small(const BatchMember *__res
     k_compact_small(m.status, (int)m.n, lo, hi, into_retry ? m.retry_list : m.theta_list, m.dcnt + slot);
 }
 template <int NT, int SLOTS>
-__global__ void __launch_bounds__(64, (SLOTS >= 2 ? (NT <= 4 ? TH_WAVES_S2 : 2) : (NT * SLOTS >= 20 ? 3 : 4))) m_theta2(const BatchMember *__restrict__ tab) {
+__global__ void __launch_bounds__(64, (SLOTS >= 2 ? (NT <= 4 ? TH_WAVES_S2 : 2) : (NT >= 8 ? 3 : 4))) m_theta2(const BatchMember *__restrict__ tab) {
     MEMBER;
     ThetaArgs ta = m.targs;
     ta.chunk = 1;

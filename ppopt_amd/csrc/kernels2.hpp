@@ -286,7 +286,7 @@ __device__ inline int kkt_fetch_or_solve(const DevProblem &P, int k, Smem &s, co
 #define TH_WAVES_S2 3   // two rows per lane, n_theta <= 4: 168 registers, no scratch (four wavefronts: 128 registers and 164 bytes); n_theta >= 8: two wavefronts, 231 registers
 #endif
 template <int NT, int SLOTS>
-MPC_GLOBAL void MPC_LB(64, (SLOTS >= 2 ? (NT <= 4 ? TH_WAVES_S2 : 2) : (NT * SLOTS >= 20 ? 3 : 4))) k_theta2(const DevProblem *__restrict__ Pg, const int32_t *__restrict__ cands, long long n, int k,
+MPC_GLOBAL void MPC_LB(64, (SLOTS >= 2 ? (NT <= 4 ? TH_WAVES_S2 : 2) : (NT >= 8 ? 3 : 4))) k_theta2(const DevProblem *__restrict__ Pg, const int32_t *__restrict__ cands, long long n, int k,
                                                     uint8_t *__restrict__ status, LevelCounters *__restrict__ ctr,
                                                     const uint8_t *__restrict__ kkcode, const double *__restrict__ Lin, ThetaArgs ta,
                                                     const int32_t *__restrict__ list) {
