@@ -854,7 +854,7 @@ MPC_GLOBAL void MPC_LB(256, XQG_WAVES) k_xq_grouped(const DevProblem *__restrict
 #define R2W 2
 #endif
 #ifndef X2_WAVES
-#define X2_WAVES 3
+#define X2_WAVES 2   // 32-column tableau: 252 registers, no scratch (three wavefronts per SIMD: 168 registers and 132 bytes; round 4: level 4 of config 4 1.06 -> 0.98 ms)
 #endif
 #ifndef X2_WAVES_16
 #define X2_WAVES_16 3   // the 16-column instantiations (168 registers, no scratch at 3 waves per SIMD; 4 waves: 64 sub-programs per launch 175.0 -> 173.4 ms on the device, config 2 unchanged -- not worth the spills)

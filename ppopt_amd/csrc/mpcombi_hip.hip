@@ -912,7 +912,7 @@ static int create_fill(const mpc_problem *p, int32_t device, void *stream, mpc_h
             h->fast = 1;
             h->fast_t = tsel * 2 + (slots_t - 1);
             h->fast_x = xsel * 2 + (slots_x - 1);
-            if (slots_x >= 2 && xsel >= 1) h->x2_wpc = std::min(h->x2_wpc, 8);   // k_x2<32,2> is built for two wavefronts per SIMD (224 registers)
+            if (xsel >= 1) h->x2_wpc = std::min(h->x2_wpc, 4 * X2_WAVES);   // the 32-column instantiations of k_x2 are built for two wavefronts per SIMD
             // zero-padded blocks of k_theta2 (ThetaArgs) for its compile-time NT
             const int NTP = tsel == 0 ? 4 : (tsel == 1 ? 8 : 10), LS = NTP + 1;
             {
