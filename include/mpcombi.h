@@ -102,6 +102,10 @@ typedef struct {
     float ms_kkt, ms_xq;
     int64_t n_xq_items, xq_pivots;
     int64_t xq_record_ints, xq_record_rows, xq_record_cols;   /* 2 mr + NXC + 3 ints, mr rows, n_d0c + 1 columns of a record */
+    /* round 5: the quick test's first pass with one thread per candidate (k_xq_thread): candidates it decided (of n_xq_items; the
+     * wavefront kernel gets the others) and its HIP-event time (inside ms_xq) */
+    int64_t n_xq_thread;
+    float ms_xq_thread, pad_;
 } mpc_level_stats;
 
 /* ---- library / device ------------------------------------------------------------------------------ */

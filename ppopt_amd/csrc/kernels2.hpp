@@ -736,6 +736,10 @@ __device__ __forceinline__ int xq_decide(PD pd, PI pi, int mr, int NXC, int ncol
     return feas;
 }
 
+#ifdef MPC_XQ_HIST
+__device__ unsigned long long g_xq_hist[64];
+__device__ unsigned long long g_xq_hist2[64];
+#endif
 template <int SLOTS>
 MPC_GLOBAL void MPC_LB(64, XQ_WAVES) k_xq(const DevProblem *__restrict__ Pg, const int32_t *__restrict__ cands, int k,
                                                const int32_t *__restrict__ list, int n_list, uint8_t *__restrict__ status,
@@ -772,6 +776,29 @@ MPC_GLOBAL void MPC_LB(64, XQ_WAVES) k_xq(const DevProblem *__restrict__ Pg, con
             const double *pd = dc.prev_d + (size_t)ps * dc.stride_d;
             int piv_local = 0;
             const int feas = xq_decide<SLOTS>(pd, pi, mr, NXC, P.n_d0c + 1, v, lane, piv_local);
+#ifdef MPC_XQ_HIST
+            if (lane == 0) atomicAdd(&g_xq_hist[(feas + 1) * 20 + min(piv_local, 19)], 1ull);   // debug build: outcome x ratio tests passed
+            {
+                // experiment: is there ANY column whose Harris test lets the new row leave at zero?  (brute force, debug build only)
+                int row = -1;
+                const int vi = lane < mr ? pi[lane] : -1, ki = lane < mr ? (pi[mr + lane] & 0xff) : RK_DEAD;
+                const unsigned long long br = __ballot(vi == v && ki == RK_INEQ);
+                if (br) row = __ffsll((long long)br) - 1;
+                int any = 0;
+                if (row >= 0) {
+                    const double b = lane < mr ? pd[lane] : 0.0;
+                    for (int q = 1; q < P.n_d0c + 1; ++q) {
+                        const double a = lane < mr ? pd[(size_t)q * mr + lane] : 0.0;
+                        const bool elig = ki == RK_INEQ && a > TOL_PIV;
+                        double tm = INFINITY, ratio = 0.0;
+                        if (elig) { const double b0 = fmax(b, 0.0), ia = fast_rcp(a); ratio = b0 * ia; tm = (b0 + HARRIS_DELTA) * ia; }
+                        tm = dpp_wave_min(tm);
+                        if (__any(lane == row && elig && !(ratio > tm))) any = 1;
+                    }
+                }
+                if (lane == 0) atomicAdd(&g_xq_hist2[any * 20 + min(piv_local, 19)], 1ull);
+            }
+#endif
             if (feas >= 0) {
                 n_quick++;
                 pivots += piv_local;
@@ -780,6 +807,121 @@ MPC_GLOBAL void MPC_LB(64, XQ_WAVES) k_xq(const DevProblem *__restrict__ Pg, con
         }
     }
     if (lane == 0) { atomicAdd(&ctr->pivots, pivots); atomicAdd(&ctr->xq_pivots, pivots); atomicAdd(&ctr->x_cached, n_quick); atomicAdd(&ctr->xtheta_lps, n_quick); }
+}
+
+// k_xq_thread (round 5): the part of xq_decide that ends within its FIRST ratio test, with ONE THREAD per candidate.
+//
+// Two thirds of config 4's last level end there (tools/xq_hist.py: 14.7 % before any ratio test -- the new row's slack is already
+// nonbasic / already zero / has no improving column --, 52.3 % because the new row itself passes the Harris test of its hinted
+// column and leaves the basis at zero).  None of that needs a wavefront: the test is a scan down ONE column of the parent's record
+// with no dependence between candidates.  Lane = candidate; siblings are neighbours in the list, so the parent's values, kinds and
+// variable ids are same-address loads and only the hinted column is the lane's own walk.  Same operations on the same numbers as
+// xq_decide (min / max are exact, so the order of the scan does not matter): a candidate decided here has the verdict k_xq would
+// have given it; everything else -- a pivot is needed, an unbounded direction, a doubtful pivot, no parent record -- keeps its
+// NEEDX status and goes on to k_xq unchanged.  ~20 wave-instructions per row of the record for 64 candidates, against ~150-200
+// per candidate in k_xq.
+MPC_GLOBAL void MPC_LB(256) k_xq_thread(const DevProblem *__restrict__ Pg, const int32_t *__restrict__ cands, int k,
+                                        const int32_t *__restrict__ list, int n_list, uint8_t *__restrict__ status,
+                                        LevelCounters *__restrict__ ctr, DictCache dc, int NXC) {
+    const DevProblem &P = *Pg;
+    const int nv = P.n_x + P.n_t, mr = P.n_d0r, ncol = P.n_d0c + 1;
+    if (dc.n_list_dev) n_list = *dc.n_list_dev;
+    unsigned int n_dec = 0, n_piv = 0;   // per thread: candidates decided / decided by the ratio test (one pivot in k_xq's count)
+    for (long long w = (long long)blockIdx.x * 256 + threadIdx.x; w < n_list; w += (long long)gridDim.x * 256) {
+        const int c = list[w];
+        const int ps = dc.parent_slot[c];
+        if (ps < 0) continue;
+        const int32_t *pi = dc.prev_i + (size_t)ps * dc.stride_i;
+        const double *pd = dc.prev_d + (size_t)ps * dc.stride_d;
+        const int v = nv + cands[(size_t)c * k + (k - 1)];
+        const unsigned al = (unsigned)pi[2 * mr + NXC];
+        int feas = -1;   // 1 feasible, 0 infeasible, -1 left to k_xq
+        // the new row's slack is a live nonbasic column of the parent's dictionary: it is zero at the parent's vertex
+#pragma unroll 8
+        for (int j = 1; j < ncol; ++j) if (pi[2 * mr + j] == v && ((al >> j) & 1u)) feas = 1;
+        int row = -1, q0 = 0;
+        if (feas < 0) {
+#pragma unroll 8
+            for (int i = mr - 1; i >= 0; --i) {
+                const int kraw = pi[mr + i];
+                if (pi[i] == v && (kraw & 0xff) == RK_INEQ) { row = i; q0 = kraw >> 8; }   // (lowest such row, as xq_decide's ballots)
+            }
+        }
+        bool by_test = false;
+        if (feas < 0 && row >= 0) {
+            const double brow = pd[row];
+            if (brow <= TOL_FEAS) feas = 1;
+            else if (q0 <= 0) feas = 0;
+            else {
+                // Four rows per trip, each vector fetched with 16-byte loads (records are 8-byte aligned, the hardware takes unaligned
+                // global accesses): a lane's column is ITS OWN walk -- 64 distinct lines per wave-level load -- and the kernel is bound
+                // by the number of such requests, not by their bytes (tools/ubench/xq_thread_bench.hip: one 8-byte load per row 0.57 ms
+                // for config 4's level, seven rows issued together 0.28, four rows in two 16-byte loads 0.19)
+                struct __attribute__((packed, aligned(8))) D4 { double v[4]; };
+                struct __attribute__((packed, aligned(4))) I4 { int v[4]; };
+                const double *col = pd + (size_t)q0 * mr;
+                float cmf = 0.0f;
+                double tmax = INFINITY, ratio_row = 0.0, a_row = 0.0;
+                bool elig_row = false;
+                for (int i0 = 0; i0 < mr; i0 += 4) {
+                    double a4[4], b4[4];
+                    int k4[4];
+                    if (i0 + 4 <= mr) {
+                        const D4 xa = *reinterpret_cast<const D4 *>(col + i0);
+                        const D4 xb = *reinterpret_cast<const D4 *>(pd + i0);
+                        const I4 xk = *reinterpret_cast<const I4 *>(pi + mr + i0);
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) { a4[u] = xa.v[u]; b4[u] = xb.v[u]; k4[u] = xk.v[u]; }
+                    } else {
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) { const int i = min(i0 + u, mr - 1); a4[u] = col[i]; b4[u] = pd[i]; k4[u] = pi[mr + i]; }
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int i = i0 + u;
+                        if (i < mr) {
+                            const double a = a4[u];
+                            const int kd = k4[u] & 0xff;
+                            const bool used = kd != RK_DEAD;
+                            if (used) cmf = fmaxf(cmf, fabsf((float)a));
+                            const bool elig = used && kd == RK_INEQ && a > TOL_PIV;
+                            if (elig) {
+                                const double b0 = fmax(b4[u], 0.0), ia = fast_rcp(a);
+                                const double ratio = b0 * ia;
+                                tmax = fmin(tmax, (b0 + HARRIS_DELTA) * ia);
+                                if (i == row) { elig_row = true; ratio_row = ratio; a_row = a; }
+                            }
+                        }
+                    }
+                }
+                // the new row is inside the Harris bound: it leaves the basis at zero (xq_decide: `mine`, l == row)
+                if (tmax != INFINITY && elig_row && !(ratio_row > tmax)) {
+                    const double growth0 = __hiloint2double(pi[2 * mr + NXC + 1], pi[2 * mr + NXC + 2]);
+                    const double inv = fast_rcp(a_row);
+                    const double growth = fmax(growth0, (double)(cmf * (float)inv));
+                    if (!(growth > GROWTH_SAFE)) { feas = 1; by_test = true; }
+                }
+            }
+        }
+        if (feas >= 0) {
+            const bool singular = status[c] == ST_NEEDX_SING;
+            status[c] = (uint8_t)(feas ? (singular ? ST_SINGULAR : ST_FEASIBLE) : ST_INFEASIBLE);
+            n_dec++;
+            if (by_test) n_piv++;
+        }
+    }
+    // one set of atomics per workgroup (the same-address atomics of 15 k wavefronts would serialise behind each other)
+    __shared__ unsigned int s_dec, s_piv;
+    if (threadIdx.x == 0) { s_dec = 0; s_piv = 0; }
+    __syncthreads();
+    if (n_dec) atomicAdd(&s_dec, n_dec);
+    if (n_piv) atomicAdd(&s_piv, n_piv);
+    __syncthreads();
+    if (threadIdx.x == 0 && s_dec) {
+        atomicAdd(&ctr->pivots, (unsigned long long)s_piv); atomicAdd(&ctr->xq_pivots, (unsigned long long)s_piv);
+        atomicAdd(&ctr->x_cached, (unsigned long long)s_dec); atomicAdd(&ctr->xtheta_lps, (unsigned long long)s_dec);
+        atomicAdd(&ctr->xq_thread, s_dec);
+    }
 }
 
 // k_xq_grouped: the same decisions with the parent's dictionary read ONCE per parent.  The candidates of a level are

@@ -324,6 +324,9 @@ struct mpc_handle {
     int no_rbox = 0;          // MPC_NO_RBOX=1: no bounding-box screen of the region rows in k_region2 (A/B)
     int no_rsplit = 0;        // MPC_NO_RSPLIT=1: one wavefront per candidate in k_region2 whatever the load (A/B)
     int no_xquick = 0;        // MPC_NO_XQUICK=1: no quick (x,theta) test on the last level (A/B)
+    int xqg_overlap = 0;      // MPC_XQG_OVERLAP=1: the region stage runs under the (x,theta) stage also when the quick test is the grouped one (experiment)
+    int xq_thread = 0;        // MPC_XQ_THREAD=1: the quick test with a one-thread-per-candidate first pass k_xq_thread (round 5; measured zero-sum on the bench configurations, off by default)
+    long long n_xq_thread = 0; float ms_xq_thread = 0;   // the last level run: candidates that pass decided, its time
     bool fetch_nowait = false; // mpc_level_regions_slots_nowait: even the integer heads are only queued
     bool skip_small = false;  // mpc_level_run_batch: this level already went through the no-round-trip launches and has to be repeated classically
     size_t o_elim[6] = {0, 0, 0, 0, 0, 0};   // offsets of Wr, UVr, AATr, Me, Ne, gE in `blocks` (mpc_program_block)
@@ -335,7 +338,7 @@ struct mpc_handle {
     long long n_needx = 0;
     DevProblem Pf{};          // view for k_verdict2 (small LDS layout: no tableau)
     int lds_f = 0, grid_f = 0;
-    DevBuf retry_list, theta_list, vretry_list, status_tmp, part_counts, part_lists, kept_g, done_g, pf_dev, pr2_dev, headd, headi, epool, facet_flags, kkt_code, kkt_L, theta_blocks, xq_groups;
+    DevBuf retry_list, theta_list, vretry_list, status_tmp, part_counts, part_lists, kept_g, done_g, pf_dev, pr2_dev, headd, headi, epool, facet_flags, kkt_code, kkt_L, theta_blocks, xq_groups, xq_list;
     ThetaArgs targs{};
     // (x,theta) dictionary cache: [0]/[1] ping-pong between the level being read (parents) and the level being written
     DevBuf dict_d[2], dict_i[2], dict_stored[2], parent_slot, parent_slot_next;
@@ -419,7 +422,7 @@ struct mpc_handle {
     } g;
     hipEvent_t ev_hi = nullptr;   // completion of the head_i copy of an asynchronous slot fetch
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
-    hipEvent_t kev[10] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // around k_theta2 / the main k_x2 launch / k_region2 / k_kkt_thread / k_xq
+    hipEvent_t kev[12] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // around k_theta2 / the main k_x2 launch / k_region2 / k_kkt_thread / k_xq / k_xq_thread
 };
 
 namespace {
@@ -523,7 +526,7 @@ void lu_solve_host(const std::vector<double> &LU, const std::vector<int> &perm, 
 // graveyard_flush, which the level paths call behind their closing synchronisation (all streams of the handle have been joined by then)
 static std::vector<DevBuf *> level_buffers(mpc_handle *h) {
     return {&h->frontier, &h->children, &h->status, &h->pruned, &h->flag, &h->pos, &h->opt_list, &h->childmask, &h->count, &h->offset, &h->recd, &h->reci,
-            &h->sums, &h->retry_list, &h->headd, &h->headi, &h->epool, &h->facet_flags, &h->kkt_code, &h->kkt_L, &h->xq_groups, &h->theta_list, &h->vretry_list,
+            &h->sums, &h->retry_list, &h->headd, &h->headi, &h->epool, &h->facet_flags, &h->kkt_code, &h->kkt_L, &h->xq_groups, &h->xq_list, &h->theta_list, &h->vretry_list,
             &h->status_tmp, &h->part_counts, &h->part_lists, &h->kept_g, &h->done_g, &h->dict_d[0], &h->dict_d[1], &h->dict_i[0], &h->dict_i[1],
             &h->dict_stored[0], &h->dict_stored[1], &h->parent_slot, &h->parent_slot_next};
 }
@@ -604,6 +607,8 @@ static int create_fill(const mpc_problem *p, int32_t device, void *stream, mpc_h
     { const char *ev = std::getenv("MPC_NO_XQGROUP"); h->no_xqgroup = ev && ev[0] == '1'; }
     { const char *ev = std::getenv("MPC_FORCE_XQGROUP"); h->force_xqgroup = ev && ev[0] == '1'; }
     { const char *ev = std::getenv("MPC_NO_XQUICK"); h->no_xquick = ev && ev[0] == '1'; }
+    { const char *ev = std::getenv("MPC_XQ_THREAD"); h->xq_thread = ev && ev[0] == '1'; }
+    { const char *ev = std::getenv("MPC_XQG_OVERLAP"); h->xqg_overlap = ev && ev[0] == '1'; }
     { const char *ev = std::getenv("MPC_NO_KKT_THREAD"); h->no_kkt_thread = ev ? std::atoi(ev) : 0; }   // 2: only the small-level path
     { const char *ev = std::getenv("MPC_NO_ROVERLAP"); h->no_roverlap = ev && ev[0] == '1'; }
     { const char *ev = std::getenv("MPC_TEST_LATE"); h->test_late = ev ? std::atoi(ev) : 0; }
@@ -1041,7 +1046,7 @@ int mpc_destroy(mpc_handle *h) {
     if (h->stream3) (void)hipStreamSynchronize(h->stream3);
     graveyard_flush(h);
     for (DevBuf *b : {&h->blocks, &h->iblocks, &h->frontier, &h->children, &h->status, &h->pruned, &h->flag, &h->pos, &h->opt_list,
-                      &h->childmask, &h->count, &h->offset, &h->recd, &h->reci, &h->ctr, &h->scratch, &h->sums, &h->retry_list, &h->pf_dev, &h->pr2_dev, &h->headd, &h->headi, &h->epool, &h->facet_flags, &h->kkt_code, &h->kkt_L, &h->theta_blocks, &h->xq_groups, &h->theta_list, &h->vretry_list, &h->status_tmp, &h->part_counts, &h->part_lists, &h->kept_g, &h->done_g, &h->dict_d[0], &h->dict_d[1], &h->dict_i[0], &h->dict_i[1],
+                      &h->childmask, &h->count, &h->offset, &h->recd, &h->reci, &h->ctr, &h->scratch, &h->sums, &h->retry_list, &h->pf_dev, &h->pr2_dev, &h->headd, &h->headi, &h->epool, &h->facet_flags, &h->kkt_code, &h->kkt_L, &h->theta_blocks, &h->xq_groups, &h->xq_list, &h->theta_list, &h->vretry_list, &h->status_tmp, &h->part_counts, &h->part_lists, &h->kept_g, &h->done_g, &h->dict_d[0], &h->dict_d[1], &h->dict_i[0], &h->dict_i[1],
                       &h->dict_stored[0], &h->dict_stored[1], &h->parent_slot, &h->parent_slot_next, &h->dcnt}) b->release();
     if (h->tot_host) { (void)host_pool_give(h->tot_host); h->tot_host = h->tot_dev = nullptr; }
     for (HostBuf *b : {&h->st_list, &h->st_status, &h->st_hd, &h->st_hi, &h->st_pool, &h->st_fxd, &h->st_fxi, &h->st_rlist, &h->st_flags}) b->release();
@@ -1077,7 +1082,7 @@ int mpc_trim(mpc_handle *h) {
     graveyard_flush(h);
     stream_release(h);
     for (DevBuf *b : {&h->frontier, &h->children, &h->status, &h->pruned, &h->flag, &h->pos, &h->opt_list, &h->childmask, &h->count, &h->offset, &h->recd, &h->reci,
-                      &h->sums, &h->retry_list, &h->headd, &h->headi, &h->epool, &h->facet_flags, &h->kkt_code, &h->kkt_L, &h->xq_groups, &h->theta_list, &h->vretry_list,
+                      &h->sums, &h->retry_list, &h->headd, &h->headi, &h->epool, &h->facet_flags, &h->kkt_code, &h->kkt_L, &h->xq_groups, &h->xq_list, &h->theta_list, &h->vretry_list,
                       &h->status_tmp, &h->part_counts, &h->part_lists, &h->kept_g, &h->done_g, &h->dict_d[0], &h->dict_d[1], &h->dict_i[0], &h->dict_i[1],
                       &h->dict_stored[0], &h->dict_stored[1], &h->parent_slot, &h->parent_slot_next}) b->release();
     for (HostBuf *b : {&h->st_list, &h->st_status, &h->st_hd, &h->st_hi, &h->st_pool, &h->st_fxd, &h->st_fxi, &h->st_rlist, &h->st_flags}) b->release();
@@ -1941,6 +1946,8 @@ static int level_run_impl(mpc_handle *h, int32_t gen_children, int32_t flags, mp
     float ms[3] = {0, 0, 0}, kms[5] = {0, 0, 0, 0, 0};
     bool kernel_timed[5] = {false, false, false, false, false};
     long long n_x_items = 0, n_theta_items = 0, n_xq_items = 0;
+    bool xq_thread_timed = false;
+    h->n_xq_thread = 0; h->ms_xq_thread = 0;
     if (n > 0) {
         const size_t nn = (size_t)n;
         HIP_TRY(h, h->status.ensure(nn, st));
@@ -2304,7 +2311,7 @@ static int level_run_impl(mpc_handle *h, int32_t gen_children, int32_t flags, mp
             const bool quick_test = cntA[3] > 0 && !(flags & MPC_LEVEL_GRAPH) && !h->storing && dc.parent_slot && !h->no_xquick;
             const bool use_grouped = quick_test && !h->no_xqgroup && ((h->last_level_n > 0 && (long long)cntA[3] >= 10 * h->last_level_n) || h->force_xqgroup) &&
                                      cntA[3] >= 4096 && lds_q <= 64 * 1024;
-            if (!h->no_roverlap && !h->theta_open && cntA[2] > 0 && h->fast_r >= 0 && !(flags & MPC_LEVEL_GRAPH) && x_items >= h->roverlap_min && !use_grouped) {
+            if (!h->no_roverlap && !h->theta_open && cntA[2] > 0 && h->fast_r >= 0 && !(flags & MPC_LEVEL_GRAPH) && x_items >= h->roverlap_min && (!use_grouped || h->xqg_overlap)) {
                 // Candidates that turn out optimal later -- re-solved doubtful ones: the n_early of the theta stage, rarely one of
                 // the (x,theta) stage -- get spare slots behind the launch's and take the LDS-engine route of the candidates
                 // k_region2 gives up on.  The spare slots cover every re-solved candidate of the theta stage plus up to 1,024 of the
@@ -2363,29 +2370,52 @@ static int level_run_impl(mpc_handle *h, int32_t gen_children, int32_t flags, mp
                 // last level: decisions only -- the quick test on three vectors of the parent's dictionary first
                 DictCache dq = dc;
                 const long long grid_q = (long long)h->n_cu * h->xq_wpc;
-                dq.chunk = (int)std::max<long long>(1, std::min<long long>(16, n_needx / (grid_q * 4)));
-                const dim3 gg((unsigned)std::min<long long>((n_needx + dq.chunk - 1) / dq.chunk, grid_q)), bb(64);
                 HIP_TRY(h, hipEventRecord(h->kev[8], st));
                 n_xq_items = n_needx;
+                // Optional first pass, one THREAD per candidate (k_xq_thread, round 5, MPC_XQ_THREAD=1): whatever the first ratio test of
+                // the hinted column decides.  What it leaves open is compacted (length on the device) and goes to the wavefront kernel
+                // unchanged.  Off by default: it decides 67 % of config 4's last level in 0.19 ms alone / 0.38 ms beside the region
+                // kernel, and the wavefront kernel gets exactly that much faster -- its time is the OTHER third, the candidates that
+                // need two to sixteen dependent pivots (config 4 level 5: 2.36 ms with, 2.35 without; config 3 4.90 / 4.79).
+                const int32_t *xq_list = needx_list;
+                int32_t xq_n = n_needx;
+                bool xqt_lean = false;
+                if (h->xq_thread && n_needx >= 4096) {
+                    const unsigned gt = (unsigned)std::min<long long>(((long long)n_needx + 255) / 256, (long long)h->n_cu * 8);
+                    HIP_TRY(h, hipEventRecord(h->kev[10], st));
+                    hipLaunchKernelGGL(k_xq_thread, dim3(gt), dim3(256), 0, st, pf, fr, k, needx_list, n_needx, stp, ctr, dq, nxc);
+                    HIP_TRY(h, hipEventRecord(h->kev[11], st));
+                    HIP_TRY(h, hipGetLastError());
+                    xq_thread_timed = true;
+                    if (lean && !use_grouped) { int rcs = compact(ST_NEEDX, ST_NEEDX_SING, nullptr, dcnt + 9); if (rcs) return rcs; xqt_lean = true; }   // (the grouped form sizes its group scan on the host)
+                    else { int32_t n_left = 0; int rcs = compact(ST_NEEDX, ST_NEEDX_SING, &n_left); if (rcs) return rcs; xq_n = n_left; }
+                    HIP_TRY(h, h->xq_list.ensure(nn * sizeof(int32_t), st));
+                    std::swap(h->xq_list, h->retry_list);   // compact() filled retry_list; keep it as the wavefront kernel's list
+                    xq_list = h->xq_list.as<int32_t>();
+                }
+                dq.chunk = (int)std::max<long long>(1, std::min<long long>(16, xq_n / (grid_q * 4)));
+                if (xqt_lean) { dq.n_list_dev = dcnt + 9; dq.chunk = 0; }   // length and chunk rule on the device
+                const dim3 gg((unsigned)std::max<long long>(1, std::min<long long>(xqt_lean ? (long long)xq_n : ((long long)xq_n + dq.chunk - 1) / dq.chunk, grid_q))), bb(64);
                 // Grouped by parent when a parent has many open children (config 3: 12.6 per parent, -0.5 ms; config 4: 7.1 per
                 // parent, where the per-candidate reads of k_xq are cheaper than one 16 KB copy per parent, +0.45 ms): threshold 10.
-                if (use_grouped) {
+                if (use_grouped && xq_n > 0) {
                     // grouped by parent: the record is staged in LDS once per parent (k_xq_grouped)
-                    HIP_TRY(h, h->xq_groups.ensure((size_t)n_needx * sizeof(int32_t), st));
-                    const int nbq = (n_needx + 255) / 256;
-                    hipLaunchKernelGGL(k_group_flags, dim3(nbq), dim3(256), 0, st, needx_list, n_needx, dq.parent_slot, h->flag.as<int32_t>());
-                    { int rcs = launch_scan(h, h->flag.as<int32_t>(), h->pos.as<int32_t>(), n_needx, h->scratch.as<int32_t>()); if (rcs) return rcs; }
-                    hipLaunchKernelGGL(k_scatter_index, dim3(nbq), dim3(256), 0, st, h->flag.as<int32_t>(), h->pos.as<int32_t>(), (long long)n_needx, h->xq_groups.as<int32_t>());
+                    HIP_TRY(h, h->xq_groups.ensure((size_t)xq_n * sizeof(int32_t), st));
+                    const int nbq = (xq_n + 255) / 256;
+                    hipLaunchKernelGGL(k_group_flags, dim3(nbq), dim3(256), 0, st, xq_list, xq_n, dq.parent_slot, h->flag.as<int32_t>());
+                    { int rcs = launch_scan(h, h->flag.as<int32_t>(), h->pos.as<int32_t>(), xq_n, h->scratch.as<int32_t>()); if (rcs) return rcs; }
+                    hipLaunchKernelGGL(k_scatter_index, dim3(nbq), dim3(256), 0, st, h->flag.as<int32_t>(), h->pos.as<int32_t>(), (long long)xq_n, h->xq_groups.as<int32_t>());
                     const int per_cu = std::max(1, std::min(h->xqg_per_cu, (int)((160 * 1024) / (lds_q + 64))));
-                    const dim3 gq((unsigned)std::min<long long>(n_needx, (long long)h->n_cu * per_cu)), bq(256);
+                    const dim3 gq((unsigned)std::min<long long>(xq_n, (long long)h->n_cu * per_cu)), bq(256);
                     if (lds_q > 48 * 1024) {
                         HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void *>(k_xq_grouped<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_q));
                         HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void *>(k_xq_grouped<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_q));
                     }
-                    if (h->fast_x & 1) hipLaunchKernelGGL((k_xq_grouped<2>), gq, bq, lds_q, st, pf, fr, k, needx_list, n_needx, stp, ctr, dq, nxc, h->xq_groups.as<int32_t>(), h->scratch.as<int32_t>());
-                    else hipLaunchKernelGGL((k_xq_grouped<1>), gq, bq, lds_q, st, pf, fr, k, needx_list, n_needx, stp, ctr, dq, nxc, h->xq_groups.as<int32_t>(), h->scratch.as<int32_t>());
-                } else if (h->fast_x & 1) hipLaunchKernelGGL((k_xq<2>), gg, bb, 0, st, pf, fr, k, needx_list, n_needx, stp, ctr, dq, nxc);
-                else hipLaunchKernelGGL((k_xq<1>), gg, bb, 0, st, pf, fr, k, needx_list, n_needx, stp, ctr, dq, nxc);
+                    if (h->fast_x & 1) hipLaunchKernelGGL((k_xq_grouped<2>), gq, bq, lds_q, st, pf, fr, k, xq_list, xq_n, stp, ctr, dq, nxc, h->xq_groups.as<int32_t>(), h->scratch.as<int32_t>());
+                    else hipLaunchKernelGGL((k_xq_grouped<1>), gq, bq, lds_q, st, pf, fr, k, xq_list, xq_n, stp, ctr, dq, nxc, h->xq_groups.as<int32_t>(), h->scratch.as<int32_t>());
+                } else if (xq_n == 0) { /* the first pass decided everything (host-known length) */ }
+                else if (h->fast_x & 1) hipLaunchKernelGGL((k_xq<2>), gg, bb, 0, st, pf, fr, k, xq_list, xq_n, stp, ctr, dq, nxc);
+                else hipLaunchKernelGGL((k_xq<1>), gg, bb, 0, st, pf, fr, k, xq_list, xq_n, stp, ctr, dq, nxc);
                 HIP_TRY(h, hipEventRecord(h->kev[9], st));
                 kernel_timed[4] = true;
                 HIP_TRY(h, hipGetLastError());
@@ -2403,6 +2433,10 @@ static int level_run_impl(mpc_handle *h, int32_t gen_children, int32_t flags, mp
                 kernel_timed[1] = true;
                 n_x_items = n_needx + dc.n_pre1 + dc.n_pre2;
             }
+            // A storing level without (x,theta) items has not flushed `prep` (launch_x does): the clear of dict_stored[dict_cur] queued in it
+            // must still run before k_children_write reads that array (stale "stored" bytes of two levels ago would send a child
+            // to another candidate's dictionary).
+            { int rcs = prep_flush(); if (rcs) return rcs; }
             // doubtful candidates of the (x,theta) stage (rare) take the same route on the main stream
             int32_t n_retry = 0;
             if (n_early > 0) {
@@ -2529,6 +2563,7 @@ static int level_run_impl(mpc_handle *h, int32_t gen_children, int32_t flags, mp
             { int rcs = queue_tail(); if (rcs) return rcs; }
             HIP_TRY(h, hipStreamSynchronize(st));
         }
+        if (prep_any || rprep_any) return fail(h, MPC_ERR_STATE, "level_run: a queued preparation (clear / copy) was never issued");
         h->r3_dirty = false;   // the main stream waited for ev_rjoin before the second partition
         std::memcpy(&host_ctr, h->tot_host + 16, sizeof(LevelCounters));
         {
@@ -2541,6 +2576,7 @@ static int level_run_impl(mpc_handle *h, int32_t gen_children, int32_t flags, mp
         HIP_TRY(h, hipEventElapsedTime(&ms[1], h->ev[1], h->ev[2]));
         HIP_TRY(h, hipEventElapsedTime(&ms[2], h->ev[2], h->ev[3]));
         for (int i = 0; i < 5; ++i) if (kernel_timed[i]) HIP_TRY(h, hipEventElapsedTime(&kms[i], h->kev[2 * i], h->kev[2 * i + 1]));
+        if (xq_thread_timed) { HIP_TRY(h, hipEventElapsedTime(&h->ms_xq_thread, h->kev[10], h->kev[11])); h->n_xq_thread = host_ctr.xq_thread; }
         if (kernel_timed[2] && host_ctr.r2_t1 > ~host_ctr.r2_not_t0 && h->wall_khz > 0)   // k_region2 times itself (see the kernel)
             kms[2] = (float)((double)(host_ctr.r2_t1 - ~host_ctr.r2_not_t0) / (double)h->wall_khz);
         if (h->debug_cycles)
@@ -2577,6 +2613,7 @@ static int level_run_impl(mpc_handle *h, int32_t gen_children, int32_t flags, mp
         stats->ms_kkt = kms[3]; stats->ms_xq = kms[4];
         stats->n_xq_items = n_xq_items; stats->xq_pivots = (int64_t)host_ctr.xq_pivots;
         stats->xq_record_ints = h->dict_stride_i; stats->xq_record_rows = h->Pf.n_d0r; stats->xq_record_cols = h->Pf.n_d0c + 1;
+        stats->n_xq_thread = h->n_xq_thread; stats->ms_xq_thread = h->ms_xq_thread;
         stats->n_region_rows = h->n_erows;
         stats->n_opt = h->n_opt;
         // bytes of one dictionary record that are actually moved: the used columns (value + D0 columns) and the integer part
@@ -2622,6 +2659,14 @@ static void worker_base_check(mpc_handle *h) {
 static void solve_release(mpc_handle *h) {
     if (!h->sv_levels) return;
     const int nl = h->sv_n.load(std::memory_order_acquire);
+    // a level's k_fetch_slots is queued behind that level's closing synchronisation: a block nobody took may still be written to
+    // (abandoned solve restarted at once) -- the stream is drained before such a block goes back to the pool
+    bool pending = false;
+    for (int i = 0; i < nl; ++i) {
+        const auto &lv = h->sv_levels[i];
+        if (!lv.handed && lv.ready_flag && !__atomic_load_n(lv.ready_flag, __ATOMIC_ACQUIRE)) pending = true;
+    }
+    if (pending && h->stream) (void)hipStreamSynchronize(h->stream);
     for (int i = 0; i < nl; ++i) {
         auto &lv = h->sv_levels[i];
         if (!lv.handed) { if (lv.hd) (void)host_pool_give(lv.hd); if (lv.hi) (void)host_pool_give(lv.hi); if (lv.er) (void)host_pool_give(lv.er); }
@@ -2843,7 +2888,17 @@ int mpc_solve_level(mpc_handle *h, int32_t level, mpc_solve_level_info *info) {
     if (lv.mode == 2 && lv.ready_flag) {
         // the arrays are being written by k_fetch_slots on the handle's stream: its last workgroup raises the flag
         for (unsigned spin = 0; !__atomic_load_n(lv.ready_flag, __ATOMIC_ACQUIRE); ++spin) {
-            if ((spin & 4095u) == 4095u && h->sv_finished.load(std::memory_order_acquire) && h->sv_rc != MPC_OK) { info->mode = -1; return h->sv_rc; }
+            if ((spin & 4095u) == 4095u && h->sv_finished.load(std::memory_order_acquire)) {
+                if (h->sv_rc != MPC_OK) { info->mode = -1; return h->sv_rc; }
+                // the loop has ended without an error: the copy kernel is queued on the handle's stream -- once that stream has drained the
+                // flag is either up or will never be (a launch that failed later than hipGetLastError could see)
+                (void)hipSetDevice(h->device);
+                const hipError_t es = hipStreamSynchronize(h->stream);
+                if (es != hipSuccess || !__atomic_load_n(lv.ready_flag, __ATOMIC_ACQUIRE)) {
+                    info->mode = -1;
+                    return fail(h, es != hipSuccess ? MPC_ERR_HIP : MPC_ERR_STATE, "mpc_solve_level: the solve ended without completing this level's record copy");
+                }
+            }
             __builtin_ia32_pause();
         }
     }
@@ -3178,6 +3233,16 @@ int mpc_level_stream_fixup(mpc_handle *h, double *head_d, int32_t *head_i, doubl
     int64_t ns = 0;
     return level_regions_slots_impl(h, head_d, head_i, h->so.n_slots, erows, h->so.cap_rows, &ns, n_rows, false, true);
 }
+#ifdef MPC_XQ_HIST
+// debug build only: histogram of k_xq's decisions, [outcome + 1][ratio tests passed]; reset after reading
+int mpc_debug_xq_hist(unsigned long long *out) {
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_xq_hist), 64 * sizeof(unsigned long long)) != hipSuccess) return MPC_ERR_HIP;
+    if (hipMemcpyFromSymbol(out + 64, HIP_SYMBOL(g_xq_hist2), 64 * sizeof(unsigned long long)) != hipSuccess) return MPC_ERR_HIP;
+    unsigned long long z[64] = {0};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_xq_hist2), z, sizeof(z)) != hipSuccess) return MPC_ERR_HIP;
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_xq_hist), z, sizeof(z)) == hipSuccess ? MPC_OK : MPC_ERR_HIP;
+}
+#endif
 int mpc_sync(mpc_handle *h) {
     if (!h) return MPC_ERR_INVALID;
     HIP_TRY(h, hipSetDevice(h->device));

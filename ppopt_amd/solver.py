@@ -91,24 +91,44 @@ class Solver:
             else:
                 groups.setdefault(tuple(numpy.shape(A)), []).append(r)
         for (m, n), members in groups.items():
-            counts = [len(requests[r][2]) for r in members]
-            total = sum(counts)
-            A3 = numpy.empty((total, m, n))
-            b2 = numpy.empty((total, m))
-            flags = numpy.zeros((total, m), dtype=numpy.uint8)
-            pos = 0
-            for r, cnt in zip(members, counts):
-                A, b, eqs = requests[r]
-                A3[pos:pos + cnt] = A
-                b2[pos:pos + cnt] = numpy.asarray(b, dtype=numpy.float64).reshape(-1)
-                for j, eq in enumerate(eqs):
-                    flags[pos + j, list(eq)] = 1
-                pos += cnt
-            status, _, _, _ = _lib.lp_solve_batch(A3, b2, None, flags, device=self.device, want_x=False)
-            pos = 0
-            for r, cnt in zip(members, counts):
-                out[r] = status[pos:pos + cnt] == _lib.LP_OPTIMAL
-                pos += cnt
+            # every LP of a device batch carries its own copy of A (the families differ in A): the batches are cut by the same host-byte
+            # budget as the fixation batches below, so many binaries / large sub-programs never make one allocation of gigabytes
+            per_lp = 8 * (m * n + m) + m
+            budget = max(1, int(self.MILP_BATCH_BYTES // per_lp))
+            # (family, first equality set, number of sets) pieces, packed into batches of at most `budget` LPs
+            batches: List[List[tuple]] = [[]]
+            room = budget
+            for r in members:
+                cnt, first = len(requests[r][2]), 0
+                out[r] = numpy.empty(cnt, dtype=bool)
+                while first < cnt:
+                    take = min(cnt - first, room)
+                    batches[-1].append((r, first, take))
+                    first += take
+                    room -= take
+                    if room == 0:
+                        batches.append([])
+                        room = budget
+            for pieces in batches:
+                total = sum(cnt for _, _, cnt in pieces)
+                if total == 0:
+                    continue
+                A3 = numpy.empty((total, m, n))
+                b2 = numpy.empty((total, m))
+                flags = numpy.zeros((total, m), dtype=numpy.uint8)
+                pos = 0
+                for r, first, cnt in pieces:
+                    A, b, eqs = requests[r]
+                    A3[pos:pos + cnt] = A
+                    b2[pos:pos + cnt] = numpy.asarray(b, dtype=numpy.float64).reshape(-1)
+                    for j in range(cnt):
+                        flags[pos + j, list(eqs[first + j])] = 1
+                    pos += cnt
+                status, _, _, _ = _lib.lp_solve_batch(A3, b2, None, flags, device=self.device, want_x=False)
+                pos = 0
+                for r, first, cnt in pieces:
+                    out[r][first:first + cnt] = status[pos:pos + cnt] == _lib.LP_OPTIMAL
+                    pos += cnt
         return out
 
     # ---- binary MILPs as LP batches (solver.py:248-282; the reference hands these to Gurobi) -------------------------

@@ -422,6 +422,32 @@ def test_device_setup_and_host_setup_give_the_same_solve(name, monkeypatch):
             assert rel_err(getattr(r1, fld), getattr(r2, fld)) <= COEF_TOL, (key, fld, rel_err(getattr(r1, fld), getattr(r2, fld)))
 
 
+# ---- the quick test's optional first pass with one thread per candidate (k_xq_thread, MPC_XQ_THREAD=1) -----------------------------
+@pytest.mark.parametrize('name', ['c4_rand_20_8_20_s0', 'c3_quadtank_n10'])
+def test_thread_pass_of_the_quick_test_changes_no_verdict(name, monkeypatch):
+    """k_xq_thread decides what the first ratio test of the hinted column decides (two thirds of config 4's last level) with the
+    arithmetic of xq_decide; everything else goes to the wavefront kernel unchanged.  Every status of every level must be the one the
+    default path gives, and the pass must really have decided candidates on the last level."""
+    from test_gpu_parity import engine_from_golden, run_levels
+    g = load_golden(name)
+    nl = int(g['n_levels']) + 1
+    runs = []
+    for env in ({}, {'MPC_XQ_THREAD': '1'}):
+        with monkeypatch.context() as m:
+            for key, val in env.items():
+                m.setenv(key, val)
+            eng = engine_from_golden(g)
+            levels, regions = run_levels(eng, nl)
+            runs.append(([(c.copy(), s.copy(), int(st.n_children), int(st.n_xq_thread)) for c, s, st in levels], sorted(tuple(r.active_set) for r in regions)))
+            eng.close()
+    (la, ra), (lb, rb) = runs
+    assert len(la) == len(lb) and ra == rb
+    for (ca, sa, na, ta), (cb, sb, nb, tb) in zip(la, lb):
+        assert numpy.array_equal(ca, cb) and numpy.array_equal(sa, sb) and na == nb
+        assert ta == 0
+    assert lb[-1][3] > 0.1 * len(lb[-1][0]), 'the thread pass decided nothing on the last level'
+
+
 # ---- levels without host round trips (level_run_small) and lean large levels -------------------------------------------------
 @pytest.mark.parametrize('name', ['rand_6_3_12_s1', 'c2_dblint_n5', 'quadtank_n3', 'c4_rand_20_8_20_s0', 'mplp_rand_5_3_12_s2'])
 def test_levels_without_host_round_trips_equal_the_classic_path(name, monkeypatch):

@@ -13,8 +13,10 @@ best = None
 for _ in range(reps):
     prof = []
     t = time.perf_counter(); sol = m.solve(prog, max_levels=ml, profile=prof); dt = (time.perf_counter() - t) * 1e3
-    row = (dt, [round(p.get('ms_wall', 0), 3) for p in prof if p['depth'] > 0], [round(p.get('ms_xq', 0) + p.get('ms_x', 0), 3) for p in prof if p['depth'] > 0],
-           [round(p.get('ms_region2', 0), 3) for p in prof if p['depth'] > 0], [round(p.get('ms_theta', 0), 3) for p in prof if p['depth'] > 0], [round(p.get('ms_kkt', 0), 3) for p in prof if p['depth'] > 0])
+    lv = [p for p in prof if p['depth'] > 0]
+    row = (dt, [round(p.get('ms_wall', 0), 3) for p in lv], [round(p.get('ms_xq', 0) + p.get('ms_x', 0), 3) for p in lv],
+           [round(p.get('ms_region2', 0), 3) for p in lv], [round(p.get('ms_theta', 0), 3) for p in lv], [round(p.get('ms_kkt', 0), 3) for p in lv],
+           [(round(p.get('ms_xq_thread', 0), 3), p.get('n_xq_thread', 0), p.get('n_xq_items', 0)) for p in lv if p.get('n_xq_items', 0)])
     if best is None or row[0] < best[0]:
         best = row
-print('%s solve %.3f ms; level walls %s (sum %.3f); x stage %s; region2 %s; theta %s; kkt %s; regions %d' % (wl, best[0], best[1], sum(best[1]), best[2], best[3], best[4], best[5], len(sol.critical_regions)))
+print('%s solve %.3f ms; level walls %s (sum %.3f); x stage %s; region2 %s; theta %s; kkt %s; xq thread pass (ms, decided, of) %s; regions %d' % (wl, best[0], best[1], sum(best[1]), best[2], best[3], best[4], best[5], best[6], len(sol.critical_regions)))
