@@ -75,7 +75,7 @@ struct LevelCounters {
     unsigned long long r_box;       // k_region2: region rows removed by the bounding-box screen
     unsigned long long r2_not_t0, r2_t1;  // k_region2: ~(wall clock of the first wavefront's start), wall clock of the last one's end
     unsigned long long xq_pivots;   // k_xq / k_xq_grouped: product-form iterations executed (each reads one column and one row of the parent's record)
-    unsigned int xq_thread, pad_xq;  // candidates of the last level's quick test decided by k_xq_thread (round 5)
+    unsigned int xq_thread, pad_xq;  // candidates of the last level's quick test decided by k_xq_thread (round 5); pad_xq: ... of which from another parent's record
 };
 
 struct Smem {

@@ -554,7 +554,12 @@ MPC_GLOBAL void MPC_LB(64, (SLOTS >= 2 ? (NT <= 4 ? TH_WAVES_S2 : 2) : (NT >= 8 
 // reads and activates ONE row instead of starting from D0 and activating all k.  The kernel then streams ~2 x 9 KB per
 // candidate (config 4) and is bound by HBM bandwidth rather than by pivots.
 // dict layout per slot: doubles [NXC][mr] (column j of row i at j*mr + i);
-// ints var[mr] kind[mr] cv[NXC] alive growth_hi growth_lo
+// ints var[mr] kind[mr] cv[NXC] alive growth_hi growth_lo pad | ineq[4] | pos bytes[n_c]   (round 5: the last two)
+//   ineq  bit i = row i takes part in ratio tests (kind RK_INEQ)
+//   pos   where the slack of program constraint c sits: 0..127 basic in that row, 128 + j nonbasic in column j; an entry is only
+//         meaningful if the row / column it names really holds that variable (entries of absent variables are stale and fail that check)
+__host__ __device__ inline int dict_ints_head(int mr, int NXC) { return 2 * mr + NXC + 4; }
+__host__ __device__ inline long long dict_ints(int mr, int NXC, int n_c) { return dict_ints_head(mr, NXC) + 4 + (n_c + 3) / 4; }
 struct DictCache {
     const int32_t *parent_slot;   // per candidate of this level (nullptr: no cache to read)
     const double *prev_d; const int32_t *prev_i;
@@ -820,107 +825,187 @@ MPC_GLOBAL void MPC_LB(64, XQ_WAVES) k_xq(const DevProblem *__restrict__ Pg, con
 // have given it; everything else -- a pivot is needed, an unbounded direction, a doubtful pivot, no parent record -- keeps its
 // NEEDX status and goes on to k_xq unchanged.  ~20 wave-instructions per row of the record for 64 candidates, against ~150-200
 // per candidate in k_xq.
-MPC_GLOBAL void MPC_LB(256) k_xq_thread(const DevProblem *__restrict__ Pg, const int32_t *__restrict__ cands, int k,
-                                        const int32_t *__restrict__ list, int n_list, uint8_t *__restrict__ status,
-                                        LevelCounters *__restrict__ ctr, DictCache dc, int NXC) {
-    const DevProblem &P = *Pg;
-    const int nv = P.n_x + P.n_t, mr = P.n_d0r, ncol = P.n_d0c + 1;
-    if (dc.n_list_dev) n_list = *dc.n_list_dev;
-    unsigned int n_dec = 0, n_piv = 0;   // per thread: candidates decided / decided by the ratio test (one pivot in k_xq's count)
-    for (long long w = (long long)blockIdx.x * 256 + threadIdx.x; w < n_list; w += (long long)gridDim.x * 256) {
-        const int c = list[w];
-        const int ps = dc.parent_slot[c];
-        if (ps < 0) continue;
-        const int32_t *pi = dc.prev_i + (size_t)ps * dc.stride_i;
-        const double *pd = dc.prev_d + (size_t)ps * dc.stride_d;
-        const int v = nv + cands[(size_t)c * k + (k - 1)];
-        const unsigned al = (unsigned)pi[2 * mr + NXC];
-        int feas = -1;   // 1 feasible, 0 infeasible, -1 left to k_xq
-        // the new row's slack is a live nonbasic column of the parent's dictionary: it is zero at the parent's vertex
-#pragma unroll 8
-        for (int j = 1; j < ncol; ++j) if (pi[2 * mr + j] == v && ((al >> j) & 1u)) feas = 1;
-        int row = -1, q0 = 0;
-        if (feas < 0) {
-#pragma unroll 8
-            for (int i = mr - 1; i >= 0; --i) {
-                const int kraw = pi[mr + i];
-                if (pi[i] == v && (kraw & 0xff) == RK_INEQ) { row = i; q0 = kraw >> 8; }   // (lowest such row, as xq_decide's ballots)
-            }
+// the test against ONE parent record: 1 feasible, 0 infeasible, -1 open; *by_test: decided by the ratio test (one pivot in k_xq's count)
+__device__ __forceinline__ int xq_first_test(const double *__restrict__ pd, const int32_t *__restrict__ pi, int mr, int ncol, int NXC, int nv, int v, bool *by_test) {
+    *by_test = false;
+    const int32_t *pm = pi + dict_ints_head(mr, NXC);
+    const int p = reinterpret_cast<const uint8_t *>(pm + 4)[v - nv];   // where the record says this slack sits (checked below)
+    if (p >= 128) {
+        // a live nonbasic column of the parent's dictionary: the slack is zero at the parent's vertex
+        const int j = p - 128;
+        if (j >= 1 && j < ncol && pi[2 * mr + j] == v && (((unsigned)pi[2 * mr + NXC] >> j) & 1u)) return 1;
+        return -1;
+    }
+    if (p >= mr || pi[p] != v) return -1;
+    const int kraw = pi[mr + p];
+    if ((kraw & 0xff) != RK_INEQ) return -1;
+    const int row = p, q0 = kraw >> 8;
+    const double brow = pd[row];
+    if (brow <= TOL_FEAS) return 1;
+    if (q0 <= 0) return 0;
+    // Four rows per trip, each vector fetched with 16-byte loads (records are 8-byte aligned, the hardware takes unaligned
+    // global accesses): a lane's column is ITS OWN walk -- 64 distinct lines per wave-level load -- and the kernel is bound
+    // by the number of such requests, not by their bytes (tools/ubench/xq_thread_bench.hip: one 8-byte load per row 0.57 ms
+    // for config 4's level, seven rows issued together 0.28, four rows in two 16-byte loads 0.19)
+    struct __attribute__((packed, aligned(8))) D4 { double v[4]; };
+    struct __attribute__((packed, aligned(4))) I4 { int v[4]; };
+    const I4 mk = *reinterpret_cast<const I4 *>(pm);
+    const double *col = pd + (size_t)q0 * mr;
+    float cmf = 0.0f;
+    double tmax = INFINITY, ratio_row = 0.0, a_row = 0.0;
+    bool elig_row = false;
+    for (int i0 = 0; i0 < mr; i0 += 4) {
+        double a4[4], b4[4];
+        if (i0 + 4 <= mr) {
+            const D4 xa = *reinterpret_cast<const D4 *>(col + i0);
+            const D4 xb = *reinterpret_cast<const D4 *>(pd + i0);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { a4[u] = xa.v[u]; b4[u] = xb.v[u]; }
+        } else {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { const int i = min(i0 + u, mr - 1); a4[u] = col[i]; b4[u] = pd[i]; }
         }
-        bool by_test = false;
-        if (feas < 0 && row >= 0) {
-            const double brow = pd[row];
-            if (brow <= TOL_FEAS) feas = 1;
-            else if (q0 <= 0) feas = 0;
-            else {
-                // Four rows per trip, each vector fetched with 16-byte loads (records are 8-byte aligned, the hardware takes unaligned
-                // global accesses): a lane's column is ITS OWN walk -- 64 distinct lines per wave-level load -- and the kernel is bound
-                // by the number of such requests, not by their bytes (tools/ubench/xq_thread_bench.hip: one 8-byte load per row 0.57 ms
-                // for config 4's level, seven rows issued together 0.28, four rows in two 16-byte loads 0.19)
-                struct __attribute__((packed, aligned(8))) D4 { double v[4]; };
-                struct __attribute__((packed, aligned(4))) I4 { int v[4]; };
-                const double *col = pd + (size_t)q0 * mr;
-                float cmf = 0.0f;
-                double tmax = INFINITY, ratio_row = 0.0, a_row = 0.0;
-                bool elig_row = false;
-                for (int i0 = 0; i0 < mr; i0 += 4) {
-                    double a4[4], b4[4];
-                    int k4[4];
-                    if (i0 + 4 <= mr) {
-                        const D4 xa = *reinterpret_cast<const D4 *>(col + i0);
-                        const D4 xb = *reinterpret_cast<const D4 *>(pd + i0);
-                        const I4 xk = *reinterpret_cast<const I4 *>(pi + mr + i0);
+        const unsigned mw = (unsigned)(i0 < 32 ? mk.v[0] : (i0 < 64 ? mk.v[1] : (i0 < 96 ? mk.v[2] : mk.v[3]))) >> (i0 & 31);   // (i0 is a multiple of four)
 #pragma unroll
-                        for (int u = 0; u < 4; ++u) { a4[u] = xa.v[u]; b4[u] = xb.v[u]; k4[u] = xk.v[u]; }
-                    } else {
-#pragma unroll
-                        for (int u = 0; u < 4; ++u) { const int i = min(i0 + u, mr - 1); a4[u] = col[i]; b4[u] = pd[i]; k4[u] = pi[mr + i]; }
-                    }
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        const int i = i0 + u;
-                        if (i < mr) {
-                            const double a = a4[u];
-                            const int kd = k4[u] & 0xff;
-                            const bool used = kd != RK_DEAD;
-                            if (used) cmf = fmaxf(cmf, fabsf((float)a));
-                            const bool elig = used && kd == RK_INEQ && a > TOL_PIV;
-                            if (elig) {
-                                const double b0 = fmax(b4[u], 0.0), ia = fast_rcp(a);
-                                const double ratio = b0 * ia;
-                                tmax = fmin(tmax, (b0 + HARRIS_DELTA) * ia);
-                                if (i == row) { elig_row = true; ratio_row = ratio; a_row = a; }
-                            }
-                        }
-                    }
-                }
-                // the new row is inside the Harris bound: it leaves the basis at zero (xq_decide: `mine`, l == row)
-                if (tmax != INFINITY && elig_row && !(ratio_row > tmax)) {
-                    const double growth0 = __hiloint2double(pi[2 * mr + NXC + 1], pi[2 * mr + NXC + 2]);
-                    const double inv = fast_rcp(a_row);
-                    const double growth = fmax(growth0, (double)(cmf * (float)inv));
-                    if (!(growth > GROWTH_SAFE)) { feas = 1; by_test = true; }
+        for (int u = 0; u < 4; ++u) {
+            const int i = i0 + u;
+            if (i < mr) {
+                const double a = a4[u];
+                // (rows of these records are RK_INEQ or RK_DEAD: k_x2 leaves no other kind behind, so "used" == "ratio-test row")
+                const bool used = (mw >> u) & 1u;
+                if (used) cmf = fmaxf(cmf, fabsf((float)a));
+                const bool elig = used && a > TOL_PIV;
+                if (elig) {
+                    const double b0 = fmax(b4[u], 0.0), ia = fast_rcp(a);
+                    const double ratio = b0 * ia;
+                    tmax = fmin(tmax, (b0 + HARRIS_DELTA) * ia);
+                    if (i == row) { elig_row = true; ratio_row = ratio; a_row = a; }
                 }
             }
-        }
-        if (feas >= 0) {
-            const bool singular = status[c] == ST_NEEDX_SING;
-            status[c] = (uint8_t)(feas ? (singular ? ST_SINGULAR : ST_FEASIBLE) : ST_INFEASIBLE);
-            n_dec++;
-            if (by_test) n_piv++;
         }
     }
-    // one set of atomics per workgroup (the same-address atomics of 15 k wavefronts would serialise behind each other)
-    __shared__ unsigned int s_dec, s_piv;
-    if (threadIdx.x == 0) { s_dec = 0; s_piv = 0; }
-    __syncthreads();
-    if (n_dec) atomicAdd(&s_dec, n_dec);
-    if (n_piv) atomicAdd(&s_piv, n_piv);
-    __syncthreads();
-    if (threadIdx.x == 0 && s_dec) {
-        atomicAdd(&ctr->pivots, (unsigned long long)s_piv); atomicAdd(&ctr->xq_pivots, (unsigned long long)s_piv);
-        atomicAdd(&ctr->x_cached, (unsigned long long)s_dec); atomicAdd(&ctr->xtheta_lps, (unsigned long long)s_dec);
-        atomicAdd(&ctr->xq_thread, s_dec);
+    // the new row is inside the Harris bound: it leaves the basis at zero (xq_decide: `mine`, l == row)
+    if (tmax != INFINITY && elig_row && !(ratio_row > tmax)) {
+        const double growth0 = __hiloint2double(pi[2 * mr + NXC + 1], pi[2 * mr + NXC + 2]);
+        const double inv = fast_rcp(a_row);
+        const double growth = fmax(growth0, (double)(cmf * (float)inv));
+        if (!(growth > GROWTH_SAFE)) { *by_test = true; return 1; }
+    }
+    return -1;
+}
+
+// Other parents (alt_tries > 0): a candidate {a < b < c < d < e} was generated from {a,b,c,d}, but {a,b,c,e}, {a,b,d,e} ... were
+// candidates of the previous level too, and those that were feasible left a dictionary.  From ANY of them the same first test is a
+// valid proof: a vertex of the face of that parent from which the missing row's slack reaches zero along one edge (feasible), or on
+// whose whole face it cannot decrease (infeasible).  The previous frontier is in lexicographic order (children are written parent
+// by parent, new row ascending), so a parent is found by binary search; prev_stored says whether it left a dictionary.
+struct XqAlt {
+    const int32_t *prev_frontier;   // [n_prev][k - 1]
+    const uint8_t *prev_stored;     // [n_prev]
+    int n_prev, tries;
+};
+// One wavefront = 64 candidates at a time, lanes always full: a candidate its generating parent leaves open goes into the wavefront's
+// queue (LDS) with "try 1"; whenever 64 are queued (or the input has run out) the wavefront takes them up again, each lane with its
+// own try number.  No global atomics, no compaction between the tries.
+MPC_GLOBAL void MPC_LB(64) k_xq_thread(const DevProblem *__restrict__ Pg, const int32_t *__restrict__ cands, int k,
+                                       const int32_t *__restrict__ list, int n_list, uint8_t *__restrict__ status,
+                                       LevelCounters *__restrict__ ctr, DictCache dc, int NXC, XqAlt alt) {
+    __shared__ int q_c[128], q_t[128];
+    const DevProblem &P = *Pg;
+    const int nv = P.n_x + P.n_t, mr = P.n_d0r, ncol = P.n_d0c + 1, lane = threadIdx.x, km = k - 1;
+    if (dc.n_list_dev) n_list = *dc.n_list_dev;
+    const int max_try = (alt.tries > 0 && alt.n_prev > 0 && k >= 2) ? min(alt.tries, km - P.n_eq) : 0;   // tries 1..max_try leave out position km - t
+    unsigned int n_dec = 0, n_piv = 0, n_alt = 0;   // per lane: candidates decided / decided by a ratio test / decided from another parent
+    int qn = 0;                                      // queued items (wave-uniform)
+    const unsigned long long below = (1ull << lane) - 1ull;
+    auto finish = [&](int c, int feas, bool by_test, bool from_alt) {
+        const bool singular = status[c] == ST_NEEDX_SING;
+        status[c] = (uint8_t)(feas ? (singular ? ST_SINGULAR : ST_FEASIBLE) : ST_INFEASIBLE);
+        n_dec++;
+        if (by_test) n_piv++;
+        if (from_alt) n_alt++;
+    };
+    auto push = [&](bool want, int c, int t) {   // wave-uniform call
+        const unsigned long long m = __ballot(want);
+        if (want) { const int pos = qn + __popcll(m & below); q_c[pos] = c; q_t[pos] = t; }
+        qn += __popcll(m);
+        wave_sync();
+    };
+    long long w0 = (long long)blockIdx.x * 64;
+    for (;;) {
+        const bool have_input = w0 < n_list;
+        if (have_input) {
+            const long long w = w0 + lane;
+            w0 += (long long)gridDim.x * 64;
+            int c = -1, feas = -1;
+            bool by_test = false, open = false;
+            if (w < n_list) {
+                c = list[w];
+                const int ps = dc.parent_slot[c];
+                if (ps >= 0) {
+                    feas = xq_first_test(dc.prev_d + (size_t)ps * dc.stride_d, dc.prev_i + (size_t)ps * dc.stride_i, mr, ncol, NXC, nv, nv + cands[(size_t)c * k + km], &by_test);
+                    open = feas < 0;
+                    if (feas >= 0) finish(c, feas, by_test, false);
+                }
+            }
+            if (max_try > 0) push(open, c, 1);
+        }
+        // the queue is taken up when it holds a full wavefront, or when nothing new will come
+        while (qn >= 64 || (!have_input && qn > 0)) {
+            const int take = min(qn, 64);
+            qn -= take;
+            int c = -1, t = 0;
+            if (lane < take) { c = q_c[qn + lane]; t = q_t[qn + lane]; }
+            wave_sync();
+            bool again = false;
+            if (c >= 0) {
+                const int32_t *as = cands + (size_t)c * k;
+                const int drop = km - t;   // position of the member this parent does not have (t = 1: the second largest)
+                // as[] without as[drop] in the previous frontier (lexicographic order)
+                auto cmp_row = [&](int i) -> int {   // sign of (row i) - (the wanted set)
+                    const int32_t *row = alt.prev_frontier + (size_t)i * km;
+                    int cmp = 0;
+                    for (int a = 0; a < km && cmp == 0; ++a) {
+                        const int qa = as[a < drop ? a : a + 1];
+                        cmp = (row[a] > qa) - (row[a] < qa);
+                    }
+                    return cmp;
+                };
+                int lo = 0, hi = alt.n_prev - 1, found = -1;
+                if (t == 1) {
+                    // {.., e} without the second largest member is a SIBLING of the generating parent {.., d}: same prefix, larger last
+                    // member, i.e. a few rows further on in the same block of the previous frontier -- walked, not searched
+                    const int ps = dc.parent_slot[c];
+                    lo = ps + 1;
+                    for (int step = 0; step < 24 && lo <= hi; ++step, ++lo) {
+                        const int cmp = cmp_row(lo);
+                        if (cmp >= 0) { if (cmp == 0) found = lo; hi = lo - 1; break; }
+                    }
+                }
+                while (lo <= hi) {
+                    const int mid = (lo + hi) >> 1;
+                    const int cmp = cmp_row(mid);
+                    if (cmp == 0) { found = mid; break; }
+                    if (cmp < 0) lo = mid + 1; else hi = mid - 1;
+                }
+                int feas = -1;
+                bool by_test = false;
+                if (found >= 0 && alt.prev_stored[found])
+                    feas = xq_first_test(dc.prev_d + (size_t)found * dc.stride_d, dc.prev_i + (size_t)found * dc.stride_i, mr, ncol, NXC, nv, nv + as[drop], &by_test);
+                if (feas >= 0) finish(c, feas, by_test, true);
+                else again = t < max_try;
+            }
+            push(again, c, t + 1);
+        }
+        if (!have_input) break;
+    }
+    // per wavefront one set of atomics (as the wavefront kernel)
+    for (int off = 32; off > 0; off >>= 1) { n_dec += __shfl_xor(n_dec, off); n_piv += __shfl_xor(n_piv, off); n_alt += __shfl_xor(n_alt, off); }
+    if (lane == 0 && n_dec) {
+        atomicAdd(&ctr->pivots, (unsigned long long)n_piv); atomicAdd(&ctr->xq_pivots, (unsigned long long)n_piv);
+        atomicAdd(&ctr->x_cached, (unsigned long long)n_dec); atomicAdd(&ctr->xtheta_lps, (unsigned long long)n_dec);
+        atomicAdd(&ctr->xq_thread, n_dec);
+        if (n_alt) atomicAdd(&ctr->pad_xq, n_alt);
     }
 }
 
@@ -1129,6 +1214,23 @@ MPC_GLOBAL void MPC_LB(64, (NXC * SLOTS >= 64 ? 2 : (NXC * SLOTS >= 32 ? X2_WAVE
                     }
                 }
                 if (lane < NXC) oi[2 * mr + lane] = lx.cv;
+                {
+                    // for the children's one-thread tests (k_xq_thread): which rows are ratio-test rows, and where each program constraint's slack sits
+                    int32_t *om = oi + dict_ints_head(mr, NXC);
+                    uint8_t *opos = reinterpret_cast<uint8_t *>(om + 4);
+                    const int ncp = P.n_c;
+#pragma unroll
+                    for (int sl = 0; sl < 2; ++sl) {
+                        const unsigned long long bm = sl < SLOTS ? __ballot(lane + 64 * sl < mr && lx.kind[sl < SLOTS ? sl : 0] == RK_INEQ) : 0ull;
+                        if (lane == 0) { om[2 * sl] = (int)(unsigned)bm; om[2 * sl + 1] = (int)(unsigned)(bm >> 32); }
+                    }
+#pragma unroll
+                    for (int sl = 0; sl < SLOTS; ++sl) {
+                        const int i = lane + 64 * sl, cidx = lx.var[sl] - nv;
+                        if (i < mr && cidx >= 0 && cidx < ncp) opos[cidx] = (uint8_t)i;
+                    }
+                    { const int cidx = lx.cv - nv; if (lane >= 1 && lane <= nc0 && ((lx.alive >> lane) & 1u) && cidx >= 0 && cidx < ncp) opos[cidx] = (uint8_t)(128 + lane); }
+                }
                 if (lane == 0) {
                     oi[2 * mr + NXC] = (int)lx.alive;
                     oi[2 * mr + NXC + 1] = __double2hiint(lx.growth);

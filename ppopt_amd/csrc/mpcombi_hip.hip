@@ -324,8 +324,9 @@ struct mpc_handle {
     int no_rbox = 0;          // MPC_NO_RBOX=1: no bounding-box screen of the region rows in k_region2 (A/B)
     int no_rsplit = 0;        // MPC_NO_RSPLIT=1: one wavefront per candidate in k_region2 whatever the load (A/B)
     int no_xquick = 0;        // MPC_NO_XQUICK=1: no quick (x,theta) test on the last level (A/B)
+    int xqt_wpc = 16;         // MPC_XQT_WPC: wavefronts per CU of k_xq_thread (it is bound by the cache's request rate: config 4's level 0.45 ms alone with 8 per CU, 0.49 with 24; beside the region kernel 0.92 / 0.70 / 0.78 / 0.75 with 4 / 8 / 12 / 16)
     int xqg_overlap = 0;      // MPC_XQG_OVERLAP=1: the region stage runs under the (x,theta) stage also when the quick test is the grouped one (experiment)
-    int xq_thread = 0;        // MPC_XQ_THREAD=1: the quick test with a one-thread-per-candidate first pass k_xq_thread (round 5; measured zero-sum on the bench configurations, off by default)
+    int xq_thread = -1;       // MPC_XQ_THREAD: 0 = the quick test without its one-thread-per-candidate first pass k_xq_thread (round 5); 1 = the pass against the generating parent only; n >= 2 = ... and up to n - 1 other parents; default: every other parent
     long long n_xq_thread = 0; float ms_xq_thread = 0;   // the last level run: candidates that pass decided, its time
     bool fetch_nowait = false; // mpc_level_regions_slots_nowait: even the integer heads are only queued
     bool skip_small = false;  // mpc_level_run_batch: this level already went through the no-round-trip launches and has to be repeated classically
@@ -360,6 +361,7 @@ struct mpc_handle {
     const int32_t *opt_ptr = nullptr;                  // list of the optimal candidates of the level (a view, not a copy)
     DevBuf frontier, children, status, pruned, flag, pos, opt_list, childmask, count, offset, recd, reci, ctr, scratch, sums;
     long long n = 0;
+    long long n_prev = 0;     // candidates of the level before (0: unknown -- frontier set by the caller)
     int k = 0;
     long long n_pruned = 0;
     long long n_pruned_extra = 0;   // masks added from outside (other ranks') behind this level's own new ones, before mpc_frontier_advance
@@ -607,8 +609,9 @@ static int create_fill(const mpc_problem *p, int32_t device, void *stream, mpc_h
     { const char *ev = std::getenv("MPC_NO_XQGROUP"); h->no_xqgroup = ev && ev[0] == '1'; }
     { const char *ev = std::getenv("MPC_FORCE_XQGROUP"); h->force_xqgroup = ev && ev[0] == '1'; }
     { const char *ev = std::getenv("MPC_NO_XQUICK"); h->no_xquick = ev && ev[0] == '1'; }
-    { const char *ev = std::getenv("MPC_XQ_THREAD"); h->xq_thread = ev && ev[0] == '1'; }
+    { const char *ev = std::getenv("MPC_XQ_THREAD"); h->xq_thread = ev ? std::atoi(ev) : -1; }
     { const char *ev = std::getenv("MPC_XQG_OVERLAP"); h->xqg_overlap = ev && ev[0] == '1'; }
+    { const char *ev = std::getenv("MPC_XQT_WPC"); if (ev && std::atoi(ev) > 0) h->xqt_wpc = std::atoi(ev); }
     { const char *ev = std::getenv("MPC_NO_KKT_THREAD"); h->no_kkt_thread = ev ? std::atoi(ev) : 0; }   // 2: only the small-level path
     { const char *ev = std::getenv("MPC_NO_ROVERLAP"); h->no_roverlap = ev && ev[0] == '1'; }
     { const char *ev = std::getenv("MPC_TEST_LATE"); h->test_late = ev ? std::atoi(ev) : 0; }
@@ -1138,7 +1141,7 @@ static int frontier_reset(mpc_handle *h, long long n, int k) {
     if (n > 0x7fffffffLL / std::max(k + 1, 1)) return fail(h, MPC_ERR_INVALID, "frontier too large for 32-bit offsets");
     HIP_TRY(h, hipSetDevice(h->device));
     HIP_TRY(h, h->frontier.ensure((size_t)std::max<long long>(n, 1) * std::max(k, 1) * sizeof(int32_t), h->stream));
-    h->n = n; h->k = k; h->level_done = false; h->n_pruned_extra = 0;
+    h->n = n; h->k = k; h->level_done = false; h->n_pruned_extra = 0; h->n_prev = 0;
     h->have_prev_dict = false; h->have_parent_slot = false;   // a frontier set from outside has no cached parent dictionaries
     return MPC_OK;
 }
@@ -1199,6 +1202,7 @@ int mpc_frontier_shard(mpc_handle *h, int32_t rank, int32_t world) {
         HIP_TRY(h, hipStreamSynchronize(st));
     }
     h->n = n_new;
+    h->n_prev = 0;   // h->children no longer holds the previous level's frontier (k_xq_thread's look-up of other parents is off for this level)
     h->level_done = false;
     return MPC_OK;
 }
@@ -1382,7 +1386,7 @@ static int level_run_small(mpc_handle *h, int32_t gen_children, int32_t flags, m
     {
         // counters, list lengths, the region kernel's completion flags and the "dictionary stored" flags: cleared by one launch
         const int nxc_ = h->fast_x >= 2 ? 32 : 16;
-        const double need_gb_ = (double)nn * ((double)nxc_ * h->Pf.n_d0r * 8.0 + (2.0 * h->Pf.n_d0r + nxc_ + 4) * 4.0) / 1e9;
+        const double need_gb_ = (double)nn * ((double)nxc_ * h->Pf.n_d0r * 8.0 + (double)dict_ints(h->Pf.n_d0r, nxc_, h->n_c) * 4.0) / 1e9;
         const bool will_store = gen_children && need_gb_ <= h->dict_budget_gb;
         HIP_TRY(h, h->done_g.ensure(nn * 2 * sizeof(unsigned int), st));
         if (will_store) HIP_TRY(h, h->dict_stored[h->dict_cur].ensure(nn, st));
@@ -1492,7 +1496,7 @@ static int level_run_small(mpc_handle *h, int32_t gen_children, int32_t flags, m
     // ---- (x,theta) stage with the dictionary cache ---------------------------------------------------------------------------------
     const int nxc = h->fast_x >= 2 ? 32 : 16;
     h->dict_stride_d = (long long)nxc * h->Pf.n_d0r;
-    h->dict_stride_i = 2LL * h->Pf.n_d0r + nxc + 4;
+    h->dict_stride_i = dict_ints(h->Pf.n_d0r, nxc, h->n_c);
     DictCache dc{};
     dc.stride_d = h->dict_stride_d; dc.stride_i = h->dict_stride_i;
     if (h->have_prev_dict && h->have_parent_slot) {
@@ -1621,8 +1625,8 @@ static int level_run_small(mpc_handle *h, int32_t gen_children, int32_t flags, m
             stats->ms_region2 = (float)((double)(host_ctr.r2_t1 - ~host_ctr.r2_not_t0) / (double)h->wall_khz);
         stats->n_xq_items = quick_test ? cnt_host[7] : 0; stats->xq_pivots = (int64_t)host_ctr.xq_pivots;
         stats->n_x_items = (quick_test ? cnt_host[8] : cnt_host[7]) + (h->storing ? (long long)cnt_host[5] + cnt_host[6] : 0);
-        stats->xq_record_ints = h->dict_stride_i; stats->xq_record_rows = h->Pf.n_d0r; stats->xq_record_cols = h->Pf.n_d0c + 1;
-        const long long rec_bytes = (long long)(h->Pf.n_d0c + 1) * h->Pf.n_d0r * 8 + h->dict_stride_i * 4;
+        stats->xq_record_ints = dict_ints_head(h->Pf.n_d0r, h->fast_x >= 2 ? 32 : 16) - 1; stats->xq_record_rows = h->Pf.n_d0r; stats->xq_record_cols = h->Pf.n_d0c + 1;
+        const long long rec_bytes = (long long)(h->Pf.n_d0c + 1) * h->Pf.n_d0r * 8 + (long long)dict_ints_head(h->Pf.n_d0r, h->fast_x >= 2 ? 32 : 16) * 4;   // (what k_x2 reads of a record; the stored record also carries the children's look-up bytes)
         stats->dict_read_bytes = (h->have_prev_dict && h->have_parent_slot) ? rec_bytes : 0;
         stats->dict_write_bytes = h->storing ? rec_bytes : 0;
         stats->ms_verdict = ms[0]; stats->ms_region = ms[1]; stats->ms_children = ms[2]; stats->ms_total = ms[0] + ms[1] + ms[2];
@@ -1697,7 +1701,7 @@ static int batch_prepare(mpc_handle *h, int32_t gen_children, int32_t flags, Bat
     const int nxc = h->fast_x >= 2 ? 32 : 16;
     m.nxc = nxc;
     h->dict_stride_d = (long long)nxc * h->Pf.n_d0r;
-    h->dict_stride_i = 2LL * h->Pf.n_d0r + nxc + 4;
+    h->dict_stride_i = dict_ints(h->Pf.n_d0r, nxc, h->n_c);
     DictCache dc{};
     dc.stride_d = h->dict_stride_d; dc.stride_i = h->dict_stride_i;
     if (h->have_prev_dict && h->have_parent_slot) {
@@ -1787,8 +1791,8 @@ static int batch_finish(mpc_handle *h, int32_t gen_children, const BatchMember &
             stats->ms_region2 = (float)((double)(host_ctr.r2_t1 - ~host_ctr.r2_not_t0) / (double)h->wall_khz);
         stats->n_xq_items = m.quick_test ? cnt_host[7] : 0; stats->xq_pivots = (int64_t)host_ctr.xq_pivots;
         stats->n_x_items = (m.quick_test ? cnt_host[8] : cnt_host[7]) + (h->storing ? (long long)cnt_host[5] + cnt_host[6] : 0);
-        stats->xq_record_ints = h->dict_stride_i; stats->xq_record_rows = h->Pf.n_d0r; stats->xq_record_cols = h->Pf.n_d0c + 1;
-        const long long rec_bytes = (long long)(h->Pf.n_d0c + 1) * h->Pf.n_d0r * 8 + h->dict_stride_i * 4;
+        stats->xq_record_ints = dict_ints_head(h->Pf.n_d0r, h->fast_x >= 2 ? 32 : 16) - 1; stats->xq_record_rows = h->Pf.n_d0r; stats->xq_record_cols = h->Pf.n_d0c + 1;
+        const long long rec_bytes = (long long)(h->Pf.n_d0c + 1) * h->Pf.n_d0r * 8 + (long long)dict_ints_head(h->Pf.n_d0r, h->fast_x >= 2 ? 32 : 16) * 4;   // (what k_x2 reads of a record; the stored record also carries the children's look-up bytes)
         stats->dict_read_bytes = (h->have_prev_dict && h->have_parent_slot) ? rec_bytes : 0;
         stats->dict_write_bytes = h->storing ? rec_bytes : 0;
         stats->ms_total = ms_total;   // the batch's launches, first to last (shared by all members)
@@ -2278,7 +2282,7 @@ static int level_run_impl(mpc_handle *h, int32_t gen_children, int32_t flags, mp
             // ---- (x,theta) stage with the dictionary cache -------------------------------------------------------------
             const int nxc = h->fast_x >= 2 ? 32 : 16;
             h->dict_stride_d = (long long)nxc * h->Pf.n_d0r;   // column-major tableau
-            h->dict_stride_i = 2LL * h->Pf.n_d0r + nxc + 4;
+            h->dict_stride_i = dict_ints(h->Pf.n_d0r, nxc, h->n_c);
             DictCache dc{};
             dc.stride_d = h->dict_stride_d; dc.stride_i = h->dict_stride_i;
             if (h->have_prev_dict && h->have_parent_slot) {
@@ -2372,18 +2376,26 @@ static int level_run_impl(mpc_handle *h, int32_t gen_children, int32_t flags, mp
                 const long long grid_q = (long long)h->n_cu * h->xq_wpc;
                 HIP_TRY(h, hipEventRecord(h->kev[8], st));
                 n_xq_items = n_needx;
-                // Optional first pass, one THREAD per candidate (k_xq_thread, round 5, MPC_XQ_THREAD=1): whatever the first ratio test of
-                // the hinted column decides.  What it leaves open is compacted (length on the device) and goes to the wavefront kernel
-                // unchanged.  Off by default: it decides 67 % of config 4's last level in 0.19 ms alone / 0.38 ms beside the region
-                // kernel, and the wavefront kernel gets exactly that much faster -- its time is the OTHER third, the candidates that
-                // need two to sixteen dependent pivots (config 4 level 5: 2.36 ms with, 2.35 without; config 3 4.90 / 4.79).
+                // First pass, one THREAD per candidate (k_xq_thread, round 5): whatever the first ratio test of the hinted column
+                // decides -- against the generating parent's record, then against the records of the candidate's OTHER parents (the
+                // previous level's sets that lack one of its other members).  What stays open is compacted (length on the device) and
+                // goes to the wavefront kernel unchanged.  Against the generating parent alone the pass decides 67 % of config 4's
+                // last level and gains nothing (the wavefront kernel's time is the other third, candidates that need two to sixteen
+                // dependent pivots from THAT vertex: level 5 2.36 ms with, 2.35 without); from another parent's vertex almost all
+                // of those are one ratio test away too: 99.76 % decided, level 5 2.35 -> 1.75 ms; config 3 93 %, 4.75 -> 3.43 ms.
                 const int32_t *xq_list = needx_list;
                 int32_t xq_n = n_needx;
                 bool xqt_lean = false;
-                if (h->xq_thread && n_needx >= 4096) {
-                    const unsigned gt = (unsigned)std::min<long long>(((long long)n_needx + 255) / 256, (long long)h->n_cu * 8);
+                if (h->xq_thread != 0 && n_needx >= 4096) {
+                    const unsigned gt = (unsigned)std::min<long long>(((long long)n_needx + 63) / 64, (long long)h->n_cu * h->xqt_wpc);
                     HIP_TRY(h, hipEventRecord(h->kev[10], st));
-                    hipLaunchKernelGGL(k_xq_thread, dim3(gt), dim3(256), 0, st, pf, fr, k, needx_list, n_needx, stp, ctr, dq, nxc);
+                    XqAlt alt{};
+                    if ((h->xq_thread >= 2 || h->xq_thread < 0) && h->n_prev > 0 && h->n_prev <= 0x7fffffffLL && h->have_prev_dict && k >= 2 &&
+                        h->children.cap >= (size_t)h->n_prev * (k - 1) * sizeof(int32_t) && h->dict_stored[1 - h->dict_cur].cap >= (size_t)h->n_prev) {
+                        alt.prev_frontier = h->children.as<int32_t>(); alt.prev_stored = h->dict_stored[1 - h->dict_cur].as<uint8_t>();
+                        alt.n_prev = (int)h->n_prev; alt.tries = h->xq_thread < 0 ? MPC_MAX_NC : h->xq_thread - 1;   // (the kernel stops at the candidate's inequality members)
+                    }
+                    hipLaunchKernelGGL(k_xq_thread, dim3(gt), dim3(64), 0, st, pf, fr, k, needx_list, n_needx, stp, ctr, dq, nxc, alt);
                     HIP_TRY(h, hipEventRecord(h->kev[11], st));
                     HIP_TRY(h, hipGetLastError());
                     xq_thread_timed = true;
@@ -2612,12 +2624,12 @@ static int level_run_impl(mpc_handle *h, int32_t gen_children, int32_t flags, mp
         stats->n_theta_items = n_theta_items;
         stats->ms_kkt = kms[3]; stats->ms_xq = kms[4];
         stats->n_xq_items = n_xq_items; stats->xq_pivots = (int64_t)host_ctr.xq_pivots;
-        stats->xq_record_ints = h->dict_stride_i; stats->xq_record_rows = h->Pf.n_d0r; stats->xq_record_cols = h->Pf.n_d0c + 1;
+        stats->xq_record_ints = dict_ints_head(h->Pf.n_d0r, h->fast_x >= 2 ? 32 : 16) - 1; stats->xq_record_rows = h->Pf.n_d0r; stats->xq_record_cols = h->Pf.n_d0c + 1;
         stats->n_xq_thread = h->n_xq_thread; stats->ms_xq_thread = h->ms_xq_thread;
         stats->n_region_rows = h->n_erows;
         stats->n_opt = h->n_opt;
         // bytes of one dictionary record that are actually moved: the used columns (value + D0 columns) and the integer part
-        const long long rec_bytes = (long long)(h->Pf.n_d0c + 1) * h->Pf.n_d0r * 8 + h->dict_stride_i * 4;
+        const long long rec_bytes = (long long)(h->Pf.n_d0c + 1) * h->Pf.n_d0r * 8 + (long long)dict_ints_head(h->Pf.n_d0r, h->fast_x >= 2 ? 32 : 16) * 4;   // (what k_x2 reads of a record; the stored record also carries the children's look-up bytes)
         stats->dict_read_bytes = (h->fast && h->have_prev_dict && h->have_parent_slot) ? rec_bytes : 0;
         stats->dict_write_bytes = (h->fast && h->storing) ? rec_bytes : 0;
         stats->ms_verdict = ms[0]; stats->ms_region = ms[1]; stats->ms_children = ms[2]; stats->ms_total = ms[0] + ms[1] + ms[2];
@@ -3373,6 +3385,7 @@ int mpc_frontier_advance(mpc_handle *h) {
     h->have_prev_dict = h->storing;
     h->dict_cur = 1 - h->dict_cur;
     h->storing = false;
+    h->n_prev = h->n;   // the frontier that has just been left sits in h->children until this level writes its own children
     h->n = h->n_children;
     h->k = h->k + 1;
     h->level_done = false;

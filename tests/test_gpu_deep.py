@@ -422,30 +422,35 @@ def test_device_setup_and_host_setup_give_the_same_solve(name, monkeypatch):
             assert rel_err(getattr(r1, fld), getattr(r2, fld)) <= COEF_TOL, (key, fld, rel_err(getattr(r1, fld), getattr(r2, fld)))
 
 
-# ---- the quick test's optional first pass with one thread per candidate (k_xq_thread, MPC_XQ_THREAD=1) -----------------------------
+# ---- the quick test's first pass with one thread per candidate (k_xq_thread) ---------------------------------------------------------
 @pytest.mark.parametrize('name', ['c4_rand_20_8_20_s0', 'c3_quadtank_n10'])
 def test_thread_pass_of_the_quick_test_changes_no_verdict(name, monkeypatch):
-    """k_xq_thread decides what the first ratio test of the hinted column decides (two thirds of config 4's last level) with the
-    arithmetic of xq_decide; everything else goes to the wavefront kernel unchanged.  Every status of every level must be the one the
-    default path gives, and the pass must really have decided candidates on the last level."""
+    """k_xq_thread decides a last-level candidate by the first ratio test of the hinted column, with the arithmetic of xq_decide:
+    against its generating parent's record (MPC_XQ_THREAD=1), and by default also against the records of its other parents -- any
+    parent's vertex from which the missing row's slack reaches zero along one edge proves the candidate feasible.  Everything it
+    leaves open goes to the wavefront kernel unchanged.  Every status of every level must be the one the wavefront kernel alone
+    gives (MPC_XQ_THREAD=0), and the pass must really have decided candidates on the last level -- more with the other parents."""
     from test_gpu_parity import engine_from_golden, run_levels
     g = load_golden(name)
     nl = int(g['n_levels']) + 1
     runs = []
-    for env in ({}, {'MPC_XQ_THREAD': '1'}):
+    for env in ({'MPC_XQ_THREAD': '0'}, {'MPC_XQ_THREAD': '1'}, {}):
         with monkeypatch.context() as m:
+            m.delenv('MPC_XQ_THREAD', raising=False)
             for key, val in env.items():
                 m.setenv(key, val)
             eng = engine_from_golden(g)
             levels, regions = run_levels(eng, nl)
             runs.append(([(c.copy(), s.copy(), int(st.n_children), int(st.n_xq_thread)) for c, s, st in levels], sorted(tuple(r.active_set) for r in regions)))
             eng.close()
-    (la, ra), (lb, rb) = runs
-    assert len(la) == len(lb) and ra == rb
-    for (ca, sa, na, ta), (cb, sb, nb, tb) in zip(la, lb):
+    (la, ra), (lb, rb), (lc, rc) = runs
+    assert len(la) == len(lb) == len(lc) and ra == rb == rc
+    for (ca, sa, na, ta), (cb, sb, nb, tb), (cc, sc, nc_, tc) in zip(la, lb, lc):
         assert numpy.array_equal(ca, cb) and numpy.array_equal(sa, sb) and na == nb
+        assert numpy.array_equal(ca, cc) and numpy.array_equal(sa, sc) and na == nc_
         assert ta == 0
     assert lb[-1][3] > 0.1 * len(lb[-1][0]), 'the thread pass decided nothing on the last level'
+    assert lc[-1][3] > lb[-1][3], 'the other parents decided nothing'
 
 
 # ---- levels without host round trips (level_run_small) and lean large levels -------------------------------------------------
