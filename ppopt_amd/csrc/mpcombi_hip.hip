@@ -273,7 +273,7 @@ struct mpc_handle {
     int device = 0;
     hipStream_t stream = nullptr;
     hipStream_t stream2 = nullptr;   // side stream: retry kernels of few long-running wavefronts overlap the main pipeline
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_xfork = nullptr, ev_xjoin = nullptr;
     hipStream_t stream3 = nullptr;   // region stage of a level, launched under its (x,theta) stage
     hipEvent_t ev_rfork = nullptr, ev_rjoin = nullptr, ev_rgo = nullptr;
     bool no_roverlap = false;        // MPC_NO_ROVERLAP=1 / mpc_set_region_overlap(h, 0): region stage after the (x,theta) stage (no overlap)
@@ -324,6 +324,8 @@ struct mpc_handle {
     int no_rbox = 0;          // MPC_NO_RBOX=1: no bounding-box screen of the region rows in k_region2 (A/B)
     int no_rsplit = 0;        // MPC_NO_RSPLIT=1: one wavefront per candidate in k_region2 whatever the load (A/B)
     int no_xquick = 0;        // MPC_NO_XQUICK=1: no quick (x,theta) test on the last level (A/B)
+    int no_xq_early = 0;      // MPC_NO_XQ_EARLY=1: the thread pass of the quick test always behind the theta stage, -1: always beside it (A/B)
+    long long prev_regions = 0, xq_early_regions = 1024;   // regions of the level before; MPC_XQ_EARLY_REGIONS
     int xqt_wpc = 16;         // MPC_XQT_WPC: wavefronts per CU of k_xq_thread (it is bound by the cache's request rate: config 4's level 0.45 ms alone with 8 per CU, 0.49 with 24; beside the region kernel 0.92 / 0.70 / 0.78 / 0.75 with 4 / 8 / 12 / 16)
     int xqg_overlap = 0;      // MPC_XQG_OVERLAP=1: the region stage runs under the (x,theta) stage also when the quick test is the grouped one (experiment)
     int xq_thread = -1;       // MPC_XQ_THREAD: 0 = the quick test without its one-thread-per-candidate first pass k_xq_thread (round 5); 1 = the pass against the generating parent only; n >= 2 = ... and up to n - 1 other parents; default: every other parent
@@ -596,6 +598,8 @@ static int create_fill(const mpc_problem *p, int32_t device, void *stream, mpc_h
     HIP_TRY(nullptr, pooled_event(&h->ev_hi, false));
     HIP_TRY(nullptr, pooled_event(&h->ev_fork, false));
     HIP_TRY(nullptr, pooled_event(&h->ev_join, false));
+    HIP_TRY(nullptr, pooled_event(&h->ev_xfork, false));
+    HIP_TRY(nullptr, pooled_event(&h->ev_xjoin, false));
     HIP_TRY(nullptr, pooled_stream(&h->stream3));
     HIP_TRY(nullptr, pooled_event(&h->ev_rfork, false));
     HIP_TRY(nullptr, pooled_event(&h->ev_rjoin, false));
@@ -612,6 +616,8 @@ static int create_fill(const mpc_problem *p, int32_t device, void *stream, mpc_h
     { const char *ev = std::getenv("MPC_XQ_THREAD"); h->xq_thread = ev ? std::atoi(ev) : -1; }
     { const char *ev = std::getenv("MPC_XQG_OVERLAP"); h->xqg_overlap = ev && ev[0] == '1'; }
     { const char *ev = std::getenv("MPC_XQT_WPC"); if (ev && std::atoi(ev) > 0) h->xqt_wpc = std::atoi(ev); }
+    { const char *ev = std::getenv("MPC_NO_XQ_EARLY"); h->no_xq_early = ev ? std::atoi(ev) : 0; }
+    { const char *ev = std::getenv("MPC_XQ_EARLY_REGIONS"); if (ev) h->xq_early_regions = std::atoll(ev); }
     { const char *ev = std::getenv("MPC_NO_KKT_THREAD"); h->no_kkt_thread = ev ? std::atoi(ev) : 0; }   // 2: only the small-level path
     { const char *ev = std::getenv("MPC_NO_ROVERLAP"); h->no_roverlap = ev && ev[0] == '1'; }
     { const char *ev = std::getenv("MPC_TEST_LATE"); h->test_late = ev ? std::atoi(ev) : 0; }
@@ -1062,6 +1068,8 @@ int mpc_destroy(mpc_handle *h) {
     return_event(h->ev_hi, false);
     return_event(h->ev_fork, false);
     return_event(h->ev_join, false);
+    return_event(h->ev_xfork, false);
+    return_event(h->ev_xjoin, false);
     return_event(h->ev_rfork, false);
     return_event(h->ev_rjoin, false);
     return_event(h->ev_rgo, false);
@@ -1141,7 +1149,7 @@ static int frontier_reset(mpc_handle *h, long long n, int k) {
     if (n > 0x7fffffffLL / std::max(k + 1, 1)) return fail(h, MPC_ERR_INVALID, "frontier too large for 32-bit offsets");
     HIP_TRY(h, hipSetDevice(h->device));
     HIP_TRY(h, h->frontier.ensure((size_t)std::max<long long>(n, 1) * std::max(k, 1) * sizeof(int32_t), h->stream));
-    h->n = n; h->k = k; h->level_done = false; h->n_pruned_extra = 0; h->n_prev = 0;
+    h->n = n; h->k = k; h->level_done = false; h->n_pruned_extra = 0; h->n_prev = 0; h->prev_regions = 0;
     h->have_prev_dict = false; h->have_parent_slot = false;   // a frontier set from outside has no cached parent dictionaries
     return MPC_OK;
 }
@@ -1950,7 +1958,7 @@ static int level_run_impl(mpc_handle *h, int32_t gen_children, int32_t flags, mp
     float ms[3] = {0, 0, 0}, kms[5] = {0, 0, 0, 0, 0};
     bool kernel_timed[5] = {false, false, false, false, false};
     long long n_x_items = 0, n_theta_items = 0, n_xq_items = 0;
-    bool xq_thread_timed = false;
+    bool xq_thread_timed = false, xq_early_ran = false;
     h->n_xq_thread = 0; h->ms_xq_thread = 0;
     if (n > 0) {
         const size_t nn = (size_t)n;
@@ -2235,6 +2243,48 @@ static int level_run_impl(mpc_handle *h, int32_t gen_children, int32_t flags, mp
                 std::swap(h->theta_list, h->retry_list);   // compact() filled retry_list; keep it as the theta list
                 theta_list = h->theta_list.as<int32_t>();
             }
+            // The quick test's thread pass BESIDE the theta stage (round 5).  On a level that keeps no dictionaries, k_kkt_thread's box
+            // screen has already sent almost every candidate to the (x,theta) question (config 4's last level: 98.5 %), and that
+            // question does not depend on the theta stage at all.  Their list is cut here and k_xq_thread takes it on the second
+            // stream -- a kernel bound by the cache's request rate beside one bound by dependent fp64 latency -- ; the two meet
+            // before the partition that follows the theta stage, which then sees only what the pass left open.
+            bool early_xq = false;
+            if (kkc && lean && h->no_xq_early <= 0 && h->xq_thread != 0 && !h->no_xquick && !(flags & MPC_LEVEL_GRAPH) && h->have_prev_dict && h->have_parent_slot &&
+                n >= 4096 && !h->force_xqgroup && (h->no_xq_early < 0 || h->prev_regions < h->xq_early_regions)) {
+                // (only when this level's region stage is expected to be short -- the previous level found fewer than xq_early_regions
+                //  regions: otherwise the pass is worth more beside the REGION kernel, which it overlaps when it runs behind the theta
+                //  stage.  Config 4's last level, 6,238 regions: 1.76 ms behind, 1.91 beside the theta stage; config 3's, 276 regions:
+                //  3.41 / 3.23 ms.  MPC_NO_XQ_EARLY=1 never, =-1 always.)
+                const int nxc_e = h->fast_x >= 2 ? 32 : 16;
+                const long long sd_e = (long long)nxc_e * h->Pf.n_d0r, si_e = dict_ints(h->Pf.n_d0r, nxc_e, h->n_c);
+                const bool will_store = gen_children && (double)nn * (sd_e * 8.0 + si_e * 4.0) / 1e9 <= h->dict_budget_gb;
+                if (!will_store) {
+                    { int rcs = compact(ST_NEEDX, ST_NEEDX_SING, nullptr, dcnt + 10); if (rcs) return rcs; }
+                    HIP_TRY(h, h->xq_list.ensure(nn * sizeof(int32_t), st));
+                    std::swap(h->xq_list, h->retry_list);
+                    DictCache dq{};
+                    dq.stride_d = sd_e; dq.stride_i = si_e;
+                    dq.parent_slot = h->parent_slot.as<int32_t>();
+                    dq.prev_d = h->dict_d[1 - h->dict_cur].as<double>(); dq.prev_i = h->dict_i[1 - h->dict_cur].as<int32_t>();
+                    dq.n_list_dev = dcnt + 10;
+                    XqAlt alt{};
+                    if ((h->xq_thread >= 2 || h->xq_thread < 0) && h->n_prev > 0 && h->n_prev <= 0x7fffffffLL && k >= 2 &&
+                        h->children.cap >= (size_t)h->n_prev * (k - 1) * sizeof(int32_t) && h->dict_stored[1 - h->dict_cur].cap >= (size_t)h->n_prev) {
+                        alt.prev_frontier = h->children.as<int32_t>(); alt.prev_stored = h->dict_stored[1 - h->dict_cur].as<uint8_t>();
+                        alt.n_prev = (int)h->n_prev; alt.tries = h->xq_thread < 0 ? MPC_MAX_NC : h->xq_thread - 1;
+                    }
+                    HIP_TRY(h, hipEventRecord(h->ev_xfork, st));
+                    HIP_TRY(h, hipStreamWaitEvent(h->stream2, h->ev_xfork, 0));
+                    const unsigned gt = (unsigned)std::min<long long>((n + 63) / 64, (long long)h->n_cu * h->xqt_wpc);
+                    HIP_TRY(h, hipEventRecord(h->kev[10], h->stream2));
+                    hipLaunchKernelGGL(k_xq_thread, dim3(gt), dim3(64), 0, h->stream2, pf, fr, k, h->xq_list.as<int32_t>(), (int)n, stp, ctr, dq, nxc_e, alt);
+                    HIP_TRY(h, hipEventRecord(h->kev[11], h->stream2));
+                    HIP_TRY(h, hipGetLastError());
+                    HIP_TRY(h, hipEventRecord(h->ev_xjoin, h->stream2));
+                    xq_thread_timed = true;
+                    early_xq = true; xq_early_ran = true;
+                }
+            }
             if (n_theta > 0) {   // two-stage theta LP
                 ThetaArgs ta = h->targs;
                 ta.chunk = (int)std::max<long long>(1, std::min<long long>(16, n_theta / ((long long)h->grid_f * 8)));
@@ -2263,6 +2313,7 @@ static int level_run_impl(mpc_handle *h, int32_t gen_children, int32_t flags, mp
             // One partition after the theta stage: [0] numerically doubtful (status 7), [1] feasible and [2] optimal (decided
             // in theta space; they only need a dictionary for their children), [3] feasibility still open.
             int32_t cntA[PART_CLASSES] = {0, 0, 0, 0};
+            if (early_xq) HIP_TRY(h, hipStreamWaitEvent(st, h->ev_xjoin, 0));   // the thread pass rewrites statuses of its own candidates
             { int rcs = partition({{ST_RETRY, 0}, {ST_FEASIBLE, 1}, {ST_OPT_PENDING, 2}, {ST_NEEDX, 3}, {ST_NEEDX_SING, 3}}, cntA); if (rcs) return rcs; }
             // The doubtful candidates are re-solved by the LDS engine, which can refactorise its basis: a few hundred
             // long-running wavefronts.  They run on the side stream while the (x,theta) stage fills the GPU; their results are
@@ -2386,7 +2437,7 @@ static int level_run_impl(mpc_handle *h, int32_t gen_children, int32_t flags, mp
                 const int32_t *xq_list = needx_list;
                 int32_t xq_n = n_needx;
                 bool xqt_lean = false;
-                if (h->xq_thread != 0 && n_needx >= 4096) {
+                if (h->xq_thread != 0 && n_needx >= 4096 && !early_xq) {
                     const unsigned gt = (unsigned)std::min<long long>(((long long)n_needx + 63) / 64, (long long)h->n_cu * h->xqt_wpc);
                     HIP_TRY(h, hipEventRecord(h->kev[10], st));
                     XqAlt alt{};
@@ -2589,6 +2640,7 @@ static int level_run_impl(mpc_handle *h, int32_t gen_children, int32_t flags, mp
         HIP_TRY(h, hipEventElapsedTime(&ms[2], h->ev[2], h->ev[3]));
         for (int i = 0; i < 5; ++i) if (kernel_timed[i]) HIP_TRY(h, hipEventElapsedTime(&kms[i], h->kev[2 * i], h->kev[2 * i + 1]));
         if (xq_thread_timed) { HIP_TRY(h, hipEventElapsedTime(&h->ms_xq_thread, h->kev[10], h->kev[11])); h->n_xq_thread = host_ctr.xq_thread; }
+        if (xq_early_ran) { n_xq_items += host_ctr.xq_thread; h->n_needx += host_ctr.xq_thread; }   // what the pass beside the theta stage decided never reached the partition's count
         if (kernel_timed[2] && host_ctr.r2_t1 > ~host_ctr.r2_not_t0 && h->wall_khz > 0)   // k_region2 times itself (see the kernel)
             kms[2] = (float)((double)(host_ctr.r2_t1 - ~host_ctr.r2_not_t0) / (double)h->wall_khz);
         if (h->debug_cycles)
@@ -3385,6 +3437,7 @@ int mpc_frontier_advance(mpc_handle *h) {
     h->have_prev_dict = h->storing;
     h->dict_cur = 1 - h->dict_cur;
     h->storing = false;
+    h->prev_regions = h->n_regions;
     h->n_prev = h->n;   // the frontier that has just been left sits in h->children until this level writes its own children
     h->n = h->n_children;
     h->k = h->k + 1;
