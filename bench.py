@@ -40,17 +40,29 @@ WORKLOADS = {
     # BASELINE.json quotes config 2 with "~50 regions": the doc formulation's state box |x| <= 4 gives 9 regions, |x| <= 20 gives 51
     'c2x20': ('double-integrator explicit-MPC mpQP, N=5, state box |x| <= 20 (n_x=15, n_theta=2, 10 equalities); full tree '
               '(4,381 candidates, 51 regions)', lambda pg: pg.double_integrator_data(5, x_bound=20.0), None),
+    # BASELINE config 5: the reference's control-allocation example (doc/control_allocation_example.rst), degenerate / LICQ-violating active sets
+    'c5': ('control-allocation mpQP of the reference documentation (degenerate and rank-deficient active sets); full tree',
+           lambda pg: pg.control_allocation_data(), None),
+    # BASELINE config 1: the 2-variable / 2-parameter transport mpLP of the reference tutorial (plumbing case)
+    'c1': ('transport mpLP of the reference tutorial (2 variables, 2 parameters); full tree', lambda pg: pg.transport_mplp_data(), None),
 }
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
-def build_program(name, device=0):
-    from ppopt_amd import MPQP_Program, Solver, problem_generator as pg
-    d = WORKLOADS[name][1](pg)
+def program_from_data(d, device=0):
+    from ppopt_amd import MPLP_Program, MPQP_Program, Solver
     with warnings.catch_warnings():
         warnings.simplefilter('ignore')
+        if d['Q'] is None:
+            return MPLP_Program(d['A'], d['b'], d['c'], d['H'], d['A_t'], d['b_t'], d['F'],
+                                equality_indices=d['equality_indices'], solver=Solver(device=device))
         return MPQP_Program(d['A'], d['b'], d['c'], d['H'], d['Q'], d['A_t'], d['b_t'], d['F'],
                             equality_indices=d['equality_indices'], solver=Solver(device=device))
+
+
+def build_program(name, device=0):
+    from ppopt_amd import problem_generator as pg
+    return program_from_data(WORKLOADS[name][1](pg), device)
 
 
 def theta_box(prog):
@@ -150,8 +162,14 @@ def main():
     ap.add_argument('--mi', type=int, default=1, help='mixed-integer enumeration extra on a synthetic mpMIQP (0 = skip)')
     ap.add_argument('--complete', type=int, default=1, help='complete solution of the workload by the connected-graph traversal, as an extra (0 = skip)')
     ap.add_argument('--dist-single', action='store_true', help='run the multi-GPU driver with a process group of one rank (self-test)')
+    ap.add_argument('--sweep', action='store_true', help='shape sweep over the target class (n_x <= 20, n_theta <= 10): one JSON line with a row per shape (tools/shape_sweep.py); not the headline')
     ap.add_argument('--deep', type=int, default=0, help='also time the six-level variant of c4 on one GPU (the scaling workload the multi-GPU runs report under extra)')
     args = ap.parse_args()
+    if args.sweep:
+        sys.path.insert(0, os.path.join(ROOT, 'tools'))
+        import shape_sweep
+        print(json.dumps(shape_sweep.run()), flush=True)
+        return
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
@@ -278,18 +296,32 @@ def main():
     #   k_xq      (last level) per candidate: list entry, parent slot, last index, status (13) + the integer part of the parent's
     #             record (4 x ints) + its value column (8 x rows) + the new row (8 x cols); per product-form iteration one column
     #             (8 x rows) and one row (8 x cols) of the record: "vectors touched x length"
+    #   round 5: most candidates of the quick test are decided by its one-thread first pass k_xq_thread (one byte of the record's position
+    #             table, three integers, the row's value, then the hinted column and the value column: 16 x rows, the row-kind mask 16),
+    #             the wavefront kernel gets what that pass leaves open.  When the pass ran inside the wavefront kernel's event window
+    #             (xq_thread_beside_theta == 0) its time is taken out of ms_xq.
+    def xq_wave_ms(p):
+        return max(0.0, p.get('ms_xq', 0.0) - (0.0 if p.get('xq_thread_beside_theta') else p.get('ms_xq_thread', 0.0)))
+    for p in all_levels:
+        p['ms_xq_wave'] = xq_wave_ms(p)
+        p['n_xq_wave_items'] = max(0, p.get('n_xq_items', 0) - p.get('n_xq_thread', 0))
     def xq_bytes(p):
         ints, rows, cols = p.get('xq_record', [0, 0, 0])
-        return p['n_xq_items'] * (13 + 4 * ints + 8 * rows + 8 * cols) + p['xq_pivots'] * 8 * (rows + cols)
-    add('k_xq', 'ms_xq', 'n_xq_items', xq_bytes)
+        return p['n_xq_wave_items'] * (13 + 4 * ints + 8 * rows + 8 * cols) + max(0, p['xq_pivots'] - p.get('n_xq_thread', 0)) * 8 * (rows + cols)
+    add('k_xq', 'ms_xq_wave', 'n_xq_wave_items', xq_bytes)
+    def xqt_bytes(p):
+        ints, rows, cols = p.get('xq_record', [0, 0, 0])
+        return p.get('n_xq_items', 0) * (13 + 1 + 12 + 8 + 16 + 16 * rows)   # one test per candidate (tests against other parents come on top: a lower bound)
+    add('k_xq_thread', 'ms_xq_thread', 'n_xq_items', xqt_bytes)
     # The roofline object follows SURVEY.md 8(d): achieved = B_alg x candidates/s for the path (all kernels of a level), against
     # the HBM peak.  `dominant_kernel` describes the kernel with the most time ON THE STEP'S CRITICAL PATH (its own algorithmic
     # bytes over its own HIP-event time), every heavy kernel stands under `kernels`.  Critical path: k_region2 runs on the handle's
     # side stream UNDER the (x,theta) stage on the large levels (mpc_level_stats.region_side_stream); there only what it takes beyond
     # that stage's kernels counts.  (Rounds 1-3 named the kernel with the largest total time, k_region2, most of which is hidden.)
     hidden = sum(min(p.get('ms_region2', 0.0), p.get('ms_x', 0.0) + p.get('ms_xq', 0.0)) for p in all_levels if p.get('region_side_stream'))
+    hidden_xqt = sum(min(p.get('ms_xq_thread', 0.0), p.get('ms_theta', 0.0)) for p in all_levels if p.get('xq_thread_beside_theta'))   # the pass under the theta stage
     for name, kk in kern.items():
-        kk['on_path_ms'] = kk['total_ms'] - (hidden if name == 'k_region2' else 0.0)
+        kk['on_path_ms'] = kk['total_ms'] - (hidden if name == 'k_region2' else (hidden_xqt if name == 'k_xq_thread' else 0.0))
     dominant = max(kern, key=lambda k: kern[k]['on_path_ms'])
     dom = kern[dominant]
     # Counter record of the same command (tools/profile_round3.sh -> tools/pmc_round.py -> profiles/r03_pmc.json): HBM-side bytes
@@ -300,7 +332,7 @@ def main():
     # fp64 share is priced at 4 cycles and the rest at 2 (v_fma_f32 wave64: 2 cycles, MI355X_MICROARCH.md).
     traffic = dom_traffic = None
     n_simd, clk_hz = 1024, 2.4e9
-    tpath = next((q for q in (os.path.join(ROOT, 'profiles', t + '_pmc.json') for t in ('r04', 'r03')) if os.path.exists(q)), '')
+    tpath = next((q for q in (os.path.join(ROOT, 'profiles', t + '_pmc.json') for t in ('r05', 'r04', 'r03')) if os.path.exists(q)), '')
     if tpath and os.path.exists(tpath):
         try:
             rec = json.load(open(tpath))
@@ -366,7 +398,7 @@ def main():
                      'achieved_over_kernel_time': bytes_path / max(ms_path, 1e-9) / 1e6,
                      'dominant_kernel': {'kernel': dominant, 'chosen_by': 'time on the critical path of the step (k_region2 under the (x,theta) stage is not)',
                                          'on_path_ms_per_step': {name: kk['on_path_ms'] / steps for name, kk in kern.items()},
-                                         'bound': 'hbm (dependent reads of the cached dictionaries)' if dominant in ('k_x2', 'k_xq') else 'fp64 VALU issue / dependent latency',
+                                         'bound': 'hbm (dependent reads of the cached dictionaries)' if dominant in ('k_x2', 'k_xq', 'k_xq_thread') else 'fp64 VALU issue / dependent latency',
                                          'achieved': dom['achieved_GBs'], 'frac': dom['achieved_GBs'] / HBM_PEAK_GBS,
                                          'launches': dom['launches'], 'avg_launch_ms': dom['avg_launch_ms'],
                                          'algorithmic_bytes_per_launch': dom['algorithmic_bytes'] / max(dom['launches'], 1),
@@ -510,7 +542,7 @@ def main():
                                 'one_by_one_ms': 1e3 * t_one, 'together_ms': 1e3 * t_many, 'speedup': t_one / t_many,
                                 'device_ms_shared_levels': float(sum(pp.get('ms_launches', 0.0) for pp in prof_sm)),
                                 'programs_per_s_together': len(small) / t_many}
-    if rank == 0 and not distributed and args.complete > 0 and args.workload in ('c4', 'c3', 'c2', 'c2x20'):
+    if rank == 0 and not distributed and args.complete > 0 and args.workload in ('c4', 'c3', 'c2', 'c2x20', 'c5'):
         # The COMPLETE explicit solution of the same program by the connected-graph traversal (mpqp_algorithm.graph, reference
         # mp_solvers/mpqp_graph.py) on the same kernels, wave / visited set / neighbours resident on the device.  Not part of `value`.
         from ppopt_amd.mp_solvers import mpqp_hip_combi_graph

@@ -105,7 +105,7 @@ typedef struct {
     /* round 5: the quick test's first pass with one thread per candidate (k_xq_thread): candidates it decided (of n_xq_items; the
      * wavefront kernel gets the others) and its HIP-event time (inside ms_xq) */
     int64_t n_xq_thread;
-    float ms_xq_thread, pad_;
+    float ms_xq_thread, xq_thread_beside_theta;   /* 1: the pass ran on the second stream beside the theta stage (outside ms_xq), 0: inside ms_xq */
 } mpc_level_stats;
 
 /* ---- library / device ------------------------------------------------------------------------------ */

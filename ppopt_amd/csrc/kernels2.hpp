@@ -826,14 +826,19 @@ MPC_GLOBAL void MPC_LB(64, XQ_WAVES) k_xq(const DevProblem *__restrict__ Pg, con
 // NEEDX status and goes on to k_xq unchanged.  ~20 wave-instructions per row of the record for 64 candidates, against ~150-200
 // per candidate in k_xq.
 // the test against ONE parent record: 1 feasible, 0 infeasible, -1 open; *by_test: decided by the ratio test (one pivot in k_xq's count)
-__device__ __forceinline__ int xq_first_test(const double *__restrict__ pd, const int32_t *__restrict__ pi, int mr, int ncol, int NXC, int nv, int v, bool *by_test) {
+// *step (when the answer is "feasible"): how the parent's dictionary becomes the candidate's -- XS_DROP << 16 | column: the slack is a
+// live nonbasic column, which is deleted;  XS_ZERO << 16 | row << 8: the slack is basic at zero, the row pivots on its largest entry;
+// XS_PIVOT << 16 | row << 8 | column: ONE pivot, the row leaves through the Harris test of its hinted column.
+constexpr int XS_DROP = 1, XS_ZERO = 2, XS_PIVOT = 3;
+__device__ __forceinline__ int xq_first_test(const double *__restrict__ pd, const int32_t *__restrict__ pi, int mr, int ncol, int NXC, int nv, int v, bool *by_test,
+                                             int *step = nullptr) {
     *by_test = false;
     const int32_t *pm = pi + dict_ints_head(mr, NXC);
     const int p = reinterpret_cast<const uint8_t *>(pm + 4)[v - nv];   // where the record says this slack sits (checked below)
     if (p >= 128) {
         // a live nonbasic column of the parent's dictionary: the slack is zero at the parent's vertex
         const int j = p - 128;
-        if (j >= 1 && j < ncol && pi[2 * mr + j] == v && (((unsigned)pi[2 * mr + NXC] >> j) & 1u)) return 1;
+        if (j >= 1 && j < ncol && pi[2 * mr + j] == v && (((unsigned)pi[2 * mr + NXC] >> j) & 1u)) { if (step) *step = (XS_DROP << 16) | j; return 1; }
         return -1;
     }
     if (p >= mr || pi[p] != v) return -1;
@@ -841,7 +846,7 @@ __device__ __forceinline__ int xq_first_test(const double *__restrict__ pd, cons
     if ((kraw & 0xff) != RK_INEQ) return -1;
     const int row = p, q0 = kraw >> 8;
     const double brow = pd[row];
-    if (brow <= TOL_FEAS) return 1;
+    if (brow <= TOL_FEAS) { if (step) *step = (XS_ZERO << 16) | (row << 8); return 1; }
     if (q0 <= 0) return 0;
     // Four rows per trip, each vector fetched with 16-byte loads (records are 8-byte aligned, the hardware takes unaligned
     // global accesses): a lane's column is ITS OWN walk -- 64 distinct lines per wave-level load -- and the kernel is bound
@@ -889,7 +894,7 @@ __device__ __forceinline__ int xq_first_test(const double *__restrict__ pd, cons
         const double growth0 = __hiloint2double(pi[2 * mr + NXC + 1], pi[2 * mr + NXC + 2]);
         const double inv = fast_rcp(a_row);
         const double growth = fmax(growth0, (double)(cmf * (float)inv));
-        if (!(growth > GROWTH_SAFE)) { *by_test = true; return 1; }
+        if (!(growth > GROWTH_SAFE)) { *by_test = true; if (step) *step = (XS_PIVOT << 16) | (row << 8) | q0; return 1; }
     }
     return -1;
 }
@@ -904,26 +909,63 @@ struct XqAlt {
     const uint8_t *prev_stored;     // [n_prev]
     int n_prev, tries;
 };
+// Plan mode (x1_list != nullptr): a level that KEEPS dictionaries.  Every candidate that needs one -- the open ones (`list`) and, before
+// them, the ones the theta stage already decided (pre1, pre2: status untouched) -- is asked the same question, and the answer is kept
+// as a plan: from which parent slot, by which single step (xq_first_test's *step).  Planned candidates are appended to x1_list (k_x1
+// streams the parent's record through that one pivot), the others to rest[segment] (k_x2, the register simplex, as before).
+struct XqPlan {
+    int32_t *plan_slot, *plan_step;   // [n] by candidate
+    int32_t *x1_list, *x1_n;
+    int32_t *rest[3], *rest_n[3];
+    const int32_t *pre1, *pre2;
+    int n_pre1, n_pre2;
+};
 // One wavefront = 64 candidates at a time, lanes always full: a candidate its generating parent leaves open goes into the wavefront's
 // queue (LDS) with "try 1"; whenever 64 are queued (or the input has run out) the wavefront takes them up again, each lane with its
 // own try number.  No global atomics, no compaction between the tries.
 MPC_GLOBAL void MPC_LB(64) k_xq_thread(const DevProblem *__restrict__ Pg, const int32_t *__restrict__ cands, int k,
                                        const int32_t *__restrict__ list, int n_list, uint8_t *__restrict__ status,
-                                       LevelCounters *__restrict__ ctr, DictCache dc, int NXC, XqAlt alt) {
+                                       LevelCounters *__restrict__ ctr, DictCache dc, int NXC, XqAlt alt, XqPlan pl) {
     __shared__ int q_c[128], q_t[128];
     const DevProblem &P = *Pg;
     const int nv = P.n_x + P.n_t, mr = P.n_d0r, ncol = P.n_d0c + 1, lane = threadIdx.x, km = k - 1;
     if (dc.n_list_dev) n_list = *dc.n_list_dev;
+    const bool plan = pl.x1_list != nullptr;
+    const int n_pre = plan ? pl.n_pre1 + pl.n_pre2 : 0;
+    const long long n_items = (long long)n_pre + n_list;
     const int max_try = (alt.tries > 0 && alt.n_prev > 0 && k >= 2) ? min(alt.tries, km - P.n_eq) : 0;   // tries 1..max_try leave out position km - t
     unsigned int n_dec = 0, n_piv = 0, n_alt = 0;   // per lane: candidates decided / decided by a ratio test / decided from another parent
     int qn = 0;                                      // queued items (wave-uniform)
     const unsigned long long below = (1ull << lane) - 1ull;
-    auto finish = [&](int c, int feas, bool by_test, bool from_alt) {
-        const bool singular = status[c] == ST_NEEDX_SING;
-        status[c] = (uint8_t)(feas ? (singular ? ST_SINGULAR : ST_FEASIBLE) : ST_INFEASIBLE);
-        n_dec++;
-        if (by_test) n_piv++;
-        if (from_alt) n_alt++;
+    // appends the candidates of the lanes with `want` to a list in global memory (one atomic per wavefront and call)
+    auto append = [&](bool want, int c, int32_t *dst, int32_t *cnt) {
+        const unsigned long long m = __ballot(want);
+        if (m == 0ull) return;
+        int base = 0;
+        if (lane == 0) base = atomicAdd(cnt, __popcll(m));
+        base = __builtin_amdgcn_readfirstlane(base);
+        if (want) dst[base + __popcll(m & below)] = c;
+    };
+    // an item ends here: feas 1 / 0 / -1 (nothing found), seg 0 / 1: decided by the theta stage (dictionary only), 2: open
+    auto finish = [&](bool live, int c, int seg, int feas, bool by_test, bool from_alt, int slot, int step) {
+        bool planned = false, left = false;
+        if (live) {
+            if (seg < 2 && feas == 0) feas = -1;          // (cannot be: the theta stage found it feasible) -- left to k_x2
+            if (feas >= 0 && seg == 2) {
+                const bool singular = status[c] == ST_NEEDX_SING;
+                status[c] = (uint8_t)(feas ? (singular ? ST_SINGULAR : ST_FEASIBLE) : ST_INFEASIBLE);
+            }
+            if (feas >= 0) { n_dec++; if (by_test) n_piv++; if (from_alt) n_alt++; }
+            planned = plan && feas == 1;
+            left = plan && feas < 0;
+            if (planned) { pl.plan_slot[c] = slot; pl.plan_step[c] = step; }
+        }
+        if (plan) {
+            append(planned, c, pl.x1_list, pl.x1_n);
+            append(left && seg == 0, c, pl.rest[0], pl.rest_n[0]);
+            append(left && seg == 1, c, pl.rest[1], pl.rest_n[1]);
+            append(left && seg == 2, c, pl.rest[2], pl.rest_n[2]);
+        }
     };
     auto push = [&](bool want, int c, int t) {   // wave-uniform call
         const unsigned long long m = __ballot(want);
@@ -933,31 +975,34 @@ MPC_GLOBAL void MPC_LB(64) k_xq_thread(const DevProblem *__restrict__ Pg, const 
     };
     long long w0 = (long long)blockIdx.x * 64;
     for (;;) {
-        const bool have_input = w0 < n_list;
+        const bool have_input = w0 < n_items;
         if (have_input) {
             const long long w = w0 + lane;
             w0 += (long long)gridDim.x * 64;
-            int c = -1, feas = -1;
-            bool by_test = false, open = false;
-            if (w < n_list) {
-                c = list[w];
-                const int ps = dc.parent_slot[c];
-                if (ps >= 0) {
-                    feas = xq_first_test(dc.prev_d + (size_t)ps * dc.stride_d, dc.prev_i + (size_t)ps * dc.stride_i, mr, ncol, NXC, nv, nv + cands[(size_t)c * k + km], &by_test);
-                    open = feas < 0;
-                    if (feas >= 0) finish(c, feas, by_test, false);
+            int c = -1, feas = -1, seg = 2, slot = -1, step = 0;
+            bool by_test = false, open = false, live = false;
+            if (w < n_items) {
+                live = true;
+                if (w < n_pre) { seg = w < pl.n_pre1 ? 0 : 1; c = seg == 0 ? pl.pre1[w] : pl.pre2[w - pl.n_pre1]; }
+                else c = list[w - n_pre];
+                slot = dc.parent_slot[c];
+                if (slot >= 0) {
+                    feas = xq_first_test(dc.prev_d + (size_t)slot * dc.stride_d, dc.prev_i + (size_t)slot * dc.stride_i, mr, ncol, NXC, nv, nv + cands[(size_t)c * k + km], &by_test, &step);
+                    open = feas < 0 && max_try > 0;
                 }
             }
-            if (max_try > 0) push(open, c, 1);
+            finish(live && !open && (plan || feas >= 0), c, seg, feas, by_test, false, slot, step);
+            if (max_try > 0) push(open, c, 1 | (seg << 8));
         }
         // the queue is taken up when it holds a full wavefront, or when nothing new will come
         while (qn >= 64 || (!have_input && qn > 0)) {
             const int take = min(qn, 64);
             qn -= take;
-            int c = -1, t = 0;
-            if (lane < take) { c = q_c[qn + lane]; t = q_t[qn + lane]; }
+            int c = -1, t = 0, seg = 2;
+            if (lane < take) { c = q_c[qn + lane]; t = q_t[qn + lane] & 0xff; seg = q_t[qn + lane] >> 8; }
             wave_sync();
-            bool again = false;
+            bool again = false, by_test = false;
+            int feas = -1, found = -1, step = 0;
             if (c >= 0) {
                 const int32_t *as = cands + (size_t)c * k;
                 const int drop = km - t;   // position of the member this parent does not have (t = 1: the second largest)
@@ -971,13 +1016,13 @@ MPC_GLOBAL void MPC_LB(64) k_xq_thread(const DevProblem *__restrict__ Pg, const 
                     }
                     return cmp;
                 };
-                int lo = 0, hi = alt.n_prev - 1, found = -1;
+                int lo = 0, hi = alt.n_prev - 1;
                 if (t == 1) {
                     // {.., e} without the second largest member is a SIBLING of the generating parent {.., d}: same prefix, larger last
                     // member, i.e. a few rows further on in the same block of the previous frontier -- walked, not searched
                     const int ps = dc.parent_slot[c];
                     lo = ps + 1;
-                    for (int step = 0; step < 24 && lo <= hi; ++step, ++lo) {
+                    for (int stp = 0; stp < 24 && lo <= hi; ++stp, ++lo) {
                         const int cmp = cmp_row(lo);
                         if (cmp >= 0) { if (cmp == 0) found = lo; hi = lo - 1; break; }
                     }
@@ -988,21 +1033,20 @@ MPC_GLOBAL void MPC_LB(64) k_xq_thread(const DevProblem *__restrict__ Pg, const 
                     if (cmp == 0) { found = mid; break; }
                     if (cmp < 0) lo = mid + 1; else hi = mid - 1;
                 }
-                int feas = -1;
-                bool by_test = false;
                 if (found >= 0 && alt.prev_stored[found])
-                    feas = xq_first_test(dc.prev_d + (size_t)found * dc.stride_d, dc.prev_i + (size_t)found * dc.stride_i, mr, ncol, NXC, nv, nv + as[drop], &by_test);
-                if (feas >= 0) finish(c, feas, by_test, true);
-                else again = t < max_try;
+                    feas = xq_first_test(dc.prev_d + (size_t)found * dc.stride_d, dc.prev_i + (size_t)found * dc.stride_i, mr, ncol, NXC, nv, nv + as[drop], &by_test, &step);
+                if (seg < 2 && feas == 0) feas = -1;
+                again = feas < 0 && t < max_try;
             }
-            push(again, c, t + 1);
+            finish(c >= 0 && !again && (plan || feas >= 0), c, seg, feas, by_test, true, found, step);
+            push(again, c, (t + 1) | (seg << 8));
         }
         if (!have_input) break;
     }
     // per wavefront one set of atomics (as the wavefront kernel)
     for (int off = 32; off > 0; off >>= 1) { n_dec += __shfl_xor(n_dec, off); n_piv += __shfl_xor(n_piv, off); n_alt += __shfl_xor(n_alt, off); }
     if (lane == 0 && n_dec) {
-        atomicAdd(&ctr->pivots, (unsigned long long)n_piv); atomicAdd(&ctr->xq_pivots, (unsigned long long)n_piv);
+        if (!plan) { atomicAdd(&ctr->pivots, (unsigned long long)n_piv); atomicAdd(&ctr->xq_pivots, (unsigned long long)n_piv); }   // (plan mode: k_x1 counts the pivots it executes)
         atomicAdd(&ctr->x_cached, (unsigned long long)n_dec); atomicAdd(&ctr->xtheta_lps, (unsigned long long)n_dec);
         atomicAdd(&ctr->xq_thread, n_dec);
         if (n_alt) atomicAdd(&ctr->pad_xq, n_alt);
@@ -1256,6 +1300,158 @@ MPC_GLOBAL void MPC_LB(64, (NXC * SLOTS >= 64 ? 2 : (NXC * SLOTS >= 32 ? X2_WAVE
         atomicAdd(&ctr->cycles[2], (unsigned long long)cyc_x);
         atomicAdd(&ctr->pivots, pivots); atomicAdd(&ctr->xtheta_fallbacks, n_retry); atomicAdd(&ctr->x_cached, n_cached);
     }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// k_x1 (round 5): the dictionary of a candidate whose plan (k_xq_thread, plan mode) is ONE step from a parent's record -- the step
+// k_x2 would take from that record, executed as a STREAM: the pivot column and the pivot row's scale are the only state, every other
+// column is read, updated with one fma per entry and written back.  No tableau in registers (a dozen VGPRs instead of 250: eight
+// wavefronts per SIMD where k_x2<32,.> has two), no pricing, no ratio test (the plan is the outcome of both), one or two tableau rows
+// per lane alike.  Same operations on the same numbers as RegLp::pivot_core / drop_col and k_x2's store: the record is bit for bit
+// the one k_x2 leaves when it starts from that parent (tests/test_gpu_deep.py, MPC_X1=1 against MPC_X1=0).
+//   XS_DROP   the new row's slack is a live nonbasic column: the column is deleted (zeroed), nothing else changes
+//   XS_ZERO   it is basic at zero: the row pivots on its largest entry (RegLp::best_col) and that column is deleted; no entry: the row is dead
+//   XS_PIVOT  it leaves the basis through the Harris test of column q: pivot (row, q), growth monitor, column q deleted
+template <int SLOTS>
+MPC_GLOBAL void MPC_LB(64, 8) k_x1(const DevProblem *__restrict__ Pg, const int32_t *__restrict__ x1_list, const int32_t *__restrict__ x1_n,
+                                    LevelCounters *__restrict__ ctr, DictCache dc, int NXC, const int32_t *__restrict__ plan_slot,
+                                    const int32_t *__restrict__ plan_step) {
+    const DevProblem &P = *Pg;
+    const int lane = lane_id(), nv = P.n_x + P.n_t, mr = P.n_d0r, nc0 = P.n_d0c;
+    const int n = *x1_n;
+    unsigned long long pivots = 0;
+    auto at = [&](const double (&vec)[SLOTS], int r) -> double {
+        if (SLOTS == 1) return readlane_f64(vec[0], r & 63);
+        return readlane_f64(r < 64 ? opaque(vec[0]) : opaque(vec[SLOTS - 1]), r & 63);
+    };
+    auto at_i = [&](const int (&vec)[SLOTS], int r) -> int {
+        if (SLOTS == 1) return __builtin_amdgcn_readlane(vec[0], r & 63);
+        return __builtin_amdgcn_readlane(r < 64 ? opaque(vec[0]) : opaque(vec[SLOTS - 1]), r & 63);
+    };
+    for (int w = blockIdx.x; w < n; w += gridDim.x) {
+        const int c = x1_list[w];
+        const int ps = plan_slot[c], step = plan_step[c];
+        const int type = step >> 16, r = (step >> 8) & 0xff;
+        int q = step & 0xff;
+        const double *pd = dc.prev_d + (size_t)ps * dc.stride_d;
+        const int32_t *pi = dc.prev_i + (size_t)ps * dc.stride_i;
+        double *od = dc.cur_d + (size_t)c * dc.stride_d;
+        int32_t *oi = dc.cur_i + (size_t)c * dc.stride_i;
+        int var[SLOTS], kind[SLOTS];
+#pragma unroll
+        for (int sl = 0; sl < SLOTS; ++sl) {
+            const int i = lane + 64 * sl;
+            var[sl] = i < mr ? pi[i] : -1;
+            kind[sl] = i < mr ? (pi[mr + i] & 0xff) : RK_DEAD;
+        }
+        int cvv = lane < NXC + 3 ? pi[2 * mr + lane] : -1;
+        unsigned alive = (unsigned)__builtin_amdgcn_readlane(cvv, NXC);
+        double growth = __hiloint2double(__builtin_amdgcn_readlane(cvv, NXC + 1), __builtin_amdgcn_readlane(cvv, NXC + 2));
+        bool pivot = type == XS_PIVOT;
+        if (type == XS_ZERO) {
+            // RegLp::best_col: the largest |entry| of the row above the pivot tolerance, lowest column among equals (deleted columns are zero)
+            const double e = (lane >= 1 && lane <= nc0) ? fabs(pd[(size_t)lane * mr + r]) : 0.0;
+            const double em = dpp_wave_max(e);
+            if (em > TOL_PIV) { q = uni(__ffsll((long long)__ballot(e == em && lane >= 1 && lane <= nc0)) - 1); pivot = true; }
+            else {
+#pragma unroll
+                for (int sl = 0; sl < SLOTS; ++sl) if (lane + 64 * sl == r) kind[sl] = RK_DEAD;
+            }
+        }
+        double f[SLOTS], fz[SLOTS];
+        double inv = 0.0;
+#pragma unroll
+        for (int sl = 0; sl < SLOTS; ++sl) { f[sl] = 0.0; fz[sl] = 0.0; }
+        if (pivot) {
+            float cmf = 0.0f;
+#pragma unroll
+            for (int sl = 0; sl < SLOTS; ++sl) {
+                const int i = lane + 64 * sl;
+                f[sl] = i < mr ? pd[(size_t)q * mr + i] : 0.0;
+                if (i < mr && kind[sl] != RK_DEAD) cmf = fmaxf(cmf, fabsf((float)f[sl]));
+                fz[sl] = i == r ? 0.0 : f[sl];
+            }
+            inv = fast_rcp(at(f, r));
+            if (type == XS_PIVOT) growth = fmax(growth, (double)(dpp_wave_max_f32(cmf) * (float)inv));   // (the ratio-test pivot is monitored, the pivot on a zero row is not: RegLp::primal / pivot)
+            pivots++;
+        }
+        const int qdel = (pivot || type == XS_DROP) ? q : -1;   // the column that is deleted
+        int qhint[SLOTS];
+        double gbest[SLOTS];
+#pragma unroll
+        for (int sl = 0; sl < SLOTS; ++sl) { qhint[sl] = 0; gbest[sl] = TOL_COST; }
+        // columns in groups of CB: all loads of a group are issued before the first is used (the stream is bound by how many bytes are in
+        // flight, one column at a time left the kernel at a third of the memory rate)
+        constexpr int CB = SLOTS == 1 ? 8 : 4;
+        for (int j0 = 0; j0 <= nc0; j0 += CB) {
+            double t[CB][SLOTS];
+#pragma unroll
+            for (int u = 0; u < CB; ++u) {
+                const int j = min(j0 + u, nc0);
+#pragma unroll
+                for (int sl = 0; sl < SLOTS; ++sl) { const int i = lane + 64 * sl; t[u][sl] = i < mr ? pd[(size_t)j * mr + i] : 0.0; }
+            }
+#pragma unroll
+            for (int u = 0; u < CB; ++u) {
+                const int j = j0 + u;
+                if (j <= nc0) {
+                    if (j == qdel) {
+#pragma unroll
+                        for (int sl = 0; sl < SLOTS; ++sl) t[u][sl] = 0.0;
+                    } else if (pivot) {
+                        const double trj = at(t[u], r) * inv;    // the pivot row's entry, scaled in its own lane by pivot_core
+#pragma unroll
+                        for (int sl = 0; sl < SLOTS; ++sl) t[u][sl] = fma(-fz[sl], trj, (lane + 64 * sl == r) ? trj : t[u][sl]);   // (the pivot lane too: fz = 0, as pivot_core)
+                    }
+#pragma unroll
+                    for (int sl = 0; sl < SLOTS; ++sl) {
+                        const int i = lane + 64 * sl;
+                        if (i < mr) {
+                            od[(size_t)j * mr + i] = t[u][sl];
+                            if (j >= 1 && t[u][sl] > gbest[sl]) { gbest[sl] = t[u][sl]; qhint[sl] = j; }
+                        }
+                    }
+                }
+            }
+        }
+        if (pivot) {
+            // the entering variable becomes basic in row r, the row's old variable sits in the (deleted) column
+            const int vq = __builtin_amdgcn_readlane(cvv, q), vr = at_i(var, r);
+#pragma unroll
+            for (int sl = 0; sl < SLOTS; ++sl) if (lane + 64 * sl == r) { var[sl] = vq; kind[sl] = RK_INEQ; }
+            if (lane == q) cvv = vr;
+        }
+        if (qdel >= 0) alive &= ~(1u << qdel);
+#pragma unroll
+        for (int sl = 0; sl < SLOTS; ++sl) {
+            const int i = lane + 64 * sl;
+            if (i < mr) { oi[i] = var[sl]; oi[mr + i] = kind[sl] | (qhint[sl] << 8); }
+        }
+        if (lane < NXC) oi[2 * mr + lane] = cvv;
+        {
+            int32_t *om = oi + dict_ints_head(mr, NXC);
+            uint8_t *opos = reinterpret_cast<uint8_t *>(om + 4);
+            const int ncp = P.n_c;
+#pragma unroll
+            for (int sl = 0; sl < 2; ++sl) {
+                const unsigned long long bm = sl < SLOTS ? __ballot(lane + 64 * sl < mr && kind[sl < SLOTS ? sl : 0] == RK_INEQ) : 0ull;
+                if (lane == 0) { om[2 * sl] = (int)(unsigned)bm; om[2 * sl + 1] = (int)(unsigned)(bm >> 32); }
+            }
+#pragma unroll
+            for (int sl = 0; sl < SLOTS; ++sl) {
+                const int i = lane + 64 * sl, cidx = var[sl] - nv;
+                if (i < mr && cidx >= 0 && cidx < ncp) opos[cidx] = (uint8_t)i;
+            }
+            { const int cidx = cvv - nv; if (lane >= 1 && lane <= nc0 && ((alive >> lane) & 1u) && cidx >= 0 && cidx < ncp) opos[cidx] = (uint8_t)(128 + lane); }
+        }
+        if (lane == 0) {
+            oi[2 * mr + NXC] = (int)alive;
+            oi[2 * mr + NXC + 1] = __double2hiint(growth);
+            oi[2 * mr + NXC + 2] = __double2loint(growth);
+            dc.stored[c] = 1;
+        }
+    }
+    if (lane == 0 && pivots) atomicAdd(&ctr->pivots, pivots);
 }
 
 // ------------------------------------------------------------------------------------------------------------------

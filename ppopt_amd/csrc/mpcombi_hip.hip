@@ -324,6 +324,9 @@ struct mpc_handle {
     int no_rbox = 0;          // MPC_NO_RBOX=1: no bounding-box screen of the region rows in k_region2 (A/B)
     int no_rsplit = 0;        // MPC_NO_RSPLIT=1: one wavefront per candidate in k_region2 whatever the load (A/B)
     int no_xquick = 0;        // MPC_NO_XQUICK=1: no quick (x,theta) test on the last level (A/B)
+    int x1 = 1;               // MPC_X1=0: every dictionary of a storing level by the register simplex k_x2 (rounds 1-4); 1: one-step plans (k_xq_thread, plan mode) streamed by k_x1, from the generating parent only; 2 (default): ... and from the candidate's other parents
+    int x1_wpc = 16;          // MPC_X1_WPC: wavefronts per CU of k_x1 (config 4, level 4, beside the region kernel: x stage 1.13 / 0.95 / 1.02 ms with 8 / 16 / 32)
+    long long n_x1 = 0;       // dictionaries of the last level run that k_x1 wrote
     int no_xq_early = 0;      // MPC_NO_XQ_EARLY=1: the thread pass of the quick test always behind the theta stage, -1: always beside it (A/B)
     long long prev_regions = 0, xq_early_regions = 1024;   // regions of the level before; MPC_XQ_EARLY_REGIONS
     int xqt_wpc = 16;         // MPC_XQT_WPC: wavefronts per CU of k_xq_thread (it is bound by the cache's request rate: config 4's level 0.45 ms alone with 8 per CU, 0.49 with 24; beside the region kernel 0.92 / 0.70 / 0.78 / 0.75 with 4 / 8 / 12 / 16)
@@ -341,7 +344,7 @@ struct mpc_handle {
     long long n_needx = 0;
     DevProblem Pf{};          // view for k_verdict2 (small LDS layout: no tableau)
     int lds_f = 0, grid_f = 0;
-    DevBuf retry_list, theta_list, vretry_list, status_tmp, part_counts, part_lists, kept_g, done_g, pf_dev, pr2_dev, headd, headi, epool, facet_flags, kkt_code, kkt_L, theta_blocks, xq_groups, xq_list;
+    DevBuf retry_list, theta_list, vretry_list, status_tmp, part_counts, part_lists, kept_g, done_g, pf_dev, pr2_dev, headd, headi, epool, facet_flags, kkt_code, kkt_L, theta_blocks, xq_groups, xq_list, x1_buf;
     ThetaArgs targs{};
     // (x,theta) dictionary cache: [0]/[1] ping-pong between the level being read (parents) and the level being written
     DevBuf dict_d[2], dict_i[2], dict_stored[2], parent_slot, parent_slot_next;
@@ -530,7 +533,7 @@ void lu_solve_host(const std::vector<double> &LU, const std::vector<int> &perm, 
 // graveyard_flush, which the level paths call behind their closing synchronisation (all streams of the handle have been joined by then)
 static std::vector<DevBuf *> level_buffers(mpc_handle *h) {
     return {&h->frontier, &h->children, &h->status, &h->pruned, &h->flag, &h->pos, &h->opt_list, &h->childmask, &h->count, &h->offset, &h->recd, &h->reci,
-            &h->sums, &h->retry_list, &h->headd, &h->headi, &h->epool, &h->facet_flags, &h->kkt_code, &h->kkt_L, &h->xq_groups, &h->xq_list, &h->theta_list, &h->vretry_list,
+            &h->sums, &h->retry_list, &h->headd, &h->headi, &h->epool, &h->facet_flags, &h->kkt_code, &h->kkt_L, &h->xq_groups, &h->xq_list, &h->x1_buf, &h->theta_list, &h->vretry_list,
             &h->status_tmp, &h->part_counts, &h->part_lists, &h->kept_g, &h->done_g, &h->dict_d[0], &h->dict_d[1], &h->dict_i[0], &h->dict_i[1],
             &h->dict_stored[0], &h->dict_stored[1], &h->parent_slot, &h->parent_slot_next};
 }
@@ -616,6 +619,8 @@ static int create_fill(const mpc_problem *p, int32_t device, void *stream, mpc_h
     { const char *ev = std::getenv("MPC_XQ_THREAD"); h->xq_thread = ev ? std::atoi(ev) : -1; }
     { const char *ev = std::getenv("MPC_XQG_OVERLAP"); h->xqg_overlap = ev && ev[0] == '1'; }
     { const char *ev = std::getenv("MPC_XQT_WPC"); if (ev && std::atoi(ev) > 0) h->xqt_wpc = std::atoi(ev); }
+    { const char *ev = std::getenv("MPC_X1"); h->x1 = ev ? std::atoi(ev) : 2; }
+    { const char *ev = std::getenv("MPC_X1_WPC"); if (ev && std::atoi(ev) > 0) h->x1_wpc = std::atoi(ev); }
     { const char *ev = std::getenv("MPC_NO_XQ_EARLY"); h->no_xq_early = ev ? std::atoi(ev) : 0; }
     { const char *ev = std::getenv("MPC_XQ_EARLY_REGIONS"); if (ev) h->xq_early_regions = std::atoll(ev); }
     { const char *ev = std::getenv("MPC_NO_KKT_THREAD"); h->no_kkt_thread = ev ? std::atoi(ev) : 0; }   // 2: only the small-level path
@@ -1055,7 +1060,7 @@ int mpc_destroy(mpc_handle *h) {
     if (h->stream3) (void)hipStreamSynchronize(h->stream3);
     graveyard_flush(h);
     for (DevBuf *b : {&h->blocks, &h->iblocks, &h->frontier, &h->children, &h->status, &h->pruned, &h->flag, &h->pos, &h->opt_list,
-                      &h->childmask, &h->count, &h->offset, &h->recd, &h->reci, &h->ctr, &h->scratch, &h->sums, &h->retry_list, &h->pf_dev, &h->pr2_dev, &h->headd, &h->headi, &h->epool, &h->facet_flags, &h->kkt_code, &h->kkt_L, &h->theta_blocks, &h->xq_groups, &h->xq_list, &h->theta_list, &h->vretry_list, &h->status_tmp, &h->part_counts, &h->part_lists, &h->kept_g, &h->done_g, &h->dict_d[0], &h->dict_d[1], &h->dict_i[0], &h->dict_i[1],
+                      &h->childmask, &h->count, &h->offset, &h->recd, &h->reci, &h->ctr, &h->scratch, &h->sums, &h->retry_list, &h->pf_dev, &h->pr2_dev, &h->headd, &h->headi, &h->epool, &h->facet_flags, &h->kkt_code, &h->kkt_L, &h->theta_blocks, &h->xq_groups, &h->xq_list, &h->x1_buf, &h->theta_list, &h->vretry_list, &h->status_tmp, &h->part_counts, &h->part_lists, &h->kept_g, &h->done_g, &h->dict_d[0], &h->dict_d[1], &h->dict_i[0], &h->dict_i[1],
                       &h->dict_stored[0], &h->dict_stored[1], &h->parent_slot, &h->parent_slot_next, &h->dcnt}) b->release();
     if (h->tot_host) { (void)host_pool_give(h->tot_host); h->tot_host = h->tot_dev = nullptr; }
     for (HostBuf *b : {&h->st_list, &h->st_status, &h->st_hd, &h->st_hi, &h->st_pool, &h->st_fxd, &h->st_fxi, &h->st_rlist, &h->st_flags}) b->release();
@@ -1093,7 +1098,7 @@ int mpc_trim(mpc_handle *h) {
     graveyard_flush(h);
     stream_release(h);
     for (DevBuf *b : {&h->frontier, &h->children, &h->status, &h->pruned, &h->flag, &h->pos, &h->opt_list, &h->childmask, &h->count, &h->offset, &h->recd, &h->reci,
-                      &h->sums, &h->retry_list, &h->headd, &h->headi, &h->epool, &h->facet_flags, &h->kkt_code, &h->kkt_L, &h->xq_groups, &h->xq_list, &h->theta_list, &h->vretry_list,
+                      &h->sums, &h->retry_list, &h->headd, &h->headi, &h->epool, &h->facet_flags, &h->kkt_code, &h->kkt_L, &h->xq_groups, &h->xq_list, &h->x1_buf, &h->theta_list, &h->vretry_list,
                       &h->status_tmp, &h->part_counts, &h->part_lists, &h->kept_g, &h->done_g, &h->dict_d[0], &h->dict_d[1], &h->dict_i[0], &h->dict_i[1],
                       &h->dict_stored[0], &h->dict_stored[1], &h->parent_slot, &h->parent_slot_next}) b->release();
     for (HostBuf *b : {&h->st_list, &h->st_status, &h->st_hd, &h->st_hi, &h->st_pool, &h->st_fxd, &h->st_fxi, &h->st_rlist, &h->st_flags}) b->release();
@@ -1958,7 +1963,7 @@ static int level_run_impl(mpc_handle *h, int32_t gen_children, int32_t flags, mp
     float ms[3] = {0, 0, 0}, kms[5] = {0, 0, 0, 0, 0};
     bool kernel_timed[5] = {false, false, false, false, false};
     long long n_x_items = 0, n_theta_items = 0, n_xq_items = 0;
-    bool xq_thread_timed = false, xq_early_ran = false;
+    bool xq_thread_timed = false, xq_early_ran = false, x1_ran = false;
     h->n_xq_thread = 0; h->ms_xq_thread = 0;
     if (n > 0) {
         const size_t nn = (size_t)n;
@@ -2277,7 +2282,7 @@ static int level_run_impl(mpc_handle *h, int32_t gen_children, int32_t flags, mp
                     HIP_TRY(h, hipStreamWaitEvent(h->stream2, h->ev_xfork, 0));
                     const unsigned gt = (unsigned)std::min<long long>((n + 63) / 64, (long long)h->n_cu * h->xqt_wpc);
                     HIP_TRY(h, hipEventRecord(h->kev[10], h->stream2));
-                    hipLaunchKernelGGL(k_xq_thread, dim3(gt), dim3(64), 0, h->stream2, pf, fr, k, h->xq_list.as<int32_t>(), (int)n, stp, ctr, dq, nxc_e, alt);
+                    hipLaunchKernelGGL(k_xq_thread, dim3(gt), dim3(64), 0, h->stream2, pf, fr, k, h->xq_list.as<int32_t>(), (int)n, stp, ctr, dq, nxc_e, alt, XqPlan{});
                     HIP_TRY(h, hipEventRecord(h->kev[11], h->stream2));
                     HIP_TRY(h, hipGetLastError());
                     HIP_TRY(h, hipEventRecord(h->ev_xjoin, h->stream2));
@@ -2446,7 +2451,7 @@ static int level_run_impl(mpc_handle *h, int32_t gen_children, int32_t flags, mp
                         alt.prev_frontier = h->children.as<int32_t>(); alt.prev_stored = h->dict_stored[1 - h->dict_cur].as<uint8_t>();
                         alt.n_prev = (int)h->n_prev; alt.tries = h->xq_thread < 0 ? MPC_MAX_NC : h->xq_thread - 1;   // (the kernel stops at the candidate's inequality members)
                     }
-                    hipLaunchKernelGGL(k_xq_thread, dim3(gt), dim3(64), 0, st, pf, fr, k, needx_list, n_needx, stp, ctr, dq, nxc, alt);
+                    hipLaunchKernelGGL(k_xq_thread, dim3(gt), dim3(64), 0, st, pf, fr, k, needx_list, n_needx, stp, ctr, dq, nxc, alt, XqPlan{});
                     HIP_TRY(h, hipEventRecord(h->kev[11], st));
                     HIP_TRY(h, hipGetLastError());
                     xq_thread_timed = true;
@@ -2490,7 +2495,53 @@ static int level_run_impl(mpc_handle *h, int32_t gen_children, int32_t flags, mp
             }
             if (n_needx + dc.n_pre1 + dc.n_pre2 > 0) {   // feasibility for the candidates left open (+ dictionary-only items)
                 HIP_TRY(h, hipEventRecord(h->kev[2], st));
-                int rcs = launch_x(needx_list, n_needx, dc);
+                int rcs = MPC_OK;
+                const long long n_dict = (long long)n_needx + dc.n_pre1 + dc.n_pre2;
+                if (h->storing && dc.parent_slot && h->x1 > 0 && !xq_lean && n_dict >= 2048) {
+                    // One-step plans (round 5).  Every candidate that needs a dictionary is asked by ONE THREAD whether a parent's record is
+                    // one known step away (k_xq_thread in plan mode: the generating parent, then the candidate's other parents); k_x1 then
+                    // streams that record through the step -- no tableau in registers, no pricing, no ratio test --, and only what has no
+                    // such plan goes through the register simplex k_x2 as before, from its generating parent.
+                    { int rcq = prep_flush(); if (rcq) return rcq; }
+                    HIP_TRY(h, h->x1_buf.ensure(6 * nn * sizeof(int32_t), st));
+                    int32_t *xb = h->x1_buf.as<int32_t>();
+                    XqPlan pl{};
+                    pl.plan_slot = xb; pl.plan_step = xb + nn; pl.x1_list = xb + 2 * nn; pl.x1_n = dcnt + 12;
+                    for (int sg = 0; sg < 3; ++sg) { pl.rest[sg] = xb + (3 + sg) * nn; pl.rest_n[sg] = dcnt + 13 + sg; }
+                    pl.pre1 = dc.pre1; pl.n_pre1 = dc.n_pre1; pl.pre2 = dc.pre2; pl.n_pre2 = dc.n_pre2;
+                    XqAlt alt{};
+                    if (h->x1 >= 2 && h->n_prev > 0 && h->n_prev <= 0x7fffffffLL && k >= 2 &&
+                        h->children.cap >= (size_t)h->n_prev * (k - 1) * sizeof(int32_t) && h->dict_stored[1 - h->dict_cur].cap >= (size_t)h->n_prev) {
+                        alt.prev_frontier = h->children.as<int32_t>(); alt.prev_stored = h->dict_stored[1 - h->dict_cur].as<uint8_t>();
+                        alt.n_prev = (int)h->n_prev; alt.tries = MPC_MAX_NC;
+                    }
+                    DictCache dq = dc;
+                    dq.n_list_dev = nullptr;
+                    const unsigned gt = (unsigned)std::min<long long>((n_dict + 63) / 64, (long long)h->n_cu * h->xqt_wpc);
+                    HIP_TRY(h, hipEventRecord(h->kev[10], st));
+                    hipLaunchKernelGGL(k_xq_thread, dim3(gt), dim3(64), 0, st, pf, fr, k, needx_list, n_needx, stp, ctr, dq, nxc, alt, pl);
+                    HIP_TRY(h, hipEventRecord(h->kev[11], st));
+                    xq_thread_timed = true;
+                    const unsigned g1 = (unsigned)std::min<long long>(n_dict, (long long)h->n_cu * h->x1_wpc);
+                    if (h->fast_x & 1) hipLaunchKernelGGL((k_x1<2>), dim3(g1), dim3(64), 0, st, pf, pl.x1_list, pl.x1_n, ctr, dc, nxc, pl.plan_slot, pl.plan_step);
+                    else hipLaunchKernelGGL((k_x1<1>), dim3(g1), dim3(64), 0, st, pf, pl.x1_list, pl.x1_n, ctr, dc, nxc, pl.plan_slot, pl.plan_step);
+                    HIP_TRY(h, hipGetLastError());
+                    // what is left: the register simplex, list lengths on the device
+                    DictCache dr = dc;
+                    dr.pre1 = pl.rest[0]; dr.n_pre1 = 0; dr.n_pre1_dev = pl.rest_n[0];
+                    dr.pre2 = pl.rest[1]; dr.n_pre2 = 0; dr.n_pre2_dev = pl.rest_n[1];
+                    dr.n_list_dev = pl.rest_n[2]; dr.chunk = 0;
+                    const long long grid_r = (long long)h->n_cu * std::min<long long>(4, h->x2_wpc);
+                    const dim3 gg((unsigned)std::max<long long>(1, std::min<long long>(n_dict, grid_r))), bb(64);
+                    switch (h->fast_x) {
+                        case 0: hipLaunchKernelGGL((k_x2<16, 1>), gg, bb, 0, st, pf, fr, k, pl.rest[2], (int)n_needx, stp, ctr, dr); break;
+                        case 1: hipLaunchKernelGGL((k_x2<16, 2>), gg, bb, 0, st, pf, fr, k, pl.rest[2], (int)n_needx, stp, ctr, dr); break;
+                        case 2: hipLaunchKernelGGL((k_x2<32, 1>), gg, bb, 0, st, pf, fr, k, pl.rest[2], (int)n_needx, stp, ctr, dr); break;
+                        default: hipLaunchKernelGGL((k_x2<32, 2>), gg, bb, 0, st, pf, fr, k, pl.rest[2], (int)n_needx, stp, ctr, dr); break;
+                    }
+                    HIP_TRY(h, hipGetLastError());
+                    x1_ran = true;
+                } else rcs = launch_x(needx_list, n_needx, dc);
                 if (rcs) return rcs;
                 HIP_TRY(h, hipEventRecord(h->kev[3], st));
                 kernel_timed[1] = true;
@@ -2640,6 +2691,8 @@ static int level_run_impl(mpc_handle *h, int32_t gen_children, int32_t flags, mp
         HIP_TRY(h, hipEventElapsedTime(&ms[2], h->ev[2], h->ev[3]));
         for (int i = 0; i < 5; ++i) if (kernel_timed[i]) HIP_TRY(h, hipEventElapsedTime(&kms[i], h->kev[2 * i], h->kev[2 * i + 1]));
         if (xq_thread_timed) { HIP_TRY(h, hipEventElapsedTime(&h->ms_xq_thread, h->kev[10], h->kev[11])); h->n_xq_thread = host_ctr.xq_thread; }
+        h->n_x1 = x1_ran ? (long long)(h->tot_host + 16 + (int)(sizeof(LevelCounters) / 4))[12] : 0;   // dictionaries k_x1 wrote
+        if (h->debug_cycles && x1_ran) { const int32_t *ch = h->tot_host + 16 + (int)(sizeof(LevelCounters) / 4); std::fprintf(stderr, "[mpc] k=%d one-step plans: %d streamed by k_x1, %d + %d + %d left to k_x2 (plan pass %.3f ms)\n", k, ch[12], ch[13], ch[14], ch[15], h->ms_xq_thread); }
         if (xq_early_ran) { n_xq_items += host_ctr.xq_thread; h->n_needx += host_ctr.xq_thread; }   // what the pass beside the theta stage decided never reached the partition's count
         if (kernel_timed[2] && host_ctr.r2_t1 > ~host_ctr.r2_not_t0 && h->wall_khz > 0)   // k_region2 times itself (see the kernel)
             kms[2] = (float)((double)(host_ctr.r2_t1 - ~host_ctr.r2_not_t0) / (double)h->wall_khz);
@@ -2677,7 +2730,7 @@ static int level_run_impl(mpc_handle *h, int32_t gen_children, int32_t flags, mp
         stats->ms_kkt = kms[3]; stats->ms_xq = kms[4];
         stats->n_xq_items = n_xq_items; stats->xq_pivots = (int64_t)host_ctr.xq_pivots;
         stats->xq_record_ints = dict_ints_head(h->Pf.n_d0r, h->fast_x >= 2 ? 32 : 16) - 1; stats->xq_record_rows = h->Pf.n_d0r; stats->xq_record_cols = h->Pf.n_d0c + 1;
-        stats->n_xq_thread = h->n_xq_thread; stats->ms_xq_thread = h->ms_xq_thread;
+        stats->n_xq_thread = h->n_xq_thread; stats->ms_xq_thread = h->ms_xq_thread; stats->xq_thread_beside_theta = xq_early_ran ? 1.0f : 0.0f;
         stats->n_region_rows = h->n_erows;
         stats->n_opt = h->n_opt;
         // bytes of one dictionary record that are actually moved: the used columns (value + D0 columns) and the integer part

@@ -453,6 +453,38 @@ def test_thread_pass_of_the_quick_test_changes_no_verdict(name, monkeypatch):
     assert lc[-1][3] > lb[-1][3], 'the other parents decided nothing'
 
 
+# ---- one-step plans on the levels that keep dictionaries (k_xq_thread plan mode + k_x1) -----------------------------------------------
+@pytest.mark.parametrize('name', ['c4_rand_20_8_20_s0', 'c3_quadtank_n10', 'c2_dblint_n5_x20'])
+def test_streamed_one_step_dictionaries_equal_the_register_simplex(name, monkeypatch):
+    """MPC_X1=1: a candidate whose dictionary is ONE step from its generating parent's record (column deleted / zero row pivoted /
+    one Harris pivot) gets it from k_x1, which streams the record through that step, instead of k_x2's register simplex.  Same
+    operations on the same numbers: every status, every child list and every region record of every level must be IDENTICAL, bit for
+    bit, to MPC_X1=0.  (The default, MPC_X1=2, also starts from the candidate's other parents: other vertices of the same faces, so the
+    records differ while every verdict is the reference's -- the deep goldens run with the default.)"""
+    from test_gpu_parity import engine_from_golden, run_levels
+    g = load_golden(name)
+    nl = None if bool(g['complete']) else int(g['n_levels']) + 1
+    runs = []
+    for env in ({'MPC_X1': '0'}, {'MPC_X1': '1'}):
+        with monkeypatch.context() as m:
+            for key, val in env.items():
+                m.setenv(key, val)
+            eng = engine_from_golden(g)
+            levels, regions = run_levels(eng, nl)
+            runs.append(([(c.copy(), s.copy(), int(st.n_children)) for c, s, st in levels], {tuple(r.active_set): r for r in regions}))
+            eng.close()
+    (la, ra), (lb, rb) = runs
+    assert len(la) == len(lb)
+    for (ca, sa, na), (cb, sb, nb) in zip(la, lb):
+        assert numpy.array_equal(ca, cb) and numpy.array_equal(sa, sb) and na == nb
+    assert set(ra) == set(rb)
+    for key, r1 in ra.items():
+        r2 = rb[key]
+        assert r1.omega_set == r2.omega_set and r1.lambda_set == r2.lambda_set and r1.regular_set == r2.regular_set, key
+        for fld in ('A', 'b', 'C', 'd', 'E', 'f'):
+            assert numpy.array_equal(getattr(r1, fld), getattr(r2, fld)), (key, fld)
+
+
 # ---- levels without host round trips (level_run_small) and lean large levels -------------------------------------------------
 @pytest.mark.parametrize('name', ['rand_6_3_12_s1', 'c2_dblint_n5', 'quadtank_n3', 'c4_rand_20_8_20_s0', 'mplp_rand_5_3_12_s2'])
 def test_levels_without_host_round_trips_equal_the_classic_path(name, monkeypatch):

@@ -219,7 +219,7 @@ int main(int argc, char **argv) {
     for (int gmul : {8}) {
         const unsigned g = (unsigned)std::min<long long>((n + 255) / 256, 256LL * gmul);
         std::printf("grid %u blocks of 256\n", g);
-        timed("k_xq_thread (library)", [&] { hipLaunchKernelGGL(k_xq_thread, dim3(g * 4), dim3(64), 0, 0, Pd, cands, k, list, (int)n, status, ctr, dc, NXC, XqAlt{}); });
+        timed("k_xq_thread (library)", [&] { hipLaunchKernelGGL(k_xq_thread, dim3(g * 4), dim3(64), 0, 0, Pd, cands, k, list, (int)n, status, ctr, dc, NXC, XqAlt{}, XqPlan{}); });
         timed("variant 1: column check + row search only", [&] { hipLaunchKernelGGL(k_variant<1>, dim3(g), dim3(256), 0, 0, Pd, cands, k, list, (int)n, status, dc, NXC); });
         timed("variant 2: ratio scan, loads batched by seven", [&] { hipLaunchKernelGGL(k_variant<2>, dim3(g), dim3(256), 0, 0, Pd, cands, k, list, (int)n, status, dc, NXC); });
         timed("variant 3: column staged through LDS", [&] { hipLaunchKernelGGL(k_variant<3>, dim3(g), dim3(256), 4 * 64 * (mr | 1) * 8, 0, Pd, cands, k, list, (int)n, status, dc, NXC); });
@@ -234,7 +234,7 @@ int main(int argc, char **argv) {
     {
         const unsigned g = (unsigned)((n + 255) / 256);
         std::printf("grid %u blocks (one pass)\n", g);
-        timed("k_xq_thread (library)", [&] { hipLaunchKernelGGL(k_xq_thread, dim3(g * 4), dim3(64), 0, 0, Pd, cands, k, list, (int)n, status, ctr, dc, NXC, XqAlt{}); });
+        timed("k_xq_thread (library)", [&] { hipLaunchKernelGGL(k_xq_thread, dim3(g * 4), dim3(64), 0, 0, Pd, cands, k, list, (int)n, status, ctr, dc, NXC, XqAlt{}, XqPlan{}); });
         timed("variant 2", [&] { hipLaunchKernelGGL(k_variant<2>, dim3(g), dim3(256), 0, 0, Pd, cands, k, list, (int)n, status, dc, NXC); });
         timed("variant 3", [&] { hipLaunchKernelGGL(k_variant<3>, dim3(g), dim3(256), 4 * 64 * (mr | 1) * 8, 0, Pd, cands, k, list, (int)n, status, dc, NXC); });
     }
