@@ -574,6 +574,7 @@ struct DictCache {
     // != nullptr: the three list lengths are read from device memory (the level runs without host round trips)
     const int32_t *n_list_dev, *n_pre1_dev, *n_pre2_dev;
     int max_blocks;  // > 0 (with device-resident lengths): only that many blocks of the launch work, the others leave (a member's share of a shared launch)
+    int flag_retry;  // k_xq / k_xq_grouped: a candidate whose run meets a doubtful pivot gets ST_RETRY at once (k_x2 would only repeat the run to find the same)
 };
 // k_xq: the last level's quick (x,theta) test.  No dictionary is stored on the last level, so a candidate only needs a
 // DECISION: up to XQ_ITERS simplex iterations from the parent's dictionary in product form (revised simplex with an eta
@@ -712,7 +713,7 @@ __device__ __forceinline__ int xq_decide(PD pd, PI pi, int mr, int NXC, int ncol
                 }
                 const double inv = fast_rcp(rpiv);
                 growth = fmax(growth, (double)(colmax * (float)inv));
-                if (growth > GROWTH_SAFE) break;            // k_x2 repeats the run and flags it
+                if (growth > GROWTH_SAFE) { feas = -2; break; }   // a doubtful pivot: k_x2 would repeat the run and flag it (-2: the caller may flag it at once)
                 piv_local++;
                 if (l == row) { feas = 1; break; }          // the new row's slack leaves the basis at zero
                 if (it + 1 == XQ_ITERS) break;
@@ -757,7 +758,7 @@ MPC_GLOBAL void MPC_LB(64, XQ_WAVES) k_xq(const DevProblem *__restrict__ Pg, con
         if (dc.chunk <= 0) dc.chunk = (int)max(1ll, min(16ll, (long long)n_list / (active * 4)));
         if ((long long)blockIdx.x >= active || (long long)blockIdx.x * dc.chunk >= n_list) return;
     }
-    unsigned long long pivots = 0, n_quick = 0;
+    unsigned long long pivots = 0, n_quick = 0, n_doubt = 0;
     for (;;) {
         unsigned int w0 = 0;
         if (lane == 0) w0 = atomicAdd(&ctr->work_q, (unsigned)dc.chunk);
@@ -808,10 +809,16 @@ MPC_GLOBAL void MPC_LB(64, XQ_WAVES) k_xq(const DevProblem *__restrict__ Pg, con
                 n_quick++;
                 pivots += piv_local;
                 if (lane == 0) status[c] = (uint8_t)(feas ? (singular ? ST_SINGULAR : ST_FEASIBLE) : ST_INFEASIBLE);
+            } else if (feas == -2 && dc.flag_retry) {
+                n_doubt++;
+                if (lane == 0) status[c] = (uint8_t)ST_RETRY;
             }
         }
     }
-    if (lane == 0) { atomicAdd(&ctr->pivots, pivots); atomicAdd(&ctr->xq_pivots, pivots); atomicAdd(&ctr->x_cached, n_quick); atomicAdd(&ctr->xtheta_lps, n_quick); }
+    if (lane == 0) {
+        atomicAdd(&ctr->pivots, pivots); atomicAdd(&ctr->xq_pivots, pivots); atomicAdd(&ctr->x_cached, n_quick); atomicAdd(&ctr->xtheta_lps, n_quick);
+        if (n_doubt) atomicAdd(&ctr->xtheta_fallbacks, n_doubt);
+    }
 }
 
 // k_xq_thread (round 5): the part of xq_decide that ends within its FIRST ratio test, with ONE THREAD per candidate.
@@ -1078,7 +1085,7 @@ MPC_GLOBAL void MPC_LB(256, XQG_WAVES) k_xq_grouped(const DevProblem *__restrict
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nv = P.n_x + P.n_t, mr = P.n_d0r;
     const unsigned n_groups = (unsigned)*n_groups_p;
     const int nd = min(((P.n_d0c + 1) * mr + 1) & ~1, (int)dc.stride_d), ni = (int)dc.stride_i;   // the used columns only (even count: 16-byte copies)
-    unsigned long long pivots = 0, n_quick = 0;
+    unsigned long long pivots = 0, n_quick = 0, n_doubt = 0;
     for (;;) {
         if (tid == 0) item_s = atomicAdd(&ctr->work_q, 1u);
         __syncthreads();
@@ -1110,12 +1117,18 @@ MPC_GLOBAL void MPC_LB(256, XQG_WAVES) k_xq_grouped(const DevProblem *__restrict
                     n_quick++;
                     pivots += piv_local;
                     if (lane == 0) status[c] = (uint8_t)(feas ? (singular ? ST_SINGULAR : ST_FEASIBLE) : ST_INFEASIBLE);
+                } else if (feas == -2 && dc.flag_retry) {
+                    n_doubt++;
+                    if (lane == 0) status[c] = (uint8_t)ST_RETRY;
                 }
             }
         }
         __syncthreads();
     }
-    if (lane == 0) { atomicAdd(&ctr->pivots, pivots); atomicAdd(&ctr->xq_pivots, pivots); atomicAdd(&ctr->x_cached, n_quick); atomicAdd(&ctr->xtheta_lps, n_quick); }
+    if (lane == 0) {
+        atomicAdd(&ctr->pivots, pivots); atomicAdd(&ctr->xq_pivots, pivots); atomicAdd(&ctr->x_cached, n_quick); atomicAdd(&ctr->xtheta_lps, n_quick);
+        if (n_doubt) atomicAdd(&ctr->xtheta_fallbacks, n_doubt);
+    }
 }
 
 #ifndef R2_CERT

@@ -327,6 +327,7 @@ struct mpc_handle {
     int x1 = 1;               // MPC_X1=0: every dictionary of a storing level by the register simplex k_x2 (rounds 1-4); 1: one-step plans (k_xq_thread, plan mode) streamed by k_x1, from the generating parent only; 2 (default): ... and from the candidate's other parents
     int x1_wpc = 16;          // MPC_X1_WPC: wavefronts per CU of k_x1 (config 4, level 4, beside the region kernel: x stage 1.13 / 0.95 / 1.02 ms with 8 / 16 / 32)
     long long n_x1 = 0;       // dictionaries of the last level run that k_x1 wrote
+    int xq_retry = 0;         // MPC_XQ_RETRY=1: a doubtful pivot met by the quick test is flagged by the quick test itself and re-solved at once on the second stream (round 5; off: on config 3 half of the doubtful candidates only show in k_x2, beyond the quick test's sixteen iterations, so the level pays the LDS engine twice -- 3.55 ms against 3.28)
     int no_xq_early = 0;      // MPC_NO_XQ_EARLY=1: the thread pass of the quick test always behind the theta stage, -1: always beside it (A/B)
     long long prev_regions = 0, xq_early_regions = 1024;   // regions of the level before; MPC_XQ_EARLY_REGIONS
     int xqt_wpc = 16;         // MPC_XQT_WPC: wavefronts per CU of k_xq_thread (it is bound by the cache's request rate: config 4's level 0.45 ms alone with 8 per CU, 0.49 with 24; beside the region kernel 0.92 / 0.70 / 0.78 / 0.75 with 4 / 8 / 12 / 16)
@@ -344,7 +345,7 @@ struct mpc_handle {
     long long n_needx = 0;
     DevProblem Pf{};          // view for k_verdict2 (small LDS layout: no tableau)
     int lds_f = 0, grid_f = 0;
-    DevBuf retry_list, theta_list, vretry_list, status_tmp, part_counts, part_lists, kept_g, done_g, pf_dev, pr2_dev, headd, headi, epool, facet_flags, kkt_code, kkt_L, theta_blocks, xq_groups, xq_list, x1_buf;
+    DevBuf retry_list, theta_list, vretry_list, status_tmp, part_counts, part_lists, kept_g, done_g, pf_dev, pr2_dev, headd, headi, epool, facet_flags, kkt_code, kkt_L, theta_blocks, xq_groups, xq_list, x1_buf, xretry_list;
     ThetaArgs targs{};
     // (x,theta) dictionary cache: [0]/[1] ping-pong between the level being read (parents) and the level being written
     DevBuf dict_d[2], dict_i[2], dict_stored[2], parent_slot, parent_slot_next;
@@ -533,7 +534,7 @@ void lu_solve_host(const std::vector<double> &LU, const std::vector<int> &perm, 
 // graveyard_flush, which the level paths call behind their closing synchronisation (all streams of the handle have been joined by then)
 static std::vector<DevBuf *> level_buffers(mpc_handle *h) {
     return {&h->frontier, &h->children, &h->status, &h->pruned, &h->flag, &h->pos, &h->opt_list, &h->childmask, &h->count, &h->offset, &h->recd, &h->reci,
-            &h->sums, &h->retry_list, &h->headd, &h->headi, &h->epool, &h->facet_flags, &h->kkt_code, &h->kkt_L, &h->xq_groups, &h->xq_list, &h->x1_buf, &h->theta_list, &h->vretry_list,
+            &h->sums, &h->retry_list, &h->headd, &h->headi, &h->epool, &h->facet_flags, &h->kkt_code, &h->kkt_L, &h->xq_groups, &h->xq_list, &h->x1_buf, &h->xretry_list, &h->theta_list, &h->vretry_list,
             &h->status_tmp, &h->part_counts, &h->part_lists, &h->kept_g, &h->done_g, &h->dict_d[0], &h->dict_d[1], &h->dict_i[0], &h->dict_i[1],
             &h->dict_stored[0], &h->dict_stored[1], &h->parent_slot, &h->parent_slot_next};
 }
@@ -620,6 +621,7 @@ static int create_fill(const mpc_problem *p, int32_t device, void *stream, mpc_h
     { const char *ev = std::getenv("MPC_XQG_OVERLAP"); h->xqg_overlap = ev && ev[0] == '1'; }
     { const char *ev = std::getenv("MPC_XQT_WPC"); if (ev && std::atoi(ev) > 0) h->xqt_wpc = std::atoi(ev); }
     { const char *ev = std::getenv("MPC_X1"); h->x1 = ev ? std::atoi(ev) : 2; }
+    { const char *ev = std::getenv("MPC_XQ_RETRY"); h->xq_retry = ev && ev[0] == '1'; }
     { const char *ev = std::getenv("MPC_X1_WPC"); if (ev && std::atoi(ev) > 0) h->x1_wpc = std::atoi(ev); }
     { const char *ev = std::getenv("MPC_NO_XQ_EARLY"); h->no_xq_early = ev ? std::atoi(ev) : 0; }
     { const char *ev = std::getenv("MPC_XQ_EARLY_REGIONS"); if (ev) h->xq_early_regions = std::atoll(ev); }
@@ -1060,7 +1062,7 @@ int mpc_destroy(mpc_handle *h) {
     if (h->stream3) (void)hipStreamSynchronize(h->stream3);
     graveyard_flush(h);
     for (DevBuf *b : {&h->blocks, &h->iblocks, &h->frontier, &h->children, &h->status, &h->pruned, &h->flag, &h->pos, &h->opt_list,
-                      &h->childmask, &h->count, &h->offset, &h->recd, &h->reci, &h->ctr, &h->scratch, &h->sums, &h->retry_list, &h->pf_dev, &h->pr2_dev, &h->headd, &h->headi, &h->epool, &h->facet_flags, &h->kkt_code, &h->kkt_L, &h->theta_blocks, &h->xq_groups, &h->xq_list, &h->x1_buf, &h->theta_list, &h->vretry_list, &h->status_tmp, &h->part_counts, &h->part_lists, &h->kept_g, &h->done_g, &h->dict_d[0], &h->dict_d[1], &h->dict_i[0], &h->dict_i[1],
+                      &h->childmask, &h->count, &h->offset, &h->recd, &h->reci, &h->ctr, &h->scratch, &h->sums, &h->retry_list, &h->pf_dev, &h->pr2_dev, &h->headd, &h->headi, &h->epool, &h->facet_flags, &h->kkt_code, &h->kkt_L, &h->theta_blocks, &h->xq_groups, &h->xq_list, &h->x1_buf, &h->xretry_list, &h->theta_list, &h->vretry_list, &h->status_tmp, &h->part_counts, &h->part_lists, &h->kept_g, &h->done_g, &h->dict_d[0], &h->dict_d[1], &h->dict_i[0], &h->dict_i[1],
                       &h->dict_stored[0], &h->dict_stored[1], &h->parent_slot, &h->parent_slot_next, &h->dcnt}) b->release();
     if (h->tot_host) { (void)host_pool_give(h->tot_host); h->tot_host = h->tot_dev = nullptr; }
     for (HostBuf *b : {&h->st_list, &h->st_status, &h->st_hd, &h->st_hi, &h->st_pool, &h->st_fxd, &h->st_fxi, &h->st_rlist, &h->st_flags}) b->release();
@@ -1098,7 +1100,7 @@ int mpc_trim(mpc_handle *h) {
     graveyard_flush(h);
     stream_release(h);
     for (DevBuf *b : {&h->frontier, &h->children, &h->status, &h->pruned, &h->flag, &h->pos, &h->opt_list, &h->childmask, &h->count, &h->offset, &h->recd, &h->reci,
-                      &h->sums, &h->retry_list, &h->headd, &h->headi, &h->epool, &h->facet_flags, &h->kkt_code, &h->kkt_L, &h->xq_groups, &h->xq_list, &h->x1_buf, &h->theta_list, &h->vretry_list,
+                      &h->sums, &h->retry_list, &h->headd, &h->headi, &h->epool, &h->facet_flags, &h->kkt_code, &h->kkt_L, &h->xq_groups, &h->xq_list, &h->x1_buf, &h->xretry_list, &h->theta_list, &h->vretry_list,
                       &h->status_tmp, &h->part_counts, &h->part_lists, &h->kept_g, &h->done_g, &h->dict_d[0], &h->dict_d[1], &h->dict_i[0], &h->dict_i[1],
                       &h->dict_stored[0], &h->dict_stored[1], &h->parent_slot, &h->parent_slot_next}) b->release();
     for (HostBuf *b : {&h->st_list, &h->st_status, &h->st_hd, &h->st_hi, &h->st_pool, &h->st_fxd, &h->st_fxi, &h->st_rlist, &h->st_flags}) b->release();
@@ -2426,6 +2428,7 @@ static int level_run_impl(mpc_handle *h, int32_t gen_children, int32_t flags, mp
                 HIP_TRY(h, hipGetLastError());
                 n_needx = 0;
             }
+            bool xretry_forked = false;
             if (quick_test) {
                 // last level: decisions only -- the quick test on three vectors of the parent's dictionary first
                 DictCache dq = dc;
@@ -2463,6 +2466,10 @@ static int level_run_impl(mpc_handle *h, int32_t gen_children, int32_t flags, mp
                 }
                 dq.chunk = (int)std::max<long long>(1, std::min<long long>(16, xq_n / (grid_q * 4)));
                 if (xqt_lean) { dq.n_list_dev = dcnt + 9; dq.chunk = 0; }   // length and chunk rule on the device
+                // doubtful pivots are flagged by the quick test itself and re-solved at once on the second stream (below), unless that stream
+                // is busy with the theta stage's own doubtful candidates (their statuses are still ST_RETRY in the status array)
+                const bool xq_flags_retry = h->xq_retry && n_early == 0 && lean;
+                dq.flag_retry = xq_flags_retry ? 1 : 0;
                 const dim3 gg((unsigned)std::max<long long>(1, std::min<long long>(xqt_lean ? (long long)xq_n : ((long long)xq_n + dq.chunk - 1) / dq.chunk, grid_q))), bb(64);
                 // Grouped by parent when a parent has many open children (config 3: 12.6 per parent, -0.5 ms; config 4: 7.1 per
                 // parent, where the per-candidate reads of k_xq are cheaper than one 16 KB copy per parent, +0.45 ms): threshold 10.
@@ -2487,6 +2494,22 @@ static int level_run_impl(mpc_handle *h, int32_t gen_children, int32_t flags, mp
                 HIP_TRY(h, hipEventRecord(h->kev[9], st));
                 kernel_timed[4] = true;
                 HIP_TRY(h, hipGetLastError());
+                if (xq_flags_retry) {
+                    // The candidates the quick test flagged as doubtful (config 3's last level: 217) are re-solved by the LDS engine NOW, on the
+                    // second stream, beside k_x2 and the end of the level -- rounds 1-4 let k_x2 repeat their runs to flag them, and started
+                    // the re-solve (0.6 ms of a few hundred long wavefronts) behind everything else, then repeated the end of the level.
+                    { int rcs = compact(ST_RETRY, ST_RETRY, nullptr, dcnt + 11); if (rcs) return rcs; }
+                    HIP_TRY(h, h->xretry_list.ensure(nn * sizeof(int32_t), st));
+                    std::swap(h->xretry_list, h->retry_list);
+                    HIP_TRY(h, hipEventRecord(h->ev_xfork, st));
+                    HIP_TRY(h, hipStreamWaitEvent(h->stream2, h->ev_xfork, 0));
+                    HIP_TRY(h, hipMemsetAsync(&ctr->work_retry, 0, sizeof(unsigned int), h->stream2));
+                    hipLaunchKernelGGL(k_verdict, dim3((unsigned)std::max<long long>(1, std::min<long long>(std::min<long long>(xq_n, 4096), h->grid_v))), dim3(64), h->lds_v, h->stream2, h->Pv,
+                                       h->frontier.as<int32_t>(), (long long)xq_n, k, stp, ctr, h->xretry_list.as<int32_t>(), dcnt + 11);
+                    HIP_TRY(h, hipGetLastError());
+                    HIP_TRY(h, hipEventRecord(h->ev_xjoin, h->stream2));
+                    xretry_forked = true;
+                }
                 int32_t n_left = 0;
                 if (lean) { int rcs = compact(ST_NEEDX, ST_NEEDX_SING, nullptr, dcnt + 8); if (rcs) return rcs; xq_lean = true; n_left = n_needx; }
                 else { int rcs = compact(ST_NEEDX, ST_NEEDX_SING, &n_left); if (rcs) return rcs; }
@@ -2563,6 +2586,10 @@ static int level_run_impl(mpc_handle *h, int32_t gen_children, int32_t flags, mp
             }
             // second partition: [0] doubtful candidates of the (x,theta) stage, [2] the optimal candidates for the region stage
             int32_t cntB[PART_CLASSES] = {0, 0, 0, 0};
+            if (xretry_forked) {   // the re-solved doubtful candidates of the quick test carry their final statuses now
+                HIP_TRY(h, hipStreamWaitEvent(st, h->ev_xjoin, 0));
+                HIP_TRY(h, hipMemsetAsync(&ctr->work_retry, 0, sizeof(unsigned int), st));
+            }
             if (region_launched) HIP_TRY(h, hipStreamWaitEvent(st, h->ev_rjoin, 0));   // the region kernel rewrites statuses
             bool have_cntB = false;
             if (region_launched && lean && !h->no_spec_tail) {

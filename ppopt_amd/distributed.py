@@ -277,6 +277,32 @@ def allgather_table(row: List[int], device, group=None) -> List[List[int]]:
     return torch.stack(parts).cpu().tolist()
 
 
+class DistributedLevelError(RuntimeError):
+    """Raised on EVERY rank of the group, in the same level, when some rank's sharded level failed (device error, out of memory, any
+    exception of its engine): the failing rank reports the fault in that level's statistics exchange instead of leaving the others
+    waiting in it, so no rank hangs in a collective -- all of them leave the solve together (round 5).  ``failed_ranks`` lists the
+    ranks that reported a fault; on those ranks ``__cause__`` is the engine's own exception."""
+
+    def __init__(self, message, failed_ranks):
+        super().__init__(message)
+        self.failed_ranks = list(failed_ranks)
+
+
+GATHER_TIMEOUT_S = 600.0     # an asynchronous region gather that has not completed after this long is a dead peer, not a slow one
+
+
+def _wait(work):
+    """Bounded wait for an asynchronous collective (gloo honours the timeout on the host; RCCL's wait only orders the current stream
+    behind the transfer and returns at once -- a dead peer then surfaces in the communicator's own watchdog)."""
+    if work is None:
+        return
+    try:
+        import datetime
+        work.wait(datetime.timedelta(seconds=GATHER_TIMEOUT_S))
+    except TypeError:
+        work.wait()
+
+
 class _RepeatWithoutOverlap(Exception):
     """Raised on EVERY rank of the group in the same level: some rank's level returned MPC_ERR_CAPACITY (more late optimal
     candidates than the overlapped region stage had reserved slots for; include/mpcombi.h, mpc_set_region_overlap)."""
@@ -341,7 +367,7 @@ def _solve_distributed(engine, program=None, group=None, profile: Optional[List[
             solution.critical_regions.extend(own or [])
             return
         if gathers[1][1] is not None:
-            gathers[1][1].wait()      # the integer heads' gather (the current stream waits for it, not the host)
+            _wait(gathers[1][1])      # the integer heads' gather (the current stream waits for it, not the host)
         # Host copies are queued in the order the host needs them: the integer heads of every piece first (a region object is a lazy
         # view: building it needs the heads only), then the two large arrays.  The objects of a level are built while its large
         # arrays are still on their way; the solve waits for them once, before it returns.
@@ -361,7 +387,7 @@ def _solve_distributed(engine, program=None, group=None, profile: Optional[List[
                 queued.append([a, c, hi, ev])
         for j in (0, 2):
             if gathers[j][1] is not None:
-                gathers[j][1].wait()
+                _wait(gathers[j][1])
         copied = [q for q in queued if q is not own]
         for q in copied:
             q[0], q[1] = to_host(q[0], True), to_host(q[1], True)
@@ -389,6 +415,7 @@ def _solve_distributed(engine, program=None, group=None, profile: Optional[List[
         capacity = getattr(engine, 'capacity_error', ())      # exception type(s) of "out of spare region slots", if the engine has one
         own_regs = own_arrays = None
         own_rows = 0
+        fault = None
         try:
             if sharded and collect_regions and getattr(engine, 'streams_own_records', False):
                 # this rank's records are streamed to the host while the region kernel runs and become objects chunk by chunk (the
@@ -417,6 +444,14 @@ def _solve_distributed(engine, program=None, group=None, profile: Optional[List[
             if not sharded:
                 raise _RepeatWithoutOverlap()      # replicated level: every rank is here
             st = {'n': 0, 'n_children': 0, 'n_pruned_new': 0, 'n_regions': 0, 'lp_pivots': -1, 'status': [0] * 6}
+        except Exception as exc:      # noqa: BLE001 -- whatever the engine raised
+            if not sharded or world == 1:
+                raise      # replicated level / one rank: nobody is waiting in a collective of this level
+            # a sharded level: the other ranks are on their way into this level's statistics exchange -- this rank joins it with a
+            # fault marker, and every rank leaves the solve there (DistributedLevelError) instead of hanging
+            fault = exc
+            own_regs = own_arrays = None
+            st = {'n': 0, 'n_children': 0, 'n_pruned_new': 0, 'n_regions': 0, 'lp_pivots': -2, 'status': [0] * 6}
         total = st
         tensors = None
         if sharded:
@@ -435,6 +470,12 @@ def _solve_distributed(engine, program=None, group=None, profile: Optional[List[
             n_slots, n_rows = (int(tensors[0].shape[0]), int(tensors[2].shape[0])) if tensors is not None else (0, 0)
             table = allgather_table([st['n'], st['n_children'], st['n_pruned_new'], st['n_regions'], st['lp_pivots'],
                                      n_slots, n_rows, *st['status']], engine.device, group)
+            bad = [r_ for r_, row_ in enumerate(table) if row_[4] == -2]
+            if bad:
+                err = DistributedLevelError(f'level {depth + 1} (cardinality {int(k)}) failed on rank(s) {bad}; every rank leaves the solve', bad)
+                if fault is not None:
+                    raise err from fault
+                raise err
             if any(r[4] < 0 for r in table):
                 raise _RepeatWithoutOverlap()      # some rank's level failed for want of spare slots: all ranks repeat
             total = {'n': sum(r[0] for r in table), 'n_children': sum(r[1] for r in table),

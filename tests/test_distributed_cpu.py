@@ -236,3 +236,61 @@ def test_two_rank_options(mode):
     else:
         assert sorted(res[1][0]) == ref
         assert res[1][1] == 1 and res[0][1] == 0
+
+
+class BrokenEngine(OracleLevelEngine):
+    """Raises an ordinary exception (a device fault, out of memory ...) in ONE level on ONE rank."""
+
+    def __init__(self, P, rank, fail_rank, fail_level):
+        super().__init__(P)
+        self.rank, self.fail_rank, self.fail_level, self.level = rank, fail_rank, fail_level, 0
+
+    def root(self):
+        self.level = 0
+        super().root()
+
+    def run(self, gen_children):
+        self.level += 1
+        if self.rank == self.fail_rank and self.level == self.fail_level:
+            raise RuntimeError('device fault (test)')
+        return super().run(gen_children)
+
+
+def _worker_fault(rank, world, port, name, shard_min, fail_level, out):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    import datetime
+    dist.init_process_group('gloo', rank=rank, world_size=world, timeout=datetime.timedelta(seconds=60))
+    try:
+        from oracle import oracle as orc
+        from ppopt_amd.distributed import DistributedLevelError, solve_distributed
+        P = orc.problem_from_golden(load_golden(name))
+        try:
+            solve_distributed(BrokenEngine(P, rank, fail_rank=1, fail_level=fail_level), shard_min=shard_min)
+            out[rank] = ('returned', None, None)
+        except DistributedLevelError as exc:
+            out[rank] = ('level error', exc.failed_ranks, type(exc.__cause__).__name__ if exc.__cause__ is not None else None)
+        except Exception as exc:      # noqa: BLE001
+            out[rank] = ('other', type(exc).__name__, str(exc)[:200])
+    finally:
+        dist.destroy_process_group()
+
+
+def test_a_rank_that_fails_in_a_sharded_level_takes_every_rank_out_together():
+    """rank 1's engine raises inside a SHARDED level (level 3 of rand_4_2_10_s0 with shard_min 20).  The failing
+    rank must still join that level's statistics exchange (with a fault marker), and BOTH ranks must leave the solve with
+    DistributedLevelError naming rank 1 -- the healthy rank within seconds, not after a collective's timeout (the process group of
+    this test gives up after 60 s; the whole test is far below that)."""
+    import time
+    world, name, shard_min = 2, 'rand_4_2_10_s0', 20
+    port = 33500 + (os.getpid() % 2000)
+    t0 = time.time()
+    with mp.Manager() as mgr:
+        out = mgr.dict()
+        mp.spawn(_worker_fault, args=(world, port, name, shard_min, 3, out), nprocs=world, join=True)
+        res = dict(out)
+    assert time.time() - t0 < 50.0
+    assert res[0][0] == 'level error' and res[0][1] == [1] and res[0][2] is None
+    assert res[1][0] == 'level error' and res[1][1] == [1] and res[1][2] == 'RuntimeError'

@@ -18,9 +18,9 @@ import sqlite3
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-OUT = os.path.join(ROOT, 'profiles', os.environ.get('PMC_TAG', 'r04') + '_pmc.json')
+OUT = os.path.join(ROOT, 'profiles', os.environ.get('PMC_TAG', 'r05') + '_pmc.json')
 LEVELS = {'c4': 5, 'c3': 4, 'c2': 5}
-HEAVY = ('k_theta2', 'k_x2', 'k_region2', 'k_xq_grouped', 'k_xq', 'k_kkt_thread', 'k_level_small')
+HEAVY = ('k_theta2', 'k_x2', 'k_x1', 'k_region2', 'k_xq_grouped', 'k_xq_thread', 'k_xq', 'k_kkt_thread', 'k_level_small')
 
 
 def load():
@@ -87,9 +87,10 @@ def bench(wl, solves, dbs):
     w, wtot = per_kernel(dbs['write'], ('WRITE_SIZE',))
     kernels = {}
     for key in sorted(set(f) | set(w)):
-        launches = solves * (1 if key.startswith('k_xq') else LEVELS[wl])   # the quick test runs on the last level only
+        launches = solves * (1 if key in ('k_xq', 'k_xq_grouped') else LEVELS[wl])   # the quick test's wavefront kernel runs on the last level only (its thread pass also plans the storing levels)
         # k_xq: per iteration one column (63 coalesced 8-byte entries) and one row (n_col <= 29 strided entries): weights 63 : 29
-        f_fetch = (63 * f_r8 + 29 * f_rs) / 92.0 if key == 'k_xq' else (f_r16 if key in ('k_x2', 'k_xq_grouped') else f_r8)
+        # k_xq_thread: every lane walks its own column with 16-byte loads, 64 distinct sectors per wave-level load: the sector factor
+        f_fetch = (63 * f_r8 + 29 * f_rs) / 92.0 if key == 'k_xq' else (f_rs if key == 'k_xq_thread' else (f_r16 if key in ('k_x2', 'k_xq_grouped') else f_r8))
         f_write = f_w16 if key == 'k_x2' else f_w8
         fetch = f_fetch * 1024.0 * f.get(key, {}).get('FETCH_SIZE', [0, 0.0])[1]
         write = f_write * 1024.0 * w.get(key, {}).get('WRITE_SIZE', [0, 0.0])[1]
@@ -107,7 +108,7 @@ def bench(wl, solves, dbs):
         if tag in dbs and os.path.exists(dbs[tag]):
             t, _ = per_kernel(dbs[tag])
             for key, ctrs in t.items():
-                launches = solves * (1 if key.startswith('k_xq') else LEVELS[wl])
+                launches = solves * (1 if key in ('k_xq', 'k_xq_grouped') else LEVELS[wl])
                 k = kernels.setdefault(key, {'launches_counted': launches})
                 sq = k.setdefault('sq_per_launch', {})
                 st = k.setdefault('sq_per_step', {})

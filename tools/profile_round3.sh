@@ -1,11 +1,11 @@
-# Profile of the bench command (run on the GPU box):  bash tools/profile_round3.sh <workload> [steps] [warmup] [tag]   (tag: r03, r04 ...; default r04)
+# Profile of the bench command (run on the GPU box):  bash tools/profile_round3.sh <workload> [steps] [warmup] [tag]   (tag: r03, r04, r05 ...; default r05)
 # 1. calibration of FETCH_SIZE / WRITE_SIZE on known byte counts (tools/calib/pmc_calib, two passes)
 # 2. kernel trace + stats of `bench.py --workload W --steps S --warmup U --cpu-sample 0 --locate 0 --mi 0 --complete 0`
 # 3. FETCH_SIZE, WRITE_SIZE, SQ and (if the counters exist) VALU-F64 instruction counters, each in its own --pmc pass
 # Under rocprofv3 the program goes directly after `--` (python3 bench.py ... / the binary): no wrapper, no env, no shell.
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-wl=${1:-c4}; steps=${2:-20}; warm=${3:-5}; tag=${4:-r04}; export PMC_TAG=$tag
+wl=${1:-c4}; steps=${2:-20}; warm=${3:-5}; tag=${4:-r05}; export PMC_TAG=$tag
 O=$R/gpurun_out/prof3; mkdir -p $O
 rocprofv3 -L > $O/counters_list.txt 2>&1
 if [ ! -f $O/calib_done ]; then

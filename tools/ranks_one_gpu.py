@@ -3,7 +3,7 @@
 solve, and per level the ranks' shard sizes (candidates, regions, children) -- the imbalance of the static subtree ownership
 that follows the one split.  Times are NOT multi-GPU times (the ranks share one device).
 
-    python tools/ranks_one_gpu.py [workload=c4] [world sizes, default 2 4 8]   -> gpurun_out/r3/ranks_<workload>.json
+    python tools/ranks_one_gpu.py [workload=c4] [world sizes, default 2 4 8]   -> gpurun_out/r5/ranks_<workload>.json   (workloads: bench.py's, c4x6, qt6, di8x20)
 """
 import json
 import os
@@ -15,6 +15,18 @@ import torch.distributed as dist
 import torch.multiprocessing as mp
 
 
+def workload(wl):
+    """(program, max_levels): bench.py's workloads, the six-level variant of config 4 (c4x6) and two further MPC programs."""
+    import bench
+    from ppopt_amd import problem_generator as pg
+    extra = {'c4x6': (lambda: pg.generate_mpqp_data(20, 8, 20, 0), 6),
+             'qt6': (lambda: pg.quad_tank_data(6), None),                                 # quad tank, horizon 6: n_x = 12, n_theta = 4
+             'di8x20': (lambda: pg.double_integrator_data(8, x_bound=20.0), None)}          # double integrator, horizon 8, wide state box
+    if wl in extra:
+        return bench.program_from_data(extra[wl][0](), 0), extra[wl][1]
+    return bench.build_program(wl, 0), bench.WORKLOADS[wl][2]
+
+
 def worker(rank, world, port, wl, out):
     os.environ['MASTER_ADDR'] = '127.0.0.1'
     os.environ['MASTER_PORT'] = str(port)
@@ -23,10 +35,10 @@ def worker(rank, world, port, wl, out):
     torch.cuda.set_device(0)
     dist.init_process_group('gloo', rank=rank, world_size=world)
     try:
-        prog = bench.build_program(wl, 0)
+        prog, ml = workload(wl)
         eng = HipLevelEngine(prog, 0)
         prof = []
-        sol = solve_distributed(eng, prog, profile=prof, max_levels=bench.WORKLOADS[wl][2])
+        sol = solve_distributed(eng, prog, profile=prof, max_levels=ml)
         out[rank] = (sorted(tuple(r.active_set) for r in sol.critical_regions),
                      [{'k': p['k'], 'candidates': p['candidates'], 'local': p.get('local_candidates'), 'sharded': bool(p.get('sharded')),
                        'regions': p['regions'], 'children': p['children'], 'ms_kernels': p.get('ms_verdict', 0) + p.get('ms_region', 0) + p.get('ms_children', 0)}
@@ -41,7 +53,8 @@ if __name__ == '__main__':
     worlds = [int(v) for v in sys.argv[2:]] or [2, 4, 8]
     import bench
     from ppopt_amd.mp_solvers import mpqp_hip_combinatorial
-    solo = mpqp_hip_combinatorial.solve(bench.build_program(wl, 0), max_levels=bench.WORKLOADS[wl][2])
+    prog0, ml0 = workload(wl)
+    solo = mpqp_hip_combinatorial.solve(prog0, max_levels=ml0)
     ref = sorted(tuple(r.active_set) for r in solo.critical_regions)
     report = {'workload': wl, 'regions_single_rank': len(ref), 'worlds': {}}
     ctx = mp.get_context('spawn')          # fresh children: a process that has touched the GPU is never re-executed
@@ -64,5 +77,5 @@ if __name__ == '__main__':
         report['worlds'][str(world)] = {'all_ranks_equal_single_rank_solve': ok, 'exit_codes': [p.exitcode for p in ps], 'levels': levels}
         print(f'world {world}: every rank returns the single-rank region set: {ok}; shards per level: '
               + '; '.join(f"k={lv['k']}: {lv['shards']} (max/mean {lv['imbalance_max_over_mean']:.3f})" for lv in levels if lv['sharded']), flush=True)
-    os.makedirs('gpurun_out/r3', exist_ok=True)
-    json.dump(report, open(f'gpurun_out/r3/ranks_{wl}.json', 'w'), indent=1)
+    os.makedirs('gpurun_out/r5', exist_ok=True)
+    json.dump(report, open(f'gpurun_out/r5/ranks_{wl}.json', 'w'), indent=1)
