@@ -316,7 +316,10 @@ int mpc_level_regions_slots_nowait(mpc_handle *h, double *head_d, int32_t *head_
  * per member).  Arrays of n_handles entries; a member without regions gets n_slots = n_rows = 0 and may pass null buffers. */
 int mpc_level_batch_fetch(mpc_handle **handles, int32_t n_handles, double *const *head_d, int32_t *const *head_i, const int64_t *cap_slots,
                           double *const *erows, const int64_t *cap_rows, int64_t *n_slots, int64_t *n_rows);
-int mpc_sync(mpc_handle *h);   /* waits for everything queued on the handle's stream */
+int mpc_sync(mpc_handle *h);   /* waits for everything queued on the handle's stream (and for a pending shared record copy of mpc_level_batch_fetch) */
+/* mpc_level_batch_fetch copies the records of all members that hold them in slot form with ONE launch (round 5); mpc_fetch_wait waits
+ * for that launch on the given device (mpc_sync of any member and the next mpc_level_batch_start do so too) */
+int mpc_fetch_wait(int32_t device);
 /* Page-locked host memory from a recycling pool (blocks return to the pool on mpc_host_free and are handed out again
  * without re-pinning).  For result arrays that are filled by mpc_level_regions_slots. */
 int mpc_host_alloc(uint64_t bytes, void **out);

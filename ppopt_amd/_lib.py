@@ -156,6 +156,7 @@ def load():
         'mpc_level_regions_slots_nowait': (ctypes.c_int, [H, _dp, _ip, ctypes.c_int64, _dp, ctypes.c_int64, _lp, _lp]),
         'mpc_level_batch_fetch': (ctypes.c_int, [ctypes.POINTER(H), ctypes.c_int32, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_void_p), _lp, ctypes.POINTER(ctypes.c_void_p), _lp, _lp, _lp]),
         'mpc_sync': (ctypes.c_int, [H]),
+        'mpc_fetch_wait': (ctypes.c_int, [ctypes.c_int32]),
         'mpc_locator_create': (ctypes.c_int, [ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int64, _lp, _dp, _dp, _dp, _dp, _dp,
                                                ctypes.POINTER(ctypes.c_void_p)]),
         'mpc_locator_query': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, _dp, ctypes.c_double, ctypes.c_int32, _lp, _dp,
@@ -198,7 +199,7 @@ EXPORTED_SYMBOLS = ['mpc_device_count', 'mpc_version', 'mpc_last_global_error', 
                     'mpc_frontier_root', 'mpc_frontier_set', 'mpc_frontier_set_device', 'mpc_frontier_info',
                     'mpc_frontier_get', 'mpc_pruned_clear', 'mpc_pruned_add', 'mpc_pruned_add_device',
                     'mpc_pruned_count', 'mpc_pruned_get', 'mpc_level_run', 'mpc_level_run_ex', 'mpc_level_run_batch', 'mpc_frontier_advance_batch', 'mpc_level_memory_gb', 'mpc_trim', 'mpc_level_batch_start', 'mpc_level_batch_wait', 'mpc_level_regions_slots_nowait', 'mpc_level_batch_fetch', 'mpc_level_status', 'mpc_level_start', 'mpc_level_stream_info', 'mpc_level_chunk_wait', 'mpc_level_wait', 'mpc_level_stream_fixup', 'mpc_base_result', 'mpc_solve_start', 'mpc_solve_level', 'mpc_solve_chunk_wait', 'mpc_solve_level_wait', 'mpc_solve_wait', 'mpc_level_regions', 'mpc_compact_strides',
-                    'mpc_level_regions_compact', 'mpc_frontier_shard', 'mpc_level_slots', 'mpc_level_regions_slots', 'mpc_level_regions_slots_async', 'mpc_sync', 'mpc_host_alloc', 'mpc_host_free', 'mpc_locator_create', 'mpc_locator_query', 'mpc_locator_destroy', 'mpc_locator_set_adjacency', 'mpc_level_children', 'mpc_level_children_device', 'mpc_level_pruned_new',
+                    'mpc_level_regions_compact', 'mpc_frontier_shard', 'mpc_level_slots', 'mpc_level_regions_slots', 'mpc_level_regions_slots_async', 'mpc_sync', 'mpc_fetch_wait', 'mpc_host_alloc', 'mpc_host_free', 'mpc_locator_create', 'mpc_locator_query', 'mpc_locator_destroy', 'mpc_locator_set_adjacency', 'mpc_level_children', 'mpc_level_children_device', 'mpc_level_pruned_new',
                     'mpc_level_pruned_new_device', 'mpc_level_regions_device', 'mpc_frontier_advance', 'mpc_qp_solve_batch', 'mpc_facet_centres', 'mpc_graph_begin', 'mpc_graph_wave', 'mpc_graph_group_run', 'mpc_graph_wave_close', 'mpc_check_level', 'mpc_lp_solve_batch']
 
 
@@ -476,12 +477,20 @@ class Engine:
         rc = engines[0]._L.mpc_level_batch_fetch(hs, B, pd, pi, caps, pe, capr, n1, n2)
         if rc != 0:
             Engine._raise_for(engines, rc)
+        # (the members' arrays are complete after Engine.fetch_wait / any member's sync / the next level_batch_start)
         out = []
         for j, e in enumerate(engines):
             ns, nr = int(n1[j]), int(n2[j])
             out.append((big_d[od[j]:od[j] + ns * fds[j]].reshape(ns, fds[j]), big_i[oi[j]:oi[j] + ns * fis[j]].reshape(ns, fis[j]),
                         big_e[oe[j]:oe[j] + nr * (e.n_t + 1)].reshape(nr, e.n_t + 1), int(e._last.k)))
         return out
+
+    @staticmethod
+    def fetch_wait(engine):
+        """Waits for the shared record copy of the last ``level_batch_fetch`` on the engine's device (mpc_fetch_wait)."""
+        rc = engine._L.mpc_fetch_wait(int(engine.device))
+        if rc != 0:
+            engine._check(rc, 'mpc_fetch_wait')
 
     @staticmethod
     def _raise_for(engines, rc):

@@ -835,6 +835,18 @@ MPC_GLOBAL void MPC_LB(256) k_fetch_slots(FetchCopy a) {
     }
 }
 
+// The records of MANY handles copied to page-locked host memory by ONE launch (round 5: the shared launches of many programs paid
+// three copy commands per member and level -- ~16 us of host time each on this runtime, 1.8 ms per level for 128 members).
+// blockIdx.y = table entry (one array of one member), blockIdx.x strides over its 4-byte words.
+struct FetchEntry { const void *src; void *dst; unsigned long long bytes; };
+MPC_GLOBAL void MPC_LB(256) k_fetch_many(const FetchEntry *__restrict__ tab) {
+    const FetchEntry e = tab[blockIdx.y];
+    const unsigned long long words = e.bytes / 4;
+    const unsigned int *src = static_cast<const unsigned int *>(e.src);
+    unsigned int *dst = static_cast<unsigned int *>(e.dst);
+    for (unsigned long long i = blockIdx.x * 256ull + threadIdx.x; i < words; i += (unsigned long long)gridDim.x * 256ull) dst[i] = src[i];
+}
+
 // copies a few words of device memory into pinned host memory (a read-back without a copy command: on this runtime a
 // hipMemcpyAsync costs the host ~16 us, a launch ~3 us)
 MPC_GLOBAL void k_publish_words(const unsigned int *__restrict__ src, unsigned int *__restrict__ dst, int n) {

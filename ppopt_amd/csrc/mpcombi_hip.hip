@@ -546,6 +546,7 @@ static int create_fill(const mpc_problem *p, int32_t device, void *stream, mpc_h
 static void stream_release(mpc_handle *h);
 static void solve_release(mpc_handle *h);
 static double batch_level_gb(const mpc_handle *h, int32_t gen_children);
+static int fetch_many_wait(int device);
 static int lp_batch_impl(int32_t device, int64_t n_lp, int32_t m, int32_t n, const double *A, int32_t shared_A, const double *b,
                          int32_t shared_b, const double *c, int32_t shared_c, const uint8_t *eq, int32_t *status, double *x,
                          double *obj, int32_t *iters, int32_t *tight);
@@ -1861,6 +1862,7 @@ int mpc_level_batch_start(mpc_handle **hs, int32_t n_handles, const int32_t *gen
         if (std::adjacent_find(sorted.begin(), sorted.end()) != sorted.end()) return fail(h0, MPC_ERR_INVALID, "mpc_level_run_batch: a handle appears twice");
     }
     HIP_TRY(h0, hipSetDevice(h0->device));
+    if (fetch_many_wait(h0->device) != MPC_OK) return fail(h0, MPC_ERR_HIP, "mpc_level_batch_start: the shared record copy (k_fetch_many) failed");   // the members' record buffers are free again
     std::unique_ptr<BatchToken> t(new BatchToken());
     t->hs.assign(hs, hs + n_handles);
     t->gen.assign(gen_children, gen_children + n_handles);
@@ -3361,12 +3363,66 @@ int mpc_level_regions_slots_nowait(mpc_handle *h, double *head_d, int32_t *head_
     h->fetch_nowait = false;
     return rc;
 }
+// one event per device: "the last k_fetch_many has finished" (recorded on the stream it ran on)
+static std::mutex g_fetch_mutex;
+static std::map<int, hipEvent_t> g_fetch_event;
+static DevBuf g_fetch_tab_dev;
+static HostBuf g_fetch_tab_host;
+static int fetch_many_wait(int device) {
+    // Every copy launch waits for the one before it (its table is reused), so the LATEST record of the device's event covers all earlier
+    // launches: whoever waits -- from any thread, for any member -- waits for that record (a completed event returns at once).
+    hipEvent_t ev = nullptr;
+    {
+        std::lock_guard<std::mutex> lk(g_fetch_mutex);
+        auto it = g_fetch_event.find(device);
+        if (it == g_fetch_event.end() || !it->second) return MPC_OK;
+        ev = it->second;
+    }
+    return hipEventSynchronize(ev) == hipSuccess ? MPC_OK : MPC_ERR_HIP;
+}
+int mpc_fetch_wait(int32_t device) { return fetch_many_wait(device); }
+
 int mpc_level_batch_fetch(mpc_handle **hs, int32_t n_handles, double *const *head_d, int32_t *const *head_i, const int64_t *cap_slots,
                           double *const *erows, const int64_t *cap_rows, int64_t *n_slots, int64_t *n_rows) {
     if (!hs || n_handles < 0 || !head_d || !head_i || !cap_slots || !erows || !cap_rows || !n_slots || !n_rows) return MPC_ERR_INVALID;
+    static const bool no_many = [] { const char *ev = std::getenv("MPC_NO_FETCH_MANY"); return ev && ev[0] == '1'; }();   // A/B: three copy commands per member
+    std::vector<FetchEntry> tab;
+    mpc_handle *lead = nullptr;
     for (int i = 0; i < n_handles; ++i) {
-        const int rc = mpc_level_regions_slots_nowait(hs[i], head_d[i], head_i[i], cap_slots[i], erows[i], cap_rows[i], n_slots + i, n_rows + i);
+        mpc_handle *h = hs[i];
+        if (!h) return MPC_ERR_INVALID;
+        // every record in slot form on the device, nothing streamed, nothing re-solved by the LDS engine: the copy kernel takes the member
+        const bool fast = !no_many && h->level_done && !h->so.active && h->n_regions > 0 && h->n_opt > 0 && h->used_region2 && h->n_rretry == 0 &&
+                          cap_slots[i] >= h->n_opt && cap_rows[i] >= h->n_erows && head_d[i] && head_i[i] && (erows[i] || h->n_erows == 0) &&
+                          (!lead || lead->device == h->device);
+        void *d_hd = nullptr, *d_hi = nullptr, *d_er = nullptr;
+        if (fast && hipHostGetDevicePointer(&d_hd, head_d[i], 0) == hipSuccess && hipHostGetDevicePointer(&d_hi, head_i[i], 0) == hipSuccess &&
+            (h->n_erows == 0 || hipHostGetDevicePointer(&d_er, erows[i], 0) == hipSuccess)) {
+            if (!lead) lead = h;
+            tab.push_back({h->headi.p, d_hi, (unsigned long long)h->n_opt * h->fi * sizeof(int32_t)});
+            tab.push_back({h->headd.p, d_hd, (unsigned long long)h->n_opt * h->fd * sizeof(double)});
+            if (h->n_erows > 0) tab.push_back({h->epool.p, d_er, (unsigned long long)h->n_erows * (h->n_t + 1) * sizeof(double)});
+            n_slots[i] = h->n_opt; n_rows[i] = h->n_erows;
+            continue;
+        }
+        (void)hipGetLastError();
+        const int rc = mpc_level_regions_slots_nowait(h, head_d[i], head_i[i], cap_slots[i], erows[i], cap_rows[i], n_slots + i, n_rows + i);
         if (rc != MPC_OK) return rc;
+    }
+    if (!tab.empty()) {
+        HIP_TRY(lead, hipSetDevice(lead->device));
+        std::lock_guard<std::mutex> lk(g_fetch_mutex);
+        if (g_fetch_event.count(lead->device) && g_fetch_event[lead->device]) HIP_TRY(lead, hipEventSynchronize(g_fetch_event[lead->device]));   // the table of the previous call is free again
+        const size_t bytes = tab.size() * sizeof(FetchEntry);
+        HIP_TRY(lead, g_fetch_tab_host.ensure(bytes));
+        HIP_TRY(lead, g_fetch_tab_dev.ensure(bytes, lead->stream));
+        std::memcpy(g_fetch_tab_host.p, tab.data(), bytes);
+        HIP_TRY(lead, hipMemcpyAsync(g_fetch_tab_dev.p, g_fetch_tab_host.p, bytes, hipMemcpyHostToDevice, lead->stream));
+        hipLaunchKernelGGL(k_fetch_many, dim3(8, (unsigned)tab.size()), dim3(256), 0, lead->stream, g_fetch_tab_dev.as<FetchEntry>());
+        HIP_TRY(lead, hipGetLastError());
+        auto &ev = g_fetch_event[lead->device];
+        if (!ev) HIP_TRY(lead, pooled_event(&ev, false));
+        HIP_TRY(lead, hipEventRecord(ev, lead->stream));
     }
     return MPC_OK;
 }
@@ -3391,6 +3447,7 @@ int mpc_sync(mpc_handle *h) {
     if (!h) return MPC_ERR_INVALID;
     HIP_TRY(h, hipSetDevice(h->device));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
+    if (fetch_many_wait(h->device) != MPC_OK) return fail(h, MPC_ERR_HIP, "mpc_sync: the shared record copy (k_fetch_many) failed");   // (its stream may be another member's)
     return MPC_OK;
 }
 

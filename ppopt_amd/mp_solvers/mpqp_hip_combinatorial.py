@@ -412,7 +412,10 @@ def _solve_many(programs, device: int = 0, max_levels: Optional[int] = None, pru
             for i, _ in fetched:
                 if i not in started and i not in finished:
                     engs[i].sync()
-            # ... and the region objects of the finished level are built while the device works on it
+            # ... and the region objects of the finished level are built while the device works on it (the records of all members came by
+            # one copy launch: complete once its event has passed -- it has, whenever a next level was started)
+            if fetched:
+                Engine.fetch_wait(engs[fetched[0][0]])
             for i, (hd, hi, er, kk) in fetched:
                 eng = engs[i]
                 slots = numpy.flatnonzero(hi[:, 0] == REGION_STATUS)
