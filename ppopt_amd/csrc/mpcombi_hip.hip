@@ -329,7 +329,7 @@ struct mpc_handle {
     long long n_x1 = 0;       // dictionaries of the last level run that k_x1 wrote
     int xq_retry = 0;         // MPC_XQ_RETRY=1: a doubtful pivot met by the quick test is flagged by the quick test itself and re-solved at once on the second stream (round 5; off: on config 3 half of the doubtful candidates only show in k_x2, beyond the quick test's sixteen iterations, so the level pays the LDS engine twice -- 3.55 ms against 3.28)
     int no_xq_early = 0;      // MPC_NO_XQ_EARLY=1: the thread pass of the quick test always behind the theta stage, -1: always beside it (A/B)
-    long long prev_regions = 0, xq_early_regions = 1024;   // regions of the level before; MPC_XQ_EARLY_REGIONS
+    long long prev_regions = 0, xq_early_regions = 0;   // MPC_XQ_EARLY_REGIONS = r > 0: the pass runs beside the theta stage only when the level before found fewer than r regions (0: always)
     int xqt_wpc = 16;         // MPC_XQT_WPC: wavefronts per CU of k_xq_thread (it is bound by the cache's request rate: config 4's level 0.45 ms alone with 8 per CU, 0.49 with 24; beside the region kernel 0.92 / 0.70 / 0.78 / 0.75 with 4 / 8 / 12 / 16)
     int xqg_overlap = 0;      // MPC_XQG_OVERLAP=1: the region stage runs under the (x,theta) stage also when the quick test is the grouped one (experiment)
     int xq_thread = -1;       // MPC_XQ_THREAD: 0 = the quick test without its one-thread-per-candidate first pass k_xq_thread (round 5); 1 = the pass against the generating parent only; n >= 2 = ... and up to n - 1 other parents; default: every other parent
@@ -2259,11 +2259,11 @@ static int level_run_impl(mpc_handle *h, int32_t gen_children, int32_t flags, mp
             // before the partition that follows the theta stage, which then sees only what the pass left open.
             bool early_xq = false;
             if (kkc && lean && h->no_xq_early <= 0 && h->xq_thread != 0 && !h->no_xquick && !(flags & MPC_LEVEL_GRAPH) && h->have_prev_dict && h->have_parent_slot &&
-                n >= 4096 && !h->force_xqgroup && (h->no_xq_early < 0 || h->prev_regions < h->xq_early_regions)) {
-                // (only when this level's region stage is expected to be short -- the previous level found fewer than xq_early_regions
-                //  regions: otherwise the pass is worth more beside the REGION kernel, which it overlaps when it runs behind the theta
-                //  stage.  Config 4's last level, 6,238 regions: 1.76 ms behind, 1.91 beside the theta stage; config 3's, 276 regions:
-                //  3.41 / 3.23 ms.  MPC_NO_XQ_EARLY=1 never, =-1 always.)
+                n >= 4096 && !h->force_xqgroup && (h->no_xq_early < 0 || h->prev_regions < h->xq_early_regions || h->xq_early_regions <= 0)) {
+                // (The pass then overlaps the theta stage AND the region stage: the partition behind the theta stage lists only the doubtful
+                //  and the optimal candidates -- classes the pass never touches --, the region kernel starts on its stream, and the open
+                //  candidates are listed when the pass has ended.  Config 4's last level: 1.86 ms with the pass behind the theta stage,
+                //  1.72 beside it; config 3's: 3.45 / 3.25.  MPC_NO_XQ_EARLY=1: behind.)
                 const int nxc_e = h->fast_x >= 2 ? 32 : 16;
                 const long long sd_e = (long long)nxc_e * h->Pf.n_d0r, si_e = dict_ints(h->Pf.n_d0r, nxc_e, h->n_c);
                 const bool will_store = gen_children && (double)nn * (sd_e * 8.0 + si_e * 4.0) / 1e9 <= h->dict_budget_gb;
@@ -2322,8 +2322,13 @@ static int level_run_impl(mpc_handle *h, int32_t gen_children, int32_t flags, mp
             // One partition after the theta stage: [0] numerically doubtful (status 7), [1] feasible and [2] optimal (decided
             // in theta space; they only need a dictionary for their children), [3] feasibility still open.
             int32_t cntA[PART_CLASSES] = {0, 0, 0, 0};
-            if (early_xq) HIP_TRY(h, hipStreamWaitEvent(st, h->ev_xjoin, 0));   // the thread pass rewrites statuses of its own candidates
-            { int rcs = partition({{ST_RETRY, 0}, {ST_FEASIBLE, 1}, {ST_OPT_PENDING, 2}, {ST_NEEDX, 3}, {ST_NEEDX_SING, 3}}, cntA); if (rcs) return rcs; }
+            if (early_xq) {
+                // The thread pass is still rewriting the statuses of ITS candidates (NEEDX -> feasible / infeasible / singular) on the second
+                // stream: this partition asks only for the two classes it never touches -- doubtful and optimal candidates of the theta
+                // stage --, so that the region stage can start beside it; the open candidates are listed when the pass has ended (below).
+                { int rcs = partition({{ST_RETRY, 0}, {ST_OPT_PENDING, 2}}, cntA); if (rcs) return rcs; }
+                cntA[3] = (int32_t)std::min<long long>(n, 0x7fffffffLL);     // a bound, for the decisions that follow; the count comes after the join
+            } else { int rcs = partition({{ST_RETRY, 0}, {ST_FEASIBLE, 1}, {ST_OPT_PENDING, 2}, {ST_NEEDX, 3}, {ST_NEEDX_SING, 3}}, cntA); if (rcs) return rcs; }
             // The doubtful candidates are re-solved by the LDS engine, which can refactorise its basis: a few hundred
             // long-running wavefronts.  They run on the side stream while the (x,theta) stage fills the GPU; their results are
             // applied to the status array after the join.
@@ -2374,7 +2379,7 @@ static int level_run_impl(mpc_handle *h, int32_t gen_children, int32_t flags, mp
             const size_t lds_q = (size_t)h->dict_stride_d * sizeof(double) + (size_t)h->dict_stride_i * sizeof(int32_t);
             const bool quick_test = cntA[3] > 0 && !(flags & MPC_LEVEL_GRAPH) && !h->storing && dc.parent_slot && !h->no_xquick;
             const bool use_grouped = quick_test && !h->no_xqgroup && ((h->last_level_n > 0 && (long long)cntA[3] >= 10 * h->last_level_n) || h->force_xqgroup) &&
-                                     cntA[3] >= 4096 && lds_q <= 64 * 1024;
+                                     cntA[3] >= 4096 && lds_q <= 64 * 1024 && !early_xq;   // (after the thread pass few candidates per parent are left)
             if (!h->no_roverlap && !h->theta_open && cntA[2] > 0 && h->fast_r >= 0 && !(flags & MPC_LEVEL_GRAPH) && x_items >= h->roverlap_min && (!use_grouped || h->xqg_overlap)) {
                 // Candidates that turn out optimal later -- re-solved doubtful ones: the n_early of the theta stage, rarely one of
                 // the (x,theta) stage -- get spare slots behind the launch's and take the LDS-engine route of the candidates
@@ -2420,8 +2425,16 @@ static int level_run_impl(mpc_handle *h, int32_t gen_children, int32_t flags, mp
                 dc.pre1 = part_list(1); dc.n_pre1 = cntA[1];
                 dc.pre2 = part_list(2); dc.n_pre2 = cntA[2];
             }
+            if (early_xq) {
+                // the thread pass has ended: what it left open (and what the theta stage left open) is listed now
+                HIP_TRY(h, hipStreamWaitEvent(st, h->ev_xjoin, 0));
+                int32_t n_left = 0;
+                { int rcs = compact(ST_NEEDX, ST_NEEDX_SING, &n_left); if (rcs) return rcs; }
+                std::swap(h->xq_list, h->retry_list);     // (xq_list held the pass's input: free again)
+                cntA[3] = n_left;
+            }
             int32_t n_needx = cntA[3];
-            const int32_t *needx_list = part_list(3);
+            const int32_t *needx_list = early_xq ? h->xq_list.as<int32_t>() : part_list(3);
             h->n_needx = n_needx;
             if ((flags & MPC_LEVEL_GRAPH) && n_needx > 0) {
                 // connected-graph traversal: only "is the critical region non-empty" is asked; the candidates whose theta stage
