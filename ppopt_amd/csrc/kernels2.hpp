@@ -1014,9 +1014,22 @@ MPC_GLOBAL void MPC_LB(64) k_xq_thread(const DevProblem *__restrict__ Pg, const 
                 const int32_t *as = cands + (size_t)c * k;
                 const int drop = km - t;   // position of the member this parent does not have (t = 1: the second largest)
                 // as[] without as[drop] in the previous frontier (lexicographic order)
+                // the wanted set, and the comparison with a row of the previous frontier: the row's members are fetched together (one
+                // round trip per step of the search instead of one per member -- the look-up is a chain of dependent reads)
+                int want[8];
+#pragma unroll
+                for (int a = 0; a < 8; ++a) want[a] = a < km ? as[a < drop ? a : a + 1] : 0;
                 auto cmp_row = [&](int i) -> int {   // sign of (row i) - (the wanted set)
                     const int32_t *row = alt.prev_frontier + (size_t)i * km;
                     int cmp = 0;
+                    if (km <= 8) {
+                        int rv[8];
+#pragma unroll
+                        for (int a = 0; a < 8; ++a) rv[a] = a < km ? row[a] : 0;
+#pragma unroll
+                        for (int a = 0; a < 8; ++a) if (cmp == 0 && a < km) cmp = (rv[a] > want[a]) - (rv[a] < want[a]);
+                        return cmp;
+                    }
                     for (int a = 0; a < km && cmp == 0; ++a) {
                         const int qa = as[a < drop ? a : a + 1];
                         cmp = (row[a] > qa) - (row[a] < qa);
@@ -1395,15 +1408,28 @@ MPC_GLOBAL void MPC_LB(64, 8) k_x1(const DevProblem *__restrict__ Pg, const int3
         for (int sl = 0; sl < SLOTS; ++sl) { qhint[sl] = 0; gbest[sl] = TOL_COST; }
         // columns in groups of CB: all loads of a group are issued before the first is used (the stream is bound by how many bytes are in
         // flight, one column at a time left the kernel at a third of the memory rate)
+        // ... and the loads of the NEXT group are issued before the stores of this one: loads and stores share one in-order counter
+        // on this hardware, so a load that follows a store in program order waits for that store to reach memory -- with the groups
+        // one after the other an item took four round trips of load AND store latency (config 4, level 4: 0.63 ms for 138 k records)
         constexpr int CB = SLOTS == 1 ? 8 : 4;
-        for (int j0 = 0; j0 <= nc0; j0 += CB) {
-            double t[CB][SLOTS];
+        double tn[CB][SLOTS];
+        auto load_group = [&](int j0) {
 #pragma unroll
             for (int u = 0; u < CB; ++u) {
                 const int j = min(j0 + u, nc0);
 #pragma unroll
-                for (int sl = 0; sl < SLOTS; ++sl) { const int i = lane + 64 * sl; t[u][sl] = i < mr ? pd[(size_t)j * mr + i] : 0.0; }
+                for (int sl = 0; sl < SLOTS; ++sl) { const int i = lane + 64 * sl; tn[u][sl] = i < mr ? pd[(size_t)j * mr + i] : 0.0; }
             }
+        };
+        load_group(0);
+        for (int j0 = 0; j0 <= nc0; j0 += CB) {
+            double t[CB][SLOTS];
+#pragma unroll
+            for (int u = 0; u < CB; ++u) {
+#pragma unroll
+                for (int sl = 0; sl < SLOTS; ++sl) t[u][sl] = tn[u][sl];
+            }
+            if (j0 + CB <= nc0) load_group(j0 + CB);
 #pragma unroll
             for (int u = 0; u < CB; ++u) {
                 const int j = j0 + u;
