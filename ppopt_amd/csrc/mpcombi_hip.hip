@@ -325,6 +325,7 @@ struct mpc_handle {
     int no_rsplit = 0;        // MPC_NO_RSPLIT=1: one wavefront per candidate in k_region2 whatever the load (A/B)
     int no_xquick = 0;        // MPC_NO_XQUICK=1: no quick (x,theta) test on the last level (A/B)
     int x1 = 1;               // MPC_X1=0: every dictionary of a storing level by the register simplex k_x2 (rounds 1-4); 1: one-step plans (k_xq_thread, plan mode) streamed by k_x1, from the generating parent only; 2 (default): ... and from the candidate's other parents
+    long long xqt_min = 4096, x1_min = 2048;   // MPC_XQT_MIN / MPC_X1_MIN: smallest list the one-thread pass / the one-step plans take (tests set 1: every level of a small program goes through them)
     int x1_wpc = 16;          // MPC_X1_WPC: wavefronts per CU of k_x1 (config 4, level 4, beside the region kernel: x stage 1.13 / 0.95 / 1.02 ms with 8 / 16 / 32)
     long long n_x1 = 0;       // dictionaries of the last level run that k_x1 wrote
     int xq_retry = 0;         // MPC_XQ_RETRY=1: a doubtful pivot met by the quick test is flagged by the quick test itself and re-solved at once on the second stream (round 5; off: on config 3 half of the doubtful candidates only show in k_x2, beyond the quick test's sixteen iterations, so the level pays the LDS engine twice -- 3.55 ms against 3.28)
@@ -624,6 +625,8 @@ static int create_fill(const mpc_problem *p, int32_t device, void *stream, mpc_h
     { const char *ev = std::getenv("MPC_X1"); h->x1 = ev ? std::atoi(ev) : 2; }
     { const char *ev = std::getenv("MPC_XQ_RETRY"); h->xq_retry = ev && ev[0] == '1'; }
     { const char *ev = std::getenv("MPC_X1_WPC"); if (ev && std::atoi(ev) > 0) h->x1_wpc = std::atoi(ev); }
+    { const char *ev = std::getenv("MPC_XQT_MIN"); if (ev) h->xqt_min = std::atoll(ev); }
+    { const char *ev = std::getenv("MPC_X1_MIN"); if (ev) h->x1_min = std::atoll(ev); }
     { const char *ev = std::getenv("MPC_NO_XQ_EARLY"); h->no_xq_early = ev ? std::atoi(ev) : 0; }
     { const char *ev = std::getenv("MPC_XQ_EARLY_REGIONS"); if (ev) h->xq_early_regions = std::atoll(ev); }
     { const char *ev = std::getenv("MPC_NO_KKT_THREAD"); h->no_kkt_thread = ev ? std::atoi(ev) : 0; }   // 2: only the small-level path
@@ -2259,7 +2262,7 @@ static int level_run_impl(mpc_handle *h, int32_t gen_children, int32_t flags, mp
             // before the partition that follows the theta stage, which then sees only what the pass left open.
             bool early_xq = false;
             if (kkc && lean && h->no_xq_early <= 0 && h->xq_thread != 0 && !h->no_xquick && !(flags & MPC_LEVEL_GRAPH) && h->have_prev_dict && h->have_parent_slot &&
-                n >= 4096 && !h->force_xqgroup && (h->no_xq_early < 0 || h->prev_regions < h->xq_early_regions || h->xq_early_regions <= 0)) {
+                n >= h->xqt_min && !h->force_xqgroup && (h->no_xq_early < 0 || h->prev_regions < h->xq_early_regions || h->xq_early_regions <= 0)) {
                 // (The pass then overlaps the theta stage AND the region stage: the partition behind the theta stage lists only the doubtful
                 //  and the optimal candidates -- classes the pass never touches --, the region kernel starts on its stream, and the open
                 //  candidates are listed when the pass has ended.  Config 4's last level: 1.86 ms with the pass behind the theta stage,
@@ -2460,7 +2463,7 @@ static int level_run_impl(mpc_handle *h, int32_t gen_children, int32_t flags, mp
                 const int32_t *xq_list = needx_list;
                 int32_t xq_n = n_needx;
                 bool xqt_lean = false;
-                if (h->xq_thread != 0 && n_needx >= 4096 && !early_xq) {
+                if (h->xq_thread != 0 && n_needx >= h->xqt_min && !early_xq) {
                     const unsigned gt = (unsigned)std::min<long long>(((long long)n_needx + 63) / 64, (long long)h->n_cu * h->xqt_wpc);
                     HIP_TRY(h, hipEventRecord(h->kev[10], st));
                     XqAlt alt{};
@@ -2535,7 +2538,7 @@ static int level_run_impl(mpc_handle *h, int32_t gen_children, int32_t flags, mp
                 HIP_TRY(h, hipEventRecord(h->kev[2], st));
                 int rcs = MPC_OK;
                 const long long n_dict = (long long)n_needx + dc.n_pre1 + dc.n_pre2;
-                if (h->storing && dc.parent_slot && h->x1 > 0 && !xq_lean && n_dict >= 2048) {
+                if (h->storing && dc.parent_slot && h->x1 > 0 && !xq_lean && n_dict >= h->x1_min) {
                     // One-step plans (round 5).  Every candidate that needs a dictionary is asked by ONE THREAD whether a parent's record is
                     // one known step away (k_xq_thread in plan mode: the generating parent, then the candidate's other parents); k_x1 then
                     // streams that record through the step -- no tableau in registers, no pricing, no ratio test --, and only what has no

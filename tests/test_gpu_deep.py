@@ -485,6 +485,32 @@ def test_streamed_one_step_dictionaries_equal_the_register_simplex(name, monkeyp
             assert numpy.array_equal(getattr(r1, fld), getattr(r2, fld)), (key, fld)
 
 
+@pytest.mark.parametrize('name', ['rand_6_3_12_s1', 'c2_dblint_n5', 'quadtank_n3', 'rand_5_3_8_s3', 'mplp_rand_5_3_12_s2', 'c5_control_allocation'])
+def test_one_thread_pass_and_one_step_plans_forced_on_every_level(name, monkeypatch):
+    """The round-5 paths take lists of >= 4,096 (thread pass) / 2,048 (plans) candidates by default, i.e. only the large levels of large
+    programs.  MPC_XQT_MIN=1 MPC_X1_MIN=1 MPC_NO_SMALLPATH=1 sends EVERY level of a small program through them -- other parents, plans,
+    k_x1, the pass beside the theta stage: the statuses of every level and the region set must be those of the default run (which
+    the golden tests hold against the reference).  (tools/fuzz_scan.py under the same switches: 1.25 M candidates of 490 programs, no
+    verdict differs from the CPU oracle, profiles/r05_fuzz_forced_paths.log.)"""
+    from test_gpu_parity import engine_from_golden, run_levels
+    g = load_golden(name)
+    nl = None if bool(g['complete']) else int(g['n_levels']) + 1
+    runs = []
+    for env in ({}, {'MPC_NO_SMALLPATH': '1', 'MPC_XQT_MIN': '1', 'MPC_X1_MIN': '1'}):
+        with monkeypatch.context() as m:
+            for key, val in env.items():
+                m.setenv(key, val)
+            eng = engine_from_golden(g)
+            levels, regions = run_levels(eng, nl)
+            runs.append(([(c.copy(), s.copy(), int(st.n_children), int(st.n_xq_thread)) for c, s, st in levels], sorted(tuple(r.active_set) for r in regions)))
+            eng.close()
+    (la, ra), (lb, rb) = runs
+    assert len(la) == len(lb) and ra == rb
+    for (ca, sa, na, ta), (cb, sb, nb, tb) in zip(la, lb):
+        assert numpy.array_equal(ca, cb) and numpy.array_equal(sa, sb) and na == nb
+    assert sum(t for *_, t in lb) > 0, 'the forced run never used the one-thread pass'
+
+
 # ---- levels without host round trips (level_run_small) and lean large levels -------------------------------------------------
 @pytest.mark.parametrize('name', ['rand_6_3_12_s1', 'c2_dblint_n5', 'quadtank_n3', 'c4_rand_20_8_20_s0', 'mplp_rand_5_3_12_s2'])
 def test_levels_without_host_round_trips_equal_the_classic_path(name, monkeypatch):
