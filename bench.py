@@ -284,8 +284,14 @@ def main():
                       'algorithmic_bytes': nbytes, 'achieved_GBs': nbytes / max(tot_ms, 1e-9) / 1e6}
     add('k_theta2', 'ms_theta', 'n_theta_items',
         lambda p: p['n_theta_items'] * (4 * p['k'] + 2 + 8 * p['k'] * (nt + 1)) + 8 * nc * (nc + nt + 1))
-    add('k_x2', 'ms_x', 'n_x_items',
-        lambda p: p['n_x_items'] * (p['dict_read_bytes'] + p['dict_write_bytes'] + 4 + 4 * p['k'] + 1))
+    #   round 5: on a level that keeps dictionaries ms_x spans the plan pass (k_xq_thread in plan mode, ms_x_plan), the streamed one-step
+    #             dictionaries (k_x1: n_x1 records read and written, ms_x1) and the register simplex k_x2 for what has no plan (the rest)
+    for p in all_levels:
+        p['ms_x2'] = max(0.0, p.get('ms_x', 0.0) - p.get('ms_x1', 0.0) - p.get('ms_x_plan', 0.0))
+        p['n_x2_items'] = max(0, p.get('n_x_items', 0) - p.get('n_x1', 0))
+    add('k_x2', 'ms_x2', 'n_x2_items',
+        lambda p: p['n_x2_items'] * (p['dict_read_bytes'] + p['dict_write_bytes'] + 4 + 4 * p['k'] + 1))
+    add('k_x1', 'ms_x1', 'n_x1', lambda p: p.get('n_x1', 0) * (p['dict_read_bytes'] + p['dict_write_bytes'] + 12))
     R = lambda k: 8 * (nt + 1) * (nx + k + n_e) + 4 * (8 + 2 * k + prog.A_t.shape[0] + 2 * (nc - k))
     add('k_region2', 'ms_region2', 'n_opt', lambda p: p['n_opt'] * (4 * p['k'] + 8 * p['k'] * (nt + 1) + R(p['k'])))
     #   k_kkt_thread  per candidate: active set (4k) in, KKT code + status out, the multipliers (8 k (n_t+1)) of the candidates its
@@ -311,7 +317,7 @@ def main():
     add('k_xq', 'ms_xq_wave', 'n_xq_wave_items', xq_bytes)
     def xqt_bytes(p):
         ints, rows, cols = p.get('xq_record', [0, 0, 0])
-        return p.get('n_xq_items', 0) * (13 + 1 + 12 + 8 + 16 + 16 * rows)   # one test per candidate (tests against other parents come on top: a lower bound)
+        return (p.get('n_xq_items', 0) if not p.get('ms_x_plan') else p.get('n_x_items', 0)) * (13 + 1 + 12 + 8 + 16 + 16 * rows)   # one test per candidate (tests against other parents come on top: a lower bound)
     add('k_xq_thread', 'ms_xq_thread', 'n_xq_items', xqt_bytes)
     # The roofline object follows SURVEY.md 8(d): achieved = B_alg x candidates/s for the path (all kernels of a level), against
     # the HBM peak.  `dominant_kernel` describes the kernel with the most time ON THE STEP'S CRITICAL PATH (its own algorithmic
@@ -398,7 +404,7 @@ def main():
                      'achieved_over_kernel_time': bytes_path / max(ms_path, 1e-9) / 1e6,
                      'dominant_kernel': {'kernel': dominant, 'chosen_by': 'time on the critical path of the step (k_region2 under the (x,theta) stage is not)',
                                          'on_path_ms_per_step': {name: kk['on_path_ms'] / steps for name, kk in kern.items()},
-                                         'bound': 'hbm (dependent reads of the cached dictionaries)' if dominant in ('k_x2', 'k_xq', 'k_xq_thread') else 'fp64 VALU issue / dependent latency',
+                                         'bound': ('hbm (a record streamed in and out per candidate)' if dominant == 'k_x1' else 'hbm (dependent reads of the cached dictionaries)') if dominant in ('k_x1', 'k_x2', 'k_xq', 'k_xq_thread') else 'fp64 VALU issue / dependent latency',
                                          'achieved': dom['achieved_GBs'], 'frac': dom['achieved_GBs'] / HBM_PEAK_GBS,
                                          'launches': dom['launches'], 'avg_launch_ms': dom['avg_launch_ms'],
                                          'algorithmic_bytes_per_launch': dom['algorithmic_bytes'] / max(dom['launches'], 1),

@@ -106,6 +106,10 @@ typedef struct {
      * wavefront kernel gets the others) and its HIP-event time (inside ms_xq) */
     int64_t n_xq_thread;
     float ms_xq_thread, xq_thread_beside_theta;   /* 1: the pass ran on the second stream beside the theta stage (outside ms_xq), 0: inside ms_xq */
+    /* round 5: one-step plans on a level that keeps dictionaries: records written by k_x1 (the streamed single pivot), its HIP-event
+     * time and that of the plan pass (k_xq_thread in plan mode) -- both inside ms_x, whose remainder is the register simplex k_x2 */
+    int64_t n_x1;
+    float ms_x1, ms_x_plan;
 } mpc_level_stats;
 
 /* ---- library / device ------------------------------------------------------------------------------ */

@@ -57,7 +57,8 @@ class LevelStats(ctypes.Structure):
                 ('n_theta_items', ctypes.c_int64), ('n_region_rows', ctypes.c_int64),
                 ('ms_kkt', ctypes.c_float), ('ms_xq', ctypes.c_float), ('n_xq_items', ctypes.c_int64), ('xq_pivots', ctypes.c_int64),
                 ('xq_record_ints', ctypes.c_int64), ('xq_record_rows', ctypes.c_int64), ('xq_record_cols', ctypes.c_int64),
-                ('n_xq_thread', ctypes.c_int64), ('ms_xq_thread', ctypes.c_float), ('xq_thread_beside_theta', ctypes.c_float)]
+                ('n_xq_thread', ctypes.c_int64), ('ms_xq_thread', ctypes.c_float), ('xq_thread_beside_theta', ctypes.c_float),
+                ('n_x1', ctypes.c_int64), ('ms_x1', ctypes.c_float), ('ms_x_plan', ctypes.c_float)]
 
 
 class SolveLevelInfo(ctypes.Structure):

@@ -328,6 +328,7 @@ struct mpc_handle {
     long long xqt_min = 4096, x1_min = 2048;   // MPC_XQT_MIN / MPC_X1_MIN: smallest list the one-thread pass / the one-step plans take (tests set 1: every level of a small program goes through them)
     int x1_wpc = 16;          // MPC_X1_WPC: wavefronts per CU of k_x1 (config 4, level 4, beside the region kernel: x stage 1.13 / 0.95 / 1.02 ms with 8 / 16 / 32)
     long long n_x1 = 0;       // dictionaries of the last level run that k_x1 wrote
+    float ms_x1 = 0;
     int xq_retry = 0;         // MPC_XQ_RETRY=1: a doubtful pivot met by the quick test is flagged by the quick test itself and re-solved at once on the second stream (round 5; off: on config 3 half of the doubtful candidates only show in k_x2, beyond the quick test's sixteen iterations, so the level pays the LDS engine twice -- 3.55 ms against 3.28)
     int no_xq_early = 0;      // MPC_NO_XQ_EARLY=1: the thread pass of the quick test always behind the theta stage, -1: always beside it (A/B)
     long long prev_regions = 0, xq_early_regions = 0;   // MPC_XQ_EARLY_REGIONS = r > 0: the pass runs beside the theta stage only when the level before found fewer than r regions (0: always)
@@ -431,7 +432,7 @@ struct mpc_handle {
     } g;
     hipEvent_t ev_hi = nullptr;   // completion of the head_i copy of an asynchronous slot fetch
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
-    hipEvent_t kev[12] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // around k_theta2 / the main k_x2 launch / k_region2 / k_kkt_thread / k_xq / k_xq_thread
+    hipEvent_t kev[14] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // around k_theta2 / the main k_x2 launch / k_region2 / k_kkt_thread / k_xq / k_xq_thread
 };
 
 namespace {
@@ -2564,8 +2565,10 @@ static int level_run_impl(mpc_handle *h, int32_t gen_children, int32_t flags, mp
                     HIP_TRY(h, hipEventRecord(h->kev[11], st));
                     xq_thread_timed = true;
                     const unsigned g1 = (unsigned)std::min<long long>(n_dict, (long long)h->n_cu * h->x1_wpc);
+                    HIP_TRY(h, hipEventRecord(h->kev[12], st));
                     if (h->fast_x & 1) hipLaunchKernelGGL((k_x1<2>), dim3(g1), dim3(64), 0, st, pf, pl.x1_list, pl.x1_n, ctr, dc, nxc, pl.plan_slot, pl.plan_step);
                     else hipLaunchKernelGGL((k_x1<1>), dim3(g1), dim3(64), 0, st, pf, pl.x1_list, pl.x1_n, ctr, dc, nxc, pl.plan_slot, pl.plan_step);
+                    HIP_TRY(h, hipEventRecord(h->kev[13], st));
                     HIP_TRY(h, hipGetLastError());
                     // what is left: the register simplex, list lengths on the device
                     DictCache dr = dc;
@@ -2736,6 +2739,8 @@ static int level_run_impl(mpc_handle *h, int32_t gen_children, int32_t flags, mp
         HIP_TRY(h, hipEventElapsedTime(&ms[2], h->ev[2], h->ev[3]));
         for (int i = 0; i < 5; ++i) if (kernel_timed[i]) HIP_TRY(h, hipEventElapsedTime(&kms[i], h->kev[2 * i], h->kev[2 * i + 1]));
         if (xq_thread_timed) { HIP_TRY(h, hipEventElapsedTime(&h->ms_xq_thread, h->kev[10], h->kev[11])); h->n_xq_thread = host_ctr.xq_thread; }
+        h->ms_x1 = 0;
+        if (x1_ran) HIP_TRY(h, hipEventElapsedTime(&h->ms_x1, h->kev[12], h->kev[13]));
         h->n_x1 = x1_ran ? (long long)(h->tot_host + 16 + (int)(sizeof(LevelCounters) / 4))[12] : 0;   // dictionaries k_x1 wrote
         if (h->debug_cycles && x1_ran) { const int32_t *ch = h->tot_host + 16 + (int)(sizeof(LevelCounters) / 4); std::fprintf(stderr, "[mpc] k=%d one-step plans: %d streamed by k_x1, %d + %d + %d left to k_x2 (plan pass %.3f ms)\n", k, ch[12], ch[13], ch[14], ch[15], h->ms_xq_thread); }
         if (xq_early_ran) { n_xq_items += host_ctr.xq_thread; h->n_needx += host_ctr.xq_thread; }   // what the pass beside the theta stage decided never reached the partition's count
@@ -2776,6 +2781,7 @@ static int level_run_impl(mpc_handle *h, int32_t gen_children, int32_t flags, mp
         stats->n_xq_items = n_xq_items; stats->xq_pivots = (int64_t)host_ctr.xq_pivots;
         stats->xq_record_ints = dict_ints_head(h->Pf.n_d0r, h->fast_x >= 2 ? 32 : 16) - 1; stats->xq_record_rows = h->Pf.n_d0r; stats->xq_record_cols = h->Pf.n_d0c + 1;
         stats->n_xq_thread = h->n_xq_thread; stats->ms_xq_thread = h->ms_xq_thread; stats->xq_thread_beside_theta = xq_early_ran ? 1.0f : 0.0f;
+        stats->n_x1 = h->n_x1; stats->ms_x1 = h->ms_x1; stats->ms_x_plan = x1_ran ? h->ms_xq_thread : 0.0f;
         stats->n_region_rows = h->n_erows;
         stats->n_opt = h->n_opt;
         // bytes of one dictionary record that are actually moved: the used columns (value + D0 columns) and the integer part

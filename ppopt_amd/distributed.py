@@ -88,6 +88,7 @@ class HipLevelEngine:
                 'dict_write_bytes': int(st.dict_write_bytes), 'ms_kkt': float(st.ms_kkt), 'ms_xq': float(st.ms_xq),
                 'n_xq_items': int(st.n_xq_items), 'xq_pivots': int(st.xq_pivots),
                 'n_xq_thread': int(st.n_xq_thread), 'ms_xq_thread': float(st.ms_xq_thread), 'xq_thread_beside_theta': bool(st.xq_thread_beside_theta),
+                'n_x1': int(st.n_x1), 'ms_x1': float(st.ms_x1), 'ms_x_plan': float(st.ms_x_plan),
                 'xq_record': [int(st.xq_record_ints), int(st.xq_record_rows), int(st.xq_record_cols)]}
 
     def _fresh(self, shape, dtype) -> torch.Tensor:
@@ -515,7 +516,7 @@ def _solve_distributed(engine, program=None, group=None, profile: Optional[List[
                             'ms_children': st.get('ms_children', 0.0), 'local_candidates': st['n'], 'sharded': sharded,
                             **{key: st.get(key, 0) for key in ('ms_theta', 'ms_x', 'ms_region2', 'n_x_items', 'n_opt', 'n_theta_items',
                                                                'dict_read_bytes', 'dict_write_bytes', 'ms_kkt', 'ms_xq', 'n_xq_items',
-                                                               'xq_pivots', 'xq_record', 'n_xq_thread', 'ms_xq_thread', 'xq_thread_beside_theta')}})
+                                                               'xq_pivots', 'xq_record', 'n_xq_thread', 'ms_xq_thread', 'xq_thread_beside_theta', 'n_x1', 'ms_x1', 'ms_x_plan')}})
         if not gen_children or total['n_children'] == 0:
             break
         engine.advance()

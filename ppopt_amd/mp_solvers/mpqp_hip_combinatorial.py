@@ -233,6 +233,7 @@ def _level_profile(depth, st, ms_wall):
             'dict_read_bytes': int(st.dict_read_bytes), 'dict_write_bytes': int(st.dict_write_bytes),
             'ms_kkt': float(st.ms_kkt), 'ms_xq': float(st.ms_xq), 'n_xq_items': int(st.n_xq_items), 'xq_pivots': int(st.xq_pivots),
             'n_xq_thread': int(st.n_xq_thread), 'ms_xq_thread': float(st.ms_xq_thread), 'xq_thread_beside_theta': bool(st.xq_thread_beside_theta),
+            'n_x1': int(st.n_x1), 'ms_x1': float(st.ms_x1), 'ms_x_plan': float(st.ms_x_plan),
             'xq_record': [int(st.xq_record_ints), int(st.xq_record_rows), int(st.xq_record_cols)],
             'ms_wall': ms_wall}
 
