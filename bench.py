@@ -161,6 +161,7 @@ def main():
     ap.add_argument('--locate', type=int, default=100000, help='points of the point-location extra (0 = skip)')
     ap.add_argument('--mi', type=int, default=1, help='mixed-integer enumeration extra on a synthetic mpMIQP (0 = skip)')
     ap.add_argument('--complete', type=int, default=1, help='complete solution of the workload by the connected-graph traversal, as an extra (0 = skip)')
+    ap.add_argument('--events-in-value', action='store_true', help='one timed region only, with the HIP-event records of the per-kernel accounting inside it (the protocol of rounds 1-4)')
     ap.add_argument('--dist-single', action='store_true', help='run the multi-GPU driver with a process group of one rank (self-test)')
     ap.add_argument('--sweep', action='store_true', help='shape sweep over the target class (n_x <= 20, n_theta <= 10): one JSON line with a row per shape (tools/shape_sweep.py); not the headline')
     ap.add_argument('--deep', type=int, default=0, help='also time the six-level variant of c4 on one GPU (the scaling workload the multi-GPU runs report under extra)')
@@ -223,7 +224,7 @@ def main():
 
     # warm-up solves are held together and released together, so that the allocators (the engine's device buffers, the
     # pooled page-locked result arrays) reach their steady state before the timed region
-    warm = [step([]) for _ in range(args.warmup)]
+    warm = [step([] if (args.events_in_value or i % 2) else None) for i in range(args.warmup)]
     del warm
     # everything allocated so far (torch, the program, the engine) is long-lived: keep the cyclic collector from walking
     # it again and again while the timed steps create their region objects
@@ -236,22 +237,39 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    profiles = []
-    fence()
-    t0 = time.perf_counter()
-    step_ms = []
-    for _ in range(args.steps):
-        prof = []
-        ts = time.perf_counter()
-        sol = step(prof)
-        step_ms.append(1e3 * (time.perf_counter() - ts))
-        profiles.append(prof)
-    fence()
-    elapsed = time.perf_counter() - t0
-    if distributed:
-        t = torch.tensor([elapsed], dtype=torch.float64, device='cuda')
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    # Two timed regions of K steps each over the same program.  The FIRST is the one `value` / `ms_per_step` come from: the solve as a user
+    # runs it (no profile asked for, so the library records no HIP events inside its levels: mpc_set_timing).  The SECOND repeats the K
+    # steps with a profile per step: the library then brackets every stage and heavy kernel of a level with HIP events on the stream the
+    # kernel is launched on (about fourteen records per large level), and the per-kernel durations of `roofline` / `kernel_ms_per_step`
+    # are those, live, of this run; that region's own rate is reported beside the first (`ms_per_step_with_kernel_events`): the event
+    # records cost 0.1-0.2 ms per solve (markers the queue stops at), which is why they are not in the first.  --events-in-value keeps
+    # them in the first region as rounds 1-4 did.
+    def timed_region(with_profile):
+        profs, ms_list, last = [], [], None
+        fence()
+        t0_ = time.perf_counter()
+        for _ in range(args.steps):
+            pr = [] if with_profile else None
+            ts = time.perf_counter()
+            last = step(pr)
+            ms_list.append(1e3 * (time.perf_counter() - ts))
+            profs.append(pr)
+        fence()
+        el = time.perf_counter() - t0_
+        if distributed:
+            t = torch.tensor([el], dtype=torch.float64, device='cuda')
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = float(t.item())
+        return el, profs, ms_list, last
+
+    if args.events_in_value:
+        elapsed, profiles, step_ms, sol = timed_region(True)
+        elapsed_events = elapsed
+    else:
+        elapsed, _, step_ms, sol = timed_region(False)
+        del sol
+        step(None)      # (hand-over: the region objects of the last untimed-events step are released outside the next region)
+        elapsed_events, profiles, _, sol = timed_region(True)
 
     # ---- accounting (identical on every rank; rank 0 reports) ----------------------------------------------
     prof = profiles[-1]
@@ -383,6 +401,12 @@ def main():
         'steps': args.steps,
         'warmup': args.warmup,
         'ms_per_step': 1e3 * elapsed / steps,
+        'ms_per_step_with_kernel_events': 1e3 * elapsed_events / steps,
+        'kernel_timing': ('HIP events inside the one timed region (--events-in-value)' if args.events_in_value else
+                          'value / ms_per_step: K timed steps of the solve as a user runs it (no profile: the library records no HIP events inside '
+                          'its levels); per-kernel durations (roofline.dominant_kernel, roofline.kernels, kernel_ms_per_step): a second timed region '
+                          'of the same K steps with a profile per step = HIP events around every stage and heavy kernel on the stream it is '
+                          'launched on; that region runs at ms_per_step_with_kernel_events'),
         'higher_is_better': True,
         'scaling': 'strong',
         'vs_baseline': None,

@@ -237,6 +237,11 @@ int mpc_level_batch_wait(void *token, mpc_level_stats *stats, int32_t *n_batched
  * candidate is demoted -- and the caller repeats the solve with on = 0, where every optimal candidate is known at launch.
  * (Reference: full_process never loses a region, mp_solvers/mpqp_parrallel_combinatorial.py:52-61.) */
 int mpc_set_region_overlap(mpc_handle *h, int32_t on);
+/* mpc_set_timing(h, 0): the levels of this handle run WITHOUT the HIP-event records around their stages and heavy kernels -- about
+ * fourteen records per large level, four per small one, each a marker the queue stops at (measured, one MI355X: 0.16 ms of a 4.9 ms
+ * config-4 solve, 0.11 of a 1.1 ms config-2 solve).  The ms_* fields of mpc_level_stats are then 0, every count is as before.  The host
+ * layer switches the records on for the solves that ask for a profile.  Default: on (MPC_NO_KEV=1 in the environment: off). */
+int mpc_set_timing(mpc_handle *h, int32_t on);
 int mpc_level_start(mpc_handle *h, int32_t gen_children, int32_t flags);
 int mpc_level_stream_info(mpc_handle *h, double **head_d, int32_t **head_i, double **erows, int64_t *n_slots, int64_t *cap_rows,
                           int32_t *chunk, int32_t *n_chunks);

@@ -111,6 +111,7 @@ def load():
         'mpc_last_error': (ctypes.c_char_p, [H]),
         'mpc_mask_words': (ctypes.c_int32, [H]),
         'mpc_set_region_overlap': (ctypes.c_int, [H, ctypes.c_int32]),
+        'mpc_set_timing': (ctypes.c_int, [H, ctypes.c_int32]),
         'mpc_program_block': (ctypes.c_int, [H, ctypes.c_int32, _dp, ctypes.c_int64, _lp]),
         'mpc_region_doubles': (ctypes.c_int64, [H]),
         'mpc_region_ints': (ctypes.c_int64, [H]),
@@ -196,7 +197,7 @@ def load():
 
 
 EXPORTED_SYMBOLS = ['mpc_device_count', 'mpc_version', 'mpc_last_global_error', 'mpc_create', 'mpc_destroy',
-                    'mpc_last_error', 'mpc_mask_words', 'mpc_set_region_overlap', 'mpc_program_block', 'mpc_region_doubles', 'mpc_region_ints', 'mpc_lds_bytes', 'mpc_stream',
+                    'mpc_last_error', 'mpc_mask_words', 'mpc_set_region_overlap', 'mpc_set_timing', 'mpc_program_block', 'mpc_region_doubles', 'mpc_region_ints', 'mpc_lds_bytes', 'mpc_stream',
                     'mpc_frontier_root', 'mpc_frontier_set', 'mpc_frontier_set_device', 'mpc_frontier_info',
                     'mpc_frontier_get', 'mpc_pruned_clear', 'mpc_pruned_add', 'mpc_pruned_add_device',
                     'mpc_pruned_count', 'mpc_pruned_get', 'mpc_level_run', 'mpc_level_run_ex', 'mpc_level_run_batch', 'mpc_frontier_advance_batch', 'mpc_level_memory_gb', 'mpc_trim', 'mpc_level_batch_start', 'mpc_level_batch_wait', 'mpc_level_regions_slots_nowait', 'mpc_level_batch_fetch', 'mpc_level_status', 'mpc_level_start', 'mpc_level_stream_info', 'mpc_level_chunk_wait', 'mpc_level_wait', 'mpc_level_stream_fixup', 'mpc_base_result', 'mpc_solve_start', 'mpc_solve_level', 'mpc_solve_chunk_wait', 'mpc_solve_level_wait', 'mpc_solve_wait', 'mpc_level_regions', 'mpc_compact_strides',
@@ -312,6 +313,14 @@ class Engine:
 
     def set_region_overlap(self, on: bool):
         self._check(self._L.mpc_set_region_overlap(self._h, 1 if on else 0), 'mpc_set_region_overlap')
+
+    def set_timing(self, on: bool):
+        """HIP-event records around the stages and heavy kernels of this handle's levels (mpc_set_timing): the drivers switch them on
+        for the solves that ask for a profile; without them the ms_* fields of the level statistics are 0."""
+        on = bool(on)
+        if getattr(self, '_timing', None) is not on:
+            self._check(self._L.mpc_set_timing(self._h, 1 if on else 0), 'mpc_set_timing')
+            self._timing = on
 
     def close(self):
         if getattr(self, '_twin', None) is not None:

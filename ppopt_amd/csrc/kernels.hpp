@@ -1047,6 +1047,76 @@ MPC_GLOBAL void k_pruned_append(const int32_t *__restrict__ cands, long long n, 
     for (int w = 0; w < MW; ++w) out[MW * (size_t)pos + w] = p[w];
 }
 
+// ---- small levels, round 5: the end of a level in ONE single-block launch instead of five -------------------------------------------
+// k_small_end = k_histogram + k_pruned_append + the two counts the host needs before it accepts the level (candidates the (x,theta)
+// stage left doubtful: ST_RETRY -> *n_retry; optimal candidates that missed the region launch: ST_OPT_PENDING -> *n_late); with pub_dst
+// (a level without children) also k_publish_words2.  A level of <= 4096 candidates: four trips of 1024 threads.
+__device__ __forceinline__ unsigned int load_word_agent(const unsigned int *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+template <int MW>
+MPC_GLOBAL void MPC_LB(1024) k_small_end(const int32_t *__restrict__ cands, int n, int k, const uint8_t *__restrict__ status,
+                                         unsigned long long *__restrict__ pruned_out, LevelCounters *ctr, int keep_lowdim,
+                                         int32_t *__restrict__ n_retry, int32_t *__restrict__ n_late,
+                                         const unsigned int *pub_src2, int pub_n2, unsigned int *pub_dst) {
+    __shared__ unsigned int hist[16];
+    const int lane = threadIdx.x & 63;
+    if (threadIdx.x < 16) hist[threadIdx.x] = 0;
+    __syncthreads();
+    for (int start = 0; start < n; start += 1024) {
+        const int i = start + (int)threadIdx.x;
+        const int st = i < n ? status[i] : 15;
+#pragma unroll
+        for (int b = 0; b < 12; ++b) {
+            const unsigned long long m = __ballot(st == b);
+            if (lane == 0 && m) atomicAdd(&hist[b], (unsigned int)__popcll(m));
+        }
+        const bool cut = st == ST_INFEASIBLE || (st == ST_OPT_NO_REGION && !keep_lowdim);
+        const unsigned long long mc = __ballot(cut);
+        if (mc) {
+            unsigned int base = 0;
+            if (lane == 0) base = atomicAdd(&ctr->n_pruned_new, (unsigned int)__popcll(mc));
+            base = (unsigned int)__builtin_amdgcn_readfirstlane((int)base);
+            if (cut) {
+                unsigned long long pm[MW];
+                set_mask<MW>(cands + (size_t)i * k, k, pm);
+                const size_t pos = base + (unsigned int)__popcll(mc & ((1ull << lane) - 1ull));
+#pragma unroll
+                for (int w = 0; w < MW; ++w) pruned_out[MW * pos + w] = pm[w];
+            }
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < 8) {     // (k_histogram's bins: status & 7)
+        const unsigned int v = hist[threadIdx.x] + (threadIdx.x < 4 ? hist[threadIdx.x + 8] : 0u);
+        if (v) atomicAdd(&ctr->status[threadIdx.x], (unsigned long long)v);
+    }
+    if (threadIdx.x == 0) { *n_retry = (int32_t)hist[ST_RETRY]; *n_late = (int32_t)hist[ST_OPT_PENDING]; }
+    if (pub_dst) {
+        __threadfence();
+        __syncthreads();
+        const unsigned int *src1 = reinterpret_cast<const unsigned int *>(ctr);
+        const int n1 = (int)(sizeof(LevelCounters) / 4);
+        for (int i = threadIdx.x; i < n1 + pub_n2; i += 1024) pub_dst[i] = load_word_agent(i < n1 ? src1 + i : pub_src2 + (i - n1));
+    }
+}
+// k_scan_small + k_publish_words2 (a level with children: the scan's total is the last count the host waits for)
+MPC_GLOBAL void MPC_LB(1024) k_scan_publish(const int32_t *__restrict__ in, int32_t *__restrict__ out, int n, int32_t *total,
+                                            const unsigned int *src1, int n1, const unsigned int *src2, int n2, unsigned int *dst) {
+    __shared__ int tot;
+    int carry = 0;
+    for (int start = 0; start < n; start += SCAN_BLOCK) {
+        const int i = start + (int)threadIdx.x;
+        const int ex = block_exclusive_scan_1024(i < n ? in[i] : 0, &tot);
+        __syncthreads();
+        if (i < n) out[i] = ex + carry;
+        carry += tot;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *total = carry;
+    __threadfence();
+    __syncthreads();
+    for (int i = threadIdx.x; i < n1 + n2; i += 1024) dst[i] = load_word_agent(i < n1 ? src1 + i : src2 + (i - n1));
+}
+
 // graph mode (MPC_LEVEL_GRAPH): the (x,theta) feasibility question is not posed -- "feasibility open" becomes "no region"
 MPC_GLOBAL void k_close_open(const int32_t *__restrict__ list, int n_list, uint8_t *__restrict__ status) {
     const int w = blockIdx.x * blockDim.x + threadIdx.x;

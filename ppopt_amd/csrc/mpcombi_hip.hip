@@ -298,9 +298,13 @@ struct mpc_handle {
     bool no_spec_tail = false;       // MPC_NO_SPEC_TAIL=1: a large level waits for the second partition and for the region kernel's give-up count before
                                      // it queues its end (round-3 behaviour); default: the end is queued behind the partition, one synchronisation
     bool test_small_fallback = false; // MPC_TEST_SMALL_FALLBACK=1 (tests): every level run without host round trips reports "repeat on the classic path"
+    bool timing = true;              // mpc_set_timing: HIP-event records around the stages and kernels of a level (off: their times in the stats are 0)
+    bool no_kev = false;             // MPC_NO_KEV=1: never
     bool no_smallpath = false;       // MPC_NO_SMALLPATH=1: levels of any size take the classic path with its host round trips (A/B)
     long long smallpath_max = 4096;  // MPC_SMALLPATH_MAX: largest level (candidates) that runs without host round trips (measured: config 4 is
                                      // fastest with 1,024-4,096 -- a level of 15,691 candidates prefers the classic path, which streams its records)
+    bool no_small_fuse = false;      // MPC_NO_SMALL_FUSE=1: the small path with its round-4 launches (doubtful candidates re-solved in place; A/B, tests)
+    long long n_smallpath_doubtful = 0;   // small levels repeated because the fused form met a doubtful candidate
     long long n_smallpath = 0, n_smallpath_fallback = 0;   // levels run that way / of which repeated on the classic path
     DevBuf dcnt;                     // device-resident list lengths of such a level
     long long roverlap_min = 2048, roverlap_long = 50000;   // MPC_ROVERLAP_MIN / MPC_ROVERLAP_LONG (items of the (x,theta) stage)
@@ -634,6 +638,8 @@ static int create_fill(const mpc_problem *p, int32_t device, void *stream, mpc_h
     { const char *ev = std::getenv("MPC_NO_ROVERLAP"); h->no_roverlap = ev && ev[0] == '1'; }
     { const char *ev = std::getenv("MPC_TEST_LATE"); h->test_late = ev ? std::atoi(ev) : 0; }
     { const char *ev = std::getenv("MPC_TEST_SPARE"); h->test_spare = ev ? std::atoi(ev) : 0; }
+    { const char *ev = std::getenv("MPC_NO_KEV"); h->no_kev = ev && ev[0] == '1'; h->timing = !h->no_kev; }
+    { const char *ev = std::getenv("MPC_NO_SMALL_FUSE"); h->no_small_fuse = ev && ev[0] == '1'; }
     { const char *ev = std::getenv("MPC_NO_SMALLPATH"); h->no_smallpath = ev && ev[0] == '1'; }
     { const char *ev = std::getenv("MPC_NO_LEAN"); h->no_lean = ev && ev[0] == '1'; }
     { const char *ev = std::getenv("MPC_NO_SPEC_TAIL"); h->no_spec_tail = ev && ev[0] == '1'; }
@@ -1150,6 +1156,7 @@ int mpc_program_block(mpc_handle *h, int32_t which, double *out, int64_t cap, in
     return MPC_OK;
 }
 int mpc_set_region_overlap(mpc_handle *h, int32_t on) { if (!h) return MPC_ERR_INVALID; h->no_roverlap = !on; return MPC_OK; }
+int mpc_set_timing(mpc_handle *h, int32_t on) { if (!h) return MPC_ERR_INVALID; h->timing = on && !h->no_kev; return MPC_OK; }
 int64_t mpc_region_doubles(const mpc_handle *h) { return h ? h->rec_d : 0; }
 int64_t mpc_region_ints(const mpc_handle *h) { return h ? h->rec_i : 0; }
 int32_t mpc_lds_bytes(const mpc_handle *h, int32_t which) { return !h ? 0 : (which == 0 ? h->lds_v : h->lds_r); }
@@ -1376,17 +1383,17 @@ static bool small_path_ok(const mpc_handle *h, long long n, int k, int32_t flags
 }
 
 // MPC_DEBUG_SMALL=1: at exit, how many no-round-trip levels had doubtful candidates (re-solved in place by the LDS engine) in their two verdict stages
-static std::atomic<long long> g_small_levels{0}, g_small_retry_theta{0}, g_small_retry_x{0}, g_small_retry_cands{0};
+static std::atomic<long long> g_small_levels{0}, g_small_retry_theta{0}, g_small_retry_x{0}, g_small_retry_cands{0}, g_small_repeats{0}, g_small_repeats_doubtful{0};
 static void small_debug_note(const int32_t *cnt_host) {
     static const bool on = [] {
         const char *ev = std::getenv("MPC_DEBUG_SMALL");
         if (!(ev && ev[0] == '1')) return false;
-        std::atexit([] { std::fprintf(stderr, "[mpc] small levels %lld: with doubtful candidates after the theta stage %lld, after the (x,theta) stage %lld (candidates %lld)\n",
-                                      g_small_levels.load(), g_small_retry_theta.load(), g_small_retry_x.load(), g_small_retry_cands.load()); });
+        std::atexit([] { std::fprintf(stderr, "[mpc] small levels %lld: with doubtful candidates after the theta stage %lld, after the (x,theta) stage %lld (candidates %lld); repeated on the classic path %lld (because of doubtful candidates %lld)\n",
+                                      g_small_levels.load(), g_small_retry_theta.load(), g_small_retry_x.load(), g_small_retry_cands.load(), g_small_repeats.load(), g_small_repeats_doubtful.load()); });
         return true;
     }();
     if (!on) return;
-    g_small_levels++; g_small_retry_theta += cnt_host[12] > 0; g_small_retry_x += cnt_host[24] > 0; g_small_retry_cands += cnt_host[12] + cnt_host[24];
+    g_small_levels++; g_small_retry_theta += (cnt_host[12] + cnt_host[4]) > 0; g_small_retry_x += cnt_host[24] > 0; g_small_retry_cands += cnt_host[12] + cnt_host[4] + cnt_host[24];
 }
 
 static int level_run_small(mpc_handle *h, int32_t gen_children, int32_t flags, mpc_level_stats *stats, bool *fallback) {
@@ -1432,7 +1439,7 @@ static int level_run_small(mpc_handle *h, int32_t gen_children, int32_t flags, m
     h->used_region2 = false; h->n_rretry = 0; h->n_erows = 0;
     h->fd = h->n_x * h->n_t + h->n_x + k * h->n_t + k;
     h->fi = 8 + k + h->n_tc + k + 2 * (h->n_c - k);
-    HIP_TRY(h, hipEventRecord(h->ev[0], st));
+    if (h->timing) HIP_TRY(h, hipEventRecord(h->ev[0], st));
     // ---- KKT solves + box screen, theta stage ----------------------------------------------------------------------------------
     const uint8_t *kkc = nullptr;
     const double *kkl = nullptr;
@@ -1468,13 +1475,21 @@ static int level_run_small(mpc_handle *h, int32_t gen_children, int32_t flags, m
     }
     // the doubtful candidates of the theta stage are re-solved in place by the LDS engine first (the classic path does this on a
     // side stream under the (x,theta) stage), so that the partition below already knows every optimal candidate they yield
-    hipLaunchKernelGGL(k_partition_small, dim3(1), dim3(1024), 0, st, h->status.as<uint8_t>(), (int)n, spec_of({{ST_RETRY, 0}}), h->part_lists.as<int32_t>(), (long long)n, dcnt + 12);
-    hipLaunchKernelGGL(k_verdict, dim3((unsigned)std::min<long long>(n, 128)), dim3(64), h->lds_v, st, h->Pv, fr, n, k, stp, ctr, part_list(0), dcnt + 12);
-    // open parameter set: "optimal" only if the reference's max-t LP is bounded (k_recession), decided before the region launch below
-    if (h->theta_open) hipLaunchKernelGGL(k_recession, dim3((unsigned)std::min<long long>(n, 256)), dim3(64), h->lds_v, st, h->Pv, fr, n, k, stp);
-    // classes after the theta stage: [1] feasible, [2] optimal, [3] feasibility open
+    // Round 5 (`fused`): doubtful candidates are rare (numerically doubtful pivots of the register simplex), so the level does not spend
+    // three launches on them at each of its two verdict stages: ONE partition lists them as class 0 beside the classes below, the level
+    // goes on without them, and if there was one (counted in [4] / [24]) the host repeats the level on the classic path -- as it does for
+    // the other rare cases.  The end of the level is one launch (k_small_end) instead of five, the scan carries the publish.
+    const bool fused = !h->theta_open && !h->no_small_fuse;
+    if (!fused) {
+        hipLaunchKernelGGL(k_partition_small, dim3(1), dim3(1024), 0, st, h->status.as<uint8_t>(), (int)n, spec_of({{ST_RETRY, 0}}), h->part_lists.as<int32_t>(), (long long)n, dcnt + 12);
+        hipLaunchKernelGGL(k_verdict, dim3((unsigned)std::min<long long>(n, 128)), dim3(64), h->lds_v, st, h->Pv, fr, n, k, stp, ctr, part_list(0), dcnt + 12);
+        // open parameter set: "optimal" only if the reference's max-t LP is bounded (k_recession), decided before the region launch below
+        if (h->theta_open) hipLaunchKernelGGL(k_recession, dim3((unsigned)std::min<long long>(n, 256)), dim3(64), h->lds_v, st, h->Pv, fr, n, k, stp);
+    }
+    // classes after the theta stage: [1] feasible, [2] optimal, [3] feasibility open ([0] doubtful, fused form only)
     hipLaunchKernelGGL(k_partition_small, dim3(1), dim3(1024), 0, st, h->status.as<uint8_t>(), (int)n,
-                       spec_of({{ST_FEASIBLE, 1}, {ST_OPT_PENDING, 2}, {ST_NEEDX, 3}, {ST_NEEDX_SING, 3}}), h->part_lists.as<int32_t>(), (long long)n, dcnt + 4);
+                       fused ? spec_of({{ST_RETRY, 0}, {ST_FEASIBLE, 1}, {ST_OPT_PENDING, 2}, {ST_NEEDX, 3}, {ST_NEEDX_SING, 3}})
+                             : spec_of({{ST_FEASIBLE, 1}, {ST_OPT_PENDING, 2}, {ST_NEEDX, 3}, {ST_NEEDX_SING, 3}}), h->part_lists.as<int32_t>(), (long long)n, dcnt + 4);
     HIP_TRY(h, hipGetLastError());
     // ---- region stage: one slot per optimal candidate, buffers sized by the bound.  It needs the theta stage's verdicts only; a
     // candidate that turns out optimal only later -- a doubtful one of the (x,theta) stage, re-solved -- sends the level to the classic
@@ -1512,7 +1527,7 @@ static int level_run_small(mpc_handle *h, int32_t gen_children, int32_t flags, m
         HIP_TRY(h, hipGetLastError());
         h->used_region2 = true;
     }
-    HIP_TRY(h, hipMemsetAsync(&ctr->work_retry, 0, sizeof(unsigned int), st));
+    if (!fused) HIP_TRY(h, hipMemsetAsync(&ctr->work_retry, 0, sizeof(unsigned int), st));
     // ---- (x,theta) stage with the dictionary cache ---------------------------------------------------------------------------------
     const int nxc = h->fast_x >= 2 ? 32 : 16;
     h->dict_stride_d = (long long)nxc * h->Pf.n_d0r;
@@ -1563,21 +1578,35 @@ static int level_run_small(mpc_handle *h, int32_t gen_children, int32_t flags, m
         }
     }
     HIP_TRY(h, hipGetLastError());
+    const int keep_lowdim = (flags & MPC_LEVEL_KEEP_LOWDIM) ? 1 : 0;
+    static_assert(sizeof(LevelCounters) + 64 + 32 * 4 <= 4096, "LevelCounters + list lengths must fit the pinned block");
+    unsigned int *pub_dst = reinterpret_cast<unsigned int *>(h->tot_dev + 16);
+    if (fused) {
+        // doubtful candidates of the (x,theta) stage -> [24], optimal ones that missed the region launch -> [17], status histogram,
+        // pruned masks (and, on a level without children, the publish): one launch
+        if (h->timing) { HIP_TRY(h, hipEventRecord(h->ev[1], st)); HIP_TRY(h, hipEventRecord(h->ev[2], st)); }
+        unsigned long long *pout = h->pruned.as<unsigned long long>() + (size_t)h->n_pruned * h->mw;
+        if (h->mw == 2) hipLaunchKernelGGL(k_small_end<2>, dim3(1), dim3(1024), 0, st, fr, (int)n, k, stp, pout, ctr, keep_lowdim, dcnt + 24, dcnt + 17,
+                                           reinterpret_cast<const unsigned int *>(dcnt), 32, gen_children ? (unsigned int *)nullptr : pub_dst);
+        else hipLaunchKernelGGL(k_small_end<4>, dim3(1), dim3(1024), 0, st, fr, (int)n, k, stp, pout, ctr, keep_lowdim, dcnt + 24, dcnt + 17,
+                                reinterpret_cast<const unsigned int *>(dcnt), 32, gen_children ? (unsigned int *)nullptr : pub_dst);
+        HIP_TRY(h, hipGetLastError());
+    } else {
     // doubtful candidates of the (x,theta) stage (rare): re-solved in place as well
     hipLaunchKernelGGL(k_partition_small, dim3(1), dim3(1024), 0, st, h->status.as<uint8_t>(), (int)n, spec_of({{ST_RETRY, 0}}), h->part_lists.as<int32_t>(), (long long)n, dcnt + 24);
     hipLaunchKernelGGL(k_verdict, dim3((unsigned)std::min<long long>(n, 128)), dim3(64), h->lds_v, st, h->Pv, fr, n, k, stp, ctr, part_list(0), dcnt + 24);
     HIP_TRY(h, hipGetLastError());
-    HIP_TRY(h, hipEventRecord(h->ev[1], st));
+    if (h->timing) HIP_TRY(h, hipEventRecord(h->ev[1], st));
     // a candidate that is still "optimal, region pending" now was not in the region launch: counted in [17]
     hipLaunchKernelGGL(k_partition_small, dim3(1), dim3(1024), 0, st, h->status.as<uint8_t>(), (int)n, spec_of({{ST_OPT_PENDING, 1}}), h->part_lists.as<int32_t>(), (long long)n, dcnt + 16);
     HIP_TRY(h, hipGetLastError());
-    HIP_TRY(h, hipEventRecord(h->ev[2], st));
+    if (h->timing) HIP_TRY(h, hipEventRecord(h->ev[2], st));
     // ---- pruned masks of this level + children -------------------------------------------------------------------------------------
-    const int keep_lowdim = (flags & MPC_LEVEL_KEEP_LOWDIM) ? 1 : 0;
     if (h->mw == 2) hipLaunchKernelGGL(k_pruned_append<2>, dim3(blocks256), dim3(256), 0, st, h->frontier.as<int32_t>(), n, k, h->status.as<uint8_t>(),
                                        h->pruned.as<unsigned long long>() + (size_t)h->n_pruned * h->mw, ctr, keep_lowdim);
     else hipLaunchKernelGGL(k_pruned_append<4>, dim3(blocks256), dim3(256), 0, st, h->frontier.as<int32_t>(), n, k, h->status.as<uint8_t>(),
                             h->pruned.as<unsigned long long>() + (size_t)h->n_pruned * h->mw, ctr, keep_lowdim);
+    }
     if (gen_children) {
         HIP_TRY(h, h->childmask.ensure(nn * h->mw * sizeof(uint64_t), st));
         HIP_TRY(h, h->count.ensure(nn * sizeof(int32_t), st));
@@ -1589,35 +1618,37 @@ static int level_run_small(mpc_handle *h, int32_t gen_children, int32_t flags, m
                                            h->pruned.as<unsigned long long>(), (long long)h->n_pruned, h->childmask.as<unsigned long long>(), h->count.as<int32_t>(), keep_lowdim);
         else hipLaunchKernelGGL(k_children_count<4>, dim3((unsigned)n), dim3(64), 0, st, h->Pv, h->frontier.as<int32_t>(), n, k, h->status.as<uint8_t>(),
                                 h->pruned.as<unsigned long long>(), (long long)h->n_pruned, h->childmask.as<unsigned long long>(), h->count.as<int32_t>(), keep_lowdim);
-        hipLaunchKernelGGL(k_scan_small, dim3(1), dim3(SCAN_BLOCK), 0, st, h->count.as<int32_t>(), h->offset.as<int32_t>(), (int)n, dcnt + 20);
+        if (fused) hipLaunchKernelGGL(k_scan_publish, dim3(1), dim3(SCAN_BLOCK), 0, st, h->count.as<int32_t>(), h->offset.as<int32_t>(), (int)n, dcnt + 20,
+                                      reinterpret_cast<const unsigned int *>(ctr), (int)(sizeof(LevelCounters) / 4), reinterpret_cast<const unsigned int *>(dcnt), 32, pub_dst);
+        else hipLaunchKernelGGL(k_scan_small, dim3(1), dim3(SCAN_BLOCK), 0, st, h->count.as<int32_t>(), h->offset.as<int32_t>(), (int)n, dcnt + 20);
         hipLaunchKernelGGL(k_children_write, dim3((unsigned)n), dim3(64), 0, st, h->frontier.as<int32_t>(), n, k, h->mw,
                            h->childmask.as<unsigned long long>(), h->offset.as<int32_t>(), h->children.as<int32_t>(),
                            h->storing ? h->dict_stored[h->dict_cur].as<uint8_t>() : (const uint8_t *)nullptr, h->parent_slot_next.as<int32_t>());
         HIP_TRY(h, hipGetLastError());
     }
-    hipLaunchKernelGGL(k_histogram, dim3(std::min(blocks256, 1024)), dim3(256), 0, st, h->status.as<uint8_t>(), n, ctr);
-    HIP_TRY(h, hipEventRecord(h->ev[3], st));
-    static_assert(sizeof(LevelCounters) + 64 + 32 * 4 <= 4096, "LevelCounters + list lengths must fit the pinned block");
+    if (!fused) hipLaunchKernelGGL(k_histogram, dim3(std::min(blocks256, 1024)), dim3(256), 0, st, h->status.as<uint8_t>(), n, ctr);
+    if (h->timing) HIP_TRY(h, hipEventRecord(h->ev[3], st));
     int32_t *cnt_host = h->tot_host + 16 + (int)(sizeof(LevelCounters) / 4);
-    hipLaunchKernelGGL(k_publish_words2, dim3(1), dim3(128), 0, st, reinterpret_cast<const unsigned int *>(ctr), (int)(sizeof(LevelCounters) / 4),
-                       reinterpret_cast<const unsigned int *>(dcnt), 32, reinterpret_cast<unsigned int *>(h->tot_dev + 16));
+    if (!fused) hipLaunchKernelGGL(k_publish_words2, dim3(1), dim3(128), 0, st, reinterpret_cast<const unsigned int *>(ctr), (int)(sizeof(LevelCounters) / 4),
+                                   reinterpret_cast<const unsigned int *>(dcnt), 32, pub_dst);
     HIP_TRY(h, hipGetLastError());
     HIP_TRY(h, hipStreamSynchronize(st));   // the level's only synchronisation
     LevelCounters host_ctr;
     std::memcpy(&host_ctr, h->tot_host + 16, sizeof(LevelCounters));
     h->n_smallpath++;
     small_debug_note(cnt_host);
-    if (host_ctr.n_rretry > 0 || cnt_host[17] > 0 || h->test_small_fallback) {
+    if (fused && (cnt_host[4] > 0 || cnt_host[24] > 0)) { h->n_smallpath_doubtful++; g_small_repeats_doubtful++; }
+    if (host_ctr.n_rretry > 0 || cnt_host[17] > 0 || h->test_small_fallback || (fused && (cnt_host[4] > 0 || cnt_host[24] > 0))) {
         // a candidate k_region2 gave up on (the LDS-engine region kernel is not part of this path), or one that turned out optimal
         // after the region launch: the level is repeated classically
-        h->n_smallpath_fallback++;
+        h->n_smallpath_fallback++; g_small_repeats++;
         *fallback = true;
         return MPC_OK;
     }
     float ms[3] = {0, 0, 0};
-    HIP_TRY(h, hipEventElapsedTime(&ms[0], h->ev[0], h->ev[1]));
-    HIP_TRY(h, hipEventElapsedTime(&ms[1], h->ev[1], h->ev[2]));
-    HIP_TRY(h, hipEventElapsedTime(&ms[2], h->ev[2], h->ev[3]));
+    if (h->timing) HIP_TRY(h, hipEventElapsedTime(&ms[0], h->ev[0], h->ev[1]));
+    if (h->timing) HIP_TRY(h, hipEventElapsedTime(&ms[1], h->ev[1], h->ev[2]));
+    if (h->timing) HIP_TRY(h, hipEventElapsedTime(&ms[2], h->ev[2], h->ev[3]));
     h->n_opt = cnt_host[6];
     h->n_children = gen_children ? cnt_host[20] : 0;
     h->n_needx = cnt_host[7];
@@ -1901,13 +1932,13 @@ int mpc_level_batch_start(mpc_handle **hs, int32_t n_handles, const int32_t *gen
         mpc_handle *hl = hs[t->members[0].id];     // ids are the caller's positions (batch_level_launch reorders the members)
         t->st = hl->stream;
         const int lead = t->members[0].id;
-        HIP_TRY(hl, hipEventRecord(hl->ev[0], t->st));
+        if (hl->timing) HIP_TRY(hl, hipEventRecord(hl->ev[0], t->st));
         const size_t tab_bytes = t->members.size() * sizeof(BatchMember);
         HIP_TRY(hl, t->tab_dev.ensure(tab_bytes, t->st));
         HIP_TRY(hl, t->tab_host.ensure(tab_bytes));
         hipError_t e = batch_level_launch(t->members.data(), (int)t->members.size(), t->st, t->tab_host.as<BatchMember>(), t->tab_dev.as<BatchMember>());
         if (e != hipSuccess) { (void)hipStreamSynchronize(t->st); return fail(hl, MPC_ERR_HIP, std::string("batch level launch: ") + hipGetErrorString(e)); }   // (what was queued still reads the table)
-        HIP_TRY(hl, hipEventRecord(hl->ev[3], t->st));
+        if (hl->timing) HIP_TRY(hl, hipEventRecord(hl->ev[3], t->st));
         t->alone.insert(t->alone.begin(), -1 - lead);      // first entry < 0: the member whose events bracket the launches
     }
     *token = t.release();
@@ -1925,7 +1956,7 @@ int mpc_level_batch_wait(void *token, mpc_level_stats *stats, int32_t *n_batched
         HIP_TRY(hl, hipSetDevice(hl->device));
         HIP_TRY(hl, hipStreamSynchronize(t->st));   // the level's only synchronisation, for all members
         float ms = 0;
-        HIP_TRY(hl, hipEventElapsedTime(&ms, hl->ev[0], hl->ev[3]));
+        if (hl->timing) HIP_TRY(hl, hipEventElapsedTime(&ms, hl->ev[0], hl->ev[3]));
         for (const BatchMember &m : t->members) {
             bool fallback = false;
             const int rc = batch_finish(t->hs[m.id], t->gen[m.id], m, ms, stats ? stats + m.id : nullptr, &fallback);
@@ -2150,7 +2181,7 @@ static int level_run_impl(mpc_handle *h, int32_t gen_children, int32_t flags, mp
                 { int rcs = prep_flush(); if (rcs) return rcs; }
                 { int rcs = prep_flush_on(rprep, rprep_any, st); if (rcs) return rcs; }
             }
-            HIP_TRY(h, hipEventRecord(h->kev[4], rst));
+            if (h->timing) HIP_TRY(h, hipEventRecord(h->kev[4], rst));
             switch (h->fast_r) {
                 case 0: MPC_LAUNCH_R2(4, 1); break;
                 case 1: MPC_LAUNCH_R2(4, 2); break;
@@ -2160,7 +2191,7 @@ static int level_run_impl(mpc_handle *h, int32_t gen_children, int32_t flags, mp
                 default: MPC_LAUNCH_R2(10, 2); break;
             }
 #undef MPC_LAUNCH_R2
-            HIP_TRY(h, hipEventRecord(h->kev[5], rst));
+            if (h->timing) HIP_TRY(h, hipEventRecord(h->kev[5], rst));
             if (rst != st) { h->r3_dirty = true; h->region_side_stream = true; HIP_TRY(h, hipEventRecord(h->ev_rjoin, rst)); }
             kernel_timed[2] = true;
             HIP_TRY(h, hipGetLastError());
@@ -2208,7 +2239,7 @@ static int level_run_impl(mpc_handle *h, int32_t gen_children, int32_t flags, mp
             }
             hipLaunchKernelGGL(k_histogram, dim3(std::min(blocks256, 1024)), dim3(256), 0, st, h->status.as<uint8_t>(), n, ctr);
             HIP_TRY(h, hipGetLastError());
-            HIP_TRY(h, hipEventRecord(h->ev[3], st));
+            if (h->timing) HIP_TRY(h, hipEventRecord(h->ev[3], st));
             static_assert(sizeof(LevelCounters) % 4 == 0 && sizeof(LevelCounters) + 64 + 32 * 4 <= 4096, "LevelCounters + list lengths must fit the pinned block");
             hipLaunchKernelGGL(k_publish_words2, dim3(1), dim3(128), 0, st, reinterpret_cast<const unsigned int *>(ctr), (int)(sizeof(LevelCounters) / 4),
                                reinterpret_cast<const unsigned int *>(dcnt), 32, reinterpret_cast<unsigned int *>(h->tot_dev + 16));
@@ -2223,7 +2254,7 @@ static int level_run_impl(mpc_handle *h, int32_t gen_children, int32_t flags, mp
             return MPC_OK;
         };
         // verdict
-        HIP_TRY(h, hipEventRecord(h->ev[0], st));
+        if (h->timing) HIP_TRY(h, hipEventRecord(h->ev[0], st));
         if (h->fast && !h->force_v1) {
             const int32_t *fr = h->frontier.as<int32_t>();
             uint8_t *stp = h->status.as<uint8_t>();
@@ -2239,13 +2270,13 @@ static int level_run_impl(mpc_handle *h, int32_t gen_children, int32_t flags, mp
                 kkc = h->kkt_code.as<uint8_t>(); kkl = h->kkt_L.as<double>();
                 const dim3 g((unsigned)blocks256), b(256);
                 const ThetaArgs ta = h->targs;
-                HIP_TRY(h, hipEventRecord(h->kev[6], st));
+                if (h->timing) HIP_TRY(h, hipEventRecord(h->kev[6], st));
 #define MPC_LAUNCH_KKT(K_) case K_: if (h->fast_t >= 4) hipLaunchKernelGGL((k_kkt_thread<K_, 10>), g, b, 0, st, pf, fr, n, h->kkt_code.as<uint8_t>(), h->kkt_L.as<double>(), stp, ta, ctr); \
                                     else if (h->fast_t >= 2) hipLaunchKernelGGL((k_kkt_thread<K_, 8>), g, b, 0, st, pf, fr, n, h->kkt_code.as<uint8_t>(), h->kkt_L.as<double>(), stp, ta, ctr); \
                                     else hipLaunchKernelGGL((k_kkt_thread<K_, 4>), g, b, 0, st, pf, fr, n, h->kkt_code.as<uint8_t>(), h->kkt_L.as<double>(), stp, ta, ctr); break
                 switch (kd) { MPC_LAUNCH_KKT(1); MPC_LAUNCH_KKT(2); MPC_LAUNCH_KKT(3); MPC_LAUNCH_KKT(4); MPC_LAUNCH_KKT(5); MPC_LAUNCH_KKT(6); MPC_LAUNCH_KKT(7); MPC_LAUNCH_KKT(8); }
 #undef MPC_LAUNCH_KKT
-                HIP_TRY(h, hipEventRecord(h->kev[7], st));
+                if (h->timing) HIP_TRY(h, hipEventRecord(h->kev[7], st));
                 kernel_timed[3] = true;
                 HIP_TRY(h, hipGetLastError());
                 int32_t n_todo = 0;
@@ -2289,9 +2320,9 @@ static int level_run_impl(mpc_handle *h, int32_t gen_children, int32_t flags, mp
                     HIP_TRY(h, hipEventRecord(h->ev_xfork, st));
                     HIP_TRY(h, hipStreamWaitEvent(h->stream2, h->ev_xfork, 0));
                     const unsigned gt = (unsigned)std::min<long long>((n + 63) / 64, (long long)h->n_cu * h->xqt_wpc);
-                    HIP_TRY(h, hipEventRecord(h->kev[10], h->stream2));
+                    if (h->timing) HIP_TRY(h, hipEventRecord(h->kev[10], h->stream2));
                     hipLaunchKernelGGL(k_xq_thread, dim3(gt), dim3(64), 0, h->stream2, pf, fr, k, h->xq_list.as<int32_t>(), (int)n, stp, ctr, dq, nxc_e, alt, XqPlan{});
-                    HIP_TRY(h, hipEventRecord(h->kev[11], h->stream2));
+                    if (h->timing) HIP_TRY(h, hipEventRecord(h->kev[11], h->stream2));
                     HIP_TRY(h, hipGetLastError());
                     HIP_TRY(h, hipEventRecord(h->ev_xjoin, h->stream2));
                     xq_thread_timed = true;
@@ -2309,7 +2340,7 @@ static int level_run_impl(mpc_handle *h, int32_t gen_children, int32_t flags, mp
                 if (!theta_lean && ta.wave_div > 0) grid_th = std::min<long long>(grid_th, std::max<long long>(256, n_theta / ta.wave_div));
                 if (!theta_lean) ta.chunk = (int)std::max<long long>(1, std::min<long long>(16, n_theta / (grid_th * 8)));
                 const dim3 g((unsigned)std::min<long long>(theta_lean ? n_theta : (n_theta + ta.chunk - 1) / ta.chunk, grid_th)), b(64);
-                HIP_TRY(h, hipEventRecord(h->kev[0], st));
+                if (h->timing) HIP_TRY(h, hipEventRecord(h->kev[0], st));
                 switch (h->fast_t) {
                     case 0: hipLaunchKernelGGL((k_theta2<4, 1>), g, b, h->lds_f, st, pf, fr, n_theta, k, stp, ctr, kkc, kkl, ta, theta_list); break;
                     case 1: hipLaunchKernelGGL((k_theta2<4, 2>), g, b, h->lds_f, st, pf, fr, n_theta, k, stp, ctr, kkc, kkl, ta, theta_list); break;
@@ -2318,7 +2349,7 @@ static int level_run_impl(mpc_handle *h, int32_t gen_children, int32_t flags, mp
                     case 4: hipLaunchKernelGGL((k_theta2<10, 1>), g, b, h->lds_f, st, pf, fr, n_theta, k, stp, ctr, kkc, kkl, ta, theta_list); break;
                     default: hipLaunchKernelGGL((k_theta2<10, 2>), g, b, h->lds_f, st, pf, fr, n_theta, k, stp, ctr, kkc, kkl, ta, theta_list); break;
                 }
-                HIP_TRY(h, hipEventRecord(h->kev[1], st));
+                if (h->timing) HIP_TRY(h, hipEventRecord(h->kev[1], st));
                 kernel_timed[0] = true;
                 n_theta_items = n_theta;
                 HIP_TRY(h, hipGetLastError());
@@ -2452,7 +2483,7 @@ static int level_run_impl(mpc_handle *h, int32_t gen_children, int32_t flags, mp
                 // last level: decisions only -- the quick test on three vectors of the parent's dictionary first
                 DictCache dq = dc;
                 const long long grid_q = (long long)h->n_cu * h->xq_wpc;
-                HIP_TRY(h, hipEventRecord(h->kev[8], st));
+                if (h->timing) HIP_TRY(h, hipEventRecord(h->kev[8], st));
                 n_xq_items = n_needx;
                 // First pass, one THREAD per candidate (k_xq_thread, round 5): whatever the first ratio test of the hinted column
                 // decides -- against the generating parent's record, then against the records of the candidate's OTHER parents (the
@@ -2466,7 +2497,7 @@ static int level_run_impl(mpc_handle *h, int32_t gen_children, int32_t flags, mp
                 bool xqt_lean = false;
                 if (h->xq_thread != 0 && n_needx >= h->xqt_min && !early_xq) {
                     const unsigned gt = (unsigned)std::min<long long>(((long long)n_needx + 63) / 64, (long long)h->n_cu * h->xqt_wpc);
-                    HIP_TRY(h, hipEventRecord(h->kev[10], st));
+                    if (h->timing) HIP_TRY(h, hipEventRecord(h->kev[10], st));
                     XqAlt alt{};
                     if ((h->xq_thread >= 2 || h->xq_thread < 0) && h->n_prev > 0 && h->n_prev <= 0x7fffffffLL && h->have_prev_dict && k >= 2 &&
                         h->children.cap >= (size_t)h->n_prev * (k - 1) * sizeof(int32_t) && h->dict_stored[1 - h->dict_cur].cap >= (size_t)h->n_prev) {
@@ -2474,7 +2505,7 @@ static int level_run_impl(mpc_handle *h, int32_t gen_children, int32_t flags, mp
                         alt.n_prev = (int)h->n_prev; alt.tries = h->xq_thread < 0 ? MPC_MAX_NC : h->xq_thread - 1;   // (the kernel stops at the candidate's inequality members)
                     }
                     hipLaunchKernelGGL(k_xq_thread, dim3(gt), dim3(64), 0, st, pf, fr, k, needx_list, n_needx, stp, ctr, dq, nxc, alt, XqPlan{});
-                    HIP_TRY(h, hipEventRecord(h->kev[11], st));
+                    if (h->timing) HIP_TRY(h, hipEventRecord(h->kev[11], st));
                     HIP_TRY(h, hipGetLastError());
                     xq_thread_timed = true;
                     if (lean && !use_grouped) { int rcs = compact(ST_NEEDX, ST_NEEDX_SING, nullptr, dcnt + 9); if (rcs) return rcs; xqt_lean = true; }   // (the grouped form sizes its group scan on the host)
@@ -2510,7 +2541,7 @@ static int level_run_impl(mpc_handle *h, int32_t gen_children, int32_t flags, mp
                 } else if (xq_n == 0) { /* the first pass decided everything (host-known length) */ }
                 else if (h->fast_x & 1) hipLaunchKernelGGL((k_xq<2>), gg, bb, 0, st, pf, fr, k, xq_list, xq_n, stp, ctr, dq, nxc);
                 else hipLaunchKernelGGL((k_xq<1>), gg, bb, 0, st, pf, fr, k, xq_list, xq_n, stp, ctr, dq, nxc);
-                HIP_TRY(h, hipEventRecord(h->kev[9], st));
+                if (h->timing) HIP_TRY(h, hipEventRecord(h->kev[9], st));
                 kernel_timed[4] = true;
                 HIP_TRY(h, hipGetLastError());
                 if (xq_flags_retry) {
@@ -2536,7 +2567,7 @@ static int level_run_impl(mpc_handle *h, int32_t gen_children, int32_t flags, mp
                 needx_list = h->retry_list.as<int32_t>();
             }
             if (n_needx + dc.n_pre1 + dc.n_pre2 > 0) {   // feasibility for the candidates left open (+ dictionary-only items)
-                HIP_TRY(h, hipEventRecord(h->kev[2], st));
+                if (h->timing) HIP_TRY(h, hipEventRecord(h->kev[2], st));
                 int rcs = MPC_OK;
                 const long long n_dict = (long long)n_needx + dc.n_pre1 + dc.n_pre2;
                 if (h->storing && dc.parent_slot && h->x1 > 0 && !xq_lean && n_dict >= h->x1_min) {
@@ -2560,15 +2591,15 @@ static int level_run_impl(mpc_handle *h, int32_t gen_children, int32_t flags, mp
                     DictCache dq = dc;
                     dq.n_list_dev = nullptr;
                     const unsigned gt = (unsigned)std::min<long long>((n_dict + 63) / 64, (long long)h->n_cu * h->xqt_wpc);
-                    HIP_TRY(h, hipEventRecord(h->kev[10], st));
+                    if (h->timing) HIP_TRY(h, hipEventRecord(h->kev[10], st));
                     hipLaunchKernelGGL(k_xq_thread, dim3(gt), dim3(64), 0, st, pf, fr, k, needx_list, n_needx, stp, ctr, dq, nxc, alt, pl);
-                    HIP_TRY(h, hipEventRecord(h->kev[11], st));
+                    if (h->timing) HIP_TRY(h, hipEventRecord(h->kev[11], st));
                     xq_thread_timed = true;
                     const unsigned g1 = (unsigned)std::min<long long>(n_dict, (long long)h->n_cu * h->x1_wpc);
-                    HIP_TRY(h, hipEventRecord(h->kev[12], st));
+                    if (h->timing) HIP_TRY(h, hipEventRecord(h->kev[12], st));
                     if (h->fast_x & 1) hipLaunchKernelGGL((k_x1<2>), dim3(g1), dim3(64), 0, st, pf, pl.x1_list, pl.x1_n, ctr, dc, nxc, pl.plan_slot, pl.plan_step);
                     else hipLaunchKernelGGL((k_x1<1>), dim3(g1), dim3(64), 0, st, pf, pl.x1_list, pl.x1_n, ctr, dc, nxc, pl.plan_slot, pl.plan_step);
-                    HIP_TRY(h, hipEventRecord(h->kev[13], st));
+                    if (h->timing) HIP_TRY(h, hipEventRecord(h->kev[13], st));
                     HIP_TRY(h, hipGetLastError());
                     // what is left: the register simplex, list lengths on the device
                     DictCache dr = dc;
@@ -2587,7 +2618,7 @@ static int level_run_impl(mpc_handle *h, int32_t gen_children, int32_t flags, mp
                     x1_ran = true;
                 } else rcs = launch_x(needx_list, n_needx, dc);
                 if (rcs) return rcs;
-                HIP_TRY(h, hipEventRecord(h->kev[3], st));
+                if (h->timing) HIP_TRY(h, hipEventRecord(h->kev[3], st));
                 kernel_timed[1] = true;
                 n_x_items = n_needx + dc.n_pre1 + dc.n_pre2;
             }
@@ -2622,8 +2653,8 @@ static int level_run_impl(mpc_handle *h, int32_t gen_children, int32_t flags, mp
                 // the end of the level is repeated (its two accumulating counters are cleared; everything else it wrote is overwritten).
                 { int rcs = partition({{ST_RETRY, 0}, {ST_OPT_PENDING, 2}}, cntB, true); if (rcs) return rcs; }
                 hipLaunchKernelGGL(k_publish_words, dim3(1), dim3(64), 0, st, &ctr->n_rretry, reinterpret_cast<unsigned int *>(h->tot_dev + 8), 1);
-                HIP_TRY(h, hipEventRecord(h->ev[1], st));
-                HIP_TRY(h, hipEventRecord(h->ev[2], st));
+                if (h->timing) HIP_TRY(h, hipEventRecord(h->ev[1], st));
+                if (h->timing) HIP_TRY(h, hipEventRecord(h->ev[2], st));
                 { int rcs = queue_tail(); if (rcs) return rcs; }
                 HIP_TRY(h, hipStreamSynchronize(st));
                 for (int c = 0; c < PART_CLASSES; ++c) cntB[c] = h->tot_host[12 + c];
@@ -2682,7 +2713,7 @@ static int level_run_impl(mpc_handle *h, int32_t gen_children, int32_t flags, mp
             HIP_TRY(h, hipGetLastError());
             { int rcs = recession(); if (rcs) return rcs; }
         }
-        if (!tail_done) HIP_TRY(h, hipEventRecord(h->ev[1], st));
+        if (!tail_done) if (h->timing) HIP_TRY(h, hipEventRecord(h->ev[1], st));
         // optimal candidates -> region kernel
         int32_t n_opt = n_opt_fast;
         if (n_opt < 0) {
@@ -2720,7 +2751,7 @@ static int level_run_impl(mpc_handle *h, int32_t gen_children, int32_t flags, mp
             if (rcs) return rcs;
         }
         if (!tail_done) {
-            HIP_TRY(h, hipEventRecord(h->ev[2], st));
+            if (h->timing) HIP_TRY(h, hipEventRecord(h->ev[2], st));
             // pruned masks of this level + children, histogram, counters
             { int rcs = queue_tail(); if (rcs) return rcs; }
             HIP_TRY(h, hipStreamSynchronize(st));
@@ -2734,13 +2765,13 @@ static int level_run_impl(mpc_handle *h, int32_t gen_children, int32_t flags, mp
             if (theta_lean) n_theta_items = cnt_host[0];
             if (xq_lean) n_x_items = (long long)cnt_host[8] + (n_x_items - n_xq_items);   // what the quick test left + the dictionary-only items
         }
-        HIP_TRY(h, hipEventElapsedTime(&ms[0], h->ev[0], h->ev[1]));
-        HIP_TRY(h, hipEventElapsedTime(&ms[1], h->ev[1], h->ev[2]));
-        HIP_TRY(h, hipEventElapsedTime(&ms[2], h->ev[2], h->ev[3]));
-        for (int i = 0; i < 5; ++i) if (kernel_timed[i]) HIP_TRY(h, hipEventElapsedTime(&kms[i], h->kev[2 * i], h->kev[2 * i + 1]));
-        if (xq_thread_timed) { HIP_TRY(h, hipEventElapsedTime(&h->ms_xq_thread, h->kev[10], h->kev[11])); h->n_xq_thread = host_ctr.xq_thread; }
+        if (h->timing) HIP_TRY(h, hipEventElapsedTime(&ms[0], h->ev[0], h->ev[1]));
+        if (h->timing) HIP_TRY(h, hipEventElapsedTime(&ms[1], h->ev[1], h->ev[2]));
+        if (h->timing) HIP_TRY(h, hipEventElapsedTime(&ms[2], h->ev[2], h->ev[3]));
+        for (int i = 0; i < 5; ++i) if (kernel_timed[i] && h->timing) HIP_TRY(h, hipEventElapsedTime(&kms[i], h->kev[2 * i], h->kev[2 * i + 1]));
+        if ((xq_thread_timed) && h->timing) { HIP_TRY(h, hipEventElapsedTime(&h->ms_xq_thread, h->kev[10], h->kev[11])); h->n_xq_thread = host_ctr.xq_thread; }
         h->ms_x1 = 0;
-        if (x1_ran) HIP_TRY(h, hipEventElapsedTime(&h->ms_x1, h->kev[12], h->kev[13]));
+        if ((x1_ran) && h->timing) HIP_TRY(h, hipEventElapsedTime(&h->ms_x1, h->kev[12], h->kev[13]));
         h->n_x1 = x1_ran ? (long long)(h->tot_host + 16 + (int)(sizeof(LevelCounters) / 4))[12] : 0;   // dictionaries k_x1 wrote
         if (h->debug_cycles && x1_ran) { const int32_t *ch = h->tot_host + 16 + (int)(sizeof(LevelCounters) / 4); std::fprintf(stderr, "[mpc] k=%d one-step plans: %d streamed by k_x1, %d + %d + %d left to k_x2 (plan pass %.3f ms)\n", k, ch[12], ch[13], ch[14], ch[15], h->ms_xq_thread); }
         if (xq_early_ran) { n_xq_items += host_ctr.xq_thread; h->n_needx += host_ctr.xq_thread; }   // what the pass beside the theta stage decided never reached the partition's count

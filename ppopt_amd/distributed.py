@@ -61,6 +61,9 @@ class HipLevelEngine:
             twin.level_wait()
         self.eng.set_region_overlap(on)
 
+    def set_timing(self, on: bool):
+        self.eng.set_timing(on)
+
     def clear_pruned(self):
         self.eng.pruned_clear()
 
@@ -354,6 +357,7 @@ def _solve_distributed(engine, program=None, group=None, profile: Optional[List[
     if max_levels is not None:
         max_depth = min(max_depth, max_levels)
     solution = Solution(program, [])
+    getattr(engine, 'set_timing', lambda on: None)(profile is not None)      # HIP-event records inside the levels only for a profile
     engine.clear_pruned()
     engine.root()
     sharded = False

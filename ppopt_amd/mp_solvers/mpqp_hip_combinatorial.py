@@ -132,6 +132,7 @@ def _solve(program, num_cores: int = -1, device: int = 0, profile: Optional[List
     if stream is None:
         stream = os.environ.get('MPC_NO_STREAM', '0') != '1'
     eng = program.engine(device, closed=closed)
+    eng.set_timing(profile is not None)      # HIP-event records inside the levels only when somebody reads their times
     n_x, n_t, n_c, n_tc = eng.n_x, eng.n_t, eng.n_c, eng.n_tc
     solution = Solution(program, [])
     max_depth = max(n_x, n_t) - eng.n_eq
@@ -345,6 +346,7 @@ def _solve_many(programs, device: int = 0, max_levels: Optional[int] = None, pru
     for e in engs:
         d = max(e.n_x, e.n_t) - e.n_eq
         depth_max.append(d if max_levels is None else min(d, max_levels))
+        e.set_timing(profile is not None)
         e.pruned_clear()
         e.frontier_root()
     # Device memory: a member's level holds buffers sized by its number of candidates (region records, children, two generations of
