@@ -1089,7 +1089,7 @@ MPC_GLOBAL void MPC_LB(1024) k_small_end(const int32_t *__restrict__ cands, int 
         const unsigned int v = hist[threadIdx.x] + (threadIdx.x < 4 ? hist[threadIdx.x + 8] : 0u);
         if (v) atomicAdd(&ctr->status[threadIdx.x], (unsigned long long)v);
     }
-    if (threadIdx.x == 0) { *n_retry = (int32_t)hist[ST_RETRY]; *n_late = (int32_t)hist[ST_OPT_PENDING]; }
+    if (threadIdx.x == 0) { *n_retry = (int32_t)hist[7];   /* 7 = ST_RETRY (kernels2.hpp) */ *n_late = (int32_t)hist[ST_OPT_PENDING]; }
     if (pub_dst) {
         __threadfence();
         __syncthreads();

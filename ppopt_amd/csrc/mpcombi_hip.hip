@@ -1642,6 +1642,12 @@ static int level_run_small(mpc_handle *h, int32_t gen_children, int32_t flags, m
         // a candidate k_region2 gave up on (the LDS-engine region kernel is not part of this path), or one that turned out optimal
         // after the region launch: the level is repeated classically
         h->n_smallpath_fallback++; g_small_repeats++;
+        // The repeat must not look for other parents' records: this run's k_children_write has overwritten the previous level's frontier
+        // (it lives in the children buffer since the hand-over), which that search walks.
+        h->n_prev = 0;
+        // A program that produces doubtful candidates keeps doing so (measured: 10-17 % of the small levels of random mpQPs, none on the
+        // named configurations): its handle goes back to re-solving them in place, so the repeat is paid once per handle.
+        if (fused && (cnt_host[4] > 0 || cnt_host[24] > 0)) h->no_small_fuse = true;
         *fallback = true;
         return MPC_OK;
     }
