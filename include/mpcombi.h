@@ -329,6 +329,42 @@ int mpc_sync(mpc_handle *h);   /* waits for everything queued on the handle's st
 /* mpc_level_batch_fetch copies the records of all members that hold them in slot form with ONE launch (round 5); mpc_fetch_wait waits
  * for that launch on the given device (mpc_sync of any member and the next mpc_level_batch_start do so too) */
 int mpc_fetch_wait(int32_t device);
+/* ---- the level loop of MANY programs inside the library (round 5) -------------------------------------------------------------------
+ * The caller of the combinatorial path for many small programs -- the mixed-integer enumeration maps solve_mpqp over its sub-programs
+ * (reference mp_solvers/mpmiqp_enumeration.py:41-50), each of which runs the level loop of mpqp_parrallel_combinatorial.py:102-139 -- as
+ * ONE loop on a thread of the library: shared launches of a level for all members (mpc_level_batch_start / _wait), the record copy of
+ * the level for all members into three page-locked blocks (mpc_level_batch_fetch), the members' frontier hand-overs, the next level.
+ * The device never waits for the caller between levels; the caller only consumes, level by level:
+ *   mpc_solve_many_start(handles, n, max_levels[n], flags, &job)   every handle: pruned list cleared, frontier rooted, then the loop
+ *          (flags: MPC_LEVEL_KEEP_LOWDIM).  The handles must not be touched until mpc_solve_many_wait has returned.
+ *   mpc_solve_many_level(job, level, &info)   blocks until level `level` (0-based) has been run and its records are COMPLETE in the
+ *          three blocks (member j's arrays start at off_d[j] / off_i[j] / off_e[j] elements, n_slots[j] slots of the member's fd / fi,
+ *          n_rows[j] rows of n_t + 1).  The blocks are the caller's from then on (mpc_host_free; null when no member found a region);
+ *          the small arrays of `info` live until mpc_solve_many_wait.  info.n_members == 0: the loop ended before this level --
+ *          info.done = 1: every member has run its last level; 2: the next level of the remaining members does not fit the memory budget
+ *          of the shared launches together (MPC_BATCH_BUDGET_GB): their frontiers are advanced, their next level has NOT been started,
+ *          the caller takes over (admission / parking: the host layer's loop).
+ *   mpc_solve_many_wait(job)   joins the loop and frees the job: the loop's return code (the failing member carries the message).
+ * flags & MPC_SOLVE_MANY_BASE: when every member has run its last level (not after a hand-over) the loop closes with one more shared level
+ * over the BASE active set of every program (the equality rows alone, one candidate each, pruned lists cleared: the reference tests it
+ * last, mpqp_parrallel_combinatorial.py:142-146); that level's info carries base = 1. */
+#define MPC_SOLVE_MANY_BASE 128
+typedef struct {
+    int32_t level, n_members, n_shared, done;
+    int32_t base, pad_;              /* base = 1: this is the closing level of the base active sets (MPC_SOLVE_MANY_BASE)   */
+    const int32_t *member;           /* [n_members] positions in the handle array of mpc_solve_many_start          */
+    const mpc_level_stats *stats;    /* [n_members]                                                                 */
+    const int64_t *n_slots, *n_rows; /* [n_members] record slots / region rows copied (0: the member found no region) */
+    const int64_t *off_d, *off_i, *off_e;   /* [n_members] element offsets inside head_d / head_i / erows            */
+    double *head_d;
+    int32_t *head_i;
+    double *erows;
+    int64_t len_d, len_i, len_e;     /* elements of the three blocks                                                */
+    double ms_wall;                  /* wall time of the level on the loop's thread                                 */
+} mpc_many_level_info;
+int mpc_solve_many_start(mpc_handle **handles, int32_t n_handles, const int32_t *max_levels, int32_t flags, void **job);
+int mpc_solve_many_level(void *job, int32_t level, mpc_many_level_info *info);
+int mpc_solve_many_wait(void *job);
 /* Page-locked host memory from a recycling pool (blocks return to the pool on mpc_host_free and are handed out again
  * without re-pinning).  For result arrays that are filled by mpc_level_regions_slots. */
 int mpc_host_alloc(uint64_t bytes, void **out);

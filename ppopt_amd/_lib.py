@@ -15,6 +15,7 @@ LIB_PATH = os.environ.get('MPC_LIB_PATH') or os.path.join(_HERE, 'csrc', 'libmpc
 
 MPC_OK, MPC_ERR_INVALID, MPC_ERR_HIP, MPC_ERR_CAPACITY, MPC_ERR_STATE = range(5)
 MPC_LOCATE_OVERLAPPING, MPC_LOCATE_INCLUSIVE, MPC_LOCATE_WALK = 1, 2, 4   # flags of mpc_locator_query
+MPC_SOLVE_MANY_BASE = 128   # flag of mpc_solve_many_start
 MPC_LEVEL_STREAM, MPC_LEVEL_GRAPH, MPC_LEVEL_THEN_BASE, MPC_LEVEL_KEEP_LOWDIM, MPC_LEVEL_ONLY_BASE = 1, 4, 8, 16, 32   # flags of mpc_level_start / mpc_level_run_ex
 MPC_SOLVE_FETCH = 64   # flag of mpc_solve_start
 INFEASIBLE, FEASIBLE, OPTIMAL_NO_REGION, REGION, SINGULAR_KKT, LP_LIMIT = range(6)
@@ -66,6 +67,17 @@ class SolveLevelInfo(ctypes.Structure):
     _fields_ = [('level', ctypes.c_int32), ('k', ctypes.c_int32), ('mode', ctypes.c_int32), ('chunk', ctypes.c_int32),
                 ('n_chunks', ctypes.c_int32), ('pad_', ctypes.c_int32), ('n', ctypes.c_int64), ('n_slots', ctypes.c_int64),
                 ('n_rows', ctypes.c_int64), ('head_d', ctypes.c_void_p), ('head_i', ctypes.c_void_p), ('erows', ctypes.c_void_p)]
+
+
+class ManyLevelInfo(ctypes.Structure):
+    """mpc_many_level_info (include/mpcombi.h)."""
+    _fields_ = [('level', ctypes.c_int32), ('n_members', ctypes.c_int32), ('n_shared', ctypes.c_int32), ('done', ctypes.c_int32),
+                ('base', ctypes.c_int32), ('pad_', ctypes.c_int32),
+                ('member', ctypes.POINTER(ctypes.c_int32)), ('stats', ctypes.POINTER(LevelStats)),
+                ('n_slots', ctypes.POINTER(ctypes.c_int64)), ('n_rows', ctypes.POINTER(ctypes.c_int64)),
+                ('off_d', ctypes.POINTER(ctypes.c_int64)), ('off_i', ctypes.POINTER(ctypes.c_int64)), ('off_e', ctypes.POINTER(ctypes.c_int64)),
+                ('head_d', ctypes.c_void_p), ('head_i', ctypes.c_void_p), ('erows', ctypes.c_void_p),
+                ('len_d', ctypes.c_int64), ('len_i', ctypes.c_int64), ('len_e', ctypes.c_int64), ('ms_wall', ctypes.c_double)]
 
 
 _lib = None
@@ -159,6 +171,9 @@ def load():
         'mpc_level_batch_fetch': (ctypes.c_int, [ctypes.POINTER(H), ctypes.c_int32, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_void_p), _lp, ctypes.POINTER(ctypes.c_void_p), _lp, _lp, _lp]),
         'mpc_sync': (ctypes.c_int, [H]),
         'mpc_fetch_wait': (ctypes.c_int, [ctypes.c_int32]),
+        'mpc_solve_many_start': (ctypes.c_int, [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int32, ctypes.POINTER(ctypes.c_int32), ctypes.c_int32, ctypes.POINTER(ctypes.c_void_p)]),
+        'mpc_solve_many_level': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int32, ctypes.POINTER(ManyLevelInfo)]),
+        'mpc_solve_many_wait': (ctypes.c_int, [ctypes.c_void_p]),
         'mpc_locator_create': (ctypes.c_int, [ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int64, _lp, _dp, _dp, _dp, _dp, _dp,
                                                ctypes.POINTER(ctypes.c_void_p)]),
         'mpc_locator_query': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, _dp, ctypes.c_double, ctypes.c_int32, _lp, _dp,
@@ -201,7 +216,7 @@ EXPORTED_SYMBOLS = ['mpc_device_count', 'mpc_version', 'mpc_last_global_error', 
                     'mpc_frontier_root', 'mpc_frontier_set', 'mpc_frontier_set_device', 'mpc_frontier_info',
                     'mpc_frontier_get', 'mpc_pruned_clear', 'mpc_pruned_add', 'mpc_pruned_add_device',
                     'mpc_pruned_count', 'mpc_pruned_get', 'mpc_level_run', 'mpc_level_run_ex', 'mpc_level_run_batch', 'mpc_frontier_advance_batch', 'mpc_level_memory_gb', 'mpc_trim', 'mpc_level_batch_start', 'mpc_level_batch_wait', 'mpc_level_regions_slots_nowait', 'mpc_level_batch_fetch', 'mpc_level_status', 'mpc_level_start', 'mpc_level_stream_info', 'mpc_level_chunk_wait', 'mpc_level_wait', 'mpc_level_stream_fixup', 'mpc_base_result', 'mpc_solve_start', 'mpc_solve_level', 'mpc_solve_chunk_wait', 'mpc_solve_level_wait', 'mpc_solve_wait', 'mpc_level_regions', 'mpc_compact_strides',
-                    'mpc_level_regions_compact', 'mpc_frontier_shard', 'mpc_level_slots', 'mpc_level_regions_slots', 'mpc_level_regions_slots_async', 'mpc_sync', 'mpc_fetch_wait', 'mpc_host_alloc', 'mpc_host_free', 'mpc_locator_create', 'mpc_locator_query', 'mpc_locator_destroy', 'mpc_locator_set_adjacency', 'mpc_level_children', 'mpc_level_children_device', 'mpc_level_pruned_new',
+                    'mpc_level_regions_compact', 'mpc_frontier_shard', 'mpc_level_slots', 'mpc_level_regions_slots', 'mpc_level_regions_slots_async', 'mpc_sync', 'mpc_fetch_wait', 'mpc_solve_many_start', 'mpc_solve_many_level', 'mpc_solve_many_wait', 'mpc_host_alloc', 'mpc_host_free', 'mpc_locator_create', 'mpc_locator_query', 'mpc_locator_destroy', 'mpc_locator_set_adjacency', 'mpc_level_children', 'mpc_level_children_device', 'mpc_level_pruned_new',
                     'mpc_level_pruned_new_device', 'mpc_level_regions_device', 'mpc_frontier_advance', 'mpc_qp_solve_batch', 'mpc_facet_centres', 'mpc_graph_begin', 'mpc_graph_wave', 'mpc_graph_group_run', 'mpc_graph_wave_close', 'mpc_check_level', 'mpc_lp_solve_batch']
 
 
@@ -494,6 +509,62 @@ class Engine:
             out.append((big_d[od[j]:od[j] + ns * fds[j]].reshape(ns, fds[j]), big_i[oi[j]:oi[j] + ns * fis[j]].reshape(ns, fis[j]),
                         big_e[oe[j]:oe[j] + nr * (e.n_t + 1)].reshape(nr, e.n_t + 1), int(e._last.k)))
         return out
+
+    @staticmethod
+    def solve_many_start(engines, max_levels, keep_lowdim: bool = False, base: bool = False):
+        """The level loop of all ``engines`` on a thread of the library (mpc_solve_many_start): every engine's pruned list is cleared, its
+        frontier rooted, then level after level with shared launches; returns the job for ``solve_many_level`` / ``solve_many_wait``.
+        The engines must not be touched until ``solve_many_wait`` has returned."""
+        B = len(engines)
+        hs = (ctypes.c_void_p * B)(*[e._h for e in engines])
+        ml = (ctypes.c_int32 * B)(*[int(v) for v in max_levels])
+        job = ctypes.c_void_p()
+        rc = engines[0]._L.mpc_solve_many_start(hs, B, ml, (MPC_LEVEL_KEEP_LOWDIM if keep_lowdim else 0) | (MPC_SOLVE_MANY_BASE if base else 0), ctypes.byref(job))
+        if rc != 0:
+            Engine._raise_for(engines, rc)
+        return (job, list(engines))
+
+    @staticmethod
+    def solve_many_level(job, level: int):
+        """Blocks until level ``level`` of the job has been run and its records are complete (mpc_solve_many_level).  Returns
+        ``(done, None)`` past the last level (done = 1: all members finished, 2: the caller takes over -- memory budget), else
+        ``(0, (members, stats, n_shared, ms_wall, records, base))`` (``base``: the closing level of the base active sets) with ``records`` = [(member, head_d, head_i, erows, k)] for the members
+        that found regions (views into three page-locked blocks that return to the pool with their last view)."""
+        jb, engines = job
+        info = ManyLevelInfo()
+        rc = engines[0]._L.mpc_solve_many_level(jb, int(level), ctypes.byref(info))
+        if rc != 0:
+            Engine._raise_for(engines, rc)
+        nm = int(info.n_members)
+        if nm == 0:
+            return int(info.done), None
+        members = info.member[:nm]
+        stats = [info.stats[j] for j in range(nm)]
+        for i, st in zip(members, stats):
+            engines[i]._last = st
+        records = []
+        if info.head_d:
+            big_d = pinned_adopt(info.head_d, (int(info.len_d),), numpy.float64)
+            big_i = pinned_adopt(info.head_i, (int(info.len_i),), numpy.int32)
+            big_e = pinned_adopt(info.erows, (max(int(info.len_e), 1),), numpy.float64)
+            ns, nr, od, oi, oe = info.n_slots[:nm], info.n_rows[:nm], info.off_d[:nm], info.off_i[:nm], info.off_e[:nm]
+            for j, i in enumerate(members):
+                if ns[j] == 0:
+                    continue
+                e, k = engines[i], int(stats[j].k)
+                fd = e.n_x * e.n_t + e.n_x + k * e.n_t + k
+                fi = 8 + k + e.n_tc + k + 2 * (e.n_c - k)
+                records.append((i, big_d[od[j]:od[j] + ns[j] * fd].reshape(ns[j], fd), big_i[oi[j]:oi[j] + ns[j] * fi].reshape(ns[j], fi),
+                                big_e[oe[j]:oe[j] + nr[j] * (e.n_t + 1)].reshape(nr[j], e.n_t + 1), k))
+        return 0, (members, stats, int(info.n_shared), float(info.ms_wall), records, bool(info.base))
+
+    @staticmethod
+    def solve_many_wait(job):
+        """Joins the loop and frees the job (mpc_solve_many_wait); raises what the loop failed with."""
+        jb, engines = job
+        rc = engines[0]._L.mpc_solve_many_wait(jb)
+        if rc != 0:
+            Engine._raise_for(engines, rc)
 
     @staticmethod
     def fetch_wait(engine):

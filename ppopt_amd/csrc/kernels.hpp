@@ -1117,6 +1117,81 @@ MPC_GLOBAL void MPC_LB(1024) k_scan_publish(const int32_t *__restrict__ in, int3
     for (int i = threadIdx.x; i < n1 + n2; i += 1024) dst[i] = load_word_agent(i < n1 ? src1 + i : src2 + (i - n1));
 }
 
+// ---- records of the candidates the register region kernel gave up on, into their slots ON THE DEVICE (round 5) -------------------------
+// k_region2 marks such a slot ST_RETRY, the LDS-engine kernel k_region re-solves the candidate into a FIXED-stride record (recd / reci,
+// in the order of retry_list).  Until round 5 the host merged those into the slot arrays after the copy (level_regions_slots_impl:
+// eight copy commands and a synchronisation per member -- 2-3 ms per level of 128 programs); this kernel writes them into the slot
+// arrays where they are, the rows [f | E] behind the pooled ones (row0 on), so the member's records leave with the shared copy launch.
+// One block per member; same arithmetic-free moves as the host loop, same slot contents.
+constexpr int RRETRY_MERGE_MAX = 1024;
+struct RretryMerge {
+    const int32_t *opt_list; const int32_t *rlist; const uint8_t *status; const double *recd; const int32_t *reci;
+    double *headd; int32_t *headi; double *epool;
+    int n_opt, n_rretry, rec_d, rec_i, fd, fi, row0, nx, nt, nc, ntc, k;
+};
+MPC_GLOBAL void MPC_LB(256) k_rretry_merge(RretryMerge a) {
+    __shared__ int slots[RRETRY_MERGE_MAX], src[RRETRY_MERGE_MAX], rowoff[RRETRY_MERGE_MAX];
+    __shared__ int wc[4];
+    __shared__ int m;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) m = 0;
+    __syncthreads();
+    for (int start = 0; start < a.n_opt; start += 256) {     // the slots marked "given up", in slot order
+        const int w = start + tid;
+        const bool f = w < a.n_opt && a.headi[(size_t)w * a.fi] == 7;   // 7 = ST_RETRY (kernels2.hpp)
+        const unsigned long long mk = __ballot(f);
+        if (lane == 0) wc[wave] = __popcll(mk);
+        __syncthreads();
+        int before = m;
+        for (int v = 0; v < wave; ++v) before += wc[v];
+        const int pos = before + __popcll(mk & ((1ull << lane) - 1ull));
+        if (f && pos < RRETRY_MERGE_MAX) slots[pos] = w;
+        __syncthreads();
+        if (tid == 0) m += wc[0] + wc[1] + wc[2] + wc[3];
+        __syncthreads();
+    }
+    const int mm = min(m, RRETRY_MERGE_MAX);
+    for (int j = tid; j < mm; j += 256) {
+        const int cand = a.opt_list[slots[j]];
+        int r = -1;
+        for (int q = 0; q < a.n_rretry; ++q) if (a.rlist[q] == cand) { r = q; break; }
+        src[j] = r;
+        rowoff[j] = (r >= 0 && a.status[cand] == ST_REGION) ? a.reci[(size_t)r * a.rec_i + 1] : 0;
+    }
+    __syncthreads();
+    if (tid == 0) { int run = a.row0; for (int j = 0; j < mm; ++j) { const int ne = rowoff[j]; rowoff[j] = run; run += ne; } }
+    __syncthreads();
+    const int nx = a.nx, nt = a.nt, nc = a.nc, ntc = a.ntc, k = a.k, nr = nt + 1;
+    for (int j = 0; j < mm; ++j) {
+        const int w = slots[j], cand = a.opt_list[w], r = src[j];
+        const int st = a.status[cand];
+        int32_t *oi = a.headi + (size_t)w * a.fi;
+        double *od = a.headd + (size_t)w * a.fd;
+        for (int i = tid; i < a.fi; i += 256) oi[i] = i == 0 ? st : (i == 1 ? cand : (i < 8 ? 0 : -1));
+        if (r < 0 || st != ST_REGION) continue;      // (uniform)
+        for (int i = tid; i < a.fd; i += 256) od[i] = 0.0;
+        __syncthreads();
+        const double *rd = a.recd + (size_t)r * a.rec_d;
+        const int32_t *ri = a.reci + (size_t)r * a.rec_i;
+        const int kk = ri[0], nE = ri[1], n_om = ri[2], n_la = ri[3], n_re = ri[4];
+        const double *Al = rd + nx * nt + nx, *bl = Al + (size_t)nc * nt, *E = bl + nc, *f = E + (size_t)(nc + ntc) * nt;
+        for (int i = tid; i < nx * nt + nx; i += 256) od[i] = rd[i];
+        for (int i = tid; i < kk * nt; i += 256) od[nx * nt + nx + i] = Al[i];
+        for (int i = tid; i < kk; i += 256) od[nx * nt + nx + k * nt + i] = bl[i];
+        if (tid == 0) { oi[2] = nE; oi[3] = n_om; oi[4] = n_la; oi[5] = n_re; oi[6] = rowoff[j]; }
+        int32_t *act = oi + 8, *om = act + k, *la = om + ntc, *ridx = la + k, *rcon = ridx + (nc - k);
+        for (int i = tid; i < kk; i += 256) act[i] = ri[5 + i];
+        for (int i = tid; i < n_om; i += 256) om[i] = ri[5 + nc + i];
+        for (int i = tid; i < n_la; i += 256) la[i] = ri[5 + nc + ntc + i];
+        for (int i = tid; i < n_re; i += 256) { ridx[i] = ri[5 + nc + ntc + nc + i]; rcon[i] = ri[5 + nc + ntc + nc + nc + i]; }
+        for (int i = tid; i < nE * nr; i += 256) {
+            const int rr = i / nr, t = i - rr * nr;
+            a.epool[(size_t)(rowoff[j] + rr) * nr + t] = t == 0 ? f[rr] : E[(size_t)rr * nt + (t - 1)];
+        }
+        __syncthreads();
+    }
+}
+
 // graph mode (MPC_LEVEL_GRAPH): the (x,theta) feasibility question is not posed -- "feasibility open" becomes "no region"
 MPC_GLOBAL void k_close_open(const int32_t *__restrict__ list, int n_list, uint8_t *__restrict__ status) {
     const int w = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1145,6 +1220,8 @@ MPC_GLOBAL void k_take_rows(const int32_t *__restrict__ src, long long n_new, in
     dst[idx] = src[(start + r * stride) * width + (idx - r * width)];
 }
 
+// the base active set: the equality rows alone (one candidate of n_eq indices)
+MPC_GLOBAL void k_base_frontier(int n_eq, int32_t *out) { for (int i = threadIdx.x; i < n_eq; i += blockDim.x) out[i] = i; }
 MPC_GLOBAL void k_root_frontier(int n_eq, int n_c, int32_t *out) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     const int cnt = n_c - n_eq;

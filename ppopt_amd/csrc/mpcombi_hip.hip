@@ -363,6 +363,7 @@ struct mpc_handle {
     DevProblem Pr2{};         // view for k_region2
     int lds_r2 = 0, grid_r2 = 0, fast_r = -1;   // fast_r: k_region2 instantiation, -1 = none (n_t == 1 or too many rows)
     bool used_region2 = false;
+    long long rretry_rows = -1;      // >= 0: the re-solved candidates' records have been written into their slots on the device (k_rretry_merge); rows of epool in use then (bound)
     long long n_rretry = 0, n_erows = 0;
     int fd = 0, fi = 0;
     HostBuf st_list, st_status, st_hd, st_hi, st_pool, st_fxd, st_fxi, st_rlist;   // pinned staging for region fetches
@@ -1436,7 +1437,7 @@ static int level_run_small(mpc_handle *h, int32_t gen_children, int32_t flags, m
         return spec;
     };
     const int blocks256 = (int)((n + 255) / 256);
-    h->used_region2 = false; h->n_rretry = 0; h->n_erows = 0;
+    h->used_region2 = false; h->n_rretry = 0; h->n_erows = 0; h->rretry_rows = -1;
     h->fd = h->n_x * h->n_t + h->n_x + k * h->n_t + k;
     h->fi = 8 + k + h->n_tc + k + 2 * (h->n_c - k);
     if (h->timing) HIP_TRY(h, hipEventRecord(h->ev[0], st));
@@ -1708,7 +1709,7 @@ static int batch_prepare(mpc_handle *h, int32_t gen_children, int32_t flags, Bat
     HIP_TRY(h, h->theta_list.ensure(nn * sizeof(int32_t), st));
     HIP_TRY(h, h->part_lists.ensure((size_t)PART_CLASSES * nn * sizeof(int32_t), st));
     HIP_TRY(h, h->dcnt.ensure(32 * sizeof(int32_t), st));
-    h->used_region2 = false; h->n_rretry = 0; h->n_erows = 0;
+    h->used_region2 = false; h->n_rretry = 0; h->n_erows = 0; h->rretry_rows = -1;
     h->fd = h->n_x * h->n_t + h->n_x + k * h->n_t + k;
     h->fi = 8 + k + h->n_tc + k + 2 * (h->n_c - k);
     m.k = k; m.kd = k - h->targs.ne; m.fast_t = h->fast_t; m.fast_x = h->fast_x; m.fast_r = h->fast_r; m.mw = h->mw;
@@ -2108,7 +2109,7 @@ static int level_run_impl(mpc_handle *h, int32_t gen_children, int32_t flags, mp
         const double *kkl = nullptr;
         // region stage on the register engine: one slot per candidate of h->opt_ptr.  Buffers are prepared on the main stream; the
         // kernel goes to `rst` (the main stream, or stream3 when the stage runs under the level's (x,theta) stage)
-        h->used_region2 = false; h->n_rretry = 0; h->n_erows = 0;
+        h->used_region2 = false; h->n_rretry = 0; h->n_erows = 0; h->rretry_rows = -1;
         h->fd = h->n_x * h->n_t + h->n_x + k * h->n_t + k;
         h->fi = 8 + k + h->n_tc + k + 2 * (h->n_c - k);
         int32_t *region_out_hi = nullptr;   // head_i of the level's slots as the device sees it (device buffer or mapped host block)
@@ -3312,8 +3313,10 @@ static int level_regions_slots_impl(mpc_handle *h, double *head_d, int32_t *head
     HIP_TRY(h, hipSetDevice(h->device));
     const int nx = h->n_x, nt = h->n_t, nc = h->n_c, ntc = h->n_tc, k = h->k, nr = nt + 1, fd = h->fd, fi = h->fi;
     const long long n_opt = h->n_opt, rows_t = nc - h->n_eq + ntc;
-    const long long n_fixed = h->used_region2 ? h->n_rretry : n_opt;
-    const long long rows_need = h->used_region2 ? h->n_erows + h->n_rretry * rows_t : h->n_regions * rows_t;
+    const bool merged = h->used_region2 && h->rretry_rows >= 0;   // k_rretry_merge has written the re-solved candidates' records into their slots
+    const long long pool_rows = merged ? h->rretry_rows : h->n_erows;
+    const long long n_fixed = h->used_region2 ? (merged ? 0 : h->n_rretry) : n_opt;
+    const long long rows_need = h->used_region2 ? (merged ? pool_rows : h->n_erows + h->n_rretry * rows_t) : h->n_regions * rows_t;
     if (cap_rows < rows_need) return fail(h, MPC_ERR_CAPACITY, "row buffer too small (see mpc_compact_strides max_rows)");
     hipStream_t s = h->stream;
     if (n_fixed > 0) {
@@ -3333,20 +3336,20 @@ static int level_regions_slots_impl(mpc_handle *h, double *head_d, int32_t *head
         HIP_TRY(h, hipMemcpyAsync(head_i, h->headi.p, (size_t)n_opt * fi * sizeof(int32_t), hipMemcpyDeviceToHost, s));
         HIP_TRY(h, hipEventRecord(h->ev_hi, s));
         HIP_TRY(h, hipMemcpyAsync(head_d, h->headd.p, (size_t)n_opt * fd * sizeof(double), hipMemcpyDeviceToHost, s));
-        if (h->n_erows > 0) HIP_TRY(h, hipMemcpyAsync(erows, h->epool.p, (size_t)h->n_erows * nr * sizeof(double), hipMemcpyDeviceToHost, s));
+        if (pool_rows > 0) HIP_TRY(h, hipMemcpyAsync(erows, h->epool.p, (size_t)pool_rows * nr * sizeof(double), hipMemcpyDeviceToHost, s));
         if (!h->fetch_nowait) HIP_TRY(h, hipEventSynchronize(h->ev_hi));
         if (n_slots) *n_slots = n_opt;
-        if (n_rows) *n_rows = h->n_erows;
+        if (n_rows) *n_rows = pool_rows;
         return MPC_OK;
     }
     if (h->used_region2) {
         if (!in_place) {
             HIP_TRY(h, hipMemcpyAsync(head_d, h->headd.p, (size_t)n_opt * fd * sizeof(double), hipMemcpyDeviceToHost, s));
             HIP_TRY(h, hipMemcpyAsync(head_i, h->headi.p, (size_t)n_opt * fi * sizeof(int32_t), hipMemcpyDeviceToHost, s));
-            if (h->n_erows > 0) HIP_TRY(h, hipMemcpyAsync(erows, h->epool.p, (size_t)h->n_erows * nr * sizeof(double), hipMemcpyDeviceToHost, s));
+            if (pool_rows > 0) HIP_TRY(h, hipMemcpyAsync(erows, h->epool.p, (size_t)pool_rows * nr * sizeof(double), hipMemcpyDeviceToHost, s));
         }
-        wrow = h->n_erows;
-        if (h->n_rretry > 0) {
+        wrow = pool_rows;
+        if (h->n_rretry > 0 && !merged) {
             HIP_TRY(h, h->st_rlist.ensure((size_t)h->n_rretry * sizeof(int32_t)));
             HIP_TRY(h, hipMemcpyAsync(h->st_rlist.p, h->retry_list.p, (size_t)h->n_rretry * sizeof(int32_t), hipMemcpyDeviceToHost, s));
         }
@@ -3445,26 +3448,48 @@ int mpc_level_batch_fetch(mpc_handle **hs, int32_t n_handles, double *const *hea
                           double *const *erows, const int64_t *cap_rows, int64_t *n_slots, int64_t *n_rows) {
     if (!hs || n_handles < 0 || !head_d || !head_i || !cap_slots || !erows || !cap_rows || !n_slots || !n_rows) return MPC_ERR_INVALID;
     static const bool no_many = [] { const char *ev = std::getenv("MPC_NO_FETCH_MANY"); return ev && ev[0] == '1'; }();   // A/B: three copy commands per member
+    static const bool no_merge = [] { const char *ev = std::getenv("MPC_NO_RRETRY_MERGE"); return ev && ev[0] == '1'; }();   // A/B, tests: re-solved candidates' records merged by the host (round 4)
+    auto no_merge_or = [&](bool plain) { return no_merge && !plain; };
     std::vector<FetchEntry> tab;
     mpc_handle *lead = nullptr;
     for (int i = 0; i < n_handles; ++i) {
         mpc_handle *h = hs[i];
         if (!h) return MPC_ERR_INVALID;
         // every record in slot form on the device, nothing streamed, nothing re-solved by the LDS engine: the copy kernel takes the member
-        const bool fast = !no_many && h->level_done && !h->so.active && h->n_regions > 0 && h->n_opt > 0 && h->used_region2 && h->n_rretry == 0 &&
-                          cap_slots[i] >= h->n_opt && cap_rows[i] >= h->n_erows && head_d[i] && head_i[i] && (erows[i] || h->n_erows == 0) &&
+        // (round 5: also a member with candidates re-solved by the LDS-engine kernel -- k_rretry_merge writes their records into the slots first)
+        const long long rows_t = h->n_c - h->n_eq + h->n_tc;
+        const bool merge = h->n_rretry > 0 && h->rretry_rows < 0;
+        const long long rows_out = h->n_rretry > 0 ? h->n_erows + h->n_rretry * rows_t : h->n_erows;   // (bound: a re-solved region keeps at most rows_t rows)
+        const bool fast = !no_many && !no_merge_or(h->n_rretry == 0) && h->level_done && !h->so.active && h->n_regions > 0 && h->n_opt > 0 && h->used_region2 &&
+                          h->n_rretry <= RRETRY_MERGE_MAX && h->n_opt <= 0x7fffffffLL &&
+                          (h->n_rretry == 0 || (h->recd.p && h->reci.p && h->retry_list.p && h->epool.cap >= (size_t)rows_out * (h->n_t + 1) * sizeof(double))) &&
+                          cap_slots[i] >= h->n_opt && cap_rows[i] >= rows_out && head_d[i] && head_i[i] && (erows[i] || rows_out == 0) &&
                           (!lead || lead->device == h->device);
         void *d_hd = nullptr, *d_hi = nullptr, *d_er = nullptr;
         if (fast && hipHostGetDevicePointer(&d_hd, head_d[i], 0) == hipSuccess && hipHostGetDevicePointer(&d_hi, head_i[i], 0) == hipSuccess &&
-            (h->n_erows == 0 || hipHostGetDevicePointer(&d_er, erows[i], 0) == hipSuccess)) {
-            if (!lead) lead = h;
+            (rows_out == 0 || hipHostGetDevicePointer(&d_er, erows[i], 0) == hipSuccess)) {
+            if (!lead) { lead = h; HIP_TRY(lead, hipSetDevice(lead->device)); }
+            if (merge) {
+                if (h->stream != lead->stream) HIP_TRY(h, hipStreamSynchronize(h->stream));   // (a member that took its level alone: its kernels ran on its own stream)
+                RretryMerge a{};
+                a.opt_list = h->opt_ptr; a.rlist = h->retry_list.as<int32_t>(); a.status = h->status.as<uint8_t>(); a.recd = h->recd.as<double>(); a.reci = h->reci.as<int32_t>();
+                a.headd = h->headd.as<double>(); a.headi = h->headi.as<int32_t>(); a.epool = h->epool.as<double>();
+                a.n_opt = (int)h->n_opt; a.n_rretry = (int)h->n_rretry; a.rec_d = (int)h->rec_d; a.rec_i = (int)h->rec_i; a.fd = h->fd; a.fi = h->fi; a.row0 = (int)h->n_erows;
+                a.nx = h->n_x; a.nt = h->n_t; a.nc = h->n_c; a.ntc = h->n_tc; a.k = h->k;
+                hipLaunchKernelGGL(k_rretry_merge, dim3(1), dim3(256), 0, lead->stream, a);
+                HIP_TRY(h, hipGetLastError());
+                h->rretry_rows = rows_out;
+            }
             tab.push_back({h->headi.p, d_hi, (unsigned long long)h->n_opt * h->fi * sizeof(int32_t)});
             tab.push_back({h->headd.p, d_hd, (unsigned long long)h->n_opt * h->fd * sizeof(double)});
-            if (h->n_erows > 0) tab.push_back({h->epool.p, d_er, (unsigned long long)h->n_erows * (h->n_t + 1) * sizeof(double)});
-            n_slots[i] = h->n_opt; n_rows[i] = h->n_erows;
+            if (rows_out > 0) tab.push_back({h->epool.p, d_er, (unsigned long long)rows_out * (h->n_t + 1) * sizeof(double)});
+            n_slots[i] = h->n_opt; n_rows[i] = rows_out;
             continue;
         }
         (void)hipGetLastError();
+        { static const bool dbg = [] { const char *ev = std::getenv("MPC_DEBUG_MANY"); return ev && ev[0] == '1'; }();
+          if (dbg) std::fprintf(stderr, "[many] member %d outside the copy launch: level_done %d streamed %d regions %lld n_opt %lld region2 %d rretry %lld cap_slots %lld erows %lld cap_rows %lld\n", i, (int)h->level_done, (int)h->so.active,
+                                (long long)h->n_regions, (long long)h->n_opt, (int)h->used_region2, (long long)h->n_rretry, (long long)cap_slots[i], (long long)h->n_erows, (long long)cap_rows[i]); }
         const int rc = mpc_level_regions_slots_nowait(h, head_d[i], head_i[i], cap_slots[i], erows[i], cap_rows[i], n_slots + i, n_rows + i);
         if (rc != MPC_OK) return rc;
     }
@@ -3645,6 +3670,215 @@ int mpc_frontier_advance_batch(mpc_handle **hs, int32_t n_handles) {
     if (!hs || n_handles < 0) return MPC_ERR_INVALID;
     for (int i = 0; i < n_handles; ++i) { const int rc = mpc_frontier_advance(hs[i]); if (rc != MPC_OK) return rc; }
     return MPC_OK;
+}
+
+// ---- the level loop of many programs on a thread of the library (include/mpcombi.h: mpc_solve_many_*) ----------------------------------
+struct ManyLevel {
+    std::vector<int32_t> member;
+    std::vector<mpc_level_stats> stats;
+    std::vector<int64_t> ns, nr, od, oi, oe;
+    void *hd = nullptr, *hi = nullptr, *er = nullptr;
+    int64_t ld = 0, li = 0, le = 0;
+    int32_t n_shared = 0;
+    double ms_wall = 0;
+    bool base = false;       // the closing level of the base active sets
+    bool taken = false;      // the blocks belong to the caller
+    ~ManyLevel() { if (!taken) { if (hd) (void)host_pool_give(hd); if (hi) (void)host_pool_give(hi); if (er) (void)host_pool_give(er); } }
+};
+struct ManyJob {
+    std::vector<mpc_handle *> hs;
+    std::vector<int32_t> max_levels;
+    int32_t flags = 0;
+    std::thread th;
+    std::mutex m;
+    std::condition_variable cv;
+    std::vector<std::unique_ptr<ManyLevel>> levels;   // appended by the loop, read by the caller (under m)
+    bool finished = false, handover = false;
+    int rc = MPC_OK;
+};
+
+static void many_loop(ManyJob *J) {
+    auto finish = [&](int rc) {
+        std::lock_guard<std::mutex> lk(J->m);
+        J->rc = rc; J->finished = true;
+        J->cv.notify_all();
+    };
+    const int B = (int)J->hs.size();
+    if (B == 0) return finish(MPC_OK);
+    mpc_handle *h0 = J->hs[0];
+    if (hipSetDevice(h0->device) != hipSuccess) return finish(fail(h0, MPC_ERR_HIP, "mpc_solve_many: hipSetDevice failed"));
+    const double budget_gb = 0.6 * [] { const char *ev = std::getenv("MPC_BATCH_BUDGET_GB"); return ev ? std::atof(ev) : 160.0; }();   // (headroom as in the host layer's loop)
+    std::vector<int> depth(B, 0);
+    std::vector<int32_t> active;
+    for (int i = 0; i < B; ++i) {
+        mpc_handle *h = J->hs[i];
+        int rc = mpc_pruned_clear(h);
+        if (rc == MPC_OK) rc = mpc_frontier_root(h);
+        if (rc != MPC_OK) return finish(rc);
+        if (J->max_levels[i] > 0) active.push_back(i);
+    }
+    auto gen_of = [&](int i) { return depth[i] + 1 != J->max_levels[i] ? 1 : 0; };
+    auto start = [&](const std::vector<int32_t> &act, void **token) -> int {
+        std::vector<mpc_handle *> hh; std::vector<int32_t> gg;
+        for (int i : act) { hh.push_back(J->hs[i]); gg.push_back(gen_of(i)); }
+        return mpc_level_batch_start(hh.data(), (int32_t)hh.size(), gg.data(), J->flags & ~MPC_SOLVE_MANY_BASE, token);
+    };
+    void *token = nullptr;
+    static const bool dbg = [] { const char *ev = std::getenv("MPC_DEBUG_MANY"); return ev && ev[0] == '1'; }();
+    auto now = [] { return std::chrono::steady_clock::now(); };
+    auto ms_since = [&](std::chrono::steady_clock::time_point a) { return std::chrono::duration<double, std::milli>(now() - a).count(); };
+    { const auto ts = now(); if (!active.empty()) { const int rc = start(active, &token); if (rc != MPC_OK) return finish(rc); } if (dbg) std::fprintf(stderr, "[many] first start %.3f ms\n", ms_since(ts)); }
+    bool base_phase = false;
+    auto start_base = [&]() -> int {      // every program's base active set as one more shared level (reference driver :142-146)
+        active.clear();
+        for (int i = 0; i < B; ++i) {
+            mpc_handle *h = J->hs[i];
+            int rc = frontier_reset(h, 1, h->n_eq);
+            if (rc != MPC_OK) return rc;
+            if (h->n_eq > 0) { hipLaunchKernelGGL(k_base_frontier, dim3(1), dim3(64), 0, h->stream, h->n_eq, h->frontier.as<int32_t>()); HIP_TRY(h, hipGetLastError()); }
+            h->n_pruned = 0; h->n_pruned_extra = 0;
+            active.push_back(i);
+        }
+        for (int i = 0; i < B; ++i) if (J->hs[i]->stream != J->hs[0]->stream && J->hs[i]->n_eq > 0) HIP_TRY(J->hs[i], hipStreamSynchronize(J->hs[i]->stream));   // (the shared launches run on the first member's stream)
+        base_phase = true;
+        std::vector<mpc_handle *> hh(J->hs); std::vector<int32_t> gg(B, 0);
+        return mpc_level_batch_start(hh.data(), B, gg.data(), J->flags & ~MPC_SOLVE_MANY_BASE, &token);
+    };
+    if (active.empty() && (J->flags & MPC_SOLVE_MANY_BASE)) { const int rc = start_base(); if (rc != MPC_OK) return finish(rc); }
+    while (!active.empty()) {
+        const auto t0 = std::chrono::steady_clock::now();
+        double t_wait = 0, t_fetch = 0, t_adv = 0, t_start = 0;
+        const int nb = (int)active.size();
+        std::unique_ptr<ManyLevel> L(new ManyLevel());
+        L->member = active;
+        L->base = base_phase;
+        L->stats.resize(nb);
+        {
+            // (mpc_level_batch_wait writes stats[m.id] with ids = positions in ITS handle list = positions in `active`)
+            const auto ts = now();
+            const int rc = mpc_level_batch_wait(token, L->stats.data(), &L->n_shared);
+            t_wait = ms_since(ts);
+            token = nullptr;
+            if (rc != MPC_OK) return finish(rc);
+        }
+        // the level's records: three blocks for all members (sizes from each member's statistics, as the host layer's level_batch_fetch)
+        const auto tf = now();
+        L->ns.assign(nb, 0); L->nr.assign(nb, 0); L->od.assign(nb, 0); L->oi.assign(nb, 0); L->oe.assign(nb, 0);
+        std::vector<int64_t> fds(nb), fis(nb);
+        for (int j = 0; j < nb; ++j) {
+            const mpc_handle *h = J->hs[active[j]];
+            const mpc_level_stats &st = L->stats[j];
+            const int k = st.k;
+            fds[j] = (int64_t)h->n_x * h->n_t + h->n_x + (int64_t)k * h->n_t + k;
+            fis[j] = 8 + k + h->n_tc + k + 2 * (h->n_c - k);
+            const int64_t rows_t = h->n_c - h->n_eq + h->n_tc;
+            if (st.n_regions > 0) {
+                L->ns[j] = st.n_opt;
+                L->nr[j] = st.n_region_rows ? st.n_region_rows + st.n_region_retry * rows_t : st.n_regions * rows_t;
+            }
+            L->od[j] = L->ld; L->oi[j] = L->li; L->oe[j] = L->le;
+            L->ld += L->ns[j] * fds[j]; L->li += L->ns[j] * fis[j]; L->le += L->nr[j] * (h->n_t + 1);
+        }
+        if (L->ld > 0) {
+            if (host_pool_take((size_t)L->ld * 8, &L->hd, nullptr) != hipSuccess || host_pool_take((size_t)L->li * 4, &L->hi, nullptr) != hipSuccess ||
+                host_pool_take((size_t)std::max<int64_t>(L->le, 1) * 8, &L->er, nullptr) != hipSuccess)
+                return finish(fail(h0, MPC_ERR_HIP, "mpc_solve_many: page-locked memory for the level's records"));
+            std::vector<mpc_handle *> hh; std::vector<double *> pd, pe; std::vector<int32_t *> pi; std::vector<int64_t> cs, cr, n1, n2; std::vector<int> at;
+            for (int j = 0; j < nb; ++j) {
+                if (L->ns[j] == 0) continue;
+                hh.push_back(J->hs[active[j]]); at.push_back(j);
+                pd.push_back(static_cast<double *>(L->hd) + L->od[j]); pi.push_back(static_cast<int32_t *>(L->hi) + L->oi[j]);
+                pe.push_back(static_cast<double *>(L->er) + L->oe[j]);
+                cs.push_back(L->ns[j]); cr.push_back(L->nr[j]);
+            }
+            n1.assign(hh.size(), 0); n2.assign(hh.size(), 0);
+            const int rc = mpc_level_batch_fetch(hh.data(), (int32_t)hh.size(), pd.data(), pi.data(), cs.data(), pe.data(), cr.data(), n1.data(), n2.data());
+            if (rc != MPC_OK) return finish(rc);
+            for (size_t q = 0; q < hh.size(); ++q) { L->ns[at[q]] = n1[q]; L->nr[at[q]] = n2[q]; }
+            // a member outside the shared copy launch (records re-solved by the LDS engine, streamed ...) queued its copies on its own stream
+            for (mpc_handle *h : hh) if (hipStreamQuery(h->stream) != hipSuccess) { (void)hipGetLastError(); if (hipStreamSynchronize(h->stream) != hipSuccess) return finish(fail(h, MPC_ERR_HIP, "mpc_solve_many: record copy")); }
+        }
+        t_fetch = ms_since(tf);
+        const auto ta = now();
+        std::vector<int32_t> nxt;
+        if (!base_phase) for (int j = 0; j < nb; ++j) if (gen_of(active[j]) && L->stats[j].n_children > 0) nxt.push_back(active[j]);
+        double need_gb = 0.0;
+        for (int i : nxt) {
+            const int rc = mpc_frontier_advance(J->hs[i]);
+            if (rc != MPC_OK) return finish(rc);
+            depth[i] += 1;
+            need_gb += batch_level_gb(J->hs[i], gen_of(i));
+        }
+        const bool handover = !nxt.empty() && need_gb > budget_gb;
+        t_adv = ms_since(ta);
+        const auto tst = now();
+        const bool then_base = nxt.empty() && !base_phase && (J->flags & MPC_SOLVE_MANY_BASE);
+        if (!nxt.empty() && !handover) {
+            const int rc = start(nxt, &token);      // (waits for the shared record copy first: the members' record buffers are written again)
+            if (rc != MPC_OK) return finish(rc);
+        } else if (then_base) {
+            const int rc = start_base();
+            if (rc != MPC_OK) return finish(rc);
+        } else if (fetch_many_wait(h0->device) != MPC_OK) return finish(fail(h0, MPC_ERR_HIP, "mpc_solve_many: the shared record copy failed"));
+        t_start = ms_since(tst);
+        L->ms_wall = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        if (dbg) std::fprintf(stderr, "[many] level of %d members: wait+finish %.3f fetch %.3f advance %.3f next start %.3f total %.3f ms\n", nb, t_wait, t_fetch, t_adv, t_start, L->ms_wall);
+        {
+            std::lock_guard<std::mutex> lk(J->m);
+            J->levels.push_back(std::move(L));
+            if (handover) J->handover = true;
+            J->cv.notify_all();
+        }
+        if (handover) break;
+        if (then_base) continue;      // (`active` = every member, set by start_base)
+        active.swap(nxt);
+    }
+    finish(MPC_OK);
+}
+
+extern "C" int mpc_solve_many_start(mpc_handle **hs, int32_t n_handles, const int32_t *max_levels, int32_t flags, void **job) {
+    if (!hs || n_handles < 0 || !max_levels || !job) return MPC_ERR_INVALID;
+    *job = nullptr;
+    for (int i = 0; i < n_handles; ++i) {
+        if (!hs[i]) return MPC_ERR_INVALID;
+        std::lock_guard<std::mutex> lk(hs[i]->wm);
+        if (hs[i]->w_busy) return fail(hs[i], MPC_ERR_STATE, "a level started with mpc_level_start is still running");
+    }
+    std::unique_ptr<ManyJob> J(new ManyJob());
+    J->hs.assign(hs, hs + n_handles);
+    J->max_levels.assign(max_levels, max_levels + n_handles);
+    J->flags = flags & (MPC_LEVEL_KEEP_LOWDIM | MPC_SOLVE_MANY_BASE);
+    ManyJob *raw = J.get();
+    try { J->th = std::thread(many_loop, raw); } catch (...) { return fail(n_handles ? hs[0] : nullptr, MPC_ERR_STATE, "mpc_solve_many_start: no thread"); }
+    *job = J.release();
+    return MPC_OK;
+}
+extern "C" int mpc_solve_many_level(void *job, int32_t level, mpc_many_level_info *info) {
+    if (!job || !info || level < 0) return MPC_ERR_INVALID;
+    ManyJob *J = static_cast<ManyJob *>(job);
+    std::unique_lock<std::mutex> lk(J->m);
+    J->cv.wait(lk, [&] { return (int)J->levels.size() > level || J->finished; });
+    std::memset(info, 0, sizeof(*info));
+    info->level = level;
+    if ((int)J->levels.size() <= level) {
+        info->done = J->handover ? 2 : 1;
+        return J->rc;
+    }
+    ManyLevel &L = *J->levels[level];
+    info->n_members = (int32_t)L.member.size(); info->n_shared = L.n_shared; info->base = L.base ? 1 : 0;
+    info->member = L.member.data(); info->stats = L.stats.data();
+    info->n_slots = L.ns.data(); info->n_rows = L.nr.data(); info->off_d = L.od.data(); info->off_i = L.oi.data(); info->off_e = L.oe.data();
+    info->head_d = static_cast<double *>(L.hd); info->head_i = static_cast<int32_t *>(L.hi); info->erows = static_cast<double *>(L.er);
+    info->len_d = L.ld; info->len_i = L.li; info->len_e = std::max<int64_t>(L.le, L.hd ? 1 : 0);
+    info->ms_wall = L.ms_wall;
+    L.taken = true;
+    return MPC_OK;
+}
+extern "C" int mpc_solve_many_wait(void *job) {
+    if (!job) return MPC_ERR_INVALID;
+    std::unique_ptr<ManyJob> J(static_cast<ManyJob *>(job));
+    if (J->th.joinable()) J->th.join();
+    return J->rc;
 }
 
 }  // extern "C"

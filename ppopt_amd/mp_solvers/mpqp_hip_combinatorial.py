@@ -72,6 +72,7 @@ REGION_STATUS = 3   # MPC_REGION
 # overlap gains there (sub-programs of the mixed-integer enumeration, the first levels of every solve)
 STREAM_MIN_CANDIDATES = int(os.environ.get('MPC_STREAM_MIN', '512'))
 BASE_ON_TWIN = os.environ.get('MPC_NO_TWIN', '0') != '1'   # the base-set check on a second handle, started with the first streamed level
+MANY_LOOP = os.environ.get('MPC_NO_MANY_LOOP', '0') != '1'     # solve_many: the level loop of all members inside the library (mpc_solve_many_start); '1' = from here (A/B, tests)
 SOLVE_LOOP = os.environ.get('MPC_NO_SOLVE_LOOP', '0') != '1'   # the level loop inside the library (mpc_solve_start); '1' = level by level from here (A/B)
 
 
@@ -347,8 +348,9 @@ def _solve_many(programs, device: int = 0, max_levels: Optional[int] = None, pru
         d = max(e.n_x, e.n_t) - e.n_eq
         depth_max.append(d if max_levels is None else min(d, max_levels))
         e.set_timing(profile is not None)
-        e.pruned_clear()
-        e.frontier_root()
+        if not MANY_LOOP:      # (the library's loop does both itself)
+            e.pruned_clear()
+            e.frontier_root()
     # Device memory: a member's level holds buffers sized by its number of candidates (region records, children, two generations of
     # the dictionary cache: Engine.level_memory_gb).  Members whose next level does not fit the budget next to the others are PARKED
     # at their current level and resumed when the running ones have finished (and given their level buffers back: Engine.trim).
@@ -371,12 +373,58 @@ def _solve_many(programs, device: int = 0, max_levels: Optional[int] = None, pru
                 take.append(i)
                 used += need[i]
         return sorted(take)
+    def take_records(fetched):
+        for i, (hd, hi, er, kk) in fetched:
+            eng = engs[i]
+            slots = numpy.flatnonzero(hi[:, 0] == REGION_STATUS)
+            batch = RegionBatch(hd, hi, er, eng.n_x, eng.n_t, eng.n_c, eng.n_tc, kk, slots)
+            sols[i].region_batches.append(batch)
+            sols[i].critical_regions.extend(batch.regions())
+
+    level_no = 0
+    base_done = False
+    first = [i for i in range(len(engs)) if depth_max[i] > 0]
+    job = None
     try:
-        active = admit([i for i in range(len(engs)) if depth_max[i] > 0])
+        if MANY_LOOP and first:
+            # The loop over the levels of ALL members runs on a thread of the library (mpc_solve_many_*): shared launches, the level's record
+            # copy, the frontier hand-overs, the next level -- the device does not wait for this interpreter between levels; this thread
+            # builds the region objects of a level while later levels run.  The loop stops when the members' next level would not fit the
+            # memory budget together (done == 2): the admission / parking loop below takes over from the frontiers it left.
+            job = Engine.solve_many_start(engs, depth_max, keep_lowdim=not prune_lowdim, base=True)
+            first = []
+            n_lib = 0
+            while True:
+                done, lv = Engine.solve_many_level(job, n_lib)
+                if lv is None:
+                    break
+                n_lib += 1
+                members, stats, n_shared, ms_wall, records, is_base = lv
+                take_records([(i, (hd, hi, er, kk)) for i, hd, hi, er, kk in records])
+                if is_base:      # the closing level of the base active sets (reference driver :142-146), run by the library's loop as well
+                    base_done = True
+                    if profile is not None:
+                        profile.append({'depth': 0, 'members': len(members), 'shared_launches': n_shared, 'candidates': len(members),
+                                        'regions': int(sum(int(st.n_regions) for st in stats)), 'ms_wall': ms_wall, 'in_library': True})
+                    continue
+                first = []
+                for i, st in zip(members, stats):
+                    if gen_of(i) and st.n_children:
+                        depth_of[i] += 1
+                        first.append(i)
+                level_no += 1
+                if profile is not None:
+                    profile.append({'depth': level_no, 'members': len(members), 'shared_launches': n_shared, 'parked': 0,
+                                    'candidates': int(sum(int(st.n) for st in stats)), 'regions': int(sum(int(st.n_regions) for st in stats)),
+                                    'ms_launches': float(stats[0].ms_total) if stats else 0.0, 'ms_wait': 0.0, 'ms_wall': ms_wall, 'in_library': True})
+            jb, job = job, None
+            Engine.solve_many_wait(jb)
+            if done != 2:
+                first = []      # every member ran its last level inside the library
+        active = admit(first) if first else []
         gens = [gen_of(i) for i in active]
         token = Engine.level_batch_start([engs[i] for i in active], gens, keep_lowdim=not prune_lowdim) if active else None
         in_flight[0] = token
-        level_no = 0
         while active:
             t0 = time.perf_counter()
             in_flight[0] = None             # the wait consumes the token, whatever it returns
@@ -419,12 +467,7 @@ def _solve_many(programs, device: int = 0, max_levels: Optional[int] = None, pru
             # one copy launch: complete once its event has passed -- it has, whenever a next level was started)
             if fetched:
                 Engine.fetch_wait(engs[fetched[0][0]])
-            for i, (hd, hi, er, kk) in fetched:
-                eng = engs[i]
-                slots = numpy.flatnonzero(hi[:, 0] == REGION_STATUS)
-                batch = RegionBatch(hd, hi, er, eng.n_x, eng.n_t, eng.n_c, eng.n_tc, kk, slots)
-                sols[i].region_batches.append(batch)
-                sols[i].critical_regions.extend(batch.regions())
+            take_records(fetched)
             level_no += 1
             if profile is not None:
                 profile.append({'depth': level_no, 'members': len(active), 'shared_launches': n_shared, 'parked': len(parked),
@@ -435,23 +478,34 @@ def _solve_many(programs, device: int = 0, max_levels: Optional[int] = None, pru
             e.sync()
         # the base active set of every program (driver :142-146), as one more shared level of one candidate each
         t0 = time.perf_counter()
-        for e in engs:
-            e.frontier_set(numpy.arange(e.n_eq, dtype=numpy.int32).reshape(1, -1))
-            e.pruned_clear()
-        stats, n_shared = Engine.level_run_batch(engs, [False] * len(engs), keep_lowdim=not prune_lowdim)
-        for i, (e, st) in enumerate(zip(engs, stats)):
-            if st.n_regions:
-                rd, ri, _ = e.level_regions()
-                sols[i].add_region(unpack_region(rd[0], ri[0], e.n_x, e.n_t, e.n_c, e.n_tc))
-                sols[i].loose_regions.append(sols[i].critical_regions[-1])
-        if profile is not None:
-            profile.append({'depth': 0, 'members': len(engs), 'shared_launches': n_shared, 'candidates': len(engs),
-                            'regions': int(sum(int(st.n_regions) for st in stats)), 'ms_wall': (time.perf_counter() - t0) * 1e3})
+        if not base_done:
+            for e in engs:
+                e.frontier_set(numpy.arange(e.n_eq, dtype=numpy.int32).reshape(1, -1))
+                e.pruned_clear()
+            stats, n_shared = Engine.level_run_batch(engs, [False] * len(engs), keep_lowdim=not prune_lowdim)
+            for i, (e, st) in enumerate(zip(engs, stats)):
+                if st.n_regions:
+                    rd, ri, _ = e.level_regions()
+                    sols[i].add_region(unpack_region(rd[0], ri[0], e.n_x, e.n_t, e.n_c, e.n_tc))
+                    sols[i].loose_regions.append(sols[i].critical_regions[-1])
+            if profile is not None:
+                profile.append({'depth': 0, 'members': len(engs), 'shared_launches': n_shared, 'candidates': len(engs),
+                                'regions': int(sum(int(st.n_regions) for st in stats)), 'ms_wall': (time.perf_counter() - t0) * 1e3})
     except MpcCapacityError:
         # a member that fell back to the overlapped single-program path ran out of reserved record slots (never observed): one by one
+        if job is not None:
+            try:
+                Engine.solve_many_wait(job)      # (the loop has ended with that error: joined before the handles are used again)
+            except Exception:
+                pass
         return [solve(p, device=device, max_levels=max_levels, prune_lowdim=prune_lowdim) for p in programs]
     except BaseException:
         # a level may have been started and not waited for: let it finish (the handles must be idle before anybody touches them again)
+        if job is not None:
+            try:
+                Engine.solve_many_wait(job)
+            except Exception:
+                pass
         if in_flight[0] is not None:
             try:
                 Engine.level_batch_wait(in_flight[0])
