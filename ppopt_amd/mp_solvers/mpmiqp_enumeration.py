@@ -25,7 +25,7 @@ from ..utils.general_utils import num_cpu_cores
 from . import mpqp_hip_combinatorial
 from .solve_mpqp import _COMBINATORIAL, mpqp_algorithm, solve_mpqp
 
-BATCH_CHUNKS = int(os.environ.get('MPC_BATCH_CHUNKS', '1'))   # chunks of fixations solved together (see below)
+BATCH_CHUNKS = int(os.environ.get('MPC_BATCH_CHUNKS', '2'))   # chunks of fixations solved together (see below)
 MAX_BATCH = int(os.environ.get('MPC_MAX_BATCH', '256'))       # most sub-programs alive at once (one host thread each while they are constructed)
 
 
@@ -120,7 +120,9 @@ def solve_mpmiqp_enumeration(program, num_cores: int = -1,
         # MPC_BATCH_CHUNKS > 1: the fixations are solved in chunks -- while the device works on the levels of one chunk (the host waits
         # inside the C ABI, GIL released) a second thread substitutes, presolves and sets up the sub-programs of the next one.  Measured
         # on the bench workload (64 fixations): 1 chunk 345 ms, 2 chunks 368, 4 chunks 350-435, 8 chunks 425-450 -- the host work of
-        # the two threads shares one interpreter lock and smaller batches fill the device less; default 1.
+        # the two threads shares one interpreter lock and smaller batches fill the device less.  Round 5: the level loop of a chunk runs
+        # inside the library (mpc_solve_many_*), this thread sleeps in the C ABI for most of a chunk, and the second thread's constructions
+        # no longer fight for the lock: 1 chunk 112 ms, 2 chunks 103-106, 3 chunks 105-110, 4 chunks 118 (tools/mi_phases.py); default 2.
         n_fix = len(feasible_combinations)
         chunk = min(MAX_BATCH, n_fix if num_cores <= 1 else max(8, -(-n_fix // BATCH_CHUNKS)))
         chunks = [feasible_combinations[i:i + chunk] for i in range(0, n_fix, chunk)]

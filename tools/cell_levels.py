@@ -13,4 +13,4 @@ prof = []
 m.solve(prog, max_levels=ml, profile=prof)
 for p in prof:
     if p['depth'] > 0:
-        print({k: (round(v, 3) if isinstance(v, float) else v) for k, v in p.items() if k in ('k', 'candidates', 'status', 'regions', 'ms_kkt', 'ms_theta', 'ms_x', 'ms_xq', 'ms_xq_thread', 'ms_region2', 'n_x_items', 'n_xq_items', 'n_xq_thread', 'ms_wall', 'xtheta_fallbacks', 'ms_verdict', 'ms_region', 'ms_children')})
+        print({k: (round(v, 3) if isinstance(v, float) else v) for k, v in p.items() if k in ('k', 'candidates', 'status', 'regions', 'ms_kkt', 'ms_theta', 'ms_x', 'ms_xq', 'ms_xq_thread', 'ms_region2', 'n_x_items', 'n_xq_items', 'n_xq_thread', 'ms_wall', 'xtheta_fallbacks', 'ms_verdict', 'ms_region', 'ms_children', 'n_x1', 'ms_x1', 'ms_x_plan', 'lp_pivots', 'xq_pivots', 'n_theta_items', 'n_opt', 'xtheta_lps')})
