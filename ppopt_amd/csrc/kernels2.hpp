@@ -54,7 +54,22 @@ struct ThetaArgs {
     // tail of few long LPs: measured on config 4 (round 4, MPC_TH_CAP) an item takes 29 us with one wavefront per SIMD, 48 us with two
     // and 130 us with four -- the launch was fastest with HALF (level 5: 15 k items) or a QUARTER (level 4: 5 k items) of its wave slots.
     int wave_div, wave_max;
+    // k_kkt_thread (round 5): when set, the kernel lists its own output -- the candidates it leaves to k_theta2 (status ST_TODO) in
+    // kt_list / *kt_n, those its box screen sends to the (x,theta) question (ST_NEEDX) in kx_list / *kx_n -- with one atomic per wavefront
+    // and exit point, instead of a five-launch compaction of the status array per list behind it.  The lists are index-ordered within
+    // a wavefront's piece only; they are work lists (every candidate's result is written by candidate index), so the order changes nothing.
+    int32_t *kt_list, *kt_n, *kx_list, *kx_n;
 };
+// every ACTIVE lane appends `value`: one atomic per call site and wavefront
+__device__ __forceinline__ void wave_append(int32_t *list, int32_t *cnt, int value) {
+    const unsigned long long m = __ballot(1);
+    const int lane = threadIdx.x & 63;
+    const int rank = __popcll(m & ((1ull << lane) - 1ull));
+    int base = 0;
+    if (rank == 0) base = atomicAdd(cnt, __popcll(m));
+    base = __builtin_amdgcn_readfirstlane(base);
+    list[base + rank] = value;
+}
 
 // ------------------------------------------------------------------------------------------------------------------
 // k_kkt_thread: the mode-0 KKT solve AND the box screen of the theta stage with ONE THREAD per candidate (K = cardinality
@@ -125,7 +140,7 @@ MPC_GLOBAL void MPC_LB(256) k_kkt_thread(const DevProblem *__restrict__ Pg, cons
             }
         }
         clear = clear && (vol > 1e-10);
-        if (!clear) { code[c] = (uint8_t)KK_UNDECIDED; status[c] = (uint8_t)ST_TODO; return; }
+        if (!clear) { code[c] = (uint8_t)KK_UNDECIDED; status[c] = (uint8_t)ST_TODO; if (ta.kt_list) wave_append(ta.kt_list, ta.kt_n, (int)c); return; }
     }
     // ---- S = Wr[as,as] = L L'  (chol_solve arithmetic; the pivots are those of the full Schur matrix behind its equality block) ----
     double diag0[K], invd[K];
@@ -152,7 +167,7 @@ MPC_GLOBAL void MPC_LB(256) k_kkt_thread(const DevProblem *__restrict__ Pg, cons
             for (int cc = j + 1; cc <= i; ++cc) S[i][cc] = fma(-S[i][j], S[cc][j], S[i][cc]);
         }
     }
-    if (!ok) { code[c] = 2; status[c] = (uint8_t)ST_TODO; return; }
+    if (!ok) { code[c] = 2; status[c] = (uint8_t)ST_TODO; if (ta.kt_list) wave_append(ta.kt_list, ta.kt_n, (int)c); return; }
     // ---- multipliers of the inequality rows, all n_t + 1 right-hand sides (zero beyond n_t) -----------------------------------------
     double Lr[K][LS];
 #pragma unroll
@@ -237,6 +252,7 @@ MPC_GLOBAL void MPC_LB(256) k_kkt_thread(const DevProblem *__restrict__ Pg, cons
     if (fired) {
         code[c] = ill ? KK_ILL : 0;
         status[c] = (uint8_t)ST_NEEDX;
+        if (ta.kx_list) wave_append(ta.kx_list, ta.kx_n, (int)c);
         return;
     }
     double *out = Lout + (size_t)c * kf * nr;
@@ -261,6 +277,7 @@ MPC_GLOBAL void MPC_LB(256) k_kkt_thread(const DevProblem *__restrict__ Pg, cons
     }
     code[c] = ill ? KK_ILL : 0;
     status[c] = (uint8_t)ST_TODO;
+    if (ta.kt_list) wave_append(ta.kt_list, ta.kt_n, (int)c);
 }
 
 // the KKT result of candidate c: from k_kkt_thread's output when it decided, else solved here

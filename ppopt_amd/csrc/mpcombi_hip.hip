@@ -303,6 +303,7 @@ struct mpc_handle {
     bool no_smallpath = false;       // MPC_NO_SMALLPATH=1: levels of any size take the classic path with its host round trips (A/B)
     long long smallpath_max = 4096;  // MPC_SMALLPATH_MAX: largest level (candidates) that runs without host round trips (measured: config 4 is
                                      // fastest with 1,024-4,096 -- a level of 15,691 candidates prefers the classic path, which streams its records)
+    bool no_kkt_lists = false;       // MPC_NO_KKT_LISTS=1: the work lists behind k_kkt_thread by compaction of the status array (round 4; A/B, tests)
     bool no_small_fuse = false;      // MPC_NO_SMALL_FUSE=1: the small path with its round-4 launches (doubtful candidates re-solved in place; A/B, tests)
     long long n_smallpath_doubtful = 0;   // small levels repeated because the fused form met a doubtful candidate
     long long n_smallpath = 0, n_smallpath_fallback = 0;   // levels run that way / of which repeated on the classic path
@@ -640,6 +641,7 @@ static int create_fill(const mpc_problem *p, int32_t device, void *stream, mpc_h
     { const char *ev = std::getenv("MPC_TEST_LATE"); h->test_late = ev ? std::atoi(ev) : 0; }
     { const char *ev = std::getenv("MPC_TEST_SPARE"); h->test_spare = ev ? std::atoi(ev) : 0; }
     { const char *ev = std::getenv("MPC_NO_KEV"); h->no_kev = ev && ev[0] == '1'; h->timing = !h->no_kev; }
+    { const char *ev = std::getenv("MPC_NO_KKT_LISTS"); h->no_kkt_lists = ev && ev[0] == '1'; }
     { const char *ev = std::getenv("MPC_NO_SMALL_FUSE"); h->no_small_fuse = ev && ev[0] == '1'; }
     { const char *ev = std::getenv("MPC_NO_SMALLPATH"); h->no_smallpath = ev && ev[0] == '1'; }
     { const char *ev = std::getenv("MPC_NO_LEAN"); h->no_lean = ev && ev[0] == '1'; }
@@ -2270,13 +2272,23 @@ static int level_run_impl(mpc_handle *h, int32_t gen_children, int32_t flags, mp
             // fetch the multipliers of the candidates the screen left open
             long long n_theta = n;
             const int32_t *theta_list = nullptr;
+            bool kkt_listed = false;
             const int kd = k - h->targs.ne;   // rows the one-thread KKT kernel solves for (the equality rows are eliminated)
             if (h->kkt_mode == 0 && kd >= 1 && kd <= 8 && h->no_kkt_thread != 1) {
                 HIP_TRY(h, h->kkt_code.ensure(nn, st));
                 HIP_TRY(h, h->kkt_L.ensure(nn * (size_t)k * (h->n_t + 1) * sizeof(double), st));
                 kkc = h->kkt_code.as<uint8_t>(); kkl = h->kkt_L.as<double>();
                 const dim3 g((unsigned)blocks256), b(256);
-                const ThetaArgs ta = h->targs;
+                ThetaArgs ta = h->targs;
+                // (round 5) a lean level lets the kernel list its own output: the theta stage's work list and the candidates its box
+                // screen sends to the (x,theta) question -- two compactions of five launches each saved on the level's critical path
+                const bool kkt_lists = lean && !h->no_kkt_lists && n <= 0x7fffffffLL;
+                if (kkt_lists) {
+                    HIP_TRY(h, h->theta_list.ensure(nn * sizeof(int32_t), st));
+                    HIP_TRY(h, h->xq_list.ensure(nn * sizeof(int32_t), st));
+                    ta.kt_list = h->theta_list.as<int32_t>(); ta.kt_n = dcnt + 0;
+                    ta.kx_list = h->xq_list.as<int32_t>(); ta.kx_n = dcnt + 10;
+                }
                 if (h->timing) HIP_TRY(h, hipEventRecord(h->kev[6], st));
 #define MPC_LAUNCH_KKT(K_) case K_: if (h->fast_t >= 4) hipLaunchKernelGGL((k_kkt_thread<K_, 10>), g, b, 0, st, pf, fr, n, h->kkt_code.as<uint8_t>(), h->kkt_L.as<double>(), stp, ta, ctr); \
                                     else if (h->fast_t >= 2) hipLaunchKernelGGL((k_kkt_thread<K_, 8>), g, b, 0, st, pf, fr, n, h->kkt_code.as<uint8_t>(), h->kkt_L.as<double>(), stp, ta, ctr); \
@@ -2287,11 +2299,14 @@ static int level_run_impl(mpc_handle *h, int32_t gen_children, int32_t flags, mp
                 kernel_timed[3] = true;
                 HIP_TRY(h, hipGetLastError());
                 int32_t n_todo = 0;
-                if (lean) { int rcs = compact(ST_TODO, ST_TODO, nullptr, dcnt + 0); if (rcs) return rcs; theta_lean = true; n_todo = (int32_t)n; }
-                else { int rcs = compact(ST_TODO, ST_TODO, &n_todo); if (rcs) return rcs; }
+                if (kkt_lists) { theta_lean = true; n_todo = (int32_t)n; kkt_listed = true; }
+                else {
+                    if (lean) { int rcs = compact(ST_TODO, ST_TODO, nullptr, dcnt + 0); if (rcs) return rcs; theta_lean = true; n_todo = (int32_t)n; }
+                    else { int rcs = compact(ST_TODO, ST_TODO, &n_todo); if (rcs) return rcs; }
+                    HIP_TRY(h, h->theta_list.ensure(nn * sizeof(int32_t), st));
+                    std::swap(h->theta_list, h->retry_list);   // compact() filled retry_list; keep it as the theta list
+                }
                 n_theta = n_todo;   // lean: the bound
-                HIP_TRY(h, h->theta_list.ensure(nn * sizeof(int32_t), st));
-                std::swap(h->theta_list, h->retry_list);   // compact() filled retry_list; keep it as the theta list
                 theta_list = h->theta_list.as<int32_t>();
             }
             // The quick test's thread pass BESIDE the theta stage (round 5).  On a level that keeps no dictionaries, k_kkt_thread's box
@@ -2310,9 +2325,11 @@ static int level_run_impl(mpc_handle *h, int32_t gen_children, int32_t flags, mp
                 const long long sd_e = (long long)nxc_e * h->Pf.n_d0r, si_e = dict_ints(h->Pf.n_d0r, nxc_e, h->n_c);
                 const bool will_store = gen_children && (double)nn * (sd_e * 8.0 + si_e * 4.0) / 1e9 <= h->dict_budget_gb;
                 if (!will_store) {
-                    { int rcs = compact(ST_NEEDX, ST_NEEDX_SING, nullptr, dcnt + 10); if (rcs) return rcs; }
-                    HIP_TRY(h, h->xq_list.ensure(nn * sizeof(int32_t), st));
-                    std::swap(h->xq_list, h->retry_list);
+                    if (!kkt_listed) {      // (else k_kkt_thread has listed them in xq_list, length in dcnt[10])
+                        { int rcs = compact(ST_NEEDX, ST_NEEDX_SING, nullptr, dcnt + 10); if (rcs) return rcs; }
+                        HIP_TRY(h, h->xq_list.ensure(nn * sizeof(int32_t), st));
+                        std::swap(h->xq_list, h->retry_list);
+                    }
                     DictCache dq{};
                     dq.stride_d = sd_e; dq.stride_i = si_e;
                     dq.parent_slot = h->parent_slot.as<int32_t>();
