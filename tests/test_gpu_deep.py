@@ -500,7 +500,8 @@ def test_one_thread_pass_and_one_step_plans_forced_on_every_level(name, monkeypa
     # round-5 paths -- the repeat must not search the previous frontier for other parents (that run's children have overwritten it;
     # found in round 5 when doubtful candidates began to send small levels to the repeat); fourth: the small path in its round-4 form
     for env in ({}, {'MPC_NO_SMALLPATH': '1', 'MPC_XQT_MIN': '1', 'MPC_X1_MIN': '1'},
-                {'MPC_TEST_SMALL_FALLBACK': '1', 'MPC_XQT_MIN': '1', 'MPC_X1_MIN': '1'}, {'MPC_NO_SMALL_FUSE': '1'}):
+                {'MPC_TEST_SMALL_FALLBACK': '1', 'MPC_XQT_MIN': '1', 'MPC_X1_MIN': '1'}, {'MPC_NO_SMALL_FUSE': '1'},
+                {'MPC_NO_SMALLPATH': '1', 'MPC_XQT_MIN': '1', 'MPC_X1_MIN': '1', 'MPC_NO_KKT_LISTS': '1'}):      # (fifth: work lists by compaction instead of k_kkt_thread's own)
         with monkeypatch.context() as m:
             for key, val in env.items():
                 m.setenv(key, val)
