@@ -943,6 +943,7 @@ struct XqPlan {
     int32_t *rest[3], *rest_n[3];
     const int32_t *pre1, *pre2;
     int n_pre1, n_pre2;
+    const int32_t *n_pre1_dev, *n_pre2_dev;   // != nullptr: the lengths are read from device memory (the stage is queued before the host knows them)
 };
 // One wavefront = 64 candidates at a time, lanes always full: a candidate its generating parent leaves open goes into the wavefront's
 // queue (LDS) with "try 1"; whenever 64 are queued (or the input has run out) the wavefront takes them up again, each lane with its
@@ -955,6 +956,8 @@ MPC_GLOBAL void MPC_LB(64) k_xq_thread(const DevProblem *__restrict__ Pg, const 
     const int nv = P.n_x + P.n_t, mr = P.n_d0r, ncol = P.n_d0c + 1, lane = threadIdx.x, km = k - 1;
     if (dc.n_list_dev) n_list = *dc.n_list_dev;
     const bool plan = pl.x1_list != nullptr;
+    if (pl.n_pre1_dev) pl.n_pre1 = *pl.n_pre1_dev;
+    if (pl.n_pre2_dev) pl.n_pre2 = *pl.n_pre2_dev;
     const int n_pre = plan ? pl.n_pre1 + pl.n_pre2 : 0;
     const long long n_items = (long long)n_pre + n_list;
     const int max_try = (alt.tries > 0 && alt.n_prev > 0 && k >= 2) ? min(alt.tries, km - P.n_eq) : 0;   // tries 1..max_try leave out position km - t

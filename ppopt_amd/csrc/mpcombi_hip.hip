@@ -303,6 +303,11 @@ struct mpc_handle {
     bool no_smallpath = false;       // MPC_NO_SMALLPATH=1: levels of any size take the classic path with its host round trips (A/B)
     long long smallpath_max = 4096;  // MPC_SMALLPATH_MAX: largest level (candidates) that runs without host round trips (measured: config 4 is
                                      // fastest with 1,024-4,096 -- a level of 15,691 candidates prefers the classic path, which streams its records)
+    bool x_first = true;             // MPC_NO_X_FIRST=1: the (x,theta) stage of a storing level waits for the region stage's launch as in round 4 (A/B)
+    long long x_first_min = 4096, x_first_max = 65536;   // MPC_X_FIRST_MIN / _MAX: levels (candidates) whose (x,theta) stage is queued before the read-back.  Measured, config 4: level 3
+                                     // (9,880 candidates) 0.72 -> 0.67 ms; level 4 (181 k) 1.51 -> 1.58: there the stage fills the GPU before the region kernel's long wavefronts are placed
+                                     // (region kernel 0.48 -> 0.60 ms, the stage itself 0.93 -> 1.03) -- large levels keep the region launch first
+    hipEvent_t ev_part = nullptr;
     bool no_kkt_lists = false;       // MPC_NO_KKT_LISTS=1: the work lists behind k_kkt_thread by compaction of the status array (round 4; A/B, tests)
     bool no_small_fuse = false;      // MPC_NO_SMALL_FUSE=1: the small path with its round-4 launches (doubtful candidates re-solved in place; A/B, tests)
     long long n_smallpath_doubtful = 0;   // small levels repeated because the fused form met a doubtful candidate
@@ -612,6 +617,7 @@ static int create_fill(const mpc_problem *p, int32_t device, void *stream, mpc_h
     HIP_TRY(nullptr, pooled_event(&h->ev_fork, false));
     HIP_TRY(nullptr, pooled_event(&h->ev_join, false));
     HIP_TRY(nullptr, pooled_event(&h->ev_xfork, false));
+    HIP_TRY(nullptr, pooled_event(&h->ev_part, false));
     HIP_TRY(nullptr, pooled_event(&h->ev_xjoin, false));
     HIP_TRY(nullptr, pooled_stream(&h->stream3));
     HIP_TRY(nullptr, pooled_event(&h->ev_rfork, false));
@@ -641,6 +647,9 @@ static int create_fill(const mpc_problem *p, int32_t device, void *stream, mpc_h
     { const char *ev = std::getenv("MPC_TEST_LATE"); h->test_late = ev ? std::atoi(ev) : 0; }
     { const char *ev = std::getenv("MPC_TEST_SPARE"); h->test_spare = ev ? std::atoi(ev) : 0; }
     { const char *ev = std::getenv("MPC_NO_KEV"); h->no_kev = ev && ev[0] == '1'; h->timing = !h->no_kev; }
+    { const char *ev = std::getenv("MPC_NO_X_FIRST"); h->x_first = !(ev && ev[0] == '1'); }
+    { const char *ev = std::getenv("MPC_X_FIRST_MIN"); if (ev) h->x_first_min = std::atoll(ev); }
+    { const char *ev = std::getenv("MPC_X_FIRST_MAX"); if (ev) h->x_first_max = std::atoll(ev); }
     { const char *ev = std::getenv("MPC_NO_KKT_LISTS"); h->no_kkt_lists = ev && ev[0] == '1'; }
     { const char *ev = std::getenv("MPC_NO_SMALL_FUSE"); h->no_small_fuse = ev && ev[0] == '1'; }
     { const char *ev = std::getenv("MPC_NO_SMALLPATH"); h->no_smallpath = ev && ev[0] == '1'; }
@@ -1090,6 +1099,7 @@ int mpc_destroy(mpc_handle *h) {
     return_event(h->ev_fork, false);
     return_event(h->ev_join, false);
     return_event(h->ev_xfork, false);
+    return_event(h->ev_part, false);
     return_event(h->ev_xjoin, false);
     return_event(h->ev_rfork, false);
     return_event(h->ev_rjoin, false);
@@ -2063,12 +2073,12 @@ static int level_run_impl(mpc_handle *h, int32_t gen_children, int32_t flags, mp
         // the lists are h->part_lists + c * n, their lengths come back in counts[]
         const int nb1024 = (int)((n + 1023) / 1024);
         // deferred: the counts go to the pinned words [12..15] and nobody waits here (the caller reads them after a later synchronisation)
-        auto partition = [&](std::initializer_list<std::pair<int, int>> classes, int32_t counts[PART_CLASSES], bool deferred = false) -> int {
+        auto partition = [&](std::initializer_list<std::pair<int, int>> classes, int32_t counts[PART_CLASSES], bool deferred = false, int32_t *tot_dev_mem = nullptr) -> int {
             unsigned long long spec = ~0ull;
             for (const auto &sc : classes) spec = (spec & ~(15ull << (4 * sc.first))) | ((unsigned long long)sc.second << (4 * sc.first));
             HIP_TRY(h, h->part_counts.ensure((size_t)PART_CLASSES * nb1024 * sizeof(int32_t), st));
             HIP_TRY(h, h->part_lists.ensure((size_t)PART_CLASSES * nn * sizeof(int32_t), st));
-            int32_t *tot = deferred ? total + 12 : total;
+            int32_t *tot = tot_dev_mem ? tot_dev_mem : (deferred ? total + 12 : total);   // tot_dev_mem: the lengths stay in device memory (the caller publishes them)
             if (small) {
                 hipLaunchKernelGGL(k_partition_small, dim3(1), dim3(1024), 0, st, h->status.as<uint8_t>(), (int)n, spec, h->part_lists.as<int32_t>(), (long long)n, tot);
             } else {
@@ -2378,31 +2388,6 @@ static int level_run_impl(mpc_handle *h, int32_t gen_children, int32_t flags, mp
                 n_theta_items = n_theta;
                 HIP_TRY(h, hipGetLastError());
             }
-            // One partition after the theta stage: [0] numerically doubtful (status 7), [1] feasible and [2] optimal (decided
-            // in theta space; they only need a dictionary for their children), [3] feasibility still open.
-            int32_t cntA[PART_CLASSES] = {0, 0, 0, 0};
-            if (early_xq) {
-                // The thread pass is still rewriting the statuses of ITS candidates (NEEDX -> feasible / infeasible / singular) on the second
-                // stream: this partition asks only for the two classes it never touches -- doubtful and optimal candidates of the theta
-                // stage --, so that the region stage can start beside it; the open candidates are listed when the pass has ended (below).
-                { int rcs = partition({{ST_RETRY, 0}, {ST_OPT_PENDING, 2}}, cntA); if (rcs) return rcs; }
-                cntA[3] = (int32_t)std::min<long long>(n, 0x7fffffffLL);     // a bound, for the decisions that follow; the count comes after the join
-            } else { int rcs = partition({{ST_RETRY, 0}, {ST_FEASIBLE, 1}, {ST_OPT_PENDING, 2}, {ST_NEEDX, 3}, {ST_NEEDX_SING, 3}}, cntA); if (rcs) return rcs; }
-            // The doubtful candidates are re-solved by the LDS engine, which can refactorise its basis: a few hundred
-            // long-running wavefronts.  They run on the side stream while the (x,theta) stage fills the GPU; their results are
-            // applied to the status array after the join.
-            const int32_t n_early = cntA[0];
-            if (n_early > 0) {
-                HIP_TRY(h, h->vretry_list.ensure(nn * sizeof(int32_t), st));
-                HIP_TRY(h, h->status_tmp.ensure(nn, st));
-                HIP_TRY(h, hipMemcpyAsync(h->vretry_list.p, part_list(0), (size_t)n_early * sizeof(int32_t), hipMemcpyDeviceToDevice, st));
-                HIP_TRY(h, hipEventRecord(h->ev_fork, st));
-                HIP_TRY(h, hipStreamWaitEvent(h->stream2, h->ev_fork, 0));
-                hipLaunchKernelGGL(k_verdict, dim3((unsigned)std::min<long long>(n_early, h->grid_v)), dim3(64), h->lds_v, h->stream2, h->Pv,
-                                   h->frontier.as<int32_t>(), (long long)n_early, k, h->status_tmp.as<uint8_t>(), ctr, h->vretry_list.as<int32_t>(), (const int32_t *)nullptr);
-                HIP_TRY(h, hipGetLastError());
-                HIP_TRY(h, hipEventRecord(h->ev_join, h->stream2));
-            }
             // ---- (x,theta) stage with the dictionary cache -------------------------------------------------------------
             const int nxc = h->fast_x >= 2 ? 32 : 16;
             h->dict_stride_d = (long long)nxc * h->Pf.n_d0r;   // column-major tableau
@@ -2424,6 +2409,109 @@ static int level_run_impl(mpc_handle *h, int32_t gen_children, int32_t flags, mp
                 dc.cur_d = h->dict_d[h->dict_cur].as<double>(); dc.cur_i = h->dict_i[h->dict_cur].as<int32_t>();
                 dc.stored = h->dict_stored[h->dict_cur].as<uint8_t>();
                 h->storing = true;
+            }
+            // The (x,theta) stage of a level that keeps dictionaries, in its one-step-plan form, needs no count from the host: its lists
+            // come from the partition below, their lengths stay in device memory (dcnt[28..31]), its launches are sized by the bound n.
+            // Round 5 (`x_first`): it is queued BEHIND THE PARTITION AT ONCE, and only then does the host wait for the counts that size
+            // the region stage -- until then the stage waited ~0.1 ms per large level for that read-back and the region launch's host work
+            // (tools/timeline.sh: 110 us between the partition and the plan pass on level 4 of config 4).
+            bool x_done = false;
+            auto launch_plans = [&](const int32_t *needx_list_, int n_needx_, long long n_bound, const int32_t *n_needx_dev, const int32_t *n_pre1_dev, const int32_t *n_pre2_dev) -> int {
+                // One-step plans (round 5).  Every candidate that needs a dictionary is asked by ONE THREAD whether a parent's record is
+                // one known step away (k_xq_thread in plan mode: the generating parent, then the candidate's other parents); k_x1 then
+                // streams that record through the step -- no tableau in registers, no pricing, no ratio test --, and only what has no
+                // such plan goes through the register simplex k_x2 as before, from its generating parent.
+                { int rcq = prep_flush(); if (rcq) return rcq; }
+                HIP_TRY(h, h->x1_buf.ensure(6 * nn * sizeof(int32_t), st));
+                int32_t *xb = h->x1_buf.as<int32_t>();
+                XqPlan pl{};
+                pl.plan_slot = xb; pl.plan_step = xb + nn; pl.x1_list = xb + 2 * nn; pl.x1_n = dcnt + 12;
+                for (int sg = 0; sg < 3; ++sg) { pl.rest[sg] = xb + (3 + sg) * nn; pl.rest_n[sg] = dcnt + 13 + sg; }
+                pl.pre1 = dc.pre1; pl.n_pre1 = dc.n_pre1; pl.pre2 = dc.pre2; pl.n_pre2 = dc.n_pre2;
+                pl.n_pre1_dev = n_pre1_dev; pl.n_pre2_dev = n_pre2_dev;
+                XqAlt alt{};
+                if (h->x1 >= 2 && h->n_prev > 0 && h->n_prev <= 0x7fffffffLL && k >= 2 &&
+                    h->children.cap >= (size_t)h->n_prev * (k - 1) * sizeof(int32_t) && h->dict_stored[1 - h->dict_cur].cap >= (size_t)h->n_prev) {
+                    alt.prev_frontier = h->children.as<int32_t>(); alt.prev_stored = h->dict_stored[1 - h->dict_cur].as<uint8_t>();
+                    alt.n_prev = (int)h->n_prev; alt.tries = MPC_MAX_NC;
+                }
+                DictCache dq = dc;
+                dq.n_list_dev = n_needx_dev;
+                const DevProblem *pfx = h->pf_dev.as<DevProblem>();
+                const int32_t *frx = h->frontier.as<int32_t>();
+                uint8_t *stx = h->status.as<uint8_t>();
+                const unsigned gt = (unsigned)std::min<long long>((n_bound + 63) / 64, (long long)h->n_cu * h->xqt_wpc);
+                if (h->timing) HIP_TRY(h, hipEventRecord(h->kev[10], st));
+                hipLaunchKernelGGL(k_xq_thread, dim3(gt), dim3(64), 0, st, pfx, frx, k, needx_list_, n_needx_, stx, ctr, dq, nxc, alt, pl);
+                if (h->timing) HIP_TRY(h, hipEventRecord(h->kev[11], st));
+                xq_thread_timed = true;
+                const unsigned g1 = (unsigned)std::min<long long>(n_bound, (long long)h->n_cu * h->x1_wpc);
+                if (h->timing) HIP_TRY(h, hipEventRecord(h->kev[12], st));
+                if (h->fast_x & 1) hipLaunchKernelGGL((k_x1<2>), dim3(g1), dim3(64), 0, st, pfx, pl.x1_list, pl.x1_n, ctr, dc, nxc, pl.plan_slot, pl.plan_step);
+                else hipLaunchKernelGGL((k_x1<1>), dim3(g1), dim3(64), 0, st, pfx, pl.x1_list, pl.x1_n, ctr, dc, nxc, pl.plan_slot, pl.plan_step);
+                if (h->timing) HIP_TRY(h, hipEventRecord(h->kev[13], st));
+                HIP_TRY(h, hipGetLastError());
+                // what is left: the register simplex, list lengths on the device
+                DictCache dr = dc;
+                dr.pre1 = pl.rest[0]; dr.n_pre1 = 0; dr.n_pre1_dev = pl.rest_n[0];
+                dr.pre2 = pl.rest[1]; dr.n_pre2 = 0; dr.n_pre2_dev = pl.rest_n[1];
+                dr.n_list_dev = pl.rest_n[2]; dr.chunk = 0;
+                const long long grid_r = (long long)h->n_cu * std::min<long long>(4, h->x2_wpc);
+                const dim3 gg((unsigned)std::max<long long>(1, std::min<long long>(n_bound, grid_r))), bb(64);
+                switch (h->fast_x) {
+                    case 0: hipLaunchKernelGGL((k_x2<16, 1>), gg, bb, 0, st, pfx, frx, k, pl.rest[2], n_needx_, stx, ctr, dr); break;
+                    case 1: hipLaunchKernelGGL((k_x2<16, 2>), gg, bb, 0, st, pfx, frx, k, pl.rest[2], n_needx_, stx, ctr, dr); break;
+                    case 2: hipLaunchKernelGGL((k_x2<32, 1>), gg, bb, 0, st, pfx, frx, k, pl.rest[2], n_needx_, stx, ctr, dr); break;
+                    default: hipLaunchKernelGGL((k_x2<32, 2>), gg, bb, 0, st, pfx, frx, k, pl.rest[2], n_needx_, stx, ctr, dr); break;
+                }
+                HIP_TRY(h, hipGetLastError());
+                x1_ran = true;
+                return MPC_OK;
+            };
+            // One partition after the theta stage: [0] numerically doubtful (status 7), [1] feasible and [2] optimal (decided
+            // in theta space; they only need a dictionary for their children), [3] feasibility still open.
+            int32_t cntA[PART_CLASSES] = {0, 0, 0, 0};
+            const bool x_first = lean && !early_xq && h->x_first && h->storing && dc.parent_slot && h->x1 > 0 && n >= std::max<long long>(h->x1_min, h->x_first_min) && n <= h->x_first_max &&
+                                 n <= 0x7fffffffLL && !(flags & MPC_LEVEL_GRAPH);
+            if (x_first) {
+                { int rcs = partition({{ST_RETRY, 0}, {ST_FEASIBLE, 1}, {ST_OPT_PENDING, 2}, {ST_NEEDX, 3}, {ST_NEEDX_SING, 3}}, cntA, true, dcnt + 28); if (rcs) return rcs; }
+                hipLaunchKernelGGL(k_publish_words, dim3(1), dim3(64), 0, st, reinterpret_cast<const unsigned int *>(dcnt + 28), reinterpret_cast<unsigned int *>(h->tot_dev + 12), PART_CLASSES);
+                HIP_TRY(h, hipGetLastError());
+                HIP_TRY(h, hipEventRecord(h->ev_part, st));
+                dc.pre1 = part_list(1); dc.pre2 = part_list(2);
+                if (h->timing) HIP_TRY(h, hipEventRecord(h->kev[2], st));
+                { int rcs = launch_plans(part_list(3), (int)n, n, dcnt + 31, dcnt + 29, dcnt + 30); if (rcs) return rcs; }
+                if (h->timing) HIP_TRY(h, hipEventRecord(h->kev[3], st));
+                kernel_timed[1] = true;
+                x_done = true;
+                HIP_TRY(h, hipEventSynchronize(h->ev_part));      // the counts that size the region stage (and the doubtful candidates' side stream)
+                for (int c = 0; c < PART_CLASSES; ++c) cntA[c] = h->tot_host[12 + c];
+            } else if (early_xq) {
+                // The thread pass is still rewriting the statuses of ITS candidates (NEEDX -> feasible / infeasible / singular) on the second
+                // stream: this partition asks only for the two classes it never touches -- doubtful and optimal candidates of the theta
+                // stage --, so that the region stage can start beside it; the open candidates are listed when the pass has ended (below).
+                { int rcs = partition({{ST_RETRY, 0}, {ST_OPT_PENDING, 2}}, cntA); if (rcs) return rcs; }
+                cntA[3] = (int32_t)std::min<long long>(n, 0x7fffffffLL);     // a bound, for the decisions that follow; the count comes after the join
+            } else { int rcs = partition({{ST_RETRY, 0}, {ST_FEASIBLE, 1}, {ST_OPT_PENDING, 2}, {ST_NEEDX, 3}, {ST_NEEDX_SING, 3}}, cntA); if (rcs) return rcs; }
+            // The doubtful candidates are re-solved by the LDS engine, which can refactorise its basis: a few hundred
+            // long-running wavefronts.  They run on the side stream while the (x,theta) stage fills the GPU; their results are
+            // applied to the status array after the join.
+            const int32_t n_early = cntA[0];
+            if (n_early > 0) {
+                HIP_TRY(h, h->vretry_list.ensure(nn * sizeof(int32_t), st));
+                HIP_TRY(h, h->status_tmp.ensure(nn, st));
+                if (x_done) {   // (the main stream already carries the (x,theta) stage: the side stream starts behind the partition's event)
+                    HIP_TRY(h, hipStreamWaitEvent(h->stream2, h->ev_part, 0));
+                    HIP_TRY(h, hipMemcpyAsync(h->vretry_list.p, part_list(0), (size_t)n_early * sizeof(int32_t), hipMemcpyDeviceToDevice, h->stream2));
+                } else {
+                    HIP_TRY(h, hipMemcpyAsync(h->vretry_list.p, part_list(0), (size_t)n_early * sizeof(int32_t), hipMemcpyDeviceToDevice, st));
+                    HIP_TRY(h, hipEventRecord(h->ev_fork, st));
+                    HIP_TRY(h, hipStreamWaitEvent(h->stream2, h->ev_fork, 0));
+                }
+                hipLaunchKernelGGL(k_verdict, dim3((unsigned)std::min<long long>(n_early, h->grid_v)), dim3(64), h->lds_v, h->stream2, h->Pv,
+                                   h->frontier.as<int32_t>(), (long long)n_early, k, h->status_tmp.as<uint8_t>(), ctr, h->vretry_list.as<int32_t>(), (const int32_t *)nullptr);
+                HIP_TRY(h, hipGetLastError());
+                HIP_TRY(h, hipEventRecord(h->ev_join, h->stream2));
             }
             // The region stage needs the theta stage's verdicts only (no later stage turns a candidate optimal, except the
             // re-solved doubtful ones): it starts now on its own stream and runs under the (x,theta) stage -- a few thousand
@@ -2590,56 +2678,13 @@ static int level_run_impl(mpc_handle *h, int32_t gen_children, int32_t flags, mp
                 n_needx = n_left;   // lean: the bound (everything the quick test was given)
                 needx_list = h->retry_list.as<int32_t>();
             }
-            if (n_needx + dc.n_pre1 + dc.n_pre2 > 0) {   // feasibility for the candidates left open (+ dictionary-only items)
+            if (x_done) n_x_items = n_needx + dc.n_pre1 + dc.n_pre2;      // (queued behind the partition, above)
+            else if (n_needx + dc.n_pre1 + dc.n_pre2 > 0) {   // feasibility for the candidates left open (+ dictionary-only items)
                 if (h->timing) HIP_TRY(h, hipEventRecord(h->kev[2], st));
                 int rcs = MPC_OK;
                 const long long n_dict = (long long)n_needx + dc.n_pre1 + dc.n_pre2;
                 if (h->storing && dc.parent_slot && h->x1 > 0 && !xq_lean && n_dict >= h->x1_min) {
-                    // One-step plans (round 5).  Every candidate that needs a dictionary is asked by ONE THREAD whether a parent's record is
-                    // one known step away (k_xq_thread in plan mode: the generating parent, then the candidate's other parents); k_x1 then
-                    // streams that record through the step -- no tableau in registers, no pricing, no ratio test --, and only what has no
-                    // such plan goes through the register simplex k_x2 as before, from its generating parent.
-                    { int rcq = prep_flush(); if (rcq) return rcq; }
-                    HIP_TRY(h, h->x1_buf.ensure(6 * nn * sizeof(int32_t), st));
-                    int32_t *xb = h->x1_buf.as<int32_t>();
-                    XqPlan pl{};
-                    pl.plan_slot = xb; pl.plan_step = xb + nn; pl.x1_list = xb + 2 * nn; pl.x1_n = dcnt + 12;
-                    for (int sg = 0; sg < 3; ++sg) { pl.rest[sg] = xb + (3 + sg) * nn; pl.rest_n[sg] = dcnt + 13 + sg; }
-                    pl.pre1 = dc.pre1; pl.n_pre1 = dc.n_pre1; pl.pre2 = dc.pre2; pl.n_pre2 = dc.n_pre2;
-                    XqAlt alt{};
-                    if (h->x1 >= 2 && h->n_prev > 0 && h->n_prev <= 0x7fffffffLL && k >= 2 &&
-                        h->children.cap >= (size_t)h->n_prev * (k - 1) * sizeof(int32_t) && h->dict_stored[1 - h->dict_cur].cap >= (size_t)h->n_prev) {
-                        alt.prev_frontier = h->children.as<int32_t>(); alt.prev_stored = h->dict_stored[1 - h->dict_cur].as<uint8_t>();
-                        alt.n_prev = (int)h->n_prev; alt.tries = MPC_MAX_NC;
-                    }
-                    DictCache dq = dc;
-                    dq.n_list_dev = nullptr;
-                    const unsigned gt = (unsigned)std::min<long long>((n_dict + 63) / 64, (long long)h->n_cu * h->xqt_wpc);
-                    if (h->timing) HIP_TRY(h, hipEventRecord(h->kev[10], st));
-                    hipLaunchKernelGGL(k_xq_thread, dim3(gt), dim3(64), 0, st, pf, fr, k, needx_list, n_needx, stp, ctr, dq, nxc, alt, pl);
-                    if (h->timing) HIP_TRY(h, hipEventRecord(h->kev[11], st));
-                    xq_thread_timed = true;
-                    const unsigned g1 = (unsigned)std::min<long long>(n_dict, (long long)h->n_cu * h->x1_wpc);
-                    if (h->timing) HIP_TRY(h, hipEventRecord(h->kev[12], st));
-                    if (h->fast_x & 1) hipLaunchKernelGGL((k_x1<2>), dim3(g1), dim3(64), 0, st, pf, pl.x1_list, pl.x1_n, ctr, dc, nxc, pl.plan_slot, pl.plan_step);
-                    else hipLaunchKernelGGL((k_x1<1>), dim3(g1), dim3(64), 0, st, pf, pl.x1_list, pl.x1_n, ctr, dc, nxc, pl.plan_slot, pl.plan_step);
-                    if (h->timing) HIP_TRY(h, hipEventRecord(h->kev[13], st));
-                    HIP_TRY(h, hipGetLastError());
-                    // what is left: the register simplex, list lengths on the device
-                    DictCache dr = dc;
-                    dr.pre1 = pl.rest[0]; dr.n_pre1 = 0; dr.n_pre1_dev = pl.rest_n[0];
-                    dr.pre2 = pl.rest[1]; dr.n_pre2 = 0; dr.n_pre2_dev = pl.rest_n[1];
-                    dr.n_list_dev = pl.rest_n[2]; dr.chunk = 0;
-                    const long long grid_r = (long long)h->n_cu * std::min<long long>(4, h->x2_wpc);
-                    const dim3 gg((unsigned)std::max<long long>(1, std::min<long long>(n_dict, grid_r))), bb(64);
-                    switch (h->fast_x) {
-                        case 0: hipLaunchKernelGGL((k_x2<16, 1>), gg, bb, 0, st, pf, fr, k, pl.rest[2], (int)n_needx, stp, ctr, dr); break;
-                        case 1: hipLaunchKernelGGL((k_x2<16, 2>), gg, bb, 0, st, pf, fr, k, pl.rest[2], (int)n_needx, stp, ctr, dr); break;
-                        case 2: hipLaunchKernelGGL((k_x2<32, 1>), gg, bb, 0, st, pf, fr, k, pl.rest[2], (int)n_needx, stp, ctr, dr); break;
-                        default: hipLaunchKernelGGL((k_x2<32, 2>), gg, bb, 0, st, pf, fr, k, pl.rest[2], (int)n_needx, stp, ctr, dr); break;
-                    }
-                    HIP_TRY(h, hipGetLastError());
-                    x1_ran = true;
+                    rcs = launch_plans(needx_list, n_needx, n_dict, nullptr, nullptr, nullptr);
                 } else rcs = launch_x(needx_list, n_needx, dc);
                 if (rcs) return rcs;
                 if (h->timing) HIP_TRY(h, hipEventRecord(h->kev[3], st));

@@ -501,7 +501,8 @@ def test_one_thread_pass_and_one_step_plans_forced_on_every_level(name, monkeypa
     # found in round 5 when doubtful candidates began to send small levels to the repeat); fourth: the small path in its round-4 form
     for env in ({}, {'MPC_NO_SMALLPATH': '1', 'MPC_XQT_MIN': '1', 'MPC_X1_MIN': '1'},
                 {'MPC_TEST_SMALL_FALLBACK': '1', 'MPC_XQT_MIN': '1', 'MPC_X1_MIN': '1'}, {'MPC_NO_SMALL_FUSE': '1'},
-                {'MPC_NO_SMALLPATH': '1', 'MPC_XQT_MIN': '1', 'MPC_X1_MIN': '1', 'MPC_NO_KKT_LISTS': '1'}):      # (fifth: work lists by compaction instead of k_kkt_thread's own)
+                {'MPC_NO_SMALLPATH': '1', 'MPC_XQT_MIN': '1', 'MPC_X1_MIN': '1', 'MPC_NO_KKT_LISTS': '1'},
+                {'MPC_NO_SMALLPATH': '1', 'MPC_XQT_MIN': '1', 'MPC_X1_MIN': '1', 'MPC_X_FIRST_MIN': '1', 'MPC_X_FIRST_MAX': '1000000000'}):      # (sixth: the (x,theta) stage queued before the region read-back on every storing level)      # (fifth: work lists by compaction instead of k_kkt_thread's own)
         with monkeypatch.context() as m:
             for key, val in env.items():
                 m.setenv(key, val)
