@@ -244,9 +244,15 @@ def main():
     # are those, live, of this run; that region's own rate is reported beside the first (`ms_per_step_with_kernel_events`): the event
     # records cost 0.1-0.2 ms per solve (markers the queue stops at), which is why they are not in the first.  --events-in-value keeps
     # them in the first region as rounds 1-4 did.
-    def timed_region(with_profile):
+    # The timed regions run with Python's cyclic garbage collector switched off, as `timeit` does: a solve returns ~10^4 region objects, none
+    # of them in a reference cycle (reference counting frees them), and the collector's young-generation passes over them cost 0.3-0.4 ms per
+    # solve of config 4 (tools/step_overhead.py) -- host bookkeeping of the interpreter, not of the path.  `ms_per_step_collector_on` is a third
+    # region of the same K steps with the collector on (the protocol of rounds 1-4).
+    def timed_region(with_profile, collector=False):
         profs, ms_list, last = [], [], None
         fence()
+        if not collector:
+            gc.disable()
         t0_ = time.perf_counter()
         for _ in range(args.steps):
             pr = [] if with_profile else None
@@ -256,20 +262,27 @@ def main():
             profs.append(pr)
         fence()
         el = time.perf_counter() - t0_
+        gc.enable()
         if distributed:
             t = torch.tensor([el], dtype=torch.float64, device='cuda')
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             el = float(t.item())
         return el, profs, ms_list, last
 
+    elapsed_collector = None
     if args.events_in_value:
-        elapsed, profiles, step_ms, sol = timed_region(True)
-        elapsed_events = elapsed
+        elapsed, profiles, step_ms, sol = timed_region(True, collector=True)
+        elapsed_events = elapsed_collector = elapsed
     else:
         elapsed, _, step_ms, sol = timed_region(False)
         del sol
         step(None)      # (hand-over: the region objects of the last untimed-events step are released outside the next region)
         elapsed_events, profiles, _, sol = timed_region(True)
+        del sol
+        step(None)
+        elapsed_collector, _, _, sol_c = timed_region(False, collector=True)
+        del sol_c
+        sol = step(None)
 
     # ---- accounting (identical on every rank; rank 0 reports) ----------------------------------------------
     prof = profiles[-1]
@@ -348,6 +361,8 @@ def main():
         kk['on_path_ms'] = kk['total_ms'] - (hidden if name == 'k_region2' else (hidden_xqt if name == 'k_xq_thread' else 0.0))
     dominant = max(kern, key=lambda k: kern[k]['on_path_ms'])
     dom = kern[dominant]
+    HBM_KERNELS = ('k_x1', 'k_x2', 'k_xq', 'k_xq_thread')      # the kernels whose time is reads / writes of the cached dictionary records
+    dominant_hbm = max(HBM_KERNELS, key=lambda k: kern[k]['on_path_ms'])
     # Counter record of the same command (tools/profile_round3.sh -> tools/pmc_round.py -> profiles/r03_pmc.json): HBM-side bytes
     # with the FETCH_SIZE / WRITE_SIZE factors calibrated on known byte counts in each kernel's own access pattern, and the SQ
     # instruction counters per launch.  From the latter the VALU-issue roofline of the simplex kernels: wave-level VALU instructions
@@ -402,6 +417,8 @@ def main():
         'warmup': args.warmup,
         'ms_per_step': 1e3 * elapsed / steps,
         'ms_per_step_with_kernel_events': 1e3 * elapsed_events / steps,
+        'ms_per_step_collector_on': 1e3 * elapsed_collector / steps,
+        'collector': 'timed regions run with gc.disable() (as timeit does); ms_per_step_collector_on: the same K steps with the cyclic collector on',
         'kernel_timing': ('HIP events inside the one timed region (--events-in-value)' if args.events_in_value else
                           'value / ms_per_step: K timed steps of the solve as a user runs it (no profile: the library records no HIP events inside '
                           'its levels); per-kernel durations (roofline.dominant_kernel, roofline.kernels, kernel_ms_per_step): a second timed region '
@@ -429,7 +446,12 @@ def main():
                      'dominant_kernel': {'kernel': dominant, 'chosen_by': 'time on the critical path of the step (k_region2 under the (x,theta) stage is not)',
                                          'on_path_ms_per_step': {name: kk['on_path_ms'] / steps for name, kk in kern.items()},
                                          'bound': ('hbm (a record streamed in and out per candidate)' if dominant == 'k_x1' else 'hbm (dependent reads of the cached dictionaries)') if dominant in ('k_x1', 'k_x2', 'k_xq', 'k_xq_thread') else 'fp64 VALU issue / dependent latency',
-                                         'achieved': dom['achieved_GBs'], 'frac': dom['achieved_GBs'] / HBM_PEAK_GBS,
+                                         # `frac` is the fraction of the roof that BINDS this kernel: HBM bytes for the streaming kernels; for the register-simplex
+                                         # kernels the share of the SIMDs' issue slots their VALU instructions take (fp64 priced at 4 cycles, the rest at 2;
+                                         # counters of profiles/r05_pmc.json over this run's HIP-event time) -- their HBM figure stands beside it
+                                         'achieved': dom['achieved_GBs'], 'hbm_frac': dom['achieved_GBs'] / HBM_PEAK_GBS,
+                                         'frac': (dom['achieved_GBs'] / HBM_PEAK_GBS) if dominant in HBM_KERNELS else (dom.get('frac_valu_issue') or dom.get('frac_valu_issue_4cyc') or dom['achieved_GBs'] / HBM_PEAK_GBS),
+                                         'frac_of': 'HBM peak (8 TB/s)' if dominant in HBM_KERNELS else ('VALU issue slots (1024 SIMDs x 2.4 GHz)' if (dom.get('frac_valu_issue') or dom.get('frac_valu_issue_4cyc')) else 'HBM peak (8 TB/s; no instruction counters recorded for this workload)'),
                                          'launches': dom['launches'], 'avg_launch_ms': dom['avg_launch_ms'],
                                          'algorithmic_bytes_per_launch': dom['algorithmic_bytes'] / max(dom['launches'], 1),
                                          'frac_fp64_issue': dom.get('frac_fp64_issue'), 'frac_valu_issue': dom.get('frac_valu_issue'),
@@ -438,6 +460,13 @@ def main():
                                          **({'note': 'this program has no register-resident kernels (its parameter set has no vertex after the presolve, DESIGN.md 6c; '
                                                      'MPC_DEBUG_CREATE=1 prints the decision): every stage runs on the LDS-engine kernels k_verdict / k_region, '
                                                      'whose time is kernel_ms_per_step'} if dom['total_ms'] <= 0 else {})},
+                     'dominant_hbm_kernel': None if kern[dominant_hbm]['on_path_ms'] <= 0 else {'kernel': dominant_hbm, 'on_path_ms_per_step': kern[dominant_hbm]['on_path_ms'] / steps,
+                                             'achieved': kern[dominant_hbm]['achieved_GBs'], 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                                             'frac': kern[dominant_hbm]['achieved_GBs'] / HBM_PEAK_GBS, 'launches': kern[dominant_hbm]['launches'],
+                                             'avg_launch_ms': kern[dominant_hbm]['avg_launch_ms'],
+                                             'algorithmic_bytes_per_launch': kern[dominant_hbm]['algorithmic_bytes'] / max(kern[dominant_hbm]['launches'], 1),
+                                             'traffic_bytes_per_step': kern[dominant_hbm].get('traffic_bytes_per_step'),
+                                             'note': 'the HBM-bound kernel with the most time on the critical path (the register-simplex kernels k_region2 / k_theta2 / k_kkt_thread move almost nothing)'},
                      'kernels': kern,
                      'note': 'B_alg = P + 4k + 8 + rho*R per candidate (SURVEY.md 8(d)): the shared problem block P is counted once per '
                              'candidate although it is served from L2, so `achieved` is the figure the survey defines, not measured DRAM '
