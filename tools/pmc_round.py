@@ -77,7 +77,16 @@ def calib(fetch_db, write_db):
     print(json.dumps(res, indent=1))
 
 
+def solves_in(db, fallback):
+    """solves of the profiled command = dispatches of k_root_frontier (one per solve); bench.py runs more than steps + warm-up solves since
+    round 5 (a second and third timed region, hand-over steps), so the count is taken from the trace itself"""
+    cur = sqlite3.connect(db).cursor()
+    row = cur.execute("select count(distinct dispatch_id) from counters_collection where kernel_name like '%k_root_frontier%'").fetchone()
+    return int(row[0]) if row and row[0] else fallback
+
+
 def bench(wl, solves, dbs):
+    solves = solves_in(dbs['fetch'], solves)
     d = load()
     cal = d.get('calibration', {})
     fac = lambda name, default: cal.get(name, {}).get('factor', default)

@@ -17,7 +17,7 @@ if [ ! -f $O/calib_done ]; then
   python3 $R/tools/rocpd_summary.py $CW $O/${tag}_calib_write.csv > /dev/null
   (cd $R && python3 tools/pmc_round.py calib $CF $CW > $O/${tag}_calibration.txt 2>&1) && touch $O/calib_done
 fi
-ARGS="bench.py --workload $wl --steps $steps --warmup $warm --cpu-sample 0 --locate 0 --mi 0 --complete 0"
+ARGS="bench.py --workload $wl --steps $steps --warmup $warm --cpu-sample 0 --locate 0 --mi 0 --complete 0 --events-in-value"   # (one timed region under the profiler: steps + warm-up solves)
 rm -rf /tmp/pk /tmp/pf /tmp/pw /tmp/psq /tmp/p64
 (cd $R && rocprofv3 --kernel-trace --stats -d /tmp/pk -o run -- python3 $ARGS > $O/pk_$wl.log 2>&1)
 (cd $R && rocprofv3 --pmc FETCH_SIZE -d /tmp/pf -o run -- python3 $ARGS > $O/pf_$wl.log 2>&1)
