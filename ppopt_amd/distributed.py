@@ -24,6 +24,8 @@ with RCCL (``HipLevelEngine``) and -- in the CPU tests -- on CPU tensors with gl
 """
 from typing import Dict, List, Optional
 
+import os
+
 import numpy
 import torch
 import torch.distributed as dist
@@ -161,6 +163,19 @@ class HipLevelEngine:
             torch.cuda.current_stream(self.device).synchronize()
             self.eng.pruned_add_device(m.data_ptr(), m.shape[0])
 
+    def frontier_tensor(self) -> torch.Tensor:
+        """The current frontier [n, k] as an int32 tensor on the engine's device (re-shard step)."""
+        return torch.from_numpy(self.eng.frontier_get()).to(self.device)
+
+    def set_frontier_tensor(self, cands: torch.Tensor):
+        """Replaces the frontier (the pruned list stays); the candidates start from the program's own vertex dictionary."""
+        cands = cands.to(torch.int32).contiguous()
+        if cands.is_cuda:
+            torch.cuda.current_stream(cands.device).synchronize()
+            self.eng.frontier_set_device(cands.data_ptr(), int(cands.shape[0]), int(cands.shape[1]))
+        else:
+            self.eng.frontier_set(cands.numpy())
+
     def advance(self):
         self.eng.frontier_advance()
 
@@ -279,6 +294,10 @@ def allgather_table(row: List[int], device, group=None) -> List[List[int]]:
     parts = [torch.empty_like(mine) for _ in range(world)]
     dist.all_gather(parts, mine, group=group)
     return torch.stack(parts).cpu().tolist()
+
+
+RESHARD = float(os.environ.get('MPC_RESHARD', '0') or 0)            # > 0: re-split the frontier evenly when the largest shard exceeds this multiple of the mean (e.g. 1.15)
+RESHARD_MIN = int(os.environ.get('MPC_RESHARD_MIN', '0') or 0)        # ... and the next frontier has at least this many candidates
 
 
 class DistributedLevelError(RuntimeError):
@@ -524,6 +543,23 @@ def _solve_distributed(engine, program=None, group=None, profile: Optional[List[
         if not gen_children or total['n_children'] == 0:
             break
         engine.advance()
+        if sharded and world > 1 and RESHARD > 0.0 and hasattr(engine, 'frontier_tensor'):
+            # Re-shard (a switch, off by default): the split is made once and the subtrees grow unevenly -- measured
+            # largest / mean shard 1.00-1.08 on configs 3 and 4, 1.19 on the late levels of a wide double integrator
+            # (profiles/r05_ranks_*.json).  When the next frontier's largest share exceeds RESHARD x the mean, the ranks' children are
+            # all-gathered (rank order: a deterministic list, no duplicates -- the subtrees are disjoint) and every rank takes an equal
+            # slice.  Every rank holds every pruned set (they are exchanged each level), so any rank can take any child; the children start
+            # from the program's own vertex dictionary on the next level (their parents' records stayed where they were made).
+            counts = [int(r_[1]) for r_ in table]
+            mean = sum(counts) / float(world)
+            if mean > 0 and max(counts) > RESHARD * mean and sum(counts) >= RESHARD_MIN:
+                parts = allgather_rows(engine.frontier_tensor(), counts, group)
+                allc = torch.cat([p_ for p_ in parts if p_.shape[0]], dim=0) if any(p_.shape[0] for p_ in parts) else parts[0]
+                n_all = int(allc.shape[0])
+                lo, hi = rank * n_all // world, (rank + 1) * n_all // world
+                engine.set_frontier_tensor(allc[lo:hi].contiguous())
+                if profile is not None and profile:
+                    profile[-1]['resharded'] = {'before': counts, 'after': [(r_ + 1) * n_all // world - r_ * n_all // world for r_ in range(world)]}
     if pending is not None:      # the last sharded level
         finish(pending)
     # the base active set, on every rank (one candidate; identical result everywhere)

@@ -96,6 +96,12 @@ class OracleLevelEngine:
         self.pruned.extend(self.new)
         self.cands = self.kids
 
+    def frontier_tensor(self):
+        return torch.from_numpy(numpy.ascontiguousarray(self.cands, dtype=numpy.int32))
+
+    def set_frontier_tensor(self, cands):
+        self.cands = numpy.ascontiguousarray(cands.numpy(), dtype=numpy.int32)
+
     def _unpack(self, status, d, i):
         from ppopt_amd.mp_solvers.mpqp_hip_combinatorial import unpack_regions
         sel = status == 3
@@ -208,6 +214,55 @@ def test_two_rank_split_reproduces_reference(name, shard_min):
         assert all(res[0][3])
     if shard_min == 10 ** 9:
         assert not any(res[0][3])
+
+
+def _worker_reshard(rank, world, port, name, out):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        from oracle import oracle as orc
+        from ppopt_amd import distributed
+        distributed.RESHARD = 1.0001      # any imbalance of the next frontier triggers the step
+        g = load_golden(name)
+        profile = []
+        sol = distributed.solve_distributed(OracleLevelEngine(orc.problem_from_golden(g)), profile=profile, shard_min=1)
+        out[rank] = ([tuple(r.active_set) for r in sol.critical_regions],
+                     [(p['candidates'], p['status'], p.get('local_candidates'), p.get('resharded')) for p in profile if p['depth'] > 0])
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('name', ['dblint_n3', 'rand_4_2_10_s0'])
+def test_reshard_step_keeps_the_levels_and_balances_them(name):
+    """MPC_RESHARD: after a sharded level whose ranks hold unequal numbers of children, the children are
+    all-gathered in rank order and every rank takes an equal slice.  With the threshold at 1.0001 the step runs whenever the shares
+    differ: every level must still be the reference's (candidates, status histogram), both ranks must return the reference's regions,
+    the local shares after a step differ by at most one candidate, and the step must have run at least once."""
+    world = 2
+    port = 33500 + (os.getpid() % 2000)
+    with mp.Manager() as mgr:
+        out = mgr.dict()
+        mp.spawn(_worker_reshard, args=(world, port, name, out), nprocs=world, join=True)
+        res = dict(out)
+    g = load_golden(name)
+    ref = sorted(golden_regions(g))
+    steps = 0
+    for rank in range(world):
+        sets, levels = res[rank]
+        assert sorted(sets) == ref, f'rank {rank}'
+        for i, (n, hist, local, resh) in enumerate(levels):
+            assert n == len(g[f'L{i}_verdict'])
+            assert hist[:5] == numpy.bincount(g[f'L{i}_verdict'], minlength=5).tolist()
+    for i, ((n, _, a, resh), (_, _, b, _)) in enumerate(zip(res[0][1], res[1][1])):
+        assert a + b == n
+        if i > 0 and res[0][1][i - 1][3]:      # the level before ended with a re-shard: this level's shares are equal
+            assert abs(a - b) <= 1
+            assert sum(res[0][1][i - 1][3]['after']) == n
+        steps += 1 if resh else 0
+    assert steps > 0, 'the re-shard step never ran'
 
 
 def test_single_process_path_without_process_group(oracle):

@@ -78,4 +78,5 @@ if __name__ == '__main__':
         print(f'world {world}: every rank returns the single-rank region set: {ok}; shards per level: '
               + '; '.join(f"k={lv['k']}: {lv['shards']} (max/mean {lv['imbalance_max_over_mean']:.3f})" for lv in levels if lv['sharded']), flush=True)
     os.makedirs('gpurun_out/r5', exist_ok=True)
-    json.dump(report, open(f'gpurun_out/r5/ranks_{wl}.json', 'w'), indent=1)
+    report['reshard_threshold'] = float(os.environ.get('MPC_RESHARD', '0') or 0)
+    json.dump(report, open(f'gpurun_out/r5/ranks_{wl}' + ('_reshard' if report['reshard_threshold'] > 0 else '') + '.json', 'w'), indent=1)
