@@ -115,9 +115,44 @@ __global__ void __launch_bounds__(64, XQ_WAVES) m_xq(const BatchMember *__restri
     dq.max_blocks = m.xq_blocks;
     k_xq<SLOTS>(m.pf, m.fr, m.k, part_list_of(m, 3), (int)m.n, m.status, m.ctr, dq, m.nxc);
 }
+// one-step plans (round 5; mpcombi_hip.hip launch_plans): the members with `plan` ask, one thread per candidate, whether a parent's record is
+// one known step away; k_x1 streams those records through the step; m_x2 below gets what is left (lists in the member's x1_buf)
+__global__ void __launch_bounds__(64) m_xq_plan(const BatchMember *__restrict__ tab) {
+    MEMBER;
+    if (!m.plan) return;
+    DictCache dq = m.dc;
+    dq.n_list_dev = m.dcnt + 7;
+    int32_t *xb = m.x1_buf;
+    const size_t nn = (size_t)m.n;
+    XqPlan pl{};
+    pl.plan_slot = xb; pl.plan_step = xb + nn; pl.x1_list = xb + 2 * nn; pl.x1_n = m.dcnt + 9;
+    for (int sg = 0; sg < 3; ++sg) { pl.rest[sg] = xb + (3 + sg) * nn; pl.rest_n[sg] = m.dcnt + 29 + sg; }
+    pl.pre1 = part_list_of(m, 1); pl.n_pre1_dev = m.dcnt + 5;
+    pl.pre2 = part_list_of(m, 2); pl.n_pre2_dev = m.dcnt + 6;
+    k_xq_thread(m.pf, m.fr, m.k, part_list_of(m, 3), (int)m.n, m.status, m.ctr, dq, m.nxc, m.alt, pl);
+}
+template <int SLOTS>
+__global__ void __launch_bounds__(64, 8) m_x1(const BatchMember *__restrict__ tab) {
+    MEMBER;
+    if (!m.plan) return;
+    int32_t *xb = m.x1_buf;
+    const size_t nn = (size_t)m.n;
+    k_x1<SLOTS>(m.pf, xb + 2 * nn, m.dcnt + 9, m.ctr, m.dc, m.nxc, xb, xb + nn);
+}
 template <int NXC, int SLOTS>
 __global__ void __launch_bounds__(64, (NXC * SLOTS >= 64 ? 2 : (NXC * SLOTS >= 32 ? X2_WAVES : X2_WAVES_16))) m_x2(const BatchMember *__restrict__ tab) {
     MEMBER;
+    if (m.plan) {     // what the plan pass left: three lists in x1_buf, lengths in dcnt[29..31]
+        int32_t *xb = m.x1_buf;
+        const size_t nn = (size_t)m.n;
+        DictCache dr = m.dc;
+        dr.pre1 = xb + 3 * nn; dr.n_pre1 = 0; dr.n_pre1_dev = m.dcnt + 29;
+        dr.pre2 = xb + 4 * nn; dr.n_pre2 = 0; dr.n_pre2_dev = m.dcnt + 30;
+        dr.n_list_dev = m.dcnt + 31;
+        dr.max_blocks = m.x2_blocks;
+        k_x2<NXC, SLOTS>(m.pf, m.fr, m.k, xb + 5 * nn, (int)m.n, m.status, m.ctr, dr);
+        return;
+    }
     DictCache d = m.dc;
     d.n_list_dev = m.dcnt + (m.quick_test ? 8 : 7);
     d.max_blocks = m.x2_blocks;
@@ -184,7 +219,7 @@ hipError_t batch_level_launch(BatchMember *members, int B, hipStream_t st, Batch
     // (budgets in wavefronts per CU, swept on the bench enumeration -- four-parameter sub-programs, the NT = 4 instantiations: the theta
     //  kernel 8 / 16 / 32 -> 67.5 / 60.3 / 58.3 ms of shared levels, the region kernel 8 / 16 -> 67.5 / 66.4, k_x2 8 / 12 / 16 -> 63.0 / 60.3 / 62.4)
     static const int wpc_th = env_int("MPC_BATCH_WPC_TH", 32), wpc_xq = env_int("MPC_BATCH_WPC_XQ", 20), wpc_x2 = env_int("MPC_BATCH_WPC_X2", 12),
-                     wpc_r2 = env_int("MPC_BATCH_WPC_R2", 16), use_shares = env_int("MPC_BATCH_SHARES", 1), w_share = env_int("MPC_BATCH_WSHARE", 1);
+                     wpc_r2 = env_int("MPC_BATCH_WPC_R2", 16), wpc_plan = env_int("MPC_BATCH_WPC_PLAN", 16), wpc_x1 = env_int("MPC_BATCH_WPC_X1", 16), use_shares = env_int("MPC_BATCH_SHARES", 1), w_share = env_int("MPC_BATCH_WSHARE", 1);
     for (int g0 = 0; g0 < B && use_shares;) {
         int g1 = g0 + 1;
         while (g1 < B && group_key(members[g1]) == group_key(members[g0])) ++g1;
@@ -196,6 +231,7 @@ hipError_t batch_level_launch(BatchMember *members, int B, hipStream_t st, Batch
             auto share = [&](int wpc) { return (int)std::max(4.0, std::ceil(f * wpc * m.n_cu)); };
             m.r2_wcap = w_share ? share(wpc_r2) : 0;
             m.th_blocks = share(wpc_th); m.xq_blocks = share(wpc_xq); m.x2_blocks = share(wpc_x2); m.r2_blocks = share(wpc_r2);
+            m.plan_blocks = share(wpc_plan); m.x1_blocks = share(wpc_x1);
         }
         g0 = g1;
     }
@@ -258,6 +294,19 @@ hipError_t batch_level_launch(BatchMember *members, int B, hipStream_t st, Batch
             if (r.fast_x & 1) hipLaunchKernelGGL((m_xq<2>), gg, bb, 0, st, tab);
             else hipLaunchKernelGGL((m_xq<1>), gg, bb, 0, st, tab);
             hipLaunchKernelGGL(m_compact_small, dim3(1, G), dim3(1024), 0, st, tab, ST_NEEDX, ST_NEEDX_SING, 1, 8);
+        }
+        {
+            bool any_plan = false;
+            int pl_max = 0, x1_max = 0;
+            for (int i = g0; i < g1; ++i) { any_plan = any_plan || members[i].plan; pl_max = std::max(pl_max, members[i].plan_blocks); x1_max = std::max(x1_max, members[i].x1_blocks); }
+            if (any_plan) {
+                const dim3 gp((unsigned)std::max<long long>(1, std::min<long long>((n_max + 63) / 64, pl_max > 0 ? pl_max : (long long)r.n_cu * 16)), G), bb(64);
+                hipLaunchKernelGGL(m_xq_plan, gp, bb, 0, st, tab);
+                const dim3 g1((unsigned)std::max<long long>(1, std::min<long long>(n_max, x1_max > 0 ? x1_max : (long long)r.n_cu * 16)), G);
+                if (r.fast_x & 1) hipLaunchKernelGGL((m_x1<2>), g1, bb, 0, st, tab);
+                else hipLaunchKernelGGL((m_x1<1>), g1, bb, 0, st, tab);
+                TRY(hipGetLastError());
+            }
         }
         {
             const dim3 gg((unsigned)std::min<long long>(n_max, x2_max > 0 ? x2_max : (long long)r.n_cu * 16), G), bb(64);

@@ -84,6 +84,12 @@ struct BatchMember {
     unsigned int *pub_ctr, *pub_cnt;     // device aliases of the member's pinned counters block
     BatchZero zero[6];                   // cleared before the first launch
     int n_zero;
+    // round 5: one-step plans on a storing level whose candidates have parents' records (the single program's k_xq_thread plan mode + k_x1):
+    // plan = 1: the member takes part; x1_buf: 6 n ints (plan slot, plan step, k_x1's list, the three lists left to k_x2); lengths in
+    // dcnt[9] (k_x1's list) and dcnt[29..31]; alt: the previous frontier for the look-up of other parents (empty: generating parent only)
+    int plan, plan_blocks, x1_blocks;
+    int32_t *x1_buf;
+    XqAlt alt;
 };
 
 // Queues the launches of one level for the B members on `st` (no synchronisation).  The members are reordered into groups.

@@ -308,6 +308,10 @@ struct mpc_handle {
                                      // (9,880 candidates) 0.72 -> 0.67 ms; level 4 (181 k) 1.51 -> 1.58: there the stage fills the GPU before the region kernel's long wavefronts are placed
                                      // (region kernel 0.48 -> 0.60 ms, the stage itself 0.93 -> 1.03) -- large levels keep the region launch first
     hipEvent_t ev_part = nullptr;
+    bool no_batch_plans = true;      // MPC_BATCH_PLANS=1 switches the one-step plans on in the shared launches (tests).  Measured on the bench enumeration (64 sub-programs, 16-column
+                                     // records of 3.5 KB) and on 128 small programs: SLOWER with them (121 against 108 ms; 20.9 against 19.6 ms, device 10.1 against 8.6) -- the register
+                                     // simplex on so small a record costs less than the plan pass's batch of dependent look-ups; off by default
+    long long batch_plan_min = 64;   // MPC_BATCH_PLAN_MIN: smallest member level (candidates) that plans
     bool no_kkt_lists = false;       // MPC_NO_KKT_LISTS=1: the work lists behind k_kkt_thread by compaction of the status array (round 4; A/B, tests)
     bool no_small_fuse = false;      // MPC_NO_SMALL_FUSE=1: the small path with its round-4 launches (doubtful candidates re-solved in place; A/B, tests)
     long long n_smallpath_doubtful = 0;   // small levels repeated because the fused form met a doubtful candidate
@@ -650,6 +654,8 @@ static int create_fill(const mpc_problem *p, int32_t device, void *stream, mpc_h
     { const char *ev = std::getenv("MPC_NO_X_FIRST"); h->x_first = !(ev && ev[0] == '1'); }
     { const char *ev = std::getenv("MPC_X_FIRST_MIN"); if (ev) h->x_first_min = std::atoll(ev); }
     { const char *ev = std::getenv("MPC_X_FIRST_MAX"); if (ev) h->x_first_max = std::atoll(ev); }
+    { const char *ev = std::getenv("MPC_BATCH_PLANS"); h->no_batch_plans = !(ev && ev[0] == '1'); }
+    { const char *ev = std::getenv("MPC_BATCH_PLAN_MIN"); if (ev) h->batch_plan_min = std::atoll(ev); }
     { const char *ev = std::getenv("MPC_NO_KKT_LISTS"); h->no_kkt_lists = ev && ev[0] == '1'; }
     { const char *ev = std::getenv("MPC_NO_SMALL_FUSE"); h->no_small_fuse = ev && ev[0] == '1'; }
     { const char *ev = std::getenv("MPC_NO_SMALLPATH"); h->no_smallpath = ev && ev[0] == '1'; }
@@ -1794,6 +1800,20 @@ static int batch_prepare(mpc_handle *h, int32_t gen_children, int32_t flags, Bat
     }
     dc.chunk = 1;
     m.dc = dc;
+    // one-step plans (round 5): a storing level whose candidates have parents' records; the look-up of other parents needs the previous
+    // frontier, which sits in the children buffer -- only while that buffer is not about to be re-allocated for this level's children
+    m.plan = 0; m.x1_buf = nullptr; m.alt = XqAlt{}; m.plan_blocks = m.x1_blocks = 0;
+    if (h->storing && dc.parent_slot && h->x1 > 0 && !h->no_batch_plans && n >= h->batch_plan_min && n <= 0x7fffffffLL / 8) {
+        HIP_TRY(h, h->x1_buf.ensure(6 * nn * sizeof(int32_t), st));
+        m.x1_buf = h->x1_buf.as<int32_t>();
+        m.plan = 1;
+        const size_t child_bytes = gen_children ? nn * (size_t)std::max(h->n_c - k, 1) * (k + 1) * sizeof(int32_t) : 0;
+        if (h->x1 >= 2 && h->n_prev > 0 && h->n_prev <= 0x7fffffffLL && k >= 2 && h->children.cap >= child_bytes &&
+            h->children.cap >= (size_t)h->n_prev * (k - 1) * sizeof(int32_t) && h->dict_stored[1 - h->dict_cur].cap >= (size_t)h->n_prev) {
+            m.alt.prev_frontier = h->children.as<int32_t>(); m.alt.prev_stored = h->dict_stored[1 - h->dict_cur].as<uint8_t>();
+            m.alt.n_prev = (int)h->n_prev; m.alt.tries = MPC_MAX_NC;
+        }
+    }
     m.storing = h->storing ? 1 : 0;
     m.dict_stored_cur = h->storing ? h->dict_stored[h->dict_cur].as<uint8_t>() : nullptr;
     m.quick_test = (!h->storing && dc.parent_slot && !h->no_xquick) ? 1 : 0;

@@ -229,6 +229,24 @@ def test_solve_many_equals_solve():
                 assert numpy.asarray(getattr(r1, fld)).tobytes() == numpy.asarray(getattr(r2, fld)).tobytes(), (n, fld)
 
 
+def test_solve_many_with_one_step_plans_in_the_shared_launches(monkeypatch):
+    """MPC_BATCH_PLANS=1 (off by default: measured slower on small records): the members' storing levels take the single program's
+    one-step plans (k_xq_thread plan mode, k_x1, the rest through k_x2) inside the shared launches.  Same regions, same order, same
+    numbers as the separate solves."""
+    from ppopt_amd.mp_solvers import mpqp_hip_combinatorial
+    one = [mpqp_hip_combinatorial.solve(p) for p in _programs()]
+    monkeypatch.setenv('MPC_BATCH_PLANS', '1')
+    monkeypatch.setenv('MPC_BATCH_PLAN_MIN', '1')
+    many = mpqp_hip_combinatorial.solve_many(_programs())
+    for n, (a, b) in enumerate(zip(one, many)):
+        assert len(a.critical_regions) == len(b.critical_regions) > 0, n
+        for r1, r2 in zip(a.critical_regions, b.critical_regions):
+            assert list(r1.active_set) == list(r2.active_set), n
+            assert r1.omega_set == r2.omega_set and r1.lambda_set == r2.lambda_set and r1.regular_set == r2.regular_set, n
+            for fld in ('A', 'b', 'C', 'd', 'E', 'f'):
+                assert numpy.asarray(getattr(r1, fld)).tobytes() == numpy.asarray(getattr(r2, fld)).tobytes(), (n, fld)
+
+
 def test_enumeration_batched_equals_one_by_one(monkeypatch):
     """The mixed-integer enumeration with the sub-programs solved together against MPC_NO_BATCH=1 (one handle per fixation, host
     threads): the same regions with the same fixations, bit for bit."""
