@@ -61,6 +61,19 @@ def test_struct_layout_matches_header():
     for line in out2[1:]:
         if line.strip():
             assert int(line.split()[1]) == getattr(_lib.SolveLevelInfo, line.split()[0]).offset, line
+    # mpc_many_level_info (round 5: the level loop of many programs behind one call)
+    fields3 = [name for name, *_ in _lib.ManyLevelInfo._fields_]
+    prog3 = '#include <stdio.h>\n#include <stddef.h>\n#include "mpcombi.h"\nint main(void) {\n  printf("%zu\\n", sizeof(mpc_many_level_info));\n' + \
+            ''.join(f'  printf("{f} %zu\\n", offsetof(mpc_many_level_info, {f}));\n' for f in fields3) + '  return 0;\n}\n'
+    with tempfile.TemporaryDirectory() as tmp:
+        src, exe = os.path.join(tmp, 'l.c'), os.path.join(tmp, 'l')
+        open(src, 'w').write(prog3)
+        subprocess.check_call(['gcc', '-I', os.path.join(ROOT, 'include'), src, '-o', exe])
+        out3 = subprocess.check_output([exe]).decode().split('\n')
+    assert int(out3[0]) == ctypes.sizeof(_lib.ManyLevelInfo)
+    for line in out3[1:]:
+        if line.strip():
+            assert int(line.split()[1]) == getattr(_lib.ManyLevelInfo, line.split()[0]).offset, line
 
 
 def test_flag_constants_match_the_header():
@@ -70,7 +83,8 @@ def test_flag_constants_match_the_header():
     for name in ('MPC_LEVEL_STREAM', 'MPC_LEVEL_GRAPH', 'MPC_LEVEL_THEN_BASE', 'MPC_LEVEL_KEEP_LOWDIM', 'MPC_LEVEL_ONLY_BASE'):
         assert name in defs and getattr(_lib, name) == defs[name], name
     assert _lib.MPC_SOLVE_FETCH == defs['MPC_SOLVE_FETCH']
-    flags = [defs[n] for n in defs if n.startswith('MPC_LEVEL_')] + [defs['MPC_SOLVE_FETCH']]      # mpc_solve_start takes them together
+    assert _lib.MPC_SOLVE_MANY_BASE == defs['MPC_SOLVE_MANY_BASE']
+    flags = [defs[n] for n in defs if n.startswith('MPC_LEVEL_')] + [defs['MPC_SOLVE_FETCH'], defs['MPC_SOLVE_MANY_BASE']]      # mpc_solve_start / mpc_solve_many_start take them together
     assert len(set(flags)) == len(flags) and all(f & (f - 1) == 0 for f in flags)      # distinct single bits
 
 
