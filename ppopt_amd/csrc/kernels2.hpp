@@ -55,21 +55,11 @@ struct ThetaArgs {
     // and 130 us with four -- the launch was fastest with HALF (level 5: 15 k items) or a QUARTER (level 4: 5 k items) of its wave slots.
     int wave_div, wave_max;
     // k_kkt_thread (round 5): when set, the kernel lists its own output -- the candidates it leaves to k_theta2 (status ST_TODO) in
-    // kt_list / *kt_n, those its box screen sends to the (x,theta) question (ST_NEEDX) in kx_list / *kx_n -- with one atomic per wavefront
-    // and exit point, instead of a five-launch compaction of the status array per list behind it.  The lists are index-ordered within
-    // a wavefront's piece only; they are work lists (every candidate's result is written by candidate index), so the order changes nothing.
+    // kt_list / *kt_n, those its box screen sends to the (x,theta) question (ST_NEEDX) in kx_list / *kx_n -- with one atomic per workgroup
+    // and list, instead of a five-launch compaction of the status array per list behind it.  The lists are index-ordered within
+    // a workgroup's piece only; they are work lists (every candidate's result is written by candidate index), so the order changes nothing.
     int32_t *kt_list, *kt_n, *kx_list, *kx_n;
 };
-// every ACTIVE lane appends `value`: one atomic per call site and wavefront
-__device__ __forceinline__ void wave_append(int32_t *list, int32_t *cnt, int value) {
-    const unsigned long long m = __ballot(1);
-    const int lane = threadIdx.x & 63;
-    const int rank = __popcll(m & ((1ull << lane) - 1ull));
-    int base = 0;
-    if (rank == 0) base = atomicAdd(cnt, __popcll(m));
-    base = __builtin_amdgcn_readfirstlane(base);
-    list[base + rank] = value;
-}
 
 // ------------------------------------------------------------------------------------------------------------------
 // k_kkt_thread: the mode-0 KKT solve AND the box screen of the theta stage with ONE THREAD per candidate (K = cardinality
