@@ -188,6 +188,18 @@ __global__ void m_publish(const BatchMember *__restrict__ tab) {
     k_publish_words(reinterpret_cast<const unsigned int *>(m.dcnt), m.pub_cnt, 32);
 }
 
+}  // namespace
+// ---- one program: region kernel + (x,theta) kernel as one grid (batch_level.hpp, SmallRX) -------------------------------------------
+// (outside the unnamed namespace: the profiler then shows mpc::s_region2_x2<...>)
+template <int NT, int SL, int NXC, int SLX>
+__global__ void __launch_bounds__(64, 2) s_region2_x2(SmallRX a) {
+    if (blockIdx.y == 0)
+        k_region2<NT, SL>(a.pr, a.fr, a.k, a.opt_list, a.n, a.status, a.headd, a.headi, a.fd, a.fi, a.epool, a.ctr, a.kkc, a.kkl, a.W, a.kept_g, a.ldk, a.done_g, a.tvp_box, a.rs);
+    else
+        k_x2<NXC, SLX>(a.pf, a.fr, a.k, a.list, a.n, a.status, a.ctr, a.dc);
+}
+namespace {
+
 unsigned long long spec_of(std::initializer_list<std::pair<int, int>> classes) {
     unsigned long long spec = ~0ull;
     for (const auto &sc : classes) spec = (spec & ~(15ull << (4 * sc.first))) | ((unsigned long long)sc.second << (4 * sc.first));
@@ -207,6 +219,19 @@ hipError_t raise_lds(F *fn, int bytes) {
 }  // namespace
 
 #define TRY(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) return e_; } while (0)
+
+bool small_region2_x2_launch(int fast_r, int fast_x, unsigned grid_r, unsigned grid_x, int lds_r2, hipStream_t st, const SmallRX &a, hipError_t *err) {
+    // the pairs the named configurations and the enumeration's sub-programs use (each instantiation holds both kernels' code)
+    const dim3 g(std::max(std::max(grid_r, grid_x), 1u), 2), b(64);
+    *err = hipSuccess;
+#define MPC_RX(NT_, SL_, NXC_, SLX_) do { *err = raise_lds(s_region2_x2<NT_, SL_, NXC_, SLX_>, lds_r2); if (*err == hipSuccess) { hipLaunchKernelGGL((s_region2_x2<NT_, SL_, NXC_, SLX_>), g, b, lds_r2, st, a); *err = hipGetLastError(); } return true; } while (0)
+    if (fast_r == 0 && fast_x == 0) MPC_RX(4, 1, 16, 1);
+    if (fast_r == 0 && fast_x == 2) MPC_RX(4, 1, 32, 1);
+    if (fast_r == 2 && fast_x == 0) MPC_RX(8, 1, 16, 1);
+    if (fast_r == 2 && fast_x == 2) MPC_RX(8, 1, 32, 1);
+#undef MPC_RX
+    return false;
+}
 
 hipError_t batch_level_launch(BatchMember *members, int B, hipStream_t st, BatchMember *g_tab_host, BatchMember *g_tab_dev) {
     if (B <= 0) return hipSuccess;

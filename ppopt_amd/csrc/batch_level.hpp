@@ -92,6 +92,21 @@ struct BatchMember {
     XqAlt alt;
 };
 
+// ---- one program, small level: the region kernel and the (x,theta) kernel in ONE launch (round 5) ------------------------------------------
+// On a level of a few thousand candidates both kernels are 20-80 us of latency with a handful of wavefronts each; they work on disjoint
+// candidates (optimal / open + dictionary-only), so the no-round-trip path launches them as ONE grid: blockIdx.y = 0 runs k_region2's body,
+// blockIdx.y = 1 k_x2's (the x-extent is the larger of the two needs; surplus blocks of either leave at once) -- the overlap the classic
+// path gets from a second stream, without the two event hops that cost as much as it saves at this size.
+struct SmallRX {
+    // k_region2's arguments
+    const DevProblem *pr; const int32_t *fr; int k; const int32_t *opt_list; int n; uint8_t *status; double *headd; int32_t *headi; int fd, fi;
+    double *epool; LevelCounters *ctr; const uint8_t *kkc; const double *kkl; int W; uint8_t *kept_g; int ldk; unsigned int *done_g; const double *tvp_box; RegionStream rs;
+    // k_x2's
+    const DevProblem *pf; const int32_t *list; DictCache dc;
+};
+// false: no merged instantiation for this pair of kernel selectors (the caller launches the two kernels one after the other)
+bool small_region2_x2_launch(int fast_r, int fast_x, unsigned grid_r, unsigned grid_x, int lds_r2, hipStream_t st, const SmallRX &a, hipError_t *err);
+
 // Queues the launches of one level for the B members on `st` (no synchronisation).  The members are reordered into groups.
 // tab_host (page-locked) / tab_dev: room for B BatchMember each, owned by the caller until the launches have completed (the kernels
 // read their arguments from tab_dev).  Returns hipSuccess or the first error.

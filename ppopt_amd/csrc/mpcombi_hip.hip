@@ -313,6 +313,7 @@ struct mpc_handle {
                                      // simplex on so small a record costs less than the plan pass's batch of dependent look-ups; off by default
     long long batch_plan_min = 64;   // MPC_BATCH_PLAN_MIN: smallest member level (candidates) that plans
     bool no_kkt_lists = false;       // MPC_NO_KKT_LISTS=1: the work lists behind k_kkt_thread by compaction of the status array (round 4; A/B, tests)
+    bool no_small_rx = false;        // MPC_NO_SMALL_RX=1: region kernel and (x,theta) kernel of a small level as two launches (A/B, tests)
     bool no_small_fuse = false;      // MPC_NO_SMALL_FUSE=1: the small path with its round-4 launches (doubtful candidates re-solved in place; A/B, tests)
     long long n_smallpath_doubtful = 0;   // small levels repeated because the fused form met a doubtful candidate
     long long n_smallpath = 0, n_smallpath_fallback = 0;   // levels run that way / of which repeated on the classic path
@@ -657,6 +658,7 @@ static int create_fill(const mpc_problem *p, int32_t device, void *stream, mpc_h
     { const char *ev = std::getenv("MPC_BATCH_PLANS"); h->no_batch_plans = !(ev && ev[0] == '1'); }
     { const char *ev = std::getenv("MPC_BATCH_PLAN_MIN"); if (ev) h->batch_plan_min = std::atoll(ev); }
     { const char *ev = std::getenv("MPC_NO_KKT_LISTS"); h->no_kkt_lists = ev && ev[0] == '1'; }
+    { const char *ev = std::getenv("MPC_NO_SMALL_RX"); h->no_small_rx = ev && ev[0] == '1'; }
     { const char *ev = std::getenv("MPC_NO_SMALL_FUSE"); h->no_small_fuse = ev && ev[0] == '1'; }
     { const char *ev = std::getenv("MPC_NO_SMALLPATH"); h->no_smallpath = ev && ev[0] == '1'; }
     { const char *ev = std::getenv("MPC_NO_LEAN"); h->no_lean = ev && ev[0] == '1'; }
@@ -1516,6 +1518,8 @@ static int level_run_small(mpc_handle *h, int32_t gen_children, int32_t flags, m
     // the overlap of two 50-100 us kernels saves: config 2 1.76 ms against 1.68 in line; round 4, config 4, whose regions take 150 us:
     // 5.47 / 5.61 ms forked against 5.48 / 5.54 in line -- the region kernel itself is 0.185 instead of 0.158 ms beside k_x2.) -----------------------------------------------
     h->opt_ptr = part_list(2);
+    SmallRX rx{};
+    unsigned grid_r = 1;
     {
         const int rows_t_ = h->n_c - h->n_eq + h->n_tc;
         HIP_TRY(h, h->headd.ensure(nn * h->fd * sizeof(double), st));
@@ -1528,12 +1532,20 @@ static int level_run_small(mpc_handle *h, int32_t gen_children, int32_t flags, m
         rs.n_opt_dev = dcnt + 6;
         rs.w_cap = h->grid_r2; rs.w_max = h->rsplit_max;
         const int W = h->no_rsplit ? 1 : 0;   // 0: chosen in the kernel from the number of optimal candidates
-        const dim3 g((unsigned)std::min<long long>(n * std::max(h->rsplit_max, 1), h->grid_r2)), b(64);
+        grid_r = (unsigned)std::min<long long>(n * std::max(h->rsplit_max, 1), h->grid_r2);
         const DevProblem *pr = h->pr2_dev.as<DevProblem>();
-#define MPC_LAUNCH_R2(NT_, SL_) hipLaunchKernelGGL((k_region2<NT_, SL_>), g, b, h->lds_r2, st, pr, h->frontier.as<int32_t>(), k, h->opt_ptr, (int)n, \
-                                                   h->status.as<uint8_t>(), h->headd.as<double>(), h->headi.as<int32_t>(), h->fd, h->fi, h->epool.as<double>(), ctr, kkc, kkl, \
-                                                   W, h->kept_g.as<uint8_t>(), ldk, h->done_g.as<unsigned int>(), \
-                                                   h->no_rbox ? (const double *)nullptr : h->targs.tvp + (size_t)NT_ * NT_ + NT_, rs)
+        const int nt_r = h->fast_r <= 1 ? 4 : (h->fast_r <= 3 ? 8 : 10);
+        rx.pr = pr; rx.fr = h->frontier.as<int32_t>(); rx.k = k; rx.opt_list = h->opt_ptr; rx.n = (int)n; rx.status = h->status.as<uint8_t>();
+        rx.headd = h->headd.as<double>(); rx.headi = h->headi.as<int32_t>(); rx.fd = h->fd; rx.fi = h->fi; rx.epool = h->epool.as<double>(); rx.ctr = ctr;
+        rx.kkc = kkc; rx.kkl = kkl; rx.W = W; rx.kept_g = h->kept_g.as<uint8_t>(); rx.ldk = ldk; rx.done_g = h->done_g.as<unsigned int>();
+        rx.tvp_box = h->no_rbox ? (const double *)nullptr : h->targs.tvp + (size_t)nt_r * nt_r + nt_r; rx.rs = rs;
+        h->used_region2 = true;
+    }
+    // (the launch itself comes below: together with the (x,theta) kernel in one grid where an instantiation of the pair exists)
+    auto launch_region2 = [&]() -> int {
+        const dim3 g(grid_r), b(64);
+#define MPC_LAUNCH_R2(NT_, SL_) hipLaunchKernelGGL((k_region2<NT_, SL_>), g, b, h->lds_r2, st, rx.pr, rx.fr, rx.k, rx.opt_list, rx.n, rx.status, rx.headd, rx.headi, rx.fd, rx.fi, rx.epool, \
+                                                   rx.ctr, rx.kkc, rx.kkl, rx.W, rx.kept_g, rx.ldk, rx.done_g, rx.tvp_box, rx.rs)
         switch (h->fast_r) {
             case 0: MPC_LAUNCH_R2(4, 1); break;
             case 1: MPC_LAUNCH_R2(4, 2); break;
@@ -1544,8 +1556,8 @@ static int level_run_small(mpc_handle *h, int32_t gen_children, int32_t flags, m
         }
 #undef MPC_LAUNCH_R2
         HIP_TRY(h, hipGetLastError());
-        h->used_region2 = true;
-    }
+        return MPC_OK;
+    };
     if (!fused) HIP_TRY(h, hipMemsetAsync(&ctr->work_retry, 0, sizeof(unsigned int), st));
     // ---- (x,theta) stage with the dictionary cache ---------------------------------------------------------------------------------
     const int nxc = h->fast_x >= 2 ? 32 : 16;
@@ -1574,6 +1586,17 @@ static int level_run_small(mpc_handle *h, int32_t gen_children, int32_t flags, m
     const int32_t *needx_list = part_list(3);
     const int32_t *needx_n = dcnt + 7;
     const bool quick_test = !h->storing && dc.parent_slot && !h->no_xquick;
+    bool merged_rx = false;
+    if (fused && !quick_test && !h->no_small_rx) {
+        // region kernel + (x,theta) kernel as ONE grid (batch_level.hpp, SmallRX): the two work on disjoint candidates
+        DictCache d = dc;
+        d.n_list_dev = needx_n;
+        rx.pf = pf; rx.list = needx_list; rx.dc = d;
+        hipError_t e_rx = hipSuccess;
+        merged_rx = small_region2_x2_launch(h->fast_r, h->fast_x, grid_r, (unsigned)std::min<long long>(n, (long long)h->n_cu * 16), h->lds_r2, st, rx, &e_rx);
+        if (merged_rx) HIP_TRY(h, e_rx);
+    }
+    if (!merged_rx) { int rcr = launch_region2(); if (rcr) return rcr; }
     if (quick_test) {   // last level: decisions only -- the quick test on a few vectors of the parent's dictionary first
         DictCache dq = dc;
         dq.n_list_dev = needx_n;
@@ -1584,7 +1607,7 @@ static int level_run_small(mpc_handle *h, int32_t gen_children, int32_t flags, m
         needx_list = h->retry_list.as<int32_t>();
         needx_n = dcnt + 8;
     }
-    {
+    if (!merged_rx) {
         DictCache d = dc;
         d.n_list_dev = needx_n;
         // bound of the work items: every candidate once (open, or decided and expanded for its dictionary)
