@@ -533,7 +533,9 @@ def test_levels_without_host_round_trips_equal_the_classic_path(name, monkeypatc
     g = load_golden(name)
     nl = None if bool(g['complete']) else int(g['n_levels']) + 1
     runs = []
-    for env in ({}, {'MPC_NO_SMALLPATH': '1', 'MPC_NO_LEAN': '1'}, {'MPC_SMALLPATH_MAX': '1000000000'}, {'MPC_TEST_SMALL_FALLBACK': '1'}):
+    # (fifth, round 5: the small path with the region kernel and the (x,theta) kernel as two launches instead of one grid, and its end in five launches)
+    for env in ({}, {'MPC_NO_SMALLPATH': '1', 'MPC_NO_LEAN': '1'}, {'MPC_SMALLPATH_MAX': '1000000000'}, {'MPC_TEST_SMALL_FALLBACK': '1'},
+                {'MPC_NO_SMALL_RX': '1', 'MPC_NO_SMALL_FUSE': '1'}):
         with monkeypatch.context() as m:
             for key, val in env.items():
                 m.setenv(key, val)
