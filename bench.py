@@ -244,11 +244,11 @@ def main():
     # are those, live, of this run; that region's own rate is reported beside the first (`ms_per_step_with_kernel_events`): the event
     # records cost 0.1-0.2 ms per solve (markers the queue stops at), which is why they are not in the first.  --events-in-value keeps
     # them in the first region as rounds 1-4 did.
-    # The timed regions run with Python's cyclic garbage collector switched off, as `timeit` does: a solve returns ~10^4 region objects, none
-    # of them in a reference cycle (reference counting frees them), and the collector's young-generation passes over them cost 0.3-0.4 ms per
-    # solve of config 4 (tools/step_overhead.py) -- host bookkeeping of the interpreter, not of the path.  `ms_per_step_collector_on` is a third
-    # region of the same K steps with the collector on (the protocol of rounds 1-4).
-    def timed_region(with_profile, collector=False):
+    # Round 6: `value` / `ms_per_step` are timed with Python's cyclic collector ON, exactly as a user's
+    # `solve()` runs (the product's solve does not pause it: measured slower, mpqp_hip_combinatorial.solve_many's docstring).  A third
+    # region repeats the K steps with the collector off (round 5's headline protocol, `ms_per_step_collector_off`): a solve returns ~10^4
+    # region objects, none in a reference cycle, and the young-generation passes over them cost ~0.1 ms per solve of config 4.
+    def timed_region(with_profile, collector=True):
         profs, ms_list, last = [], [], None
         fence()
         if not collector:
@@ -269,10 +269,10 @@ def main():
             el = float(t.item())
         return el, profs, ms_list, last
 
-    elapsed_collector = None
+    elapsed_nogc = None
     if args.events_in_value:
-        elapsed, profiles, step_ms, sol = timed_region(True, collector=True)
-        elapsed_events = elapsed_collector = elapsed
+        elapsed, profiles, step_ms, sol = timed_region(True)
+        elapsed_events = elapsed
     else:
         elapsed, _, step_ms, sol = timed_region(False)
         del sol
@@ -280,7 +280,7 @@ def main():
         elapsed_events, profiles, _, sol = timed_region(True)
         del sol
         step(None)
-        elapsed_collector, _, _, sol_c = timed_region(False, collector=True)
+        elapsed_nogc, _, _, sol_c = timed_region(False, collector=False)
         del sol_c
         sol = step(None)
 
@@ -417,8 +417,9 @@ def main():
         'warmup': args.warmup,
         'ms_per_step': 1e3 * elapsed / steps,
         'ms_per_step_with_kernel_events': 1e3 * elapsed_events / steps,
-        'ms_per_step_collector_on': 1e3 * elapsed_collector / steps,
-        'collector': 'timed regions run with gc.disable() (as timeit does); ms_per_step_collector_on: the same K steps with the cyclic collector on',
+        'ms_per_step_collector_off': (1e3 * elapsed_nogc / steps) if elapsed_nogc is not None else None,
+        'collector': ('value / ms_per_step: the cyclic collector ON, as a user\'s solve() runs (round 5 timed them with gc.disable()); '
+                      'ms_per_step_collector_off: the same K steps with gc.disable(), round 5\'s protocol'),
         'kernel_timing': ('HIP events inside the one timed region (--events-in-value)' if args.events_in_value else
                           'value / ms_per_step: K timed steps of the solve as a user runs it (no profile: the library records no HIP events inside '
                           'its levels); per-kernel durations (roofline.dominant_kernel, roofline.kernels, kernel_ms_per_step): a second timed region '
@@ -432,6 +433,10 @@ def main():
         'config': {'workload': f'{args.workload}: {descr}', 'n_x': nx, 'n_theta': nt,
                    'n_c': nc, 'n_eq': len(prog.equality_indices), 'n_tc': int(prog.A_t.shape[0]),
                    'candidates_per_step': candidates, 'regions_per_step': regions,
+                   # (protocol figures where the driver's parser keeps them: VERDICT r5 item 8a)
+                   'ms_per_step_with_kernel_events': 1e3 * elapsed_events / steps,
+                   'ms_per_step_collector_off': (1e3 * elapsed_nogc / steps) if elapsed_nogc is not None else None,
+                   'value_protocol': 'collector on, no HIP-event records inside the levels',
                    'parallelism': (f'{world} GPU(s): small levels replicated, one split, then subtree-local levels that exchange '
                                    f'only pruned masks') if distributed else 'single GPU'},
         'regions_per_s': regions * steps / elapsed,
@@ -549,7 +554,7 @@ def main():
             best, n_reg = timed(3)          # default: the sub-programs share every launch of a level (mpc_level_run_batch)
             os.environ['MPC_NO_BATCH'] = '1'
             try:
-                best_1, n_reg_1 = timed(2)  # one handle per fixation, eight host threads (round 2's form)
+                best_1, n_reg_1 = timed(3)  # one handle per fixation, eight host threads (round 2's form)
             finally:
                 del os.environ['MPC_NO_BATCH']
             # the device's share of the batched form: the launches of each shared level, first to last (events)
@@ -594,7 +599,7 @@ def main():
             n_one = [len(sv) for sv in sols_one]
             del sols_one
             sols_many = None
-            for _ in range(4):
+            for _ in range(3):      # (the same repeat count for both forms: ADVICE r5)
                 sols_many = None
                 tq = time.perf_counter()
                 sols_many = mhc.solve_many(small, device=local_rank)

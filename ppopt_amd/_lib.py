@@ -539,7 +539,8 @@ class Engine:
         if nm == 0:
             return int(info.done), None
         members = info.member[:nm]
-        stats = [info.stats[j] for j in range(nm)]
+        # copies: info.stats[j] is a view into the job's own vector, which mpc_solve_many_wait frees (the engines keep `_last`)
+        stats = [LevelStats.from_buffer_copy(info.stats[j]) for j in range(nm)]
         for i, st in zip(members, stats):
             engines[i]._last = st
         records = []

@@ -46,6 +46,8 @@ struct DevProblem {
     const double *Gt;   // n_c x n_x            row i = (Q^-1 A_i')'
     const double *X0H;  // n_x x (n_t+1)        [-Q^-1 c | -Q^-1 H]
     const double *AAT;  // n_c x n_c            A A'  (Gram matrix of the rows: fast rank screen, kernels2.hpp)
+    const double *AT;   // n_x x n_c            A' (column l of A contiguous: k_region2's lanes, one inactive row each, read it coalesced)
+    const double *tvp;  // k_region2's view only: the zero-padded [tv_minv (NT x NT) | tv_theta | box lo | box hi] block of ThetaArgs (staged in LDS)
     const double *base; // (n_c+n_tc) x (1+n_x+n_t)   [b | A | -F ; b_t | 0 | A_t]
     // pre-crashed dictionary of the (x,theta) LP at a feasible vertex of the base polytope (built once per program):
     // basic slack rows d0_rows (n_d0r) in terms of the nonbasic inequality slacks d0_cols (n_d0c); program

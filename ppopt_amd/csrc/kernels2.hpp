@@ -1543,6 +1543,7 @@ MPC_GLOBAL void MPC_LB(64, 8) k_x1(const DevProblem *__restrict__ Pg, const int3
 // head_d (stride fd): A_x[n_x*n_t] b_x[n_x] A_l[k*n_t] b_l[k]
 // head_i (stride fi): status cand nE n_om n_la n_re e_off 0 | active[k] | omega[n_tc] | lambda[k] | reg_idx[n_c-k] | reg_con[n_c-k]
 // pool row: f, E[0..n_t)
+typedef const __attribute__((address_space(1))) double *gdp;   // a pointer the compiler may treat as global memory (members of DevProblem are generic: flat loads that also wait for LDS)
 constexpr double BOX_REDUNDANT_MARGIN = 1e-6;   // unit-norm row units; ten times the LP feasibility tolerance
 
 // Streaming of the region records to the host WHILE the kernel runs (single-GPU solve loop).  head_d / head_i / epool then
@@ -1587,6 +1588,10 @@ MPC_GLOBAL void MPC_LB(64, (SLOTS >= 2 ? 2 : R2W)) k_region2(
         if ((long long)blockIdx.x >= (long long)n_opt * W || (rs.max_blocks > 0 && (int)blockIdx.x >= rs.max_blocks)) return;   // surplus block of a launch sized by a bound
     }
     if (lane == 0) atomicMax(&ctr->r2_not_t0, ~(unsigned long long)wall_clock64());
+    // parameter vertex (inverse of its tight rows, the vertex itself) and the bounding box of the parameter set: staged once per wavefront
+    double *tvm = s.T, *tvt = s.T + NT * NT, *blo = tvt + NT, *bhi = blo + NT;
+    { gdp src = (gdp)P.tvp; for (int idx = lane; idx < NT * NT + 3 * NT; idx += 64) s.T[idx] = src[idx]; }
+    wave_sync();
     for (;;) {
         unsigned int item = 0;
         if (lane == 0) item = atomicAdd(&ctr->work_r2, 1u);
@@ -1598,107 +1603,194 @@ MPC_GLOBAL void MPC_LB(64, (SLOTS >= 2 ? 2 : R2W)) k_region2(
         bool is_last = true;
         const long long t0 = clock64();
         const int c = opt_list[w];
+        // Round 6: the chain of dependent memory round trips in front of the first pivot is as short as the data allows -- (1) the
+        // candidate's index, (2) its members + KKT code + multipliers together, (3) the rows of A' / b / F / A_t behind the complement
+        // list, each kind of row's loads issued before anything waits; the parameter vertex and the bounding box come from LDS.
+        // Same operations in the same order on every entry as before (x_law_schur, the A X products, the sigma substitution).
+        bool ill = false;
+        int kk = -1;
+        if (kkcode) {
+            int code = kkcode[c];
+            if (code != KK_UNDECIDED) {
+                if (code == KK_ILL) { ill = true; code = 0; }
+                if (code == 0) {
+                    const int cnt = k * nr;
+                    gdp src = (gdp)Lin + (size_t)c * cnt;
+                    for (int idx = lane; idx < cnt; idx += 64) s.L[idx] = src[idx];
+                }
+                kk = code;
+            }
+        }
         const int nin = load_active_set(P, cands + (size_t)c * k, k, s);
         double *hd = head_d + (size_t)w * fd;
         int32_t *hi = head_i + (size_t)w * fi;
         for (int i = lane; i < fi; i += 64) hi[i] = i < 8 ? 0 : -1;
         int st = ST_REGION;
-        bool ill = false;
-        const int kk = kkt_fetch_or_solve(P, k, s, kkcode, Lin, (size_t)c, &ill);
+        if (kk < 0) kk = kkt_solve(P, k, s, &ill);
         if (kk != 0) st = kk == 1 ? ST_INFEASIBLE : ST_SINGULAR;
         int nE = 0, n_om = 0, n_la = 0, n_re = 0, e_off = 0;
         bool retry = false;
         int reason = 0;
         if (st == ST_REGION) {
-            if (P.kkt_mode == 0) x_law_schur(P, k, s);
+            if (P.kkt_mode == 0) {
+                // x-law [b_x | A_x] = X0H - sum_a G'[as[a]] (x) L[a]  (x_law_schur's sums, four entries per lane and four members per step in flight)
+                gdp X0H = (gdp)P.X0H, Gt = (gdp)P.Gt;
+                const int nxr = nx * nr;
+                for (int idx0 = lane; idx0 < nxr; idx0 += 256) {
+                    double acc[4];
+                    int ii[4], tt[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int idx = idx0 + 64 * u, ic = idx < nxr ? idx : 0;
+                        ii[u] = ic / nr; tt[u] = ic - ii[u] * nr;
+                        acc[u] = X0H[ic];
+                    }
+                    int a = 0;
+                    for (; a + 4 <= k; a += 4) {
+                        double gv[4][4];
+#pragma unroll
+                        for (int v = 0; v < 4; ++v) {
+                            const int ra = s.as[a + v] * nx;
+#pragma unroll
+                            for (int u = 0; u < 4; ++u) gv[v][u] = Gt[ra + ii[u]];
+                        }
+#pragma unroll
+                        for (int v = 0; v < 4; ++v)
+#pragma unroll
+                            for (int u = 0; u < 4; ++u) acc[u] = fma(-gv[v][u], s.L[(a + v) * nr + tt[u]], acc[u]);
+                    }
+                    for (; a < k; ++a) {
+                        const int ra = s.as[a] * nx;
+                        double gv[4];
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) gv[u] = Gt[ra + ii[u]];
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) acc[u] = fma(-gv[u], s.L[a * nr + tt[u]], acc[u]);
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) if (idx0 + 64 * u < nxr) s.X[idx0 + 64 * u] = acc[u];
+                }
+                wave_sync();
+            }
             const int nlam = k - e, m = nlam + nin + ntc, ldE = nr;
             RegLp<NC, SLOTS> lp;
             lp.m = m + 1; lp.iters = 0; lp.max_iter = 50 * (m + nt) + 200; lp.growth = 0.0;
             lp.alive = (1u << (nt + 2)) - 2u;          // columns 1..nt (sigma) and nt+1 (r)
             lp.cv = lane <= nt ? ID_SIGMA + lane : ID_R;
             wave_sync();
+            // FULLC: n_theta equals the instantiation's NT -- no guards on the parameter index (uniform branches otherwise)
+            auto build_rows = [&](auto FULLC) {
+                constexpr bool FULL = decltype(FULLC)::value;
+                gdp gb = (gdp)P.b, gF = (gdp)P.F, gbt = (gdp)P.b_t, gAt = (gdp)P.A_t, gAT = (gdp)P.AT;
 #pragma unroll
-            for (int sl = 0; sl < SLOTS; ++sl) {
-                const int i = lane + 64 * sl;
-                double h = 0.0, g[NT];
+                for (int sl = 0; sl < SLOTS; ++sl) {
+                    const int i = lane + 64 * sl;
+                    double h = 0.0, g[NT];
 #pragma unroll
-                for (int t = 0; t < NT; ++t) g[t] = 0.0;
-                if (i < nlam) {
-                    h = s.L[(e + i) * nr];
+                    for (int t = 0; t < NT; ++t) g[t] = 0.0;
+                    const bool is_lam = i < nlam, is_in = !is_lam && i < nlam + nin, is_tc = !is_lam && !is_in && i < m;
+                    // right-hand side and F / A_t row of this lane's constraint: one batch of loads for both kinds of rows
+                    const int ci = is_in ? s.inact[i - nlam] : 0, it = is_tc ? i - nlam - nin : 0;
+                    double hv = 0.0, fv[NT];
 #pragma unroll
-                    for (int t = 0; t < NT; ++t) if (t < nt) g[t] = -s.L[(e + i) * nr + 1 + t];
-                } else if (i < nlam + nin) {
-                    const int ci = s.inact[i - nlam];
-                    double acc[NT + 1];
+                    for (int t = 0; t < NT; ++t) fv[t] = 0.0;
+                    if (is_in || is_tc) {
+                        gdp hp = is_in ? gb + ci : gbt + it;
+                        gdp fp = is_in ? gF + (size_t)ci * nt : gAt + (size_t)it * nt;
+                        hv = *hp;
 #pragma unroll
-                    for (int t = 0; t <= NT; ++t) acc[t] = 0.0;
-                    for (int l = 0; l < nx; ++l) {
-                        const double a = P.A[ci * nx + l];
-#pragma unroll
-                        for (int t = 0; t <= NT; ++t) if (t <= nt) acc[t] = fma(a, s.X[l * nr + t], acc[t]);
+                        for (int t = 0; t < NT; ++t) if (FULL || t < nt) fv[t] = fp[t];
                     }
-                    h = P.b[ci] - acc[0];
+                    if (is_lam) {
+                        h = s.L[(e + i) * nr];
 #pragma unroll
-                    for (int t = 0; t < NT; ++t) if (t < nt) g[t] = acc[1 + t] - P.F[ci * nt + t];
-                } else if (i < m) {
-                    h = P.b_t[i - nlam - nin];
+                        for (int t = 0; t < NT; ++t) if (FULL || t < nt) g[t] = -s.L[(e + i) * nr + 1 + t];
+                    } else if (is_in) {
+                        gdp at = gAT + ci;
+                        double acc[NT + 1];
 #pragma unroll
-                    for (int t = 0; t < NT; ++t) if (t < nt) g[t] = P.A_t[(i - nlam - nin) * nt + t];
+                        for (int t = 0; t <= NT; ++t) acc[t] = 0.0;
+                        int l = 0;
+                        for (; l + 4 <= nx; l += 4) {
+                            double a4[4];
+#pragma unroll
+                            for (int u = 0; u < 4; ++u) a4[u] = at[(size_t)(l + u) * nc];
+#pragma unroll
+                            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                                for (int t = 0; t <= NT; ++t) if (FULL || t <= nt) acc[t] = fma(a4[u], s.X[(l + u) * nr + t], acc[t]);
+                        }
+                        for (; l < nx; ++l) {
+                            const double a = at[(size_t)l * nc];
+#pragma unroll
+                            for (int t = 0; t <= NT; ++t) if (FULL || t <= nt) acc[t] = fma(a, s.X[l * nr + t], acc[t]);
+                        }
+                        h = hv - acc[0];
+#pragma unroll
+                        for (int t = 0; t < NT; ++t) if (FULL || t < nt) g[t] = acc[1 + t] - fv[t];
+                    } else if (is_tc) {
+                        h = hv;
+#pragma unroll
+                        for (int t = 0; t < NT; ++t) if (FULL || t < nt) g[t] = fv[t];
+                    }
+                    bool keep = false;
+                    double ss = 0.0;
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) { if (!(fabs(g[t]) <= ZERO_ROW_ATOL)) keep = true; ss = fma(g[t], g[t], ss); }
+                    keep = keep && i < m;
+                    double nrm = 0.0;
+                    if (keep) {
+                        const double inv = 1.0 / sqrt(ss);
+                        h *= inv;
+                        double s2 = 0.0;
+#pragma unroll
+                        for (int t = 0; t < NT; ++t) { g[t] *= inv; s2 = fma(g[t], g[t], s2); }
+                        nrm = sqrt(s2);
+                        s.E[i * ldE] = h;
+#pragma unroll
+                        for (int t = 0; t < NT; ++t) if (FULL || t < nt) s.E[i * ldE + 1 + t] = g[t];
+                    }
+                    // Box screen: the region lies inside the parameter polytope, hence inside its (outward padded) bounding box
+                    // [lo, hi].  A row whose left-hand side cannot reach f_i - 1e-6 anywhere in the box is never tight on the
+                    // region: the reference's LP "row i as an equality" is infeasible for it (strongly redundant, dropped), and
+                    // it cannot bring the Chebyshev radius below 1e-8 either (a ball of radius min(r', 1e-6) around the centre
+                    // found without it satisfies it).  Such rows leave the LP before the first pivot.
+                    bool boxred = false;
+                    if (keep && box && i < nlam + nin) {
+                        double mx = 0.0;
+#pragma unroll
+                        for (int t = 0; t < NT; ++t) if (g[t] != 0.0) mx = fma(g[t], g[t] > 0.0 ? bhi[t] : blo[t], mx);
+                        boxred = mx < h - BOX_REDUNDANT_MARGIN;
+                    }
+                    if (i < m) s.kept[i] = keep ? (boxred ? 2 : 0) : 3;   // 0 undecided, 1 kept, 2 redundant, 3 dropped (numerically zero row)
+                    rc_box += __popcll(__ballot(boxred));
+                    if (boxred) keep = false;
+                    lp.var[sl] = i;
+                    lp.kind[sl] = keep ? RK_INEQ : RK_DEAD;
+                    // dictionary row at the parameter vertex (theta = tv_theta - tv_minv sigma); the staged blocks are zero beyond n_theta,
+                    // which leaves every sum as it is (a sum that starts at +0 never turns -0)
+                    double b0 = h;
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) b0 = fma(-g[t], tvt[t], b0);
+                    lp.t[sl][0] = keep ? b0 : 0.0;
+#pragma unroll
+                    for (int j = 0; j < NT; ++j) {
+                        double acc = 0.0;
+#pragma unroll
+                        for (int t = 0; t < NT; ++t) acc = fma(g[t], tvm[t * NT + j], acc);
+                        lp.t[sl][1 + j] = keep ? -acc : 0.0;
+                    }
+                    // the r column sits at index nt+1 (runtime): select chain over the compile-time slots
+#pragma unroll
+                    for (int j = 1; j < NC; ++j) if (j == nt + 1) lp.t[sl][j] = nrm; else if (j > nt + 1) lp.t[sl][j] = 0.0;
+                    if (i == m) {   // cost row: minimise -r
+                        lp.kind[sl] = RK_COST;
+#pragma unroll
+                        for (int j = 0; j < NC; ++j) lp.t[sl][j] = (j == nt + 1) ? -1.0 : 0.0;
+                    }
                 }
-                bool keep = false;
-                double ss = 0.0;
-#pragma unroll
-                for (int t = 0; t < NT; ++t) { if (!(fabs(g[t]) <= ZERO_ROW_ATOL)) keep = true; ss = fma(g[t], g[t], ss); }
-                keep = keep && i < m;
-                double nrm = 0.0;
-                if (keep) {
-                    const double inv = 1.0 / sqrt(ss);
-                    h *= inv;
-                    double s2 = 0.0;
-#pragma unroll
-                    for (int t = 0; t < NT; ++t) { g[t] *= inv; s2 = fma(g[t], g[t], s2); }
-                    nrm = sqrt(s2);
-                    s.E[i * ldE] = h;
-#pragma unroll
-                    for (int t = 0; t < NT; ++t) if (t < nt) s.E[i * ldE + 1 + t] = g[t];
-                }
-                // Box screen: the region lies inside the parameter polytope, hence inside its (outward padded) bounding box
-                // [lo, hi].  A row whose left-hand side cannot reach f_i - 1e-6 anywhere in the box is never tight on the
-                // region: the reference's LP "row i as an equality" is infeasible for it (strongly redundant, dropped), and
-                // it cannot bring the Chebyshev radius below 1e-8 either (a ball of radius min(r', 1e-6) around the centre
-                // found without it satisfies it).  Such rows leave the LP before the first pivot.
-                bool boxred = false;
-                if (keep && box && i < nlam + nin) {
-                    double mx = 0.0;
-#pragma unroll
-                    for (int t = 0; t < NT; ++t) if (g[t] != 0.0) mx = fma(g[t], g[t] > 0.0 ? box[NT + t] : box[t], mx);
-                    boxred = mx < h - BOX_REDUNDANT_MARGIN;
-                }
-                if (i < m) s.kept[i] = keep ? (boxred ? 2 : 0) : 3;   // 0 undecided, 1 kept, 2 redundant, 3 dropped (numerically zero row)
-                rc_box += __popcll(__ballot(boxred));
-                if (boxred) keep = false;
-                lp.var[sl] = i;
-                lp.kind[sl] = keep ? RK_INEQ : RK_DEAD;
-                double b0 = h;
-#pragma unroll
-                for (int t = 0; t < NT; ++t) if (t < nt) b0 = fma(-g[t], P.tv_theta[t], b0);
-                lp.t[sl][0] = keep ? b0 : 0.0;
-#pragma unroll
-                for (int j = 0; j < NT; ++j) {
-                    double acc = 0.0;
-#pragma unroll
-                    for (int t = 0; t < NT; ++t) if (t < nt && j < nt) acc = fma(g[t], P.tv_minv[t * nt + j], acc);
-                    lp.t[sl][1 + j] = keep ? -acc : 0.0;
-                }
-                // the r column sits at index nt+1 (runtime): select chain over the compile-time slots
-#pragma unroll
-                for (int j = 1; j < NC; ++j) if (j == nt + 1) lp.t[sl][j] = nrm; else if (j > nt + 1) lp.t[sl][j] = 0.0;
-                if (i == m) {   // cost row: minimise -r
-                    lp.kind[sl] = RK_COST;
-#pragma unroll
-                    for (int j = 0; j < NC; ++j) lp.t[sl][j] = (j == nt + 1) ? -1.0 : 0.0;
-                }
-            }
+            };
+            if (nt == NT) build_rows(std::true_type{}); else build_rows(std::false_type{});
             wave_sync();
             const long long tr1 = clock64();
             rc_rows += tr1 - t0;

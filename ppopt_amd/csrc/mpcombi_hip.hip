@@ -852,6 +852,9 @@ static int create_fill(const mpc_problem *p, int32_t device, void *stream, mpc_h
         }
     }
     const size_t oAAT = put_or_reserve(AAT, (size_t)nc * nc);
+    std::vector<double> ATr((size_t)std::max(nx * nc, 1), 0.0);      // A transposed (k_region2's row build reads a column of A per step)
+    for (int i = 0; i < nc; ++i) for (int l = 0; l < nx; ++l) ATr[(size_t)l * nc + i] = p->A[(size_t)i * nx + l];
+    const size_t oATr = put(ATr.data(), ATr.size());
     // equality rows eliminated from the Schur blocks (setup_mfma.hpp): lets k_kkt_thread take active sets of ne + (1..8) rows
     const bool want_elim = ne > 0 && dev_schur && ![] { const char *ev = std::getenv("MPC_NO_EQ_ELIM"); return ev && ev[0] == '1'; }();
     const std::vector<double> none;
@@ -911,7 +914,7 @@ static int create_fill(const mpc_problem *p, int32_t device, void *stream, mpc_h
     DevProblem P{};
     P.n_x = nx; P.n_t = nt; P.n_c = nc; P.n_eq = ne; P.n_tc = ntc; P.is_qp = h->is_qp; P.kkt_mode = mode;
     P.A = d + oA; P.b = d + ob; P.F = d + oF; P.c = d + oc; P.H = d + oH; P.Q = d + oQ; P.A_t = d + oAt; P.b_t = d + obt;
-    P.W = d + oW; P.UV = d + oUV; P.Gt = d + oGt; P.X0H = d + oX0H; P.base = d + obase; P.AAT = d + oAAT;
+    P.W = d + oW; P.UV = d + oUV; P.Gt = d + oGt; P.X0H = d + oX0H; P.base = d + obase; P.AAT = d + oAAT; P.AT = d + oATr;
     P.d0T = d + od0T; P.tv_theta = d + otvt; P.tv_minv = d + otvm; P.tv_rows = d + otvr;
     P.has_tv = tv_theta.empty() ? 0 : 1; P.n_tpre = tv_theta.empty() ? 0 : ntc - nt;
     P.d0 = d + od0; P.has_d0 = d0.empty() ? 0 : 1; P.n_d0r = (int)d0_rows.size(); P.n_d0c = (int)d0_cols.size();
@@ -1030,8 +1033,10 @@ static int create_fill(const mpc_problem *p, int32_t device, void *stream, mpc_h
             const int slots_r = rows_t + 1 <= 64 ? 1 : (rows_t + 1 <= 128 ? 2 : 0);
             if (nt >= 2 && slots_r) {
                 h->fast_r = tsel * 2 + (slots_r - 1);
-                const Layout l2 = make_layout(2, std::max(size_K, nt * (2 * nt + 1)), size_L, rows_t * nr, size_X, kmax, nc, nt + 2, 2, rows_t);
+                // (T: the staged [tv_minv | tv_theta | box] block, round 6)
+                const Layout l2 = make_layout(NTP * NTP + 3 * NTP, std::max(size_K, nt * (2 * nt + 1)), size_L, rows_t * nr, size_X, kmax, nc, nt + 2, 2, rows_t);
                 h->Pr2 = P; apply_layout(h->Pr2, l2); h->lds_r2 = l2.bytes;
+                h->Pr2.tvp = h->targs.tvp;
                 h->grid_r2 = h->n_cu * std::min(4 * (slots_r >= 2 ? 2 : R2W), waves_per_cu(h->lds_r2));   // waves per SIMD of the launch bounds
                 HIP_TRY(nullptr, h->pr2_dev.ensure(sizeof(DevProblem), h->stream));
                 HIP_TRY(nullptr, hipMemcpyAsync(h->pr2_dev.p, &h->Pr2, sizeof(DevProblem), hipMemcpyHostToDevice, h->stream));
@@ -2023,7 +2028,13 @@ int mpc_level_batch_wait(void *token, mpc_level_stats *stats, int32_t *n_batched
             bool fallback = false;
             const int rc = batch_finish(t->hs[m.id], t->gen[m.id], m, ms, stats ? stats + m.id : nullptr, &fallback);
             if (rc != MPC_OK) return rc;
-            if (fallback) t->alone.push_back(m.id);
+            if (fallback) {
+                // The member ran in the shared launches: m_children_write has overwritten the previous level's frontier in h->children,
+                // which the classic path's search for other parents (k_xq_thread, alt.prev_frontier) would walk with the wrong row width.
+                // As in level_run_small's repeat: no other-parent look-ups on the repeated level.  (Members that never ran keep n_prev.)
+                t->hs[m.id]->n_prev = 0;
+                t->alone.push_back(m.id);
+            }
             else if (n_batched) ++*n_batched;
         }
     }
@@ -3533,8 +3544,9 @@ int mpc_level_regions_slots_nowait(mpc_handle *h, double *head_d, int32_t *head_
 // one event per device: "the last k_fetch_many has finished" (recorded on the stream it ran on)
 static std::mutex g_fetch_mutex;
 static std::map<int, hipEvent_t> g_fetch_event;
-static DevBuf g_fetch_tab_dev;
-static HostBuf g_fetch_tab_host;
+// the launch's table, one pair of buffers PER DEVICE: the wait that frees a table for reuse is the same device's previous launch
+static std::map<int, DevBuf> g_fetch_tab_dev_of;
+static std::map<int, HostBuf> g_fetch_tab_host_of;
 static int fetch_many_wait(int device) {
     // Every copy launch waits for the one before it (its table is reused), so the LATEST record of the device's event covers all earlier
     // launches: whoever waits -- from any thread, for any member -- waits for that record (a completed event returns at once).
@@ -3603,6 +3615,8 @@ int mpc_level_batch_fetch(mpc_handle **hs, int32_t n_handles, double *const *hea
         std::lock_guard<std::mutex> lk(g_fetch_mutex);
         if (g_fetch_event.count(lead->device) && g_fetch_event[lead->device]) HIP_TRY(lead, hipEventSynchronize(g_fetch_event[lead->device]));   // the table of the previous call is free again
         const size_t bytes = tab.size() * sizeof(FetchEntry);
+        DevBuf &g_fetch_tab_dev = g_fetch_tab_dev_of[lead->device];
+        HostBuf &g_fetch_tab_host = g_fetch_tab_host_of[lead->device];
         HIP_TRY(lead, g_fetch_tab_host.ensure(bytes));
         HIP_TRY(lead, g_fetch_tab_dev.ensure(bytes, lead->stream));
         std::memcpy(g_fetch_tab_host.p, tab.data(), bytes);

@@ -315,15 +315,30 @@ GATHER_TIMEOUT_S = 600.0     # an asynchronous region gather that has not comple
 
 
 def _wait(work):
-    """Bounded wait for an asynchronous collective (gloo honours the timeout on the host; RCCL's wait only orders the current stream
-    behind the transfer and returns at once -- a dead peer then surfaces in the communicator's own watchdog)."""
+    """Wait for an asynchronous collective.  gloo: bounded on the host (GATHER_TIMEOUT_S).  RCCL (backend 'nccl'): ``wait()`` WITHOUT a
+    timeout only orders the current stream behind the transfer and returns at once -- which is what the overlap of the region gathers
+    with the next level relies on; a user-supplied timeout would make torch's WorkNCCL::wait poll on the host until the collective has
+    completed.  A dead peer then surfaces through the process group's own timeout / watchdog."""
     if work is None:
         return
+    if _is_host_backend(work):
+        try:
+            import datetime
+            work.wait(datetime.timedelta(seconds=GATHER_TIMEOUT_S))
+            return
+        except TypeError:
+            pass
+    work.wait()
+
+
+def _is_host_backend(work) -> bool:
+    """True for work objects of a CPU backend (gloo).  Decided from the default group's backend: the driver's collectives all run on
+    the group it was given, and a mixed 'cpu:gloo,cuda:nccl' group carries device tensors over RCCL."""
     try:
-        import datetime
-        work.wait(datetime.timedelta(seconds=GATHER_TIMEOUT_S))
-    except TypeError:
-        work.wait()
+        import torch.distributed as dist
+        return 'nccl' not in str(dist.get_backend()).lower()
+    except Exception:
+        return True
 
 
 class _RepeatWithoutOverlap(Exception):

@@ -179,6 +179,34 @@ def test_batch_members_that_fall_back_are_run_alone(monkeypatch):
         e.close()
 
 
+def test_batch_members_that_fall_back_beyond_the_root_level(monkeypatch):
+    """a member that ran in the shared launches has had its children written over the previous level's frontier; when it
+    then reports "repeat on the classic path", the repeat must not search that buffer for other parents' records (k_xq_thread /
+    one-step plans, forced on for every list size here).  Three levels, every one repeated: statuses, regions, children and pruned
+    masks are those of the single-program levels."""
+    from ppopt_amd import _lib
+    from test_gpu_parity import engine_from_golden
+    names = ['rand_6_3_12_s1', 'quadtank_n3', 'c2_dblint_n5', 'c4_rand_20_8_20_s0']
+    goldens = [load_golden(n) for n in names]
+    monkeypatch.setenv('MPC_X1_MIN', '1')
+    monkeypatch.setenv('MPC_XQT_MIN', '1')
+    alone = [_levels_alone(g, 3) for g in goldens]
+    monkeypatch.setenv('MPC_TEST_SMALL_FALLBACK', '1')
+    engs = [engine_from_golden(g) for g in goldens]
+    for e in engs:
+        e.pruned_clear(); e.frontier_root()
+    for depth in range(3):
+        gens = [depth != 2] * len(engs)
+        stats, n_shared = _lib.Engine.level_run_batch(engs, gens)
+        assert n_shared == 0
+        for i, (e, st) in enumerate(zip(engs, stats)):
+            _same(_snapshot(e, st, gens[i]), alone[i][depth], (names[i], depth))
+            if gens[i]:
+                e.frontier_advance()
+    for e in engs:
+        e.close()
+
+
 def test_batch_memory_budget_runs_the_overflow_alone(monkeypatch):
     """MPC_BATCH_BUDGET_GB: members whose level buffers would not fit the budget next to the others are run after the shared
     launches, one at a time -- same results."""
