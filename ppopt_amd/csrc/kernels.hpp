@@ -78,6 +78,10 @@ struct LevelCounters {
     unsigned long long r2_not_t0, r2_t1;  // k_region2: ~(wall clock of the first wavefront's start), wall clock of the last one's end
     unsigned long long xq_pivots;   // k_xq / k_xq_grouped: product-form iterations executed (each reads one column and one row of the parent's record)
     unsigned int xq_thread, pad_xq;  // candidates of the last level's quick test decided by k_xq_thread (round 5); pad_xq: ... of which from another parent's record
+    // Round 6: the queue between the theta stage and the region stage of a large last level.  k_theta2 appends every candidate it finds
+    // optimal (q_tail; the entries live in the level's opt_list, -1 until written), region wavefronts claim positions (work_r2 is the
+    // head); q_closed is raised by a one-thread launch behind the theta kernel: the tail is final.
+    unsigned int q_tail, q_closed, q_fault, q_early;   // q_fault: a claimed entry never arrived (never observed); q_early: regions built by the early launch
 };
 
 struct Smem {
@@ -854,6 +858,10 @@ MPC_GLOBAL void MPC_LB(256) k_fetch_many(const FetchEntry *__restrict__ tab) {
 MPC_GLOBAL void k_publish_words(const unsigned int *__restrict__ src, unsigned int *__restrict__ dst, int n) {
     for (int i = threadIdx.x; i < n; i += blockDim.x) dst[i] = src[i];
 }
+MPC_GLOBAL void MPC_LB(256) k_fill_i32(int32_t *__restrict__ dst, long long n, int32_t v) {
+    for (long long i = blockIdx.x * 256ll + threadIdx.x; i < n; i += (long long)gridDim.x * 256ll) dst[i] = v;
+}
+MPC_GLOBAL void k_set_u32(unsigned int *__restrict__ dst, unsigned int v) { if (threadIdx.x == 0 && blockIdx.x == 0) __hip_atomic_store(dst, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT); }
 // two sources, one after the other in dst (a level's counters and its list lengths: one launch)
 MPC_GLOBAL void k_publish_words2(const unsigned int *__restrict__ src1, int n1, const unsigned int *__restrict__ src2, int n2, unsigned int *__restrict__ dst) {
     for (int i = threadIdx.x; i < n1 + n2; i += blockDim.x) dst[i] = i < n1 ? src1[i] : src2[i - n1];

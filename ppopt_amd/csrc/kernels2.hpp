@@ -59,6 +59,10 @@ struct ThetaArgs {
     // and list, instead of a five-launch compaction of the status array per list behind it.  The lists are index-ordered within
     // a workgroup's piece only; they are work lists (every candidate's result is written by candidate index), so the order changes nothing.
     int32_t *kt_list, *kt_n, *kx_list, *kx_n;
+    // k_theta2 (round 6): != nullptr: every candidate found optimal is appended to optq (position from *q_tail) at once, so that region
+    // wavefronts of a launch that is ALREADY running can start on it while the rest of the theta stage is still being solved
+    int32_t *optq; unsigned int *q_tail;
+    int prio;   // > 0: the kernel's wavefronts raise their issue priority (s_setprio): the theta stage is the critical path beside the early region launch
 };
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -337,6 +341,7 @@ MPC_GLOBAL void MPC_LB(64, (SLOTS >= 2 ? (NT <= 4 ? TH_WAVES_S2 : 2) : (NT >= 8 
         if (ta.chunk <= 0) ta.chunk = (int)max(1ll, min(16ll, n / (active * 8)));
         if ((long long)blockIdx.x >= active || (long long)blockIdx.x * ta.chunk >= n) return;
     }
+    if (ta.prio >= 3) __builtin_amdgcn_s_setprio(3); else if (ta.prio == 2) __builtin_amdgcn_s_setprio(2); else if (ta.prio == 1) __builtin_amdgcn_s_setprio(1);
     extern __shared__ __attribute__((aligned(16))) double smem[];
     Smem s = carve(P, smem);
     constexpr int LS = NT + 1;
@@ -565,7 +570,16 @@ MPC_GLOBAL void MPC_LB(64, (SLOTS >= 2 ? (NT <= 4 ? TH_WAVES_S2 : 2) : (NT >= 8 
         cyc_theta += t2 - t1;
         if (st < 0 && !retry) st = singular ? ST_NEEDX_SING : ST_NEEDX;  // feasibility still open: (x,theta) LP, k_x2
         if (retry) { st = ST_RETRY; n_retry++; }
-        if (lane == 0) status[c] = (uint8_t)st;
+        if (lane == 0) {
+            status[c] = (uint8_t)st;
+            if (st == ST_OPT_PENDING && ta.optq) {
+                // (the entry is written after its position has been counted: a consumer that claims the position waits for the entry)
+                const unsigned int pos = atomicAdd(ta.q_tail, 1u);
+                // (relaxed: a consumer needs nothing but the entry itself -- a release at agent scope is a write-back of the L2, and 6,238 of
+                //  them made the theta kernel of config 4's last level 0.36 -> 0.50 ms; the queue is filled with -1 at the level's start)
+                __hip_atomic_store(&ta.optq[pos], (int32_t)c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
       }
     }
     if (lane == 0) {
@@ -1561,6 +1575,11 @@ struct RegionStream {
     const int32_t *n_opt_dev;
     int w_cap, w_max;
     int max_blocks;        // > 0 (with n_opt_dev): only that many blocks of the launch work (a member's share of a shared launch)
+    // Round 6, the queue form (large last level): opt_list is the queue k_theta2 fills (LevelCounters::q_tail; an entry is -1 until written),
+    // ctr->work_r2 its head; one wavefront per candidate, slot = queue position.  early == 1: the launch runs BESIDE the theta kernel --
+    // a wavefront claims a position and sleeps until its entry arrives or q_closed is up; early == 2: the drain launch behind the theta
+    // kernel (the queue is closed when it starts: it never waits).
+    int early, spin_max, q_cap;   // q_cap: entries of the queue array
 };
 
 template <int NT, int SLOTS>
@@ -1592,17 +1611,52 @@ MPC_GLOBAL void MPC_LB(64, (SLOTS >= 2 ? 2 : R2W)) k_region2(
     double *tvm = s.T, *tvt = s.T + NT * NT, *blo = tvt + NT, *bhi = blo + NT;
     { gdp src = (gdp)P.tvp; for (int idx = lane; idx < NT * NT + 3 * NT; idx += 64) s.T[idx] = src[idx]; }
     wave_sync();
+    if (rs.early) W = 1;
     for (;;) {
         unsigned int item = 0;
-        if (lane == 0) item = atomicAdd(&ctr->work_r2, 1u);
-        item = (unsigned)__builtin_amdgcn_readfirstlane((int)item);
-        if (item >= (unsigned)n_opt * (unsigned)W) break;
+        int c_q = -1;
+        if (rs.early) {
+            // Claim the next POSITION of the queue, then wait for its entry: every waiting wavefront polls its own address (a first form
+            // in which all of them polled head / tail / closed -- three words of one L2 channel -- slowed the theta kernel beside it
+            // 2.5x and the thread pass 5x).  The early launch sleeps ~5 us between looks and asks every eighth look whether the queue
+            // has been closed (then an empty entry means "beyond the tail": leave); the drain launch starts behind the theta kernel,
+            // where every entry below the tail is visible: an empty one ends the wavefront at once.
+            if (lane == 0) {
+                item = atomicAdd(&ctr->work_r2, 1u);
+                if (item >= (unsigned)rs.q_cap) item = 0xffffffffu;
+                else {
+                    const int32_t *qe = opt_list + item;
+                    for (int looks = 0;; ++looks) {
+                        c_q = __hip_atomic_load(qe, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (-1 = not written)
+                        if (c_q >= 0 || rs.early == 2) break;
+                        if ((looks & 7) == 7 && __hip_atomic_load(&ctr->q_closed, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT)) {
+                            c_q = __hip_atomic_load(qe, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+                            break;
+                        }
+                        if (looks >= rs.spin_max) { atomicAdd(&ctr->q_fault, 1u); break; }   // (a second of waiting: the level fails instead of hanging)
+                        __builtin_amdgcn_s_sleep(127); __builtin_amdgcn_s_sleep(127);
+                    }
+                    if (c_q < 0) item = 0xffffffffu;
+                    else {
+                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                        if (rs.early == 1) atomicAdd(&ctr->q_early, 1u);
+                    }
+                }
+            }
+            item = (unsigned)__builtin_amdgcn_readfirstlane((int)item);
+            c_q = __builtin_amdgcn_readfirstlane(c_q);
+            if (item == 0xffffffffu) break;
+        } else {
+            if (lane == 0) item = atomicAdd(&ctr->work_r2, 1u);
+            item = (unsigned)__builtin_amdgcn_readfirstlane((int)item);
+            if (item >= (unsigned)n_opt * (unsigned)W) break;
+        }
         const unsigned int w = item / (unsigned)W;
         const int part = (int)(item - w * (unsigned)W);
         auto own = [&](int row) -> bool { return W == 1 || row % W == part; };
         bool is_last = true;
         const long long t0 = clock64();
-        const int c = opt_list[w];
+        const int c = rs.early ? c_q : opt_list[w];
         // Round 6: the chain of dependent memory round trips in front of the first pivot is as short as the data allows -- (1) the
         // candidate's index, (2) its members + KKT code + multipliers together, (3) the rows of A' / b / F / A_t behind the complement
         // list, each kind of row's loads issued before anything waits; the parameter vertex and the bounding box come from LDS.
@@ -1870,7 +1924,7 @@ MPC_GLOBAL void MPC_LB(64, (SLOTS >= 2 ? 2 : R2W)) k_region2(
                         if (lp.kind[sl] == RK_INEQ && lp.var[sl] < m && lp.t[sl][0] > KEEP_TOL && own(lp.var[sl])) {
                             double mx = 0.0;
 #pragma unroll
-                            for (int j = 1; j < NC; ++j) mx = fmax(mx, (double)lp.t[sl][j]);
+                            for (int j = 1; j < NC; ++j) mx = bare_max(mx, (double)lp.t[sl][j]);   // (finite tableau entries: the bare instruction, no canonicalising copy)
                             if (R2_CERT && !(mx > TOL_COST) && s.kept[lp.var[sl]] == 0) {
                                 s.kept[lp.var[sl]] = 2;
 #ifdef R2_DEBUG
@@ -1893,7 +1947,7 @@ MPC_GLOBAL void MPC_LB(64, (SLOTS >= 2 ? 2 : R2W)) k_region2(
                             else {
                                 double mx = 0.0;
 #pragma unroll
-                                for (int j = 1; j < NC; ++j) mx = fmax(mx, (double)lp.t[sl][j]);
+                                for (int j = 1; j < NC; ++j) mx = bare_max(mx, (double)lp.t[sl][j]);   // (finite tableau entries: the bare instruction, no canonicalising copy)
                                 if (R2_CERT && !(mx > TOL_COST) && s.kept[lp.var[sl]] == 0) {
                                     s.kept[lp.var[sl]] = 2;
 #ifdef R2_DEBUG

@@ -37,7 +37,36 @@ template <int CTRL> __device__ __forceinline__ int dpp_i32(int v) { return __bui
 template <int CTRL> __device__ __forceinline__ double dpp_f64(double v) {
     return __hiloint2double(dpp_i32<CTRL>(__double2hiint(v)), dpp_i32<CTRL>(__double2loint(v)));
 }
-// row_shr:1,2,4,8 leave the reduction of each 16-lane row in its last lane; four v_readlane finish it
+// Wave reductions of the ratio test (round 6).  A lane value moved by DPP / v_readlane reaches fmin / fmax as two integer halves, so the
+// compiler puts a canonicalising v_max x, x in front of every min / max, and a row_shr step has lanes without a source, which costs two
+// copies of the running value per step: seven instructions per step of an f64 reduction, three reductions per pivot.  Here a step is a
+// ROTATION within the 16-lane row (row_ror: every lane has a source, no copy) and the min / max itself is the bare instruction -- the
+// reduced values are ratios, pivots and absolute values: never NaN, never -0, so the result is the same number whatever the order.
+// After four steps every lane of a row holds the row's result; four v_readlane + four min / max with a scalar operand finish it.
+template <int CTRL> __device__ __forceinline__ int dpp_all_i32(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, true); }
+template <int CTRL> __device__ __forceinline__ double dpp_all_f64(double v) {
+    return __hiloint2double(dpp_all_i32<CTRL>(__double2hiint(v)), dpp_all_i32<CTRL>(__double2loint(v)));
+}
+__device__ __forceinline__ double bare_min(double a, double b) { double r; asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ double bare_max(double a, double b) { double r; asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ double bare_min_s(double a_uniform, double b) { double r; asm("v_min_f64 %0, %1, %2" : "=v"(r) : "s"(a_uniform), "v"(b)); return r; }
+__device__ __forceinline__ double bare_max_s(double a_uniform, double b) { double r; asm("v_max_f64 %0, %1, %2" : "=v"(r) : "s"(a_uniform), "v"(b)); return r; }
+__device__ __forceinline__ float bare_maxf(float a, float b) { float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ float bare_maxf_s(float a_uniform, float b) { float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "s"(a_uniform), "v"(b)); return r; }
+// (results: the same value in every lane)
+__device__ __forceinline__ double rot_wave_min(double v) {
+    v = bare_min(v, dpp_all_f64<0x121>(v)); v = bare_min(v, dpp_all_f64<0x122>(v)); v = bare_min(v, dpp_all_f64<0x124>(v)); v = bare_min(v, dpp_all_f64<0x128>(v));
+    const double a = readlane_f64(v, 0), b = readlane_f64(v, 16), c = readlane_f64(v, 32), d = readlane_f64(v, 48);
+    return bare_min_s(d, bare_min_s(c, bare_min_s(b, bare_min_s(a, v))));
+}
+__device__ __forceinline__ double rot_wave_max(double v) {
+    v = bare_max(v, dpp_all_f64<0x121>(v)); v = bare_max(v, dpp_all_f64<0x122>(v)); v = bare_max(v, dpp_all_f64<0x124>(v)); v = bare_max(v, dpp_all_f64<0x128>(v));
+    const double a = readlane_f64(v, 0), b = readlane_f64(v, 16), c = readlane_f64(v, 32), d = readlane_f64(v, 48);
+    return bare_max_s(d, bare_max_s(c, bare_max_s(b, bare_max_s(a, v))));
+}
+// The row_shr forms (rounds 1-5), kept for the kernels that run under a tight register cap (k_x1, k_xq, k_xq_grouped: the rotation forms
+// above cost them 90-150 bytes of scratch each) -- row_shr:1,2,4,8 leave the reduction of each 16-lane row in its last lane; four
+// v_readlane finish it
 __device__ __forceinline__ double dpp_wave_min(double v) {
     v = fmin(v, dpp_f64<0x111>(v)); v = fmin(v, dpp_f64<0x112>(v)); v = fmin(v, dpp_f64<0x114>(v)); v = fmin(v, dpp_f64<0x118>(v));
     return fmin(fmin(readlane_f64(v, 15), readlane_f64(v, 31)), fmin(readlane_f64(v, 47), readlane_f64(v, 63)));
@@ -87,6 +116,14 @@ __device__ __forceinline__ float dpp_wave_max_f32(float v) {
     const int b = __float_as_int(v);
     return fmaxf(fmaxf(__int_as_float(__builtin_amdgcn_readlane(b, 15)), __int_as_float(__builtin_amdgcn_readlane(b, 31))),
                  fmaxf(__int_as_float(__builtin_amdgcn_readlane(b, 47)), __int_as_float(__builtin_amdgcn_readlane(b, 63))));
+}
+__device__ __forceinline__ float rot_wave_max_f32(float v) {
+    v = bare_maxf(v, __int_as_float(dpp_all_i32<0x121>(__float_as_int(v)))); v = bare_maxf(v, __int_as_float(dpp_all_i32<0x122>(__float_as_int(v))));
+    v = bare_maxf(v, __int_as_float(dpp_all_i32<0x124>(__float_as_int(v)))); v = bare_maxf(v, __int_as_float(dpp_all_i32<0x128>(__float_as_int(v))));
+    const int b = __float_as_int(v);
+    const float r0 = __int_as_float(__builtin_amdgcn_readlane(b, 0)), r1 = __int_as_float(__builtin_amdgcn_readlane(b, 16));
+    const float r2 = __int_as_float(__builtin_amdgcn_readlane(b, 32)), r3 = __int_as_float(__builtin_amdgcn_readlane(b, 48));
+    return bare_maxf_s(r3, bare_maxf_s(r2, bare_maxf_s(r1, bare_maxf_s(r0, v))));
 }
 __device__ __forceinline__ int dpp_wave_min_i32(int v) {
     v = min(v, dpp_i32<0x111>(v)); v = min(v, dpp_i32<0x112>(v)); v = min(v, dpp_i32<0x114>(v)); v = min(v, dpp_i32<0x118>(v));
@@ -271,23 +308,39 @@ struct RegLp {
     }
 
     // Dantzig pricing of row `crow` (phase 1: the row of x0, minimise; else the cost row): scan inside the owning lane.
-    // P1: entries > TOL_COST are improving; else entries < -TOL_COST.  Returns the column or -1; *mask = improving columns.
+    // P1: entries > TOL_COST are improving; else entries < -TOL_COST.  Returns the column or -1.
     template <bool P1>
-    __device__ __forceinline__ int price(int crow, unsigned *mask) const {
-        int q[SLOTS], mk[SLOTS];
+    __device__ __forceinline__ int price(int crow) const {
+        // round 6: the largest improving entry by a chain of bare max (min for the cost row: the entries are compared as stored, no
+        // negation), then the lowest column that holds it -- a compare and one select per column where "if (g > best) { best = g; q = j; }"
+        // was a compare and three selects.  Same column: the first of the largest entries, none unless it exceeds TOL_COST.
+        int q[SLOTS];
 #pragma unroll
         for (int s = 0; s < SLOTS; ++s) {
-            q[s] = -1; mk[s] = 0;
-            double best = TOL_COST;
+            double best = P1 ? TOL_COST : -TOL_COST;
+#pragma unroll
+            for (int j = 1; j < NC; ++j) best = P1 ? bare_max(best, t[s].get(j)) : bare_min(best, t[s].get(j));
+            q[s] = -1;
+#pragma unroll
+            for (int j = NC - 1; j >= 1; --j) q[s] = (t[s].get(j) == best) ? j : q[s];
+            if (!(P1 ? best > TOL_COST : best < -TOL_COST)) q[s] = -1;
+        }
+        return row_entry_i(crow, q);
+    }
+    // the improving columns of row `crow` as a bit mask (Bland's rule only: off the path of an ordinary pivot since round 6)
+    template <bool P1>
+    __device__ __forceinline__ unsigned improving_mask(int crow) const {
+        int mk[SLOTS];
+#pragma unroll
+        for (int s = 0; s < SLOTS; ++s) {
+            mk[s] = 0;
 #pragma unroll
             for (int j = 1; j < NC; ++j) {
                 const double g = P1 ? t[s].get(j) : -t[s].get(j);
                 if (g > TOL_COST) mk[s] |= (1 << j);
-                if (g > best) { best = g; q[s] = j; }
             }
         }
-        *mask = (unsigned)row_entry_i(crow, mk);
-        return row_entry_i(crow, q);
+        return (unsigned)row_entry_i(crow, mk);
     }
 
     // primal simplex; phase1_row >= 0: minimise x0 (basic in that row), else minimise the RK_COST row `cost_row`.
@@ -310,10 +363,10 @@ struct RegLp {
             const bool bland = deg > DEG_SWITCH;
             const int crow = uni(phase1_row >= 0 ? phase1_row : cost_row);
             if (phase1_row >= 0 && beta(phase1_row) <= TOL_FEAS) return 0;
-            unsigned improving = 0;
-            int q = phase1_row >= 0 ? price<true>(crow, &improving) : price<false>(crow, &improving);
+            int q = phase1_row >= 0 ? price<true>(crow) : price<false>(crow);
             if (q < 0) return 0;
             if (bland) {   // smallest variable id among the improving columns
+                const unsigned improving = phase1_row >= 0 ? improving_mask<true>(crow) : improving_mask<false>(crow);
                 const bool mine = lane >= 1 && lane < NC && ((improving >> lane) & 1u);
                 const int vmin = dpp_wave_min_i32(mine ? cv : 0x7fffffff);
                 q = __ffsll((long long)__ballot(mine && cv == vmin)) - 1;
@@ -328,18 +381,17 @@ struct RegLp {
             for (int s = 0; s < SLOTS; ++s) {
                 const int i = lane + 64 * s;
                 a[s] = t[s].getq(q);
-                const bool used = i < m && kind[s] != RK_DEAD;
+                const bool used = (i < m) & (kind[s] != RK_DEAD);      // (bitwise: no short-circuit branches)
                 if (used) cmf = fmaxf(cmf, fabsf((float)a[s]));
-                elig[s] = used && (kind[s] == RK_INEQ || kind[s] == RK_X0) && a[s] > TOL_PIV;
-                ratio[s] = 0.0;
-                if (elig[s]) {
-                    const double b0 = fmax(t[s].get(0), 0.0), ia = fast_rcp(a[s]);
-                    ratio[s] = b0 * ia;
-                    tmax = fmin(tmax, (b0 + HARRIS_DELTA) * ia);
-                }
+                elig[s] = used & ((kind[s] == RK_INEQ) | (kind[s] == RK_X0)) & (a[s] > TOL_PIV);
+                // (round 6: straight-line -- the reciprocal is taken in every lane, of 1 where the row is not eligible, and the results are
+                //  selected: the nested exec-mask blocks of the branchy form cost more than the five instructions they skipped)
+                const double b0 = fmax(t[s].get(0), 0.0), ia = fast_rcp(elig[s] ? a[s] : 1.0);
+                ratio[s] = elig[s] ? b0 * ia : 0.0;
+                tmax = fmin(tmax, elig[s] ? (b0 + HARRIS_DELTA) * ia : INFINITY);
             }
-            const float colmax = dpp_wave_max_f32(cmf);
-            tmax = dpp_wave_min(tmax);
+            const float colmax = rot_wave_max_f32(cmf);
+            tmax = rot_wave_min(tmax);
             if (tmax == INFINITY) return 2;
             int r = -1;
             bool leaving_x0 = false;
@@ -348,7 +400,7 @@ struct RegLp {
                 double rm = INFINITY;
 #pragma unroll
                 for (int s = 0; s < SLOTS; ++s) if (elig[s]) rm = fmin(rm, ratio[s]);
-                rm = dpp_wave_min(rm);
+                rm = rot_wave_min(rm);
                 unsigned long long key = 0; int idx = -1;
 #pragma unroll
                 for (int s = 0; s < SLOTS; ++s)
@@ -375,7 +427,7 @@ struct RegLp {
                     double am = 0.0;
 #pragma unroll
                     for (int s = 0; s < SLOTS; ++s) if (pass[s]) am = fmax(am, a[s]);
-                    rpiv = dpp_wave_max(am);
+                    rpiv = rot_wave_max(am);
 #pragma unroll
                     for (int s = SLOTS - 1; s >= 0; --s) {
                         const unsigned long long br = __ballot(pass[s] && a[s] == rpiv);
@@ -425,7 +477,7 @@ struct RegLp {
             neg[s] = lane + 64 * s < m && kind[s] == RK_INEQ && v0 < -TOL_FEAS;
             if (neg[s]) vmin = fmin(vmin, v0);
         }
-        vmin = dpp_wave_min(vmin);
+        vmin = rot_wave_min(vmin);
         if (vmin == INFINITY) return LP_OPTIMAL;
         int r = -1;
 #pragma unroll

@@ -275,6 +275,12 @@ struct mpc_handle {
     hipStream_t stream2 = nullptr;   // side stream: retry kernels of few long-running wavefronts overlap the main pipeline
     hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_xfork = nullptr, ev_xjoin = nullptr;
     hipStream_t stream3 = nullptr;   // region stage of a level, launched under its (x,theta) stage
+    hipStream_t stream4 = nullptr;   // round 6: the drain launch of the queue form of the region stage (beside the early launch on stream3)
+    hipEvent_t ev_rjoin2 = nullptr, ev_nth = nullptr;   // its completion; "the theta list's length has been published"
+    int r2_early = 0;                // MPC_R2_EARLY=1: the queue form of a large last level's region stage (measured slower, DESIGN 6h: off; tests switch it on)
+    long long r2_early_min = 65536;  // MPC_R2_EARLY_MIN: smallest level that takes the queue form
+    int r2_early_wpc = 0, r2_early_spin = 200000, r2_early_thw = 1, r2_early_prio = 3;   // ... MPC_R2_EARLY_THW: theta wavefronts per SIMD beside the early launch; MPC_R2_EARLY_PRIO: their issue priority   // MPC_R2_EARLY_WPC: wavefronts per CU of the early launch; MPC_R2_EARLY_SPIN: looks at an empty queue before a wavefront leaves
+    long long n_r2_early = 0;        // regions the early launch built in the last level run (statistics)
     hipEvent_t ev_rfork = nullptr, ev_rjoin = nullptr, ev_rgo = nullptr;
     bool no_roverlap = false;        // MPC_NO_ROVERLAP=1 / mpc_set_region_overlap(h, 0): region stage after the (x,theta) stage (no overlap)
     bool r3_dirty = false;           // a region kernel launched on stream3 has not been joined by a completed level yet
@@ -625,6 +631,15 @@ static int create_fill(const mpc_problem *p, int32_t device, void *stream, mpc_h
     HIP_TRY(nullptr, pooled_event(&h->ev_part, false));
     HIP_TRY(nullptr, pooled_event(&h->ev_xjoin, false));
     HIP_TRY(nullptr, pooled_stream(&h->stream3));
+    HIP_TRY(nullptr, pooled_stream(&h->stream4));
+    HIP_TRY(nullptr, pooled_event(&h->ev_rjoin2, false));
+    HIP_TRY(nullptr, pooled_event(&h->ev_nth, false));
+    { const char *ev = std::getenv("MPC_R2_EARLY"); if (ev) h->r2_early = std::atoi(ev); }
+    { const char *ev = std::getenv("MPC_R2_EARLY_MIN"); if (ev) h->r2_early_min = std::atoll(ev); }
+    { const char *ev = std::getenv("MPC_R2_EARLY_WPC"); if (ev) h->r2_early_wpc = std::max(0, std::atoi(ev)); }
+    { const char *ev = std::getenv("MPC_R2_EARLY_SPIN"); if (ev) h->r2_early_spin = std::max(0, std::atoi(ev)); }
+    { const char *ev = std::getenv("MPC_R2_EARLY_THW"); if (ev) h->r2_early_thw = std::max(1, std::atoi(ev)); }
+    { const char *ev = std::getenv("MPC_R2_EARLY_PRIO"); if (ev) h->r2_early_prio = std::max(0, std::min(3, std::atoi(ev))); }
     HIP_TRY(nullptr, pooled_event(&h->ev_rfork, false));
     HIP_TRY(nullptr, pooled_event(&h->ev_rjoin, false));
     HIP_TRY(nullptr, pooled_event(&h->ev_rgo, false));
@@ -1096,6 +1111,7 @@ int mpc_destroy(mpc_handle *h) {
     (void)hipStreamSynchronize(h->stream);
     if (h->stream2) (void)hipStreamSynchronize(h->stream2);
     if (h->stream3) (void)hipStreamSynchronize(h->stream3);
+    if (h->stream4) (void)hipStreamSynchronize(h->stream4);
     graveyard_flush(h);
     for (DevBuf *b : {&h->blocks, &h->iblocks, &h->frontier, &h->children, &h->status, &h->pruned, &h->flag, &h->pos, &h->opt_list,
                       &h->childmask, &h->count, &h->offset, &h->recd, &h->reci, &h->ctr, &h->scratch, &h->sums, &h->retry_list, &h->pf_dev, &h->pr2_dev, &h->headd, &h->headi, &h->epool, &h->facet_flags, &h->kkt_code, &h->kkt_L, &h->theta_blocks, &h->xq_groups, &h->xq_list, &h->x1_buf, &h->xretry_list, &h->theta_list, &h->vretry_list, &h->status_tmp, &h->part_counts, &h->part_lists, &h->kept_g, &h->done_g, &h->dict_d[0], &h->dict_d[1], &h->dict_i[0], &h->dict_i[1],
@@ -1119,6 +1135,9 @@ int mpc_destroy(mpc_handle *h) {
     return_event(h->ev_rgo, false);
     return_stream(h->stream2);
     return_stream(h->stream3);
+    return_stream(h->stream4);
+    return_event(h->ev_rjoin2, false);
+    return_event(h->ev_nth, false);
     if (h->own_stream) return_stream(h->stream);
     delete h;
     return MPC_OK;
@@ -1134,6 +1153,7 @@ int mpc_trim(mpc_handle *h) {
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     if (h->stream2) HIP_TRY(h, hipStreamSynchronize(h->stream2));
     if (h->stream3) HIP_TRY(h, hipStreamSynchronize(h->stream3));
+    if (h->stream4) HIP_TRY(h, hipStreamSynchronize(h->stream4));
     graveyard_flush(h);
     stream_release(h);
     for (DevBuf *b : {&h->frontier, &h->children, &h->status, &h->pruned, &h->flag, &h->pos, &h->opt_list, &h->childmask, &h->count, &h->offset, &h->recd, &h->reci,
@@ -1376,7 +1396,7 @@ static void stream_ready(mpc_handle *h) {
 }
 static void stream_release(mpc_handle *h) {   // blocks of a streamed level nobody took
     // a level that ended early (error return) after launching its region kernel on stream3 may still be writing the blocks
-    if (h->r3_dirty) { (void)hipStreamSynchronize(h->stream3); h->r3_dirty = false; }
+    if (h->r3_dirty) { (void)hipStreamSynchronize(h->stream3); if (h->stream4) (void)hipStreamSynchronize(h->stream4); h->r3_dirty = false; }
     if (!h->so.taken) { if (h->so.hd) (void)host_pool_give(h->so.hd); if (h->so.hi) (void)host_pool_give(h->so.hi); if (h->so.er) (void)host_pool_give(h->so.er); }
     h->so = mpc_handle::StreamOut();
 }
@@ -2121,6 +2141,12 @@ static int level_run_impl(mpc_handle *h, int32_t gen_children, int32_t flags, mp
             hipLaunchKernelGGL(k_zero_bufs, dim3(1), dim3(256), 0, st, z);
             HIP_TRY(h, hipGetLastError());
         }
+        // (round 6) a large last level: the theta kernel will list its optimal candidates itself (the queue form below); entries -1 = not written
+        const bool r2_queue_ready = lean && h->r2_early > 0 && !gen_children && n >= h->r2_early_min && n <= 0x7fffffffLL && h->fast && h->fast_r >= 0 && !h->force_v1 && !(flags & MPC_LEVEL_GRAPH);
+        if (r2_queue_ready) {
+            hipLaunchKernelGGL(k_fill_i32, dim3((unsigned)std::min<long long>(1024, (n + 255) / 256)), dim3(256), 0, st, h->opt_list.as<int32_t>(), n, -1);
+            HIP_TRY(h, hipGetLastError());
+        }
         int32_t *dcnt = h->dcnt.as<int32_t>();
         bool theta_lean = false, xq_lean = false, children_lean = false;
         // deterministic partition of the candidates into up to four lists by status (spec: status -> class nibble, 15 = none);
@@ -2179,14 +2205,17 @@ static int level_run_impl(mpc_handle *h, int32_t gen_children, int32_t flags, mp
         h->fd = h->n_x * h->n_t + h->n_x + k * h->n_t + k;
         h->fi = 8 + k + h->n_tc + k + 2 * (h->n_c - k);
         int32_t *region_out_hi = nullptr;   // head_i of the level's slots as the device sees it (device buffer or mapped host block)
-        auto region2_launch = [&](int32_t n_opt, int32_t extra, hipStream_t rst, bool one_wave) -> int {
+        // Round 6, the queue form (`early`): the launch runs BESIDE the theta kernel and takes the optimal candidates from the queue that kernel
+        // fills (n_opt is then the BOUND that sizes the buffers: the length of the theta list); region2_drain below is its second launch.
+        struct R2Saved { double *hd = nullptr, *er = nullptr; int32_t *hi = nullptr; RegionStream rs{}; int ldk = 0; bool valid = false; } r2s;
+        auto region2_launch = [&](int32_t n_opt, int32_t extra, hipStream_t rst, bool one_wave, bool early = false) -> int {
             const int rows_t_ = h->n_c - h->n_eq + h->n_tc;
             const size_t n_tot = (size_t)n_opt + (size_t)extra;   // slots: the launch's candidates + spare ones for late optimal candidates
             HIP_TRY(h, h->headd.ensure(n_tot * h->fd * sizeof(double), st));
             HIP_TRY(h, h->headi.ensure(n_tot * h->fi * sizeof(int32_t), st));
             HIP_TRY(h, h->epool.ensure(n_tot * rows_t_ * (h->n_t + 1) * sizeof(double), st));
             // few optimal candidates: several wavefronts per candidate (the facet tests are split among them)
-            int W = (h->no_rsplit || one_wave) ? 1 : h->rsplit_max;
+            int W = (h->no_rsplit || one_wave || early) ? 1 : h->rsplit_max;
             while (W > 1 && (long long)n_opt * W > h->grid_r2) W >>= 1;
             const int ldk = (rows_t_ + 1 + 63) & ~63;
             if (W > 1) {
@@ -2196,7 +2225,8 @@ static int level_run_impl(mpc_handle *h, int32_t gen_children, int32_t flags, mp
             }
             // an overlapped launch may take only a share of the wave slots (r2_cap_pct): its 256-register wavefronts otherwise fill the
             // register file of every SIMD they sit on and the (x,theta) kernel beside them gets no slot there until they leave
-            const long long grid_cap = (rst != st && one_wave) ? std::max<long long>(h->n_cu, (long long)h->grid_r2 * h->r2_cap_pct / 100) : h->grid_r2;
+            const long long grid_cap = early ? std::min<long long>(h->grid_r2, (long long)h->n_cu * h->r2_early_wpc)
+                                       : ((rst != st && one_wave) ? std::max<long long>(h->n_cu, (long long)h->grid_r2 * h->r2_cap_pct / 100) : h->grid_r2);
             const dim3 g((unsigned)std::min<long long>((long long)n_opt * W, grid_cap)), b(64);
             const DevProblem *pr = h->pr2_dev.as<DevProblem>();
             // where the records go: device buffers (fetched / gathered later), or -- streaming -- page-locked host blocks the
@@ -2235,8 +2265,17 @@ static int level_run_impl(mpc_handle *h, int32_t gen_children, int32_t flags, mp
                                                    W, h->kept_g.as<uint8_t>(), ldk, h->done_g.as<unsigned int>(), \
                                                    h->no_rbox ? (const double *)nullptr : h->targs.tvp + (size_t)NT_ * NT_ + NT_, rs)
             region_out_hi = out_hi;
-            if (extra > 0) { rprep.head_i = out_hi; rprep.fi = h->fi; rprep.first = n_opt; rprep.extra = extra; rprep_any = true; }
-            if (rst != st) {
+            if (early) {
+                // every slot is marked empty first: which of them the queue will reach is not known yet (the host's region objects are cut
+                // from whole chunks of slots)
+                rprep.head_i = out_hi; rprep.fi = h->fi; rprep.first = 0; rprep.extra = (int)n_tot; rprep_any = true;
+                rs.early = 1; rs.spin_max = h->r2_early_spin; rs.q_cap = (int)std::min<size_t>(nn, 0x7fffffff);
+                r2s.hd = out_hd; r2s.hi = out_hi; r2s.er = out_er; r2s.rs = rs; r2s.ldk = ldk; r2s.valid = true;
+            } else if (extra > 0) { rprep.head_i = out_hi; rprep.fi = h->fi; rprep.first = n_opt; rprep.extra = extra; rprep_any = true; }
+            if (early) {
+                // (everything this launch reads was queued on the main stream in front of the event the host has just waited for)
+                { int rcs = prep_flush_on(rprep, rprep_any, rst); if (rcs) return rcs; }
+            } else if (rst != st) {
                 // The side stream does NOT wait for the main stream: every caller has synchronised the main stream (the partition whose
                 // counts sized this launch) and has queued nothing since that the region kernel reads, so the region stage's own
                 // preparation and the kernel go straight to the side stream -- one cross-stream hop (~25 us) less per large level than the
@@ -2255,6 +2294,8 @@ static int level_run_impl(mpc_handle *h, int32_t gen_children, int32_t flags, mp
                 { int rcs = prep_flush_on(rprep, rprep_any, st); if (rcs) return rcs; }
             }
             if (h->timing) HIP_TRY(h, hipEventRecord(h->kev[4], rst));
+            if (early && h->r2_early_wpc <= 0) { /* MPC_R2_EARLY_WPC=0: no wavefronts beside the theta kernel, the drain launch alone (it still starts without a partition and its read-back) */ }
+            else
             switch (h->fast_r) {
                 case 0: MPC_LAUNCH_R2(4, 1); break;
                 case 1: MPC_LAUNCH_R2(4, 2); break;
@@ -2269,9 +2310,37 @@ static int level_run_impl(mpc_handle *h, int32_t gen_children, int32_t flags, mp
             kernel_timed[2] = true;
             HIP_TRY(h, hipGetLastError());
             h->used_region2 = true;
-            stream_ready(h);   // the caller of mpc_level_stream_info may start consuming chunks
+            if (!early) stream_ready(h);   // the caller of mpc_level_stream_info may start consuming chunks (queue form: once the queue's length is known)
             return MPC_OK;
         };
+        // the drain launch of the queue form: behind the theta kernel (the queue is closed), on its own stream beside the early launch
+        auto region2_drain = [&](int32_t n_opt) -> int {
+            const dim3 g((unsigned)std::max<long long>(1, std::min<long long>(n_opt, h->grid_r2))), b(64);
+            const DevProblem *pr = h->pr2_dev.as<DevProblem>();
+            RegionStream rs = r2s.rs;
+            rs.early = 2;
+            double *out_hd = r2s.hd, *out_er = r2s.er; int32_t *out_hi = r2s.hi;
+            const int ldk = r2s.ldk, W = 1;
+            hipStream_t rst = h->stream4;
+#define MPC_LAUNCH_R2(NT_, SL_) hipLaunchKernelGGL((k_region2<NT_, SL_>), g, b, h->lds_r2, rst, pr, h->frontier.as<int32_t>(), k, h->opt_ptr, n_opt, \
+                                                   h->status.as<uint8_t>(), out_hd, out_hi, h->fd, h->fi, out_er, ctr, kkc, kkl, \
+                                                   W, h->kept_g.as<uint8_t>(), ldk, h->done_g.as<unsigned int>(), \
+                                                   h->no_rbox ? (const double *)nullptr : h->targs.tvp + (size_t)NT_ * NT_ + NT_, rs)
+            switch (h->fast_r) {
+                case 0: MPC_LAUNCH_R2(4, 1); break;
+                case 1: MPC_LAUNCH_R2(4, 2); break;
+                case 2: MPC_LAUNCH_R2(8, 1); break;
+                case 3: MPC_LAUNCH_R2(8, 2); break;
+                case 4: MPC_LAUNCH_R2(10, 1); break;
+                default: MPC_LAUNCH_R2(10, 2); break;
+            }
+#undef MPC_LAUNCH_R2
+            HIP_TRY(h, hipGetLastError());
+            HIP_TRY(h, hipEventRecord(h->ev_rjoin2, rst));
+            return MPC_OK;
+        };
+        bool r2_early = false, r2_drained = false, r2_early_A = false;   // r2_early: the theta kernel lists its optimal candidates; _A: an early region launch runs beside it
+        long long r2_early_ntot = 0;   // slots of the queue form's buffers (the bound + spare ones)
         bool region_launched = false;
         int32_t n_late = 0;   // optimal candidates found after an overlapped region launch (spare slots)
         int32_t n_opt_fast = -1;   // >= 0: the fast path has already built h->opt_list
@@ -2417,8 +2486,31 @@ static int level_run_impl(mpc_handle *h, int32_t gen_children, int32_t flags, mp
                     early_xq = true; xq_early_ran = true;
                 }
             }
+            // Round 6: region wavefronts BESIDE the theta stage of a large last level (the queue form).  The theta
+            // kernel appends every candidate it finds optimal to a queue (the level's opt_list) the moment it has decided it; a first
+            // region launch of a few wavefronts per CU is already running on the side stream and builds regions while the theta stage is
+            // still solving -- until now the region stage waited for the theta kernel's tail, a partition and a host read-back.  The
+            // record buffers are sized by the length of the theta list, which k_kkt_thread has counted: published here, read by the host
+            // while the theta kernel already runs.  A second launch behind the theta kernel drains the queue with the full width.
+            if (r2_queue_ready && early_xq && kkt_listed && n_theta > 0 && !h->theta_open && !h->no_roverlap && h->test_late <= 0 && h->test_spare <= 0) {
+                r2_early = true;
+                if (h->r2_early_wpc > 0) {   // (the early launch's buffers are sized by the theta list's length: read while the theta kernel runs)
+                    hipLaunchKernelGGL(k_publish_words, dim3(1), dim3(64), 0, st, reinterpret_cast<const unsigned int *>(dcnt + 0), reinterpret_cast<unsigned int *>(h->tot_dev + 9), 1);
+                    HIP_TRY(h, hipGetLastError());
+                    HIP_TRY(h, hipEventRecord(h->ev_nth, st));
+                }
+            }
             if (n_theta > 0) {   // two-stage theta LP
                 ThetaArgs ta = h->targs;
+                if (r2_early) {
+                    ta.optq = h->opt_list.as<int32_t>(); ta.q_tail = &ctr->q_tail;
+                    // one theta wavefront per SIMD (the kernel is a tail of few long LPs: 0.40 / 0.33 ms with one / two, round 5) leaves
+                    // every SIMD room for a region wavefront of the early launch; the theta wavefronts issue with priority (ThetaArgs::prio)
+                    if (h->r2_early_wpc > 0) {
+                        if (ta.wave_max > 0) ta.wave_max = std::min<int>(ta.wave_max, h->r2_early_thw * 4 * h->n_cu);
+                        ta.prio = h->r2_early_prio;
+                    }
+                }
                 ta.chunk = (int)std::max<long long>(1, std::min<long long>(16, n_theta / ((long long)h->grid_f * 8)));
                 if (theta_lean) { ta.n_dev = dcnt + 0; ta.chunk = 0; }   // length and chunk rule on the device
                 // wave slots the theta kernel takes (ThetaArgs::wave_div / wave_max): with the length on the device the kernel applies the
@@ -2441,6 +2533,25 @@ static int level_run_impl(mpc_handle *h, int32_t gen_children, int32_t flags, mp
                 kernel_timed[0] = true;
                 n_theta_items = n_theta;
                 HIP_TRY(h, hipGetLastError());
+                if (r2_early) {
+                    // the queue closes behind the theta kernel; its length and the number of doubtful candidates are published for the host
+                    hipLaunchKernelGGL(k_set_u32, dim3(1), dim3(64), 0, st, &ctr->q_closed, 1u);
+                    hipLaunchKernelGGL(k_publish_words, dim3(1), dim3(64), 0, st, &ctr->q_tail, reinterpret_cast<unsigned int *>(h->tot_dev + 10), 1);
+                    hipLaunchKernelGGL(k_publish_words, dim3(1), dim3(64), 0, st, &ctr->n_retry_theta, reinterpret_cast<unsigned int *>(h->tot_dev + 11), 1);
+                    HIP_TRY(h, hipGetLastError());
+                    HIP_TRY(h, hipEventRecord(h->ev_part, st));
+                    if (h->r2_early_wpc > 0) {
+                        // ... and while the theta kernel runs: the early region launch (MPC_R2_EARLY_WPC > 0; off by default)
+                        HIP_TRY(h, hipEventSynchronize(h->ev_nth));
+                        const int32_t n_theta_host = h->tot_host[9];
+                        const int32_t spare = (int32_t)std::min<long long>(std::max<long long>(2048, n_theta_host / 8), 1 << 20);
+                        h->opt_ptr = h->opt_list.as<int32_t>();
+                        int rcs = n_theta_host > 0 ? region2_launch(n_theta_host, spare, h->stream3, true, true) : MPC_OK;
+                        if (rcs) return rcs;
+                        r2_early_ntot = (long long)n_theta_host + spare;
+                        r2_early_A = n_theta_host > 0;
+                    }
+                }
             }
             // ---- (x,theta) stage with the dictionary cache -------------------------------------------------------------
             const int nxc = h->fast_x >= 2 ? 32 : 16;
@@ -2544,7 +2655,15 @@ static int level_run_impl(mpc_handle *h, int32_t gen_children, int32_t flags, mp
                 // The thread pass is still rewriting the statuses of ITS candidates (NEEDX -> feasible / infeasible / singular) on the second
                 // stream: this partition asks only for the two classes it never touches -- doubtful and optimal candidates of the theta
                 // stage --, so that the region stage can start beside it; the open candidates are listed when the pass has ended (below).
-                { int rcs = partition({{ST_RETRY, 0}, {ST_OPT_PENDING, 2}}, cntA); if (rcs) return rcs; }
+                if (r2_early) {
+                    // (queue form: the optimal candidates are the queue; region wavefronts are already rewriting their statuses.  The doubtful
+                    //  candidates are counted by the theta kernel itself: without one -- the usual case -- no partition is needed at all, and
+                    //  its 1024-thread workgroups would wait for room beside the region wavefronts: 0.75 ms on config 4's last level)
+                    HIP_TRY(h, hipEventSynchronize(h->ev_part));
+                    if (h->tot_host[11] > 0) { int rcs = partition({{ST_RETRY, 0}}, cntA); if (rcs) return rcs; }
+                    cntA[2] = h->tot_host[10];
+                    h->opt_ptr = h->opt_list.as<int32_t>();
+                } else { int rcs = partition({{ST_RETRY, 0}, {ST_OPT_PENDING, 2}}, cntA); if (rcs) return rcs; }
                 cntA[3] = (int32_t)std::min<long long>(n, 0x7fffffffLL);     // a bound, for the decisions that follow; the count comes after the join
             } else { int rcs = partition({{ST_RETRY, 0}, {ST_FEASIBLE, 1}, {ST_OPT_PENDING, 2}, {ST_NEEDX, 3}, {ST_NEEDX_SING, 3}}, cntA); if (rcs) return rcs; }
             // The doubtful candidates are re-solved by the LDS engine, which can refactorise its basis: a few hundred
@@ -2581,6 +2700,19 @@ static int level_run_impl(mpc_handle *h, int32_t gen_children, int32_t flags, mp
             const bool quick_test = cntA[3] > 0 && !(flags & MPC_LEVEL_GRAPH) && !h->storing && dc.parent_slot && !h->no_xquick;
             const bool use_grouped = quick_test && !h->no_xqgroup && ((h->last_level_n > 0 && (long long)cntA[3] >= 10 * h->last_level_n) || h->force_xqgroup) &&
                                      cntA[3] >= 4096 && lds_q <= 64 * 1024 && !early_xq;   // (after the thread pass few candidates per parent are left)
+            if (r2_early_A) {
+                // queue form: the early launch is running; the queue is closed and holds cntA[2] candidates -- the drain launch takes what is
+                // left with the full width, and the host learns how many chunks of slots there are
+                h->n_opt = cntA[2];
+                region_extra = (int32_t)std::max<long long>(0, r2_early_ntot - cntA[2]);     // every slot behind the queue's is a spare one
+                if (h->so.active) {
+                    h->so.n_chunks = (int)(((long long)cntA[2] + (1ll << h->so.shift) - 1) >> h->so.shift);
+                    h->cw_chunks = h->so.n_chunks;
+                }
+                if (cntA[2] > 0) { int rcs = region2_drain(cntA[2]); if (rcs) return rcs; r2_drained = true; }
+                region_launched = true;
+                stream_ready(h);
+            } else
             if (!h->no_roverlap && !h->theta_open && cntA[2] > 0 && h->fast_r >= 0 && !(flags & MPC_LEVEL_GRAPH) && x_items >= h->roverlap_min && (!use_grouped || h->xqg_overlap)) {
                 // Candidates that turn out optimal later -- re-solved doubtful ones: the n_early of the theta stage, rarely one of
                 // the (x,theta) stage -- get spare slots behind the launch's and take the LDS-engine route of the candidates
@@ -2592,7 +2724,7 @@ static int level_run_impl(mpc_handle *h, int32_t gen_children, int32_t flags, mp
                 const int32_t hold = std::min<int32_t>(std::max(h->test_late, 0), cntA[2] - 1);
                 const int32_t n_launch = cntA[2] - hold;
                 region_extra = std::max(0, n_early + hold + std::min<int32_t>(cntA[3], 1024) - std::max(h->test_spare, 0));
-                rprep.copy_dst = h->opt_list.as<int32_t>(); rprep.copy_src = part_list(2); rprep.copy_n = n_launch; rprep_any = true;
+                if (!r2_early) { rprep.copy_dst = h->opt_list.as<int32_t>(); rprep.copy_src = part_list(2); rprep.copy_n = n_launch; rprep_any = true; }   // (queue form: the list IS the queue)
                 h->opt_ptr = h->opt_list.as<int32_t>();
                 h->n_opt = n_launch;
                 int rcs = region2_launch(n_launch, region_extra, h->stream3, x_items >= h->roverlap_long);
@@ -2766,6 +2898,7 @@ static int level_run_impl(mpc_handle *h, int32_t gen_children, int32_t flags, mp
                 HIP_TRY(h, hipMemsetAsync(&ctr->work_retry, 0, sizeof(unsigned int), st));
             }
             if (region_launched) HIP_TRY(h, hipStreamWaitEvent(st, h->ev_rjoin, 0));   // the region kernel rewrites statuses
+            if (r2_drained) HIP_TRY(h, hipStreamWaitEvent(st, h->ev_rjoin2, 0));
             bool have_cntB = false;
             if (region_launched && lean && !h->no_spec_tail) {
                 // The overlapped region stage has finished (the stream waits for it above), so in the usual case nothing is left to do but
@@ -2809,6 +2942,7 @@ static int level_run_impl(mpc_handle *h, int32_t gen_children, int32_t flags, mp
                                    h->frontier.as<int32_t>(), (long long)n_retry, k, h->status.as<uint8_t>(), ctr, part_list(0), (const int32_t *)nullptr);
                 HIP_TRY(h, hipGetLastError());
                 if (region_launched) HIP_TRY(h, hipStreamWaitEvent(st, h->ev_rjoin, 0));
+                if (r2_drained) HIP_TRY(h, hipStreamWaitEvent(st, h->ev_rjoin2, 0));
                 { int rcs = recession(); if (rcs) return rcs; }
                 { int rcs = partition({{ST_OPT_PENDING, 2}}, cntB); if (rcs) return rcs; }   // they may have turned out optimal
             }
@@ -2882,6 +3016,18 @@ static int level_run_impl(mpc_handle *h, int32_t gen_children, int32_t flags, mp
         if (prep_any || rprep_any) return fail(h, MPC_ERR_STATE, "level_run: a queued preparation (clear / copy) was never issued");
         h->r3_dirty = false;   // the main stream waited for ev_rjoin before the second partition
         std::memcpy(&host_ctr, h->tot_host + 16, sizeof(LevelCounters));
+        h->n_r2_early = 0;
+        if (r2_early_A) {
+            if (host_ctr.q_fault) return fail(h, MPC_ERR_HIP, "region stage, queue form: a claimed queue entry never arrived");
+            h->n_r2_early = host_ctr.q_early;
+            // the last chunk of slots is a partial one the kernel could not recognise as complete (it never knew the queue's final length):
+            // every slot is complete now
+            if (h->so.active && h->st_flags.p) {
+                int32_t *fl = h->st_flags.as<int32_t>();
+                for (int j = 0; j < h->so.n_chunks; ++j) __atomic_store_n(fl + j, 1, __ATOMIC_RELEASE);
+            }
+            if (std::getenv("MPC_DEBUG_R2_EARLY")) std::fprintf(stderr, "[mpc] k=%d queue form of the region stage: %u of %lld regions' candidates built by the early launch\n", k, host_ctr.q_early, (long long)h->n_opt);
+        }
         {
             const int32_t *cnt_host = h->tot_host + 16 + (int)(sizeof(LevelCounters) / 4);
             if (children_lean) h->n_children = cnt_host[20];

@@ -677,3 +677,27 @@ def test_config4_one_level_beyond_the_goldens_equals_the_oracle_on_a_sample(orac
 def kkt_cond_large(P, active_set):
     from conftest import kkt_condition
     return kkt_condition(P, active_set) > 1e6
+
+
+def test_queue_form_of_the_last_level_region_stage_gives_the_same_regions(monkeypatch):
+    """Round 6, measured and left off: on a large last level the theta kernel lists its optimal candidates in a queue and region
+    wavefronts of an early launch (MPC_R2_EARLY_WPC per CU) take them while the theta stage is still solving; a drain launch behind the theta
+    kernel takes the rest.  Slot order then follows the queue (atomic), so the comparison is by active set: the regions of config 4's
+    fifth level are those of the default form, bit for bit, with the early launch and with the drain launch alone."""
+    from ppopt_amd.mp_solvers import mpqp_hip_combinatorial
+    import bench
+    prog = bench.build_program('c4')
+    ref = {tuple(r.active_set): r for r in mpqp_hip_combinatorial.solve(prog, max_levels=5).critical_regions}
+    prog.release_engine()
+    for wpc in ('4', '0'):
+        monkeypatch.setenv('MPC_R2_EARLY', '1')
+        monkeypatch.setenv('MPC_R2_EARLY_WPC', wpc)
+        prog2 = bench.build_program('c4')
+        got = {tuple(r.active_set): r for r in mpqp_hip_combinatorial.solve(prog2, max_levels=5).critical_regions}
+        prog2.release_engine()
+        assert got.keys() == ref.keys(), wpc
+        for key, r in got.items():
+            q = ref[key]
+            assert r.omega_set == q.omega_set and r.lambda_set == q.lambda_set and r.regular_set == q.regular_set, (wpc, key)
+            for fld in ('A', 'b', 'C', 'd', 'E', 'f'):
+                assert numpy.asarray(getattr(r, fld)).tobytes() == numpy.asarray(getattr(q, fld)).tobytes(), (wpc, key, fld)
