@@ -796,9 +796,17 @@ static int create_fill(const mpc_problem *p, int32_t device, void *stream, mpc_h
         int32_t lp_status = -1;
         if (ok) {
             std::vector<uint8_t> eqf(ntc, 0);
-            int rc0 = ntc > nt ? lp_batch_impl(device, 1, ntc, nt, p->A_t, 1, p->b_t, 1, nullptr, 1, eqf.data(), &lp_status, nullptr, nullptr, nullptr, tight.data()) : MPC_ERR_INVALID;
-            HIP_TRY(nullptr, hipSetDevice(device));
-            ok = rc0 == MPC_OK && lp_status == LP_OPTIMAL;
+            if (ntc == nt) {
+                // Exactly n_theta rows (round 6): if they are independent (the LU below decides) their common point is the set's only vertex
+                // -- a pointed cone, e.g. the lower bounds of theta that a presolve leaves when the main rows imply the upper ones
+                // (profiles/r05_sweep.json: mpqp_10_2_20 / _30 ran on the LDS-engine kernels for want of this case).
+                for (int i = 0; i < ntc; ++i) tight[i] = 1;
+                lp_status = LP_OPTIMAL;
+            } else {
+                int rc0 = lp_batch_impl(device, 1, ntc, nt, p->A_t, 1, p->b_t, 1, nullptr, 1, eqf.data(), &lp_status, nullptr, nullptr, nullptr, tight.data());
+                HIP_TRY(nullptr, hipSetDevice(device));
+                ok = rc0 == MPC_OK && lp_status == LP_OPTIMAL;
+            }
         }
         std::vector<int> B;
         for (int i = 0; i < ntc && ok; ++i) if (tight[i]) B.push_back(i);
@@ -1415,6 +1423,11 @@ static void stream_release(mpc_handle *h) {   // blocks of a streamed level nobo
 // dcnt layout (int32): [0] theta list | [12] doubtful after the theta stage | [4..7] classes after their re-solve: -, feasible,
 // optimal (= the region launch), open | [8] open after the quick test | [24] doubtful after the (x,theta) stage | [17] optimal
 // candidates that missed the region launch | [20] children
+// Largest number of inequality rows k_kkt_thread solves for (one thread per candidate, everything in registers).  Round 6: 8 -> 10 -- the
+// K = 9, 10 instantiations keep their k x k system and the k x (n_theta + 1) multipliers in 234-256 VGPRs (+ up to 108 AGPRs as spill space,
+// one wavefront per SIMD at n_theta > 4) and still beat the wavefront-wide LDS solve inside k_theta2 several times over; K = 12
+// needs 364 registers at every n_theta.  The shared launches of several programs (batch_level.hip) keep 8.
+constexpr int KKT_THREAD_MAX = 10;
 static bool small_path_ok(const mpc_handle *h, long long n, int k, int32_t flags, int32_t gen_children) {
     if (h->no_smallpath || !h->fast || h->force_v1 || h->fast_r < 0 || n < 1 || n > h->smallpath_max) return false;
     if (flags & MPC_LEVEL_GRAPH) return false;
@@ -1493,7 +1506,7 @@ static int level_run_small(mpc_handle *h, int32_t gen_children, int32_t flags, m
     ThetaArgs ta = h->targs;
     ta.chunk = 1;
     const int kd = k - h->targs.ne;   // rows the one-thread KKT kernel solves for (the equality rows are eliminated)
-    if (h->kkt_mode == 0 && kd >= 1 && kd <= 8 && !h->no_kkt_thread) {
+    if (h->kkt_mode == 0 && kd >= 1 && kd <= KKT_THREAD_MAX && !h->no_kkt_thread) {
         HIP_TRY(h, h->kkt_code.ensure(nn, st));
         HIP_TRY(h, h->kkt_L.ensure(nn * (size_t)k * (h->n_t + 1) * sizeof(double), st));
         kkc = h->kkt_code.as<uint8_t>(); kkl = h->kkt_L.as<double>();
@@ -1502,7 +1515,7 @@ static int level_run_small(mpc_handle *h, int32_t gen_children, int32_t flags, m
 #define MPC_LAUNCH_KKT(K_) case K_: if (h->fast_t >= 4) hipLaunchKernelGGL((k_kkt_thread<K_, 10>), g, b, 0, st, pf, fr, n, h->kkt_code.as<uint8_t>(), h->kkt_L.as<double>(), stp, tk, ctr); \
                                     else if (h->fast_t >= 2) hipLaunchKernelGGL((k_kkt_thread<K_, 8>), g, b, 0, st, pf, fr, n, h->kkt_code.as<uint8_t>(), h->kkt_L.as<double>(), stp, tk, ctr); \
                                     else hipLaunchKernelGGL((k_kkt_thread<K_, 4>), g, b, 0, st, pf, fr, n, h->kkt_code.as<uint8_t>(), h->kkt_L.as<double>(), stp, tk, ctr); break
-        switch (kd) { MPC_LAUNCH_KKT(1); MPC_LAUNCH_KKT(2); MPC_LAUNCH_KKT(3); MPC_LAUNCH_KKT(4); MPC_LAUNCH_KKT(5); MPC_LAUNCH_KKT(6); MPC_LAUNCH_KKT(7); MPC_LAUNCH_KKT(8); }
+        switch (kd) { MPC_LAUNCH_KKT(1); MPC_LAUNCH_KKT(2); MPC_LAUNCH_KKT(3); MPC_LAUNCH_KKT(4); MPC_LAUNCH_KKT(5); MPC_LAUNCH_KKT(6); MPC_LAUNCH_KKT(7); MPC_LAUNCH_KKT(8); MPC_LAUNCH_KKT(9); MPC_LAUNCH_KKT(10); }
 #undef MPC_LAUNCH_KKT
         hipLaunchKernelGGL(k_compact_small, dim3(1), dim3(1024), 0, st, h->status.as<uint8_t>(), (int)n, ST_TODO, ST_TODO, h->theta_list.as<int32_t>(), dcnt + 0);
         theta_list = h->theta_list.as<int32_t>();
@@ -2407,7 +2420,7 @@ static int level_run_impl(mpc_handle *h, int32_t gen_children, int32_t flags, mp
             const int32_t *theta_list = nullptr;
             bool kkt_listed = false;
             const int kd = k - h->targs.ne;   // rows the one-thread KKT kernel solves for (the equality rows are eliminated)
-            if (h->kkt_mode == 0 && kd >= 1 && kd <= 8 && h->no_kkt_thread != 1) {
+            if (h->kkt_mode == 0 && kd >= 1 && kd <= KKT_THREAD_MAX && h->no_kkt_thread != 1) {
                 HIP_TRY(h, h->kkt_code.ensure(nn, st));
                 HIP_TRY(h, h->kkt_L.ensure(nn * (size_t)k * (h->n_t + 1) * sizeof(double), st));
                 kkc = h->kkt_code.as<uint8_t>(); kkl = h->kkt_L.as<double>();
@@ -2426,7 +2439,7 @@ static int level_run_impl(mpc_handle *h, int32_t gen_children, int32_t flags, mp
 #define MPC_LAUNCH_KKT(K_) case K_: if (h->fast_t >= 4) hipLaunchKernelGGL((k_kkt_thread<K_, 10>), g, b, 0, st, pf, fr, n, h->kkt_code.as<uint8_t>(), h->kkt_L.as<double>(), stp, ta, ctr); \
                                     else if (h->fast_t >= 2) hipLaunchKernelGGL((k_kkt_thread<K_, 8>), g, b, 0, st, pf, fr, n, h->kkt_code.as<uint8_t>(), h->kkt_L.as<double>(), stp, ta, ctr); \
                                     else hipLaunchKernelGGL((k_kkt_thread<K_, 4>), g, b, 0, st, pf, fr, n, h->kkt_code.as<uint8_t>(), h->kkt_L.as<double>(), stp, ta, ctr); break
-                switch (kd) { MPC_LAUNCH_KKT(1); MPC_LAUNCH_KKT(2); MPC_LAUNCH_KKT(3); MPC_LAUNCH_KKT(4); MPC_LAUNCH_KKT(5); MPC_LAUNCH_KKT(6); MPC_LAUNCH_KKT(7); MPC_LAUNCH_KKT(8); }
+                switch (kd) { MPC_LAUNCH_KKT(1); MPC_LAUNCH_KKT(2); MPC_LAUNCH_KKT(3); MPC_LAUNCH_KKT(4); MPC_LAUNCH_KKT(5); MPC_LAUNCH_KKT(6); MPC_LAUNCH_KKT(7); MPC_LAUNCH_KKT(8); MPC_LAUNCH_KKT(9); MPC_LAUNCH_KKT(10); }
 #undef MPC_LAUNCH_KKT
                 if (h->timing) HIP_TRY(h, hipEventRecord(h->kev[7], st));
                 kernel_timed[3] = true;

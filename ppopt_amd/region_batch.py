@@ -189,9 +189,18 @@ def materialize_regions(regions) -> None:
 
 
 def _materialize_groups(groups) -> None:
+    import operator
     for B, regs in groups.values():
-        js = numpy.fromiter((r._j for r in regs), dtype=numpy.int64, count=len(regs))
-        hd, hi = B.hd[js], B.hi[js]
+        n = len(regs)
+        if n == 0:
+            continue
+        js = numpy.fromiter(map(operator.attrgetter('_j'), regs), dtype=numpy.int64, count=n)
+        j0 = int(js[0])
+        # (round 6) the usual case -- a level's regions in slot order, one contiguous run -- takes the slot rows as a VIEW, not as a gathered copy
+        if n == 1 or (int(js[-1]) - j0 == n - 1 and bool(numpy.all(js[1:] - js[:-1] == 1))):
+            hd, hi = B.hd[j0:j0 + n], B.hi[j0:j0 + n]
+        else:
+            hd, hi = B.hd[js], B.hi[js]
         # one list of views per matrix field (cut in C by iterating the stacked array), one tolist per index field
         A = list(hd[:, B.oA:B.ob].reshape(-1, B.n_x, B.n_t))
         b = list(hd[:, B.ob:B.oC].reshape(-1, B.n_x, 1))
@@ -202,17 +211,19 @@ def _materialize_groups(groups) -> None:
         n_om, n_la, n_re = hi[:, 3].tolist(), hi[:, 4].tolist(), hi[:, 5].tolist()
         act = hi[:, B.iact:B.iact + B.k].tolist()
         # (only as many columns as the longest list of the batch: the padded widths are n_tc, k and n_c - k)
-        w_om, w_la, w_re = (int(hi[:, c].max()) if len(regs) else 0 for c in (3, 4, 5))
+        w_om, w_la, w_re = (int(hi[:, c].max()) for c in (3, 4, 5))
         om = hi[:, B.iom:B.iom + w_om].tolist()
         la = hi[:, B.ila:B.ila + w_la].tolist()
         ri = hi[:, B.iri:B.iri + w_re].tolist()
         rc = hi[:, B.irc:B.irc + w_re].tolist()
         erE, erf = B.er[:, 1:], B.er[:, :1]
-        for i, r in enumerate(regs):
-            o0, o1 = lo[i], up[i]
-            fields = {'A': A[i], 'b': b[i], 'C': C[i], 'd': d[i], 'E': erE[o0:o1], 'f': erf[o0:o1], 'active_set': act[i],
-                      'omega_set': om[i][:n_om[i]], 'lambda_set': la[i][:n_la[i]], 'regular_set': [ri[i][:n_re[i]], rc[i][:n_re[i]]]}
+        # (one zip over the columns: no index operations inside the loop; a region nobody has read yet gets the dictionary itself)
+        for r, Ai, bi, Ci, di, o0, o1, acti, omi, lai, rii, rci, n1, n2, m in zip(regs, A, b, C, d, lo, up, act, om, la, ri, rc, n_om, n_la, n_re):
+            fields = {'A': Ai, 'b': bi, 'C': Ci, 'd': di, 'E': erE[o0:o1], 'f': erf[o0:o1], 'active_set': acti,
+                      'omega_set': omi[:n1], 'lambda_set': lai[:n2], 'regular_set': [rii[:m], rci[:m]]}
             dd = r.__dict__
             if dd:      # fields that were read (or assigned) before keep their values
                 fields.update(dd)
-            dd.update(fields)
+                dd.update(fields)
+            else:
+                r.__dict__ = fields

@@ -701,3 +701,49 @@ def test_queue_form_of_the_last_level_region_stage_gives_the_same_regions(monkey
             assert r.omega_set == q.omega_set and r.lambda_set == q.lambda_set and r.regular_set == q.regular_set, (wpc, key)
             for fld in ('A', 'b', 'C', 'd', 'E', 'f'):
                 assert numpy.asarray(getattr(r, fld)).tobytes() == numpy.asarray(getattr(q, fld)).tobytes(), (wpc, key, fld)
+
+
+def test_one_thread_kkt_solves_of_nine_and_ten_rows_equal_the_wavefront_solves():
+    """Round 6: k_kkt_thread covers active sets of up to ten inequality rows (eight until now; deeper levels solved their KKT systems
+    inside k_theta2, wavefront-wide in LDS).  generate_mpqp_data(10, 2, 20, 7) runs to cardinality 10 (its parameter set is a pointed
+    cone of exactly n_theta rows: the register-resident kernels take it since round 6 as well): every level's statuses and every region
+    with the one-thread solves are those with MPC_NO_KKT_THREAD=1, bit for bit -- the same operations in the same order (kkt.hpp)."""
+    import subprocess
+    import sys
+    code = r'''
+import sys, warnings, hashlib, json
+sys.path.insert(0, %r)
+import numpy
+from ppopt_amd import MPQP_Program, problem_generator as pg
+d = pg.generate_mpqp_data(10, 2, 20, 7)
+with warnings.catch_warnings():
+    warnings.simplefilter('ignore')
+    prog = MPQP_Program(d['A'], d['b'], d['c'], d['H'], d['Q'], d['A_t'], d['b_t'], d['F'])
+eng = prog.engine(0)
+eng.pruned_clear(); eng.frontier_root()
+out = []
+depth_max = max(eng.n_x, eng.n_t) - eng.n_eq
+for depth in range(depth_max):
+    gen = depth + 1 != depth_max
+    st = eng.level_run(gen)
+    hd, hi, er, kk, slots = eng.level_regions_slots()
+    regs = sorted((numpy.array(hi[j][8:8 + int(st.k)]).tobytes(), numpy.array(hd[j]).tobytes(), numpy.array(er[int(hi[j][6]):int(hi[j][6]) + int(hi[j][2])]).tobytes()) for j in slots.tolist())
+    h = hashlib.sha256()
+    h.update(eng.frontier_get().tobytes()); h.update(eng.level_status().tobytes())
+    for r in regs:
+        for piece in r: h.update(piece)
+    out.append([int(st.k), int(st.n), int(st.n_regions), h.hexdigest()])
+    if not gen or st.n_children == 0:
+        break
+    eng.frontier_advance()
+print(json.dumps(out))
+''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    import json
+    runs = []
+    for env in ({}, {'MPC_NO_KKT_THREAD': '1'}):
+        e = dict(os.environ); e.update(env)
+        r = subprocess.run([sys.executable, '-c', code], env=e, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        runs.append(json.loads(r.stdout.strip().splitlines()[-1]))
+    assert len(runs[0]) == 10 and runs[0][-1][0] == 10
+    assert runs[0] == runs[1]

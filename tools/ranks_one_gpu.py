@@ -3,7 +3,7 @@
 solve, and per level the ranks' shard sizes (candidates, regions, children) -- the imbalance of the static subtree ownership
 that follows the one split.  Times are NOT multi-GPU times (the ranks share one device).
 
-    python tools/ranks_one_gpu.py [workload=c4] [world sizes, default 2 4 8]   -> gpurun_out/r5/ranks_<workload>.json   (workloads: bench.py's, c4x6, qt6, di8x20)
+    python tools/ranks_one_gpu.py [workload=c4] [world sizes, default 2 4 8]   -> gpurun_out/r6/ranks_<workload>.json   (workloads: bench.py's, c4x6, qt6, di8x20)
 """
 import json
 import os
@@ -41,7 +41,11 @@ def worker(rank, world, port, wl, out):
         sol = solve_distributed(eng, prog, profile=prof, max_levels=ml)
         out[rank] = (sorted(tuple(r.active_set) for r in sol.critical_regions),
                      [{'k': p['k'], 'candidates': p['candidates'], 'local': p.get('local_candidates'), 'sharded': bool(p.get('sharded')),
-                       'regions': p['regions'], 'children': p['children'], 'ms_kernels': p.get('ms_verdict', 0) + p.get('ms_region', 0) + p.get('ms_children', 0)}
+                       'regions': p['regions'], 'children': p['children'], 'ms_kernels': p.get('ms_verdict', 0) + p.get('ms_region', 0) + p.get('ms_children', 0),
+                       # round 6: what the one-thread pass of the (x,theta) question decided on THIS rank -- after a shard the
+                       # look-up of a candidate's other parents sees only the rank's own part of the previous frontier
+                       'xq_items': int(p.get('n_xq_items', 0) or 0), 'xq_thread': int(p.get('n_xq_thread', 0) or 0),
+                       'x_items': int(p.get('n_x_items', 0) or 0), 'x1': int(p.get('n_x1', 0) or 0)}
                       for p in prof if p['depth'] > 0])
         eng.close()
     finally:
@@ -54,7 +58,10 @@ if __name__ == '__main__':
     import bench
     from ppopt_amd.mp_solvers import mpqp_hip_combinatorial
     prog0, ml0 = workload(wl)
-    solo = mpqp_hip_combinatorial.solve(prog0, max_levels=ml0)
+    solo_prof = []
+    solo = mpqp_hip_combinatorial.solve(prog0, max_levels=ml0, profile=solo_prof)
+    solo_rates = {p['k']: {'thread_pass_hit_rate': round(p['n_xq_thread'] / p['n_xq_items'], 4) if p.get('n_xq_items') else None,
+                           'one_step_plan_rate': round(p['n_x1'] / p['n_x_items'], 4) if p.get('n_x_items') else None} for p in solo_prof if p['depth'] > 0}
     ref = sorted(tuple(r.active_set) for r in solo.critical_regions)
     report = {'workload': wl, 'regions_single_rank': len(ref), 'worlds': {}}
     ctx = mp.get_context('spawn')          # fresh children: a process that has touched the GPU is never re-executed
@@ -73,10 +80,15 @@ if __name__ == '__main__':
             ms = [res[r][1][i]['ms_kernels'] for r in sorted(res)]
             levels.append({'k': res[0][1][i]['k'], 'candidates': res[0][1][i]['candidates'], 'sharded': res[0][1][i]['sharded'], 'shards': loc,
                            'imbalance_max_over_mean': max(loc) / (sum(loc) / len(loc)) if res[0][1][i]['sharded'] else 1.0,
-                           'kernel_ms_per_rank_sharing_one_gpu': [round(v, 3) for v in ms]})
+                           'kernel_ms_per_rank_sharing_one_gpu': [round(v, 3) for v in ms],
+                           # share of the quick test's candidates the thread pass decided (last level) / of the dictionaries built by a one-step plan
+                           # (storing levels), per rank; `single_rank` = the same figure of the one-rank solve
+                           'thread_pass_hit_rate_per_rank': [round(res[r][1][i]['xq_thread'] / res[r][1][i]['xq_items'], 4) if res[r][1][i]['xq_items'] else None for r in sorted(res)],
+                           'one_step_plan_rate_per_rank': [round(res[r][1][i]['x1'] / res[r][1][i]['x_items'], 4) if res[r][1][i]['x_items'] else None for r in sorted(res)],
+                           'single_rank': solo_rates.get(res[0][1][i]['k'])})
         report['worlds'][str(world)] = {'all_ranks_equal_single_rank_solve': ok, 'exit_codes': [p.exitcode for p in ps], 'levels': levels}
         print(f'world {world}: every rank returns the single-rank region set: {ok}; shards per level: '
               + '; '.join(f"k={lv['k']}: {lv['shards']} (max/mean {lv['imbalance_max_over_mean']:.3f})" for lv in levels if lv['sharded']), flush=True)
-    os.makedirs('gpurun_out/r5', exist_ok=True)
+    os.makedirs('gpurun_out/r6', exist_ok=True)
     report['reshard_threshold'] = float(os.environ.get('MPC_RESHARD', '0') or 0)
-    json.dump(report, open(f'gpurun_out/r5/ranks_{wl}' + ('_reshard' if report['reshard_threshold'] > 0 else '') + '.json', 'w'), indent=1)
+    json.dump(report, open(f'gpurun_out/r6/ranks_{wl}' + ('_reshard' if report['reshard_threshold'] > 0 else '') + '.json', 'w'), indent=1)
