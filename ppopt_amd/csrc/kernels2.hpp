@@ -1013,7 +1013,7 @@ MPC_GLOBAL void MPC_LB(64) k_xq_thread(const DevProblem *__restrict__ Pg, const 
             if (feas >= 0) { n_dec++; if (by_test) n_piv++; if (from_alt) n_alt++; }
             planned = plan && feas == 1;
             left = plan && feas < 0;
-            if (planned) { pl.plan_slot[c] = slot; pl.plan_step[c] = step; }
+            if (planned) { pl.plan_slot[c] = slot; pl.plan_step[c] = step; if (dc.stored) dc.stored[c] = 1; }   // (k_x1 WILL store it: the level's end need not wait for that, round 6)
         }
         if (plan) {
             append(planned, c, pl.x1_list, pl.x1_n);
@@ -1386,8 +1386,11 @@ MPC_GLOBAL void MPC_LB(64, (NXC * SLOTS >= 64 ? 2 : (NXC * SLOTS >= 32 ? X2_WAVE
 //   XS_DROP   the new row's slack is a live nonbasic column: the column is deleted (zeroed), nothing else changes
 //   XS_ZERO   it is basic at zero: the row pivots on its largest entry (RegLp::best_col) and that column is deleted; no entry: the row is dead
 //   XS_PIVOT  it leaves the basis through the Harris test of column q: pivot (row, q), growth monitor, column q deleted
+#ifndef X1_WAVES
+#define X1_WAVES 7   // wavefronts per SIMD of k_x1 (72 registers: the next item's header rides along with the current item's columns, round 6)
+#endif
 template <int SLOTS>
-MPC_GLOBAL void MPC_LB(64, 8) k_x1(const DevProblem *__restrict__ Pg, const int32_t *__restrict__ x1_list, const int32_t *__restrict__ x1_n,
+MPC_GLOBAL void MPC_LB(64, X1_WAVES) k_x1(const DevProblem *__restrict__ Pg, const int32_t *__restrict__ x1_list, const int32_t *__restrict__ x1_n,
                                     LevelCounters *__restrict__ ctr, DictCache dc, int NXC, const int32_t *__restrict__ plan_slot,
                                     const int32_t *__restrict__ plan_step) {
     const DevProblem &P = *Pg;
@@ -1402,24 +1405,43 @@ MPC_GLOBAL void MPC_LB(64, 8) k_x1(const DevProblem *__restrict__ Pg, const int3
         if (SLOTS == 1) return __builtin_amdgcn_readlane(vec[0], r & 63);
         return __builtin_amdgcn_readlane(r < 64 ? opaque(vec[0]) : opaque(vec[SLOTS - 1]), r & 63);
     };
-    for (int w = blockIdx.x; w < n; w += gridDim.x) {
-        const int c = x1_list[w];
-        const int ps = plan_slot[c], step = plan_step[c];
+    // Round 6: an item's HEADER -- list entry, plan (parent slot, step), the record's integer part -- is requested while the item before
+    // it is still streaming its columns: an item used to start with three dependent round trips (list -> plan -> integers / pivot
+    // column) before its first column group could be asked for, a third of its time at config 4's level 4.  Deleted columns of the
+    // parent's record (known from the integer part: `alive`) are not read at all -- they are zero by construction -- only written.
+    struct Head { int c, ps, step; int var[SLOTS], kindw[SLOTS], cvv; };
+    auto head_plan = [&](int w, Head &hd) {      // first hop: which candidate, which parent, which step (wave-uniform)
+        hd.c = x1_list[w];
+        hd.ps = plan_slot[hd.c]; hd.step = plan_step[hd.c];
+    };
+    auto head_ints = [&](Head &hd) {             // second hop: the integer part of the parent's record
+        const int32_t *pi = dc.prev_i + (size_t)hd.ps * dc.stride_i;
+#pragma unroll
+        for (int sl = 0; sl < SLOTS; ++sl) {
+            const int i = lane + 64 * sl;
+            hd.var[sl] = i < mr ? pi[i] : -1;
+            hd.kindw[sl] = i < mr ? pi[mr + i] : RK_DEAD;
+        }
+        hd.cvv = lane < NXC + 3 ? pi[2 * mr + lane] : -1;
+    };
+    const int w0 = blockIdx.x, G = gridDim.x;
+    Head cur{}, nxt{};
+    if (w0 < n) { head_plan(w0, cur); head_ints(cur); }
+    for (int w = w0; w < n; w += G) {
+        const bool more = w + G < n;
+        if (more) head_plan(w + G, nxt);
+        const int c = cur.c, ps = cur.ps, step = cur.step;
         const int type = step >> 16, r = (step >> 8) & 0xff;
         int q = step & 0xff;
         const double *pd = dc.prev_d + (size_t)ps * dc.stride_d;
-        const int32_t *pi = dc.prev_i + (size_t)ps * dc.stride_i;
         double *od = dc.cur_d + (size_t)c * dc.stride_d;
         int32_t *oi = dc.cur_i + (size_t)c * dc.stride_i;
         int var[SLOTS], kind[SLOTS];
 #pragma unroll
-        for (int sl = 0; sl < SLOTS; ++sl) {
-            const int i = lane + 64 * sl;
-            var[sl] = i < mr ? pi[i] : -1;
-            kind[sl] = i < mr ? (pi[mr + i] & 0xff) : RK_DEAD;
-        }
-        int cvv = lane < NXC + 3 ? pi[2 * mr + lane] : -1;
+        for (int sl = 0; sl < SLOTS; ++sl) { var[sl] = cur.var[sl]; kind[sl] = (lane + 64 * sl) < mr ? (cur.kindw[sl] & 0xff) : RK_DEAD; }
+        int cvv = cur.cvv;
         unsigned alive = (unsigned)__builtin_amdgcn_readlane(cvv, NXC);
+        const unsigned alive_in = alive | 1u;     // columns of the parent's record that hold data (column 0: the values)
         double growth = __hiloint2double(__builtin_amdgcn_readlane(cvv, NXC + 1), __builtin_amdgcn_readlane(cvv, NXC + 2));
         bool pivot = type == XS_PIVOT;
         if (type == XS_ZERO) {
@@ -1465,8 +1487,9 @@ MPC_GLOBAL void MPC_LB(64, 8) k_x1(const DevProblem *__restrict__ Pg, const int3
 #pragma unroll
             for (int u = 0; u < CB; ++u) {
                 const int j = min(j0 + u, nc0);
+                const bool data = (alive_in >> j) & 1u;      // (uniform) a deleted column is zero in every row: not read
 #pragma unroll
-                for (int sl = 0; sl < SLOTS; ++sl) { const int i = lane + 64 * sl; tn[u][sl] = i < mr ? pd[(size_t)j * mr + i] : 0.0; }
+                for (int sl = 0; sl < SLOTS; ++sl) { const int i = lane + 64 * sl; tn[u][sl] = (data && i < mr) ? pd[(size_t)j * mr + i] : 0.0; }
             }
         };
         load_group(0);
@@ -1478,6 +1501,7 @@ MPC_GLOBAL void MPC_LB(64, 8) k_x1(const DevProblem *__restrict__ Pg, const int3
                 for (int sl = 0; sl < SLOTS; ++sl) t[u][sl] = tn[u][sl];
             }
             if (j0 + CB <= nc0) load_group(j0 + CB);
+            else if (more) head_ints(nxt);      // behind the item's last column group: the next item's integers (its plan has long arrived)
 #pragma unroll
             for (int u = 0; u < CB; ++u) {
                 const int j = j0 + u;
@@ -1537,8 +1561,9 @@ MPC_GLOBAL void MPC_LB(64, 8) k_x1(const DevProblem *__restrict__ Pg, const int3
             oi[2 * mr + NXC + 2] = __double2loint(growth);
             dc.stored[c] = 1;
         }
+        cur = nxt;
     }
-    if (lane == 0 && pivots) atomicAdd(&ctr->pivots, pivots);
+    if (ctr && lane == 0 && pivots) atomicAdd(&ctr->pivots, pivots);
 }
 
 // ------------------------------------------------------------------------------------------------------------------

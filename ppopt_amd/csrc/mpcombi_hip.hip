@@ -277,6 +277,12 @@ struct mpc_handle {
     hipStream_t stream3 = nullptr;   // region stage of a level, launched under its (x,theta) stage
     hipStream_t stream4 = nullptr;   // round 6: the drain launch of the queue form of the region stage (beside the early launch on stream3)
     hipEvent_t ev_rjoin2 = nullptr, ev_nth = nullptr;   // its completion; "the theta list's length has been published"
+    // Round 6: the streamed one-step dictionaries of a storing level (k_x1) run on stream4 BESIDE the end of their level (children, pruned
+    // masks, counters) and the next level's KKT kernel -- nothing of those reads a dictionary; the first kernel of the next level that
+    // does waits for ev_x1done (x1_join).  MPC_X1_DEFER=0: in line, as round 5.  Not when a profile asks for per-kernel event times.
+    hipEvent_t ev_x1go = nullptr, ev_x1done = nullptr;
+    bool x1_pending = false;
+    int x1_defer = 1;
     int r2_early = 0;                // MPC_R2_EARLY=1: the queue form of a large last level's region stage (measured slower, DESIGN 6h: off; tests switch it on)
     long long r2_early_min = 65536;  // MPC_R2_EARLY_MIN: smallest level that takes the queue form
     int r2_early_wpc = 0, r2_early_spin = 200000, r2_early_thw = 1, r2_early_prio = 3;   // ... MPC_R2_EARLY_THW: theta wavefronts per SIMD beside the early launch; MPC_R2_EARLY_PRIO: their issue priority   // MPC_R2_EARLY_WPC: wavefronts per CU of the early launch; MPC_R2_EARLY_SPIN: looks at an empty queue before a wavefront leaves
@@ -634,6 +640,9 @@ static int create_fill(const mpc_problem *p, int32_t device, void *stream, mpc_h
     HIP_TRY(nullptr, pooled_stream(&h->stream4));
     HIP_TRY(nullptr, pooled_event(&h->ev_rjoin2, false));
     HIP_TRY(nullptr, pooled_event(&h->ev_nth, false));
+    HIP_TRY(nullptr, pooled_event(&h->ev_x1go, false));
+    HIP_TRY(nullptr, pooled_event(&h->ev_x1done, false));
+    { const char *ev = std::getenv("MPC_X1_DEFER"); if (ev) h->x1_defer = std::atoi(ev); }
     { const char *ev = std::getenv("MPC_R2_EARLY"); if (ev) h->r2_early = std::atoi(ev); }
     { const char *ev = std::getenv("MPC_R2_EARLY_MIN"); if (ev) h->r2_early_min = std::atoll(ev); }
     { const char *ev = std::getenv("MPC_R2_EARLY_WPC"); if (ev) h->r2_early_wpc = std::max(0, std::atoi(ev)); }
@@ -1146,6 +1155,8 @@ int mpc_destroy(mpc_handle *h) {
     return_stream(h->stream4);
     return_event(h->ev_rjoin2, false);
     return_event(h->ev_nth, false);
+    return_event(h->ev_x1go, false);
+    return_event(h->ev_x1done, false);
     if (h->own_stream) return_stream(h->stream);
     delete h;
     return MPC_OK;
@@ -1162,6 +1173,7 @@ int mpc_trim(mpc_handle *h) {
     if (h->stream2) HIP_TRY(h, hipStreamSynchronize(h->stream2));
     if (h->stream3) HIP_TRY(h, hipStreamSynchronize(h->stream3));
     if (h->stream4) HIP_TRY(h, hipStreamSynchronize(h->stream4));
+    h->x1_pending = false;
     graveyard_flush(h);
     stream_release(h);
     for (DevBuf *b : {&h->frontier, &h->children, &h->status, &h->pruned, &h->flag, &h->pos, &h->opt_list, &h->childmask, &h->count, &h->offset, &h->recd, &h->reci,
@@ -1428,6 +1440,13 @@ static void stream_release(mpc_handle *h) {   // blocks of a streamed level nobo
 // one wavefront per SIMD at n_theta > 4) and still beat the wavefront-wide LDS solve inside k_theta2 several times over; K = 12
 // needs 364 registers at every n_theta.  The shared launches of several programs (batch_level.hip) keep 8.
 constexpr int KKT_THREAD_MAX = 10;
+// every stream of the handle that may read or write dictionary records waits for the deferred k_x1 of the previous level (stream waits: the host does not block)
+static int x1_join(mpc_handle *h) {
+    if (!h->x1_pending) return MPC_OK;
+    for (hipStream_t sx : {h->stream, h->stream2, h->stream3}) if (sx) HIP_TRY(h, hipStreamWaitEvent(sx, h->ev_x1done, 0));
+    h->x1_pending = false;
+    return MPC_OK;
+}
 static bool small_path_ok(const mpc_handle *h, long long n, int k, int32_t flags, int32_t gen_children) {
     if (h->no_smallpath || !h->fast || h->force_v1 || h->fast_r < 0 || n < 1 || n > h->smallpath_max) return false;
     if (flags & MPC_LEVEL_GRAPH) return false;
@@ -1457,6 +1476,7 @@ static void small_debug_note(const int32_t *cnt_host) {
 
 static int level_run_small(mpc_handle *h, int32_t gen_children, int32_t flags, mpc_level_stats *stats, bool *fallback) {
     *fallback = false;
+    { int rcj = x1_join(h); if (rcj) return rcj; }
     const long long n = h->n;
     const int k = h->k;
     const size_t nn = (size_t)n;
@@ -2008,6 +2028,7 @@ int mpc_level_batch_start(mpc_handle **hs, int32_t n_handles, const int32_t *gen
     for (int i = 0; i < n_handles; ++i) {
         mpc_handle *h = hs[i];
         stream_release(h);
+        { int rcj = x1_join(h); if (rcj) return rcj; }
         // MPC_SMALLPATH_MAX bounds the single-program path only (above it the overlapped classic path is faster for ONE program)
         const long long keep_max = h->smallpath_max;
         // (bounded: the shared launches compact / partition / scan a member with single 1024-thread blocks -- beyond 2^18 candidates a
@@ -2092,6 +2113,10 @@ static int level_run_impl(mpc_handle *h, int32_t gen_children, int32_t flags, mp
     if (!h) return MPC_ERR_INVALID;
     HIP_TRY(h, hipSetDevice(h->device));
     stream_release(h);
+    // (a deferred k_x1 of the previous level: joined at once unless this is a large level whose first kernel, k_kkt_thread, reads no dictionary)
+    const bool x1_late_join = h->x1_pending && h->fast && !h->force_v1 && h->kkt_mode == 0 && h->no_kkt_thread != 1 && !h->no_lean &&
+                              (h->skip_small || !small_path_ok(h, h->n, h->k, flags, gen_children)) && h->k - h->targs.ne >= 1 && h->k - h->targs.ne <= KKT_THREAD_MAX;
+    if (!x1_late_join) { int rcj = x1_join(h); if (rcj) return rcj; }
     if (!h->skip_small && small_path_ok(h, h->n, h->k, flags, gen_children)) {
         bool fallback = false;
         const int rcs = level_run_small(h, gen_children, flags, stats, &fallback);
@@ -2460,6 +2485,8 @@ static int level_run_impl(mpc_handle *h, int32_t gen_children, int32_t flags, mp
             // question does not depend on the theta stage at all.  Their list is cut here and k_xq_thread takes it on the second
             // stream -- a kernel bound by the cache's request rate beside one bound by dependent fp64 latency -- ; the two meet
             // before the partition that follows the theta stage, which then sees only what the pass left open.
+            // (the previous level's deferred k_x1 is joined by whoever reads dictionary records first: the thread pass on the second stream
+            //  below -- the theta kernel reads none and goes ahead --, else the (x,theta) stage behind the theta stage)
             bool early_xq = false;
             if (kkc && lean && h->no_xq_early <= 0 && h->xq_thread != 0 && !h->no_xquick && !(flags & MPC_LEVEL_GRAPH) && h->have_prev_dict && h->have_parent_slot &&
                 n >= h->xqt_min && !h->force_xqgroup && (h->no_xq_early < 0 || h->prev_regions < h->xq_early_regions || h->xq_early_regions <= 0)) {
@@ -2489,6 +2516,7 @@ static int level_run_impl(mpc_handle *h, int32_t gen_children, int32_t flags, mp
                     }
                     HIP_TRY(h, hipEventRecord(h->ev_xfork, st));
                     HIP_TRY(h, hipStreamWaitEvent(h->stream2, h->ev_xfork, 0));
+                    if (h->x1_pending) HIP_TRY(h, hipStreamWaitEvent(h->stream2, h->ev_x1done, 0));   // (the main stream joins later: x1_join before its own first reader)
                     const unsigned gt = (unsigned)std::min<long long>((n + 63) / 64, (long long)h->n_cu * h->xqt_wpc);
                     if (h->timing) HIP_TRY(h, hipEventRecord(h->kev[10], h->stream2));
                     hipLaunchKernelGGL(k_xq_thread, dim3(gt), dim3(64), 0, h->stream2, pf, fr, k, h->xq_list.as<int32_t>(), (int)n, stp, ctr, dq, nxc_e, alt, XqPlan{});
@@ -2624,11 +2652,20 @@ static int level_run_impl(mpc_handle *h, int32_t gen_children, int32_t flags, mp
                 if (h->timing) HIP_TRY(h, hipEventRecord(h->kev[11], st));
                 xq_thread_timed = true;
                 const unsigned g1 = (unsigned)std::min<long long>(n_bound, (long long)h->n_cu * h->x1_wpc);
+                // Round 6: the stream of one-step dictionaries goes to stream4 and is NOT waited for by this level: its records are read
+                // by the next level's (x,theta) kernels only (x1_join), the plan pass has already marked the planned candidates as
+                // "dictionary stored" for k_children_write.  The end of this level (k_x2 for the unplanned rest, children, counters), the
+                // hand-over and the next level's KKT kernel run beside it.
+                const bool defer = h->x1_defer > 0 && !h->timing && h->stream4;
+                hipStream_t sx1 = defer ? h->stream4 : st;
+                if (defer) { HIP_TRY(h, hipEventRecord(h->ev_x1go, st)); HIP_TRY(h, hipStreamWaitEvent(sx1, h->ev_x1go, 0)); }
                 if (h->timing) HIP_TRY(h, hipEventRecord(h->kev[12], st));
-                if (h->fast_x & 1) hipLaunchKernelGGL((k_x1<2>), dim3(g1), dim3(64), 0, st, pfx, pl.x1_list, pl.x1_n, ctr, dc, nxc, pl.plan_slot, pl.plan_step);
-                else hipLaunchKernelGGL((k_x1<1>), dim3(g1), dim3(64), 0, st, pfx, pl.x1_list, pl.x1_n, ctr, dc, nxc, pl.plan_slot, pl.plan_step);
+                LevelCounters *ctr_x1 = defer ? (LevelCounters *)nullptr : ctr;   // (its pivot count would land in the next level's counters)
+                if (h->fast_x & 1) hipLaunchKernelGGL((k_x1<2>), dim3(g1), dim3(64), 0, sx1, pfx, pl.x1_list, pl.x1_n, ctr_x1, dc, nxc, pl.plan_slot, pl.plan_step);
+                else hipLaunchKernelGGL((k_x1<1>), dim3(g1), dim3(64), 0, sx1, pfx, pl.x1_list, pl.x1_n, ctr_x1, dc, nxc, pl.plan_slot, pl.plan_step);
                 if (h->timing) HIP_TRY(h, hipEventRecord(h->kev[13], st));
                 HIP_TRY(h, hipGetLastError());
+                if (defer) { HIP_TRY(h, hipEventRecord(h->ev_x1done, sx1)); h->x1_pending = true; }
                 // what is left: the register simplex, list lengths on the device
                 DictCache dr = dc;
                 dr.pre1 = pl.rest[0]; dr.n_pre1 = 0; dr.n_pre1_dev = pl.rest_n[0];
@@ -2646,6 +2683,8 @@ static int level_run_impl(mpc_handle *h, int32_t gen_children, int32_t flags, mp
                 x1_ran = true;
                 return MPC_OK;
             };
+            // (behind the theta kernel: everything the main stream and the side streams launch from here on may read dictionary records)
+            { int rcj = x1_join(h); if (rcj) return rcj; }
             // One partition after the theta stage: [0] numerically doubtful (status 7), [1] feasible and [2] optimal (decided
             // in theta space; they only need a dictionary for their children), [3] feasibility still open.
             int32_t cntA[PART_CLASSES] = {0, 0, 0, 0};

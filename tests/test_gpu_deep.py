@@ -747,3 +747,25 @@ print(json.dumps(out))
         runs.append(json.loads(r.stdout.strip().splitlines()[-1]))
     assert len(runs[0]) == 10 and runs[0][-1][0] == 10
     assert runs[0] == runs[1]
+
+
+def test_deferred_one_step_dictionaries_change_nothing(monkeypatch):
+    """Round 6: on a storing level k_x1 runs on its own stream beside the end of the level and the next level's KKT kernel, and is joined by
+    the first kernel that reads a dictionary record (MPC_X1_DEFER, default on, only without per-kernel event timing).  Config 4 to its
+    fifth level and config 3 to its fourth: the regions with and without the deferral are the same objects, bit for bit."""
+    import bench
+    from ppopt_amd.mp_solvers import mpqp_hip_combinatorial
+    for wl in ('c4', 'c3'):
+        sols = []
+        for defer in ('1', '0'):
+            monkeypatch.setenv('MPC_X1_DEFER', defer)
+            prog = bench.build_program(wl)
+            sols.append(mpqp_hip_combinatorial.solve(prog, max_levels=bench.WORKLOADS[wl][2]))      # (no profile: the deferral is active)
+            prog.release_engine()
+        a, b = sols
+        assert len(a.critical_regions) == len(b.critical_regions) > 100
+        for r1, r2 in zip(a.critical_regions, b.critical_regions):
+            assert list(r1.active_set) == list(r2.active_set)
+            assert r1.omega_set == r2.omega_set and r1.lambda_set == r2.lambda_set and r1.regular_set == r2.regular_set
+            for fld in ('A', 'b', 'C', 'd', 'E', 'f'):
+                assert numpy.asarray(getattr(r1, fld)).tobytes() == numpy.asarray(getattr(r2, fld)).tobytes(), (wl, fld)
