@@ -371,7 +371,7 @@ def main():
     # fp64 share is priced at 4 cycles and the rest at 2 (v_fma_f32 wave64: 2 cycles, MI355X_MICROARCH.md).
     traffic = dom_traffic = None
     n_simd, clk_hz = 1024, 2.4e9
-    tpath = next((q for q in (os.path.join(ROOT, 'profiles', t + '_pmc.json') for t in ('r05', 'r04', 'r03')) if os.path.exists(q)), '')
+    tpath = next((q for q in (os.path.join(ROOT, 'profiles', t + '_pmc.json') for t in ('r06', 'r05', 'r04', 'r03')) if os.path.exists(q)), '')
     if tpath and os.path.exists(tpath):
         try:
             rec = json.load(open(tpath))

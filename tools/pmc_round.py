@@ -18,7 +18,7 @@ import sqlite3
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-OUT = os.path.join(ROOT, 'profiles', os.environ.get('PMC_TAG', 'r05') + '_pmc.json')
+OUT = os.path.join(ROOT, 'profiles', os.environ.get('PMC_TAG', 'r06') + '_pmc.json')
 LEVELS = {'c4': 5, 'c3': 4, 'c2': 5}
 HEAVY = ('k_theta2', 'k_x2', 'k_x1', 'k_region2', 'k_xq_grouped', 'k_xq_thread', 'k_xq', 'k_kkt_thread', 'k_level_small')
 

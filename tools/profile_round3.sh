@@ -5,7 +5,7 @@
 # Under rocprofv3 the program goes directly after `--` (python3 bench.py ... / the binary): no wrapper, no env, no shell.
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-wl=${1:-c4}; steps=${2:-20}; warm=${3:-5}; tag=${4:-r05}; export PMC_TAG=$tag
+wl=${1:-c4}; steps=${2:-20}; warm=${3:-5}; tag=${4:-r06}; export PMC_TAG=$tag
 O=$R/gpurun_out/prof3; mkdir -p $O
 rocprofv3 -L > $O/counters_list.txt 2>&1
 if [ ! -f $O/calib_done ]; then
