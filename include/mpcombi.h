@@ -242,6 +242,14 @@ int mpc_set_region_overlap(mpc_handle *h, int32_t on);
  * config-4 solve, 0.11 of a 1.1 ms config-2 solve).  The ms_* fields of mpc_level_stats are then 0, every count is as before.  The host
  * layer switches the records on for the solves that ask for a profile.  Default: on (MPC_NO_KEV=1 in the environment: off). */
 int mpc_set_timing(mpc_handle *h, int32_t on);
+/* mpc_engine_kind: which kernels this handle's levels run on (diagnostics: the shape sweep records it per cell).  out[0] = 1 the
+ * register-resident kernels (k_kkt_thread / k_theta2 / k_x2 / k_region2 ...), 0 the LDS-engine kernels (k_verdict / k_region);
+ * out[1] = rows per lane of the theta LP (1 / 2; 0: none), out[2] = of the (x,theta) dictionary, out[3] = of the region LP (0: the
+ * LDS-engine region kernel); out[4] = compile-time n_theta of the instantiation (4 / 8 / 10); out[5] = 1: the parameter set is open in
+ * some direction (k_recession behind the verdict stages); out[6] = KKT mode (0 Schur / Cholesky, 1 dense); out[7] = largest number of
+ * inequality rows k_kkt_thread solves for.  (No counterpart in the reference: it has one code path for every program,
+ * mplp_program.py:411-444.) */
+int mpc_engine_kind(mpc_handle *h, int32_t out[8]);
 int mpc_level_start(mpc_handle *h, int32_t gen_children, int32_t flags);
 int mpc_level_stream_info(mpc_handle *h, double **head_d, int32_t **head_i, double **erows, int64_t *n_slots, int64_t *cap_rows,
                           int32_t *chunk, int32_t *n_chunks);

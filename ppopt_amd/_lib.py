@@ -124,6 +124,7 @@ def load():
         'mpc_mask_words': (ctypes.c_int32, [H]),
         'mpc_set_region_overlap': (ctypes.c_int, [H, ctypes.c_int32]),
         'mpc_set_timing': (ctypes.c_int, [H, ctypes.c_int32]),
+        'mpc_engine_kind': (ctypes.c_int, [H, ctypes.POINTER(ctypes.c_int32)]),
         'mpc_program_block': (ctypes.c_int, [H, ctypes.c_int32, _dp, ctypes.c_int64, _lp]),
         'mpc_region_doubles': (ctypes.c_int64, [H]),
         'mpc_region_ints': (ctypes.c_int64, [H]),
@@ -212,7 +213,7 @@ def load():
 
 
 EXPORTED_SYMBOLS = ['mpc_device_count', 'mpc_version', 'mpc_last_global_error', 'mpc_create', 'mpc_destroy',
-                    'mpc_last_error', 'mpc_mask_words', 'mpc_set_region_overlap', 'mpc_set_timing', 'mpc_program_block', 'mpc_region_doubles', 'mpc_region_ints', 'mpc_lds_bytes', 'mpc_stream',
+                    'mpc_last_error', 'mpc_mask_words', 'mpc_set_region_overlap', 'mpc_set_timing', 'mpc_engine_kind', 'mpc_program_block', 'mpc_region_doubles', 'mpc_region_ints', 'mpc_lds_bytes', 'mpc_stream',
                     'mpc_frontier_root', 'mpc_frontier_set', 'mpc_frontier_set_device', 'mpc_frontier_info',
                     'mpc_frontier_get', 'mpc_pruned_clear', 'mpc_pruned_add', 'mpc_pruned_add_device',
                     'mpc_pruned_count', 'mpc_pruned_get', 'mpc_level_run', 'mpc_level_run_ex', 'mpc_level_run_batch', 'mpc_frontier_advance_batch', 'mpc_level_memory_gb', 'mpc_trim', 'mpc_level_batch_start', 'mpc_level_batch_wait', 'mpc_level_regions_slots_nowait', 'mpc_level_batch_fetch', 'mpc_level_status', 'mpc_level_start', 'mpc_level_stream_info', 'mpc_level_chunk_wait', 'mpc_level_wait', 'mpc_level_stream_fixup', 'mpc_base_result', 'mpc_solve_start', 'mpc_solve_level', 'mpc_solve_chunk_wait', 'mpc_solve_level_wait', 'mpc_solve_wait', 'mpc_level_regions', 'mpc_compact_strides',
@@ -336,6 +337,13 @@ class Engine:
         if getattr(self, '_timing', None) is not on:
             self._check(self._L.mpc_set_timing(self._h, 1 if on else 0), 'mpc_set_timing')
             self._timing = on
+
+    def engine_kind(self) -> dict:
+        """Which kernels this handle's levels run on (mpc_engine_kind)."""
+        out = (ctypes.c_int32 * 8)()
+        self._check(self._L.mpc_engine_kind(self._h, out), 'mpc_engine_kind')
+        return {'register_engine': bool(out[0]), 'rows_per_lane_theta': int(out[1]), 'rows_per_lane_x': int(out[2]), 'rows_per_lane_region': int(out[3]),
+                'n_theta_instantiation': int(out[4]), 'theta_open': bool(out[5]), 'kkt_mode': int(out[6]), 'kkt_thread_max_rows': int(out[7])}
 
     def close(self):
         if getattr(self, '_twin', None) is not None:

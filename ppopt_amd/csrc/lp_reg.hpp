@@ -213,6 +213,12 @@ struct RegLp {
     int m;            // rows in use (row index = lane + 64*slot)
     int iters, max_iter;
     double growth;
+    // the wave reductions of this instantiation: row rotations with bare min / max (round 6), except for the two-row 32-column tableau
+    // (k_x2<32,2>: 256 registers and 260 bytes of scratch already -- the rotation forms cost it 36 bytes more and 6-8 % of its time)
+    static constexpr bool ROT = !(SLOTS >= 2 && NC > 16);
+    static __device__ __forceinline__ double wred_min(double v) { return ROT ? rot_wave_min(v) : dpp_wave_min(v); }
+    static __device__ __forceinline__ double wred_max(double v) { return ROT ? rot_wave_max(v) : dpp_wave_max(v); }
+    static __device__ __forceinline__ float wred_max_f32(float v) { return ROT ? rot_wave_max_f32(v) : dpp_wave_max_f32(v); }
 
     __device__ __forceinline__ double row_entry(int r, const double (&c)[SLOTS]) const {
         const int rl = r & 63;
@@ -390,8 +396,8 @@ struct RegLp {
                 ratio[s] = elig[s] ? b0 * ia : 0.0;
                 tmax = fmin(tmax, elig[s] ? (b0 + HARRIS_DELTA) * ia : INFINITY);
             }
-            const float colmax = rot_wave_max_f32(cmf);
-            tmax = rot_wave_min(tmax);
+            const float colmax = wred_max_f32(cmf);
+            tmax = wred_min(tmax);
             if (tmax == INFINITY) return 2;
             int r = -1;
             bool leaving_x0 = false;
@@ -400,7 +406,7 @@ struct RegLp {
                 double rm = INFINITY;
 #pragma unroll
                 for (int s = 0; s < SLOTS; ++s) if (elig[s]) rm = fmin(rm, ratio[s]);
-                rm = rot_wave_min(rm);
+                rm = wred_min(rm);
                 unsigned long long key = 0; int idx = -1;
 #pragma unroll
                 for (int s = 0; s < SLOTS; ++s)
@@ -427,7 +433,7 @@ struct RegLp {
                     double am = 0.0;
 #pragma unroll
                     for (int s = 0; s < SLOTS; ++s) if (pass[s]) am = fmax(am, a[s]);
-                    rpiv = rot_wave_max(am);
+                    rpiv = wred_max(am);
 #pragma unroll
                     for (int s = SLOTS - 1; s >= 0; --s) {
                         const unsigned long long br = __ballot(pass[s] && a[s] == rpiv);
@@ -477,7 +483,7 @@ struct RegLp {
             neg[s] = lane + 64 * s < m && kind[s] == RK_INEQ && v0 < -TOL_FEAS;
             if (neg[s]) vmin = fmin(vmin, v0);
         }
-        vmin = rot_wave_min(vmin);
+        vmin = wred_min(vmin);
         if (vmin == INFINITY) return LP_OPTIMAL;
         int r = -1;
 #pragma unroll

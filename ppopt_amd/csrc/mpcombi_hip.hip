@@ -3844,6 +3844,19 @@ int mpc_debug_xq_hist(unsigned long long *out) {
     return hipMemcpyToSymbol(HIP_SYMBOL(g_xq_hist), z, sizeof(z)) == hipSuccess ? MPC_OK : MPC_ERR_HIP;
 }
 #endif
+int mpc_engine_kind(mpc_handle *h, int32_t out[8]) {
+    if (!h || !out) return MPC_ERR_INVALID;
+    const bool fast = h->fast && !h->force_v1;
+    out[0] = fast ? 1 : 0;
+    out[1] = fast ? (h->fast_t & 1) + 1 : 0;
+    out[2] = fast ? (h->fast_x & 1) + 1 : 0;
+    out[3] = (fast && h->fast_r >= 0) ? (h->fast_r & 1) + 1 : 0;
+    out[4] = fast ? (h->fast_t <= 1 ? 4 : (h->fast_t <= 3 ? 8 : 10)) : 0;
+    out[5] = h->theta_open ? 1 : 0;
+    out[6] = h->kkt_mode;
+    out[7] = (fast && h->kkt_mode == 0 && h->no_kkt_thread != 1) ? KKT_THREAD_MAX : 0;
+    return MPC_OK;
+}
 int mpc_sync(mpc_handle *h) {
     if (!h) return MPC_ERR_INVALID;
     HIP_TRY(h, hipSetDevice(h->device));

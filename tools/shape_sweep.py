@@ -75,11 +75,14 @@ def cell(name, d, device=0, reps=3):
     cands = sum(p['candidates'] for p in prof)
     row.update({'candidates': cands, 'regions': nreg, 'ms': 1e3 * best, 'candidates_per_s': cands / best, 'ns_per_candidate': 1e9 * best / max(cands, 1),
                 'largest_level': max(p['candidates'] for p in lv), 'deepest_k': max(p['k'] for p in lv),
-                'kkt_in_theta_kernel': bool(max(p['k'] for p in lv) - ne > 8),
                 'two_rows_per_lane': {'theta_region': row['rows_theta'] > 64, 'x': row['rows_x'] > 64},
                 'kernel_ms': {key: round(sum(p.get(key, 0.0) for p in lv), 3) for key in ('ms_kkt', 'ms_theta', 'ms_x', 'ms_xq', 'ms_xq_thread', 'ms_region2')},
                 'stage_ms': {key: round(sum(p.get(key, 0.0) for p in lv), 3) for key in ('ms_verdict', 'ms_region', 'ms_children')},
-                'register_engine': bool(sum(p.get('ms_theta', 0.0) for p in lv) > 0.0)})
+                # (round 6) the engine from the handle itself (mpc_engine_kind), and the heavy kernels by their HIP-event time over all levels
+                **prog.engine(device, closed=True).engine_kind(),
+                'kernels_by_time': sorted(((key[3:], round(sum(p.get(key, 0.0) for p in lv), 3)) for key in
+                                           ('ms_kkt', 'ms_theta', 'ms_x', 'ms_xq', 'ms_xq_thread', 'ms_x1', 'ms_region2', 'ms_children')), key=lambda kv: -kv[1])})
+    row['kkt_in_theta_kernel'] = bool(row['deepest_k'] - ne > row['kkt_thread_max_rows'])      # levels whose KKT systems are solved wavefront-wide inside k_theta2
     prog.release_engine()
     return row
 
