@@ -1,17 +1,19 @@
-"""Per-level stage times of one generate_mpqp_data(n_x, n_theta, m, seed) program (second solve): python tools/dbg_levels.py nx nt m [seed=7]"""
+"""Per-level stage times of one generate_mpqp_data(n_x, n_theta, m, seed) program (second solve): python tools/dbg_levels.py nx nt m [seed=7] [max_levels]
+(give max_levels for programs whose full depth is out of reach: the sweep's cells stop at 10^7 candidates)"""
 import sys, warnings
 sys.path.insert(0, '.')
 from ppopt_amd import MPQP_Program, problem_generator as pg
 from ppopt_amd.mp_solvers import mpqp_hip_combinatorial as m
 nx, nt, mm = (int(v) for v in sys.argv[1:4])
 seed = int(sys.argv[4]) if len(sys.argv) > 4 else 7
+ml = int(sys.argv[5]) if len(sys.argv) > 5 else None
 d = pg.generate_mpqp_data(nx, nt, mm, seed)
 with warnings.catch_warnings():
     warnings.simplefilter('ignore')
     prog = MPQP_Program(d['A'], d['b'], d['c'], d['H'], d['Q'], d['A_t'], d['b_t'], d['F'])
-m.solve(prog)
+m.solve(prog, max_levels=ml)
 prof = []
-sol = m.solve(prog, profile=prof)
+sol = m.solve(prog, profile=prof, max_levels=ml)
 print('regions', len(sol))
 for p in prof:
     if p['depth'] > 0:
