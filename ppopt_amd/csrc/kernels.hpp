@@ -1015,6 +1015,124 @@ MPC_GLOBAL void MPC_LB(64) k_children_count(DevProblem P, const int32_t *__restr
     }
 }
 
+// ---- round 6: the pruned list bucketed by each set's SMALLEST non-equality member ---------------------------------------------------
+// A pruned set p matters to a parent P only if p \ P is a single index i beyond P's last member -- then every other member of p, its
+// smallest in particular, is a member of P (sets of one non-equality member aside: they are ORed into `singles` once).  A parent therefore
+// scans the buckets of ITS OWN members only -- k of n_c buckets -- instead of the whole list: the children stage of a deep tree is
+// O(parents x pruned sets) (generate_mpqp_data(10,2,30): 640 k parents x 30 k sets, half of the solve).
+// bucket_head: [0..256) counts, then offsets [256..513), then cursors [513..769), then `singles` as MW 64-bit words at [776..)
+constexpr int PB_OFF = 256, PB_CUR = 513, PB_SINGLES = 776, PB_WORDS = PB_SINGLES + 2 * 4;
+template <int MW>
+__device__ __forceinline__ int pruned_min_member(const unsigned long long *p, int ne, int *n_members) {
+    int first = -1, cnt = 0;
+#pragma unroll
+    for (int w = 0; w < MW; ++w) {
+        unsigned long long v = p[w];
+        const int lo = ne - 64 * w;                      // equality rows are members of every set: left out
+        if (lo >= 64) v = 0ull; else if (lo > 0) v &= ~((1ull << lo) - 1ull);
+        cnt += __popcll(v);
+        if (first < 0 && v) first = 64 * w + __ffsll((long long)v) - 1;
+    }
+    *n_members = cnt;
+    return first;
+}
+template <int MW>
+MPC_GLOBAL void MPC_LB(256) k_pruned_bucket_count(const unsigned long long *__restrict__ pruned, long long n_pruned, int ne, int32_t *__restrict__ head) {
+    const long long j = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (j >= n_pruned) return;
+    int cnt = 0;
+    const int b = pruned_min_member<MW>(pruned + (size_t)MW * j, ne, &cnt);
+    if (cnt <= 1) {
+        // one non-equality member: ORed into `singles`; none (the base set itself is pruned): every index is "pruned"
+        unsigned long long *singles = reinterpret_cast<unsigned long long *>(head + PB_SINGLES);
+#pragma unroll
+        for (int w = 0; w < MW; ++w) { const unsigned long long v = cnt == 0 ? ~0ull : pruned[(size_t)MW * j + w]; if (v) atomicOr(&singles[w], v); }
+    } else if (b >= 0) atomicAdd(&head[b], 1);
+}
+MPC_GLOBAL void MPC_LB(256) k_pruned_bucket_scan(int32_t *__restrict__ head) {
+    __shared__ int sh[256];
+    const int t = threadIdx.x;
+    sh[t] = head[t];
+    __syncthreads();
+    for (int off = 1; off < 256; off <<= 1) { const int v = t >= off ? sh[t - off] : 0; __syncthreads(); sh[t] += v; __syncthreads(); }
+    head[PB_OFF + t + 1] = sh[t];
+    if (t == 0) head[PB_OFF] = 0;
+    head[PB_CUR + t] = 0;
+}
+template <int MW>
+MPC_GLOBAL void MPC_LB(256) k_pruned_bucket_scatter(const unsigned long long *__restrict__ pruned, long long n_pruned, int ne, int32_t *__restrict__ head,
+                                                            unsigned long long *__restrict__ out) {
+    const long long j = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (j >= n_pruned) return;
+    int cnt = 0;
+    const int b = pruned_min_member<MW>(pruned + (size_t)MW * j, ne, &cnt);
+    if (cnt <= 1 || b < 0) return;
+    const int pos = head[PB_OFF + b] + atomicAdd(&head[PB_CUR + b], 1);
+#pragma unroll
+    for (int w = 0; w < MW; ++w) out[(size_t)MW * pos + w] = pruned[(size_t)MW * j + w];
+}
+// k_children_count over the bucketed list: the same test on every pruned set whose smallest non-equality member is a member of the parent
+template <int MW>
+MPC_GLOBAL void MPC_LB(64) k_children_count_b(DevProblem P, const int32_t *__restrict__ cands, long long n, int k,
+                                                         const uint8_t *__restrict__ status,
+                                                         const unsigned long long *__restrict__ bucketed, const int32_t *__restrict__ head,
+                                                         unsigned long long *__restrict__ childmask, int32_t *__restrict__ count, int keep_lowdim) {
+    const long long c = blockIdx.x;
+    const int lane = lane_id();
+    if (c >= n) return;
+    const int st = status[c];
+    unsigned long long m[MW];
+#pragma unroll
+    for (int w = 0; w < MW; ++w) m[w] = 0;
+    if (expands(st, keep_lowdim)) {
+        const int32_t *as = cands + (size_t)c * k;
+        unsigned long long p[MW], a[MW], kill[MW];
+        set_mask<MW>(as, k, p);
+        const int start = k > 0 ? as[k - 1] + 1 : 0;
+        int stop = P.n_c;
+        if (!P.is_qp && st == ST_FEASIBLE) stop = min(stop, (k + 1) + P.n_c - P.n_x);
+        const unsigned long long *singles = reinterpret_cast<const unsigned long long *>(head + PB_SINGLES);
+#pragma unroll
+        for (int w = 0; w < MW; ++w) {   // allowed children: bits start .. stop-1
+            const int lo = max(start - 64 * w, 0), hi = min(stop - 64 * w, 64);
+            a[w] = hi > lo ? ((hi >= 64 ? ~0ull : ((1ull << hi) - 1ull)) & ~((1ull << lo) - 1ull)) : 0ull;
+            kill[w] = singles[w] & ~p[w];          // a pruned set of ONE non-equality member i: exactly child i contains it
+            // (... and if the parent itself holds such a member every child does -- cannot be for a consistent list, as in k_children_count)
+            const int lo_e = P.n_eq - 64 * w;
+            const unsigned long long emask = lo_e >= 64 ? ~0ull : (lo_e > 0 ? ((1ull << lo_e) - 1ull) : 0ull);
+            if (singles[w] & p[w] & ~emask) kill[w] = ~0ull;
+        }
+        for (int mi = P.n_eq; mi < k; ++mi) {
+            const int b = as[mi];
+            const int j0 = head[PB_OFF + b], j1 = head[PB_OFF + b + 1];
+            for (int j = j0 + lane; j < j1; j += 64) {
+                unsigned long long d[MW];
+                int bits = 0;
+#pragma unroll
+                for (int w = 0; w < MW; ++w) { d[w] = bucketed[(size_t)MW * j + w] & ~p[w]; bits += __popcll(d[w]); }
+                if (bits == 0) {
+#pragma unroll
+                    for (int w = 0; w < MW; ++w) kill[w] = ~0ull;
+                } else if (bits == 1) {
+#pragma unroll
+                    for (int w = 0; w < MW; ++w) kill[w] |= d[w];
+                }
+            }
+        }
+#pragma unroll
+        for (int w = 0; w < MW; ++w) {
+            for (int off = 32; off > 0; off >>= 1) kill[w] |= __shfl_xor(kill[w], off);
+            m[w] = a[w] & ~kill[w];
+        }
+    }
+    if (lane == 0) {
+        int cnt = 0;
+#pragma unroll
+        for (int w = 0; w < MW; ++w) { childmask[MW * c + w] = m[w]; cnt += __popcll(m[w]); }
+        count[c] = cnt;
+    }
+}
+
 // stored / parent_slot (both optional): child -> index of its parent when the parent left its (x,theta) dictionary in the
 // dictionary cache (k_x2), else -1
 MPC_GLOBAL void MPC_LB(64) k_children_write(const int32_t *__restrict__ cands, long long n, int k, int mw,

@@ -283,6 +283,10 @@ struct mpc_handle {
     hipEvent_t ev_x1go = nullptr, ev_x1done = nullptr;
     bool x1_pending = false;
     int x1_defer = 1;
+    // Round 6: the pruned list bucketed by smallest non-equality member (kernels.hpp, k_children_count_b), rebuilt at the start of every level
+    // whose children stage is large enough to pay for it (MPC_PRUNED_BUCKET_MIN: parents x pruned sets; 0 = never)
+    DevBuf pruned_b, pruned_head;
+    double pruned_bucket_min = 2.0e7;
     int r2_early = 0;                // MPC_R2_EARLY=1: the queue form of a large last level's region stage (measured slower, DESIGN 6h: off; tests switch it on)
     long long r2_early_min = 65536;  // MPC_R2_EARLY_MIN: smallest level that takes the queue form
     int r2_early_wpc = 0, r2_early_spin = 200000, r2_early_thw = 1, r2_early_prio = 3;   // ... MPC_R2_EARLY_THW: theta wavefronts per SIMD beside the early launch; MPC_R2_EARLY_PRIO: their issue priority   // MPC_R2_EARLY_WPC: wavefronts per CU of the early launch; MPC_R2_EARLY_SPIN: looks at an empty queue before a wavefront leaves
@@ -643,6 +647,7 @@ static int create_fill(const mpc_problem *p, int32_t device, void *stream, mpc_h
     HIP_TRY(nullptr, pooled_event(&h->ev_x1go, false));
     HIP_TRY(nullptr, pooled_event(&h->ev_x1done, false));
     { const char *ev = std::getenv("MPC_X1_DEFER"); if (ev) h->x1_defer = std::atoi(ev); }
+    { const char *ev = std::getenv("MPC_PRUNED_BUCKET_MIN"); if (ev) h->pruned_bucket_min = std::atof(ev); }
     { const char *ev = std::getenv("MPC_R2_EARLY"); if (ev) h->r2_early = std::atoi(ev); }
     { const char *ev = std::getenv("MPC_R2_EARLY_MIN"); if (ev) h->r2_early_min = std::atoll(ev); }
     { const char *ev = std::getenv("MPC_R2_EARLY_WPC"); if (ev) h->r2_early_wpc = std::max(0, std::atoi(ev)); }
@@ -1131,7 +1136,7 @@ int mpc_destroy(mpc_handle *h) {
     if (h->stream4) (void)hipStreamSynchronize(h->stream4);
     graveyard_flush(h);
     for (DevBuf *b : {&h->blocks, &h->iblocks, &h->frontier, &h->children, &h->status, &h->pruned, &h->flag, &h->pos, &h->opt_list,
-                      &h->childmask, &h->count, &h->offset, &h->recd, &h->reci, &h->ctr, &h->scratch, &h->sums, &h->retry_list, &h->pf_dev, &h->pr2_dev, &h->headd, &h->headi, &h->epool, &h->facet_flags, &h->kkt_code, &h->kkt_L, &h->theta_blocks, &h->xq_groups, &h->xq_list, &h->x1_buf, &h->xretry_list, &h->theta_list, &h->vretry_list, &h->status_tmp, &h->part_counts, &h->part_lists, &h->kept_g, &h->done_g, &h->dict_d[0], &h->dict_d[1], &h->dict_i[0], &h->dict_i[1],
+                      &h->childmask, &h->count, &h->offset, &h->recd, &h->reci, &h->ctr, &h->pruned_b, &h->pruned_head, &h->scratch, &h->sums, &h->retry_list, &h->pf_dev, &h->pr2_dev, &h->headd, &h->headi, &h->epool, &h->facet_flags, &h->kkt_code, &h->kkt_L, &h->theta_blocks, &h->xq_groups, &h->xq_list, &h->x1_buf, &h->xretry_list, &h->theta_list, &h->vretry_list, &h->status_tmp, &h->part_counts, &h->part_lists, &h->kept_g, &h->done_g, &h->dict_d[0], &h->dict_d[1], &h->dict_i[0], &h->dict_i[1],
                       &h->dict_stored[0], &h->dict_stored[1], &h->parent_slot, &h->parent_slot_next, &h->dcnt}) b->release();
     if (h->tot_host) { (void)host_pool_give(h->tot_host); h->tot_host = h->tot_dev = nullptr; }
     for (HostBuf *b : {&h->st_list, &h->st_status, &h->st_hd, &h->st_hi, &h->st_pool, &h->st_fxd, &h->st_fxi, &h->st_rlist, &h->st_flags}) b->release();
@@ -2179,6 +2184,24 @@ static int level_run_impl(mpc_handle *h, int32_t gen_children, int32_t flags, mp
             hipLaunchKernelGGL(k_zero_bufs, dim3(1), dim3(256), 0, st, z);
             HIP_TRY(h, hipGetLastError());
         }
+        // (round 6) the pruned list of the earlier levels, bucketed by smallest non-equality member, for this level's children stage: three
+        // small launches at the level's start (nothing waits for them before k_children_count_b)
+        bool pruned_bucketed = false;
+        if (gen_children && !(flags & MPC_LEVEL_GRAPH) && h->pruned_bucket_min > 0 && h->n_c <= 256 && h->n_pruned >= 1024 &&
+            (double)n * (double)h->n_pruned >= h->pruned_bucket_min && h->n_pruned <= 0x7fffffffLL) {
+            HIP_TRY(h, h->pruned_b.ensure((size_t)h->n_pruned * h->mw * sizeof(uint64_t), st));
+            HIP_TRY(h, h->pruned_head.ensure((size_t)PB_WORDS * sizeof(int32_t), st));
+            HIP_TRY(h, hipMemsetAsync(h->pruned_head.p, 0, (size_t)PB_WORDS * sizeof(int32_t), st));
+            const dim3 gb((unsigned)((h->n_pruned + 255) / 256)), bb(256);
+            const int ne_b = h->n_eq;
+            if (h->mw == 2) hipLaunchKernelGGL(k_pruned_bucket_count<2>, gb, bb, 0, st, h->pruned.as<unsigned long long>(), (long long)h->n_pruned, ne_b, h->pruned_head.as<int32_t>());
+            else hipLaunchKernelGGL(k_pruned_bucket_count<4>, gb, bb, 0, st, h->pruned.as<unsigned long long>(), (long long)h->n_pruned, ne_b, h->pruned_head.as<int32_t>());
+            hipLaunchKernelGGL(k_pruned_bucket_scan, dim3(1), dim3(256), 0, st, h->pruned_head.as<int32_t>());
+            if (h->mw == 2) hipLaunchKernelGGL(k_pruned_bucket_scatter<2>, gb, bb, 0, st, h->pruned.as<unsigned long long>(), (long long)h->n_pruned, ne_b, h->pruned_head.as<int32_t>(), h->pruned_b.as<unsigned long long>());
+            else hipLaunchKernelGGL(k_pruned_bucket_scatter<4>, gb, bb, 0, st, h->pruned.as<unsigned long long>(), (long long)h->n_pruned, ne_b, h->pruned_head.as<int32_t>(), h->pruned_b.as<unsigned long long>());
+            HIP_TRY(h, hipGetLastError());
+            pruned_bucketed = true;
+        }
         // (round 6) a large last level: the theta kernel will list its optimal candidates itself (the queue form below); entries -1 = not written
         const bool r2_queue_ready = lean && h->r2_early > 0 && !gen_children && n >= h->r2_early_min && n <= 0x7fffffffLL && h->fast && h->fast_r >= 0 && !h->force_v1 && !(flags & MPC_LEVEL_GRAPH);
         if (r2_queue_ready) {
@@ -2395,6 +2418,12 @@ static int level_run_impl(mpc_handle *h, int32_t gen_children, int32_t flags, mp
                 HIP_TRY(h, h->childmask.ensure(nn * h->mw * sizeof(uint64_t), st));
                 HIP_TRY(h, h->count.ensure(nn * sizeof(int32_t), st));
                 HIP_TRY(h, h->offset.ensure(nn * sizeof(int32_t), st));
+                if (pruned_bucketed) {
+                    if (h->mw == 2) hipLaunchKernelGGL(k_children_count_b<2>, dim3((unsigned)n), dim3(64), 0, st, h->Pv, h->frontier.as<int32_t>(), n, k, h->status.as<uint8_t>(),
+                                                       h->pruned_b.as<unsigned long long>(), h->pruned_head.as<int32_t>(), h->childmask.as<unsigned long long>(), h->count.as<int32_t>(), keep_lowdim);
+                    else hipLaunchKernelGGL(k_children_count_b<4>, dim3((unsigned)n), dim3(64), 0, st, h->Pv, h->frontier.as<int32_t>(), n, k, h->status.as<uint8_t>(),
+                                            h->pruned_b.as<unsigned long long>(), h->pruned_head.as<int32_t>(), h->childmask.as<unsigned long long>(), h->count.as<int32_t>(), keep_lowdim);
+                } else
                 if (h->mw == 2) hipLaunchKernelGGL(k_children_count<2>, dim3((unsigned)n), dim3(64), 0, st, h->Pv, h->frontier.as<int32_t>(), n, k, h->status.as<uint8_t>(),
                                                    h->pruned.as<unsigned long long>(), (long long)h->n_pruned, h->childmask.as<unsigned long long>(), h->count.as<int32_t>(), keep_lowdim);
                 else hipLaunchKernelGGL(k_children_count<4>, dim3((unsigned)n), dim3(64), 0, st, h->Pv, h->frontier.as<int32_t>(), n, k, h->status.as<uint8_t>(),

@@ -769,3 +769,31 @@ def test_deferred_one_step_dictionaries_change_nothing(monkeypatch):
             assert r1.omega_set == r2.omega_set and r1.lambda_set == r2.lambda_set and r1.regular_set == r2.regular_set
             for fld in ('A', 'b', 'C', 'd', 'E', 'f'):
                 assert numpy.asarray(getattr(r1, fld)).tobytes() == numpy.asarray(getattr(r2, fld)).tobytes(), (wl, fld)
+
+
+def test_children_from_the_bucketed_pruned_list_equal_the_full_scan(monkeypatch):
+    """Round 6: on a level whose children stage is large (parents x pruned sets >= MPC_PRUNED_BUCKET_MIN) a parent scans only the pruned sets
+    whose smallest non-equality member is one of its own members (k_children_count_b over a list bucketed at the level's start) instead of
+    the whole list.  Config 4 to level 4 (three levels of children) and a program with an equality row: the children of every level -- hence
+    the frontiers -- are identical with the bucketed scan forced onto every level and with the full scan."""
+    from test_gpu_parity import engine_from_golden
+    for name, n_levels in (('c4_rand_20_8_20_s0', 4), ('c2_dblint_n5', 5), ('quadtank_n3', 5)):
+        g = load_golden(name)
+        runs = []
+        for env in ('1', '0'):
+            monkeypatch.setenv('MPC_PRUNED_BUCKET_MIN', env)      # 1: every level with >= 1,024 pruned sets; 0: never
+            monkeypatch.setenv('MPC_NO_SMALLPATH', '1')            # (the bucketed scan lives on the classic path)
+            eng = engine_from_golden(g)
+            eng.pruned_clear(); eng.frontier_root()
+            fr = []
+            for depth in range(n_levels):
+                st = eng.level_run(True)
+                fr.append((eng.level_children().copy(), eng.level_status().copy()))
+                if st.n_children == 0:
+                    break
+                eng.frontier_advance()
+            eng.close()
+            runs.append(fr)
+        assert len(runs[0]) == len(runs[1]) >= 3
+        for (c1, s1), (c2, s2) in zip(*runs):
+            assert numpy.array_equal(s1, s2) and numpy.array_equal(c1, c2), name
