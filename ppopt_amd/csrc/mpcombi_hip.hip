@@ -287,6 +287,7 @@ struct mpc_handle {
     // whose children stage is large enough to pay for it (MPC_PRUNED_BUCKET_MIN: parents x pruned sets; 0 = never)
     DevBuf pruned_b, pruned_head;
     double pruned_bucket_min = 2.0e7;
+    long long pruned_bucket_np = 1024;   // MPC_PRUNED_BUCKET_NP: ... and at least this many pruned sets (tests: 1)
     int r2_early = 0;                // MPC_R2_EARLY=1: the queue form of a large last level's region stage (measured slower, DESIGN 6h: off; tests switch it on)
     long long r2_early_min = 65536;  // MPC_R2_EARLY_MIN: smallest level that takes the queue form
     int r2_early_wpc = 0, r2_early_spin = 200000, r2_early_thw = 1, r2_early_prio = 3;   // ... MPC_R2_EARLY_THW: theta wavefronts per SIMD beside the early launch; MPC_R2_EARLY_PRIO: their issue priority   // MPC_R2_EARLY_WPC: wavefronts per CU of the early launch; MPC_R2_EARLY_SPIN: looks at an empty queue before a wavefront leaves
@@ -648,6 +649,7 @@ static int create_fill(const mpc_problem *p, int32_t device, void *stream, mpc_h
     HIP_TRY(nullptr, pooled_event(&h->ev_x1done, false));
     { const char *ev = std::getenv("MPC_X1_DEFER"); if (ev) h->x1_defer = std::atoi(ev); }
     { const char *ev = std::getenv("MPC_PRUNED_BUCKET_MIN"); if (ev) h->pruned_bucket_min = std::atof(ev); }
+    { const char *ev = std::getenv("MPC_PRUNED_BUCKET_NP"); if (ev) h->pruned_bucket_np = std::atoll(ev); }
     { const char *ev = std::getenv("MPC_R2_EARLY"); if (ev) h->r2_early = std::atoi(ev); }
     { const char *ev = std::getenv("MPC_R2_EARLY_MIN"); if (ev) h->r2_early_min = std::atoll(ev); }
     { const char *ev = std::getenv("MPC_R2_EARLY_WPC"); if (ev) h->r2_early_wpc = std::max(0, std::atoi(ev)); }
@@ -2187,7 +2189,7 @@ static int level_run_impl(mpc_handle *h, int32_t gen_children, int32_t flags, mp
         // (round 6) the pruned list of the earlier levels, bucketed by smallest non-equality member, for this level's children stage: three
         // small launches at the level's start (nothing waits for them before k_children_count_b)
         bool pruned_bucketed = false;
-        if (gen_children && !(flags & MPC_LEVEL_GRAPH) && h->pruned_bucket_min > 0 && h->n_c <= 256 && h->n_pruned >= 1024 &&
+        if (gen_children && !(flags & MPC_LEVEL_GRAPH) && h->pruned_bucket_min > 0 && h->n_c <= 256 && h->n_pruned >= std::max<long long>(1, h->pruned_bucket_np) &&
             (double)n * (double)h->n_pruned >= h->pruned_bucket_min && h->n_pruned <= 0x7fffffffLL) {
             HIP_TRY(h, h->pruned_b.ensure((size_t)h->n_pruned * h->mw * sizeof(uint64_t), st));
             HIP_TRY(h, h->pruned_head.ensure((size_t)PB_WORDS * sizeof(int32_t), st));

@@ -781,7 +781,8 @@ def test_children_from_the_bucketed_pruned_list_equal_the_full_scan(monkeypatch)
         g = load_golden(name)
         runs = []
         for env in ('1', '0'):
-            monkeypatch.setenv('MPC_PRUNED_BUCKET_MIN', env)      # 1: every level with >= 1,024 pruned sets; 0: never
+            monkeypatch.setenv('MPC_PRUNED_BUCKET_MIN', env)      # 1: every level with a pruned set; 0: never
+            monkeypatch.setenv('MPC_PRUNED_BUCKET_NP', '1')
             monkeypatch.setenv('MPC_NO_SMALLPATH', '1')            # (the bucketed scan lives on the classic path)
             eng = engine_from_golden(g)
             eng.pruned_clear(); eng.frontier_root()
