@@ -43,10 +43,10 @@ __global__ void m_zero_counter(const BatchMember *__restrict__ tab, int which) {
 }
 
 // ---- theta stage --------------------------------------------------------------------------------------------------------------
-template <int K, int NT>
+template <int K, int NT, int SP>
 __global__ void __launch_bounds__(256) m_kkt_thread(const BatchMember *__restrict__ tab) {
     MEMBER;
-    k_kkt_thread<K, NT>(m.pf, m.fr, m.n, m.kkt_code, m.kkt_L, m.status, m.targs, m.ctr);
+    k_kkt_thread<K, NT, SP>(m.pf, m.fr, m.n, m.kkt_code, m.kkt_L, m.status, m.targs, m.ctr);
 }
 __global__ void __launch_bounds__(1024) m_compact_small(const BatchMember *__restrict__ tab, int lo, int hi, int into_retry, int slot) {
     MEMBER;
@@ -206,7 +206,7 @@ unsigned long long spec_of(std::initializer_list<std::pair<int, int>> classes) {
     return spec;
 }
 
-auto group_key(const BatchMember &m) { return std::make_tuple(m.k, m.kd, m.fast_t, m.fast_x, m.fast_r, m.mw, m.use_kkt, m.quick_test, m.gen_children); }
+auto group_key(const BatchMember &m) { return std::make_tuple(m.k, m.kd, m.fast_t, m.fast_x, m.fast_r, m.mw, m.use_kkt, m.kkt_listed, m.quick_test, m.gen_children); }
 
 int env_int(const char *name, int dflt) { const char *v = std::getenv(name); return v && *v ? std::atoi(v) : dflt; }
 
@@ -285,13 +285,18 @@ hipError_t batch_level_launch(BatchMember *members, int B, hipStream_t st, Batch
         const unsigned blocks256 = (unsigned)((n_max + 255) / 256);
         // KKT solves + box screen, theta stage
         if (r.use_kkt) {
-            const dim3 g(blocks256, G), b(256);
-#define MPC_LAUNCH_KKT(K_) case K_: if (r.fast_t >= 4) hipLaunchKernelGGL((m_kkt_thread<K_, 10>), g, b, 0, st, tab); \
-                                    else if (r.fast_t >= 2) hipLaunchKernelGGL((m_kkt_thread<K_, 8>), g, b, 0, st, tab); \
-                                    else hipLaunchKernelGGL((m_kkt_thread<K_, 4>), g, b, 0, st, tab); break
-            switch (r.kd) { MPC_LAUNCH_KKT(1); MPC_LAUNCH_KKT(2); MPC_LAUNCH_KKT(3); MPC_LAUNCH_KKT(4); MPC_LAUNCH_KKT(5); MPC_LAUNCH_KKT(6); MPC_LAUNCH_KKT(7); MPC_LAUNCH_KKT(8); }
+            const bool spread = r.use_kkt == 2;     // BATCH_KKT_SPREAD lanes per candidate (k_kkt_thread's comment)
+            const dim3 g(spread ? (unsigned)((n_max * BATCH_KKT_SPREAD + 255) / 256) : blocks256, G), b(256);
+#define MPC_LAUNCH_KKT_(K_, SP_) if (r.fast_t >= 4) hipLaunchKernelGGL((m_kkt_thread<K_, 10, SP_>), g, b, 0, st, tab); \
+                                    else if (r.fast_t >= 2) hipLaunchKernelGGL((m_kkt_thread<K_, 8, SP_>), g, b, 0, st, tab); \
+                                    else hipLaunchKernelGGL((m_kkt_thread<K_, 4, SP_>), g, b, 0, st, tab)
+#define MPC_LAUNCH_KKT(K_) case K_: MPC_LAUNCH_KKT_(K_, 1); break
+#define MPC_LAUNCH_KKT_S(K_) case K_: if (spread) { MPC_LAUNCH_KKT_(K_, BATCH_KKT_SPREAD); } else { MPC_LAUNCH_KKT_(K_, 1); } break
+            switch (r.kd) { MPC_LAUNCH_KKT_S(1); MPC_LAUNCH_KKT_S(2); MPC_LAUNCH_KKT_S(3); MPC_LAUNCH_KKT_S(4); MPC_LAUNCH_KKT_S(5); MPC_LAUNCH_KKT_S(6); MPC_LAUNCH_KKT(7); MPC_LAUNCH_KKT(8); }
+#undef MPC_LAUNCH_KKT_S
 #undef MPC_LAUNCH_KKT
-            hipLaunchKernelGGL(m_compact_small, dim3(1, G), dim3(1024), 0, st, tab, ST_TODO, ST_TODO, 0, 0);
+#undef MPC_LAUNCH_KKT_
+            if (!r.kkt_listed) hipLaunchKernelGGL(m_compact_small, dim3(1, G), dim3(1024), 0, st, tab, ST_TODO, ST_TODO, 0, 0);
         }
         {
             const dim3 g((unsigned)std::min<long long>(n_max, th_max > 0 ? th_max : grid_f), G), b(64);

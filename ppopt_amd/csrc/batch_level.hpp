@@ -40,12 +40,15 @@
 
 namespace mpc {
 
+// use_kkt == 2: k_kkt_thread with this many lanes per candidate (levels of a batch are small by construction), up to KMAX inequality rows
+constexpr int BATCH_KKT_SPREAD = 8, BATCH_KKT_SPREAD_KMAX = 6;
+
 struct BatchZero { void *p; unsigned long long bytes; };
 
 struct BatchMember {
     int id;                  // position in the caller's array (batch_level_launch reorders the members into groups)
     // ---- what selects the kernels (members of one group agree on all of these) ------------------------------------------------
-    int k, kd, fast_t, fast_x, fast_r, mw, use_kkt, quick_test, gen_children;
+    int k, kd, fast_t, fast_x, fast_r, mw, use_kkt /* 0, 1, 2: spread */, kkt_listed, quick_test, gen_children;
     // ---- sizes ------------------------------------------------------------------------------------------------------------------
     long long n;             // candidates of the level
     int grid_f, grid_r2, n_cu, lds_f, lds_v, lds_r2, rsplit_max;

@@ -682,33 +682,69 @@ __device__ __forceinline__ int block_exclusive_scan_1024(int v, int *total_out) 
     __syncthreads();
     return incl - v + wsum[w];
 }
-MPC_GLOBAL void MPC_LB(1024) k_scan_block_sums(const int32_t *__restrict__ in, long long n, int32_t *__restrict__ sums) {
-    __shared__ int tot;
-    const long long i = blockIdx.x * (long long)SCAN_BLOCK + threadIdx.x;
-    (void)block_exclusive_scan_1024(i < n ? in[i] : 0, &tot);
+// The same scan of 1024 items by 1024 / IT threads, IT consecutive items per thread (IT = 4: four-wavefront workgroups, which find room
+// on a compute unit that a persistent kernel's wavefronts occupy; a 16-wavefront workgroup waits there until a whole unit drains).
+template <int IT>
+__device__ __forceinline__ void block_exclusive_scan_it(const int (&v)[IT], int (&ex)[IT], int *total_out) {
+    constexpr int NW = 16 / IT;
+    __shared__ int wsum_it[NW];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    int s = 0;
+#pragma unroll
+    for (int k = 0; k < IT; ++k) s += v[k];
+    int incl = s;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) { const int o = __shfl_up(incl, off); if (lane >= off) incl += o; }
+    if (lane == 63) wsum_it[w] = incl;
     __syncthreads();
+    int base = 0;
+#pragma unroll
+    for (int k = 0; k < NW; ++k) base += k < w ? wsum_it[k] : 0;
+    if (total_out && threadIdx.x == 64 * NW - 1) *total_out = base + incl;
+    int run = base + incl - s;
+#pragma unroll
+    for (int k = 0; k < IT; ++k) { ex[k] = run; run += v[k]; }
+    __syncthreads();
+}
+template <int IT>
+MPC_GLOBAL void MPC_LB(1024 / IT) k_scan_block_sums(const int32_t *__restrict__ in, long long n, int32_t *__restrict__ sums) {
+    __shared__ int tot;
+    const long long i0 = blockIdx.x * (long long)SCAN_BLOCK + (long long)threadIdx.x * IT;
+    int v[IT], ex[IT];
+#pragma unroll
+    for (int k = 0; k < IT; ++k) v[k] = i0 + k < n ? in[i0 + k] : 0;
+    block_exclusive_scan_it<IT>(v, ex, &tot);
     if (threadIdx.x == 0) sums[blockIdx.x] = tot;
 }
 // one block: exclusive scan of up to nb block sums in place (chunked), total -> *total
-MPC_GLOBAL void MPC_LB(1024) k_scan_sums(int32_t *__restrict__ sums, int nb, int32_t *__restrict__ total) {
+template <int IT>
+MPC_GLOBAL void MPC_LB(1024 / IT) k_scan_sums(int32_t *__restrict__ sums, int nb, int32_t *__restrict__ total) {
     __shared__ int tot;
     int carry = 0;
     for (int base = 0; base < nb; base += SCAN_BLOCK) {
-        const int i = base + threadIdx.x;
-        const int v = i < nb ? sums[i] : 0;
-        const int ex = block_exclusive_scan_1024(v, &tot);
-        __syncthreads();
-        if (i < nb) sums[i] = ex + carry;
+        const int i0 = base + (int)threadIdx.x * IT;
+        int v[IT], ex[IT];
+#pragma unroll
+        for (int k = 0; k < IT; ++k) v[k] = i0 + k < nb ? sums[i0 + k] : 0;
+        block_exclusive_scan_it<IT>(v, ex, &tot);
+#pragma unroll
+        for (int k = 0; k < IT; ++k) if (i0 + k < nb) sums[i0 + k] = ex[k] + carry;
         carry += tot;
         __syncthreads();
     }
     if (threadIdx.x == 0) *total = carry;
 }
-MPC_GLOBAL void MPC_LB(1024) k_scan_apply(const int32_t *__restrict__ in, int32_t *__restrict__ out, long long n,
+template <int IT>
+MPC_GLOBAL void MPC_LB(1024 / IT) k_scan_apply(const int32_t *__restrict__ in, int32_t *__restrict__ out, long long n,
                                                     const int32_t *__restrict__ sums) {
-    const long long i = blockIdx.x * (long long)SCAN_BLOCK + threadIdx.x;
-    const int ex = block_exclusive_scan_1024(i < n ? in[i] : 0, nullptr);
-    if (i < n) out[i] = ex + sums[blockIdx.x];
+    const long long i0 = blockIdx.x * (long long)SCAN_BLOCK + (long long)threadIdx.x * IT;
+    int v[IT], ex[IT];
+#pragma unroll
+    for (int k = 0; k < IT; ++k) v[k] = i0 + k < n ? in[i0 + k] : 0;
+    block_exclusive_scan_it<IT>(v, ex, nullptr);
+    const int add = sums[blockIdx.x];
+#pragma unroll
+    for (int k = 0; k < IT; ++k) if (i0 + k < n) out[i0 + k] = ex[k] + add;
 }
 
 // ---- deterministic multi-class partition by status -----------------------------------------------------------------------
@@ -716,16 +752,22 @@ MPC_GLOBAL void MPC_LB(1024) k_scan_apply(const int32_t *__restrict__ in, int32_
 // frontier order (lists + c*n) and their lengths, instead of one flag/scan/scatter round per class.
 constexpr int PART_CLASSES = 4;
 __device__ __forceinline__ int part_class(unsigned long long spec, int st) { return (int)((spec >> (4 * (st & 15))) & 15ull); }
-MPC_GLOBAL void MPC_LB(1024) k_part_count(const uint8_t *__restrict__ status, long long n, unsigned long long spec,
+// 1024 statuses per workgroup of 1024 / IT threads: sub-chunk j of the workgroup is the 1024 / IT statuses from j * (1024 / IT)
+template <int IT>
+MPC_GLOBAL void MPC_LB(1024 / IT) k_part_count(const uint8_t *__restrict__ status, long long n, unsigned long long spec,
                                                      int32_t *__restrict__ blockcounts, int nb) {
+    constexpr int BT = 1024 / IT, NW = BT / 64;
     __shared__ int wc[16][PART_CLASSES];
-    const long long i = blockIdx.x * 1024LL + threadIdx.x;
-    const int cls = i < n ? part_class(spec, status[i]) : 15;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
 #pragma unroll
-    for (int c = 0; c < PART_CLASSES; ++c) {
-        const unsigned long long m = __ballot(cls == c);
-        if (lane == 0) wc[wave][c] = __popcll(m);
+    for (int j = 0; j < IT; ++j) {
+        const long long i = blockIdx.x * 1024LL + j * BT + threadIdx.x;
+        const int cls = i < n ? part_class(spec, status[i]) : 15;
+#pragma unroll
+        for (int c = 0; c < PART_CLASSES; ++c) {
+            const unsigned long long m = __ballot(cls == c);
+            if (lane == 0) wc[j * NW + wave][c] = __popcll(m);
+        }
     }
     __syncthreads();
     if (threadIdx.x < PART_CLASSES) {
@@ -735,39 +777,52 @@ MPC_GLOBAL void MPC_LB(1024) k_part_count(const uint8_t *__restrict__ status, lo
     }
 }
 // grid = PART_CLASSES blocks: exclusive scan of each class's block counts in place, totals[c] = list length
-MPC_GLOBAL void MPC_LB(1024) k_part_sums(int32_t *__restrict__ blockcounts, int nb, int32_t *__restrict__ totals) {
+template <int IT>
+MPC_GLOBAL void MPC_LB(1024 / IT) k_part_sums(int32_t *__restrict__ blockcounts, int nb, int32_t *__restrict__ totals) {
     __shared__ int tot;
     int32_t *sums = blockcounts + (size_t)blockIdx.x * nb;
     int carry = 0;
     for (int base = 0; base < nb; base += SCAN_BLOCK) {
-        const int i = base + threadIdx.x;
-        const int v = i < nb ? sums[i] : 0;
-        const int ex = block_exclusive_scan_1024(v, &tot);
-        __syncthreads();
-        if (i < nb) sums[i] = ex + carry;
+        const int i0 = base + (int)threadIdx.x * IT;
+        int v[IT], ex[IT];
+#pragma unroll
+        for (int k = 0; k < IT; ++k) v[k] = i0 + k < nb ? sums[i0 + k] : 0;
+        block_exclusive_scan_it<IT>(v, ex, &tot);
+#pragma unroll
+        for (int k = 0; k < IT; ++k) if (i0 + k < nb) sums[i0 + k] = ex[k] + carry;
         carry += tot;
         __syncthreads();
     }
     if (threadIdx.x == 0) totals[blockIdx.x] = carry;
 }
-MPC_GLOBAL void MPC_LB(1024) k_part_scatter(const uint8_t *__restrict__ status, long long n, unsigned long long spec,
+template <int IT>
+MPC_GLOBAL void MPC_LB(1024 / IT) k_part_scatter(const uint8_t *__restrict__ status, long long n, unsigned long long spec,
                                                        const int32_t *__restrict__ blockbase, int nb, int32_t *__restrict__ lists) {
+    constexpr int BT = 1024 / IT, NW = BT / 64;
     __shared__ int wc[16][PART_CLASSES];
-    const long long i = blockIdx.x * 1024LL + threadIdx.x;
-    const int cls = i < n ? part_class(spec, status[i]) : 15;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    int within = 0;
+    int cls[IT], within[IT];
 #pragma unroll
-    for (int c = 0; c < PART_CLASSES; ++c) {
-        const unsigned long long m = __ballot(cls == c);
-        if (lane == 0) wc[wave][c] = __popcll(m);
-        if (cls == c) within = __popcll(m & ((1ull << lane) - 1ull));
+    for (int j = 0; j < IT; ++j) {
+        const long long i = blockIdx.x * 1024LL + j * BT + threadIdx.x;
+        cls[j] = i < n ? part_class(spec, status[i]) : 15;
+        within[j] = 0;
+#pragma unroll
+        for (int c = 0; c < PART_CLASSES; ++c) {
+            const unsigned long long m = __ballot(cls[j] == c);
+            if (lane == 0) wc[j * NW + wave][c] = __popcll(m);
+            if (cls[j] == c) within[j] = __popcll(m & ((1ull << lane) - 1ull));
+        }
     }
     __syncthreads();
-    if (cls < PART_CLASSES) {
-        int before = 0;
-        for (int w = 0; w < wave; ++w) before += wc[w][cls];
-        lists[(size_t)cls * n + blockbase[cls * nb + blockIdx.x] + before + within] = (int32_t)i;
+#pragma unroll
+    for (int j = 0; j < IT; ++j) {
+        if (cls[j] < PART_CLASSES) {
+            const long long i = blockIdx.x * 1024LL + j * BT + threadIdx.x;
+            int before = 0;
+            for (int w = 0; w < j * NW + wave; ++w) before += wc[w][cls[j]];
+            lists[(size_t)cls[j] * n + blockbase[cls[j] * nb + blockIdx.x] + before + within[j]] = (int32_t)i;
+        }
     }
 }
 

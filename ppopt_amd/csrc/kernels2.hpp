@@ -89,14 +89,22 @@ constexpr int KK_UNDECIDED = 255;
 constexpr int KK_ILL = 64;        // solved, but the Schur system is ill-conditioned (CHOL_ILL_TOL, kkt.hpp)
 constexpr int ST_TODO = 10;       // internal: waiting for k_theta2
 constexpr int ST_RRETRY = 11;     // status[] of a candidate k_region2 gave up on (its slot carries ST_RETRY): re-solved by k_region
-template <int K, int NT>
+// SP > 1 (small levels, round 6): SP neighbouring lanes share a candidate.  Each repeats the factorisation and the multipliers (the same
+// registers, the same values) and screens every SP-th group of inactive rows; the verdict is the OR of theirs, lane 0 of the group writes.
+// The screen is a chain of dependent L2 round trips -- n_c / RU of them, 40 of the kernel's 50 us on a level of thirty candidates -- and a
+// level that does not fill the chip has the lanes to cut the chain SP-fold: same rows, same arithmetic per row, the same verdict.
+template <int K, int NT, int SP = 1>
 MPC_GLOBAL void MPC_LB(256) k_kkt_thread(const DevProblem *__restrict__ Pg, const int32_t *__restrict__ cands, long long n,
                                                      uint8_t *__restrict__ code, double *__restrict__ Lout, uint8_t *__restrict__ status,
                                                      ThetaArgs ta, LevelCounters *__restrict__ ctr) {
     // K = the INEQUALITY rows of the active set; the program's ne equality rows lead every candidate (cardinality ne + K) and are
     // eliminated from the systems below (ThetaArgs: Wr, UVrp, AATr) -- with ne == 0 these are the original blocks.
+    static_assert(SP >= 1 && SP <= 64 && (SP & (SP - 1)) == 0, "lanes per candidate: a power of two within a wavefront");
     const DevProblem &P = *Pg;
-    const long long c = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long c = gid / SP;
+    const int sub = (int)(gid & (SP - 1));
+    const bool lead = sub == 0;
     int kind = 0;      // 1: left to the theta stage (ST_TODO), 2: sent to the (x,theta) question by the screen (ST_NEEDX)
   do {
     if (c >= n) break;
@@ -136,7 +144,7 @@ MPC_GLOBAL void MPC_LB(256) k_kkt_thread(const DevProblem *__restrict__ Pg, cons
             }
         }
         clear = clear && (vol > 1e-10);
-        if (!clear) { code[c] = (uint8_t)KK_UNDECIDED; status[c] = (uint8_t)ST_TODO; kind = 1; break; }
+        if (!clear) { if (lead) { code[c] = (uint8_t)KK_UNDECIDED; status[c] = (uint8_t)ST_TODO; } kind = 1; break; }
     }
     // ---- S = Wr[as,as] = L L'  (chol_solve arithmetic; the pivots are those of the full Schur matrix behind its equality block) ----
     double diag0[K], invd[K];
@@ -163,7 +171,7 @@ MPC_GLOBAL void MPC_LB(256) k_kkt_thread(const DevProblem *__restrict__ Pg, cons
             for (int cc = j + 1; cc <= i; ++cc) S[i][cc] = fma(-S[i][j], S[cc][j], S[i][cc]);
         }
     }
-    if (!ok) { code[c] = 2; status[c] = (uint8_t)ST_TODO; kind = 1; break; }
+    if (!ok) { if (lead) { code[c] = 2; status[c] = (uint8_t)ST_TODO; } kind = 1; break; }
     // ---- multipliers of the inequality rows, all n_t + 1 right-hand sides (zero beyond n_t) -----------------------------------------
     double Lr[K][LS];
 #pragma unroll
@@ -195,7 +203,7 @@ MPC_GLOBAL void MPC_LB(256) k_kkt_thread(const DevProblem *__restrict__ Pg, cons
     // (no early exit inside a group of rows: a group is ONE basic block, so the scheduler can issue all its loads first; from five rows of
     // active set on the kernel is bound by registers and throughput -- config 4's level of 10^6 candidates -- and keeps one row per trip)
     constexpr int RU = K <= 2 ? 8 : (K <= 4 ? 4 : 1);
-    for (int c0 = ne; c0 < nc; c0 += RU) {
+    for (int c0 = ne + sub * RU; c0 < nc; c0 += RU * SP) {
       double wpre[RU][K];
 #pragma unroll
       for (int u = 0; u < RU; ++u) {
@@ -245,12 +253,17 @@ MPC_GLOBAL void MPC_LB(256) k_kkt_thread(const DevProblem *__restrict__ Pg, cons
       }
       if (__all(fired)) break;
     }
+    if (SP > 1) {     // (every lane of a candidate is here together: they took the same exits above)
+        const unsigned long long fm = __ballot(fired);
+        const int l0 = (int)(threadIdx.x & 63) & ~(SP - 1);
+        fired = ((fm >> l0) & (SP >= 64 ? ~0ull : ((1ull << SP) - 1ull))) != 0ull;
+    }
     if (fired) {
-        code[c] = ill ? KK_ILL : 0;
-        status[c] = (uint8_t)ST_NEEDX;
+        if (lead) { code[c] = ill ? KK_ILL : 0; status[c] = (uint8_t)ST_NEEDX; }
         kind = 2;
         break;
     }
+    if (!lead) { kind = 1; break; }
     double *out = Lout + (size_t)c * kf * nr;
     // multipliers of the equality rows:  lambda_E = -(Me + Ne[:, as] lambda_a)
     for (int i = 0; i < ne; ++i) {
@@ -275,6 +288,7 @@ MPC_GLOBAL void MPC_LB(256) k_kkt_thread(const DevProblem *__restrict__ Pg, cons
     status[c] = (uint8_t)ST_TODO;
     kind = 1;
   } while (false);
+    if (!lead) kind = 0;
     // the kernel's own work lists (ThetaArgs::kt_list / kx_list): ONE atomic per workgroup and list -- per wavefront and exit point they cost
     // the last level of config 4 (15 k wavefronts, 98.5 % of the candidates on one list) 0.11 ms of atomics on one address
     if (ta.kt_list) {     // (uniform: every thread of the workgroup is here, whatever it decided)

@@ -283,6 +283,9 @@ struct mpc_handle {
     hipEvent_t ev_x1go = nullptr, ev_x1done = nullptr;
     bool x1_pending = false;
     int x1_defer = 1;
+    int x1_lds_cap = 0;
+    int kkt_spread = 1;         // small levels: k_kkt_thread with KKT_SPREAD lanes per candidate (MPC_KKT_SPREAD=0: one lane)
+    int helper_it = 4;          // scan / partition helpers: 4 = four-wavefront workgroups of 4 items per thread, 1 = 1024-thread workgroups (MPC_HELPER_IT)
     // Round 6: the pruned list bucketed by smallest non-equality member (kernels.hpp, k_children_count_b), rebuilt at the start of every level
     // whose children stage is large enough to pay for it (MPC_PRUNED_BUCKET_MIN: parents x pruned sets; 0 = never)
     DevBuf pruned_b, pruned_head;
@@ -648,6 +651,9 @@ static int create_fill(const mpc_problem *p, int32_t device, void *stream, mpc_h
     HIP_TRY(nullptr, pooled_event(&h->ev_x1go, false));
     HIP_TRY(nullptr, pooled_event(&h->ev_x1done, false));
     { const char *ev = std::getenv("MPC_X1_DEFER"); if (ev) h->x1_defer = std::atoi(ev); }
+    { const char *ev = std::getenv("MPC_X1_LDS_CAP"); if (ev) h->x1_lds_cap = std::max(0, std::atoi(ev)); }
+    { const char *ev = std::getenv("MPC_KKT_SPREAD"); if (ev) h->kkt_spread = std::atoi(ev); }
+    { const char *ev = std::getenv("MPC_HELPER_IT"); if (ev) h->helper_it = std::atoi(ev) == 1 ? 1 : 4; }
     { const char *ev = std::getenv("MPC_PRUNED_BUCKET_MIN"); if (ev) h->pruned_bucket_min = std::atof(ev); }
     { const char *ev = std::getenv("MPC_PRUNED_BUCKET_NP"); if (ev) h->pruned_bucket_np = std::atoll(ev); }
     { const char *ev = std::getenv("MPC_R2_EARLY"); if (ev) h->r2_early = std::atoi(ev); }
@@ -1363,9 +1369,15 @@ static int launch_scan(mpc_handle *h, const int32_t *in, int32_t *out, long long
     }
     const int nb = (int)((n + SCAN_BLOCK - 1) / SCAN_BLOCK);
     HIP_TRY(h, h->sums.ensure((size_t)std::max(nb, 1) * sizeof(int32_t), h->stream));
-    hipLaunchKernelGGL(k_scan_block_sums, dim3(nb), dim3(SCAN_BLOCK), 0, h->stream, in, n, h->sums.as<int32_t>());
-    hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(SCAN_BLOCK), 0, h->stream, h->sums.as<int32_t>(), nb, total_dev);
-    hipLaunchKernelGGL(k_scan_apply, dim3(nb), dim3(SCAN_BLOCK), 0, h->stream, in, out, n, h->sums.as<int32_t>());
+    if (h->helper_it == 4) {   // four-wavefront workgroups (see block_exclusive_scan_it)
+        hipLaunchKernelGGL(k_scan_block_sums<4>, dim3(nb), dim3(SCAN_BLOCK / 4), 0, h->stream, in, n, h->sums.as<int32_t>());
+        hipLaunchKernelGGL(k_scan_sums<4>, dim3(1), dim3(SCAN_BLOCK / 4), 0, h->stream, h->sums.as<int32_t>(), nb, total_dev);
+        hipLaunchKernelGGL(k_scan_apply<4>, dim3(nb), dim3(SCAN_BLOCK / 4), 0, h->stream, in, out, n, h->sums.as<int32_t>());
+    } else {
+        hipLaunchKernelGGL(k_scan_block_sums<1>, dim3(nb), dim3(SCAN_BLOCK), 0, h->stream, in, n, h->sums.as<int32_t>());
+        hipLaunchKernelGGL(k_scan_sums<1>, dim3(1), dim3(SCAN_BLOCK), 0, h->stream, h->sums.as<int32_t>(), nb, total_dev);
+        hipLaunchKernelGGL(k_scan_apply<1>, dim3(nb), dim3(SCAN_BLOCK), 0, h->stream, in, out, n, h->sums.as<int32_t>());
+    }
     HIP_TRY(h, hipGetLastError());
     return MPC_OK;
 }
@@ -1447,6 +1459,7 @@ static void stream_release(mpc_handle *h) {   // blocks of a streamed level nobo
 // one wavefront per SIMD at n_theta > 4) and still beat the wavefront-wide LDS solve inside k_theta2 several times over; K = 12
 // needs 364 registers at every n_theta.  The shared launches of several programs (batch_level.hip) keep 8.
 constexpr int KKT_THREAD_MAX = 10;
+constexpr int KKT_SPREAD = BATCH_KKT_SPREAD, KKT_SPREAD_KMAX = BATCH_KKT_SPREAD_KMAX;   // small levels: lanes per candidate of k_kkt_thread, up to this many inequality rows
 // every stream of the handle that may read or write dictionary records waits for the deferred k_x1 of the previous level (stream waits: the host does not block)
 static int x1_join(mpc_handle *h) {
     if (!h->x1_pending) return MPC_OK;
@@ -1537,14 +1550,27 @@ static int level_run_small(mpc_handle *h, int32_t gen_children, int32_t flags, m
         HIP_TRY(h, h->kkt_code.ensure(nn, st));
         HIP_TRY(h, h->kkt_L.ensure(nn * (size_t)k * (h->n_t + 1) * sizeof(double), st));
         kkc = h->kkt_code.as<uint8_t>(); kkl = h->kkt_L.as<double>();
-        const dim3 g((unsigned)blocks256), b(256);
-        const ThetaArgs tk = h->targs;
-#define MPC_LAUNCH_KKT(K_) case K_: if (h->fast_t >= 4) hipLaunchKernelGGL((k_kkt_thread<K_, 10>), g, b, 0, st, pf, fr, n, h->kkt_code.as<uint8_t>(), h->kkt_L.as<double>(), stp, tk, ctr); \
-                                    else if (h->fast_t >= 2) hipLaunchKernelGGL((k_kkt_thread<K_, 8>), g, b, 0, st, pf, fr, n, h->kkt_code.as<uint8_t>(), h->kkt_L.as<double>(), stp, tk, ctr); \
-                                    else hipLaunchKernelGGL((k_kkt_thread<K_, 4>), g, b, 0, st, pf, fr, n, h->kkt_code.as<uint8_t>(), h->kkt_L.as<double>(), stp, tk, ctr); break
-        switch (kd) { MPC_LAUNCH_KKT(1); MPC_LAUNCH_KKT(2); MPC_LAUNCH_KKT(3); MPC_LAUNCH_KKT(4); MPC_LAUNCH_KKT(5); MPC_LAUNCH_KKT(6); MPC_LAUNCH_KKT(7); MPC_LAUNCH_KKT(8); MPC_LAUNCH_KKT(9); MPC_LAUNCH_KKT(10); }
+        ThetaArgs tk = h->targs;
+        // the kernel lists the candidates it leaves to the theta stage itself (one atomic per workgroup; a work list: its order changes nothing)
+        const bool kkt_lists = !h->no_kkt_lists;
+        if (kkt_lists) {
+            HIP_TRY(h, h->xq_list.ensure(nn * sizeof(int32_t), st));
+            tk.kt_list = h->theta_list.as<int32_t>(); tk.kt_n = dcnt + 0;
+            tk.kx_list = h->xq_list.as<int32_t>(); tk.kx_n = dcnt + 10;
+        }
+        // KKT_SPREAD lanes per candidate while the active set is small (the kernel's comment): the level's 50 us floor becomes ~15
+        const bool spread = h->kkt_spread > 0 && kd <= KKT_SPREAD_KMAX;
+        const dim3 g((unsigned)(spread ? (n * KKT_SPREAD + 255) / 256 : blocks256)), b(256);
+#define MPC_LAUNCH_KKT_(K_, SP_) if (h->fast_t >= 4) hipLaunchKernelGGL((k_kkt_thread<K_, 10, SP_>), g, b, 0, st, pf, fr, n, h->kkt_code.as<uint8_t>(), h->kkt_L.as<double>(), stp, tk, ctr); \
+                                    else if (h->fast_t >= 2) hipLaunchKernelGGL((k_kkt_thread<K_, 8, SP_>), g, b, 0, st, pf, fr, n, h->kkt_code.as<uint8_t>(), h->kkt_L.as<double>(), stp, tk, ctr); \
+                                    else hipLaunchKernelGGL((k_kkt_thread<K_, 4, SP_>), g, b, 0, st, pf, fr, n, h->kkt_code.as<uint8_t>(), h->kkt_L.as<double>(), stp, tk, ctr)
+#define MPC_LAUNCH_KKT(K_) case K_: MPC_LAUNCH_KKT_(K_, 1); break
+#define MPC_LAUNCH_KKT_S(K_) case K_: if (spread) { MPC_LAUNCH_KKT_(K_, KKT_SPREAD); } else { MPC_LAUNCH_KKT_(K_, 1); } break
+        switch (kd) { MPC_LAUNCH_KKT_S(1); MPC_LAUNCH_KKT_S(2); MPC_LAUNCH_KKT_S(3); MPC_LAUNCH_KKT_S(4); MPC_LAUNCH_KKT_S(5); MPC_LAUNCH_KKT_S(6); MPC_LAUNCH_KKT(7); MPC_LAUNCH_KKT(8); MPC_LAUNCH_KKT(9); MPC_LAUNCH_KKT(10); }
+#undef MPC_LAUNCH_KKT_S
 #undef MPC_LAUNCH_KKT
-        hipLaunchKernelGGL(k_compact_small, dim3(1), dim3(1024), 0, st, h->status.as<uint8_t>(), (int)n, ST_TODO, ST_TODO, h->theta_list.as<int32_t>(), dcnt + 0);
+#undef MPC_LAUNCH_KKT_
+        if (!kkt_lists) hipLaunchKernelGGL(k_compact_small, dim3(1), dim3(1024), 0, st, h->status.as<uint8_t>(), (int)n, ST_TODO, ST_TODO, h->theta_list.as<int32_t>(), dcnt + 0);
         theta_list = h->theta_list.as<int32_t>();
         ta.n_dev = dcnt + 0;
     }
@@ -1829,10 +1855,18 @@ static int batch_prepare(mpc_handle *h, int32_t gen_children, int32_t flags, Bat
     m.zero[m.n_zero++] = {h->ctr.p, sizeof(LevelCounters)};
     m.zero[m.n_zero++] = {h->dcnt.p, 32 * sizeof(int32_t)};
     m.use_kkt = (h->kkt_mode == 0 && m.kd >= 1 && m.kd <= 8 && h->no_kkt_thread != 1) ? 1 : 0;
+    if (m.use_kkt && h->kkt_spread > 0 && m.kd <= BATCH_KKT_SPREAD_KMAX) m.use_kkt = 2;   // BATCH_KKT_SPREAD lanes per candidate (k_kkt_thread)
+    m.kkt_listed = 0;
     if (m.use_kkt) {
         HIP_TRY(h, h->kkt_code.ensure(nn, st));
         HIP_TRY(h, h->kkt_L.ensure(nn * (size_t)k * (h->n_t + 1) * sizeof(double), st));
         m.kkt_code = h->kkt_code.as<uint8_t>(); m.kkt_L = h->kkt_L.as<double>();
+        if (!h->no_kkt_lists) {   // the kernel lists what it leaves to the theta stage (as level_run_small)
+            HIP_TRY(h, h->xq_list.ensure(nn * sizeof(int32_t), st));
+            m.targs.kt_list = m.theta_list; m.targs.kt_n = m.dcnt + 0;
+            m.targs.kx_list = h->xq_list.as<int32_t>(); m.targs.kx_n = m.dcnt + 10;
+            m.kkt_listed = 1;
+        }
     }
     // region stage: one slot per optimal candidate, buffers sized by the bound
     auto part_list = [&](int c) -> int32_t * { return h->part_lists.as<int32_t>() + (size_t)c * nn; };
@@ -2225,10 +2259,17 @@ static int level_run_impl(mpc_handle *h, int32_t gen_children, int32_t flags, mp
             if (small) {
                 hipLaunchKernelGGL(k_partition_small, dim3(1), dim3(1024), 0, st, h->status.as<uint8_t>(), (int)n, spec, h->part_lists.as<int32_t>(), (long long)n, tot);
             } else {
-                hipLaunchKernelGGL(k_part_count, dim3(nb1024), dim3(1024), 0, st, h->status.as<uint8_t>(), n, spec, h->part_counts.as<int32_t>(), nb1024);
-                hipLaunchKernelGGL(k_part_sums, dim3(PART_CLASSES), dim3(1024), 0, st, h->part_counts.as<int32_t>(), nb1024, tot);
-                hipLaunchKernelGGL(k_part_scatter, dim3(nb1024), dim3(1024), 0, st, h->status.as<uint8_t>(), n, spec, h->part_counts.as<int32_t>(), nb1024,
-                                   h->part_lists.as<int32_t>());
+                if (h->helper_it == 4) {
+                    hipLaunchKernelGGL(k_part_count<4>, dim3(nb1024), dim3(256), 0, st, h->status.as<uint8_t>(), n, spec, h->part_counts.as<int32_t>(), nb1024);
+                    hipLaunchKernelGGL(k_part_sums<4>, dim3(PART_CLASSES), dim3(256), 0, st, h->part_counts.as<int32_t>(), nb1024, tot);
+                    hipLaunchKernelGGL(k_part_scatter<4>, dim3(nb1024), dim3(256), 0, st, h->status.as<uint8_t>(), n, spec, h->part_counts.as<int32_t>(), nb1024,
+                                       h->part_lists.as<int32_t>());
+                } else {
+                    hipLaunchKernelGGL(k_part_count<1>, dim3(nb1024), dim3(1024), 0, st, h->status.as<uint8_t>(), n, spec, h->part_counts.as<int32_t>(), nb1024);
+                    hipLaunchKernelGGL(k_part_sums<1>, dim3(PART_CLASSES), dim3(1024), 0, st, h->part_counts.as<int32_t>(), nb1024, tot);
+                    hipLaunchKernelGGL(k_part_scatter<1>, dim3(nb1024), dim3(1024), 0, st, h->status.as<uint8_t>(), n, spec, h->part_counts.as<int32_t>(), nb1024,
+                                       h->part_lists.as<int32_t>());
+                }
             }
             HIP_TRY(h, hipGetLastError());
             if (deferred) return MPC_OK;
@@ -2692,8 +2733,13 @@ static int level_run_impl(mpc_handle *h, int32_t gen_children, int32_t flags, mp
                 if (defer) { HIP_TRY(h, hipEventRecord(h->ev_x1go, st)); HIP_TRY(h, hipStreamWaitEvent(sx1, h->ev_x1go, 0)); }
                 if (h->timing) HIP_TRY(h, hipEventRecord(h->kev[12], st));
                 LevelCounters *ctr_x1 = defer ? (LevelCounters *)nullptr : ctr;   // (its pivot count would land in the next level's counters)
-                if (h->fast_x & 1) hipLaunchKernelGGL((k_x1<2>), dim3(g1), dim3(64), 0, sx1, pfx, pl.x1_list, pl.x1_n, ctr_x1, dc, nxc, pl.plan_slot, pl.plan_step);
-                else hipLaunchKernelGGL((k_x1<1>), dim3(g1), dim3(64), 0, sx1, pfx, pl.x1_list, pl.x1_n, ctr_x1, dc, nxc, pl.plan_slot, pl.plan_step);
+                // A deferred k_x1 must leave every CU room for a 1024-thread workgroup: the partition / scan kernels of the level's end are
+                // such blocks, and beside persistent k_x1 wavefronts packed seven to a SIMD one of them waited 0.37 ms for a CU
+                // (`profiles/r06_c4_timeline.log`).  An (unused) LDS allocation of 1/x1_wpc of the CU's 160 KB caps the kernel at its launch width per CU.
+                // MPC_X1_LDS_CAP = c > 0: the deferred kernel asks for (144 KB / c) of LDS it never touches, which holds it to c wavefronts per compute unit
+                const unsigned lds_x1 = defer && h->x1_lds_cap > 0 ? (unsigned)((144 * 1024) / h->x1_lds_cap) & ~255u : 0u;
+                if (h->fast_x & 1) hipLaunchKernelGGL((k_x1<2>), dim3(g1), dim3(64), lds_x1, sx1, pfx, pl.x1_list, pl.x1_n, ctr_x1, dc, nxc, pl.plan_slot, pl.plan_step);
+                else hipLaunchKernelGGL((k_x1<1>), dim3(g1), dim3(64), lds_x1, sx1, pfx, pl.x1_list, pl.x1_n, ctr_x1, dc, nxc, pl.plan_slot, pl.plan_step);
                 if (h->timing) HIP_TRY(h, hipEventRecord(h->kev[13], st));
                 HIP_TRY(h, hipGetLastError());
                 if (defer) { HIP_TRY(h, hipEventRecord(h->ev_x1done, sx1)); h->x1_pending = true; }

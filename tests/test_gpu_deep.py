@@ -798,3 +798,50 @@ def test_children_from_the_bucketed_pruned_list_equal_the_full_scan(monkeypatch)
         assert len(runs[0]) == len(runs[1]) >= 3
         for (c1, s1), (c2, s2) in zip(*runs):
             assert numpy.array_equal(s1, s2) and numpy.array_equal(c1, c2), name
+
+
+def test_small_level_kkt_lanes_and_helper_workgroups_change_nothing(monkeypatch):
+    """Round 6: (a) on a small level k_kkt_thread gives a candidate eight lanes -- each repeats the factorisation, the box screen's rows are
+    dealt among them, the verdict is the OR (MPC_KKT_SPREAD=0: one lane) -- and lists its own output instead of a compaction launch
+    (MPC_NO_KKT_LISTS=1); (b) the scan / partition helpers of a large level are four-wavefront workgroups of four items per thread
+    (MPC_HELPER_IT=1: sixteen wavefronts of one).  Every level's statuses and children, and every region of configs 4 and 2, are the same
+    either way."""
+    import bench
+    from ppopt_amd.mp_solvers import mpqp_hip_combinatorial
+    from test_gpu_parity import engine_from_golden
+    new = {'MPC_KKT_SPREAD': '1', 'MPC_NO_KKT_LISTS': '0', 'MPC_HELPER_IT': '4'}
+    old = {'MPC_KKT_SPREAD': '0', 'MPC_NO_KKT_LISTS': '1', 'MPC_HELPER_IT': '1'}
+    for name, n_levels in (('c4_rand_20_8_20_s0', 4), ('c2_dblint_n5', 5), ('quadtank_n3', 5), ('c3_quadtank_n10', 3)):
+        g = load_golden(name)
+        runs = []
+        for env in (new, old):
+            for kk, vv in env.items():
+                monkeypatch.setenv(kk, vv)
+            eng = engine_from_golden(g)
+            eng.pruned_clear(); eng.frontier_root()
+            fr = []
+            for depth in range(n_levels):
+                st = eng.level_run(True)
+                fr.append((eng.level_children().copy(), eng.level_status().copy(), st.n_regions))
+                if st.n_children == 0:
+                    break
+                eng.frontier_advance()
+            eng.close()
+            runs.append(fr)
+        assert len(runs[0]) == len(runs[1]) >= 2
+        for (c1, s1, r1), (c2, s2, r2) in zip(*runs):
+            assert numpy.array_equal(s1, s2) and numpy.array_equal(c1, c2) and r1 == r2, name
+    for wl in ('c4', 'c2'):
+        sols = []
+        for env in (new, old):
+            for kk, vv in env.items():
+                monkeypatch.setenv(kk, vv)
+            prog = bench.build_program(wl)
+            sols.append(mpqp_hip_combinatorial.solve(prog, max_levels=bench.WORKLOADS[wl][2]))
+            prog.release_engine()
+        a, b = sols
+        assert len(a.critical_regions) == len(b.critical_regions) > 3
+        for r1, r2 in zip(a.critical_regions, b.critical_regions):
+            assert list(r1.active_set) == list(r2.active_set)
+            for fld in ('A', 'b', 'C', 'd', 'E', 'f'):
+                assert numpy.asarray(getattr(r1, fld)).tobytes() == numpy.asarray(getattr(r2, fld)).tobytes(), (wl, fld)
