@@ -634,6 +634,10 @@ struct DictCache {
     const int32_t *n_list_dev, *n_pre1_dev, *n_pre2_dev;
     int max_blocks;  // > 0 (with device-resident lengths): only that many blocks of the launch work, the others leave (a member's share of a shared launch)
     int flag_retry;  // k_xq / k_xq_grouped: a candidate whose run meets a doubtful pivot gets ST_RETRY at once (k_x2 would only repeat the run to find the same)
+    // k_x2 (round 6): a run that started from the program's own dictionary D0 (no cached parent) is a short fresh run -- k drives, nothing
+    // accumulated before them -- and its DECISION stands up to this growth (GROWTH_FRESH, the theta LP's rule; 0: GROWTH_SAFE as for a cached
+    // run).  Its dictionary is still only stored below GROWTH_SAFE: what the children inherit keeps the strict bound.
+    double fresh_limit;
 };
 // k_xq: the last level's quick (x,theta) test.  No dictionary is stored on the last level, so a candidate only needs a
 // DECISION: up to XQ_ITERS simplex iterations from the parent's dictionary in product form (revised simplex with an eta
@@ -1371,7 +1375,7 @@ MPC_GLOBAL void MPC_LB(64, (NXC * SLOTS >= 64 ? 2 : (NXC * SLOTS >= 32 ? X2_WAVE
                 }
             }
             pivots += lx.iters;
-            if (!retry && r != LP_ITERLIMIT && lx.growth > GROWTH_SAFE) retry = true;
+            if (!retry && r != LP_ITERLIMIT && lx.growth > ((!cached && dc.fresh_limit > 0.0) ? dc.fresh_limit : GROWTH_SAFE)) retry = true;
             if (!retry) {
                 if (r == LP_OPTIMAL) st = singular ? ST_SINGULAR : ST_FEASIBLE;
                 else if (r == LP_ITERLIMIT) st = ST_LP_LIMIT;

@@ -284,6 +284,7 @@ struct mpc_handle {
     bool x1_pending = false;
     int x1_defer = 1;
     int x1_lds_cap = 0;
+    double x_fresh_limit = 1e6;   // k_x2: growth up to which a run from D0 decides (DictCache::fresh_limit; MPC_X_FRESH_LIMIT=0: GROWTH_SAFE)
     int kkt_spread = 1;         // small levels: k_kkt_thread with KKT_SPREAD lanes per candidate (MPC_KKT_SPREAD=0: one lane)
     int helper_it = 4;          // scan / partition helpers: 4 = four-wavefront workgroups of 4 items per thread, 1 = 1024-thread workgroups (MPC_HELPER_IT)
     // Round 6: the pruned list bucketed by smallest non-equality member (kernels.hpp, k_children_count_b), rebuilt at the start of every level
@@ -653,6 +654,7 @@ static int create_fill(const mpc_problem *p, int32_t device, void *stream, mpc_h
     { const char *ev = std::getenv("MPC_X1_DEFER"); if (ev) h->x1_defer = std::atoi(ev); }
     { const char *ev = std::getenv("MPC_X1_LDS_CAP"); if (ev) h->x1_lds_cap = std::max(0, std::atoi(ev)); }
     { const char *ev = std::getenv("MPC_KKT_SPREAD"); if (ev) h->kkt_spread = std::atoi(ev); }
+    { const char *ev = std::getenv("MPC_X_FRESH_LIMIT"); if (ev) h->x_fresh_limit = std::atof(ev); }
     { const char *ev = std::getenv("MPC_HELPER_IT"); if (ev) h->helper_it = std::atoi(ev) == 1 ? 1 : 4; }
     { const char *ev = std::getenv("MPC_PRUNED_BUCKET_MIN"); if (ev) h->pruned_bucket_min = std::atof(ev); }
     { const char *ev = std::getenv("MPC_PRUNED_BUCKET_NP"); if (ev) h->pruned_bucket_np = std::atoll(ev); }
@@ -1655,6 +1657,7 @@ static int level_run_small(mpc_handle *h, int32_t gen_children, int32_t flags, m
     h->dict_stride_d = (long long)nxc * h->Pf.n_d0r;
     h->dict_stride_i = dict_ints(h->Pf.n_d0r, nxc, h->n_c);
     DictCache dc{};
+    dc.fresh_limit = h->x_fresh_limit;
     dc.stride_d = h->dict_stride_d; dc.stride_i = h->dict_stride_i;
     if (h->have_prev_dict && h->have_parent_slot) {
         dc.parent_slot = h->parent_slot.as<int32_t>();
@@ -1901,6 +1904,7 @@ static int batch_prepare(mpc_handle *h, int32_t gen_children, int32_t flags, Bat
     h->dict_stride_d = (long long)nxc * h->Pf.n_d0r;
     h->dict_stride_i = dict_ints(h->Pf.n_d0r, nxc, h->n_c);
     DictCache dc{};
+    dc.fresh_limit = h->x_fresh_limit;
     dc.stride_d = h->dict_stride_d; dc.stride_i = h->dict_stride_i;
     if (h->have_prev_dict && h->have_parent_slot) {
         dc.parent_slot = h->parent_slot.as<int32_t>();
@@ -2671,6 +2675,8 @@ static int level_run_impl(mpc_handle *h, int32_t gen_children, int32_t flags, mp
             h->dict_stride_d = (long long)nxc * h->Pf.n_d0r;   // column-major tableau
             h->dict_stride_i = dict_ints(h->Pf.n_d0r, nxc, h->n_c);
             DictCache dc{};
+            dc.fresh_limit = h->x_fresh_limit;
+    dc.fresh_limit = h->x_fresh_limit;
             dc.stride_d = h->dict_stride_d; dc.stride_i = h->dict_stride_i;
             if (h->have_prev_dict && h->have_parent_slot) {
                 dc.parent_slot = h->parent_slot.as<int32_t>();

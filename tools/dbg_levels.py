@@ -20,3 +20,5 @@ for p in prof:
         print('k %2d n %7d wall %7.3f | kkt %6.3f theta %6.3f (items %d) x %6.3f xq %6.3f xqt %6.3f (%d of %d) x1 %6.3f region2 %6.3f (opt %d, side %d) | verdict %6.3f region %6.3f children %6.3f | status %s' % (
             p['k'], p['candidates'], p['ms_wall'], p['ms_kkt'], p['ms_theta'], p['n_theta_items'], p['ms_x'], p['ms_xq'], p['ms_xq_thread'], p['n_xq_thread'], p['n_xq_items'], p['ms_x1'], p['ms_region2'], p['n_opt'], p['region_side_stream'],
             p['ms_verdict'], p['ms_region'], p['ms_children'], p['status']))
+        print('      x items %d, x1 %d, (x,theta) LPs %d, fallbacks to the LDS engine %d, pivots %d (quick test %d), dictionary bytes read %.2e written %.2e' % (
+            p['n_x_items'], p['n_x1'], p['xtheta_lps'], p['xtheta_fallbacks'], p['lp_pivots'], p['xq_pivots'], p['dict_read_bytes'], p['dict_write_bytes']))
