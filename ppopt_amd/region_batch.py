@@ -180,12 +180,35 @@ def materialize_regions(regions) -> None:
     """Touches every field of many regions at once: the regions of one RegionBatch are cut out of its three arrays with a handful
     of array-wide operations (one reshape per matrix field, one ``tolist`` per index field) instead of ten small slices per
     region.  Regions that are ordinary ``CriticalRegion`` objects are left as they are."""
-    groups = {}
-    for r in regions:
-        if isinstance(r, BatchCriticalRegion):
-            groups.setdefault(id(r._batch), (r._batch, []))[1].append(r)
     with gc_paused():      # 10^5 small lists and views that are not garbage: the cycle collector would walk them again and again
-        _materialize_groups(groups)
+        _materialize_groups(_group_by_batch(regions))
+
+
+def _group_by_batch(regions):
+    """{id(batch): (batch, [regions])}.  A solution's list is runs of regions of the same batch (a level, or a chunk of one): the runs are
+    found with one array comparison instead of a dictionary operation per region."""
+    import operator
+    regions = regions if isinstance(regions, list) else list(regions)
+    groups = {}
+    try:
+        batches = list(map(operator.attrgetter('_batch'), regions))
+    except AttributeError:      # ordinary CriticalRegion objects among them: the general way
+        for r in regions:
+            if isinstance(r, BatchCriticalRegion):
+                groups.setdefault(id(r._batch), (r._batch, []))[1].append(r)
+        return groups
+    n = len(batches)
+    if n == 0:
+        return groups
+    ids = numpy.fromiter(map(id, batches), dtype=numpy.int64, count=n)
+    cuts = [0] + (numpy.flatnonzero(ids[1:] != ids[:-1]) + 1).tolist() + [n]
+    for a, b in zip(cuts[:-1], cuts[1:]):
+        g = groups.get(int(ids[a]))
+        if g is None:
+            groups[int(ids[a])] = (batches[a], regions[a:b])
+        else:
+            g[1].extend(regions[a:b])
+    return groups
 
 
 def _materialize_groups(groups) -> None:
@@ -208,19 +231,24 @@ def _materialize_groups(groups) -> None:
         d = list(hd[:, B.od:B.od + B.k].reshape(-1, B.k, 1))
         lo = hi[:, 6].tolist()
         up = (hi[:, 6] + hi[:, 2]).tolist()
-        n_om, n_la, n_re = hi[:, 3].tolist(), hi[:, 4].tolist(), hi[:, 5].tolist()
+        n_om, n_la = hi[:, 3].tolist(), hi[:, 4].tolist()
         act = hi[:, B.iact:B.iact + B.k].tolist()
         # (only as many columns as the longest list of the batch: the padded widths are n_tc, k and n_c - k)
         w_om, w_la, w_re = (int(hi[:, c].max()) for c in (3, 4, 5))
         om = hi[:, B.iom:B.iom + w_om].tolist()
         la = hi[:, B.ila:B.ila + w_la].tolist()
-        ri = hi[:, B.iri:B.iri + w_re].tolist()
-        rc = hi[:, B.irc:B.irc + w_re].tolist()
+        # the two lists of the regular set are long rows with short contents (n_c - k columns, a region's own rows in use): only the entries
+        # in use become Python integers -- one flat list per field, cut by the running offsets
+        used = numpy.arange(w_re, dtype=numpy.int32)[None, :] < hi[:, 5:6]
+        ri_flat = hi[:, B.iri:B.iri + w_re][used].tolist()
+        rc_flat = hi[:, B.irc:B.irc + w_re][used].tolist()
+        r1 = numpy.cumsum(hi[:, 5], dtype=numpy.int64).tolist()
+        r0 = [0] + r1[:-1]
         erE, erf = B.er[:, 1:], B.er[:, :1]
         # (one zip over the columns: no index operations inside the loop; a region nobody has read yet gets the dictionary itself)
-        for r, Ai, bi, Ci, di, o0, o1, acti, omi, lai, rii, rci, n1, n2, m in zip(regs, A, b, C, d, lo, up, act, om, la, ri, rc, n_om, n_la, n_re):
+        for r, Ai, bi, Ci, di, o0, o1, acti, omi, lai, q0, q1, n1, n2 in zip(regs, A, b, C, d, lo, up, act, om, la, r0, r1, n_om, n_la):
             fields = {'A': Ai, 'b': bi, 'C': Ci, 'd': di, 'E': erE[o0:o1], 'f': erf[o0:o1], 'active_set': acti,
-                      'omega_set': omi[:n1], 'lambda_set': lai[:n2], 'regular_set': [rii[:m], rci[:m]]}
+                      'omega_set': omi[:n1], 'lambda_set': lai[:n2], 'regular_set': [ri_flat[q0:q1], rc_flat[q0:q1]]}
             dd = r.__dict__
             if dd:      # fields that were read (or assigned) before keep their values
                 fields.update(dd)
