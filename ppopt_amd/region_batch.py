@@ -94,6 +94,10 @@ class _Lazy:
         return d[self.key]
 
 
+_FIELD_NAMES = ('A', 'b', 'C', 'd', 'E', 'f', 'active_set', 'omega_set', 'lambda_set', 'regular_set')
+_FIELDS = frozenset(_FIELD_NAMES)
+
+
 class BatchCriticalRegion(CriticalRegion):
     """A CriticalRegion backed by row ``j`` of a RegionBatch (same fields, same index conventions)."""
     # the two references live in slots: the instance dictionary (inherited from the dataclass) is only created when a field is
@@ -171,8 +175,9 @@ class BatchCriticalRegion(CriticalRegion):
 
     def materialize(self) -> 'BatchCriticalRegion':
         """Touches every field (so that nothing refers to the batch lazily any more)."""
-        for name in ('A', 'b', 'C', 'd', 'E', 'f', 'active_set', 'omega_set', 'lambda_set', 'regular_set'):
-            getattr(self, name)
+        if not self.__dict__.keys() >= _FIELDS:      # (after Solution.materialize every field is there already: one set comparison)
+            for name in _FIELD_NAMES:
+                getattr(self, name)
         return self
 
 
