@@ -82,6 +82,7 @@ struct LevelCounters {
     // optimal (q_tail; the entries live in the level's opt_list, -1 until written), region wavefronts claim positions (work_r2 is the
     // head); q_closed is raised by a one-thread launch behind the theta kernel: the tail is final.
     unsigned int q_tail, q_closed, q_fault, q_early;   // q_fault: a claimed entry never arrived (never observed); q_early: regions built by the early launch
+    unsigned int x_second, pad_x2;   // k_x2 (round 6): doubtful cached runs repeated from D0 inside the kernel (DictCache::second_max)
 };
 
 struct Smem {

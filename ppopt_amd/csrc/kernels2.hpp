@@ -638,6 +638,7 @@ struct DictCache {
     // accumulated before them -- and its DECISION stands up to this growth (GROWTH_FRESH, the theta LP's rule; 0: GROWTH_SAFE as for a cached
     // run).  Its dictionary is still only stored below GROWTH_SAFE: what the children inherit keeps the strict bound.
     double fresh_limit;
+    int second_max;  // k_x2: repeats from D0 of doubtful cached runs the level may spend (0: none; the kernel's comment)
 };
 // k_xq: the last level's quick (x,theta) test.  No dictionary is stored on the last level, so a candidate only needs a
 // DECISION: up to XQ_ITERS simplex iterations from the parent's dictionary in product form (revised simplex with an eta
@@ -1262,15 +1263,22 @@ MPC_GLOBAL void MPC_LB(64, (NXC * SLOTS >= 64 ? 2 : (NXC * SLOTS >= 32 ? X2_WAVE
       for (int u = 0; u < cnt; ++u) {
         const bool dict_only = all_dict_only || (int)w0 + u < n_pre;
         const int c = __builtin_amdgcn_readlane(my_c, u);
-        const int ps = __builtin_amdgcn_readlane(my_ps, u);
+        int ps = __builtin_amdgcn_readlane(my_ps, u);
         const int32_t *as = cands + (size_t)c * k;
         const bool singular = __builtin_amdgcn_readlane(my_st, u) == ST_NEEDX_SING;
         bool retry = false;
         int st = -1;
         const long long t2 = clock64();
+        // Round 6: a run from a cached record that turns out doubtful (the growth it inherited or met) is repeated HERE from the program's own
+        // dictionary -- k drives from D0, nothing inherited -- while the level's budget of such repeats lasts (DictCache::second_max, counted in
+        // LevelCounters::x_second); only what is doubtful again goes to the LDS engine.  A handful of doubtful candidates used to cost a level
+        // a launch of the LDS engine that lasts as long as its longest LP (config 3's last level: 217 candidates, 0.62 ms) plus the repeated
+        // end of the level; a level with 10^5 of them keeps the LDS engine (its throughput on them is the better one).
+        for (int attempt = 0;; ++attempt) {
+            retry = false; st = -1;
         {
             // the next item's dictionary is pulled towards the L2 while this one is solved (one 128-byte line per lane)
-            if (u + 1 < cnt) {
+            if (attempt == 0 && u + 1 < cnt) {
                 const int psn = __builtin_amdgcn_readlane(my_ps, u + 1);
                 if (psn >= 0) {
                     const int32_t *nx = reinterpret_cast<const int32_t *>(dc.prev_d + (size_t)psn * dc.stride_d);
@@ -1381,6 +1389,12 @@ MPC_GLOBAL void MPC_LB(64, (NXC * SLOTS >= 64 ? 2 : (NXC * SLOTS >= 32 ? X2_WAVE
                 else if (r == LP_ITERLIMIT) st = ST_LP_LIMIT;
                 else st = ST_INFEASIBLE;
             }
+        }
+            if (!(retry && ps >= 0 && attempt == 0 && dc.second_max > 0)) break;
+            unsigned int taken = 0;
+            if (lane == 0) taken = atomicAdd(&ctr->x_second, 1u);
+            if ((unsigned)__builtin_amdgcn_readfirstlane((int)taken) >= (unsigned)dc.second_max) break;
+            ps = -1;
         }
         cyc_x += clock64() - t2;
         if (retry) { st = ST_RETRY; n_retry++; }

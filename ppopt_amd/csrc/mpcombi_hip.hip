@@ -284,7 +284,9 @@ struct mpc_handle {
     bool x1_pending = false;
     int x1_defer = 1;
     int x1_lds_cap = 0;
+    int x_second_max = 1024;     // k_x2: a level's budget of doubtful cached runs repeated from D0 in the kernel (MPC_X_SECOND_MAX; 0: all go to the LDS engine)
     double x_fresh_limit = 1e6;   // k_x2: growth up to which a run from D0 decides (DictCache::fresh_limit; MPC_X_FRESH_LIMIT=0: GROWTH_SAFE)
+    int kkt_spread_threads = 1 << 19;   // classic path: the spread form while candidates x KKT_SPREAD stays below this (MPC_KKT_SPREAD_THREADS)
     int kkt_spread = 1;         // small levels: k_kkt_thread with KKT_SPREAD lanes per candidate (MPC_KKT_SPREAD=0: one lane)
     int helper_it = 4;          // scan / partition helpers: 4 = four-wavefront workgroups of 4 items per thread, 1 = 1024-thread workgroups (MPC_HELPER_IT)
     // Round 6: the pruned list bucketed by smallest non-equality member (kernels.hpp, k_children_count_b), rebuilt at the start of every level
@@ -654,7 +656,9 @@ static int create_fill(const mpc_problem *p, int32_t device, void *stream, mpc_h
     { const char *ev = std::getenv("MPC_X1_DEFER"); if (ev) h->x1_defer = std::atoi(ev); }
     { const char *ev = std::getenv("MPC_X1_LDS_CAP"); if (ev) h->x1_lds_cap = std::max(0, std::atoi(ev)); }
     { const char *ev = std::getenv("MPC_KKT_SPREAD"); if (ev) h->kkt_spread = std::atoi(ev); }
+    { const char *ev = std::getenv("MPC_KKT_SPREAD_THREADS"); if (ev) h->kkt_spread_threads = std::max(0, std::atoi(ev)); }
     { const char *ev = std::getenv("MPC_X_FRESH_LIMIT"); if (ev) h->x_fresh_limit = std::atof(ev); }
+    { const char *ev = std::getenv("MPC_X_SECOND_MAX"); if (ev) h->x_second_max = std::max(0, std::atoi(ev)); }
     { const char *ev = std::getenv("MPC_HELPER_IT"); if (ev) h->helper_it = std::atoi(ev) == 1 ? 1 : 4; }
     { const char *ev = std::getenv("MPC_PRUNED_BUCKET_MIN"); if (ev) h->pruned_bucket_min = std::atof(ev); }
     { const char *ev = std::getenv("MPC_PRUNED_BUCKET_NP"); if (ev) h->pruned_bucket_np = std::atoll(ev); }
@@ -1657,7 +1661,7 @@ static int level_run_small(mpc_handle *h, int32_t gen_children, int32_t flags, m
     h->dict_stride_d = (long long)nxc * h->Pf.n_d0r;
     h->dict_stride_i = dict_ints(h->Pf.n_d0r, nxc, h->n_c);
     DictCache dc{};
-    dc.fresh_limit = h->x_fresh_limit;
+    dc.fresh_limit = h->x_fresh_limit; dc.second_max = h->x_second_max;
     dc.stride_d = h->dict_stride_d; dc.stride_i = h->dict_stride_i;
     if (h->have_prev_dict && h->have_parent_slot) {
         dc.parent_slot = h->parent_slot.as<int32_t>();
@@ -1904,7 +1908,7 @@ static int batch_prepare(mpc_handle *h, int32_t gen_children, int32_t flags, Bat
     h->dict_stride_d = (long long)nxc * h->Pf.n_d0r;
     h->dict_stride_i = dict_ints(h->Pf.n_d0r, nxc, h->n_c);
     DictCache dc{};
-    dc.fresh_limit = h->x_fresh_limit;
+    dc.fresh_limit = h->x_fresh_limit; dc.second_max = h->x_second_max;
     dc.stride_d = h->dict_stride_d; dc.stride_i = h->dict_stride_i;
     if (h->have_prev_dict && h->have_parent_slot) {
         dc.parent_slot = h->parent_slot.as<int32_t>();
@@ -2525,7 +2529,9 @@ static int level_run_impl(mpc_handle *h, int32_t gen_children, int32_t flags, mp
                 HIP_TRY(h, h->kkt_code.ensure(nn, st));
                 HIP_TRY(h, h->kkt_L.ensure(nn * (size_t)k * (h->n_t + 1) * sizeof(double), st));
                 kkc = h->kkt_code.as<uint8_t>(); kkl = h->kkt_L.as<double>();
-                const dim3 g((unsigned)blocks256), b(256);
+                // (round 6) KKT_SPREAD lanes per candidate while that still leaves the level short of the chip's thread slots (k_kkt_thread's comment)
+                const bool spread = h->kkt_spread > 0 && kd <= KKT_SPREAD_KMAX && n * KKT_SPREAD <= (long long)h->kkt_spread_threads;
+                const dim3 g((unsigned)(spread ? (n * KKT_SPREAD + 255) / 256 : blocks256)), b(256);
                 ThetaArgs ta = h->targs;
                 // (round 5) a lean level lets the kernel list its own output: the theta stage's work list and the candidates its box
                 // screen sends to the (x,theta) question -- two compactions of five launches each saved on the level's critical path
@@ -2537,11 +2543,15 @@ static int level_run_impl(mpc_handle *h, int32_t gen_children, int32_t flags, mp
                     ta.kx_list = h->xq_list.as<int32_t>(); ta.kx_n = dcnt + 10;
                 }
                 if (h->timing) HIP_TRY(h, hipEventRecord(h->kev[6], st));
-#define MPC_LAUNCH_KKT(K_) case K_: if (h->fast_t >= 4) hipLaunchKernelGGL((k_kkt_thread<K_, 10>), g, b, 0, st, pf, fr, n, h->kkt_code.as<uint8_t>(), h->kkt_L.as<double>(), stp, ta, ctr); \
-                                    else if (h->fast_t >= 2) hipLaunchKernelGGL((k_kkt_thread<K_, 8>), g, b, 0, st, pf, fr, n, h->kkt_code.as<uint8_t>(), h->kkt_L.as<double>(), stp, ta, ctr); \
-                                    else hipLaunchKernelGGL((k_kkt_thread<K_, 4>), g, b, 0, st, pf, fr, n, h->kkt_code.as<uint8_t>(), h->kkt_L.as<double>(), stp, ta, ctr); break
-                switch (kd) { MPC_LAUNCH_KKT(1); MPC_LAUNCH_KKT(2); MPC_LAUNCH_KKT(3); MPC_LAUNCH_KKT(4); MPC_LAUNCH_KKT(5); MPC_LAUNCH_KKT(6); MPC_LAUNCH_KKT(7); MPC_LAUNCH_KKT(8); MPC_LAUNCH_KKT(9); MPC_LAUNCH_KKT(10); }
+#define MPC_LAUNCH_KKT_(K_, SP_) if (h->fast_t >= 4) hipLaunchKernelGGL((k_kkt_thread<K_, 10, SP_>), g, b, 0, st, pf, fr, n, h->kkt_code.as<uint8_t>(), h->kkt_L.as<double>(), stp, ta, ctr); \
+                                    else if (h->fast_t >= 2) hipLaunchKernelGGL((k_kkt_thread<K_, 8, SP_>), g, b, 0, st, pf, fr, n, h->kkt_code.as<uint8_t>(), h->kkt_L.as<double>(), stp, ta, ctr); \
+                                    else hipLaunchKernelGGL((k_kkt_thread<K_, 4, SP_>), g, b, 0, st, pf, fr, n, h->kkt_code.as<uint8_t>(), h->kkt_L.as<double>(), stp, ta, ctr)
+#define MPC_LAUNCH_KKT(K_) case K_: MPC_LAUNCH_KKT_(K_, 1); break
+#define MPC_LAUNCH_KKT_S(K_) case K_: if (spread) { MPC_LAUNCH_KKT_(K_, KKT_SPREAD); } else { MPC_LAUNCH_KKT_(K_, 1); } break
+                switch (kd) { MPC_LAUNCH_KKT_S(1); MPC_LAUNCH_KKT_S(2); MPC_LAUNCH_KKT_S(3); MPC_LAUNCH_KKT_S(4); MPC_LAUNCH_KKT_S(5); MPC_LAUNCH_KKT_S(6); MPC_LAUNCH_KKT(7); MPC_LAUNCH_KKT(8); MPC_LAUNCH_KKT(9); MPC_LAUNCH_KKT(10); }
+#undef MPC_LAUNCH_KKT_S
 #undef MPC_LAUNCH_KKT
+#undef MPC_LAUNCH_KKT_
                 if (h->timing) HIP_TRY(h, hipEventRecord(h->kev[7], st));
                 kernel_timed[3] = true;
                 HIP_TRY(h, hipGetLastError());
@@ -2675,8 +2685,8 @@ static int level_run_impl(mpc_handle *h, int32_t gen_children, int32_t flags, mp
             h->dict_stride_d = (long long)nxc * h->Pf.n_d0r;   // column-major tableau
             h->dict_stride_i = dict_ints(h->Pf.n_d0r, nxc, h->n_c);
             DictCache dc{};
-            dc.fresh_limit = h->x_fresh_limit;
-    dc.fresh_limit = h->x_fresh_limit;
+            dc.fresh_limit = h->x_fresh_limit; dc.second_max = h->x_second_max;
+    dc.fresh_limit = h->x_fresh_limit; dc.second_max = h->x_second_max;
             dc.stride_d = h->dict_stride_d; dc.stride_i = h->dict_stride_i;
             if (h->have_prev_dict && h->have_parent_slot) {
                 dc.parent_slot = h->parent_slot.as<int32_t>();

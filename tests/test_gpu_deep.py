@@ -845,3 +845,31 @@ def test_small_level_kkt_lanes_and_helper_workgroups_change_nothing(monkeypatch)
             assert list(r1.active_set) == list(r2.active_set)
             for fld in ('A', 'b', 'C', 'd', 'E', 'f'):
                 assert numpy.asarray(getattr(r1, fld)).tobytes() == numpy.asarray(getattr(r2, fld)).tobytes(), (wl, fld)
+
+
+def test_doubtful_cached_runs_repeated_inside_the_kernel_give_the_lds_engines_verdicts(monkeypatch):
+    """Round 6: k_x2 repeats a doubtful run from a cached record at once from the program's own dictionary (MPC_X_SECOND_MAX repeats per
+    level; a fresh run decides up to growth MPC_X_FRESH_LIMIT) instead of leaving it to the LDS engine behind the level.  Config 3 -- the
+    configuration with such candidates, 217 on its last level -- and a random program: every level's statuses and children with the
+    repeats and the fresh-run rule switched off (everything doubtful goes to the LDS engine, rounds 2-5) and on."""
+    from test_gpu_parity import engine_from_golden
+    for name, n_levels in (('c3_quadtank_n10', 4), ('c4_rand_20_8_20_s0', 4), ('big_24_7_34_s430912', 3)):
+        g = load_golden(name)
+        runs = []
+        for second, fresh in (('1024', '1e6'), ('0', '0')):
+            monkeypatch.setenv('MPC_X_SECOND_MAX', second)
+            monkeypatch.setenv('MPC_X_FRESH_LIMIT', fresh)
+            eng = engine_from_golden(g)
+            eng.pruned_clear(); eng.frontier_root()
+            fr = []
+            for depth in range(n_levels):
+                st = eng.level_run(True)
+                fr.append((eng.level_children().copy(), eng.level_status().copy(), st.n_regions))
+                if st.n_children == 0:
+                    break
+                eng.frontier_advance()
+            eng.close()
+            runs.append(fr)
+        assert len(runs[0]) == len(runs[1]) >= 2
+        for (c1, s1, r1), (c2, s2, r2) in zip(*runs):
+            assert numpy.array_equal(s1, s2) and numpy.array_equal(c1, c2) and r1 == r2, name
