@@ -285,7 +285,8 @@ hipError_t batch_level_launch(BatchMember *members, int B, hipStream_t st, Batch
         const unsigned blocks256 = (unsigned)((n_max + 255) / 256);
         // KKT solves + box screen, theta stage
         if (r.use_kkt) {
-            const bool spread = r.use_kkt == 2;     // BATCH_KKT_SPREAD lanes per candidate (k_kkt_thread's comment)
+            // BATCH_KKT_SPREAD lanes per candidate (k_kkt_thread's comment) while the group's launch stays short of the chip's thread slots
+            const bool spread = r.use_kkt == 2 && (long long)n_max * G * BATCH_KKT_SPREAD <= BATCH_KKT_SPREAD_THREADS;
             const dim3 g(spread ? (unsigned)((n_max * BATCH_KKT_SPREAD + 255) / 256) : blocks256, G), b(256);
 #define MPC_LAUNCH_KKT_(K_, SP_) if (r.fast_t >= 4) hipLaunchKernelGGL((m_kkt_thread<K_, 10, SP_>), g, b, 0, st, tab); \
                                     else if (r.fast_t >= 2) hipLaunchKernelGGL((m_kkt_thread<K_, 8, SP_>), g, b, 0, st, tab); \

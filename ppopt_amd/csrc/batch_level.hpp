@@ -41,7 +41,7 @@
 namespace mpc {
 
 // use_kkt == 2: k_kkt_thread with this many lanes per candidate (levels of a batch are small by construction), up to KMAX inequality rows
-constexpr int BATCH_KKT_SPREAD = 8, BATCH_KKT_SPREAD_KMAX = 6;
+constexpr int BATCH_KKT_SPREAD = 8, BATCH_KKT_SPREAD_KMAX = 6, BATCH_KKT_SPREAD_THREADS = 1 << 19;
 
 struct BatchZero { void *p; unsigned long long bytes; };
 
