@@ -638,6 +638,7 @@ struct DictCache {
     // accumulated before them -- and its DECISION stands up to this growth (GROWTH_FRESH, the theta LP's rule; 0: GROWTH_SAFE as for a cached
     // run).  Its dictionary is still only stored below GROWTH_SAFE: what the children inherit keeps the strict bound.
     double fresh_limit;
+    int skip_below;  // k_xq with a device-resident list length: a list shorter than this is left to k_x2 (the kernel's comment)
     int second_max;  // k_x2: repeats from D0 of doubtful cached runs the level may spend (0: none; the kernel's comment)
 };
 // k_xq: the last level's quick (x,theta) test.  No dictionary is stored on the last level, so a candidate only needs a
@@ -818,6 +819,11 @@ MPC_GLOBAL void MPC_LB(64, XQ_WAVES) k_xq(const DevProblem *__restrict__ Pg, con
     const int lane = lane_id(), nv = P.n_x + P.n_t, mr = P.n_d0r;
     if (dc.n_list_dev) {
         n_list = *dc.n_list_dev;
+        // Round 6: a SHORT list is left to k_x2 as it is.  What the one-thread pass leaves over are the candidates that need several
+        // iterations, and here every iteration is a chain of dependent reads of the parent's record (sixteen of them: 0.37 ms for config 4's
+        // 2.7 k candidates, the launch lasts as long as its longest item) -- k_x2 loads the record once and pivots in registers.  The product
+        // form pays when the list is long enough for its smaller traffic to matter.
+        if (n_list < dc.skip_below) return;
         const long long active = dc.max_blocks > 0 ? min((long long)gridDim.x, (long long)dc.max_blocks) : (long long)gridDim.x;
         if (dc.chunk <= 0) dc.chunk = (int)max(1ll, min(16ll, (long long)n_list / (active * 4)));
         if ((long long)blockIdx.x >= active || (long long)blockIdx.x * dc.chunk >= n_list) return;

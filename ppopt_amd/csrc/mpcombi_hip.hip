@@ -282,8 +282,10 @@ struct mpc_handle {
     // does waits for ev_x1done (x1_join).  MPC_X1_DEFER=0: in line, as round 5.  Not when a profile asks for per-kernel event times.
     hipEvent_t ev_x1go = nullptr, ev_x1done = nullptr;
     bool x1_pending = false;
-    int x1_defer = 1;
+    std::function<int()> x1_stash;   // x1_defer >= 2: the deferred k_x1 launch, issued by x1_flush behind the level's last kernels
+    int x1_defer = 1;           // 1: k_x1 on its own stream from the plan pass on; 2: issued behind the level's last kernels (measured: the children stage gets its 0.26 ms back, the next level's KKT kernel loses 0.40 beside k_x1 -- its W gathers live in the L2 that k_x1 streams through: config 4 3.89 -> 3.95 ms, config 3 4.17 -> 4.27); 0: in line
     int x1_lds_cap = 0;
+    int xq_skip_below = 100000;  // the last level's product-form quick test leaves a list shorter than this to k_x2 when a tableau row is one lane's (MPC_XQ_SKIP_BELOW; 0: never).  Measured: config 3 (62 k left over) 4.26 -> 4.18 ms, config 4 (2.7 k) unchanged -- its last level ends with the region kernel
     int x_second_max = 1024;     // k_x2: a level's budget of doubtful cached runs repeated from D0 in the kernel (MPC_X_SECOND_MAX; 0: all go to the LDS engine)
     double x_fresh_limit = 1e6;   // k_x2: growth up to which a run from D0 decides (DictCache::fresh_limit; MPC_X_FRESH_LIMIT=0: GROWTH_SAFE)
     int kkt_spread_threads = 1 << 19;   // classic path: the spread form while candidates x KKT_SPREAD stays below this (MPC_KKT_SPREAD_THREADS)
@@ -659,6 +661,7 @@ static int create_fill(const mpc_problem *p, int32_t device, void *stream, mpc_h
     { const char *ev = std::getenv("MPC_KKT_SPREAD_THREADS"); if (ev) h->kkt_spread_threads = std::max(0, std::atoi(ev)); }
     { const char *ev = std::getenv("MPC_X_FRESH_LIMIT"); if (ev) h->x_fresh_limit = std::atof(ev); }
     { const char *ev = std::getenv("MPC_X_SECOND_MAX"); if (ev) h->x_second_max = std::max(0, std::atoi(ev)); }
+    { const char *ev = std::getenv("MPC_XQ_SKIP_BELOW"); if (ev) h->xq_skip_below = std::max(0, std::atoi(ev)); }
     { const char *ev = std::getenv("MPC_HELPER_IT"); if (ev) h->helper_it = std::atoi(ev) == 1 ? 1 : 4; }
     { const char *ev = std::getenv("MPC_PRUNED_BUCKET_MIN"); if (ev) h->pruned_bucket_min = std::atof(ev); }
     { const char *ev = std::getenv("MPC_PRUNED_BUCKET_NP"); if (ev) h->pruned_bucket_np = std::atoll(ev); }
@@ -1192,7 +1195,7 @@ int mpc_trim(mpc_handle *h) {
     if (h->stream2) HIP_TRY(h, hipStreamSynchronize(h->stream2));
     if (h->stream3) HIP_TRY(h, hipStreamSynchronize(h->stream3));
     if (h->stream4) HIP_TRY(h, hipStreamSynchronize(h->stream4));
-    h->x1_pending = false;
+    h->x1_pending = false; h->x1_stash = nullptr;
     graveyard_flush(h);
     stream_release(h);
     for (DevBuf *b : {&h->frontier, &h->children, &h->status, &h->pruned, &h->flag, &h->pos, &h->opt_list, &h->childmask, &h->count, &h->offset, &h->recd, &h->reci,
@@ -1467,7 +1470,17 @@ static void stream_release(mpc_handle *h) {   // blocks of a streamed level nobo
 constexpr int KKT_THREAD_MAX = 10;
 constexpr int KKT_SPREAD = BATCH_KKT_SPREAD, KKT_SPREAD_KMAX = BATCH_KKT_SPREAD_KMAX;   // small levels: lanes per candidate of k_kkt_thread, up to this many inequality rows
 // every stream of the handle that may read or write dictionary records waits for the deferred k_x1 of the previous level (stream waits: the host does not block)
+// issues a stashed k_x1 launch (MPC_X1_DEFER=2: behind the level's children stage, so that it runs beside the NEXT level's KKT kernel -- issue
+// bound, no traffic -- instead of beside the children stage, which like k_x1 is bound by the memory system: config 4's k_children_count_b
+// took 0.34 ms beside it, 0.08 alone)
+static int x1_flush(mpc_handle *h) {
+    if (!h->x1_stash) return MPC_OK;
+    std::function<int()> f;
+    f.swap(h->x1_stash);
+    return f();
+}
 static int x1_join(mpc_handle *h) {
+    { int rcf = x1_flush(h); if (rcf) return rcf; }
     if (!h->x1_pending) return MPC_OK;
     for (hipStream_t sx : {h->stream, h->stream2, h->stream3}) if (sx) HIP_TRY(h, hipStreamWaitEvent(sx, h->ev_x1done, 0));
     h->x1_pending = false;
@@ -1934,7 +1947,7 @@ static int batch_prepare(mpc_handle *h, int32_t gen_children, int32_t flags, Bat
     // frontier, which sits in the children buffer -- only while that buffer is not about to be re-allocated for this level's children
     m.plan = 0; m.x1_buf = nullptr; m.alt = XqAlt{}; m.plan_blocks = m.x1_blocks = 0;
     if (h->storing && dc.parent_slot && h->x1 > 0 && !h->no_batch_plans && n >= h->batch_plan_min && n <= 0x7fffffffLL / 8) {
-        HIP_TRY(h, h->x1_buf.ensure(6 * nn * sizeof(int32_t), st));
+        HIP_TRY(h, h->x1_buf.ensure((6 * nn + 16) * sizeof(int32_t), st));
         m.x1_buf = h->x1_buf.as<int32_t>();
         m.plan = 1;
         const size_t child_bytes = gen_children ? nn * (size_t)std::max(h->n_c - k, 1) * (k + 1) * sizeof(int32_t) : 0;
@@ -2504,6 +2517,7 @@ static int level_run_impl(mpc_handle *h, int32_t gen_children, int32_t flags, mp
             hipLaunchKernelGGL(k_publish_words2, dim3(1), dim3(128), 0, st, reinterpret_cast<const unsigned int *>(ctr), (int)(sizeof(LevelCounters) / 4),
                                reinterpret_cast<const unsigned int *>(dcnt), 32, reinterpret_cast<unsigned int *>(h->tot_dev + 16));
             HIP_TRY(h, hipGetLastError());
+            { int rcf = x1_flush(h); if (rcf) return rcf; }      // (MPC_X1_DEFER=2: k_x1 starts behind the level's last kernels)
             return MPC_OK;
         };
         // open parameter set: the candidates the verdict stage calls optimal are asked whether the reference's max-t LP is bounded (k_recession)
@@ -2716,7 +2730,7 @@ static int level_run_impl(mpc_handle *h, int32_t gen_children, int32_t flags, mp
                 // streams that record through the step -- no tableau in registers, no pricing, no ratio test --, and only what has no
                 // such plan goes through the register simplex k_x2 as before, from its generating parent.
                 { int rcq = prep_flush(); if (rcq) return rcq; }
-                HIP_TRY(h, h->x1_buf.ensure(6 * nn * sizeof(int32_t), st));
+                HIP_TRY(h, h->x1_buf.ensure((6 * nn + 16) * sizeof(int32_t), st));
                 int32_t *xb = h->x1_buf.as<int32_t>();
                 XqPlan pl{};
                 pl.plan_slot = xb; pl.plan_step = xb + nn; pl.x1_list = xb + 2 * nn; pl.x1_n = dcnt + 12;
@@ -2745,20 +2759,33 @@ static int level_run_impl(mpc_handle *h, int32_t gen_children, int32_t flags, mp
                 // "dictionary stored" for k_children_write.  The end of this level (k_x2 for the unplanned rest, children, counters), the
                 // hand-over and the next level's KKT kernel run beside it.
                 const bool defer = h->x1_defer > 0 && !h->timing && h->stream4;
+                const bool late = defer && h->x1_defer >= 2;      // issued by x1_flush behind the level's last kernels
                 hipStream_t sx1 = defer ? h->stream4 : st;
-                if (defer) { HIP_TRY(h, hipEventRecord(h->ev_x1go, st)); HIP_TRY(h, hipStreamWaitEvent(sx1, h->ev_x1go, 0)); }
+                if (defer && !late) { HIP_TRY(h, hipEventRecord(h->ev_x1go, st)); HIP_TRY(h, hipStreamWaitEvent(sx1, h->ev_x1go, 0)); }
                 if (h->timing) HIP_TRY(h, hipEventRecord(h->kev[12], st));
                 LevelCounters *ctr_x1 = defer ? (LevelCounters *)nullptr : ctr;   // (its pivot count would land in the next level's counters)
-                // A deferred k_x1 must leave every CU room for a 1024-thread workgroup: the partition / scan kernels of the level's end are
-                // such blocks, and beside persistent k_x1 wavefronts packed seven to a SIMD one of them waited 0.37 ms for a CU
-                // (`profiles/r06_c4_timeline.log`).  An (unused) LDS allocation of 1/x1_wpc of the CU's 160 KB caps the kernel at its launch width per CU.
                 // MPC_X1_LDS_CAP = c > 0: the deferred kernel asks for (144 KB / c) of LDS it never touches, which holds it to c wavefronts per compute unit
                 const unsigned lds_x1 = defer && h->x1_lds_cap > 0 ? (unsigned)((144 * 1024) / h->x1_lds_cap) & ~255u : 0u;
-                if (h->fast_x & 1) hipLaunchKernelGGL((k_x1<2>), dim3(g1), dim3(64), lds_x1, sx1, pfx, pl.x1_list, pl.x1_n, ctr_x1, dc, nxc, pl.plan_slot, pl.plan_step);
-                else hipLaunchKernelGGL((k_x1<1>), dim3(g1), dim3(64), lds_x1, sx1, pfx, pl.x1_list, pl.x1_n, ctr_x1, dc, nxc, pl.plan_slot, pl.plan_step);
+                const int32_t *x1_n_ptr = pl.x1_n;
+                if (late) {
+                    // the list's length lives among the level's counters, which the next level clears: the late launch reads a copy
+                    int32_t *keep = xb + 6 * nn;
+                    hipLaunchKernelGGL(k_publish_words, dim3(1), dim3(64), 0, st, reinterpret_cast<const unsigned int *>(pl.x1_n), reinterpret_cast<unsigned int *>(keep), 1);
+                    x1_n_ptr = keep;
+                }
+                const bool two = (h->fast_x & 1) != 0;
+                const int32_t *x1_list_p = pl.x1_list, *plan_slot_p = pl.plan_slot, *plan_step_p = pl.plan_step;
+                auto launch_x1 = [h, two, g1, lds_x1, sx1, pfx, x1_list_p, x1_n_ptr, ctr_x1, dc, nxc, plan_slot_p, plan_step_p, late, defer]() -> int {
+                    if (late) { HIP_TRY(h, hipEventRecord(h->ev_x1go, h->stream)); HIP_TRY(h, hipStreamWaitEvent(sx1, h->ev_x1go, 0)); }
+                    if (two) hipLaunchKernelGGL((k_x1<2>), dim3(g1), dim3(64), lds_x1, sx1, pfx, x1_list_p, x1_n_ptr, ctr_x1, dc, nxc, plan_slot_p, plan_step_p);
+                    else hipLaunchKernelGGL((k_x1<1>), dim3(g1), dim3(64), lds_x1, sx1, pfx, x1_list_p, x1_n_ptr, ctr_x1, dc, nxc, plan_slot_p, plan_step_p);
+                    HIP_TRY(h, hipGetLastError());
+                    if (defer) { HIP_TRY(h, hipEventRecord(h->ev_x1done, sx1)); h->x1_pending = true; }
+                    return MPC_OK;
+                };
+                if (late) h->x1_stash = launch_x1;
+                else { int rcx = launch_x1(); if (rcx) return rcx; }
                 if (h->timing) HIP_TRY(h, hipEventRecord(h->kev[13], st));
-                HIP_TRY(h, hipGetLastError());
-                if (defer) { HIP_TRY(h, hipEventRecord(h->ev_x1done, sx1)); h->x1_pending = true; }
                 // what is left: the register simplex, list lengths on the device
                 DictCache dr = dc;
                 dr.pre1 = pl.rest[0]; dr.n_pre1 = 0; dr.n_pre1_dev = pl.rest_n[0];
@@ -2958,7 +2985,7 @@ static int level_run_impl(mpc_handle *h, int32_t gen_children, int32_t flags, mp
                     xq_list = h->xq_list.as<int32_t>();
                 }
                 dq.chunk = (int)std::max<long long>(1, std::min<long long>(16, xq_n / (grid_q * 4)));
-                if (xqt_lean) { dq.n_list_dev = dcnt + 9; dq.chunk = 0; }   // length and chunk rule on the device
+                if (xqt_lean) { dq.n_list_dev = dcnt + 9; dq.chunk = 0; dq.skip_below = (h->fast_x & 1) ? 0 : h->xq_skip_below; }   // length and chunk rule on the device; a short list is left to k_x2
                 // doubtful pivots are flagged by the quick test itself and re-solved at once on the second stream (below), unless that stream
                 // is busy with the theta stage's own doubtful candidates (their statuses are still ST_RETRY in the status array)
                 const bool xq_flags_retry = h->xq_retry && n_early == 0 && lean;
@@ -2982,6 +3009,7 @@ static int level_run_impl(mpc_handle *h, int32_t gen_children, int32_t flags, mp
                     if (h->fast_x & 1) hipLaunchKernelGGL((k_xq_grouped<2>), gq, bq, lds_q, st, pf, fr, k, xq_list, xq_n, stp, ctr, dq, nxc, h->xq_groups.as<int32_t>(), h->scratch.as<int32_t>());
                     else hipLaunchKernelGGL((k_xq_grouped<1>), gq, bq, lds_q, st, pf, fr, k, xq_list, xq_n, stp, ctr, dq, nxc, h->xq_groups.as<int32_t>(), h->scratch.as<int32_t>());
                 } else if (xq_n == 0) { /* the first pass decided everything (host-known length) */ }
+                else if (!xqt_lean && !(h->fast_x & 1) && xq_n < h->xq_skip_below) { /* a short list (host-known length) is left to k_x2: k_xq's comment */ }
                 else if (h->fast_x & 1) hipLaunchKernelGGL((k_xq<2>), gg, bb, 0, st, pf, fr, k, xq_list, xq_n, stp, ctr, dq, nxc);
                 else hipLaunchKernelGGL((k_xq<1>), gg, bb, 0, st, pf, fr, k, xq_list, xq_n, stp, ctr, dq, nxc);
                 if (h->timing) HIP_TRY(h, hipEventRecord(h->kev[9], st));
