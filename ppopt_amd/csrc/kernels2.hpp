@@ -234,22 +234,16 @@ MPC_GLOBAL void MPC_LB(256) k_kkt_thread(const DevProblem *__restrict__ Pg, cons
             for (int t = 0; t < NT; ++t) g[t] = 0.0;
             mx = 0.0;
         }
-        double sc = 1.0;
-        if (mx > 0.0) {
-            int ex;
-            (void)frexp(mx, &ex);
-            sc = theta_row_scale(ex);
-            h *= sc;
-#pragma unroll
-            for (int t = 0; t < NT; ++t) g[t] *= sc;
-        }
+        // k_theta2 scales the row by a power of two sc (theta_row_scale) and tests smax_scaled < -10 TOL sc.  A power-of-two scale commutes
+        // with every rounding of the sum below, so the unscaled test is the same decision bit for bit -- without frexp / ldexp and NT + 2
+        // multiplications per row (round 6)
         double smax = h;
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
             const double term = g[t] > 0.0 ? g[t] * blo[t] : (g[t] < 0.0 ? g[t] * bhi[t] : 0.0);
             smax -= term;
         }
-        if (!active && smax < -10 * TOL_FEAS * sc) fired = true;   // the margin is meant in the row's own units
+        if (!active && smax < -10 * TOL_FEAS) fired = true;   // the margin is meant in the row's own units (scaled: both sides times sc)
       }
       if (__all(fired)) break;
     }
