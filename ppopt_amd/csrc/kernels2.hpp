@@ -54,6 +54,9 @@ struct ThetaArgs {
     // tail of few long LPs: measured on config 4 (round 4, MPC_TH_CAP) an item takes 29 us with one wavefront per SIMD, 48 us with two
     // and 130 us with four -- the launch was fastest with HALF (level 5: 15 k items) or a QUARTER (level 4: 5 k items) of its wave slots.
     int wave_div, wave_max;
+    // k_kkt_thread: every side of the parameter set's bounding box is finite (mpc_create): the box screen takes the largest value of a row
+    // over the box as h + sum_t max(a_t blo_t, a_t bhi_t) -- four instructions per parameter instead of nine, the same number bit for bit
+    int box_finite;
     // k_kkt_thread (round 5): when set, the kernel lists its own output -- the candidates it leaves to k_theta2 (status ST_TODO) in
     // kt_list / *kt_n, those its box screen sends to the (x,theta) question (ST_NEEDX) in kx_list / *kx_n -- with one atomic per workgroup
     // and list, instead of a five-launch compaction of the status array per list behind it.  The lists are index-ordered within
@@ -229,6 +232,16 @@ MPC_GLOBAL void MPC_LB(256) k_kkt_thread(const DevProblem *__restrict__ Pg, cons
         double h = acc[0], g[NT], mx = 0.0;
 #pragma unroll
         for (int t = 0; t < NT; ++t) { g[t] = -acc[1 + t]; mx = fmax(mx, fabs(g[t])); }
+        if (ta.box_finite) {
+            // (round 6) -g theta over the box is largest at blo where g > 0 and at bhi where g < 0: max(a blo, a bhi) with a = -g picks that
+            // product (rounded exactly as g blo / g bhi are, up to the sign); a row of all-zero coefficients keeps h alone
+            double sm = h;
+#pragma unroll
+            for (int t = 0; t < NT; ++t) sm += fmax(acc[1 + t] * blo[t], acc[1 + t] * bhi[t]);
+            const double smax = mx > ZERO_ROW_ATOL ? sm : h;
+            if (!active && smax < -10 * TOL_FEAS) fired = true;
+            continue;
+        }
         if (!(mx > ZERO_ROW_ATOL)) {
 #pragma unroll
             for (int t = 0; t < NT; ++t) g[t] = 0.0;
