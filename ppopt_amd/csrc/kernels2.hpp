@@ -88,6 +88,9 @@ struct ThetaArgs {
 //               infeasible -> status ST_NEEDX, the candidate never reaches k_theta2.
 //   output      code[c] in {0 ok, 2 singular, KK_UNDECIDED};  status[c] = ST_NEEDX (screened) or ST_TODO;
 //               Lout[c*K*nr + i*nr + t] = [b_l | A_l] for the candidates that go on to k_theta2
+#ifndef KKT_RU56
+#define KKT_RU56 1   // rows per trip of k_kkt_thread's box screen at five and six active rows (1: round 5)
+#endif
 constexpr int KK_UNDECIDED = 255;
 constexpr int KK_ILL = 64;        // solved, but the Schur system is ill-conditioned (CHOL_ILL_TOL, kkt.hpp)
 constexpr int ST_TODO = 10;       // internal: waiting for k_theta2
@@ -205,7 +208,7 @@ MPC_GLOBAL void MPC_LB(256) k_kkt_thread(const DevProblem *__restrict__ Pg, cons
     // tools/timeline.sh).  Same rows, same order, same arithmetic per row.
     // (no early exit inside a group of rows: a group is ONE basic block, so the scheduler can issue all its loads first; from five rows of
     // active set on the kernel is bound by registers and throughput -- config 4's level of 10^6 candidates -- and keeps one row per trip)
-    constexpr int RU = K <= 2 ? 8 : (K <= 4 ? 4 : 1);
+    constexpr int RU = K <= 2 ? 8 : (K <= 4 ? 4 : (K <= 6 ? KKT_RU56 : 1));
     for (int c0 = ne + sub * RU; c0 < nc; c0 += RU * SP) {
       double wpre[RU][K];
 #pragma unroll
