@@ -1060,7 +1060,7 @@ static int create_fill(const mpc_problem *p, int32_t device, void *stream, mpc_h
                 HIP_TRY(nullptr, hipMemcpyAsync(h->theta_blocks.p, tb.data(), tb.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
                 HIP_TRY(nullptr, hipStreamSynchronize(h->stream));
                 const double *tbd = h->theta_blocks.as<double>();
-                h->targs.box_finite = (box_done && !box_open) ? 1 : 0;
+                { const char *ev = std::getenv("MPC_KKT_BOX_SELECT"); h->targs.box_finite = (box_done && !box_open && !(ev && ev[0] == '1')) ? 1 : 0; }   // (=1: the select form of the screen's row test on every program; tests)
                 h->targs.W = P.W; h->targs.UVp = tbd + oUVp; h->targs.tvp = tbd + otvp; h->targs.tv_rows = tbd + otvr; h->targs.chunk = 1;
                 h->targs.ne = elim_ok ? ne : 0;
                 {   // MPC_TH_DIV (work items per wavefront of k_theta2, default 4; 0 = round-3 behaviour) / MPC_TH_MAXW (waves per SIMD, default 2)

@@ -809,8 +809,8 @@ def test_small_level_kkt_lanes_and_helper_workgroups_change_nothing(monkeypatch)
     import bench
     from ppopt_amd.mp_solvers import mpqp_hip_combinatorial
     from test_gpu_parity import engine_from_golden
-    new = {'MPC_KKT_SPREAD': '1', 'MPC_NO_KKT_LISTS': '0', 'MPC_HELPER_IT': '4'}
-    old = {'MPC_KKT_SPREAD': '0', 'MPC_NO_KKT_LISTS': '1', 'MPC_HELPER_IT': '1'}
+    new = {'MPC_KKT_SPREAD': '1', 'MPC_NO_KKT_LISTS': '0', 'MPC_HELPER_IT': '4', 'MPC_KKT_BOX_SELECT': '0'}
+    old = {'MPC_KKT_SPREAD': '0', 'MPC_NO_KKT_LISTS': '1', 'MPC_HELPER_IT': '1', 'MPC_KKT_BOX_SELECT': '1'}      # (the last: the screen's row test with selects instead of max(a blo, a bhi))
     for name, n_levels in (('c4_rand_20_8_20_s0', 4), ('c2_dblint_n5', 5), ('quadtank_n3', 5), ('c3_quadtank_n10', 3)):
         g = load_golden(name)
         runs = []
