@@ -226,11 +226,12 @@ def main():
     # pooled page-locked result arrays) reach their steady state before the timed region
     warm = [step([] if (args.events_in_value or i % 2) else None) for i in range(args.warmup)]
     del warm
-    # everything allocated so far (torch, the program, the engine) is long-lived: keep the cyclic collector from walking
-    # it again and again while the timed steps create their region objects
+    # Round 6: no gc.freeze() here any more (rounds 4-5 froze torch, the program and the engine so that the collector would not walk them
+    # during the timed steps): the process is a user's process.  The product's solve() holds the collector while it creates its region
+    # objects and hands them to the oldest generation without a walk (region_batch.gc_paused / _promote_young; MPC_KEEP_GC=1 and
+    # MPC_GC_PROMOTE=0 switch that off).
     import gc
     gc.collect()
-    gc.freeze()
 
     def fence():
         if distributed:
@@ -245,7 +246,7 @@ def main():
     # records cost 0.1-0.2 ms per solve (markers the queue stops at), which is why they are not in the first.  --events-in-value keeps
     # them in the first region as rounds 1-4 did.
     # Round 6: `value` / `ms_per_step` are timed with Python's cyclic collector ON, exactly as a user's
-    # `solve()` runs (the product's solve does not pause it: measured slower, mpqp_hip_combinatorial.solve_many's docstring).  A third
+    # `solve()` runs (the product's solve holds it while it creates its objects: that IS the product's behaviour, tested).  A third
     # region repeats the K steps with the collector off (round 5's headline protocol, `ms_per_step_collector_off`): a solve returns ~10^4
     # region objects, none in a reference cycle, and the young-generation passes over them cost ~0.1 ms per solve of config 4.
     def timed_region(with_profile, collector=True):
@@ -418,7 +419,7 @@ def main():
         'ms_per_step': 1e3 * elapsed / steps,
         'ms_per_step_with_kernel_events': 1e3 * elapsed_events / steps,
         'ms_per_step_collector_off': (1e3 * elapsed_nogc / steps) if elapsed_nogc is not None else None,
-        'collector': ('value / ms_per_step: the cyclic collector ON, as a user\'s solve() runs (round 5 timed them with gc.disable()); '
+        'collector': ('value / ms_per_step: the cyclic collector ON in the process, as a user\'s solve() runs -- solve() itself holds it while it creates its region objects (region_batch.gc_paused; MPC_KEEP_GC=1 leaves it running) -- (round 5 timed them with gc.disable()); '
                       'ms_per_step_collector_off: the same K steps with gc.disable(), round 5\'s protocol'),
         'kernel_timing': ('HIP events inside the one timed region (--events-in-value)' if args.events_in_value else
                           'value / ms_per_step: K timed steps of the solve as a user runs it (no profile: the library records no HIP events inside '

@@ -30,7 +30,7 @@ import numpy
 import torch
 import torch.distributed as dist
 
-from .region_batch import RegionBatch
+from .region_batch import RegionBatch, gc_paused
 from .solution import Solution
 
 
@@ -359,6 +359,11 @@ def solve_distributed(engine, program=None, group=None, profile: Optional[List[D
     together with the region stage behind the (x,theta) stage.  No candidate is ever demoted."""
     if full_solution not in ('all', 'rank0'):
         raise ValueError("full_solution must be 'all' or 'rank0'")
+    with gc_paused():      # (round 6) as the single-GPU solve(): the region objects are created with the cycle collector held
+        return _solve_distributed_guarded(engine, program, group, profile, collect_regions, max_levels, shard_min, force_shard, full_solution)
+
+
+def _solve_distributed_guarded(engine, program, group, profile, collect_regions, max_levels, shard_min, force_shard, full_solution) -> Solution:
     try:
         return _solve_distributed(engine, program, group, profile, collect_regions, max_levels, shard_min, force_shard, full_solution)
     except _RepeatWithoutOverlap:

@@ -246,7 +246,9 @@ def solve(program, num_cores: int = -1, device: Optional[int] = None, seeds: Opt
     """mpqp_algorithm.combinatorial_graph (mpqp_combi_graph.py:68-145): all critical regions reachable from the seeds
     through chains of non-empty regions that differ by one row.  ``profile`` receives one dict per wave;
     ``max_candidates``: stop after that many examined active sets."""
-    return _traverse(program, device, seeds, profile, max_candidates, True)
+    from ..region_batch import gc_paused
+    with gc_paused():      # (round 6) the region objects are created with the cycle collector held, as in mpqp_hip_combinatorial.solve
+        return _traverse(program, device, seeds, profile, max_candidates, True)
 
 
 def solve_graph(program, num_cores: int = -1, device: Optional[int] = None, seeds: Optional[List[List[int]]] = None,
@@ -259,7 +261,9 @@ def solve_graph(program, num_cores: int = -1, device: Optional[int] = None, seed
     subsets), so the (x,theta) feasibility LP is not posed: every visited set gets the rank test, the KKT solve and the
     "region non-empty" LP of MPC_LEVEL_GRAPH.  Like the reference, the method can miss regions whose neighbours differ
     by more than one row (mpqp_graph.py:50)."""
-    return _traverse(program, device, seeds, profile, max_candidates, False)
+    from ..region_batch import gc_paused
+    with gc_paused():
+        return _traverse(program, device, seeds, profile, max_candidates, False)
 
 
 def _seed_active_sets(program, eng) -> List[List[int]]:

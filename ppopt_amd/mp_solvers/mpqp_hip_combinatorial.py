@@ -91,6 +91,11 @@ def solve(program, num_cores: int = -1, device: int = 0, profile: Optional[List[
     """``_solve`` below; should a level report more late optimal candidates than its overlapped region stage had reserved record
     slots for (MPC_ERR_CAPACITY, include/mpcombi.h: mpc_set_region_overlap -- never observed, forced in the tests), the solve is
     repeated with the region stage behind the (x,theta) stage, where nothing can be late.  No candidate is ever demoted."""
+    with gc_paused():      # (round 6) ~10^4 region objects per solve, none in a cycle: region_batch.gc_paused / _promote_young
+        return _solve_guarded(program, num_cores, device, profile, collect_regions, max_levels, stream, prune_lowdim)
+
+
+def _solve_guarded(program, num_cores, device, profile, collect_regions, max_levels, stream, prune_lowdim) -> Solution:
     from .._lib import MpcCapacityError, MpcError
     closed = True
     try:

@@ -27,8 +27,8 @@ def gc_paused():
     """The cycle collector is held while ``solve_many`` creates its region objects (re-entrant, any thread).  Such a call allocates 10^5
     small container objects that are not garbage and form no cycles; every 700 of them start a collection of the young generation,
     every tenth of those one of the next, and the full collections walk everything alive.  Reference counting frees objects as
-    before; the collector runs again as soon as the outermost call returns.  ``MPC_KEEP_GC=1`` leaves it alone.  (tools/step_overhead.py
-    for the single solve, where holding the collector does not pay.)"""
+    before; the collector runs again as soon as the outermost call returns (``_promote_young`` below: without a walk over the new
+    objects).  ``MPC_KEEP_GC=1`` leaves the collector alone.  Round 6: ``solve()`` holds it too."""
     global _gc_pauses, _gc_was_enabled
     import os
     if os.environ.get('MPC_KEEP_GC', '0') == '1':
@@ -45,7 +45,23 @@ def gc_paused():
         with _gc_lock:
             _gc_pauses -= 1
             if _gc_pauses == 0 and _gc_was_enabled:
+                _promote_young()
                 gc.enable()
+
+
+def _promote_young():
+    """Called with the collector still held, at the end of the outermost pause.  The pause has left thousands of new container objects in
+    the young generation; the first allocation after ``gc.enable()`` would start a collection that walks every one of them (10^4 regions:
+    0.1-0.3 ms, 10^5: 5 ms -- as much as the collections the pause avoided), and the survivors are walked again when the middle generation
+    is collected.  ``gc.freeze(); gc.unfreeze()`` splices all generations into the permanent one and that back into the OLDEST (two list
+    operations, no object is visited): the new objects -- region views that hold two references and form no cycles -- are from now on
+    looked at by full collections only, like anything that has lived for a while.  So is whatever else was young at that moment; objects
+    the caller has frozen deliberately stay frozen (the step is skipped then).  ``MPC_GC_PROMOTE=0`` switches it off."""
+    import os
+    if os.environ.get('MPC_GC_PROMOTE', '1') == '0' or gc.get_freeze_count() != 0 or gc.get_count()[0] < 2000:
+        return
+    gc.freeze()
+    gc.unfreeze()
 
 
 class RegionBatch:

@@ -328,3 +328,60 @@ def test_gc_paused_is_reentrant_and_restores_the_collector(monkeypatch):
     monkeypatch.setenv('MPC_KEEP_GC', '1')
     with gc_paused():
         assert gc.isenabled()
+
+
+def test_gc_pause_hands_the_new_objects_to_the_oldest_generation_without_losing_any_garbage(monkeypatch):
+    """Round 6 (region_batch._promote_young; solve() and solve_distributed() hold the collector now): at the end of the
+    outermost pause the young generation is spliced into the oldest one (gc.freeze(); gc.unfreeze()) instead of being walked by the next
+    allocation -- the collector comes back enabled with an empty young generation, nothing stays frozen, a reference cycle that became
+    garbage during the pause is still found by the next full collection, objects the caller has frozen deliberately stay frozen, and
+    MPC_GC_PROMOTE=0 / a short pause leave the generations alone."""
+    import gc
+    import weakref
+    from ppopt_amd.region_batch import gc_paused
+
+    class Node:
+        pass
+    gc.collect()
+    assert gc.isenabled() and gc.get_freeze_count() == 0
+    with gc_paused():
+        keep = [[i] for i in range(5000)]
+        a, b = Node(), Node()
+        a.other, b.other = b, a
+        ref = weakref.ref(a)
+        del a, b                      # a garbage cycle made while the collector is held
+    assert gc.isenabled() and gc.get_freeze_count() == 0
+    assert gc.get_count()[0] < 100    # (no young objects left for the next allocation to walk)
+    assert ref() is not None
+    gc.collect()
+    assert ref() is None and len(keep) == 5000
+    # short pause: nothing to promote
+    gc.collect()
+    before = gc.get_count()
+    with gc_paused():
+        few = [[i] for i in range(10)]
+    assert gc.isenabled() and gc.get_count()[0] >= before[0] and len(few) == 10
+    # the switch
+    calls = []
+    real_freeze = gc.freeze
+    monkeypatch.setattr(gc, 'freeze', lambda: (calls.append(1), real_freeze())[1])
+    monkeypatch.setenv('MPC_GC_PROMOTE', '0')
+    with gc_paused():
+        many = [[i] for i in range(5000)]
+    assert gc.isenabled() and not calls and len(many) == 5000
+    monkeypatch.delenv('MPC_GC_PROMOTE')
+    with gc_paused():
+        many2 = [[i] for i in range(5000)]
+    assert gc.isenabled() and len(calls) == 1 and gc.get_freeze_count() == 0 and len(many2) == 5000
+    monkeypatch.setattr(gc, 'freeze', real_freeze)
+    # a caller's own frozen objects are not thawed
+    gc.collect()
+    gc.freeze()
+    try:
+        frozen = gc.get_freeze_count()
+        assert frozen > 0
+        with gc_paused():
+            more = [[i] for i in range(5000)]
+        assert gc.get_freeze_count() == frozen and gc.isenabled() and len(more) == 5000
+    finally:
+        gc.unfreeze()
