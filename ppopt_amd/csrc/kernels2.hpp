@@ -489,7 +489,19 @@ MPC_GLOBAL void MPC_LB(64, (SLOTS >= 2 ? (NT <= 4 ? TH_WAVES_S2 : 2) : (NT >= 8 
                     }
                     // the largest slack h - g theta this row can have over the bounding box of the parameter polytope: if even
                     // that is negative the row alone makes the theta LP infeasible (margin 10 x the LP's tolerance)
-                    {
+                    if (SLOTS == 1 && ta.box_finite) {      // (two rows per lane: the second form tips k_theta2<4,2> into scratch under its register cap)
+                        // (round 6, as k_kkt_thread) under a finite box the extremes of h - g theta are h + sum max / min (-g blo, -g bhi): the
+                        // two products serve both bounds, the numbers are those of the select form below bit for bit
+                        double smax = h, smin = h;
+#pragma unroll
+                        for (int t = 0; t < NT; ++t) {
+                            const double p0 = -g[t] * blo[t], p1 = -g[t] * bhi[t];
+                            smax += fmax(p0, p1);
+                            if (SLOTS >= 2) smin += fmin(p0, p1);
+                        }
+                        if (i < m && smax < -10 * TOL_FEAS * sc) { if (i < nlam) box_lam = true; else box_slack = true; }
+                        if (SLOTS >= 2 && smin > 10 * TOL_FEAS * sc * 10) live[sl] = false;
+                    } else {
                         double smax = h;
 #pragma unroll
                         for (int t = 0; t < NT; ++t) {
