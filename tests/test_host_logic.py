@@ -385,3 +385,57 @@ def test_gc_pause_hands_the_new_objects_to_the_oldest_generation_without_losing_
         assert gc.get_freeze_count() == frozen and gc.isenabled() and len(more) == 5000
     finally:
         gc.unfreeze()
+
+
+def test_materialisation_by_the_c_loop_equals_the_python_loop(monkeypatch):
+    """Round 6: Solution.materialize runs its per-region loop in C when ppopt_amd/_fastmat.so is built (csrc_host/fastmat.c, __graft_entry__.build)
+    and in Python otherwise: the same fields with the same values, shapes and element types either way -- for slots in order, for a
+    selection of slots out of order, with a field assigned before (kept), and for regions without rows / with empty index lists."""
+    import ppopt_amd.region_batch as rb
+    from ppopt_amd.region_batch import RegionBatch
+    if rb._fastmat is None:
+        pytest.skip('ppopt_amd/_fastmat.so is not built (python __graft_entry__.py builds it)')
+    rng = numpy.random.default_rng(5)
+    n_x, n_t, n_c, n_tc, k = 5, 3, 11, 6, 2
+    fd = n_x * n_t + n_x + k * n_t + k
+    fi = 8 + k + n_tc + k + 2 * (n_c - k)
+    n = 40
+    hd = rng.random((n, fd))
+    hi = -numpy.ones((n, fi), dtype=numpy.int32)
+    off = 0
+    for j in range(n):
+        nE = int(rng.integers(0, 6))
+        n_om, n_la, n_re = int(rng.integers(0, n_tc + 1)), int(rng.integers(0, k + 1)), int(rng.integers(0, n_c - k + 1))
+        hi[j, :8] = [3, j, nE, n_om, n_la, n_re, off, 0]
+        off += nE
+        hi[j, 8:8 + k] = sorted(rng.choice(n_c, k, replace=False).tolist())
+        hi[j, 8 + k:8 + k + n_om] = rng.integers(0, n_tc, n_om)
+        hi[j, 8 + k + n_tc:8 + k + n_tc + n_la] = rng.integers(0, k, n_la)
+        hi[j, 8 + 2 * k + n_tc:8 + 2 * k + n_tc + n_re] = rng.integers(0, n_c, n_re)
+        hi[j, 8 + 2 * k + n_tc + (n_c - k):8 + 2 * k + n_tc + (n_c - k) + n_re] = rng.integers(0, n_c, n_re)
+    er = rng.random((off, n_t + 1))
+    for slots in (numpy.arange(n), numpy.array([7, 3, 21, 22, 23, 39, 0])):
+        by_c = RegionBatch(hd, hi, er, n_x, n_t, n_c, n_tc, k, slots).regions()
+        by_py = RegionBatch(hd, hi, er, n_x, n_t, n_c, n_tc, k, slots).regions()
+        marker = numpy.zeros((n_x, 1))
+        by_c[2].b = marker
+        by_py[2].b = marker
+        rb.materialize_regions(by_c)
+        monkeypatch.setattr(rb, '_fastmat', None)
+        rb.materialize_regions(by_py)
+        monkeypatch.undo()
+        assert by_c[2].b is marker and by_py[2].b is marker
+        for a, b in zip(by_c, by_py):
+            assert set(a.__dict__) == set(b.__dict__) == set(rb._FIELD_NAMES)
+            for fld in ('A', 'b', 'C', 'd', 'E', 'f'):
+                x, y = getattr(a, fld), getattr(b, fld)
+                assert x.shape == y.shape and x.dtype == y.dtype and numpy.array_equal(x, y), fld
+                assert x.size == 0 or numpy.shares_memory(x, hd) or numpy.shares_memory(x, er) or x is marker
+            assert a.active_set == b.active_set and a.omega_set == b.omega_set and a.lambda_set == b.lambda_set and a.regular_set == b.regular_set
+            assert all(type(v) is int for v in a.active_set + a.omega_set + a.lambda_set + a.regular_set[0] + a.regular_set[1])
+    # a header that does not fit its arrays: the C loop declines, the Python loop takes over (here it raises nothing: slices clip)
+    bad = hi.copy()
+    bad[5, 2] = 10 ** 6
+    regs = RegionBatch(hd, bad, er, n_x, n_t, n_c, n_tc, k).regions()
+    rb.materialize_regions(regs)
+    assert regs[4].E.shape[1] == n_t and 'A' in regs[5].__dict__
