@@ -112,7 +112,44 @@ static PyObject *fill(PyObject *self, PyObject *args) {
     Py_RETURN_NONE;
 }
 
-static PyMethodDef methods[] = {{"fill", fill, METH_VARARGS, "fill(regs, hd, hi, er, js, layout): the fields of every region of a level"}, {NULL, NULL, 0, NULL}};
+/* make(cls, batch, slots) -> [cls instances]: RegionBatch.regions_of without a Python-level __init__ per region.  cls has the two __slots__
+ * members `_batch` and `_j` (BatchCriticalRegion); every instance gets (batch, slots[i]).  ~40 ns per region instead of ~100. */
+#include <structmember.h>
+static PyObject *make(PyObject *self, PyObject *args) {
+    PyObject *cls, *batch, *slots;
+    if (!PyArg_ParseTuple(args, "OOO!", &cls, &batch, &PyList_Type, &slots)) return NULL;
+    if (!PyType_Check(cls)) { PyErr_SetString(PyExc_TypeError, "make: a class expected"); return NULL; }
+    Py_ssize_t off[2];
+    const char *names[2] = {"_batch", "_j"};
+    for (int i = 0; i < 2; ++i) {
+        PyObject *desc = PyObject_GetAttrString(cls, names[i]);
+        if (!desc) return NULL;
+        if (Py_TYPE(desc) != &PyMemberDescr_Type || ((PyMemberDescrObject *)desc)->d_member->type != T_OBJECT_EX) {
+            Py_DECREF(desc);
+            PyErr_SetString(PyExc_TypeError, "make: the class has no such slot member");
+            return NULL;
+        }
+        off[i] = ((PyMemberDescrObject *)desc)->d_member->offset;
+        Py_DECREF(desc);
+    }
+    PyTypeObject *tp = (PyTypeObject *)cls;
+    const Py_ssize_t n = PyList_GET_SIZE(slots);
+    PyObject *out = PyList_New(n);
+    if (!out) return NULL;
+    for (Py_ssize_t i = 0; i < n; ++i) {
+        PyObject *obj = tp->tp_alloc(tp, 0);
+        if (!obj) { Py_DECREF(out); return NULL; }
+        PyObject *j = PyList_GET_ITEM(slots, i);
+        Py_INCREF(batch); Py_INCREF(j);
+        *(PyObject **)((char *)obj + off[0]) = batch;
+        *(PyObject **)((char *)obj + off[1]) = j;
+        PyList_SET_ITEM(out, i, obj);
+    }
+    return out;
+}
+
+static PyMethodDef methods[] = {{"make", make, METH_VARARGS, "make(cls, batch, slots): one instance of cls per slot, its members _batch and _j set"},
+                                {"fill", fill, METH_VARARGS, "fill(regs, hd, hi, er, js, layout): the fields of every region of a level"}, {NULL, NULL, 0, NULL}};
 static struct PyModuleDef moddef = {PyModuleDef_HEAD_INIT, "_fastmat", "per-region loop of Solution.materialize (host side)", -1, methods};
 
 PyMODINIT_FUNC PyInit__fastmat(void) {

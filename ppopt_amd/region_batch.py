@@ -92,10 +92,13 @@ class RegionBatch:
         return len(self.slots)
 
     def regions(self) -> List['BatchCriticalRegion']:
-        return list(map(BatchCriticalRegion, itertools.repeat(self), self.slots.tolist()))
+        return self.regions_of(self.slots.tolist())
 
     def regions_of(self, slots) -> List['BatchCriticalRegion']:
-        """Region objects of the given slots (a streamed level hands its slots over chunk by chunk)."""
+        """Region objects of the given slots (a streamed level hands its slots over chunk by chunk).  (Round 6: created by the C helper
+        when it is built -- no Python-level ``__init__`` per region.)"""
+        if _fastmat is not None and type(slots) is list:
+            return _fastmat.make(BatchCriticalRegion, self, slots)
         return list(map(BatchCriticalRegion, itertools.repeat(self), slots))
 
 
