@@ -1007,23 +1007,7 @@ struct XqAlt {
     const int32_t *prev_frontier;   // [n_prev][k - 1]
     const uint8_t *prev_stored;     // [n_prev]
     int n_prev, tries;
-    // (round 6) != nullptr: idx[2 p], idx[2 p + 1] = first row and one past the last row of the previous frontier whose first two members are
-    // (p / idx_nc, p % idx_nc) (k_prefix_index; 0, 0: no such row).  The search for another parent starts in that block instead of the whole
-    // frontier: log2(n_prev / C(n_c, 2)) dependent reads instead of log2(n_prev) -- 7 instead of 17 on config 4's last level.
-    const int32_t *idx;
-    int idx_nc;
 };
-// one thread per row of the previous frontier (km = k - 1 >= 2 members per row, lexicographic order): block boundaries by first-two-member prefix
-MPC_GLOBAL void k_prefix_index(const int32_t *__restrict__ fr, int n_prev, int km, int nc, int32_t *__restrict__ idx) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n_prev) return;
-    const int32_t *row = fr + (size_t)i * km;
-    const int p = row[0] * nc + row[1];
-    const int pl = i > 0 ? row[-km] * nc + row[1 - km] : -1;
-    const int pn = i + 1 < n_prev ? row[km] * nc + row[km + 1] : -1;
-    if (p != pl) idx[2 * p] = i;
-    if (p != pn) idx[2 * p + 1] = i + 1;
-}
 // Plan mode (x1_list != nullptr): a level that KEEPS dictionaries.  Every candidate that needs one -- the open ones (`list`) and, before
 // them, the ones the theta stage already decided (pre1, pre2: status untouched) -- is asked the same question, and the answer is kept
 // as a plan: from which parent slot, by which single step (xq_first_test's *step).  Planned candidates are appended to x1_list (k_x1
@@ -1148,12 +1132,11 @@ MPC_GLOBAL void MPC_LB(64) k_xq_thread(const DevProblem *__restrict__ Pg, const 
                     return cmp;
                 };
                 int lo = 0, hi = alt.n_prev - 1;
-                if (alt.idx && km >= 2) { const int32_t *ip = alt.idx + 2 * (want[0] * alt.idx_nc + want[1]); lo = ip[0]; hi = ip[1] - 1; }
                 if (t == 1) {
                     // {.., e} without the second largest member is a SIBLING of the generating parent {.., d}: same prefix, larger last
                     // member, i.e. a few rows further on in the same block of the previous frontier -- walked, not searched
                     const int ps = dc.parent_slot[c];
-                    lo = max(lo, ps + 1);
+                    lo = ps + 1;
                     for (int stp = 0; stp < 24 && lo <= hi; ++stp, ++lo) {
                         const int cmp = cmp_row(lo);
                         if (cmp >= 0) { if (cmp == 0) found = lo; hi = lo - 1; break; }

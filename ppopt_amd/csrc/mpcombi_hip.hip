@@ -285,8 +285,6 @@ struct mpc_handle {
     std::function<int()> x1_stash;   // x1_defer >= 2: the deferred k_x1 launch, issued by x1_flush behind the level's last kernels
     int x1_defer = 1;           // 1: k_x1 on its own stream from the plan pass on; 2: issued behind the level's last kernels (measured: the children stage gets its 0.26 ms back, the next level's KKT kernel loses 0.40 beside k_x1 -- its W gathers live in the L2 that k_x1 streams through: config 4 3.89 -> 3.95 ms, config 3 4.17 -> 4.27); 0: in line
     int x1_lds_cap = 0;
-    DevBuf prefix_idx;           // k_prefix_index: block boundaries of the previous frontier by first-two-member prefix (XqAlt::idx)
-    long long prefix_idx_min = 4096;   // smallest previous frontier that gets one (MPC_PREFIX_INDEX_MIN; -1: never)
     int xq_skip_below = 100000;  // the last level's product-form quick test leaves a list shorter than this to k_x2 when a tableau row is one lane's (MPC_XQ_SKIP_BELOW; 0: never).  Measured: config 3 (62 k left over) 4.26 -> 4.18 ms, config 4 (2.7 k) unchanged -- its last level ends with the region kernel
     int x_second_max = 1024;     // k_x2: a level's budget of doubtful cached runs repeated from D0 in the kernel (MPC_X_SECOND_MAX; 0: all go to the LDS engine)
     double x_fresh_limit = 1e6;   // k_x2: growth up to which a run from D0 decides (DictCache::fresh_limit; MPC_X_FRESH_LIMIT=0: GROWTH_SAFE)
@@ -579,7 +577,7 @@ void lu_solve_host(const std::vector<double> &LU, const std::vector<int> &perm, 
 // graveyard_flush, which the level paths call behind their closing synchronisation (all streams of the handle have been joined by then)
 static std::vector<DevBuf *> level_buffers(mpc_handle *h) {
     return {&h->frontier, &h->children, &h->status, &h->pruned, &h->flag, &h->pos, &h->opt_list, &h->childmask, &h->count, &h->offset, &h->recd, &h->reci,
-            &h->sums, &h->retry_list, &h->headd, &h->headi, &h->epool, &h->facet_flags, &h->kkt_code, &h->kkt_L, &h->xq_groups, &h->xq_list, &h->x1_buf, &h->xretry_list, &h->prefix_idx, &h->theta_list, &h->vretry_list,
+            &h->sums, &h->retry_list, &h->headd, &h->headi, &h->epool, &h->facet_flags, &h->kkt_code, &h->kkt_L, &h->xq_groups, &h->xq_list, &h->x1_buf, &h->xretry_list, &h->theta_list, &h->vretry_list,
             &h->status_tmp, &h->part_counts, &h->part_lists, &h->kept_g, &h->done_g, &h->dict_d[0], &h->dict_d[1], &h->dict_i[0], &h->dict_i[1],
             &h->dict_stored[0], &h->dict_stored[1], &h->parent_slot, &h->parent_slot_next};
 }
@@ -664,7 +662,6 @@ static int create_fill(const mpc_problem *p, int32_t device, void *stream, mpc_h
     { const char *ev = std::getenv("MPC_X_FRESH_LIMIT"); if (ev) h->x_fresh_limit = std::atof(ev); }
     { const char *ev = std::getenv("MPC_X_SECOND_MAX"); if (ev) h->x_second_max = std::max(0, std::atoi(ev)); }
     { const char *ev = std::getenv("MPC_XQ_SKIP_BELOW"); if (ev) h->xq_skip_below = std::max(0, std::atoi(ev)); }
-    { const char *ev = std::getenv("MPC_PREFIX_INDEX_MIN"); if (ev) h->prefix_idx_min = std::atoll(ev); }
     { const char *ev = std::getenv("MPC_HELPER_IT"); if (ev) h->helper_it = std::atoi(ev) == 1 ? 1 : 4; }
     { const char *ev = std::getenv("MPC_PRUNED_BUCKET_MIN"); if (ev) h->pruned_bucket_min = std::atof(ev); }
     { const char *ev = std::getenv("MPC_PRUNED_BUCKET_NP"); if (ev) h->pruned_bucket_np = std::atoll(ev); }
@@ -1157,7 +1154,7 @@ int mpc_destroy(mpc_handle *h) {
     if (h->stream4) (void)hipStreamSynchronize(h->stream4);
     graveyard_flush(h);
     for (DevBuf *b : {&h->blocks, &h->iblocks, &h->frontier, &h->children, &h->status, &h->pruned, &h->flag, &h->pos, &h->opt_list,
-                      &h->childmask, &h->count, &h->offset, &h->recd, &h->reci, &h->ctr, &h->pruned_b, &h->pruned_head, &h->scratch, &h->sums, &h->retry_list, &h->pf_dev, &h->pr2_dev, &h->headd, &h->headi, &h->epool, &h->facet_flags, &h->kkt_code, &h->kkt_L, &h->theta_blocks, &h->xq_groups, &h->xq_list, &h->x1_buf, &h->xretry_list, &h->prefix_idx, &h->theta_list, &h->vretry_list, &h->status_tmp, &h->part_counts, &h->part_lists, &h->kept_g, &h->done_g, &h->dict_d[0], &h->dict_d[1], &h->dict_i[0], &h->dict_i[1],
+                      &h->childmask, &h->count, &h->offset, &h->recd, &h->reci, &h->ctr, &h->pruned_b, &h->pruned_head, &h->scratch, &h->sums, &h->retry_list, &h->pf_dev, &h->pr2_dev, &h->headd, &h->headi, &h->epool, &h->facet_flags, &h->kkt_code, &h->kkt_L, &h->theta_blocks, &h->xq_groups, &h->xq_list, &h->x1_buf, &h->xretry_list, &h->theta_list, &h->vretry_list, &h->status_tmp, &h->part_counts, &h->part_lists, &h->kept_g, &h->done_g, &h->dict_d[0], &h->dict_d[1], &h->dict_i[0], &h->dict_i[1],
                       &h->dict_stored[0], &h->dict_stored[1], &h->parent_slot, &h->parent_slot_next, &h->dcnt}) b->release();
     if (h->tot_host) { (void)host_pool_give(h->tot_host); h->tot_host = h->tot_dev = nullptr; }
     for (HostBuf *b : {&h->st_list, &h->st_status, &h->st_hd, &h->st_hi, &h->st_pool, &h->st_fxd, &h->st_fxi, &h->st_rlist, &h->st_flags}) b->release();
@@ -1203,7 +1200,7 @@ int mpc_trim(mpc_handle *h) {
     graveyard_flush(h);
     stream_release(h);
     for (DevBuf *b : {&h->frontier, &h->children, &h->status, &h->pruned, &h->flag, &h->pos, &h->opt_list, &h->childmask, &h->count, &h->offset, &h->recd, &h->reci,
-                      &h->sums, &h->retry_list, &h->headd, &h->headi, &h->epool, &h->facet_flags, &h->kkt_code, &h->kkt_L, &h->xq_groups, &h->xq_list, &h->x1_buf, &h->xretry_list, &h->prefix_idx, &h->theta_list, &h->vretry_list,
+                      &h->sums, &h->retry_list, &h->headd, &h->headi, &h->epool, &h->facet_flags, &h->kkt_code, &h->kkt_L, &h->xq_groups, &h->xq_list, &h->x1_buf, &h->xretry_list, &h->theta_list, &h->vretry_list,
                       &h->status_tmp, &h->part_counts, &h->part_lists, &h->kept_g, &h->done_g, &h->dict_d[0], &h->dict_d[1], &h->dict_i[0], &h->dict_i[1],
                       &h->dict_stored[0], &h->dict_stored[1], &h->parent_slot, &h->parent_slot_next}) b->release();
     for (HostBuf *b : {&h->st_list, &h->st_status, &h->st_hd, &h->st_hi, &h->st_pool, &h->st_fxd, &h->st_fxi, &h->st_rlist, &h->st_flags}) b->release();
@@ -2475,22 +2472,6 @@ static int level_run_impl(mpc_handle *h, int32_t gen_children, int32_t flags, mp
         int32_t n_opt_fast = -1;   // >= 0: the fast path has already built h->opt_list
         // The end of a level -- pruned masks, children, histogram, counters published -- as launches only (the caller synchronises).
         bool tail_done = false;
-        // (round 6) the index of the previous frontier's blocks for the one-thread pass's search for other parents (XqAlt::idx), built once per
-        // level on the main stream before the first launch that uses it
-        bool prefix_built = false;
-        auto prefix_index = [&](XqAlt &alt) -> int {
-            if (!alt.prev_frontier || k < 3 || h->prefix_idx_min < 0 || alt.n_prev < h->prefix_idx_min) return MPC_OK;
-            const size_t words = (size_t)2 * h->n_c * h->n_c;
-            if (!prefix_built) {
-                HIP_TRY(h, h->prefix_idx.ensure(words * sizeof(int32_t), st));
-                HIP_TRY(h, hipMemsetAsync(h->prefix_idx.p, 0, words * sizeof(int32_t), st));
-                hipLaunchKernelGGL(k_prefix_index, dim3((unsigned)((alt.n_prev + 255) / 256)), dim3(256), 0, st, alt.prev_frontier, alt.n_prev, k - 1, h->n_c, h->prefix_idx.as<int32_t>());
-                HIP_TRY(h, hipGetLastError());
-                prefix_built = true;
-            }
-            alt.idx = h->prefix_idx.as<int32_t>(); alt.idx_nc = h->n_c;
-            return MPC_OK;
-        };
         auto queue_tail = [&]() -> int {
             const int keep_lowdim = (flags & MPC_LEVEL_KEEP_LOWDIM) ? 1 : 0;
             if (flags & MPC_LEVEL_GRAPH) { /* no pruning in the graph traversal */ }
@@ -2634,7 +2615,6 @@ static int level_run_impl(mpc_handle *h, int32_t gen_children, int32_t flags, mp
                         alt.prev_frontier = h->children.as<int32_t>(); alt.prev_stored = h->dict_stored[1 - h->dict_cur].as<uint8_t>();
                         alt.n_prev = (int)h->n_prev; alt.tries = h->xq_thread < 0 ? MPC_MAX_NC : h->xq_thread - 1;
                     }
-                    { int rcp = prefix_index(alt); if (rcp) return rcp; }
                     HIP_TRY(h, hipEventRecord(h->ev_xfork, st));
                     HIP_TRY(h, hipStreamWaitEvent(h->stream2, h->ev_xfork, 0));
                     if (h->x1_pending) HIP_TRY(h, hipStreamWaitEvent(h->stream2, h->ev_x1done, 0));   // (the main stream joins later: x1_join before its own first reader)
@@ -2764,7 +2744,6 @@ static int level_run_impl(mpc_handle *h, int32_t gen_children, int32_t flags, mp
                     alt.prev_frontier = h->children.as<int32_t>(); alt.prev_stored = h->dict_stored[1 - h->dict_cur].as<uint8_t>();
                     alt.n_prev = (int)h->n_prev; alt.tries = MPC_MAX_NC;
                 }
-                { int rcp = prefix_index(alt); if (rcp) return rcp; }
                 DictCache dq = dc;
                 dq.n_list_dev = n_needx_dev;
                 const DevProblem *pfx = h->pf_dev.as<DevProblem>();
@@ -2996,7 +2975,6 @@ static int level_run_impl(mpc_handle *h, int32_t gen_children, int32_t flags, mp
                         alt.prev_frontier = h->children.as<int32_t>(); alt.prev_stored = h->dict_stored[1 - h->dict_cur].as<uint8_t>();
                         alt.n_prev = (int)h->n_prev; alt.tries = h->xq_thread < 0 ? MPC_MAX_NC : h->xq_thread - 1;   // (the kernel stops at the candidate's inequality members)
                     }
-                    { int rcp = prefix_index(alt); if (rcp) return rcp; }
                     hipLaunchKernelGGL(k_xq_thread, dim3(gt), dim3(64), 0, st, pf, fr, k, needx_list, n_needx, stp, ctr, dq, nxc, alt, XqPlan{});
                     if (h->timing) HIP_TRY(h, hipEventRecord(h->kev[11], st));
                     HIP_TRY(h, hipGetLastError());
