@@ -298,6 +298,7 @@ def test_gc_paused_is_reentrant_and_restores_the_collector(monkeypatch):
     import gc
     import threading
     from ppopt_amd.region_batch import gc_paused
+    monkeypatch.delenv('MPC_KEEP_GC', raising=False)
     assert gc.isenabled()
     with gc_paused():
         assert not gc.isenabled()
@@ -339,6 +340,8 @@ def test_gc_pause_hands_the_new_objects_to_the_oldest_generation_without_losing_
     import gc
     import weakref
     from ppopt_amd.region_batch import gc_paused
+    monkeypatch.delenv('MPC_KEEP_GC', raising=False)
+    monkeypatch.delenv('MPC_GC_PROMOTE', raising=False)
 
     class Node:
         pass
